@@ -1,0 +1,185 @@
+/*
+ * mendeliht_hip.h -- C ABI of the MI355X-native IHT hot path.
+ *
+ * Drop-in boundary for MendelIHT.jl's IHT inner loop.  The reference has no
+ * FFI layer; its seam is Julia dispatch on the design-matrix type
+ * (`fit_iht(y, x::AbstractMatrix{T}, z)` src/fit.jl:60-63,
+ *  `cv_iht` src/cross_validation.jl:60-63, `IHTVariable{T,M}`
+ *  src/data_structures.jl:4).  Each entry point below names the reference
+ * method(s) it replaces; INTEGRATION.md shows the `ccall` glue a maintainer
+ * adds on the Julia side (julia/MendelIHTHip.jl).
+ *
+ * Conventions: every function returns an `int` status (MIH_OK = 0); all
+ * pointers are HOST pointers unless the name says `_dev`; matrices are
+ * column-major (Julia layout); indices crossing the boundary are 0-based
+ * unless stated; the library owns device memory behind opaque handles and the
+ * caller owns every host buffer.  A handle is immutable after creation and may
+ * be shared by host threads; each fit call builds its own workspace + stream.
+ */
+#ifndef MENDELIHT_HIP_H
+#define MENDELIHT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes <-> Julia exceptions (src/fit.jl:87-101,259-260;
+ * src/data_structures.jl:63-85; src/utilities.jl:554,975-993) */
+enum {
+    MIH_OK = 0,
+    MIH_BAD_DIM = 1,        /* DimensionMismatch */
+    MIH_BAD_ARG = 2,        /* ArgumentError / DomainError / AssertionError */
+    MIH_NOT_CENTERED = 3,   /* "x is not centered!" fit.jl:98 */
+    MIH_NAN_LOGL = 4,       /* "Loglikelihood function is NaN" fit.jl:259 */
+    MIH_INF_LOGL = 5,       /* "Loglikelihood function is Inf" fit.jl:260 */
+    MIH_HIP_ERROR = 6,
+    MIH_OOM = 7,
+    MIH_NO_DEVICE = 8
+};
+
+/* Distributions / links of the GLM (GLM.jl, Distributions.jl; fit.jl:66-67) */
+enum { MIH_NORMAL = 0, MIH_BERNOULLI = 1, MIH_POISSON = 2, MIH_NEGBIN = 3 };
+enum { MIH_IDENTITY = 0, MIH_LOGIT = 1, MIH_LOG = 2 };
+enum { MIH_ESTR_NONE = 0, MIH_ESTR_MM = 1, MIH_ESTR_NEWTON = 2 };
+
+typedef struct mih_mat mih_mat;     /* device-resident design matrix */
+
+/* ---- library / device ------------------------------------------------------ */
+int mih_device_count(int *count);
+/* thread-local message of the last failing call on this host thread */
+int mih_last_error(char *buf, size_t len);
+int mih_version(int *major, int *minor);
+
+/* ---- design matrix: replaces SnpArrays.SnpLinAlg{T}(::SnpArray; model=ADDITIVE_MODEL,
+ *      center, scale, impute) as constructed at src/wrapper.jl:68-69 and test/L0_reg_test.jl:11.
+ * bed_cols: p columns of PLINK .bed body (after the 3-byte header), each
+ * col_stride_bytes >= ceil(n/4) bytes, codes 00->0, 01->missing, 10->1, 11->2.
+ * dtype must be 64 (Float64).  Uploads once; computes mu_j (mean of non-missing
+ * dosages) and sinv_j = 1/sqrt(mu_j(1-mu_j/2)) (1 when that sqrt is 0) on device. */
+int mih_snp_create(const uint8_t *bed_cols, int64_t n, int64_t p, int64_t col_stride_bytes,
+                   int center, int scale, int impute, int dtype, int device, mih_mat **out);
+/* On-device synthetic SnpArray for benchmarks: maf_j ~ U(0,0.5), g_ij ~ Binomial(2, maf_j),
+ * each entry missing with probability missing_rate (distributions of
+ * src/simulate_utilities.jl:33-47,85-101; counter-based hash RNG, seed-reproducible). */
+int mih_snp_create_synthetic(int64_t n, int64_t p, uint64_t seed, double missing_rate,
+                             int center, int scale, int impute, int device, mih_mat **out);
+/* Dense Float64 design matrix (the reference's `x::Matrix{Float64}` path), n x p column-major. */
+int mih_dense_create(const double *x, int64_t n, int64_t p, int device, mih_mat **out);
+int mih_dense_create_synthetic(int64_t n, int64_t p, uint64_t seed, int device, mih_mat **out);
+int mih_mat_destroy(mih_mat *h);
+int mih_mat_dims(const mih_mat *h, int64_t *n, int64_t *p);
+/* `x.μ`, `x.σinv` of the SnpLinAlg */
+int mih_snp_mu_sigma(const mih_mat *h, double *mu, double *sinv);
+/* Re-encode the device matrix as PLINK .bed columns (ceil(n/4) bytes each): lets a
+ * synthetic matrix be handed to any other PLINK consumer. */
+int mih_snp_export_bed(const mih_mat *h, uint8_t *bed_cols_out);
+
+/* ---- genotype linear algebra ---------------------------------------------- */
+/* mul!(out, Transpose(x), r)  -- call site src/utilities.jl:133 (score!) */
+int mih_xtv(const mih_mat *h, const double *r, double *out);
+/* SnpArrays.mul!(p_by_r, Transpose(sla), n_by_r) -- call site src/multivariate.jl:85;
+ * R is n x m column-major, OUT is p x m column-major. */
+int mih_xtv_batched(const mih_mat *h, const double *R, int m, double *OUT);
+/* out = sum_t x[:, idx[t]] * val[t]  -- the column loops of update_xb!
+ * (src/utilities.jl:98-106) and iht_stepsize! (:731-739); idx 0-based. */
+int mih_xv_sparse(const mih_mat *h, const int64_t *idx, const double *val, int64_t nnz, double *out);
+
+/* ---- projections ----------------------------------------------------------- */
+/* project_k!(x, k) src/utilities.jl:553-559: zero every |x_i| < |k-th largest|;
+ * ties at the threshold are kept; *n_kept = number of non-zeros left. */
+int mih_project_topk(double *x, int64_t len, int64_t k, int64_t *n_kept);
+/* project_group_sparse!(y, group, J, k) src/utilities.jl:613-679; group labels 1..G. */
+int mih_project_group_sparse(double *y, const int64_t *group, int64_t len, int64_t J,
+                             const int64_t *k, int k_is_vector);
+
+/* ---- fit_iht ---------------------------------------------------------------- */
+/* keyword arguments of fit_iht (src/fit.jl:64-81) */
+typedef struct mih_fit_params {
+    int64_t  k;               /* sparsity (ignored when ks != NULL) */
+    int64_t  J;               /* max groups */
+    int32_t  dist, link;      /* MIH_NORMAL.., MIH_IDENTITY.. */
+    double   nb_r;            /* NegativeBinomial r (d.r) */
+    double   tol;
+    int32_t  max_iter, min_iter, max_step;
+    int32_t  est_r;           /* MIH_ESTR_* */
+    const uint8_t *zkeep;     /* q flags or NULL = trues(q) */
+    const double  *weight;    /* p prior weights or NULL */
+    const int64_t *group;     /* p group labels (1-based) or NULL */
+    const int64_t *ks;        /* per-group sparsity (k::Vector{Int}) or NULL */
+    int64_t  nks;
+    /* per-iteration callback = the `verbose` line of fit.jl:194-196; may be NULL */
+    void (*progress)(void *user, int iter, double logl, int backtracks, double tol);
+    void    *progress_user;
+} mih_fit_params;
+
+/* IHTResult (src/data_structures.jl:245-256) + the per-iteration log */
+typedef struct mih_fit_result {
+    double   time;            /* seconds inside the fit loop (fit.jl:157,200) */
+    double   logl;            /* best loglikelihood */
+    int64_t  iter;
+    double   pve;             /* sigma_g (src/pve.jl:32) */
+    double   nb_r;            /* final NegBin r */
+    int32_t  choose_fired;    /* 1 if the reference's RNG tie-break _choose! would have run */
+    int32_t  n_trace;
+    double  *beta;            /* caller-allocated p  (best_b) */
+    double  *c;               /* caller-allocated q  (best_c) */
+    double  *logl_trace;      /* caller-allocated max_iter doubles, or NULL */
+    double  *tol_trace;       /* "                                      */
+    int32_t *bt_trace;        /* caller-allocated max_iter int32,  or NULL */
+    double  *mu;              /* caller-allocated n (final v.mu), or NULL */
+} mih_fit_result;
+
+/* fit_iht(y, x, z; ...) src/fit.jl:60-118 with init_beta=false, debias=false,
+ * memory_efficient=true.  z is n x q column-major (first column all ones);
+ * train is NULL (all samples) or n flags = cv_train_idx. */
+int mih_fit_iht(const mih_mat *h, const mih_fit_params *prm, const double *y,
+                const double *z, int64_t q, const uint8_t *train, mih_fit_result *res);
+
+/* cv_iht(y, x, z; path, q, folds, ...) src/cross_validation.jl:60-131.
+ * folds: n labels in 1..nfolds.  The (fold,k) combinations are enumerated
+ * fold-major (cross_validation.jl:217-223); this call evaluates those with
+ * index % world == rank and writes their held-out deviance sums into
+ * mses_raw[nfolds*npath] (others left 0), so ranks combine with ONE sum-reduce /
+ * gather.  mih_cv_meanloss then applies meanloss (:304-320). */
+int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y,
+               const double *z, int64_t q, const int32_t *folds, int32_t nfolds,
+               const int64_t *path, int64_t npath, int32_t rank, int32_t world,
+               double *mses_raw);
+int mih_cv_meanloss(const double *mses_raw, const int32_t *folds, int64_t n, int32_t nfolds,
+                    int64_t npath, double *mse_out);
+
+/* ---- multivariate Gaussian IHT (src/multivariate.jl) ------------------------ */
+typedef struct mih_mv_result {
+    double   time, logl;
+    int64_t  iter;
+    int32_t  choose_fired, n_trace;
+    double  *B;               /* r x p */
+    double  *C;               /* r x q */
+    double  *Sigma;           /* r x r = inv(Gamma) */
+    double  *pve;             /* r */
+    double  *logl_trace, *tol_trace;
+    int32_t *bt_trace;
+} mih_mv_result;
+/* fit_iht(Y, Transpose(x), Z; d=MvNormal) : Y r x n, Z q x n column-major */
+int mih_fit_mv(const mih_mat *h, const mih_fit_params *prm, const double *Y, int64_t r,
+               const double *Z, int64_t q, const uint8_t *train, mih_mv_result *res);
+int mih_cv_mv(const mih_mat *h, const mih_fit_params *prm, const double *Y, int64_t r,
+              const double *Z, int64_t q, const int32_t *folds, int32_t nfolds,
+              const int64_t *path, int64_t npath, int32_t rank, int32_t world, double *mses_raw);
+
+/* ---- measurement hooks (bench.py; no reference counterpart) ----------------- */
+/* Runs `iters` X'r passes back to back on the handle's stream with r resident
+ * in HBM, bracketed by HIP events; *ms_per_pass = average kernel-chain time. */
+int mih_bench_xtv(const mih_mat *h, int variant, int iters, int warmup, uint64_t seed,
+                  float *ms_per_pass, double *checksum);
+/* Algorithmic bytes of one X'r pass: p*ceil(n/4) + 8*m*(n+p) + 16*p. */
+int mih_xtv_algorithmic_bytes(const mih_mat *h, int m, double *bytes);
+/* Select the X'r kernel variant used by every subsequent call (tuning knob). */
+int mih_set_xtv_variant(int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MENDELIHT_HIP_H */

@@ -1,0 +1,731 @@
+"""Host-side mirror of MendelIHT.jl's hot-path API over the C ABI (ctypes).
+
+Names, keyword arguments, defaults and error behaviour follow the reference:
+  fit_iht   src/fit.jl:60-118          cv_iht          src/cross_validation.jl:60-131
+  iht       src/wrapper.jl:52-120      cross_validate  src/wrapper.jl:301-349
+  project_k! / project_group_sparse!   src/utilities.jl:553-559, 613-679
+  SnpLinAlg (SnpArrays.jl)             constructed as in src/wrapper.jl:68-69
+All numerics run in libmendeliht_hip.so on the GPU; this file only marshals.
+"""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBNAME = "libmendeliht_hip.so"
+
+
+class MendelIHTError(RuntimeError):
+    """Base class for errors reported by the HIP library."""
+
+
+class DimensionMismatch(MendelIHTError, ValueError):
+    pass
+
+
+class ArgumentError(MendelIHTError, ValueError):
+    pass
+
+
+_STATUS = {1: DimensionMismatch, 2: ArgumentError, 3: ArgumentError, 4: MendelIHTError, 5: MendelIHTError,
+           6: MendelIHTError, 7: MemoryError, 8: MendelIHTError}
+
+
+def library_path():
+    return os.path.join(_HERE, _LIBNAME)
+
+
+class _FitParams(C.Structure):
+    _fields_ = [("k", C.c_int64), ("J", C.c_int64), ("dist", C.c_int32), ("link", C.c_int32),
+                ("nb_r", C.c_double), ("tol", C.c_double),
+                ("max_iter", C.c_int32), ("min_iter", C.c_int32), ("max_step", C.c_int32), ("est_r", C.c_int32),
+                ("zkeep", C.c_void_p), ("weight", C.c_void_p), ("group", C.c_void_p), ("ks", C.c_void_p),
+                ("nks", C.c_int64), ("progress", C.c_void_p), ("progress_user", C.c_void_p)]
+
+
+class _FitResult(C.Structure):
+    _fields_ = [("time", C.c_double), ("logl", C.c_double), ("iter", C.c_int64), ("pve", C.c_double),
+                ("nb_r", C.c_double), ("choose_fired", C.c_int32), ("n_trace", C.c_int32),
+                ("beta", C.c_void_p), ("c", C.c_void_p), ("logl_trace", C.c_void_p), ("tol_trace", C.c_void_p),
+                ("bt_trace", C.c_void_p), ("mu", C.c_void_p)]
+
+
+class _MvResult(C.Structure):
+    _fields_ = [("time", C.c_double), ("logl", C.c_double), ("iter", C.c_int64),
+                ("choose_fired", C.c_int32), ("n_trace", C.c_int32),
+                ("B", C.c_void_p), ("C", C.c_void_p), ("Sigma", C.c_void_p), ("pve", C.c_void_p),
+                ("logl_trace", C.c_void_p), ("tol_trace", C.c_void_p), ("bt_trace", C.c_void_p)]
+
+
+_PROGRESS = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double)
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library; fails loudly when it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise MendelIHTError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for this path.")
+    L = C.CDLL(path)
+    vp, i64, i32, dbl = C.c_void_p, C.c_int64, C.c_int32, C.c_double
+    sig = {
+        "mih_device_count": [C.POINTER(C.c_int)],
+        "mih_last_error": [C.c_char_p, C.c_size_t],
+        "mih_version": [C.POINTER(C.c_int), C.POINTER(C.c_int)],
+        "mih_snp_create": [vp, i64, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
+        "mih_snp_create_synthetic": [i64, i64, C.c_uint64, dbl, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
+        "mih_dense_create": [vp, i64, i64, C.c_int, C.POINTER(vp)],
+        "mih_dense_create_synthetic": [i64, i64, C.c_uint64, C.c_int, C.POINTER(vp)],
+        "mih_mat_destroy": [vp],
+        "mih_mat_dims": [vp, C.POINTER(i64), C.POINTER(i64)],
+        "mih_snp_mu_sigma": [vp, vp, vp],
+        "mih_snp_export_bed": [vp, vp],
+        "mih_xtv": [vp, vp, vp],
+        "mih_xtv_batched": [vp, vp, C.c_int, vp],
+        "mih_xv_sparse": [vp, vp, vp, i64, vp],
+        "mih_project_topk": [vp, i64, i64, C.POINTER(i64)],
+        "mih_project_group_sparse": [vp, vp, i64, i64, vp, C.c_int],
+        "mih_fit_iht": [vp, C.POINTER(_FitParams), vp, vp, i64, vp, C.POINTER(_FitResult)],
+        "mih_cv_iht": [vp, C.POINTER(_FitParams), vp, vp, i64, vp, i32, vp, i64, i32, i32, vp],
+        "mih_cv_meanloss": [vp, vp, i64, i32, i64, vp],
+        "mih_fit_mv": [vp, C.POINTER(_FitParams), vp, i64, vp, i64, vp, C.POINTER(_MvResult)],
+        "mih_cv_mv": [vp, C.POINTER(_FitParams), vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, vp],
+        "mih_bench_xtv": [vp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_float), C.POINTER(dbl)],
+        "mih_xtv_algorithmic_bytes": [vp, C.c_int, C.POINTER(dbl)],
+        "mih_set_xtv_variant": [C.c_int],
+    }
+    for name, args in sig.items():
+        f = getattr(L, name)
+        f.argtypes = args
+        f.restype = C.c_int
+    _lib = L
+    return L
+
+
+def exported_symbols():
+    """Every symbol include/mendeliht_hip.h declares (checked by the CPU test-suite)."""
+    return ["mih_device_count", "mih_last_error", "mih_version", "mih_snp_create", "mih_snp_create_synthetic",
+            "mih_dense_create", "mih_dense_create_synthetic", "mih_mat_destroy", "mih_mat_dims",
+            "mih_snp_mu_sigma", "mih_snp_export_bed", "mih_xtv", "mih_xtv_batched", "mih_xv_sparse",
+            "mih_project_topk", "mih_project_group_sparse", "mih_fit_iht", "mih_cv_iht", "mih_cv_meanloss",
+            "mih_fit_mv", "mih_cv_mv", "mih_bench_xtv", "mih_xtv_algorithmic_bytes", "mih_set_xtv_variant"]
+
+
+def _check(rc):
+    if rc == 0:
+        return
+    buf = C.create_string_buffer(512)
+    lib().mih_last_error(buf, 512)
+    raise _STATUS.get(rc, MendelIHTError)(f"[mih status {rc}] {buf.value.decode(errors='replace')}")
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    n = C.c_int(0)
+    _check(lib().mih_device_count(C.byref(n)))
+    return n.value
+
+
+# ---- distributions and links (Distributions.jl / GLM.jl names) -----------------------
+class _Dist:
+    code = 0
+    name = "Normal"
+
+    def __repr__(self):
+        return f"{self.name}()"
+
+
+class Normal(_Dist):
+    code, name = 0, "Normal"
+
+
+class Bernoulli(_Dist):
+    code, name = 1, "Bernoulli"
+
+
+class Poisson(_Dist):
+    code, name = 2, "Poisson"
+
+
+class NegativeBinomial(_Dist):
+    code, name = 3, "NegativeBinomial"
+
+    def __init__(self, r=1.0, p=0.5):
+        self.r, self.p = float(r), float(p)
+
+    def __repr__(self):
+        return f"NegativeBinomial(r={self.r}, p={self.p})"
+
+
+class MvNormal(_Dist):
+    code, name = -1, "MvNormal"
+
+
+class IdentityLink:
+    code = 0
+
+    def __repr__(self):
+        return "IdentityLink()"
+
+
+class LogitLink:
+    code = 1
+
+    def __repr__(self):
+        return "LogitLink()"
+
+
+class LogLink:
+    code = 2
+
+    def __repr__(self):
+        return "LogLink()"
+
+
+def _inst(x):
+    return x() if isinstance(x, type) else x
+
+
+# ---- design matrices -------------------------------------------------------------------
+def read_bed(path, n):
+    """PLINK .bed (SNP-major, header 6c 1b 01) -> (p, ceil(n/4)) uint8 column bytes."""
+    raw = np.fromfile(path, dtype=np.uint8)
+    if raw.size < 3 or raw[0] != 0x6C or raw[1] != 0x1B or raw[2] != 0x01:
+        raise ArgumentError(f"{path} is not a SNP-major PLINK .bed file")
+    stride = (n + 3) // 4
+    body = raw[3:]
+    if body.size % stride:
+        raise DimensionMismatch(f"{path}: size does not match n={n}")
+    return body.reshape(-1, stride)
+
+
+class _Mat:
+    def __init__(self):
+        self._h = C.c_void_p(None)
+        self.n = self.p = 0
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().mih_mat_destroy(self._h)
+                self._h = C.c_void_p(None)
+        except Exception:
+            pass
+
+    @property
+    def shape(self):
+        return (self.n, self.p)
+
+    def _dims(self):
+        n, p = C.c_int64(0), C.c_int64(0)
+        _check(lib().mih_mat_dims(self._h, C.byref(n), C.byref(p)))
+        self.n, self.p = n.value, p.value
+
+    # mul!(out, Transpose(x), r)
+    def xtv(self, r):
+        r = np.asarray(r, dtype=np.float64)
+        if r.ndim == 1:
+            if r.size != self.n:
+                raise DimensionMismatch(f"r has length {r.size}, expected {self.n}")
+            r = np.ascontiguousarray(r)
+            out = np.empty(self.p)
+            _check(lib().mih_xtv(self._h, _p(r), _p(out)))
+            return out
+        if r.shape[0] != self.n:
+            raise DimensionMismatch(f"R has {r.shape[0]} rows, expected {self.n}")
+        R = np.asfortranarray(r)
+        out = np.empty((self.p, R.shape[1]), order="F")
+        _check(lib().mih_xtv_batched(self._h, _p(R), R.shape[1], _p(out)))
+        return out
+
+    def xv_sparse(self, idx, val):
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        out = np.empty(self.n)
+        _check(lib().mih_xv_sparse(self._h, _p(idx), _p(val), idx.size, _p(out)))
+        return out
+
+    def bench_xtv(self, variant=-1, iters=10, warmup=2, seed=1):
+        ms, cs = C.c_float(0), C.c_double(0)
+        _check(lib().mih_bench_xtv(self._h, variant, iters, warmup, seed, C.byref(ms), C.byref(cs)))
+        return ms.value, cs.value
+
+    def algorithmic_bytes(self, m=1):
+        b = C.c_double(0)
+        _check(lib().mih_xtv_algorithmic_bytes(self._h, m, C.byref(b)))
+        return b.value
+
+
+class SnpLinAlg(_Mat):
+    """SnpLinAlg{Float64}(s::SnpArray; model=ADDITIVE_MODEL, center, scale, impute) on the GPU."""
+
+    def __init__(self, bed, n=None, center=False, scale=False, impute=True, device=0, _handle=None):
+        super().__init__()
+        self.center, self.scale, self.impute = bool(center), bool(scale), bool(impute)
+        self.device = device
+        if _handle is not None:
+            self._h = _handle
+            self._dims()
+            return
+        if isinstance(bed, (str, os.PathLike)):
+            if n is None:
+                raise ArgumentError("n (number of samples) is required with a .bed path")
+            bed = read_bed(bed, n)
+        cols = np.ascontiguousarray(bed, dtype=np.uint8)
+        if cols.ndim != 2:
+            raise DimensionMismatch("bed columns must be a (p, stride) uint8 array")
+        if n is None:
+            raise ArgumentError("n (number of samples) is required")
+        h = C.c_void_p(None)
+        _check(lib().mih_snp_create(_p(cols), n, cols.shape[0], cols.shape[1], int(center), int(scale),
+                                    int(impute), 64, device, C.byref(h)))
+        self._h = h
+        self._dims()
+
+    @classmethod
+    def synthetic(cls, n, p, seed=2024, missing_rate=0.0, center=True, scale=True, impute=True, device=0):
+        h = C.c_void_p(None)
+        _check(lib().mih_snp_create_synthetic(n, p, seed, float(missing_rate), int(center), int(scale),
+                                              int(impute), device, C.byref(h)))
+        return cls(None, center=center, scale=scale, impute=impute, device=device, _handle=h)
+
+    def mu_sigma(self):
+        mu, s = np.empty(self.p), np.empty(self.p)
+        _check(lib().mih_snp_mu_sigma(self._h, _p(mu), _p(s)))
+        return mu, s
+
+    def export_bed(self):
+        out = np.empty((self.p, (self.n + 3) // 4), dtype=np.uint8)
+        _check(lib().mih_snp_export_bed(self._h, _p(out)))
+        return out
+
+
+class DenseMatrix(_Mat):
+    """The reference's `x::Matrix{Float64}` design matrix, resident in HBM."""
+
+    def __init__(self, x, device=0, _handle=None):
+        super().__init__()
+        self.device = device
+        if _handle is not None:
+            self._h = _handle
+            self._dims()
+            return
+        x = np.asfortranarray(x, dtype=np.float64)
+        if x.ndim != 2:
+            raise DimensionMismatch("x must be a matrix")
+        h = C.c_void_p(None)
+        _check(lib().mih_dense_create(_p(x), x.shape[0], x.shape[1], device, C.byref(h)))
+        self._h = h
+        self._dims()
+
+    @classmethod
+    def synthetic(cls, n, p, seed=2024, device=0):
+        h = C.c_void_p(None)
+        _check(lib().mih_dense_create_synthetic(n, p, seed, device, C.byref(h)))
+        return cls(None, device=device, _handle=h)
+
+
+def _as_mat(x):
+    if isinstance(x, _Mat):
+        return x
+    if isinstance(x, np.ndarray):
+        if x.dtype == np.uint8:
+            raise ArgumentError("x is a SnpArray! Please convert it to a SnpLinAlg first!")
+        return DenseMatrix(x)
+    raise ArgumentError(f"unsupported design matrix type {type(x)}")
+
+
+# ---- projections ---------------------------------------------------------------------------
+def project_k(x, k):
+    """project_k!(x, k): keep the k largest |x_i| (ties kept); returns the projected copy."""
+    if k < 0:
+        raise ArgumentError(f"DomainError: Attempted to project to sparsity level {k}")
+    x = np.array(x, dtype=np.float64).ravel()
+    kept = C.c_int64(0)
+    _check(lib().mih_project_topk(_p(x), x.size, int(k), C.byref(kept)))
+    return x
+
+
+def project_group_sparse(y, group, J, k):
+    y = np.array(y, dtype=np.float64).ravel()
+    group = np.ascontiguousarray(group, dtype=np.int64)
+    if group.size != y.size:
+        raise DimensionMismatch("group must have the length of y")
+    kv = np.ascontiguousarray(np.atleast_1d(k), dtype=np.int64)
+    _check(lib().mih_project_group_sparse(_p(y), _p(group), y.size, int(J), _p(kv), int(np.ndim(k) > 0)))
+    return y
+
+
+def standardize(z):
+    """standardize!(z) (src/utilities.jl:494-530): column-wise (z - mean) * 1/sample-sd."""
+    z = np.array(z, dtype=np.float64)
+    mu = z.mean(axis=0)
+    sd = np.sqrt(((z - mu) ** 2).sum(axis=0) / (z.shape[0] - 1))
+    return (z - mu) / sd
+
+
+# ---- results -------------------------------------------------------------------------------
+class IHTResult:
+    """IHTResult (src/data_structures.jl:245-256)."""
+
+    def __init__(self, time, logl, iter, beta, c, J, k, group, d, sigma_g, trace=None, choose_fired=False, mu=None):
+        self.time, self.logl, self.iter = time, logl, iter
+        self.beta, self.c, self.J, self.k, self.group, self.d = beta, c, J, k, group, d
+        self.σg = self.sigma_g = sigma_g
+        self.trace = trace or {}
+        self.choose_fired = choose_fired
+        self.mu = mu
+
+    def __repr__(self):
+        nz = np.flatnonzero(self.beta)
+        cz = np.flatnonzero(self.c)
+        lines = ["", f"IHT estimated {nz.size} nonzero SNP predictors and {cz.size} non-genetic predictors.", "",
+                 f"Compute time (sec):     {self.time}", f"Final loglikelihood:    {self.logl}",
+                 f"SNP PVE:                {self.σg}", f"Iterations:             {self.iter}", "",
+                 "Selected genetic predictors:", " Position  Estimated_β"]
+        lines += [f" {j + 1:8d}  {self.beta[j]: .6g}" for j in nz]
+        lines += ["", "Selected nongenetic predictors:", " Position  Estimated_β"]
+        lines += [f" {j + 1:8d}  {self.c[j]: .6g}" for j in cz]
+        return "\n".join(lines)
+
+
+class mIHTResult:
+    """mIHTResult (src/data_structures.jl:263-273)."""
+
+    def __init__(self, time, logl, iter, beta, c, k, traits, Sigma, sigma_g, trace=None, choose_fired=False):
+        self.time, self.logl, self.iter, self.beta, self.c = time, logl, iter, beta, c
+        self.k, self.traits, self.Σ, self.σg = k, traits, Sigma, sigma_g
+        self.Sigma, self.sigma_g = Sigma, sigma_g
+        self.trace = trace or {}
+        self.choose_fired = choose_fired
+
+
+def _is_multivariate(y):
+    y = np.asarray(y)
+    return y.ndim == 2 and y.shape[0] > 1 and y.shape[1] > 1
+
+
+def _print_signature(io):
+    print("****                   MendelIHT (mendeliht.jl_amd, MI355X)         ****", file=io)
+    print("****     hot path of OpenMendel/MendelIHT.jl v1.4.11 on gfx950      ****", file=io)
+    print("", file=io)
+
+
+def _print_parameters(io, k, d, l, use_maf, group, debias, tol, max_iter, min_iter):
+    reg = {"Normal": "linear", "Bernoulli": "logistic", "Poisson": "Poisson", "NegativeBinomial": "NegativeBinomial",
+           "MvNormal": "Multivariate Gaussian"}.get(d.name, "unknown")
+    print(f"Running sparse {reg} regression", file=io)
+    print(f"Link functin = {l}", file=io)
+    if np.ndim(k) == 0:
+        print(f"Sparsity parameter (k) = {k}", file=io)
+    else:
+        print("Sparsity parameter (k) = using group membership specified in k", file=io)
+    print(f"Prior weight scaling = {'on' if use_maf else 'off'}", file=io)
+    print(f"Doubly sparse projection = {'on' if group is not None and len(group) > 0 else 'off'}", file=io)
+    print(f"Debias = {'on' if debias else 'off'}", file=io)
+    print(f"Max IHT iterations = {max_iter}", file=io)
+    print(f"Converging when tol < {tol} and iteration ≥ {min_iter}:\n", file=io)
+
+
+def _params(k, J, d, l, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, q, p, keep, progress=None):
+    prm = _FitParams()
+    ks = None
+    if np.ndim(k) > 0:
+        ks = np.ascontiguousarray(k, dtype=np.int64)
+        if group is None or len(group) <= 1:
+            raise ArgumentError("Doubly sparse projection specified (since k is a vector) but there are no group information.")
+        prm.k = 0
+    else:
+        if k < 0:
+            raise ArgumentError("Value of k (max predictors per group) must be nonnegative!")
+        prm.k = int(k)
+    prm.J = int(J)
+    prm.dist = max(d.code, 0)
+    prm.link = l.code
+    prm.nb_r = getattr(d, "r", 1.0)
+    prm.tol = float(tol)
+    prm.max_iter, prm.min_iter, prm.max_step = int(max_iter), int(min_iter), int(max_step)
+    er = est_r if isinstance(est_r, str) else ("None" if est_r is None else str(est_r))
+    er = er.lstrip(":").lower()
+    if er not in ("none", "mm", "newton"):
+        raise ArgumentError(f"Only support method is Newton or MM, but got {est_r}")
+    prm.est_r = {"none": 0, "mm": 1, "newton": 2}[er]
+    zk = None
+    if zkeep is not None:
+        zk = np.ascontiguousarray(zkeep, dtype=np.uint8)
+        if zk.size != q:
+            raise DimensionMismatch(f"zkeep must have length {q} but was {zk.size}")
+    w = None
+    if weight is not None and len(weight) > 0:
+        w = np.ascontiguousarray(weight, dtype=np.float64)
+        if w.size != p:
+            raise DimensionMismatch(f"weight must have length {p} but was {w.size}")
+    g = None
+    if group is not None and len(group) > 0:
+        g = np.ascontiguousarray(group, dtype=np.int64)
+        if g.size != p:
+            raise DimensionMismatch(f"group must have length {p} but was {g.size}")
+    prm.zkeep, prm.weight, prm.group, prm.ks = _p(zk), _p(w), _p(g), _p(ks)
+    prm.nks = 0 if ks is None else ks.size
+    cb = None
+    if progress is not None:
+        cb = _PROGRESS(progress)
+        prm.progress = C.cast(cb, C.c_void_p)
+    keep.extend([zk, w, g, ks, cb])
+    return prm
+
+
+def fit_iht(y, x, z=None, *, k=10, J=1, d=None, l=None, group=None, weight=None, zkeep=None, est_r="None",
+            use_maf=False, debias=False, verbose=True, tol=1e-4, max_iter=200, min_iter=5, max_step=3,
+            io=None, init_beta=False, memory_efficient=True, train=None):
+    """fit_iht(y, x, z; k, J, d, l, ...) -- src/fit.jl:60-118.
+
+    Univariate: y (n,), x SnpLinAlg/DenseMatrix (n x p), z (n, q) with a leading column of ones.
+    Multivariate (d=MvNormal or y 2-D): y (r, n), z (q, n), x is the same SnpLinAlg (its transpose is implied).
+    """
+    io = io or sys.stdout
+    x = _as_mat(x)
+    mv = _is_multivariate(y)
+    d = _inst(d) if d is not None else (MvNormal() if mv else Normal())
+    l = _inst(l) if l is not None else IdentityLink()
+    if debias:
+        raise ArgumentError("Currently debiasing only works with memory_efficient=false (not available on the GPU path)")
+    if init_beta:
+        raise ArgumentError("init_beta=true is not implemented on the GPU path yet")
+    if not memory_efficient:
+        raise ArgumentError("the GPU path is always memory_efficient=true")
+    if isinstance(x, SnpLinAlg):
+        if not x.center:
+            raise ArgumentError("x is not centered! Please construct SnpLinAlg{Float64}(::SnpArray, center=true, scale=true)")
+        if not x.scale:
+            print("Warning: x is not scaled! We highly recommend `scale=true` in `SnpLinAlg` constructor", file=sys.stderr)
+        if not x.impute:
+            print("Warning: x does not have impute flag! We highly recommend `impute=true` in `SnpLinAlg` constructor", file=sys.stderr)
+    if verbose:
+        _print_signature(io)
+    if mv:
+        return _fit_mv(y, x, z, k, d, l, zkeep, verbose, tol, max_iter, min_iter, max_step, io, train)
+    y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).ravel())
+    n = x.n
+    z = np.ones((n, 1)) if z is None else np.asarray(z, dtype=np.float64)
+    z = np.asfortranarray(z.reshape(z.shape[0], -1))
+    if not (y.size == n == z.shape[0]):
+        raise DimensionMismatch(f"row dimension of y, x, and z ({y.size}, {n}, {z.shape[0]}) are not equal")
+    _checky(y, d)
+    q = z.shape[1]
+    lines = []
+
+    def progress(_user, it, logl, bt, tl):
+        line = f"Iteration {it}: loglikelihood = {logl!r}, backtracks = {bt}, tol = {tl!r}"
+        lines.append(line)
+        if verbose:
+            print(line, file=io)
+
+    keep = []
+    prm = _params(k, J, d, l, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, q, x.p, keep, progress)
+    if verbose:
+        _print_parameters(io, k, d, l, use_maf, group, debias, tol, max_iter, min_iter)
+    tr = None if train is None else np.ascontiguousarray(train, dtype=np.uint8)
+    beta, c, mu = np.zeros(x.p), np.zeros(q), np.zeros(n)
+    nt = max(int(max_iter), 1)
+    lt, tt, bt = np.zeros(nt), np.zeros(nt), np.zeros(nt, dtype=np.int32)
+    res = _FitResult()
+    res.beta, res.c, res.mu = _p(beta), _p(c), _p(mu)
+    res.logl_trace, res.tol_trace, res.bt_trace = _p(lt), _p(tt), _p(bt)
+    _check(lib().mih_fit_iht(x._h, C.byref(prm), _p(y), _p(z), q, _p(tr), C.byref(res)))
+    m = res.n_trace
+    if verbose and res.iter >= max_iter:
+        print(f"Did not converge after {max_iter} iterations! IHT run time was {res.time} seconds", file=io)
+    dd = NegativeBinomial(res.nb_r) if isinstance(d, NegativeBinomial) else d
+    return IHTResult(res.time, res.logl, res.iter, beta, c, J, k, np.array([] if group is None else group), dd, res.pve,
+                     trace=dict(logl=lt[:m].copy(), tol=tt[:m].copy(), backtracks=bt[:m].copy(), lines=lines),
+                     choose_fired=bool(res.choose_fired), mu=mu)
+
+
+def _checky(y, d):
+    if isinstance(d, Bernoulli) and not np.all((y == 0) | (y == 1)):
+        raise ArgumentError("Bernoulli data y must be 1 or 0 only")
+    if isinstance(d, (Poisson, NegativeBinomial)) and (np.any(y < 0) or np.any(y != np.floor(y))):
+        raise ArgumentError("Poisson/NegativeBinomial data must be nonnegative integers")
+
+
+def _fit_mv(Y, x, Z, k, d, l, zkeep, verbose, tol, max_iter, min_iter, max_step, io, train):
+    Y = np.asfortranarray(np.asarray(Y, dtype=np.float64))
+    r, n = Y.shape
+    Z = np.ones((1, n)) if Z is None else np.asarray(Z, dtype=np.float64)
+    Z = np.asfortranarray(Z.reshape(-1, Z.shape[-1]) if Z.ndim > 1 else Z.reshape(1, -1))
+    if not (n == x.n == Z.shape[1]):
+        raise DimensionMismatch(f"number of samples in y, x, and z = {n}, {x.n}, {Z.shape[1]} are not equal")
+    if np.ndim(k) > 0:
+        raise ArgumentError("multivariate IHT takes an integer k")
+    q = Z.shape[0]
+    lines = []
+
+    def progress(_user, it, logl, bt, tl):
+        line = f"Iteration {it}: loglikelihood = {logl!r}, backtracks = {bt}, tol = {tl!r}"
+        lines.append(line)
+        if verbose:
+            print(line, file=io)
+
+    keep = []
+    prm = _params(k, 1, Normal(), l, tol, max_iter, min_iter, max_step, "None", zkeep, None, None, q, x.p, keep, progress)
+    if verbose:
+        _print_parameters(io, k, MvNormal(), l, False, None, False, tol, max_iter, min_iter)
+    tr = None if train is None else np.ascontiguousarray(train, dtype=np.uint8)
+    B, Cm = np.zeros((r, x.p), order="F"), np.zeros((r, q), order="F")
+    S, pve = np.zeros((r, r), order="F"), np.zeros(r)
+    nt = max(int(max_iter), 1)
+    lt, tt, bt = np.zeros(nt), np.zeros(nt), np.zeros(nt, dtype=np.int32)
+    res = _MvResult()
+    res.B, res.C, res.Sigma, res.pve = _p(B), _p(Cm), _p(S), _p(pve)
+    res.logl_trace, res.tol_trace, res.bt_trace = _p(lt), _p(tt), _p(bt)
+    _check(lib().mih_fit_mv(x._h, C.byref(prm), _p(Y), r, _p(Z), q, _p(tr), C.byref(res)))
+    m = res.n_trace
+    return mIHTResult(res.time, res.logl, res.iter, B, Cm, k, r, S, pve,
+                      trace=dict(logl=lt[:m].copy(), tol=tt[:m].copy(), backtracks=bt[:m].copy(), lines=lines),
+                      choose_fired=bool(res.choose_fired))
+
+
+def cv_iht(y, x, z=None, *, d=None, l=None, path=range(1, 21), q=5, est_r="None", group=None, weight=None,
+           zkeep=None, folds=None, debias=False, verbose=True, max_iter=100, min_iter=5, init_beta=False,
+           memory_efficient=True, tol=1e-4, max_step=3, rank=0, world=1, reduce=None, return_raw=False):
+    """cv_iht(y, x, z; path, q, folds, ...) -- src/cross_validation.jl:60-131.
+
+    `rank`/`world` shard the (fold, k) combinations over processes (one GPU each); `reduce`
+    is a callable that sum-reduces the raw q x len(path) loss matrix across ranks (see
+    mendeliht.jl_amd.dist.cv_iht_distributed for the torch.distributed/RCCL version).
+    """
+    x = _as_mat(x)
+    mv = _is_multivariate(y)
+    d = _inst(d) if d is not None else (MvNormal() if mv else Normal())
+    l = _inst(l) if l is not None else IdentityLink()
+    if debias or init_beta or not memory_efficient:
+        raise ArgumentError("debias / init_beta / memory_efficient=false are not available on the GPU path")
+    path = np.ascontiguousarray(list(path), dtype=np.int64)
+    n = x.n
+    if path.size == 0:
+        raise ArgumentError("path is empty")
+    if path.max() > x.p:
+        raise ArgumentError("Sparsity level in `path` cannot be larger than total number of variables")
+    if folds is None:
+        folds = np.random.randint(1, q + 1, size=n)      # rand(1:q, n) (cross_validation.jl:72)
+    folds = np.ascontiguousarray(folds, dtype=np.int32)
+    if folds.size != n:
+        raise DimensionMismatch("folds must have one label per sample")
+    raw = np.zeros((q, path.size))
+    keep = []
+    if mv:
+        Y = np.asfortranarray(np.asarray(y, dtype=np.float64))
+        r = Y.shape[0]
+        Z = np.ones((1, n)) if z is None else np.asarray(z, dtype=np.float64)
+        Z = np.asfortranarray(Z.reshape(-1, Z.shape[-1]) if Z.ndim > 1 else Z.reshape(1, -1))
+        prm = _params(1, 1, Normal(), l, tol, max_iter, min_iter, max_step, "None", zkeep, None, None, Z.shape[0], x.p, keep)
+        _check(lib().mih_cv_mv(x._h, C.byref(prm), _p(Y), r, _p(Z), Z.shape[0], _p(folds), q, _p(path), path.size,
+                               rank, world, _p(raw)))
+    else:
+        yv = np.ascontiguousarray(np.asarray(y, dtype=np.float64).ravel())
+        zz = np.ones((n, 1)) if z is None else np.asarray(z, dtype=np.float64)
+        zz = np.asfortranarray(zz.reshape(zz.shape[0], -1))
+        if not (yv.size == n == zz.shape[0]):
+            raise DimensionMismatch(f"row dimension of y, x, and z ({yv.size}, {n}, {zz.shape[0]}) are not equal")
+        _checky(yv, d)
+        prm = _params(1, 1, d, l, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, zz.shape[1], x.p, keep)
+        _check(lib().mih_cv_iht(x._h, C.byref(prm), _p(yv), _p(zz), zz.shape[1], _p(folds), q, _p(path), path.size,
+                                rank, world, _p(raw)))
+    if reduce is not None:
+        raw = reduce(raw)
+    mse = np.zeros(path.size)
+    _check(lib().mih_cv_meanloss(_p(np.ascontiguousarray(raw)), _p(folds), n, q, path.size, _p(mse)))
+    if verbose and rank == 0:
+        print("\n\nCrossvalidation Results:\n\tk\tMSE")
+        for kk, m in zip(path, mse):
+            print(f"\t{kk}\t{m}")
+        print(f"\nBest k = {path[int(np.argmin(mse))]}\n")
+    return (mse, raw) if return_raw else mse
+
+
+# ---- file-level wrappers (src/wrapper.jl) ----------------------------------------------------
+def _read_fam_phenotypes(prefix, col):
+    vals = []
+    with open(prefix + ".fam") as f:
+        for line in f:
+            parts = line.split()
+            vals.append(float(parts[col - 1]))
+    return np.array(vals)
+
+
+def _count_lines(path):
+    with open(path) as f:
+        return sum(1 for _ in f)
+
+
+def _parse_inputs(plinkfile, phenotypes, covariates):
+    n = _count_lines(plinkfile + ".fam")
+    x = SnpLinAlg(plinkfile + ".bed", n, center=True, scale=True, impute=True)   # wrapper.jl:68-69
+    if isinstance(phenotypes, int):
+        y = _read_fam_phenotypes(plinkfile, phenotypes)                            # wrapper.jl:136-218
+    elif isinstance(phenotypes, (list, tuple)):
+        y = np.stack([_read_fam_phenotypes(plinkfile, c) for c in phenotypes])
+    else:
+        y = np.loadtxt(phenotypes, delimiter=",", ndmin=1)
+        if y.ndim == 2:
+            y = y.T if y.shape[1] > 1 else y.ravel()
+    if covariates:
+        z = np.loadtxt(covariates, delimiter=",", ndmin=2)                          # wrapper.jl:228-247
+        if z.shape[1] > 1:
+            z[:, 1:] = standardize(z[:, 1:])
+    else:
+        z = np.ones((n, 1))
+    return x, y, z
+
+
+def iht(plinkfile, k, d, *, phenotypes=6, covariates="", summaryfile="iht.summary.txt", betafile="iht.beta.txt",
+        covariancefile="iht.cov.txt", **kwargs):
+    """iht(filename, k, d; phenotypes, covariates, ...) -- src/wrapper.jl:52-120 (PLINK input)."""
+    x, y, z = _parse_inputs(plinkfile, phenotypes, covariates)
+    d = _inst(d)
+    if _is_multivariate(y):
+        result = fit_iht(y, x, z.T, k=k, d=d, **kwargs)
+    else:
+        l = kwargs.pop("l", None) or {1: LogitLink(), 2: LogLink(), 3: LogLink()}.get(d.code, IdentityLink())
+        result = fit_iht(y, x, z, k=k, d=d, l=l, **kwargs)
+    if summaryfile:
+        with open(summaryfile, "w") as f:
+            f.write(repr(result) if isinstance(result, IHTResult) else f"logl = {result.logl}\niter = {result.iter}\n")
+    if betafile:
+        np.savetxt(betafile, result.beta.T if isinstance(result, mIHTResult) else result.beta)
+    if covariancefile and isinstance(result, mIHTResult):
+        np.savetxt(covariancefile, result.Σ, delimiter=",")
+    return result
+
+
+def cross_validate(plinkfile, d, *, path=range(1, 21), q=5, phenotypes=6, covariates="",
+                   cv_summaryfile="cviht.summary.txt", **kwargs):
+    """cross_validate(filename, d; path, q, ...) -- src/wrapper.jl:301-349 (PLINK input)."""
+    x, y, z = _parse_inputs(plinkfile, phenotypes, covariates)
+    d = _inst(d)
+    t0 = time.time()
+    if _is_multivariate(y):
+        mse = cv_iht(y, x, z.T, d=d, path=path, q=q, **kwargs)
+    else:
+        l = kwargs.pop("l", None) or {1: LogitLink(), 2: LogLink(), 3: LogLink()}.get(d.code, IdentityLink())
+        mse = cv_iht(y, x, z, d=d, l=l, path=path, q=q, **kwargs)
+    if cv_summaryfile:
+        with open(cv_summaryfile, "w") as f:
+            f.write("k,mse\n")
+            for kk, m in zip(path, mse):
+                f.write(f"{kk},{m}\n")
+            f.write(f"\ntotal time (sec) = {time.time() - t0}\n")
+    return mse

@@ -1,0 +1,735 @@
+// fit.hip -- the univariate IHT loop, device-resident: fit_iht!/iht_one_step!
+// (src/fit.jl:145-263) over the kernels of xtv.hip / xv.hip / topk.hip, plus the
+// GLM element-wise kernels (score!, update_mu!, loglikelihood, iht_stepsize!
+// weights: src/utilities.jl:9-135,722-764) and cv_iht (src/cross_validation.jl).
+//
+// What lives where: X (2-bit), y, z, cv_wts, xb, zc, mu, r, df and the projection
+// buffer stay in HBM for the whole fit.  The model itself is k-sparse, so b, b0,
+// best_b are (index, value) lists on the host, and the q-vectors c, df2 are host
+// scalars; per iteration the host reads back only: the step-size reduction, the
+// projection survivors (k entries), the loglikelihood scalars, Z'r and df[S].
+#include "common.h"
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <limits>
+
+namespace mih {
+
+constexpr int kMaxQ = 64;
+struct QVec { double v[kMaxQ]; };
+
+// ---- GLM closed forms (GLM.jl / Distributions.jl) --------------------
+__device__ __forceinline__ double d_linkinv(int link, double eta)
+{
+    switch (link) {
+    case MIH_LOGIT: return 1.0 / (1.0 + exp(-eta));
+    case MIH_LOG:   return exp(eta);
+    default:        return eta;
+    }
+}
+__device__ __forceinline__ double d_mueta(int link, double eta)
+{
+    switch (link) {
+    case MIH_LOGIT: { double e = exp(-fabs(eta)); double f = 1.0 + e; return e / (f * f); }
+    case MIH_LOG:   return exp(eta);
+    default:        return 1.0;
+    }
+}
+__device__ __forceinline__ double d_glmvar(int dist, double mu, double nb_r)
+{
+    switch (dist) {
+    case MIH_BERNOULLI: return mu * (1.0 - mu);
+    case MIH_POISSON:   return mu;
+    case MIH_NEGBIN:    return mu * (1.0 + mu / nb_r);
+    default:            return 1.0;
+    }
+}
+__device__ __forceinline__ double d_xlogy(double x, double y) { return x == 0.0 ? 0.0 : x * log(y); }
+__device__ __forceinline__ double d_devresid(int dist, double y, double mu, double nb_r)
+{
+    switch (dist) {
+    case MIH_BERNOULLI: return (y == 1.0) ? -2.0 * log(mu) : -2.0 * log1p(-mu);
+    case MIH_POISSON:   return 2.0 * (d_xlogy(y, y / mu) - (y - mu));
+    case MIH_NEGBIN: {
+        double v = 2.0 * (d_xlogy(y, y / mu) + d_xlogy(y + nb_r, (mu + nb_r) / (y + nb_r)));
+        return (mu == 0.0) ? nan("") : v;
+    }
+    default: { double d = y - mu; return d * d; }
+    }
+}
+// loglik_obs without the Normal branch (utilities.jl:32-43); Normal is closed-form from the deviance
+__device__ __forceinline__ double d_loglik_obs(int dist, double y, double mu, double nb_r)
+{
+    switch (dist) {
+    case MIH_BERNOULLI: return (y == 1.0) ? log(mu) : log(1.0 - mu);
+    case MIH_POISSON:   return d_xlogy(y, mu) - mu - lgamma(y + 1.0);
+    case MIH_NEGBIN: {
+        double pp = nb_r / (mu + nb_r);
+        return lgamma(nb_r + y) - lgamma(nb_r) - lgamma(y + 1.0) + nb_r * log(pp) + d_xlogy(y, 1.0 - pp);
+    }
+    default: return 0.0;
+    }
+}
+
+// deterministic block sum (fixed tree) of up to NV values per thread
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double *out /* NV values, thread 0 */)
+{
+    __shared__ double red[NV][256];
+    #pragma unroll
+    for (int k = 0; k < NV; ++k) red[k][threadIdx.x] = v[k];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            #pragma unroll
+            for (int k = 0; k < NV; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        #pragma unroll
+        for (int k = 0; k < NV; ++k) out[k] = red[k][0];
+    }
+}
+
+// second stage: sum `nblocks` rows of NV partials in fixed order
+__global__ void k_final_sum(const double *__restrict__ partial, int nblocks, int nv, double *__restrict__ out)
+{
+    __shared__ double red[256];
+    for (int k = 0; k < nv; ++k) {
+        double a = 0.0;
+        for (int b = threadIdx.x; b < nblocks; b += 256) a += partial[(int64_t)b * nv + k];
+        red[threadIdx.x] = a;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+        if (threadIdx.x == 0) out[k] = red[0];
+        __syncthreads();
+    }
+}
+
+// zc = Z c  (utilities.jl:113), optional clamp (utilities.jl:114-117)
+__global__ void k_zmul(const double *__restrict__ z, int64_t n, int q, QVec c, int clamp20, double *__restrict__ zc)
+{
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a = 0.0;
+    for (int l = 0; l < q; ++l) a += z[(int64_t)l * n + i] * c.v[l];
+    if (clamp20) a = a < -20.0 ? -20.0 : (a > 20.0 ? 20.0 : a);
+    zc[i] = a;
+}
+
+// update_mu! (utilities.jl:74-82) fused with deviance (:52-59) and the loglik terms (:9-20).
+// partial[b] = { sum w*devresid, sum w*loglik_obs (non-Normal), sum w }
+__global__ void __launch_bounds__(256)
+k_mu_loglik(const double *__restrict__ xb, const double *__restrict__ zc, const double *__restrict__ y,
+            const double *__restrict__ w, int64_t n, int dist, int link, double nb_r, int with_zc,
+            double *__restrict__ mu, double *__restrict__ partial)
+{
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    double v[3] = {0.0, 0.0, 0.0};
+    if (i < n) {
+        double eta = with_zc ? xb[i] + zc[i] : xb[i];
+        double m = d_linkinv(link, eta);
+        mu[i] = m;
+        double wt = w[i];
+        v[0] = wt * d_devresid(dist, y[i], m, nb_r);
+        v[1] = (dist == MIH_NORMAL) ? 0.0 : wt * d_loglik_obs(dist, y[i], m, nb_r);
+        v[2] = wt;
+    }
+    block_sum<3>(v, partial ? partial + 3ll * blockIdx.x : nullptr);
+}
+
+// score! residual (utilities.jl:128-132): r = mueta(eta)/var(mu) * (y-mu) * cv_wts, written in
+// natural order (missing-entry correction, Z'r) and in the X'r kernel's tile permutation.
+__global__ void __launch_bounds__(256)
+k_resid(const double *__restrict__ xb, const double *__restrict__ zc, const double *__restrict__ y,
+        const double *__restrict__ mu, const double *__restrict__ w, int64_t n, int64_t n_perm,
+        int dist, int link, double nb_r, double *__restrict__ r, double *__restrict__ rperm)
+{
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n_perm) return;
+    double v = 0.0;
+    if (i < n) {
+        double eta = xb[i] + zc[i];
+        double m = mu[i];
+        v = d_mueta(link, eta) / d_glmvar(dist, m, nb_r) * (y[i] - m) * w[i];
+        r[i] = v;
+    }
+    if (rperm) rperm[rperm_pos(i)] = v;
+}
+
+// df2 = Z' r (utilities.jl:134): one workgroup per covariate, fixed-order tree
+__global__ void __launch_bounds__(256)
+k_zt_r(const double *__restrict__ z, const double *__restrict__ r, int64_t n, double *__restrict__ out)
+{
+    const double *zl = z + (int64_t)blockIdx.x * n;
+    double v[1] = {0.0};
+    for (int64_t i = threadIdx.x; i < n; i += 256) v[0] += zl[i] * r[i];
+    block_sum<1>(v, out + blockIdx.x);
+}
+
+// iht_stepsize! tail (utilities.jl:744-756): xgk = (X_S df_S + Z_idc df2_idc) * sqrt(mueta^2/var) * w;
+// partial[b] = sum xgk^2
+__global__ void __launch_bounds__(256)
+k_stepsize(const double *__restrict__ xgk, const double *__restrict__ z, const double *__restrict__ xb,
+           const double *__restrict__ zc, const double *__restrict__ mu, const double *__restrict__ w,
+           int64_t n, int q, QVec df2_idc, int dist, int link, double nb_r, double *__restrict__ partial)
+{
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    double v[1] = {0.0};
+    if (i < n) {
+        double a = 0.0;
+        for (int l = 0; l < q; ++l) a += z[(int64_t)l * n + i] * df2_idc.v[l];
+        double g = xgk[i] + a;
+        double me = d_mueta(link, xb[i] + zc[i]);
+        double sw = sqrt(me * me / d_glmvar(dist, mu[i], nb_r)) * w[i];
+        g *= sw;
+        v[0] = g * g;
+    }
+    block_sum<1>(v, partial + blockIdx.x);
+}
+
+// vectorize!(full_b, b, c, weight, zkeep) after the axpy (utilities.jl:258-263,291-315):
+// full[j] = eta*df[j]*w_j here; the k support entries are patched by k_scatter_b.
+__global__ void k_grad_full(const double *__restrict__ df, const double *__restrict__ weight, int64_t p,
+                            double eta, double *__restrict__ full)
+{
+    int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (j >= p) return;
+    double v = eta * df[j];
+    full[j] = weight ? v * weight[j] : v;
+}
+__global__ void k_scatter_b(const int64_t *__restrict__ idx, const double *__restrict__ val, int64_t nnz,
+                            const double *__restrict__ df, const double *__restrict__ weight, double eta,
+                            double *__restrict__ full)
+{
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= nnz) return;
+    int64_t j = idx[t];
+    double v = fma(eta, df[j], val[t]);          // BLAS.axpy!(eta, df, b) is an fma per element
+    full[j] = weight ? v * weight[j] : v;
+}
+// unvectorize! for the gradient at init (utilities.jl:420): df <- projected full / weight
+__global__ void k_unvec(const double *__restrict__ full, const double *__restrict__ weight, int64_t p,
+                        double *__restrict__ df)
+{
+    int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (j >= p) return;
+    df[j] = weight ? full[j] / weight[j] : full[j];
+}
+__global__ void k_gather(const double *__restrict__ src, const int64_t *__restrict__ idx, int64_t nnz,
+                         double *__restrict__ out)
+{
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t < nnz) out[t] = src[idx[t]];
+}
+__global__ void k_mask_to_wts(const uint8_t *__restrict__ m, int64_t n, int invert, double *__restrict__ w)
+{
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) w[i] = ((m[i] != 0) != (invert != 0)) ? 1.0 : 0.0;
+}
+
+static inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+struct Sparse {                       // a k-sparse p-vector, sorted by index
+    std::vector<int64_t> idx;
+    std::vector<double> val;
+    void clear() { idx.clear(); val.clear(); }
+};
+
+static double h_linkinv(int link, double eta)
+{
+    switch (link) { case MIH_LOGIT: return 1.0 / (1.0 + std::exp(-eta)); case MIH_LOG: return std::exp(eta); default: return eta; }
+}
+static double h_mueta(int link, double eta)
+{
+    switch (link) {
+    case MIH_LOGIT: { double e = std::exp(-std::fabs(eta)); double f = 1.0 + e; return e / (f * f); }
+    case MIH_LOG: return std::exp(eta);
+    default: return 1.0;
+    }
+}
+
+// One IHTVariable (src/data_structures.jl:4-43), device-resident.
+struct IhtVar {
+    const mih_mat *h = nullptr;
+    int64_t n = 0, p = 0; int q = 0;
+    int64_t k = 0, J = 1; std::vector<int64_t> ks;
+    int dist = 0, link = 0, est_r = 0; double nb_r = 1.0;
+    std::vector<uint8_t> zkeep; int64_t zkeepn = 0;
+    const double *y_host = nullptr;
+    hipStream_t s = nullptr;
+    // device
+    DevBuf<double> y, z, w, xb, zc, mu, r, xgk, df, full, weight, red, scal, gval;
+    DevBuf<int64_t> sidx; DevBuf<double> sval;   // staging for support lists
+    DevBuf<uint8_t> mask;
+    XtvWork xtv; XvWork xv; TopkWork topk;
+    int nb = 0;                                   // row blocks
+    // host
+    Sparse b, b0, best_b, idx;                    // idx.val = df on the support
+    std::vector<uint8_t> idc, idc0;
+    std::vector<double> c, c0, best_c, df2;
+    int64_t ntrain = 0;
+    bool choose_fired = false;
+    bool has_weight = false;
+
+    int create(const mih_mat *hh, const mih_fit_params *prm, const double *yh, const double *zh, int64_t qq)
+    {
+        h = hh; n = h->n; p = h->p; q = (int)qq; y_host = yh;
+        k = prm->k; J = prm->J; dist = prm->dist; link = prm->link; est_r = prm->est_r; nb_r = prm->nb_r;
+        if (prm->ks && prm->nks > 0) { ks.assign(prm->ks, prm->ks + prm->nks); k = 0; }
+        zkeep.resize(q); zkeepn = 0;
+        for (int l = 0; l < q; ++l) { zkeep[l] = prm->zkeep ? (prm->zkeep[l] != 0) : 1; zkeepn += zkeep[l]; }
+        MIH_HIP(hipStreamCreate(&s));
+        nb = (int)nblk(n);
+        MIH_TRY(y.alloc(n)); MIH_TRY(z.alloc((size_t)n * q)); MIH_TRY(w.alloc(n)); MIH_TRY(xb.alloc(n));
+        MIH_TRY(zc.alloc(n)); MIH_TRY(mu.alloc(n)); MIH_TRY(r.alloc(n)); MIH_TRY(xgk.alloc(n));
+        MIH_TRY(df.alloc(p)); MIH_TRY(full.alloc((size_t)p + q)); MIH_TRY(mask.alloc(n));
+        MIH_TRY(red.alloc((size_t)nb * 4)); MIH_TRY(scal.alloc(kMaxQ + 8));
+        int64_t kcap = std::max<int64_t>(k + q, 64) + 1024;
+        for (int64_t v : ks) kcap += v;
+        MIH_TRY(sidx.alloc(kcap)); MIH_TRY(sval.alloc(kcap)); MIH_TRY(gval.alloc(kcap));
+        MIH_TRY(xtv_work_init(h, xtv, 1));
+        MIH_TRY(xv_work_init(h, xv, kcap));
+        MIH_TRY(topk_work_init(topk, kcap));
+        MIH_HIP(hipMemcpyAsync(y.p, yh, sizeof(double) * n, hipMemcpyHostToDevice, s));
+        MIH_HIP(hipMemcpyAsync(z.p, zh, sizeof(double) * (size_t)n * q, hipMemcpyHostToDevice, s));
+        if (prm->weight) {
+            has_weight = true;
+            MIH_TRY(weight.alloc(p));
+            MIH_HIP(hipMemcpyAsync(weight.p, prm->weight, sizeof(double) * p, hipMemcpyHostToDevice, s));
+        }
+        c.assign(q, 0.0); c0 = c; best_c = c; df2 = c; idc.assign(q, 0); idc0 = idc;
+        return MIH_OK;
+    }
+    ~IhtVar() { if (s) (void)hipStreamDestroy(s); }
+
+    int ensure_stage(int64_t nnz)
+    {
+        if ((size_t)nnz <= sidx.n) return MIH_OK;
+        MIH_HIP(hipStreamSynchronize(s));
+        MIH_TRY(sidx.alloc((size_t)nnz * 2)); MIH_TRY(sval.alloc((size_t)nnz * 2)); MIH_TRY(gval.alloc((size_t)nnz * 2));
+        return MIH_OK;
+    }
+    int upload(const std::vector<int64_t> &ix, const std::vector<double> &vl)
+    {
+        MIH_TRY(ensure_stage((int64_t)ix.size()));
+        if (!ix.empty()) {
+            MIH_HIP(hipMemcpyAsync(sidx.p, ix.data(), sizeof(int64_t) * ix.size(), hipMemcpyHostToDevice, s));
+            MIH_HIP(hipMemcpyAsync(sval.p, vl.data(), sizeof(double) * vl.size(), hipMemcpyHostToDevice, s));
+        }
+        return MIH_OK;
+    }
+    QVec qvec(const std::vector<double> &v) const { QVec o; for (int l = 0; l < kMaxQ; ++l) o.v[l] = l < q ? v[l] : 0.0; return o; }
+
+    int set_weights(const uint8_t *m, int invert)      // cv_wts from a train mask
+    {
+        if (!m) {
+            std::vector<double> ones(n, invert ? 0.0 : 1.0);
+            MIH_HIP(hipMemcpyAsync(w.p, ones.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
+            MIH_HIP(hipStreamSynchronize(s));
+            return MIH_OK;
+        }
+        MIH_HIP(hipMemcpyAsync(mask.p, m, n, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_mask_to_wts, dim3(nblk(n)), dim3(256), 0, s, mask.p, n, invert, w.p);
+        return MIH_OK;
+    }
+
+    // update_xb! (utilities.jl:93-118)
+    int update_xb()
+    {
+        int clamp = (dist != MIH_NORMAL);
+        MIH_TRY(upload(b.idx, b.val));
+        MIH_TRY(xv_sparse_device(h, xv, sidx.p, sval.p, (int64_t)b.idx.size(), xb.p, clamp, s));
+        hipLaunchKernelGGL(k_zmul, dim3(nblk(n)), dim3(256), 0, s, z.p, n, q, qvec(c), clamp, zc.p);
+        return MIH_OK;
+    }
+    // update_mu! + loglikelihood; returns logl and the raw deviance
+    int mu_loglik(int with_zc, double *logl, double *dev)
+    {
+        hipLaunchKernelGGL(k_mu_loglik, dim3(nb), dim3(256), 0, s, xb.p, zc.p, y.p, w.p, n, dist, link, nb_r, with_zc, mu.p, red.p);
+        hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, s, red.p, nb, 3, scal.p);
+        double o[3];
+        MIH_HIP(hipMemcpyAsync(o, scal.p, sizeof(o), hipMemcpyDeviceToHost, s));
+        MIH_HIP(hipStreamSynchronize(s));
+        if (dev) *dev = o[0];
+        if (logl) {
+            if (dist == MIH_NORMAL) {
+                double phi = o[0] / (double)n;           // utilities.jl:15: divides by length(y)
+                double sd = std::sqrt(phi);
+                // sum_i w_i * ( -(z_i^2 + log 2pi)/2 - log sd ),  z_i = (y_i-mu_i)/sd
+                *logl = -(o[0] / (sd * sd) + o[2] * 1.8378770664093454835606594728112) / 2.0 - o[2] * std::log(sd);
+            } else *logl = o[1];
+        }
+        return MIH_OK;
+    }
+    // score! (utilities.jl:126-135) + df[idx] gather for the next step size
+    int score()
+    {
+        double *rp = (h->kind == 0) ? xtv.rperm.p : nullptr;
+        int64_t np = (h->kind == 0) ? xtv.n_perm : n;
+        hipLaunchKernelGGL(k_resid, dim3(nblk(np)), dim3(256), 0, s, xb.p, zc.p, y.p, mu.p, w.p, n, np, dist, link, nb_r, r.p, rp);
+        if (h->kind == 0) MIH_TRY(xtv_device_preperm(h, xtv, r.p, 1, df.p, s));
+        else MIH_TRY(xtv_device(h, xtv, r.p, 1, df.p, s));
+        hipLaunchKernelGGL(k_zt_r, dim3(q), dim3(256), 0, s, z.p, r.p, n, scal.p);
+        MIH_HIP(hipMemcpyAsync(df2.data(), scal.p, sizeof(double) * q, hipMemcpyDeviceToHost, s));
+        return MIH_OK;
+    }
+    int gather_df_support()
+    {
+        int64_t nnz = (int64_t)idx.idx.size();
+        idx.val.assign(nnz, 0.0);
+        if (nnz) {
+            MIH_TRY(ensure_stage(nnz));
+            MIH_HIP(hipMemcpyAsync(sidx.p, idx.idx.data(), sizeof(int64_t) * nnz, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_gather, dim3(nblk(nnz)), dim3(256), 0, s, df.p, sidx.p, nnz, gval.p);
+            MIH_HIP(hipMemcpyAsync(idx.val.data(), gval.p, sizeof(double) * nnz, hipMemcpyDeviceToHost, s));
+        }
+        MIH_HIP(hipStreamSynchronize(s));
+        return MIH_OK;
+    }
+
+    // _choose! (utilities.jl:444-458): RNG tie-break in the reference; deterministic here
+    // (drop the smallest |b|, ties highest index) and flagged.
+    void choose()
+    {
+        int64_t sparsity = k + zkeepn, groups = (J == 0) ? 1 : J;
+        int64_t nz = (int64_t)b.idx.size() - zkeepn;
+        for (int l = 0; l < q; ++l) nz += idc[l];
+        if (nz <= groups * sparsity) return;
+        int64_t excess = nz - groups * sparsity;
+        choose_fired = true;
+        std::vector<size_t> ord(b.idx.size());
+        for (size_t i = 0; i < ord.size(); ++i) ord[i] = i;
+        std::sort(ord.begin(), ord.end(), [&](size_t a, size_t bb) {
+            double fa = std::fabs(b.val[a]), fb = std::fabs(b.val[bb]);
+            if (fa != fb) return fa < fb;
+            return b.idx[a] > b.idx[bb];
+        });
+        std::vector<char> drop(b.idx.size(), 0);
+        for (int64_t t = 0; t < excess && t < (int64_t)ord.size(); ++t) drop[ord[t]] = 1;
+        Sparse nb2;
+        for (size_t i = 0; i < b.idx.size(); ++i) if (!drop[i]) { nb2.idx.push_back(b.idx[i]); nb2.val.push_back(b.val[i]); }
+        b = nb2;
+    }
+
+    // project the (p+q) buffer `full` to k+zkeepn and split the survivors into (SNP list, covariate values)
+    int project_full(Sparse &snp, std::vector<double> &ctail, std::vector<uint8_t> &ctail_nz)
+    {
+        std::vector<int64_t> si; std::vector<double> sv;
+        MIH_TRY(topk_project_device(full.p, p + q, k + zkeepn, topk, s, si, sv));
+        snp.clear();
+        ctail_nz.assign(q, 0);
+        for (size_t t = 0; t < si.size(); ++t) {
+            if (si[t] < p) { snp.idx.push_back(si[t]); snp.val.push_back(sv[t]); }
+            else { ctail[si[t] - p] = sv[t]; ctail_nz[si[t] - p] = 1; }
+        }
+        return MIH_OK;
+    }
+
+    // _iht_gradstep! (utilities.jl:252-280) from base model (bb, cc) with step eta
+    int gradstep(const Sparse &bb, const std::vector<double> &cc, double eta)
+    {
+        if (!ks.empty() || has_group) { set_error("group projection is handled by gradstep_group"); return MIH_BAD_ARG; }
+        const double *wp = has_weight ? weight.p : nullptr;
+        hipLaunchKernelGGL(k_grad_full, dim3(nblk(p)), dim3(256), 0, s, df.p, wp, p, eta, full.p);
+        MIH_TRY(upload(bb.idx, bb.val));
+        if (!bb.idx.empty())
+            hipLaunchKernelGGL(k_scatter_b, dim3(nblk((int64_t)bb.idx.size())), dim3(256), 0, s, sidx.p, sval.p, (int64_t)bb.idx.size(), df.p, wp, eta, full.p);
+        std::vector<double> cn(q), tail(q);
+        for (int l = 0; l < q; ++l) {
+            cn[l] = std::fma(eta, df2[l], cc[l]);
+            tail[l] = zkeep[l] ? std::numeric_limits<double>::infinity() : cn[l];
+        }
+        MIH_HIP(hipMemcpyAsync(full.p + p, tail.data(), sizeof(double) * q, hipMemcpyHostToDevice, s));
+        Sparse snp; std::vector<double> ct(q, 0.0); std::vector<uint8_t> cnz;
+        MIH_TRY(project_full(snp, ct, cnz));
+        if (has_weight) {           // unvectorize!: b = full / weight on the survivors
+            std::vector<double> hw(snp.idx.size());
+            MIH_TRY(ensure_stage((int64_t)snp.idx.size()));
+            if (!snp.idx.empty()) {
+                MIH_HIP(hipMemcpyAsync(sidx.p, snp.idx.data(), sizeof(int64_t) * snp.idx.size(), hipMemcpyHostToDevice, s));
+                hipLaunchKernelGGL(k_gather, dim3(nblk((int64_t)snp.idx.size())), dim3(256), 0, s, weight.p, sidx.p, (int64_t)snp.idx.size(), gval.p);
+                MIH_HIP(hipMemcpyAsync(hw.data(), gval.p, sizeof(double) * hw.size(), hipMemcpyDeviceToHost, s));
+                MIH_HIP(hipStreamSynchronize(s));
+            }
+            for (size_t t = 0; t < hw.size(); ++t) snp.val[t] /= hw[t];
+        }
+        b = snp;
+        for (int l = 0; l < q; ++l) {
+            c[l] = zkeep[l] ? cn[l] : (cnz[l] ? ct[l] : 0.0);
+            idc[l] = (c[l] != 0.0);
+        }
+        choose();
+        idx.idx = b.idx;          // idx = b .!= 0
+        return MIH_OK;
+    }
+    bool has_group = false;
+
+    // init_iht_indices! (utilities.jl:366-438), init_beta=false
+    int init(const uint8_t *train)
+    {
+        b.clear(); b0.clear(); best_b.clear(); idx.clear();
+        std::fill(c.begin(), c.end(), 0.0); c0 = c; best_c = c; std::fill(df2.begin(), df2.end(), 0.0);
+        for (int l = 0; l < q; ++l) { idc[l] = zkeep[l]; idc0[l] = zkeep[l]; }
+        choose_fired = false;
+        MIH_TRY(set_weights(train, 0));
+        ntrain = 0; double ybar = 0.0;
+        for (int64_t i = 0; i < n; ++i) if (!train || train[i]) { ybar += y_host[i]; ntrain++; }
+        if (ntrain == 0) { set_error("no training samples"); return MIH_BAD_ARG; }
+        ybar /= (double)ntrain;
+        for (int it = 0; it < 20; ++it) {          // utilities.jl:400-405
+            double g1 = h_linkinv(link, c[0]), g2 = h_mueta(link, c[0]);
+            double step = (g1 - ybar) / g2;
+            step = step < -1.0 ? -1.0 : (step > 1.0 ? 1.0 : step);
+            c[0] -= step;
+            if (std::fabs(g1 - ybar) < 1e-10) break;
+        }
+        MIH_HIP(hipMemsetAsync(xb.p, 0, sizeof(double) * n, s));
+        hipLaunchKernelGGL(k_zmul, dim3(nblk(n)), dim3(256), 0, s, z.p, n, q, qvec(c), 0, zc.p);   // no clamp at init (utilities.jl:406)
+        hipLaunchKernelGGL(k_mu_loglik, dim3(nb), dim3(256), 0, s, xb.p, zc.p, y.p, w.p, n, dist, link, nb_r, 1, mu.p, red.p);
+        MIH_TRY(score());
+        MIH_HIP(hipStreamSynchronize(s));
+        // vectorize!(full_b, df, df2) ; project_k! ; unvectorize! -> df is replaced by its own projection
+        const double *wp = has_weight ? weight.p : nullptr;
+        hipLaunchKernelGGL(k_grad_full, dim3(nblk(p)), dim3(256), 0, s, df.p, wp, p, 1.0, full.p);
+        std::vector<double> tail(q);
+        for (int l = 0; l < q; ++l) tail[l] = zkeep[l] ? std::numeric_limits<double>::infinity() : df2[l];
+        MIH_HIP(hipMemcpyAsync(full.p + p, tail.data(), sizeof(double) * q, hipMemcpyHostToDevice, s));
+        Sparse snp; std::vector<double> ct(q, 0.0); std::vector<uint8_t> cnz;
+        MIH_TRY(project_full(snp, ct, cnz));
+        hipLaunchKernelGGL(k_unvec, dim3(nblk(p)), dim3(256), 0, s, full.p, wp, p, df.p);
+        for (int l = 0; l < q; ++l) if (!zkeep[l]) df2[l] = cnz[l] ? ct[l] : 0.0;
+        idx.idx = snp.idx;
+        for (int l = 0; l < q; ++l) idc[l] = zkeep[l];
+        // _choose!(v) at init looks at idx with b == 0: it can only fire on exact ties; flag it
+        {
+            int64_t nz = (int64_t)idx.idx.size() - zkeepn;
+            for (int l = 0; l < q; ++l) nz += idc[l];
+            if (nz > ((J == 0) ? 1 : J) * (k + zkeepn)) {
+                choose_fired = true;
+                int64_t excess = nz - ((J == 0) ? 1 : J) * (k + zkeepn);
+                for (int64_t t = 0; t < excess && !idx.idx.empty(); ++t) idx.idx.pop_back();
+            }
+        }
+        MIH_TRY(gather_df_support());
+        return MIH_OK;
+    }
+
+    // iht_stepsize! (utilities.jl:722-764)
+    int stepsize(double *eta)
+    {
+        MIH_TRY(upload(idx.idx, idx.val));
+        MIH_TRY(xv_sparse_device(h, xv, sidx.p, sval.p, (int64_t)idx.idx.size(), xgk.p, 0, s));
+        std::vector<double> d2(q);
+        double numer = 0.0;
+        for (size_t t = 0; t < idx.val.size(); ++t) numer += idx.val[t] * idx.val[t];
+        for (int l = 0; l < q; ++l) { d2[l] = idc[l] ? df2[l] : 0.0; if (idc[l]) numer += df2[l] * df2[l]; }
+        hipLaunchKernelGGL(k_stepsize, dim3(nb), dim3(256), 0, s, xgk.p, z.p, xb.p, zc.p, mu.p, w.p, n, q, qvec(d2), dist, link, nb_r, red.p);
+        hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, s, red.p, nb, 1, scal.p);
+        double denom = 0.0;
+        MIH_HIP(hipMemcpyAsync(&denom, scal.p, sizeof(double), hipMemcpyDeviceToHost, s));
+        MIH_HIP(hipStreamSynchronize(s));
+        double e = numer / denom;
+        if (std::isinf(e) || std::isnan(e)) e = 1e-8;
+        *eta = e;
+        return MIH_OK;
+    }
+
+    double save_prev(double cur, double best)        // utilities.jl:702-712
+    {
+        b0 = b; c0 = c; idc0 = idc;
+        if (cur > best) { best_b = b; best_c = c; }
+        return cur > best ? cur : best;
+    }
+    int save_best_model()                            // utilities.jl:995-1006
+    {
+        b = best_b; c = best_c; idx.idx = b.idx;
+        for (int l = 0; l < q; ++l) idc[l] = (c[l] != 0.0);
+        MIH_TRY(update_xb());
+        MIH_TRY(mu_loglik(0, nullptr, nullptr));     // mu = linkinv(xb): genetic part only
+        return MIH_OK;
+    }
+    double check_convergence() const                 // utilities.jl:953-957
+    {
+        double d = 0.0, nbm = 0.0;
+        size_t i = 0, j = 0;
+        while (i < b.idx.size() || j < b0.idx.size()) {
+            double vb = 0.0, v0 = 0.0;
+            if (j >= b0.idx.size() || (i < b.idx.size() && b.idx[i] < b0.idx[j])) vb = b.val[i++];
+            else if (i >= b.idx.size() || b0.idx[j] < b.idx[i]) v0 = b0.val[j++];
+            else { vb = b.val[i++]; v0 = b0.val[j++]; }
+            d = std::max(d, std::fabs(vb - v0)); nbm = std::max(nbm, std::fabs(v0));
+        }
+        for (int l = 0; l < q; ++l) { d = std::max(d, std::fabs(c[l] - c0[l])); nbm = std::max(nbm, std::fabs(c0[l])); }
+        return d / (nbm + 1.0);
+    }
+
+    // iht_one_step! (fit.jl:213-263)
+    int one_step(double old_logl, int nstep, int *bt, double *new_logl)
+    {
+        double eta;
+        MIH_TRY(stepsize(&eta));
+        MIH_TRY(gradstep(b, c, eta));
+        MIH_TRY(update_xb());
+        double logl;
+        MIH_TRY(mu_loglik(1, &logl, nullptr));
+        int es = 0;
+        while (old_logl > logl && es < nstep) {       // _iht_backtrack_ (utilities.jl:484-486)
+            eta /= 2;
+            MIH_TRY(gradstep(b0, c0, eta));           // backtrack! (utilities.jl:959-973)
+            MIH_TRY(update_xb());
+            MIH_TRY(mu_loglik(1, &logl, nullptr));
+            es++;
+        }
+        MIH_TRY(score());
+        MIH_TRY(gather_df_support());
+        if (std::isnan(logl)) { set_error("Loglikelihood function is NaN, aborting..."); return MIH_NAN_LOGL; }
+        if (std::isinf(logl)) { set_error("Loglikelihood function is Inf, aborting..."); return MIH_INF_LOGL; }
+        *bt = es; *new_logl = logl;
+        return MIH_OK;
+    }
+
+    // fit_iht! (fit.jl:145-207)
+    int fit_loop(const mih_fit_params *prm, double *best_out, int64_t *iter_out, double *lt, double *tt,
+                 int32_t *btt, int32_t *ntrace)
+    {
+        double next_logl = -std::numeric_limits<double>::infinity(), best = next_logl;
+        int64_t mm = 0; int32_t nt = 0;
+        for (int iter = 1; iter <= prm->max_iter; ++iter) {
+            if (iter >= prm->max_iter) {             // fit.jl:170: max_iter=N performs N-1 steps
+                best = save_prev(next_logl, best);
+                MIH_TRY(save_best_model());
+                mm = iter;
+                break;
+            }
+            best = save_prev(next_logl, best);
+            int nbt = 0;
+            MIH_TRY(one_step(next_logl, prm->max_step, &nbt, &next_logl));
+            double sc = check_convergence();
+            if (lt) lt[nt] = next_logl;
+            if (tt) tt[nt] = sc;
+            if (btt) btt[nt] = nbt;
+            nt++;
+            if (prm->progress) prm->progress(prm->progress_user, iter, next_logl, nbt, sc);
+            if (iter >= prm->min_iter && sc < prm->tol) {
+                best = save_prev(next_logl, best);
+                MIH_TRY(save_best_model());
+                mm = iter;
+                break;
+            }
+        }
+        *best_out = best; *iter_out = mm;
+        if (ntrace) *ntrace = nt;
+        return MIH_OK;
+    }
+};
+
+static int check_params(const mih_mat *h, const mih_fit_params *prm, int64_t q)
+{
+    if (!h || !prm) { set_error("null handle/params"); return MIH_BAD_ARG; }
+    if (prm->J < 0) { set_error("Value of J (max number of groups) must be nonnegative!"); return MIH_BAD_ARG; }
+    if (prm->max_iter < 0) { set_error("Value of max_iter must be nonnegative!"); return MIH_BAD_ARG; }
+    if (prm->max_step < 0) { set_error("Value of max_step must be nonnegative!"); return MIH_BAD_ARG; }
+    if (!(prm->tol > 2.220446049250313e-16)) { set_error("Value of global tol must exceed machine precision!"); return MIH_BAD_ARG; }
+    if (h->kind == 0 && !h->center) { set_error("x is not centered! Please construct SnpLinAlg{Float64}(::SnpArray, center=true, scale=true)"); return MIH_NOT_CENTERED; }
+    if (prm->est_r != MIH_ESTR_NONE && prm->dist != MIH_NEGBIN) { set_error("Only negative binomial regression currently supports nuisance parameter estimation"); return MIH_BAD_ARG; }
+    if (prm->est_r != MIH_ESTR_NONE) { set_error("est_r (NegBin nuisance estimation) is not implemented on the device path yet"); return MIH_BAD_ARG; }
+    if (prm->group || prm->ks) { set_error("group / doubly-sparse projection is not implemented in the device fit loop yet (use mih_project_group_sparse)"); return MIH_BAD_ARG; }
+    if (!prm->ks && prm->k < 0) { set_error("Value of k (max predictors per group) must be nonnegative!"); return MIH_BAD_ARG; }
+    if (q < 1 || q > kMaxQ) { set_error("number of covariates q=%lld must be in 1..%d", (long long)q, kMaxQ); return MIH_BAD_DIM; }
+    if (prm->dist < 0 || prm->dist > MIH_NEGBIN || prm->link < 0 || prm->link > MIH_LOG) { set_error("unknown distribution/link"); return MIH_BAD_ARG; }
+    return MIH_OK;
+}
+
+static double sample_var(const double *a, int64_t n)
+{
+    double m = 0.0; for (int64_t i = 0; i < n; ++i) m += a[i]; m /= (double)n;
+    double s = 0.0; for (int64_t i = 0; i < n; ++i) s += (a[i] - m) * (a[i] - m);
+    return s / (double)(n - 1);
+}
+
+}  // namespace mih
+
+using namespace mih;
+
+extern "C" {
+
+int mih_fit_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, const double *z,
+                int64_t q, const uint8_t *train, mih_fit_result *res)
+{
+    MIH_TRY(check_params(h, prm, q));
+    if (!y || !z || !res) { set_error("null argument"); return MIH_BAD_ARG; }
+    MIH_HIP(hipSetDevice(h->device));
+    IhtVar v;
+    MIH_TRY(v.create(h, prm, y, z, q));
+    MIH_TRY(v.init(train));
+    auto t0 = std::chrono::steady_clock::now();
+    MIH_TRY(v.fit_loop(prm, &res->logl, &res->iter, res->logl_trace, res->tol_trace, res->bt_trace, &res->n_trace));
+    res->time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::vector<double> mu(h->n);
+    MIH_HIP(hipMemcpyAsync(mu.data(), v.mu.p, sizeof(double) * h->n, hipMemcpyDeviceToHost, v.s));
+    MIH_HIP(hipStreamSynchronize(v.s));
+    res->pve = sample_var(mu.data(), h->n) / sample_var(y, h->n);   // pve.jl:22,32
+    res->nb_r = v.nb_r;
+    res->choose_fired = v.choose_fired ? 1 : 0;
+    if (res->beta) {
+        std::memset(res->beta, 0, sizeof(double) * h->p);
+        for (size_t t = 0; t < v.best_b.idx.size(); ++t) res->beta[v.best_b.idx[t]] = v.best_b.val[t];
+    }
+    if (res->c) for (int l = 0; l < (int)q; ++l) res->c[l] = v.best_c[l];
+    if (res->mu) std::memcpy(res->mu, mu.data(), sizeof(double) * h->n);
+    return MIH_OK;
+}
+
+int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, const double *z,
+               int64_t q, const int32_t *folds, int32_t nfolds, const int64_t *path, int64_t npath,
+               int32_t rank, int32_t world, double *mses_raw)
+{
+    MIH_TRY(check_params(h, prm, q));
+    if (!y || !z || !folds || !path || !mses_raw || nfolds < 1 || npath < 1 || world < 1 || rank < 0 || rank >= world) { set_error("null/invalid argument"); return MIH_BAD_ARG; }
+    int64_t n = h->n, kmax = 0;
+    for (int64_t i = 0; i < npath; ++i) kmax = std::max(kmax, path[i]);
+    if (kmax > h->p) { set_error("Sparsity level in `path` cannot be larger than total number of variables"); return MIH_BAD_ARG; }
+    for (int64_t i = 0; i < n; ++i) if (folds[i] < 1 || folds[i] > nfolds) { set_error("folds must be in 1..q"); return MIH_BAD_ARG; }
+    MIH_HIP(hipSetDevice(h->device));
+    for (int64_t i = 0; i < (int64_t)nfolds * npath; ++i) mses_raw[i] = 0.0;
+    mih_fit_params pr = *prm;
+    pr.k = kmax; pr.progress = nullptr;
+    IhtVar v;
+    MIH_TRY(v.create(h, &pr, y, z, q));
+    std::vector<uint8_t> train(n);
+    int64_t combo = 0;
+    for (int32_t fold = 1; fold <= nfolds; ++fold)
+        for (int64_t ik = 0; ik < npath; ++ik, ++combo) {
+            if (combo % world != rank) continue;
+            for (int64_t i = 0; i < n; ++i) train[i] = (folds[i] != fold);
+            v.k = path[ik];                              // cross_validation.jl:110
+            MIH_TRY(v.init(train.data()));
+            double best; int64_t it;
+            MIH_TRY(v.fit_loop(&pr, &best, &it, nullptr, nullptr, nullptr, nullptr));
+            MIH_TRY(v.set_weights(train.data(), 1));     // cv_wts <- test mask (:115-116)
+            MIH_TRY(v.update_xb());                      // predict! (:279-286)
+            double dev;
+            MIH_TRY(v.mu_loglik(1, nullptr, &dev));
+            mses_raw[(int64_t)(fold - 1) * npath + ik] = dev;
+        }
+    return MIH_OK;
+}
+
+int mih_cv_meanloss(const double *mses_raw, const int32_t *folds, int64_t n, int32_t nfolds,
+                    int64_t npath, double *mse_out)
+{
+    if (!mses_raw || !folds || !mse_out) return MIH_BAD_ARG;
+    std::vector<int64_t> cnt(nfolds, 0);
+    for (int64_t i = 0; i < n; ++i) { if (folds[i] < 1 || folds[i] > nfolds) return MIH_BAD_ARG; cnt[folds[i] - 1]++; }
+    for (int64_t i = 0; i < npath; ++i) mse_out[i] = 0.0;
+    for (int32_t j = 0; j < nfolds; ++j) {                 // cross_validation.jl:312-317
+        double wf = (double)cnt[j] / (double)n;
+        for (int64_t i = 0; i < npath; ++i) mse_out[i] += mses_raw[i + (int64_t)j * npath] * wf;
+    }
+    return MIH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,474 @@
+// snp.hip -- device-resident design matrices: upload/transcode of PLINK 2-bit
+// columns, column statistics (mu, sinv), missing-entry side lists, synthetic
+// generators, export.  Replaces the SnpLinAlg constructor the reference calls at
+// src/wrapper.jl:68-69 (SnpArrays.jl linalg_direct.jl; semantics SURVEY.md 8c).
+#include "common.h"
+#include <cstdarg>
+#include <cmath>
+
+namespace mih {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line)
+{
+    set_error("HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? MIH_OOM : MIH_HIP_ERROR;
+}
+
+// PLINK codes -> dosage codes for 16 packed genotypes: 00->00, 01->00 (missing), 10->01, 11->10.
+__device__ __forceinline__ uint32_t plink_to_dosage(uint32_t w)
+{
+    uint32_t hi = w & 0xAAAAAAAAu;
+    uint32_t both = (w << 1) & hi;
+    return (hi >> 1) + (both >> 1);
+}
+__device__ __forceinline__ uint32_t plink_missing_mask(uint32_t w)   // bit 2s set where code == 01
+{
+    return (~w >> 1) & w & 0x55555555u;
+}
+
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+// One workgroup per column: transcode raw PLINK bytes to dosage dwords and count.
+__global__ void __launch_bounds__(256)
+k_transcode(const uint8_t *__restrict__ raw, int64_t raw_stride, int64_t n, int64_t ncols,
+            uint32_t *__restrict__ X, int64_t stride_dw, int64_t col0,
+            int32_t *__restrict__ cnt /* [ncols][3]: n1, n2, nmiss */)
+{
+    __shared__ int32_t red[3][256];
+    for (int64_t jc = blockIdx.x; jc < ncols; jc += gridDim.x) {
+        const uint8_t *src = raw + jc * raw_stride;
+        uint32_t *dst = X + (col0 + jc) * stride_dw;
+        int64_t nbytes = (n + 3) >> 2;
+        int32_t c1 = 0, c2 = 0, cm = 0;
+        for (int64_t t = threadIdx.x; t < stride_dw; t += blockDim.x) {
+            uint32_t w = 0;
+            int64_t b0 = t * 4;
+            #pragma unroll
+            for (int b = 0; b < 4; ++b)
+                if (b0 + b < nbytes) w |= (uint32_t)src[b0 + b] << (8 * b);
+            int64_t rows_left = n - t * 16;       // valid genotypes in this dword
+            uint32_t valid = rows_left >= 16 ? 0xFFFFFFFFu
+                           : rows_left <= 0 ? 0u : ((1u << (2 * rows_left)) - 1u);
+            w &= valid;
+            uint32_t d = plink_to_dosage(w);
+            uint32_t m = plink_missing_mask(w) & valid;
+            dst[t] = d;
+            c1 += __popc(d & 0x55555555u);
+            c2 += __popc(d & 0xAAAAAAAAu);
+            cm += __popc(m);
+        }
+        red[0][threadIdx.x] = c1; red[1][threadIdx.x] = c2; red[2][threadIdx.x] = cm;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) {
+                red[0][threadIdx.x] += red[0][threadIdx.x + s];
+                red[1][threadIdx.x] += red[1][threadIdx.x + s];
+                red[2][threadIdx.x] += red[2][threadIdx.x + s];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            cnt[3 * (col0 + jc) + 0] = red[0][0];
+            cnt[3 * (col0 + jc) + 1] = red[1][0];
+            cnt[3 * (col0 + jc) + 2] = red[2][0];
+        }
+        __syncthreads();
+    }
+}
+
+// mu_j = (n1 + 2 n2) / (n - nmiss); sinv_j = 1/sqrt(mu(1-mu/2)) if that sqrt > 0 else 1
+__global__ void k_col_stats(const int32_t *__restrict__ cnt, int64_t n, int64_t p,
+                            double *__restrict__ mu, double *__restrict__ sinv)
+{
+    int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (j >= p) return;
+    double n1 = cnt[3 * j], n2 = cnt[3 * j + 1], nm = cnt[3 * j + 2];
+    double m = (n1 + 2.0 * n2) / ((double)n - nm);
+    double s = sqrt(m * (1.0 - m / 2.0));
+    mu[j] = m;
+    sinv[j] = (s > 0.0) ? 1.0 / s : 1.0;
+}
+
+// One wave per column: append the rows whose raw PLINK code is 01, ascending.
+__global__ void __launch_bounds__(64)
+k_fill_missing_raw(const uint8_t *__restrict__ raw, int64_t raw_stride, int64_t n, int64_t ncols,
+                   int64_t col0, const int64_t *__restrict__ miss_ptr, int32_t *__restrict__ miss_row)
+{
+    int64_t jc = blockIdx.x;
+    if (jc >= ncols) return;
+    const uint8_t *src = raw + jc * raw_stride;
+    int64_t base = miss_ptr[col0 + jc];
+    int lane = threadIdx.x;
+    for (int64_t i0 = 0; i0 < n; i0 += 64) {
+        int64_t i = i0 + lane;
+        bool miss = false;
+        if (i < n) miss = ((src[i >> 2] >> (2 * (i & 3))) & 3) == 1;
+        unsigned long long bal = __ballot(miss);
+        if (miss) {
+            int off = __popcll(bal & ((1ull << lane) - 1ull));
+            miss_row[base + off] = (int32_t)i;
+        }
+        base += __popcll(bal);
+    }
+}
+
+// ---- synthetic SnpArray ------------------------------------------------------
+__device__ __forceinline__ void synth_entry(uint32_t key_g, uint32_t key_m, uint32_t thr16,
+                                            uint32_t miss_thr, int64_t i, uint32_t &dos, bool &miss)
+{
+    uint32_t h = lowbias32((uint32_t)i * 0x9E3779B1u ^ key_g);
+    dos = ((h & 0xFFFFu) < thr16) + ((h >> 16) < thr16);
+    miss = miss_thr != 0 && lowbias32((uint32_t)i * 0x85EBCA77u ^ key_m) < miss_thr;
+}
+
+__device__ __forceinline__ void synth_col_keys(uint64_t seed, int64_t j, uint32_t &key_g,
+                                               uint32_t &key_m, uint32_t &thr16)
+{
+    uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
+    key_g = lowbias32((uint32_t)j ^ lowbias32(s0 ^ 0xA511E9B3u)) ^ lowbias32((uint32_t)(j >> 32) + s1);
+    key_m = lowbias32(key_g ^ 0x68E31DA4u);
+    uint32_t u = lowbias32(key_g ^ 0xB5297A4Du) >> 8;          // 24 bits
+    double maf = 0.5 * ((double)u + 0.5) / 16777216.0;          // U(0, 0.5)
+    thr16 = (uint32_t)(maf * 65536.0);
+}
+
+__global__ void __launch_bounds__(256)
+k_synth(uint32_t *__restrict__ X, int64_t stride_dw, int64_t n, int64_t p, uint64_t seed,
+        uint32_t miss_thr, int32_t *__restrict__ cnt)
+{
+    __shared__ int32_t red[3][256];
+    for (int64_t j = blockIdx.x; j < p; j += gridDim.x) {
+        uint32_t key_g, key_m, thr16;
+        synth_col_keys(seed, j, key_g, key_m, thr16);
+        uint32_t *dst = X + j * stride_dw;
+        int32_t c1 = 0, c2 = 0, cm = 0;
+        for (int64_t t = threadIdx.x; t < stride_dw; t += blockDim.x) {
+            uint32_t d = 0;
+            #pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                int64_t i = t * 16 + s;
+                uint32_t dos; bool miss;
+                synth_entry(key_g, key_m, thr16, miss_thr, i, dos, miss);
+                if (i < n) {
+                    if (miss) cm++;
+                    else { d |= dos << (2 * s); c1 += (dos == 1); c2 += (dos == 2); }
+                }
+            }
+            dst[t] = d;
+        }
+        red[0][threadIdx.x] = c1; red[1][threadIdx.x] = c2; red[2][threadIdx.x] = cm;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) {
+                red[0][threadIdx.x] += red[0][threadIdx.x + s];
+                red[1][threadIdx.x] += red[1][threadIdx.x + s];
+                red[2][threadIdx.x] += red[2][threadIdx.x + s];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { cnt[3 * j] = red[0][0]; cnt[3 * j + 1] = red[1][0]; cnt[3 * j + 2] = red[2][0]; }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(64)
+k_fill_missing_synth(int64_t n, int64_t p, uint64_t seed, uint32_t miss_thr,
+                     const int64_t *__restrict__ miss_ptr, int32_t *__restrict__ miss_row)
+{
+    int64_t j = blockIdx.x;
+    if (j >= p) return;
+    uint32_t key_g, key_m, thr16;
+    synth_col_keys(seed, j, key_g, key_m, thr16);
+    int64_t base = miss_ptr[j];
+    int lane = threadIdx.x;
+    for (int64_t i0 = 0; i0 < n; i0 += 64) {
+        int64_t i = i0 + lane;
+        uint32_t dos; bool miss = false;
+        if (i < n) synth_entry(key_g, key_m, thr16, miss_thr, i, dos, miss);
+        unsigned long long bal = __ballot(miss);
+        if (miss) miss_row[base + __popcll(bal & ((1ull << lane) - 1ull))] = (int32_t)i;
+        base += __popcll(bal);
+    }
+}
+
+// dense synthetic: approx N(0,1) entries (sum of 4 uniforms, variance-normalised)
+__global__ void k_synth_dense(double *__restrict__ D, int64_t total, uint64_t seed)
+{
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    uint32_t s0 = lowbias32((uint32_t)seed ^ 0x3C6EF372u), s1 = lowbias32((uint32_t)(seed >> 32) ^ 0xDAA66D2Bu);
+    for (; i < total; i += stride) {
+        uint32_t a = lowbias32((uint32_t)i ^ s0) ^ lowbias32((uint32_t)(i >> 32) + s1);
+        uint32_t b = lowbias32(a ^ 0x9E3779B9u);
+        double u = ((a & 0xFFFF) + (a >> 16) + (b & 0xFFFF) + (b >> 16)) * (1.0 / 65536.0) - 2.0;
+        D[i] = u * 1.7320508075688772;   // var of sum of 4 U(0,1) = 1/3
+    }
+}
+
+// ---- export back to PLINK codes -----------------------------------------------
+__global__ void k_export(const uint32_t *__restrict__ X, int64_t stride_dw, int64_t p,
+                         uint32_t *__restrict__ out)
+{
+    int64_t total = p * stride_dw;
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        uint32_t d = X[i];
+        uint32_t nz = (d | (d >> 1)) & 0x55555555u;   // dosage != 0
+        uint32_t two = (d >> 1) & 0x55555555u;        // dosage == 2
+        out[i] = (nz << 1) | two;                     // 0->00, 1->10, 2->11
+    }
+}
+
+__global__ void k_export_missing(uint32_t *__restrict__ out, int64_t stride_dw, int64_t p,
+                                 const int64_t *__restrict__ miss_ptr, const int32_t *__restrict__ miss_row)
+{
+    int64_t j = blockIdx.x;
+    if (j >= p) return;
+    for (int64_t t = miss_ptr[j] + threadIdx.x; t < miss_ptr[j + 1]; t += blockDim.x) {
+        int32_t i = miss_row[t];
+        atomicOr(&out[j * stride_dw + (i >> 4)], 1u << (2 * (i & 15)));
+    }
+}
+
+static int finish_missing_ptr(mih_mat *h, const std::vector<int32_t> &cnt, std::vector<int64_t> &ptr)
+{
+    ptr.assign((size_t)h->p + 1, 0);
+    for (int64_t j = 0; j < h->p; ++j) ptr[j + 1] = ptr[j] + cnt[3 * j + 2];
+    h->total_missing = ptr[h->p];
+    MIH_HIP(hipMalloc((void **)&h->miss_ptr, sizeof(int64_t) * (size_t)(h->p + 1)));
+    MIH_HIP(hipMemcpy(h->miss_ptr, ptr.data(), sizeof(int64_t) * (size_t)(h->p + 1), hipMemcpyHostToDevice));
+    MIH_HIP(hipMalloc((void **)&h->miss_row, sizeof(int32_t) * (size_t)(h->total_missing > 0 ? h->total_missing : 1)));
+    return MIH_OK;
+}
+
+static int alloc_snp(mih_mat *h)
+{
+    h->stride_dw = round_up((h->n + 15) / 16, 64);
+    h->n_pad = h->stride_dw * 16;
+    size_t bytes = sizeof(uint32_t) * (size_t)h->p * (size_t)h->stride_dw;
+    hipError_t e = hipMalloc((void **)&h->X, bytes);
+    if (e != hipSuccess) { set_error("hipMalloc of %zu bytes for the genotype matrix failed: %s", bytes, hipGetErrorString(e)); return MIH_OOM; }
+    MIH_HIP(hipMalloc((void **)&h->mu, sizeof(double) * (size_t)h->p));
+    MIH_HIP(hipMalloc((void **)&h->sinv, sizeof(double) * (size_t)h->p));
+    return MIH_OK;
+}
+
+}  // namespace mih
+
+using namespace mih;
+
+extern "C" {
+
+int mih_device_count(int *count)
+{
+    if (!count) { set_error("count is NULL"); return MIH_BAD_ARG; }
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *count = 0; (void)hipGetLastError(); return MIH_OK; }
+    *count = c;
+    return MIH_OK;
+}
+
+int mih_last_error(char *buf, size_t len)
+{
+    if (!buf || len == 0) return MIH_BAD_ARG;
+    snprintf(buf, len, "%s", g_err);
+    return MIH_OK;
+}
+
+int mih_version(int *major, int *minor)
+{
+    if (major) *major = 0;
+    if (minor) *minor = 1;
+    return MIH_OK;
+}
+
+static int select_device(int device)
+{
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess || c == 0) {
+        (void)hipGetLastError();
+        set_error("no HIP device available (the MI355X path has no CPU fallback)");
+        return MIH_NO_DEVICE;
+    }
+    if (device < 0 || device >= c) { set_error("device %d out of range (count %d)", device, c); return MIH_BAD_ARG; }
+    MIH_HIP(hipSetDevice(device));
+    return MIH_OK;
+}
+
+int mih_snp_create(const uint8_t *bed_cols, int64_t n, int64_t p, int64_t col_stride_bytes,
+                   int center, int scale, int impute, int dtype, int device, mih_mat **out)
+{
+    if (!bed_cols || !out) { set_error("null argument"); return MIH_BAD_ARG; }
+    if (n <= 0 || p <= 0 || col_stride_bytes < (n + 3) / 4) { set_error("bad dimensions n=%lld p=%lld stride=%lld", (long long)n, (long long)p, (long long)col_stride_bytes); return MIH_BAD_DIM; }
+    if (n >= (1ll << 31)) { set_error("n must be < 2^31"); return MIH_BAD_DIM; }
+    if (dtype != 64) { set_error("only dtype=64 (Float64) is implemented"); return MIH_BAD_ARG; }
+    MIH_TRY(select_device(device));
+    mih_mat *h = new mih_mat();
+    h->kind = 0; h->device = device; h->n = n; h->p = p;
+    h->center = center; h->scale = scale; h->impute = impute;
+    int rc = alloc_snp(h);
+    if (rc) { mih_mat_destroy(h); return rc; }
+    if (hipStreamCreate(&h->stream) != hipSuccess) { mih_mat_destroy(h); return MIH_HIP_ERROR; }
+
+    // stage raw columns through a bounded device buffer
+    const int64_t chunk_bytes = 256ll << 20;
+    int64_t cols_per_chunk = chunk_bytes / col_stride_bytes;
+    if (cols_per_chunk < 1) cols_per_chunk = 1;
+    if (cols_per_chunk > p) cols_per_chunk = p;
+    DevBuf<uint8_t> raw; DevBuf<int32_t> cnt;
+    if ((rc = raw.alloc((size_t)(cols_per_chunk * col_stride_bytes))) || (rc = cnt.alloc((size_t)(3 * p)))) { mih_mat_destroy(h); return rc; }
+    auto fail = [&](int code) { mih_mat_destroy(h); return code; };
+    for (int64_t c0 = 0; c0 < p; c0 += cols_per_chunk) {
+        int64_t nc = (p - c0 < cols_per_chunk) ? p - c0 : cols_per_chunk;
+        if (hipMemcpy(raw.p, bed_cols + c0 * col_stride_bytes, (size_t)(nc * col_stride_bytes), hipMemcpyHostToDevice) != hipSuccess) return fail(MIH_HIP_ERROR);
+        int grid = (int)(nc < 65535 ? nc : 65535);
+        hipLaunchKernelGGL(k_transcode, dim3(grid), dim3(256), 0, h->stream, raw.p, col_stride_bytes, n, nc, h->X, h->stride_dw, c0, cnt.p);
+        if (hipStreamSynchronize(h->stream) != hipSuccess) { set_error("transcode kernel failed"); return fail(MIH_HIP_ERROR); }
+    }
+    hipLaunchKernelGGL(k_col_stats, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, h->stream, cnt.p, n, p, h->mu, h->sinv);
+    std::vector<int32_t> hcnt((size_t)(3 * p));
+    if (hipMemcpy(hcnt.data(), cnt.p, sizeof(int32_t) * hcnt.size(), hipMemcpyDeviceToHost) != hipSuccess) return fail(MIH_HIP_ERROR);
+    std::vector<int64_t> ptr;
+    if ((rc = finish_missing_ptr(h, hcnt, ptr))) return fail(rc);
+    if (h->total_missing > 0) {
+        for (int64_t c0 = 0; c0 < p; c0 += cols_per_chunk) {
+            int64_t nc = (p - c0 < cols_per_chunk) ? p - c0 : cols_per_chunk;
+            if (hipMemcpy(raw.p, bed_cols + c0 * col_stride_bytes, (size_t)(nc * col_stride_bytes), hipMemcpyHostToDevice) != hipSuccess) return fail(MIH_HIP_ERROR);
+            hipLaunchKernelGGL(k_fill_missing_raw, dim3((unsigned)nc), dim3(64), 0, h->stream, raw.p, col_stride_bytes, n, nc, c0, h->miss_ptr, h->miss_row);
+            if (hipStreamSynchronize(h->stream) != hipSuccess) { set_error("missing-list kernel failed"); return fail(MIH_HIP_ERROR); }
+        }
+    }
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(MIH_HIP_ERROR);
+    *out = h;
+    return MIH_OK;
+}
+
+int mih_snp_create_synthetic(int64_t n, int64_t p, uint64_t seed, double missing_rate,
+                             int center, int scale, int impute, int device, mih_mat **out)
+{
+    if (!out) return MIH_BAD_ARG;
+    if (n <= 0 || p <= 0 || n >= (1ll << 31)) { set_error("bad dimensions"); return MIH_BAD_DIM; }
+    if (!(missing_rate >= 0.0 && missing_rate < 1.0)) { set_error("missing_rate must be in [0,1)"); return MIH_BAD_ARG; }
+    MIH_TRY(select_device(device));
+    mih_mat *h = new mih_mat();
+    h->kind = 0; h->device = device; h->n = n; h->p = p;
+    h->center = center; h->scale = scale; h->impute = impute;
+    int rc = alloc_snp(h);
+    if (rc) { mih_mat_destroy(h); return rc; }
+    auto fail = [&](int code) { mih_mat_destroy(h); return code; };
+    if (hipStreamCreate(&h->stream) != hipSuccess) return fail(MIH_HIP_ERROR);
+    DevBuf<int32_t> cnt;
+    if ((rc = cnt.alloc((size_t)(3 * p)))) return fail(rc);
+    uint32_t miss_thr = (uint32_t)(missing_rate * 4294967296.0);
+    int grid = (int)(p < 16384 ? p : 16384);
+    hipLaunchKernelGGL(k_synth, dim3(grid), dim3(256), 0, h->stream, h->X, h->stride_dw, n, p, seed, miss_thr, cnt.p);
+    hipLaunchKernelGGL(k_col_stats, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, h->stream, cnt.p, n, p, h->mu, h->sinv);
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { set_error("synthetic generator failed: %s", hipGetErrorString(hipGetLastError())); return fail(MIH_HIP_ERROR); }
+    std::vector<int32_t> hcnt((size_t)(3 * p));
+    if (hipMemcpy(hcnt.data(), cnt.p, sizeof(int32_t) * hcnt.size(), hipMemcpyDeviceToHost) != hipSuccess) return fail(MIH_HIP_ERROR);
+    std::vector<int64_t> ptr;
+    if ((rc = finish_missing_ptr(h, hcnt, ptr))) return fail(rc);
+    if (h->total_missing > 0) {
+        hipLaunchKernelGGL(k_fill_missing_synth, dim3((unsigned)p), dim3(64), 0, h->stream, n, p, seed, miss_thr, h->miss_ptr, h->miss_row);
+        if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(MIH_HIP_ERROR);
+    }
+    *out = h;
+    return MIH_OK;
+}
+
+int mih_dense_create(const double *x, int64_t n, int64_t p, int device, mih_mat **out)
+{
+    if (!x || !out) return MIH_BAD_ARG;
+    if (n <= 0 || p <= 0) return MIH_BAD_DIM;
+    MIH_TRY(select_device(device));
+    mih_mat *h = new mih_mat();
+    h->kind = 1; h->device = device; h->n = n; h->p = p; h->center = h->scale = h->impute = 0;
+    auto fail = [&](int code) { mih_mat_destroy(h); return code; };
+    if (hipMalloc((void **)&h->D, sizeof(double) * (size_t)n * (size_t)p) != hipSuccess) { set_error("hipMalloc for dense matrix failed"); (void)hipGetLastError(); return fail(MIH_OOM); }
+    if (hipMemcpy(h->D, x, sizeof(double) * (size_t)n * (size_t)p, hipMemcpyHostToDevice) != hipSuccess) return fail(MIH_HIP_ERROR);
+    if (hipStreamCreate(&h->stream) != hipSuccess) return fail(MIH_HIP_ERROR);
+    *out = h;
+    return MIH_OK;
+}
+
+int mih_dense_create_synthetic(int64_t n, int64_t p, uint64_t seed, int device, mih_mat **out)
+{
+    if (!out) return MIH_BAD_ARG;
+    if (n <= 0 || p <= 0) return MIH_BAD_DIM;
+    MIH_TRY(select_device(device));
+    mih_mat *h = new mih_mat();
+    h->kind = 1; h->device = device; h->n = n; h->p = p; h->center = h->scale = h->impute = 0;
+    auto fail = [&](int code) { mih_mat_destroy(h); return code; };
+    if (hipMalloc((void **)&h->D, sizeof(double) * (size_t)n * (size_t)p) != hipSuccess) { set_error("hipMalloc for dense matrix failed"); (void)hipGetLastError(); return fail(MIH_OOM); }
+    if (hipStreamCreate(&h->stream) != hipSuccess) return fail(MIH_HIP_ERROR);
+    hipLaunchKernelGGL(k_synth_dense, dim3(8192), dim3(256), 0, h->stream, h->D, n * p, seed);
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(MIH_HIP_ERROR);
+    *out = h;
+    return MIH_OK;
+}
+
+int mih_mat_destroy(mih_mat *h)
+{
+    if (!h) return MIH_OK;
+    (void)hipSetDevice(h->device);
+    if (h->X) (void)hipFree(h->X);
+    if (h->mu) (void)hipFree(h->mu);
+    if (h->sinv) (void)hipFree(h->sinv);
+    if (h->miss_ptr) (void)hipFree(h->miss_ptr);
+    if (h->miss_row) (void)hipFree(h->miss_row);
+    if (h->D) (void)hipFree(h->D);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return MIH_OK;
+}
+
+int mih_mat_dims(const mih_mat *h, int64_t *n, int64_t *p)
+{
+    if (!h) return MIH_BAD_ARG;
+    if (n) *n = h->n;
+    if (p) *p = h->p;
+    return MIH_OK;
+}
+
+int mih_snp_mu_sigma(const mih_mat *h, double *mu, double *sinv)
+{
+    if (!h || h->kind != 0) { set_error("not a SnpLinAlg handle"); return MIH_BAD_ARG; }
+    MIH_HIP(hipSetDevice(h->device));
+    if (mu) MIH_HIP(hipMemcpy(mu, h->mu, sizeof(double) * (size_t)h->p, hipMemcpyDeviceToHost));
+    if (sinv) MIH_HIP(hipMemcpy(sinv, h->sinv, sizeof(double) * (size_t)h->p, hipMemcpyDeviceToHost));
+    return MIH_OK;
+}
+
+int mih_snp_export_bed(const mih_mat *h, uint8_t *bed_cols_out)
+{
+    if (!h || h->kind != 0 || !bed_cols_out) return MIH_BAD_ARG;
+    MIH_HIP(hipSetDevice(h->device));
+    DevBuf<uint32_t> tmp;
+    MIH_TRY(tmp.alloc((size_t)h->p * (size_t)h->stride_dw));
+    hipLaunchKernelGGL(k_export, dim3(4096), dim3(256), 0, h->stream, h->X, h->stride_dw, h->p, tmp.p);
+    if (h->total_missing > 0)
+        hipLaunchKernelGGL(k_export_missing, dim3((unsigned)h->p), dim3(64), 0, h->stream, tmp.p, h->stride_dw, h->p, h->miss_ptr, h->miss_row);
+    MIH_HIP(hipStreamSynchronize(h->stream));
+    size_t width = (size_t)((h->n + 3) / 4);
+    MIH_HIP(hipMemcpy2D(bed_cols_out, width, tmp.p, (size_t)h->stride_dw * 4, width, (size_t)h->p, hipMemcpyDeviceToHost));
+    return MIH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,176 @@
+// xv.hip -- out = X[:, S] * v over a small support S (|S| = k << p).
+// Replaces the memory-efficient column loops of update_xb! (src/utilities.jl:98-106)
+// and iht_stepsize! (src/utilities.jl:731-739), which call SnpLinAlg getindex.
+//
+// x[i,j] = (g_ij - mu_j) * sinv_j (missing -> mu_j when impute), so
+//   out_i = sum_t g_{i,S_t} * a_t + sum_t b_t,  a_t = sinv*v_t,  b_t = -mu*sinv*v_t,
+// plus +mu*sinv*v_t on the rows where column S_t is missing (imputed entries are 0
+// after centring).  HBM-bound on k columns of 2-bit data (k*ceil(n/4) bytes).
+#include "common.h"
+
+namespace mih {
+
+__global__ void k_xv_coef(const int64_t *__restrict__ idx, const double *__restrict__ val, int64_t nnz,
+                          const double *__restrict__ mu, const double *__restrict__ sinv,
+                          int center, int scale, double *__restrict__ A, double *__restrict__ B)
+{
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= nnz) return;
+    int64_t j = idx[t];
+    double s = scale ? sinv[j] : 1.0;
+    double a = s * val[t];
+    A[t] = a;
+    B[t] = center ? -mu[j] * a : 0.0;
+}
+
+// grid (row blocks, column groups): thread = one dword = 16 rows; partial[g][i].
+__global__ void __launch_bounds__(256)
+k_xv_snp(const uint32_t *__restrict__ X, int64_t stride_dw, int64_t ndw,
+         const int64_t *__restrict__ idx, const double *__restrict__ A, const double *__restrict__ B,
+         int64_t nnz, int groups, int64_t n_pad, double *__restrict__ partial)
+{
+    int64_t dw = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    int g = blockIdx.y;
+    if (dw >= ndw) return;
+    int64_t per = (nnz + groups - 1) / groups;
+    int64_t t0 = g * per, t1 = t0 + per < nnz ? t0 + per : nnz;
+    double acc[16];
+    #pragma unroll
+    for (int s = 0; s < 16; ++s) acc[s] = 0.0;
+    double bsum = 0.0;
+    for (int64_t t = t0; t < t1; ++t) {
+        uint32_t w = X[idx[t] * stride_dw + dw];
+        double a = A[t];
+        bsum += B[t];
+        #pragma unroll
+        for (int s = 0; s < 16; ++s) acc[s] = fma((double)((w >> (2 * s)) & 3u), a, acc[s]);
+    }
+    double *dst = partial + (int64_t)g * n_pad + dw * 16;
+    #pragma unroll
+    for (int s = 0; s < 16; ++s) dst[s] = acc[s] + bsum;
+}
+
+__global__ void __launch_bounds__(256)
+k_xv_dense(const double *__restrict__ D, int64_t n, const int64_t *__restrict__ idx,
+           const double *__restrict__ val, int64_t nnz, int groups, int64_t n_pad,
+           double *__restrict__ partial)
+{
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    int g = blockIdx.y;
+    if (i >= n) return;
+    int64_t per = (nnz + groups - 1) / groups;
+    int64_t t0 = g * per, t1 = t0 + per < nnz ? t0 + per : nnz;
+    double acc = 0.0;
+    for (int64_t t = t0; t < t1; ++t) acc = fma(D[idx[t] * n + i], val[t], acc);
+    partial[(int64_t)g * n_pad + i] = acc;
+}
+
+__global__ void k_xv_reduce(const double *__restrict__ partial, int groups, int64_t n_pad, int64_t n,
+                            int clamp20, double *__restrict__ out)
+{
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a = 0.0;
+    for (int g = 0; g < groups; ++g) a += partial[(int64_t)g * n_pad + i];
+    if (clamp20) a = a < -20.0 ? -20.0 : (a > 20.0 ? 20.0 : a);
+    out[i] = a;
+}
+
+// Imputed (missing) entries: one workgroup walks the support columns in order, so the
+// additions to any one row happen in a fixed order (bit-reproducible, no atomics).
+__global__ void __launch_bounds__(1024)
+k_xv_missing(const int64_t *__restrict__ idx, const double *__restrict__ A, int64_t nnz,
+             const double *__restrict__ mu,
+             const int64_t *__restrict__ miss_ptr, const int32_t *__restrict__ miss_row,
+             double *__restrict__ out)
+{
+    for (int64_t t = 0; t < nnz; ++t) {
+        int64_t j = idx[t];
+        int64_t a = miss_ptr[j], b = miss_ptr[j + 1];
+        double fix = mu[j] * A[t];   // imputed dosage mu_j instead of the stored 0
+        for (int64_t e = a + threadIdx.x; e < b; e += blockDim.x) out[miss_row[e]] += fix;
+        if (b > a) __syncthreads();
+    }
+}
+
+__global__ void k_clamp20(double *__restrict__ x, int64_t n)
+{
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a = x[i];
+    x[i] = a < -20.0 ? -20.0 : (a > 20.0 ? 20.0 : a);
+}
+
+int xv_work_init(const mih_mat *h, XvWork &w, int64_t max_nnz)
+{
+    w.groups = 16;
+    int64_t np = (h->kind == 0) ? h->n_pad : h->n;
+    MIH_TRY(w.partial.alloc((size_t)w.groups * (size_t)np));
+    if (max_nnz < 64) max_nnz = 64;
+    MIH_TRY(w.coefA.alloc((size_t)max_nnz));
+    MIH_TRY(w.coefB.alloc((size_t)max_nnz));
+    w.cap = max_nnz;
+    return MIH_OK;
+}
+
+int xv_sparse_device(const mih_mat *h, XvWork &w, const int64_t *idx_dev, const double *val_dev,
+                     int64_t nnz, double *out_dev, int clamp20, hipStream_t s)
+{
+    if (nnz == 0) {
+        MIH_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * (size_t)h->n, s));
+        return MIH_OK;
+    }
+    if (nnz > w.cap) {
+        MIH_HIP(hipStreamSynchronize(s));
+        MIH_TRY(w.coefA.alloc((size_t)nnz * 2));
+        MIH_TRY(w.coefB.alloc((size_t)nnz * 2));
+        w.cap = nnz * 2;
+    }
+    int groups = (int)(nnz < w.groups ? nnz : w.groups);
+    int64_t np = (h->kind == 0) ? h->n_pad : h->n;
+    if (h->kind == 0) {
+        hipLaunchKernelGGL(k_xv_coef, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, s, idx_dev, val_dev, nnz,
+                           h->mu, h->sinv, h->center, h->scale, w.coefA.p, w.coefB.p);
+        int64_t ndw = h->stride_dw;
+        hipLaunchKernelGGL(k_xv_snp, dim3((unsigned)((ndw + 255) / 256), groups), dim3(256), 0, s, h->X, h->stride_dw, ndw,
+                           idx_dev, w.coefA.p, w.coefB.p, nnz, groups, np, w.partial.p);
+        bool fix = h->impute && h->total_missing > 0;
+        hipLaunchKernelGGL(k_xv_reduce, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, s, w.partial.p, groups, np, h->n,
+                           fix ? 0 : clamp20, out_dev);
+        if (fix) {
+            hipLaunchKernelGGL(k_xv_missing, dim3(1), dim3(1024), 0, s, idx_dev, w.coefA.p, nnz, h->mu, h->miss_ptr, h->miss_row, out_dev);
+            if (clamp20) hipLaunchKernelGGL(k_clamp20, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, s, out_dev, h->n);
+        }
+    } else {
+        hipLaunchKernelGGL(k_xv_dense, dim3((unsigned)((h->n + 255) / 256), groups), dim3(256), 0, s, h->D, h->n, idx_dev, val_dev,
+                           nnz, groups, np, w.partial.p);
+        hipLaunchKernelGGL(k_xv_reduce, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, s, w.partial.p, groups, np, h->n,
+                           clamp20, out_dev);
+    }
+    MIH_HIP(hipGetLastError());
+    return MIH_OK;
+}
+
+}  // namespace mih
+
+using namespace mih;
+
+extern "C" int mih_xv_sparse(const mih_mat *h, const int64_t *idx, const double *val, int64_t nnz, double *out)
+{
+    if (!h || !out || nnz < 0 || (nnz > 0 && (!idx || !val))) { set_error("null/invalid argument"); return MIH_BAD_ARG; }
+    for (int64_t t = 0; t < nnz; ++t)
+        if (idx[t] < 0 || idx[t] >= h->p) { set_error("column index %lld out of range", (long long)idx[t]); return MIH_BAD_DIM; }
+    MIH_HIP(hipSetDevice(h->device));
+    XvWork w;
+    MIH_TRY(xv_work_init(h, w, nnz));
+    DevBuf<int64_t> di; DevBuf<double> dv, dout;
+    MIH_TRY(di.alloc((size_t)nnz)); MIH_TRY(dv.alloc((size_t)nnz)); MIH_TRY(dout.alloc((size_t)h->n));
+    if (nnz) {
+        MIH_HIP(hipMemcpyAsync(di.p, idx, sizeof(int64_t) * (size_t)nnz, hipMemcpyHostToDevice, h->stream));
+        MIH_HIP(hipMemcpyAsync(dv.p, val, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, h->stream));
+    }
+    MIH_TRY(xv_sparse_device(h, w, di.p, dv.p, nnz, dout.p, 0, h->stream));
+    MIH_HIP(hipMemcpyAsync(out, dout.p, sizeof(double) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+    MIH_HIP(hipStreamSynchronize(h->stream));
+    return MIH_OK;
+}

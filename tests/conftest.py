@@ -1,0 +1,67 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FIX = os.path.join(ROOT, "tests", "fixtures")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as O
+    O.lib()
+    return O
+
+
+@pytest.fixture(scope="session")
+def mih():
+    import mendeliht_amd
+    return mendeliht_amd
+
+
+@pytest.fixture(scope="session")
+def normal_data():
+    """The reference's shipped example: data/normal.bed + fam column 6 + covariates.txt."""
+    n = 1000
+    y = np.loadtxt(os.path.join(FIX, "normal_y_fam6.txt"))
+    z = np.loadtxt(os.path.join(FIX, "covariates.txt"), delimiter=",")
+    mu = z[:, 1:].mean(axis=0)
+    sd = np.sqrt(((z[:, 1:] - mu) ** 2).sum(axis=0) / (n - 1))
+    z[:, 1:] = (z[:, 1:] - mu) / sd          # standardize! (utilities.jl:494-530), wrapper.jl:245
+    return dict(n=n, bed=os.path.join(FIX, "normal.bed"), y=y, z=z,
+                y2=np.loadtxt(os.path.join(FIX, "phenotypes.txt")))
+
+
+def make_bed(rng, n, p, missing_rate=0.0, maf_lo=0.02, maf_hi=0.5):
+    """Random PLINK columns with the reference simulator's distributions
+    (simulate_utilities.jl:33-47: maf ~ U, g ~ Binomial(2, maf); codes :88-99)."""
+    maf = rng.uniform(maf_lo, maf_hi, size=p)
+    g = rng.binomial(2, maf[:, None], size=(p, n))
+    code = np.array([0, 2, 3], dtype=np.uint8)[g]
+    if missing_rate > 0:
+        code[rng.random((p, n)) < missing_rate] = 1
+    stride = (n + 3) // 4
+    padded = np.zeros((p, stride * 4), dtype=np.uint8)
+    padded[:, :n] = code
+    cols = (padded[:, 0::4] | (padded[:, 1::4] << 2) | (padded[:, 2::4] << 4) | (padded[:, 3::4] << 6)).astype(np.uint8)
+    return cols
+
+
+def hash_folds(n, q, seed=2026):
+    """folds_i = 1 + (hash(seed, i) mod q): explicit, RNG-free folds."""
+    i = np.arange(n, dtype=np.uint64)
+    x = (i + np.uint64(seed)) * np.uint64(0x9E3779B97F4A7C15)
+    x ^= x >> np.uint64(31)
+    x *= np.uint64(0xBF58476D1CE4E5B9)
+    x ^= x >> np.uint64(29)
+    return (1 + (x % np.uint64(q))).astype(np.int32)
