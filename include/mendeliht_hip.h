@@ -169,7 +169,25 @@ int mih_cv_mv(const mih_mat *h, const mih_fit_params *prm, const double *Y, int6
               const double *Z, int64_t q, const int32_t *folds, int32_t nfolds,
               const int64_t *path, int64_t npath, int32_t rank, int32_t world, double *mses_raw);
 
+/* ---- stepping session: one IHTVariable kept alive across calls ---------------- */
+/* `initialize(...)` (src/data_structures.jl:117-135) + repeated `iht_one_step!`
+ * (src/fit.jl:213-263) under the caller's control; used by bench.py to time exactly K
+ * iterations and by callers that want their own convergence logic. */
+typedef struct mih_session mih_session;
+int mih_session_create(const mih_mat *h, const mih_fit_params *prm, const double *y,
+                       const double *z, int64_t q, const uint8_t *train, mih_session **out);
+/* save_prev! + iht_one_step! + check_convergence (fit.jl:182-193) */
+int mih_session_step(mih_session *s, double *logl, int32_t *backtracks, double *tol);
+/* current model (v.b, v.c), not the best-so-far copy */
+int mih_session_model(mih_session *s, double *beta, double *c);
+int mih_session_destroy(mih_session *s);
+
 /* ---- measurement hooks (bench.py; no reference counterpart) ----------------- */
+/* When enabled, every launch of the dominant X'r kernel is bracketed by HIP events on
+ * the stream it is launched on; mih_profile_read synchronises and returns the totals
+ * since the last reset. */
+int mih_profile_enable(int on);
+int mih_profile_read(double *xtv_kernel_ms, int64_t *xtv_launches, int reset);
 /* Runs `iters` X'r passes back to back on the handle's stream with r resident
  * in HBM, bracketed by HIP events; *ms_per_pass = average kernel-chain time. */
 int mih_bench_xtv(const mih_mat *h, int variant, int iters, int warmup, uint64_t seed,

@@ -12,7 +12,8 @@ is missing.
 from .api import (  # noqa: F401
     Bernoulli, IdentityLink, IHTResult, LogitLink, LogLink, MendelIHTError, MvNormal, NegativeBinomial,
     Normal, Poisson, SnpLinAlg, DenseMatrix, cross_validate, cv_iht, device_count, fit_iht, iht,
-    library_path, mIHTResult, project_group_sparse, project_k, read_bed, standardize, lib,
+    library_path, mIHTResult, project_group_sparse, project_k, read_bed, standardize, lib, IHTSession,
+    profile_enable, profile_read,
 )
 from . import dist  # noqa: F401
 

@@ -102,6 +102,12 @@ def lib():
         "mih_bench_xtv": [vp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_float), C.POINTER(dbl)],
         "mih_xtv_algorithmic_bytes": [vp, C.c_int, C.POINTER(dbl)],
         "mih_set_xtv_variant": [C.c_int],
+        "mih_session_create": [vp, C.POINTER(_FitParams), vp, vp, i64, vp, C.POINTER(vp)],
+        "mih_session_step": [vp, C.POINTER(dbl), C.POINTER(i32), C.POINTER(dbl)],
+        "mih_session_model": [vp, vp, vp],
+        "mih_session_destroy": [vp],
+        "mih_profile_enable": [C.c_int],
+        "mih_profile_read": [C.POINTER(dbl), C.POINTER(i64), C.c_int],
     }
     for name, args in sig.items():
         f = getattr(L, name)
@@ -117,7 +123,9 @@ def exported_symbols():
             "mih_dense_create", "mih_dense_create_synthetic", "mih_mat_destroy", "mih_mat_dims",
             "mih_snp_mu_sigma", "mih_snp_export_bed", "mih_xtv", "mih_xtv_batched", "mih_xv_sparse",
             "mih_project_topk", "mih_project_group_sparse", "mih_fit_iht", "mih_cv_iht", "mih_cv_meanloss",
-            "mih_fit_mv", "mih_cv_mv", "mih_bench_xtv", "mih_xtv_algorithmic_bytes", "mih_set_xtv_variant"]
+            "mih_fit_mv", "mih_cv_mv", "mih_bench_xtv", "mih_xtv_algorithmic_bytes", "mih_set_xtv_variant",
+            "mih_session_create", "mih_session_step", "mih_session_model", "mih_session_destroy",
+            "mih_profile_enable", "mih_profile_read"]
 
 
 def _check(rc):
@@ -410,6 +418,58 @@ class mIHTResult:
         self.Sigma, self.sigma_g = Sigma, sigma_g
         self.trace = trace or {}
         self.choose_fired = choose_fired
+
+
+class IHTSession:
+    """An IHTVariable kept alive on the GPU: `initialize` once, then `step()` = one iht_one_step!."""
+
+    def __init__(self, y, x, z=None, *, k=10, J=1, d=None, l=None, zkeep=None, weight=None, max_step=3, train=None):
+        x = _as_mat(x)
+        d = _inst(d) if d is not None else Normal()
+        l = _inst(l) if l is not None else IdentityLink()
+        self.x = x
+        y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).ravel())
+        z = np.ones((x.n, 1)) if z is None else np.asarray(z, dtype=np.float64)
+        z = np.asfortranarray(z.reshape(z.shape[0], -1))
+        if not (y.size == x.n == z.shape[0]):
+            raise DimensionMismatch(f"row dimension of y, x, and z ({y.size}, {x.n}, {z.shape[0]}) are not equal")
+        self.q = z.shape[1]
+        self._keep = [y, z]
+        prm = _params(k, J, d, l, 1e-4, 1 << 30, 5, max_step, "None", zkeep, weight, None, self.q, x.p, self._keep)
+        tr = None if train is None else np.ascontiguousarray(train, dtype=np.uint8)
+        self._h = C.c_void_p(None)
+        _check(lib().mih_session_create(x._h, C.byref(prm), _p(y), _p(z), self.q, _p(tr), C.byref(self._h)))
+
+    def step(self):
+        logl, bt, tol = C.c_double(0), C.c_int32(0), C.c_double(0)
+        _check(lib().mih_session_step(self._h, C.byref(logl), C.byref(bt), C.byref(tol)))
+        return logl.value, bt.value, tol.value
+
+    def model(self):
+        beta, c = np.zeros(self.x.p), np.zeros(self.q)
+        _check(lib().mih_session_model(self._h, _p(beta), _p(c)))
+        return beta, c
+
+    def close(self):
+        if self._h:
+            lib().mih_session_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def profile_enable(on=True):
+    _check(lib().mih_profile_enable(int(on)))
+
+
+def profile_read(reset=True):
+    ms, n = C.c_double(0), C.c_int64(0)
+    _check(lib().mih_profile_read(C.byref(ms), C.byref(n), int(reset)))
+    return ms.value, n.value
 
 
 def _is_multivariate(y):

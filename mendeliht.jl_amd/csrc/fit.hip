@@ -718,6 +718,60 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, con
     return MIH_OK;
 }
 
+struct mih_session_impl {
+    IhtVar v;
+    mih_fit_params prm;
+    double next_logl, best;
+};
+
+int mih_session_create(const mih_mat *h, const mih_fit_params *prm, const double *y, const double *z,
+                       int64_t q, const uint8_t *train, mih_session **out)
+{
+    MIH_TRY(check_params(h, prm, q));
+    if (!y || !z || !out) { set_error("null argument"); return MIH_BAD_ARG; }
+    MIH_HIP(hipSetDevice(h->device));
+    mih_session_impl *s = new mih_session_impl();
+    s->prm = *prm;
+    s->next_logl = s->best = -std::numeric_limits<double>::infinity();
+    int rc = s->v.create(h, prm, y, z, q);
+    if (!rc) rc = s->v.init(train);
+    if (rc) { delete s; return rc; }
+    *out = reinterpret_cast<mih_session *>(s);
+    return MIH_OK;
+}
+
+int mih_session_step(mih_session *ss, double *logl, int32_t *backtracks, double *tol)
+{
+    if (!ss) return MIH_BAD_ARG;
+    mih_session_impl *s = reinterpret_cast<mih_session_impl *>(ss);
+    MIH_HIP(hipSetDevice(s->v.h->device));
+    s->best = s->v.save_prev(s->next_logl, s->best);
+    int nbt = 0;
+    MIH_TRY(s->v.one_step(s->next_logl, s->prm.max_step, &nbt, &s->next_logl));
+    if (logl) *logl = s->next_logl;
+    if (backtracks) *backtracks = nbt;
+    if (tol) *tol = s->v.check_convergence();
+    return MIH_OK;
+}
+
+int mih_session_model(mih_session *ss, double *beta, double *c)
+{
+    if (!ss) return MIH_BAD_ARG;
+    mih_session_impl *s = reinterpret_cast<mih_session_impl *>(ss);
+    if (beta) {
+        std::memset(beta, 0, sizeof(double) * s->v.p);
+        for (size_t t = 0; t < s->v.b.idx.size(); ++t) beta[s->v.b.idx[t]] = s->v.b.val[t];
+    }
+    if (c) for (int l = 0; l < s->v.q; ++l) c[l] = s->v.c[l];
+    return MIH_OK;
+}
+
+int mih_session_destroy(mih_session *ss)
+{
+    delete reinterpret_cast<mih_session_impl *>(ss);
+    return MIH_OK;
+}
+
 int mih_cv_meanloss(const double *mses_raw, const int32_t *folds, int64_t n, int32_t nfolds,
                     int64_t npath, double *mse_out)
 {

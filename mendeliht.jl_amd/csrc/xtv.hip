@@ -16,10 +16,34 @@
 // (slice = blockIdx % splits, so one XCD keeps re-reading one slice of r from
 // its own L2); partials are combined in fixed order => bit-reproducible.
 #include "common.h"
+#include <mutex>
+#include <utility>
 
 namespace mih {
 
 int g_xtv_variant = -1;   // -1: built-in default
+
+// ---- optional per-launch HIP-event timing of the dominant kernel (bench.py roofline) ----
+static bool g_profile = false;
+static std::mutex g_prof_mu;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
+static double g_prof_ms = 0.0;
+static int64_t g_prof_launches = 0;
+
+static void prof_begin(hipStream_t s, hipEvent_t &e0, hipEvent_t &e1)
+{
+    e0 = e1 = nullptr;
+    if (!g_profile) return;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }
+    (void)hipEventRecord(e0, s);
+}
+static void prof_end(hipStream_t s, hipEvent_t e0, hipEvent_t e1)
+{
+    if (!e0) return;
+    (void)hipEventRecord(e1, s);
+    std::lock_guard<std::mutex> g(g_prof_mu);
+    g_prof_events.emplace_back(e0, e1);
+}
 
 __global__ void k_permute_r(const double *__restrict__ r, int64_t n, int64_t n_perm, int m,
                             double *__restrict__ rperm)
@@ -322,7 +346,11 @@ int xtv_device_preperm(const mih_mat *h, XtvWork &w, const double *r_dev, int m,
     hipLaunchKernelGGL(k_slice_sums, dim3((unsigned)(splits * m)), dim3(256), 0, s, w.rperm.p, w.n_perm, nchunks, splits, w.sums.p);
     for (int t = 0; t < m; ++t) {
         double *partial = w.partial.p + (int64_t)t * splits * h->p;
-        MIH_TRY(dispatch_xtv(v, h, w.rperm.p + (int64_t)t * w.n_perm, nchunks, splits, partial, s));
+        hipEvent_t e0, e1;
+        prof_begin(s, e0, e1);
+        int rc = dispatch_xtv(v, h, w.rperm.p + (int64_t)t * w.n_perm, nchunks, splits, partial, s);
+        prof_end(s, e0, e1);
+        if (rc) return rc;
         hipLaunchKernelGGL(k_xtv_finalize, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, s, partial,
                            w.sums.p + (int64_t)t * splits, splits, A, B, h->p, r_dev + (int64_t)t * h->n, h->mu, h->sinv,
                            h->miss_ptr, h->miss_row, h->center, h->scale, h->impute, out_dev + (int64_t)t * h->p);
@@ -336,6 +364,29 @@ int xtv_device_preperm(const mih_mat *h, XtvWork &w, const double *r_dev, int m,
 using namespace mih;
 
 extern "C" {
+
+int mih_profile_enable(int on)
+{
+    g_profile = on != 0;
+    return MIH_OK;
+}
+
+int mih_profile_read(double *xtv_kernel_ms, int64_t *xtv_launches, int reset)
+{
+    std::lock_guard<std::mutex> g(g_prof_mu);
+    for (auto &pr : g_prof_events) {
+        float ms = 0.f;
+        if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+            g_prof_ms += ms; g_prof_launches++;
+        }
+        (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
+    }
+    g_prof_events.clear();
+    if (xtv_kernel_ms) *xtv_kernel_ms = g_prof_ms;
+    if (xtv_launches) *xtv_launches = g_prof_launches;
+    if (reset) { g_prof_ms = 0.0; g_prof_launches = 0; }
+    return MIH_OK;
+}
 
 int mih_set_xtv_variant(int variant)
 {

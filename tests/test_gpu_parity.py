@@ -1,0 +1,316 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the golden vectors.
+
+Tolerances (BASELINE.json north_star): support indices bit-exact at fixed k; beta within 1e-5
+relative for Gaussian, 1e-4 for GLM links.  Kernel-level results are held to 1e-11.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import FIX, GOLD, hash_folds, make_bed
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / (np.max(np.abs(b)) + 1e-300))
+
+
+@pytest.fixture(scope="module")
+def normal_pair(mih, oracle, normal_data):
+    bed = mih.read_bed(normal_data["bed"], normal_data["n"])
+    x = mih.SnpLinAlg(bed, normal_data["n"], center=True, scale=True, impute=True)
+    return x, oracle.Mat.from_bed_columns(bed, normal_data["n"])
+
+
+def test_device_present_and_native_library_loaded(mih):
+    assert mih.device_count() >= 1
+    assert os.path.exists(mih.library_path())
+
+
+def test_mu_sinv_and_xtv_all_variants(mih, normal_pair):
+    x, ox = normal_pair
+    mu, s = x.mu_sigma()
+    omu, os_ = ox.mu_sinv()
+    assert np.array_equal(mu, omu) and np.array_equal(s, os_)
+    r = np.random.default_rng(0).standard_normal(x.n)
+    ref = ox.xtv(r)
+    nv = 0
+    while mih.lib().mih_set_xtv_variant(nv) == 0:
+        assert rel(x.xtv(r), ref) < 1e-11, nv
+        nv += 1
+    assert nv >= 3
+    mih.lib().mih_set_xtv_variant(-1)
+    assert rel(x.xtv(r), ref) < 1e-11
+
+
+@pytest.mark.parametrize("n,p,miss", [(1003, 257, 0.02), (77, 33, 0.1), (5000, 100, 0.0), (2049, 64, 0.05),
+                                      (16, 5, 0.0), (1, 3, 0.0), (4097, 9, 0.3)])
+@pytest.mark.parametrize("flags", [(1, 1, 1), (1, 1, 0), (0, 0, 1), (1, 0, 1)])
+def test_ragged_missing_flags(mih, oracle, n, p, miss, flags):
+    """n not divisible by 4/16/64/1024, missing genotypes, monomorphic columns, every flag combination."""
+    rng = np.random.default_rng(n * 31 + p)
+    cols = make_bed(rng, n, p, miss)
+    cols[0, :] = 0                                     # all-zero column: sinv = 1
+    c, s, i = flags
+    x = mih.SnpLinAlg(cols, n, center=c, scale=s, impute=i)
+    ox = oracle.Mat.from_bed_columns(cols, n, center=c, scale=s, impute=i)
+    mu, sv = x.mu_sigma()
+    omu, osv = ox.mu_sinv()
+    np.testing.assert_allclose(mu, omu, rtol=1e-15)
+    np.testing.assert_allclose(sv, osv, rtol=1e-15)
+    r = rng.standard_normal(n)
+    assert rel(x.xtv(r), ox.xtv(r)) < 1e-11
+    idx = np.sort(rng.choice(p, size=min(4, p), replace=False))
+    val = rng.standard_normal(idx.size)
+    mask = np.zeros(p, np.uint8)
+    mask[idx] = 1
+    coef = np.zeros(p)
+    coef[idx] = val
+    assert rel(x.xv_sparse(idx, val), ox.xv_masked(mask, coef)) < 1e-11
+    assert np.array_equal(x.export_bed(), cols)        # encode -> device layout -> decode round trip
+
+
+def test_xtv_batched_and_empty_support(mih, oracle, normal_pair):
+    x, ox = normal_pair
+    R = np.random.default_rng(1).standard_normal((x.n, 3))
+    assert rel(x.xtv(R), ox.xtv_multi(R)) < 1e-11
+    assert np.all(x.xv_sparse(np.zeros(0, np.int64), np.zeros(0)) == 0.0)
+    with pytest.raises(mih.MendelIHTError):
+        x.xv_sparse(np.array([x.p]), np.array([1.0]))
+
+
+def test_synthetic_matrix_matches_oracle_after_export(mih, oracle):
+    for miss in (0.0, 0.03):
+        x = mih.SnpLinAlg.synthetic(3001, 130, seed=11, missing_rate=miss)
+        cols = x.export_bed()
+        ox = oracle.Mat.from_bed_columns(cols, 3001)
+        mu, _ = x.mu_sigma()
+        assert np.all((mu > 0) & (mu < 1.2))
+        r = np.random.default_rng(2).standard_normal(3001)
+        assert rel(x.xtv(r), ox.xtv(r)) < 1e-11
+        x2 = mih.SnpLinAlg.synthetic(3001, 40, seed=11, missing_rate=miss)   # same seed: same leading columns
+        assert np.array_equal(x2.export_bed(), cols[:40])
+
+
+def test_project_k_device(mih, oracle):
+    """project_k! (utilities.jl:553-559) incl. the reference's top-k property test (utilities_test.jl:166-176)."""
+    rng = np.random.default_rng(3)
+    x = rng.random(100000)
+    out = mih.project_k(x, 100)
+    assert np.array_equal(out, oracle.project_k(x, 100))
+    assert np.count_nonzero(out) == 100
+    v = rng.standard_normal(1000003)
+    for k in (1, 7, 200, 5000, v.size):
+        assert np.array_equal(mih.project_k(v, k), oracle.project_k(v, k)), k
+    t = np.array([1.0, -2.0, 2.0, 0.5, np.inf, -0.0])
+    assert np.array_equal(mih.project_k(t, 2), oracle.project_k(t, 2))     # tie at the threshold kept; Inf survives
+    assert list(mih.project_k(np.array([1.0, -2.0, 2.0, 0.5]), 1)) == [0.0, -2.0, 2.0, 0.0]
+    with pytest.raises(mih.MendelIHTError):
+        mih.project_k(t, -1)
+    with pytest.raises(mih.MendelIHTError):
+        mih.project_k(t, 0)
+
+
+def test_g1_golden_log_on_gpu(mih, normal_pair, normal_data):
+    """The reference's recorded run (docs/src/man/examples.md:230-267) reproduced by the HIP path."""
+    g = json.load(open(os.path.join(GOLD, "golden_normal_k7.json")))
+    x, _ = normal_pair
+    res = mih.fit_iht(normal_data["y"], x, normal_data["z"], k=7, verbose=False)
+    assert res.iter == g["iterations"]
+    np.testing.assert_allclose(res.trace["logl"], g["logl"], rtol=1e-11)
+    np.testing.assert_allclose(res.trace["tol"], g["tol"], rtol=1e-8)
+    assert list(res.trace["backtracks"]) == g["backtracks"]
+    nz = np.flatnonzero(res.beta)
+    assert list(nz + 1) == g["positions_1based"]
+    np.testing.assert_allclose(res.beta[nz], g["beta_printed"], rtol=5e-6)
+    np.testing.assert_allclose(res.c, g["c_printed"], rtol=5e-6)
+    assert res.σg == pytest.approx(g["pve"], rel=1e-9)
+    assert res.trace["lines"][0].startswith("Iteration 1: loglikelihood = -1403.60851544")
+
+
+def _sim(oracle, ox, rng, k, scale=0.5):
+    p = ox.p
+    b = np.zeros(p)
+    supp = rng.choice(p, k, replace=False)
+    b[supp] = rng.standard_normal(k) * scale
+    mask = np.zeros(p, np.uint8)
+    mask[supp] = 1
+    return ox.xv_masked(mask, b)
+
+
+@pytest.mark.parametrize("family", ["normal", "bernoulli", "poisson", "negbin"])
+def test_fit_iht_families_vs_oracle(mih, oracle, normal_pair, family):
+    x, ox = normal_pair
+    rng = np.random.default_rng(10)
+    eta = _sim(oracle, ox, rng, 8)
+    n = x.n
+    if family == "normal":
+        y, d, l, od, ol, tol = eta + 1 + rng.standard_normal(n), mih.Normal(), mih.IdentityLink(), "normal", "identity", 1e-5
+    elif family == "bernoulli":
+        y, d, l, od, ol, tol = (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float), mih.Bernoulli(), mih.LogitLink(), "bernoulli", "logit", 1e-4
+    elif family == "poisson":
+        y, d, l, od, ol, tol = rng.poisson(np.exp(0.3 * eta)).astype(float), mih.Poisson(), mih.LogLink(), "poisson", "log", 1e-4
+    else:
+        mu = np.exp(0.3 * eta)
+        y, d, l, od, ol, tol = rng.negative_binomial(10, 10 / (mu + 10)).astype(float), mih.NegativeBinomial(10.0), mih.LogLink(), "negbin", "log", 1e-4
+    res = mih.fit_iht(y, x, None, k=8, d=d, l=l, verbose=False)
+    o = oracle.fit_iht(ox, y, None, k=8, dist=od, link=ol, nb_r=10.0)
+    assert res.iter == o["iter"]
+    assert np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"]))      # bit-exact support
+    nz = np.flatnonzero(o["beta"])
+    np.testing.assert_allclose(res.beta[nz], o["beta"][nz], rtol=tol)
+    np.testing.assert_allclose(res.c, o["c"], rtol=tol)
+    assert res.logl == pytest.approx(o["logl"], rel=1e-9)
+    assert list(res.trace["backtracks"]) == list(o["bt_trace"])
+    np.testing.assert_allclose(res.mu, o["mu"], rtol=1e-6, atol=1e-9)
+    assert res.σg == pytest.approx(o["pve"], rel=1e-6)
+    assert np.count_nonzero(res.beta) == 8 and res.c[0] != 0                        # L0_reg_test.jl:21-24
+
+
+def test_fit_iht_zkeep_weights_train_mask(mih, oracle):
+    rng = np.random.default_rng(12)
+    n, p = 700, 500
+    cols = make_bed(rng, n, p, 0.01)
+    x = mih.SnpLinAlg(cols, n, center=True, scale=True, impute=True)
+    ox = oracle.Mat.from_bed_columns(cols, n)
+    z = np.column_stack([np.ones(n), rng.standard_normal(n), rng.standard_normal(n)])
+    y = _sim(oracle, ox, rng, 5, 0.6) + z @ np.array([1.0, 1.2, 0.0]) + rng.standard_normal(n)
+    w = rng.uniform(1.0, 2.0, p)
+    train = (rng.random(n) < 0.8).astype(np.uint8)
+    for kw, okw in [(dict(zkeep=[1, 0, 0]), dict(zkeep=[1, 0, 0])),
+                    (dict(weight=w), dict(weight=w)),
+                    (dict(train=train), dict(train=train)),
+                    (dict(zkeep=[1, 1, 0], weight=w, train=train), dict(zkeep=[1, 1, 0], weight=w, train=train))]:
+        res = mih.fit_iht(y, x, z, k=6, verbose=False, **kw)
+        o = oracle.fit_iht(ox, y, z, k=6, **okw)
+        assert res.iter == o["iter"], kw.keys()
+        assert np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"]))
+        np.testing.assert_allclose(res.beta, o["beta"], rtol=1e-5, atol=1e-12)
+        np.testing.assert_allclose(res.c, o["c"], rtol=1e-5, atol=1e-12)
+        assert res.logl == pytest.approx(o["logl"], rel=1e-9)
+
+
+def test_fit_iht_dense_matrix(mih, oracle):
+    """The reference's Matrix{Float64} design matrix (test/L0_reg_test.jl dense cases)."""
+    rng = np.random.default_rng(13)
+    n, p, k = 500, 1200, 7
+    X = rng.standard_normal((n, p))
+    b = np.zeros(p)
+    b[rng.choice(p, k, replace=False)] = rng.standard_normal(k)
+    y = X @ b + 0.5 + rng.standard_normal(n)
+    xd = mih.DenseMatrix(X)
+    od = oracle.Mat.from_dense(X)
+    r = rng.standard_normal(n)
+    assert rel(xd.xtv(r), X.T @ r) < 1e-12
+    res = mih.fit_iht(y, xd, None, k=k, verbose=False)
+    o = oracle.fit_iht(od, y, None, k=k)
+    assert res.iter == o["iter"]
+    assert np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"]))
+    np.testing.assert_allclose(res.beta, o["beta"], rtol=1e-5, atol=1e-12)
+    yb = (rng.random(n) < 1 / (1 + np.exp(-(X @ b)))).astype(float)
+    res = mih.fit_iht(yb, xd, None, k=k, d=mih.Bernoulli(), l=mih.LogitLink(), verbose=False)
+    o = oracle.fit_iht(od, yb, None, k=k, dist="bernoulli", link="logit")
+    assert np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"]))
+    np.testing.assert_allclose(res.beta, o["beta"], rtol=1e-4, atol=1e-12)
+
+
+def test_max_iter_semantics_and_errors(mih, normal_pair, normal_data):
+    x, _ = normal_pair
+    res = mih.fit_iht(normal_data["y"], x, normal_data["z"], k=7, max_iter=3, verbose=False)
+    assert res.iter == 3 and len(res.trace["logl"]) == 2            # fit.jl:170: max_iter=N takes N-1 steps
+    with pytest.raises(mih.MendelIHTError):
+        mih.fit_iht(normal_data["y"][:-1], x, None, k=7, verbose=False)         # DimensionMismatch
+    xs = mih.SnpLinAlg(np.zeros((4, 3), dtype=np.uint8), n=10, center=False, scale=True)
+    with pytest.raises(mih.MendelIHTError):
+        mih.fit_iht(np.zeros(10), xs, None, k=1, verbose=False)                 # "x is not centered!"
+    with pytest.raises(mih.MendelIHTError):
+        mih.cv_iht(normal_data["y"], x, None, path=[x.p + 1], q=3, folds=hash_folds(x.n, 3), verbose=False)
+
+
+def test_session_steps_equal_fit_trace(mih, normal_pair, normal_data):
+    x, _ = normal_pair
+    res = mih.fit_iht(normal_data["y"], x, normal_data["z"], k=7, verbose=False)
+    s = mih.IHTSession(normal_data["y"], x, normal_data["z"], k=7)
+    for i in range(res.iter):
+        logl, bt, tol = s.step()
+        assert logl == res.trace["logl"][i] and bt == res.trace["backtracks"][i] and tol == res.trace["tol"][i]
+    s.close()
+
+
+@pytest.mark.parametrize("family", ["normal", "bernoulli"])
+def test_cv_iht_vs_oracle_and_sharding(mih, oracle, normal_pair, normal_data, family):
+    x, ox = normal_pair
+    n = x.n
+    folds = hash_folds(n, 3)
+    if family == "normal":
+        y, z, kw, okw, tol = normal_data["y"], normal_data["z"], {}, {}, 1e-5
+    else:
+        rng = np.random.default_rng(20)
+        eta = _sim(oracle, ox, rng, 6, 0.7)
+        y, z = (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float), None
+        kw, okw, tol = dict(d=mih.Bernoulli(), l=mih.LogitLink()), dict(dist="bernoulli", link="logit"), 1e-4
+    path = list(range(0, 7))
+    mse, raw = mih.cv_iht(y, x, z, path=path, q=3, folds=folds, verbose=False, return_raw=True, **kw)
+    omse, oraw = oracle.cv_iht(ox, y, z, path=path, q=3, folds=folds, **okw)
+    np.testing.assert_allclose(raw, oraw, rtol=tol)
+    np.testing.assert_allclose(mse, omse, rtol=tol)
+    assert np.all(mse > 0)                                         # test/cv_iht_test.jl:29-34
+    assert int(np.argmin(mse)) == int(np.argmin(omse))
+    # the (fold,k) combinations sharded over 2 ranks sum to the unsharded result (one gather)
+    parts = [mih.cv_iht(y, x, z, path=path, q=3, folds=folds, verbose=False, return_raw=True, rank=r, world=2, **kw)[1]
+             for r in range(2)]
+    assert np.array_equal(parts[0] + parts[1], raw)
+    assert np.count_nonzero(parts[0]) + np.count_nonzero(parts[1]) == raw.size
+
+
+def test_file_level_wrappers(mih, tmp_path, normal_data):
+    """iht(...) / cross_validate(...) on a PLINK trio (src/wrapper.jl:52-120, 301-349)."""
+    import shutil
+    prefix = str(tmp_path / "normal")
+    shutil.copy(normal_data["bed"], prefix + ".bed")
+    with open(prefix + ".fam", "w") as f:
+        for i, v in enumerate(normal_data["y"]):
+            f.write(f"{i + 1}\t1\t0\t0\t1\t{v!r}\n")
+    g = json.load(open(os.path.join(GOLD, "golden_normal_k7.json")))
+    res = mih.iht(prefix, 7, mih.Normal, covariates=os.path.join(FIX, "covariates.txt"), phenotypes=6,
+                  summaryfile=str(tmp_path / "s.txt"), betafile=str(tmp_path / "b.txt"), verbose=False)
+    assert list(np.flatnonzero(res.beta) + 1) == g["positions_1based"]
+    assert res.logl == pytest.approx(g["final_logl"], rel=1e-11)
+    assert np.count_nonzero(np.loadtxt(tmp_path / "b.txt")) == 7
+    mse = mih.cross_validate(prefix, mih.Normal, path=range(5, 9), q=3, folds=hash_folds(1000, 3),
+                             covariates=os.path.join(FIX, "covariates.txt"), cv_summaryfile=str(tmp_path / "cv.txt"),
+                             verbose=False)
+    assert mse.shape == (4,) and np.all(mse > 0)
+
+
+def test_full_size_properties_n500k(mih, oracle):
+    """BASELINE configs[2] geometry (n = 500 000): properties that need no full-size oracle.
+    Column count is cut to 16 384 (2 GB of 2-bit data) so the test stays in seconds; the leading columns are
+    bit-identical to the p = 1M benchmark matrix (per-column RNG keys)."""
+    n, p = 500_000, 16_384
+    x = mih.SnpLinAlg.synthetic(n, p, seed=2024)
+    rng = np.random.default_rng(5)
+    r1, r2 = rng.standard_normal(n), rng.standard_normal(n)
+    a, b = 0.75, -1.5
+    o1, o2, o12 = x.xtv(r1), x.xtv(r2), x.xtv(a * r1 + b * r2)
+    assert rel(o12, a * o1 + b * o2) < 1e-10                       # linearity
+    assert np.array_equal(x.xtv(r1), o1)                           # run-to-run bit reproducibility
+    assert np.max(np.abs(x.xtv(np.ones(n)))) < 1e-6                # centred columns: X'1 = 0
+    xs = mih.SnpLinAlg.synthetic(n, 64, seed=2024)                 # oracle on a column sample
+    ox = oracle.Mat.from_bed_columns(xs.export_bed(), n)
+    assert rel(o1[:64], ox.xtv(r1)) < 1e-10
+    nv = 0
+    while mih.lib().mih_set_xtv_variant(nv) == 0:                  # every kernel variant, full row count
+        assert rel(x.xtv(r1)[:64], ox.xtv(r1)) < 1e-10, nv
+        nv += 1
+    mih.lib().mih_set_xtv_variant(-1)
+    idx = np.sort(rng.choice(64, 9, replace=False))
+    val = rng.standard_normal(9)
+    mask = np.zeros(64, np.uint8)
+    mask[idx] = 1
+    coef = np.zeros(64)
+    coef[idx] = val
+    assert rel(x.xv_sparse(idx, val), ox.xv_masked(mask, coef)) < 1e-11

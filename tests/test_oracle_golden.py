@@ -1,0 +1,212 @@
+"""The CPU oracle against the reference's own recorded outputs and invariants (no GPU)."""
+import json
+import os
+
+import numpy as np
+import pytest
+from scipy import stats
+
+from conftest import FIX, GOLD, hash_folds, make_bed
+
+
+def test_g1_recorded_log_normal_k7(oracle, normal_data):
+    """docs/src/man/examples.md:230-267: iht("normal", 7, Normal, covariates=..., phenotypes=6)."""
+    g = json.load(open(os.path.join(GOLD, "golden_normal_k7.json")))
+    x = oracle.Mat.from_bed_file(normal_data["bed"], normal_data["n"])
+    r = oracle.fit_iht(x, normal_data["y"], normal_data["z"], k=7)
+    assert r["iter"] == g["iterations"]
+    np.testing.assert_allclose(r["logl_trace"], g["logl"], rtol=1e-12)
+    np.testing.assert_allclose(r["tol_trace"], g["tol"], rtol=1e-9)
+    assert list(r["bt_trace"]) == g["backtracks"]
+    assert r["logl"] == pytest.approx(g["final_logl"], rel=1e-13)
+    nz = np.flatnonzero(r["beta"])
+    assert list(nz + 1) == g["positions_1based"]          # bit-exact support
+    np.testing.assert_allclose(r["beta"][nz], g["beta_printed"], rtol=5e-6)   # printed to 6 digits
+    np.testing.assert_allclose(r["c"], g["c_printed"], rtol=5e-6)
+    assert r["pve"] == pytest.approx(g["pve"], rel=1e-10)
+    assert not r["choose_fired"]
+
+
+def test_g2_shipped_summary_k8(oracle, normal_data):
+    """data/iht.summary.txt (older release): converged optimum only."""
+    g = json.load(open(os.path.join(GOLD, "golden_iht_summary_k8.json")))
+    x = oracle.Mat.from_bed_file(normal_data["bed"], normal_data["n"])
+    r = oracle.fit_iht(x, normal_data["y2"], normal_data["z"], k=8)
+    nz = np.flatnonzero(r["beta"])
+    assert list(nz + 1) == g["positions_1based"]
+    np.testing.assert_allclose(r["beta"][nz], g["beta_printed"], rtol=2e-4)
+    np.testing.assert_allclose(r["c"], g["c_printed"], rtol=1e-4)
+    assert r["logl"] == pytest.approx(g["final_logl"], rel=1e-6)
+    assert r["pve"] == pytest.approx(g["pve"], rel=1e-4)
+
+
+def test_g1b_k9_intercept_only(oracle, normal_data):
+    """BASELINE config 1 (README.md:104 gives the command, no output): SURVEY's independent probe."""
+    x = oracle.Mat.from_bed_file(normal_data["bed"], normal_data["n"])
+    r = oracle.fit_iht(x, normal_data["y"], None, k=9)
+    assert r["iter"] == 10
+    assert r["logl"] == pytest.approx(-1612.734968, abs=1e-5)
+    assert list(np.flatnonzero(r["beta"]) + 1) == [1266, 3137, 4246, 4717, 6290, 7629, 7755, 8375, 9415]
+    assert r["c"][0] == pytest.approx(1.65222721, abs=1e-7)
+
+
+def test_snplinalg_semantics(oracle):
+    """mu = mean of non-missing, sinv = 1/sqrt(mu(1-mu/2)) else 1; X'r against a dense numpy matrix."""
+    rng = np.random.default_rng(0)
+    n, p = 203, 57
+    cols = make_bed(rng, n, p, missing_rate=0.05)
+    cols[3, :] = 0                      # monomorphic SNP -> sinv = 1
+    x = oracle.Mat.from_bed_columns(cols, n)
+    code = np.stack([(cols[:, i // 4] >> (2 * (i % 4))) & 3 for i in range(n)], axis=1)   # p x n
+    g = np.where(code == 2, 1.0, np.where(code == 3, 2.0, 0.0))
+    miss = code == 1
+    mu = g.sum(1) / (~miss).sum(1)
+    sd = np.sqrt(mu * (1 - mu / 2))
+    sinv = np.where(sd > 0, 1 / np.where(sd > 0, sd, 1), 1.0)
+    omu, osinv = x.mu_sinv()
+    np.testing.assert_allclose(omu, mu, rtol=1e-14)
+    np.testing.assert_allclose(osinv, sinv, rtol=1e-14)
+    assert osinv[3] == 1.0
+    X = ((np.where(miss, mu[:, None], g) - mu[:, None]) * sinv[:, None]).T     # n x p standardized, imputed
+    r = rng.standard_normal(n)
+    np.testing.assert_allclose(x.xtv(r), X.T @ r, rtol=1e-11, atol=1e-11)
+    idx = np.zeros(p, np.uint8)
+    idx[[1, 5, 40]] = 1
+    coef = rng.standard_normal(p)
+    sel = idx.astype(bool)
+    np.testing.assert_allclose(x.xv_masked(idx, coef), X[:, sel] @ coef[sel], rtol=1e-11, atol=1e-12)
+    assert x.getindex(7, 5) == pytest.approx(X[7, 5], rel=1e-14, abs=1e-15)
+
+
+def test_loglikelihood_vs_logpdf(oracle):
+    """test/utilities_test.jl:20-51: loglikelihood equals the sum of logpdfs; :53-61 deviance."""
+    rng = np.random.default_rng(1)
+    n = 500
+    w = np.ones(n)
+    L, p_ = oracle.lib(), oracle._p
+    mu = rng.uniform(0.05, 0.95, n)
+    y = (rng.random(n) < mu).astype(float)
+    ll = L.orc_loglikelihood(oracle.BERNOULLI, 1.0, p_(y), p_(mu), p_(w), n)
+    assert ll == pytest.approx(stats.bernoulli.logpmf(y, mu).sum(), rel=1e-12)
+    mu = rng.uniform(0.5, 5, n)
+    y = rng.poisson(mu).astype(float)
+    ll = L.orc_loglikelihood(oracle.POISSON, 1.0, p_(y), p_(mu), p_(w), n)
+    assert ll == pytest.approx(stats.poisson.logpmf(y, mu).sum(), rel=1e-12)
+    rr = 3.5
+    y = rng.negative_binomial(rr, rr / (mu + rr)).astype(float)
+    ll = L.orc_loglikelihood(oracle.NEGBIN, rr, p_(y), p_(mu), p_(w), n)
+    assert ll == pytest.approx(stats.nbinom.logpmf(y, rr, rr / (mu + rr)).sum(), rel=1e-10)
+    mu = rng.standard_normal(n)
+    y = mu + rng.standard_normal(n)
+    ll = L.orc_loglikelihood(oracle.NORMAL, 1.0, p_(y), p_(mu), p_(w), n)
+    sd = np.sqrt(((y - mu) ** 2).sum() / n)
+    assert ll == pytest.approx(stats.norm.logpdf(y, mu, sd).sum(), rel=1e-12)
+    dev = L.orc_deviance(oracle.NORMAL, 1.0, p_(y), p_(mu), p_(w), n)
+    assert dev == pytest.approx(((y - mu) ** 2).sum(), rel=1e-14)
+
+
+def test_links(oracle):
+    """test/utilities_test.jl:63-92."""
+    L = oracle.lib()
+    for eta in (-3.0, -0.2, 0.0, 1.7):
+        assert L.orc_linkinv(oracle.IDENTITY, eta) == eta
+        assert L.orc_linkinv(oracle.LOGIT, eta) == pytest.approx(1 / (1 + np.exp(-eta)), rel=1e-15)
+        assert L.orc_linkinv(oracle.LOG, eta) == pytest.approx(np.exp(eta), rel=1e-15)
+        mu = 1 / (1 + np.exp(-eta))
+        assert L.orc_mueta(oracle.LOGIT, eta) == pytest.approx(mu * (1 - mu), rel=1e-13)
+
+
+def test_project_k_property(oracle):
+    """test/utilities_test.jl:166-176."""
+    rng = np.random.default_rng(2)
+    x = rng.random(100000)
+    k = 100
+    out = oracle.project_k(x, k)
+    keep = np.argsort(-x)[:k]
+    assert np.count_nonzero(out) == k
+    assert np.array_equal(np.sort(np.flatnonzero(out)), np.sort(keep))
+    assert np.array_equal(out[keep], x[keep])
+    t = oracle.project_k(np.array([1.0, -2.0, 2.0, 0.5]), 2)      # ties at the threshold are kept
+    assert list(t) == [0.0, -2.0, 2.0, 0.0]
+    t = oracle.project_k(np.array([1.0, -2.0, 2.0, 0.5]), 1)
+    assert list(t) == [0.0, -2.0, 2.0, 0.0]
+    with pytest.raises(ValueError):
+        oracle.project_k(x, -1)
+
+
+def test_project_group_sparse_properties(oracle):
+    """test/utilities_test.jl:180-213."""
+    rng = np.random.default_rng(3)
+    m, n, k, J = 5, 50, 3, 2
+    y = rng.standard_normal(n)
+    group = np.repeat(np.arange(1, m + 1), n // m)
+    out = oracle.project_group_sparse(y, group, J, k)
+    nzg = [np.count_nonzero(out[group == g]) for g in range(1, m + 1)]
+    assert sum(c > 0 for c in nzg) == J
+    assert all(c in (0, k) for c in nzg)
+    assert np.count_nonzero(out) == J * k
+    one = np.ones(n, dtype=np.int64)                      # one group == project_k
+    assert np.array_equal(oracle.project_group_sparse(y, one, 1, 7), oracle.project_k(y, 7))
+    ks = np.array([1, 2, 3, 4, 5])                        # per-group k vector
+    out = oracle.project_group_sparse(y, group, 5, ks)
+    assert [np.count_nonzero(out[group == g]) for g in range(1, m + 1)] == list(ks)
+
+
+def test_fit_invariants_per_family(oracle):
+    """test/L0_reg_test.jl:21-24,49-52,74-77,99-102: count(!iszero, beta) == k, intercept estimated."""
+    rng = np.random.default_rng(4)
+    n, p, k = 600, 800, 6
+    cols = make_bed(rng, n, p)
+    x = oracle.Mat.from_bed_columns(cols, n)
+    b = np.zeros(p)
+    supp = rng.choice(p, k, replace=False)
+    b[supp] = rng.choice([-1, 1], k) * rng.uniform(0.3, 0.8, k)
+    m = np.zeros(p, np.uint8)
+    m[supp] = 1
+    eta = x.xv_masked(m, b)
+    cases = [("normal", "identity", eta + 1 + rng.standard_normal(n)),
+             ("bernoulli", "logit", (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float)),
+             ("poisson", "log", rng.poisson(np.exp(0.4 * eta)).astype(float)),
+             ("negbin", "log", rng.negative_binomial(10, 10 / (np.exp(0.4 * eta) + 10)).astype(float))]
+    for dist, link, y in cases:
+        r = oracle.fit_iht(x, y, None, k=k, dist=dist, link=link, nb_r=10.0)
+        assert np.count_nonzero(r["beta"]) == k, dist
+        assert r["c"][0] != 0
+        assert np.isfinite(r["logl"])
+
+
+def test_zkeep_and_cv(oracle):
+    """test/L0_reg_test.jl:169-173 (zkeep) and test/cv_iht_test.jl:29-38 (mses > 0; k > p throws)."""
+    rng = np.random.default_rng(5)
+    n, p = 400, 300
+    cols = make_bed(rng, n, p)
+    x = oracle.Mat.from_bed_columns(cols, n)
+    z = np.column_stack([np.ones(n), rng.standard_normal(n), rng.standard_normal(n)])
+    b = np.zeros(p)
+    b[[5, 50, 200]] = [0.7, -0.6, 0.5]
+    m = (b != 0).astype(np.uint8)
+    y = x.xv_masked(m, b) + z @ np.array([1.0, 1.5, 0.0]) + rng.standard_normal(n)
+    r = oracle.fit_iht(x, y, z, k=4, zkeep=[1, 0, 0])
+    assert r["c"][0] != 0
+    assert np.count_nonzero(r["beta"]) + np.count_nonzero(r["c"][1:]) == 4
+    folds = hash_folds(n, 3)
+    mse, raw = oracle.cv_iht(x, y, z, path=range(0, 8), q=3, folds=folds, max_iter=10)
+    assert mse.shape == (8,) and np.all(mse > 0) and np.all(raw > 0)
+    with pytest.raises(RuntimeError):
+        oracle.cv_iht(x, y, z, path=[p + 1], q=3, folds=folds)
+
+
+def test_multivariate_shipped_data(oracle):
+    """SURVEY 8c G3 plausibility target: data/multivariate.* with k=10 (true Sigma is shipped)."""
+    n = 1000
+    x = oracle.Mat.from_bed_file(os.path.join(FIX, "multivariate.bed"), n)
+    Y = np.loadtxt(os.path.join(FIX, "multivariate.phen"), delimiter=",").T
+    S = np.loadtxt(os.path.join(FIX, "multivariate.trait.cov"), delimiter=",")
+    r = oracle.fit_mv(x, Y, None, k=10)
+    assert r["iter"] >= 5 and np.isfinite(r["logl"])
+    assert np.count_nonzero(r["B"]) <= 10
+    np.testing.assert_allclose(r["Sigma"], S, atol=0.12)
+    assert np.all(r["pve"] > 0)
+    sel0 = set(np.flatnonzero(r["B"][0]) + 1)
+    sel1 = set(np.flatnonzero(r["B"][1]) + 1)
+    assert {134, 442, 450, 1891, 2557, 3243} <= sel0 and {1014, 5214} <= sel1
