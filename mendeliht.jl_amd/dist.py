@@ -42,10 +42,11 @@ def gather_losses(raw):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return raw
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-    mine = torch.from_numpy(np.ascontiguousarray(raw, dtype=np.float64)).to(dev)
-    out = torch.empty((dist.get_world_size(),) + tuple(mine.shape), dtype=torch.float64, device=dev)
+    raw = np.ascontiguousarray(raw, dtype=np.float64)
+    mine = torch.from_numpy(raw.ravel().copy()).to(dev)
+    out = torch.empty(dist.get_world_size() * mine.numel(), dtype=torch.float64, device=dev)
     dist.all_gather_into_tensor(out, mine)
-    return out.sum(dim=0).cpu().numpy()
+    return out.view(dist.get_world_size(), -1).sum(dim=0).cpu().numpy().reshape(raw.shape)
 
 
 def cv_iht_distributed(y, x, z=None, **kw):
