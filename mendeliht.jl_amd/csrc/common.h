@@ -93,13 +93,17 @@ int  xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double
 // Same but r already permuted into w.rperm and sums filled (fused producer path).
 int  xtv_device_preperm(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double *out_dev, hipStream_t s);
 // device-side helper: position of row i in the tile-permuted residual vector
-__host__ __device__ inline int64_t rperm_pos(int64_t i)
+// (a lane of the X'r kernel holds `lw` consecutive dwords = 16*lw rows of a 1024*lw-row superchunk)
+__host__ __device__ inline int64_t rperm_pos(int64_t i, int lw)
 {
-    int64_t c = i >> 10;
-    int l = (int)((i & 1023) >> 4);
-    int s = (int)(i & 15);
-    return ((c * 8 + (s >> 1)) * 64 + l) * 2 + (s & 1);
+    int64_t sc = i / (1024 * lw);
+    int w = (int)(i - sc * (1024 * lw));
+    int l = w / (16 * lw);          // lane
+    int d = (w / 16) % lw;          // dword within the lane's load
+    int s = w & 15;                 // slot within the dword
+    return (((sc * lw + d) * 8 + (s >> 1)) * 64 + l) * 2 + (s & 1);
 }
+int  xtv_current_lw();
 int  xtv_num_variants();
 extern int g_xtv_variant;
 

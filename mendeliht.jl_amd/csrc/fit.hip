@@ -145,7 +145,7 @@ k_mu_loglik(const double *__restrict__ xb, const double *__restrict__ zc, const 
 __global__ void __launch_bounds__(256)
 k_resid(const double *__restrict__ xb, const double *__restrict__ zc, const double *__restrict__ y,
         const double *__restrict__ mu, const double *__restrict__ w, int64_t n, int64_t n_perm,
-        int dist, int link, double nb_r, double *__restrict__ r, double *__restrict__ rperm)
+        int dist, int link, double nb_r, int lw, double *__restrict__ r, double *__restrict__ rperm)
 {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n_perm) return;
@@ -156,7 +156,7 @@ k_resid(const double *__restrict__ xb, const double *__restrict__ zc, const doub
         v = d_mueta(link, eta) / d_glmvar(dist, m, nb_r) * (y[i] - m) * w[i];
         r[i] = v;
     }
-    if (rperm) rperm[rperm_pos(i)] = v;
+    if (rperm) rperm[rperm_pos(i, lw)] = v;
 }
 
 // df2 = Z' r (utilities.jl:134): one workgroup per covariate, fixed-order tree
@@ -369,7 +369,7 @@ struct IhtVar {
     {
         double *rp = (h->kind == 0) ? xtv.rperm.p : nullptr;
         int64_t np = (h->kind == 0) ? xtv.n_perm : n;
-        hipLaunchKernelGGL(k_resid, dim3(nblk(np)), dim3(256), 0, s, xb.p, zc.p, y.p, mu.p, w.p, n, np, dist, link, nb_r, r.p, rp);
+        hipLaunchKernelGGL(k_resid, dim3(nblk(np)), dim3(256), 0, s, xb.p, zc.p, y.p, mu.p, w.p, n, np, dist, link, nb_r, xtv_current_lw(), r.p, rp);
         if (h->kind == 0) MIH_TRY(xtv_device_preperm(h, xtv, r.p, 1, df.p, s));
         else MIH_TRY(xtv_device(h, xtv, r.p, 1, df.p, s));
         hipLaunchKernelGGL(k_zt_r, dim3(q), dim3(256), 0, s, z.p, r.p, n, scal.p);

@@ -259,7 +259,7 @@ static int finish_missing_ptr(mih_mat *h, const std::vector<int32_t> &cnt, std::
 
 static int alloc_snp(mih_mat *h)
 {
-    h->stride_dw = round_up((h->n + 15) / 16, 64);
+    h->stride_dw = round_up((h->n + 15) / 16, 256);   // 1 KB: whole superchunks for every load width
     h->n_pad = h->stride_dw * 16;
     size_t bytes = sizeof(uint32_t) * (size_t)h->p * (size_t)h->stride_dw;
     hipError_t e = hipMalloc((void **)&h->X, bytes);

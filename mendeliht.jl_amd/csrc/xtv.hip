@@ -45,7 +45,7 @@ static void prof_end(hipStream_t s, hipEvent_t e0, hipEvent_t e1)
     g_prof_events.emplace_back(e0, e1);
 }
 
-__global__ void k_permute_r(const double *__restrict__ r, int64_t n, int64_t n_perm, int m,
+__global__ void k_permute_r(const double *__restrict__ r, int64_t n, int64_t n_perm, int m, int lw,
                             double *__restrict__ rperm)
 {
     int64_t total = n_perm * m;
@@ -53,22 +53,22 @@ __global__ void k_permute_r(const double *__restrict__ r, int64_t n, int64_t n_p
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; t < total; t += stride) {
         int64_t v = t / n_perm, i = t - v * n_perm;
-        rperm[v * n_perm + rperm_pos(i)] = (i < n) ? r[v * n + i] : 0.0;
+        rperm[v * n_perm + rperm_pos(i, lw)] = (i < n) ? r[v * n + i] : 0.0;
     }
 }
 
 // carrier[v][s] = sum of r over the rows of slice s (fixed order per block => deterministic)
 __global__ void __launch_bounds__(256)
-k_slice_sums(const double *__restrict__ rperm, int64_t n_perm, int64_t nchunks, int splits,
+k_slice_sums(const double *__restrict__ rperm, int64_t n_perm, int64_t nsc, int rows_per_sc, int splits,
              double *__restrict__ carrier)
 {
     __shared__ double red[256];
     int s = blockIdx.x % splits, v = blockIdx.x / splits;
-    int64_t cps = (nchunks + splits - 1) / splits;
-    int64_t c0 = s * cps, c1 = c0 + cps < nchunks ? c0 + cps : nchunks;
+    int64_t sps = (nsc + splits - 1) / splits;
+    int64_t c0 = s * sps, c1 = c0 + sps < nsc ? c0 + sps : nsc;
     const double *src = rperm + v * n_perm;
     double a = 0.0;
-    for (int64_t i = c0 * 1024 + threadIdx.x; i < c1 * 1024; i += 256) a += src[i];
+    for (int64_t i = c0 * rows_per_sc + threadIdx.x; i < c1 * rows_per_sc; i += 256) a += src[i];
     red[threadIdx.x] = a;
     __syncthreads();
     for (int k = 128; k > 0; k >>= 1) {
@@ -82,18 +82,21 @@ k_slice_sums(const double *__restrict__ rperm, int64_t n_perm, int64_t nchunks, 
 // MODE 0: bit-field extract + v_cvt_f64_u32 (plain baseline)         acc = sum g r
 // MODE 1: shift + and_or into the mantissa of 2.0                    acc = sum (2+g/2) r
 // MODE 2: three word shifts + one SDWA byte-select AND per dosage    acc = sum (2+g/2) r
+// MODE 3: load-only probe (bench only; results are meaningless)
+struct DecodePairs { double d[4]; };   // persistent {lo = 0, hi = 0x40000000 | g << 18} register pairs
+
 template <int MODE>
-__device__ __forceinline__ void dot16(uint32_t w, const double (&r)[16], double &acc);
+__device__ __forceinline__ void dot16(uint32_t w, const double (&r)[16], double &acc, DecodePairs &dp);
 
 template <>
-__device__ __forceinline__ void dot16<0>(uint32_t w, const double (&r)[16], double &acc)
+__device__ __forceinline__ void dot16<0>(uint32_t w, const double (&r)[16], double &acc, DecodePairs &)
 {
     #pragma unroll
     for (int s = 0; s < 16; ++s) acc = fma((double)((w >> (2 * s)) & 3u), r[s], acc);
 }
 
 template <>
-__device__ __forceinline__ void dot16<1>(uint32_t w, const double (&r)[16], double &acc)
+__device__ __forceinline__ void dot16<1>(uint32_t w, const double (&r)[16], double &acc, DecodePairs &)
 {
     #pragma unroll
     for (int s = 0; s < 16; ++s) {
@@ -103,26 +106,48 @@ __device__ __forceinline__ void dot16<1>(uint32_t w, const double (&r)[16], doub
     }
 }
 
-#define MIH_SDWA_AND(HI, SRC, BYTE)                                                           \
-    asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE "                  \
-        "src0_sel:BYTE_" #BYTE " src1_sel:DWORD" : "+v"(HI) : "v"(SRC), "v"(mask))
+// The SDWA AND writes (byte K of SRC) & 0x0C into byte 2 of the high word of D and preserves the
+// other three bytes, so D keeps {lo = 0, byte 3 = 0x40} for the whole kernel: no re-initialisation.
+#define MIH_SDWA_UPD(D, SRC, BYTE)                                                               \
+    {                                                                                              \
+        uint32_t h_ = (uint32_t)__double2hiint(D);                                                 \
+        asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE "                  \
+            "src0_sel:BYTE_" #BYTE " src1_sel:DWORD" : "+v"(h_) : "v"(SRC), "v"(mask));            \
+        D = __hiloint2double((int)h_, __double2loint(D));                                          \
+    }
 
 template <>
-__device__ __forceinline__ void dot16<2>(uint32_t w, const double (&r)[16], double &acc)
+__device__ __forceinline__ void dot16<2>(uint32_t w, const double (&r)[16], double &acc, DecodePairs &dp)
 {
-    // slot q of byte k holds row 4k+q; move slot q to bits 2-3 of its byte, then one
-    // SDWA AND drops (byte & 0x0C) into byte 2 of the high word of 2.0.
+    // slot q of byte K holds row 4K+q; shift slot q onto bits 2-3 of its byte once per dword.
     const uint32_t mask = 0x0Cu;
     uint32_t w0 = w << 2, w2 = w >> 2, w3 = w >> 4;
-    uint32_t h0 = 0x40000000u, h1 = 0x40000000u, h2 = 0x40000000u, h3 = 0x40000000u;
-#define MIH_BYTE(K)                                                                            \
-    MIH_SDWA_AND(h0, w0, K); MIH_SDWA_AND(h1, w, K); MIH_SDWA_AND(h2, w2, K); MIH_SDWA_AND(h3, w3, K); \
-    acc = fma(__hiloint2double((int)h0, 0), r[4 * K + 0], acc);                                \
-    acc = fma(__hiloint2double((int)h1, 0), r[4 * K + 1], acc);                                \
-    acc = fma(__hiloint2double((int)h2, 0), r[4 * K + 2], acc);                                \
-    acc = fma(__hiloint2double((int)h3, 0), r[4 * K + 3], acc);
+#define MIH_BYTE(K)                                                                               \
+    MIH_SDWA_UPD(dp.d[0], w0, K) MIH_SDWA_UPD(dp.d[1], w, K)                                      \
+    MIH_SDWA_UPD(dp.d[2], w2, K) MIH_SDWA_UPD(dp.d[3], w3, K)                                     \
+    acc = fma(dp.d[0], r[4 * K + 0], acc); acc = fma(dp.d[1], r[4 * K + 1], acc);                  \
+    acc = fma(dp.d[2], r[4 * K + 2], acc); acc = fma(dp.d[3], r[4 * K + 3], acc);
     MIH_BYTE(0) MIH_BYTE(1) MIH_BYTE(2) MIH_BYTE(3)
 #undef MIH_BYTE
+}
+
+// Probes (bench only, ids 100+): 3 = loads + LDS + barriers without the decode/FMA work,
+// 4 = real decode/FMA + genotype loads but r from registers (no LDS, no staging, no barriers),
+// 5 = real decode/FMA + LDS but no genotype loads.
+template <>
+__device__ __forceinline__ void dot16<3>(uint32_t w, const double (&r)[16], double &acc, DecodePairs &)
+{
+    acc += __hiloint2double((int)(w & 0x000FFFFFu) | 0x3FF00000, 0) * r[0];
+}
+template <>
+__device__ __forceinline__ void dot16<4>(uint32_t w, const double (&r)[16], double &acc, DecodePairs &dp)
+{
+    dot16<2>(w, r, acc, dp);
+}
+template <>
+__device__ __forceinline__ void dot16<5>(uint32_t w, const double (&r)[16], double &acc, DecodePairs &dp)
+{
+    dot16<2>(w, r, acc, dp);
 }
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -132,71 +157,118 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
-// WAVES waves x C columns per workgroup; TCH chunks of r per LDS stage (double-buffered).
-template <int WAVES, int C, int TCH, int MODE>
+template <int LW> struct LoadVec;
+template <> struct LoadVec<1> { using type = uint32_t; };
+template <> struct LoadVec<2> { using type = uint2; };
+template <> struct LoadVec<4> { using type = uint4; };
+__device__ __forceinline__ uint32_t vec_get(uint32_t v, int) { return v; }
+__device__ __forceinline__ uint32_t vec_get(const uint2 &v, int d) { return d == 0 ? v.x : v.y; }
+__device__ __forceinline__ uint32_t vec_get(const uint4 &v, int d) { return d == 0 ? v.x : d == 1 ? v.y : d == 2 ? v.z : v.w; }
+
+// WAVES waves x C columns per workgroup.  A lane loads LW consecutive dwords (16*LW rows) of a
+// column per "superchunk" of 1024*LW rows, so one wave-load is 256*LW contiguous bytes; TSC
+// superchunks of r are staged per LDS buffer (double-buffered).
+template <int WAVES, int C, int LW, int TSC, int MODE>
 __global__ void __launch_bounds__(WAVES * 64)
 k_xtv(const uint32_t *__restrict__ X, int64_t stride_dw, int64_t p,
-      const double2 *__restrict__ rperm, int64_t nchunks, int splits,
+      const double2 *__restrict__ rperm, int64_t nsc, int splits,
       double *__restrict__ partial /* [splits][p] */)
 {
-    __shared__ double2 tile[2][TCH * 512];
+    using Vec = typename LoadVec<LW>::type;
+    constexpr int VC = TSC * LW;                  // 1024-row virtual chunks per stage
+    __shared__ double2 tile[2][VC * 512];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int split = blockIdx.x % splits;
     const int64_t cg = blockIdx.x / splits;
-    const int64_t cps = (nchunks + splits - 1) / splits;
-    const int64_t c0 = split * cps;
-    const int64_t c1 = (c0 + cps < nchunks) ? c0 + cps : nchunks;
+    const int64_t sps = (nsc + splits - 1) / splits;
+    const int64_t c0 = split * sps;
+    const int64_t c1 = (c0 + sps < nsc) ? c0 + sps : nsc;
     const int64_t j0 = cg * (WAVES * C) + wave * C;
 
-    const uint32_t *col[C];
+    const Vec *col[C];
     #pragma unroll
     for (int c = 0; c < C; ++c) {
         int64_t j = j0 + c < p ? j0 + c : p - 1;
-        col[c] = X + j * stride_dw + lane;
+        col[c] = reinterpret_cast<const Vec *>(X + j * stride_dw) + lane;
     }
     double acc[C];
     #pragma unroll
     for (int c = 0; c < C; ++c) acc[c] = 0.0;
+    DecodePairs dp;
+    #pragma unroll
+    for (int t = 0; t < 4; ++t) dp.d[t] = 2.0;
 
-    auto stage = [&](int buf, int64_t cbase) {
-        // TCH*512 double2 per stage, WAVES*64 threads
+    // r-tile staging is split (issue the global loads early, store to LDS late) so that the loads'
+    // latency hides under the decode/FMA work of the current stage instead of stalling its start.
+    constexpr int NST = (VC * 512) / (WAVES * 64);
+    static_assert((VC * 512) % (WAVES * 64) == 0, "stage must divide evenly over the workgroup");
+    double2 sreg[NST];
+    auto stage_load = [&](int64_t cbase) {
         #pragma unroll
-        for (int t = threadIdx.x; t < TCH * 512; t += WAVES * 64) {
-            int64_t ch = cbase + t / 512;
-            double2 v = make_double2(0.0, 0.0);
-            if (ch < c1) v = rperm[cbase * 512 + t];
-            tile[buf][t] = v;
+        for (int k = 0; k < NST; ++k) {
+            int t = threadIdx.x + k * (WAVES * 64);
+            int64_t sc = cbase + t / (512 * LW);
+            sreg[k] = make_double2(0.0, 0.0);
+            if (sc < c1) sreg[k] = rperm[cbase * (512 * LW) + t];
         }
     };
+    auto stage_store = [&](int buf) {
+        #pragma unroll
+        for (int k = 0; k < NST; ++k) tile[buf][threadIdx.x + k * (WAVES * 64)] = sreg[k];
+    };
 
+    constexpr bool kUseLds = (MODE != 4);        // probe 4: r from registers, no staging / barriers
+    constexpr bool kUseGlobal = (MODE != 5);     // probe 5: no genotype loads
     if (c0 < c1) {
-        uint32_t wcur[C], wnext[C];
+        Vec wcur[C], wnext[C];
         #pragma unroll
         for (int c = 0; c < C; ++c) wcur[c] = col[c][c0 * 64];
-        stage(0, c0);
-        __syncthreads();
+        if (kUseLds) {
+            stage_load(c0);
+            stage_store(0);
+            __syncthreads();
+        }
         int buf = 0;
-        for (int64_t cbase = c0; cbase < c1; cbase += TCH) {
-            if (cbase + TCH < c1) stage(buf ^ 1, cbase + TCH);
-            const int nch = (c1 - cbase < TCH) ? (int)(c1 - cbase) : TCH;
-            for (int ch = 0; ch < nch; ++ch) {
-                const int64_t cc = cbase + ch;
-                const int64_t cn = (cc + 1 < c1) ? cc + 1 : cc;   // prefetch next chunk's dwords
-                #pragma unroll
-                for (int c = 0; c < C; ++c) wnext[c] = col[c][cn * 64];
-                double r[16];
-                #pragma unroll
-                for (int m = 0; m < 8; ++m) {
-                    double2 v = tile[buf][(ch * 8 + m) * 64 + lane];
-                    r[2 * m] = v.x; r[2 * m + 1] = v.y;
+        for (int64_t cbase = c0; cbase < c1; cbase += TSC) {
+            const bool more = cbase + TSC < c1;
+            if (kUseLds && more) stage_load(cbase + TSC);
+            const int nsc_here = (c1 - cbase < TSC) ? (int)(c1 - cbase) : TSC;
+            for (int sc = 0; sc < nsc_here; ++sc) {
+                const int64_t cc = cbase + sc;
+                const int64_t cn = (cc + 1 < c1) ? cc + 1 : cc;   // prefetch the next superchunk
+                if (kUseGlobal) {
+                    #pragma unroll
+                    for (int c = 0; c < C; ++c) wnext[c] = col[c][cn * 64];
                 }
                 #pragma unroll
-                for (int c = 0; c < C; ++c) dot16<MODE>(wcur[c], r, acc[c]);
-                #pragma unroll
-                for (int c = 0; c < C; ++c) wcur[c] = wnext[c];
+                for (int d = 0; d < LW; ++d) {
+                    double r[16];
+                    if (kUseLds) {
+                        #pragma unroll
+                        for (int m = 0; m < 8; ++m) {
+                            double2 v = tile[buf][((sc * LW + d) * 8 + m) * 64 + lane];
+                            r[2 * m] = v.x; r[2 * m + 1] = v.y;
+                        }
+                    } else {
+                        #pragma unroll
+                        for (int m = 0; m < 16; ++m) r[m] = 1.0 + 0.125 * m + lane;
+                    }
+                    #pragma unroll
+                    for (int c = 0; c < C; ++c) dot16<MODE>(vec_get(wcur[c], d), r, acc[c], dp);
+                }
+                if (kUseGlobal) {
+                    #pragma unroll
+                    for (int c = 0; c < C; ++c) wcur[c] = wnext[c];
+                } else {
+                    #pragma unroll
+                    for (int c = 0; c < C; ++c) asm volatile("" : "+v"(wcur[c]));   // keep the decode work alive
+                }
             }
-            __syncthreads();
+            if (kUseLds) {
+                if (more) stage_store(buf ^ 1);
+                __syncthreads();
+            }
             buf ^= 1;
         }
     }
@@ -260,50 +332,58 @@ k_xtv_dense(const double *__restrict__ D, int64_t n, int64_t p, const double *__
     if (lane == 0) out[j] = s;
 }
 
-struct Variant { int waves, c, tch, mode, splits; };
+struct Variant { int waves, c, lw, tsc, mode, splits; };
 static const Variant kVariants[] = {
-    {4, 8, 2, 1, 1},   // 0: default v1
-    {4, 8, 2, 0, 1},   // 1: cvt baseline
-    {4, 8, 2, 2, 1},   // 2: SDWA decode
-    {4, 8, 2, 1, 8},   // 3: v1 + 8 row slices (XCD-affine)
-    {4, 8, 2, 2, 8},   // 4: SDWA + 8 slices
-    {8, 8, 2, 2, 1},   // 5: 8 waves
-    {8, 8, 2, 2, 8},   // 6
-    {4, 4, 2, 2, 1},   // 7: fewer columns per wave
-    {4, 4, 2, 2, 8},   // 8
-    {4, 16, 2, 2, 1},  // 9: more columns per wave
-    {4, 16, 2, 2, 8},  // 10
-    {4, 8, 4, 2, 8},   // 11: bigger r stage
-    {8, 4, 2, 2, 8},   // 12
-    {4, 8, 2, 0, 8},   // 13
+    {4, 8, 1, 2, 2, 8},    // 0: SDWA decode, dword loads, 8 XCD-affine row slices
+    {4, 8, 1, 2, 1, 8},    // 1: shift+and_or decode
+    {4, 8, 1, 2, 0, 8},    // 2: cvt baseline
+    {4, 8, 1, 2, 2, 1},    // 3: no row slicing
+    {8, 8, 1, 2, 2, 8},    // 4: 8 waves
+    {4, 4, 1, 2, 2, 8},    // 5
+    {4, 16, 1, 2, 2, 8},   // 6
+    {8, 4, 1, 2, 2, 8},    // 7
+};
+// ids 100+: load-only probes of the same access pattern (bench only; numerically meaningless)
+static const Variant kProbes[] = {
+    {4, 8, 1, 2, 3, 8},    // 100: loads + LDS, no decode/FMA
+    {4, 8, 1, 2, 4, 8},    // 101: loads + decode/FMA, no LDS
+    {4, 8, 1, 2, 5, 8},    // 102: LDS + decode/FMA, no genotype loads
+    {8, 8, 1, 2, 4, 8},    // 103
+    {4, 4, 1, 2, 4, 8},    // 104
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+constexpr int kNumProbes = sizeof(kProbes) / sizeof(kProbes[0]);
+constexpr int kDefaultVariant = 0;
 int xtv_num_variants() { return kNumVariants; }
+bool xtv_variant_valid(int v) { return v < kNumVariants || (v >= 100 && v < 100 + kNumProbes); }
 
 static Variant current_variant()
 {
     int v = g_xtv_variant;
-    if (v < 0 || v >= kNumVariants) v = 4;
+    if (v >= 100 && v < 100 + kNumProbes) return kProbes[v - 100];
+    if (v < 0 || v >= kNumVariants) v = kDefaultVariant;
     return kVariants[v];
 }
+int xtv_current_lw() { return current_variant().lw; }
 
-template <int WAVES, int C, int TCH, int MODE>
-static void launch_xtv(const mih_mat *h, const double *rperm, int64_t nchunks, int splits,
+template <int WAVES, int C, int LW, int TSC, int MODE>
+static void launch_xtv(const mih_mat *h, const double *rperm, int64_t nsc, int splits,
                        double *partial, hipStream_t s)
 {
     int64_t groups = (h->p + WAVES * C - 1) / (WAVES * C);
     dim3 grid((unsigned)(groups * splits));
-    hipLaunchKernelGGL((k_xtv<WAVES, C, TCH, MODE>), grid, dim3(WAVES * 64), 0, s, h->X, h->stride_dw, h->p,
-                       reinterpret_cast<const double2 *>(rperm), nchunks, splits, partial);
+    hipLaunchKernelGGL((k_xtv<WAVES, C, LW, TSC, MODE>), grid, dim3(WAVES * 64), 0, s, h->X, h->stride_dw, h->p,
+                       reinterpret_cast<const double2 *>(rperm), nsc, splits, partial);
 }
 
-static int dispatch_xtv(const Variant &v, const mih_mat *h, const double *rperm, int64_t nchunks,
+static int dispatch_xtv(const Variant &v, const mih_mat *h, const double *rperm, int64_t nsc,
                         int splits, double *partial, hipStream_t s)
 {
-#define MIH_CASE(W, CC, T, M) \
-    if (v.waves == W && v.c == CC && v.tch == T && v.mode == M) { launch_xtv<W, CC, T, M>(h, rperm, nchunks, splits, partial, s); return MIH_OK; }
-    MIH_CASE(4, 8, 2, 1) MIH_CASE(4, 8, 2, 0) MIH_CASE(4, 8, 2, 2) MIH_CASE(8, 8, 2, 2)
-    MIH_CASE(4, 4, 2, 2) MIH_CASE(4, 16, 2, 2) MIH_CASE(4, 8, 4, 2) MIH_CASE(8, 4, 2, 2)
+#define MIH_CASE(W, CC, L, T, M) \
+    if (v.waves == W && v.c == CC && v.lw == L && v.tsc == T && v.mode == M) { launch_xtv<W, CC, L, T, M>(h, rperm, nsc, splits, partial, s); return MIH_OK; }
+    MIH_CASE(4, 8, 1, 2, 2) MIH_CASE(4, 8, 1, 2, 1) MIH_CASE(4, 8, 1, 2, 0) MIH_CASE(8, 8, 1, 2, 2)
+    MIH_CASE(4, 4, 1, 2, 2) MIH_CASE(4, 16, 1, 2, 2)
+    MIH_CASE(4, 8, 1, 2, 3) MIH_CASE(4, 8, 1, 2, 4) MIH_CASE(4, 8, 1, 2, 5) MIH_CASE(8, 8, 1, 2, 4) MIH_CASE(4, 4, 1, 2, 4) MIH_CASE(8, 4, 1, 2, 2)
 #undef MIH_CASE
     set_error("unknown X'r kernel variant");
     return MIH_BAD_ARG;
@@ -331,24 +411,24 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
         return MIH_OK;
     }
     if (m > w.m_cap) { set_error("X'r workspace too small"); return MIH_BAD_ARG; }
-    hipLaunchKernelGGL(k_permute_r, dim3(1024), dim3(256), 0, s, r_dev, h->n, w.n_perm, m, w.rperm.p);
+    hipLaunchKernelGGL(k_permute_r, dim3(1024), dim3(256), 0, s, r_dev, h->n, w.n_perm, m, xtv_current_lw(), w.rperm.p);
     return xtv_device_preperm(h, w, r_dev, m, out_dev, s);
 }
 
 int xtv_device_preperm(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double *out_dev, hipStream_t s)
 {
     Variant v = current_variant();
-    int64_t nchunks = h->stride_dw / 64;
+    int64_t nsc = h->stride_dw / (64 * v.lw);       // superchunks per column
     int splits = v.splits;
-    if (splits > nchunks) splits = (int)nchunks;
+    if (splits > nsc) splits = (int)nsc;
     if (splits > w.splits_cap) splits = w.splits_cap;
     double A = (v.mode == 0) ? 1.0 : 2.0, B = (v.mode == 0) ? 0.0 : 4.0;
-    hipLaunchKernelGGL(k_slice_sums, dim3((unsigned)(splits * m)), dim3(256), 0, s, w.rperm.p, w.n_perm, nchunks, splits, w.sums.p);
+    hipLaunchKernelGGL(k_slice_sums, dim3((unsigned)(splits * m)), dim3(256), 0, s, w.rperm.p, w.n_perm, nsc, 1024 * v.lw, splits, w.sums.p);
     for (int t = 0; t < m; ++t) {
         double *partial = w.partial.p + (int64_t)t * splits * h->p;
         hipEvent_t e0, e1;
         prof_begin(s, e0, e1);
-        int rc = dispatch_xtv(v, h, w.rperm.p + (int64_t)t * w.n_perm, nchunks, splits, partial, s);
+        int rc = dispatch_xtv(v, h, w.rperm.p + (int64_t)t * w.n_perm, nsc, splits, partial, s);
         prof_end(s, e0, e1);
         if (rc) return rc;
         hipLaunchKernelGGL(k_xtv_finalize, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, s, partial,
@@ -390,7 +470,7 @@ int mih_profile_read(double *xtv_kernel_ms, int64_t *xtv_launches, int reset)
 
 int mih_set_xtv_variant(int variant)
 {
-    if (variant >= xtv_num_variants()) { set_error("variant %d out of range", variant); return MIH_BAD_ARG; }
+    if (!xtv_variant_valid(variant)) { set_error("variant %d out of range", variant); return MIH_BAD_ARG; }
     g_xtv_variant = variant;
     return MIH_OK;
 }
@@ -453,7 +533,7 @@ int mih_bench_xtv(const mih_mat *h, int variant, int iters, int warmup, uint64_t
     if (!h || iters < 1 || !ms_per_pass) return MIH_BAD_ARG;
     MIH_HIP(hipSetDevice(h->device));
     int saved = g_xtv_variant;
-    if (variant >= 0) { if (variant >= xtv_num_variants()) return MIH_BAD_ARG; g_xtv_variant = variant; }
+    if (variant >= 0) { if (!xtv_variant_valid(variant)) return MIH_BAD_ARG; g_xtv_variant = variant; }
     XtvWork w;
     int rc = xtv_work_init(h, w, 1);
     DevBuf<double> r, out, cs;
