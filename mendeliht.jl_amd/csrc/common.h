@@ -54,21 +54,25 @@ struct DevBuf {
 
 // Device-resident design matrix.
 //
-// kind 0 (SnpLinAlg): 2-bit dosage codes, column-major, `stride_dw` dwords per SNP
-// column (a multiple of 64 dwords = 256 B so every wave-load is one aligned
-// 256-B segment).  Device code is the DOSAGE itself (00->0, 01->1, 10->2; the
-// PLINK code is remapped once at upload) and missing entries are stored as 0
-// with their row numbers kept in a per-column CSR side list, so the inner
-// loop of X'r decodes with one bit-field op and never branches on missingness.
-// Pad rows beyond n are 0.
+// kind 0 (SnpLinAlg): 2-bit dosage codes in a TILE-MAJOR layout built for the matrix cores.
+// A tile is 32 SNP columns x 128 rows = 1 KB = one wave-load of 16 B per lane:
+//     X[(cg * nbp + bp) * 64 + lane] : uint4,   lane = 32*h + m
+// where cg = column / 32, m = column % 32, bp = row / 128, and the lane's four dwords are
+// {e=0,u=0}, {e=0,u=1}, {e=1,u=0}, {e=1,u=1} covering rows 128*bp + 64*e + 32*h + 16*u + (0..15),
+// two bits per row, low bits first.  With this layout lane (m, h) of a wave holds exactly the
+// A-operand fragment (row m, K-half h) of v_mfma_scale_f32_32x32x64_f8f6f4 for both 64-row blocks.
+// The code is the DOSAGE itself (00->0, 01->1, 10->2; PLINK's code is remapped once at upload):
+// placed in the low bits of a nibble it is the FP4 (e2m1) number dosage/2.  Missing entries are
+// stored as 0 with their row numbers in a per-column CSR side list; pad rows/columns are 0.
 struct mih_mat {
     int       kind = 0;            // 0 snp, 1 dense
     int       device = 0;
     int64_t   n = 0, p = 0;
     int       center = 1, scale = 1, impute = 1;
-    int64_t   stride_dw = 0;       // dwords per column
-    int64_t   n_pad = 0;           // rows covered by stride (= stride_dw*16)
-    uint32_t *X = nullptr;         // p * stride_dw dwords
+    int64_t   ncg = 0;             // column groups of 32
+    int64_t   nbp = 0;             // row block pairs of 128
+    int64_t   n_pad = 0;           // nbp * 128
+    uint32_t *X = nullptr;         // ncg * nbp * 64 * 4 dwords
     double   *mu = nullptr, *sinv = nullptr;   // p
     int64_t  *miss_ptr = nullptr;  // p+1
     int32_t  *miss_row = nullptr;  // total_missing
@@ -80,30 +84,25 @@ struct mih_mat {
 namespace mih {
 
 // ---- X'r ---------------------------------------------------------------------
+// index (in dwords) of the 16 rows 16*t .. 16*t+15 of column j inside the tile-major layout
+__host__ __device__ inline int64_t xword(int64_t nbp, int64_t j, int64_t t)
+{
+    int64_t cg = j >> 5, blk = t >> 2, bp = blk >> 1;
+    int m = (int)(j & 31), h = (int)((t >> 1) & 1), u = (int)(t & 1), e = (int)(blk & 1);
+    return (((cg * nbp + bp) * 64 + (h * 32 + m)) << 2) + (e << 1) + u;
+}
+
+constexpr int kDigits = 28;          // balanced base-4 digits of the fixed-point residual (56 bits)
+
 struct XtvWork {            // scratch for one in-flight X'r
-    DevBuf<double> rperm;   // m * n_perm  (tile-permuted residuals)
-    DevBuf<double> partial; // splits * m * p raw dots
-    DevBuf<double> sums;    // m * 2 : sum(r) (and spare)
-    int64_t n_perm = 0;
+    DevBuf<uint32_t> digits;   // m * nblk * 64 lanes * 4 dwords : FP4 digit planes of r (B operand)
+    DevBuf<double>   partial;  // splits * m * ncg*32 raw dots
+    DevBuf<double>   scal;     // m * 4 : {max|r| bits, 2^-e, sum r, spare}
     int m_cap = 0, splits_cap = 0;
 };
 int  xtv_work_init(const mih_mat *h, XtvWork &w, int m);
-// r_dev: m vectors of length n (natural order, column-major n x m) on device; out_dev p x m.
+// r_dev: m vectors of length n (column-major n x m) on device; out_dev p x m.
 int  xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double *out_dev, hipStream_t s);
-// Same but r already permuted into w.rperm and sums filled (fused producer path).
-int  xtv_device_preperm(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double *out_dev, hipStream_t s);
-// device-side helper: position of row i in the tile-permuted residual vector
-// (a lane of the X'r kernel holds `lw` consecutive dwords = 16*lw rows of a 1024*lw-row superchunk)
-__host__ __device__ inline int64_t rperm_pos(int64_t i, int lw)
-{
-    int64_t sc = i / (1024 * lw);
-    int w = (int)(i - sc * (1024 * lw));
-    int l = w / (16 * lw);          // lane
-    int d = (w / 16) % lw;          // dword within the lane's load
-    int s = w & 15;                 // slot within the dword
-    return (((sc * lw + d) * 8 + (s >> 1)) * 64 + l) * 2 + (s & 1);
-}
-int  xtv_current_lw();
 int  xtv_num_variants();
 extern int g_xtv_variant;
 

@@ -140,23 +140,17 @@ k_mu_loglik(const double *__restrict__ xb, const double *__restrict__ zc, const 
     block_sum<3>(v, partial ? partial + 3ll * blockIdx.x : nullptr);
 }
 
-// score! residual (utilities.jl:128-132): r = mueta(eta)/var(mu) * (y-mu) * cv_wts, written in
-// natural order (missing-entry correction, Z'r) and in the X'r kernel's tile permutation.
+// score! residual (utilities.jl:128-132): r = mueta(eta)/var(mu) * (y-mu) * cv_wts
 __global__ void __launch_bounds__(256)
 k_resid(const double *__restrict__ xb, const double *__restrict__ zc, const double *__restrict__ y,
-        const double *__restrict__ mu, const double *__restrict__ w, int64_t n, int64_t n_perm,
-        int dist, int link, double nb_r, int lw, double *__restrict__ r, double *__restrict__ rperm)
+        const double *__restrict__ mu, const double *__restrict__ w, int64_t n,
+        int dist, int link, double nb_r, double *__restrict__ r)
 {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= n_perm) return;
-    double v = 0.0;
-    if (i < n) {
-        double eta = xb[i] + zc[i];
-        double m = mu[i];
-        v = d_mueta(link, eta) / d_glmvar(dist, m, nb_r) * (y[i] - m) * w[i];
-        r[i] = v;
-    }
-    if (rperm) rperm[rperm_pos(i, lw)] = v;
+    if (i >= n) return;
+    double eta = xb[i] + zc[i];
+    double m = mu[i];
+    r[i] = d_mueta(link, eta) / d_glmvar(dist, m, nb_r) * (y[i] - m) * w[i];
 }
 
 // df2 = Z' r (utilities.jl:134): one workgroup per covariate, fixed-order tree
@@ -367,11 +361,8 @@ struct IhtVar {
     // score! (utilities.jl:126-135) + df[idx] gather for the next step size
     int score()
     {
-        double *rp = (h->kind == 0) ? xtv.rperm.p : nullptr;
-        int64_t np = (h->kind == 0) ? xtv.n_perm : n;
-        hipLaunchKernelGGL(k_resid, dim3(nblk(np)), dim3(256), 0, s, xb.p, zc.p, y.p, mu.p, w.p, n, np, dist, link, nb_r, xtv_current_lw(), r.p, rp);
-        if (h->kind == 0) MIH_TRY(xtv_device_preperm(h, xtv, r.p, 1, df.p, s));
-        else MIH_TRY(xtv_device(h, xtv, r.p, 1, df.p, s));
+        hipLaunchKernelGGL(k_resid, dim3(nblk(n)), dim3(256), 0, s, xb.p, zc.p, y.p, mu.p, w.p, n, dist, link, nb_r, r.p);
+        MIH_TRY(xtv_device(h, xtv, r.p, 1, df.p, s));
         hipLaunchKernelGGL(k_zt_r, dim3(q), dim3(256), 0, s, z.p, r.p, n, scal.p);
         MIH_HIP(hipMemcpyAsync(df2.data(), scal.p, sizeof(double) * q, hipMemcpyDeviceToHost, s));
         return MIH_OK;

@@ -43,52 +43,59 @@ __device__ __forceinline__ uint32_t lowbias32(uint32_t x)
     return x;
 }
 
-// One workgroup per column: transcode raw PLINK bytes to dosage dwords and count.
-__global__ void __launch_bounds__(256)
-k_transcode(const uint8_t *__restrict__ raw, int64_t raw_stride, int64_t n, int64_t ncols,
-            uint32_t *__restrict__ X, int64_t stride_dw, int64_t col0,
-            int32_t *__restrict__ cnt /* [ncols][3]: n1, n2, nmiss */)
+// Per-column counters of one workgroup (8 threads share a column) -> 96 integer atomics per block.
+__device__ __forceinline__ void flush_counts(int32_t c1, int32_t c2, int32_t cm, int64_t cg, int64_t p,
+                                             int32_t *__restrict__ cnt)
 {
-    __shared__ int32_t red[3][256];
-    for (int64_t jc = blockIdx.x; jc < ncols; jc += gridDim.x) {
-        const uint8_t *src = raw + jc * raw_stride;
-        uint32_t *dst = X + (col0 + jc) * stride_dw;
-        int64_t nbytes = (n + 3) >> 2;
-        int32_t c1 = 0, c2 = 0, cm = 0;
-        for (int64_t t = threadIdx.x; t < stride_dw; t += blockDim.x) {
-            uint32_t w = 0;
-            int64_t b0 = t * 4;
-            #pragma unroll
-            for (int b = 0; b < 4; ++b)
-                if (b0 + b < nbytes) w |= (uint32_t)src[b0 + b] << (8 * b);
-            int64_t rows_left = n - t * 16;       // valid genotypes in this dword
-            uint32_t valid = rows_left >= 16 ? 0xFFFFFFFFu
-                           : rows_left <= 0 ? 0u : ((1u << (2 * rows_left)) - 1u);
-            w &= valid;
-            uint32_t d = plink_to_dosage(w);
-            uint32_t m = plink_missing_mask(w) & valid;
-            dst[t] = d;
-            c1 += __popc(d & 0x55555555u);
-            c2 += __popc(d & 0xAAAAAAAAu);
-            cm += __popc(m);
-        }
-        red[0][threadIdx.x] = c1; red[1][threadIdx.x] = c2; red[2][threadIdx.x] = cm;
-        __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
-            if ((int)threadIdx.x < s) {
-                red[0][threadIdx.x] += red[0][threadIdx.x + s];
-                red[1][threadIdx.x] += red[1][threadIdx.x + s];
-                red[2][threadIdx.x] += red[2][threadIdx.x + s];
-            }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) {
-            cnt[3 * (col0 + jc) + 0] = red[0][0];
-            cnt[3 * (col0 + jc) + 1] = red[1][0];
-            cnt[3 * (col0 + jc) + 2] = red[2][0];
-        }
-        __syncthreads();
+    __shared__ int32_t red[3][32];
+    if (threadIdx.x < 96) red[threadIdx.x / 32][threadIdx.x % 32] = 0;
+    __syncthreads();
+    int m = threadIdx.x & 31;
+    atomicAdd(&red[0][m], c1); atomicAdd(&red[1][m], c2); atomicAdd(&red[2][m], cm);
+    __syncthreads();
+    if (threadIdx.x < 96) {
+        int k = threadIdx.x / 32, mm = threadIdx.x % 32;
+        int64_t j = cg * 32 + mm;
+        if (j < p && red[k][mm]) atomicAdd(&cnt[3 * j + k], red[k][mm]);
     }
+}
+
+// grid (chunks of block pairs, column groups).  Thread (w, lane) builds the lane records of block
+// pairs w, w+4, ... of its chunk: transcode raw PLINK bytes to dosage codes and count.
+constexpr int kBpPerBlock = 64;
+__global__ void __launch_bounds__(256)
+k_transcode(const uint8_t *__restrict__ raw, int64_t raw_stride, int64_t n, int64_t p, int64_t col0,
+            int64_t ncols, uint4 *__restrict__ X, int64_t nbp, int32_t *__restrict__ cnt)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, m = lane & 31, h = lane >> 5;
+    const int64_t cg = col0 / 32 + blockIdx.y;
+    const int64_t j = cg * 32 + m, jl = j - col0;
+    const bool live = j < p && jl < ncols;
+    const uint8_t *src = raw + (live ? jl : 0) * raw_stride;
+    const int64_t nbytes = (n + 3) >> 2;
+    int32_t c1 = 0, c2 = 0, cm = 0;
+    int64_t bp0 = (int64_t)blockIdx.x * kBpPerBlock;
+    for (int64_t bp = bp0 + w; bp < bp0 + kBpPerBlock && bp < nbp; bp += 4) {
+        uint32_t d[4];
+        #pragma unroll
+        for (int q = 0; q < 4; ++q) {                       // q = 2*e + u
+            int64_t t = bp * 8 + (q >> 1) * 4 + h * 2 + (q & 1);
+            uint32_t wv = 0;
+            if (live) {
+                int64_t b0 = t * 4;
+                #pragma unroll
+                for (int b = 0; b < 4; ++b) if (b0 + b < nbytes) wv |= (uint32_t)src[b0 + b] << (8 * b);
+                int64_t rows_left = n - t * 16;
+                uint32_t valid = rows_left >= 16 ? 0xFFFFFFFFu : rows_left <= 0 ? 0u : ((1u << (2 * rows_left)) - 1u);
+                wv &= valid;
+            }
+            uint32_t dd = plink_to_dosage(wv);
+            d[q] = dd;
+            c1 += __popc(dd & 0x55555555u); c2 += __popc(dd & 0xAAAAAAAAu); cm += __popc(plink_missing_mask(wv));
+        }
+        X[(cg * nbp + bp) * 64 + lane] = make_uint4(d[0], d[1], d[2], d[3]);
+    }
+    flush_counts(c1, c2, cm, cg, p, cnt);
 }
 
 // mu_j = (n1 + 2 n2) / (n - nmiss); sinv_j = 1/sqrt(mu(1-mu/2)) if that sqrt > 0 else 1
@@ -148,42 +155,40 @@ __device__ __forceinline__ void synth_col_keys(uint64_t seed, int64_t j, uint32_
 }
 
 __global__ void __launch_bounds__(256)
-k_synth(uint32_t *__restrict__ X, int64_t stride_dw, int64_t n, int64_t p, uint64_t seed,
+k_synth(uint4 *__restrict__ X, int64_t nbp, int64_t n, int64_t p, uint64_t seed,
         uint32_t miss_thr, int32_t *__restrict__ cnt)
 {
-    __shared__ int32_t red[3][256];
-    for (int64_t j = blockIdx.x; j < p; j += gridDim.x) {
-        uint32_t key_g, key_m, thr16;
-        synth_col_keys(seed, j, key_g, key_m, thr16);
-        uint32_t *dst = X + j * stride_dw;
-        int32_t c1 = 0, c2 = 0, cm = 0;
-        for (int64_t t = threadIdx.x; t < stride_dw; t += blockDim.x) {
-            uint32_t d = 0;
-            #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                int64_t i = t * 16 + s;
-                uint32_t dos; bool miss;
-                synth_entry(key_g, key_m, thr16, miss_thr, i, dos, miss);
-                if (i < n) {
-                    if (miss) cm++;
-                    else { d |= dos << (2 * s); c1 += (dos == 1); c2 += (dos == 2); }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, m = lane & 31, h = lane >> 5;
+    const int64_t cg = blockIdx.y;
+    const int64_t j = cg * 32 + m;
+    const bool live = j < p;
+    uint32_t key_g = 0, key_m = 0, thr16 = 0;
+    if (live) synth_col_keys(seed, j, key_g, key_m, thr16);
+    int32_t c1 = 0, c2 = 0, cm = 0;
+    int64_t bp0 = (int64_t)blockIdx.x * kBpPerBlock;
+    for (int64_t bp = bp0 + w; bp < bp0 + kBpPerBlock && bp < nbp; bp += 4) {
+        uint32_t d[4];
+        #pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int64_t t = bp * 8 + (q >> 1) * 4 + h * 2 + (q & 1);
+            uint32_t dd = 0;
+            if (live) {
+                #pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    int64_t i = t * 16 + s;
+                    uint32_t dos; bool miss;
+                    synth_entry(key_g, key_m, thr16, miss_thr, i, dos, miss);
+                    if (i < n) {
+                        if (miss) cm++;
+                        else { dd |= dos << (2 * s); c1 += (dos == 1); c2 += (dos == 2); }
+                    }
                 }
             }
-            dst[t] = d;
+            d[q] = dd;
         }
-        red[0][threadIdx.x] = c1; red[1][threadIdx.x] = c2; red[2][threadIdx.x] = cm;
-        __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
-            if ((int)threadIdx.x < s) {
-                red[0][threadIdx.x] += red[0][threadIdx.x + s];
-                red[1][threadIdx.x] += red[1][threadIdx.x + s];
-                red[2][threadIdx.x] += red[2][threadIdx.x + s];
-            }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) { cnt[3 * j] = red[0][0]; cnt[3 * j + 1] = red[1][0]; cnt[3 * j + 2] = red[2][0]; }
-        __syncthreads();
+        X[(cg * nbp + bp) * 64 + lane] = make_uint4(d[0], d[1], d[2], d[3]);
     }
+    flush_counts(c1, c2, cm, cg, p, cnt);
 }
 
 __global__ void __launch_bounds__(64)
@@ -221,28 +226,37 @@ __global__ void k_synth_dense(double *__restrict__ D, int64_t total, uint64_t se
 }
 
 // ---- export back to PLINK codes -----------------------------------------------
-__global__ void k_export(const uint32_t *__restrict__ X, int64_t stride_dw, int64_t p,
+// out is column-major with `ndw` dwords per column
+__global__ void k_export(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, int64_t p, int64_t ndw,
                          uint32_t *__restrict__ out)
 {
-    int64_t total = p * stride_dw;
+    int64_t total = ncg * nbp * 64;
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < total; i += stride) {
-        uint32_t d = X[i];
-        uint32_t nz = (d | (d >> 1)) & 0x55555555u;   // dosage != 0
-        uint32_t two = (d >> 1) & 0x55555555u;        // dosage == 2
-        out[i] = (nz << 1) | two;                     // 0->00, 1->10, 2->11
+        int lane = (int)(i & 63), m = lane & 31, h = lane >> 5;
+        int64_t tile = i >> 6, cg = tile / nbp, bp = tile - cg * nbp, j = cg * 32 + m;
+        if (j >= p) continue;
+        uint4 v = X[i];
+        uint32_t d[4] = {v.x, v.y, v.z, v.w};
+        #pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int64_t t = bp * 8 + (q >> 1) * 4 + h * 2 + (q & 1);
+            uint32_t nz = (d[q] | (d[q] >> 1)) & 0x55555555u;   // dosage != 0
+            uint32_t two = (d[q] >> 1) & 0x55555555u;           // dosage == 2
+            out[j * ndw + t] = (nz << 1) | two;                 // 0->00, 1->10, 2->11
+        }
     }
 }
 
-__global__ void k_export_missing(uint32_t *__restrict__ out, int64_t stride_dw, int64_t p,
+__global__ void k_export_missing(uint32_t *__restrict__ out, int64_t ndw, int64_t p,
                                  const int64_t *__restrict__ miss_ptr, const int32_t *__restrict__ miss_row)
 {
     int64_t j = blockIdx.x;
     if (j >= p) return;
     for (int64_t t = miss_ptr[j] + threadIdx.x; t < miss_ptr[j + 1]; t += blockDim.x) {
         int32_t i = miss_row[t];
-        atomicOr(&out[j * stride_dw + (i >> 4)], 1u << (2 * (i & 15)));
+        atomicOr(&out[j * ndw + (i >> 4)], 1u << (2 * (i & 15)));
     }
 }
 
@@ -259,9 +273,10 @@ static int finish_missing_ptr(mih_mat *h, const std::vector<int32_t> &cnt, std::
 
 static int alloc_snp(mih_mat *h)
 {
-    h->stride_dw = round_up((h->n + 15) / 16, 256);   // 1 KB: whole superchunks for every load width
-    h->n_pad = h->stride_dw * 16;
-    size_t bytes = sizeof(uint32_t) * (size_t)h->p * (size_t)h->stride_dw;
+    h->ncg = (h->p + 31) / 32;
+    h->nbp = (h->n + 127) / 128;
+    h->n_pad = h->nbp * 128;
+    size_t bytes = sizeof(uint4) * (size_t)h->ncg * (size_t)h->nbp * 64;
     hipError_t e = hipMalloc((void **)&h->X, bytes);
     if (e != hipSuccess) { set_error("hipMalloc of %zu bytes for the genotype matrix failed: %s", bytes, hipGetErrorString(e)); return MIH_OOM; }
     MIH_HIP(hipMalloc((void **)&h->mu, sizeof(double) * (size_t)h->p));
@@ -329,17 +344,19 @@ int mih_snp_create(const uint8_t *bed_cols, int64_t n, int64_t p, int64_t col_st
 
     // stage raw columns through a bounded device buffer
     const int64_t chunk_bytes = 256ll << 20;
-    int64_t cols_per_chunk = chunk_bytes / col_stride_bytes;
-    if (cols_per_chunk < 1) cols_per_chunk = 1;
-    if (cols_per_chunk > p) cols_per_chunk = p;
+    int64_t cols_per_chunk = chunk_bytes / col_stride_bytes / 32 * 32;   // whole column groups
+    if (cols_per_chunk < 32) cols_per_chunk = 32;
+    if (cols_per_chunk > round_up(p, 32)) cols_per_chunk = round_up(p, 32);
     DevBuf<uint8_t> raw; DevBuf<int32_t> cnt;
     if ((rc = raw.alloc((size_t)(cols_per_chunk * col_stride_bytes))) || (rc = cnt.alloc((size_t)(3 * p)))) { mih_mat_destroy(h); return rc; }
     auto fail = [&](int code) { mih_mat_destroy(h); return code; };
+    if (hipMemsetAsync(cnt.p, 0, sizeof(int32_t) * 3 * (size_t)p, h->stream) != hipSuccess) return fail(MIH_HIP_ERROR);
     for (int64_t c0 = 0; c0 < p; c0 += cols_per_chunk) {
         int64_t nc = (p - c0 < cols_per_chunk) ? p - c0 : cols_per_chunk;
         if (hipMemcpy(raw.p, bed_cols + c0 * col_stride_bytes, (size_t)(nc * col_stride_bytes), hipMemcpyHostToDevice) != hipSuccess) return fail(MIH_HIP_ERROR);
-        int grid = (int)(nc < 65535 ? nc : 65535);
-        hipLaunchKernelGGL(k_transcode, dim3(grid), dim3(256), 0, h->stream, raw.p, col_stride_bytes, n, nc, h->X, h->stride_dw, c0, cnt.p);
+        dim3 grid((unsigned)((h->nbp + kBpPerBlock - 1) / kBpPerBlock), (unsigned)((nc + 31) / 32));
+        hipLaunchKernelGGL(k_transcode, grid, dim3(256), 0, h->stream, raw.p, col_stride_bytes, n, p, c0, nc,
+                           reinterpret_cast<uint4 *>(h->X), h->nbp, cnt.p);
         if (hipStreamSynchronize(h->stream) != hipSuccess) { set_error("transcode kernel failed"); return fail(MIH_HIP_ERROR); }
     }
     hipLaunchKernelGGL(k_col_stats, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, h->stream, cnt.p, n, p, h->mu, h->sinv);
@@ -377,8 +394,9 @@ int mih_snp_create_synthetic(int64_t n, int64_t p, uint64_t seed, double missing
     DevBuf<int32_t> cnt;
     if ((rc = cnt.alloc((size_t)(3 * p)))) return fail(rc);
     uint32_t miss_thr = (uint32_t)(missing_rate * 4294967296.0);
-    int grid = (int)(p < 16384 ? p : 16384);
-    hipLaunchKernelGGL(k_synth, dim3(grid), dim3(256), 0, h->stream, h->X, h->stride_dw, n, p, seed, miss_thr, cnt.p);
+    if (hipMemsetAsync(cnt.p, 0, sizeof(int32_t) * 3 * (size_t)p, h->stream) != hipSuccess) return fail(MIH_HIP_ERROR);
+    dim3 grid((unsigned)((h->nbp + kBpPerBlock - 1) / kBpPerBlock), (unsigned)h->ncg);
+    hipLaunchKernelGGL(k_synth, grid, dim3(256), 0, h->stream, reinterpret_cast<uint4 *>(h->X), h->nbp, n, p, seed, miss_thr, cnt.p);
     hipLaunchKernelGGL(k_col_stats, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, h->stream, cnt.p, n, p, h->mu, h->sinv);
     if (hipStreamSynchronize(h->stream) != hipSuccess) { set_error("synthetic generator failed: %s", hipGetErrorString(hipGetLastError())); return fail(MIH_HIP_ERROR); }
     std::vector<int32_t> hcnt((size_t)(3 * p));
@@ -461,13 +479,14 @@ int mih_snp_export_bed(const mih_mat *h, uint8_t *bed_cols_out)
     if (!h || h->kind != 0 || !bed_cols_out) return MIH_BAD_ARG;
     MIH_HIP(hipSetDevice(h->device));
     DevBuf<uint32_t> tmp;
-    MIH_TRY(tmp.alloc((size_t)h->p * (size_t)h->stride_dw));
-    hipLaunchKernelGGL(k_export, dim3(4096), dim3(256), 0, h->stream, h->X, h->stride_dw, h->p, tmp.p);
+    int64_t ndw = h->n_pad / 16;
+    MIH_TRY(tmp.alloc((size_t)h->p * (size_t)ndw));
+    hipLaunchKernelGGL(k_export, dim3(4096), dim3(256), 0, h->stream, reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, h->p, ndw, tmp.p);
     if (h->total_missing > 0)
-        hipLaunchKernelGGL(k_export_missing, dim3((unsigned)h->p), dim3(64), 0, h->stream, tmp.p, h->stride_dw, h->p, h->miss_ptr, h->miss_row);
+        hipLaunchKernelGGL(k_export_missing, dim3((unsigned)h->p), dim3(64), 0, h->stream, tmp.p, ndw, h->p, h->miss_ptr, h->miss_row);
     MIH_HIP(hipStreamSynchronize(h->stream));
     size_t width = (size_t)((h->n + 3) / 4);
-    MIH_HIP(hipMemcpy2D(bed_cols_out, width, tmp.p, (size_t)h->stride_dw * 4, width, (size_t)h->p, hipMemcpyDeviceToHost));
+    MIH_HIP(hipMemcpy2D(bed_cols_out, width, tmp.p, (size_t)ndw * 4, width, (size_t)h->p, hipMemcpyDeviceToHost));
     return MIH_OK;
 }
 

@@ -1,20 +1,33 @@
-// xtv.hip -- out = X' r over the 2-bit genotype matrix: the hot loop of the IHT
-// iteration.  Replaces `mul!(v.df, Transpose(x), v.r)` (src/utilities.jl:133;
-// SnpArrays.jl linalg_direct.jl `_snparray_AtX_*` kernels) and, batched,
-// `SnpArrays.mul!(p_by_r, Transpose(sla), n_by_r)` (src/multivariate.jl:85).
+// xtv.hip -- out = X' r over the 2-bit genotype matrix: the hot loop of the IHT iteration.
+// Replaces `mul!(v.df, Transpose(x), v.r)` (src/utilities.jl:133; SnpArrays.jl linalg_direct.jl
+// `_snparray_AtX_*` kernels) and, batched, `SnpArrays.mul!(p_by_r, Transpose(sla), n_by_r)`
+// (src/multivariate.jl:85).
 //
 //   out_j = sinv_j * ( sum_i g_ij r_i  [+ mu_j * sum_{i missing in j} r_i]  - mu_j * sum_i r_i )
 //
-// Kernel shape (bandwidth-first, no MFMA): a wave owns C SNP columns and walks the
-// rows in chunks of 1024 (64 lanes x one dword = 16 dosages per lane); each
-// wave-load is one aligned 256-B segment of a column.  The residual tile for the
-// same rows sits in LDS, shared by the workgroup's waves, in a lane-major
-// permutation so every ds_read_b128 is conflict-free.  Dosage -> double without
-// a convert: the 2-bit field is dropped into the top mantissa bits of 2.0, so
-// d = 2 + g/2 and  sum d*r = 2*sum r + (1/2) sum g*r; the constant part is
-// removed in the finalize kernel.  Row range can be split over `splits` slices
-// (slice = blockIdx % splits, so one XCD keeps re-reading one slice of r from
-// its own L2); partials are combined in fixed order => bit-reproducible.
+// Why this is not a plain f64 FMA loop.  Measured on MI355X (tools/instbench.hip): a wave64
+// v_fma_f64 costs 2.2 ns per SIMD and the cheapest dosage->double decode (one SDWA byte-select AND)
+// 1.85 ns, so a decode+FMA kernel tops out at ~4.0 TB/s of 2-bit data (50 % of the HBM peak) with
+// the memory system half idle (the round-1 VALU kernel reached 3.5 TB/s).  The dosage matrix is
+// exact small-integer data, so the dot products are done EXACTLY in fixed point on the matrix pipe:
+//   * a 2-bit dosage code placed in the low bits of a nibble IS the FP4 (e2m1) number g/2, so the
+//     A operand of v_mfma_scale_f32_32x32x64_f8f6f4 is built with one AND per 8 dosages;
+//   * r is scaled by a power of two to |R| < 2^54, rounded to an integer and written as 28 balanced
+//     base-4 digits d in {-2,-1,0,1} (FP4 values -1, -0.5, 0, 0.5); the 28 digit planes are 28 of
+//     the 32 B-operand columns, so ONE MFMA multiplies a 32-column x 64-row dosage tile with all
+//     digits of the residual;
+//   * every product and every partial sum is a multiple of 1/4 below 2^22 in magnitude, so the f32
+//     accumulators are exact and the result does not depend on summation order (bit-reproducible);
+//   * the digit sums are recombined in f64 (sum_t 4^t * S_t, fixed order) and rescaled by 2^-e.
+// The only inexact step is the rounding of r to 2^-55 of max|r| -- tighter than the rounding an
+// n-term f64 dot product accumulates.  Per 2048 dosages: 1 MFMA (13.7 ns/SIMD) + ~8 VALU ops, far
+// below the 87 ns/SIMD the HBM stream allows at 6 TB/s, so the kernel is memory-bound.
+//
+// Work decomposition: a wave owns CT column groups (32 SNPs each) and walks a slice of the rows in
+// 128-row steps; per step it loads CT x 1 KB of dosages (one contiguous 16 B/lane wave-load per
+// tile) and the 2 KB of digit planes for those rows (L2-resident, shared by all waves).  Rows are
+// split in `splits` slices (slice = blockIdx % splits: the blocks of one XCD share a slice of the
+// digit planes in their L2); slice partials are combined in fixed order by the finalize kernel.
 #include "common.h"
 #include <mutex>
 #include <utility>
@@ -45,255 +58,178 @@ static void prof_end(hipStream_t s, hipEvent_t e0, hipEvent_t e1)
     g_prof_events.emplace_back(e0, e1);
 }
 
-__global__ void k_permute_r(const double *__restrict__ r, int64_t n, int64_t n_perm, int m, int lw,
-                            double *__restrict__ rperm)
-{
-    int64_t total = n_perm * m;
-    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; t < total; t += stride) {
-        int64_t v = t / n_perm, i = t - v * n_perm;
-        rperm[v * n_perm + rperm_pos(i, lw)] = (i < n) ? r[v * n + i] : 0.0;
-    }
-}
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 
-// carrier[v][s] = sum of r over the rows of slice s (fixed order per block => deterministic)
+// ---- residual -> fixed-point digit planes -------------------------------------------------
+// scal[4v + 0] = max|r_v|, scal[4v + 1] = 2^-e, scal[4v + 2] = sum r_v, scal[4v + 3] = 2^e
 __global__ void __launch_bounds__(256)
-k_slice_sums(const double *__restrict__ rperm, int64_t n_perm, int64_t nsc, int rows_per_sc, int splits,
-             double *__restrict__ carrier)
+k_r_stats(const double *__restrict__ r, int64_t n, int m, double *__restrict__ part /* [m][gridDim.x][2] */)
 {
-    __shared__ double red[256];
-    int s = blockIdx.x % splits, v = blockIdx.x / splits;
-    int64_t sps = (nsc + splits - 1) / splits;
-    int64_t c0 = s * sps, c1 = c0 + sps < nsc ? c0 + sps : nsc;
-    const double *src = rperm + v * n_perm;
-    double a = 0.0;
-    for (int64_t i = c0 * rows_per_sc + threadIdx.x; i < c1 * rows_per_sc; i += 256) a += src[i];
-    red[threadIdx.x] = a;
-    __syncthreads();
-    for (int k = 128; k > 0; k >>= 1) {
-        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __shared__ double smax[256], ssum[256];
+    for (int v = 0; v < m; ++v) {
+        double mx = 0.0, sm = 0.0;
+        for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+            double x = r[(int64_t)v * n + i];
+            mx = fmax(mx, fabs(x)); sm += x;
+        }
+        smax[threadIdx.x] = mx; ssum[threadIdx.x] = sm;
+        __syncthreads();
+        for (int k = 128; k > 0; k >>= 1) {
+            if ((int)threadIdx.x < k) { smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + k]); ssum[threadIdx.x] += ssum[threadIdx.x + k]; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { part[((int64_t)v * gridDim.x + blockIdx.x) * 2] = smax[0]; part[((int64_t)v * gridDim.x + blockIdx.x) * 2 + 1] = ssum[0]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) carrier[v * splits + s] = red[0];
 }
 
-// ---- decode + FMA for one dword (16 dosages) -------------------------------------
-// MODE 0: bit-field extract + v_cvt_f64_u32 (plain baseline)         acc = sum g r
-// MODE 1: shift + and_or into the mantissa of 2.0                    acc = sum (2+g/2) r
-// MODE 2: three word shifts + one SDWA byte-select AND per dosage    acc = sum (2+g/2) r
-// MODE 3: load-only probe (bench only; results are meaningless)
-struct DecodePairs { double d[4]; };   // persistent {lo = 0, hi = 0x40000000 | g << 18} register pairs
-
-template <int MODE>
-__device__ __forceinline__ void dot16(uint32_t w, const double (&r)[16], double &acc, DecodePairs &dp);
-
-template <>
-__device__ __forceinline__ void dot16<0>(uint32_t w, const double (&r)[16], double &acc, DecodePairs &)
+__global__ void k_r_stats_final(const double *__restrict__ part, int nblocks, int m, double *__restrict__ scal)
 {
-    #pragma unroll
-    for (int s = 0; s < 16; ++s) acc = fma((double)((w >> (2 * s)) & 3u), r[s], acc);
+    int v = blockIdx.x;
+    if (threadIdx.x != 0 || v >= m) return;
+    double mx = 0.0, sm = 0.0;
+    for (int b = 0; b < nblocks; ++b) { mx = fmax(mx, part[((int64_t)v * nblocks + b) * 2]); sm += part[((int64_t)v * nblocks + b) * 2 + 1]; }
+    // exponent e with max|r| * 2^e < 2^54 ; an all-zero (or non-finite) residual keeps e = 0
+    int e = 0;
+    if (mx > 0.0 && mx < 1.0e300) e = 53 - ilogb(mx);
+    scal[4 * v + 0] = mx;
+    scal[4 * v + 1] = ldexp(1.0, -e);
+    scal[4 * v + 2] = sm;
+    scal[4 * v + 3] = ldexp(1.0, e);
 }
 
-template <>
-__device__ __forceinline__ void dot16<1>(uint32_t w, const double (&r)[16], double &acc, DecodePairs &)
+// One thread per (64-row block, lane = 32*h + t): digit t of the 32 rows of half h, packed as the
+// FP4 B-operand fragment (element order identical to the A fragment built in k_xtv_mfma).
+__global__ void __launch_bounds__(256)
+k_digits(const double *__restrict__ r, int64_t n, int64_t nblk, int m, const double *__restrict__ scal,
+         uint4 *__restrict__ dig /* [m][nblk][64] */)
 {
-    #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-        uint32_t sh = (s <= 9) ? (w << (18 - 2 * s)) : (w >> (2 * s - 18));
-        uint32_t hi = (sh & 0x000C0000u) | 0x40000000u;
-        acc = fma(__hiloint2double((int)hi, 0), r[s], acc);
+    int64_t gid = blockIdx.x * 256ll + threadIdx.x;
+    int64_t total = (int64_t)m * nblk * 64;
+    if (gid >= total) return;
+    int lane = (int)(gid & 63), t = lane & 31, h = lane >> 5;
+    int64_t vb = gid >> 6, v = vb / nblk, blk = vb - v * nblk;
+    uint32_t out[4] = {0u, 0u, 0u, 0u};
+    if (t < kDigits) {
+        const double sc = scal[4 * v + 3];
+        const double *rv = r + v * n;
+        int64_t row0 = blk * 64 + h * 32;
+        #pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            #pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                int64_t i = row0 + u * 16 + s;
+                double x = (i < n) ? rv[i] : 0.0;
+                long long R = __double2ll_rn(x * sc);
+                unsigned long long U = (unsigned long long)(R + 0xAAAAAAAAAAAAAALL);   // all 28 digits + 2
+                uint32_t d = (uint32_t)(U >> (2 * t)) & 3u;                              // digit + 2 in 0..3
+                uint32_t code = (0x109Au >> (4 * d)) & 0xFu;                             // -1, -0.5, 0, +0.5 in FP4
+                out[2 * u + (s & 1)] |= code << (4 * (s >> 1));
+            }
+        }
     }
+    dig[gid] = make_uint4(out[0], out[1], out[2], out[3]);
 }
 
-// The SDWA AND writes (byte K of SRC) & 0x0C into byte 2 of the high word of D and preserves the
-// other three bytes, so D keeps {lo = 0, byte 3 = 0x40} for the whole kernel: no re-initialisation.
-#define MIH_SDWA_UPD(D, SRC, BYTE)                                                               \
-    {                                                                                              \
-        uint32_t h_ = (uint32_t)__double2hiint(D);                                                 \
-        asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE "                  \
-            "src0_sel:BYTE_" #BYTE " src1_sel:DWORD" : "+v"(h_) : "v"(SRC), "v"(mask));            \
-        D = __hiloint2double((int)h_, __double2loint(D));                                          \
-    }
-
-template <>
-__device__ __forceinline__ void dot16<2>(uint32_t w, const double (&r)[16], double &acc, DecodePairs &dp)
+// ---- the matrix-pipe kernel -------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// dosage tiles are read exactly once per pass: stream them past the caches (nt), so the digit
+// planes every wave re-reads stay resident in L2
+__device__ __forceinline__ uint4 ld_stream(const uint4 *p)
 {
-    // slot q of byte K holds row 4K+q; shift slot q onto bits 2-3 of its byte once per dword.
-    const uint32_t mask = 0x0Cu;
-    uint32_t w0 = w << 2, w2 = w >> 2, w3 = w >> 4;
-#define MIH_BYTE(K)                                                                               \
-    MIH_SDWA_UPD(dp.d[0], w0, K) MIH_SDWA_UPD(dp.d[1], w, K)                                      \
-    MIH_SDWA_UPD(dp.d[2], w2, K) MIH_SDWA_UPD(dp.d[3], w3, K)                                     \
-    acc = fma(dp.d[0], r[4 * K + 0], acc); acc = fma(dp.d[1], r[4 * K + 1], acc);                  \
-    acc = fma(dp.d[2], r[4 * K + 2], acc); acc = fma(dp.d[3], r[4 * K + 3], acc);
-    MIH_BYTE(0) MIH_BYTE(1) MIH_BYTE(2) MIH_BYTE(3)
-#undef MIH_BYTE
+    u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-// Probes (bench only, ids 100+): 3 = loads + LDS + barriers without the decode/FMA work,
-// 4 = real decode/FMA + genotype loads but r from registers (no LDS, no staging, no barriers),
-// 5 = real decode/FMA + LDS but no genotype loads.
-template <>
-__device__ __forceinline__ void dot16<3>(uint32_t w, const double (&r)[16], double &acc, DecodePairs &)
+__device__ __forceinline__ f32x16 mfma_fp4(uint32_t u0, uint32_t u1, const uint4 &b, f32x16 acc)
 {
-    acc += __hiloint2double((int)(w & 0x000FFFFFu) | 0x3FF00000, 0) * r[0];
-}
-template <>
-__device__ __forceinline__ void dot16<4>(uint32_t w, const double (&r)[16], double &acc, DecodePairs &dp)
-{
-    dot16<2>(w, r, acc, dp);
-}
-template <>
-__device__ __forceinline__ void dot16<5>(uint32_t w, const double (&r)[16], double &acc, DecodePairs &dp)
-{
-    dot16<2>(w, r, acc, dp);
+    const uint32_t M = 0x33333333u;
+    i32x8 a = {(int)(u0 & M), (int)((u0 >> 2) & M), (int)(u1 & M), (int)((u1 >> 2) & M), 0, 0, 0, 0};
+    i32x8 bb = {(int)b.x, (int)b.y, (int)b.z, (int)b.w, 0, 0, 0, 0};
+    // cbsz = blgp = 4: A and B are FP4 (e2m1); E8M0 scales 127 = 2^0
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bb, acc, 4, 4, 0, 127, 0, 127);
 }
 
-__device__ __forceinline__ double wave_sum(double v)
-{
-    #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-template <int LW> struct LoadVec;
-template <> struct LoadVec<1> { using type = uint32_t; };
-template <> struct LoadVec<2> { using type = uint2; };
-template <> struct LoadVec<4> { using type = uint4; };
-__device__ __forceinline__ uint32_t vec_get(uint32_t v, int) { return v; }
-__device__ __forceinline__ uint32_t vec_get(const uint2 &v, int d) { return d == 0 ? v.x : v.y; }
-__device__ __forceinline__ uint32_t vec_get(const uint4 &v, int d) { return d == 0 ? v.x : d == 1 ? v.y : d == 2 ? v.z : v.w; }
-
-// WAVES waves x C columns per workgroup.  A lane loads LW consecutive dwords (16*LW rows) of a
-// column per "superchunk" of 1024*LW rows, so one wave-load is 256*LW contiguous bytes; TSC
-// superchunks of r are staged per LDS buffer (double-buffered).
-template <int WAVES, int C, int LW, int TSC, int MODE>
+template <int WAVES, int CT>
 __global__ void __launch_bounds__(WAVES * 64)
-k_xtv(const uint32_t *__restrict__ X, int64_t stride_dw, int64_t p,
-      const double2 *__restrict__ rperm, int64_t nsc, int splits,
-      double *__restrict__ partial /* [splits][p] */)
+k_xtv_mfma(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *__restrict__ dig,
+           int splits, const double *__restrict__ scal, double *__restrict__ partial /* [splits][ncg*32] */)
 {
-    using Vec = typename LoadVec<LW>::type;
-    constexpr int VC = TSC * LW;                  // 1024-row virtual chunks per stage
-    __shared__ double2 tile[2][VC * 512];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int split = blockIdx.x % splits;
-    const int64_t cg = blockIdx.x / splits;
-    const int64_t sps = (nsc + splits - 1) / splits;
-    const int64_t c0 = split * sps;
-    const int64_t c1 = (c0 + sps < nsc) ? c0 + sps : nsc;
-    const int64_t j0 = cg * (WAVES * C) + wave * C;
+    const int64_t grp = blockIdx.x / splits;
+    const int64_t cg0 = (grp * WAVES + wave) * CT;
+    if (cg0 >= ncg) return;
+    const int64_t bps = (nbp + splits - 1) / splits;
+    const int64_t b0 = split * bps;
+    const int64_t b1 = (b0 + bps < nbp) ? b0 + bps : nbp;
 
-    const Vec *col[C];
+    f32x16 acc[CT];
     #pragma unroll
-    for (int c = 0; c < C; ++c) {
-        int64_t j = j0 + c < p ? j0 + c : p - 1;
-        col[c] = reinterpret_cast<const Vec *>(X + j * stride_dw) + lane;
-    }
-    double acc[C];
-    #pragma unroll
-    for (int c = 0; c < C; ++c) acc[c] = 0.0;
-    DecodePairs dp;
-    #pragma unroll
-    for (int t = 0; t < 4; ++t) dp.d[t] = 2.0;
-
-    // r-tile staging is split (issue the global loads early, store to LDS late) so that the loads'
-    // latency hides under the decode/FMA work of the current stage instead of stalling its start.
-    constexpr int NST = (VC * 512) / (WAVES * 64);
-    static_assert((VC * 512) % (WAVES * 64) == 0, "stage must divide evenly over the workgroup");
-    double2 sreg[NST];
-    auto stage_load = [&](int64_t cbase) {
+    for (int c = 0; c < CT; ++c)
         #pragma unroll
-        for (int k = 0; k < NST; ++k) {
-            int t = threadIdx.x + k * (WAVES * 64);
-            int64_t sc = cbase + t / (512 * LW);
-            sreg[k] = make_double2(0.0, 0.0);
-            if (sc < c1) sreg[k] = rperm[cbase * (512 * LW) + t];
+        for (int g = 0; g < 16; ++g) acc[c][g] = 0.f;
+
+    if (b0 < b1) {
+        const uint4 *ap[CT];
+        #pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            int64_t cg = cg0 + c < ncg ? cg0 + c : ncg - 1;
+            ap[c] = X + (cg * nbp) * 64 + lane;
         }
-    };
-    auto stage_store = [&](int buf) {
+        const uint4 *bp_ = dig + lane;
+        uint4 acur[CT], anext[CT], bcur[2], bnext[2];
         #pragma unroll
-        for (int k = 0; k < NST; ++k) tile[buf][threadIdx.x + k * (WAVES * 64)] = sreg[k];
-    };
-
-    constexpr bool kUseLds = (MODE != 4);        // probe 4: r from registers, no staging / barriers
-    constexpr bool kUseGlobal = (MODE != 5);     // probe 5: no genotype loads
-    if (c0 < c1) {
-        Vec wcur[C], wnext[C];
-        #pragma unroll
-        for (int c = 0; c < C; ++c) wcur[c] = col[c][c0 * 64];
-        if (kUseLds) {
-            stage_load(c0);
-            stage_store(0);
-            __syncthreads();
-        }
-        int buf = 0;
-        for (int64_t cbase = c0; cbase < c1; cbase += TSC) {
-            const bool more = cbase + TSC < c1;
-            if (kUseLds && more) stage_load(cbase + TSC);
-            const int nsc_here = (c1 - cbase < TSC) ? (int)(c1 - cbase) : TSC;
-            for (int sc = 0; sc < nsc_here; ++sc) {
-                const int64_t cc = cbase + sc;
-                const int64_t cn = (cc + 1 < c1) ? cc + 1 : cc;   // prefetch the next superchunk
-                if (kUseGlobal) {
-                    #pragma unroll
-                    for (int c = 0; c < C; ++c) wnext[c] = col[c][cn * 64];
-                }
-                #pragma unroll
-                for (int d = 0; d < LW; ++d) {
-                    double r[16];
-                    if (kUseLds) {
-                        #pragma unroll
-                        for (int m = 0; m < 8; ++m) {
-                            double2 v = tile[buf][((sc * LW + d) * 8 + m) * 64 + lane];
-                            r[2 * m] = v.x; r[2 * m + 1] = v.y;
-                        }
-                    } else {
-                        #pragma unroll
-                        for (int m = 0; m < 16; ++m) r[m] = 1.0 + 0.125 * m + lane;
-                    }
-                    #pragma unroll
-                    for (int c = 0; c < C; ++c) dot16<MODE>(vec_get(wcur[c], d), r, acc[c], dp);
-                }
-                if (kUseGlobal) {
-                    #pragma unroll
-                    for (int c = 0; c < C; ++c) wcur[c] = wnext[c];
-                } else {
-                    #pragma unroll
-                    for (int c = 0; c < C; ++c) asm volatile("" : "+v"(wcur[c]));   // keep the decode work alive
-                }
+        for (int c = 0; c < CT; ++c) acur[c] = ld_stream(ap[c] + b0 * 64);
+        bcur[0] = bp_[(2 * b0) * 64]; bcur[1] = bp_[(2 * b0 + 1) * 64];
+        for (int64_t bp = b0; bp < b1; ++bp) {
+            const int64_t bn = (bp + 1 < b1) ? bp + 1 : bp;
+            #pragma unroll
+            for (int c = 0; c < CT; ++c) anext[c] = ld_stream(ap[c] + bn * 64);
+            bnext[0] = bp_[(2 * bn) * 64]; bnext[1] = bp_[(2 * bn + 1) * 64];
+            #pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                acc[c] = mfma_fp4(acur[c].x, acur[c].y, bcur[0], acc[c]);
+                acc[c] = mfma_fp4(acur[c].z, acur[c].w, bcur[1], acc[c]);
             }
-            if (kUseLds) {
-                if (more) stage_store(buf ^ 1);
-                __syncthreads();
-            }
-            buf ^= 1;
+            #pragma unroll
+            for (int c = 0; c < CT; ++c) acur[c] = anext[c];
+            bcur[0] = bnext[0]; bcur[1] = bnext[1];
         }
     }
+
+    // D layout: column n = lane & 31 (digit), row (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5) (SNP).
+    // acc = (1/4) sum_i g_i d_i exactly; recombine digits: sum_t 4^t * (4 acc_t), then * 2^-e.
+    const int dgt = lane & 31;
+    const double wgt = (dgt < kDigits) ? ldexp(1.0, 2 + 2 * dgt) : 0.0;
+    const double inv = scal[1];
     #pragma unroll
-    for (int c = 0; c < C; ++c) {
-        double v = wave_sum(acc[c]);
-        if (lane == 0 && j0 + c < p) partial[(int64_t)split * p + j0 + c] = v;
+    for (int c = 0; c < CT; ++c) {
+        #pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            double v = (double)acc[c][g] * wgt;
+            #pragma unroll
+            for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);   // within each 32-lane half
+            int row = (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
+            if (dgt == 0 && cg0 + c < ncg) partial[(int64_t)split * (ncg * 32) + (cg0 + c) * 32 + row] = v * inv;
+        }
     }
 }
 
-// Combine slices, undo the mantissa offset, add the missing-entry correction, centre, scale.
+// Combine slices, add the missing-entry correction, centre, scale.
 __global__ void __launch_bounds__(256)
-k_xtv_finalize(const double *__restrict__ partial, const double *__restrict__ carrier, int splits,
-               double scaleA, double scaleB, int64_t p, const double *__restrict__ r,
+k_xtv_finalize(const double *__restrict__ partial, int splits, int64_t pstride, int64_t p,
+               const double *__restrict__ scal, const double *__restrict__ r,
                const double *__restrict__ mu, const double *__restrict__ sinv,
                const int64_t *__restrict__ miss_ptr, const int32_t *__restrict__ miss_row,
                int center, int scale, int impute, double *__restrict__ out)
 {
     int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (j >= p) return;
-    double dot = 0.0, sumr = 0.0;
-    for (int s = 0; s < splits; ++s) {
-        dot += scaleA * partial[(int64_t)s * p + j] - scaleB * carrier[s];
-        sumr += carrier[s];
-    }
+    double dot = 0.0;
+    for (int s = 0; s < splits; ++s) dot += partial[(int64_t)s * pstride + j];
     double m = mu[j];
     if (impute) {
         int64_t a = miss_ptr[j], b = miss_ptr[j + 1];
@@ -303,12 +239,19 @@ k_xtv_finalize(const double *__restrict__ partial, const double *__restrict__ ca
             dot += m * ms;
         }
     }
-    if (center) dot -= m * sumr;
+    if (center) dot -= m * scal[2];
     if (scale) dot *= sinv[j];
     out[j] = dot;
 }
 
 // ---- dense design matrix: out_j = sum_i D[i,j] r_i (one wave per column) ---------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+    #pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
 __global__ void __launch_bounds__(256)
 k_xtv_dense(const double *__restrict__ D, int64_t n, int64_t p, const double *__restrict__ r,
             double *__restrict__ out)
@@ -332,72 +275,60 @@ k_xtv_dense(const double *__restrict__ D, int64_t n, int64_t p, const double *__
     if (lane == 0) out[j] = s;
 }
 
-struct Variant { int waves, c, lw, tsc, mode, splits; };
+struct Variant { int waves, ct, splits; };
 static const Variant kVariants[] = {
-    {4, 8, 1, 2, 2, 8},    // 0: SDWA decode, dword loads, 8 XCD-affine row slices
-    {4, 8, 1, 2, 1, 8},    // 1: shift+and_or decode
-    {4, 8, 1, 2, 0, 8},    // 2: cvt baseline
-    {4, 8, 1, 2, 2, 1},    // 3: no row slicing
-    {8, 8, 1, 2, 2, 8},    // 4: 8 waves
-    {4, 4, 1, 2, 2, 8},    // 5
-    {4, 16, 1, 2, 2, 8},   // 6
-    {8, 4, 1, 2, 2, 8},    // 7
-};
-// ids 100+: load-only probes of the same access pattern (bench only; numerically meaningless)
-static const Variant kProbes[] = {
-    {4, 8, 1, 2, 3, 8},    // 100: loads + LDS, no decode/FMA
-    {4, 8, 1, 2, 4, 8},    // 101: loads + decode/FMA, no LDS
-    {4, 8, 1, 2, 5, 8},    // 102: LDS + decode/FMA, no genotype loads
-    {8, 8, 1, 2, 4, 8},    // 103
-    {4, 4, 1, 2, 4, 8},    // 104
+    {4, 2, 8},    // 0
+    {4, 1, 8},    // 1
+    {4, 4, 8},    // 2: default
+    {8, 2, 8},    // 3
+    {8, 1, 8},    // 4
+    {4, 2, 1},    // 5: no row slicing
+    {4, 1, 1},    // 6
+    {4, 4, 1},    // 7
+    {4, 2, 16},   // 8
+    {2, 2, 8},    // 9
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
-constexpr int kNumProbes = sizeof(kProbes) / sizeof(kProbes[0]);
-constexpr int kDefaultVariant = 0;
+constexpr int kDefaultVariant = 2;
+constexpr int kMaxSplits = 16;
 int xtv_num_variants() { return kNumVariants; }
-bool xtv_variant_valid(int v) { return v < kNumVariants || (v >= 100 && v < 100 + kNumProbes); }
+static bool xtv_variant_valid(int v) { return v < kNumVariants; }
 
 static Variant current_variant()
 {
     int v = g_xtv_variant;
-    if (v >= 100 && v < 100 + kNumProbes) return kProbes[v - 100];
     if (v < 0 || v >= kNumVariants) v = kDefaultVariant;
     return kVariants[v];
 }
-int xtv_current_lw() { return current_variant().lw; }
 
-template <int WAVES, int C, int LW, int TSC, int MODE>
-static void launch_xtv(const mih_mat *h, const double *rperm, int64_t nsc, int splits,
-                       double *partial, hipStream_t s)
+template <int WAVES, int CT>
+static void launch_xtv(const mih_mat *h, const uint4 *dig, int splits, const double *scal, double *partial, hipStream_t s)
 {
-    int64_t groups = (h->p + WAVES * C - 1) / (WAVES * C);
-    dim3 grid((unsigned)(groups * splits));
-    hipLaunchKernelGGL((k_xtv<WAVES, C, LW, TSC, MODE>), grid, dim3(WAVES * 64), 0, s, h->X, h->stride_dw, h->p,
-                       reinterpret_cast<const double2 *>(rperm), nsc, splits, partial);
+    int64_t groups = (h->ncg + WAVES * CT - 1) / (WAVES * CT);
+    hipLaunchKernelGGL((k_xtv_mfma<WAVES, CT>), dim3((unsigned)(groups * splits)), dim3(WAVES * 64), 0, s,
+                       reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, splits, scal, partial);
 }
 
-static int dispatch_xtv(const Variant &v, const mih_mat *h, const double *rperm, int64_t nsc,
-                        int splits, double *partial, hipStream_t s)
+static int dispatch_xtv(const Variant &v, const mih_mat *h, const uint4 *dig, int splits, const double *scal,
+                        double *partial, hipStream_t s)
 {
-#define MIH_CASE(W, CC, L, T, M) \
-    if (v.waves == W && v.c == CC && v.lw == L && v.tsc == T && v.mode == M) { launch_xtv<W, CC, L, T, M>(h, rperm, nsc, splits, partial, s); return MIH_OK; }
-    MIH_CASE(4, 8, 1, 2, 2) MIH_CASE(4, 8, 1, 2, 1) MIH_CASE(4, 8, 1, 2, 0) MIH_CASE(8, 8, 1, 2, 2)
-    MIH_CASE(4, 4, 1, 2, 2) MIH_CASE(4, 16, 1, 2, 2)
-    MIH_CASE(4, 8, 1, 2, 3) MIH_CASE(4, 8, 1, 2, 4) MIH_CASE(4, 8, 1, 2, 5) MIH_CASE(8, 8, 1, 2, 4) MIH_CASE(4, 4, 1, 2, 4) MIH_CASE(8, 4, 1, 2, 2)
+#define MIH_CASE(W, C) if (v.waves == W && v.ct == C) { launch_xtv<W, C>(h, dig, splits, scal, partial, s); return MIH_OK; }
+    MIH_CASE(4, 1) MIH_CASE(4, 2) MIH_CASE(4, 4) MIH_CASE(8, 1) MIH_CASE(8, 2) MIH_CASE(2, 2)
 #undef MIH_CASE
     set_error("unknown X'r kernel variant");
     return MIH_BAD_ARG;
 }
 
+constexpr int kStatBlocks = 64;
+
 int xtv_work_init(const mih_mat *h, XtvWork &w, int m)
 {
     if (h->kind != 0) return MIH_OK;
-    int max_splits = 8;
-    w.n_perm = h->n_pad;
-    MIH_TRY(w.rperm.alloc((size_t)m * (size_t)w.n_perm));
-    MIH_TRY(w.partial.alloc((size_t)max_splits * (size_t)m * (size_t)h->p));
-    MIH_TRY(w.sums.alloc((size_t)m * (size_t)max_splits));
-    w.m_cap = m; w.splits_cap = max_splits;
+    int64_t nblk = h->nbp * 2;
+    MIH_TRY(w.digits.alloc((size_t)m * (size_t)nblk * 64 * 4));
+    MIH_TRY(w.partial.alloc((size_t)kMaxSplits * (size_t)m * (size_t)h->ncg * 32));
+    MIH_TRY(w.scal.alloc((size_t)m * 4 + (size_t)m * kStatBlocks * 2));
+    w.m_cap = m; w.splits_cap = kMaxSplits;
     return MIH_OK;
 }
 
@@ -411,29 +342,28 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
         return MIH_OK;
     }
     if (m > w.m_cap) { set_error("X'r workspace too small"); return MIH_BAD_ARG; }
-    hipLaunchKernelGGL(k_permute_r, dim3(1024), dim3(256), 0, s, r_dev, h->n, w.n_perm, m, xtv_current_lw(), w.rperm.p);
-    return xtv_device_preperm(h, w, r_dev, m, out_dev, s);
-}
-
-int xtv_device_preperm(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double *out_dev, hipStream_t s)
-{
     Variant v = current_variant();
-    int64_t nsc = h->stride_dw / (64 * v.lw);       // superchunks per column
     int splits = v.splits;
-    if (splits > nsc) splits = (int)nsc;
+    if (splits > h->nbp) splits = (int)h->nbp;
     if (splits > w.splits_cap) splits = w.splits_cap;
-    double A = (v.mode == 0) ? 1.0 : 2.0, B = (v.mode == 0) ? 0.0 : 4.0;
-    hipLaunchKernelGGL(k_slice_sums, dim3((unsigned)(splits * m)), dim3(256), 0, s, w.rperm.p, w.n_perm, nsc, 1024 * v.lw, splits, w.sums.p);
+    const int64_t nblk = h->nbp * 2, pstride = h->ncg * 32;
+    double *part = w.scal.p + (size_t)m * 4;
+    hipLaunchKernelGGL(k_r_stats, dim3(kStatBlocks), dim3(256), 0, s, r_dev, h->n, m, part);
+    hipLaunchKernelGGL(k_r_stats_final, dim3(m), dim3(64), 0, s, part, kStatBlocks, m, w.scal.p);
+    int64_t total = (int64_t)m * nblk * 64;
+    hipLaunchKernelGGL(k_digits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, r_dev, h->n, nblk, m, w.scal.p,
+                       reinterpret_cast<uint4 *>(w.digits.p));
     for (int t = 0; t < m; ++t) {
-        double *partial = w.partial.p + (int64_t)t * splits * h->p;
+        double *partial = w.partial.p + (int64_t)t * splits * pstride;
+        const uint4 *dig = reinterpret_cast<const uint4 *>(w.digits.p) + (int64_t)t * nblk * 64;
         hipEvent_t e0, e1;
         prof_begin(s, e0, e1);
-        int rc = dispatch_xtv(v, h, w.rperm.p + (int64_t)t * w.n_perm, nsc, splits, partial, s);
+        int rc = dispatch_xtv(v, h, dig, splits, w.scal.p + 4 * t, partial, s);
         prof_end(s, e0, e1);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_xtv_finalize, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, s, partial,
-                           w.sums.p + (int64_t)t * splits, splits, A, B, h->p, r_dev + (int64_t)t * h->n, h->mu, h->sinv,
-                           h->miss_ptr, h->miss_row, h->center, h->scale, h->impute, out_dev + (int64_t)t * h->p);
+        hipLaunchKernelGGL(k_xtv_finalize, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, s, partial, splits, pstride, h->p,
+                           w.scal.p + 4 * t, r_dev + (int64_t)t * h->n, h->mu, h->sinv, h->miss_ptr, h->miss_row,
+                           h->center, h->scale, h->impute, out_dev + (int64_t)t * h->p);
     }
     MIH_HIP(hipGetLastError());
     return MIH_OK;

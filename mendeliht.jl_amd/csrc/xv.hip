@@ -25,7 +25,7 @@ __global__ void k_xv_coef(const int64_t *__restrict__ idx, const double *__restr
 
 // grid (row blocks, column groups): thread = one dword = 16 rows; partial[g][i].
 __global__ void __launch_bounds__(256)
-k_xv_snp(const uint32_t *__restrict__ X, int64_t stride_dw, int64_t ndw,
+k_xv_snp(const uint32_t *__restrict__ X, int64_t nbp, int64_t ndw,
          const int64_t *__restrict__ idx, const double *__restrict__ A, const double *__restrict__ B,
          int64_t nnz, int groups, int64_t n_pad, double *__restrict__ partial)
 {
@@ -39,7 +39,7 @@ k_xv_snp(const uint32_t *__restrict__ X, int64_t stride_dw, int64_t ndw,
     for (int s = 0; s < 16; ++s) acc[s] = 0.0;
     double bsum = 0.0;
     for (int64_t t = t0; t < t1; ++t) {
-        uint32_t w = X[idx[t] * stride_dw + dw];
+        uint32_t w = X[xword(nbp, idx[t], dw)];
         double a = A[t];
         bsum += B[t];
         #pragma unroll
@@ -131,8 +131,8 @@ int xv_sparse_device(const mih_mat *h, XvWork &w, const int64_t *idx_dev, const 
     if (h->kind == 0) {
         hipLaunchKernelGGL(k_xv_coef, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, s, idx_dev, val_dev, nnz,
                            h->mu, h->sinv, h->center, h->scale, w.coefA.p, w.coefB.p);
-        int64_t ndw = h->stride_dw;
-        hipLaunchKernelGGL(k_xv_snp, dim3((unsigned)((ndw + 255) / 256), groups), dim3(256), 0, s, h->X, h->stride_dw, ndw,
+        int64_t ndw = h->n_pad / 16;
+        hipLaunchKernelGGL(k_xv_snp, dim3((unsigned)((ndw + 255) / 256), groups), dim3(256), 0, s, h->X, h->nbp, ndw,
                            idx_dev, w.coefA.p, w.coefB.p, nnz, groups, np, w.partial.p);
         bool fix = h->impute && h->total_missing > 0;
         hipLaunchKernelGGL(k_xv_reduce, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, s, w.partial.p, groups, np, h->n,
