@@ -149,6 +149,13 @@ def main():
     sess.close()
 
     if rank == 0:
+        if a.traffic_bytes is None:      # PMC traffic comes from a separate rocprofv3 pass (profiles/)
+            try:
+                t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+                if t["workload"] == {"n": n, "p": p}:
+                    a.traffic_bytes = t["hbm_bytes_per_launch"]
+            except (OSError, KeyError, ValueError):
+                pass
         alg_bytes = x.algorithmic_bytes(1)
         kern_ms = xtv_ms / max(launches, 1)
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if launches else 0.0
@@ -170,7 +177,7 @@ def main():
                        "final_logl": logl},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": a.traffic_bytes,
-                         "kernel": "k_xtv", "kernel_ms": kern_ms, "launches": launches,
+                         "kernel": "k_xtv_mfma", "kernel_ms": kern_ms, "launches": launches,
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -153,14 +153,23 @@ k_resid(const double *__restrict__ xb, const double *__restrict__ zc, const doub
     r[i] = d_mueta(link, eta) / d_glmvar(dist, m, nb_r) * (y[i] - m) * w[i];
 }
 
-// df2 = Z' r (utilities.jl:134): one workgroup per covariate, fixed-order tree
+// df2 = Z' r (utilities.jl:134): kZtrBlocks workgroups per covariate (grid.y), fixed-order trees
+constexpr int kZtrBlocks = 128;
 __global__ void __launch_bounds__(256)
-k_zt_r(const double *__restrict__ z, const double *__restrict__ r, int64_t n, double *__restrict__ out)
+k_zt_r(const double *__restrict__ z, const double *__restrict__ r, int64_t n, double *__restrict__ part)
 {
-    const double *zl = z + (int64_t)blockIdx.x * n;
+    const double *zl = z + (int64_t)blockIdx.y * n;
     double v[1] = {0.0};
-    for (int64_t i = threadIdx.x; i < n; i += 256) v[0] += zl[i] * r[i];
-    block_sum<1>(v, out + blockIdx.x);
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += 256ll * kZtrBlocks) v[0] += zl[i] * r[i];
+    block_sum<1>(v, part + (int64_t)blockIdx.y * kZtrBlocks + blockIdx.x);
+}
+__global__ void __launch_bounds__(64)
+k_zt_r_final(const double *__restrict__ part, double *__restrict__ out)
+{
+    if (threadIdx.x != 0) return;
+    double a = 0.0;
+    for (int b = 0; b < kZtrBlocks; ++b) a += part[(int64_t)blockIdx.x * kZtrBlocks + b];
+    out[blockIdx.x] = a;
 }
 
 // iht_stepsize! tail (utilities.jl:744-756): xgk = (X_S df_S + Z_idc df2_idc) * sqrt(mueta^2/var) * w;
@@ -255,7 +264,7 @@ struct IhtVar {
     const double *y_host = nullptr;
     hipStream_t s = nullptr;
     // device
-    DevBuf<double> y, z, w, xb, zc, mu, r, xgk, df, full, weight, red, scal, gval;
+    DevBuf<double> y, z, w, xb, zc, mu, r, xgk, df, full, weight, red, scal, gval, ztr;
     DevBuf<int64_t> sidx; DevBuf<double> sval;   // staging for support lists
     DevBuf<uint8_t> mask;
     XtvWork xtv; XvWork xv; TopkWork topk;
@@ -280,7 +289,7 @@ struct IhtVar {
         MIH_TRY(y.alloc(n)); MIH_TRY(z.alloc((size_t)n * q)); MIH_TRY(w.alloc(n)); MIH_TRY(xb.alloc(n));
         MIH_TRY(zc.alloc(n)); MIH_TRY(mu.alloc(n)); MIH_TRY(r.alloc(n)); MIH_TRY(xgk.alloc(n));
         MIH_TRY(df.alloc(p)); MIH_TRY(full.alloc((size_t)p + q)); MIH_TRY(mask.alloc(n));
-        MIH_TRY(red.alloc((size_t)nb * 4)); MIH_TRY(scal.alloc(kMaxQ + 8));
+        MIH_TRY(red.alloc((size_t)nb * 4)); MIH_TRY(scal.alloc(kMaxQ + 8)); MIH_TRY(ztr.alloc((size_t)kMaxQ * kZtrBlocks));
         int64_t kcap = std::max<int64_t>(k + q, 64) + 1024;
         for (int64_t v : ks) kcap += v;
         MIH_TRY(sidx.alloc(kcap)); MIH_TRY(sval.alloc(kcap)); MIH_TRY(gval.alloc(kcap));
@@ -363,7 +372,8 @@ struct IhtVar {
     {
         hipLaunchKernelGGL(k_resid, dim3(nblk(n)), dim3(256), 0, s, xb.p, zc.p, y.p, mu.p, w.p, n, dist, link, nb_r, r.p);
         MIH_TRY(xtv_device(h, xtv, r.p, 1, df.p, s));
-        hipLaunchKernelGGL(k_zt_r, dim3(q), dim3(256), 0, s, z.p, r.p, n, scal.p);
+        hipLaunchKernelGGL(k_zt_r, dim3(kZtrBlocks, q), dim3(256), 0, s, z.p, r.p, n, ztr.p);
+        hipLaunchKernelGGL(k_zt_r_final, dim3(q), dim3(64), 0, s, ztr.p, scal.p);
         MIH_HIP(hipMemcpyAsync(df2.data(), scal.p, sizeof(double) * q, hipMemcpyDeviceToHost, s));
         return MIH_OK;
     }
