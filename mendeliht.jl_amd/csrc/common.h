@@ -130,5 +130,11 @@ int  topk_work_init(TopkWork &w, int64_t max_keep);
 // In-place project_k! on a device vector; returns threshold and survivors (sorted by index) on host.
 int  topk_project_device(double *x_dev, int64_t len, int64_t k, TopkWork &w, hipStream_t s,
                          std::vector<int64_t> &idx_out, std::vector<double> &val_out);
+// every non-zero of a device vector as (index, value), sorted by index
+int  collect_nonzero_device(double *x_dev, int64_t len, TopkWork &w, hipStream_t s,
+                            std::vector<int64_t> &idx_out, std::vector<double> &val_out);
+// project_group_sparse! in place on a device vector (group labels 1..G, k_dev: 1 or G entries)
+int  group_project_device(double *y_dev, const int64_t *group_dev, int64_t len, int64_t G, int64_t J,
+                          const int64_t *k_dev, int k_is_vector, hipStream_t s);
 
 }  // namespace mih

@@ -290,7 +290,7 @@ struct IhtVar {
         MIH_TRY(zc.alloc(n)); MIH_TRY(mu.alloc(n)); MIH_TRY(r.alloc(n)); MIH_TRY(xgk.alloc(n));
         MIH_TRY(df.alloc(p)); MIH_TRY(full.alloc((size_t)p + q)); MIH_TRY(mask.alloc(n));
         MIH_TRY(red.alloc((size_t)nb * 4)); MIH_TRY(scal.alloc(kMaxQ + 8)); MIH_TRY(ztr.alloc((size_t)kMaxQ * kZtrBlocks));
-        int64_t kcap = std::max<int64_t>(k + q, 64) + 1024;
+        int64_t kcap = std::max<int64_t>(std::max<int64_t>(J, 1) * k + q, 64) + 1024;
         for (int64_t v : ks) kcap += v;
         MIH_TRY(sidx.alloc(kcap)); MIH_TRY(sval.alloc(kcap)); MIH_TRY(gval.alloc(kcap));
         MIH_TRY(xtv_work_init(h, xtv, 1));
@@ -302,6 +302,23 @@ struct IhtVar {
             has_weight = true;
             MIH_TRY(weight.alloc(p));
             MIH_HIP(hipMemcpyAsync(weight.p, prm->weight, sizeof(double) * p, hipMemcpyHostToDevice, s));
+        }
+        if (prm->group) {
+            has_group = true;
+            G = 0;
+            for (int64_t j = 0; j < p; ++j) {
+                if (prm->group[j] < 1) { set_error("group labels must be 1..G"); return MIH_BAD_ARG; }
+                G = std::max(G, prm->group[j]);
+            }
+            if (!ks.empty() && (int64_t)ks.size() < G) { set_error("k (vector) must have one entry per group"); return MIH_BAD_DIM; }
+            MIH_TRY(group_dev.alloc(p));
+            MIH_HIP(hipMemcpyAsync(group_dev.p, prm->group, sizeof(int64_t) * p, hipMemcpyHostToDevice, s));
+            std::vector<int64_t> kk = ks.empty() ? std::vector<int64_t>{k} : ks;
+            MIH_TRY(kgrp_dev.alloc(kk.size()));
+            MIH_HIP(hipMemcpy(kgrp_dev.p, kk.data(), sizeof(int64_t) * kk.size(), hipMemcpyHostToDevice));
+        } else if (!ks.empty()) {
+            set_error("Doubly sparse projection specified (since k is a vector) but there are no group information.");
+            return MIH_BAD_ARG;
         }
         c.assign(q, 0.0); c0 = c; best_c = c; df2 = c; idc.assign(q, 0); idc0 = idc;
         return MIH_OK;
@@ -432,7 +449,22 @@ struct IhtVar {
     // _iht_gradstep! (utilities.jl:252-280) from base model (bb, cc) with step eta
     int gradstep(const Sparse &bb, const std::vector<double> &cc, double eta)
     {
-        if (!ks.empty() || has_group) { set_error("group projection is handled by gradstep_group"); return MIH_BAD_ARG; }
+        if (has_group) {
+            // utilities.jl:266-268: project_group_sparse!(v.b, v.group, J, k): no prior weights, and the
+            // covariates are not projected in this branch
+            hipLaunchKernelGGL(k_grad_full, dim3(nblk(p)), dim3(256), 0, s, df.p, (const double *)nullptr, p, eta, full.p);
+            MIH_TRY(upload(bb.idx, bb.val));
+            if (!bb.idx.empty())
+                hipLaunchKernelGGL(k_scatter_b, dim3(nblk((int64_t)bb.idx.size())), dim3(256), 0, s, sidx.p, sval.p, (int64_t)bb.idx.size(), df.p, (const double *)nullptr, eta, full.p);
+            MIH_TRY(group_project_device(full.p, group_dev.p, p, G, J, kgrp_dev.p, ks.empty() ? 0 : 1, s));
+            Sparse snp;
+            MIH_TRY(collect_nonzero_device(full.p, p, topk, s, snp.idx, snp.val));
+            b = snp;
+            for (int l = 0; l < q; ++l) { c[l] = std::fma(eta, df2[l], cc[l]); idc[l] = (c[l] != 0.0); }
+            if (ks.empty()) choose();         // typeof(k) == Int && _choose!(v)
+            idx.idx = b.idx;
+            return MIH_OK;
+        }
         const double *wp = has_weight ? weight.p : nullptr;
         hipLaunchKernelGGL(k_grad_full, dim3(nblk(p)), dim3(256), 0, s, df.p, wp, p, eta, full.p);
         MIH_TRY(upload(bb.idx, bb.val));
@@ -467,6 +499,8 @@ struct IhtVar {
         return MIH_OK;
     }
     bool has_group = false;
+    int64_t G = 0;
+    DevBuf<int64_t> group_dev, kgrp_dev;
 
     // init_iht_indices! (utilities.jl:366-438), init_beta=false
     int init(const uint8_t *train)
@@ -492,6 +526,14 @@ struct IhtVar {
         hipLaunchKernelGGL(k_mu_loglik, dim3(nb), dim3(256), 0, s, xb.p, zc.p, y.p, w.p, n, dist, link, nb_r, 1, mu.p, red.p);
         MIH_TRY(score());
         MIH_HIP(hipStreamSynchronize(s));
+        if (!ks.empty()) {
+            // utilities.jl:427-429: project_group_sparse!(v.df, group, J, ks); idx is then taken from
+            // v.b (all zero) -> empty initial support; idc = trues
+            MIH_TRY(group_project_device(df.p, group_dev.p, p, G, J, kgrp_dev.p, 1, s));
+            idx.clear();
+            for (int l = 0; l < q; ++l) idc[l] = 1;
+            return MIH_OK;
+        }
         // vectorize!(full_b, df, df2) ; project_k! ; unvectorize! -> df is replaced by its own projection
         const double *wp = has_weight ? weight.p : nullptr;
         hipLaunchKernelGGL(k_grad_full, dim3(nblk(p)), dim3(256), 0, s, df.p, wp, p, 1.0, full.p);
@@ -637,7 +679,6 @@ static int check_params(const mih_mat *h, const mih_fit_params *prm, int64_t q)
     if (h->kind == 0 && !h->center) { set_error("x is not centered! Please construct SnpLinAlg{Float64}(::SnpArray, center=true, scale=true)"); return MIH_NOT_CENTERED; }
     if (prm->est_r != MIH_ESTR_NONE && prm->dist != MIH_NEGBIN) { set_error("Only negative binomial regression currently supports nuisance parameter estimation"); return MIH_BAD_ARG; }
     if (prm->est_r != MIH_ESTR_NONE) { set_error("est_r (NegBin nuisance estimation) is not implemented on the device path yet"); return MIH_BAD_ARG; }
-    if (prm->group || prm->ks) { set_error("group / doubly-sparse projection is not implemented in the device fit loop yet (use mih_project_group_sparse)"); return MIH_BAD_ARG; }
     if (!prm->ks && prm->k < 0) { set_error("Value of k (max predictors per group) must be nonnegative!"); return MIH_BAD_ARG; }
     if (q < 1 || q > kMaxQ) { set_error("number of covariates q=%lld must be in 1..%d", (long long)q, kMaxQ); return MIH_BAD_DIM; }
     if (prm->dist < 0 || prm->dist > MIH_NEGBIN || prm->link < 0 || prm->link > MIH_LOG) { set_error("unknown distribution/link"); return MIH_BAD_ARG; }

@@ -79,6 +79,9 @@ int topk_work_init(TopkWork &w, int64_t max_keep)
     return MIH_OK;
 }
 
+static int compact_device(double *x_dev, int64_t len, TopkWork &w, hipStream_t s,
+                          std::vector<int64_t> &idx_out, std::vector<double> &val_out);
+
 int topk_project_device(double *x_dev, int64_t len, int64_t k, TopkWork &w, hipStream_t s,
                         std::vector<int64_t> &idx_out, std::vector<double> &val_out)
 {
@@ -92,6 +95,14 @@ int topk_project_device(double *x_dev, int64_t len, int64_t k, TopkWork &w, hipS
         hipLaunchKernelGGL(k_hist, dim3(grid), dim3(256), 0, s, x_dev, len, shift, w.state.p, w.hist.p);
         hipLaunchKernelGGL(k_pick, dim3(1), dim3(64), 0, s, w.hist.p, w.state.p, shift);
     }
+    return compact_device(x_dev, len, w, s, idx_out, val_out);
+}
+
+// threshold pass with the key already in state[2]: zero what is below, gather what survives
+static int compact_device(double *x_dev, int64_t len, TopkWork &w, hipStream_t s,
+                          std::vector<int64_t> &idx_out, std::vector<double> &val_out)
+{
+    int grid = (int)std::min<int64_t>((len + 255) / 256, 2048);
     for (int attempt = 0; attempt < 2; ++attempt) {
         MIH_HIP(hipMemsetAsync(w.sel_cnt.p, 0, sizeof(uint32_t), s));
         hipLaunchKernelGGL(k_threshold, dim3(grid), dim3(256), 0, s, x_dev, len, w.state.p, w.sel_idx.p, w.sel_val.p,
@@ -119,6 +130,14 @@ int topk_project_device(double *x_dev, int64_t len, int64_t k, TopkWork &w, hipS
     }
     set_error("top-k compaction failed");
     return MIH_HIP_ERROR;
+}
+
+int collect_nonzero_device(double *x_dev, int64_t len, TopkWork &w, hipStream_t s,
+                           std::vector<int64_t> &idx_out, std::vector<double> &val_out)
+{
+    uint64_t st[4] = {0ull, 0ull, 0ull, 0ull};       // threshold key 0: nothing is zeroed
+    MIH_HIP(hipMemcpyAsync(w.state.p, st, sizeof(st), hipMemcpyHostToDevice, s));
+    return compact_device(x_dev, len, w, s, idx_out, val_out);
 }
 
 }  // namespace mih

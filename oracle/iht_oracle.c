@@ -527,8 +527,9 @@ static void choose(ihtvar *v)
 /* _iht_gradstep! utilities.jl:252-280 */
 static int gradstep(ihtvar *v, double eta)
 {
-    for (int64_t j = 0; j < v->p; ++j) v->b[j] += eta * v->df[j];
-    for (int64_t j = 0; j < v->q; ++j) v->c[j] += eta * v->df2[j];
+    /* BLAS.axpy! (utilities.jl:258-259): OpenBLAS' daxpy kernels are FMA-based */
+    for (int64_t j = 0; j < v->p; ++j) v->b[j] = fma(eta, v->df[j], v->b[j]);
+    for (int64_t j = 0; j < v->q; ++j) v->c[j] = fma(eta, v->df2[j], v->c[j]);
     int k_is_int = (v->nks == 0);
     if (!v->group) {
         vectorize(v, v->full_b, v->b, v->c);

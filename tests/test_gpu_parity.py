@@ -327,3 +327,58 @@ def test_full_size_properties_n500k(mih, oracle):
     coef = np.zeros(64)
     coef[idx] = val
     assert rel(x.xv_sparse(idx, val), ox.xv_masked(mask, coef)) < 1e-11
+
+
+def test_project_group_sparse_device(mih, oracle):
+    """project_group_sparse! (utilities.jl:613-679) incl. the reference's property tests (utilities_test.jl:180-213)."""
+    rng = np.random.default_rng(30)
+    m, n, k, J = 5, 50, 3, 2
+    y = rng.standard_normal(n)
+    group = np.repeat(np.arange(1, m + 1), n // m)
+    out = mih.project_group_sparse(y, group, J, k)
+    assert np.array_equal(out, oracle.project_group_sparse(y, group, J, k))
+    nzg = [np.count_nonzero(out[group == g]) for g in range(1, m + 1)]
+    assert sum(c > 0 for c in nzg) == J and all(c in (0, k) for c in nzg)
+    one = np.ones(n, dtype=np.int64)
+    assert np.array_equal(mih.project_group_sparse(y, one, 1, 7), mih.project_k(y, 7))   # J=1 group == project_k!
+    ks = np.array([1, 2, 3, 4, 5])
+    assert np.array_equal(mih.project_group_sparse(y, group, 5, ks), oracle.project_group_sparse(y, group, 5, ks))
+    # large, unordered labels, empty groups, ties
+    p = 200003
+    v = rng.standard_normal(p)
+    v[::7] = np.round(v[::7], 1)                     # many exact ties
+    g = rng.integers(1, 5000, size=p)
+    g[g == 17] = 18                                  # an empty group
+    for (JJ, kk) in [(10, 3), (4999, 1), (1, 50)]:
+        assert np.array_equal(mih.project_group_sparse(v, g, JJ, kk), oracle.project_group_sparse(v, g, JJ, kk)), (JJ, kk)
+    kv = rng.integers(0, 4, size=4999)
+    assert np.array_equal(mih.project_group_sparse(v, g, 300, kv), oracle.project_group_sparse(v, g, 300, kv))
+
+
+def test_fit_iht_group_projection(mih, oracle):
+    """Group IHT (test/L0_reg_test.jl:176-242): scalar k per group and per-group k vector."""
+    rng = np.random.default_rng(31)
+    n, p = 600, 1000
+    cols = make_bed(rng, n, p)
+    x = mih.SnpLinAlg(cols, n, center=True, scale=True, impute=True)
+    ox = oracle.Mat.from_bed_columns(cols, n)
+    group = np.repeat(np.arange(1, 51), p // 50)
+    b = np.zeros(p)
+    for g0 in (3, 17, 40):
+        b[(g0 - 1) * 20 + rng.choice(20, 3, replace=False)] = rng.choice([-1, 1], 3) * rng.uniform(0.4, 0.9, 3)
+    mask = (b != 0).astype(np.uint8)
+    y = ox.xv_masked(mask, b) + 0.7 + rng.standard_normal(n)
+    res = mih.fit_iht(y, x, None, k=3, J=3, group=group, verbose=False)
+    o = oracle.fit_iht(ox, y, None, k=3, J=3, group=group)
+    assert res.iter == o["iter"]
+    assert np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"]))
+    np.testing.assert_allclose(res.beta, o["beta"], rtol=1e-5, atol=1e-12)
+    assert res.logl == pytest.approx(o["logl"], rel=1e-9)
+    assert np.count_nonzero(res.beta) <= 9 and len(set(group[np.flatnonzero(res.beta)])) <= 3
+    ks = np.full(50, 2)
+    ks[[2, 16, 39]] = 3
+    res = mih.fit_iht(y, x, None, k=ks, J=4, group=group, verbose=False)
+    o = oracle.fit_iht(ox, y, None, k=ks, J=4, group=group)
+    assert res.iter == o["iter"]
+    assert np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"]))
+    np.testing.assert_allclose(res.beta, o["beta"], rtol=1e-5, atol=1e-12)
