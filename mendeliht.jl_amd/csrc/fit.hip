@@ -9,6 +9,7 @@
 // scalars; per iteration the host reads back only: the step-size reduction, the
 // projection survivors (k entries), the loglikelihood scalars, Z'r and df[S].
 #include "common.h"
+#include "fit_common.h"
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -69,42 +70,6 @@ __device__ __forceinline__ double d_loglik_obs(int dist, double y, double mu, do
         return lgamma(nb_r + y) - lgamma(nb_r) - lgamma(y + 1.0) + nb_r * log(pp) + d_xlogy(y, 1.0 - pp);
     }
     default: return 0.0;
-    }
-}
-
-// deterministic block sum (fixed tree) of up to NV values per thread
-template <int NV>
-__device__ __forceinline__ void block_sum(double (&v)[NV], double *out /* NV values, thread 0 */)
-{
-    __shared__ double red[NV][256];
-    #pragma unroll
-    for (int k = 0; k < NV; ++k) red[k][threadIdx.x] = v[k];
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) {
-            #pragma unroll
-            for (int k = 0; k < NV; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        #pragma unroll
-        for (int k = 0; k < NV; ++k) out[k] = red[k][0];
-    }
-}
-
-// second stage: sum `nblocks` rows of NV partials in fixed order
-__global__ void k_final_sum(const double *__restrict__ partial, int nblocks, int nv, double *__restrict__ out)
-{
-    __shared__ double red[256];
-    for (int k = 0; k < nv; ++k) {
-        double a = 0.0;
-        for (int b = threadIdx.x; b < nblocks; b += 256) a += partial[(int64_t)b * nv + k];
-        red[threadIdx.x] = a;
-        __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
-        if (threadIdx.x == 0) out[k] = red[0];
-        __syncthreads();
     }
 }
 
@@ -221,26 +186,6 @@ __global__ void k_unvec(const double *__restrict__ full, const double *__restric
     if (j >= p) return;
     df[j] = weight ? full[j] / weight[j] : full[j];
 }
-__global__ void k_gather(const double *__restrict__ src, const int64_t *__restrict__ idx, int64_t nnz,
-                         double *__restrict__ out)
-{
-    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (t < nnz) out[t] = src[idx[t]];
-}
-__global__ void k_mask_to_wts(const uint8_t *__restrict__ m, int64_t n, int invert, double *__restrict__ w)
-{
-    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i < n) w[i] = ((m[i] != 0) != (invert != 0)) ? 1.0 : 0.0;
-}
-
-static inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
-
-struct Sparse {                       // a k-sparse p-vector, sorted by index
-    std::vector<int64_t> idx;
-    std::vector<double> val;
-    void clear() { idx.clear(); val.clear(); }
-};
-
 static double h_linkinv(int link, double eta)
 {
     switch (link) { case MIH_LOGIT: return 1.0 / (1.0 + std::exp(-eta)); case MIH_LOG: return std::exp(eta); default: return eta; }

@@ -1,5 +1,684 @@
-// placeholder, replaced below
+// mv.hip -- multivariate-Gaussian IHT (src/multivariate.jl) on the device.
+//
+// Layout: every r x n matrix of the reference (Y, BX, CZ, mu, resid, r_by_n1) is kept as r
+// "planes" of n doubles (trait-major), which is exactly the n x r column-major operand the
+// batched X'R pass takes (multivariate.jl:83-86: n_by_r = r_by_n1', p_by_r = X * n_by_r).
+// df is r planes of p doubles.  B is k-sparse and lives on the host as (linear index i + r*j,
+// value) pairs in the reference's vec(B) order; C, df2, Gamma are small host matrices
+// (column-major r x q / r x r, as in Julia).  The r x r algebra (pivoted Cholesky, inverse,
+// logdet) runs on the host exactly as the reference leaves it to LAPACK.
 #include "common.h"
+#include "fit_common.h"
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <limits>
+
+namespace mih {
+
+constexpr int kMaxR = 32;
+constexpr int kMaxRQ = 256;               // r * q entries of C passed by value
+struct RMat { double v[kMaxR * kMaxR]; }; // column-major r x r
+struct CMat { double v[kMaxRQ]; };        // column-major r x q
+constexpr int kRedBlocks = 128;
+
+// mu = BX + CZ (multivariate.jl:39-43), CZ = C*Z (:30), resid = (Y - mu) * cv_wts (:50-58)
+__global__ void __launch_bounds__(256)
+k_mv_resid(const double *__restrict__ Y, const double *__restrict__ Z, const double *__restrict__ BX,
+           const double *__restrict__ w, int64_t n, int r, int q, CMat C, double *__restrict__ MU,
+           double *__restrict__ RES)
+{
+    int64_t s = blockIdx.x * 256ll + threadIdx.x;
+    if (s >= n) return;
+    double wt = w[s];
+    for (int i = 0; i < r; ++i) {
+        double cz = 0.0;
+        for (int l = 0; l < q; ++l) cz += C.v[i + r * l] * Z[(int64_t)l * n + s];
+        double m = BX[(int64_t)i * n + s] + cz;
+        MU[(int64_t)i * n + s] = m;
+        RES[(int64_t)i * n + s] = (Y[(int64_t)i * n + s] - m) * wt;
+    }
+}
+
+// dot products of plane pairs: pair t = (a[t], b[t]) -> part[t][block]
+__global__ void __launch_bounds__(256)
+k_mv_dots(const double *__restrict__ A, const double *__restrict__ B, int64_t n, const int32_t *__restrict__ pa,
+          const int32_t *__restrict__ pb, double *__restrict__ part)
+{
+    const double *x = A + (int64_t)pa[blockIdx.y] * n, *y = B + (int64_t)pb[blockIdx.y] * n;
+    double v[1] = {0.0};
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += 256ll * kRedBlocks) v[0] += x[i] * y[i];
+    block_sum<1>(v, part + (int64_t)blockIdx.y * kRedBlocks + blockIdx.x);
+}
+__global__ void __launch_bounds__(64)
+k_mv_dots_final(const double *__restrict__ part, double *__restrict__ out)
+{
+    if (threadIdx.x != 0) return;
+    double a = 0.0;
+    for (int b = 0; b < kRedBlocks; ++b) a += part[(int64_t)blockIdx.x * kRedBlocks + b];
+    out[blockIdx.x] = a;
+}
+
+// T1 = G * RES per sample (score!, multivariate.jl:67); optionally * w and upper-triangular only
+__global__ void __launch_bounds__(256)
+k_mv_apply(const double *__restrict__ IN, int64_t n, int r, RMat G, int upper, const double *__restrict__ w,
+           double *__restrict__ OUT, double *__restrict__ part /* sum of squares per block, or null */)
+{
+    int64_t s = blockIdx.x * 256ll + threadIdx.x;
+    double v[1] = {0.0};
+    if (s < n) {
+        double in[kMaxR];
+        double wt = w ? w[s] : 1.0;
+        for (int l = 0; l < r; ++l) in[l] = IN[(int64_t)l * n + s] * wt;
+        for (int i = 0; i < r; ++i) {
+            double a = 0.0;
+            for (int l = upper ? i : 0; l < r; ++l) a += G.v[i + r * l] * in[l];
+            if (OUT) OUT[(int64_t)i * n + s] = a;
+            v[0] += a * a;
+        }
+    }
+    if (part) block_sum<1>(v, part + blockIdx.x);
+}
+
+// vectorize!(full_b, B, C) after the axpy (multivariate.jl:99-113): full[i + r*j] = eta * df[i][j]
+__global__ void k_mv_full(const double *__restrict__ DF, int64_t p, int r, double eta, double *__restrict__ full)
+{
+    int64_t t = blockIdx.x * 256ll + threadIdx.x;
+    if (t >= p * r) return;
+    int64_t j = t / r; int i = (int)(t - j * r);
+    full[t] = eta * DF[(int64_t)i * p + j];
+}
+__global__ void k_mv_scatter(const int64_t *__restrict__ li, const double *__restrict__ val, int64_t nnz,
+                             const double *__restrict__ DF, int64_t p, int r, double eta, double *__restrict__ full)
+{
+    int64_t t = blockIdx.x * 256ll + threadIdx.x;
+    if (t >= nnz) return;
+    int64_t l = li[t], j = l / r; int i = (int)(l - j * r);
+    full[l] = fma(eta, DF[(int64_t)i * p + j], val[t]);
+}
+// unvectorize! of the projected gradient at init (multivariate.jl:438-440): df[i][j] = full[i + r*j]
+__global__ void k_mv_unvec(const double *__restrict__ full, int64_t p, int r, double *__restrict__ DF)
+{
+    int64_t t = blockIdx.x * 256ll + threadIdx.x;
+    if (t >= p * r) return;
+    int64_t j = t / r; int i = (int)(t - j * r);
+    DF[(int64_t)i * p + j] = full[t];
+}
+__global__ void k_mv_gather(const double *__restrict__ DF, int64_t p, int r, const int64_t *__restrict__ cols, int64_t nc,
+                            double *__restrict__ out /* [r][nc] */)
+{
+    int64_t t = blockIdx.x * 256ll + threadIdx.x;
+    if (t >= nc * r) return;
+    int64_t i = t / nc, c = t - i * nc;
+    out[t] = DF[i * p + cols[c]];
+}
+// predict!(v::mIHTVariable) (cross_validation.jl:288-299): sum (Y - mu)^2 * cv_wts
+__global__ void __launch_bounds__(256)
+k_mv_mse(const double *__restrict__ Y, const double *__restrict__ MU, const double *__restrict__ w, int64_t n, int r,
+         double *__restrict__ part)
+{
+    int64_t s = blockIdx.x * 256ll + threadIdx.x;
+    double v[1] = {0.0};
+    if (s < n) for (int i = 0; i < r; ++i) { double d = Y[(int64_t)i * n + s] - MU[(int64_t)i * n + s]; v[0] += d * d * w[s]; }
+    block_sum<1>(v, part + blockIdx.x);
+}
+
+// ---- small dense r x r algebra on the host (column-major) -----------------------------------
+static bool chol_upper(std::vector<double> &A, int r)
+{
+    for (int j = 0; j < r; ++j) {
+        double d = A[j + r * j];
+        for (int l = 0; l < j; ++l) d -= A[l + r * j] * A[l + r * j];
+        if (!(d > 0.0)) return false;
+        d = std::sqrt(d); A[j + r * j] = d;
+        for (int i = j + 1; i < r; ++i) {
+            double s = A[j + r * i];
+            for (int l = 0; l < j; ++l) s -= A[l + r * j] * A[l + r * i];
+            A[j + r * i] = s / d;
+        }
+    }
+    return true;
+}
+// inv!(cholesky!(Symmetric(A, :U))) (multivariate.jl:280): full symmetric inverse
+static bool spd_inverse(std::vector<double> &A, int r)
+{
+    if (!chol_upper(A, r)) return false;
+    std::vector<double> Ui((size_t)r * r, 0.0);
+    for (int j = 0; j < r; ++j) {
+        Ui[j + r * j] = 1.0 / A[j + r * j];
+        for (int i = j - 1; i >= 0; --i) {
+            double s = 0.0;
+            for (int l = i + 1; l <= j; ++l) s += A[i + r * l] * Ui[l + r * j];
+            Ui[i + r * j] = -s / A[i + r * i];
+        }
+    }
+    for (int i = 0; i < r; ++i)
+        for (int j = 0; j < r; ++j) {
+            double s = 0.0;
+            for (int l = std::max(i, j); l < r; ++l) s += Ui[i + r * l] * Ui[j + r * l];
+            A[i + r * j] = s;
+        }
+    return true;
+}
+// cholesky!(Symmetric(G,:U), Val(true)); triu!(G) (multivariate.jl:241-242): LAPACK dpstf2 with
+// tol = 0 (diagonal pivoting, first maximum); the permutation is dropped as the reference does.
+static void pivoted_chol_triu(std::vector<double> &G, int r)
+{
+    std::vector<double> dot(r, 0.0);
+    for (int j = 0; j < r; ++j) {
+        int pvt = j; double ajj = -std::numeric_limits<double>::infinity();
+        for (int i = j; i < r; ++i) {
+            if (j > 0) dot[i] += G[(j - 1) + r * i] * G[(j - 1) + r * i];
+            double d = G[i + r * i] - dot[i];
+            if (d > ajj) { ajj = d; pvt = i; }
+        }
+        if (!(ajj > 0.0)) { G[j + r * j] = ajj; break; }
+        if (pvt != j) {
+            G[pvt + r * pvt] = G[j + r * j];
+            for (int l = 0; l < j; ++l) std::swap(G[l + r * j], G[l + r * pvt]);
+            for (int i = pvt + 1; i < r; ++i) std::swap(G[j + r * i], G[pvt + r * i]);
+            for (int i = j + 1; i < pvt; ++i) std::swap(G[j + r * i], G[i + r * pvt]);
+            std::swap(dot[j], dot[pvt]);
+        }
+        ajj = std::sqrt(ajj); G[j + r * j] = ajj;
+        for (int i = j + 1; i < r; ++i) {
+            double s = G[j + r * i];
+            for (int l = 0; l < j; ++l) s -= G[l + r * j] * G[l + r * i];
+            G[j + r * i] = s / ajj;
+        }
+    }
+    for (int j = 0; j < r; ++j) for (int i = j + 1; i < r; ++i) G[i + r * j] = 0.0;
+}
+// LU with partial pivoting: log|det|, sign, optional inverse
+static bool lu_logdet_inverse(const std::vector<double> &Ain, int r, double *logabsdet, int *sign, std::vector<double> *inv)
+{
+    std::vector<double> A = Ain; std::vector<int> piv(r);
+    int sg = 1; double lad = 0.0;
+    for (int j = 0; j < r; ++j) {
+        int pv = j; double mx = std::fabs(A[j + r * j]);
+        for (int i = j + 1; i < r; ++i) if (std::fabs(A[i + r * j]) > mx) { mx = std::fabs(A[i + r * j]); pv = i; }
+        piv[j] = pv;
+        if (pv != j) { sg = -sg; for (int c = 0; c < r; ++c) std::swap(A[j + r * c], A[pv + r * c]); }
+        double d = A[j + r * j];
+        if (d == 0.0) return false;
+        if (d < 0) sg = -sg;
+        lad += std::log(std::fabs(d));
+        for (int i = j + 1; i < r; ++i) A[i + r * j] /= d;
+        for (int c = j + 1; c < r; ++c) { double f = A[j + r * c]; for (int i = j + 1; i < r; ++i) A[i + r * c] -= A[i + r * j] * f; }
+    }
+    if (inv) {
+        inv->assign((size_t)r * r, 0.0);
+        for (int c = 0; c < r; ++c) {
+            double *col = inv->data() + (size_t)r * c;
+            for (int i = 0; i < r; ++i) col[i] = (i == c) ? 1.0 : 0.0;
+            for (int j = 0; j < r; ++j) if (piv[j] != j) std::swap(col[j], col[piv[j]]);
+            for (int j = 0; j < r; ++j) for (int i = j + 1; i < r; ++i) col[i] -= A[i + r * j] * col[j];
+            for (int j = r - 1; j >= 0; --j) { col[j] /= A[j + r * j]; for (int i = 0; i < j; ++i) col[i] -= A[i + r * j] * col[j]; }
+        }
+    }
+    if (logabsdet) *logabsdet = lad;
+    if (sign) *sign = sg;
+    return true;
+}
+
+// One mIHTVariable (src/data_structures.jl:140-180), device-resident.
+struct MvVar {
+    const mih_mat *h = nullptr;
+    int64_t n = 0, p = 0, k = 0; int q = 0, r = 0;
+    std::vector<uint8_t> zkeep; int64_t zkeepn = 0;      // r * sum(zkeep)
+    const double *Y_host = nullptr;
+    hipStream_t s = nullptr;
+    DevBuf<double> Y, Z, w, BX, MU, RES, T1, DF, full, red, scal, gval, tmpn;
+    DevBuf<int64_t> sidx; DevBuf<double> sval; DevBuf<uint8_t> mask; DevBuf<int32_t> pairs;
+    XtvWork xtv; XvWork xv; TopkWork topk;
+    int nb = 0;
+    // host
+    Sparse B, B0, best_B;                  // linear index i + r*j
+    std::vector<int64_t> cols;             // idx: columns with a non-zero (sorted)
+    std::vector<double> dfcols;            // df[:, idx] as [r][ncols]
+    std::vector<double> C, C0, best_C, df2, G, G0, gram;
+    std::vector<uint8_t> idc;
+    int64_t nsamples = 0;
+    bool choose_fired = false;
+
+    ~MvVar() { if (s) (void)hipStreamDestroy(s); }
+
+    int create(const mih_mat *hh, const mih_fit_params *prm, const double *Yh, int64_t rr, const double *Zh, int64_t qq)
+    {
+        h = hh; n = h->n; p = h->p; r = (int)rr; q = (int)qq; k = prm->k; Y_host = Yh;
+        if (r < 1 || r > kMaxR) { set_error("number of traits r=%d must be in 1..%d", r, kMaxR); return MIH_BAD_DIM; }
+        if (q < 1 || r * q > kMaxRQ) { set_error("r*q = %d exceeds %d", r * q, kMaxRQ); return MIH_BAD_DIM; }
+        zkeep.resize(q); int64_t zs = 0;
+        for (int l = 0; l < q; ++l) { zkeep[l] = prm->zkeep ? (prm->zkeep[l] != 0) : 1; zs += zkeep[l]; }
+        zkeepn = (int64_t)r * zs;
+        MIH_HIP(hipStreamCreate(&s));
+        nb = (int)nblk(n);
+        size_t rn = (size_t)r * n;
+        MIH_TRY(Y.alloc(rn)); MIH_TRY(Z.alloc((size_t)q * n)); MIH_TRY(w.alloc(n)); MIH_TRY(BX.alloc(rn)); MIH_TRY(MU.alloc(rn));
+        MIH_TRY(RES.alloc(rn)); MIH_TRY(T1.alloc(rn)); MIH_TRY(DF.alloc((size_t)r * p)); MIH_TRY(full.alloc((size_t)r * (p + q)));
+        MIH_TRY(red.alloc(std::max<size_t>((size_t)nb, (size_t)kMaxR * kMaxR * kRedBlocks))); MIH_TRY(scal.alloc((size_t)kMaxR * kMaxR + 64));
+        MIH_TRY(tmpn.alloc(n)); MIH_TRY(mask.alloc(n)); MIH_TRY(pairs.alloc(2 * (size_t)kMaxR * kMaxR));
+        int64_t kcap = std::max<int64_t>(k + (int64_t)r * q, 64) + 1024;
+        MIH_TRY(sidx.alloc(kcap)); MIH_TRY(sval.alloc(kcap)); MIH_TRY(gval.alloc((size_t)kcap * r));
+        MIH_TRY(xtv_work_init(h, xtv, r)); MIH_TRY(xv_work_init(h, xv, kcap)); MIH_TRY(topk_work_init(topk, kcap));
+        // Y (r x n) and Z (q x n) column-major -> planes
+        std::vector<double> pl(std::max(rn, (size_t)q * n));
+        for (int64_t sidx_ = 0; sidx_ < n; ++sidx_) for (int i = 0; i < r; ++i) pl[(size_t)i * n + sidx_] = Yh[i + (size_t)r * sidx_];
+        MIH_HIP(hipMemcpy(Y.p, pl.data(), sizeof(double) * rn, hipMemcpyHostToDevice));
+        for (int64_t sidx_ = 0; sidx_ < n; ++sidx_) for (int l = 0; l < q; ++l) pl[(size_t)l * n + sidx_] = Zh[l + (size_t)q * sidx_];
+        MIH_HIP(hipMemcpy(Z.p, pl.data(), sizeof(double) * (size_t)q * n, hipMemcpyHostToDevice));
+        C.assign((size_t)r * q, 0.0); C0 = C; best_C = C; df2 = C; idc.assign(q, 0);
+        G.assign((size_t)r * r, 0.0); G0 = G; gram = G;
+        return MIH_OK;
+    }
+
+    int ensure_stage(int64_t nnz)
+    {
+        if ((size_t)nnz <= sidx.n) return MIH_OK;
+        MIH_HIP(hipStreamSynchronize(s));
+        MIH_TRY(sidx.alloc((size_t)nnz * 2)); MIH_TRY(sval.alloc((size_t)nnz * 2)); MIH_TRY(gval.alloc((size_t)nnz * 2 * r));
+        return MIH_OK;
+    }
+    CMat cmat(const std::vector<double> &c) const { CMat o; for (int t = 0; t < kMaxRQ; ++t) o.v[t] = t < r * q ? c[t] : 0.0; return o; }
+    RMat rmat(const std::vector<double> &g) const { RMat o; for (int t = 0; t < kMaxR * kMaxR; ++t) o.v[t] = t < r * r ? g[t] : 0.0; return o; }
+
+    int set_weights(const uint8_t *m, int invert)
+    {
+        if (!m) {
+            std::vector<double> ones(n, invert ? 0.0 : 1.0);
+            MIH_HIP(hipMemcpy(w.p, ones.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+            return MIH_OK;
+        }
+        MIH_HIP(hipMemcpyAsync(mask.p, m, n, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_mask_to_wts, dim3(nblk(n)), dim3(256), 0, s, mask.p, n, invert, w.p);
+        return MIH_OK;
+    }
+    void update_cols()         // update_support!(v.idx, v.B) (multivariate.jl:197-206)
+    {
+        cols.clear();
+        for (size_t t = 0; t < B.idx.size(); ++t) { int64_t j = B.idx[t] / r; if (cols.empty() || cols.back() != j) cols.push_back(j); }
+    }
+    // BX = B[:,idx] * X[idx,:] (multivariate.jl:21-31), one sparse X*v per trait
+    int update_xb()
+    {
+        update_cols();
+        int64_t nc = (int64_t)cols.size();
+        MIH_TRY(ensure_stage(nc));
+        std::vector<double> coef(nc);
+        if (nc) MIH_HIP(hipMemcpyAsync(sidx.p, cols.data(), sizeof(int64_t) * nc, hipMemcpyHostToDevice, s));
+        for (int i = 0; i < r; ++i) {
+            std::fill(coef.begin(), coef.end(), 0.0);
+            size_t c = 0;
+            for (size_t t = 0; t < B.idx.size(); ++t) {
+                int64_t j = B.idx[t] / r; int ii = (int)(B.idx[t] - j * r);
+                while (cols[c] != j) ++c;
+                if (ii == i) coef[c] = B.val[t];
+            }
+            if (nc) {
+                MIH_HIP(hipMemcpyAsync(sval.p, coef.data(), sizeof(double) * nc, hipMemcpyHostToDevice, s));
+                MIH_HIP(hipStreamSynchronize(s));     // coef is reused by the next trait
+            }
+            MIH_TRY(xv_sparse_device(h, xv, sidx.p, sval.p, nc, BX.p + (size_t)i * n, 0, s));
+        }
+        return MIH_OK;
+    }
+    // update_mu! + update_resid! (+ Gram matrix resid*resid' for solve_Sigma!/loglikelihood)
+    int resid_and_gram()
+    {
+        hipLaunchKernelGGL(k_mv_resid, dim3(nb), dim3(256), 0, s, Y.p, Z.p, BX.p, w.p, n, r, q, cmat(C), MU.p, RES.p);
+        std::vector<int32_t> pr;
+        for (int a = 0; a < r; ++a) for (int b = a; b < r; ++b) pr.push_back(a);
+        size_t np_ = pr.size();
+        for (int a = 0; a < r; ++a) for (int b = a; b < r; ++b) pr.push_back(b);
+        MIH_HIP(hipMemcpyAsync(pairs.p, pr.data(), sizeof(int32_t) * pr.size(), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_mv_dots, dim3(kRedBlocks, (unsigned)np_), dim3(256), 0, s, RES.p, RES.p, n, pairs.p, pairs.p + np_, red.p);
+        hipLaunchKernelGGL(k_mv_dots_final, dim3((unsigned)np_), dim3(64), 0, s, red.p, scal.p);
+        std::vector<double> g(np_);
+        MIH_HIP(hipMemcpyAsync(g.data(), scal.p, sizeof(double) * np_, hipMemcpyDeviceToHost, s));
+        MIH_HIP(hipStreamSynchronize(s));
+        size_t t = 0;
+        for (int a = 0; a < r; ++a) for (int b = a; b < r; ++b, ++t) { gram[a + r * b] = g[t]; gram[b + r * a] = g[t]; }
+        return MIH_OK;
+    }
+    // solve_Sigma! (multivariate.jl:276-282): Gamma = inv(resid*resid' / nsamples)
+    int solve_sigma()
+    {
+        MIH_TRY(resid_and_gram());
+        std::vector<double> a = gram;
+        for (auto &x : a) x /= (double)nsamples;
+        if (!spd_inverse(a, r)) { set_error("residual covariance is not positive definite"); return MIH_NAN_LOGL; }
+        G = a;
+        return MIH_OK;
+    }
+    // loglikelihood (multivariate.jl:9-13): n/2 logdet(Gamma) - 1/2 tr(Gamma * resid*resid')
+    double loglik() const
+    {
+        double tr = 0.0;
+        for (int a = 0; a < r; ++a) { double sacc = 0.0; for (int l = 0; l < r; ++l) sacc += G[a + r * l] * gram[l + r * a]; tr += sacc; }
+        double lad; int sg;
+        if (!lu_logdet_inverse(G, r, &lad, &sg, nullptr) || sg < 0) return std::numeric_limits<double>::quiet_NaN();
+        return (double)nsamples / 2.0 * lad - 0.5 * tr;
+    }
+    // score! (multivariate.jl:66-92)
+    int score()
+    {
+        hipLaunchKernelGGL(k_mv_apply, dim3(nb), dim3(256), 0, s, RES.p, n, r, rmat(G), 0, (const double *)nullptr, T1.p, (double *)nullptr);
+        MIH_TRY(xtv_device(h, xtv, T1.p, r, DF.p, s));
+        std::vector<int32_t> pr;
+        for (int l = 0; l < q; ++l) for (int i = 0; i < r; ++i) pr.push_back(i);
+        size_t np_ = pr.size();
+        for (int l = 0; l < q; ++l) for (int i = 0; i < r; ++i) pr.push_back(l);
+        MIH_HIP(hipMemcpyAsync(pairs.p, pr.data(), sizeof(int32_t) * pr.size(), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_mv_dots, dim3(kRedBlocks, (unsigned)np_), dim3(256), 0, s, T1.p, Z.p, n, pairs.p, pairs.p + np_, red.p);
+        hipLaunchKernelGGL(k_mv_dots_final, dim3((unsigned)np_), dim3(64), 0, s, red.p, scal.p);
+        MIH_HIP(hipMemcpyAsync(df2.data(), scal.p, sizeof(double) * np_, hipMemcpyDeviceToHost, s));   // [i + r*l]
+        MIH_HIP(hipStreamSynchronize(s));
+        return MIH_OK;
+    }
+    int gather_df_cols()
+    {
+        int64_t nc = (int64_t)cols.size();
+        dfcols.assign((size_t)nc * r, 0.0);
+        if (!nc) return MIH_OK;
+        MIH_TRY(ensure_stage(nc));
+        MIH_HIP(hipMemcpyAsync(sidx.p, cols.data(), sizeof(int64_t) * nc, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_mv_gather, dim3(nblk(nc * r)), dim3(256), 0, s, DF.p, p, r, sidx.p, nc, gval.p);
+        MIH_HIP(hipMemcpyAsync(dfcols.data(), gval.p, sizeof(double) * nc * r, hipMemcpyDeviceToHost, s));
+        MIH_HIP(hipStreamSynchronize(s));
+        return MIH_OK;
+    }
+    // iht_stepsize! (multivariate.jl:220-254): covariates ignored, pivoted Cholesky of Gamma
+    int stepsize(double *eta)
+    {
+        int64_t nc = (int64_t)cols.size();
+        double numer = 0.0;
+        for (double x : dfcols) numer += x * x;
+        for (int i = 0; i < r; ++i) {
+            if (nc) {
+                MIH_HIP(hipMemcpyAsync(sidx.p, cols.data(), sizeof(int64_t) * nc, hipMemcpyHostToDevice, s));
+                MIH_HIP(hipMemcpyAsync(sval.p, dfcols.data() + (size_t)i * nc, sizeof(double) * nc, hipMemcpyHostToDevice, s));
+            }
+            MIH_TRY(xv_sparse_device(h, xv, sidx.p, sval.p, nc, T1.p + (size_t)i * n, 0, s));
+        }
+        pivoted_chol_triu(G, r);                                   // Gamma is left holding U (fit.jl:230-232 recomputes it)
+        hipLaunchKernelGGL(k_mv_apply, dim3(nb), dim3(256), 0, s, T1.p, n, r, rmat(G), 1, w.p, (double *)nullptr, red.p);
+        hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, s, red.p, nb, 1, scal.p);
+        double denom = 0.0;
+        MIH_HIP(hipMemcpyAsync(&denom, scal.p, sizeof(double), hipMemcpyDeviceToHost, s));
+        MIH_HIP(hipStreamSynchronize(s));
+        double e = numer / denom;
+        if (std::isinf(e) || std::isnan(e)) e = 1e-8;
+        *eta = e;
+        return MIH_OK;
+    }
+    // _choose!(v::mIHTVariable) (multivariate.jl:310-351): RNG in the reference; deterministic + flag here
+    void choose()
+    {
+        int64_t cnz = 0;
+        for (int l = 0; l < q; ++l) if (!zkeep[l]) for (int i = 0; i < r; ++i) cnz += (C[i + r * l] != 0.0);
+        int64_t excess = (int64_t)B.idx.size() + cnz - (k + zkeepn);
+        if (excess <= 0) return;
+        choose_fired = true;
+        std::vector<size_t> ord(B.idx.size());
+        for (size_t i = 0; i < ord.size(); ++i) ord[i] = i;
+        std::sort(ord.begin(), ord.end(), [&](size_t a, size_t b) {
+            double fa = std::fabs(B.val[a]), fb = std::fabs(B.val[b]);
+            if (fa != fb) return fa < fb;
+            return B.idx[a] > B.idx[b];
+        });
+        std::vector<char> drop(B.idx.size(), 0);
+        int64_t t = 0;
+        for (; t < excess && t < (int64_t)ord.size(); ++t) drop[ord[t]] = 1;
+        Sparse nb2;
+        for (size_t i = 0; i < B.idx.size(); ++i) if (!drop[i]) { nb2.idx.push_back(B.idx[i]); nb2.val.push_back(B.val[i]); }
+        B = nb2;
+        for (int l = 0; l < q && t < excess; ++l) if (!zkeep[l]) for (int i = 0; i < r && t < excess; ++i) if (C[i + r * l] != 0.0) { C[i + r * l] = 0.0; ++t; }
+    }
+    // project the r(p+q) buffer and split survivors; tail = covariate part of the vector
+    int project_full(Sparse &snp, std::vector<double> &ctail, std::vector<uint8_t> &cnz)
+    {
+        std::vector<int64_t> si; std::vector<double> sv;
+        MIH_TRY(topk_project_device(full.p, (int64_t)r * (p + q), k + zkeepn, topk, s, si, sv));
+        snp.clear(); cnz.assign((size_t)r * q, 0); ctail.assign((size_t)r * q, 0.0);
+        for (size_t t = 0; t < si.size(); ++t) {
+            if (si[t] < (int64_t)r * p) { snp.idx.push_back(si[t]); snp.val.push_back(sv[t]); }
+            else { ctail[si[t] - (int64_t)r * p] = sv[t]; cnz[si[t] - (int64_t)r * p] = 1; }
+        }
+        return MIH_OK;
+    }
+    // _iht_gradstep! + project_k!(v) (multivariate.jl:99-127) from base (Bb, Cb)
+    int gradstep(const Sparse &Bb, const std::vector<double> &Cb, double eta)
+    {
+        hipLaunchKernelGGL(k_mv_full, dim3(nblk(p * r)), dim3(256), 0, s, DF.p, p, r, eta, full.p);
+        MIH_TRY(ensure_stage((int64_t)Bb.idx.size()));
+        if (!Bb.idx.empty()) {
+            MIH_HIP(hipMemcpyAsync(sidx.p, Bb.idx.data(), sizeof(int64_t) * Bb.idx.size(), hipMemcpyHostToDevice, s));
+            MIH_HIP(hipMemcpyAsync(sval.p, Bb.val.data(), sizeof(double) * Bb.val.size(), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_mv_scatter, dim3(nblk((int64_t)Bb.idx.size())), dim3(256), 0, s, sidx.p, sval.p, (int64_t)Bb.idx.size(), DF.p, p, r, eta, full.p);
+        }
+        std::vector<double> cn((size_t)r * q), tail((size_t)r * q);
+        for (int l = 0; l < q; ++l) for (int i = 0; i < r; ++i) {
+            cn[i + r * l] = std::fma(eta, df2[i + r * l], Cb[i + r * l]);
+            tail[i + r * l] = zkeep[l] ? std::numeric_limits<double>::infinity() : cn[i + r * l];
+        }
+        MIH_HIP(hipMemcpyAsync(full.p + (size_t)r * p, tail.data(), sizeof(double) * r * q, hipMemcpyHostToDevice, s));
+        Sparse snp; std::vector<double> ct; std::vector<uint8_t> cnz;
+        MIH_TRY(project_full(snp, ct, cnz));
+        B = snp;
+        for (int l = 0; l < q; ++l) for (int i = 0; i < r; ++i)
+            C[i + r * l] = zkeep[l] ? cn[i + r * l] : (cnz[i + r * l] ? ct[i + r * l] : 0.0);
+        choose();
+        update_cols();
+        for (int l = 0; l < q; ++l) { idc[l] = 0; for (int i = 0; i < r; ++i) if (C[i + r * l] != 0.0) idc[l] = 1; }
+        return MIH_OK;
+    }
+    // init_iht_indices!(v::mIHTVariable) (multivariate.jl:376-452), init_beta = false
+    int init(const uint8_t *train)
+    {
+        if (k < 1) { set_error("Multivariate IHT requires k >= 1!"); return MIH_BAD_ARG; }
+        B.clear(); B0.clear(); best_B.clear(); cols.clear(); dfcols.clear();
+        std::fill(C.begin(), C.end(), 0.0); C0 = C; best_C = C; std::fill(df2.begin(), df2.end(), 0.0);
+        for (int l = 0; l < q; ++l) idc[l] = zkeep[l];
+        std::fill(G.begin(), G.end(), 0.0);
+        for (int i = 0; i < r; ++i) G[i + r * i] = 1.0;
+        G0 = G;
+        choose_fired = false;
+        MIH_TRY(set_weights(train, 0));
+        nsamples = 0;
+        for (int64_t j = 0; j < n; ++j) nsamples += (!train || train[j]);
+        if (nsamples == 0) { set_error("no training samples"); return MIH_BAD_ARG; }
+        for (int i = 0; i < r; ++i) {                               // intercept = masked trait means (:416-422)
+            double ybar = 0.0;
+            for (int64_t j = 0; j < n; ++j) if (!train || train[j]) ybar += Y_host[i + (size_t)r * j];
+            C[i] = ybar / (double)nsamples;
+        }
+        MIH_HIP(hipMemsetAsync(BX.p, 0, sizeof(double) * (size_t)r * n, s));
+        MIH_TRY(resid_and_gram());                                   // update_mu!, update_resid!
+        MIH_TRY(score());
+        // vectorize!(full_b, df, df2); project_k!; unvectorize! (:438-440): df replaced by its projection
+        hipLaunchKernelGGL(k_mv_full, dim3(nblk(p * r)), dim3(256), 0, s, DF.p, p, r, 1.0, full.p);
+        std::vector<double> tail((size_t)r * q);
+        for (int l = 0; l < q; ++l) for (int i = 0; i < r; ++i) tail[i + r * l] = zkeep[l] ? std::numeric_limits<double>::infinity() : df2[i + r * l];
+        MIH_HIP(hipMemcpyAsync(full.p + (size_t)r * p, tail.data(), sizeof(double) * r * q, hipMemcpyHostToDevice, s));
+        Sparse snp; std::vector<double> ct; std::vector<uint8_t> cnz;
+        MIH_TRY(project_full(snp, ct, cnz));
+        hipLaunchKernelGGL(k_mv_unvec, dim3(nblk(p * r)), dim3(256), 0, s, full.p, p, r, DF.p);
+        for (int l = 0; l < q; ++l) if (!zkeep[l]) for (int i = 0; i < r; ++i) df2[i + r * l] = cnz[i + r * l] ? ct[i + r * l] : 0.0;
+        cols.clear();
+        for (size_t t = 0; t < snp.idx.size(); ++t) { int64_t j = snp.idx[t] / r; if (cols.empty() || cols.back() != j) cols.push_back(j); }
+        for (int l = 0; l < q; ++l) { idc[l] = 0; for (int i = 0; i < r; ++i) if (df2[i + r * l] != 0.0) idc[l] = 1; }
+        MIH_TRY(gather_df_cols());
+        return MIH_OK;
+    }
+    double save_prev(double cur, double best)
+    {
+        B0 = B; C0 = C; G0 = G;
+        if (cur > best) { best_B = B; best_C = C; }
+        return cur > best ? cur : best;
+    }
+    int save_best_model()                         // multivariate.jl:485-496: mu includes CZ
+    {
+        B = best_B; C = best_C;
+        MIH_TRY(update_xb());
+        hipLaunchKernelGGL(k_mv_resid, dim3(nb), dim3(256), 0, s, Y.p, Z.p, BX.p, w.p, n, r, q, cmat(C), MU.p, RES.p);
+        return MIH_OK;
+    }
+    double check_convergence() const
+    {
+        double d = 0.0, nbm = 0.0;
+        size_t i = 0, j = 0;
+        while (i < B.idx.size() || j < B0.idx.size()) {
+            double vb = 0.0, v0 = 0.0;
+            if (j >= B0.idx.size() || (i < B.idx.size() && B.idx[i] < B0.idx[j])) vb = B.val[i++];
+            else if (i >= B.idx.size() || B0.idx[j] < B.idx[i]) v0 = B0.val[j++];
+            else { vb = B.val[i++]; v0 = B0.val[j++]; }
+            d = std::max(d, std::fabs(vb - v0)); nbm = std::max(nbm, std::fabs(v0));
+        }
+        for (size_t t = 0; t < C.size(); ++t) { d = std::max(d, std::fabs(C[t] - C0[t])); nbm = std::max(nbm, std::fabs(C0[t])); }
+        return d / (nbm + 1.0);
+    }
+    int one_step(double old_logl, int nstep, int *bt, double *new_logl)
+    {
+        double eta;
+        MIH_TRY(stepsize(&eta));
+        MIH_TRY(gradstep(B, C, eta));
+        MIH_TRY(update_xb());
+        MIH_TRY(solve_sigma());
+        double logl = loglik();
+        int es = 0;
+        while (old_logl > logl && es < nstep) {
+            eta /= 2;
+            G = G0;                                                  // backtrack! (multivariate.jl:460-473)
+            MIH_TRY(gradstep(B0, C0, eta));
+            MIH_TRY(update_xb());
+            MIH_TRY(solve_sigma());
+            logl = loglik();
+            es++;
+        }
+        MIH_TRY(score());
+        MIH_TRY(gather_df_cols());
+        if (std::isnan(logl)) { set_error("Loglikelihood function is NaN, aborting..."); return MIH_NAN_LOGL; }
+        if (std::isinf(logl)) { set_error("Loglikelihood function is Inf, aborting..."); return MIH_INF_LOGL; }
+        *bt = es; *new_logl = logl;
+        return MIH_OK;
+    }
+    int fit_loop(const mih_fit_params *prm, double *best_out, int64_t *iter_out, double *lt, double *tt, int32_t *btt, int32_t *ntrace)
+    {
+        double next_logl = -std::numeric_limits<double>::infinity(), best = next_logl;
+        int64_t mm = 0; int32_t nt = 0;
+        for (int iter = 1; iter <= prm->max_iter; ++iter) {
+            if (iter >= prm->max_iter) { best = save_prev(next_logl, best); MIH_TRY(save_best_model()); mm = iter; break; }
+            best = save_prev(next_logl, best);
+            int nbt = 0;
+            MIH_TRY(one_step(next_logl, prm->max_step, &nbt, &next_logl));
+            double sc = check_convergence();
+            if (lt) lt[nt] = next_logl;
+            if (tt) tt[nt] = sc;
+            if (btt) btt[nt] = nbt;
+            nt++;
+            if (prm->progress) prm->progress(prm->progress_user, iter, next_logl, nbt, sc);
+            if (iter >= prm->min_iter && sc < prm->tol) { best = save_prev(next_logl, best); MIH_TRY(save_best_model()); mm = iter; break; }
+        }
+        *best_out = best; *iter_out = mm;
+        if (ntrace) *ntrace = nt;
+        return MIH_OK;
+    }
+};
+
+static int mv_check(const mih_mat *h, const mih_fit_params *prm)
+{
+    if (!h || !prm) { set_error("null handle/params"); return MIH_BAD_ARG; }
+    if (prm->max_iter < 0 || prm->max_step < 0) { set_error("max_iter / max_step must be nonnegative"); return MIH_BAD_ARG; }
+    if (!(prm->tol > 2.220446049250313e-16)) { set_error("Value of global tol must exceed machine precision!"); return MIH_BAD_ARG; }
+    if (h->kind == 0 && !h->center) { set_error("x is not centered! Please construct SnpLinAlg{Float64}(::SnpArray, center=true, scale=true)"); return MIH_NOT_CENTERED; }
+    return MIH_OK;
+}
+
+static double sample_var(const double *a, int64_t n)
+{
+    double m = 0.0; for (int64_t i = 0; i < n; ++i) m += a[i]; m /= (double)n;
+    double s = 0.0; for (int64_t i = 0; i < n; ++i) s += (a[i] - m) * (a[i] - m);
+    return s / (double)(n - 1);
+}
+
+}  // namespace mih
+
 using namespace mih;
-extern "C" int mih_fit_mv(const mih_mat *, const mih_fit_params *, const double *, int64_t, const double *, int64_t, const uint8_t *, mih_mv_result *) { set_error("not implemented"); return MIH_BAD_ARG; }
-extern "C" int mih_cv_mv(const mih_mat *, const mih_fit_params *, const double *, int64_t, const double *, int64_t, const int32_t *, int32_t, const int64_t *, int64_t, int32_t, int32_t, double *) { set_error("not implemented"); return MIH_BAD_ARG; }
+
+extern "C" {
+
+int mih_fit_mv(const mih_mat *h, const mih_fit_params *prm, const double *Y, int64_t r, const double *Z, int64_t q,
+               const uint8_t *train, mih_mv_result *res)
+{
+    MIH_TRY(mv_check(h, prm));
+    if (!Y || !Z || !res) { set_error("null argument"); return MIH_BAD_ARG; }
+    MIH_HIP(hipSetDevice(h->device));
+    MvVar v;
+    MIH_TRY(v.create(h, prm, Y, r, Z, q));
+    MIH_TRY(v.init(train));
+    auto t0 = std::chrono::steady_clock::now();
+    MIH_TRY(v.fit_loop(prm, &res->logl, &res->iter, res->logl_trace, res->tol_trace, res->bt_trace, &res->n_trace));
+    res->time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    res->choose_fired = v.choose_fired ? 1 : 0;
+    int rr = (int)r;
+    if (res->B) {
+        std::memset(res->B, 0, sizeof(double) * (size_t)rr * h->p);
+        for (size_t t = 0; t < v.best_B.idx.size(); ++t) res->B[v.best_B.idx[t]] = v.best_B.val[t];
+    }
+    if (res->C) for (size_t t = 0; t < v.best_C.size(); ++t) res->C[t] = v.best_C[t];
+    if (res->Sigma) {                                              // inv(v.Gamma) (data_structures.jl:275)
+        std::vector<double> inv;
+        if (!lu_logdet_inverse(v.G, rr, nullptr, nullptr, &inv)) { set_error("Gamma is singular"); return MIH_NAN_LOGL; }
+        for (size_t t = 0; t < inv.size(); ++t) res->Sigma[t] = inv[t];
+    }
+    if (res->pve) {                                                // pve.jl:36-38
+        std::vector<double> mu((size_t)rr * h->n), yy(h->n);
+        MIH_HIP(hipMemcpyAsync(mu.data(), v.MU.p, sizeof(double) * mu.size(), hipMemcpyDeviceToHost, v.s));
+        MIH_HIP(hipStreamSynchronize(v.s));
+        for (int i = 0; i < rr; ++i) {
+            for (int64_t s_ = 0; s_ < h->n; ++s_) yy[s_] = Y[i + (size_t)rr * s_];
+            res->pve[i] = sample_var(mu.data() + (size_t)i * h->n, h->n) / sample_var(yy.data(), h->n);
+        }
+    }
+    return MIH_OK;
+}
+
+int mih_cv_mv(const mih_mat *h, const mih_fit_params *prm, const double *Y, int64_t r, const double *Z, int64_t q,
+              const int32_t *folds, int32_t nfolds, const int64_t *path, int64_t npath, int32_t rank, int32_t world,
+              double *mses_raw)
+{
+    MIH_TRY(mv_check(h, prm));
+    if (!Y || !Z || !folds || !path || !mses_raw || nfolds < 1 || npath < 1 || world < 1 || rank < 0 || rank >= world) { set_error("null/invalid argument"); return MIH_BAD_ARG; }
+    int64_t n = h->n, kmax = 0;
+    for (int64_t i = 0; i < npath; ++i) kmax = std::max(kmax, path[i]);
+    for (int64_t i = 0; i < n; ++i) if (folds[i] < 1 || folds[i] > nfolds) { set_error("folds must be in 1..q"); return MIH_BAD_ARG; }
+    MIH_HIP(hipSetDevice(h->device));
+    for (int64_t i = 0; i < (int64_t)nfolds * npath; ++i) mses_raw[i] = 0.0;
+    mih_fit_params pr = *prm;
+    pr.k = kmax; pr.progress = nullptr;
+    MvVar v;
+    MIH_TRY(v.create(h, &pr, Y, r, Z, q));
+    std::vector<uint8_t> train(n);
+    int64_t combo = 0;
+    for (int32_t fold = 1; fold <= nfolds; ++fold)
+        for (int64_t ik = 0; ik < npath; ++ik, ++combo) {
+            if (combo % world != rank) continue;
+            for (int64_t i = 0; i < n; ++i) train[i] = (folds[i] != fold);
+            v.k = path[ik];
+            MIH_TRY(v.init(train.data()));
+            double best; int64_t it;
+            MIH_TRY(v.fit_loop(&pr, &best, &it, nullptr, nullptr, nullptr, nullptr));
+            MIH_TRY(v.set_weights(train.data(), 1));
+            MIH_TRY(v.update_xb());                               // predict! (cross_validation.jl:288-299)
+            hipLaunchKernelGGL(k_mv_resid, dim3(v.nb), dim3(256), 0, v.s, v.Y.p, v.Z.p, v.BX.p, v.w.p, n, v.r, v.q, v.cmat(v.C), v.MU.p, v.RES.p);
+            hipLaunchKernelGGL(k_mv_mse, dim3(v.nb), dim3(256), 0, v.s, v.Y.p, v.MU.p, v.w.p, n, v.r, v.red.p);
+            hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, v.s, v.red.p, v.nb, 1, v.scal.p);
+            double mse = 0.0;
+            MIH_HIP(hipMemcpyAsync(&mse, v.scal.p, sizeof(double), hipMemcpyDeviceToHost, v.s));
+            MIH_HIP(hipStreamSynchronize(v.s));
+            mses_raw[(int64_t)(fold - 1) * npath + ik] = mse;
+        }
+    return MIH_OK;
+}
+
+}  // extern "C"

@@ -382,3 +382,64 @@ def test_fit_iht_group_projection(mih, oracle):
     assert res.iter == o["iter"]
     assert np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"]))
     np.testing.assert_allclose(res.beta, o["beta"], rtol=1e-5, atol=1e-12)
+
+
+def _mv_problem(oracle, ox, rng, r, k, q=1):
+    p, n = ox.p, ox.n
+    B = np.zeros((r, p))
+    for _ in range(k):
+        B[rng.integers(r), rng.integers(p)] = rng.standard_normal() * 0.6
+    XB = np.zeros((r, n))
+    for i in range(r):
+        mask = (B[i] != 0).astype(np.uint8)
+        XB[i] = ox.xv_masked(mask, B[i])
+    A = rng.standard_normal((r, r))
+    L = np.linalg.cholesky(A @ A.T / r + np.eye(r) * 0.5)
+    Z = np.vstack([np.ones(n)] + [rng.standard_normal(n) for _ in range(q - 1)])
+    Cm = rng.standard_normal((r, q))
+    Y = XB + Cm @ Z + L @ rng.standard_normal((r, n))
+    return Y, Z
+
+
+@pytest.mark.parametrize("r,k,q", [(2, 10, 1), (3, 12, 2), (5, 20, 1)])
+def test_multivariate_fit_vs_oracle(mih, oracle, normal_pair, r, k, q):
+    """fit_iht with MvNormal traits (src/multivariate.jl; test/multivariate_test.jl:84-118)."""
+    x, ox = normal_pair
+    rng = np.random.default_rng(40 + r)
+    Y, Z = _mv_problem(oracle, ox, rng, r, k, q)
+    zk = None if q == 1 else [1] + [0] * (q - 1)
+    res = mih.fit_iht(Y, x, Z, k=k, zkeep=zk, verbose=False)
+    o = oracle.fit_mv(ox, Y, Z, k=k, zkeep=zk)
+    assert res.iter == o["iter"] and res.iter >= 5
+    assert np.array_equal(res.beta != 0, o["B"] != 0)                         # bit-exact support
+    np.testing.assert_allclose(res.beta, o["B"], rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(res.c, o["C"], rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(res.Σ, o["Sigma"], rtol=1e-6)
+    np.testing.assert_allclose(res.σg, o["pve"], rtol=1e-6)
+    assert res.logl == pytest.approx(o["logl"], rel=1e-9)
+    assert list(res.trace["backtracks"]) == list(o["bt_trace"])
+    assert res.beta.shape == (r, x.p) and np.count_nonzero(res.beta) <= k and np.all(res.σg > 0)
+
+
+def test_multivariate_shipped_data_and_cv(mih, oracle):
+    """data/multivariate.* (true Sigma shipped) + cv_iht on multivariate traits (cv_iht_test.jl:259-284)."""
+    n = 1000
+    bed = mih.read_bed(os.path.join(FIX, "multivariate.bed"), n)
+    x = mih.SnpLinAlg(bed, n, center=True, scale=True, impute=True)
+    ox = oracle.Mat.from_bed_columns(bed, n)
+    Y = np.loadtxt(os.path.join(FIX, "multivariate.phen"), delimiter=",").T
+    S = np.loadtxt(os.path.join(FIX, "multivariate.trait.cov"), delimiter=",")
+    res = mih.fit_iht(Y, x, None, k=10, verbose=False)
+    o = oracle.fit_mv(ox, Y, None, k=10)
+    assert res.iter == o["iter"]
+    assert np.array_equal(res.beta != 0, o["B"] != 0)
+    np.testing.assert_allclose(res.beta, o["B"], rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(res.Σ, S, atol=0.12)
+    with pytest.raises(mih.MendelIHTError):
+        mih.fit_iht(Y.T, x, None, k=10, verbose=False)                         # un-transposed input: DimensionMismatch
+    folds = hash_folds(n, 3)
+    mse, raw = mih.cv_iht(Y, x, None, path=[2, 6, 10, 14], q=3, folds=folds, verbose=False, return_raw=True)
+    omse, oraw = oracle.cv_mv(ox, Y, None, path=[2, 6, 10, 14], q=3, folds=folds)
+    np.testing.assert_allclose(raw, oraw, rtol=1e-4)
+    np.testing.assert_allclose(mse, omse, rtol=1e-4)
+    assert np.all(mse > 0)
