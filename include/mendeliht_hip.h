@@ -192,6 +192,9 @@ int mih_profile_read(double *xtv_kernel_ms, int64_t *xtv_launches, int reset);
  * in HBM, bracketed by HIP events; *ms_per_pass = average kernel-chain time. */
 int mih_bench_xtv(const mih_mat *h, int variant, int iters, int warmup, uint64_t seed,
                   float *ms_per_pass, double *checksum);
+/* Same for m right-hand sides; at most max_fused (1, 2 or 4) of them share one pass over X. */
+int mih_bench_xtv_batched(const mih_mat *h, int variant, int m, int max_fused, int iters, int warmup,
+                          uint64_t seed, float *ms_per_pass, double *checksum);
 /* Algorithmic bytes of one X'r pass: p*ceil(n/4) + 8*m*(n+p) + 16*p. */
 int mih_xtv_algorithmic_bytes(const mih_mat *h, int m, double *bytes);
 /* Select the X'r kernel variant used by every subsequent call (tuning knob). */

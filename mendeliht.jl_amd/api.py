@@ -100,6 +100,7 @@ def lib():
         "mih_fit_mv": [vp, C.POINTER(_FitParams), vp, i64, vp, i64, vp, C.POINTER(_MvResult)],
         "mih_cv_mv": [vp, C.POINTER(_FitParams), vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, vp],
         "mih_bench_xtv": [vp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_float), C.POINTER(dbl)],
+        "mih_bench_xtv_batched": [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_float), C.POINTER(dbl)],
         "mih_xtv_algorithmic_bytes": [vp, C.c_int, C.POINTER(dbl)],
         "mih_set_xtv_variant": [C.c_int],
         "mih_session_create": [vp, C.POINTER(_FitParams), vp, vp, i64, vp, C.POINTER(vp)],
@@ -123,7 +124,7 @@ def exported_symbols():
             "mih_dense_create", "mih_dense_create_synthetic", "mih_mat_destroy", "mih_mat_dims",
             "mih_snp_mu_sigma", "mih_snp_export_bed", "mih_xtv", "mih_xtv_batched", "mih_xv_sparse",
             "mih_project_topk", "mih_project_group_sparse", "mih_fit_iht", "mih_cv_iht", "mih_cv_meanloss",
-            "mih_fit_mv", "mih_cv_mv", "mih_bench_xtv", "mih_xtv_algorithmic_bytes", "mih_set_xtv_variant",
+            "mih_fit_mv", "mih_cv_mv", "mih_bench_xtv", "mih_bench_xtv_batched", "mih_xtv_algorithmic_bytes", "mih_set_xtv_variant",
             "mih_session_create", "mih_session_step", "mih_session_model", "mih_session_destroy",
             "mih_profile_enable", "mih_profile_read"]
 
@@ -268,6 +269,11 @@ class _Mat:
     def bench_xtv(self, variant=-1, iters=10, warmup=2, seed=1):
         ms, cs = C.c_float(0), C.c_double(0)
         _check(lib().mih_bench_xtv(self._h, variant, iters, warmup, seed, C.byref(ms), C.byref(cs)))
+        return ms.value, cs.value
+
+    def bench_xtv_batched(self, m, max_fused=4, variant=-1, iters=5, warmup=1, seed=1):
+        ms, cs = C.c_float(0), C.c_double(0)
+        _check(lib().mih_bench_xtv_batched(self._h, variant, m, max_fused, iters, warmup, seed, C.byref(ms), C.byref(cs)))
         return ms.value, cs.value
 
     def algorithmic_bytes(self, m=1):

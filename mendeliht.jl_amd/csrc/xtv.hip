@@ -151,10 +151,12 @@ __device__ __forceinline__ f32x16 mfma_fp4(uint32_t u0, uint32_t u1, const uint4
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bb, acc, 4, 4, 0, 127, 0, 127);
 }
 
-template <int WAVES, int CT>
+// NR right-hand sides ride the same pass: the dosage tile is loaded and expanded once and fed to NR
+// MFMAs (one per residual vector's digit planes).
+template <int WAVES, int CT, int NR>
 __global__ void __launch_bounds__(WAVES * 64)
-k_xtv_mfma(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *__restrict__ dig,
-           int splits, const double *__restrict__ scal, double *__restrict__ partial /* [splits][ncg*32] */)
+k_xtv_mfma(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *__restrict__ dig, int64_t dig_stride,
+           int splits, const double *__restrict__ scal, double *__restrict__ partial /* [NR][splits][ncg*32] */)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -166,11 +168,13 @@ k_xtv_mfma(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *_
     const int64_t b0 = split * bps;
     const int64_t b1 = (b0 + bps < nbp) ? b0 + bps : nbp;
 
-    f32x16 acc[CT];
+    f32x16 acc[CT][NR];
     #pragma unroll
     for (int c = 0; c < CT; ++c)
         #pragma unroll
-        for (int g = 0; g < 16; ++g) acc[c][g] = 0.f;
+        for (int v = 0; v < NR; ++v)
+            #pragma unroll
+            for (int g = 0; g < 16; ++g) acc[c][v][g] = 0.f;
 
     if (b0 < b1) {
         const uint4 *ap[CT];
@@ -180,23 +184,29 @@ k_xtv_mfma(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *_
             ap[c] = X + (cg * nbp) * 64 + lane;
         }
         const uint4 *bp_ = dig + lane;
-        uint4 acur[CT], anext[CT], bcur[2], bnext[2];
+        uint4 acur[CT], anext[CT], bcur[NR][2], bnext[NR][2];
         #pragma unroll
         for (int c = 0; c < CT; ++c) acur[c] = ld_stream(ap[c] + b0 * 64);
-        bcur[0] = bp_[(2 * b0) * 64]; bcur[1] = bp_[(2 * b0 + 1) * 64];
+        #pragma unroll
+        for (int v = 0; v < NR; ++v) { bcur[v][0] = bp_[v * dig_stride + (2 * b0) * 64]; bcur[v][1] = bp_[v * dig_stride + (2 * b0 + 1) * 64]; }
         for (int64_t bp = b0; bp < b1; ++bp) {
             const int64_t bn = (bp + 1 < b1) ? bp + 1 : bp;
             #pragma unroll
             for (int c = 0; c < CT; ++c) anext[c] = ld_stream(ap[c] + bn * 64);
-            bnext[0] = bp_[(2 * bn) * 64]; bnext[1] = bp_[(2 * bn + 1) * 64];
+            #pragma unroll
+            for (int v = 0; v < NR; ++v) { bnext[v][0] = bp_[v * dig_stride + (2 * bn) * 64]; bnext[v][1] = bp_[v * dig_stride + (2 * bn + 1) * 64]; }
             #pragma unroll
             for (int c = 0; c < CT; ++c) {
-                acc[c] = mfma_fp4(acur[c].x, acur[c].y, bcur[0], acc[c]);
-                acc[c] = mfma_fp4(acur[c].z, acur[c].w, bcur[1], acc[c]);
+                #pragma unroll
+                for (int v = 0; v < NR; ++v) {
+                    acc[c][v] = mfma_fp4(acur[c].x, acur[c].y, bcur[v][0], acc[c][v]);
+                    acc[c][v] = mfma_fp4(acur[c].z, acur[c].w, bcur[v][1], acc[c][v]);
+                }
             }
             #pragma unroll
             for (int c = 0; c < CT; ++c) acur[c] = anext[c];
-            bcur[0] = bnext[0]; bcur[1] = bnext[1];
+            #pragma unroll
+            for (int v = 0; v < NR; ++v) { bcur[v][0] = bnext[v][0]; bcur[v][1] = bnext[v][1]; }
         }
     }
 
@@ -204,16 +214,20 @@ k_xtv_mfma(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *_
     // acc = (1/4) sum_i g_i d_i exactly; recombine digits: sum_t 4^t * (4 acc_t), then * 2^-e.
     const int dgt = lane & 31;
     const double wgt = (dgt < kDigits) ? ldexp(1.0, 2 + 2 * dgt) : 0.0;
-    const double inv = scal[1];
     #pragma unroll
-    for (int c = 0; c < CT; ++c) {
+    for (int v = 0; v < NR; ++v) {
+        const double inv = scal[4 * v + 1];
         #pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            double v = (double)acc[c][g] * wgt;
+        for (int c = 0; c < CT; ++c) {
             #pragma unroll
-            for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);   // within each 32-lane half
-            int row = (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
-            if (dgt == 0 && cg0 + c < ncg) partial[(int64_t)split * (ncg * 32) + (cg0 + c) * 32 + row] = v * inv;
+            for (int g = 0; g < 16; ++g) {
+                double x = (double)acc[c][v][g] * wgt;
+                #pragma unroll
+                for (int off = 16; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);   // within each 32-lane half
+                int row = (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
+                if (dgt == 0 && cg0 + c < ncg)
+                    partial[((int64_t)v * splits + split) * (ncg * 32) + (cg0 + c) * 32 + row] = x * inv;
+            }
         }
     }
 }
@@ -291,6 +305,7 @@ static const Variant kVariants[] = {
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kDefaultVariant = 2;
 constexpr int kMaxSplits = 16;
+int g_xtv_max_nr = 2;     // right-hand sides fused per pass (1, 2 or 4; measured: 2 is fastest until B is LDS-shared)
 int xtv_num_variants() { return kNumVariants; }
 static bool xtv_variant_valid(int v) { return v < kNumVariants; }
 
@@ -301,18 +316,22 @@ static Variant current_variant()
     return kVariants[v];
 }
 
-template <int WAVES, int CT>
-static void launch_xtv(const mih_mat *h, const uint4 *dig, int splits, const double *scal, double *partial, hipStream_t s)
+template <int WAVES, int CT, int NR>
+static void launch_xtv(const mih_mat *h, const uint4 *dig, int64_t dig_stride, int splits, const double *scal,
+                       double *partial, hipStream_t s)
 {
     int64_t groups = (h->ncg + WAVES * CT - 1) / (WAVES * CT);
-    hipLaunchKernelGGL((k_xtv_mfma<WAVES, CT>), dim3((unsigned)(groups * splits)), dim3(WAVES * 64), 0, s,
-                       reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, splits, scal, partial);
+    hipLaunchKernelGGL((k_xtv_mfma<WAVES, CT, NR>), dim3((unsigned)(groups * splits)), dim3(WAVES * 64), 0, s,
+                       reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig_stride, splits, scal, partial);
 }
 
-static int dispatch_xtv(const Variant &v, const mih_mat *h, const uint4 *dig, int splits, const double *scal,
-                        double *partial, hipStream_t s)
+// nr = 1: the tuned single-RHS variants; nr = 2 / 4: fused multi-RHS passes (64 / 128 accumulator registers)
+static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 *dig, int64_t dig_stride, int splits,
+                        const double *scal, double *partial, hipStream_t s)
 {
-#define MIH_CASE(W, C) if (v.waves == W && v.ct == C) { launch_xtv<W, C>(h, dig, splits, scal, partial, s); return MIH_OK; }
+    if (nr == 4) { launch_xtv<4, 2, 4>(h, dig, dig_stride, splits, scal, partial, s); return MIH_OK; }
+    if (nr == 2) { launch_xtv<4, 2, 2>(h, dig, dig_stride, splits, scal, partial, s); return MIH_OK; }
+#define MIH_CASE(W, C) if (v.waves == W && v.ct == C) { launch_xtv<W, C, 1>(h, dig, dig_stride, splits, scal, partial, s); return MIH_OK; }
     MIH_CASE(4, 1) MIH_CASE(4, 2) MIH_CASE(4, 4) MIH_CASE(8, 1) MIH_CASE(8, 2) MIH_CASE(2, 2)
 #undef MIH_CASE
     set_error("unknown X'r kernel variant");
@@ -353,17 +372,21 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
     int64_t total = (int64_t)m * nblk * 64;
     hipLaunchKernelGGL(k_digits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, r_dev, h->n, nblk, m, w.scal.p,
                        reinterpret_cast<uint4 *>(w.digits.p));
-    for (int t = 0; t < m; ++t) {
+    for (int t = 0; t < m;) {
+        int nr = (m - t >= 4 && g_xtv_max_nr >= 4) ? 4 : (m - t >= 2 && g_xtv_max_nr >= 2) ? 2 : 1;
         double *partial = w.partial.p + (int64_t)t * splits * pstride;
         const uint4 *dig = reinterpret_cast<const uint4 *>(w.digits.p) + (int64_t)t * nblk * 64;
         hipEvent_t e0, e1;
         prof_begin(s, e0, e1);
-        int rc = dispatch_xtv(v, h, dig, splits, w.scal.p + 4 * t, partial, s);
+        int rc = dispatch_xtv(v, nr, h, dig, nblk * 64, splits, w.scal.p + 4 * t, partial, s);
         prof_end(s, e0, e1);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_xtv_finalize, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, s, partial, splits, pstride, h->p,
-                           w.scal.p + 4 * t, r_dev + (int64_t)t * h->n, h->mu, h->sinv, h->miss_ptr, h->miss_row,
-                           h->center, h->scale, h->impute, out_dev + (int64_t)t * h->p);
+        for (int u = t; u < t + nr; ++u)
+            hipLaunchKernelGGL(k_xtv_finalize, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, s,
+                               w.partial.p + (int64_t)u * splits * pstride, splits, pstride, h->p,
+                               w.scal.p + 4 * u, r_dev + (int64_t)u * h->n, h->mu, h->sinv, h->miss_ptr, h->miss_row,
+                               h->center, h->scale, h->impute, out_dev + (int64_t)u * h->p);
+        t += nr;
     }
     MIH_HIP(hipGetLastError());
     return MIH_OK;
@@ -460,24 +483,33 @@ __global__ void k_checksum(const double *x, int64_t p, double *out)
 int mih_bench_xtv(const mih_mat *h, int variant, int iters, int warmup, uint64_t seed,
                   float *ms_per_pass, double *checksum)
 {
-    if (!h || iters < 1 || !ms_per_pass) return MIH_BAD_ARG;
+    return mih_bench_xtv_batched(h, variant, 1, 4, iters, warmup, seed, ms_per_pass, checksum);
+}
+
+int mih_bench_xtv_batched(const mih_mat *h, int variant, int m, int max_fused, int iters, int warmup, uint64_t seed,
+                          float *ms_per_pass, double *checksum)
+{
+    if (!h || iters < 1 || !ms_per_pass || m < 1) return MIH_BAD_ARG;
+    int saved_nr = g_xtv_max_nr;
+    g_xtv_max_nr = max_fused;
+    struct Restore { int v; ~Restore() { g_xtv_max_nr = v; } } restore{saved_nr};
     MIH_HIP(hipSetDevice(h->device));
     int saved = g_xtv_variant;
     if (variant >= 0) { if (!xtv_variant_valid(variant)) return MIH_BAD_ARG; g_xtv_variant = variant; }
     XtvWork w;
-    int rc = xtv_work_init(h, w, 1);
+    int rc = xtv_work_init(h, w, m);
     DevBuf<double> r, out, cs;
-    if (!rc) rc = r.alloc((size_t)h->n);
-    if (!rc) rc = out.alloc((size_t)h->p);
+    if (!rc) rc = r.alloc((size_t)h->n * m);
+    if (!rc) rc = out.alloc((size_t)h->p * m);
     if (!rc) rc = cs.alloc(1);
     if (rc) { g_xtv_variant = saved; return rc; }
     hipStream_t s = h->stream;
-    hipLaunchKernelGGL(k_fill_random, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, s, r.p, h->n, seed);
-    for (int i = 0; i < warmup && !rc; ++i) rc = xtv_device(h, w, r.p, 1, out.p, s);
+    hipLaunchKernelGGL(k_fill_random, dim3((unsigned)((h->n * m + 255) / 256)), dim3(256), 0, s, r.p, h->n * m, seed);
+    for (int i = 0; i < warmup && !rc; ++i) rc = xtv_device(h, w, r.p, m, out.p, s);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, s);
-    for (int i = 0; i < iters && !rc; ++i) rc = xtv_device(h, w, r.p, 1, out.p, s);
+    for (int i = 0; i < iters && !rc; ++i) rc = xtv_device(h, w, r.p, m, out.p, s);
     (void)hipEventRecord(e1, s);
     hipError_t e = hipEventSynchronize(e1);
     float ms = 0.f;
@@ -488,7 +520,7 @@ int mih_bench_xtv(const mih_mat *h, int variant, int iters, int warmup, uint64_t
     if (e != hipSuccess) return hip_fail(e, "bench sync", __FILE__, __LINE__);
     *ms_per_pass = ms / iters;
     if (checksum) {
-        hipLaunchKernelGGL(k_checksum, dim3(1), dim3(256), 0, s, out.p, h->p, cs.p);
+        hipLaunchKernelGGL(k_checksum, dim3(1), dim3(256), 0, s, out.p, h->p * m, cs.p);
         MIH_HIP(hipMemcpyAsync(checksum, cs.p, sizeof(double), hipMemcpyDeviceToHost, s));
         MIH_HIP(hipStreamSynchronize(s));
     }
