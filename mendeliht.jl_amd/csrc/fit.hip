@@ -137,6 +137,42 @@ k_zt_r_final(const double *__restrict__ part, double *__restrict__ out)
     out[blockIdx.x] = a;
 }
 
+// NegBin nuisance-parameter sums over all samples (utilities.jl:158-173 MM, :186-194 Newton).
+// which = 0: { sum_i sum_{j<y_i} r/(r+j), sum_i log(r/(r+mu_i)) }; which = 1: { dl/dr, d2l/dr2 }
+__device__ __forceinline__ double d_digamma(double x)
+{
+    double r = 0.0;
+    while (x < 6.0) { r -= 1.0 / x; x += 1.0; }
+    double f = 1.0 / (x * x);
+    return r + log(x) - 0.5 / x - f * (1.0 / 12 - f * (1.0 / 120 - f * (1.0 / 252 - f * (1.0 / 240 - f * (1.0 / 132)))));
+}
+__device__ __forceinline__ double d_trigamma(double x)
+{
+    double r = 0.0;
+    while (x < 6.0) { r += 1.0 / (x * x); x += 1.0; }
+    double f = 1.0 / (x * x);
+    return r + 1.0 / x + f / 2 + f / x * (1.0 / 6 - f * (1.0 / 30 - f * (1.0 / 42 - f * (1.0 / 30 - f * (5.0 / 66)))));
+}
+__global__ void __launch_bounds__(256)
+k_nb_sums(const double *__restrict__ y, const double *__restrict__ mu, int64_t n, double r, int which,
+          double *__restrict__ partial)
+{
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    double v[2] = {0.0, 0.0};
+    if (i < n) {
+        double yi = y[i], mi = mu[i];
+        if (which == 0) {
+            double num = 0.0;
+            for (long long j = 0; j <= (long long)yi - 1; ++j) num += r / (r + (double)j);
+            v[0] = num; v[1] = log(r / (r + mi));
+        } else {
+            v[0] = -(yi + r) / (mi + r) - log(mi + r) + 1.0 + log(r) + d_digamma(r + yi) - d_digamma(r);
+            v[1] = (yi + r) / ((mi + r) * (mi + r)) - 2.0 / (mi + r) + 1.0 / r + d_trigamma(r + yi) - d_trigamma(r);
+        }
+    }
+    block_sum<2>(v, partial + 2ll * blockIdx.x);
+}
+
 // iht_stepsize! tail (utilities.jl:744-756): xgk = (X_S df_S + Z_idc df2_idc) * sqrt(mueta^2/var) * w;
 // partial[b] = sum xgk^2
 __global__ void __launch_bounds__(256)
@@ -554,6 +590,50 @@ struct IhtVar {
         return d / (nbm + 1.0);
     }
 
+    // mle_for_r (utilities.jl:141-247): NegBin nuisance parameter by MM or Newton; every sum runs over
+    // ALL samples (the reference does not apply cv_wts here), the line search uses loglikelihood(v).
+    int nb_sums(int which, double rr, double *out2)
+    {
+        hipLaunchKernelGGL(k_nb_sums, dim3(nb), dim3(256), 0, s, y.p, mu.p, n, rr, which, red.p);
+        hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, s, red.p, nb, 2, scal.p);
+        MIH_HIP(hipMemcpyAsync(out2, scal.p, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+        MIH_HIP(hipStreamSynchronize(s));
+        return MIH_OK;
+    }
+    int mle_for_r()
+    {
+        double o[2];
+        if (est_r == MIH_ESTR_MM) {                    // update_r_MM (utilities.jl:158-173)
+            MIH_TRY(nb_sums(0, nb_r, o));
+            nb_r = -o[0] / o[1];
+            return MIH_OK;
+        }
+        // update_r_newton (utilities.jl:180-247)
+        double rr = nb_r, new_r = 1.0, stepsz = 1.0;
+        const double saved = nb_r;
+        auto ll_at = [&](double x, double *val) { nb_r = x; int rc = mu_loglik(1, val, nullptr); return rc; };
+        for (int it = 0; it < 100; ++it) {
+            MIH_TRY(nb_sums(1, rr, o));
+            double inc = (o[1] < 0.0) ? o[0] / o[1] : o[0];
+            new_r = rr - stepsz * inc;
+            double old_logl, new_logl;
+            MIH_TRY(ll_at(rr, &old_logl));
+            for (int j = 0; j < 20; ++j) {
+                if (new_r <= 0.0) { stepsz /= 2; new_r = rr - stepsz * inc; }
+                else {
+                    MIH_TRY(ll_at(new_r, &new_logl));
+                    if (old_logl >= new_logl) { stepsz /= 2; new_r = rr - stepsz * inc; }
+                    else break;
+                }
+            }
+            if (std::fabs(rr - new_r) <= 1e-6) { nb_r = new_r; return MIH_OK; }
+            rr = new_r;
+        }
+        (void)saved;
+        nb_r = rr;
+        return MIH_OK;
+    }
+
     // iht_one_step! (fit.jl:213-263)
     int one_step(double old_logl, int nstep, int *bt, double *new_logl)
     {
@@ -563,12 +643,14 @@ struct IhtVar {
         MIH_TRY(update_xb());
         double logl;
         MIH_TRY(mu_loglik(1, &logl, nullptr));
+        if (est_r != MIH_ESTR_NONE) { MIH_TRY(mle_for_r()); MIH_TRY(mu_loglik(1, &logl, nullptr)); }   // fit.jl:235-240
         int es = 0;
         while (old_logl > logl && es < nstep) {       // _iht_backtrack_ (utilities.jl:484-486)
             eta /= 2;
             MIH_TRY(gradstep(b0, c0, eta));           // backtrack! (utilities.jl:959-973)
             MIH_TRY(update_xb());
             MIH_TRY(mu_loglik(1, &logl, nullptr));
+            if (est_r != MIH_ESTR_NONE) { MIH_TRY(mle_for_r()); MIH_TRY(mu_loglik(1, &logl, nullptr)); }
             es++;
         }
         MIH_TRY(score());
@@ -623,7 +705,6 @@ static int check_params(const mih_mat *h, const mih_fit_params *prm, int64_t q)
     if (!(prm->tol > 2.220446049250313e-16)) { set_error("Value of global tol must exceed machine precision!"); return MIH_BAD_ARG; }
     if (h->kind == 0 && !h->center) { set_error("x is not centered! Please construct SnpLinAlg{Float64}(::SnpArray, center=true, scale=true)"); return MIH_NOT_CENTERED; }
     if (prm->est_r != MIH_ESTR_NONE && prm->dist != MIH_NEGBIN) { set_error("Only negative binomial regression currently supports nuisance parameter estimation"); return MIH_BAD_ARG; }
-    if (prm->est_r != MIH_ESTR_NONE) { set_error("est_r (NegBin nuisance estimation) is not implemented on the device path yet"); return MIH_BAD_ARG; }
     if (!prm->ks && prm->k < 0) { set_error("Value of k (max predictors per group) must be nonnegative!"); return MIH_BAD_ARG; }
     if (q < 1 || q > kMaxQ) { set_error("number of covariates q=%lld must be in 1..%d", (long long)q, kMaxQ); return MIH_BAD_DIM; }
     if (prm->dist < 0 || prm->dist > MIH_NEGBIN || prm->link < 0 || prm->link > MIH_LOG) { set_error("unknown distribution/link"); return MIH_BAD_ARG; }

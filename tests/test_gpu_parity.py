@@ -443,3 +443,23 @@ def test_multivariate_shipped_data_and_cv(mih, oracle):
     np.testing.assert_allclose(raw, oraw, rtol=1e-4)
     np.testing.assert_allclose(mse, omse, rtol=1e-4)
     assert np.all(mse > 0)
+
+
+@pytest.mark.parametrize("method", ["MM", "Newton"])
+def test_negbin_nuisance_estimation(mih, oracle, normal_pair, method):
+    """est_r=:MM / :Newton (utilities.jl:141-247; test/L0_reg_test.jl:245-296)."""
+    x, ox = normal_pair
+    rng = np.random.default_rng(50)
+    eta = _sim(oracle, ox, rng, 6, 0.4)
+    mu = np.exp(0.5 + 0.3 * eta)
+    y = rng.negative_binomial(5, 5 / (mu + 5)).astype(float)
+    res = mih.fit_iht(y, x, None, k=6, d=mih.NegativeBinomial(1.0), l=mih.LogLink(), est_r=method, verbose=False)
+    o = oracle.fit_iht(ox, y, None, k=6, dist="negbin", link="log", nb_r=1.0, est_r=method.lower())
+    assert res.iter == o["iter"]
+    assert np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"]))
+    np.testing.assert_allclose(res.beta, o["beta"], rtol=1e-4, atol=1e-12)
+    assert res.d.r == pytest.approx(o["nb_r"], rel=1e-6)
+    assert res.logl == pytest.approx(o["logl"], rel=1e-8)
+    assert 1.0 < res.d.r < 50.0
+    with pytest.raises(mih.MendelIHTError):
+        mih.fit_iht(y, x, None, k=6, d=mih.Poisson(), l=mih.LogLink(), est_r="MM", verbose=False)   # fit.jl:93-94
