@@ -232,6 +232,97 @@ k_xtv_mfma(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *_
     }
 }
 
+// Four right-hand sides per pass with the digit planes shared through LDS: one 512-thread workgroup
+// (8 waves x CT column groups) stages the 8 KB of digit planes of a 128-row step once (each thread one
+// 16-B load, double-buffered, loads issued a step ahead) and every wave feeds its dosage tiles to
+// 4 x 2 MFMAs per tile.  L2 traffic for the digits drops 8x compared with per-wave loads, which is
+// what keeps the 4-RHS pass on the HBM roofline instead of the L2's.
+template <int CT>
+__global__ void __launch_bounds__(512)
+k_xtv_mfma_lds4(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *__restrict__ dig, int64_t dig_stride,
+                int splits, const double *__restrict__ scal, double *__restrict__ partial /* [4][splits][ncg*32] */)
+{
+    constexpr int NR = 4, WAVES = 8;
+    __shared__ uint4 btile[2][NR * 2 * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int split = blockIdx.x % splits;
+    const int64_t grp = blockIdx.x / splits;
+    const int64_t cg0 = (grp * WAVES + wave) * CT;
+    const bool live = cg0 < ncg;                      // idle waves still take part in staging/barriers
+    const int64_t bps = (nbp + splits - 1) / splits;
+    const int64_t b0 = split * bps;
+    const int64_t b1 = (b0 + bps < nbp) ? b0 + bps : nbp;
+
+    f32x16 acc[CT][NR];
+    #pragma unroll
+    for (int c = 0; c < CT; ++c)
+        #pragma unroll
+        for (int v = 0; v < NR; ++v)
+            #pragma unroll
+            for (int g = 0; g < 16; ++g) acc[c][v][g] = 0.f;
+
+    if (b0 < b1) {
+        const uint4 *ap[CT];
+        #pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            int64_t cg = cg0 + c < ncg ? cg0 + c : ncg - 1;
+            ap[c] = X + (cg * nbp) * 64 + lane;
+        }
+        // thread -> (rhs v, block e, lane): its slot of the staged tile
+        const int sv = threadIdx.x >> 7, se = (threadIdx.x >> 6) & 1;
+        const uint4 *bsrc = dig + sv * dig_stride + se * 64 + lane;
+        uint4 acur[CT], anext[CT], bstage;
+        #pragma unroll
+        for (int c = 0; c < CT; ++c) acur[c] = ld_stream(ap[c] + b0 * 64);
+        btile[0][threadIdx.x] = bsrc[(2 * b0) * 64];
+        __syncthreads();
+        int buf = 0;
+        for (int64_t bp = b0; bp < b1; ++bp) {
+            const int64_t bn = (bp + 1 < b1) ? bp + 1 : bp;
+            #pragma unroll
+            for (int c = 0; c < CT; ++c) anext[c] = ld_stream(ap[c] + bn * 64);
+            bstage = bsrc[(2 * bn) * 64];
+            if (live) {
+                #pragma unroll
+                for (int v = 0; v < NR; ++v) {
+                    const uint4 bq0 = btile[buf][(v * 2 + 0) * 64 + lane];
+                    const uint4 bq1 = btile[buf][(v * 2 + 1) * 64 + lane];
+                    #pragma unroll
+                    for (int c = 0; c < CT; ++c) {
+                        acc[c][v] = mfma_fp4(acur[c].x, acur[c].y, bq0, acc[c][v]);
+                        acc[c][v] = mfma_fp4(acur[c].z, acur[c].w, bq1, acc[c][v]);
+                    }
+                }
+            }
+            btile[buf ^ 1][threadIdx.x] = bstage;
+            __syncthreads();
+            buf ^= 1;
+            #pragma unroll
+            for (int c = 0; c < CT; ++c) acur[c] = anext[c];
+        }
+    }
+    if (!live) return;
+    const int dgt = lane & 31;
+    const double wgt = (dgt < kDigits) ? ldexp(1.0, 2 + 2 * dgt) : 0.0;
+    #pragma unroll
+    for (int v = 0; v < NR; ++v) {
+        const double inv = scal[4 * v + 1];
+        #pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            #pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                double x = (double)acc[c][v][g] * wgt;
+                #pragma unroll
+                for (int off = 16; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+                int row = (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
+                if (dgt == 0 && cg0 + c < ncg)
+                    partial[((int64_t)v * splits + split) * (ncg * 32) + (cg0 + c) * 32 + row] = x * inv;
+            }
+        }
+    }
+}
+
 // Combine slices, add the missing-entry correction, centre, scale.
 __global__ void __launch_bounds__(256)
 k_xtv_finalize(const double *__restrict__ partial, int splits, int64_t pstride, int64_t p,
@@ -305,7 +396,7 @@ static const Variant kVariants[] = {
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kDefaultVariant = 2;
 constexpr int kMaxSplits = 16;
-int g_xtv_max_nr = 2;     // right-hand sides fused per pass (1, 2 or 4; measured: 2 is fastest until B is LDS-shared)
+int g_xtv_max_nr = 4;     // right-hand sides fused per pass (1, 2 or 4); 4 = LDS-shared digit planes
 int xtv_num_variants() { return kNumVariants; }
 static bool xtv_variant_valid(int v) { return v < kNumVariants; }
 
@@ -329,7 +420,13 @@ static void launch_xtv(const mih_mat *h, const uint4 *dig, int64_t dig_stride, i
 static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 *dig, int64_t dig_stride, int splits,
                         const double *scal, double *partial, hipStream_t s)
 {
-    if (nr == 4) { launch_xtv<4, 2, 4>(h, dig, dig_stride, splits, scal, partial, s); return MIH_OK; }
+    if (nr == 4) {
+        constexpr int CT4 = 2;
+        int64_t groups = (h->ncg + 8 * CT4 - 1) / (8 * CT4);
+        hipLaunchKernelGGL((k_xtv_mfma_lds4<CT4>), dim3((unsigned)(groups * splits)), dim3(512), 0, s,
+                           reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig_stride, splits, scal, partial);
+        return MIH_OK;
+    }
     if (nr == 2) { launch_xtv<4, 2, 2>(h, dig, dig_stride, splits, scal, partial, s); return MIH_OK; }
 #define MIH_CASE(W, C) if (v.waves == W && v.ct == C) { launch_xtv<W, C, 1>(h, dig, dig_stride, splits, scal, partial, s); return MIH_OK; }
     MIH_CASE(4, 1) MIH_CASE(4, 2) MIH_CASE(4, 4) MIH_CASE(8, 1) MIH_CASE(8, 2) MIH_CASE(2, 2)
