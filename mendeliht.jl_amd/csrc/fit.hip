@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cmath>
 #include <limits>
+#include <memory>
 
 namespace mih {
 
@@ -258,14 +259,19 @@ struct IhtVar {
     bool choose_fired = false;
     bool has_weight = false;
 
-    int create(const mih_mat *hh, const mih_fit_params *prm, const double *yh, const double *zh, int64_t qq)
+    bool own_stream = true, batched = false;
+    // shared_stream != null: this variable is one of a lock-step batch (mih_cv_iht): it runs on the
+    // batch's stream and leaves the X'r pass to the batch driver.
+    int create(const mih_mat *hh, const mih_fit_params *prm, const double *yh, const double *zh, int64_t qq,
+               hipStream_t shared_stream = nullptr)
     {
         h = hh; n = h->n; p = h->p; q = (int)qq; y_host = yh;
         k = prm->k; J = prm->J; dist = prm->dist; link = prm->link; est_r = prm->est_r; nb_r = prm->nb_r;
         if (prm->ks && prm->nks > 0) { ks.assign(prm->ks, prm->ks + prm->nks); k = 0; }
         zkeep.resize(q); zkeepn = 0;
         for (int l = 0; l < q; ++l) { zkeep[l] = prm->zkeep ? (prm->zkeep[l] != 0) : 1; zkeepn += zkeep[l]; }
-        MIH_HIP(hipStreamCreate(&s));
+        if (shared_stream) { s = shared_stream; own_stream = false; batched = true; }
+        else MIH_HIP(hipStreamCreate(&s));
         nb = (int)nblk(n);
         MIH_TRY(y.alloc(n)); MIH_TRY(z.alloc((size_t)n * q)); MIH_TRY(w.alloc(n)); MIH_TRY(xb.alloc(n));
         MIH_TRY(zc.alloc(n)); MIH_TRY(mu.alloc(n)); MIH_TRY(r.alloc(n)); MIH_TRY(xgk.alloc(n));
@@ -274,7 +280,7 @@ struct IhtVar {
         int64_t kcap = std::max<int64_t>(std::max<int64_t>(J, 1) * k + q, 64) + 1024;
         for (int64_t v : ks) kcap += v;
         MIH_TRY(sidx.alloc(kcap)); MIH_TRY(sval.alloc(kcap)); MIH_TRY(gval.alloc(kcap));
-        MIH_TRY(xtv_work_init(h, xtv, 1));
+        if (!batched) MIH_TRY(xtv_work_init(h, xtv, 1));
         MIH_TRY(xv_work_init(h, xv, kcap));
         MIH_TRY(topk_work_init(topk, kcap));
         MIH_HIP(hipMemcpyAsync(y.p, yh, sizeof(double) * n, hipMemcpyHostToDevice, s));
@@ -304,7 +310,7 @@ struct IhtVar {
         c.assign(q, 0.0); c0 = c; best_c = c; df2 = c; idc.assign(q, 0); idc0 = idc;
         return MIH_OK;
     }
-    ~IhtVar() { if (s) (void)hipStreamDestroy(s); }
+    ~IhtVar() { if (s && own_stream) (void)hipStreamDestroy(s); }
 
     int ensure_stage(int64_t nnz)
     {
@@ -368,8 +374,17 @@ struct IhtVar {
     // score! (utilities.jl:126-135) + df[idx] gather for the next step size
     int score()
     {
-        hipLaunchKernelGGL(k_resid, dim3(nblk(n)), dim3(256), 0, s, xb.p, zc.p, y.p, mu.p, w.p, n, dist, link, nb_r, r.p);
+        MIH_TRY(resid_only());
         MIH_TRY(xtv_device(h, xtv, r.p, 1, df.p, s));
+        return score_post();
+    }
+    int resid_only()
+    {
+        hipLaunchKernelGGL(k_resid, dim3(nblk(n)), dim3(256), 0, s, xb.p, zc.p, y.p, mu.p, w.p, n, dist, link, nb_r, r.p);
+        return MIH_OK;
+    }
+    int score_post()       // df is in place (own X'r pass or the batch driver's)
+    {
         hipLaunchKernelGGL(k_zt_r, dim3(kZtrBlocks, q), dim3(256), 0, s, z.p, r.p, n, ztr.p);
         hipLaunchKernelGGL(k_zt_r_final, dim3(q), dim3(64), 0, s, ztr.p, scal.p);
         MIH_HIP(hipMemcpyAsync(df2.data(), scal.p, sizeof(double) * q, hipMemcpyDeviceToHost, s));
@@ -486,6 +501,12 @@ struct IhtVar {
     // init_iht_indices! (utilities.jl:366-438), init_beta=false
     int init(const uint8_t *train)
     {
+        MIH_TRY(init_pre(train));
+        MIH_TRY(xtv_device(h, xtv, r.p, 1, df.p, s));
+        return init_post();
+    }
+    int init_pre(const uint8_t *train)
+    {
         b.clear(); b0.clear(); best_b.clear(); idx.clear();
         std::fill(c.begin(), c.end(), 0.0); c0 = c; best_c = c; std::fill(df2.begin(), df2.end(), 0.0);
         for (int l = 0; l < q; ++l) { idc[l] = zkeep[l]; idc0[l] = zkeep[l]; }
@@ -505,7 +526,11 @@ struct IhtVar {
         MIH_HIP(hipMemsetAsync(xb.p, 0, sizeof(double) * n, s));
         hipLaunchKernelGGL(k_zmul, dim3(nblk(n)), dim3(256), 0, s, z.p, n, q, qvec(c), 0, zc.p);   // no clamp at init (utilities.jl:406)
         hipLaunchKernelGGL(k_mu_loglik, dim3(nb), dim3(256), 0, s, xb.p, zc.p, y.p, w.p, n, dist, link, nb_r, 1, mu.p, red.p);
-        MIH_TRY(score());
+        return resid_only();
+    }
+    int init_post()
+    {
+        MIH_TRY(score_post());
         MIH_HIP(hipStreamSynchronize(s));
         if (!ks.empty()) {
             // utilities.jl:427-429: project_group_sparse!(v.df, group, J, ks); idx is then taken from
@@ -637,6 +662,13 @@ struct IhtVar {
     // iht_one_step! (fit.jl:213-263)
     int one_step(double old_logl, int nstep, int *bt, double *new_logl)
     {
+        MIH_TRY(step_pre(old_logl, nstep, bt, new_logl));
+        MIH_TRY(xtv_device(h, xtv, r.p, 1, df.p, s));
+        return step_post(*new_logl);
+    }
+    // everything of iht_one_step! before the X'r pass (ends with the working residual in r)
+    int step_pre(double old_logl, int nstep, int *bt, double *new_logl)
+    {
         double eta;
         MIH_TRY(stepsize(&eta));
         MIH_TRY(gradstep(b, c, eta));
@@ -653,11 +685,15 @@ struct IhtVar {
             if (est_r != MIH_ESTR_NONE) { MIH_TRY(mle_for_r()); MIH_TRY(mu_loglik(1, &logl, nullptr)); }
             es++;
         }
-        MIH_TRY(score());
+        *bt = es; *new_logl = logl;
+        return resid_only();
+    }
+    int step_post(double logl)
+    {
+        MIH_TRY(score_post());
         MIH_TRY(gather_df_support());
         if (std::isnan(logl)) { set_error("Loglikelihood function is NaN, aborting..."); return MIH_NAN_LOGL; }
         if (std::isinf(logl)) { set_error("Loglikelihood function is Inf, aborting..."); return MIH_INF_LOGL; }
-        *bt = es; *new_logl = logl;
         return MIH_OK;
     }
 
@@ -751,6 +787,75 @@ int mih_fit_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, co
     return MIH_OK;
 }
 
+// ---- cv_iht: lock-step batches -----------------------------------------------------------
+// The (fold, k) fits of cross_validation.jl:100-121 are independent; on one GPU they advance in
+// lock-step so that ONE pass over the 2-bit matrix serves the score of every fit of the batch
+// (multi-RHS X'R, 4 residual vectors per pass).  Each fit keeps its own IHTVariable, backtracks and
+// converges on its own; a fit that finishes is scored on its held-out samples and leaves the batch.
+struct CvFit {
+    std::unique_ptr<IhtVar> v;
+    std::vector<uint8_t> train;
+    int64_t out_index = 0;
+    int iter = 1, nbt = 0;
+    double next_logl = -std::numeric_limits<double>::infinity(), best = -std::numeric_limits<double>::infinity();
+    bool done = false;
+};
+
+static int cv_batched_xtv(const mih_mat *h, XtvWork &xw, std::vector<CvFit *> &fits, DevBuf<double> &R, DevBuf<double> &DF,
+                          hipStream_t s)
+{
+    const int m = (int)fits.size();
+    if (m == 0) return MIH_OK;
+    for (int t = 0; t < m; ++t)
+        MIH_HIP(hipMemcpyAsync(R.p + (size_t)t * h->n, fits[t]->v->r.p, sizeof(double) * h->n, hipMemcpyDeviceToDevice, s));
+    MIH_TRY(xtv_device(h, xw, R.p, m, DF.p, s));
+    for (int t = 0; t < m; ++t)
+        MIH_HIP(hipMemcpyAsync(fits[t]->v->df.p, DF.p + (size_t)t * h->p, sizeof(double) * h->p, hipMemcpyDeviceToDevice, s));
+    return MIH_OK;
+}
+
+static int cv_finish(CvFit &f, double *mses_raw)
+{
+    f.best = f.v->save_prev(f.next_logl, f.best);
+    MIH_TRY(f.v->save_best_model());
+    MIH_TRY(f.v->set_weights(f.train.data(), 1));     // cv_wts <- test mask (cross_validation.jl:115-116)
+    MIH_TRY(f.v->update_xb());                        // predict! (:279-286)
+    double dev;
+    MIH_TRY(f.v->mu_loglik(1, nullptr, &dev));
+    mses_raw[f.out_index] = dev;
+    f.done = true;
+    f.v.reset();                                       // release the fit's device buffers
+    return MIH_OK;
+}
+
+static int cv_run_batch(const mih_mat *h, const mih_fit_params &pr, std::vector<CvFit> &fits, XtvWork &xw,
+                        DevBuf<double> &R, DevBuf<double> &DF, hipStream_t s, double *mses_raw)
+{
+    std::vector<CvFit *> need;
+    for (auto &f : fits) { MIH_TRY(f.v->init_pre(f.train.data())); need.push_back(&f); }
+    MIH_TRY(cv_batched_xtv(h, xw, need, R, DF, s));
+    for (auto *f : need) MIH_TRY(f->v->init_post());
+    for (;;) {
+        need.clear();
+        for (auto &f : fits) {
+            if (f.done) continue;
+            if (f.iter >= pr.max_iter) { MIH_TRY(cv_finish(f, mses_raw)); continue; }        // fit.jl:170-179
+            f.best = f.v->save_prev(f.next_logl, f.best);
+            MIH_TRY(f.v->step_pre(f.next_logl, pr.max_step, &f.nbt, &f.next_logl));
+            need.push_back(&f);
+        }
+        if (need.empty()) break;
+        MIH_TRY(cv_batched_xtv(h, xw, need, R, DF, s));
+        for (auto *f : need) {
+            MIH_TRY(f->v->step_post(f->next_logl));
+            double sc = f->v->check_convergence();
+            if (f->iter >= pr.min_iter && sc < pr.tol) MIH_TRY(cv_finish(*f, mses_raw));     // fit.jl:197-203
+            else f->iter++;
+        }
+    }
+    return MIH_OK;
+}
+
 int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, const double *z,
                int64_t q, const int32_t *folds, int32_t nfolds, const int64_t *path, int64_t npath,
                int32_t rank, int32_t world, double *mses_raw)
@@ -765,24 +870,64 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, con
     for (int64_t i = 0; i < (int64_t)nfolds * npath; ++i) mses_raw[i] = 0.0;
     mih_fit_params pr = *prm;
     pr.k = kmax; pr.progress = nullptr;
-    IhtVar v;
-    MIH_TRY(v.create(h, &pr, y, z, q));
-    std::vector<uint8_t> train(n);
+
+    if (prm->est_r != MIH_ESTR_NONE) {
+        // the NegBin nuisance parameter is carried from one fit to the next in the reference (v.d is
+        // never reset, cross_validation.jl:91,110): keep the sequential order for that case
+        IhtVar v;
+        MIH_TRY(v.create(h, &pr, y, z, q));
+        std::vector<uint8_t> train(n);
+        int64_t combo = 0;
+        for (int32_t fold = 1; fold <= nfolds; ++fold)
+            for (int64_t ik = 0; ik < npath; ++ik, ++combo) {
+                if (combo % world != rank) continue;
+                for (int64_t i = 0; i < n; ++i) train[i] = (folds[i] != fold);
+                v.k = path[ik];                              // cross_validation.jl:110
+                MIH_TRY(v.init(train.data()));
+                double best; int64_t it;
+                MIH_TRY(v.fit_loop(&pr, &best, &it, nullptr, nullptr, nullptr, nullptr));
+                MIH_TRY(v.set_weights(train.data(), 1));
+                MIH_TRY(v.update_xb());
+                double dev;
+                MIH_TRY(v.mu_loglik(1, nullptr, &dev));
+                mses_raw[(int64_t)(fold - 1) * npath + ik] = dev;
+            }
+        return MIH_OK;
+    }
+
+    // this rank's combinations, fold-major (cross_validation.jl:217-223), in batches
+    std::vector<std::pair<int32_t, int64_t>> mine;
     int64_t combo = 0;
     for (int32_t fold = 1; fold <= nfolds; ++fold)
-        for (int64_t ik = 0; ik < npath; ++ik, ++combo) {
-            if (combo % world != rank) continue;
-            for (int64_t i = 0; i < n; ++i) train[i] = (folds[i] != fold);
-            v.k = path[ik];                              // cross_validation.jl:110
-            MIH_TRY(v.init(train.data()));
-            double best; int64_t it;
-            MIH_TRY(v.fit_loop(&pr, &best, &it, nullptr, nullptr, nullptr, nullptr));
-            MIH_TRY(v.set_weights(train.data(), 1));     // cv_wts <- test mask (:115-116)
-            MIH_TRY(v.update_xb());                      // predict! (:279-286)
-            double dev;
-            MIH_TRY(v.mu_loglik(1, nullptr, &dev));
-            mses_raw[(int64_t)(fold - 1) * npath + ik] = dev;
+        for (int64_t ik = 0; ik < npath; ++ik, ++combo)
+            if (combo % world == rank) mine.emplace_back(fold, ik);
+    if (mine.empty()) return MIH_OK;
+    const int kMaxBatch = 16;
+    const int mb = (int)std::min<size_t>(mine.size(), kMaxBatch);
+    hipStream_t s = nullptr;
+    MIH_HIP(hipStreamCreate(&s));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{s};
+    XtvWork xw;
+    DevBuf<double> R, DF;
+    MIH_TRY(xtv_work_init(h, xw, mb));
+    MIH_TRY(R.alloc((size_t)mb * n));
+    MIH_TRY(DF.alloc((size_t)mb * h->p));
+    for (size_t start = 0; start < mine.size(); start += mb) {
+        size_t end = std::min(mine.size(), start + mb);
+        std::vector<CvFit> fits(end - start);
+        for (size_t t = start; t < end; ++t) {
+            CvFit &f = fits[t - start];
+            int32_t fold = mine[t].first; int64_t ik = mine[t].second;
+            mih_fit_params pf = pr;
+            pf.k = path[ik];                                  // v.k = sparsity (cross_validation.jl:110)
+            f.v.reset(new IhtVar());
+            MIH_TRY(f.v->create(h, &pf, y, z, q, s));
+            f.train.resize(n);
+            for (int64_t i = 0; i < n; ++i) f.train[i] = (folds[i] != fold);
+            f.out_index = (int64_t)(fold - 1) * npath + ik;
         }
+        MIH_TRY(cv_run_batch(h, pr, fits, xw, R, DF, s, mses_raw));
+    }
     return MIH_OK;
 }
 
