@@ -112,6 +112,8 @@ typedef struct mih_fit_params {
     /* per-iteration callback = the `verbose` line of fit.jl:194-196; may be NULL */
     void (*progress)(void *user, int iter, double logl, int backtracks, double tol);
     void    *progress_user;
+    int32_t  init_beta;       /* fit.jl:80 init_beta: start from the p univariate regressions
+                                 (initialize_beta!, src/utilities.jl:776-812; Normal only) */
 } mih_fit_params;
 
 /* IHTResult (src/data_structures.jl:245-256) + the per-iteration log */

@@ -43,7 +43,8 @@ class _FitParams(C.Structure):
                 ("nb_r", C.c_double), ("tol", C.c_double),
                 ("max_iter", C.c_int32), ("min_iter", C.c_int32), ("max_step", C.c_int32), ("est_r", C.c_int32),
                 ("zkeep", C.c_void_p), ("weight", C.c_void_p), ("group", C.c_void_p), ("ks", C.c_void_p),
-                ("nks", C.c_int64), ("progress", C.c_void_p), ("progress_user", C.c_void_p)]
+                ("nks", C.c_int64), ("progress", C.c_void_p), ("progress_user", C.c_void_p),
+                ("init_beta", C.c_int32)]
 
 
 class _FitResult(C.Structure):
@@ -505,7 +506,8 @@ def _print_parameters(io, k, d, l, use_maf, group, debias, tol, max_iter, min_it
     print(f"Converging when tol < {tol} and iteration ≥ {min_iter}:\n", file=io)
 
 
-def _params(k, J, d, l, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, q, p, keep, progress=None):
+def _params(k, J, d, l, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, q, p, keep, progress=None,
+            init_beta=False):
     prm = _FitParams()
     ks = None
     if np.ndim(k) > 0:
@@ -545,6 +547,7 @@ def _params(k, J, d, l, tol, max_iter, min_iter, max_step, est_r, zkeep, weight,
             raise DimensionMismatch(f"group must have length {p} but was {g.size}")
     prm.zkeep, prm.weight, prm.group, prm.ks = _p(zk), _p(w), _p(g), _p(ks)
     prm.nks = 0 if ks is None else ks.size
+    prm.init_beta = int(bool(init_beta))
     cb = None
     if progress is not None:
         cb = _PROGRESS(progress)
@@ -568,8 +571,8 @@ def fit_iht(y, x, z=None, *, k=10, J=1, d=None, l=None, group=None, weight=None,
     l = _inst(l) if l is not None else IdentityLink()
     if debias:
         raise ArgumentError("Currently debiasing only works with memory_efficient=false (not available on the GPU path)")
-    if init_beta:
-        raise ArgumentError("init_beta=true is not implemented on the GPU path yet")
+    if init_beta and not isinstance(d, Normal):
+        raise ArgumentError("Intializing beta values only work for Gaussian phenotypes! Sorry!")
     if not memory_efficient:
         raise ArgumentError("the GPU path is always memory_efficient=true")
     if isinstance(x, SnpLinAlg):
@@ -600,7 +603,8 @@ def fit_iht(y, x, z=None, *, k=10, J=1, d=None, l=None, group=None, weight=None,
             print(line, file=io)
 
     keep = []
-    prm = _params(k, J, d, l, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, q, x.p, keep, progress)
+    prm = _params(k, J, d, l, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, q, x.p, keep, progress,
+                  init_beta=init_beta)
     if verbose:
         _print_parameters(io, k, d, l, use_maf, group, debias, tol, max_iter, min_iter)
     tr = None if train is None else np.ascontiguousarray(train, dtype=np.uint8)
@@ -677,8 +681,10 @@ def cv_iht(y, x, z=None, *, d=None, l=None, path=range(1, 21), q=5, est_r="None"
     mv = _is_multivariate(y)
     d = _inst(d) if d is not None else (MvNormal() if mv else Normal())
     l = _inst(l) if l is not None else IdentityLink()
-    if debias or init_beta or not memory_efficient:
-        raise ArgumentError("debias / init_beta / memory_efficient=false are not available on the GPU path")
+    if debias or not memory_efficient:
+        raise ArgumentError("debias / memory_efficient=false are not available on the GPU path")
+    if init_beta and (mv or not isinstance(d, Normal)):
+        raise ArgumentError("init_beta is available for univariate Gaussian phenotypes only on the GPU path")
     path = np.ascontiguousarray(list(path), dtype=np.int64)
     n = x.n
     if path.size == 0:
@@ -707,7 +713,8 @@ def cv_iht(y, x, z=None, *, d=None, l=None, path=range(1, 21), q=5, est_r="None"
         if not (yv.size == n == zz.shape[0]):
             raise DimensionMismatch(f"row dimension of y, x, and z ({yv.size}, {n}, {zz.shape[0]}) are not equal")
         _checky(yv, d)
-        prm = _params(1, 1, d, l, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, zz.shape[1], x.p, keep)
+        prm = _params(1, 1, d, l, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, zz.shape[1], x.p, keep,
+                      init_beta=init_beta)
         _check(lib().mih_cv_iht(x._h, C.byref(prm), _p(yv), _p(zz), zz.shape[1], _p(folds), q, _p(path), path.size,
                                 rank, world, _p(raw)))
     if reduce is not None:

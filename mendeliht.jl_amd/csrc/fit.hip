@@ -174,6 +174,105 @@ k_nb_sums(const double *__restrict__ y, const double *__restrict__ mu, int64_t n
     block_sum<2>(v, partial + 2ll * blockIdx.x);
 }
 
+// ---- initialize_beta! (utilities.jl:776-812): the p univariate regressions y ~ 1 + x_j ------------
+// right-hand sides of the fused X'R pass: w (-> sum_train x_j) and w.*y (-> x_j'y over the training rows)
+__global__ void k_ib_rhs(const double *__restrict__ y, const double *__restrict__ w, int64_t n, double *__restrict__ R)
+{
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    R[i] = w[i];
+    R[n + i] = w[i] * y[i];
+}
+// bit 2s of word t is set iff row 16t+s is a training row
+__global__ void k_ib_mask(const double *__restrict__ w, int64_t n, int64_t nwords, uint32_t *__restrict__ M)
+{
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= nwords) return;
+    uint32_t m = 0;
+    for (int s = 0; s < 16; ++s) { int64_t i = t * 16 + s; if (i < n && w[i] != 0.0) m |= 1u << (2 * s); }
+    M[t] = m;
+}
+// dosage-1 / dosage-2 counts per column over the training rows (exact integers), tile-major walk
+constexpr int kIbBpPerBlock = 64;
+__global__ void __launch_bounds__(256)
+k_ib_counts(const uint4 *__restrict__ X, int64_t nbp, int64_t p, const uint32_t *__restrict__ M, int32_t *__restrict__ cnt)
+{
+    __shared__ int32_t red[2][32];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, m = lane & 31, h = lane >> 5;
+    const int64_t cg = blockIdx.y;
+    int32_t c1 = 0, c2 = 0;
+    int64_t bp0 = (int64_t)blockIdx.x * kIbBpPerBlock;
+    for (int64_t bp = bp0 + wv; bp < bp0 + kIbBpPerBlock && bp < nbp; bp += 4) {
+        uint4 v = X[(cg * nbp + bp) * 64 + lane];
+        uint32_t d[4] = {v.x, v.y, v.z, v.w};
+        #pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            uint32_t mt = M[bp * 8 + (qd >> 1) * 4 + h * 2 + (qd & 1)];
+            c1 += __popc(d[qd] & mt); c2 += __popc((d[qd] >> 1) & mt);
+        }
+    }
+    if (threadIdx.x < 64) red[threadIdx.x / 32][threadIdx.x % 32] = 0;
+    __syncthreads();
+    atomicAdd(&red[0][m], c1); atomicAdd(&red[1][m], c2);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        int kk = threadIdx.x / 32, mm = threadIdx.x % 32;
+        int64_t j = cg * 32 + mm;
+        if (j < p && red[kk][mm]) atomicAdd(&cnt[2 * j + kk], red[kk][mm]);
+    }
+}
+// per column: linreg! (utilities.jl:823-842) on the standardized, imputed column restricted to the
+// training rows.  Sx, Sxy come from the X'R pass; Sxx from the integer counts.  A failed Cholesky
+// leaves the UNSOLVED right-hand side (sum y, x'y) exactly as the reference's `catch` does.
+__global__ void k_ib_solve(const double *__restrict__ S /* [2][p]: Sx, Sxy */, const int32_t *__restrict__ cnt,
+                           const int64_t *__restrict__ miss_ptr, const int32_t *__restrict__ miss_row,
+                           const double *__restrict__ w, const double *__restrict__ mu, const double *__restrict__ sinv,
+                           int kind, int center, int scale, int impute, int64_t p, double N, double Sy,
+                           const double *__restrict__ dense_sxx, double *__restrict__ beta, double *__restrict__ icpt)
+{
+    int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (j >= p) return;
+    double sx = S[j], sxy = S[p + j], sxx;
+    if (kind == 0) {
+        double m = mu[j], s = scale ? sinv[j] : 1.0, cm = center ? m : 0.0;
+        double nm = 0.0;
+        for (int64_t t = miss_ptr[j]; t < miss_ptr[j + 1]; ++t) nm += (w[miss_row[t]] != 0.0) ? 1.0 : 0.0;
+        double c1 = cnt[2 * j], c2 = cnt[2 * j + 1], c0 = N - nm - c1 - c2;
+        double xm = ((impute ? m : 0.0) - cm);
+        sxx = s * s * (c0 * cm * cm + c1 * (1.0 - cm) * (1.0 - cm) + c2 * (2.0 - cm) * (2.0 - cm) + nm * xm * xm);
+    } else sxx = dense_sxx[j];
+    double u11 = sqrt(N), u12 = sx / u11, d = sxx - u12 * u12;
+    double b0, b1;
+    if (!(N > 0.0) || !(d > 0.0)) { b0 = Sy; b1 = sxy; }
+    else {
+        double u22 = sqrt(d), w1 = Sy / u11, w2 = (sxy - u12 * w1) / u22;
+        b1 = w2 / u22; b0 = (w1 - u12 * b1) / u11;
+    }
+    beta[j] = b1 < -2.0 ? -2.0 : (b1 > 2.0 ? 2.0 : b1);      // clamp!(v.b, -2, 2)
+    icpt[j] = b0;
+}
+// dense design matrix: sum over training rows of x^2 per column
+__global__ void __launch_bounds__(256)
+k_ib_dense_sxx(const double *__restrict__ D, const double *__restrict__ w, int64_t n, int64_t p, double *__restrict__ out)
+{
+    int64_t j = blockIdx.x;
+    double v[1] = {0.0};
+    for (int64_t i = threadIdx.x; i < n; i += 256) { double x = D[j * n + i]; v[0] += x * x * w[i]; }
+    block_sum<1>(v, out + j);
+}
+__global__ void __launch_bounds__(256)
+k_ib_sum(const double *__restrict__ x, int64_t p, double *__restrict__ part)
+{
+    double v[1] = {0.0};
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < p; i += 256ll * gridDim.x) v[0] += x[i];
+    block_sum<1>(v, part + blockIdx.x);
+}
+__global__ void k_ib_full(const double *__restrict__ beta, const double *__restrict__ weight, int64_t p, double *__restrict__ full)
+{
+    int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (j < p) full[j] = weight ? beta[j] * weight[j] : beta[j];
+}
+
 // iht_stepsize! tail (utilities.jl:744-756): xgk = (X_S df_S + Z_idc df2_idc) * sqrt(mueta^2/var) * w;
 // partial[b] = sum xgk^2
 __global__ void __launch_bounds__(256)
@@ -243,7 +342,8 @@ struct IhtVar {
     int64_t k = 0, J = 1; std::vector<int64_t> ks;
     int dist = 0, link = 0, est_r = 0; double nb_r = 1.0;
     std::vector<uint8_t> zkeep; int64_t zkeepn = 0;
-    const double *y_host = nullptr;
+    const double *y_host = nullptr, *z_host = nullptr;
+    int init_beta = 0;
     hipStream_t s = nullptr;
     // device
     DevBuf<double> y, z, w, xb, zc, mu, r, xgk, df, full, weight, red, scal, gval, ztr;
@@ -265,7 +365,7 @@ struct IhtVar {
     int create(const mih_mat *hh, const mih_fit_params *prm, const double *yh, const double *zh, int64_t qq,
                hipStream_t shared_stream = nullptr)
     {
-        h = hh; n = h->n; p = h->p; q = (int)qq; y_host = yh;
+        h = hh; n = h->n; p = h->p; q = (int)qq; y_host = yh; z_host = zh; init_beta = prm->init_beta;
         k = prm->k; J = prm->J; dist = prm->dist; link = prm->link; est_r = prm->est_r; nb_r = prm->nb_r;
         if (prm->ks && prm->nks > 0) { ks.assign(prm->ks, prm->ks + prm->nks); k = 0; }
         zkeep.resize(q); zkeepn = 0;
@@ -507,6 +607,7 @@ struct IhtVar {
     }
     int init_pre(const uint8_t *train)
     {
+        train_cur = train;
         b.clear(); b0.clear(); best_b.clear(); idx.clear();
         std::fill(c.begin(), c.end(), 0.0); c0 = c; best_c = c; std::fill(df2.begin(), df2.end(), 0.0);
         for (int l = 0; l < q; ++l) { idc[l] = zkeep[l]; idc0[l] = zkeep[l]; }
@@ -528,10 +629,81 @@ struct IhtVar {
         hipLaunchKernelGGL(k_mu_loglik, dim3(nb), dim3(256), 0, s, xb.p, zc.p, y.p, w.p, n, dist, link, nb_r, 1, mu.p, red.p);
         return resid_only();
     }
+    // initialize_beta!(v, cv_idx) + project_k!(v) (utilities.jl:412-414, 776-812, 561-573).  Two extra
+    // passes over X: the fused 2-RHS X'R (sum x, x'y per SNP over the training rows) and a popcount
+    // pass (sum x^2 from exact dosage counts).  df stays the dense intercept-only gradient.
+    int init_beta_phase(const uint8_t *train)
+    {
+        if (dist != MIH_NORMAL) { set_error("Intializing beta values only work for Gaussian phenotypes! Sorry!"); return MIH_BAD_ARG; }
+        XtvWork xw2; DevBuf<double> R2, S2, betad, icpt, sxxd; DevBuf<uint32_t> M; DevBuf<int32_t> cnt;
+        MIH_TRY(xtv_work_init(h, xw2, 2));
+        MIH_TRY(R2.alloc((size_t)2 * n)); MIH_TRY(S2.alloc((size_t)2 * p)); MIH_TRY(betad.alloc(p)); MIH_TRY(icpt.alloc(p));
+        hipLaunchKernelGGL(k_ib_rhs, dim3(nblk(n)), dim3(256), 0, s, y.p, w.p, n, R2.p);
+        MIH_TRY(xtv_device(h, xw2, R2.p, 2, S2.p, s));
+        double Sy = 0.0, N = 0.0;
+        std::vector<double> ys;
+        for (int64_t i = 0; i < n; ++i) if (!train || train[i]) { Sy += y_host[i]; N += 1.0; ys.push_back(y_host[i]); }
+        if (h->kind == 0) {
+            int64_t nwords = h->n_pad / 16;
+            MIH_TRY(M.alloc(nwords)); MIH_TRY(cnt.alloc((size_t)2 * p));
+            MIH_HIP(hipMemsetAsync(cnt.p, 0, sizeof(int32_t) * 2 * p, s));
+            hipLaunchKernelGGL(k_ib_mask, dim3(nblk(nwords)), dim3(256), 0, s, w.p, n, nwords, M.p);
+            dim3 grid((unsigned)((h->nbp + kIbBpPerBlock - 1) / kIbBpPerBlock), (unsigned)h->ncg);
+            hipLaunchKernelGGL(k_ib_counts, grid, dim3(256), 0, s, reinterpret_cast<const uint4 *>(h->X), h->nbp, p, M.p, cnt.p);
+        } else {
+            MIH_TRY(sxxd.alloc(p));
+            hipLaunchKernelGGL(k_ib_dense_sxx, dim3((unsigned)p), dim3(256), 0, s, h->D, w.p, n, p, sxxd.p);
+        }
+        hipLaunchKernelGGL(k_ib_solve, dim3(nblk(p)), dim3(256), 0, s, S2.p, cnt.p, h->miss_ptr, h->miss_row, w.p, h->mu, h->sinv,
+                           h->kind, h->center, h->scale, h->impute, p, N, Sy, sxxd.p, betad.p, icpt.p);
+        const int nsb = 64;
+        hipLaunchKernelGGL(k_ib_sum, dim3(nsb), dim3(256), 0, s, icpt.p, p, red.p);
+        hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, s, red.p, nsb, 1, scal.p);
+        double c0sum = 0.0;
+        MIH_HIP(hipMemcpyAsync(&c0sum, scal.p, sizeof(double), hipMemcpyDeviceToHost, s));
+        MIH_HIP(hipStreamSynchronize(s));
+        // non-genetic covariates 2..q on the host (utilities.jl:799-806)
+        for (int l = 1; l < q; ++l) {
+            double sx = 0, sxx = 0, sxy = 0;
+            size_t t = 0;
+            for (int64_t i = 0; i < n; ++i) if (!train || train[i]) { double xv = z_host[(size_t)l * n + i]; sx += xv; sxx += xv * xv; sxy += xv * ys[t++]; }
+            double u11 = std::sqrt(N), u12 = sx / u11, d = sxx - u12 * u12, b0v, b1v;
+            if (!(N > 0.0) || !(d > 0.0)) { b0v = Sy; b1v = sxy; }
+            else { double u22 = std::sqrt(d), w1 = Sy / u11, w2 = (sxy - u12 * w1) / u22; b1v = w2 / u22; b0v = (w1 - u12 * b1v) / u11; }
+            c0sum += b0v; c[l] = b1v;
+        }
+        c[0] = c0sum / (double)(p + q - 1);
+        for (int l = 0; l < q; ++l) c[l] = c[l] < -2.0 ? -2.0 : (c[l] > 2.0 ? 2.0 : c[l]);
+        c0 = c;
+        // project_k!(v): vectorize (weights, Inf for kept covariates), top-(k + zkeepn), unvectorize
+        const double *wp = has_weight ? weight.p : nullptr;
+        hipLaunchKernelGGL(k_ib_full, dim3(nblk(p)), dim3(256), 0, s, betad.p, wp, p, full.p);
+        std::vector<double> tail(q);
+        for (int l = 0; l < q; ++l) tail[l] = zkeep[l] ? std::numeric_limits<double>::infinity() : c[l];
+        MIH_HIP(hipMemcpyAsync(full.p + p, tail.data(), sizeof(double) * q, hipMemcpyHostToDevice, s));
+        Sparse snp; std::vector<double> ct(q, 0.0); std::vector<uint8_t> cnz;
+        MIH_TRY(project_full(snp, ct, cnz));
+        if (has_weight && !snp.idx.empty()) {
+            std::vector<double> hw(snp.idx.size());
+            MIH_TRY(ensure_stage((int64_t)snp.idx.size()));
+            MIH_HIP(hipMemcpyAsync(sidx.p, snp.idx.data(), sizeof(int64_t) * snp.idx.size(), hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_gather, dim3(nblk((int64_t)snp.idx.size())), dim3(256), 0, s, weight.p, sidx.p, (int64_t)snp.idx.size(), gval.p);
+            MIH_HIP(hipMemcpyAsync(hw.data(), gval.p, sizeof(double) * hw.size(), hipMemcpyDeviceToHost, s));
+            MIH_HIP(hipStreamSynchronize(s));
+            for (size_t t = 0; t < hw.size(); ++t) snp.val[t] /= hw[t];
+        }
+        b = snp; b0 = b;
+        for (int l = 0; l < q; ++l) { if (!zkeep[l]) c[l] = cnz[l] ? ct[l] : 0.0; idc[l] = (c[l] != 0.0); }
+        idx.idx = b.idx;
+        MIH_TRY(gather_df_support());
+        return MIH_OK;
+    }
+    const uint8_t *train_cur = nullptr;
     int init_post()
     {
         MIH_TRY(score_post());
         MIH_HIP(hipStreamSynchronize(s));
+        if (init_beta) return init_beta_phase(train_cur);
         if (!ks.empty()) {
             // utilities.jl:427-429: project_group_sparse!(v.df, group, J, ks); idx is then taken from
             // v.b (all zero) -> empty initial support; idc = trues
@@ -871,8 +1043,8 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, con
     mih_fit_params pr = *prm;
     pr.k = kmax; pr.progress = nullptr;
 
-    if (prm->est_r != MIH_ESTR_NONE) {
-        // the NegBin nuisance parameter is carried from one fit to the next in the reference (v.d is
+    if (prm->est_r != MIH_ESTR_NONE || prm->init_beta) {
+        // init_beta needs two extra passes per fit (not batched yet); the NegBin nuisance parameter is carried from one fit to the next in the reference (v.d is
         // never reset, cross_validation.jl:91,110): keep the sequential order for that case
         IhtVar v;
         MIH_TRY(v.create(h, &pr, y, z, q));

@@ -389,6 +389,7 @@ typedef struct {
     int64_t zkeepn;
     const int64_t *group; const double *weight;
     int choose_fired;
+    int init_beta;
 } ihtvar;
 
 static double *dalloc(int64_t n) { return (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double)); }
@@ -403,7 +404,7 @@ static ihtvar *iv_create(const orc_mat *x, const orc_params *prm, const double *
     v->k = prm->k; v->J = prm->J; v->ks = prm->ks; v->nks = prm->ks ? prm->nks : 0;
     if (v->nks > 0) v->k = 0;                         /* data_structures.jl:75-81 */
     v->dist = prm->dist; v->link = prm->link; v->nb_r = prm->nb_r; v->est_r = prm->est_r;
-    v->group = prm->group; v->weight = prm->weight;
+    v->group = prm->group; v->weight = prm->weight; v->init_beta = prm->init_beta;
     v->b = dalloc(p); v->b0 = dalloc(p); v->best_b = dalloc(p); v->df = dalloc(p);
     v->xb = dalloc(n); v->xgk = dalloc(n); v->r = dalloc(n); v->zc = dalloc(n);
     v->zdf2 = dalloc(n); v->mu = dalloc(n); v->cv_wts = dalloc(n);
@@ -547,7 +548,59 @@ static int gradstep(ihtvar *v, double eta)
     return ORC_OK;
 }
 
-/* init_iht_indices! utilities.jl:366-438 (init_beta=false path) */
+/* linreg! utilities.jl:823-842: regress y on [1 x]; on a Cholesky failure (e.g. a constant x) the
+ * reference's `catch` returns xty_store UNSOLVED, i.e. (sum y, x'y) */
+static void linreg(const double *x, const double *y, int64_t N, double *b0, double *b1)
+{
+    double sx = 0.0, sxx = 0.0, sy = 0.0, sxy = 0.0;
+    for (int64_t i = 0; i < N; ++i) { sx += x[i]; sxx += x[i] * x[i]; sy += y[i]; sxy += x[i] * y[i]; }
+    double u11 = sqrt((double)N), u12 = sx / u11, d = sxx - u12 * u12;
+    if (!(N > 0) || !(d > 0.0)) { *b0 = sy; *b1 = sxy; return; }
+    double u22 = sqrt(d);
+    double w1 = sy / u11, w2 = (sxy - u12 * w1) / u22;
+    *b1 = w2 / u22;
+    *b0 = (w1 - u12 * *b1) / u11;
+}
+
+/* initialize_beta! utilities.jl:776-812 followed by project_k!(v) utilities.jl:561-573 */
+static int initialize_beta(ihtvar *v)
+{
+    int64_t n = v->n, p = v->p, q = v->q, nt = 0;
+    for (int64_t i = 0; i < n; ++i) nt += (v->cv_wts[i] != 0.0);
+    double *xs = dalloc(nt), *ys = dalloc(nt), *col = dalloc(n);
+    int64_t t = 0;
+    for (int64_t i = 0; i < n; ++i) if (v->cv_wts[i] != 0.0) ys[t++] = v->y[i];
+    double c0 = 0.0, b0, b1;
+    for (int64_t j = 0; j < p; ++j) {
+        memset(col, 0, sizeof(double) * (size_t)n);
+        axpy_col(v->x, j, 1.0, col);
+        t = 0;
+        for (int64_t i = 0; i < n; ++i) if (v->cv_wts[i] != 0.0) xs[t++] = col[i];
+        linreg(xs, ys, nt, &b0, &b1);
+        c0 += b0; v->b[j] = b1;
+    }
+    for (int64_t l = 1; l < q; ++l) {
+        t = 0;
+        for (int64_t i = 0; i < n; ++i) if (v->cv_wts[i] != 0.0) xs[t++] = v->z[l * n + i];
+        linreg(xs, ys, nt, &b0, &b1);
+        c0 += b0; v->c[l] = b1;
+    }
+    v->c[0] = c0 / (double)(p + q - 1);
+    for (int64_t j = 0; j < p; ++j) v->b[j] = v->b[j] < -2.0 ? -2.0 : (v->b[j] > 2.0 ? 2.0 : v->b[j]);
+    for (int64_t l = 0; l < q; ++l) v->c[l] = v->c[l] < -2.0 ? -2.0 : (v->c[l] > 2.0 ? 2.0 : v->c[l]);
+    memcpy(v->b0, v->b, sizeof(double) * (size_t)p); memcpy(v->c0, v->c, sizeof(double) * (size_t)q);
+    free(xs); free(ys); free(col);
+    /* project_k!(v) */
+    vectorize(v, v->full_b, v->b, v->c);
+    int rc = orc_project_k(v->full_b, p + q, v->k + v->zkeepn);
+    if (rc) return rc;
+    unvectorize(v, v->full_b, v->b, v->c);
+    for (int64_t j = 0; j < p; ++j) v->idx[j] = (v->b[j] != 0.0);
+    for (int64_t l = 0; l < q; ++l) v->idc[l] = (v->c[l] != 0.0);
+    return ORC_OK;
+}
+
+/* init_iht_indices! utilities.jl:366-438 */
 static int init_iht_indices(ihtvar *v, const uint8_t *train)
 {
     int64_t n = v->n, p = v->p, q = v->q;
@@ -580,6 +633,10 @@ static int init_iht_indices(ihtvar *v, const uint8_t *train)
     update_mu(v);
     score(v);
 
+    if (v->init_beta) {
+        if (v->dist != ORC_NORMAL) return ORC_BAD_ARG;       /* utilities.jl:391-392 */
+        return initialize_beta(v);
+    }
     /* initial support from the largest gradient entries; df is overwritten by
      * its own projection (utilities.jl:417-425) */
     vectorize(v, v->full_b, v->df, v->df2);

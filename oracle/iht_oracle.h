@@ -57,6 +57,7 @@ typedef struct orc_params {
     const int64_t *group;     /* p (1-based labels) or NULL (fit.jl:68) */
     const int64_t *ks;        /* per-group sparsity or NULL (k::Vector{Int}) */
     int64_t  nks;
+    int32_t  init_beta;       /* fit.jl:80: start from univariate regression estimates (Normal only) */
 } orc_params;
 
 typedef struct orc_result {

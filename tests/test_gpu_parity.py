@@ -463,3 +463,39 @@ def test_negbin_nuisance_estimation(mih, oracle, normal_pair, method):
     assert 1.0 < res.d.r < 50.0
     with pytest.raises(mih.MendelIHTError):
         mih.fit_iht(y, x, None, k=6, d=mih.Poisson(), l=mih.LogLink(), est_r="MM", verbose=False)   # fit.jl:93-94
+
+
+def test_init_beta(mih, oracle, normal_pair, normal_data):
+    """init_beta=true (fit.jl:80; utilities.jl:776-842; test/L0_reg_test.jl:299-320)."""
+    x, ox = normal_pair
+    res = mih.fit_iht(normal_data["y"], x, normal_data["z"], k=7, init_beta=True, verbose=False)
+    o = oracle.fit_iht(ox, normal_data["y"], normal_data["z"], k=7, init_beta=True)
+    assert res.iter == o["iter"]
+    assert np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"]))
+    np.testing.assert_allclose(res.beta, o["beta"], rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(res.c, o["c"], rtol=1e-5)
+    np.testing.assert_allclose(res.trace["logl"], o["logl_trace"], rtol=1e-9)
+    assert np.count_nonzero(res.beta) == 7
+    # missing data, a constant SNP (Cholesky failure branch of linreg!), a train mask and prior weights
+    rng = np.random.default_rng(60)
+    n, p = 500, 400
+    cols = make_bed(rng, n, p, 0.03)
+    cols[5, :] = 0
+    xs = mih.SnpLinAlg(cols, n, center=True, scale=True, impute=True)
+    oxs = oracle.Mat.from_bed_columns(cols, n)
+    z = np.column_stack([np.ones(n), rng.standard_normal(n)])
+    y = _sim(oracle, oxs, rng, 5, 0.7) + z @ np.array([0.5, 1.0]) + rng.standard_normal(n)
+    train = (rng.random(n) < 0.8).astype(np.uint8)
+    w = rng.uniform(1, 2, p)
+    for kw in (dict(), dict(train=train), dict(weight=w, zkeep=[1, 0])):
+        res = mih.fit_iht(y, xs, z, k=6, init_beta=True, verbose=False, **kw)
+        o = oracle.fit_iht(oxs, y, z, k=6, init_beta=True, **kw)
+        assert res.iter == o["iter"], kw.keys()
+        assert np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"]))
+        np.testing.assert_allclose(res.beta, o["beta"], rtol=1e-5, atol=1e-12)
+    with pytest.raises(mih.MendelIHTError):
+        mih.fit_iht((y > 0).astype(float), xs, z, k=6, d=mih.Bernoulli(), l=mih.LogitLink(), init_beta=True, verbose=False)
+    folds = hash_folds(n, 3)
+    mse = mih.cv_iht(y, xs, z, path=[3, 5, 7], q=3, folds=folds, init_beta=True, verbose=False)
+    omse, _ = oracle.cv_iht(oxs, y, z, path=[3, 5, 7], q=3, folds=folds, init_beta=True)
+    np.testing.assert_allclose(mse, omse, rtol=1e-5)
