@@ -392,6 +392,12 @@ static const Variant kVariants[] = {
     {4, 4, 1},    // 7
     {4, 2, 16},   // 8
     {2, 2, 8},    // 9
+    {8, 4, 8},    // 10
+    {4, 4, 4},    // 11
+    {4, 4, 16},   // 12
+    {4, 8, 8},    // 13
+    {2, 4, 8},    // 14
+    {8, 4, 16},   // 15
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kDefaultVariant = 2;
@@ -429,7 +435,7 @@ static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 
     }
     if (nr == 2) { launch_xtv<4, 2, 2>(h, dig, dig_stride, splits, scal, partial, s); return MIH_OK; }
 #define MIH_CASE(W, C) if (v.waves == W && v.ct == C) { launch_xtv<W, C, 1>(h, dig, dig_stride, splits, scal, partial, s); return MIH_OK; }
-    MIH_CASE(4, 1) MIH_CASE(4, 2) MIH_CASE(4, 4) MIH_CASE(8, 1) MIH_CASE(8, 2) MIH_CASE(2, 2)
+    MIH_CASE(4, 1) MIH_CASE(4, 2) MIH_CASE(4, 4) MIH_CASE(8, 1) MIH_CASE(8, 2) MIH_CASE(2, 2) MIH_CASE(8, 4) MIH_CASE(4, 8) MIH_CASE(2, 4)
 #undef MIH_CASE
     set_error("unknown X'r kernel variant");
     return MIH_BAD_ARG;

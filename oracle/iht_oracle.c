@@ -57,8 +57,14 @@ orc_mat *orc_snp_create(const uint8_t *cols, int64_t n, int64_t p, int64_t strid
 {
     lut_init();
     orc_mat *m = (orc_mat *)calloc(1, sizeof(orc_mat));
-    m->kind = 0; m->n = n; m->p = p; m->cols = cols; m->stride = stride;
+    m->kind = 0; m->n = n; m->p = p; m->stride = stride;
     m->center = center; m->scale = scale; m->impute = impute;
+    /* private copy, first-touched by the thread that will stream it (NUMA-local pages for the
+     * OpenMP X'r used as the CPU baseline; the static column schedule below is the same everywhere) */
+    m->owned = (uint8_t *)malloc((size_t)p * (size_t)stride);
+    #pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int64_t j = 0; j < p; ++j) memcpy(m->owned + j * stride, cols + j * stride, (size_t)stride);
+    m->cols = m->owned;
     m->mu = (double *)malloc(sizeof(double) * (size_t)p);
     m->sinv = (double *)malloc(sizeof(double) * (size_t)p);
     #pragma omp parallel for num_threads(g_threads) schedule(static)
@@ -84,7 +90,7 @@ orc_mat *orc_dense_create(const double *x, int64_t n, int64_t p)
 void orc_mat_destroy(orc_mat *m)
 {
     if (!m) return;
-    free(m->mu); free(m->sinv); free(m);
+    free(m->mu); free(m->sinv); free(m->owned); free(m);
 }
 
 void orc_mat_mu_sinv(const orc_mat *m, double *mu, double *sinv)

@@ -40,6 +40,7 @@ typedef struct orc_mat {
     int64_t  stride;
     int      center, scale, impute;
     double  *mu, *sinv;       /* owned, length p */
+    uint8_t *owned;           /* private NUMA-local copy of the columns */
     /* kind 1 */
     const double *dense;      /* n x p column-major, not owned */
 } orc_mat;

@@ -499,3 +499,34 @@ def test_init_beta(mih, oracle, normal_pair, normal_data):
     mse = mih.cv_iht(y, xs, z, path=[3, 5, 7], q=3, folds=folds, init_beta=True, verbose=False)
     omse, _ = oracle.cv_iht(oxs, y, z, path=[3, 5, 7], q=3, folds=folds, init_beta=True)
     np.testing.assert_allclose(mse, omse, rtol=1e-5)
+
+
+def test_full_size_baseline_config_p1M(mih, oracle):
+    """BASELINE configs[2] at its FULL size (n = 500 000, p = 1 000 000; 125 GB of 2-bit data in HBM):
+    size-independent properties + the oracle on a column sample taken from both ends of the matrix."""
+    n, p = 500_000, 1_000_000
+    x = mih.SnpLinAlg.synthetic(n, p, seed=2024)
+    rng = np.random.default_rng(6)
+    r1, r2 = rng.standard_normal(n), rng.standard_normal(n)
+    o1, o2 = x.xtv(r1), x.xtv(r2)
+    o12 = x.xtv(0.5 * r1 - 2.0 * r2)
+    assert rel(o12, 0.5 * o1 - 2.0 * o2) < 1e-10                   # linearity
+    assert np.array_equal(x.xtv(r1), o1)                           # bit-reproducible
+    assert np.max(np.abs(x.xtv(np.ones(n)))) < 1e-6                # centred columns
+    R = np.column_stack([r1, r2, r1 + r2, r1 - r2, 2 * r1])        # fused multi-RHS pass == single passes
+    O5 = x.xtv(R)
+    assert np.array_equal(O5[:, 0], o1) and np.array_equal(O5[:, 1], o2)
+    xs = mih.SnpLinAlg.synthetic(n, 96, seed=2024)                 # same leading columns as the big matrix
+    ox = oracle.Mat.from_bed_columns(xs.export_bed(), n)
+    assert rel(o1[:96], ox.xtv(r1)) < 1e-10
+    mu, sinv = x.mu_sigma()
+    omu, osinv = ox.mu_sinv()
+    assert np.array_equal(mu[:96], omu) and np.array_equal(sinv[:96], osinv)
+    idx = np.array([3, 40, 95, p - 1])                             # X*beta through the last column too
+    val = rng.standard_normal(4)
+    xb = x.xv_sparse(idx, val)
+    mask = np.zeros(96, np.uint8); mask[idx[:3]] = 1
+    coef = np.zeros(96); coef[idx[:3]] = val[:3]
+    last = x.xv_sparse(idx[3:], val[3:])
+    assert rel(xb - last, ox.xv_masked(mask, coef)) < 1e-10
+    assert abs(last.mean()) < 1e-9 * (1 + np.abs(last).max())      # a standardized column has mean 0
