@@ -33,8 +33,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=500_000)
-    ap.add_argument("--p", type=int, default=1_000_000)
+    ap.add_argument("--n", type=int, default=int(os.environ.get("MIH_BENCH_N", 500_000)))
+    ap.add_argument("--p", type=int, default=int(os.environ.get("MIH_BENCH_P", 1_000_000)))
     ap.add_argument("--k", type=int, default=200)
     ap.add_argument("--variant", type=int, default=-1, help="X'r kernel variant (-1 = library default)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
@@ -94,11 +94,15 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # MIH_BENCH_BACKEND=gloo + MIH_BENCH_ONE_DEVICE=1: multi-rank smoke test on a single-GPU box
+    backend = os.environ.get("MIH_BENCH_BACKEND", "nccl")
+    if os.environ.get("MIH_BENCH_ONE_DEVICE"):
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     import mendeliht_amd as m
 
@@ -140,7 +144,7 @@ def main():
     m.profile_enable(False)
     xtv_ms, launches = m.profile_read(reset=True)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
