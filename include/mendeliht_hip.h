@@ -201,6 +201,8 @@ int mih_bench_xtv_batched(const mih_mat *h, int variant, int m, int max_fused, i
 int mih_xtv_algorithmic_bytes(const mih_mat *h, int m, double *bytes);
 /* Select the X'r kernel variant used by every subsequent call (tuning knob). */
 int mih_set_xtv_variant(int variant);
+/* Select the shape of the fused 4-right-hand-side kernel (0 = built-in default; tuning knob). */
+int mih_set_xtv_multi_variant(int variant);
 
 #ifdef __cplusplus
 }

@@ -232,24 +232,29 @@ k_xtv_mfma(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *_
     }
 }
 
-// Four right-hand sides per pass with the digit planes shared through LDS: one 512-thread workgroup
-// (8 waves x CT column groups) stages the 8 KB of digit planes of a 128-row step once (each thread one
-// 16-B load, double-buffered, loads issued a step ahead) and every wave feeds its dosage tiles to
-// 4 x 2 MFMAs per tile.  L2 traffic for the digits drops 8x compared with per-wave loads, which is
-// what keeps the 4-RHS pass on the HBM roofline instead of the L2's.
-template <int CT>
-__global__ void __launch_bounds__(512)
-k_xtv_mfma_lds4(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *__restrict__ dig, int64_t dig_stride,
-                int splits, const double *__restrict__ scal, double *__restrict__ partial /* [4][splits][ncg*32] */)
+// Four right-hand sides per pass with the digit planes shared through LDS.  A workgroup of WAVES
+// waves x CT column groups stages the 8 KB of digit planes of each 128-row block once (instead of once
+// per wave: L2 traffic for the digits drops WAVES-fold, which is what keeps the pass off the L2
+// roofline) and every wave feeds its dosage tiles to 4 x 2 MFMAs per tile.  A barrier step covers RB
+// blocks; the digits of step t+1 are loaded during step t-1 and stored to the idle LDS buffer at the
+// top of step t, the dosage tiles of step t+1 are loaded at the top of step t, so no load is waited
+// for in the step that issued it.  Measured (tools/sweep_multi.py, tools/probe_power.py,
+// profiles/r01_power_clock_smi.log): every workgroup shape lands on 29.5 ms because the pass is
+// POWER-bound, not issue- or latency-bound -- the package sits at its ~1340 W cap and the shader
+// clock drops from 2360 MHz (1 RHS) to ~1935 MHz (4 RHS); all-zero digit planes run 17 % faster.
+// MODE 1 / 2 (no MFMAs / no dosage loads) exist only for those timing probes.
+template <int CT, int RB, int MODE = 0, int WAVES = 8>   // MODE 1: no MFMAs, 2: no dosage loads (timing probes only)
+__global__ void __launch_bounds__(WAVES * 64, 2)
+k_xtv_mfma_lds4rb(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *__restrict__ dig, int64_t dig_stride,
+                  int splits, const double *__restrict__ scal, double *__restrict__ partial /* [4][splits][ncg*32] */)
 {
-    constexpr int NR = 4, WAVES = 8;
-    __shared__ uint4 btile[2][NR * 2 * 64];
+    constexpr int NR = 4, NT = WAVES * 64, PER = 512 / NT;   // PER staged slots per thread and block
+    __shared__ uint4 btile[2][RB][NR * 2 * 64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int split = blockIdx.x % splits;
     const int64_t grp = blockIdx.x / splits;
     const int64_t cg0 = (grp * WAVES + wave) * CT;
-    const bool live = cg0 < ncg;                      // idle waves still take part in staging/barriers
     const int64_t bps = (nbp + splits - 1) / splits;
     const int64_t b0 = split * bps;
     const int64_t b1 = (b0 + bps < nbp) ? b0 + bps : nbp;
@@ -263,46 +268,88 @@ k_xtv_mfma_lds4(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uin
             for (int g = 0; g < 16; ++g) acc[c][v][g] = 0.f;
 
     if (b0 < b1) {
+        const int64_t last = b1 - 1;
         const uint4 *ap[CT];
         #pragma unroll
         for (int c = 0; c < CT; ++c) {
-            int64_t cg = cg0 + c < ncg ? cg0 + c : ncg - 1;
+            int64_t cg = cg0 + c < ncg ? cg0 + c : ncg - 1;      // idle waves redo the last group
             ap[c] = X + (cg * nbp) * 64 + lane;
         }
-        // thread -> (rhs v, block e, lane): its slot of the staged tile
-        const int sv = threadIdx.x >> 7, se = (threadIdx.x >> 6) & 1;
-        const uint4 *bsrc = dig + sv * dig_stride + se * 64 + lane;
-        uint4 acur[CT], anext[CT], bstage;
+        // staged slot s = threadIdx.x + u*NT of a 128-row block: rhs s >> 7, 64-row half (s >> 6) & 1
+        const uint4 *bsrc[PER];
         #pragma unroll
-        for (int c = 0; c < CT; ++c) acur[c] = ld_stream(ap[c] + b0 * 64);
-        btile[0][threadIdx.x] = bsrc[(2 * b0) * 64];
+        for (int u = 0; u < PER; ++u) {
+            const int sl = threadIdx.x + u * NT;
+            bsrc[u] = dig + (int64_t)(sl >> 7) * dig_stride + ((sl >> 6) & 1) * 64 + lane;
+        }
+        uint4 acur[RB][CT], anext[RB][CT];
+        u32x4 bstage[RB][PER];      // native vector type: stays in registers across the loop edge
+        #pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            const int64_t bq = (b0 + q < last) ? b0 + q : last;
+            #pragma unroll
+            for (int c = 0; c < CT; ++c) acur[q][c] = ld_stream(ap[c] + bq * 64);
+            const int64_t b2 = (b0 + RB + q < last) ? b0 + RB + q : last;
+            #pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                btile[0][q][threadIdx.x + u * NT] = bsrc[u][(2 * bq) * 64];
+                bstage[q][u] = *reinterpret_cast<const u32x4 *>(bsrc[u] + (2 * b2) * 64);
+            }
+        }
         __syncthreads();
         int buf = 0;
-        for (int64_t bp = b0; bp < b1; ++bp) {
-            const int64_t bn = (bp + 1 < b1) ? bp + 1 : bp;
+        // bstage is carried across the loop edge: the digits of step t+1 are loaded during step t-1
+        // and stored to the idle LDS buffer at the top of step t, so neither that load nor the dosage
+        // prefetch is waited for in the step that issued it.
+        for (int64_t bp = b0; bp < b1; bp += RB) {
             #pragma unroll
-            for (int c = 0; c < CT; ++c) anext[c] = ld_stream(ap[c] + bn * 64);
-            bstage = bsrc[(2 * bn) * 64];
-            if (live) {
+            for (int q = 0; q < RB; ++q)
                 #pragma unroll
-                for (int v = 0; v < NR; ++v) {
-                    const uint4 bq0 = btile[buf][(v * 2 + 0) * 64 + lane];
-                    const uint4 bq1 = btile[buf][(v * 2 + 1) * 64 + lane];
-                    #pragma unroll
-                    for (int c = 0; c < CT; ++c) {
-                        acc[c][v] = mfma_fp4(acur[c].x, acur[c].y, bq0, acc[c][v]);
-                        acc[c][v] = mfma_fp4(acur[c].z, acur[c].w, bq1, acc[c][v]);
+                for (int u = 0; u < PER; ++u) *reinterpret_cast<u32x4 *>(&btile[buf ^ 1][q][threadIdx.x + u * NT]) = bstage[q][u];
+            #pragma unroll
+            for (int q = 0; q < RB; ++q) {
+                const int64_t bn = (bp + RB + q < last) ? bp + RB + q : last;
+                #pragma unroll
+                for (int c = 0; c < CT; ++c) { if (MODE != 2) anext[q][c] = ld_stream(ap[c] + bn * 64); else anext[q][c] = acur[q][c]; }
+                const int64_t b2 = (bp + 2 * RB + q < last) ? bp + 2 * RB + q : last;
+                #pragma unroll
+                for (int u = 0; u < PER; ++u) bstage[q][u] = *reinterpret_cast<const u32x4 *>(bsrc[u] + (2 * b2) * 64);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // keep the prefetch loads ahead of the MFMA section
+            // (block q, rhs v) items in sequence; the digit fragments of item i+1 are read from LDS
+            // before the MFMAs of item i are issued so the LDS latency hides behind the matrix pipe
+            uint4 bfr[2][2];
+            bfr[0][0] = btile[buf][0][lane];
+            bfr[0][1] = btile[buf][0][64 + lane];
+            #pragma unroll
+            for (int i = 0; i < RB * NR; ++i) {
+                const int q = i / NR, v = i % NR;
+                if (i + 1 < RB * NR) {
+                    const int q1 = (i + 1) / NR, v1 = (i + 1) % NR;
+                    bfr[(i + 1) & 1][0] = btile[buf][q1][(v1 * 2 + 0) * 64 + lane];
+                    bfr[(i + 1) & 1][1] = btile[buf][q1][(v1 * 2 + 1) * 64 + lane];
+                }
+                const uint32_t keep = (bp + q < b1) ? 0xFFFFFFFFu : 0u;     // blocks past the slice end add zero
+                #pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    if (MODE != 1) {
+                        acc[c][v] = mfma_fp4(acur[q][c].x & keep, acur[q][c].y & keep, bfr[i & 1][0], acc[c][v]);
+                        acc[c][v] = mfma_fp4(acur[q][c].z & keep, acur[q][c].w & keep, bfr[i & 1][1], acc[c][v]);
+                    } else {
+                        acc[c][v][0] += __uint_as_float((acur[q][c].x ^ acur[q][c].y ^ acur[q][c].z ^ acur[q][c].w) & keep & bfr[i & 1][0].x & bfr[i & 1][1].y);
                     }
                 }
             }
-            btile[buf ^ 1][threadIdx.x] = bstage;
+            __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             buf ^= 1;
             #pragma unroll
-            for (int c = 0; c < CT; ++c) acur[c] = anext[c];
+            for (int q = 0; q < RB; ++q)
+                #pragma unroll
+                for (int c = 0; c < CT; ++c) acur[q][c] = anext[q][c];
         }
     }
-    if (!live) return;
+    if (cg0 >= ncg) return;
     const int dgt = lane & 31;
     const double wgt = (dgt < kDigits) ? ldexp(1.0, 2 + 2 * dgt) : 0.0;
     #pragma unroll
@@ -403,6 +450,7 @@ constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kDefaultVariant = 2;
 constexpr int kMaxSplits = 16;
 int g_xtv_max_nr = 4;     // right-hand sides fused per pass (1, 2 or 4); 4 = LDS-shared digit planes
+int g_xtv_multi_variant = 0;   // which 4-RHS kernel shape (tuning knob, mih_set_xtv_multi_variant)
 int xtv_num_variants() { return kNumVariants; }
 static bool xtv_variant_valid(int v) { return v < kNumVariants; }
 
@@ -427,11 +475,18 @@ static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 
                         const double *scal, double *partial, hipStream_t s)
 {
     if (nr == 4) {
-        constexpr int CT4 = 2;
-        int64_t groups = (h->ncg + 8 * CT4 - 1) / (8 * CT4);
-        hipLaunchKernelGGL((k_xtv_mfma_lds4<CT4>), dim3((unsigned)(groups * splits)), dim3(512), 0, s,
-                           reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig_stride, splits, scal, partial);
-        return MIH_OK;
+#define MIH_LDS4(ID, C, RB, MODE, W) if (g_xtv_multi_variant == ID) { \
+        int64_t groups = (h->ncg + W * C - 1) / (W * C); \
+        hipLaunchKernelGGL((k_xtv_mfma_lds4rb<C, RB, MODE, W>), dim3((unsigned)(groups * splits)), dim3(W * 64), 0, s, \
+                           reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig_stride, splits, scal, partial); \
+        return MIH_OK; }
+        MIH_LDS4(0, 2, 2, 0, 8)      // default
+        MIH_LDS4(1, 2, 1, 0, 8) MIH_LDS4(2, 2, 3, 0, 8) MIH_LDS4(3, 2, 4, 0, 8) MIH_LDS4(4, 1, 4, 0, 8)
+        MIH_LDS4(5, 2, 1, 0, 4) MIH_LDS4(6, 2, 2, 0, 4)
+        MIH_LDS4(7, 2, 2, 1, 8) MIH_LDS4(8, 2, 2, 2, 8)      // timing probes (results are NOT X'r)
+#undef MIH_LDS4
+        set_error("unknown 4-RHS kernel variant");
+        return MIH_BAD_ARG;
     }
     if (nr == 2) { launch_xtv<4, 2, 2>(h, dig, dig_stride, splits, scal, partial, s); return MIH_OK; }
 #define MIH_CASE(W, C) if (v.waves == W && v.ct == C) { launch_xtv<W, C, 1>(h, dig, dig_stride, splits, scal, partial, s); return MIH_OK; }
@@ -447,9 +502,15 @@ int xtv_work_init(const mih_mat *h, XtvWork &w, int m)
 {
     if (h->kind != 0) return MIH_OK;
     int64_t nblk = h->nbp * 2;
-    MIH_TRY(w.digits.alloc((size_t)m * (size_t)nblk * 64 * 4));
-    MIH_TRY(w.partial.alloc((size_t)kMaxSplits * (size_t)m * (size_t)h->ncg * 32));
-    MIH_TRY(w.scal.alloc((size_t)m * 4 + (size_t)m * kStatBlocks * 2));
+    // capacity rounded up to a multiple of 4: three leftover right-hand sides ride a 4-RHS pass with an
+    // all-zero digit plane (29 ms) instead of a 2-RHS + a 1-RHS pass (45 ms); the padding stays zero
+    const int m4 = (m + 3) & ~3;
+    MIH_TRY(w.digits.alloc((size_t)m4 * (size_t)nblk * 64 * 4));
+    MIH_TRY(w.partial.alloc((size_t)kMaxSplits * (size_t)m4 * (size_t)h->ncg * 32));
+    MIH_TRY(w.scal.alloc((size_t)m4 * 4 + (size_t)m * kStatBlocks * 2));
+    MIH_HIP(hipMemsetAsync(w.digits.p, 0, sizeof(*w.digits.p) * (size_t)m4 * (size_t)nblk * 64 * 4, h->stream));
+    MIH_HIP(hipMemsetAsync(w.scal.p, 0, sizeof(double) * (size_t)m4 * 4, h->stream));
+    MIH_HIP(hipStreamSynchronize(h->stream));
     w.m_cap = m; w.splits_cap = kMaxSplits;
     return MIH_OK;
 }
@@ -469,14 +530,15 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
     if (splits > h->nbp) splits = (int)h->nbp;
     if (splits > w.splits_cap) splits = w.splits_cap;
     const int64_t nblk = h->nbp * 2, pstride = h->ncg * 32;
-    double *part = w.scal.p + (size_t)m * 4;
+    double *part = w.scal.p + (size_t)((w.m_cap + 3) & ~3) * 4;
     hipLaunchKernelGGL(k_r_stats, dim3(kStatBlocks), dim3(256), 0, s, r_dev, h->n, m, part);
     hipLaunchKernelGGL(k_r_stats_final, dim3(m), dim3(64), 0, s, part, kStatBlocks, m, w.scal.p);
     int64_t total = (int64_t)m * nblk * 64;
     hipLaunchKernelGGL(k_digits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, r_dev, h->n, nblk, m, w.scal.p,
                        reinterpret_cast<uint4 *>(w.digits.p));
     for (int t = 0; t < m;) {
-        int nr = (m - t >= 4 && g_xtv_max_nr >= 4) ? 4 : (m - t >= 2 && g_xtv_max_nr >= 2) ? 2 : 1;
+        int nr = (m - t >= 3 && g_xtv_max_nr >= 4 && t + 4 <= ((w.m_cap + 3) & ~3)) ? 4
+                 : (m - t >= 2 && g_xtv_max_nr >= 2) ? 2 : 1;
         double *partial = w.partial.p + (int64_t)t * splits * pstride;
         const uint4 *dig = reinterpret_cast<const uint4 *>(w.digits.p) + (int64_t)t * nblk * 64;
         hipEvent_t e0, e1;
@@ -484,7 +546,7 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
         int rc = dispatch_xtv(v, nr, h, dig, nblk * 64, splits, w.scal.p + 4 * t, partial, s);
         prof_end(s, e0, e1);
         if (rc) return rc;
-        for (int u = t; u < t + nr; ++u)
+        for (int u = t; u < t + nr && u < m; ++u)
             hipLaunchKernelGGL(k_xtv_finalize, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, s,
                                w.partial.p + (int64_t)u * splits * pstride, splits, pstride, h->p,
                                w.scal.p + 4 * u, r_dev + (int64_t)u * h->n, h->mu, h->sinv, h->miss_ptr, h->miss_row,
@@ -528,6 +590,13 @@ int mih_set_xtv_variant(int variant)
 {
     if (!xtv_variant_valid(variant)) { set_error("variant %d out of range", variant); return MIH_BAD_ARG; }
     g_xtv_variant = variant;
+    return MIH_OK;
+}
+
+int mih_set_xtv_multi_variant(int variant)
+{
+    if (variant < 0 || variant > 8) { set_error("multi-RHS variant %d out of range", variant); return MIH_BAD_ARG; }
+    g_xtv_multi_variant = variant;
     return MIH_OK;
 }
 

@@ -77,8 +77,11 @@ def test_ragged_missing_flags(mih, oracle, n, p, miss, flags):
 
 def test_xtv_batched_and_empty_support(mih, oracle, normal_pair):
     x, ox = normal_pair
-    R = np.random.default_rng(1).standard_normal((x.n, 3))
-    assert rel(x.xtv(R), ox.xtv_multi(R)) < 1e-11
+    R = np.random.default_rng(1).standard_normal((x.n, 9))
+    assert rel(x.xtv(R[:, :3]), ox.xtv_multi(R[:, :3])) < 1e-11
+    singles = np.column_stack([x.xtv(R[:, v]) for v in range(9)])
+    for m_rhs in range(1, 10):          # every split into 4-/2-/1-RHS passes (3 left over ride a padded 4-pass)
+        assert np.array_equal(x.xtv(R[:, :m_rhs]), singles[:, :m_rhs]), m_rhs
     assert np.all(x.xv_sparse(np.zeros(0, np.int64), np.zeros(0)) == 0.0)
     with pytest.raises(mih.MendelIHTError):
         x.xv_sparse(np.array([x.p]), np.array([1.0]))

@@ -1,0 +1,13 @@
+"""Run the X'r pass in a loop for a few seconds (for sampling clocks/power with rocm-smi alongside)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import mendeliht_amd as m
+nrhs, mv, secs = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3])
+x = m.SnpLinAlg.synthetic(500_000, 1_000_000, seed=2024)
+m.lib().mih_set_xtv_multi_variant(mv)
+print("ready", flush=True)
+t0 = time.time()
+while time.time() - t0 < secs:
+    ms, _ = x.bench_xtv_batched(nrhs, max_fused=4, iters=20, warmup=0)
+    print(f"nrhs={nrhs} {ms:.2f} ms/pass", flush=True)
