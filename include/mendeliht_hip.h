@@ -65,6 +65,11 @@ int mih_snp_create(const uint8_t *bed_cols, int64_t n, int64_t p, int64_t col_st
  * src/simulate_utilities.jl:33-47,85-101; counter-based hash RNG, seed-reproducible). */
 int mih_snp_create_synthetic(int64_t n, int64_t p, uint64_t seed, double missing_rate,
                              int center, int scale, int impute, int device, mih_mat **out);
+/* Columns [col_offset, col_offset + p) of the same synthetic matrix (the generator is keyed by
+ * (seed, global column)): one shard of a column-sharded fit. */
+int mih_snp_create_synthetic_shard(int64_t n, int64_t p, int64_t col_offset, uint64_t seed,
+                                   double missing_rate, int center, int scale, int impute,
+                                   int device, mih_mat **out);
 /* Dense Float64 design matrix (the reference's `x::Matrix{Float64}` path), n x p column-major. */
 int mih_dense_create(const double *x, int64_t n, int64_t p, int device, mih_mat **out);
 int mih_dense_create_synthetic(int64_t n, int64_t p, uint64_t seed, int device, mih_mat **out);
@@ -95,6 +100,27 @@ int mih_project_group_sparse(double *y, const int64_t *group, int64_t len, int64
                              const int64_t *k, int k_is_vector);
 
 /* ---- fit_iht ---------------------------------------------------------------- */
+/* Column-sharded single fit (one process per GPU): every process owns a contiguous block
+ * of the SNP columns as its own mih_mat; y, z and all n-vectors are replicated.  The reference has no
+ * multi-device fit, so there is no line to cite for the exchange itself: the library calls back into
+ * the host at the points where iht_stepsize!/update_xb! (src/utilities.jl:722-764, 93-118) sum over
+ * the support columns, where project_k! (utilities.jl:553-559) needs the global k-th largest entry,
+ * and where check_convergence (utilities.jl:953-957) takes a max over beta.  The host implements the
+ * two collectives with its own communicator (RCCL through torch.distributed in the Python mirror,
+ * MPI.Allreduce in the Julia glue).  Both must return 0 on success, on every rank, in the same order. */
+typedef struct mih_comm {
+    int32_t rank, world;
+    int64_t col_offset;       /* global 0-based index of this shard's first column */
+    int64_t p_global;         /* total number of SNP columns over all shards */
+    /* in-place reduction of `count` doubles over the ranks; op 0 = sum, 1 = max.  on_device = 1: buf is
+     * device memory on the fit's GPU and everything queued on the fit's stream has completed; the
+     * callback returns after the reduced values are visible to any stream. */
+    int (*allreduce)(void *user, double *buf, int64_t count, int32_t op, int32_t on_device);
+    /* recv[r*count .. (r+1)*count) = `send` of rank r; host memory */
+    int (*allgather)(void *user, const double *send, int64_t count, double *recv);
+    void *user;
+} mih_comm;
+
 /* keyword arguments of fit_iht (src/fit.jl:64-81) */
 typedef struct mih_fit_params {
     int64_t  k;               /* sparsity (ignored when ks != NULL) */
@@ -114,6 +140,9 @@ typedef struct mih_fit_params {
     void    *progress_user;
     int32_t  init_beta;       /* fit.jl:80 init_beta: start from the p univariate regressions
                                  (initialize_beta!, src/utilities.jl:776-812; Normal only) */
+    const mih_comm *comm;     /* NULL = single process; else this process's shard of a column-sharded
+                                 fit: h, weight, res->beta cover the LOCAL columns only (mih_fit_iht and
+                                 mih_session_* only; no group / init_beta / cross-validation) */
 } mih_fit_params;
 
 /* IHTResult (src/data_structures.jl:245-256) + the per-iteration log */

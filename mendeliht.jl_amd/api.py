@@ -44,7 +44,17 @@ class _FitParams(C.Structure):
                 ("max_iter", C.c_int32), ("min_iter", C.c_int32), ("max_step", C.c_int32), ("est_r", C.c_int32),
                 ("zkeep", C.c_void_p), ("weight", C.c_void_p), ("group", C.c_void_p), ("ks", C.c_void_p),
                 ("nks", C.c_int64), ("progress", C.c_void_p), ("progress_user", C.c_void_p),
-                ("init_beta", C.c_int32)]
+                ("init_beta", C.c_int32), ("comm", C.c_void_p)]
+
+
+class _Comm(C.Structure):
+    """mih_comm (include/mendeliht_hip.h): the exchange callbacks of a column-sharded fit."""
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("col_offset", C.c_int64), ("p_global", C.c_int64),
+                ("allreduce", C.c_void_p), ("allgather", C.c_void_p), ("user", C.c_void_p)]
+
+
+_ALLREDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32)
+_ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
 
 class _FitResult(C.Structure):
@@ -84,6 +94,7 @@ def lib():
         "mih_version": [C.POINTER(C.c_int), C.POINTER(C.c_int)],
         "mih_snp_create": [vp, i64, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
         "mih_snp_create_synthetic": [i64, i64, C.c_uint64, dbl, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
+        "mih_snp_create_synthetic_shard": [i64, i64, i64, C.c_uint64, dbl, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
         "mih_dense_create": [vp, i64, i64, C.c_int, C.POINTER(vp)],
         "mih_dense_create_synthetic": [i64, i64, C.c_uint64, C.c_int, C.POINTER(vp)],
         "mih_mat_destroy": [vp],
@@ -123,6 +134,7 @@ def lib():
 def exported_symbols():
     """Every symbol include/mendeliht_hip.h declares (checked by the CPU test-suite)."""
     return ["mih_device_count", "mih_last_error", "mih_version", "mih_snp_create", "mih_snp_create_synthetic",
+            "mih_snp_create_synthetic_shard",
             "mih_dense_create", "mih_dense_create_synthetic", "mih_mat_destroy", "mih_mat_dims",
             "mih_snp_mu_sigma", "mih_snp_export_bed", "mih_xtv", "mih_xtv_batched", "mih_xv_sparse",
             "mih_project_topk", "mih_project_group_sparse", "mih_fit_iht", "mih_cv_iht", "mih_cv_meanloss",
@@ -312,10 +324,12 @@ class SnpLinAlg(_Mat):
         self._dims()
 
     @classmethod
-    def synthetic(cls, n, p, seed=2024, missing_rate=0.0, center=True, scale=True, impute=True, device=0):
+    def synthetic(cls, n, p, seed=2024, missing_rate=0.0, center=True, scale=True, impute=True, device=0,
+                  col_offset=0):
+        """Columns [col_offset, col_offset + p) of the seeded synthetic SnpArray (col_offset > 0: one shard)."""
         h = C.c_void_p(None)
-        _check(lib().mih_snp_create_synthetic(n, p, seed, float(missing_rate), int(center), int(scale),
-                                              int(impute), device, C.byref(h)))
+        _check(lib().mih_snp_create_synthetic_shard(n, p, int(col_offset), seed, float(missing_rate), int(center),
+                                                    int(scale), int(impute), device, C.byref(h)))
         return cls(None, center=center, scale=scale, impute=impute, device=device, _handle=h)
 
     def mu_sigma(self):
@@ -432,7 +446,8 @@ class mIHTResult:
 class IHTSession:
     """An IHTVariable kept alive on the GPU: `initialize` once, then `step()` = one iht_one_step!."""
 
-    def __init__(self, y, x, z=None, *, k=10, J=1, d=None, l=None, zkeep=None, weight=None, max_step=3, train=None):
+    def __init__(self, y, x, z=None, *, k=10, J=1, d=None, l=None, zkeep=None, weight=None, max_step=3, train=None,
+                 comm=None):
         x = _as_mat(x)
         d = _inst(d) if d is not None else Normal()
         l = _inst(l) if l is not None else IdentityLink()
@@ -444,7 +459,8 @@ class IHTSession:
             raise DimensionMismatch(f"row dimension of y, x, and z ({y.size}, {x.n}, {z.shape[0]}) are not equal")
         self.q = z.shape[1]
         self._keep = [y, z]
-        prm = _params(k, J, d, l, 1e-4, 1 << 30, 5, max_step, "None", zkeep, weight, None, self.q, x.p, self._keep)
+        prm = _params(k, J, d, l, 1e-4, 1 << 30, 5, max_step, "None", zkeep, weight, None, self.q, x.p, self._keep,
+                      comm=comm)
         tr = None if train is None else np.ascontiguousarray(train, dtype=np.uint8)
         self._h = C.c_void_p(None)
         _check(lib().mih_session_create(x._h, C.byref(prm), _p(y), _p(z), self.q, _p(tr), C.byref(self._h)))
@@ -509,8 +525,11 @@ def _print_parameters(io, k, d, l, use_maf, group, debias, tol, max_iter, min_it
 
 
 def _params(k, J, d, l, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, q, p, keep, progress=None,
-            init_beta=False):
+            init_beta=False, comm=None):
     prm = _FitParams()
+    if comm is not None:            # column-sharded fit: mendeliht.jl_amd.dist.ColumnComm
+        prm.comm = comm.pointer()
+        keep.append(comm)
     ks = None
     if np.ndim(k) > 0:
         ks = np.ascontiguousarray(k, dtype=np.int64)
@@ -560,8 +579,11 @@ def _params(k, J, d, l, tol, max_iter, min_iter, max_step, est_r, zkeep, weight,
 
 def fit_iht(y, x, z=None, *, k=10, J=1, d=None, l=None, group=None, weight=None, zkeep=None, est_r="None",
             use_maf=False, debias=False, verbose=True, tol=1e-4, max_iter=200, min_iter=5, max_step=3,
-            io=None, init_beta=False, memory_efficient=True, train=None):
+            io=None, init_beta=False, memory_efficient=True, train=None, comm=None):
     """fit_iht(y, x, z; k, J, d, l, ...) -- src/fit.jl:60-118.
+
+    comm: a `dist.ColumnComm` when x holds only this process's block of SNP columns (column-sharded fit
+    over several GPUs; beta in the result then covers the local columns -- see dist.fit_iht_sharded).
 
     Univariate: y (n,), x SnpLinAlg/DenseMatrix (n x p), z (n, q) with a leading column of ones.
     Multivariate (d=MvNormal or y 2-D): y (r, n), z (q, n), x is the same SnpLinAlg (its transpose is implied).
@@ -606,7 +628,7 @@ def fit_iht(y, x, z=None, *, k=10, J=1, d=None, l=None, group=None, weight=None,
 
     keep = []
     prm = _params(k, J, d, l, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, q, x.p, keep, progress,
-                  init_beta=init_beta)
+                  init_beta=init_beta, comm=comm)
     if verbose:
         _print_parameters(io, k, d, l, use_maf, group, debias, tol, max_iter, min_iter)
     tr = None if train is None else np.ascontiguousarray(train, dtype=np.uint8)

@@ -315,6 +315,20 @@ __global__ void k_scatter_b(const int64_t *__restrict__ idx, const double *__res
     full[j] = weight ? v * weight[j] : v;
 }
 // unvectorize! for the gradient at init (utilities.jl:420): df <- projected full / weight
+__global__ void k_scatter_set(const int64_t *__restrict__ idx, const double *__restrict__ val, int64_t nnz, double *__restrict__ out)
+{
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t < nnz) out[idx[t]] = val[t];
+}
+
+__global__ void k_clamp_pm20(double *__restrict__ x, int64_t n)
+{
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a = x[i];
+    x[i] = a < -20.0 ? -20.0 : (a > 20.0 ? 20.0 : a);
+}
+
 __global__ void k_unvec(const double *__restrict__ full, const double *__restrict__ weight, int64_t p,
                         double *__restrict__ df)
 {
@@ -359,6 +373,28 @@ struct IhtVar {
     bool choose_fired = false;
     bool has_weight = false;
 
+    // column-sharded fit (mih_comm): this process owns columns [col0, col0 + p) of pg; n-vectors replicated
+    const mih_comm *comm = nullptr;
+    int64_t col0 = 0, pg = 0;
+    int comm_fail(int rc) { set_error("communicator callback failed (%d)", rc); return MIH_BAD_ARG; }
+    int allreduce_dev(double *buf, int64_t cnt, int op)
+    {
+        MIH_HIP(hipStreamSynchronize(s));
+        int rc = comm->allreduce(comm->user, buf, cnt, op, 1);
+        return rc ? comm_fail(rc) : MIH_OK;
+    }
+    int allreduce_host(double *buf, int64_t cnt, int op)
+    {
+        int rc = comm->allreduce(comm->user, buf, cnt, op, 0);
+        return rc ? comm_fail(rc) : MIH_OK;
+    }
+    int allgather_host(const double *send, int64_t cnt, std::vector<double> &recv)
+    {
+        recv.assign((size_t)cnt * comm->world, 0.0);
+        int rc = comm->allgather(comm->user, send, cnt, recv.data());
+        return rc ? comm_fail(rc) : MIH_OK;
+    }
+
     bool own_stream = true, batched = false;
     // shared_stream != null: this variable is one of a lock-step batch (mih_cv_iht): it runs on the
     // batch's stream and leaves the X'r pass to the batch driver.
@@ -366,6 +402,17 @@ struct IhtVar {
                hipStream_t shared_stream = nullptr)
     {
         h = hh; n = h->n; p = h->p; q = (int)qq; y_host = yh; z_host = zh; init_beta = prm->init_beta;
+        comm = prm->comm; pg = p; col0 = 0;
+        if (comm) {
+            if (!comm->allreduce || !comm->allgather || comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world ||
+                comm->col_offset < 0 || comm->col_offset + p > comm->p_global) {
+                set_error("invalid mih_comm (callbacks, rank/world or column range)"); return MIH_BAD_ARG;
+            }
+            if (prm->group || prm->ks || prm->init_beta) {
+                set_error("group projection and init_beta are not available in a column-sharded fit"); return MIH_BAD_ARG;
+            }
+            col0 = comm->col_offset; pg = comm->p_global;
+        }
         k = prm->k; J = prm->J; dist = prm->dist; link = prm->link; est_r = prm->est_r; nb_r = prm->nb_r;
         if (prm->ks && prm->nks > 0) { ks.assign(prm->ks, prm->ks + prm->nks); k = 0; }
         zkeep.resize(q); zkeepn = 0;
@@ -448,6 +495,11 @@ struct IhtVar {
     {
         int clamp = (dist != MIH_NORMAL);
         MIH_TRY(upload(b.idx, b.val));
+        if (comm) {          // partial X_S b_S of the local support columns, summed over the shards, then the clamp
+            MIH_TRY(xv_sparse_device(h, xv, sidx.p, sval.p, (int64_t)b.idx.size(), xb.p, 0, s));
+            MIH_TRY(allreduce_dev(xb.p, n, 0));
+            if (clamp) hipLaunchKernelGGL(k_clamp_pm20, dim3(nblk(n)), dim3(256), 0, s, xb.p, n);
+        } else
         MIH_TRY(xv_sparse_device(h, xv, sidx.p, sval.p, (int64_t)b.idx.size(), xb.p, clamp, s));
         hipLaunchKernelGGL(k_zmul, dim3(nblk(n)), dim3(256), 0, s, z.p, n, q, qvec(c), clamp, zc.p);
         return MIH_OK;
@@ -506,12 +558,14 @@ struct IhtVar {
 
     // _choose! (utilities.jl:444-458): RNG tie-break in the reference; deterministic here
     // (drop the smallest |b|, ties highest index) and flagged.
-    void choose()
+    int choose()
     {
         int64_t sparsity = k + zkeepn, groups = (J == 0) ? 1 : J;
-        int64_t nz = (int64_t)b.idx.size() - zkeepn;
+        int64_t nsnp = (int64_t)b.idx.size();
+        if (comm) { double t = (double)nsnp; MIH_TRY(allreduce_host(&t, 1, 0)); nsnp = (int64_t)t; }
+        int64_t nz = nsnp - zkeepn;
         for (int l = 0; l < q; ++l) nz += idc[l];
-        if (nz <= groups * sparsity) return;
+        if (nz <= groups * sparsity) return MIH_OK;
         int64_t excess = nz - groups * sparsity;
         choose_fired = true;
         std::vector<size_t> ord(b.idx.size());
@@ -522,15 +576,41 @@ struct IhtVar {
             return b.idx[a] > b.idx[bb];
         });
         std::vector<char> drop(b.idx.size(), 0);
-        for (int64_t t = 0; t < excess && t < (int64_t)ord.size(); ++t) drop[ord[t]] = 1;
+        if (!comm) {
+            for (int64_t t = 0; t < excess && t < (int64_t)ord.size(); ++t) drop[ord[t]] = 1;
+        } else {
+            // every shard offers its `excess` smallest entries as (|b|, global index); the globally smallest
+            // `excess` (ties: highest global index first) are dropped by their owners
+            std::vector<double> mine((size_t)excess * 2), all;
+            for (int64_t t = 0; t < excess; ++t) {
+                bool have = t < (int64_t)ord.size();
+                mine[2 * t] = have ? std::fabs(b.val[ord[t]]) : std::numeric_limits<double>::infinity();
+                mine[2 * t + 1] = have ? (double)(col0 + b.idx[ord[t]]) : -1.0;
+            }
+            MIH_TRY(allgather_host(mine.data(), excess * 2, all));
+            std::vector<std::pair<double, double>> cand;
+            for (size_t t = 0; t + 1 < all.size(); t += 2) if (all[t + 1] >= 0.0) cand.emplace_back(all[t], all[t + 1]);
+            std::sort(cand.begin(), cand.end(), [](const std::pair<double, double> &a, const std::pair<double, double> &bb) {
+                if (a.first != bb.first) return a.first < bb.first;
+                return a.second > bb.second;
+            });
+            for (int64_t t = 0; t < excess && t < (int64_t)cand.size(); ++t) {
+                int64_t g = (int64_t)cand[t].second - col0;
+                if (g < 0 || g >= p) continue;
+                auto it = std::lower_bound(b.idx.begin(), b.idx.end(), g);
+                if (it != b.idx.end() && *it == g) drop[it - b.idx.begin()] = 1;
+            }
+        }
         Sparse nb2;
         for (size_t i = 0; i < b.idx.size(); ++i) if (!drop[i]) { nb2.idx.push_back(b.idx[i]); nb2.val.push_back(b.val[i]); }
         b = nb2;
+        return MIH_OK;
     }
 
     // project the (p+q) buffer `full` to k+zkeepn and split the survivors into (SNP list, covariate values)
     int project_full(Sparse &snp, std::vector<double> &ctail, std::vector<uint8_t> &ctail_nz)
     {
+        if (comm) return project_full_sharded(snp, ctail, ctail_nz);
         std::vector<int64_t> si; std::vector<double> sv;
         MIH_TRY(topk_project_device(full.p, p + q, k + zkeepn, topk, s, si, sv));
         snp.clear();
@@ -539,6 +619,37 @@ struct IhtVar {
             if (si[t] < p) { snp.idx.push_back(si[t]); snp.val.push_back(sv[t]); }
             else { ctail[si[t] - p] = sv[t]; ctail_nz[si[t] - p] = 1; }
         }
+        return MIH_OK;
+    }
+    // project_k! over the shards: the K-th largest |entry| of the whole vector is the K-th largest of
+    // the union of every shard's own top-K (plus the covariate tail, which every rank holds); ties at
+    // that value are kept, as in utilities.jl:553-559.  Local survivors of the local projection are a
+    // superset of the global survivors because the global threshold is >= every local one.
+    int project_full_sharded(Sparse &snp, std::vector<double> &ctail, std::vector<uint8_t> &ctail_nz)
+    {
+        const int64_t K = k + zkeepn;
+        if (K <= 0 || K > pg + q) { set_error("Attempted to project to sparsity level %lld (vector length %lld)", (long long)K, (long long)(pg + q)); return MIH_BAD_ARG; }
+        std::vector<double> tail(q);
+        MIH_HIP(hipMemcpyAsync(tail.data(), full.p + p, sizeof(double) * q, hipMemcpyDeviceToHost, s));
+        std::vector<int64_t> si; std::vector<double> sv;
+        const int64_t Kloc = std::min<int64_t>(K, p);
+        if (Kloc > 0) MIH_TRY(topk_project_device(full.p, p, Kloc, topk, s, si, sv));
+        MIH_HIP(hipStreamSynchronize(s));
+        std::vector<double> mags(sv.size());
+        for (size_t t = 0; t < sv.size(); ++t) mags[t] = std::fabs(sv[t]);
+        std::sort(mags.begin(), mags.end(), std::greater<double>());
+        std::vector<double> mine((size_t)K, -1.0), all;        // -1 = no entry (magnitudes are >= 0)
+        for (int64_t t = 0; t < K && t < (int64_t)mags.size(); ++t) mine[t] = mags[t];
+        MIH_TRY(allgather_host(mine.data(), K, all));
+        for (int l = 0; l < q; ++l) all.push_back(std::fabs(tail[l]));
+        std::nth_element(all.begin(), all.begin() + (K - 1), all.end(), std::greater<double>());
+        const double a = all[K - 1];
+        snp.clear();
+        ctail_nz.assign(q, 0);
+        for (size_t t = 0; t < si.size(); ++t)
+            if (std::fabs(sv[t]) >= a) { snp.idx.push_back(si[t]); snp.val.push_back(sv[t]); }
+        for (int l = 0; l < q; ++l)
+            if (std::fabs(tail[l]) >= a) { ctail[l] = tail[l]; ctail_nz[l] = 1; }
         return MIH_OK;
     }
 
@@ -557,7 +668,7 @@ struct IhtVar {
             MIH_TRY(collect_nonzero_device(full.p, p, topk, s, snp.idx, snp.val));
             b = snp;
             for (int l = 0; l < q; ++l) { c[l] = std::fma(eta, df2[l], cc[l]); idc[l] = (c[l] != 0.0); }
-            if (ks.empty()) choose();         // typeof(k) == Int && _choose!(v)
+            if (ks.empty()) MIH_TRY(choose());         // typeof(k) == Int && _choose!(v)
             idx.idx = b.idx;
             return MIH_OK;
         }
@@ -590,7 +701,7 @@ struct IhtVar {
             c[l] = zkeep[l] ? cn[l] : (cnz[l] ? ct[l] : 0.0);
             idc[l] = (c[l] != 0.0);
         }
-        choose();
+        MIH_TRY(choose());
         idx.idx = b.idx;          // idx = b .!= 0
         return MIH_OK;
     }
@@ -720,18 +831,36 @@ struct IhtVar {
         MIH_HIP(hipMemcpyAsync(full.p + p, tail.data(), sizeof(double) * q, hipMemcpyHostToDevice, s));
         Sparse snp; std::vector<double> ct(q, 0.0); std::vector<uint8_t> cnz;
         MIH_TRY(project_full(snp, ct, cnz));
+        if (comm) {          // the device copy was only projected to the LOCAL threshold: rebuild it from the survivors
+            MIH_HIP(hipMemsetAsync(full.p, 0, sizeof(double) * p, s));
+            MIH_TRY(upload(snp.idx, snp.val));
+            if (!snp.idx.empty())
+                hipLaunchKernelGGL(k_scatter_set, dim3(nblk((int64_t)snp.idx.size())), dim3(256), 0, s, sidx.p, sval.p, (int64_t)snp.idx.size(), full.p);
+        }
         hipLaunchKernelGGL(k_unvec, dim3(nblk(p)), dim3(256), 0, s, full.p, wp, p, df.p);
         for (int l = 0; l < q; ++l) if (!zkeep[l]) df2[l] = cnz[l] ? ct[l] : 0.0;
         idx.idx = snp.idx;
         for (int l = 0; l < q; ++l) idc[l] = zkeep[l];
         // _choose!(v) at init looks at idx with b == 0: it can only fire on exact ties; flag it
         {
-            int64_t nz = (int64_t)idx.idx.size() - zkeepn;
+            int64_t nsnp = (int64_t)idx.idx.size();
+            if (comm) { double t = (double)nsnp; MIH_TRY(allreduce_host(&t, 1, 0)); nsnp = (int64_t)t; }
+            int64_t nz = nsnp - zkeepn;
             for (int l = 0; l < q; ++l) nz += idc[l];
             if (nz > ((J == 0) ? 1 : J) * (k + zkeepn)) {
                 choose_fired = true;
                 int64_t excess = nz - ((J == 0) ? 1 : J) * (k + zkeepn);
-                for (int64_t t = 0; t < excess && !idx.idx.empty(); ++t) idx.idx.pop_back();
+                if (!comm) {
+                    for (int64_t t = 0; t < excess && !idx.idx.empty(); ++t) idx.idx.pop_back();
+                } else {         // drop the `excess` highest GLOBAL indices
+                    std::vector<double> mine((size_t)excess, -1.0), all;
+                    for (int64_t t = 0; t < excess && t < (int64_t)idx.idx.size(); ++t)
+                        mine[t] = (double)(col0 + idx.idx[idx.idx.size() - 1 - t]);
+                    MIH_TRY(allgather_host(mine.data(), excess, all));
+                    std::sort(all.begin(), all.end(), std::greater<double>());
+                    const double cut = all[excess - 1];       // indices >= cut go
+                    while (!idx.idx.empty() && cut >= 0.0 && (double)(col0 + idx.idx.back()) >= cut) idx.idx.pop_back();
+                }
             }
         }
         MIH_TRY(gather_df_support());
@@ -746,6 +875,7 @@ struct IhtVar {
         std::vector<double> d2(q);
         double numer = 0.0;
         for (size_t t = 0; t < idx.val.size(); ++t) numer += idx.val[t] * idx.val[t];
+        if (comm) { MIH_TRY(allreduce_dev(xgk.p, n, 0)); MIH_TRY(allreduce_host(&numer, 1, 0)); }
         for (int l = 0; l < q; ++l) { d2[l] = idc[l] ? df2[l] : 0.0; if (idc[l]) numer += df2[l] * df2[l]; }
         hipLaunchKernelGGL(k_stepsize, dim3(nb), dim3(256), 0, s, xgk.p, z.p, xb.p, zc.p, mu.p, w.p, n, q, qvec(d2), dist, link, nb_r, red.p);
         hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, s, red.p, nb, 1, scal.p);
@@ -772,7 +902,7 @@ struct IhtVar {
         MIH_TRY(mu_loglik(0, nullptr, nullptr));     // mu = linkinv(xb): genetic part only
         return MIH_OK;
     }
-    double check_convergence() const                 // utilities.jl:953-957
+    double check_convergence()                       // utilities.jl:953-957
     {
         double d = 0.0, nbm = 0.0;
         size_t i = 0, j = 0;
@@ -782,6 +912,11 @@ struct IhtVar {
             else if (i >= b.idx.size() || b0.idx[j] < b.idx[i]) v0 = b0.val[j++];
             else { vb = b.val[i++]; v0 = b0.val[j++]; }
             d = std::max(d, std::fabs(vb - v0)); nbm = std::max(nbm, std::fabs(v0));
+        }
+        if (comm) {
+            double two[2] = {d, nbm};
+            if (allreduce_host(two, 2, 1)) return std::numeric_limits<double>::quiet_NaN();
+            d = two[0]; nbm = two[1];
         }
         for (int l = 0; l < q; ++l) { d = std::max(d, std::fabs(c[l] - c0[l])); nbm = std::max(nbm, std::fabs(c0[l])); }
         return d / (nbm + 1.0);
@@ -1033,6 +1168,7 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, con
                int32_t rank, int32_t world, double *mses_raw)
 {
     MIH_TRY(check_params(h, prm, q));
+    if (prm->comm) { set_error("cross-validation shards over (fold,k) combinations (rank/world), not over columns"); return MIH_BAD_ARG; }
     if (!y || !z || !folds || !path || !mses_raw || nfolds < 1 || npath < 1 || world < 1 || rank < 0 || rank >= world) { set_error("null/invalid argument"); return MIH_BAD_ARG; }
     int64_t n = h->n, kmax = 0;
     for (int64_t i = 0; i < npath; ++i) kmax = std::max(kmax, path[i]);

@@ -589,6 +589,7 @@ static int mv_check(const mih_mat *h, const mih_fit_params *prm)
 {
     if (!h || !prm) { set_error("null handle/params"); return MIH_BAD_ARG; }
     if (prm->max_iter < 0 || prm->max_step < 0) { set_error("max_iter / max_step must be nonnegative"); return MIH_BAD_ARG; }
+    if (prm->comm) { set_error("column-sharded fits are univariate only"); return MIH_BAD_ARG; }
     if (!(prm->tol > 2.220446049250313e-16)) { set_error("Value of global tol must exceed machine precision!"); return MIH_BAD_ARG; }
     if (h->kind == 0 && !h->center) { set_error("x is not centered! Please construct SnpLinAlg{Float64}(::SnpArray, center=true, scale=true)"); return MIH_NOT_CENTERED; }
     return MIH_OK;

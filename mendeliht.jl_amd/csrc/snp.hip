@@ -155,7 +155,7 @@ __device__ __forceinline__ void synth_col_keys(uint64_t seed, int64_t j, uint32_
 }
 
 __global__ void __launch_bounds__(256)
-k_synth(uint4 *__restrict__ X, int64_t nbp, int64_t n, int64_t p, uint64_t seed,
+k_synth(uint4 *__restrict__ X, int64_t nbp, int64_t n, int64_t p, int64_t col0, uint64_t seed,
         uint32_t miss_thr, int32_t *__restrict__ cnt)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, m = lane & 31, h = lane >> 5;
@@ -163,7 +163,7 @@ k_synth(uint4 *__restrict__ X, int64_t nbp, int64_t n, int64_t p, uint64_t seed,
     const int64_t j = cg * 32 + m;
     const bool live = j < p;
     uint32_t key_g = 0, key_m = 0, thr16 = 0;
-    if (live) synth_col_keys(seed, j, key_g, key_m, thr16);
+    if (live) synth_col_keys(seed, col0 + j, key_g, key_m, thr16);
     int32_t c1 = 0, c2 = 0, cm = 0;
     int64_t bp0 = (int64_t)blockIdx.x * kBpPerBlock;
     for (int64_t bp = bp0 + w; bp < bp0 + kBpPerBlock && bp < nbp; bp += 4) {
@@ -192,13 +192,13 @@ k_synth(uint4 *__restrict__ X, int64_t nbp, int64_t n, int64_t p, uint64_t seed,
 }
 
 __global__ void __launch_bounds__(64)
-k_fill_missing_synth(int64_t n, int64_t p, uint64_t seed, uint32_t miss_thr,
+k_fill_missing_synth(int64_t n, int64_t p, int64_t col0, uint64_t seed, uint32_t miss_thr,
                      const int64_t *__restrict__ miss_ptr, int32_t *__restrict__ miss_row)
 {
     int64_t j = blockIdx.x;
     if (j >= p) return;
     uint32_t key_g, key_m, thr16;
-    synth_col_keys(seed, j, key_g, key_m, thr16);
+    synth_col_keys(seed, col0 + j, key_g, key_m, thr16);
     int64_t base = miss_ptr[j];
     int lane = threadIdx.x;
     for (int64_t i0 = 0; i0 < n; i0 += 64) {
@@ -380,6 +380,12 @@ int mih_snp_create(const uint8_t *bed_cols, int64_t n, int64_t p, int64_t col_st
 int mih_snp_create_synthetic(int64_t n, int64_t p, uint64_t seed, double missing_rate,
                              int center, int scale, int impute, int device, mih_mat **out)
 {
+    return mih_snp_create_synthetic_shard(n, p, 0, seed, missing_rate, center, scale, impute, device, out);
+}
+
+int mih_snp_create_synthetic_shard(int64_t n, int64_t p, int64_t col_offset, uint64_t seed, double missing_rate,
+                                   int center, int scale, int impute, int device, mih_mat **out)
+{
     if (!out) return MIH_BAD_ARG;
     if (n <= 0 || p <= 0 || n >= (1ll << 31)) { set_error("bad dimensions"); return MIH_BAD_DIM; }
     if (!(missing_rate >= 0.0 && missing_rate < 1.0)) { set_error("missing_rate must be in [0,1)"); return MIH_BAD_ARG; }
@@ -396,7 +402,7 @@ int mih_snp_create_synthetic(int64_t n, int64_t p, uint64_t seed, double missing
     uint32_t miss_thr = (uint32_t)(missing_rate * 4294967296.0);
     if (hipMemsetAsync(cnt.p, 0, sizeof(int32_t) * 3 * (size_t)p, h->stream) != hipSuccess) return fail(MIH_HIP_ERROR);
     dim3 grid((unsigned)((h->nbp + kBpPerBlock - 1) / kBpPerBlock), (unsigned)h->ncg);
-    hipLaunchKernelGGL(k_synth, grid, dim3(256), 0, h->stream, reinterpret_cast<uint4 *>(h->X), h->nbp, n, p, seed, miss_thr, cnt.p);
+    hipLaunchKernelGGL(k_synth, grid, dim3(256), 0, h->stream, reinterpret_cast<uint4 *>(h->X), h->nbp, n, p, col_offset, seed, miss_thr, cnt.p);
     hipLaunchKernelGGL(k_col_stats, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, h->stream, cnt.p, n, p, h->mu, h->sinv);
     if (hipStreamSynchronize(h->stream) != hipSuccess) { set_error("synthetic generator failed: %s", hipGetErrorString(hipGetLastError())); return fail(MIH_HIP_ERROR); }
     std::vector<int32_t> hcnt((size_t)(3 * p));
@@ -404,7 +410,7 @@ int mih_snp_create_synthetic(int64_t n, int64_t p, uint64_t seed, double missing
     std::vector<int64_t> ptr;
     if ((rc = finish_missing_ptr(h, hcnt, ptr))) return fail(rc);
     if (h->total_missing > 0) {
-        hipLaunchKernelGGL(k_fill_missing_synth, dim3((unsigned)p), dim3(64), 0, h->stream, n, p, seed, miss_thr, h->miss_ptr, h->miss_row);
+        hipLaunchKernelGGL(k_fill_missing_synth, dim3((unsigned)p), dim3(64), 0, h->stream, n, p, col_offset, seed, miss_thr, h->miss_ptr, h->miss_row);
         if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(MIH_HIP_ERROR);
     }
     *out = h;

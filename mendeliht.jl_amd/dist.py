@@ -1,10 +1,15 @@
-"""Multi-GPU sharding of the cross-validation loop (src/cross_validation.jl:98-121).
+"""Multi-GPU paths: one process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" on
+CPU-only test boxes).
 
-One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" on
-CPU-only test boxes).  Every rank holds a full 2-bit replica of X in its own HBM and
-evaluates the (fold, k) combinations whose fold-major index is congruent to its rank;
-the only data-path exchange is ONE all-gather of the q x len(path) held-out losses.
+1. Cross-validation (src/cross_validation.jl:98-121): every rank holds a full 2-bit replica of X in its
+   own HBM and evaluates the (fold, k) combinations whose fold-major index is congruent to its rank;
+   the only data-path exchange is ONE all-gather of the q x len(path) held-out losses.
+2. Column-sharded single fit (`ColumnComm`, `fit_iht_sharded`): every rank holds a contiguous block of
+   the SNP columns; per iteration the library asks for two n-vector sums (X_S b_S of update_xb!, X_S g_S
+   of iht_stepsize!), one small all-gather (the top-k candidates of project_k!) and a few scalars.  The
+   X'r pass itself needs no exchange.
 """
+import ctypes as C
 import os
 
 import numpy as np
@@ -60,3 +65,135 @@ def cv_iht_distributed(y, x, z=None, **kw):
     else:
         rank, world = 0, 1
     return cv_iht(y, x, z, rank=rank, world=world, reduce=gather_losses, **kw)
+
+
+class ColumnComm:
+    """The `mih_comm` of one rank of a column-sharded fit: ctypes callbacks over torch.distributed.
+
+    Device buffers handed over by the library are wrapped in place (`__cuda_array_interface__`) and
+    reduced by RCCL; with the gloo backend they are staged through host memory.
+    """
+
+    def __init__(self, col_offset, p_global, device=0, group=None):
+        import torch.distributed as dist
+
+        from .api import _ALLGATHER, _ALLREDUCE, _Comm
+
+        self.group = group
+        self.device = device
+        self.error = None
+        on = dist.is_initialized()
+        self.rank = dist.get_rank(group) if on else 0
+        self.world = dist.get_world_size(group) if on else 1
+        self.backend = dist.get_backend(group) if on else None
+        self._ar = _ALLREDUCE(self._allreduce)
+        self._ag = _ALLGATHER(self._allgather)
+        self._c = _Comm(self.rank, self.world, int(col_offset), int(p_global),
+                        C.cast(self._ar, C.c_void_p), C.cast(self._ag, C.c_void_p), None)
+
+    def pointer(self):
+        return C.addressof(self._c)
+
+    # -- callbacks (must not raise through ctypes: report failure by return code) -----------------
+    def _allreduce(self, _user, buf, count, op, on_device):
+        try:
+            import torch
+            import torch.distributed as dist
+
+            if self.world == 1:
+                return 0
+            rop = dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX
+            if on_device:
+                t = torch.as_tensor(_DevArray(buf, count), device=f"cuda:{self.device}")
+                if self.backend == "nccl":
+                    dist.all_reduce(t, op=rop, group=self.group)
+                else:
+                    hcopy = t.cpu()
+                    dist.all_reduce(hcopy, op=rop, group=self.group)
+                    t.copy_(hcopy)
+                torch.cuda.synchronize(self.device)
+            else:
+                arr = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_double)), shape=(count,))
+                t = torch.from_numpy(arr)
+                if self.backend == "nccl":
+                    d = t.to(f"cuda:{self.device}")
+                    dist.all_reduce(d, op=rop, group=self.group)
+                    arr[:] = d.cpu().numpy()
+                else:
+                    dist.all_reduce(t, op=rop, group=self.group)
+            return 0
+        except Exception as e:      # noqa: BLE001
+            self.error = e
+            return 1
+
+    def _allgather(self, _user, send, count, recv):
+        try:
+            import torch
+            import torch.distributed as dist
+
+            src = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_double)), shape=(count,))
+            dst = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_double)), shape=(count * self.world,))
+            if self.world == 1:
+                dst[:] = src
+                return 0
+            dev = f"cuda:{self.device}" if self.backend == "nccl" else "cpu"
+            mine = torch.from_numpy(src.copy()).to(dev)
+            out = torch.empty(count * self.world, dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(out, mine, group=self.group)
+            dst[:] = out.cpu().numpy()
+            return 0
+        except Exception as e:      # noqa: BLE001
+            self.error = e
+            return 1
+
+
+class _DevArray:
+    """A device pointer as a CUDA-array-interface object (zero-copy view for torch.as_tensor)."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def column_block(p_global, rank, world):
+    """(offset, size) of the contiguous block of SNP columns a rank owns; blocks are multiples of 32
+    columns (one MFMA column group) except the last."""
+    groups = (p_global + 31) // 32
+    per = (groups + world - 1) // world
+    lo = min(rank * per * 32, p_global)
+    hi = min((rank + 1) * per * 32, p_global)
+    return lo, hi - lo
+
+
+def fit_iht_sharded(y, x_shard, z=None, *, col_offset, p_global, weight=None, **kw):
+    """fit_iht on a design matrix whose SNP columns are sharded over the ranks of the process group.
+
+    x_shard holds columns [col_offset, col_offset + x_shard.p); y, z are replicated.  Returns the same
+    IHTResult on every rank with the full-length beta assembled from the shards.
+    """
+    import torch
+    import torch.distributed as dist
+
+    from .api import fit_iht
+
+    comm = ColumnComm(col_offset, p_global, device=x_shard.device)
+    if weight is not None:
+        weight = np.asarray(weight, dtype=np.float64)[col_offset:col_offset + x_shard.p]
+    try:
+        res = fit_iht(y, x_shard, z, weight=weight, comm=comm, **kw)
+    except Exception:
+        if comm.error is not None:
+            raise comm.error
+        raise
+    beta = np.zeros(p_global)
+    nz = np.flatnonzero(res.beta)
+    mine = (nz + col_offset, res.beta[nz])
+    if comm.world > 1:
+        parts = [None] * comm.world
+        dist.all_gather_object(parts, mine)
+    else:
+        parts = [mine]
+    for gi, gv in parts:
+        beta[gi] = gv
+    res.beta = beta
+    return res

@@ -1,0 +1,96 @@
+"""Worker of the column-sharded fit test: launched once per rank by torch.distributed.run
+(tests/test_gpu_sharded.py).  Every rank builds its block of SNP columns on the SAME GPU (the test box
+has one), the ranks talk over gloo; rank 0 also runs the unsharded fit and writes both to JSON."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import mendeliht_amd as m                                   # noqa: E402
+from mendeliht_amd import dist as D                         # noqa: E402
+from conftest import FIX, make_bed                          # noqa: E402
+
+
+def summary(res):
+    nz = np.flatnonzero(res.beta)
+    return dict(support=nz.tolist(), beta=res.beta[nz].tolist(), c=np.asarray(res.c).tolist(), logl=res.logl,
+                iter=int(res.iter), logl_trace=res.trace["logl"].tolist(), bt=res.trace["backtracks"].tolist(),
+                tol=res.trace["tol"].tolist(), choose_fired=bool(res.choose_fired), sigma_g=res.σg)
+
+
+def main():
+    out_path = sys.argv[1]
+    rank, world, _ = D.init_from_env(backend="gloo")
+    import torch.distributed as dist
+
+    cases = {}
+
+    def run(name, cols, n, y, z, **kw):
+        p = cols.shape[0]
+        lo, cnt = D.column_block(p, rank, world)
+        xs = m.SnpLinAlg(cols[lo:lo + cnt], n=n, center=True, scale=True, impute=True)
+        sh = D.fit_iht_sharded(y, xs, z, col_offset=lo, p_global=p, verbose=False, **kw)
+        entry = dict(sharded=summary(sh), block=[lo, cnt])
+        if rank == 0:
+            xf = m.SnpLinAlg(cols, n=n, center=True, scale=True, impute=True)
+            entry["single"] = summary(m.fit_iht(y, xf, z, verbose=False, **kw))
+        cases[name] = entry
+
+    # 1. the reference's shipped example (G1): Normal, k = 7, two covariates
+    n = 1000
+    cols = m.read_bed(os.path.join(FIX, "normal.bed"), n)
+    y = np.loadtxt(os.path.join(FIX, "normal_y_fam6.txt"))
+    z = np.loadtxt(os.path.join(FIX, "covariates.txt"), delimiter=",")
+    z[:, 1:] = (z[:, 1:] - z[:, 1:].mean(axis=0)) / z[:, 1:].std(axis=0, ddof=1)
+    run("normal_k7", cols, n, y, z, k=7)
+
+    # 2. logistic with missing genotypes, prior weights, a covariate that competes in the projection
+    rng = np.random.default_rng(42)
+    n, p = 1501, 2300                                        # ragged: not a multiple of 128 rows / 32 columns
+    cols = make_bed(rng, n, p, missing_rate=0.02)
+    xo = m.SnpLinAlg(cols, n=n, center=True, scale=True, impute=True)
+    supp = rng.choice(p, 8, replace=False)
+    eta = xo.xv_sparse(np.sort(supp), rng.standard_normal(8) * 0.7)
+    zz = np.column_stack([np.ones(n), rng.standard_normal(n), rng.standard_normal(n)])
+    eta = eta + 0.3 * zz[:, 1]
+    yb = (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float)
+    w = rng.uniform(0.5, 2.0, p)
+    run("logistic_weights_zkeep", cols, n, yb, zz, k=9, d=m.Bernoulli(), l=m.LogitLink(), weight=w,
+        zkeep=[True, True, False])
+
+    # 3. Poisson, intercept only, a train mask
+    lam = np.exp(0.4 * xo.xv_sparse(np.sort(supp[:4]), np.array([0.5, -0.4, 0.3, 0.6])) + 0.2)
+    yp = rng.poisson(lam).astype(float)
+    train = (np.arange(n) % 5 != 0).astype(np.uint8)
+    run("poisson_train", cols, n, yp, None, k=6, d=m.Poisson(), l=m.LogLink(), train=train)
+
+    # 4. NegBin with the nuisance parameter estimated (replicated n-vector work)
+    run("negbin_newton", cols, n, yp, None, k=5, d=m.NegativeBinomial(2.0), l=m.LogLink(), est_r="Newton")
+
+    # 5. exact ties: duplicated columns straddling the shard boundary make _choose! fire globally
+    lo1, cnt1 = D.column_block(p, 0, world)
+    dup = cols.copy()
+    if world > 1:
+        dup[lo1 + cnt1] = dup[lo1 + cnt1 - 1]                # first column of rank 1 = last column of rank 0
+        dup[3] = dup[lo1 + cnt1 - 1]
+        dup[7] = dup[lo1 + cnt1 - 1]                         # 4 tied columns, k = 2: nonzero = 4 > k + zkeepn = 3
+    run("ties_choose", dup, n, xo.xv_sparse(np.array([lo1 + cnt1 - 1]), np.array([1.0])) + 0.01 * rng.standard_normal(n),
+        None, k=2)
+
+    dist.barrier()
+    if rank == 0:
+        with open(out_path, "w") as f:
+            json.dump(dict(world=world, cases=cases), f)
+    else:
+        with open(out_path + f".r{rank}", "w") as f:
+            json.dump(dict(cases=cases), f)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

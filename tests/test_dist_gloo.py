@@ -45,3 +45,42 @@ def test_two_rank_gather_of_fold_losses(tmp_path):
     full = np.arange(1.0, q * npath + 1).reshape(q, npath)
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"r{r}.npy"), full)
+
+
+def _comm_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import ctypes as C
+
+    import torch.distributed as dist
+    from mendeliht_amd import dist as D
+
+    D.init_from_env(backend="gloo")
+    lo, cnt = D.column_block(1000, rank, world)
+    comm = D.ColumnComm(lo, 1000)
+    assert (comm.rank, comm.world) == (rank, world) and comm.pointer() != 0
+    # the callbacks exactly as the library invokes them (host buffers; no GPU in this test)
+    v = np.arange(6, dtype=np.float64) * (rank + 1)
+    assert comm._ar(None, v.ctypes.data_as(C.c_void_p), 6, 0, 0) == 0                     # sum
+    mx = np.array([float(rank), -float(rank)])
+    assert comm._ar(None, mx.ctypes.data_as(C.c_void_p), 2, 1, 0) == 0                    # max
+    send = np.array([10.0 * rank + 1, 10.0 * rank + 2])
+    recv = np.zeros(2 * world)
+    assert comm._ag(None, send.ctypes.data_as(C.c_void_p), 2, recv.ctypes.data_as(C.c_void_p)) == 0
+    np.save(os.path.join(out_dir, f"c{rank}.npy"), np.concatenate([v, mx, recv, [lo, cnt]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_column_comm_callbacks_two_ranks(tmp_path):
+    world = 2
+    mp.spawn(_comm_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        got = np.load(tmp_path / f"c{r}.npy")
+        assert np.array_equal(got[:6], np.arange(6.0) * 3)           # (1 + 2) x arange
+        assert np.array_equal(got[6:8], [1.0, 0.0])
+        assert np.array_equal(got[8:12], [1.0, 2.0, 11.0, 12.0])
+    blocks = [np.load(tmp_path / f"c{r}.npy")[12:] for r in range(world)]
+    assert blocks[0][0] == 0 and blocks[0][0] + blocks[0][1] == blocks[1][0] and blocks[1][0] + blocks[1][1] == 1000
+    assert blocks[0][1] % 32 == 0
