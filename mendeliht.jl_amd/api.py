@@ -753,6 +753,29 @@ def cv_iht(y, x, z=None, *, d=None, l=None, path=range(1, 21), q=5, est_r="None"
     return (mse, raw) if return_raw else mse
 
 
+def iht_run_many_models(y, x, z=None, *, d=None, l=None, path=range(1, 21), est_r="None", group=None, weight=None,
+                        use_maf=False, debias=False, verbose=True, parallel=False, max_iter=100, rank=0, world=1,
+                        reduce=None):
+    """iht_run_many_models(y, x, z; path, ...) -- src/cross_validation.jl:232-273: fit_iht on the FULL data
+    for every model size in `path` (no hold-out), returns the loglikelihoods.  `parallel` (pmap in the
+    reference) is accepted and ignored: the fits of one process run back to back on its GPU; `rank` /
+    `world` shard `path` over processes and `reduce` sums the loglikelihood vector across them."""
+    path = [int(k) for k in path]
+    logl = np.zeros(len(path))
+    for i, k in enumerate(path):
+        if i % world != rank:
+            continue
+        logl[i] = fit_iht(y, x, z, J=1, k=k, d=d, l=l, est_r=est_r, group=group, weight=weight, use_maf=use_maf,
+                          debias=debias, verbose=False, max_iter=max_iter).logl
+    if reduce is not None:
+        logl = reduce(logl)
+    if verbose and rank == 0:
+        print("\n\nResults of running many models:\n\tk\tloglikelihood")
+        for k, v in zip(path, logl):
+            print(f"\t{k}\t{v}")
+    return logl
+
+
 # ---- file-level wrappers (src/wrapper.jl) ----------------------------------------------------
 def _read_fam_phenotypes(prefix, col):
     vals = []

@@ -533,3 +533,17 @@ def test_full_size_baseline_config_p1M(mih, oracle):
     last = x.xv_sparse(idx[3:], val[3:])
     assert rel(xb - last, ox.xv_masked(mask, coef)) < 1e-10
     assert abs(last.mean()) < 1e-9 * (1 + np.abs(last).max())      # a standardized column has mean 0
+
+
+def test_iht_run_many_models(mih, oracle, normal_pair, normal_data, capsys):
+    """iht_run_many_models (cross_validation.jl:232-273): one full-data fit per model size, max_iter = 100."""
+    x, ox = normal_pair
+    y, z = normal_data["y"], normal_data["z"]
+    path = [1, 3, 7, 12]
+    ll = mih.iht_run_many_models(y, x, z, path=path, verbose=True)
+    assert "loglikelihood" in capsys.readouterr().out
+    want = [oracle.fit_iht(ox, y, z, k=k, max_iter=100)["logl"] for k in path]
+    np.testing.assert_allclose(ll, want, rtol=1e-10)
+    assert np.all(np.diff(ll) > 0)                                   # more predictors, no hold-out: logl grows
+    halves = [mih.iht_run_many_models(y, x, z, path=path, verbose=False, rank=r, world=2) for r in range(2)]
+    assert np.array_equal(halves[0] + halves[1], ll)                 # sharding over ranks
