@@ -595,7 +595,7 @@ def fit_iht(y, x, z=None, *, k=10, J=1, d=None, l=None, group=None, weight=None,
     l = _inst(l) if l is not None else IdentityLink()
     if debias:
         raise ArgumentError("Currently debiasing only works with memory_efficient=false (not available on the GPU path)")
-    if init_beta and not isinstance(d, Normal):
+    if init_beta and not isinstance(d, (Normal, MvNormal)):
         raise ArgumentError("Intializing beta values only work for Gaussian phenotypes! Sorry!")
     if not memory_efficient:
         raise ArgumentError("the GPU path is always memory_efficient=true")
@@ -609,7 +609,7 @@ def fit_iht(y, x, z=None, *, k=10, J=1, d=None, l=None, group=None, weight=None,
     if verbose:
         _print_signature(io)
     if mv:
-        return _fit_mv(y, x, z, k, d, l, zkeep, verbose, tol, max_iter, min_iter, max_step, io, train)
+        return _fit_mv(y, x, z, k, d, l, zkeep, verbose, tol, max_iter, min_iter, max_step, io, train, init_beta)
     y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).ravel())
     n = x.n
     z = np.ones((n, 1)) if z is None else np.asarray(z, dtype=np.float64)
@@ -655,7 +655,7 @@ def _checky(y, d):
         raise ArgumentError("Poisson/NegativeBinomial data must be nonnegative integers")
 
 
-def _fit_mv(Y, x, Z, k, d, l, zkeep, verbose, tol, max_iter, min_iter, max_step, io, train):
+def _fit_mv(Y, x, Z, k, d, l, zkeep, verbose, tol, max_iter, min_iter, max_step, io, train, init_beta=False):
     Y = np.asfortranarray(np.asarray(Y, dtype=np.float64))
     r, n = Y.shape
     Z = np.ones((1, n)) if Z is None else np.asarray(Z, dtype=np.float64)
@@ -674,7 +674,8 @@ def _fit_mv(Y, x, Z, k, d, l, zkeep, verbose, tol, max_iter, min_iter, max_step,
             print(line, file=io)
 
     keep = []
-    prm = _params(k, 1, Normal(), l, tol, max_iter, min_iter, max_step, "None", zkeep, None, None, q, x.p, keep, progress)
+    prm = _params(k, 1, Normal(), l, tol, max_iter, min_iter, max_step, "None", zkeep, None, None, q, x.p, keep, progress,
+                  init_beta=init_beta)
     if verbose:
         _print_parameters(io, k, MvNormal(), l, False, None, False, tol, max_iter, min_iter)
     tr = None if train is None else np.ascontiguousarray(train, dtype=np.uint8)
@@ -707,8 +708,8 @@ def cv_iht(y, x, z=None, *, d=None, l=None, path=range(1, 21), q=5, est_r="None"
     l = _inst(l) if l is not None else IdentityLink()
     if debias or not memory_efficient:
         raise ArgumentError("debias / memory_efficient=false are not available on the GPU path")
-    if init_beta and (mv or not isinstance(d, Normal)):
-        raise ArgumentError("init_beta is available for univariate Gaussian phenotypes only on the GPU path")
+    if init_beta and not isinstance(d, (Normal, MvNormal)):
+        raise ArgumentError("Intializing beta values only work for Gaussian phenotypes! Sorry!")
     path = np.ascontiguousarray(list(path), dtype=np.int64)
     n = x.n
     if path.size == 0:
@@ -727,7 +728,8 @@ def cv_iht(y, x, z=None, *, d=None, l=None, path=range(1, 21), q=5, est_r="None"
         r = Y.shape[0]
         Z = np.ones((1, n)) if z is None else np.asarray(z, dtype=np.float64)
         Z = np.asfortranarray(Z.reshape(-1, Z.shape[-1]) if Z.ndim > 1 else Z.reshape(1, -1))
-        prm = _params(1, 1, Normal(), l, tol, max_iter, min_iter, max_step, "None", zkeep, None, None, Z.shape[0], x.p, keep)
+        prm = _params(1, 1, Normal(), l, tol, max_iter, min_iter, max_step, "None", zkeep, None, None, Z.shape[0], x.p, keep,
+                      init_beta=init_beta)
         _check(lib().mih_cv_mv(x._h, C.byref(prm), _p(Y), r, _p(Z), Z.shape[0], _p(folds), q, _p(path), path.size,
                                rank, world, _p(raw)))
     else:

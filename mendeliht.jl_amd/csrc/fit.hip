@@ -176,12 +176,13 @@ k_nb_sums(const double *__restrict__ y, const double *__restrict__ mu, int64_t n
 
 // ---- initialize_beta! (utilities.jl:776-812): the p univariate regressions y ~ 1 + x_j ------------
 // right-hand sides of the fused X'R pass: w (-> sum_train x_j) and w.*y (-> x_j'y over the training rows)
-__global__ void k_ib_rhs(const double *__restrict__ y, const double *__restrict__ w, int64_t n, double *__restrict__ R)
+__global__ void k_ib_rhs(const double *__restrict__ y /* m planes */, const double *__restrict__ w, int64_t n, int m,
+                         double *__restrict__ R /* 1 + m planes */)
 {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     R[i] = w[i];
-    R[n + i] = w[i] * y[i];
+    for (int t = 0; t < m; ++t) R[(int64_t)(1 + t) * n + i] = w[i] * y[(int64_t)t * n + i];
 }
 // bit 2s of word t is set iff row 16t+s is a training row
 __global__ void k_ib_mask(const double *__restrict__ w, int64_t n, int64_t nwords, uint32_t *__restrict__ M)
@@ -224,7 +225,7 @@ k_ib_counts(const uint4 *__restrict__ X, int64_t nbp, int64_t p, const uint32_t 
 // per column: linreg! (utilities.jl:823-842) on the standardized, imputed column restricted to the
 // training rows.  Sx, Sxy come from the X'R pass; Sxx from the integer counts.  A failed Cholesky
 // leaves the UNSOLVED right-hand side (sum y, x'y) exactly as the reference's `catch` does.
-__global__ void k_ib_solve(const double *__restrict__ S /* [2][p]: Sx, Sxy */, const int32_t *__restrict__ cnt,
+__global__ void k_ib_solve(const double *__restrict__ Sxv, const double *__restrict__ Sxyv, const int32_t *__restrict__ cnt,
                            const int64_t *__restrict__ miss_ptr, const int32_t *__restrict__ miss_row,
                            const double *__restrict__ w, const double *__restrict__ mu, const double *__restrict__ sinv,
                            int kind, int center, int scale, int impute, int64_t p, double N, double Sy,
@@ -232,7 +233,7 @@ __global__ void k_ib_solve(const double *__restrict__ S /* [2][p]: Sx, Sxy */, c
 {
     int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (j >= p) return;
-    double sx = S[j], sxy = S[p + j], sxx;
+    double sx = Sxv[j], sxy = Sxyv[j], sxx;
     if (kind == 0) {
         double m = mu[j], s = scale ? sinv[j] : 1.0, cm = center ? m : 0.0;
         double nm = 0.0;
@@ -350,6 +351,44 @@ static double h_mueta(int link, double eta)
 }
 
 // One IHTVariable (src/data_structures.jl:4-43), device-resident.
+// initialize_beta! regressions (utilities.jl:776-812, multivariate.jl:519-558) for m responses kept as
+// planes of n doubles: beta_dev[t][j] = slope of y_t ~ 1 + x_j over the training rows (clamped to +-2),
+// icpt_sum[t] = sum_j intercept.  Two extra passes over X: ONE fused (1+m)-RHS X'R (sum x and x'y_t per
+// SNP) and a popcount pass (sum x^2 from exact dosage counts).
+int init_beta_regress_device(const mih_mat *h, const double *w_dev, const double *Y_dev, int m, double N,
+                             const double *Sy_host, double *beta_dev, double *icpt_sum_host,
+                             DevBuf<double> &red, DevBuf<double> &scal, hipStream_t s)
+{
+    const int64_t n = h->n, p = h->p;
+    XtvWork xw; DevBuf<double> R, S, icpt, sxxd; DevBuf<uint32_t> M; DevBuf<int32_t> cnt;
+    MIH_TRY(xtv_work_init(h, xw, 1 + m));
+    MIH_TRY(R.alloc((size_t)(1 + m) * n)); MIH_TRY(S.alloc((size_t)(1 + m) * p)); MIH_TRY(icpt.alloc(p));
+    hipLaunchKernelGGL(k_ib_rhs, dim3(nblk(n)), dim3(256), 0, s, Y_dev, w_dev, n, m, R.p);
+    MIH_TRY(xtv_device(h, xw, R.p, 1 + m, S.p, s));
+    if (h->kind == 0) {
+        int64_t nwords = h->n_pad / 16;
+        MIH_TRY(M.alloc(nwords)); MIH_TRY(cnt.alloc((size_t)2 * p));
+        MIH_HIP(hipMemsetAsync(cnt.p, 0, sizeof(int32_t) * 2 * p, s));
+        hipLaunchKernelGGL(k_ib_mask, dim3(nblk(nwords)), dim3(256), 0, s, w_dev, n, nwords, M.p);
+        dim3 grid((unsigned)((h->nbp + kIbBpPerBlock - 1) / kIbBpPerBlock), (unsigned)h->ncg);
+        hipLaunchKernelGGL(k_ib_counts, grid, dim3(256), 0, s, reinterpret_cast<const uint4 *>(h->X), h->nbp, p, M.p, cnt.p);
+    } else {
+        MIH_TRY(sxxd.alloc(p));
+        hipLaunchKernelGGL(k_ib_dense_sxx, dim3((unsigned)p), dim3(256), 0, s, h->D, w_dev, n, p, sxxd.p);
+    }
+    const int nsb = 64;
+    for (int t = 0; t < m; ++t) {
+        hipLaunchKernelGGL(k_ib_solve, dim3(nblk(p)), dim3(256), 0, s, S.p, S.p + (size_t)(1 + t) * p, cnt.p, h->miss_ptr, h->miss_row,
+                           w_dev, h->mu, h->sinv, h->kind, h->center, h->scale, h->impute, p, N, Sy_host[t], sxxd.p,
+                           beta_dev + (size_t)t * p, icpt.p);
+        hipLaunchKernelGGL(k_ib_sum, dim3(nsb), dim3(256), 0, s, icpt.p, p, red.p);
+        hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, s, red.p, nsb, 1, scal.p);
+        MIH_HIP(hipMemcpyAsync(&icpt_sum_host[t], scal.p, sizeof(double), hipMemcpyDeviceToHost, s));
+        MIH_HIP(hipStreamSynchronize(s));
+    }
+    return MIH_OK;
+}
+
 struct IhtVar {
     const mih_mat *h = nullptr;
     int64_t n = 0, p = 0; int q = 0;
@@ -746,33 +785,13 @@ struct IhtVar {
     int init_beta_phase(const uint8_t *train)
     {
         if (dist != MIH_NORMAL) { set_error("Intializing beta values only work for Gaussian phenotypes! Sorry!"); return MIH_BAD_ARG; }
-        XtvWork xw2; DevBuf<double> R2, S2, betad, icpt, sxxd; DevBuf<uint32_t> M; DevBuf<int32_t> cnt;
-        MIH_TRY(xtv_work_init(h, xw2, 2));
-        MIH_TRY(R2.alloc((size_t)2 * n)); MIH_TRY(S2.alloc((size_t)2 * p)); MIH_TRY(betad.alloc(p)); MIH_TRY(icpt.alloc(p));
-        hipLaunchKernelGGL(k_ib_rhs, dim3(nblk(n)), dim3(256), 0, s, y.p, w.p, n, R2.p);
-        MIH_TRY(xtv_device(h, xw2, R2.p, 2, S2.p, s));
+        DevBuf<double> betad;
+        MIH_TRY(betad.alloc(p));
         double Sy = 0.0, N = 0.0;
         std::vector<double> ys;
         for (int64_t i = 0; i < n; ++i) if (!train || train[i]) { Sy += y_host[i]; N += 1.0; ys.push_back(y_host[i]); }
-        if (h->kind == 0) {
-            int64_t nwords = h->n_pad / 16;
-            MIH_TRY(M.alloc(nwords)); MIH_TRY(cnt.alloc((size_t)2 * p));
-            MIH_HIP(hipMemsetAsync(cnt.p, 0, sizeof(int32_t) * 2 * p, s));
-            hipLaunchKernelGGL(k_ib_mask, dim3(nblk(nwords)), dim3(256), 0, s, w.p, n, nwords, M.p);
-            dim3 grid((unsigned)((h->nbp + kIbBpPerBlock - 1) / kIbBpPerBlock), (unsigned)h->ncg);
-            hipLaunchKernelGGL(k_ib_counts, grid, dim3(256), 0, s, reinterpret_cast<const uint4 *>(h->X), h->nbp, p, M.p, cnt.p);
-        } else {
-            MIH_TRY(sxxd.alloc(p));
-            hipLaunchKernelGGL(k_ib_dense_sxx, dim3((unsigned)p), dim3(256), 0, s, h->D, w.p, n, p, sxxd.p);
-        }
-        hipLaunchKernelGGL(k_ib_solve, dim3(nblk(p)), dim3(256), 0, s, S2.p, cnt.p, h->miss_ptr, h->miss_row, w.p, h->mu, h->sinv,
-                           h->kind, h->center, h->scale, h->impute, p, N, Sy, sxxd.p, betad.p, icpt.p);
-        const int nsb = 64;
-        hipLaunchKernelGGL(k_ib_sum, dim3(nsb), dim3(256), 0, s, icpt.p, p, red.p);
-        hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, s, red.p, nsb, 1, scal.p);
         double c0sum = 0.0;
-        MIH_HIP(hipMemcpyAsync(&c0sum, scal.p, sizeof(double), hipMemcpyDeviceToHost, s));
-        MIH_HIP(hipStreamSynchronize(s));
+        MIH_TRY(init_beta_regress_device(h, w.p, y.p, 1, N, &Sy, betad.p, &c0sum, red, scal, s));
         // non-genetic covariates 2..q on the host (utilities.jl:799-806)
         for (int l = 1; l < q; ++l) {
             double sx = 0, sxx = 0, sxy = 0;

@@ -226,7 +226,8 @@ struct MvVar {
     const mih_mat *h = nullptr;
     int64_t n = 0, p = 0, k = 0; int q = 0, r = 0;
     std::vector<uint8_t> zkeep; int64_t zkeepn = 0;      // r * sum(zkeep)
-    const double *Y_host = nullptr;
+    const double *Y_host = nullptr, *Z_host = nullptr;
+    int init_beta = 0;
     hipStream_t s = nullptr;
     DevBuf<double> Y, Z, w, BX, MU, RES, T1, DF, full, red, scal, gval, tmpn;
     DevBuf<int64_t> sidx; DevBuf<double> sval; DevBuf<uint8_t> mask; DevBuf<int32_t> pairs;
@@ -245,7 +246,7 @@ struct MvVar {
 
     int create(const mih_mat *hh, const mih_fit_params *prm, const double *Yh, int64_t rr, const double *Zh, int64_t qq)
     {
-        h = hh; n = h->n; p = h->p; r = (int)rr; q = (int)qq; k = prm->k; Y_host = Yh;
+        h = hh; n = h->n; p = h->p; r = (int)rr; q = (int)qq; k = prm->k; Y_host = Yh; Z_host = Zh; init_beta = prm->init_beta;
         if (r < 1 || r > kMaxR) { set_error("number of traits r=%d must be in 1..%d", r, kMaxR); return MIH_BAD_DIM; }
         if (q < 1 || r * q > kMaxRQ) { set_error("r*q = %d exceeds %d", r * q, kMaxRQ); return MIH_BAD_DIM; }
         zkeep.resize(q); int64_t zs = 0;
@@ -472,7 +473,49 @@ struct MvVar {
         for (int l = 0; l < q; ++l) { idc[l] = 0; for (int i = 0; i < r; ++i) if (C[i + r * l] != 0.0) idc[l] = 1; }
         return MIH_OK;
     }
-    // init_iht_indices!(v::mIHTVariable) (multivariate.jl:376-452), init_beta = false
+    // initialize_beta!(v::mIHTVariable) + project_k!(v) + update_xb!(v) (multivariate.jl:426-430, 519-558)
+    int init_beta_phase(const uint8_t *train)
+    {
+        DevBuf<double> betad;
+        MIH_TRY(betad.alloc((size_t)r * p));
+        const double N = (double)nsamples;
+        std::vector<double> Sy(r, 0.0), c0sum(r, 0.0);
+        for (int64_t j = 0; j < n; ++j) if (!train || train[j]) for (int i = 0; i < r; ++i) Sy[i] += Y_host[i + (size_t)r * j];
+        MIH_TRY(init_beta_regress_device(h, w.p, Y.p, r, N, Sy.data(), betad.p, c0sum.data(), red, scal, s));
+        for (int l = 1; l < q; ++l) {             // non-genetic covariates 2..q on the host (:547-553)
+            double sx = 0.0, sxx = 0.0;
+            std::vector<double> sxy(r, 0.0);
+            for (int64_t j = 0; j < n; ++j) if (!train || train[j]) {
+                double xv = Z_host[l + (size_t)q * j];
+                sx += xv; sxx += xv * xv;
+                for (int i = 0; i < r; ++i) sxy[i] += xv * Y_host[i + (size_t)r * j];
+            }
+            double u11 = std::sqrt(N), u12 = sx / u11, d = sxx - u12 * u12;
+            for (int i = 0; i < r; ++i) {
+                double b0v, b1v;
+                if (!(N > 0.0) || !(d > 0.0)) { b0v = Sy[i]; b1v = sxy[i]; }
+                else { double u22 = std::sqrt(d), w1 = Sy[i] / u11, w2 = (sxy[i] - u12 * w1) / u22; b1v = w2 / u22; b0v = (w1 - u12 * b1v) / u11; }
+                c0sum[i] += b0v; C[i + r * l] = b1v;
+            }
+        }
+        for (int i = 0; i < r; ++i) C[i] = c0sum[i] / (double)(p + q - 1);
+        for (auto &x : C) x = x < -2.0 ? -2.0 : (x > 2.0 ? 2.0 : x);
+        C0 = C;
+        // project_k!(v): vec(B) with the covariate tail (Inf for kept covariates), top-(k + zkeepn)
+        hipLaunchKernelGGL(k_mv_full, dim3(nblk(p * r)), dim3(256), 0, s, betad.p, p, r, 1.0, full.p);
+        std::vector<double> tail((size_t)r * q);
+        for (int l = 0; l < q; ++l) for (int i = 0; i < r; ++i) tail[i + r * l] = zkeep[l] ? std::numeric_limits<double>::infinity() : C[i + r * l];
+        MIH_HIP(hipMemcpyAsync(full.p + (size_t)r * p, tail.data(), sizeof(double) * r * q, hipMemcpyHostToDevice, s));
+        Sparse snp; std::vector<double> ct; std::vector<uint8_t> cnz;
+        MIH_TRY(project_full(snp, ct, cnz));
+        B = snp;
+        for (int l = 0; l < q; ++l) if (!zkeep[l]) for (int i = 0; i < r; ++i) C[i + r * l] = cnz[i + r * l] ? ct[i + r * l] : 0.0;
+        choose();
+        update_cols();
+        for (int l = 0; l < q; ++l) { idc[l] = 0; for (int i = 0; i < r; ++i) if (C[i + r * l] != 0.0) idc[l] = 1; }
+        return update_xb();
+    }
+    // init_iht_indices!(v::mIHTVariable) (multivariate.jl:376-452)
     int init(const uint8_t *train)
     {
         if (k < 1) { set_error("Multivariate IHT requires k >= 1!"); return MIH_BAD_ARG; }
@@ -493,8 +536,10 @@ struct MvVar {
             C[i] = ybar / (double)nsamples;
         }
         MIH_HIP(hipMemsetAsync(BX.p, 0, sizeof(double) * (size_t)r * n, s));
+        if (init_beta) MIH_TRY(init_beta_phase(train));
         MIH_TRY(resid_and_gram());                                   // update_mu!, update_resid!
         MIH_TRY(score());
+        if (init_beta) return gather_df_cols();      // the support stays the one project_k!(v) chose; df stays dense
         // vectorize!(full_b, df, df2); project_k!; unvectorize! (:438-440): df replaced by its projection
         hipLaunchKernelGGL(k_mv_full, dim3(nblk(p * r)), dim3(256), 0, s, DF.p, p, r, 1.0, full.p);
         std::vector<double> tail((size_t)r * q);

@@ -263,10 +263,12 @@ def cv_iht(x, y, z=None, path=range(1, 21), q=5, folds=None, dist="normal", link
     return mse, raw.reshape(q, path.size)
 
 
-def fit_mv(x, Y, Z=None, k=10, tol=1e-4, max_iter=200, min_iter=5, max_step=3, zkeep=None, train=None):
+def fit_mv(x, Y, Z=None, k=10, tol=1e-4, max_iter=200, min_iter=5, max_step=3, zkeep=None, train=None,
+           init_beta=False):
     """Y is r x n (traits x samples), Z is q x n; returns B (r x p), C (r x q)."""
     keep = []
-    prm = _params(k, 1, "normal", "identity", 1.0, tol, max_iter, min_iter, max_step, None, zkeep, None, None, keep)
+    prm = _params(k, 1, "normal", "identity", 1.0, tol, max_iter, min_iter, max_step, None, zkeep, None, None, keep,
+                  init_beta)
     Y = np.asfortranarray(Y, dtype=np.float64)
     r, n = Y.shape
     if Z is None:
@@ -289,9 +291,10 @@ def fit_mv(x, Y, Z=None, k=10, tol=1e-4, max_iter=200, min_iter=5, max_step=3, z
 
 
 def cv_mv(x, Y, Z=None, path=range(1, 21), q=5, folds=None, tol=1e-4, max_iter=100, min_iter=5,
-          max_step=3, zkeep=None):
+          max_step=3, zkeep=None, init_beta=False):
     keep = []
-    prm = _params(1, 1, "normal", "identity", 1.0, tol, max_iter, min_iter, max_step, None, zkeep, None, None, keep)
+    prm = _params(1, 1, "normal", "identity", 1.0, tol, max_iter, min_iter, max_step, None, zkeep, None, None, keep,
+                  init_beta)
     Y = np.asfortranarray(Y, dtype=np.float64)
     r, n = Y.shape
     if Z is None:

@@ -448,6 +448,42 @@ def test_multivariate_shipped_data_and_cv(mih, oracle):
     assert np.all(mse > 0)
 
 
+def test_multivariate_init_beta(mih, oracle, normal_pair):
+    """init_beta=true for MvNormal traits (initialize_beta!(::mIHTVariable), multivariate.jl:519-558; used by
+    test/multivariate.ipynb and test/NFBC-chr21.ipynb): shipped data, a covariate problem with a train mask, CV."""
+    n = 1000
+    bed = mih.read_bed(os.path.join(FIX, "multivariate.bed"), n)
+    x = mih.SnpLinAlg(bed, n, center=True, scale=True, impute=True)
+    ox = oracle.Mat.from_bed_columns(bed, n)
+    Y = np.loadtxt(os.path.join(FIX, "multivariate.phen"), delimiter=",").T
+    res = mih.fit_iht(Y, x, None, k=10, init_beta=True, verbose=False)
+    o = oracle.fit_mv(ox, Y, None, k=10, init_beta=True)
+    plain = oracle.fit_mv(ox, Y, None, k=10)
+    assert res.iter == o["iter"] and list(res.trace["backtracks"]) == list(o["bt_trace"])
+    assert np.array_equal(res.beta != 0, o["B"] != 0)
+    np.testing.assert_allclose(res.beta, o["B"], rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(res.c, o["C"], rtol=1e-5)
+    np.testing.assert_allclose(res.trace["logl"], o["logl_trace"], rtol=1e-9)
+    assert o["logl"] != plain["logl"]                                          # the start really differs
+    # covariates (one of them not kept), missing genotypes in X, a train mask
+    x2, ox2 = normal_pair
+    rng = np.random.default_rng(77)
+    Y2, Z2 = _mv_problem(oracle, ox2, rng, 3, 9, 3)
+    train = (np.arange(x2.n) % 4 != 1).astype(np.uint8)
+    zk = [1, 1, 0]
+    r2 = mih.fit_iht(Y2, x2, Z2, k=9, zkeep=zk, init_beta=True, train=train, verbose=False)
+    o2 = oracle.fit_mv(ox2, Y2, Z2, k=9, zkeep=zk, init_beta=True, train=train)
+    assert r2.iter == o2["iter"]
+    assert np.array_equal(r2.beta != 0, o2["B"] != 0)
+    np.testing.assert_allclose(r2.beta, o2["B"], rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(r2.c, o2["C"], rtol=1e-5, atol=1e-12)
+    assert r2.logl == pytest.approx(o2["logl"], rel=1e-9)
+    folds = hash_folds(n, 3)
+    mse = mih.cv_iht(Y, x, None, path=[3, 8], q=3, folds=folds, init_beta=True, verbose=False)
+    omse, _ = oracle.cv_mv(ox, Y, None, path=[3, 8], q=3, folds=folds, init_beta=True)
+    np.testing.assert_allclose(mse, omse, rtol=1e-4)
+
+
 @pytest.mark.parametrize("method", ["MM", "Newton"])
 def test_negbin_nuisance_estimation(mih, oracle, normal_pair, method):
     """est_r=:MM / :Newton (utilities.jl:141-247; test/L0_reg_test.jl:245-296)."""
