@@ -583,3 +583,29 @@ def test_iht_run_many_models(mih, oracle, normal_pair, normal_data, capsys):
     assert np.all(np.diff(ll) > 0)                                   # more predictors, no hold-out: logl grows
     halves = [mih.iht_run_many_models(y, x, z, path=path, verbose=False, rank=r, world=2) for r in range(2)]
     assert np.array_equal(halves[0] + halves[1], ll)                 # sharding over ranks
+
+
+def test_concurrent_fits_share_one_matrix(mih, normal_pair, normal_data):
+    """SURVEY 8b threading row: cv_iht calls the path from several host threads on a SHARED x
+    (cross_validation.jl:100-112); the handle is immutable, every fit has its own workspace and stream."""
+    import threading
+
+    x, _ = normal_pair
+    y, z = normal_data["y"], normal_data["z"]
+    ks = [3, 5, 7, 9, 11, 13]
+    want = [mih.fit_iht(y, x, z, k=k, verbose=False) for k in ks]
+    got = [None] * len(ks)
+    errs = []
+
+    def work(i):
+        try:
+            got[i] = mih.fit_iht(y, x, z, k=ks[i], verbose=False)
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(ks))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs
+    for a, b in zip(want, got):
+        assert np.array_equal(a.beta, b.beta) and np.array_equal(a.c, b.c) and a.logl == b.logl and a.iter == b.iter
