@@ -230,6 +230,12 @@ int mih_bench_xtv_batched(const mih_mat *h, int variant, int m, int max_fused, i
 int mih_xtv_algorithmic_bytes(const mih_mat *h, int m, double *bytes);
 /* Select the X'r kernel variant used by every subsequent call (tuning knob). */
 int mih_set_xtv_variant(int variant);
+/* Fixed-point width of the residual in the X'r passes of workspaces created AFTER the call.  28 (default):
+ * 28 base-4 digits = 56 bits, the dot products are exact and the only rounding (2^-55 max|r|) is below
+ * that of an n-term f64 sum.  16: 32-bit residuals, two of them share one MFMA B operand, so fused
+ * multi-RHS passes (cv_iht, multivariate, init_beta) need half the matrix-pipe work, which is what
+ * bounds them (they are power-limited); relative error of X'r about 2^-31 max|r| / |r|_rms ~ 1e-9. */
+int mih_set_xtv_digits(int digits);
 /* Select the shape of the fused 4-right-hand-side kernel (0 = built-in default; tuning knob). */
 int mih_set_xtv_multi_variant(int variant);
 

@@ -13,7 +13,7 @@ from .api import (  # noqa: F401
     Bernoulli, IdentityLink, IHTResult, LogitLink, LogLink, MendelIHTError, MvNormal, NegativeBinomial,
     Normal, Poisson, SnpLinAlg, DenseMatrix, cross_validate, cv_iht, device_count, fit_iht, iht,
     library_path, mIHTResult, project_group_sparse, project_k, read_bed, standardize, lib, IHTSession,
-    profile_enable, profile_read, iht_run_many_models,
+    profile_enable, profile_read, iht_run_many_models, set_xtv_digits,
 )
 from . import dist  # noqa: F401
 

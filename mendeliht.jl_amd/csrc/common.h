@@ -92,13 +92,16 @@ __host__ __device__ inline int64_t xword(int64_t nbp, int64_t j, int64_t t)
     return (((cg * nbp + bp) * 64 + (h * 32 + m)) << 2) + (e << 1) + u;
 }
 
-constexpr int kDigits = 28;          // balanced base-4 digits of the fixed-point residual (56 bits)
+constexpr int kDigits = 28;          // balanced base-4 digits of the fixed-point residual (56 bits): the exact mode
+constexpr int kDigitsFast = 16;      // opt-in fast mode: 32-bit fixed point, TWO residuals per MFMA B operand
 
 struct XtvWork {            // scratch for one in-flight X'r
-    DevBuf<uint32_t> digits;   // m * nblk * 64 lanes * 4 dwords : FP4 digit planes of r (B operand)
-    DevBuf<double>   partial;  // splits * m * ncg*32 raw dots
-    DevBuf<double>   scal;     // m * 4 : {max|r| bits, 2^-e, sum r, spare}
+    DevBuf<uint32_t> digits;   // ops * nblk * 64 lanes * 4 dwords : FP4 digit planes of r (B operands)
+    DevBuf<double>   partial;  // splits * rhs * ncg*32 raw dots
+    DevBuf<double>   scal;     // rhs * 4 : {max|r|, 2^-e, sum r, 2^e}
     int m_cap = 0, splits_cap = 0;
+    int per_op = 1;            // residual vectors per B operand (1: 28 digits each, 2: 16 digits each); fixed at init
+    int ops_cap = 0;           // B operands the buffers hold (multiple of 4)
 };
 int  xtv_work_init(const mih_mat *h, XtvWork &w, int m);
 // r_dev: m vectors of length n (column-major n x m) on device; out_dev p x m.

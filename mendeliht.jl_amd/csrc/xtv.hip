@@ -84,37 +84,42 @@ k_r_stats(const double *__restrict__ r, int64_t n, int m, double *__restrict__ p
     }
 }
 
-__global__ void k_r_stats_final(const double *__restrict__ part, int nblocks, int m, double *__restrict__ scal)
+__global__ void k_r_stats_final(const double *__restrict__ part, int nblocks, int m, int ebits, double *__restrict__ scal)
 {
     int v = blockIdx.x;
     if (threadIdx.x != 0 || v >= m) return;
     double mx = 0.0, sm = 0.0;
     for (int b = 0; b < nblocks; ++b) { mx = fmax(mx, part[((int64_t)v * nblocks + b) * 2]); sm += part[((int64_t)v * nblocks + b) * 2 + 1]; }
-    // exponent e with max|r| * 2^e < 2^54 ; an all-zero (or non-finite) residual keeps e = 0
+    // exponent e with max|r| * 2^e < 2^(ebits+1) (2^54 for 28 digits, 2^30 for 16); an all-zero (or
+    // non-finite) residual keeps e = 0
     int e = 0;
-    if (mx > 0.0 && mx < 1.0e300) e = 53 - ilogb(mx);
+    if (mx > 0.0 && mx < 1.0e300) e = ebits - ilogb(mx);
     scal[4 * v + 0] = mx;
     scal[4 * v + 1] = ldexp(1.0, -e);
     scal[4 * v + 2] = sm;
     scal[4 * v + 3] = ldexp(1.0, e);
 }
 
-// One thread per (64-row block, lane = 32*h + t): digit t of the 32 rows of half h, packed as the
-// FP4 B-operand fragment (element order identical to the A fragment built in k_xtv_mfma).
+// One thread per (B operand, 64-row block, lane = 32*h + t): column t of the operand is digit (t % slots) of
+// residual per_op*op + t / slots (slots = 32 / per_op), for the 32 rows of half h, packed as the FP4
+// B-operand fragment (element order identical to the A fragment built in k_xtv_mfma).
 __global__ void __launch_bounds__(256)
-k_digits(const double *__restrict__ r, int64_t n, int64_t nblk, int m, const double *__restrict__ scal,
-         uint4 *__restrict__ dig /* [m][nblk][64] */)
+k_digits(const double *__restrict__ r, int64_t n, int64_t nblk, int m, int nops, int per_op, int ndig,
+         const double *__restrict__ scal, uint4 *__restrict__ dig /* [nops][nblk][64] */)
 {
     int64_t gid = blockIdx.x * 256ll + threadIdx.x;
-    int64_t total = (int64_t)m * nblk * 64;
+    int64_t total = (int64_t)nops * nblk * 64;
     if (gid >= total) return;
     int lane = (int)(gid & 63), t = lane & 31, h = lane >> 5;
-    int64_t vb = gid >> 6, v = vb / nblk, blk = vb - v * nblk;
+    int64_t ob = gid >> 6, op = ob / nblk, blk = ob - op * nblk;
+    const int slots = 32 / per_op, dg = t % slots;
+    const int64_t v = op * per_op + t / slots;
     uint32_t out[4] = {0u, 0u, 0u, 0u};
-    if (t < kDigits) {
+    if (dg < ndig && v < m) {
         const double sc = scal[4 * v + 3];
         const double *rv = r + v * n;
         int64_t row0 = blk * 64 + h * 32;
+        const unsigned long long bias = 0xAAAAAAAAAAAAAAAAull >> (64 - 2 * ndig);   // every digit + 2
         #pragma unroll
         for (int u = 0; u < 2; ++u) {
             #pragma unroll
@@ -122,8 +127,8 @@ k_digits(const double *__restrict__ r, int64_t n, int64_t nblk, int m, const dou
                 int64_t i = row0 + u * 16 + s;
                 double x = (i < n) ? rv[i] : 0.0;
                 long long R = __double2ll_rn(x * sc);
-                unsigned long long U = (unsigned long long)(R + 0xAAAAAAAAAAAAAALL);   // all 28 digits + 2
-                uint32_t d = (uint32_t)(U >> (2 * t)) & 3u;                              // digit + 2 in 0..3
+                unsigned long long U = (unsigned long long)R + bias;
+                uint32_t d = (uint32_t)(U >> (2 * dg)) & 3u;                             // digit + 2 in 0..3
                 uint32_t code = (0x109Au >> (4 * d)) & 0xFu;                             // -1, -0.5, 0, +0.5 in FP4
                 out[2 * u + (s & 1)] |= code << (4 * (s >> 1));
             }
@@ -151,12 +156,44 @@ __device__ __forceinline__ f32x16 mfma_fp4(uint32_t u0, uint32_t u1, const uint4
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bb, acc, 4, 4, 0, 127, 0, 127);
 }
 
+// D layout: column n = lane & 31, row (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5) (SNP).  Column n holds digit
+// (n % slots) of residual per_op*v + n / slots of B operand v (slots = 32 / per_op).
+// acc = (1/4) sum_i g_i d_i exactly; recombine digits: sum_t 4^t * (4 acc_t), then * 2^-e.
+template <int CT, int NR>
+__device__ __forceinline__ void xtv_epilogue(const f32x16 (&acc)[CT][NR], int lane, int64_t cg0, int64_t ncg, int split,
+                                             int splits, int per_op, const double *__restrict__ scal,
+                                             double *__restrict__ partial)
+{
+    const int slots = 32 / per_op;
+    const int dgt = lane & (slots - 1), sub = (lane & 31) / slots;
+    const int ndig = (per_op == 1) ? kDigits : kDigitsFast;
+    const double wgt = (dgt < ndig) ? ldexp(1.0, 2 + 2 * dgt) : 0.0;
+    #pragma unroll
+    for (int v = 0; v < NR; ++v) {
+        const int rhs = v * per_op + sub;
+        const double inv = scal[4 * rhs + 1];
+        #pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            #pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                double x = (double)acc[c][v][g] * wgt;
+                if (per_op == 1) x += __shfl_xor(x, 16, 64);
+                #pragma unroll
+                for (int off = 8; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);   // within each group of `slots` lanes
+                int row = (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
+                if (dgt == 0 && cg0 + c < ncg)
+                    partial[((int64_t)rhs * splits + split) * (ncg * 32) + (cg0 + c) * 32 + row] = x * inv;
+            }
+        }
+    }
+}
+
 // NR right-hand sides ride the same pass: the dosage tile is loaded and expanded once and fed to NR
 // MFMAs (one per residual vector's digit planes).
 template <int WAVES, int CT, int NR>
 __global__ void __launch_bounds__(WAVES * 64)
 k_xtv_mfma(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *__restrict__ dig, int64_t dig_stride,
-           int splits, const double *__restrict__ scal, double *__restrict__ partial /* [NR][splits][ncg*32] */)
+           int splits, int per_op, const double *__restrict__ scal, double *__restrict__ partial /* [NR*per_op][splits][ncg*32] */)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -210,32 +247,13 @@ k_xtv_mfma(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *_
         }
     }
 
-    // D layout: column n = lane & 31 (digit), row (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5) (SNP).
-    // acc = (1/4) sum_i g_i d_i exactly; recombine digits: sum_t 4^t * (4 acc_t), then * 2^-e.
-    const int dgt = lane & 31;
-    const double wgt = (dgt < kDigits) ? ldexp(1.0, 2 + 2 * dgt) : 0.0;
-    #pragma unroll
-    for (int v = 0; v < NR; ++v) {
-        const double inv = scal[4 * v + 1];
-        #pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                double x = (double)acc[c][v][g] * wgt;
-                #pragma unroll
-                for (int off = 16; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);   // within each 32-lane half
-                int row = (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
-                if (dgt == 0 && cg0 + c < ncg)
-                    partial[((int64_t)v * splits + split) * (ncg * 32) + (cg0 + c) * 32 + row] = x * inv;
-            }
-        }
-    }
+    xtv_epilogue<CT, NR>(acc, lane, cg0, ncg, split, splits, per_op, scal, partial);
 }
 
-// Four right-hand sides per pass with the digit planes shared through LDS.  A workgroup of WAVES
+// NR (2 or 4) B operands per pass with the digit planes shared through LDS.  A workgroup of WAVES
 // waves x CT column groups stages the 8 KB of digit planes of each 128-row block once (instead of once
 // per wave: L2 traffic for the digits drops WAVES-fold, which is what keeps the pass off the L2
-// roofline) and every wave feeds its dosage tiles to 4 x 2 MFMAs per tile.  A barrier step covers RB
+// roofline) and every wave feeds its dosage tiles to NR x 2 MFMAs per tile.  A barrier step covers RB
 // blocks; the digits of step t+1 are loaded during step t-1 and stored to the idle LDS buffer at the
 // top of step t, the dosage tiles of step t+1 are loaded at the top of step t, so no load is waited
 // for in the step that issued it.  Measured (tools/sweep_multi.py, tools/probe_power.py,
@@ -243,13 +261,16 @@ k_xtv_mfma(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *_
 // POWER-bound, not issue- or latency-bound -- the package sits at its ~1340 W cap and the shader
 // clock drops from 2360 MHz (1 RHS) to ~1935 MHz (4 RHS); all-zero digit planes run 17 % faster.
 // MODE 1 / 2 (no MFMAs / no dosage loads) exist only for those timing probes.
-template <int CT, int RB, int MODE = 0, int WAVES = 8>   // MODE 1: no MFMAs, 2: no dosage loads (timing probes only)
+template <int NR, int CT, int RB, int MODE = 0, int WAVES = 8>   // MODE 1: no MFMAs, 2: no dosage loads (timing probes only)
 __global__ void __launch_bounds__(WAVES * 64, 2)
-k_xtv_mfma_lds4rb(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *__restrict__ dig, int64_t dig_stride,
-                  int splits, const double *__restrict__ scal, double *__restrict__ partial /* [4][splits][ncg*32] */)
+k_xtv_mfma_lds(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *__restrict__ dig, int64_t dig_stride,
+               int splits, int per_op, const double *__restrict__ scal, double *__restrict__ partial /* [NR*per_op][splits][ncg*32] */)
 {
-    constexpr int NR = 4, NT = WAVES * 64, PER = 512 / NT;   // PER staged slots per thread and block
-    __shared__ uint4 btile[2][RB][NR * 2 * 64];
+    constexpr int NT = WAVES * 64;
+    constexpr int BLK = NR * 2 * 64;                 // uint4 slots of one 128-row block: (operand v, 64-row half e, lane)
+    constexpr int S = RB * BLK;                      // slots staged per barrier step
+    constexpr int PER = (S + NT - 1) / NT;           // slots per thread (the last one may be idle)
+    __shared__ uint4 btile[2][S];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int split = blockIdx.x % splits;
@@ -275,26 +296,30 @@ k_xtv_mfma_lds4rb(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const u
             int64_t cg = cg0 + c < ncg ? cg0 + c : ncg - 1;      // idle waves redo the last group
             ap[c] = X + (cg * nbp) * 64 + lane;
         }
-        // staged slot s = threadIdx.x + u*NT of a 128-row block: rhs s >> 7, 64-row half (s >> 6) & 1
-        const uint4 *bsrc[PER];
+        // staged slot f = threadIdx.x + u*NT: block f / BLK of the step, operand (f % BLK) >> 7, half ((f % BLK) >> 6) & 1
+        const uint4 *bsrc[PER]; int bq_[PER]; bool bon[PER];
         #pragma unroll
         for (int u = 0; u < PER; ++u) {
-            const int sl = threadIdx.x + u * NT;
-            bsrc[u] = dig + (int64_t)(sl >> 7) * dig_stride + ((sl >> 6) & 1) * 64 + lane;
+            const int fs = threadIdx.x + u * NT;
+            bon[u] = fs < S;
+            const int fq = bon[u] ? fs : 0, wi = fq % BLK;
+            bq_[u] = fq / BLK;
+            bsrc[u] = dig + (int64_t)(wi >> 7) * dig_stride + ((wi >> 6) & 1) * 64 + (wi & 63);
         }
         uint4 acur[RB][CT], anext[RB][CT];
-        u32x4 bstage[RB][PER];      // native vector type: stays in registers across the loop edge
+        u32x4 bstage[PER];          // native vector type: stays in registers across the loop edge
         #pragma unroll
         for (int q = 0; q < RB; ++q) {
             const int64_t bq = (b0 + q < last) ? b0 + q : last;
             #pragma unroll
             for (int c = 0; c < CT; ++c) acur[q][c] = ld_stream(ap[c] + bq * 64);
-            const int64_t b2 = (b0 + RB + q < last) ? b0 + RB + q : last;
-            #pragma unroll
-            for (int u = 0; u < PER; ++u) {
-                btile[0][q][threadIdx.x + u * NT] = bsrc[u][(2 * bq) * 64];
-                bstage[q][u] = *reinterpret_cast<const u32x4 *>(bsrc[u] + (2 * b2) * 64);
-            }
+        }
+        #pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int64_t bq = (b0 + bq_[u] < last) ? b0 + bq_[u] : last;
+            const int64_t b2 = (b0 + RB + bq_[u] < last) ? b0 + RB + bq_[u] : last;
+            if (bon[u]) btile[0][threadIdx.x + u * NT] = bsrc[u][(2 * bq) * 64];
+            bstage[u] = *reinterpret_cast<const u32x4 *>(bsrc[u] + (2 * b2) * 64);
         }
         __syncthreads();
         int buf = 0;
@@ -303,31 +328,32 @@ k_xtv_mfma_lds4rb(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const u
         // prefetch is waited for in the step that issued it.
         for (int64_t bp = b0; bp < b1; bp += RB) {
             #pragma unroll
-            for (int q = 0; q < RB; ++q)
-                #pragma unroll
-                for (int u = 0; u < PER; ++u) *reinterpret_cast<u32x4 *>(&btile[buf ^ 1][q][threadIdx.x + u * NT]) = bstage[q][u];
+            for (int u = 0; u < PER; ++u)
+                if (bon[u]) *reinterpret_cast<u32x4 *>(&btile[buf ^ 1][threadIdx.x + u * NT]) = bstage[u];
             #pragma unroll
             for (int q = 0; q < RB; ++q) {
                 const int64_t bn = (bp + RB + q < last) ? bp + RB + q : last;
                 #pragma unroll
                 for (int c = 0; c < CT; ++c) { if (MODE != 2) anext[q][c] = ld_stream(ap[c] + bn * 64); else anext[q][c] = acur[q][c]; }
-                const int64_t b2 = (bp + 2 * RB + q < last) ? bp + 2 * RB + q : last;
-                #pragma unroll
-                for (int u = 0; u < PER; ++u) bstage[q][u] = *reinterpret_cast<const u32x4 *>(bsrc[u] + (2 * b2) * 64);
+            }
+            #pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int64_t b2 = (bp + 2 * RB + bq_[u] < last) ? bp + 2 * RB + bq_[u] : last;
+                bstage[u] = *reinterpret_cast<const u32x4 *>(bsrc[u] + (2 * b2) * 64);
             }
             __builtin_amdgcn_sched_barrier(0);      // keep the prefetch loads ahead of the MFMA section
-            // (block q, rhs v) items in sequence; the digit fragments of item i+1 are read from LDS
+            // (block q, operand v) items in sequence; the digit fragments of item i+1 are read from LDS
             // before the MFMAs of item i are issued so the LDS latency hides behind the matrix pipe
             uint4 bfr[2][2];
-            bfr[0][0] = btile[buf][0][lane];
-            bfr[0][1] = btile[buf][0][64 + lane];
+            bfr[0][0] = btile[buf][lane];
+            bfr[0][1] = btile[buf][64 + lane];
             #pragma unroll
             for (int i = 0; i < RB * NR; ++i) {
                 const int q = i / NR, v = i % NR;
                 if (i + 1 < RB * NR) {
                     const int q1 = (i + 1) / NR, v1 = (i + 1) % NR;
-                    bfr[(i + 1) & 1][0] = btile[buf][q1][(v1 * 2 + 0) * 64 + lane];
-                    bfr[(i + 1) & 1][1] = btile[buf][q1][(v1 * 2 + 1) * 64 + lane];
+                    bfr[(i + 1) & 1][0] = btile[buf][q1 * BLK + (v1 * 2 + 0) * 64 + lane];
+                    bfr[(i + 1) & 1][1] = btile[buf][q1 * BLK + (v1 * 2 + 1) * 64 + lane];
                 }
                 const uint32_t keep = (bp + q < b1) ? 0xFFFFFFFFu : 0u;     // blocks past the slice end add zero
                 #pragma unroll
@@ -350,24 +376,7 @@ k_xtv_mfma_lds4rb(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const u
         }
     }
     if (cg0 >= ncg) return;
-    const int dgt = lane & 31;
-    const double wgt = (dgt < kDigits) ? ldexp(1.0, 2 + 2 * dgt) : 0.0;
-    #pragma unroll
-    for (int v = 0; v < NR; ++v) {
-        const double inv = scal[4 * v + 1];
-        #pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                double x = (double)acc[c][v][g] * wgt;
-                #pragma unroll
-                for (int off = 16; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
-                int row = (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
-                if (dgt == 0 && cg0 + c < ncg)
-                    partial[((int64_t)v * splits + split) * (ncg * 32) + (cg0 + c) * 32 + row] = x * inv;
-            }
-        }
-    }
+    xtv_epilogue<CT, NR>(acc, lane, cg0, ncg, split, splits, per_op, scal, partial);
 }
 
 // Combine slices, add the missing-entry correction, centre, scale.
@@ -462,34 +471,39 @@ static Variant current_variant()
 }
 
 template <int WAVES, int CT, int NR>
-static void launch_xtv(const mih_mat *h, const uint4 *dig, int64_t dig_stride, int splits, const double *scal,
+static void launch_xtv(const mih_mat *h, const uint4 *dig, int64_t dig_stride, int splits, int per_op, const double *scal,
                        double *partial, hipStream_t s)
 {
     int64_t groups = (h->ncg + WAVES * CT - 1) / (WAVES * CT);
     hipLaunchKernelGGL((k_xtv_mfma<WAVES, CT, NR>), dim3((unsigned)(groups * splits)), dim3(WAVES * 64), 0, s,
-                       reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig_stride, splits, scal, partial);
+                       reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig_stride, splits, per_op, scal, partial);
 }
 
-// nr = 1: the tuned single-RHS variants; nr = 2 / 4: fused multi-RHS passes (64 / 128 accumulator registers)
+// nr B operands per pass: 1 = the tuned single-operand variants; 2 / 4 = fused passes (64 / 128 accumulator
+// registers).  Each operand carries per_op residual vectors.
 static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 *dig, int64_t dig_stride, int splits,
-                        const double *scal, double *partial, hipStream_t s)
+                        int per_op, const double *scal, double *partial, hipStream_t s)
 {
-    if (nr == 4) {
-#define MIH_LDS4(ID, C, RB, MODE, W) if (g_xtv_multi_variant == ID) { \
+#define MIH_LDS(NRV, ID, C, RB, MODE, W) if (nr == NRV && mv == ID) { \
         int64_t groups = (h->ncg + W * C - 1) / (W * C); \
-        hipLaunchKernelGGL((k_xtv_mfma_lds4rb<C, RB, MODE, W>), dim3((unsigned)(groups * splits)), dim3(W * 64), 0, s, \
-                           reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig_stride, splits, scal, partial); \
+        hipLaunchKernelGGL((k_xtv_mfma_lds<NRV, C, RB, MODE, W>), dim3((unsigned)(groups * splits)), dim3(W * 64), 0, s, \
+                           reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig_stride, splits, per_op, scal, partial); \
         return MIH_OK; }
-        MIH_LDS4(0, 2, 2, 0, 8)      // default
-        MIH_LDS4(1, 2, 1, 0, 8) MIH_LDS4(2, 2, 3, 0, 8) MIH_LDS4(3, 2, 4, 0, 8) MIH_LDS4(4, 1, 4, 0, 8)
-        MIH_LDS4(5, 2, 1, 0, 4) MIH_LDS4(6, 2, 2, 0, 4)
-        MIH_LDS4(7, 2, 2, 1, 8) MIH_LDS4(8, 2, 2, 2, 8)      // timing probes (results are NOT X'r)
-#undef MIH_LDS4
-        set_error("unknown 4-RHS kernel variant");
+    if (nr == 4 || nr == 2) {
+        const int mv = g_xtv_multi_variant;
+        MIH_LDS(4, 0, 2, 2, 0, 8)      // defaults
+        MIH_LDS(2, 0, 4, 1, 0, 4)
+        MIH_LDS(4, 1, 2, 1, 0, 8) MIH_LDS(4, 2, 2, 3, 0, 8) MIH_LDS(4, 3, 2, 4, 0, 8) MIH_LDS(4, 4, 1, 4, 0, 8)
+        MIH_LDS(4, 5, 2, 1, 0, 4) MIH_LDS(4, 6, 2, 2, 0, 4)
+        MIH_LDS(4, 7, 2, 2, 1, 8) MIH_LDS(4, 8, 2, 2, 2, 8)      // timing probes (results are NOT X'r)
+        MIH_LDS(2, 1, 2, 2, 0, 8) MIH_LDS(2, 2, 4, 2, 0, 8) MIH_LDS(2, 3, 2, 4, 0, 8) MIH_LDS(2, 4, 4, 1, 0, 8)
+        if (nr == 2 && mv == 5) { launch_xtv<4, 2, 2>(h, dig, dig_stride, splits, per_op, scal, partial, s); return MIH_OK; }   // per-wave digit loads
+        if (nr == 2) { MIH_LDS(2, mv, 4, 1, 0, 4) }            // variants that only exist for 4 operands
+        set_error("unknown multi-RHS kernel variant");
         return MIH_BAD_ARG;
     }
-    if (nr == 2) { launch_xtv<4, 2, 2>(h, dig, dig_stride, splits, scal, partial, s); return MIH_OK; }
-#define MIH_CASE(W, C) if (v.waves == W && v.ct == C) { launch_xtv<W, C, 1>(h, dig, dig_stride, splits, scal, partial, s); return MIH_OK; }
+#undef MIH_LDS
+#define MIH_CASE(W, C) if (v.waves == W && v.ct == C) { launch_xtv<W, C, 1>(h, dig, dig_stride, splits, per_op, scal, partial, s); return MIH_OK; }
     MIH_CASE(4, 1) MIH_CASE(4, 2) MIH_CASE(4, 4) MIH_CASE(8, 1) MIH_CASE(8, 2) MIH_CASE(2, 2) MIH_CASE(8, 4) MIH_CASE(4, 8) MIH_CASE(2, 4)
 #undef MIH_CASE
     set_error("unknown X'r kernel variant");
@@ -498,18 +512,23 @@ static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 
 
 constexpr int kStatBlocks = 64;
 
+int g_xtv_digits = kDigits;      // kDigits (exact) or kDigitsFast (two residuals per B operand); mih_set_xtv_digits
+
 int xtv_work_init(const mih_mat *h, XtvWork &w, int m)
 {
     if (h->kind != 0) return MIH_OK;
     int64_t nblk = h->nbp * 2;
-    // capacity rounded up to a multiple of 4: three leftover right-hand sides ride a 4-RHS pass with an
-    // all-zero digit plane (29 ms) instead of a 2-RHS + a 1-RHS pass (45 ms); the padding stays zero
-    const int m4 = (m + 3) & ~3;
-    MIH_TRY(w.digits.alloc((size_t)m4 * (size_t)nblk * 64 * 4));
-    MIH_TRY(w.partial.alloc((size_t)kMaxSplits * (size_t)m4 * (size_t)h->ncg * 32));
-    MIH_TRY(w.scal.alloc((size_t)m4 * 4 + (size_t)m * kStatBlocks * 2));
-    MIH_HIP(hipMemsetAsync(w.digits.p, 0, sizeof(*w.digits.p) * (size_t)m4 * (size_t)nblk * 64 * 4, h->stream));
-    MIH_HIP(hipMemsetAsync(w.scal.p, 0, sizeof(double) * (size_t)m4 * 4, h->stream));
+    w.per_op = (g_xtv_digits == kDigitsFast) ? 2 : 1;
+    // operand capacity rounded up to a multiple of 4: three leftover operands ride a 4-operand pass with an
+    // all-zero digit plane (29 ms) instead of a 2- + a 1-operand pass (45 ms)
+    const int ops = (m + w.per_op - 1) / w.per_op;
+    w.ops_cap = (ops + 3) & ~3;
+    const size_t rhs_cap = (size_t)w.ops_cap * w.per_op;
+    MIH_TRY(w.digits.alloc((size_t)w.ops_cap * (size_t)nblk * 64 * 4));
+    MIH_TRY(w.partial.alloc((size_t)kMaxSplits * rhs_cap * (size_t)h->ncg * 32));
+    MIH_TRY(w.scal.alloc(rhs_cap * 4 + (size_t)m * kStatBlocks * 2));
+    MIH_HIP(hipMemsetAsync(w.digits.p, 0, sizeof(*w.digits.p) * (size_t)w.ops_cap * (size_t)nblk * 64 * 4, h->stream));
+    MIH_HIP(hipMemsetAsync(w.scal.p, 0, sizeof(double) * rhs_cap * 4, h->stream));
     MIH_HIP(hipStreamSynchronize(h->stream));
     w.m_cap = m; w.splits_cap = kMaxSplits;
     return MIH_OK;
@@ -530,23 +549,26 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
     if (splits > h->nbp) splits = (int)h->nbp;
     if (splits > w.splits_cap) splits = w.splits_cap;
     const int64_t nblk = h->nbp * 2, pstride = h->ncg * 32;
-    double *part = w.scal.p + (size_t)((w.m_cap + 3) & ~3) * 4;
+    const int per_op = w.per_op, ndig = (per_op == 1) ? kDigits : kDigitsFast;
+    const int nops = (m + per_op - 1) / per_op;
+    double *part = w.scal.p + (size_t)w.ops_cap * per_op * 4;
     hipLaunchKernelGGL(k_r_stats, dim3(kStatBlocks), dim3(256), 0, s, r_dev, h->n, m, part);
-    hipLaunchKernelGGL(k_r_stats_final, dim3(m), dim3(64), 0, s, part, kStatBlocks, m, w.scal.p);
-    int64_t total = (int64_t)m * nblk * 64;
-    hipLaunchKernelGGL(k_digits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, r_dev, h->n, nblk, m, w.scal.p,
-                       reinterpret_cast<uint4 *>(w.digits.p));
-    for (int t = 0; t < m;) {
-        int nr = (m - t >= 3 && g_xtv_max_nr >= 4 && t + 4 <= ((w.m_cap + 3) & ~3)) ? 4
-                 : (m - t >= 2 && g_xtv_max_nr >= 2) ? 2 : 1;
-        double *partial = w.partial.p + (int64_t)t * splits * pstride;
+    hipLaunchKernelGGL(k_r_stats_final, dim3(m), dim3(64), 0, s, part, kStatBlocks, m, 2 * ndig - 3, w.scal.p);
+    int64_t total = (int64_t)nops * nblk * 64;
+    hipLaunchKernelGGL(k_digits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, r_dev, h->n, nblk, m, nops, per_op, ndig,
+                       w.scal.p, reinterpret_cast<uint4 *>(w.digits.p));
+    for (int t = 0; t < nops;) {          // t counts B operands
+        int nr = (nops - t >= 3 && g_xtv_max_nr >= 4 && t + 4 <= w.ops_cap) ? 4
+                 : (nops - t >= 2 && g_xtv_max_nr >= 2) ? 2 : 1;
+        const int u0 = t * per_op;        // first residual of this pass
+        double *partial = w.partial.p + (int64_t)u0 * splits * pstride;
         const uint4 *dig = reinterpret_cast<const uint4 *>(w.digits.p) + (int64_t)t * nblk * 64;
         hipEvent_t e0, e1;
         prof_begin(s, e0, e1);
-        int rc = dispatch_xtv(v, nr, h, dig, nblk * 64, splits, w.scal.p + 4 * t, partial, s);
+        int rc = dispatch_xtv(v, nr, h, dig, nblk * 64, splits, per_op, w.scal.p + 4 * u0, partial, s);
         prof_end(s, e0, e1);
         if (rc) return rc;
-        for (int u = t; u < t + nr && u < m; ++u)
+        for (int u = u0; u < (t + nr) * per_op && u < m; ++u)
             hipLaunchKernelGGL(k_xtv_finalize, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, s,
                                w.partial.p + (int64_t)u * splits * pstride, splits, pstride, h->p,
                                w.scal.p + 4 * u, r_dev + (int64_t)u * h->n, h->mu, h->sinv, h->miss_ptr, h->miss_row,
@@ -590,6 +612,13 @@ int mih_set_xtv_variant(int variant)
 {
     if (!xtv_variant_valid(variant)) { set_error("variant %d out of range", variant); return MIH_BAD_ARG; }
     g_xtv_variant = variant;
+    return MIH_OK;
+}
+
+int mih_set_xtv_digits(int digits)
+{
+    if (digits != kDigits && digits != kDigitsFast) { set_error("digits must be %d (exact) or %d (fast)", kDigits, kDigitsFast); return MIH_BAD_ARG; }
+    g_xtv_digits = digits;
     return MIH_OK;
 }
 

@@ -609,3 +609,45 @@ def test_concurrent_fits_share_one_matrix(mih, normal_pair, normal_data):
     assert not errs
     for a, b in zip(want, got):
         assert np.array_equal(a.beta, b.beta) and np.array_equal(a.c, b.c) and a.logl == b.logl and a.iter == b.iter
+
+
+def test_fast_digit_mode(mih, oracle, normal_pair, normal_data):
+    """mih_set_xtv_digits(16): 32-bit fixed-point residuals, two per MFMA B operand (the opt-in mode for
+    fused multi-RHS passes).  X'r stays within 1e-8 of the exact mode, is independent of how the
+    residuals are grouped into passes, and fits / cross-validation stay inside the north_star tolerance."""
+    x, ox = normal_pair
+    n = x.n
+    R = np.random.default_rng(5).standard_normal((n, 9))
+    exact = x.xtv(R)
+    mih.set_xtv_digits(16)
+    try:
+        fast = x.xtv(R)
+        scale = np.sqrt(n) * np.abs(R).max()                      # size of a null-SNP score
+        assert np.max(np.abs(fast - exact)) < 1e-8 * scale
+        assert not np.array_equal(fast, exact)                    # it really is the other arithmetic
+        singles = np.column_stack([x.xtv(R[:, v]) for v in range(9)])
+        for m_rhs in range(1, 10):                                # pairs, padded 4-operand passes, odd tails
+            assert np.array_equal(x.xtv(R[:, :m_rhs]), singles[:, :m_rhs]), m_rhs
+        assert np.array_equal(x.xtv(R), fast)                     # reproducible
+        y, z = normal_data["y"], normal_data["z"]
+        res = mih.fit_iht(y, x, z, k=7, verbose=False)
+        o = oracle.fit_iht(ox, y, z, k=7)
+        assert res.iter == o["iter"] and np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"]))
+        np.testing.assert_allclose(res.beta[res.beta != 0], o["beta"][o["beta"] != 0], rtol=1e-5)
+        assert res.logl == pytest.approx(o["logl"], rel=1e-8)
+        folds = hash_folds(n, 3)
+        path = list(range(1, 8))
+        mse = mih.cv_iht(y, x, z, path=path, q=3, folds=folds, verbose=False)
+        omse, _ = oracle.cv_iht(ox, y, z, path=path, q=3, folds=folds)
+        np.testing.assert_allclose(mse, omse, rtol=1e-5)
+        rng = np.random.default_rng(41)
+        Y, Z = _mv_problem(oracle, ox, rng, 3, 8, 2)
+        rm = mih.fit_iht(Y, x, Z, k=8, verbose=False)
+        om = oracle.fit_mv(ox, Y, Z, k=8)
+        assert np.array_equal(rm.beta != 0, om["B"] != 0)
+        np.testing.assert_allclose(rm.beta, om["B"], rtol=1e-5, atol=1e-12)
+    finally:
+        mih.set_xtv_digits(28)
+    assert np.array_equal(x.xtv(R), exact)                        # back to the exact mode
+    with pytest.raises(mih.MendelIHTError):
+        mih.set_xtv_digits(20)

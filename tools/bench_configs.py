@@ -12,7 +12,9 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import mendeliht_amd as m
 from conftest import hash_folds
 
-out = {}
+digits = int(os.environ.get("MIH_DIGITS", 28))     # 16 = the opt-in fast mode for fused multi-RHS passes
+m.set_xtv_digits(digits)
+out = {"xtv_digits": digits}
 # ---- configs[1]
 n, p, k = 50_000, 100_000, 100
 x = m.DenseMatrix.synthetic(n, p, seed=7)
@@ -63,5 +65,5 @@ out["configs[4] MvNormal r=10 k=500 n=500k p=1M"] = dict(
     xtR_ms=ms10, flop_equiv_TFLOPs=2.0 * n * p * r / (ms10 * 1e-3) / 1e12, iterations=int(res.iter),
     ms_per_iteration=1e3 * res.time / res.iter, wall_s=wall, nonzero=int(np.count_nonzero(res.beta)))
 print(json.dumps(out), flush=True)
-with open(os.path.join(ROOT, "gpurun_out", "configs.json"), "w") as f:
+with open(os.path.join(ROOT, "gpurun_out", f"configs_digits{digits}.json"), "w") as f:
     json.dump(out, f, indent=1)
