@@ -40,8 +40,10 @@ enum {
 };
 
 /* Distributions / links of the GLM (GLM.jl, Distributions.jl; fit.jl:66-67) */
-enum { MIH_NORMAL = 0, MIH_BERNOULLI = 1, MIH_POISSON = 2, MIH_NEGBIN = 3 };
-enum { MIH_IDENTITY = 0, MIH_LOGIT = 1, MIH_LOG = 2 };
+enum { MIH_NORMAL = 0, MIH_BERNOULLI = 1, MIH_POISSON = 2, MIH_NEGBIN = 3,
+       MIH_GAMMA = 4, MIH_INVGAUSS = 5 };   /* the distributions loglik_obs covers (src/utilities.jl:32-43) */
+enum { MIH_IDENTITY = 0, MIH_LOGIT = 1, MIH_LOG = 2, MIH_PROBIT = 3, MIH_CLOGLOG = 4, MIH_CAUCHIT = 5,
+       MIH_INVERSE = 6, MIH_INVSQUARE = 7, MIH_SQRT = 8 };   /* GLM.jl Link types accepted as `l` */
 enum { MIH_ESTR_NONE = 0, MIH_ESTR_MM = 1, MIH_ESTR_NEWTON = 2 };
 
 typedef struct mih_mat mih_mat;     /* device-resident design matrix */

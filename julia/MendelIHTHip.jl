@@ -78,7 +78,10 @@ end
 
 distcode(::Normal) = Int32(0); distcode(::Bernoulli) = Int32(1)
 distcode(::Poisson) = Int32(2); distcode(::NegativeBinomial) = Int32(3)
+distcode(::Gamma) = Int32(4); distcode(::InverseGaussian) = Int32(5)
 linkcode(::IdentityLink) = Int32(0); linkcode(::LogitLink) = Int32(1); linkcode(::LogLink) = Int32(2)
+linkcode(::ProbitLink) = Int32(3); linkcode(::CloglogLink) = Int32(4); linkcode(::CauchitLink) = Int32(5)
+linkcode(::InverseLink) = Int32(6); linkcode(::InverseSquareLink) = Int32(7); linkcode(::SqrtLink) = Int32(8)
 
 # fit_iht(y, x::HipSnpLinAlg, z; ...)  -- same keywords as src/fit.jl:60-82
 function fit_iht(y::AbstractVector{Float64}, x::HipSnpLinAlg{Float64}, z::AbstractVecOrMat{Float64};

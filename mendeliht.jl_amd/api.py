@@ -194,6 +194,16 @@ class NegativeBinomial(_Dist):
         return f"NegativeBinomial(r={self.r}, p={self.p})"
 
 
+class Gamma(_Dist):
+    """loglik_obs(::Gamma, ...) src/utilities.jl:34 (shape 1/phi, scale mu*phi); use with LogLink or InverseLink."""
+    code, name = 4, "Gamma"
+
+
+class InverseGaussian(_Dist):
+    """loglik_obs(::InverseGaussian, ...) src/utilities.jl:35."""
+    code, name = 5, "InverseGaussian"
+
+
 class MvNormal(_Dist):
     code, name = -1, "MvNormal"
 
@@ -217,6 +227,25 @@ class LogLink:
 
     def __repr__(self):
         return "LogLink()"
+
+
+def _link(name, code):
+    return type(name, (), {"code": code, "__repr__": lambda self: f"{name}()"})
+
+
+# the remaining GLM.jl Link types a caller may pass as `l` (linkinv / mueta closed forms in csrc/fit.hip)
+ProbitLink = _link("ProbitLink", 3)
+CloglogLink = _link("CloglogLink", 4)
+CauchitLink = _link("CauchitLink", 5)
+InverseLink = _link("InverseLink", 6)
+InverseSquareLink = _link("InverseSquareLink", 7)
+SqrtLink = _link("SqrtLink", 8)
+
+
+def canonicallink(d):
+    """GLM.canonicallink (default `l` of cv_iht / iht_run_many_models, cross_validation.jl:237)."""
+    d = _inst(d)
+    return {0: IdentityLink, 1: LogitLink, 2: LogLink, 3: LogLink, 4: InverseLink, 5: InverseSquareLink}[max(d.code, 0)]()
 
 
 def _inst(x):
@@ -659,6 +688,8 @@ def _checky(y, d):
         raise ArgumentError("Bernoulli data y must be 1 or 0 only")
     if isinstance(d, (Poisson, NegativeBinomial)) and (np.any(y < 0) or np.any(y != np.floor(y))):
         raise ArgumentError("Poisson/NegativeBinomial data must be nonnegative integers")
+    if isinstance(d, (Gamma, InverseGaussian)) and np.any(y <= 0):
+        raise ArgumentError("Gamma/InverseGaussian data must be positive")
 
 
 def _fit_mv(Y, x, Z, k, d, l, zkeep, verbose, tol, max_iter, min_iter, max_step, io, train, init_beta=False):

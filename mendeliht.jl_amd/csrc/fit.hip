@@ -27,6 +27,12 @@ __device__ __forceinline__ double d_linkinv(int link, double eta)
     switch (link) {
     case MIH_LOGIT: return 1.0 / (1.0 + exp(-eta));
     case MIH_LOG:   return exp(eta);
+    case MIH_PROBIT:    return 0.5 * erfc(-eta / 1.4142135623730951);
+    case MIH_CLOGLOG:   return -expm1(-exp(eta));
+    case MIH_CAUCHIT:   return 0.5 + atan(eta) / 3.141592653589793;
+    case MIH_INVERSE:   return 1.0 / eta;
+    case MIH_INVSQUARE: return 1.0 / sqrt(eta);
+    case MIH_SQRT:      return eta * eta;
     default:        return eta;
     }
 }
@@ -35,6 +41,12 @@ __device__ __forceinline__ double d_mueta(int link, double eta)
     switch (link) {
     case MIH_LOGIT: { double e = exp(-fabs(eta)); double f = 1.0 + e; return e / (f * f); }
     case MIH_LOG:   return exp(eta);
+    case MIH_PROBIT:    return exp(-0.5 * eta * eta) / 2.5066282746310002;
+    case MIH_CLOGLOG:   return exp(eta) * exp(-exp(eta));
+    case MIH_CAUCHIT:   return 1.0 / (3.141592653589793 * (1.0 + eta * eta));
+    case MIH_INVERSE:   return -1.0 / (eta * eta);
+    case MIH_INVSQUARE: { double m = 1.0 / sqrt(eta); return -m * m * m / 2.0; }
+    case MIH_SQRT:      return 2.0 * eta;
     default:        return 1.0;
     }
 }
@@ -44,6 +56,8 @@ __device__ __forceinline__ double d_glmvar(int dist, double mu, double nb_r)
     case MIH_BERNOULLI: return mu * (1.0 - mu);
     case MIH_POISSON:   return mu;
     case MIH_NEGBIN:    return mu * (1.0 + mu / nb_r);
+    case MIH_GAMMA:     return mu * mu;
+    case MIH_INVGAUSS:  return mu * mu * mu;
     default:            return 1.0;
     }
 }
@@ -57,6 +71,8 @@ __device__ __forceinline__ double d_devresid(int dist, double y, double mu, doub
         double v = 2.0 * (d_xlogy(y, y / mu) + d_xlogy(y + nb_r, (mu + nb_r) / (y + nb_r)));
         return (mu == 0.0) ? nan("") : v;
     }
+    case MIH_GAMMA:    return -2.0 * (log(y / mu) - (y - mu) / mu);
+    case MIH_INVGAUSS: { double d = y - mu; return d * d / (y * mu * mu); }
     default: { double d = y - mu; return d * d; }
     }
 }
@@ -86,24 +102,29 @@ __global__ void k_zmul(const double *__restrict__ z, int64_t n, int q, QVec c, i
 }
 
 // update_mu! (utilities.jl:74-82) fused with deviance (:52-59) and the loglik terms (:9-20).
-// partial[b] = { sum w*devresid, sum w*loglik_obs (non-Normal), sum w }
+// partial[b] = { sum w*devresid, A, sum w, B }: A = sum w*loglik_obs for the families whose loglik_obs does not
+// involve phi; Normal / Gamma / InverseGaussian need phi = deviance / n first, so their loglikelihood is
+// assembled on the host from sums: Gamma A = sum w (log mu + y/mu), B = sum w log y; InverseGaussian
+// B = sum w log(2 pi y^3).
 __global__ void __launch_bounds__(256)
 k_mu_loglik(const double *__restrict__ xb, const double *__restrict__ zc, const double *__restrict__ y,
             const double *__restrict__ w, int64_t n, int dist, int link, double nb_r, int with_zc,
             double *__restrict__ mu, double *__restrict__ partial)
 {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    double v[3] = {0.0, 0.0, 0.0};
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
     if (i < n) {
         double eta = with_zc ? xb[i] + zc[i] : xb[i];
         double m = d_linkinv(link, eta);
         mu[i] = m;
-        double wt = w[i];
-        v[0] = wt * d_devresid(dist, y[i], m, nb_r);
-        v[1] = (dist == MIH_NORMAL) ? 0.0 : wt * d_loglik_obs(dist, y[i], m, nb_r);
+        double wt = w[i], yi = y[i];
+        v[0] = wt * d_devresid(dist, yi, m, nb_r);
+        if (dist == MIH_GAMMA) { v[1] = wt * (log(m) + yi / m); v[3] = wt * log(yi); }
+        else if (dist == MIH_INVGAUSS) v[3] = wt * log(6.283185307179586 * yi * yi * yi);
+        else if (dist != MIH_NORMAL) v[1] = wt * d_loglik_obs(dist, yi, m, nb_r);
         v[2] = wt;
     }
-    block_sum<3>(v, partial ? partial + 3ll * blockIdx.x : nullptr);
+    block_sum<4>(v, partial ? partial + 4ll * blockIdx.x : nullptr);
 }
 
 // score! residual (utilities.jl:128-132): r = mueta(eta)/var(mu) * (y-mu) * cv_wts
@@ -337,15 +358,32 @@ __global__ void k_unvec(const double *__restrict__ full, const double *__restric
     if (j >= p) return;
     df[j] = weight ? full[j] / weight[j] : full[j];
 }
+// host copies of d_linkinv / d_mueta for the scalar intercept iteration of init_iht_indices!
 static double h_linkinv(int link, double eta)
 {
-    switch (link) { case MIH_LOGIT: return 1.0 / (1.0 + std::exp(-eta)); case MIH_LOG: return std::exp(eta); default: return eta; }
+    switch (link) {
+    case MIH_LOGIT: return 1.0 / (1.0 + std::exp(-eta));
+    case MIH_LOG: return std::exp(eta);
+    case MIH_PROBIT: return 0.5 * std::erfc(-eta / 1.4142135623730951);
+    case MIH_CLOGLOG: return -std::expm1(-std::exp(eta));
+    case MIH_CAUCHIT: return 0.5 + std::atan(eta) / 3.141592653589793;
+    case MIH_INVERSE: return 1.0 / eta;
+    case MIH_INVSQUARE: return 1.0 / std::sqrt(eta);
+    case MIH_SQRT: return eta * eta;
+    default: return eta;
+    }
 }
 static double h_mueta(int link, double eta)
 {
     switch (link) {
     case MIH_LOGIT: { double e = std::exp(-std::fabs(eta)); double f = 1.0 + e; return e / (f * f); }
     case MIH_LOG: return std::exp(eta);
+    case MIH_PROBIT: return std::exp(-0.5 * eta * eta) / 2.5066282746310002;
+    case MIH_CLOGLOG: return std::exp(eta) * std::exp(-std::exp(eta));
+    case MIH_CAUCHIT: return 1.0 / (3.141592653589793 * (1.0 + eta * eta));
+    case MIH_INVERSE: return -1.0 / (eta * eta);
+    case MIH_INVSQUARE: { double m = 1.0 / std::sqrt(eta); return -m * m * m / 2.0; }
+    case MIH_SQRT: return 2.0 * eta;
     default: return 1.0;
     }
 }
@@ -547,8 +585,8 @@ struct IhtVar {
     int mu_loglik(int with_zc, double *logl, double *dev)
     {
         hipLaunchKernelGGL(k_mu_loglik, dim3(nb), dim3(256), 0, s, xb.p, zc.p, y.p, w.p, n, dist, link, nb_r, with_zc, mu.p, red.p);
-        hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, s, red.p, nb, 3, scal.p);
-        double o[3];
+        hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, s, red.p, nb, 4, scal.p);
+        double o[4];
         MIH_HIP(hipMemcpyAsync(o, scal.p, sizeof(o), hipMemcpyDeviceToHost, s));
         MIH_HIP(hipStreamSynchronize(s));
         if (dev) *dev = o[0];
@@ -558,6 +596,12 @@ struct IhtVar {
                 double sd = std::sqrt(phi);
                 // sum_i w_i * ( -(z_i^2 + log 2pi)/2 - log sd ),  z_i = (y_i-mu_i)/sd
                 *logl = -(o[0] / (sd * sd) + o[2] * 1.8378770664093454835606594728112) / 2.0 - o[2] * std::log(sd);
+            } else if (dist == MIH_GAMMA) {          // sum_i w_i logpdf(Gamma(1/phi, mu_i phi), y_i)
+                double phi = o[0] / (double)n, a = 1.0 / phi;
+                *logl = -o[2] * (std::lgamma(a) + a * std::log(phi)) - a * o[1] + (a - 1.0) * o[3];
+            } else if (dist == MIH_INVGAUSS) {       // sum_i w_i logpdf(InverseGaussian(mu_i, 1/phi), y_i)
+                double lam = (double)n / o[0];
+                *logl = 0.5 * std::log(lam) * o[2] - 0.5 * o[3] - 0.5 * lam * o[0];
             } else *logl = o[1];
         }
         return MIH_OK;
@@ -1069,7 +1113,7 @@ static int check_params(const mih_mat *h, const mih_fit_params *prm, int64_t q)
     if (prm->est_r != MIH_ESTR_NONE && prm->dist != MIH_NEGBIN) { set_error("Only negative binomial regression currently supports nuisance parameter estimation"); return MIH_BAD_ARG; }
     if (!prm->ks && prm->k < 0) { set_error("Value of k (max predictors per group) must be nonnegative!"); return MIH_BAD_ARG; }
     if (q < 1 || q > kMaxQ) { set_error("number of covariates q=%lld must be in 1..%d", (long long)q, kMaxQ); return MIH_BAD_DIM; }
-    if (prm->dist < 0 || prm->dist > MIH_NEGBIN || prm->link < 0 || prm->link > MIH_LOG) { set_error("unknown distribution/link"); return MIH_BAD_ARG; }
+    if (prm->dist < 0 || prm->dist > MIH_INVGAUSS || prm->link < 0 || prm->link > MIH_SQRT) { set_error("unknown distribution/link"); return MIH_BAD_ARG; }
     return MIH_OK;
 }
 

@@ -219,6 +219,13 @@ double orc_linkinv(int link, double eta)
     switch (link) {
     case ORC_LOGIT: return 1.0 / (1.0 + exp(-eta));
     case ORC_LOG:   return exp(eta);
+    /* GLM.jl glmtools.jl linkinv for the remaining Link types */
+    case ORC_PROBIT:    return 0.5 * erfc(-eta / 1.4142135623730951);
+    case ORC_CLOGLOG:   return -expm1(-exp(eta));
+    case ORC_CAUCHIT:   return 0.5 + atan(eta) / 3.141592653589793;
+    case ORC_INVERSE:   return 1.0 / eta;
+    case ORC_INVSQUARE: return 1.0 / sqrt(eta);
+    case ORC_SQRT:      return eta * eta;
     default:        return eta;
     }
 }
@@ -228,6 +235,12 @@ double orc_mueta(int link, double eta)
     switch (link) {
     case ORC_LOGIT: { double e = exp(-fabs(eta)); double f = 1.0 + e; return e / (f * f); }
     case ORC_LOG:   return exp(eta);
+    case ORC_PROBIT:    return exp(-0.5 * eta * eta) / 2.5066282746310002;
+    case ORC_CLOGLOG:   return exp(eta) * exp(-exp(eta));
+    case ORC_CAUCHIT:   return 1.0 / (3.141592653589793 * (1.0 + eta * eta));
+    case ORC_INVERSE:   return -1.0 / (eta * eta);
+    case ORC_INVSQUARE: { double m = 1.0 / sqrt(eta); return -m * m * m / 2.0; }
+    case ORC_SQRT:      return 2.0 * eta;
     default:        return 1.0;
     }
 }
@@ -238,6 +251,8 @@ double orc_glmvar(int dist, double mu, double nb_r)
     case ORC_BERNOULLI: return mu * (1.0 - mu);
     case ORC_POISSON:   return mu;
     case ORC_NEGBIN:    return mu * (1.0 + mu / nb_r);
+    case ORC_GAMMA:     return mu * mu;
+    case ORC_INVGAUSS:  return mu * mu * mu;
     default:            return 1.0;
     }
 }
@@ -255,6 +270,8 @@ double orc_devresid(int dist, double y, double mu, double nb_r)
         double v = 2.0 * (xlogy(y, y / mu) + xlogy(y + nb_r, (mu + nb_r) / (y + nb_r)));
         return (mu == 0.0) ? NAN : v;
     }
+    case ORC_GAMMA:    return -2.0 * (log(y / mu) - (y - mu) / mu);
+    case ORC_INVGAUSS: { double d = y - mu; return d * d / (y * mu * mu); }
     default: { double d = y - mu; return d * d; }
     }
 }
@@ -272,6 +289,14 @@ double orc_loglik_obs(int dist, double y, double mu, double wt, double phi, doub
         double v = lgamma(nb_r + y) - lgamma(nb_r) - lgamma(y + 1.0)
                  + nb_r * log(pp) + xlogy(y, 1.0 - pp);
         return wt * v;
+    }
+    case ORC_GAMMA: {          /* wt*logpdf(Gamma(inv(phi), mu*phi), y) */
+        double a = 1.0 / phi, th = mu * phi;
+        return wt * (-lgamma(a) - a * log(th) + (a - 1.0) * log(y) - y / th);
+    }
+    case ORC_INVGAUSS: {       /* wt*logpdf(InverseGaussian(mu, inv(phi)), y) */
+        double lam = 1.0 / phi, d = y - mu;
+        return wt * (0.5 * log(lam / (6.283185307179586 * y * y * y)) - lam * d * d / (2.0 * mu * mu * y));
     }
     default: {
         double sd = sqrt(phi);

@@ -25,8 +25,9 @@
 extern "C" {
 #endif
 
-enum { ORC_NORMAL = 0, ORC_BERNOULLI = 1, ORC_POISSON = 2, ORC_NEGBIN = 3 };
-enum { ORC_IDENTITY = 0, ORC_LOGIT = 1, ORC_LOG = 2 };
+enum { ORC_NORMAL = 0, ORC_BERNOULLI = 1, ORC_POISSON = 2, ORC_NEGBIN = 3, ORC_GAMMA = 4, ORC_INVGAUSS = 5 };
+enum { ORC_IDENTITY = 0, ORC_LOGIT = 1, ORC_LOG = 2, ORC_PROBIT = 3, ORC_CLOGLOG = 4, ORC_CAUCHIT = 5,
+       ORC_INVERSE = 6, ORC_INVSQUARE = 7, ORC_SQRT = 8 };
 enum { ORC_OK = 0, ORC_BAD_DIM = 1, ORC_BAD_ARG = 2, ORC_NOT_CENTERED = 3,
        ORC_NAN_LOGL = 4, ORC_INF_LOGL = 5 };
 

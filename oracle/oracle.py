@@ -12,10 +12,12 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libiht_oracle.so")
 
-NORMAL, BERNOULLI, POISSON, NEGBIN = 0, 1, 2, 3
-IDENTITY, LOGIT, LOG = 0, 1, 2
-DIST = {"normal": NORMAL, "bernoulli": BERNOULLI, "poisson": POISSON, "negbin": NEGBIN}
-LINK = {"identity": IDENTITY, "logit": LOGIT, "log": LOG}
+NORMAL, BERNOULLI, POISSON, NEGBIN, GAMMA, INVGAUSS = 0, 1, 2, 3, 4, 5
+IDENTITY, LOGIT, LOG, PROBIT, CLOGLOG, CAUCHIT, INVERSE, INVSQUARE, SQRT = range(9)
+DIST = {"normal": NORMAL, "bernoulli": BERNOULLI, "poisson": POISSON, "negbin": NEGBIN, "gamma": GAMMA,
+        "invgauss": INVGAUSS}
+LINK = {"identity": IDENTITY, "logit": LOGIT, "log": LOG, "probit": PROBIT, "cloglog": CLOGLOG, "cauchit": CAUCHIT,
+        "inverse": INVERSE, "invsquare": INVSQUARE, "sqrt": SQRT}
 
 
 def build(force=False):

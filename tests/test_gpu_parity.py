@@ -651,3 +651,47 @@ def test_fast_digit_mode(mih, oracle, normal_pair, normal_data):
     assert np.array_equal(x.xtv(R), exact)                        # back to the exact mode
     with pytest.raises(mih.MendelIHTError):
         mih.set_xtv_digits(20)
+
+
+@pytest.mark.parametrize("case", ["gamma_log", "invgauss_log", "bernoulli_probit", "bernoulli_cloglog", "bernoulli_cauchit",
+                                  "poisson_sqrt", "gamma_inverse"])
+def test_more_families_and_links(mih, oracle, normal_pair, case):
+    """Gamma / InverseGaussian (loglik_obs, src/utilities.jl:34-35) and the remaining GLM.jl links as `l`."""
+    x, ox = normal_pair
+    n = x.n
+    rng = np.random.default_rng(60)
+    eta = 0.25 * _sim(oracle, ox, rng, 6)
+    kw = {}
+    if case == "gamma_log":
+        y, d, l, od, ol = rng.gamma(5.0, np.exp(eta + 0.5) / 5.0), mih.Gamma(), mih.LogLink(), "gamma", "log"
+    elif case == "invgauss_log":
+        y, d, l, od, ol = rng.wald(np.exp(eta + 0.5), 8.0), mih.InverseGaussian(), mih.LogLink(), "invgauss", "log"
+    elif case == "bernoulli_probit":
+        from scipy import stats
+        y, d, l, od, ol = (rng.random(n) < stats.norm.cdf(2 * eta)).astype(float), mih.Bernoulli(), mih.ProbitLink(), "bernoulli", "probit"
+    elif case == "bernoulli_cloglog":
+        y, d, l, od, ol = (rng.random(n) < 1 - np.exp(-np.exp(2 * eta - 0.5))).astype(float), mih.Bernoulli(), mih.CloglogLink(), "bernoulli", "cloglog"
+    elif case == "bernoulli_cauchit":
+        y, d, l, od, ol = (rng.random(n) < 0.5 + np.arctan(3 * eta) / np.pi).astype(float), mih.Bernoulli(), mih.CauchitLink(), "bernoulli", "cauchit"
+    elif case == "poisson_sqrt":
+        y, d, l, od, ol = rng.poisson((1.5 + eta) ** 2).astype(float), mih.Poisson(), mih.SqrtLink(), "poisson", "sqrt"
+    else:                                                    # canonical link of Gamma; few steps (the domain eta > 0 is not enforced)
+        y, d, l, od, ol = rng.gamma(5.0, 1.0 / (5.0 * (1.5 + eta))), mih.Gamma(), mih.InverseLink(), "gamma", "inverse"
+        kw = dict(max_iter=4)
+    try:
+        o = oracle.fit_iht(ox, y, None, k=6, dist=od, link=ol, **kw)
+    except RuntimeError:
+        o = None                                             # NaN loglikelihood in the reference algorithm itself
+    if o is None or not np.isfinite(o["logl"]):
+        with pytest.raises(mih.MendelIHTError):
+            mih.fit_iht(y, x, None, k=6, d=d, l=l, verbose=False, **kw)
+        return
+    res = mih.fit_iht(y, x, None, k=6, d=d, l=l, verbose=False, **kw)
+    assert res.iter == o["iter"]
+    assert np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"]))
+    nz = np.flatnonzero(o["beta"])
+    np.testing.assert_allclose(res.beta[nz], o["beta"][nz], rtol=1e-4)
+    np.testing.assert_allclose(res.c, o["c"], rtol=1e-4)
+    assert res.logl == pytest.approx(o["logl"], rel=1e-8)
+    assert list(res.trace["backtracks"]) == list(o["bt_trace"])
+    assert type(mih.canonicallink(d)).__name__ in ("InverseLink", "InverseSquareLink", "LogitLink", "LogLink")

@@ -103,6 +103,20 @@ def test_loglikelihood_vs_logpdf(oracle):
     assert ll == pytest.approx(stats.norm.logpdf(y, mu, sd).sum(), rel=1e-12)
     dev = L.orc_deviance(oracle.NORMAL, 1.0, p_(y), p_(mu), p_(w), n)
     assert dev == pytest.approx(((y - mu) ** 2).sum(), rel=1e-14)
+    # Gamma(1/phi, mu*phi) and InverseGaussian(mu, 1/phi) with phi = deviance / n (utilities.jl:15, 34-35)
+    mu = rng.uniform(0.5, 3.0, n)
+    y = rng.gamma(4.0, mu / 4.0)
+    dev = L.orc_deviance(oracle.GAMMA, 1.0, p_(y), p_(mu), p_(w), n)
+    assert dev == pytest.approx((-2 * (np.log(y / mu) - (y - mu) / mu)).sum(), rel=1e-13)
+    phi = dev / n
+    ll = L.orc_loglikelihood(oracle.GAMMA, 1.0, p_(y), p_(mu), p_(w), n)
+    assert ll == pytest.approx(stats.gamma.logpdf(y, 1 / phi, scale=mu * phi).sum(), rel=1e-11)
+    y = rng.wald(mu, 5.0)
+    dev = L.orc_deviance(oracle.INVGAUSS, 1.0, p_(y), p_(mu), p_(w), n)
+    assert dev == pytest.approx(((y - mu) ** 2 / (y * mu ** 2)).sum(), rel=1e-13)
+    lam = n / dev
+    ll = L.orc_loglikelihood(oracle.INVGAUSS, 1.0, p_(y), p_(mu), p_(w), n)
+    assert ll == pytest.approx(stats.invgauss.logpdf(y, mu / lam, scale=lam).sum(), rel=1e-11)
 
 
 def test_links(oracle):
@@ -114,6 +128,19 @@ def test_links(oracle):
         assert L.orc_linkinv(oracle.LOG, eta) == pytest.approx(np.exp(eta), rel=1e-15)
         mu = 1 / (1 + np.exp(-eta))
         assert L.orc_mueta(oracle.LOGIT, eta) == pytest.approx(mu * (1 - mu), rel=1e-13)
+        assert L.orc_linkinv(oracle.PROBIT, eta) == pytest.approx(stats.norm.cdf(eta), rel=1e-13)
+        assert L.orc_linkinv(oracle.CLOGLOG, eta) == pytest.approx(1 - np.exp(-np.exp(eta)), rel=1e-13)
+        assert L.orc_linkinv(oracle.CAUCHIT, eta) == pytest.approx(stats.cauchy.cdf(eta), rel=1e-13)
+        assert L.orc_linkinv(oracle.SQRT, eta) == eta * eta
+    for eta in (0.3, 1.0, 2.5):                              # links with a restricted domain
+        assert L.orc_linkinv(oracle.INVERSE, eta) == 1 / eta
+        assert L.orc_linkinv(oracle.INVSQUARE, eta) == pytest.approx(eta ** -0.5, rel=1e-15)
+    # mueta is the derivative of linkinv for every link (GLM.jl glmtools.jl)
+    for link in range(9):
+        for eta in (0.4, 1.3):
+            h = 1e-6
+            fd = (L.orc_linkinv(link, eta + h) - L.orc_linkinv(link, eta - h)) / (2 * h)
+            assert L.orc_mueta(link, eta) == pytest.approx(fd, rel=1e-7), link
 
 
 def test_project_k_property(oracle):
