@@ -144,7 +144,10 @@ typedef struct mih_fit_params {
                                  (initialize_beta!, src/utilities.jl:776-812; Normal only) */
     const mih_comm *comm;     /* NULL = single process; else this process's shard of a column-sharded
                                  fit: h, weight, res->beta cover the LOCAL columns only (mih_fit_iht and
-                                 mih_session_* only; no group / init_beta / cross-validation) */
+                                 mih_session_* only; no group / init_beta / debias / cross-validation) */
+    int32_t  debias;          /* fit.jl:73,188 debias: after a step (iter >= 5) that kept the support, refit the
+                                 support columns by GLM (debias!, src/utilities.jl:1014-1020; the reference needs
+                                 memory_efficient=false for it, the device builds the n x k panel on the fly) */
 } mih_fit_params;
 
 /* IHTResult (src/data_structures.jl:245-256) + the per-iteration log */

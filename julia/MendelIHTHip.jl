@@ -63,6 +63,7 @@ struct MihFitParams
     zkeep::Ptr{UInt8}; weight::Ptr{Float64}; group::Ptr{Int64}; ks::Ptr{Int64}; nks::Int64
     progress::Ptr{Cvoid}; progress_user::Ptr{Cvoid}; init_beta::Int32
     comm::Ptr{Cvoid}      # Ptr{MihComm} for a column-sharded fit, C_NULL otherwise
+    debias::Int32
 end
 # mih_comm: exchange callbacks of a column-sharded fit (one Julia process per GPU, e.g. under mpiexec)
 struct MihComm
@@ -98,7 +99,7 @@ function fit_iht(y::AbstractVector{Float64}, x::HipSnpLinAlg{Float64}, z::Abstra
         prm = MihFitParams(k, J, distcode(d), linkcode(l), d isa NegativeBinomial ? d.r : 1.0, tol,
             max_iter, min_iter, max_step, 0, pointer(zk),
             isempty(weight) ? Ptr{Float64}(C_NULL) : pointer(weight), C_NULL, C_NULL, 0, C_NULL, C_NULL,
-            Int32(get(kwargs, :init_beta, false)), get(kwargs, :comm, C_NULL))
+            Int32(get(kwargs, :init_beta, false)), get(kwargs, :comm, C_NULL), Int32(get(kwargs, :debias, false)))
         res = MihFitResult(0, 0, 0, 0, 0, 0, 0, pointer(beta), pointer(c), pointer(lt), pointer(tt),
             pointer(bt), C_NULL)
         check(ccall((:mih_fit_iht, LIB), Cint,
@@ -123,7 +124,7 @@ function cv_iht(y::AbstractVector{Float64}, x::HipSnpLinAlg{Float64}, z::Abstrac
     f32 = Vector{Int32}(folds); pth = Vector{Int64}(path)
     raw = zeros(q * length(pth)); mse = zeros(length(pth))
     prm = MihFitParams(1, 1, distcode(d), linkcode(l), d isa NegativeBinomial ? d.r : 1.0, 1e-4,
-        max_iter, min_iter, 3, 0, C_NULL, C_NULL, C_NULL, C_NULL, 0, C_NULL, C_NULL, Int32(0), C_NULL)
+        max_iter, min_iter, 3, 0, C_NULL, C_NULL, C_NULL, C_NULL, 0, C_NULL, C_NULL, Int32(0), C_NULL, Int32(get(kwargs, :debias, false)))
     check(ccall((:mih_cv_iht, LIB), Cint,
         (Ptr{Cvoid}, Ref{MihFitParams}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Int32}, Int32, Ptr{Int64},
          Int64, Int32, Int32, Ptr{Float64}),

@@ -44,7 +44,7 @@ class _FitParams(C.Structure):
                 ("max_iter", C.c_int32), ("min_iter", C.c_int32), ("max_step", C.c_int32), ("est_r", C.c_int32),
                 ("zkeep", C.c_void_p), ("weight", C.c_void_p), ("group", C.c_void_p), ("ks", C.c_void_p),
                 ("nks", C.c_int64), ("progress", C.c_void_p), ("progress_user", C.c_void_p),
-                ("init_beta", C.c_int32), ("comm", C.c_void_p)]
+                ("init_beta", C.c_int32), ("comm", C.c_void_p), ("debias", C.c_int32)]
 
 
 class _Comm(C.Structure):
@@ -560,8 +560,9 @@ def _print_parameters(io, k, d, l, use_maf, group, debias, tol, max_iter, min_it
 
 
 def _params(k, J, d, l, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, q, p, keep, progress=None,
-            init_beta=False, comm=None):
+            init_beta=False, comm=None, debias=False):
     prm = _FitParams()
+    prm.debias = int(bool(debias))
     if comm is not None:            # column-sharded fit: mendeliht.jl_amd.dist.ColumnComm
         prm.comm = comm.pointer()
         keep.append(comm)
@@ -628,8 +629,8 @@ def fit_iht(y, x, z=None, *, k=10, J=1, d=None, l=None, group=None, weight=None,
     mv = _is_multivariate(y)
     d = _inst(d) if d is not None else (MvNormal() if mv else Normal())
     l = _inst(l) if l is not None else IdentityLink()
-    if debias:
-        raise ArgumentError("Currently debiasing only works with memory_efficient=false (not available on the GPU path)")
+    if debias and mv:
+        raise ArgumentError("debias is disabled for multivariate traits (multivariate.jl:569-570)")
     if init_beta and not isinstance(d, (Normal, MvNormal)):
         raise ArgumentError("Intializing beta values only work for Gaussian phenotypes! Sorry!")
     if not memory_efficient:
@@ -663,7 +664,7 @@ def fit_iht(y, x, z=None, *, k=10, J=1, d=None, l=None, group=None, weight=None,
 
     keep = []
     prm = _params(k, J, d, l, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, q, x.p, keep, progress,
-                  init_beta=init_beta, comm=comm)
+                  init_beta=init_beta, comm=comm, debias=debias)
     if verbose:
         _print_parameters(io, k, d, l, use_maf, group, debias, tol, max_iter, min_iter)
     tr = None if train is None else np.ascontiguousarray(train, dtype=np.uint8)
@@ -743,8 +744,10 @@ def cv_iht(y, x, z=None, *, d=None, l=None, path=range(1, 21), q=5, est_r="None"
     mv = _is_multivariate(y)
     d = _inst(d) if d is not None else (MvNormal() if mv else Normal())
     l = _inst(l) if l is not None else IdentityLink()
-    if debias or not memory_efficient:
-        raise ArgumentError("debias / memory_efficient=false are not available on the GPU path")
+    if not memory_efficient:
+        raise ArgumentError("the GPU path is always memory_efficient=true")
+    if debias and mv:
+        raise ArgumentError("debias is disabled for multivariate traits (multivariate.jl:569-570)")
     if init_beta and not isinstance(d, (Normal, MvNormal)):
         raise ArgumentError("Intializing beta values only work for Gaussian phenotypes! Sorry!")
     path = np.ascontiguousarray(list(path), dtype=np.int64)
@@ -777,7 +780,7 @@ def cv_iht(y, x, z=None, *, d=None, l=None, path=range(1, 21), q=5, est_r="None"
             raise DimensionMismatch(f"row dimension of y, x, and z ({yv.size}, {n}, {zz.shape[0]}) are not equal")
         _checky(yv, d)
         prm = _params(1, 1, d, l, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, zz.shape[1], x.p, keep,
-                      init_beta=init_beta)
+                      init_beta=init_beta, debias=debias)
         _check(lib().mih_cv_iht(x._h, C.byref(prm), _p(yv), _p(zz), zz.shape[1], _p(folds), q, _p(path), path.size,
                                 rank, world, _p(raw)))
     if reduce is not None:

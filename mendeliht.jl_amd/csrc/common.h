@@ -139,6 +139,9 @@ int  collect_nonzero_device(double *x_dev, int64_t len, TopkWork &w, hipStream_t
 // project_group_sparse! in place on a device vector (group labels 1..G, k_dev: 1 or G entries)
 int  group_project_device(double *y_dev, const int64_t *group_dev, int64_t len, int64_t G, int64_t J,
                           const int64_t *k_dev, int k_is_vector, hipStream_t s);
+// debias! (utilities.jl:1014-1020): GLM refit of y on the k support columns (debias.hip); beta_out[k] on the host
+int  debias_glm_device(const mih_mat *h, const int64_t *idx_host, int64_t k, const double *y_dev, int dist, int link,
+                       double nb_r, double *beta_out, hipStream_t s);
 // initialize_beta! regressions for m response planes (fit.hip); shared by the univariate and multivariate fits
 int  init_beta_regress_device(const mih_mat *h, const double *w_dev, const double *Y_dev, int m, double N,
                               const double *Sy_host, double *beta_dev, double *icpt_sum_host,

@@ -21,75 +21,6 @@ namespace mih {
 constexpr int kMaxQ = 64;
 struct QVec { double v[kMaxQ]; };
 
-// ---- GLM closed forms (GLM.jl / Distributions.jl) --------------------
-__device__ __forceinline__ double d_linkinv(int link, double eta)
-{
-    switch (link) {
-    case MIH_LOGIT: return 1.0 / (1.0 + exp(-eta));
-    case MIH_LOG:   return exp(eta);
-    case MIH_PROBIT:    return 0.5 * erfc(-eta / 1.4142135623730951);
-    case MIH_CLOGLOG:   return -expm1(-exp(eta));
-    case MIH_CAUCHIT:   return 0.5 + atan(eta) / 3.141592653589793;
-    case MIH_INVERSE:   return 1.0 / eta;
-    case MIH_INVSQUARE: return 1.0 / sqrt(eta);
-    case MIH_SQRT:      return eta * eta;
-    default:        return eta;
-    }
-}
-__device__ __forceinline__ double d_mueta(int link, double eta)
-{
-    switch (link) {
-    case MIH_LOGIT: { double e = exp(-fabs(eta)); double f = 1.0 + e; return e / (f * f); }
-    case MIH_LOG:   return exp(eta);
-    case MIH_PROBIT:    return exp(-0.5 * eta * eta) / 2.5066282746310002;
-    case MIH_CLOGLOG:   return exp(eta) * exp(-exp(eta));
-    case MIH_CAUCHIT:   return 1.0 / (3.141592653589793 * (1.0 + eta * eta));
-    case MIH_INVERSE:   return -1.0 / (eta * eta);
-    case MIH_INVSQUARE: { double m = 1.0 / sqrt(eta); return -m * m * m / 2.0; }
-    case MIH_SQRT:      return 2.0 * eta;
-    default:        return 1.0;
-    }
-}
-__device__ __forceinline__ double d_glmvar(int dist, double mu, double nb_r)
-{
-    switch (dist) {
-    case MIH_BERNOULLI: return mu * (1.0 - mu);
-    case MIH_POISSON:   return mu;
-    case MIH_NEGBIN:    return mu * (1.0 + mu / nb_r);
-    case MIH_GAMMA:     return mu * mu;
-    case MIH_INVGAUSS:  return mu * mu * mu;
-    default:            return 1.0;
-    }
-}
-__device__ __forceinline__ double d_xlogy(double x, double y) { return x == 0.0 ? 0.0 : x * log(y); }
-__device__ __forceinline__ double d_devresid(int dist, double y, double mu, double nb_r)
-{
-    switch (dist) {
-    case MIH_BERNOULLI: return (y == 1.0) ? -2.0 * log(mu) : -2.0 * log1p(-mu);
-    case MIH_POISSON:   return 2.0 * (d_xlogy(y, y / mu) - (y - mu));
-    case MIH_NEGBIN: {
-        double v = 2.0 * (d_xlogy(y, y / mu) + d_xlogy(y + nb_r, (mu + nb_r) / (y + nb_r)));
-        return (mu == 0.0) ? nan("") : v;
-    }
-    case MIH_GAMMA:    return -2.0 * (log(y / mu) - (y - mu) / mu);
-    case MIH_INVGAUSS: { double d = y - mu; return d * d / (y * mu * mu); }
-    default: { double d = y - mu; return d * d; }
-    }
-}
-// loglik_obs without the Normal branch (utilities.jl:32-43); Normal is closed-form from the deviance
-__device__ __forceinline__ double d_loglik_obs(int dist, double y, double mu, double nb_r)
-{
-    switch (dist) {
-    case MIH_BERNOULLI: return (y == 1.0) ? log(mu) : log(1.0 - mu);
-    case MIH_POISSON:   return d_xlogy(y, mu) - mu - lgamma(y + 1.0);
-    case MIH_NEGBIN: {
-        double pp = nb_r / (mu + nb_r);
-        return lgamma(nb_r + y) - lgamma(nb_r) - lgamma(y + 1.0) + nb_r * log(pp) + d_xlogy(y, 1.0 - pp);
-    }
-    default: return 0.0;
-    }
-}
-
 // zc = Z c  (utilities.jl:113), optional clamp (utilities.jl:114-117)
 __global__ void k_zmul(const double *__restrict__ z, int64_t n, int q, QVec c, int clamp20, double *__restrict__ zc)
 {
@@ -434,7 +365,7 @@ struct IhtVar {
     int dist = 0, link = 0, est_r = 0; double nb_r = 1.0;
     std::vector<uint8_t> zkeep; int64_t zkeepn = 0;
     const double *y_host = nullptr, *z_host = nullptr;
-    int init_beta = 0;
+    int init_beta = 0, debias = 0;
     hipStream_t s = nullptr;
     // device
     DevBuf<double> y, z, w, xb, zc, mu, r, xgk, df, full, weight, red, scal, gval, ztr;
@@ -479,14 +410,14 @@ struct IhtVar {
                hipStream_t shared_stream = nullptr)
     {
         h = hh; n = h->n; p = h->p; q = (int)qq; y_host = yh; z_host = zh; init_beta = prm->init_beta;
-        comm = prm->comm; pg = p; col0 = 0;
+        comm = prm->comm; pg = p; col0 = 0; debias = prm->debias;
         if (comm) {
             if (!comm->allreduce || !comm->allgather || comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world ||
                 comm->col_offset < 0 || comm->col_offset + p > comm->p_global) {
                 set_error("invalid mih_comm (callbacks, rank/world or column range)"); return MIH_BAD_ARG;
             }
-            if (prm->group || prm->ks || prm->init_beta) {
-                set_error("group projection and init_beta are not available in a column-sharded fit"); return MIH_BAD_ARG;
+            if (prm->group || prm->ks || prm->init_beta || prm->debias) {
+                set_error("group projection, init_beta and debias are not available in a column-sharded fit"); return MIH_BAD_ARG;
             }
             col0 = comm->col_offset; pg = comm->p_global;
         }
@@ -1083,6 +1014,8 @@ struct IhtVar {
             best = save_prev(next_logl, best);
             int nbt = 0;
             MIH_TRY(one_step(next_logl, prm->max_step, &nbt, &next_logl));
+            if (debias && iter >= 5 && b.idx == b0.idx && !b.idx.empty())      // fit.jl:188: v.idx == v.idx0 && debias!(v)
+                MIH_TRY(debias_glm_device(h, b.idx.data(), (int64_t)b.idx.size(), y.p, dist, link, nb_r, b.val.data(), s));
             double sc = check_convergence();
             if (lt) lt[nt] = next_logl;
             if (tt) tt[nt] = sc;
@@ -1242,8 +1175,8 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, con
     mih_fit_params pr = *prm;
     pr.k = kmax; pr.progress = nullptr;
 
-    if (prm->est_r != MIH_ESTR_NONE || prm->init_beta) {
-        // init_beta needs two extra passes per fit (not batched yet); the NegBin nuisance parameter is carried from one fit to the next in the reference (v.d is
+    if (prm->est_r != MIH_ESTR_NONE || prm->init_beta || prm->debias) {
+        // init_beta needs two extra passes per fit and debias a GLM refit (not batched yet); the NegBin nuisance parameter is carried from one fit to the next in the reference (v.d is
         // never reset, cross_validation.jl:91,110): keep the sequential order for that case
         IhtVar v;
         MIH_TRY(v.create(h, &pr, y, z, q));

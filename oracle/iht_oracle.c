@@ -847,6 +847,132 @@ static int one_step(ihtvar *v, double old_logl, int nstep, int *bt, double *new_
 }
 
 /* fit_iht! fit.jl:145-207 */
+/* ------------------------------------------------------------------------ */
+/* debias! (utilities.jl:1014-1020): fit(GeneralizedLinearModel, xk, y, d, l) on the support columns --  */
+/* no intercept, no covariates, ALL n samples with unit weights (cv_wts is not passed) -- and           */
+/* b[idx] = beta0 of that fit.  GLM.jl 1.x is not vendored in the reference; its IRLS is restated from  */
+/* its published algorithm (glmfit.jl _fit!: mustart, first WLS on the working response, then           */
+/* delbeta!/step-halving until devold - dev < max(rtol*devold, atol), rtol = atol = 1e-6, <= 30 steps,   */
+/* minstepfac = 1e-3; Cholesky of X'WX without pivoting).  Parity of this block is unpinned.            */
+/* ------------------------------------------------------------------------ */
+static double glm_mustart(int dist, double y)
+{
+    switch (dist) {
+    case ORC_BERNOULLI: return (y + 0.5) / 2.0;
+    case ORC_POISSON:   return y + 0.1;
+    case ORC_NEGBIN:    return y + (y == 0.0 ? 1.0 / 6.0 : 0.0);
+    case ORC_GAMMA:     return y == 0.0 ? 0.1 : y;
+    default:            return y;
+    }
+}
+static int glm_linkfun(int link, double mu, double *eta)
+{
+    switch (link) {
+    case ORC_IDENTITY:  *eta = mu; return 0;
+    case ORC_LOGIT:     *eta = log(mu / (1.0 - mu)); return 0;
+    case ORC_LOG:       *eta = log(mu); return 0;
+    case ORC_CLOGLOG:   *eta = log(-log1p(-mu)); return 0;
+    case ORC_CAUCHIT:   *eta = tan(3.141592653589793 * (mu - 0.5)); return 0;
+    case ORC_INVERSE:   *eta = 1.0 / mu; return 0;
+    case ORC_INVSQUARE: *eta = 1.0 / (mu * mu); return 0;
+    case ORC_SQRT:      *eta = sqrt(mu); return 0;
+    default: return 1;                       /* ProbitLink: no closed-form quantile here */
+    }
+}
+/* eta -> mu, working residual, working weight; returns the deviance (NaN/domain failures -> +Inf) */
+static double glm_update_mu(const ihtvar *v, const double *eta, double *mu, double *wres, double *wwt)
+{
+    double dev = 0.0;
+    for (int64_t i = 0; i < v->n; ++i) {
+        double m = orc_linkinv(v->link, eta[i]), me = orc_mueta(v->link, eta[i]);
+        mu[i] = m;
+        wres[i] = (v->y[i] - m) / me;
+        wwt[i] = me * me / orc_glmvar(v->dist, m, v->nb_r);
+        dev += orc_devresid(v->dist, v->y[i], m, v->nb_r);
+    }
+    return isnan(dev) ? INFINITY : dev;
+}
+/* delbeta = (X'WX)^-1 X'W r by an unpivoted Cholesky; X is n x k column-major */
+static int glm_delbeta(const double *X, int64_t n, int64_t k, const double *w, const double *r, double *A, double *out)
+{
+    for (int64_t a = 0; a < k; ++a) {
+        for (int64_t b = a; b < k; ++b) {
+            double s = 0.0;
+            for (int64_t i = 0; i < n; ++i) s += X[i + n * a] * w[i] * X[i + n * b];
+            A[a + k * b] = s;
+        }
+        double g = 0.0;
+        for (int64_t i = 0; i < n; ++i) g += X[i + n * a] * w[i] * r[i];
+        out[a] = g;
+    }
+    for (int64_t j = 0; j < k; ++j) {                   /* A = U'U in the upper triangle */
+        double d = A[j + k * j];
+        for (int64_t l = 0; l < j; ++l) d -= A[l + k * j] * A[l + k * j];
+        if (!(d > 0.0)) return 1;
+        d = sqrt(d); A[j + k * j] = d;
+        for (int64_t i = j + 1; i < k; ++i) {
+            double s = A[j + k * i];
+            for (int64_t l = 0; l < j; ++l) s -= A[l + k * j] * A[l + k * i];
+            A[j + k * i] = s / d;
+        }
+    }
+    for (int64_t j = 0; j < k; ++j) {                   /* U' z = g */
+        double s = out[j];
+        for (int64_t l = 0; l < j; ++l) s -= A[l + k * j] * out[l];
+        out[j] = s / A[j + k * j];
+    }
+    for (int64_t j = k - 1; j >= 0; --j) {              /* U x = z */
+        double s = out[j];
+        for (int64_t l = j + 1; l < k; ++l) s -= A[j + k * l] * out[l];
+        out[j] = s / A[j + k * j];
+    }
+    return 0;
+}
+static int debias(ihtvar *v)
+{
+    int64_t n = v->n, p = v->p, k = 0;
+    for (int64_t j = 0; j < p; ++j) k += v->idx[j];
+    if (k == 0) return ORC_OK;
+    double *X = dalloc(n * k), *eta = dalloc(n), *mu = dalloc(n), *wres = dalloc(n), *wwt = dalloc(n), *t = dalloc(n);
+    double *A = dalloc(k * k), *beta0 = dalloc(k), *del = dalloc(k), *lp = dalloc(n);
+    int64_t c = 0;
+    for (int64_t j = 0; j < p; ++j) if (v->idx[j]) { axpy_col(v->x, j, 1.0, X + n * c); ++c; }   /* dalloc zero-fills */
+    int rc = ORC_OK;
+    for (int64_t i = 0; i < n; ++i) {                   /* GlmResp: mu = mustart, eta = linkfun(mu) */
+        double m = glm_mustart(v->dist, v->y[i]);
+        if (glm_linkfun(v->link, m, &eta[i])) { rc = ORC_BAD_ARG; goto done; }
+    }
+    glm_update_mu(v, eta, mu, wres, wwt);
+    for (int64_t i = 0; i < n; ++i) t[i] = eta[i] + wres[i];              /* wrkresp */
+    if (glm_delbeta(X, n, k, wwt, t, A, del)) { rc = ORC_BAD_ARG; goto done; }
+    for (int64_t a = 0; a < k; ++a) beta0[a] = del[a];                    /* installbeta!(p) from beta0 = 0 */
+    for (int64_t i = 0; i < n; ++i) { double s = 0.0; for (int64_t a = 0; a < k; ++a) s += X[i + n * a] * beta0[a]; lp[i] = s; }
+    double devold = glm_update_mu(v, lp, mu, wres, wwt);
+    int cvg = 0;
+    for (int it = 1; it <= 30; ++it) {
+        if (glm_delbeta(X, n, k, wwt, wres, A, del)) { rc = ORC_BAD_ARG; goto done; }
+        double f = 1.0, dev;
+        for (int64_t i = 0; i < n; ++i) { double s = 0.0; for (int64_t a = 0; a < k; ++a) s += X[i + n * a] * (beta0[a] + del[a]); lp[i] = s; }
+        dev = glm_update_mu(v, lp, mu, wres, wwt);
+        while (dev > devold + 1e-6 * dev) {              /* step halving */
+            f /= 2.0;
+            if (!(f > 0.001)) { rc = ORC_BAD_ARG; goto done; }
+            for (int64_t i = 0; i < n; ++i) { double s = 0.0; for (int64_t a = 0; a < k; ++a) s += X[i + n * a] * (beta0[a] + f * del[a]); lp[i] = s; }
+            dev = glm_update_mu(v, lp, mu, wres, wwt);
+        }
+        for (int64_t a = 0; a < k; ++a) beta0[a] += f * del[a];
+        if (devold - dev < fmax(1e-6 * devold, 1e-6)) { cvg = 1; break; }
+        if (!isfinite(dev)) { rc = ORC_BAD_ARG; goto done; }
+        devold = dev;
+    }
+    if (!cvg) { rc = ORC_BAD_ARG; goto done; }
+    c = 0;
+    for (int64_t j = 0; j < p; ++j) if (v->idx[j]) v->b[j] = beta0[c++];
+done:
+    free(X); free(eta); free(mu); free(wres); free(wwt); free(t); free(A); free(beta0); free(del); free(lp);
+    return rc;
+}
+
 static int fit_loop(ihtvar *v, const orc_params *prm, double *best_logl_out, int64_t *iter_out,
                     double *lt, double *tt, int32_t *bt, int32_t *ntrace)
 {
@@ -864,6 +990,10 @@ static int fit_loop(ihtvar *v, const orc_params *prm, double *best_logl_out, int
         int nbt = 0;
         int rc = one_step(v, next_logl, prm->max_step, &nbt, &next_logl);
         if (rc) return rc;
+        if (prm->debias && iter >= 5 && memcmp(v->idx, v->idx0, (size_t)v->p) == 0) {   /* fit.jl:188 */
+            rc = debias(v);
+            if (rc) return rc;
+        }
         double scaled = check_convergence(v);
         if (lt) lt[nt] = next_logl;
         if (tt) tt[nt] = scaled;

@@ -60,6 +60,7 @@ typedef struct orc_params {
     const int64_t *ks;        /* per-group sparsity or NULL (k::Vector{Int}) */
     int64_t  nks;
     int32_t  init_beta;       /* fit.jl:80: start from univariate regression estimates (Normal only) */
+    int32_t  debias;          /* fit.jl:73,188: refit the support by GLM after a step that kept it */
 } orc_params;
 
 typedef struct orc_result {

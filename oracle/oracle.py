@@ -35,7 +35,7 @@ class _Params(C.Structure):
                 ("max_iter", C.c_int32), ("min_iter", C.c_int32), ("max_step", C.c_int32),
                 ("est_r", C.c_int32),
                 ("zkeep", C.c_void_p), ("weight", C.c_void_p), ("group", C.c_void_p),
-                ("ks", C.c_void_p), ("nks", C.c_int64), ("init_beta", C.c_int32)]
+                ("ks", C.c_void_p), ("nks", C.c_int64), ("init_beta", C.c_int32), ("debias", C.c_int32)]
 
 
 class _Result(C.Structure):
@@ -194,7 +194,8 @@ def project_group_sparse(y, group, J, k):
     return y
 
 
-def _params(k, J, dist, link, nb_r, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, keep, init_beta=False):
+def _params(k, J, dist, link, nb_r, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, keep, init_beta=False,
+            debias=False):
     prm = _Params()
     ks = None
     if np.ndim(k) > 0:
@@ -214,6 +215,7 @@ def _params(k, J, dist, link, nb_r, tol, max_iter, min_iter, max_step, est_r, zk
     prm.zkeep, prm.weight, prm.group, prm.ks = _p(zk), _p(w), _p(g), _p(ks)
     prm.nks = 0 if ks is None else ks.size
     prm.init_beta = int(bool(init_beta))
+    prm.debias = int(bool(debias))
     keep.extend([zk, w, g, ks])
     return prm
 
@@ -227,9 +229,10 @@ def _z(z, n):
 
 def fit_iht(x, y, z=None, k=10, J=1, dist="normal", link="identity", nb_r=1.0, tol=1e-4,
             max_iter=200, min_iter=5, max_step=3, est_r=None, zkeep=None, weight=None,
-            group=None, train=None, init_beta=False):
+            group=None, train=None, init_beta=False, debias=False):
     keep = []
-    prm = _params(k, J, dist, link, nb_r, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, keep, init_beta)
+    prm = _params(k, J, dist, link, nb_r, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, keep, init_beta,
+                  debias)
     y = np.ascontiguousarray(y, dtype=np.float64)
     z = _z(z, x.n)
     q = z.shape[1]
@@ -250,9 +253,10 @@ def fit_iht(x, y, z=None, k=10, J=1, dist="normal", link="identity", nb_r=1.0, t
 
 def cv_iht(x, y, z=None, path=range(1, 21), q=5, folds=None, dist="normal", link="identity", nb_r=1.0,
            tol=1e-4, max_iter=100, min_iter=5, max_step=3, est_r=None, zkeep=None, weight=None,
-           group=None, J=1, init_beta=False):
+           group=None, J=1, init_beta=False, debias=False):
     keep = []
-    prm = _params(1, J, dist, link, nb_r, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, keep, init_beta)
+    prm = _params(1, J, dist, link, nb_r, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, keep, init_beta,
+                  debias)
     y = np.ascontiguousarray(y, dtype=np.float64)
     z = _z(z, x.n)
     folds = np.ascontiguousarray(folds, dtype=np.int32)

@@ -695,3 +695,39 @@ def test_more_families_and_links(mih, oracle, normal_pair, case):
     assert res.logl == pytest.approx(o["logl"], rel=1e-8)
     assert list(res.trace["backtracks"]) == list(o["bt_trace"])
     assert type(mih.canonicallink(d)).__name__ in ("InverseLink", "InverseSquareLink", "LogitLink", "LogLink")
+
+
+@pytest.mark.parametrize("family", ["normal", "bernoulli", "poisson"])
+def test_debias(mih, oracle, normal_pair, normal_data, family):
+    """debias=true (fit.jl:188 + debias!, utilities.jl:1014-1020): GLM refit of the support after a step that
+    kept it.  The reference delegates to GLM.jl's IRLS, restated in the oracle (parity unpinned)."""
+    x, ox = normal_pair
+    n = x.n
+    rng = np.random.default_rng(90)
+    eta = 0.6 * _sim(oracle, ox, rng, 7)
+    if family == "normal":
+        y, z, kw, okw, tol = normal_data["y"], normal_data["z"], {}, {}, 1e-5
+    elif family == "bernoulli":
+        y, z = (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float), None
+        kw, okw, tol = dict(d=mih.Bernoulli(), l=mih.LogitLink()), dict(dist="bernoulli", link="logit"), 1e-4
+    else:
+        y, z = rng.poisson(np.exp(0.5 * eta)).astype(float), None
+        kw, okw, tol = dict(d=mih.Poisson(), l=mih.LogLink()), dict(dist="poisson", link="log"), 1e-4
+    res = mih.fit_iht(y, x, z, k=7, debias=True, verbose=False, **kw)
+    o = oracle.fit_iht(ox, y, z, k=7, debias=True, **okw)
+    plain = oracle.fit_iht(ox, y, z, k=7, **okw)
+    assert res.iter == o["iter"] and list(res.trace["backtracks"]) == list(o["bt_trace"])
+    assert np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"]))
+    nz = np.flatnonzero(o["beta"])
+    np.testing.assert_allclose(res.beta[nz], o["beta"][nz], rtol=tol)
+    np.testing.assert_allclose(res.c, o["c"], rtol=tol)
+    np.testing.assert_allclose(res.trace["logl"], o["logl_trace"], rtol=1e-8)
+    np.testing.assert_allclose(res.trace["tol"], o["tol_trace"], rtol=1e-4, atol=1e-10)
+    assert not np.array_equal(o["tol_trace"], plain["tol_trace"])          # debiasing really happened
+    if family == "normal":                                                 # a refit support is the least-squares solution
+        folds = hash_folds(n, 3)
+        mse = mih.cv_iht(y, x, z, path=[3, 7], q=3, folds=folds, debias=True, verbose=False)
+        omse, _ = oracle.cv_iht(ox, y, z, path=[3, 7], q=3, folds=folds, debias=True)
+        np.testing.assert_allclose(mse, omse, rtol=1e-5)
+    with pytest.raises(mih.MendelIHTError):
+        mih.fit_iht(np.vstack([y, y]), x, None, k=4, debias=True, verbose=False)   # multivariate: disabled in the reference
