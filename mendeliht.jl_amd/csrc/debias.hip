@@ -2,7 +2,7 @@
 // support columns by a GLM and overwrite b[idx] with its coefficients:
 //     temp_glm = fit(GeneralizedLinearModel, v.xk, v.y, v.d, v.l);  view(v.b, v.idx) .= temp_glm.pp.beta0
 // The model has no intercept and no covariates, uses ALL n samples with unit weights (cv_wts is not
-// passed), and is fitted by GLM.jl's IRLS (glmfit.jl `_fit!`, restated in oracle/iht_oracle.c `debias`):
+// passed), and is fitted by GLM.jl's IRLS (glmfit.jl `_fit!`; GLM.jl is a dependency, not vendored in the reference):
 // mustart -> first weighted least squares on the working response -> delbeta!/step halving until
 // devold - dev < max(rtol*devold, atol) (rtol = atol = 1e-6, <= 30 steps, minstepfac 1e-3).
 //
