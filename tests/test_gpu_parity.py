@@ -731,3 +731,30 @@ def test_debias(mih, oracle, normal_pair, normal_data, family):
         np.testing.assert_allclose(mse, omse, rtol=1e-5)
     with pytest.raises(mih.MendelIHTError):
         mih.fit_iht(np.vstack([y, y]), x, None, k=4, debias=True, verbose=False)   # multivariate: disabled in the reference
+
+
+def test_snplinalg_fit_equals_dense_copy(mih, oracle):
+    """test/L0_reg_test.jl:340-348, 361-363: the memory-efficient SnpLinAlg path and a dense Float64 copy of
+    the same standardized matrix give the same model (here both on the GPU: 2-bit MFMA path vs f64 path)."""
+    rng = np.random.default_rng(17)
+    n, p, k = 1203, 517, 6
+    cols = make_bed(rng, n, p, missing_rate=0.01)
+    xs = mih.SnpLinAlg(cols, n=n, center=True, scale=True, impute=True)
+    mu, sinv = xs.mu_sigma()
+    padded = np.unpackbits(cols, axis=1, bitorder="little").reshape(p, -1, 2)[:, :n, :]
+    code = padded[:, :, 0] + 2 * padded[:, :, 1]                          # PLINK 2-bit codes, LSB first
+    g = np.select([code == 0, code == 2, code == 3], [0.0, 1.0, 2.0], default=np.nan)
+    g = np.where(np.isnan(g), mu[:, None], g)                              # impute -> mean
+    D = np.asfortranarray(((g - mu[:, None]) * sinv[:, None]).T)           # n x p standardized dense copy
+    xd = mih.DenseMatrix(D)
+    r = rng.standard_normal(n)
+    assert rel(xs.xtv(r), xd.xtv(r)) < 1e-11
+    supp = rng.choice(p, k, replace=False)
+    eta = D[:, supp] @ rng.standard_normal(k)
+    for y, kw, tol in ((eta + 1 + rng.standard_normal(n), {}, 1e-8),
+                       ((rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float), dict(d=mih.Bernoulli(), l=mih.LogitLink()), 1e-6)):
+        a = mih.fit_iht(y, xs, None, k=k, verbose=False, **kw)
+        b = mih.fit_iht(y, xd, None, k=k, verbose=False, **kw)
+        assert a.iter == b.iter and np.array_equal(np.flatnonzero(a.beta), np.flatnonzero(b.beta))
+        np.testing.assert_allclose(a.beta, b.beta, rtol=tol, atol=1e-12)
+        assert a.logl == pytest.approx(b.logl, rel=1e-10)
