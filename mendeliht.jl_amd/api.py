@@ -795,6 +795,19 @@ def cv_iht(y, x, z=None, *, d=None, l=None, path=range(1, 21), q=5, est_r="None"
     return (mse, raw) if return_raw else mse
 
 
+def maf_weights(x, max_weight=np.inf):
+    """maf_weights(x::SnpArray; max_weight) -- src/utilities.jl:682-697: prior weights 1 / (2 sqrt(p (1 - p)))
+    from the minor allele frequencies (SnpArrays.maf: over the non-missing genotypes), clamped to [1, max_weight]."""
+    if not isinstance(x, SnpLinAlg):
+        raise ArgumentError("maf_weights needs a SnpLinAlg (2-bit genotypes)")
+    mu, _ = x.mu_sigma()
+    f = mu / 2.0
+    maf = np.minimum(f, 1.0 - f)
+    with np.errstate(divide="ignore"):
+        w = 1.0 / (2.0 * np.sqrt(maf * (1.0 - maf)))
+    return np.clip(w, 1.0, max_weight)
+
+
 def iht_run_many_models(y, x, z=None, *, d=None, l=None, path=range(1, 21), est_r="None", group=None, weight=None,
                         use_maf=False, debias=False, verbose=True, parallel=False, max_iter=100, rank=0, world=1,
                         reduce=None):

@@ -758,3 +758,22 @@ def test_snplinalg_fit_equals_dense_copy(mih, oracle):
         assert a.iter == b.iter and np.array_equal(np.flatnonzero(a.beta), np.flatnonzero(b.beta))
         np.testing.assert_allclose(a.beta, b.beta, rtol=tol, atol=1e-12)
         assert a.logl == pytest.approx(b.logl, rel=1e-10)
+
+
+def test_maf_weights(mih, normal_pair):
+    """test/utilities_test.jl:215-232."""
+    x, ox = normal_pair
+    bed = mih.read_bed(os.path.join(FIX, "normal.bed"), x.n)
+    code = np.unpackbits(bed[:2], axis=1, bitorder="little").reshape(2, -1, 2)[:, :x.n, :]
+    code = code[:, :, 0] + 2 * code[:, :, 1]
+    w = mih.maf_weights(x)
+    assert np.all(w >= 1.0)
+    for j in range(2):
+        ok = code[j] != 1
+        f = np.select([code[j] == 2, code[j] == 3], [1.0, 2.0], 0.0)[ok].sum() / (2 * ok.sum())
+        m = min(f, 1 - f)
+        assert w[j] == pytest.approx(1 / (2 * np.sqrt(m * (1 - m))), rel=1e-12)
+    w2 = mih.maf_weights(x, max_weight=2.0)
+    assert np.all((w2 >= 1.0) & (w2 <= 2.0))
+    res = mih.fit_iht(np.loadtxt(os.path.join(FIX, "normal_y_fam6.txt")), x, None, k=5, weight=w2, verbose=False)
+    assert np.count_nonzero(res.beta) == 5
