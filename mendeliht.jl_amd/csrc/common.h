@@ -124,10 +124,9 @@ int  xv_sparse_device(const mih_mat *h, XvWork &w, const int64_t *idx_dev, const
 struct TopkWork {
     DevBuf<uint32_t> hist;     // 256 bins
     DevBuf<uint64_t> state;    // [0]=prefix, [1]=remaining k, [2]=threshold bits, [3]=count_ge
-    DevBuf<int64_t>  sel_idx;  // compacted survivors
-    DevBuf<double>   sel_val;
-    DevBuf<uint32_t> sel_cnt;
-    int64_t cap = 0;
+    DevBuf<uint64_t> sel;      // compacted survivors as (index, value bits) pairs; pair 0 holds the count
+    int64_t cap = 0;           // pairs the buffer can hold after the header
+    int64_t expect = 0;        // survivors expected by the caller (k + slack): fetched with the count in ONE copy
 };
 int  topk_work_init(TopkWork &w, int64_t max_keep);
 // In-place project_k! on a device vector; returns threshold and survivors (sorted by index) on host.

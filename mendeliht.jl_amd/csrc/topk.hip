@@ -7,6 +7,7 @@
 // then one threshold pass that also compacts the survivors.
 #include "common.h"
 #include <algorithm>
+#include <cstring>
 
 namespace mih {
 
@@ -15,45 +16,75 @@ __device__ __forceinline__ uint64_t abs_key(double v)
     return (uint64_t)__double_as_longlong(v) & 0x7FFFFFFFFFFFFFFFull;
 }
 
-// state[0] = prefix (bits above `shift+8` already fixed), state[1] = remaining rank
+// state[0] = prefix (bits above `shift+8` already fixed), state[1] = remaining rank.
+// |x| values of a gradient cluster in a few exponent bins, so plain LDS atomics serialise: every wave
+// has a private histogram and adds one count per distinct bin among its 64 lanes (ballot aggregation).
 __global__ void __launch_bounds__(256)
 k_hist(const double *__restrict__ x, int64_t len, int shift, const uint64_t *__restrict__ state,
        uint32_t *__restrict__ hist)
 {
-    __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
+    __shared__ uint32_t h[4][256];
+    for (int e = threadIdx.x; e < 4 * 256; e += 256) (&h[0][0])[e] = 0;
     __syncthreads();
     const uint64_t prefix = state[0];
     const bool first = (shift == 56);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t rounds = (len + stride - 1) / stride;             // every lane runs every round (ballots)
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < len; i += stride) {
-        uint64_t key = abs_key(x[i]);
-        if (first || (key >> (shift + 8)) == prefix) atomicAdd(&h[(key >> shift) & 255u], 1u);
+    for (int64_t r = 0; r < rounds; ++r, i += stride) {
+        bool live = false; uint32_t bin = 0;
+        if (i < len) {
+            uint64_t key = abs_key(x[i]);
+            live = first || (key >> (shift + 8)) == prefix;
+            bin = (uint32_t)(key >> shift) & 255u;
+        }
+        uint64_t todo = __ballot(live);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t lb = __shfl(bin, leader, 64);
+            const uint64_t same = __ballot(live && bin == lb) & todo;
+            if (lane == leader) h[wave][lb] += (uint32_t)__popcll(same);   // one lane per wave-private bin: no atomic needed
+            todo &= ~same;
+        }
     }
     __syncthreads();
-    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+    const uint32_t tot = h[0][threadIdx.x] + h[1][threadIdx.x] + h[2][threadIdx.x] + h[3][threadIdx.x];
+    if (tot) atomicAdd(&hist[threadIdx.x], tot);
 }
 
-__global__ void k_pick(uint32_t *__restrict__ hist, uint64_t *__restrict__ state, int shift)
-{
-    if (threadIdx.x != 0) return;
-    uint64_t kth = state[1], cum = 0;
-    int bin = 255;
-    for (; bin > 0; --bin) {
-        if (cum + hist[bin] >= kth) break;
-        cum += hist[bin];
-    }
-    state[0] = (shift == 56 ? 0ull : (state[0] << 8)) | (uint64_t)bin;
-    state[1] = kth - cum;
-    for (int b = 0; b < 256; ++b) hist[b] = 0;
-    if (shift == 0) state[2] = state[0];   // full 64-bit threshold key
-}
-
+// pick the bin holding the kth largest: 256 threads, suffix sums in LDS
 __global__ void __launch_bounds__(256)
-k_threshold(double *__restrict__ x, int64_t len, const uint64_t *__restrict__ state,
-            int64_t *__restrict__ sel_idx, double *__restrict__ sel_val, uint32_t *__restrict__ sel_cnt,
-            uint32_t cap)
+k_pick(uint32_t *__restrict__ hist, uint64_t *__restrict__ state, int shift)
+{
+    __shared__ uint64_t suf[257];      // suf[b] = sum of hist[b..255]
+    __shared__ int chosen;
+    const int b = threadIdx.x;
+    suf[b] = hist[b];
+    if (b == 0) { suf[256] = 0; chosen = 0; }
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        uint64_t add = (b + off < 256) ? suf[b + off] : 0;
+        __syncthreads();
+        suf[b] += add;
+        __syncthreads();
+    }
+    const uint64_t kth = state[1];
+    // the bin is the largest b with suf[b] >= kth (bin 0 if none, as the sequential scan did)
+    if (b > 0 && suf[b] >= kth && suf[b + 1] < kth) chosen = b;
+    __syncthreads();
+    hist[b] = 0;
+    if (b == 0) {
+        const int bin = chosen;
+        state[0] = (shift == 56 ? 0ull : (state[0] << 8)) | (uint64_t)bin;
+        state[1] = kth - suf[bin + 1];
+        if (shift == 0) state[2] = state[0];   // full 64-bit threshold key
+    }
+}
+
+// sel[0] = count; survivor t is the pair sel[2 + 2t] = index, sel[3 + 2t] = value bits
+__global__ void __launch_bounds__(256)
+k_threshold(double *__restrict__ x, int64_t len, const uint64_t *__restrict__ state, uint64_t *__restrict__ sel, uint32_t cap)
 {
     const uint64_t thr = state[2];
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -62,8 +93,8 @@ k_threshold(double *__restrict__ x, int64_t len, const uint64_t *__restrict__ st
         double v = x[i];
         if (abs_key(v) < thr) { if (v != 0.0) x[i] = 0.0; }
         else if (v != 0.0) {
-            uint32_t pos = atomicAdd(sel_cnt, 1u);
-            if (pos < cap) { sel_idx[pos] = i; sel_val[pos] = v; }
+            unsigned long long pos = atomicAdd((unsigned long long *)sel, 1ull);
+            if (pos < cap) { sel[2 + 2 * pos] = (uint64_t)i; sel[3 + 2 * pos] = (uint64_t)__double_as_longlong(v); }
         }
     }
 }
@@ -72,15 +103,50 @@ int topk_work_init(TopkWork &w, int64_t max_keep)
 {
     MIH_TRY(w.hist.alloc(256));
     MIH_TRY(w.state.alloc(4));
-    MIH_TRY(w.sel_cnt.alloc(1));
+    w.expect = max_keep + 64;
     w.cap = max_keep + 1024;
-    MIH_TRY(w.sel_idx.alloc((size_t)w.cap));
-    MIH_TRY(w.sel_val.alloc((size_t)w.cap));
+    MIH_TRY(w.sel.alloc(2 + 2 * (size_t)w.cap));
     return MIH_OK;
 }
 
+// threshold pass with the key already in state[2]: zero what is below, gather what survives.  The count
+// and the first `expect` pairs come back in ONE device-to-host copy (one host synchronisation).
 static int compact_device(double *x_dev, int64_t len, TopkWork &w, hipStream_t s,
-                          std::vector<int64_t> &idx_out, std::vector<double> &val_out);
+                          std::vector<int64_t> &idx_out, std::vector<double> &val_out)
+{
+    int grid = (int)std::min<int64_t>((len + 255) / 256, 2048);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        MIH_HIP(hipMemsetAsync(w.sel.p, 0, 2 * sizeof(uint64_t), s));
+        hipLaunchKernelGGL(k_threshold, dim3(grid), dim3(256), 0, s, x_dev, len, w.state.p, w.sel.p, (uint32_t)w.cap);
+        const int64_t first = std::min<int64_t>(w.expect, w.cap);
+        std::vector<uint64_t> host(2 + 2 * (size_t)first);
+        MIH_HIP(hipMemcpyAsync(host.data(), w.sel.p, sizeof(uint64_t) * host.size(), hipMemcpyDeviceToHost, s));
+        MIH_HIP(hipStreamSynchronize(s));
+        const int64_t cnt = (int64_t)host[0];
+        if (cnt > w.cap) {                     // many exact ties: grow and compact again
+            w.cap = cnt + 1024;
+            MIH_TRY(w.sel.alloc(2 + 2 * (size_t)w.cap));
+            continue;
+        }
+        if (cnt > first) {                     // more survivors than expected (ties): fetch the rest
+            host.resize(2 + 2 * (size_t)cnt);
+            MIH_HIP(hipMemcpy(host.data() + 2 + 2 * first, w.sel.p + 2 + 2 * first, sizeof(uint64_t) * 2 * (size_t)(cnt - first), hipMemcpyDeviceToHost));
+        }
+        std::vector<uint32_t> ord((size_t)cnt);
+        for (uint32_t i = 0; i < (uint32_t)cnt; ++i) ord[i] = i;
+        std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return host[2 + 2 * (size_t)a] < host[2 + 2 * (size_t)b]; });
+        idx_out.resize((size_t)cnt); val_out.resize((size_t)cnt);
+        for (uint32_t i = 0; i < (uint32_t)cnt; ++i) {
+            idx_out[i] = (int64_t)host[2 + 2 * (size_t)ord[i]];
+            uint64_t bits = host[3 + 2 * (size_t)ord[i]];
+            double v; std::memcpy(&v, &bits, sizeof(v));
+            val_out[i] = v;
+        }
+        return MIH_OK;
+    }
+    set_error("top-k compaction failed");
+    return MIH_HIP_ERROR;
+}
 
 int topk_project_device(double *x_dev, int64_t len, int64_t k, TopkWork &w, hipStream_t s,
                         std::vector<int64_t> &idx_out, std::vector<double> &val_out)
@@ -93,43 +159,9 @@ int topk_project_device(double *x_dev, int64_t len, int64_t k, TopkWork &w, hipS
     int grid = (int)std::min<int64_t>((len + 255) / 256, 2048);
     for (int shift = 56; shift >= 0; shift -= 8) {
         hipLaunchKernelGGL(k_hist, dim3(grid), dim3(256), 0, s, x_dev, len, shift, w.state.p, w.hist.p);
-        hipLaunchKernelGGL(k_pick, dim3(1), dim3(64), 0, s, w.hist.p, w.state.p, shift);
+        hipLaunchKernelGGL(k_pick, dim3(1), dim3(256), 0, s, w.hist.p, w.state.p, shift);
     }
     return compact_device(x_dev, len, w, s, idx_out, val_out);
-}
-
-// threshold pass with the key already in state[2]: zero what is below, gather what survives
-static int compact_device(double *x_dev, int64_t len, TopkWork &w, hipStream_t s,
-                          std::vector<int64_t> &idx_out, std::vector<double> &val_out)
-{
-    int grid = (int)std::min<int64_t>((len + 255) / 256, 2048);
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        MIH_HIP(hipMemsetAsync(w.sel_cnt.p, 0, sizeof(uint32_t), s));
-        hipLaunchKernelGGL(k_threshold, dim3(grid), dim3(256), 0, s, x_dev, len, w.state.p, w.sel_idx.p, w.sel_val.p,
-                           w.sel_cnt.p, (uint32_t)w.cap);
-        uint32_t cnt = 0;
-        MIH_HIP(hipMemcpyAsync(&cnt, w.sel_cnt.p, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        MIH_HIP(hipStreamSynchronize(s));
-        if ((int64_t)cnt > w.cap) {            // many exact ties: grow and compact again
-            w.cap = (int64_t)cnt + 1024;
-            MIH_TRY(w.sel_idx.alloc((size_t)w.cap));
-            MIH_TRY(w.sel_val.alloc((size_t)w.cap));
-            continue;
-        }
-        std::vector<int64_t> ti(cnt); std::vector<double> tv(cnt);
-        if (cnt) {
-            MIH_HIP(hipMemcpy(ti.data(), w.sel_idx.p, sizeof(int64_t) * cnt, hipMemcpyDeviceToHost));
-            MIH_HIP(hipMemcpy(tv.data(), w.sel_val.p, sizeof(double) * cnt, hipMemcpyDeviceToHost));
-        }
-        std::vector<uint32_t> ord(cnt);
-        for (uint32_t i = 0; i < cnt; ++i) ord[i] = i;
-        std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return ti[a] < ti[b]; });
-        idx_out.resize(cnt); val_out.resize(cnt);
-        for (uint32_t i = 0; i < cnt; ++i) { idx_out[i] = ti[ord[i]]; val_out[i] = tv[ord[i]]; }
-        return MIH_OK;
-    }
-    set_error("top-k compaction failed");
-    return MIH_HIP_ERROR;
 }
 
 int collect_nonzero_device(double *x_dev, int64_t len, TopkWork &w, hipStream_t s,

@@ -23,31 +23,45 @@ __global__ void k_xv_coef(const int64_t *__restrict__ idx, const double *__restr
     B[t] = center ? -mu[j] * a : 0.0;
 }
 
-// grid (row blocks, column groups): thread = one dword = 16 rows; partial[g][i].
+// One workgroup = 16 dwords (256 rows) x 16 column groups: thread (g, d) accumulates the columns of group
+// g for the 16 rows of dword d in registers, the 16 group partials meet in LDS and are added in group
+// order (fixed order => bit-reproducible), so no n x groups partial array goes through HBM.
+constexpr int kXvGroups = 16;
 __global__ void __launch_bounds__(256)
-k_xv_snp(const uint32_t *__restrict__ X, int64_t nbp, int64_t ndw,
+k_xv_snp(const uint32_t *__restrict__ X, int64_t nbp, int64_t ndw, int64_t n,
          const int64_t *__restrict__ idx, const double *__restrict__ A, const double *__restrict__ B,
-         int64_t nnz, int groups, int64_t n_pad, double *__restrict__ partial)
+         int64_t nnz, int groups, int clamp20, double *__restrict__ out)
 {
-    int64_t dw = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    int g = blockIdx.y;
-    if (dw >= ndw) return;
-    int64_t per = (nnz + groups - 1) / groups;
-    int64_t t0 = g * per, t1 = t0 + per < nnz ? t0 + per : nnz;
+    __shared__ double part[kXvGroups][16][17];
+    const int g = threadIdx.x >> 4, d = threadIdx.x & 15;
+    const int64_t dw = blockIdx.x * 16ll + d;
+    const int64_t per = (nnz + groups - 1) / groups;
+    const int64_t t0 = g * per, t1 = (g < groups) ? (t0 + per < nnz ? t0 + per : nnz) : t0;
     double acc[16];
     #pragma unroll
     for (int s = 0; s < 16; ++s) acc[s] = 0.0;
     double bsum = 0.0;
-    for (int64_t t = t0; t < t1; ++t) {
-        uint32_t w = X[xword(nbp, idx[t], dw)];
-        double a = A[t];
-        bsum += B[t];
-        #pragma unroll
-        for (int s = 0; s < 16; ++s) acc[s] = fma((double)((w >> (2 * s)) & 3u), a, acc[s]);
+    if (dw < ndw) {
+        for (int64_t t = t0; t < t1; ++t) {
+            uint32_t w = X[xword(nbp, idx[t], dw)];
+            double a = A[t];
+            bsum += B[t];
+            #pragma unroll
+            for (int s = 0; s < 16; ++s) acc[s] = fma((double)((w >> (2 * s)) & 3u), a, acc[s]);
+        }
     }
-    double *dst = partial + (int64_t)g * n_pad + dw * 16;
     #pragma unroll
-    for (int s = 0; s < 16; ++s) dst[s] = acc[s] + bsum;
+    for (int s = 0; s < 16; ++s) part[g][d][s] = acc[s] + bsum;
+    __syncthreads();
+    // thread -> (dword dd, row s): sum the groups in order
+    const int dd = threadIdx.x >> 4, s = threadIdx.x & 15;
+    const int64_t i = (blockIdx.x * 16ll + dd) * 16 + s;
+    if (i < n) {
+        double a = 0.0;
+        for (int gg = 0; gg < groups; ++gg) a += part[gg][dd][s];
+        if (clamp20) a = a < -20.0 ? -20.0 : (a > 20.0 ? 20.0 : a);
+        out[i] = a;
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -103,9 +117,9 @@ __global__ void k_clamp20(double *__restrict__ x, int64_t n)
 
 int xv_work_init(const mih_mat *h, XvWork &w, int64_t max_nnz)
 {
-    w.groups = 16;
+    w.groups = kXvGroups;
     int64_t np = (h->kind == 0) ? h->n_pad : h->n;
-    MIH_TRY(w.partial.alloc((size_t)w.groups * (size_t)np));
+    if (h->kind != 0) MIH_TRY(w.partial.alloc((size_t)w.groups * (size_t)np));      // the dense path still reduces through HBM
     if (max_nnz < 64) max_nnz = 64;
     MIH_TRY(w.coefA.alloc((size_t)max_nnz));
     MIH_TRY(w.coefB.alloc((size_t)max_nnz));
@@ -132,11 +146,9 @@ int xv_sparse_device(const mih_mat *h, XvWork &w, const int64_t *idx_dev, const 
         hipLaunchKernelGGL(k_xv_coef, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, s, idx_dev, val_dev, nnz,
                            h->mu, h->sinv, h->center, h->scale, w.coefA.p, w.coefB.p);
         int64_t ndw = h->n_pad / 16;
-        hipLaunchKernelGGL(k_xv_snp, dim3((unsigned)((ndw + 255) / 256), groups), dim3(256), 0, s, h->X, h->nbp, ndw,
-                           idx_dev, w.coefA.p, w.coefB.p, nnz, groups, np, w.partial.p);
         bool fix = h->impute && h->total_missing > 0;
-        hipLaunchKernelGGL(k_xv_reduce, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, s, w.partial.p, groups, np, h->n,
-                           fix ? 0 : clamp20, out_dev);
+        hipLaunchKernelGGL(k_xv_snp, dim3((unsigned)((ndw + 15) / 16)), dim3(256), 0, s, h->X, h->nbp, ndw, h->n,
+                           idx_dev, w.coefA.p, w.coefB.p, nnz, groups, fix ? 0 : clamp20, out_dev);
         if (fix) {
             hipLaunchKernelGGL(k_xv_missing, dim3(1), dim3(1024), 0, s, idx_dev, w.coefA.p, nnz, h->mu, h->miss_ptr, h->miss_row, out_dev);
             if (clamp20) hipLaunchKernelGGL(k_clamp20, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, s, out_dev, h->n);
