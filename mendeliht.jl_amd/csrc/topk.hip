@@ -16,6 +16,37 @@ __device__ __forceinline__ uint64_t abs_key(double v)
     return (uint64_t)__double_as_longlong(v) & 0x7FFFFFFFFFFFFFFFull;
 }
 
+// pick the bin holding the kth largest: 256 threads, suffix sums in LDS.  (Folding this into the last
+// workgroup of k_hist with a ticket counter was measured SLOWER: the agent-scope fence it needs writes
+// back the XCD's L2 and cost ~30 us per pass, against ~5 us for this separate launch.)
+__global__ void __launch_bounds__(256)
+k_pick(uint32_t *__restrict__ hist, uint64_t *__restrict__ state, int shift)
+{
+    __shared__ uint64_t suf[257];      // suf[b] = sum of hist[b..255]
+    __shared__ int chosen;
+    const int b = threadIdx.x;
+    suf[b] = hist[b];
+    if (b == 0) { suf[256] = 0; chosen = 0; }
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        uint64_t add = (b + off < 256) ? suf[b + off] : 0;
+        __syncthreads();
+        suf[b] += add;
+        __syncthreads();
+    }
+    const uint64_t kth = state[1];
+    // the bin is the largest b with suf[b] >= kth (bin 0 if none)
+    if (b > 0 && suf[b] >= kth && suf[b + 1] < kth) chosen = b;
+    __syncthreads();
+    hist[b] = 0;
+    if (b == 0) {
+        const int bin = chosen;
+        state[0] = (shift == 56 ? 0ull : (state[0] << 8)) | (uint64_t)bin;
+        state[1] = kth - suf[bin + 1];
+        if (shift == 0) state[2] = state[0];   // full 64-bit threshold key
+    }
+}
+
 // state[0] = prefix (bits above `shift+8` already fixed), state[1] = remaining rank.
 // |x| values of a gradient cluster in a few exponent bins, so plain LDS atomics serialise: every wave
 // has a private histogram and adds one count per distinct bin among its 64 lanes (ballot aggregation).
@@ -39,7 +70,11 @@ k_hist(const double *__restrict__ x, int64_t len, int shift, const uint64_t *__r
             live = first || (key >> (shift + 8)) == prefix;
             bin = (uint32_t)(key >> shift) & 255u;
         }
-        uint64_t todo = __ballot(live);
+        if (!first) {                       // lower bytes are spread over many bins: plain LDS atomics are cheapest
+            if (live) atomicAdd(&h[wave][bin], 1u);
+            continue;
+        }
+        uint64_t todo = __ballot(live);     // exponent byte: a handful of bins per wave -> one add per distinct bin
         while (todo) {
             const int leader = __ffsll((long long)todo) - 1;
             const uint32_t lb = __shfl(bin, leader, 64);
@@ -51,35 +86,6 @@ k_hist(const double *__restrict__ x, int64_t len, int shift, const uint64_t *__r
     __syncthreads();
     const uint32_t tot = h[0][threadIdx.x] + h[1][threadIdx.x] + h[2][threadIdx.x] + h[3][threadIdx.x];
     if (tot) atomicAdd(&hist[threadIdx.x], tot);
-}
-
-// pick the bin holding the kth largest: 256 threads, suffix sums in LDS
-__global__ void __launch_bounds__(256)
-k_pick(uint32_t *__restrict__ hist, uint64_t *__restrict__ state, int shift)
-{
-    __shared__ uint64_t suf[257];      // suf[b] = sum of hist[b..255]
-    __shared__ int chosen;
-    const int b = threadIdx.x;
-    suf[b] = hist[b];
-    if (b == 0) { suf[256] = 0; chosen = 0; }
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        uint64_t add = (b + off < 256) ? suf[b + off] : 0;
-        __syncthreads();
-        suf[b] += add;
-        __syncthreads();
-    }
-    const uint64_t kth = state[1];
-    // the bin is the largest b with suf[b] >= kth (bin 0 if none, as the sequential scan did)
-    if (b > 0 && suf[b] >= kth && suf[b + 1] < kth) chosen = b;
-    __syncthreads();
-    hist[b] = 0;
-    if (b == 0) {
-        const int bin = chosen;
-        state[0] = (shift == 56 ? 0ull : (state[0] << 8)) | (uint64_t)bin;
-        state[1] = kth - suf[bin + 1];
-        if (shift == 0) state[2] = state[0];   // full 64-bit threshold key
-    }
 }
 
 // sel[0] = count; survivor t is the pair sel[2 + 2t] = index, sel[3 + 2t] = value bits
@@ -156,7 +162,7 @@ int topk_project_device(double *x_dev, int64_t len, int64_t k, TopkWork &w, hipS
     uint64_t st[4] = {0ull, (uint64_t)k, 0ull, 0ull};
     MIH_HIP(hipMemcpyAsync(w.state.p, st, sizeof(st), hipMemcpyHostToDevice, s));
     MIH_HIP(hipMemsetAsync(w.hist.p, 0, 256 * sizeof(uint32_t), s));
-    int grid = (int)std::min<int64_t>((len + 255) / 256, 2048);
+    int grid = (int)std::min<int64_t>((len + 255) / 256, 512);     // <= 512 blocks: 256 global adds per block at the end
     for (int shift = 56; shift >= 0; shift -= 8) {
         hipLaunchKernelGGL(k_hist, dim3(grid), dim3(256), 0, s, x_dev, len, shift, w.state.p, w.hist.p);
         hipLaunchKernelGGL(k_pick, dim3(1), dim3(256), 0, s, w.hist.p, w.state.p, shift);
