@@ -53,6 +53,9 @@ int mih_device_count(int *count);
 /* thread-local message of the last failing call on this host thread */
 int mih_last_error(char *buf, size_t len);
 int mih_version(int *major, int *minor);
+/* sizeof(mih_fit_params), sizeof(mih_fit_result), sizeof(mih_mv_result), sizeof(mih_comm): lets a binding
+ * check its struct mirrors against the library it loaded. */
+int mih_abi_sizes(int64_t *sizes, int32_t n);
 
 /* ---- design matrix: replaces SnpArrays.SnpLinAlg{T}(::SnpArray; model=ADDITIVE_MODEL,
  *      center, scale, impute) as constructed at src/wrapper.jl:68-69 and test/L0_reg_test.jl:11.

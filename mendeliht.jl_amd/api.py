@@ -117,6 +117,7 @@ def lib():
         "mih_set_xtv_variant": [C.c_int],
         "mih_set_xtv_multi_variant": [C.c_int],
         "mih_set_xtv_digits": [C.c_int],
+        "mih_abi_sizes": [vp, i32],
         "mih_session_create": [vp, C.POINTER(_FitParams), vp, vp, i64, vp, C.POINTER(vp)],
         "mih_session_step": [vp, C.POINTER(dbl), C.POINTER(i32), C.POINTER(dbl)],
         "mih_session_model": [vp, vp, vp],
@@ -140,7 +141,7 @@ def exported_symbols():
             "mih_snp_mu_sigma", "mih_snp_export_bed", "mih_xtv", "mih_xtv_batched", "mih_xv_sparse",
             "mih_project_topk", "mih_project_group_sparse", "mih_fit_iht", "mih_cv_iht", "mih_cv_meanloss",
             "mih_fit_mv", "mih_cv_mv", "mih_bench_xtv", "mih_bench_xtv_batched", "mih_xtv_algorithmic_bytes", "mih_set_xtv_variant",
-            "mih_set_xtv_multi_variant", "mih_set_xtv_digits",
+            "mih_set_xtv_multi_variant", "mih_set_xtv_digits", "mih_abi_sizes",
             "mih_session_create", "mih_session_step", "mih_session_model", "mih_session_destroy",
             "mih_profile_enable", "mih_profile_read"]
 

@@ -314,6 +314,15 @@ int mih_version(int *major, int *minor)
     return MIH_OK;
 }
 
+int mih_abi_sizes(int64_t *sizes, int32_t n)
+{
+    const int64_t v[4] = {(int64_t)sizeof(mih_fit_params), (int64_t)sizeof(mih_fit_result), (int64_t)sizeof(mih_mv_result),
+                          (int64_t)sizeof(mih_comm)};
+    if (!sizes) return MIH_BAD_ARG;
+    for (int i = 0; i < n && i < 4; ++i) sizes[i] = v[i];
+    return MIH_OK;
+}
+
 static int select_device(int device)
 {
     int c = 0;

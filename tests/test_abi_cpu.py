@@ -20,6 +20,16 @@ def test_library_exports_every_declared_symbol(mih):
         assert getattr(L, s) is not None
 
 
+def test_struct_mirrors_match_the_library(mih):
+    """ctypes mirrors of the C structs have the library's sizes (catches a field added on one side only)."""
+    import ctypes as C
+
+    from mendeliht_amd import api
+    sizes = (C.c_int64 * 4)()
+    assert mih.lib().mih_abi_sizes(sizes, 4) == 0
+    assert list(sizes) == [C.sizeof(api._FitParams), C.sizeof(api._FitResult), C.sizeof(api._MvResult), C.sizeof(api._Comm)]
+
+
 def test_no_device_fails_loudly(mih):
     if mih.device_count() > 0:
         pytest.skip("a GPU is present")
