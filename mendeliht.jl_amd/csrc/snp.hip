@@ -5,6 +5,9 @@
 #include "common.h"
 #include <cstdarg>
 #include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
 
 namespace mih {
 
@@ -89,9 +92,9 @@ k_transcode(const uint8_t *__restrict__ raw, int64_t raw_stride, int64_t n, int6
                 uint32_t valid = rows_left >= 16 ? 0xFFFFFFFFu : rows_left <= 0 ? 0u : ((1u << (2 * rows_left)) - 1u);
                 wv &= valid;
             }
-            uint32_t dd = plink_to_dosage(wv);
-            d[q] = dd;
-            c1 += __popc(dd & 0x55555555u); c2 += __popc(dd & 0xAAAAAAAAu); cm += __popc(plink_missing_mask(wv));
+            const uint32_t dd = plink_to_dosage(wv), mm = plink_missing_mask(wv);
+            d[q] = dd | mm | (mm << 1);        // missing -> the unused dosage code 3 until k_missing_from_tiles has listed it
+            c1 += __popc(dd & 0x55555555u); c2 += __popc(dd & 0xAAAAAAAAu); cm += __popc(mm);
         }
         X[(cg * nbp + bp) * 64 + lane] = make_uint4(d[0], d[1], d[2], d[3]);
     }
@@ -111,26 +114,46 @@ __global__ void k_col_stats(const int32_t *__restrict__ cnt, int64_t n, int64_t 
     sinv[j] = (s > 0.0) ? 1.0 / s : 1.0;
 }
 
-// One wave per column: append the rows whose raw PLINK code is 01, ascending.
+// One wave per column group walks its tiles (one coalesced 1 KB load per 128 rows), appends the rows carrying
+// the temporary code 3 to the per-column missing lists in ascending row order and stores the tile back
+// with those entries as dosage 0 -- so a .bed is uploaded ONCE (the missing lists used to need a second
+// upload of the raw bytes).  Lane 32h+m holds rows 128bp + 64e + 32h + 16u + (0..15) of column m in
+// dword 2e+u; the two lanes of a column exchange their per-segment counts to keep the list sorted.
 __global__ void __launch_bounds__(64)
-k_fill_missing_raw(const uint8_t *__restrict__ raw, int64_t raw_stride, int64_t n, int64_t ncols,
-                   int64_t col0, const int64_t *__restrict__ miss_ptr, int32_t *__restrict__ miss_row)
+k_missing_from_tiles(uint4 *__restrict__ X, int64_t nbp, int64_t p, const int64_t *__restrict__ miss_ptr,
+                     int32_t *__restrict__ miss_row)
 {
-    int64_t jc = blockIdx.x;
-    if (jc >= ncols) return;
-    const uint8_t *src = raw + jc * raw_stride;
-    int64_t base = miss_ptr[col0 + jc];
-    int lane = threadIdx.x;
-    for (int64_t i0 = 0; i0 < n; i0 += 64) {
-        int64_t i = i0 + lane;
-        bool miss = false;
-        if (i < n) miss = ((src[i >> 2] >> (2 * (i & 3))) & 3) == 1;
-        unsigned long long bal = __ballot(miss);
-        if (miss) {
-            int off = __popcll(bal & ((1ull << lane) - 1ull));
-            miss_row[base + off] = (int32_t)i;
+    const int64_t cg = blockIdx.x;
+    const int lane = threadIdx.x, m = lane & 31, h = lane >> 5;
+    const int64_t j = cg * 32 + m;
+    int64_t base = (j < p) ? miss_ptr[j] : 0;
+    const int64_t end = (j < p) ? miss_ptr[j + 1] : 0;
+    if (__ballot(end > base) == 0ull) return;                     // no missing entry in this column group
+    for (int64_t bp = 0; bp < nbp; ++bp) {
+        uint4 v = X[(cg * nbp + bp) * 64 + lane];
+        uint32_t d[4] = {v.x, v.y, v.z, v.w}, mk[4];
+        int c[2] = {0, 0};
+        #pragma unroll
+        for (int q = 0; q < 4; ++q) { mk[q] = d[q] & (d[q] >> 1) & 0x55555555u; c[q >> 1] += __popc(mk[q]); }
+        const int o0 = __shfl_xor(c[0], 32, 64), o1 = __shfl_xor(c[1], 32, 64);     // the other half's counts
+        if (__ballot((c[0] | c[1]) != 0) == 0ull) continue;
+        // segment order within a block pair: (e0,h0) (e0,h1) (e1,h0) (e1,h1)
+        int64_t w0 = base + (h ? o0 : 0);
+        int64_t w1 = base + c[0] + o0 + (h ? o1 : 0);
+        #pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int64_t &w = (q >> 1) ? w1 : w0;
+            uint32_t bits = mk[q];
+            const int32_t row0 = (int32_t)(bp * 128 + (q >> 1) * 64 + h * 32 + (q & 1) * 16);
+            while (bits) {
+                int sft = __ffs((int)bits) - 1;
+                miss_row[w++] = row0 + (sft >> 1);
+                bits &= bits - 1;
+            }
+            d[q] &= ~(mk[q] | (mk[q] << 1));
         }
-        base += __popcll(bal);
+        if (c[0] | c[1]) X[(cg * nbp + bp) * 64 + lane] = make_uint4(d[0], d[1], d[2], d[3]);
+        base += c[0] + c[1] + o0 + o1;
     }
 }
 
@@ -351,36 +374,71 @@ int mih_snp_create(const uint8_t *bed_cols, int64_t n, int64_t p, int64_t col_st
     if (rc) { mih_mat_destroy(h); return rc; }
     if (hipStreamCreate(&h->stream) != hipSuccess) { mih_mat_destroy(h); return MIH_HIP_ERROR; }
 
-    // stage raw columns through a bounded device buffer
+    // Upload pipeline: the caller's (pageable, possibly mmapped) columns are copied by a few host threads into one
+    // of two pinned staging buffers, DMA'd to one of two device buffers on a copy stream and transcoded on the
+    // matrix's stream, so host copy, PCIe transfer and transcode of consecutive chunks overlap.
     const int64_t chunk_bytes = 256ll << 20;
     int64_t cols_per_chunk = chunk_bytes / col_stride_bytes / 32 * 32;   // whole column groups
     if (cols_per_chunk < 32) cols_per_chunk = 32;
     if (cols_per_chunk > round_up(p, 32)) cols_per_chunk = round_up(p, 32);
-    DevBuf<uint8_t> raw; DevBuf<int32_t> cnt;
-    if ((rc = raw.alloc((size_t)(cols_per_chunk * col_stride_bytes))) || (rc = cnt.alloc((size_t)(3 * p)))) { mih_mat_destroy(h); return rc; }
+    const size_t buf_bytes = (size_t)(cols_per_chunk * col_stride_bytes);
+    DevBuf<uint8_t> raw[2]; DevBuf<int32_t> cnt;
+    struct Pinned {
+        uint8_t *p[2] = {nullptr, nullptr}; hipStream_t copy = nullptr; hipEvent_t up[2] = {nullptr, nullptr}, used[2] = {nullptr, nullptr};
+        ~Pinned() {
+            for (int i = 0; i < 2; ++i) { if (p[i]) (void)hipHostFree(p[i]); if (up[i]) (void)hipEventDestroy(up[i]); if (used[i]) (void)hipEventDestroy(used[i]); }
+            if (copy) (void)hipStreamDestroy(copy);
+        }
+    } pin;
     auto fail = [&](int code) { mih_mat_destroy(h); return code; };
-    if (hipMemsetAsync(cnt.p, 0, sizeof(int32_t) * 3 * (size_t)p, h->stream) != hipSuccess) return fail(MIH_HIP_ERROR);
-    for (int64_t c0 = 0; c0 < p; c0 += cols_per_chunk) {
-        int64_t nc = (p - c0 < cols_per_chunk) ? p - c0 : cols_per_chunk;
-        if (hipMemcpy(raw.p, bed_cols + c0 * col_stride_bytes, (size_t)(nc * col_stride_bytes), hipMemcpyHostToDevice) != hipSuccess) return fail(MIH_HIP_ERROR);
-        dim3 grid((unsigned)((h->nbp + kBpPerBlock - 1) / kBpPerBlock), (unsigned)((nc + 31) / 32));
-        hipLaunchKernelGGL(k_transcode, grid, dim3(256), 0, h->stream, raw.p, col_stride_bytes, n, p, c0, nc,
-                           reinterpret_cast<uint4 *>(h->X), h->nbp, cnt.p);
-        if (hipStreamSynchronize(h->stream) != hipSuccess) { set_error("transcode kernel failed"); return fail(MIH_HIP_ERROR); }
+    if ((rc = raw[0].alloc(buf_bytes)) || (rc = raw[1].alloc(buf_bytes)) || (rc = cnt.alloc((size_t)(3 * p)))) return fail(rc);
+    for (int i = 0; i < 2; ++i) {
+        if (hipHostMalloc((void **)&pin.p[i], buf_bytes, hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc of the staging buffer failed"); (void)hipGetLastError(); return fail(MIH_OOM); }
+        if (hipEventCreateWithFlags(&pin.up[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&pin.used[i], hipEventDisableTiming) != hipSuccess) return fail(MIH_HIP_ERROR);
     }
+    if (hipStreamCreate(&pin.copy) != hipSuccess) return fail(MIH_HIP_ERROR);
+    if (hipMemsetAsync(cnt.p, 0, sizeof(int32_t) * 3 * (size_t)p, h->stream) != hipSuccess) return fail(MIH_HIP_ERROR);
+    unsigned nth = std::thread::hardware_concurrency();
+    nth = nth >= 16 ? 8 : (nth >= 4 ? nth / 2 : 1);
+    if (const char *e = getenv("MENDELIHT_INGEST_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 64) nth = (unsigned)v; }
+    auto host_copy = [&](uint8_t *dst, const uint8_t *src, size_t bytes) {
+        if (nth <= 1 || bytes < (8u << 20)) { std::memcpy(dst, src, bytes); return; }
+        std::vector<std::thread> th;
+        size_t per = (bytes + nth - 1) / nth;
+        for (unsigned t = 0; t < nth; ++t) {
+            size_t o = (size_t)t * per; if (o >= bytes) break;
+            size_t len = std::min(per, bytes - o);
+            th.emplace_back([=]() { std::memcpy(dst + o, src + o, len); });
+        }
+        for (auto &t : th) t.join();
+    };
+    int64_t chunk = 0;
+    for (int64_t c0 = 0; c0 < p; c0 += cols_per_chunk, ++chunk) {
+        const int b = (int)(chunk & 1);
+        int64_t nc = (p - c0 < cols_per_chunk) ? p - c0 : cols_per_chunk;
+        const size_t bytes = (size_t)(nc * col_stride_bytes);
+        if (chunk >= 2) {      // staging buffer b: its DMA must have finished; device buffer b: its transcode must have finished
+            if (hipEventSynchronize(pin.up[b]) != hipSuccess) return fail(MIH_HIP_ERROR);
+            if (hipStreamWaitEvent(pin.copy, pin.used[b], 0) != hipSuccess) return fail(MIH_HIP_ERROR);
+        }
+        host_copy(pin.p[b], bed_cols + c0 * col_stride_bytes, bytes);
+        if (hipMemcpyAsync(raw[b].p, pin.p[b], bytes, hipMemcpyHostToDevice, pin.copy) != hipSuccess) return fail(MIH_HIP_ERROR);
+        if (hipEventRecord(pin.up[b], pin.copy) != hipSuccess) return fail(MIH_HIP_ERROR);
+        if (hipStreamWaitEvent(h->stream, pin.up[b], 0) != hipSuccess) return fail(MIH_HIP_ERROR);
+        dim3 grid((unsigned)((h->nbp + kBpPerBlock - 1) / kBpPerBlock), (unsigned)((nc + 31) / 32));
+        hipLaunchKernelGGL(k_transcode, grid, dim3(256), 0, h->stream, raw[b].p, col_stride_bytes, n, p, c0, nc,
+                           reinterpret_cast<uint4 *>(h->X), h->nbp, cnt.p);
+        if (hipEventRecord(pin.used[b], h->stream) != hipSuccess) return fail(MIH_HIP_ERROR);
+    }
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { set_error("transcode kernel failed"); return fail(MIH_HIP_ERROR); }
     hipLaunchKernelGGL(k_col_stats, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, h->stream, cnt.p, n, p, h->mu, h->sinv);
     std::vector<int32_t> hcnt((size_t)(3 * p));
     if (hipMemcpy(hcnt.data(), cnt.p, sizeof(int32_t) * hcnt.size(), hipMemcpyDeviceToHost) != hipSuccess) return fail(MIH_HIP_ERROR);
     std::vector<int64_t> ptr;
     if ((rc = finish_missing_ptr(h, hcnt, ptr))) return fail(rc);
-    if (h->total_missing > 0) {
-        for (int64_t c0 = 0; c0 < p; c0 += cols_per_chunk) {
-            int64_t nc = (p - c0 < cols_per_chunk) ? p - c0 : cols_per_chunk;
-            if (hipMemcpy(raw.p, bed_cols + c0 * col_stride_bytes, (size_t)(nc * col_stride_bytes), hipMemcpyHostToDevice) != hipSuccess) return fail(MIH_HIP_ERROR);
-            hipLaunchKernelGGL(k_fill_missing_raw, dim3((unsigned)nc), dim3(64), 0, h->stream, raw.p, col_stride_bytes, n, nc, c0, h->miss_ptr, h->miss_row);
-            if (hipStreamSynchronize(h->stream) != hipSuccess) { set_error("missing-list kernel failed"); return fail(MIH_HIP_ERROR); }
-        }
-    }
+    if (h->total_missing > 0)
+        hipLaunchKernelGGL(k_missing_from_tiles, dim3((unsigned)h->ncg), dim3(64), 0, h->stream, reinterpret_cast<uint4 *>(h->X), h->nbp, p,
+                           h->miss_ptr, h->miss_row);
     if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(MIH_HIP_ERROR);
     *out = h;
     return MIH_OK;
