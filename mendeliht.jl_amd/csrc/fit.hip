@@ -12,6 +12,7 @@
 #include "fit_common.h"
 #include <algorithm>
 #include <chrono>
+#include <cstring>
 #include <cmath>
 #include <limits>
 #include <memory>
@@ -760,25 +761,36 @@ struct IhtVar {
     int init_beta_phase(const uint8_t *train)
     {
         if (dist != MIH_NORMAL) { set_error("Intializing beta values only work for Gaussian phenotypes! Sorry!"); return MIH_BAD_ARG; }
-        DevBuf<double> betad;
-        MIH_TRY(betad.alloc(p));
-        double Sy = 0.0, N = 0.0;
-        std::vector<double> ys;
-        for (int64_t i = 0; i < n; ++i) if (!train || train[i]) { Sy += y_host[i]; N += 1.0; ys.push_back(y_host[i]); }
-        double c0sum = 0.0;
-        MIH_TRY(init_beta_regress_device(h, w.p, y.p, 1, N, &Sy, betad.p, &c0sum, red, scal, s));
-        // non-genetic covariates 2..q on the host (utilities.jl:799-806)
-        for (int l = 1; l < q; ++l) {
-            double sx = 0, sxx = 0, sxy = 0;
-            size_t t = 0;
-            for (int64_t i = 0; i < n; ++i) if (!train || train[i]) { double xv = z_host[(size_t)l * n + i]; sx += xv; sxx += xv * xv; sxy += xv * ys[t++]; }
-            double u11 = std::sqrt(N), u12 = sx / u11, d = sxx - u12 * u12, b0v, b1v;
-            if (!(N > 0.0) || !(d > 0.0)) { b0v = Sy; b1v = sxy; }
-            else { double u22 = std::sqrt(d), w1 = Sy / u11, w2 = (sxy - u12 * w1) / u22; b1v = w2 / u22; b0v = (w1 - u12 * b1v) / u11; }
-            c0sum += b0v; c[l] = b1v;
+        // The regressions depend on the training mask only: cv_iht visits the (fold, k) combinations fold-major,
+        // so every k of a fold after the first reuses them (two passes over X saved per fit).
+        DevBuf<double> &betad = ib_beta;
+        const bool reuse = ib_valid && ((train == nullptr) == ib_train.empty()) &&
+                           (train == nullptr || std::memcmp(ib_train.data(), train, (size_t)n) == 0);
+        if (!reuse) {
+            ib_valid = false;
+            if (ib_beta.n < (size_t)p) MIH_TRY(ib_beta.alloc(p));
+            double Sy = 0.0, N = 0.0;
+            std::vector<double> ys;
+            for (int64_t i = 0; i < n; ++i) if (!train || train[i]) { Sy += y_host[i]; N += 1.0; ys.push_back(y_host[i]); }
+            double c0sum = 0.0;
+            MIH_TRY(init_beta_regress_device(h, w.p, y.p, 1, N, &Sy, betad.p, &c0sum, red, scal, s));
+            ib_c.assign(q, 0.0);
+            // non-genetic covariates 2..q on the host (utilities.jl:799-806)
+            for (int l = 1; l < q; ++l) {
+                double sx = 0, sxx = 0, sxy = 0;
+                size_t t = 0;
+                for (int64_t i = 0; i < n; ++i) if (!train || train[i]) { double xv = z_host[(size_t)l * n + i]; sx += xv; sxx += xv * xv; sxy += xv * ys[t++]; }
+                double u11 = std::sqrt(N), u12 = sx / u11, d = sxx - u12 * u12, b0v, b1v;
+                if (!(N > 0.0) || !(d > 0.0)) { b0v = Sy; b1v = sxy; }
+                else { double u22 = std::sqrt(d), w1 = Sy / u11, w2 = (sxy - u12 * w1) / u22; b1v = w2 / u22; b0v = (w1 - u12 * b1v) / u11; }
+                c0sum += b0v; ib_c[l] = b1v;
+            }
+            ib_c[0] = c0sum / (double)(p + q - 1);
+            for (int l = 0; l < q; ++l) ib_c[l] = ib_c[l] < -2.0 ? -2.0 : (ib_c[l] > 2.0 ? 2.0 : ib_c[l]);
+            if (train) ib_train.assign(train, train + n); else ib_train.clear();
+            ib_valid = true;
         }
-        c[0] = c0sum / (double)(p + q - 1);
-        for (int l = 0; l < q; ++l) c[l] = c[l] < -2.0 ? -2.0 : (c[l] > 2.0 ? 2.0 : c[l]);
+        c = ib_c;
         c0 = c;
         // project_k!(v): vectorize (weights, Inf for kept covariates), top-(k + zkeepn), unvectorize
         const double *wp = has_weight ? weight.p : nullptr;
@@ -804,6 +816,8 @@ struct IhtVar {
         return MIH_OK;
     }
     const uint8_t *train_cur = nullptr;
+    // initialize_beta! results of the last training mask (reused across the k of one CV fold)
+    DevBuf<double> ib_beta; std::vector<double> ib_c; std::vector<uint8_t> ib_train; bool ib_valid = false;
     int init_post()
     {
         MIH_TRY(score_post());
