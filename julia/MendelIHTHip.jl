@@ -77,6 +77,14 @@ mutable struct MihFitResult
     bt_trace::Ptr{Int32}; mu::Ptr{Float64}
 end
 
+# refuse to run against a library whose structs differ from the mirrors above (mih_abi_sizes)
+function __init__()
+    sz = zeros(Int64, 4)
+    check(ccall((:mih_abi_sizes, LIB), Cint, (Ptr{Int64}, Int32), sz, 4))
+    (sz[1] == sizeof(MihFitParams) && sz[2] == sizeof(MihFitResult) && sz[4] == sizeof(MihComm)) ||
+        error("MendelIHTHip.jl struct mirrors do not match $LIB: $sz")
+end
+
 distcode(::Normal) = Int32(0); distcode(::Bernoulli) = Int32(1)
 distcode(::Poisson) = Int32(2); distcode(::NegativeBinomial) = Int32(3)
 distcode(::Gamma) = Int32(4); distcode(::InverseGaussian) = Int32(5)
