@@ -9,7 +9,7 @@ replica per rank (the path shards only across independent fits -- weak scaling, 
 data-path collective; the driver launches ranks with torch.distributed.run).
 
 Prints ONE JSON line (rank 0).  `roofline` is measured live: HIP events around every
-launch of the dominant kernel (k_xtv) inside the timed region, on the stream it runs on.
+launch of the dominant kernel (k_xtv_mfma_lds, the X'r pass) inside the timed region, on the stream it runs on.
 `cpu_baseline` times the CPU oracle (a port, not MendelIHT.jl itself -- no Julia in the
 image) on a bounded column sample of the same matrix, rank 0 at N = 1 only.
 """
@@ -181,7 +181,7 @@ def main():
                        "final_logl": logl},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": a.traffic_bytes,
-                         "kernel": "k_xtv_mfma", "kernel_ms": kern_ms, "launches": launches,
+                         "kernel": "k_xtv_mfma_lds<1,1,4>" if a.variant < 0 else "k_xtv_mfma", "kernel_ms": kern_ms, "launches": launches,
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -236,7 +236,8 @@ int mih_bench_xtv_batched(const mih_mat *h, int variant, int m, int max_fused, i
                           uint64_t seed, float *ms_per_pass, double *checksum);
 /* Algorithmic bytes of one X'r pass: p*ceil(n/4) + 8*m*(n+p) + 16*p. */
 int mih_xtv_algorithmic_bytes(const mih_mat *h, int m, double *bytes);
-/* Select the X'r kernel variant used by every subsequent call (tuning knob). */
+/* Select the single-operand X'r kernel used by every subsequent call (tuning knob): -1 = library default
+ * (digit planes shared through LDS), 0..15 = the per-wave-load shapes {waves, column groups, row slices}. */
 int mih_set_xtv_variant(int variant);
 /* Fixed-point width of the residual in the X'r passes of workspaces created AFTER the call.  28 (default):
  * 28 base-4 digits = 56 bits, the dot products are exact and the only rounding (2^-55 max|r|) is below

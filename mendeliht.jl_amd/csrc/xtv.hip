@@ -19,7 +19,8 @@
 //   * every product and every partial sum is a multiple of 1/4 below 2^22 in magnitude, so the f32
 //     accumulators are exact and the result does not depend on summation order (bit-reproducible);
 //   * the digit sums are recombined in f64 (sum_t 4^t * S_t, fixed order) and rescaled by 2^-e.
-// The only inexact step is the rounding of r to 2^-55 of max|r| -- tighter than the rounding an
+// The inexact steps are the rounding of r to 2^-55 of max|r| and the few f64 additions that recombine the
+// digit sums (fixed order, so bit-reproducible for a given row slicing) -- tighter than the rounding an
 // n-term f64 dot product accumulates.  Per 2048 dosages: 1 MFMA (13.7 ns/SIMD) + ~8 VALU ops, far
 // below the 87 ns/SIMD the HBM stream allows at 6 TB/s, so the kernel is memory-bound.
 //
@@ -502,6 +503,15 @@ static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 
         set_error("unknown multi-RHS kernel variant");
         return MIH_BAD_ARG;
     }
+    if (nr == 1 && g_xtv_variant < 0) {
+        // library default for one operand: digit planes shared through LDS as well (17.86 ms against 18.47 ms for
+        // the per-wave-load kernels below at n=500k, p=1M; tools/sweep_single_lds.py).  An explicit
+        // mih_set_xtv_variant(v >= 0) selects the per-wave kernels instead.
+        const int mv = g_xtv_multi_variant;
+        MIH_LDS(1, 0, 1, 4, 0, 8)
+        MIH_LDS(1, 10, 1, 2, 0, 8) MIH_LDS(1, 11, 1, 6, 0, 8) MIH_LDS(1, 12, 1, 2, 0, 16) MIH_LDS(1, 13, 2, 4, 0, 8) MIH_LDS(1, 14, 4, 2, 0, 8)
+        { MIH_LDS(1, mv, 1, 4, 0, 8) }                    // multi-operand variant ids fall back to the default shape
+    }
 #undef MIH_LDS
 #define MIH_CASE(W, C) if (v.waves == W && v.ct == C) { launch_xtv<W, C, 1>(h, dig, dig_stride, splits, per_op, scal, partial, s); return MIH_OK; }
     MIH_CASE(4, 1) MIH_CASE(4, 2) MIH_CASE(4, 4) MIH_CASE(8, 1) MIH_CASE(8, 2) MIH_CASE(2, 2) MIH_CASE(8, 4) MIH_CASE(4, 8) MIH_CASE(2, 4)
@@ -610,8 +620,9 @@ int mih_profile_read(double *xtv_kernel_ms, int64_t *xtv_launches, int reset)
 
 int mih_set_xtv_variant(int variant)
 {
-    if (!xtv_variant_valid(variant)) { set_error("variant %d out of range", variant); return MIH_BAD_ARG; }
-    g_xtv_variant = variant;
+    if (variant == -1) { g_xtv_variant = -1; return MIH_OK; }      // back to the library default
+    if (variant < -1 || !xtv_variant_valid(variant)) { set_error("variant %d out of range", variant); return MIH_BAD_ARG; }
+    g_xtv_variant = variant;          // -1: library default (LDS-shared digit planes); >= 0: a per-wave-load shape
     return MIH_OK;
 }
 
@@ -624,7 +635,7 @@ int mih_set_xtv_digits(int digits)
 
 int mih_set_xtv_multi_variant(int variant)
 {
-    if (variant < 0 || variant > 8) { set_error("multi-RHS variant %d out of range", variant); return MIH_BAD_ARG; }
+    if (variant < 0 || variant > 14) { set_error("multi-RHS variant %d out of range", variant); return MIH_BAD_ARG; }
     g_xtv_multi_variant = variant;
     return MIH_OK;
 }

@@ -37,13 +37,21 @@ def test_mu_sinv_and_xtv_all_variants(mih, normal_pair):
     assert np.array_equal(mu, omu) and np.array_equal(s, os_)
     r = np.random.default_rng(0).standard_normal(x.n)
     ref = ox.xtv(r)
+    base = x.xtv(r)                                                 # library default: LDS-shared digit planes
+    assert rel(base, ref) < 1e-11
     nv = 0
-    while mih.lib().mih_set_xtv_variant(nv) == 0:
-        assert rel(x.xtv(r), ref) < 1e-11, nv
+    same_slices = (0, 1, 2, 3, 4, 9, 10, 13, 14)                    # shapes with 8 row slices, like the default
+    while mih.lib().mih_set_xtv_variant(nv) == 0:                   # the per-wave-load shapes
+        out = x.xtv(r)
+        assert rel(out, base) < 1e-13, nv                           # the slice partials are rounded f64 sums of exact digit sums
+        if nv in same_slices:
+            assert np.array_equal(out, base), nv                    # same slicing: every kernel shape agrees bit for bit
         nv += 1
     assert nv >= 3
-    mih.lib().mih_set_xtv_variant(-1)
-    assert rel(x.xtv(r), ref) < 1e-11
+    assert mih.lib().mih_set_xtv_variant(-1) == 0
+    for mv in (10, 11, 12, 13, 14, 0):                              # other LDS shapes of the single-operand pass
+        assert mih.lib().mih_set_xtv_multi_variant(mv) == 0
+        assert np.array_equal(x.xtv(r), base), mv
 
 
 @pytest.mark.parametrize("n,p,miss", [(1003, 257, 0.02), (77, 33, 0.1), (5000, 100, 0.0), (2049, 64, 0.05),
