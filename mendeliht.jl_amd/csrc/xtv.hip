@@ -95,6 +95,7 @@ __global__ void k_r_stats_final(const double *__restrict__ part, int nblocks, in
     // non-finite) residual keeps e = 0
     int e = 0;
     if (mx > 0.0 && mx < 1.0e300) e = ebits - ilogb(mx);
+    if (e > 1000) e = 1000;          // a (numerically zero) residual below 2^-947: keep 2^e finite
     scal[4 * v + 0] = mx;
     scal[4 * v + 1] = ldexp(1.0, -e);
     scal[4 * v + 2] = sm;

@@ -785,3 +785,15 @@ def test_maf_weights(mih, normal_pair):
     assert np.all((w2 >= 1.0) & (w2 <= 2.0))
     res = mih.fit_iht(np.loadtxt(os.path.join(FIX, "normal_y_fam6.txt")), x, None, k=5, weight=w2, verbose=False)
     assert np.count_nonzero(res.beta) == 5
+
+
+def test_xtv_extreme_residual_scales(mih, oracle, normal_pair):
+    """The fixed-point scale 2^e follows max|r|: huge, tiny, denormal and all-zero residuals stay finite and accurate."""
+    x, ox = normal_pair
+    r = np.random.default_rng(8).standard_normal(x.n)
+    base = ox.xtv(r)
+    for scale in (1e150, 1e-150, 1e-290, 5e-310):
+        out = x.xtv(r * scale)
+        assert np.all(np.isfinite(out))
+        assert rel(out, base * scale) < (1e-10 if scale > 1e-300 else 1e-3), scale
+    assert np.all(x.xtv(np.zeros(x.n)) == 0.0)
