@@ -557,6 +557,10 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
     if (m > w.m_cap) { set_error("X'r workspace too small"); return MIH_BAD_ARG; }
     Variant v = current_variant();
     int splits = v.splits;
+    // exactness of the f32 accumulators: a row slice may hold at most 2^22 rows (|g/2 * d| <= 1 in units of 1/4)
+    const int64_t need = (h->n_pad + (1ll << 22) - 1) >> 22;
+    if (need > w.splits_cap) { set_error("n = %lld rows needs more than %d row slices for exact accumulation", (long long)h->n, w.splits_cap); return MIH_BAD_DIM; }
+    if (splits < need) splits = (int)need;
     if (splits > h->nbp) splits = (int)h->nbp;
     if (splits > w.splits_cap) splits = w.splits_cap;
     const int64_t nblk = h->nbp * 2, pstride = h->ncg * 32;
