@@ -158,7 +158,62 @@ void orc_xtv(const orc_mat *m, const double *r, double *out)
     }
     double sumr = 0.0;
     for (int64_t i = 0; i < n; ++i) sumr += r[i];
+    /* Loop order only: blocks of XTV_NB columns walk the rows in tiles of XTV_TB bytes (= 4*XTV_TB samples), so a
+     * tile of r is reused from cache by the whole block.  Every column still adds its rows in ascending order
+     * into the same four lane accumulators as snp_col_dot, so the results are bit-identical to the
+     * column-at-a-time loop (checked by tests/test_oracle_golden.py). */
+    enum { XTV_NB = 32, XTV_TB = 2048 };
+    const int64_t nfull = n >> 2;
     #pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int64_t j0 = 0; j0 < p; j0 += XTV_NB) {
+        const int64_t nbk = (p - j0 < XTV_NB) ? p - j0 : XTV_NB;
+        double s[XTV_NB][4], ms[XTV_NB][4];
+        memset(s, 0, sizeof(s)); memset(ms, 0, sizeof(ms));
+        for (int64_t b0 = 0; b0 < nfull; b0 += XTV_TB) {
+            const int64_t b1 = (b0 + XTV_TB < nfull) ? b0 + XTV_TB : nfull;
+            for (int64_t c = 0; c < nbk; ++c) {
+                const uint8_t *col = m->cols + (j0 + c) * m->stride;
+                double s0 = s[c][0], s1 = s[c][1], s2 = s[c][2], s3 = s[c][3];
+                for (int64_t b = b0; b < b1; ++b) {
+                    const uint8_t byte = col[b];
+                    const double *rr = r + 4 * b;
+                    const double *g = LUT_G[byte];
+                    s0 += g[0] * rr[0]; s1 += g[1] * rr[1];
+                    s2 += g[2] * rr[2]; s3 += g[3] * rr[3];
+                    if (LUT_HASM[byte]) {
+                        const double *mm = LUT_M[byte];
+                        ms[c][0] += mm[0] * rr[0]; ms[c][1] += mm[1] * rr[1];
+                        ms[c][2] += mm[2] * rr[2]; ms[c][3] += mm[3] * rr[3];
+                    }
+                }
+                s[c][0] = s0; s[c][1] = s1; s[c][2] = s2; s[c][3] = s3;
+            }
+        }
+        for (int64_t c = 0; c < nbk; ++c) {
+            const int64_t j = j0 + c;
+            for (int64_t i = nfull * 4; i < n; ++i) {   /* ragged tail: pad bits ignored */
+                int cd = bed_code(m, i, j);
+                if (cd == 2) s[c][0] += r[i];
+                else if (cd == 3) s[c][0] += 2.0 * r[i];
+                else if (cd == 1) ms[c][0] += r[i];
+            }
+            double o = (s[c][0] + s[c][1]) + (s[c][2] + s[c][3]);
+            const double sm = (ms[c][0] + ms[c][1]) + (ms[c][2] + ms[c][3]);
+            if (m->impute) o += m->mu[j] * sm;
+            if (m->center) o -= m->mu[j] * sumr;
+            if (m->scale) o *= m->sinv[j];
+            out[j] = o;
+        }
+    }
+}
+
+/* the column-at-a-time form of the same sums (reference loop order; kept for the equivalence test) */
+void orc_xtv_colwise(const orc_mat *m, const double *r, double *out)
+{
+    int64_t n = m->n, p = m->p;
+    if (m->kind == 1) { orc_xtv(m, r, out); return; }
+    double sumr = 0.0;
+    for (int64_t i = 0; i < n; ++i) sumr += r[i];
     for (int64_t j = 0; j < p; ++j) {
         double sg, sm;
         snp_col_dot(m, j, r, &sg, &sm);

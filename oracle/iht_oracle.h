@@ -86,6 +86,7 @@ void     orc_mat_destroy(orc_mat *m);
 void     orc_mat_mu_sinv(const orc_mat *m, double *mu, double *sinv);
 double   orc_getindex(const orc_mat *m, int64_t i, int64_t j);
 void     orc_xtv(const orc_mat *m, const double *r, double *out);   /* mul!(out, Transpose(x), r) */
+void     orc_xtv_colwise(const orc_mat *m, const double *r, double *out);   /* same sums, one column at a time */
 void     orc_xtv_multi(const orc_mat *m, const double *R, int64_t nrhs, double *OUT);
 /* out = sum_{j: idx[j]!=0} x[:,j]*coef[j]   (utilities.jl:98-106, 731-739) */
 void     orc_xv_masked(const orc_mat *m, const uint8_t *idx, const double *coef, double *out);

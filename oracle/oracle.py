@@ -69,6 +69,7 @@ def lib():
         _lib.orc_getindex.restype = C.c_double
         _lib.orc_getindex.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
         _lib.orc_xtv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.orc_xtv_colwise.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.orc_xtv_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         _lib.orc_xv_masked.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.orc_project_k.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
@@ -147,6 +148,12 @@ class Mat:
         r = np.ascontiguousarray(r, dtype=np.float64)
         out = np.empty(self.p)
         lib().orc_xtv(self.h, _p(r), _p(out))
+        return out
+
+    def xtv_colwise(self, r):
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        out = np.empty(self.p)
+        lib().orc_xtv_colwise(self.h, _p(r), _p(out))
         return out
 
     def xtv_multi(self, R):

@@ -78,6 +78,16 @@ def test_snplinalg_semantics(oracle):
     assert x.getindex(7, 5) == pytest.approx(X[7, 5], rel=1e-14, abs=1e-15)
 
 
+def test_blocked_xtv_equals_column_loop(oracle):
+    """orc_xtv walks column blocks over row tiles for cache reuse; every column still adds its rows in the same
+    order, so it must agree bit for bit with the plain column-at-a-time loop (ragged n, missing data)."""
+    rng = np.random.default_rng(12)
+    for n, p in ((1003, 77), (9001, 130), (20000, 33)):
+        ox = oracle.Mat.from_bed_columns(make_bed(rng, n, p, missing_rate=0.03), n)
+        r = rng.standard_normal(n)
+        assert np.array_equal(ox.xtv(r), ox.xtv_colwise(r))
+
+
 def test_loglikelihood_vs_logpdf(oracle):
     """test/utilities_test.jl:20-51: loglikelihood equals the sum of logpdfs; :53-61 deviance."""
     rng = np.random.default_rng(1)
