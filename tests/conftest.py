@@ -26,6 +26,9 @@ def oracle():
 @pytest.fixture(scope="session")
 def mih():
     import mendeliht_amd
+    if not os.path.exists(mendeliht_amd.library_path()):       # a checkout without built artefacts: build once (hipcc)
+        import __graft_entry__
+        __graft_entry__.build()
     return mendeliht_amd
 
 
