@@ -115,6 +115,12 @@ def main():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     import mendeliht_amd as m
+    if not os.path.exists(m.library_path()):       # fresh checkout: compile the HIP library first
+        if rank == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        if world > 1:
+            dist.barrier()
 
     def barrier():
         if world > 1:
