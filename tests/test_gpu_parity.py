@@ -797,3 +797,30 @@ def test_xtv_extreme_residual_scales(mih, oracle, normal_pair):
         assert np.all(np.isfinite(out))
         assert rel(out, base * scale) < (1e-10 if scale > 1e-300 else 1e-3), scale
     assert np.all(x.xtv(np.zeros(x.n)) == 0.0)
+
+
+def test_large_k_and_many_covariates(mih, oracle, normal_pair, normal_data):
+    """Buffers that grow with the model: k = 1500 of p = 10 000 SNPs, and q = 24 covariates of which 19 compete
+    with the SNPs in the projection (zkeep false); q beyond the library limit is rejected."""
+    x, ox = normal_pair
+    n = x.n
+    rng = np.random.default_rng(70)
+    y = normal_data["y"]
+    res = mih.fit_iht(y, x, None, k=1500, verbose=False, max_iter=12)
+    o = oracle.fit_iht(ox, y, None, k=1500, max_iter=12)
+    assert res.iter == o["iter"] and np.count_nonzero(res.beta) == 1500
+    assert np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"]))
+    np.testing.assert_allclose(res.beta, o["beta"], rtol=1e-5, atol=1e-12)
+    q = 24
+    z = np.column_stack([np.ones(n)] + [rng.standard_normal(n) for _ in range(q - 1)])
+    yz = y + z[:, 5] * 0.8 - z[:, 17] * 0.6
+    zk = [1] * 5 + [0] * (q - 5)
+    res = mih.fit_iht(yz, x, z, k=9, zkeep=zk, verbose=False)
+    o = oracle.fit_iht(ox, yz, z, k=9, zkeep=zk)
+    assert res.iter == o["iter"]
+    assert np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"]))
+    assert np.array_equal(np.flatnonzero(res.c), np.flatnonzero(o["c"]))
+    np.testing.assert_allclose(res.c, o["c"], rtol=1e-5, atol=1e-12)
+    assert res.c[5] != 0 and res.c[17] != 0                      # the two real covariate effects survive the projection
+    with pytest.raises(mih.MendelIHTError):
+        mih.fit_iht(y, x, np.ones((n, 65)), k=3, verbose=False)
