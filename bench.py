@@ -51,6 +51,13 @@ def cpu_baseline(m, n, p, seed, target_s):
     from oracle import oracle as O
 
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None                                            # cgroup v2 CPU quota of the container, in CPUs
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        pass
     rng = np.random.default_rng(7)
     r = rng.standard_normal(n)
 
@@ -89,7 +96,7 @@ def cpu_baseline(m, n, p, seed, target_s):
     return {"value": iters_per_s, "unit": "iterations/s", "cores": cores, "kind": "port",
             "sample": f"oracle X'r (one IHT iteration = one pass) on the first {pc} of {p} SNP columns, "
                       f"n={n}, {t:.3f} s per pass (mean over >= {target_s / 3.0:.0f} s of repeats, {cores} OpenMP threads = the "
-                      f"fastest of {sorted(trials)} on {ncpu} logical CPUs), scaled by p/{pc}; "
+                      f"fastest of {sorted(trials)} on {ncpu} logical CPUs{'' if quota is None else f', cgroup CPU quota {quota:g}'}), scaled by p/{pc}; "
                       "CPU restatement, not MendelIHT.jl",
             "xtv_GBps": ((n + 3) // 4) * pc / t / 1e9}
 
