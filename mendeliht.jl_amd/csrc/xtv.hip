@@ -415,6 +415,10 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+// One wave per column.  The matrix is read exactly once: nontemporal 16 B/lane loads, four of them in
+// flight per lane (64 lanes x 64 B = 4 KB per wave-iteration), two accumulators per load slot; the
+// fixed lane -> row mapping and the fixed final tree keep the sum bit-reproducible.
 __global__ void __launch_bounds__(256)
 k_xtv_dense(const double *__restrict__ D, int64_t n, int64_t p, const double *__restrict__ r,
             double *__restrict__ out)
@@ -423,18 +427,29 @@ k_xtv_dense(const double *__restrict__ D, int64_t n, int64_t p, const double *__
     int64_t j = blockIdx.x * 4ll + (threadIdx.x >> 6);
     if (j >= p) return;
     const double *col = D + j * n;
-    double a0 = 0.0, a1 = 0.0;
-    int64_t i = lane * 2;
+    double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if ((n & 1) == 0 && (((uintptr_t)col) & 15) == 0) {
-        for (; i + 1 < n; i += 128) {
-            double2 x = *reinterpret_cast<const double2 *>(col + i);
-            double2 v = *reinterpret_cast<const double2 *>(r + i);
-            a0 = fma(x.x, v.x, a0); a1 = fma(x.y, v.y, a1);
+        const f64x2 *cx = reinterpret_cast<const f64x2 *>(col);
+        const f64x2 *rx = reinterpret_cast<const f64x2 *>(r);
+        const int64_t n2 = n >> 1;
+        int64_t i = lane;
+        for (; i + 192 < n2; i += 256) {
+            f64x2 x0 = __builtin_nontemporal_load(cx + i), x1 = __builtin_nontemporal_load(cx + i + 64);
+            f64x2 x2 = __builtin_nontemporal_load(cx + i + 128), x3 = __builtin_nontemporal_load(cx + i + 192);
+            f64x2 v0 = rx[i], v1 = rx[i + 64], v2 = rx[i + 128], v3 = rx[i + 192];
+            a[0] = fma(x0.x, v0.x, a[0]); a[1] = fma(x0.y, v0.y, a[1]);
+            a[2] = fma(x1.x, v1.x, a[2]); a[3] = fma(x1.y, v1.y, a[3]);
+            a[4] = fma(x2.x, v2.x, a[4]); a[5] = fma(x2.y, v2.y, a[5]);
+            a[6] = fma(x3.x, v3.x, a[6]); a[7] = fma(x3.y, v3.y, a[7]);
+        }
+        for (; i < n2; i += 64) {
+            f64x2 x0 = __builtin_nontemporal_load(cx + i), v0 = rx[i];
+            a[0] = fma(x0.x, v0.x, a[0]); a[1] = fma(x0.y, v0.y, a[1]);
         }
     } else {
-        for (int64_t k = lane; k < n; k += 64) a0 = fma(col[k], r[k], a0);
+        for (int64_t k = lane; k < n; k += 64) a[0] = fma(col[k], r[k], a[0]);
     }
-    double s = wave_sum(a0 + a1);
+    double s = wave_sum(((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7])));
     if (lane == 0) out[j] = s;
 }
 
