@@ -9,7 +9,7 @@
 #   mse = cv_iht(y, x, z; path=1:20, q=5, folds=folds)
 module MendelIHTHip
 
-using MendelIHT, SnpArrays, Distributions, GLM
+using MendelIHT, SnpArrays, Distributions, GLM, LinearAlgebra
 import MendelIHT: fit_iht, cv_iht, IHTResult
 
 const LIB = get(ENV, "MENDELIHT_HIP_LIB", "libmendeliht_hip.so")
