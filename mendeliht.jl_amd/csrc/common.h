@@ -50,6 +50,25 @@ struct DevBuf {
     }
 };
 
+// pinned host scratch for the small per-iteration readbacks (a device-to-host copy into pageable memory is
+// staged by the runtime and costs ~15 us more per host synchronisation)
+template <typename T>
+struct PinBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    PinBuf() = default;
+    PinBuf(const PinBuf &) = delete;
+    PinBuf &operator=(const PinBuf &) = delete;
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+    int alloc(size_t count) {
+        if (p) { (void)hipHostFree(p); p = nullptr; n = 0; }
+        if (count == 0) count = 1;
+        if (hipHostMalloc((void **)&p, count * sizeof(T), hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc(%zu bytes) failed", count * sizeof(T)); (void)hipGetLastError(); p = nullptr; return MIH_OOM; }
+        n = count;
+        return MIH_OK;
+    }
+};
+
 }  // namespace mih
 
 // Device-resident design matrix.
@@ -124,6 +143,7 @@ int  xv_sparse_device(const mih_mat *h, XvWork &w, const int64_t *idx_dev, const
 struct TopkWork {
     DevBuf<uint32_t> hist;     // 256 bins
     DevBuf<uint64_t> state;    // [0]=prefix, [1]=remaining k, [2]=threshold bits, [3]=count_ge
+    PinBuf<uint64_t> hsel;     // pinned landing buffer for the count + the first `expect` pairs
     DevBuf<uint64_t> sel;      // compacted survivors as (index, value bits) pairs; pair 0 holds the count
     int64_t cap = 0;           // pairs the buffer can hold after the header
     int64_t expect = 0;        // survivors expected by the caller (k + slack): fetched with the count in ONE copy

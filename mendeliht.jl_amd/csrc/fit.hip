@@ -373,6 +373,7 @@ struct IhtVar {
     DevBuf<int64_t> sidx; DevBuf<double> sval;   // staging for support lists
     DevBuf<uint8_t> mask;
     XtvWork xtv; XvWork xv; TopkWork topk;
+    PinBuf<double> hpin;                          // pinned landing area of the small readbacks
     int nb = 0;                                   // row blocks
     // host
     Sparse b, b0, best_b, idx;                    // idx.val = df on the support
@@ -436,6 +437,7 @@ struct IhtVar {
         int64_t kcap = std::max<int64_t>(std::max<int64_t>(J, 1) * k + q, 64) + 1024;
         for (int64_t v : ks) kcap += v;
         MIH_TRY(sidx.alloc(kcap)); MIH_TRY(sval.alloc(kcap)); MIH_TRY(gval.alloc(kcap));
+        MIH_TRY(hpin.alloc((size_t)kcap + kMaxQ + 16));
         if (!batched) MIH_TRY(xtv_work_init(h, xtv, 1));
         MIH_TRY(xv_work_init(h, xv, kcap));
         MIH_TRY(topk_work_init(topk, kcap));
@@ -518,9 +520,9 @@ struct IhtVar {
     {
         hipLaunchKernelGGL(k_mu_loglik, dim3(nb), dim3(256), 0, s, xb.p, zc.p, y.p, w.p, n, dist, link, nb_r, with_zc, mu.p, red.p);
         hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, s, red.p, nb, 4, scal.p);
-        double o[4];
-        MIH_HIP(hipMemcpyAsync(o, scal.p, sizeof(o), hipMemcpyDeviceToHost, s));
+        MIH_HIP(hipMemcpyAsync(hpin.p, scal.p, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
         MIH_HIP(hipStreamSynchronize(s));
+        const double o[4] = {hpin.p[0], hpin.p[1], hpin.p[2], hpin.p[3]};
         if (dev) *dev = o[0];
         if (logl) {
             if (dist == MIH_NORMAL) {
@@ -554,9 +556,12 @@ struct IhtVar {
     {
         hipLaunchKernelGGL(k_zt_r, dim3(kZtrBlocks, q), dim3(256), 0, s, z.p, r.p, n, ztr.p);
         hipLaunchKernelGGL(k_zt_r_final, dim3(q), dim3(64), 0, s, ztr.p, scal.p);
-        MIH_HIP(hipMemcpyAsync(df2.data(), scal.p, sizeof(double) * q, hipMemcpyDeviceToHost, s));
+        df2_pending = true;                       // lands in pinned memory; copied out at the next synchronisation
+        MIH_HIP(hipMemcpyAsync(hpin.p + (hpin.n - kMaxQ), scal.p, sizeof(double) * q, hipMemcpyDeviceToHost, s));
         return MIH_OK;
     }
+    bool df2_pending = false;
+    void take_df2() { if (df2_pending) { for (int l = 0; l < q; ++l) df2[l] = hpin.p[hpin.n - kMaxQ + l]; df2_pending = false; } }
     int gather_df_support()
     {
         int64_t nnz = (int64_t)idx.idx.size();
@@ -565,9 +570,12 @@ struct IhtVar {
             MIH_TRY(ensure_stage(nnz));
             MIH_HIP(hipMemcpyAsync(sidx.p, idx.idx.data(), sizeof(int64_t) * nnz, hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(k_gather, dim3(nblk(nnz)), dim3(256), 0, s, df.p, sidx.p, nnz, gval.p);
-            MIH_HIP(hipMemcpyAsync(idx.val.data(), gval.p, sizeof(double) * nnz, hipMemcpyDeviceToHost, s));
+            if ((size_t)nnz + kMaxQ > hpin.n) { MIH_HIP(hipStreamSynchronize(s)); take_df2(); MIH_TRY(hpin.alloc((size_t)nnz * 2 + kMaxQ + 16)); }
+            MIH_HIP(hipMemcpyAsync(hpin.p, gval.p, sizeof(double) * nnz, hipMemcpyDeviceToHost, s));
         }
         MIH_HIP(hipStreamSynchronize(s));
+        for (int64_t t = 0; t < nnz; ++t) idx.val[t] = hpin.p[t];
+        take_df2();
         return MIH_OK;
     }
 
@@ -822,6 +830,7 @@ struct IhtVar {
     {
         MIH_TRY(score_post());
         MIH_HIP(hipStreamSynchronize(s));
+        take_df2();
         if (init_beta) return init_beta_phase(train_cur);
         if (!ks.empty()) {
             // utilities.jl:427-429: project_group_sparse!(v.df, group, J, ks); idx is then taken from
@@ -887,9 +896,9 @@ struct IhtVar {
         for (int l = 0; l < q; ++l) { d2[l] = idc[l] ? df2[l] : 0.0; if (idc[l]) numer += df2[l] * df2[l]; }
         hipLaunchKernelGGL(k_stepsize, dim3(nb), dim3(256), 0, s, xgk.p, z.p, xb.p, zc.p, mu.p, w.p, n, q, qvec(d2), dist, link, nb_r, red.p);
         hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, s, red.p, nb, 1, scal.p);
-        double denom = 0.0;
-        MIH_HIP(hipMemcpyAsync(&denom, scal.p, sizeof(double), hipMemcpyDeviceToHost, s));
+        MIH_HIP(hipMemcpyAsync(hpin.p, scal.p, sizeof(double), hipMemcpyDeviceToHost, s));
         MIH_HIP(hipStreamSynchronize(s));
+        const double denom = hpin.p[0];
         double e = numer / denom;
         if (std::isinf(e) || std::isnan(e)) e = 1e-8;
         *eta = e;

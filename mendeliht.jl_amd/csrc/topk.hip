@@ -112,6 +112,7 @@ int topk_work_init(TopkWork &w, int64_t max_keep)
     w.expect = max_keep + 64;
     w.cap = max_keep + 1024;
     MIH_TRY(w.sel.alloc(2 + 2 * (size_t)w.cap));
+    MIH_TRY(w.hsel.alloc(2 + 2 * (size_t)w.expect));
     return MIH_OK;
 }
 
@@ -125,10 +126,10 @@ static int compact_device(double *x_dev, int64_t len, TopkWork &w, hipStream_t s
         MIH_HIP(hipMemsetAsync(w.sel.p, 0, 2 * sizeof(uint64_t), s));
         hipLaunchKernelGGL(k_threshold, dim3(grid), dim3(256), 0, s, x_dev, len, w.state.p, w.sel.p, (uint32_t)w.cap);
         const int64_t first = std::min<int64_t>(w.expect, w.cap);
-        std::vector<uint64_t> host(2 + 2 * (size_t)first);
-        MIH_HIP(hipMemcpyAsync(host.data(), w.sel.p, sizeof(uint64_t) * host.size(), hipMemcpyDeviceToHost, s));
+        MIH_HIP(hipMemcpyAsync(w.hsel.p, w.sel.p, sizeof(uint64_t) * (2 + 2 * (size_t)first), hipMemcpyDeviceToHost, s));
         MIH_HIP(hipStreamSynchronize(s));
-        const int64_t cnt = (int64_t)host[0];
+        const int64_t cnt = (int64_t)w.hsel.p[0];
+        std::vector<uint64_t> host(w.hsel.p, w.hsel.p + 2 + 2 * (size_t)std::min<int64_t>(cnt, first));
         if (cnt > w.cap) {                     // many exact ties: grow and compact again
             w.cap = cnt + 1024;
             MIH_TRY(w.sel.alloc(2 + 2 * (size_t)w.cap));
