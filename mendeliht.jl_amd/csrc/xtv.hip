@@ -526,6 +526,7 @@ static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 
         const int mv = g_xtv_multi_variant;
         MIH_LDS(1, 0, 1, 4, 0, 8)
         MIH_LDS(1, 10, 1, 2, 0, 8) MIH_LDS(1, 11, 1, 6, 0, 8) MIH_LDS(1, 12, 1, 2, 0, 16) MIH_LDS(1, 13, 2, 4, 0, 8) MIH_LDS(1, 14, 4, 2, 0, 8)
+        MIH_LDS(1, 15, 1, 4, 1, 8)                        // timing probe: loads only, no MFMAs (result is NOT X'r)
         { MIH_LDS(1, mv, 1, 4, 0, 8) }                    // multi-operand variant ids fall back to the default shape
     }
 #undef MIH_LDS
@@ -655,7 +656,7 @@ int mih_set_xtv_digits(int digits)
 
 int mih_set_xtv_multi_variant(int variant)
 {
-    if (variant < 0 || variant > 14) { set_error("multi-RHS variant %d out of range", variant); return MIH_BAD_ARG; }
+    if (variant < 0 || variant > 15) { set_error("multi-RHS variant %d out of range", variant); return MIH_BAD_ARG; }
     g_xtv_multi_variant = variant;
     return MIH_OK;
 }

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mendeliht_amd as m
 x = m.SnpLinAlg.synthetic(500_000, 1_000_000, seed=2024)
 B = x.algorithmic_bytes(1)
-for mv in (0, 10, 11, 12, 13, 14):
+for mv in (0, 10, 11, 12, 13, 14, 15):        # 15 = load-only probe (no MFMAs): the memory ceiling of this access shape
     m.lib().mih_set_xtv_multi_variant(mv)
     ms, cs = x.bench_xtv_batched(1, max_fused=4, iters=5, warmup=1)
     print(f"LDS shape {mv:2d}: {ms:7.3f} ms  {B / ms / 1e6:6.0f} GB/s  checksum {cs:.12e}", flush=True)
