@@ -188,6 +188,14 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y,
                double *mses_raw);
 int mih_cv_meanloss(const double *mses_raw, const int32_t *folds, int64_t n, int32_t nfolds,
                     int64_t npath, double *mse_out);
+/* The same cross-validation driven from ONE process over several GPUs, the way the reference drives it
+ * from several threads of one Julia process (Threads.@threads over the (fold,k) combinations on a shared x,
+ * cross_validation.jl:100-112): hs[g] is a replica of the matrix on GPU g (they may also share a device),
+ * one host thread per replica evaluates the combinations with index % nrep == g, and mses_raw receives the
+ * complete nfolds x npath matrix (no separate reduction step). */
+int mih_cv_iht_multi(const mih_mat *const *hs, int32_t nrep, const mih_fit_params *prm, const double *y,
+                     const double *z, int64_t q, const int32_t *folds, int32_t nfolds,
+                     const int64_t *path, int64_t npath, double *mses_raw);
 
 /* ---- multivariate Gaussian IHT (src/multivariate.jl) ------------------------ */
 typedef struct mih_mv_result {

@@ -109,6 +109,7 @@ def lib():
         "mih_fit_iht": [vp, C.POINTER(_FitParams), vp, vp, i64, vp, C.POINTER(_FitResult)],
         "mih_cv_iht": [vp, C.POINTER(_FitParams), vp, vp, i64, vp, i32, vp, i64, i32, i32, vp],
         "mih_cv_meanloss": [vp, vp, i64, i32, i64, vp],
+        "mih_cv_iht_multi": [vp, i32, C.POINTER(_FitParams), vp, vp, i64, vp, i32, vp, i64, vp],
         "mih_fit_mv": [vp, C.POINTER(_FitParams), vp, i64, vp, i64, vp, C.POINTER(_MvResult)],
         "mih_cv_mv": [vp, C.POINTER(_FitParams), vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, vp],
         "mih_bench_xtv": [vp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_float), C.POINTER(dbl)],
@@ -139,7 +140,7 @@ def exported_symbols():
             "mih_snp_create_synthetic_shard",
             "mih_dense_create", "mih_dense_create_synthetic", "mih_mat_destroy", "mih_mat_dims",
             "mih_snp_mu_sigma", "mih_snp_export_bed", "mih_xtv", "mih_xtv_batched", "mih_xv_sparse",
-            "mih_project_topk", "mih_project_group_sparse", "mih_fit_iht", "mih_cv_iht", "mih_cv_meanloss",
+            "mih_project_topk", "mih_project_group_sparse", "mih_fit_iht", "mih_cv_iht", "mih_cv_meanloss", "mih_cv_iht_multi",
             "mih_fit_mv", "mih_cv_mv", "mih_bench_xtv", "mih_bench_xtv_batched", "mih_xtv_algorithmic_bytes", "mih_set_xtv_variant",
             "mih_set_xtv_multi_variant", "mih_set_xtv_digits", "mih_abi_sizes",
             "mih_session_create", "mih_session_step", "mih_session_model", "mih_session_destroy",
@@ -737,10 +738,20 @@ def cv_iht(y, x, z=None, *, d=None, l=None, path=range(1, 21), q=5, est_r="None"
            memory_efficient=True, tol=1e-4, max_step=3, rank=0, world=1, reduce=None, return_raw=False):
     """cv_iht(y, x, z; path, q, folds, ...) -- src/cross_validation.jl:60-131.
 
+    `x` may be a list of replicas of the matrix (one per GPU): the combinations are then spread over them
+    from this one process (mih_cv_iht_multi), as the reference spreads them over its threads.
     `rank`/`world` shard the (fold, k) combinations over processes (one GPU each); `reduce`
     is a callable that sum-reduces the raw q x len(path) loss matrix across ranks (see
     mendeliht.jl_amd.dist.cv_iht_distributed for the torch.distributed/RCCL version).
     """
+    replicas = None
+    if isinstance(x, (list, tuple)):                 # one replica of the matrix per GPU, driven from this process
+        replicas = [_as_mat(r) for r in x]
+        if not replicas:
+            raise ArgumentError("empty list of matrix replicas")
+        x = replicas[0]
+        if world != 1:
+            raise ArgumentError("pass either a list of replicas (one process, several GPUs) or rank/world (one process per GPU)")
     x = _as_mat(x)
     mv = _is_multivariate(y)
     d = _inst(d) if d is not None else (MvNormal() if mv else Normal())
@@ -749,6 +760,8 @@ def cv_iht(y, x, z=None, *, d=None, l=None, path=range(1, 21), q=5, est_r="None"
         raise ArgumentError("the GPU path is always memory_efficient=true")
     if debias and mv:
         raise ArgumentError("debias is disabled for multivariate traits (multivariate.jl:569-570)")
+    if replicas is not None and mv:
+        raise ArgumentError("replica lists are supported for univariate cross-validation")
     if init_beta and not isinstance(d, (Normal, MvNormal)):
         raise ArgumentError("Intializing beta values only work for Gaussian phenotypes! Sorry!")
     path = np.ascontiguousarray(list(path), dtype=np.int64)
@@ -782,8 +795,13 @@ def cv_iht(y, x, z=None, *, d=None, l=None, path=range(1, 21), q=5, est_r="None"
         _checky(yv, d)
         prm = _params(1, 1, d, l, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, zz.shape[1], x.p, keep,
                       init_beta=init_beta, debias=debias)
-        _check(lib().mih_cv_iht(x._h, C.byref(prm), _p(yv), _p(zz), zz.shape[1], _p(folds), q, _p(path), path.size,
-                                rank, world, _p(raw)))
+        if replicas is not None:
+            hs = (C.c_void_p * len(replicas))(*[r._h for r in replicas])
+            _check(lib().mih_cv_iht_multi(hs, len(replicas), C.byref(prm), _p(yv), _p(zz), zz.shape[1], _p(folds), q,
+                                          _p(path), path.size, _p(raw)))
+        else:
+            _check(lib().mih_cv_iht(x._h, C.byref(prm), _p(yv), _p(zz), zz.shape[1], _p(folds), q, _p(path), path.size,
+                                    rank, world, _p(raw)))
     if reduce is not None:
         raw = reduce(raw)
     mse = np.zeros(path.size)

@@ -16,6 +16,8 @@
 #include <cmath>
 #include <limits>
 #include <memory>
+#include <string>
+#include <thread>
 
 namespace mih {
 
@@ -1255,6 +1257,32 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, con
         }
         MIH_TRY(cv_run_batch(h, pr, fits, xw, R, DF, s, mses_raw));
     }
+    return MIH_OK;
+}
+
+int mih_cv_iht_multi(const mih_mat *const *hs, int32_t nrep, const mih_fit_params *prm, const double *y,
+                     const double *z, int64_t q, const int32_t *folds, int32_t nfolds,
+                     const int64_t *path, int64_t npath, double *mses_raw)
+{
+    if (!hs || nrep < 1 || !mses_raw || nfolds < 1 || npath < 1) { set_error("null/invalid argument"); return MIH_BAD_ARG; }
+    for (int g = 0; g < nrep; ++g) {
+        if (!hs[g]) { set_error("replica %d is NULL", g); return MIH_BAD_ARG; }
+        if (hs[g]->n != hs[0]->n || hs[g]->p != hs[0]->p) { set_error("replica %d has different dimensions", g); return MIH_BAD_DIM; }
+    }
+    const size_t cells = (size_t)nfolds * (size_t)npath;
+    std::vector<std::vector<double>> part(nrep, std::vector<double>(cells, 0.0));
+    std::vector<int> rcs(nrep, MIH_OK);
+    std::vector<std::string> msgs(nrep);
+    std::vector<std::thread> th;
+    for (int g = 0; g < nrep; ++g)
+        th.emplace_back([&, g]() {
+            rcs[g] = mih_cv_iht(hs[g], prm, y, z, q, folds, nfolds, path, npath, g, nrep, part[g].data());
+            if (rcs[g]) { char buf[512]; (void)mih_last_error(buf, sizeof(buf)); msgs[g] = buf; }   // the error text is thread-local
+        });
+    for (auto &t : th) t.join();
+    for (int g = 0; g < nrep; ++g)
+        if (rcs[g]) { set_error("replica %d: %s", g, msgs[g].c_str()); return rcs[g]; }
+    for (size_t i = 0; i < cells; ++i) { double s = 0.0; for (int g = 0; g < nrep; ++g) s += part[g][i]; mses_raw[i] = s; }
     return MIH_OK;
 }
 

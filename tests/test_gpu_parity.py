@@ -824,3 +824,22 @@ def test_large_k_and_many_covariates(mih, oracle, normal_pair, normal_data):
     assert res.c[5] != 0 and res.c[17] != 0                      # the two real covariate effects survive the projection
     with pytest.raises(mih.MendelIHTError):
         mih.fit_iht(y, x, np.ones((n, 65)), k=3, verbose=False)
+
+
+def test_cv_iht_over_replicas_in_one_process(mih, normal_data):
+    """mih_cv_iht_multi: one host thread per matrix replica (one per GPU; here both on the single test GPU),
+    the (fold,k) grid split between them -- same losses as the single-replica call."""
+    n = normal_data["n"]
+    bed = mih.read_bed(normal_data["bed"], n)
+    xa = mih.SnpLinAlg(bed, n, center=True, scale=True, impute=True)
+    xb = mih.SnpLinAlg(bed, n, center=True, scale=True, impute=True)
+    y, z = normal_data["y"], normal_data["z"]
+    folds = hash_folds(n, 3)
+    path = list(range(1, 9))
+    one, raw1 = mih.cv_iht(y, xa, z, path=path, q=3, folds=folds, verbose=False, return_raw=True)
+    two, raw2 = mih.cv_iht(y, [xa, xb], z, path=path, q=3, folds=folds, verbose=False, return_raw=True)
+    assert np.array_equal(raw1, raw2) and np.array_equal(one, two)
+    three = mih.cv_iht(y, [xa, xb, xa], z, path=path, q=3, folds=folds, verbose=False, d=mih.Normal())
+    assert np.array_equal(three, one)
+    with pytest.raises(mih.MendelIHTError):
+        mih.cv_iht(y, [xa, mih.SnpLinAlg(bed[:100], n, center=True, scale=True)], z, path=path, q=3, folds=folds, verbose=False)
