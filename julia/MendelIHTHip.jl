@@ -143,4 +143,24 @@ function cv_iht(y::AbstractVector{Float64}, x::HipSnpLinAlg{Float64}, z::Abstrac
     return mse
 end
 
+# cv_iht over several GPUs from this one process: xs[g] is a replica of the matrix on GPU g-1
+function cv_iht(y::AbstractVector{Float64}, xs::Vector{HipSnpLinAlg{Float64}}, z::AbstractVecOrMat{Float64};
+        d::UnivariateDistribution=Normal(), l::Link=IdentityLink(), path::AbstractVector{<:Integer}=1:20,
+        q::Int=5, folds::AbstractVector{Int}=rand(1:q, size(xs[1], 1)), max_iter::Int=100, min_iter::Int=5, kwargs...)
+    nz = size(z, 2)
+    f32 = Vector{Int32}(folds); pth = Vector{Int64}(path)
+    raw = zeros(q * length(pth)); mse = zeros(length(pth))
+    hs = [x.handle for x in xs]
+    prm = MihFitParams(1, 1, distcode(d), linkcode(l), d isa NegativeBinomial ? d.r : 1.0, 1e-4,
+        max_iter, min_iter, 3, 0, C_NULL, C_NULL, C_NULL, C_NULL, 0, C_NULL, C_NULL, Int32(0), C_NULL,
+        Int32(get(kwargs, :debias, false)))
+    GC.@preserve xs check(ccall((:mih_cv_iht_multi, LIB), Cint,
+        (Ptr{Ptr{Cvoid}}, Int32, Ref{MihFitParams}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Int32}, Int32, Ptr{Int64},
+         Int64, Ptr{Float64}),
+        hs, length(hs), prm, y, z, nz, f32, q, pth, length(pth), raw))
+    check(ccall((:mih_cv_meanloss, LIB), Cint, (Ptr{Float64}, Ptr{Int32}, Int64, Int32, Int64, Ptr{Float64}),
+        raw, f32, length(folds), q, length(pth), mse))
+    return mse
+end
+
 end # module
