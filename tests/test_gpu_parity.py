@@ -843,3 +843,43 @@ def test_cv_iht_over_replicas_in_one_process(mih, normal_data):
     assert np.array_equal(three, one)
     with pytest.raises(mih.MendelIHTError):
         mih.cv_iht(y, [xa, mih.SnpLinAlg(bed[:100], n, center=True, scale=True)], z, path=path, q=3, folds=folds, verbose=False)
+
+
+def test_randomized_fits_vs_oracle(mih, oracle):
+    """A seeded sweep over shapes, missing rates, families, covariates, zkeep masks, prior weights, train masks
+    and k: the GPU fit must track the oracle (same support and iteration log) on every stable trajectory."""
+    rng = np.random.default_rng(20260)
+    fams = [("normal", "identity", mih.Normal, mih.IdentityLink, 1e-5), ("bernoulli", "logit", mih.Bernoulli, mih.LogitLink, 1e-4),
+            ("poisson", "log", mih.Poisson, mih.LogLink, 1e-4)]
+    checked = 0
+    for trial in range(14):
+        n = int(rng.integers(60, 2500)); p = int(rng.integers(40, 600)); k = int(rng.integers(1, 10))
+        miss = float(rng.choice([0.0, 0.02, 0.1])); q = int(rng.integers(1, 4))
+        od, ol, D, L, tol = fams[int(rng.integers(0, 3))]
+        cols = make_bed(rng, n, p, missing_rate=miss)
+        x = mih.SnpLinAlg(cols, n=n, center=True, scale=True, impute=True)
+        ox = oracle.Mat.from_bed_columns(cols, n)
+        z = np.column_stack([np.ones(n)] + [rng.standard_normal(n) for _ in range(q - 1)])
+        eta = 0.5 * _sim(oracle, ox, rng, min(k, 5)) + z @ (rng.standard_normal(q) * 0.3)
+        y = {"normal": eta + rng.standard_normal(n),
+             "bernoulli": (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float),
+             "poisson": rng.poisson(np.exp(np.clip(0.5 * eta, -3, 3))).astype(float)}[od]
+        kw = {}
+        if q > 1 and rng.random() < 0.5:
+            kw["zkeep"] = [1] + [int(v) for v in rng.integers(0, 2, q - 1)]
+        if rng.random() < 0.4:
+            kw["weight"] = rng.uniform(0.5, 2.0, p)
+        if rng.random() < 0.4:
+            kw["train"] = (rng.random(n) < 0.8).astype(np.uint8)
+        o = oracle.fit_iht(ox, y, z, k=k, dist=od, link=ol, max_iter=60, **kw)
+        res = mih.fit_iht(y, x, z, k=k, d=D(), l=L(), max_iter=60, verbose=False, **kw)
+        if o["bt_trace"].max(initial=0) >= 3:
+            continue                                  # chaotic trajectory (likelihood dropped after max_step backtracks)
+        tag = (trial, n, p, k, od, q, miss, sorted(kw))
+        assert res.iter == o["iter"], tag
+        assert np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"])), tag
+        np.testing.assert_allclose(res.beta, o["beta"], rtol=tol, atol=1e-10, err_msg=str(tag))
+        np.testing.assert_allclose(res.c, o["c"], rtol=tol, atol=1e-10, err_msg=str(tag))
+        assert res.logl == pytest.approx(o["logl"], rel=1e-8), tag
+        checked += 1
+    assert checked >= 8
