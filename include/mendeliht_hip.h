@@ -188,6 +188,13 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y,
                double *mses_raw);
 int mih_cv_meanloss(const double *mses_raw, const int32_t *folds, int64_t n, int32_t nfolds,
                     int64_t npath, double *mse_out);
+/* iht_run_many_models(y, x, z; path, ...) src/cross_validation.jl:232-273: fit_iht on the FULL data for every
+ * model size in path (no hold-out).  The fits advance in lock-step like the cross-validation fits (one fused
+ * multi-RHS X'r pass per round).  Entries with index % world == rank are fitted; logl_out[npath] (others 0),
+ * and optionally iter_out[npath], beta_out[npath*p], c_out[npath*q] (may be NULL). */
+int mih_fit_iht_path(const mih_mat *h, const mih_fit_params *prm, const double *y, const double *z,
+                     int64_t q, const int64_t *path, int64_t npath, int32_t rank, int32_t world,
+                     double *logl_out, int64_t *iter_out, double *beta_out, double *c_out);
 /* The same cross-validation driven from ONE process over several GPUs, the way the reference drives it
  * from several threads of one Julia process (Threads.@threads over the (fold,k) combinations on a shared x,
  * cross_validation.jl:100-112): hs[g] is a replica of the matrix on GPU g (they may also share a device),

@@ -109,6 +109,7 @@ def lib():
         "mih_fit_iht": [vp, C.POINTER(_FitParams), vp, vp, i64, vp, C.POINTER(_FitResult)],
         "mih_cv_iht": [vp, C.POINTER(_FitParams), vp, vp, i64, vp, i32, vp, i64, i32, i32, vp],
         "mih_cv_meanloss": [vp, vp, i64, i32, i64, vp],
+        "mih_fit_iht_path": [vp, C.POINTER(_FitParams), vp, vp, i64, vp, i64, i32, i32, vp, vp, vp, vp],
         "mih_cv_iht_multi": [vp, i32, C.POINTER(_FitParams), vp, vp, i64, vp, i32, vp, i64, vp],
         "mih_fit_mv": [vp, C.POINTER(_FitParams), vp, i64, vp, i64, vp, C.POINTER(_MvResult)],
         "mih_cv_mv": [vp, C.POINTER(_FitParams), vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, vp],
@@ -140,7 +141,7 @@ def exported_symbols():
             "mih_snp_create_synthetic_shard",
             "mih_dense_create", "mih_dense_create_synthetic", "mih_mat_destroy", "mih_mat_dims",
             "mih_snp_mu_sigma", "mih_snp_export_bed", "mih_xtv", "mih_xtv_batched", "mih_xv_sparse",
-            "mih_project_topk", "mih_project_group_sparse", "mih_fit_iht", "mih_cv_iht", "mih_cv_meanloss", "mih_cv_iht_multi",
+            "mih_project_topk", "mih_project_group_sparse", "mih_fit_iht", "mih_cv_iht", "mih_cv_meanloss", "mih_cv_iht_multi", "mih_fit_iht_path",
             "mih_fit_mv", "mih_cv_mv", "mih_bench_xtv", "mih_bench_xtv_batched", "mih_xtv_algorithmic_bytes", "mih_set_xtv_variant",
             "mih_set_xtv_multi_variant", "mih_set_xtv_digits", "mih_abi_sizes",
             "mih_session_create", "mih_session_step", "mih_session_model", "mih_session_destroy",
@@ -834,13 +835,24 @@ def iht_run_many_models(y, x, z=None, *, d=None, l=None, path=range(1, 21), est_
     for every model size in `path` (no hold-out), returns the loglikelihoods.  `parallel` (pmap in the
     reference) is accepted and ignored: the fits of one process run back to back on its GPU; `rank` /
     `world` shard `path` over processes and `reduce` sums the loglikelihood vector across them."""
-    path = [int(k) for k in path]
-    logl = np.zeros(len(path))
-    for i, k in enumerate(path):
-        if i % world != rank:
-            continue
-        logl[i] = fit_iht(y, x, z, J=1, k=k, d=d, l=l, est_r=est_r, group=group, weight=weight, use_maf=use_maf,
-                          debias=debias, verbose=False, max_iter=max_iter).logl
+    x = _as_mat(x)
+    if _is_multivariate(y):
+        raise ArgumentError("iht_run_many_models on the GPU path takes a univariate response")
+    d = _inst(d) if d is not None else Normal()
+    l = _inst(l) if l is not None else canonicallink(d)          # cross_validation.jl:237
+    path = np.ascontiguousarray([int(k) for k in path], dtype=np.int64)
+    yv = np.ascontiguousarray(np.asarray(y, dtype=np.float64).ravel())
+    n = x.n
+    zz = np.ones((n, 1)) if z is None else np.asarray(z, dtype=np.float64)
+    zz = np.asfortranarray(zz.reshape(zz.shape[0], -1))
+    if not (yv.size == n == zz.shape[0]):
+        raise DimensionMismatch(f"row dimension of y, x, and z ({yv.size}, {n}, {zz.shape[0]}) are not equal")
+    _checky(yv, d)
+    keep = []
+    prm = _params(1, 1, d, l, 1e-4, max_iter, 5, 3, est_r, None, weight, group, zz.shape[1], x.p, keep, debias=debias)
+    logl = np.zeros(path.size)
+    _check(lib().mih_fit_iht_path(x._h, C.byref(prm), _p(yv), _p(zz), zz.shape[1], _p(path), path.size, rank, world,
+                                  _p(logl), None, None, None))
     if reduce is not None:
         logl = reduce(logl)
     if verbose and rank == 0:

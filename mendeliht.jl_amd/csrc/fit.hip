@@ -1127,6 +1127,9 @@ struct CvFit {
     int iter = 1, nbt = 0;
     double next_logl = -std::numeric_limits<double>::infinity(), best = -std::numeric_limits<double>::infinity();
     bool done = false;
+    // iht_run_many_models mode (no hold-out): where to put the finished model instead of a held-out deviance
+    bool full_data = false;
+    double *logl_out = nullptr; int64_t *iter_out = nullptr; double *beta_out = nullptr, *c_out = nullptr;
 };
 
 static int cv_batched_xtv(const mih_mat *h, XtvWork &xw, std::vector<CvFit *> &fits, DevBuf<double> &R, DevBuf<double> &DF,
@@ -1146,6 +1149,18 @@ static int cv_finish(CvFit &f, double *mses_raw)
 {
     f.best = f.v->save_prev(f.next_logl, f.best);
     MIH_TRY(f.v->save_best_model());
+    if (f.full_data) {                                 // iht_run_many_models: the fitted model itself is the result
+        if (f.logl_out) *f.logl_out = f.best;
+        if (f.iter_out) *f.iter_out = f.iter;
+        if (f.beta_out) {
+            std::memset(f.beta_out, 0, sizeof(double) * (size_t)f.v->p);
+            for (size_t t = 0; t < f.v->best_b.idx.size(); ++t) f.beta_out[f.v->best_b.idx[t]] = f.v->best_b.val[t];
+        }
+        if (f.c_out) for (int l = 0; l < f.v->q; ++l) f.c_out[l] = f.v->best_c[l];
+        f.done = true;
+        f.v.reset();
+        return MIH_OK;
+    }
     MIH_TRY(f.v->set_weights(f.train.data(), 1));     // cv_wts <- test mask (cross_validation.jl:115-116)
     MIH_TRY(f.v->update_xb());                        // predict! (:279-286)
     double dev;
@@ -1160,7 +1175,7 @@ static int cv_run_batch(const mih_mat *h, const mih_fit_params &pr, std::vector<
                         DevBuf<double> &R, DevBuf<double> &DF, hipStream_t s, double *mses_raw)
 {
     std::vector<CvFit *> need;
-    for (auto &f : fits) { MIH_TRY(f.v->init_pre(f.train.data())); need.push_back(&f); }
+    for (auto &f : fits) { MIH_TRY(f.v->init_pre(f.train.empty() ? nullptr : f.train.data())); need.push_back(&f); }
     MIH_TRY(cv_batched_xtv(h, xw, need, R, DF, s));
     for (auto *f : need) MIH_TRY(f->v->init_post());
     for (;;) {
@@ -1256,6 +1271,71 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, con
             f.out_index = (int64_t)(fold - 1) * npath + ik;
         }
         MIH_TRY(cv_run_batch(h, pr, fits, xw, R, DF, s, mses_raw));
+    }
+    return MIH_OK;
+}
+
+int mih_fit_iht_path(const mih_mat *h, const mih_fit_params *prm, const double *y, const double *z, int64_t q,
+                     const int64_t *path, int64_t npath, int32_t rank, int32_t world,
+                     double *logl_out, int64_t *iter_out, double *beta_out, double *c_out)
+{
+    MIH_TRY(check_params(h, prm, q));
+    if (prm->comm) { set_error("model paths shard over the path entries (rank/world), not over columns"); return MIH_BAD_ARG; }
+    if (!y || !z || !path || !logl_out || npath < 1 || world < 1 || rank < 0 || rank >= world) { set_error("null/invalid argument"); return MIH_BAD_ARG; }
+    int64_t kmax = 0;
+    for (int64_t i = 0; i < npath; ++i) { if (path[i] < 0) { set_error("negative model size in path"); return MIH_BAD_ARG; } kmax = std::max(kmax, path[i]); }
+    MIH_HIP(hipSetDevice(h->device));
+    for (int64_t i = 0; i < npath; ++i) {
+        logl_out[i] = 0.0;
+        if (iter_out) iter_out[i] = 0;
+        if (c_out) for (int64_t l = 0; l < q; ++l) c_out[i * q + l] = 0.0;
+    }
+    mih_fit_params pr = *prm;
+    pr.progress = nullptr;
+    std::vector<int64_t> mine;
+    for (int64_t i = 0; i < npath; ++i) if (i % world == rank) mine.push_back(i);
+    if (mine.empty()) return MIH_OK;
+    auto slots = [&](CvFit &f, int64_t i) {
+        f.full_data = true; f.logl_out = logl_out + i; f.iter_out = iter_out ? iter_out + i : nullptr;
+        f.beta_out = beta_out ? beta_out + (size_t)i * h->p : nullptr; f.c_out = c_out ? c_out + (size_t)i * q : nullptr;
+    };
+    if (prm->est_r != MIH_ESTR_NONE || prm->init_beta || prm->debias) {      // not batched: one fit after the other
+        for (int64_t i : mine) {
+            mih_fit_params pf = pr; pf.k = path[i];
+            CvFit f; slots(f, i);
+            f.v.reset(new IhtVar());
+            MIH_TRY(f.v->create(h, &pf, y, z, q));
+            MIH_TRY(f.v->init(nullptr));
+            int64_t it = 0;
+            MIH_TRY(f.v->fit_loop(&pf, &f.best, &it, nullptr, nullptr, nullptr, nullptr));
+            // fit_loop already saved the best model: publish it
+            if (f.logl_out) *f.logl_out = f.best;
+            if (f.iter_out) *f.iter_out = it;
+            if (f.beta_out) { std::memset(f.beta_out, 0, sizeof(double) * (size_t)h->p); for (size_t t = 0; t < f.v->best_b.idx.size(); ++t) f.beta_out[f.v->best_b.idx[t]] = f.v->best_b.val[t]; }
+            if (f.c_out) for (int l = 0; l < (int)q; ++l) f.c_out[l] = f.v->best_c[l];
+        }
+        return MIH_OK;
+    }
+    const int kMaxBatch = 16;
+    const int mb = (int)std::min<size_t>(mine.size(), kMaxBatch);
+    hipStream_t s = nullptr;
+    MIH_HIP(hipStreamCreate(&s));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{s};
+    XtvWork xw; DevBuf<double> R, DF;
+    MIH_TRY(xtv_work_init(h, xw, mb));
+    MIH_TRY(R.alloc((size_t)mb * h->n));
+    MIH_TRY(DF.alloc((size_t)mb * h->p));
+    for (size_t start = 0; start < mine.size(); start += mb) {
+        size_t end = std::min(mine.size(), start + mb);
+        std::vector<CvFit> fits(end - start);
+        for (size_t t = start; t < end; ++t) {
+            CvFit &f = fits[t - start];
+            mih_fit_params pf = pr; pf.k = path[mine[t]];
+            slots(f, mine[t]);
+            f.v.reset(new IhtVar());
+            MIH_TRY(f.v->create(h, &pf, y, z, q, s));
+        }
+        MIH_TRY(cv_run_batch(h, pr, fits, xw, R, DF, s, nullptr));
     }
     return MIH_OK;
 }

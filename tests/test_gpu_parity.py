@@ -591,6 +591,13 @@ def test_iht_run_many_models(mih, oracle, normal_pair, normal_data, capsys):
     assert np.all(np.diff(ll) > 0)                                   # more predictors, no hold-out: logl grows
     halves = [mih.iht_run_many_models(y, x, z, path=path, verbose=False, rank=r, world=2) for r in range(2)]
     assert np.array_equal(halves[0] + halves[1], ll)                 # sharding over ranks
+    # the sequential branch (debias is not batched) and a GLM family through the lock-step branch
+    lld = mih.iht_run_many_models(y, x, z, path=[3, 7], debias=True, verbose=False)
+    np.testing.assert_allclose(lld, [oracle.fit_iht(ox, y, z, k=k, max_iter=100, debias=True)["logl"] for k in (3, 7)], rtol=1e-9)
+    rng = np.random.default_rng(4)
+    yb = (rng.random(x.n) < 0.5).astype(float)
+    llb = mih.iht_run_many_models(yb, x, None, path=[2, 5], d=mih.Bernoulli, verbose=False)     # canonical link
+    np.testing.assert_allclose(llb, [oracle.fit_iht(ox, yb, None, k=k, max_iter=100, dist="bernoulli", link="logit")["logl"] for k in (2, 5)], rtol=1e-8)
 
 
 def test_concurrent_fits_share_one_matrix(mih, normal_pair, normal_data):
