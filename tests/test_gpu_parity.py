@@ -577,6 +577,14 @@ def test_full_size_baseline_config_p1M(mih, oracle):
     last = x.xv_sparse(idx[3:], val[3:])
     assert rel(xb - last, ox.xv_masked(mask, coef)) < 1e-10
     assert abs(last.mean()) < 1e-9 * (1 + np.abs(last).max())      # a standardized column has mean 0
+    mih.set_xtv_digits(16)                                          # the opt-in fast mode at full size
+    try:
+        f1 = x.xtv(r1)
+        F5 = x.xtv(R)
+    finally:
+        mih.set_xtv_digits(28)
+    assert np.max(np.abs(f1 - o1)) < 1e-8 * np.sqrt(n) * np.abs(r1).max()
+    assert np.array_equal(F5[:, 0], f1) and np.max(np.abs(F5 - O5)) < 1e-8 * np.sqrt(n) * np.abs(R).max()
 
 
 def test_iht_run_many_models(mih, oracle, normal_pair, normal_data, capsys):
