@@ -13,6 +13,7 @@
 #include <chrono>
 #include <cmath>
 #include <limits>
+#include <memory>
 
 namespace mih {
 
@@ -242,9 +243,13 @@ struct MvVar {
     int64_t nsamples = 0;
     bool choose_fired = false;
 
-    ~MvVar() { if (s) (void)hipStreamDestroy(s); }
+    bool own_stream = true;
+    ~MvVar() { if (s && own_stream) (void)hipStreamDestroy(s); }
 
-    int create(const mih_mat *hh, const mih_fit_params *prm, const double *Yh, int64_t rr, const double *Zh, int64_t qq)
+    // shared_stream != null: one of a lock-step batch (mih_cv_mv): it runs on the batch's stream and leaves the
+    // X'R pass to the batch driver
+    int create(const mih_mat *hh, const mih_fit_params *prm, const double *Yh, int64_t rr, const double *Zh, int64_t qq,
+               hipStream_t shared_stream = nullptr)
     {
         h = hh; n = h->n; p = h->p; r = (int)rr; q = (int)qq; k = prm->k; Y_host = Yh; Z_host = Zh; init_beta = prm->init_beta;
         if (r < 1 || r > kMaxR) { set_error("number of traits r=%d must be in 1..%d", r, kMaxR); return MIH_BAD_DIM; }
@@ -252,7 +257,8 @@ struct MvVar {
         zkeep.resize(q); int64_t zs = 0;
         for (int l = 0; l < q; ++l) { zkeep[l] = prm->zkeep ? (prm->zkeep[l] != 0) : 1; zs += zkeep[l]; }
         zkeepn = (int64_t)r * zs;
-        MIH_HIP(hipStreamCreate(&s));
+        if (shared_stream) { s = shared_stream; own_stream = false; }
+        else MIH_HIP(hipStreamCreate(&s));
         nb = (int)nblk(n);
         size_t rn = (size_t)r * n;
         MIH_TRY(Y.alloc(rn)); MIH_TRY(Z.alloc((size_t)q * n)); MIH_TRY(w.alloc(n)); MIH_TRY(BX.alloc(rn)); MIH_TRY(MU.alloc(rn));
@@ -261,7 +267,8 @@ struct MvVar {
         MIH_TRY(tmpn.alloc(n)); MIH_TRY(mask.alloc(n)); MIH_TRY(pairs.alloc(2 * (size_t)kMaxR * kMaxR));
         int64_t kcap = std::max<int64_t>(k + (int64_t)r * q, 64) + 1024;
         MIH_TRY(sidx.alloc(kcap)); MIH_TRY(sval.alloc(kcap)); MIH_TRY(gval.alloc((size_t)kcap * r));
-        MIH_TRY(xtv_work_init(h, xtv, r)); MIH_TRY(xv_work_init(h, xv, kcap)); MIH_TRY(topk_work_init(topk, kcap));
+        if (own_stream) MIH_TRY(xtv_work_init(h, xtv, r));
+        MIH_TRY(xv_work_init(h, xv, kcap)); MIH_TRY(topk_work_init(topk, kcap));
         // Y (r x n) and Z (q x n) column-major -> planes
         std::vector<double> pl(std::max(rn, (size_t)q * n));
         for (int64_t sidx_ = 0; sidx_ < n; ++sidx_) for (int i = 0; i < r; ++i) pl[(size_t)i * n + sidx_] = Yh[i + (size_t)r * sidx_];
@@ -360,11 +367,20 @@ struct MvVar {
         if (!lu_logdet_inverse(G, r, &lad, &sg, nullptr) || sg < 0) return std::numeric_limits<double>::quiet_NaN();
         return (double)nsamples / 2.0 * lad - 0.5 * tr;
     }
-    // score! (multivariate.jl:66-92)
+    // score! (multivariate.jl:66-92) = score_pre (T1 = Gamma * resid) ; DF = X' T1' ; score_post (df2 = T1 Z')
     int score()
     {
-        hipLaunchKernelGGL(k_mv_apply, dim3(nb), dim3(256), 0, s, RES.p, n, r, rmat(G), 0, (const double *)nullptr, T1.p, (double *)nullptr);
+        MIH_TRY(score_pre());
         MIH_TRY(xtv_device(h, xtv, T1.p, r, DF.p, s));
+        return score_post();
+    }
+    int score_pre()
+    {
+        hipLaunchKernelGGL(k_mv_apply, dim3(nb), dim3(256), 0, s, RES.p, n, r, rmat(G), 0, (const double *)nullptr, T1.p, (double *)nullptr);
+        return MIH_OK;
+    }
+    int score_post()
+    {
         std::vector<int32_t> pr;
         for (int l = 0; l < q; ++l) for (int i = 0; i < r; ++i) pr.push_back(i);
         size_t np_ = pr.size();
@@ -515,8 +531,14 @@ struct MvVar {
         for (int l = 0; l < q; ++l) { idc[l] = 0; for (int i = 0; i < r; ++i) if (C[i + r * l] != 0.0) idc[l] = 1; }
         return update_xb();
     }
-    // init_iht_indices!(v::mIHTVariable) (multivariate.jl:376-452)
+    // init_iht_indices!(v::mIHTVariable) (multivariate.jl:376-452) = init_pre ; X'R pass ; init_post
     int init(const uint8_t *train)
+    {
+        MIH_TRY(init_pre(train));
+        MIH_TRY(xtv_device(h, xtv, T1.p, r, DF.p, s));
+        return init_post();
+    }
+    int init_pre(const uint8_t *train)
     {
         if (k < 1) { set_error("Multivariate IHT requires k >= 1!"); return MIH_BAD_ARG; }
         B.clear(); B0.clear(); best_B.clear(); cols.clear(); dfcols.clear();
@@ -538,7 +560,11 @@ struct MvVar {
         MIH_HIP(hipMemsetAsync(BX.p, 0, sizeof(double) * (size_t)r * n, s));
         if (init_beta) MIH_TRY(init_beta_phase(train));
         MIH_TRY(resid_and_gram());                                   // update_mu!, update_resid!
-        MIH_TRY(score());
+        return score_pre();
+    }
+    int init_post()
+    {
+        MIH_TRY(score_post());
         if (init_beta) return gather_df_cols();      // the support stays the one project_k!(v) chose; df stays dense
         // vectorize!(full_b, df, df2); project_k!; unvectorize! (:438-440): df replaced by its projection
         hipLaunchKernelGGL(k_mv_full, dim3(nblk(p * r)), dim3(256), 0, s, DF.p, p, r, 1.0, full.p);
@@ -584,6 +610,13 @@ struct MvVar {
     }
     int one_step(double old_logl, int nstep, int *bt, double *new_logl)
     {
+        MIH_TRY(step_pre(old_logl, nstep, bt, new_logl));
+        MIH_TRY(xtv_device(h, xtv, T1.p, r, DF.p, s));
+        return step_post(*new_logl);
+    }
+    // everything of iht_one_step! before the X'R pass (ends with T1 = Gamma * resid)
+    int step_pre(double old_logl, int nstep, int *bt, double *new_logl)
+    {
         double eta;
         MIH_TRY(stepsize(&eta));
         MIH_TRY(gradstep(B, C, eta));
@@ -600,11 +633,15 @@ struct MvVar {
             logl = loglik();
             es++;
         }
-        MIH_TRY(score());
+        *bt = es; *new_logl = logl;
+        return score_pre();
+    }
+    int step_post(double logl)
+    {
+        MIH_TRY(score_post());
         MIH_TRY(gather_df_cols());
         if (std::isnan(logl)) { set_error("Loglikelihood function is NaN, aborting..."); return MIH_NAN_LOGL; }
         if (std::isinf(logl)) { set_error("Loglikelihood function is Inf, aborting..."); return MIH_INF_LOGL; }
-        *bt = es; *new_logl = logl;
         return MIH_OK;
     }
     int fit_loop(const mih_fit_params *prm, double *best_out, int64_t *iter_out, double *lt, double *tt, int32_t *btt, int32_t *ntrace)
@@ -695,35 +732,99 @@ int mih_cv_mv(const mih_mat *h, const mih_fit_params *prm, const double *Y, int6
 {
     MIH_TRY(mv_check(h, prm));
     if (!Y || !Z || !folds || !path || !mses_raw || nfolds < 1 || npath < 1 || world < 1 || rank < 0 || rank >= world) { set_error("null/invalid argument"); return MIH_BAD_ARG; }
-    int64_t n = h->n, kmax = 0;
-    for (int64_t i = 0; i < npath; ++i) kmax = std::max(kmax, path[i]);
+    if (r < 1 || r > kMaxR) { set_error("number of traits r=%lld must be in 1..%d", (long long)r, kMaxR); return MIH_BAD_DIM; }
+    int64_t n = h->n;
     for (int64_t i = 0; i < n; ++i) if (folds[i] < 1 || folds[i] > nfolds) { set_error("folds must be in 1..q"); return MIH_BAD_ARG; }
     MIH_HIP(hipSetDevice(h->device));
     for (int64_t i = 0; i < (int64_t)nfolds * npath; ++i) mses_raw[i] = 0.0;
     mih_fit_params pr = *prm;
-    pr.k = kmax; pr.progress = nullptr;
-    MvVar v;
-    MIH_TRY(v.create(h, &pr, Y, r, Z, q));
-    std::vector<uint8_t> train(n);
+    pr.progress = nullptr;
+    // this rank's combinations, fold-major (cross_validation.jl:217-223), advanced in lock-step batches: every
+    // round issues ONE fused X'R pass for the r traits of every fit that needs a score (as mih_cv_iht does)
+    std::vector<std::pair<int32_t, int64_t>> mine;
     int64_t combo = 0;
     for (int32_t fold = 1; fold <= nfolds; ++fold)
-        for (int64_t ik = 0; ik < npath; ++ik, ++combo) {
-            if (combo % world != rank) continue;
-            for (int64_t i = 0; i < n; ++i) train[i] = (folds[i] != fold);
-            v.k = path[ik];
-            MIH_TRY(v.init(train.data()));
-            double best; int64_t it;
-            MIH_TRY(v.fit_loop(&pr, &best, &it, nullptr, nullptr, nullptr, nullptr));
-            MIH_TRY(v.set_weights(train.data(), 1));
-            MIH_TRY(v.update_xb());                               // predict! (cross_validation.jl:288-299)
-            hipLaunchKernelGGL(k_mv_resid, dim3(v.nb), dim3(256), 0, v.s, v.Y.p, v.Z.p, v.BX.p, v.w.p, n, v.r, v.q, v.cmat(v.C), v.MU.p, v.RES.p);
-            hipLaunchKernelGGL(k_mv_mse, dim3(v.nb), dim3(256), 0, v.s, v.Y.p, v.MU.p, v.w.p, n, v.r, v.red.p);
-            hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, v.s, v.red.p, v.nb, 1, v.scal.p);
-            double mse = 0.0;
-            MIH_HIP(hipMemcpyAsync(&mse, v.scal.p, sizeof(double), hipMemcpyDeviceToHost, v.s));
-            MIH_HIP(hipStreamSynchronize(v.s));
-            mses_raw[(int64_t)(fold - 1) * npath + ik] = mse;
+        for (int64_t ik = 0; ik < npath; ++ik, ++combo)
+            if (combo % world == rank) mine.emplace_back(fold, ik);
+    if (mine.empty()) return MIH_OK;
+    const int rr = (int)r;
+    const int per_batch = std::max(1, 16 / rr);
+    const int mb = (int)std::min<size_t>(mine.size(), (size_t)per_batch);
+    hipStream_t s = nullptr;
+    MIH_HIP(hipStreamCreate(&s));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{s};
+    XtvWork xw; DevBuf<double> R, DF;
+    MIH_TRY(xtv_work_init(h, xw, mb * rr));
+    MIH_TRY(R.alloc((size_t)mb * rr * n));
+    MIH_TRY(DF.alloc((size_t)mb * rr * h->p));
+    struct MvFit {
+        std::unique_ptr<MvVar> v; std::vector<uint8_t> train; int64_t out_index = 0; int iter = 1, nbt = 0;
+        double next_logl = -std::numeric_limits<double>::infinity(), best = -std::numeric_limits<double>::infinity();
+        bool done = false;
+    };
+    auto batched_xtv = [&](std::vector<MvFit *> &need) -> int {
+        const int m = (int)need.size();
+        if (m == 0) return MIH_OK;
+        for (int t = 0; t < m; ++t)
+            MIH_HIP(hipMemcpyAsync(R.p + (size_t)t * rr * n, need[t]->v->T1.p, sizeof(double) * (size_t)rr * n, hipMemcpyDeviceToDevice, s));
+        MIH_TRY(xtv_device(h, xw, R.p, m * rr, DF.p, s));
+        for (int t = 0; t < m; ++t)
+            MIH_HIP(hipMemcpyAsync(need[t]->v->DF.p, DF.p + (size_t)t * rr * h->p, sizeof(double) * (size_t)rr * h->p, hipMemcpyDeviceToDevice, s));
+        return MIH_OK;
+    };
+    auto finish = [&](MvFit &f) -> int {
+        MvVar &v = *f.v;
+        f.best = v.save_prev(f.next_logl, f.best);
+        MIH_TRY(v.save_best_model());
+        MIH_TRY(v.set_weights(f.train.data(), 1));
+        MIH_TRY(v.update_xb());                               // predict! (cross_validation.jl:288-299)
+        hipLaunchKernelGGL(k_mv_resid, dim3(v.nb), dim3(256), 0, v.s, v.Y.p, v.Z.p, v.BX.p, v.w.p, n, v.r, v.q, v.cmat(v.C), v.MU.p, v.RES.p);
+        hipLaunchKernelGGL(k_mv_mse, dim3(v.nb), dim3(256), 0, v.s, v.Y.p, v.MU.p, v.w.p, n, v.r, v.red.p);
+        hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, v.s, v.red.p, v.nb, 1, v.scal.p);
+        double mse = 0.0;
+        MIH_HIP(hipMemcpyAsync(&mse, v.scal.p, sizeof(double), hipMemcpyDeviceToHost, v.s));
+        MIH_HIP(hipStreamSynchronize(v.s));
+        mses_raw[f.out_index] = mse;
+        f.done = true;
+        f.v.reset();
+        return MIH_OK;
+    };
+    for (size_t start = 0; start < mine.size(); start += mb) {
+        size_t end = std::min(mine.size(), start + mb);
+        std::vector<MvFit> fits(end - start);
+        std::vector<MvFit *> need;
+        for (size_t t = start; t < end; ++t) {
+            MvFit &f = fits[t - start];
+            mih_fit_params pf = pr; pf.k = path[mine[t].second];          // v.k = sparsity (cross_validation.jl:110)
+            f.v.reset(new MvVar());
+            MIH_TRY(f.v->create(h, &pf, Y, r, Z, q, s));
+            f.train.resize(n);
+            for (int64_t i = 0; i < n; ++i) f.train[i] = (folds[i] != mine[t].first);
+            f.out_index = (int64_t)(mine[t].first - 1) * npath + mine[t].second;
+            MIH_TRY(f.v->init_pre(f.train.data()));
+            need.push_back(&f);
         }
+        MIH_TRY(batched_xtv(need));
+        for (auto *f : need) MIH_TRY(f->v->init_post());
+        for (;;) {
+            need.clear();
+            for (auto &f : fits) {
+                if (f.done) continue;
+                if (f.iter >= pr.max_iter) { MIH_TRY(finish(f)); continue; }                  // fit.jl:170-179
+                f.best = f.v->save_prev(f.next_logl, f.best);
+                MIH_TRY(f.v->step_pre(f.next_logl, pr.max_step, &f.nbt, &f.next_logl));
+                need.push_back(&f);
+            }
+            if (need.empty()) break;
+            MIH_TRY(batched_xtv(need));
+            for (auto *f : need) {
+                MIH_TRY(f->v->step_post(f->next_logl));
+                double sc = f->v->check_convergence();
+                if (f->iter >= pr.min_iter && sc < pr.tol) MIH_TRY(finish(*f));                // fit.jl:197-203
+                else f->iter++;
+            }
+        }
+    }
     return MIH_OK;
 }
 
