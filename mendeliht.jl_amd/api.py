@@ -905,7 +905,7 @@ def iht(plinkfile, k, d, *, phenotypes=6, covariates="", summaryfile="iht.summar
     if _is_multivariate(y):
         result = fit_iht(y, x, z.T, k=k, d=d, **kwargs)
     else:
-        l = kwargs.pop("l", None) or {1: LogitLink(), 2: LogLink(), 3: LogLink()}.get(d.code, IdentityLink())
+        l = kwargs.pop("l", None) or canonicallink(d)     # wrapper.jl:87 (LogLink for NegativeBinomial, else canonical)
         result = fit_iht(y, x, z, k=k, d=d, l=l, **kwargs)
     if summaryfile:
         with open(summaryfile, "w") as f:
@@ -926,7 +926,7 @@ def cross_validate(plinkfile, d, *, path=range(1, 21), q=5, phenotypes=6, covari
     if _is_multivariate(y):
         mse = cv_iht(y, x, z.T, d=d, path=path, q=q, **kwargs)
     else:
-        l = kwargs.pop("l", None) or {1: LogitLink(), 2: LogLink(), 3: LogLink()}.get(d.code, IdentityLink())
+        l = kwargs.pop("l", None) or canonicallink(d)     # wrapper.jl:87 (LogLink for NegativeBinomial, else canonical)
         mse = cv_iht(y, x, z, d=d, l=l, path=path, q=q, **kwargs)
     if cv_summaryfile:
         with open(cv_summaryfile, "w") as f:
