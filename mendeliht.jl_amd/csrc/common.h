@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 #include "../../include/mendeliht_hip.h"
 
@@ -130,14 +131,27 @@ extern int g_xtv_variant;
 
 // ---- X[:,S] v -----------------------------------------------------------------
 struct XvWork {
-    DevBuf<double> partial;   // groups * n
+    DevBuf<double> partial;   // groups * n (dense matrices only)
     DevBuf<double> coefA, coefB;  // per support column: sinv*val, -mu*sinv*val
     int64_t cap = 0; int groups = 0;
+    // Column cache (2-bit matrices): in the tile-major layout a column shares every 64 B sector with its tile
+    // neighbours, so reading k support columns costs 4-8x their size.  The support changes slowly, so each
+    // column is copied ONCE into a contiguous slot (ndw dwords) and X*v reads the slots (LRU replacement).
+    DevBuf<uint32_t> cache;   // slots * ndw
+    DevBuf<int32_t>  slot_dev;
+    DevBuf<int64_t>  fill_dev;
+    int64_t slots = 0;
+    std::unordered_map<int64_t, int32_t> slot_of;
+    std::vector<int64_t> col_of;
+    std::vector<uint64_t> stamp;
+    uint64_t tick = 0;
+    std::vector<int32_t> h_slots; std::vector<int64_t> h_fills;   // host images of slot_dev / fill_dev of the last call
 };
 int  xv_work_init(const mih_mat *h, XvWork &w, int64_t max_nnz);
-// out[i] = sum_t x[i, idx[t]] * val[t]; idx/val on device; clamp20 applies clamp!(out,-20,20)
+// out[i] = sum_t x[i, idx[t]] * val[t]; idx/val on device; clamp20 applies clamp!(out,-20,20).  idx_host (the same
+// indices on the host) enables the column cache.
 int  xv_sparse_device(const mih_mat *h, XvWork &w, const int64_t *idx_dev, const double *val_dev,
-                      int64_t nnz, double *out_dev, int clamp20, hipStream_t s);
+                      int64_t nnz, double *out_dev, int clamp20, hipStream_t s, const int64_t *idx_host = nullptr);
 
 // ---- top-k --------------------------------------------------------------------
 struct TopkWork {

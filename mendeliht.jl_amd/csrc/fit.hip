@@ -509,11 +509,11 @@ struct IhtVar {
         int clamp = (dist != MIH_NORMAL);
         MIH_TRY(upload(b.idx, b.val));
         if (comm) {          // partial X_S b_S of the local support columns, summed over the shards, then the clamp
-            MIH_TRY(xv_sparse_device(h, xv, sidx.p, sval.p, (int64_t)b.idx.size(), xb.p, 0, s));
+            MIH_TRY(xv_sparse_device(h, xv, sidx.p, sval.p, (int64_t)b.idx.size(), xb.p, 0, s, b.idx.data()));
             MIH_TRY(allreduce_dev(xb.p, n, 0));
             if (clamp) hipLaunchKernelGGL(k_clamp_pm20, dim3(nblk(n)), dim3(256), 0, s, xb.p, n);
         } else
-        MIH_TRY(xv_sparse_device(h, xv, sidx.p, sval.p, (int64_t)b.idx.size(), xb.p, clamp, s));
+        MIH_TRY(xv_sparse_device(h, xv, sidx.p, sval.p, (int64_t)b.idx.size(), xb.p, clamp, s, b.idx.data()));
         hipLaunchKernelGGL(k_zmul, dim3(nblk(n)), dim3(256), 0, s, z.p, n, q, qvec(c), clamp, zc.p);
         return MIH_OK;
     }
@@ -890,7 +890,7 @@ struct IhtVar {
     int stepsize(double *eta)
     {
         MIH_TRY(upload(idx.idx, idx.val));
-        MIH_TRY(xv_sparse_device(h, xv, sidx.p, sval.p, (int64_t)idx.idx.size(), xgk.p, 0, s));
+        MIH_TRY(xv_sparse_device(h, xv, sidx.p, sval.p, (int64_t)idx.idx.size(), xgk.p, 0, s, idx.idx.data()));
         std::vector<double> d2(q);
         double numer = 0.0;
         for (size_t t = 0; t < idx.val.size(); ++t) numer += idx.val[t] * idx.val[t];

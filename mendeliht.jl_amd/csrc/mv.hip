@@ -326,7 +326,7 @@ struct MvVar {
                 MIH_HIP(hipMemcpyAsync(sval.p, coef.data(), sizeof(double) * nc, hipMemcpyHostToDevice, s));
                 MIH_HIP(hipStreamSynchronize(s));     // coef is reused by the next trait
             }
-            MIH_TRY(xv_sparse_device(h, xv, sidx.p, sval.p, nc, BX.p + (size_t)i * n, 0, s));
+            MIH_TRY(xv_sparse_device(h, xv, sidx.p, sval.p, nc, BX.p + (size_t)i * n, 0, s, cols.data()));
         }
         return MIH_OK;
     }
@@ -415,7 +415,7 @@ struct MvVar {
                 MIH_HIP(hipMemcpyAsync(sidx.p, cols.data(), sizeof(int64_t) * nc, hipMemcpyHostToDevice, s));
                 MIH_HIP(hipMemcpyAsync(sval.p, dfcols.data() + (size_t)i * nc, sizeof(double) * nc, hipMemcpyHostToDevice, s));
             }
-            MIH_TRY(xv_sparse_device(h, xv, sidx.p, sval.p, nc, T1.p + (size_t)i * n, 0, s));
+            MIH_TRY(xv_sparse_device(h, xv, sidx.p, sval.p, nc, T1.p + (size_t)i * n, 0, s, cols.data()));
         }
         pivoted_chol_triu(G, r);                                   // Gamma is left holding U (fit.jl:230-232 recomputes it)
         hipLaunchKernelGGL(k_mv_apply, dim3(nb), dim3(256), 0, s, T1.p, n, r, rmat(G), 1, w.p, (double *)nullptr, red.p);

@@ -7,6 +7,7 @@
 // plus +mu*sinv*v_t on the rows where column S_t is missing (imputed entries are 0
 // after centring).  HBM-bound on k columns of 2-bit data (k*ceil(n/4) bytes).
 #include "common.h"
+#include <algorithm>
 
 namespace mih {
 
@@ -54,6 +55,64 @@ k_xv_snp(const uint32_t *__restrict__ X, int64_t nbp, int64_t ndw, int64_t n,
     for (int s = 0; s < 16; ++s) part[g][d][s] = acc[s] + bsum;
     __syncthreads();
     // thread -> (dword dd, row s): sum the groups in order
+    const int dd = threadIdx.x >> 4, s = threadIdx.x & 15;
+    const int64_t i = (blockIdx.x * 16ll + dd) * 16 + s;
+    if (i < n) {
+        double a = 0.0;
+        for (int gg = 0; gg < groups; ++gg) a += part[gg][dd][s];
+        if (clamp20) a = a < -20.0 ? -20.0 : (a > 20.0 ? 20.0 : a);
+        out[i] = a;
+    }
+}
+
+// copy whole columns out of the tile-major matrix into contiguous cache slots; fills[e] = slot << 40 | column
+__global__ void __launch_bounds__(256)
+k_xv_fill(const uint32_t *__restrict__ X, int64_t nbp, int64_t ndw, const int64_t *__restrict__ fills,
+          uint32_t *__restrict__ cache)
+{
+    int64_t dw = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (dw >= ndw) return;
+    const int64_t f = fills[blockIdx.y], slot = f >> 40, col = f & ((1ll << 40) - 1);
+    cache[slot * ndw + dw] = X[xword(nbp, col, dw)];
+}
+// k_xv_snp reading the cached (contiguous) copies of the support columns: same sums in the same order
+__global__ void __launch_bounds__(256)
+k_xv_snp_cached(const uint32_t *__restrict__ cache, int64_t ndw, int64_t n, const int32_t *__restrict__ slots,
+                const double *__restrict__ A, const double *__restrict__ B, int64_t nnz, int groups, int clamp20,
+                double *__restrict__ out)
+{
+    __shared__ double part[kXvGroups][16][17];
+    const int g = threadIdx.x >> 4, d = threadIdx.x & 15;
+    const int64_t dw = blockIdx.x * 16ll + d;
+    const int64_t per = (nnz + groups - 1) / groups;
+    const int64_t t0 = g * per, t1 = (g < groups) ? (t0 + per < nnz ? t0 + per : nnz) : t0;
+    double acc[16];
+    #pragma unroll
+    for (int s = 0; s < 16; ++s) acc[s] = 0.0;
+    double bsum = 0.0;
+    if (dw < ndw) {
+        int64_t t = t0;
+        for (; t + 4 <= t1; t += 4) {             // four independent loads in flight (the loop is latency-bound otherwise)
+            uint32_t w4[4]; double a4[4];
+            #pragma unroll
+            for (int u = 0; u < 4; ++u) { w4[u] = cache[(int64_t)slots[t + u] * ndw + dw]; a4[u] = A[t + u]; bsum += B[t + u]; }
+            #pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                #pragma unroll
+                for (int s = 0; s < 16; ++s) acc[s] = fma((double)((w4[u] >> (2 * s)) & 3u), a4[u], acc[s]);
+            }
+        }
+        for (; t < t1; ++t) {
+            uint32_t w = cache[(int64_t)slots[t] * ndw + dw];
+            double a = A[t];
+            bsum += B[t];
+            #pragma unroll
+            for (int s = 0; s < 16; ++s) acc[s] = fma((double)((w >> (2 * s)) & 3u), a, acc[s]);
+        }
+    }
+    #pragma unroll
+    for (int s = 0; s < 16; ++s) part[g][d][s] = acc[s] + bsum;
+    __syncthreads();
     const int dd = threadIdx.x >> 4, s = threadIdx.x & 15;
     const int64_t i = (blockIdx.x * 16ll + dd) * 16 + s;
     if (i < n) {
@@ -124,11 +183,53 @@ int xv_work_init(const mih_mat *h, XvWork &w, int64_t max_nnz)
     MIH_TRY(w.coefA.alloc((size_t)max_nnz));
     MIH_TRY(w.coefB.alloc((size_t)max_nnz));
     w.cap = max_nnz;
+    if (h->kind == 0) {
+        const int64_t ndw = h->n_pad / 16;
+        int64_t want = 2 * max_nnz + 64;
+        const int64_t budget = (int64_t)(1ull << 31) / (ndw * 4);          // at most 2 GB of cached columns
+        if (want > budget) want = budget;
+        if (want >= max_nnz) {
+            MIH_TRY(w.cache.alloc((size_t)want * (size_t)ndw));
+            MIH_TRY(w.slot_dev.alloc((size_t)want));
+            MIH_TRY(w.fill_dev.alloc((size_t)want));
+            w.slots = want; w.col_of.assign((size_t)want, -1); w.stamp.assign((size_t)want, 0); w.slot_of.clear(); w.tick = 0;
+        }
+    }
     return MIH_OK;
 }
 
+// map the support columns to cache slots (LRU), queue the copies of the new ones; false: use the direct path
+static bool xv_cache_lookup(XvWork &w, const int64_t *idx_host, int64_t nnz, std::vector<int32_t> &slots, std::vector<int64_t> &fills)
+{
+    if (w.slots <= 0 || nnz > w.slots) return false;
+    w.tick++;
+    slots.resize((size_t)nnz); fills.clear();
+    std::vector<int64_t> miss;
+    for (int64_t t = 0; t < nnz; ++t) {
+        auto it = w.slot_of.find(idx_host[t]);
+        if (it != w.slot_of.end()) { slots[t] = it->second; w.stamp[it->second] = w.tick; }
+        else { slots[t] = -1; miss.push_back(t); }
+    }
+    if (miss.empty()) return true;
+    // victims: the least recently used slots not touched by this call
+    std::vector<int32_t> order;
+    for (int32_t sl = 0; sl < (int32_t)w.slots; ++sl) if (w.stamp[sl] != w.tick) order.push_back(sl);
+    if (order.size() < miss.size()) return false;
+    std::partial_sort(order.begin(), order.begin() + miss.size(), order.end(),
+                      [&](int32_t a, int32_t b) { return w.stamp[a] != w.stamp[b] ? w.stamp[a] < w.stamp[b] : a < b; });
+    for (size_t e = 0; e < miss.size(); ++e) {
+        const int32_t sl = order[e];
+        const int64_t t = miss[e], col = idx_host[t];
+        if (w.col_of[sl] >= 0) w.slot_of.erase(w.col_of[sl]);
+        w.col_of[sl] = col; w.slot_of[col] = sl; w.stamp[sl] = w.tick;
+        slots[t] = sl;
+        fills.push_back(((int64_t)sl << 40) | col);
+    }
+    return true;
+}
+
 int xv_sparse_device(const mih_mat *h, XvWork &w, const int64_t *idx_dev, const double *val_dev,
-                     int64_t nnz, double *out_dev, int clamp20, hipStream_t s)
+                     int64_t nnz, double *out_dev, int clamp20, hipStream_t s, const int64_t *idx_host)
 {
     if (nnz == 0) {
         MIH_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * (size_t)h->n, s));
@@ -147,6 +248,17 @@ int xv_sparse_device(const mih_mat *h, XvWork &w, const int64_t *idx_dev, const 
                            h->mu, h->sinv, h->center, h->scale, w.coefA.p, w.coefB.p);
         int64_t ndw = h->n_pad / 16;
         bool fix = h->impute && h->total_missing > 0;
+        std::vector<int32_t> &slots = w.h_slots; std::vector<int64_t> &fills = w.h_fills;
+        if (idx_host && h->p < (1ll << 40) && xv_cache_lookup(w, idx_host, nnz, slots, fills)) {
+            MIH_HIP(hipMemcpyAsync(w.slot_dev.p, slots.data(), sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, s));
+            if (!fills.empty()) {
+                MIH_HIP(hipMemcpyAsync(w.fill_dev.p, fills.data(), sizeof(int64_t) * fills.size(), hipMemcpyHostToDevice, s));
+                hipLaunchKernelGGL(k_xv_fill, dim3((unsigned)((ndw + 255) / 256), (unsigned)fills.size()), dim3(256), 0, s, h->X, h->nbp, ndw,
+                                   w.fill_dev.p, w.cache.p);
+            }
+            hipLaunchKernelGGL(k_xv_snp_cached, dim3((unsigned)((ndw + 15) / 16)), dim3(256), 0, s, w.cache.p, ndw, h->n,
+                               w.slot_dev.p, w.coefA.p, w.coefB.p, nnz, groups, fix ? 0 : clamp20, out_dev);
+        } else
         hipLaunchKernelGGL(k_xv_snp, dim3((unsigned)((ndw + 15) / 16)), dim3(256), 0, s, h->X, h->nbp, ndw, h->n,
                            idx_dev, w.coefA.p, w.coefB.p, nnz, groups, fix ? 0 : clamp20, out_dev);
         if (fix) {
