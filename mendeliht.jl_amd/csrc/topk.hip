@@ -20,7 +20,7 @@ __device__ __forceinline__ uint64_t abs_key(double v)
 // workgroup of k_hist with a ticket counter was measured SLOWER: the agent-scope fence it needs writes
 // back the XCD's L2 and cost ~30 us per pass, against ~5 us for this separate launch.)
 __global__ void __launch_bounds__(256)
-k_pick(uint32_t *__restrict__ hist, uint64_t *__restrict__ state, int shift)
+k_pick(uint32_t *__restrict__ hist, uint64_t *__restrict__ state, int shift, uint64_t *__restrict__ sel)
 {
     __shared__ uint64_t suf[257];      // suf[b] = sum of hist[b..255]
     __shared__ int chosen;
@@ -43,7 +43,7 @@ k_pick(uint32_t *__restrict__ hist, uint64_t *__restrict__ state, int shift)
         const int bin = chosen;
         state[0] = (shift == 56 ? 0ull : (state[0] << 8)) | (uint64_t)bin;
         state[1] = kth - suf[bin + 1];
-        if (shift == 0) state[2] = state[0];   // full 64-bit threshold key
+        if (shift == 0) { state[2] = state[0]; sel[0] = 0; sel[1] = 0; }   // full 64-bit threshold key; survivor counter
     }
 }
 
@@ -108,6 +108,7 @@ k_threshold(double *__restrict__ x, int64_t len, const uint64_t *__restrict__ st
 int topk_work_init(TopkWork &w, int64_t max_keep)
 {
     MIH_TRY(w.hist.alloc(256));
+    MIH_HIP(hipMemset(w.hist.p, 0, 256 * sizeof(uint32_t)));      // k_pick leaves the histogram zeroed after every pass
     MIH_TRY(w.state.alloc(4));
     w.expect = max_keep + 64;
     w.cap = max_keep + 1024;
@@ -119,11 +120,11 @@ int topk_work_init(TopkWork &w, int64_t max_keep)
 // threshold pass with the key already in state[2]: zero what is below, gather what survives.  The count
 // and the first `expect` pairs come back in ONE device-to-host copy (one host synchronisation).
 static int compact_device(double *x_dev, int64_t len, TopkWork &w, hipStream_t s,
-                          std::vector<int64_t> &idx_out, std::vector<double> &val_out)
+                          std::vector<int64_t> &idx_out, std::vector<double> &val_out, bool counter_cleared = false)
 {
     int grid = (int)std::min<int64_t>((len + 255) / 256, 2048);
     for (int attempt = 0; attempt < 2; ++attempt) {
-        MIH_HIP(hipMemsetAsync(w.sel.p, 0, 2 * sizeof(uint64_t), s));
+        if (!counter_cleared || attempt > 0) MIH_HIP(hipMemsetAsync(w.sel.p, 0, 2 * sizeof(uint64_t), s));
         hipLaunchKernelGGL(k_threshold, dim3(grid), dim3(256), 0, s, x_dev, len, w.state.p, w.sel.p, (uint32_t)w.cap);
         const int64_t first = std::min<int64_t>(w.expect, w.cap);
         MIH_HIP(hipMemcpyAsync(w.hsel.p, w.sel.p, sizeof(uint64_t) * (2 + 2 * (size_t)first), hipMemcpyDeviceToHost, s));
@@ -162,13 +163,12 @@ int topk_project_device(double *x_dev, int64_t len, int64_t k, TopkWork &w, hipS
     if (k <= 0 || k > len) { set_error("Attempted to project to sparsity level %lld (vector length %lld)", (long long)k, (long long)len); return MIH_BAD_ARG; }
     uint64_t st[4] = {0ull, (uint64_t)k, 0ull, 0ull};
     MIH_HIP(hipMemcpyAsync(w.state.p, st, sizeof(st), hipMemcpyHostToDevice, s));
-    MIH_HIP(hipMemsetAsync(w.hist.p, 0, 256 * sizeof(uint32_t), s));
     int grid = (int)std::min<int64_t>((len + 255) / 256, 512);     // <= 512 blocks: 256 global adds per block at the end
     for (int shift = 56; shift >= 0; shift -= 8) {
         hipLaunchKernelGGL(k_hist, dim3(grid), dim3(256), 0, s, x_dev, len, shift, w.state.p, w.hist.p);
-        hipLaunchKernelGGL(k_pick, dim3(1), dim3(256), 0, s, w.hist.p, w.state.p, shift);
+        hipLaunchKernelGGL(k_pick, dim3(1), dim3(256), 0, s, w.hist.p, w.state.p, shift, w.sel.p);
     }
-    return compact_device(x_dev, len, w, s, idx_out, val_out);
+    return compact_device(x_dev, len, w, s, idx_out, val_out, /*counter_cleared=*/true);
 }
 
 int collect_nonzero_device(double *x_dev, int64_t len, TopkWork &w, hipStream_t s,
