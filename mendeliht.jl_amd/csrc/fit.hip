@@ -524,6 +524,7 @@ struct IhtVar {
         hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, s, red.p, nb, 4, scal.p);
         MIH_HIP(hipMemcpyAsync(hpin.p, scal.p, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
         MIH_HIP(hipStreamSynchronize(s));
+        MIH_HIP(hipGetLastError());                  // a failed launch anywhere in this iteration's chain surfaces here
         const double o[4] = {hpin.p[0], hpin.p[1], hpin.p[2], hpin.p[3]};
         if (dev) *dev = o[0];
         if (logl) {

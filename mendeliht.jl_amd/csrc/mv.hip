@@ -344,6 +344,7 @@ struct MvVar {
         std::vector<double> g(np_);
         MIH_HIP(hipMemcpyAsync(g.data(), scal.p, sizeof(double) * np_, hipMemcpyDeviceToHost, s));
         MIH_HIP(hipStreamSynchronize(s));
+        MIH_HIP(hipGetLastError());                  // a failed launch anywhere in this iteration's chain surfaces here
         size_t t = 0;
         for (int a = 0; a < r; ++a) for (int b = a; b < r; ++b, ++t) { gram[a + r * b] = g[t]; gram[b + r * a] = g[t]; }
         return MIH_OK;
