@@ -898,3 +898,24 @@ def test_randomized_fits_vs_oracle(mih, oracle):
         assert res.logl == pytest.approx(o["logl"], rel=1e-8), tag
         checked += 1
     assert checked >= 8
+
+
+def test_error_paths_nan_loglikelihood_and_bad_arguments(mih, normal_pair, normal_data):
+    """fit.jl:259-260 (NaN/Inf loglikelihood aborts), fit.jl:87-94 argument errors, k > p."""
+    x, _ = normal_pair
+    y = normal_data["y"].copy()
+    y[7] = np.nan
+    with pytest.raises(mih.MendelIHTError, match="NaN|Inf"):
+        mih.fit_iht(y, x, None, k=5, verbose=False)
+    with pytest.raises(mih.MendelIHTError):
+        mih.fit_iht(normal_data["y"], x, None, k=5, tol=1e-20, verbose=False)           # tol must exceed eps
+    with pytest.raises(mih.MendelIHTError):
+        mih.fit_iht(normal_data["y"], x, None, k=5, max_iter=-1, verbose=False)
+    with pytest.raises(mih.MendelIHTError):
+        mih.fit_iht(normal_data["y"], x, None, k=5, est_r="MM", verbose=False)          # est_r needs NegativeBinomial
+    with pytest.raises(mih.MendelIHTError):
+        mih.fit_iht(normal_data["y"], x, None, k=x.p + 2, verbose=False)                # cannot project to more than p + q
+    with pytest.raises(mih.MendelIHTError):
+        mih.fit_iht(np.abs(normal_data["y"]), x, None, k=3, d=mih.Bernoulli(), l=mih.LogitLink(), verbose=False)   # checky
+    ok = mih.fit_iht(normal_data["y"], x, None, k=5, verbose=False)                     # the handle survives the failures
+    assert np.count_nonzero(ok.beta) == 5
