@@ -77,6 +77,10 @@ int mih_snp_create_synthetic_shard(int64_t n, int64_t p, int64_t col_offset, uin
                                    int device, mih_mat **out);
 /* Dense Float64 design matrix (the reference's `x::Matrix{Float64}` path), n x p column-major. */
 int mih_dense_create(const double *x, int64_t n, int64_t p, int device, mih_mat **out);
+/* `x::Matrix{Float32}` (test/L0_reg_test.jl:245, test/cv_iht_test.jl:41): the matrix is STORED in Float32 (half
+ * the HBM traffic of X'r); y, the model and every sum stay Float64, so results are at least as accurate as the
+ * reference's all-Float32 run. */
+int mih_dense_create_f32(const float *x, int64_t n, int64_t p, int device, mih_mat **out);
 int mih_dense_create_synthetic(int64_t n, int64_t p, uint64_t seed, int device, mih_mat **out);
 int mih_mat_destroy(mih_mat *h);
 int mih_mat_dims(const mih_mat *h, int64_t *n, int64_t *p);

@@ -97,6 +97,7 @@ def lib():
         "mih_snp_create_synthetic_shard": [i64, i64, i64, C.c_uint64, dbl, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
         "mih_dense_create": [vp, i64, i64, C.c_int, C.POINTER(vp)],
         "mih_dense_create_synthetic": [i64, i64, C.c_uint64, C.c_int, C.POINTER(vp)],
+        "mih_dense_create_f32": [vp, i64, i64, C.c_int, C.POINTER(vp)],
         "mih_mat_destroy": [vp],
         "mih_mat_dims": [vp, C.POINTER(i64), C.POINTER(i64)],
         "mih_snp_mu_sigma": [vp, vp, vp],
@@ -139,7 +140,7 @@ def exported_symbols():
     """Every symbol include/mendeliht_hip.h declares (checked by the CPU test-suite)."""
     return ["mih_device_count", "mih_last_error", "mih_version", "mih_snp_create", "mih_snp_create_synthetic",
             "mih_snp_create_synthetic_shard",
-            "mih_dense_create", "mih_dense_create_synthetic", "mih_mat_destroy", "mih_mat_dims",
+            "mih_dense_create", "mih_dense_create_synthetic", "mih_dense_create_f32", "mih_mat_destroy", "mih_mat_dims",
             "mih_snp_mu_sigma", "mih_snp_export_bed", "mih_xtv", "mih_xtv_batched", "mih_xv_sparse",
             "mih_project_topk", "mih_project_group_sparse", "mih_fit_iht", "mih_cv_iht", "mih_cv_meanloss", "mih_cv_iht_multi", "mih_fit_iht_path",
             "mih_fit_mv", "mih_cv_mv", "mih_bench_xtv", "mih_bench_xtv_batched", "mih_xtv_algorithmic_bytes", "mih_set_xtv_variant",
@@ -377,20 +378,28 @@ class SnpLinAlg(_Mat):
 
 
 class DenseMatrix(_Mat):
-    """The reference's `x::Matrix{Float64}` design matrix, resident in HBM."""
+    """The reference's `x::Matrix{Float64}` / `x::Matrix{Float32}` design matrix, resident in HBM.  A float32 input
+    is stored as Float32 on the device (half the memory traffic); all arithmetic stays Float64."""
 
     def __init__(self, x, device=0, _handle=None):
         super().__init__()
         self.device = device
+        self.dtype = np.float64
         if _handle is not None:
             self._h = _handle
             self._dims()
             return
-        x = np.asfortranarray(x, dtype=np.float64)
+        x = np.asarray(x)
         if x.ndim != 2:
             raise DimensionMismatch("x must be a matrix")
         h = C.c_void_p(None)
-        _check(lib().mih_dense_create(_p(x), x.shape[0], x.shape[1], device, C.byref(h)))
+        if x.dtype == np.float32:
+            x = np.asfortranarray(x)
+            self.dtype = np.float32
+            _check(lib().mih_dense_create_f32(_p(x), x.shape[0], x.shape[1], device, C.byref(h)))
+        else:
+            x = np.asfortranarray(x, dtype=np.float64)
+            _check(lib().mih_dense_create(_p(x), x.shape[0], x.shape[1], device, C.byref(h)))
         self._h = h
         self._dims()
 

@@ -97,7 +97,8 @@ struct mih_mat {
     int64_t  *miss_ptr = nullptr;  // p+1
     int32_t  *miss_row = nullptr;  // total_missing
     int64_t   total_missing = 0;
-    double   *D = nullptr;         // dense n x p
+    double   *D = nullptr;         // dense n x p (Float64 storage)
+    float    *Df = nullptr;        // dense n x p (Float32 storage: `x::Matrix{Float32}`; arithmetic stays f64)
     hipStream_t stream = nullptr;  // for the stand-alone linear-algebra entry points
 };
 

@@ -45,10 +45,11 @@ __global__ void k_db_cols_missing(const int64_t *__restrict__ idx, const double 
     const double v = ((impute ? mu[j] : 0.0) - cm) * s;
     for (int64_t e = miss_ptr[j] + threadIdx.x; e < miss_ptr[j + 1]; e += blockDim.x) panel[miss_row[e] + n * t] = v;
 }
-__global__ void k_db_cols_dense(const double *__restrict__ D, int64_t n, const int64_t *__restrict__ idx, double *__restrict__ panel)
+template <typename T>
+__global__ void k_db_cols_dense(const T *__restrict__ D, int64_t n, const int64_t *__restrict__ idx, double *__restrict__ panel)
 {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i < n) panel[i + n * blockIdx.y] = D[idx[blockIdx.y] * n + i];
+    if (i < n) panel[i + n * blockIdx.y] = (double)D[idx[blockIdx.y] * n + i];
 }
 
 // GlmResp initialisation: mu = mustart(y), eta = linkfun(mu)
@@ -179,7 +180,8 @@ int debias_glm_device(const mih_mat *h, const int64_t *idx_host, int64_t k64, co
             hipLaunchKernelGGL(k_db_cols_missing, dim3((unsigned)k), dim3(256), 0, s, idx.p, h->mu, h->sinv, h->center, h->scale,
                                h->impute, h->miss_ptr, h->miss_row, n, panel.p);
     } else {
-        hipLaunchKernelGGL(k_db_cols_dense, dim3(nblk(n), (unsigned)k), dim3(256), 0, s, h->D, n, idx.p, panel.p);
+        if (h->Df) hipLaunchKernelGGL(k_db_cols_dense<float>, dim3(nblk(n), (unsigned)k), dim3(256), 0, s, h->Df, n, idx.p, panel.p);
+        else hipLaunchKernelGGL(k_db_cols_dense<double>, dim3(nblk(n), (unsigned)k), dim3(256), 0, s, h->D, n, idx.p, panel.p);
     }
     double *target = panel.p + (size_t)n * k;        // last panel column: the right-hand side of the WLS
 

@@ -208,12 +208,13 @@ __global__ void k_ib_solve(const double *__restrict__ Sxv, const double *__restr
     icpt[j] = b0;
 }
 // dense design matrix: sum over training rows of x^2 per column
+template <typename T>
 __global__ void __launch_bounds__(256)
-k_ib_dense_sxx(const double *__restrict__ D, const double *__restrict__ w, int64_t n, int64_t p, double *__restrict__ out)
+k_ib_dense_sxx(const T *__restrict__ D, const double *__restrict__ w, int64_t n, int64_t p, double *__restrict__ out)
 {
     int64_t j = blockIdx.x;
     double v[1] = {0.0};
-    for (int64_t i = threadIdx.x; i < n; i += 256) { double x = D[j * n + i]; v[0] += x * x * w[i]; }
+    for (int64_t i = threadIdx.x; i < n; i += 256) { double x = (double)D[j * n + i]; v[0] += x * x * w[i]; }
     block_sum<1>(v, out + j);
 }
 __global__ void __launch_bounds__(256)
@@ -346,7 +347,8 @@ int init_beta_regress_device(const mih_mat *h, const double *w_dev, const double
         hipLaunchKernelGGL(k_ib_counts, grid, dim3(256), 0, s, reinterpret_cast<const uint4 *>(h->X), h->nbp, p, M.p, cnt.p);
     } else {
         MIH_TRY(sxxd.alloc(p));
-        hipLaunchKernelGGL(k_ib_dense_sxx, dim3((unsigned)p), dim3(256), 0, s, h->D, w_dev, n, p, sxxd.p);
+        if (h->Df) hipLaunchKernelGGL(k_ib_dense_sxx<float>, dim3((unsigned)p), dim3(256), 0, s, h->Df, w_dev, n, p, sxxd.p);
+        else hipLaunchKernelGGL(k_ib_dense_sxx<double>, dim3((unsigned)p), dim3(256), 0, s, h->D, w_dev, n, p, sxxd.p);
     }
     const int nsb = 64;
     for (int t = 0; t < m; ++t) {

@@ -499,6 +499,21 @@ int mih_dense_create(const double *x, int64_t n, int64_t p, int device, mih_mat 
     return MIH_OK;
 }
 
+int mih_dense_create_f32(const float *x, int64_t n, int64_t p, int device, mih_mat **out)
+{
+    if (!x || !out) return MIH_BAD_ARG;
+    if (n <= 0 || p <= 0) return MIH_BAD_DIM;
+    MIH_TRY(select_device(device));
+    mih_mat *h = new mih_mat();
+    h->kind = 1; h->device = device; h->n = n; h->p = p; h->center = h->scale = h->impute = 0;
+    auto fail = [&](int code) { mih_mat_destroy(h); return code; };
+    if (hipMalloc((void **)&h->Df, sizeof(float) * (size_t)n * (size_t)p) != hipSuccess) { set_error("hipMalloc for dense matrix failed"); (void)hipGetLastError(); return fail(MIH_OOM); }
+    if (hipMemcpy(h->Df, x, sizeof(float) * (size_t)n * (size_t)p, hipMemcpyHostToDevice) != hipSuccess) return fail(MIH_HIP_ERROR);
+    if (hipStreamCreate(&h->stream) != hipSuccess) return fail(MIH_HIP_ERROR);
+    *out = h;
+    return MIH_OK;
+}
+
 int mih_dense_create_synthetic(int64_t n, int64_t p, uint64_t seed, int device, mih_mat **out)
 {
     if (!out) return MIH_BAD_ARG;
@@ -525,6 +540,7 @@ int mih_mat_destroy(mih_mat *h)
     if (h->miss_ptr) (void)hipFree(h->miss_ptr);
     if (h->miss_row) (void)hipFree(h->miss_row);
     if (h->D) (void)hipFree(h->D);
+    if (h->Df) (void)hipFree(h->Df);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return MIH_OK;

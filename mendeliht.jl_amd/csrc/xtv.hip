@@ -453,6 +453,42 @@ k_xtv_dense(const double *__restrict__ D, int64_t n, int64_t p, const double *__
     if (lane == 0) out[j] = s;
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// Float32 storage of the dense matrix: the same loop with 16-B loads of four floats, products and sums in f64
+__global__ void __launch_bounds__(256)
+k_xtv_dense_f32(const float *__restrict__ D, int64_t n, int64_t p, const double *__restrict__ r, double *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    int64_t j = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    if (j >= p) return;
+    const float *col = D + j * n;
+    double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if ((n & 3) == 0 && (((uintptr_t)col) & 15) == 0) {
+        const f32x4 *cx = reinterpret_cast<const f32x4 *>(col);
+        const f64x2 *rx = reinterpret_cast<const f64x2 *>(r);
+        const int64_t n4 = n >> 2;
+        int64_t i = lane;
+        for (; i + 64 < n4; i += 128) {
+            f32x4 x0 = __builtin_nontemporal_load(cx + i), x1 = __builtin_nontemporal_load(cx + i + 64);
+            f64x2 v0 = rx[2 * i], v1 = rx[2 * i + 1], v2 = rx[2 * (i + 64)], v3 = rx[2 * (i + 64) + 1];
+            a[0] = fma((double)x0.x, v0.x, a[0]); a[1] = fma((double)x0.y, v0.y, a[1]);
+            a[2] = fma((double)x0.z, v1.x, a[2]); a[3] = fma((double)x0.w, v1.y, a[3]);
+            a[4] = fma((double)x1.x, v2.x, a[4]); a[5] = fma((double)x1.y, v2.y, a[5]);
+            a[6] = fma((double)x1.z, v3.x, a[6]); a[7] = fma((double)x1.w, v3.y, a[7]);
+        }
+        for (; i < n4; i += 64) {
+            f32x4 x0 = __builtin_nontemporal_load(cx + i);
+            f64x2 v0 = rx[2 * i], v1 = rx[2 * i + 1];
+            a[0] = fma((double)x0.x, v0.x, a[0]); a[1] = fma((double)x0.y, v0.y, a[1]);
+            a[2] = fma((double)x0.z, v1.x, a[2]); a[3] = fma((double)x0.w, v1.y, a[3]);
+        }
+    } else {
+        for (int64_t k = lane; k < n; k += 64) a[0] = fma((double)col[k], r[k], a[0]);
+    }
+    double s = wave_sum(((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7])));
+    if (lane == 0) out[j] = s;
+}
+
 struct Variant { int waves, ct, splits; };
 static const Variant kVariants[] = {
     {4, 2, 8},    // 0
@@ -564,9 +600,12 @@ int xtv_work_init(const mih_mat *h, XtvWork &w, int m)
 int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double *out_dev, hipStream_t s)
 {
     if (h->kind == 1) {
-        for (int v = 0; v < m; ++v)
-            hipLaunchKernelGGL(k_xtv_dense, dim3((unsigned)((h->p + 3) / 4)), dim3(256), 0, s, h->D, h->n, h->p,
-                               r_dev + (int64_t)v * h->n, out_dev + (int64_t)v * h->p);
+        for (int v = 0; v < m; ++v) {
+            if (h->Df) hipLaunchKernelGGL(k_xtv_dense_f32, dim3((unsigned)((h->p + 3) / 4)), dim3(256), 0, s, h->Df, h->n, h->p,
+                                          r_dev + (int64_t)v * h->n, out_dev + (int64_t)v * h->p);
+            else hipLaunchKernelGGL(k_xtv_dense, dim3((unsigned)((h->p + 3) / 4)), dim3(256), 0, s, h->D, h->n, h->p,
+                                    r_dev + (int64_t)v * h->n, out_dev + (int64_t)v * h->p);
+        }
         MIH_HIP(hipGetLastError());
         return MIH_OK;
     }
@@ -667,7 +706,7 @@ int mih_xtv_algorithmic_bytes(const mih_mat *h, int m, double *bytes)
     if (h->kind == 0)
         *bytes = (double)h->p * (double)((h->n + 3) / 4) + 8.0 * m * ((double)h->n + (double)h->p) + 16.0 * (double)h->p;
     else
-        *bytes = 8.0 * (double)h->n * (double)h->p + 8.0 * m * ((double)h->n + (double)h->p);
+        *bytes = (h->Df ? 4.0 : 8.0) * (double)h->n * (double)h->p + 8.0 * m * ((double)h->n + (double)h->p);
     return MIH_OK;
 }
 

@@ -123,8 +123,9 @@ k_xv_snp_cached(const uint32_t *__restrict__ cache, int64_t ndw, int64_t n, cons
     }
 }
 
+template <typename T>
 __global__ void __launch_bounds__(256)
-k_xv_dense(const double *__restrict__ D, int64_t n, const int64_t *__restrict__ idx,
+k_xv_dense(const T *__restrict__ D, int64_t n, const int64_t *__restrict__ idx,
            const double *__restrict__ val, int64_t nnz, int groups, int64_t n_pad,
            double *__restrict__ partial)
 {
@@ -134,7 +135,7 @@ k_xv_dense(const double *__restrict__ D, int64_t n, const int64_t *__restrict__ 
     int64_t per = (nnz + groups - 1) / groups;
     int64_t t0 = g * per, t1 = t0 + per < nnz ? t0 + per : nnz;
     double acc = 0.0;
-    for (int64_t t = t0; t < t1; ++t) acc = fma(D[idx[t] * n + i], val[t], acc);
+    for (int64_t t = t0; t < t1; ++t) acc = fma((double)D[idx[t] * n + i], val[t], acc);
     partial[(int64_t)g * n_pad + i] = acc;
 }
 
@@ -266,8 +267,10 @@ int xv_sparse_device(const mih_mat *h, XvWork &w, const int64_t *idx_dev, const 
             if (clamp20) hipLaunchKernelGGL(k_clamp20, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, s, out_dev, h->n);
         }
     } else {
-        hipLaunchKernelGGL(k_xv_dense, dim3((unsigned)((h->n + 255) / 256), groups), dim3(256), 0, s, h->D, h->n, idx_dev, val_dev,
-                           nnz, groups, np, w.partial.p);
+        if (h->Df) hipLaunchKernelGGL(k_xv_dense<float>, dim3((unsigned)((h->n + 255) / 256), groups), dim3(256), 0, s, h->Df, h->n, idx_dev, val_dev,
+                                      nnz, groups, np, w.partial.p);
+        else hipLaunchKernelGGL(k_xv_dense<double>, dim3((unsigned)((h->n + 255) / 256), groups), dim3(256), 0, s, h->D, h->n, idx_dev, val_dev,
+                                nnz, groups, np, w.partial.p);
         hipLaunchKernelGGL(k_xv_reduce, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, s, w.partial.p, groups, np, h->n,
                            clamp20, out_dev);
     }

@@ -919,3 +919,40 @@ def test_error_paths_nan_loglikelihood_and_bad_arguments(mih, normal_pair, norma
         mih.fit_iht(np.abs(normal_data["y"]), x, None, k=3, d=mih.Bernoulli(), l=mih.LogitLink(), verbose=False)   # checky
     ok = mih.fit_iht(normal_data["y"], x, None, k=5, verbose=False)                     # the handle survives the failures
     assert np.count_nonzero(ok.beta) == 5
+
+
+def test_float32_dense_matrix(mih, oracle):
+    """`x::Matrix{Float32}` (test/L0_reg_test.jl:245-297 NegBin nuisance parameter on a Float32 matrix;
+    test/cv_iht_test.jl:41-78 cross-validation on a Float32 matrix): Float32 storage on the device, Float64
+    arithmetic -- identical to the oracle on the exactly-representable upcast of the same matrix."""
+    rng = np.random.default_rng(23)
+    n, p, k = 802, 350, 6
+    X32 = rng.standard_normal((n, p)).astype(np.float32)
+    X64 = X32.astype(np.float64)
+    xd = mih.DenseMatrix(X32)
+    assert xd.dtype == np.float32 and xd.algorithmic_bytes() < 4.2 * n * p + 8 * (n + p) + 1
+    od = oracle.Mat.from_dense(X64)
+    r = rng.standard_normal(n)
+    assert rel(xd.xtv(r), X64.T @ r) < 1e-12
+    idx = np.sort(rng.choice(p, 5, replace=False)); val = rng.standard_normal(5)
+    assert rel(xd.xv_sparse(idx, val), X64[:, idx] @ val) < 1e-12
+    b = np.zeros(p); b[rng.choice(p, k, replace=False)] = rng.standard_normal(k) * 0.5
+    y = X64 @ b + 1 + rng.standard_normal(n)
+    for kw, okw in ((dict(), dict()), (dict(init_beta=True), dict(init_beta=True)), (dict(debias=True), dict(debias=True))):
+        res = mih.fit_iht(y, xd, None, k=k, verbose=False, **kw)
+        o = oracle.fit_iht(od, y, None, k=k, **okw)
+        assert res.iter == o["iter"] and np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"])), kw
+        np.testing.assert_allclose(res.beta, o["beta"], rtol=1e-5, atol=1e-12)
+    mu = np.exp(0.3 * (X64 @ b))
+    ynb = rng.negative_binomial(5, 5 / (mu + 5)).astype(float)
+    res = mih.fit_iht(ynb, xd, None, k=k, d=mih.NegativeBinomial(1.0), l=mih.LogLink(), est_r="Newton", verbose=False)
+    o = oracle.fit_iht(od, ynb, None, k=k, dist="negbin", link="log", nb_r=1.0, est_r="newton")
+    assert np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"]))
+    assert res.d.r == pytest.approx(o["nb_r"], rel=1e-4)
+    folds = hash_folds(n, 3)
+    mse = mih.cv_iht(y, X32, None, path=[2, 6, 10], q=3, folds=folds, verbose=False)      # a raw float32 ndarray is accepted
+    omse, _ = oracle.cv_iht(od, y, None, path=[2, 6, 10], q=3, folds=folds)
+    np.testing.assert_allclose(mse, omse, rtol=1e-5)
+    # ragged n (not a multiple of 4): the scalar tail path of the Float32 kernel
+    xr = mih.DenseMatrix(X32[:801])
+    assert rel(xr.xtv(r[:801]), X64[:801].T @ r[:801]) < 1e-12
