@@ -258,15 +258,20 @@ def _inst(x):
 
 # ---- design matrices -------------------------------------------------------------------
 def read_bed(path, n):
-    """PLINK .bed (SNP-major, header 6c 1b 01) -> (p, ceil(n/4)) uint8 column bytes."""
-    raw = np.fromfile(path, dtype=np.uint8)
-    if raw.size < 3 or raw[0] != 0x6C or raw[1] != 0x1B or raw[2] != 0x01:
+    """PLINK .bed (SNP-major, header 6c 1b 01) -> (p, ceil(n/4)) uint8 column bytes.  The file is memory-mapped
+    (as SnpArrays.jl does): a 125 GB .bed is never copied into Python memory, its pages stream through the
+    upload pipeline of mih_snp_create."""
+    size = os.path.getsize(path)
+    with open(path, "rb") as f:
+        magic = f.read(3)
+    if size < 3 or magic != b"\x6c\x1b\x01":
         raise ArgumentError(f"{path} is not a SNP-major PLINK .bed file")
     stride = (n + 3) // 4
-    body = raw[3:]
-    if body.size % stride:
+    if (size - 3) % stride:
         raise DimensionMismatch(f"{path}: size does not match n={n}")
-    return body.reshape(-1, stride)
+    if size == 3:
+        return np.zeros((0, stride), dtype=np.uint8)
+    return np.memmap(path, dtype=np.uint8, mode="r", offset=3, shape=((size - 3) // stride, stride))
 
 
 class _Mat:
