@@ -260,8 +260,8 @@ k_xtv_mfma(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *_
 // top of step t, the dosage tiles of step t+1 are loaded at the top of step t, so no load is waited
 // for in the step that issued it.  Measured (tools/sweep_multi.py, tools/probe_power.py,
 // profiles/r01_power_clock_smi.log): every workgroup shape lands on 29.5 ms because the pass is
-// POWER-bound, not issue- or latency-bound -- the package sits at its ~1340 W cap and the shader
-// clock drops from 2360 MHz (1 RHS) to ~1935 MHz (4 RHS); all-zero digit planes run 17 % faster.
+// POWER-bound, not issue- or latency-bound -- the package sits at its power cap and the shader clock
+// drops to ~1870-1935 MHz for the 4-operand pass; all-zero digit planes run 17 % faster.
 // MODE 1 / 2 (no MFMAs / no dosage loads) exist only for those timing probes.
 template <int NR, int CT, int RB, int MODE = 0, int WAVES = 8>   // MODE 1: no MFMAs, 2: no dosage loads (timing probes only)
 __global__ void __launch_bounds__(WAVES * 64, 2)
