@@ -14,7 +14,7 @@ from .api import (  # noqa: F401
     Normal, Poisson, SnpLinAlg, DenseMatrix, cross_validate, cv_iht, device_count, fit_iht, iht,
     library_path, mIHTResult, project_group_sparse, project_k, read_bed, standardize, lib, IHTSession,
     profile_enable, profile_read, iht_run_many_models, set_xtv_digits, Gamma, InverseGaussian, ProbitLink,
-    CloglogLink, CauchitLink, InverseLink, InverseSquareLink, SqrtLink, canonicallink, maf_weights,
+    CloglogLink, CauchitLink, InverseLink, InverseSquareLink, SqrtLink, canonicallink, maf_weights, simulate_random_snparray, simulate_random_response,
 )
 from . import dist  # noqa: F401
 
@@ -22,6 +22,6 @@ __all__ = [
     "fit_iht", "cv_iht", "iht", "cross_validate", "project_k", "project_group_sparse", "SnpLinAlg",
     "DenseMatrix", "IHTResult", "mIHTResult", "Normal", "Bernoulli", "Poisson", "NegativeBinomial",
     "MvNormal", "Gamma", "InverseGaussian", "IdentityLink", "LogitLink", "LogLink", "ProbitLink", "CloglogLink",
-    "CauchitLink", "InverseLink", "InverseSquareLink", "SqrtLink", "canonicallink", "maf_weights", "read_bed", "standardize", "device_count",
+    "CauchitLink", "InverseLink", "InverseSquareLink", "SqrtLink", "canonicallink", "maf_weights", "simulate_random_snparray", "simulate_random_response", "read_bed", "standardize", "device_count",
     "library_path", "MendelIHTError", "lib", "dist", "iht_run_many_models", "IHTSession",
 ]

@@ -829,6 +829,50 @@ def cv_iht(y, x, z=None, *, d=None, l=None, path=range(1, 21), q=5, est_r="None"
     return (mse, raw) if return_raw else mse
 
 
+# ---- simulation helpers (src/simulate_utilities.jl) ---------------------------------------------------
+def simulate_random_snparray(n, p, seed=2024, missing_rate=0.0, device=0):
+    """simulate_random_snparray (simulate_utilities.jl:33-47): maf_j ~ U(0, 0.5), g_ij ~ Binomial(2, maf_j), generated
+    on the device with a counter-based generator (not Julia's RNG stream); returned ready for fit_iht, i.e. as
+    SnpLinAlg{Float64}(x, center=true, scale=true, impute=true)."""
+    return SnpLinAlg.synthetic(n, p, seed=seed, missing_rate=missing_rate, center=True, scale=True, impute=True, device=device)
+
+
+def simulate_random_response(x, k, d, l=None, *, r=10, alpha=1.0, Zu=None, seed=None):
+    """simulate_random_response(x, k, d, l; r, α, Zu) -- simulate_utilities.jl:205-244: k effects at random positions
+    (N(0,1); N(0,0.3²) for Poisson / Gamma / NegativeBinomial), eta = x*beta + Zu computed on the GPU, y ~ d(linkinv(eta)).
+    Returns (y, true_b, correct_position) with 0-based positions."""
+    x = _as_mat(x)
+    d = _inst(d)
+    l = _inst(l) if l is not None else canonicallink(d)
+    if isinstance(d, (NegativeBinomial, Gamma)) and not isinstance(l, LogLink):
+        raise ArgumentError(f"Distribution {d!r} must use LogLink!")
+    rng = np.random.default_rng(seed)
+    n, p = x.n, x.p
+    small = isinstance(d, (Poisson, Gamma, NegativeBinomial))
+    pos = np.sort(rng.choice(p, size=k, replace=False))
+    val = rng.normal(0.0, 0.3 if small else 1.0, size=k)
+    true_b = np.zeros(p)
+    true_b[pos] = val
+    eta = x.xv_sparse(pos, val) + (0.0 if Zu is None else np.asarray(Zu, dtype=np.float64).ravel())
+    inv = {0: lambda e: e, 1: lambda e: 1 / (1 + np.exp(-e)), 2: np.exp}
+    if l.code not in inv:
+        raise ArgumentError("simulate_random_response supports the Identity, Logit and Log links")
+    mu = np.clip(inv[l.code](eta), -20, 20)
+    if isinstance(d, Normal):
+        y = mu + rng.standard_normal(n)
+    elif isinstance(d, Bernoulli):
+        y = (rng.random(n) < mu).astype(np.float64)
+    elif isinstance(d, Poisson):
+        y = rng.poisson(mu).astype(np.float64)
+    elif isinstance(d, NegativeBinomial):
+        y = rng.negative_binomial(r, 1.0 / (1.0 + mu / r)).astype(np.float64)
+    elif isinstance(d, Gamma):
+        y = rng.gamma(alpha, mu / alpha)                 # shape α, rate 1/μ as in the reference
+    else:
+        raise ArgumentError(f"unsupported distribution {d!r}")
+    return y, true_b, pos
+
+
 def maf_weights(x, max_weight=np.inf):
     """maf_weights(x::SnpArray; max_weight) -- src/utilities.jl:682-697: prior weights 1 / (2 sqrt(p (1 - p)))
     from the minor allele frequencies (SnpArrays.maf: over the non-missing genotypes), clamped to [1, max_weight]."""

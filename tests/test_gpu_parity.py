@@ -956,3 +956,21 @@ def test_float32_dense_matrix(mih, oracle):
     # ragged n (not a multiple of 4): the scalar tail path of the Float32 kernel
     xr = mih.DenseMatrix(X32[:801])
     assert rel(xr.xtv(r[:801]), X64[:801].T @ r[:801]) < 1e-12
+
+
+@pytest.mark.parametrize("fam", ["normal", "bernoulli", "poisson", "negbin"])
+def test_simulate_and_recover(mih, fam):
+    """The pattern of test/L0_reg_test.jl:1-102: simulate_random_snparray + simulate_random_response, then fit_iht with
+    the true k recovers the large effects and returns exactly k non-zeros."""
+    x = mih.simulate_random_snparray(3000, 4000, seed=7)
+    d, l = {"normal": (mih.Normal, mih.IdentityLink), "bernoulli": (mih.Bernoulli, mih.LogitLink),
+            "poisson": (mih.Poisson, mih.LogLink), "negbin": (mih.NegativeBinomial, mih.LogLink)}[fam]
+    k = 10
+    y, true_b, pos = mih.simulate_random_response(x, k, d, l(), seed=11)
+    assert np.count_nonzero(true_b) == k and np.array_equal(np.flatnonzero(true_b), pos)
+    res = mih.fit_iht(y, x, None, k=k, d=d(10.0) if fam == "negbin" else d(), l=l(), verbose=False)
+    assert np.count_nonzero(res.beta) == k and res.c[0] != 0                 # L0_reg_test.jl:21-24
+    big = pos[np.abs(true_b[pos]) > (0.25 if fam in ("poisson", "negbin") else 0.6)]
+    assert np.isin(big, np.flatnonzero(res.beta)).mean() >= 0.7
+    with pytest.raises(mih.MendelIHTError):
+        mih.simulate_random_response(x, k, mih.NegativeBinomial, mih.IdentityLink())
