@@ -82,6 +82,18 @@ def main():
     run("ties_choose", dup, n, xo.xv_sparse(np.array([lo1 + cnt1 - 1]), np.array([1.0])) + 0.01 * rng.standard_normal(n),
         None, k=2)
 
+    # 6. cross-validation with the (fold, k) grid sharded over the same ranks (one all-gather of the losses)
+    from conftest import hash_folds
+    n = 1000
+    cols = m.read_bed(os.path.join(FIX, "normal.bed"), n)
+    xr = m.SnpLinAlg(cols, n=n, center=True, scale=True, impute=True)        # every rank: a full replica
+    folds = hash_folds(n, 3)
+    mse = D.cv_iht_distributed(y, xr, z, path=range(1, 9), q=3, folds=folds, verbose=False)
+    entry = dict(distributed=mse.tolist())
+    if rank == 0:
+        entry["single"] = m.cv_iht(y, xr, z, path=range(1, 9), q=3, folds=folds, verbose=False).tolist()
+    cases["cv_grid"] = entry
+
     dist.barrier()
     if rank == 0:
         with open(out_path, "w") as f:

@@ -36,6 +36,10 @@ def test_sharded_fit_matches_single_process(tmp_path, world):
     res = json.load(open(out))
     assert res["world"] == world
     others = [json.load(open(str(out) + f".r{k}"))["cases"] for k in range(1, world)]
+    cv = res["cases"].pop("cv_grid")
+    assert cv["distributed"] == cv["single"]                               # (fold,k) grid over the ranks == one process
+    for oc in others:
+        assert oc.pop("cv_grid")["distributed"] == cv["single"]
     for name, case in res["cases"].items():
         sh, one = case["sharded"], case["single"]
         # the Newton update of the NegBin r stops at |dr| <= 1e-6 (utilities.jl:242): rounding-level
