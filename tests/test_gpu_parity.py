@@ -974,3 +974,36 @@ def test_simulate_and_recover(mih, fam):
     assert np.isin(big, np.flatnonzero(res.beta)).mean() >= 0.7
     with pytest.raises(mih.MendelIHTError):
         mih.simulate_random_response(x, k, mih.NegativeBinomial, mih.IdentityLink())
+
+
+def test_randomized_multivariate_fits_vs_oracle(mih, oracle):
+    """Seeded sweep of multivariate fits: traits r, covariates q (some not kept), k, missingness, train masks,
+    init_beta -- against the oracle on every stable trajectory."""
+    rng = np.random.default_rng(31337)
+    checked = 0
+    for trial in range(10):
+        n = int(rng.integers(150, 1500)); p = int(rng.integers(60, 400)); r = int(rng.integers(2, 6))
+        q = int(rng.integers(1, 4)); k = int(rng.integers(2, 14)); miss = float(rng.choice([0.0, 0.03]))
+        cols = make_bed(rng, n, p, missing_rate=miss)
+        x = mih.SnpLinAlg(cols, n=n, center=True, scale=True, impute=True)
+        ox = oracle.Mat.from_bed_columns(cols, n)
+        Y, Z = _mv_problem(oracle, ox, rng, r, min(k, 8), q)
+        kw = {}
+        if q > 1 and rng.random() < 0.6:
+            kw["zkeep"] = [1] + [int(v) for v in rng.integers(0, 2, q - 1)]
+        if rng.random() < 0.4:
+            kw["train"] = (rng.random(n) < 0.8).astype(np.uint8)
+        if rng.random() < 0.3:
+            kw["init_beta"] = True
+        o = oracle.fit_mv(ox, Y, Z, k=k, max_iter=60, **kw)
+        res = mih.fit_iht(Y, x, Z, k=k, max_iter=60, verbose=False, **kw)
+        if o["bt_trace"].max(initial=0) >= 3:
+            continue
+        tag = (trial, n, p, r, q, k, miss, sorted(kw))
+        assert res.iter == o["iter"], tag
+        assert np.array_equal(res.beta != 0, o["B"] != 0), tag
+        np.testing.assert_allclose(res.beta, o["B"], rtol=1e-5, atol=1e-10, err_msg=str(tag))
+        np.testing.assert_allclose(res.c, o["C"], rtol=1e-5, atol=1e-10, err_msg=str(tag))
+        np.testing.assert_allclose(res.Σ, o["Sigma"], rtol=1e-6, err_msg=str(tag))
+        checked += 1
+    assert checked >= 6
