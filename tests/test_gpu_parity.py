@@ -1007,3 +1007,42 @@ def test_randomized_multivariate_fits_vs_oracle(mih, oracle):
         np.testing.assert_allclose(res.Σ, o["Sigma"], rtol=1e-6, err_msg=str(tag))
         checked += 1
     assert checked >= 6
+
+
+def test_gpu_against_committed_oracle_goldens(mih, normal_pair):
+    """The GPU path against tests/golden/oracle_goldens.json (oracle results committed as data: the families that no
+    reference fixture pins, deterministic inputs from tests/golden/make_oracle_goldens.py) -- no live oracle involved."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_oracle_goldens", os.path.join(GOLD, "make_oracle_goldens.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    gold = json.load(open(os.path.join(GOLD, "oracle_goldens.json")))["goldens"]
+    x, ox = normal_pair
+    n, sc, y, z = mod.scenarios(ox)                     # ox only supplies the deterministic linear predictor of the inputs
+    fam = {"normal": mih.Normal, "bernoulli": mih.Bernoulli, "poisson": mih.Poisson, "negbin": mih.NegativeBinomial, "gamma": mih.Gamma}
+    lnk = {"identity": mih.IdentityLink, "logit": mih.LogitLink, "log": mih.LogLink, "probit": mih.ProbitLink}
+    for name, (yy, kw, zz) in sc.items():
+        g = gold[name]
+        kw = dict(kw)
+        dname = kw.pop("dist", "normal")
+        d = fam[dname](kw.pop("nb_r")) if dname == "negbin" else fam[dname]()
+        l = lnk[kw.pop("link", "identity")]()
+        if "est_r" in kw:
+            kw["est_r"] = {"newton": "Newton", "mm": "MM"}[kw["est_r"]]
+        res = mih.fit_iht(yy, x, zz, d=d, l=l, verbose=False, **kw)
+        tol = 1e-5 if dname == "normal" else 1e-4
+        assert res.iter == g["iter"] and list(res.trace["backtracks"]) == g["backtracks"], name
+        assert list(np.flatnonzero(res.beta)) == g["support"], name
+        np.testing.assert_allclose(res.beta[g["support"]], g["beta"], rtol=tol, err_msg=name)
+        np.testing.assert_allclose(res.c, g["c"], rtol=tol, err_msg=name)
+        assert res.logl == pytest.approx(g["logl"], rel=1e-7), name
+    mse = mih.cv_iht(y, x, z, path=range(1, 9), q=3, folds=hash_folds(n, 3), verbose=False)
+    np.testing.assert_allclose(mse, gold["cv_normal_path1_8_q3"]["mse"], rtol=1e-5)
+    bed = mih.read_bed(os.path.join(FIX, "multivariate.bed"), n)
+    xm = mih.SnpLinAlg(bed, n, center=True, scale=True, impute=True)
+    Y = np.loadtxt(os.path.join(FIX, "multivariate.phen"), delimiter=",").T
+    rm = mih.fit_iht(Y, xm, None, k=10, verbose=False)
+    gm = gold["multivariate_k10"]
+    assert rm.iter == gm["iter"] and [list(map(int, ij)) for ij in np.argwhere(rm.beta != 0)] == gm["support"]
+    np.testing.assert_allclose([rm.beta[i, j] for i, j in gm["support"]], gm["B"], rtol=1e-5)
+    np.testing.assert_allclose(rm.Σ, gm["Sigma"], rtol=1e-6)

@@ -247,3 +247,30 @@ def test_multivariate_shipped_data(oracle):
     sel0 = set(np.flatnonzero(r["B"][0]) + 1)
     sel1 = set(np.flatnonzero(r["B"][1]) + 1)
     assert {134, 442, 450, 1891, 2557, 3243} <= sel0 and {1014, 5214} <= sel1
+
+
+def _oracle_goldens():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_oracle_goldens", os.path.join(GOLD, "make_oracle_goldens.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod, json.load(open(os.path.join(GOLD, "oracle_goldens.json")))["goldens"]
+
+
+def test_oracle_reproduces_its_committed_goldens(oracle):
+    """tests/golden/oracle_goldens.json was generated by this oracle (make_oracle_goldens.py) for the families no
+    reference fixture pins; regenerating it must give the same numbers (guards the oracle against silent drift)."""
+    mod, gold = _oracle_goldens()
+    cols = np.fromfile(os.path.join(FIX, "normal.bed"), dtype=np.uint8)[3:].reshape(-1, 250)
+    ox = oracle.Mat.from_bed_columns(cols, 1000)
+    n, sc, y, z = mod.scenarios(ox)
+    assert set(sc) <= set(gold)
+    for name, (yy, kw, zz) in sc.items():
+        o = oracle.fit_iht(ox, yy, zz, **kw)
+        g = gold[name]
+        assert o["iter"] == g["iter"] and list(o["bt_trace"]) == g["backtracks"], name
+        assert list(np.flatnonzero(o["beta"])) == g["support"], name
+        np.testing.assert_allclose(o["beta"][g["support"]], g["beta"], rtol=1e-10, err_msg=name)
+        assert o["logl"] == pytest.approx(g["logl"], rel=1e-12), name
+    mse, _ = oracle.cv_iht(ox, y, z, path=range(1, 9), q=3, folds=hash_folds(n, 3))
+    np.testing.assert_allclose(mse, gold["cv_normal_path1_8_q3"]["mse"], rtol=1e-10)
