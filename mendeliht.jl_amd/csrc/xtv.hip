@@ -26,9 +26,14 @@
 //
 // Work decomposition: a wave owns CT column groups (32 SNPs each) and walks a slice of the rows in
 // 128-row steps; per step it loads CT x 1 KB of dosages (one contiguous 16 B/lane wave-load per
-// tile) and the 2 KB of digit planes for those rows (L2-resident, shared by all waves).  Rows are
-// split in `splits` slices (slice = blockIdx % splits: the blocks of one XCD share a slice of the
-// digit planes in their L2); slice partials are combined in fixed order by the finalize kernel.
+// tile) and needs the 2 KB of digit planes for those rows.  Rows are split in `splits` slices
+// (slice = blockIdx % splits: the blocks of one XCD share a slice of the digit planes in their L2);
+// slice partials are combined in fixed order by the finalize kernel.  Two kernel families:
+//   k_xtv_mfma_lds<NR,CT,RB,..>  the digit planes of a 128-row block are staged ONCE per workgroup in LDS
+//                                (library default for 1, 2 and 4 B operands per pass);
+//   k_xtv_mfma<WAVES,CT,NR>      every wave loads its own digit planes from L2 (the earlier shapes, kept as
+//                                selectable variants and as a cross-check: same arithmetic, same bits).
+// An operand carries one 28-digit residual (exact mode) or two 16-digit residuals (opt-in fast mode).
 #include "common.h"
 #include <mutex>
 #include <utility>
