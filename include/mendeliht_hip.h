@@ -174,8 +174,8 @@ typedef struct mih_fit_result {
     double  *mu;              /* caller-allocated n (final v.mu), or NULL */
 } mih_fit_result;
 
-/* fit_iht(y, x, z; ...) src/fit.jl:60-118 with init_beta=false, debias=false,
- * memory_efficient=true.  z is n x q column-major (first column all ones);
+/* fit_iht(y, x, z; ...) src/fit.jl:60-118 (always the memory_efficient=true formulation: no dense
+ * n x k copy of the support is kept).  z is n x q column-major (first column all ones);
  * train is NULL (all samples) or n flags = cv_train_idx. */
 int mih_fit_iht(const mih_mat *h, const mih_fit_params *prm, const double *y,
                 const double *z, int64_t q, const uint8_t *train, mih_fit_result *res);
