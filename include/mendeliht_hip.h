@@ -250,7 +250,8 @@ int mih_profile_read(double *xtv_kernel_ms, int64_t *xtv_launches, int reset);
  * in HBM, bracketed by HIP events; *ms_per_pass = average kernel-chain time. */
 int mih_bench_xtv(const mih_mat *h, int variant, int iters, int warmup, uint64_t seed,
                   float *ms_per_pass, double *checksum);
-/* Same for m right-hand sides; at most max_fused (1, 2 or 4) of them share one pass over X. */
+/* Same for m right-hand sides; at most max_fused (1, 2 or 4) B operands (one residual each in the exact mode,
+ * two in the 16-digit mode) share one pass over X. */
 int mih_bench_xtv_batched(const mih_mat *h, int variant, int m, int max_fused, int iters, int warmup,
                           uint64_t seed, float *ms_per_pass, double *checksum);
 /* Algorithmic bytes of one X'r pass: p*ceil(n/4) + 8*m*(n+p) + 16*p. */
@@ -264,7 +265,8 @@ int mih_set_xtv_variant(int variant);
  * multi-RHS passes (cv_iht, multivariate, init_beta) need half the matrix-pipe work, which is what
  * bounds them (they are power-limited); relative error of X'r about 2^-31 max|r| / |r|_rms ~ 1e-9. */
 int mih_set_xtv_digits(int digits);
-/* Select the shape of the fused 4-right-hand-side kernel (0 = built-in default; tuning knob). */
+/* Select the launch shape of the LDS-shared X'r kernels (0 = built-in defaults; ids in csrc/xtv.hip dispatch_xtv;
+ * some ids are timing probes whose output is NOT X'r).  Tuning / measurement knob. */
 int mih_set_xtv_multi_variant(int variant);
 
 #ifdef __cplusplus
