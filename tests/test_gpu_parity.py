@@ -837,6 +837,11 @@ def test_large_k_and_many_covariates(mih, oracle, normal_pair, normal_data):
     assert np.array_equal(np.flatnonzero(res.c), np.flatnonzero(o["c"]))
     np.testing.assert_allclose(res.c, o["c"], rtol=1e-5, atol=1e-12)
     assert res.c[5] != 0 and res.c[17] != 0                      # the two real covariate effects survive the projection
+    z64 = np.column_stack([np.ones(n)] + [rng.standard_normal(n) for _ in range(63)])       # the library maximum q = 64
+    res = mih.fit_iht(y, x, z64, k=4, verbose=False)
+    o = oracle.fit_iht(ox, y, z64, k=4)
+    assert res.iter == o["iter"] and np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"]))
+    np.testing.assert_allclose(res.c, o["c"], rtol=1e-5, atol=1e-12)
     with pytest.raises(mih.MendelIHTError):
         mih.fit_iht(y, x, np.ones((n, 65)), k=3, verbose=False)
 
