@@ -1051,3 +1051,21 @@ def test_gpu_against_committed_oracle_goldens(mih, normal_pair):
     assert rm.iter == gm["iter"] and [list(map(int, ij)) for ij in np.argwhere(rm.beta != 0)] == gm["support"]
     np.testing.assert_allclose([rm.beta[i, j] for i, j in gm["support"]], gm["B"], rtol=1e-5)
     np.testing.assert_allclose(rm.Σ, gm["Sigma"], rtol=1e-6)
+
+
+def test_forty_million_rows(mih, oracle):
+    """n = 40 000 000 samples (x 64 SNPs): more than 2^22 rows per default row slice, so the pass must raise the
+    number of slices to keep the f32 accumulators exact; 32-bit row indices and 64-bit offsets at scale."""
+    n, p = 40_000_000, 64
+    x = mih.SnpLinAlg.synthetic(n, p, seed=99, missing_rate=0.001)
+    rng = np.random.default_rng(9)
+    r = rng.standard_normal(n)
+    out = x.xtv(r)
+    ox = oracle.Mat.from_bed_columns(x.export_bed()[:8], n)          # the first 8 columns on the CPU
+    ref = ox.xtv(r)
+    assert rel(out[:8], ref) < 1e-10
+    assert np.array_equal(x.xtv(r), out)
+    idx = np.array([1, 5]); val = np.array([0.7, -1.1])
+    mask = np.zeros(8, np.uint8); mask[idx] = 1
+    coef = np.zeros(8); coef[idx] = val
+    assert rel(x.xv_sparse(idx, val), ox.xv_masked(mask, coef)) < 1e-11
