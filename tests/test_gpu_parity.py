@@ -1069,3 +1069,22 @@ def test_forty_million_rows(mih, oracle):
     mask = np.zeros(8, np.uint8); mask[idx] = 1
     coef = np.zeros(8); coef[idx] = val
     assert rel(x.xv_sparse(idx, val), ox.xv_masked(mask, coef)) < 1e-11
+
+
+def test_tiny_problems(mih, oracle):
+    """Degenerate sizes: a handful of samples, a single SNP, fewer rows than one 128-row tile."""
+    rng = np.random.default_rng(0)
+    for n, p, k in ((3, 1, 1), (5, 2, 1), (9, 33, 2), (130, 1, 1)):
+        cols = make_bed(rng, n, p, maf_lo=0.3)
+        x = mih.SnpLinAlg(cols, n=n, center=True, scale=True, impute=True)
+        ox = oracle.Mat.from_bed_columns(cols, n)
+        r = rng.standard_normal(n)
+        np.testing.assert_allclose(x.xtv(r), ox.xtv(r), rtol=1e-10, atol=1e-12)
+        y = rng.standard_normal(n)
+        res = mih.fit_iht(y, x, None, k=k, verbose=False, max_iter=10)
+        o = oracle.fit_iht(ox, y, None, k=k, max_iter=10)
+        assert res.iter == o["iter"], (n, p, k)
+        np.testing.assert_allclose(res.beta, o["beta"], rtol=1e-6, atol=1e-10)
+    x1 = mih.SnpLinAlg(make_bed(rng, 1, 4, maf_lo=0.3), n=1, center=True, scale=True, impute=True)
+    with pytest.raises(mih.MendelIHTError, match="NaN|Inf"):             # one sample: zero deviance, NaN loglikelihood
+        mih.fit_iht(np.array([0.3]), x1, None, k=1, verbose=False)
