@@ -259,11 +259,16 @@ int mih_xtv_algorithmic_bytes(const mih_mat *h, int m, double *bytes);
 /* Select the single-operand X'r kernel used by every subsequent call (tuning knob): -1 = library default
  * (digit planes shared through LDS), 0..15 = the per-wave-load shapes {waves, column groups, row slices}. */
 int mih_set_xtv_variant(int variant);
-/* Fixed-point width of the residual in the X'r passes of workspaces created AFTER the call.  28 (default):
- * 28 base-4 digits = 56 bits, the dot products are exact and the only rounding (2^-55 max|r|) is below
- * that of an n-term f64 sum.  16: 32-bit residuals, two of them share one MFMA B operand, so fused
- * multi-RHS passes (cv_iht, multivariate, init_beta) need half the matrix-pipe work, which is what
- * bounds them (they are power-limited); relative error of X'r about 2^-31 max|r| / |r|_rms ~ 1e-9. */
+/* Fixed-point format of the residual in the X'r passes of workspaces created AFTER the call.  The residual is
+ * scaled by a power of two, rounded to an integer and written as digits whose halves are FP4 numbers; the dot
+ * products with the dosages are then exact and the only rounding is that of the residual.
+ *   0  (default) 16 base-13 digits (digit set {-8,-6,-4..4,6,8}), |R| < 2^57: rounding 2^-57 max|r|, below that
+ *      of an n-term f64 sum.  16 columns per residual, so TWO residuals share one 32-column MFMA B operand.
+ *   28 28 base-4 digits {-2..1}, |R| < 2^54, one residual per operand (the cross-check; also chosen automatically
+ *      above 2^24 rows, where the base-13 row slices would exceed the slice limit).
+ *   16 16 base-4 digits, |R| < 2^30, two residuals per operand.
+ *   8  8 base-13 digits, |R| < 2^27, FOUR residuals per operand: opt-in fast mode for fused multi-RHS passes
+ *      (cv_iht, multivariate, init_beta), relative error of X'r about 2^-27 max|r| / |r|_rms. */
 int mih_set_xtv_digits(int digits);
 /* Select the launch shape of the LDS-shared X'r kernels (0 = built-in defaults; ids in csrc/xtv.hip dispatch_xtv;
  * some ids are timing probes whose output is NOT X'r).  Tuning / measurement knob. */

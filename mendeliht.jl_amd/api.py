@@ -534,8 +534,10 @@ class IHTSession:
             pass
 
 
-def set_xtv_digits(digits=28):
-    """28 = exact fixed-point X'r (default); 16 = fast mode for fused multi-RHS passes (see mih_set_xtv_digits)."""
+def set_xtv_digits(digits=0):
+    """Fixed-point format of the residual in X'r (see mih_set_xtv_digits): 0 = library default (16 base-13 digits,
+    57-bit, two residuals per MFMA operand); 28 = 28 base-4 digits, one residual per operand (54-bit cross-check);
+    16 = 16 base-4 digits (32-bit); 8 = 8 base-13 digits, four residuals per operand (27-bit, opt-in fast mode)."""
     _check(lib().mih_set_xtv_digits(int(digits)))
 
 

@@ -113,16 +113,23 @@ __host__ __device__ inline int64_t xword(int64_t nbp, int64_t j, int64_t t)
     return (((cg * nbp + bp) * 64 + (h * 32 + m)) << 2) + (e << 1) + u;
 }
 
-constexpr int kDigits = 28;          // balanced base-4 digits of the fixed-point residual (56 bits): the exact mode
-constexpr int kDigitsFast = 16;      // opt-in fast mode: 32-bit fixed point, TWO residuals per MFMA B operand
+// How a residual is written as FP4 digit planes (B-operand columns).  `base` 13 uses the digit set
+// {-8,-6,-4..4,6,8} (x 0.5 = FP4 values up to 4.0), a complete residue system mod 13; `base` 4 uses {-2,-1,0,1}.
+struct DigitMode {
+    int base;        // 13 or 4
+    int ndig;        // digits per residual
+    int per_op;      // residuals per 32-column B operand (32 / per_op columns each)
+    int ebits;       // the residual is scaled to max|r| * 2^e < 2^(ebits+1)
+    int rows_log2;   // a row slice holds at most 2^rows_log2 rows (f32 accumulators stay exact)
+};
 
 struct XtvWork {            // scratch for one in-flight X'r
     DevBuf<uint32_t> digits;   // ops * nblk * 64 lanes * 4 dwords : FP4 digit planes of r (B operands)
     DevBuf<double>   partial;  // splits * rhs * ncg*32 raw dots
     DevBuf<double>   scal;     // rhs * 4 : {max|r|, 2^-e, sum r, 2^e}
     int m_cap = 0, splits_cap = 0;
-    int per_op = 1;            // residual vectors per B operand (1: 28 digits each, 2: 16 digits each); fixed at init
-    int ops_cap = 0;           // B operands the buffers hold (multiple of 4)
+    DigitMode dm = {13, 16, 2, 56, 20};   // fixed at init (mih_set_xtv_digits)
+    int ops_cap = 0;           // B operands the buffers hold
 };
 int  xtv_work_init(const mih_mat *h, XtvWork &w, int m);
 // r_dev: m vectors of length n (column-major n x m) on device; out_dev p x m.

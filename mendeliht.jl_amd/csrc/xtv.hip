@@ -96,8 +96,7 @@ __global__ void k_r_stats_final(const double *__restrict__ part, int nblocks, in
     if (threadIdx.x != 0 || v >= m) return;
     double mx = 0.0, sm = 0.0;
     for (int b = 0; b < nblocks; ++b) { mx = fmax(mx, part[((int64_t)v * nblocks + b) * 2]); sm += part[((int64_t)v * nblocks + b) * 2 + 1]; }
-    // exponent e with max|r| * 2^e < 2^(ebits+1) (2^54 for 28 digits, 2^30 for 16); an all-zero (or
-    // non-finite) residual keeps e = 0
+    // exponent e with max|r| * 2^e < 2^(ebits+1) (DigitMode::ebits); an all-zero (or non-finite) residual keeps e = 0
     int e = 0;
     if (mx > 0.0 && mx < 1.0e300) e = ebits - ilogb(mx);
     if (e > 1000) e = 1000;          // a (numerically zero) residual below 2^-947: keep 2^e finite
@@ -107,41 +106,63 @@ __global__ void k_r_stats_final(const double *__restrict__ part, int nblocks, in
     scal[4 * v + 3] = ldexp(1.0, e);
 }
 
-// One thread per (B operand, 64-row block, lane = 32*h + t): column t of the operand is digit (t % slots) of
-// residual per_op*op + t / slots (slots = 32 / per_op), for the 32 rows of half h, packed as the FP4
-// B-operand fragment (element order identical to the A fragment built in k_xtv_mfma).
+// digit of residue m (0..12) in the base-13 system: {-8,-6,-4..4,6,8} is a complete residue system mod 13 whose
+// halves are all FP4 (e2m1) numbers; every |R| <= 2^57 has a 16-digit representation (|R| <= 2^27: 8 digits)
+__device__ __forceinline__ int digit13(int m)
+{
+    return m <= 4 ? m : m >= 9 ? m - 13 : m == 5 ? -8 : m == 6 ? 6 : m == 7 ? -6 : 8;
+}
+
+// grid (ceil(nblk / 4), residual slots).  One thread per row turns the scaled residual into its digits (4-bit FP4
+// codes of d/2, digit t in nibble t); the 64 rows of a block are then transposed through LDS into the B-operand
+// fragment: column sub*slots + t of operand v / per_op holds digit t of residual v (slots = 32 / per_op), lane
+// 32*h + column carries the 32 rows of half h (element order identical to the A fragment built in mfma_fp4).
 __global__ void __launch_bounds__(256)
-k_digits(const double *__restrict__ r, int64_t n, int64_t nblk, int m, int nops, int per_op, int ndig,
+k_digits(const double *__restrict__ r, int64_t n, int64_t nblk, int m, DigitMode dm,
          const double *__restrict__ scal, uint4 *__restrict__ dig /* [nops][nblk][64] */)
 {
-    int64_t gid = blockIdx.x * 256ll + threadIdx.x;
-    int64_t total = (int64_t)nops * nblk * 64;
-    if (gid >= total) return;
-    int lane = (int)(gid & 63), t = lane & 31, h = lane >> 5;
-    int64_t ob = gid >> 6, op = ob / nblk, blk = ob - op * nblk;
-    const int slots = 32 / per_op, dg = t % slots;
-    const int64_t v = op * per_op + t / slots;
-    uint32_t out[4] = {0u, 0u, 0u, 0u};
-    if (dg < ndig && v < m) {
-        const double sc = scal[4 * v + 3];
-        const double *rv = r + v * n;
-        int64_t row0 = blk * 64 + h * 32;
-        const unsigned long long bias = 0xAAAAAAAAAAAAAAAAull >> (64 - 2 * ndig);   // every digit + 2
+    __shared__ unsigned long long nib[4][64][2];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t blk = blockIdx.x * 4ll + w;
+    const int vs = blockIdx.y;
+    const int slots = 32 / dm.per_op, op = vs / dm.per_op, sub = vs % dm.per_op;
+    unsigned long long lo = 0, hi = 0;
+    if (vs < m && blk < nblk) {
+        const int64_t i = blk * 64 + lane;
+        const double x = (i < n) ? r[(int64_t)vs * n + i] : 0.0;
+        long long R = __double2ll_rn(x * scal[4 * vs + 3]);
+        for (int t = 0; t < dm.ndig; ++t) {
+            int d;
+            if (dm.base == 4) {
+                const int mm = (int)(R & 3);
+                d = mm < 2 ? mm : mm - 4;
+                R = (R - d) >> 2;
+            } else {
+                int mm = (int)(R % 13);
+                if (mm < 0) mm += 13;
+                d = digit13(mm);
+                R = (R - d) / 13;
+            }
+            const unsigned a = (unsigned)(d < 0 ? -d : d);
+            const unsigned long long code = (a <= 4 ? a : a == 6 ? 5u : 6u) | (d < 0 ? 8u : 0u);   // FP4 code of d/2
+            if (t < 16) lo |= code << (4 * t); else hi |= code << (4 * (t - 16));
+        }
+    }
+    nib[w][lane][0] = lo; nib[w][lane][1] = hi;
+    __syncthreads();
+    if (blk < nblk && lane < 2 * slots) {
+        const int h = lane / slots, dg = lane % slots;
+        uint32_t out[4] = {0u, 0u, 0u, 0u};
         #pragma unroll
         for (int u = 0; u < 2; ++u) {
             #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                int64_t i = row0 + u * 16 + s;
-                double x = (i < n) ? rv[i] : 0.0;
-                long long R = __double2ll_rn(x * sc);
-                unsigned long long U = (unsigned long long)R + bias;
-                uint32_t d = (uint32_t)(U >> (2 * dg)) & 3u;                             // digit + 2 in 0..3
-                uint32_t code = (0x109Au >> (4 * d)) & 0xFu;                             // -1, -0.5, 0, +0.5 in FP4
+                const uint32_t code = (uint32_t)(nib[w][h * 32 + u * 16 + s][dg >> 4] >> (4 * (dg & 15))) & 0xFu;
                 out[2 * u + (s & 1)] |= code << (4 * (s >> 1));
             }
         }
+        dig[((int64_t)op * nblk + blk) * 64 + h * 32 + sub * slots + dg] = make_uint4(out[0], out[1], out[2], out[3]);
     }
-    dig[gid] = make_uint4(out[0], out[1], out[2], out[3]);
 }
 
 // ---- the matrix-pipe kernel -------------------------------------------------------------------
@@ -165,28 +186,33 @@ __device__ __forceinline__ f32x16 mfma_fp4(uint32_t u0, uint32_t u1, const uint4
 
 // D layout: column n = lane & 31, row (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5) (SNP).  Column n holds digit
 // (n % slots) of residual per_op*v + n / slots of B operand v (slots = 32 / per_op).
-// acc = (1/4) sum_i g_i d_i exactly; recombine digits: sum_t 4^t * (4 acc_t), then * 2^-e.
+// acc = (1/4) sum_i g_i d_i exactly; recombine digits: sum_t base^t * (4 acc_t), then * 2^-e.
 template <int CT, int NR>
 __device__ __forceinline__ void xtv_epilogue(const f32x16 (&acc)[CT][NR], int lane, int64_t cg0, int64_t ncg, int split,
-                                             int splits, int per_op, const double *__restrict__ scal,
+                                             int splits, DigitMode dm, const double *__restrict__ scal,
                                              double *__restrict__ partial)
 {
-    const int slots = 32 / per_op;
+    const int slots = 32 / dm.per_op;
     const int dgt = lane & (slots - 1), sub = (lane & 31) / slots;
-    const int ndig = (per_op == 1) ? kDigits : kDigitsFast;
-    const double wgt = (dgt < ndig) ? ldexp(1.0, 2 + 2 * dgt) : 0.0;
+    double wgt = 0.0;
+    if (dgt < dm.ndig) {
+        unsigned long long w = 4;                        // 4 * base^dgt < 2^58: exact in 64 bits, one rounding to f64
+        for (int t = 0; t < dgt; ++t) w *= (unsigned)dm.base;
+        wgt = (double)w;
+    }
     #pragma unroll
     for (int v = 0; v < NR; ++v) {
-        const int rhs = v * per_op + sub;
+        const int rhs = v * dm.per_op + sub;
         const double inv = scal[4 * rhs + 1];
         #pragma unroll
         for (int c = 0; c < CT; ++c) {
             #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 double x = (double)acc[c][v][g] * wgt;
-                if (per_op == 1) x += __shfl_xor(x, 16, 64);
+                if (slots > 16) x += __shfl_xor(x, 16, 64);                          // fixed tree within each group of
+                if (slots > 8) x += __shfl_xor(x, 8, 64);                            // `slots` lanes
                 #pragma unroll
-                for (int off = 8; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);   // within each group of `slots` lanes
+                for (int off = 4; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
                 int row = (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
                 if (dgt == 0 && cg0 + c < ncg)
                     partial[((int64_t)rhs * splits + split) * (ncg * 32) + (cg0 + c) * 32 + row] = x * inv;
@@ -200,7 +226,7 @@ __device__ __forceinline__ void xtv_epilogue(const f32x16 (&acc)[CT][NR], int la
 template <int WAVES, int CT, int NR>
 __global__ void __launch_bounds__(WAVES * 64)
 k_xtv_mfma(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *__restrict__ dig, int64_t dig_stride,
-           int splits, int per_op, const double *__restrict__ scal, double *__restrict__ partial /* [NR*per_op][splits][ncg*32] */)
+           int splits, DigitMode dm, const double *__restrict__ scal, double *__restrict__ partial /* [NR*per_op][splits][ncg*32] */)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -254,7 +280,7 @@ k_xtv_mfma(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *_
         }
     }
 
-    xtv_epilogue<CT, NR>(acc, lane, cg0, ncg, split, splits, per_op, scal, partial);
+    xtv_epilogue<CT, NR>(acc, lane, cg0, ncg, split, splits, dm, scal, partial);
 }
 
 // NR (2 or 4) B operands per pass with the digit planes shared through LDS.  A workgroup of WAVES
@@ -271,7 +297,7 @@ k_xtv_mfma(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *_
 template <int NR, int CT, int RB, int MODE = 0, int WAVES = 8>   // MODE 1: no MFMAs, 2: no dosage loads (timing probes only)
 __global__ void __launch_bounds__(WAVES * 64, 2)
 k_xtv_mfma_lds(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *__restrict__ dig, int64_t dig_stride,
-               int splits, int per_op, const double *__restrict__ scal, double *__restrict__ partial /* [NR*per_op][splits][ncg*32] */)
+               int splits, DigitMode dm, const double *__restrict__ scal, double *__restrict__ partial /* [NR*per_op][splits][ncg*32] */)
 {
     constexpr int NT = WAVES * 64;
     constexpr int BLK = NR * 2 * 64;                 // uint4 slots of one 128-row block: (operand v, 64-row half e, lane)
@@ -383,7 +409,7 @@ k_xtv_mfma_lds(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint
         }
     }
     if (cg0 >= ncg) return;
-    xtv_epilogue<CT, NR>(acc, lane, cg0, ncg, split, splits, per_op, scal, partial);
+    xtv_epilogue<CT, NR>(acc, lane, cg0, ncg, split, splits, dm, scal, partial);
 }
 
 // Combine slices, add the missing-entry correction, centre, scale.
@@ -529,23 +555,23 @@ static Variant current_variant()
 }
 
 template <int WAVES, int CT, int NR>
-static void launch_xtv(const mih_mat *h, const uint4 *dig, int64_t dig_stride, int splits, int per_op, const double *scal,
+static void launch_xtv(const mih_mat *h, const uint4 *dig, int64_t dig_stride, int splits, DigitMode dm, const double *scal,
                        double *partial, hipStream_t s)
 {
     int64_t groups = (h->ncg + WAVES * CT - 1) / (WAVES * CT);
     hipLaunchKernelGGL((k_xtv_mfma<WAVES, CT, NR>), dim3((unsigned)(groups * splits)), dim3(WAVES * 64), 0, s,
-                       reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig_stride, splits, per_op, scal, partial);
+                       reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig_stride, splits, dm, scal, partial);
 }
 
 // nr B operands per pass: 1 = the tuned single-operand variants; 2 / 4 = fused passes (64 / 128 accumulator
 // registers).  Each operand carries per_op residual vectors.
 static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 *dig, int64_t dig_stride, int splits,
-                        int per_op, const double *scal, double *partial, hipStream_t s)
+                        DigitMode dm, const double *scal, double *partial, hipStream_t s)
 {
 #define MIH_LDS(NRV, ID, C, RB, MODE, W) if (nr == NRV && mv == ID) { \
         int64_t groups = (h->ncg + W * C - 1) / (W * C); \
         hipLaunchKernelGGL((k_xtv_mfma_lds<NRV, C, RB, MODE, W>), dim3((unsigned)(groups * splits)), dim3(W * 64), 0, s, \
-                           reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig_stride, splits, per_op, scal, partial); \
+                           reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig_stride, splits, dm, scal, partial); \
         return MIH_OK; }
     if (nr == 4 || nr == 2) {
         const int mv = g_xtv_multi_variant;
@@ -555,7 +581,7 @@ static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 
         MIH_LDS(4, 5, 2, 1, 0, 4) MIH_LDS(4, 6, 2, 2, 0, 4)
         MIH_LDS(4, 7, 2, 2, 1, 8) MIH_LDS(4, 8, 2, 2, 2, 8)      // timing probes (results are NOT X'r)
         MIH_LDS(2, 1, 2, 2, 0, 8) MIH_LDS(2, 2, 4, 2, 0, 8) MIH_LDS(2, 3, 2, 4, 0, 8) MIH_LDS(2, 4, 4, 1, 0, 8)
-        if (nr == 2 && mv == 5) { launch_xtv<4, 2, 2>(h, dig, dig_stride, splits, per_op, scal, partial, s); return MIH_OK; }   // per-wave digit loads
+        if (nr == 2 && mv == 5) { launch_xtv<4, 2, 2>(h, dig, dig_stride, splits, dm, scal, partial, s); return MIH_OK; }   // per-wave digit loads
         if (nr == 2) { MIH_LDS(2, mv, 4, 1, 0, 4) }            // variants that only exist for 4 operands
         set_error("unknown multi-RHS kernel variant");
         return MIH_BAD_ARG;
@@ -571,7 +597,7 @@ static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 
         { MIH_LDS(1, mv, 1, 4, 0, 8) }                    // multi-operand variant ids fall back to the default shape
     }
 #undef MIH_LDS
-#define MIH_CASE(W, C) if (v.waves == W && v.ct == C) { launch_xtv<W, C, 1>(h, dig, dig_stride, splits, per_op, scal, partial, s); return MIH_OK; }
+#define MIH_CASE(W, C) if (v.waves == W && v.ct == C) { launch_xtv<W, C, 1>(h, dig, dig_stride, splits, dm, scal, partial, s); return MIH_OK; }
     MIH_CASE(4, 1) MIH_CASE(4, 2) MIH_CASE(4, 4) MIH_CASE(8, 1) MIH_CASE(8, 2) MIH_CASE(2, 2) MIH_CASE(8, 4) MIH_CASE(4, 8) MIH_CASE(2, 4)
 #undef MIH_CASE
     set_error("unknown X'r kernel variant");
@@ -580,18 +606,36 @@ static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 
 
 constexpr int kStatBlocks = 64;
 
-int g_xtv_digits = kDigits;      // kDigits (exact) or kDigitsFast (two residuals per B operand); mih_set_xtv_digits
+// mih_set_xtv_digits: 0 = library default (16 base-13 digits, two residuals per B operand, 57-bit fixed point);
+// 28 = 28 base-4 digits, one residual per operand (54-bit; the first exact mode, kept as a cross-check and
+// used automatically above 2^24 rows); 16 = 16 base-4 digits, two per operand (32-bit); 8 = 8 base-13 digits,
+// four per operand (27-bit, opt-in fast mode)
+int g_xtv_digits = 0;
+
+static bool digit_mode(int id, DigitMode &dm)
+{
+    switch (id) {
+    case 0:  dm = {13, 16, 2, 56, 20}; return true;
+    case 28: dm = {4, 28, 1, 53, 22}; return true;
+    case 16: dm = {4, 16, 2, 29, 22}; return true;
+    case 8:  dm = {13, 8, 4, 26, 20}; return true;
+    }
+    return false;
+}
 
 int xtv_work_init(const mih_mat *h, XtvWork &w, int m)
 {
     if (h->kind != 0) return MIH_OK;
     int64_t nblk = h->nbp * 2;
-    w.per_op = (g_xtv_digits == kDigitsFast) ? 2 : 1;
-    // operand capacity rounded up to a multiple of 4: three leftover operands ride a 4-operand pass with an
-    // all-zero digit plane (29 ms) instead of a 2- + a 1-operand pass (45 ms)
-    const int ops = (m + w.per_op - 1) / w.per_op;
-    w.ops_cap = (ops + 3) & ~3;
-    const size_t rhs_cap = (size_t)w.ops_cap * w.per_op;
+    digit_mode(g_xtv_digits, w.dm);
+    // the base-13 products reach 4.0, so a row slice holds 2^20 rows; beyond kMaxSplits such slices the default
+    // falls back to base-4 digits (2^22 rows per slice)
+    if (g_xtv_digits == 0 && h->n_pad > ((int64_t)kMaxSplits << w.dm.rows_log2)) digit_mode(28, w.dm);
+    // operand capacity rounded up to a multiple of 4 from three operands on: three leftover operands ride a
+    // 4-operand pass with an all-zero digit plane (29 ms) instead of a 2- + a 1-operand pass (37 ms)
+    const int ops = (m + w.dm.per_op - 1) / w.dm.per_op;
+    w.ops_cap = ops < 3 ? ops : (ops + 3) & ~3;
+    const size_t rhs_cap = (size_t)w.ops_cap * w.dm.per_op;
     MIH_TRY(w.digits.alloc((size_t)w.ops_cap * (size_t)nblk * 64 * 4));
     MIH_TRY(w.partial.alloc((size_t)kMaxSplits * rhs_cap * (size_t)h->ncg * 32));
     MIH_TRY(w.scal.alloc(rhs_cap * 4 + (size_t)m * kStatBlocks * 2));
@@ -617,20 +661,21 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
     if (m > w.m_cap) { set_error("X'r workspace too small"); return MIH_BAD_ARG; }
     Variant v = current_variant();
     int splits = v.splits;
-    // exactness of the f32 accumulators: a row slice may hold at most 2^22 rows (|g/2 * d| <= 1 in units of 1/4)
-    const int64_t need = (h->n_pad + (1ll << 22) - 1) >> 22;
+    // exactness of the f32 accumulators: |g/2 * d/2| <= 1 (base 4) or 4 (base 13) in units of 1/4, so a row
+    // slice may hold at most 2^22 / 2^20 rows
+    const DigitMode dm = w.dm;
+    const int64_t need = (h->n_pad + (1ll << dm.rows_log2) - 1) >> dm.rows_log2;
     if (need > w.splits_cap) { set_error("n = %lld rows needs more than %d row slices for exact accumulation", (long long)h->n, w.splits_cap); return MIH_BAD_DIM; }
     if (splits < need) splits = (int)need;
     if (splits > h->nbp) splits = (int)h->nbp;
     if (splits > w.splits_cap) splits = w.splits_cap;
     const int64_t nblk = h->nbp * 2, pstride = h->ncg * 32;
-    const int per_op = w.per_op, ndig = (per_op == 1) ? kDigits : kDigitsFast;
+    const int per_op = dm.per_op;
     const int nops = (m + per_op - 1) / per_op;
     double *part = w.scal.p + (size_t)w.ops_cap * per_op * 4;
     hipLaunchKernelGGL(k_r_stats, dim3(kStatBlocks), dim3(256), 0, s, r_dev, h->n, m, part);
-    hipLaunchKernelGGL(k_r_stats_final, dim3(m), dim3(64), 0, s, part, kStatBlocks, m, 2 * ndig - 3, w.scal.p);
-    int64_t total = (int64_t)nops * nblk * 64;
-    hipLaunchKernelGGL(k_digits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, r_dev, h->n, nblk, m, nops, per_op, ndig,
+    hipLaunchKernelGGL(k_r_stats_final, dim3(m), dim3(64), 0, s, part, kStatBlocks, m, dm.ebits, w.scal.p);
+    hipLaunchKernelGGL(k_digits, dim3((unsigned)((nblk + 3) / 4), (unsigned)(nops * per_op)), dim3(256), 0, s, r_dev, h->n, nblk, m, dm,
                        w.scal.p, reinterpret_cast<uint4 *>(w.digits.p));
     for (int t = 0; t < nops;) {          // t counts B operands
         int nr = (nops - t >= 3 && g_xtv_max_nr >= 4 && t + 4 <= w.ops_cap) ? 4
@@ -640,7 +685,7 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
         const uint4 *dig = reinterpret_cast<const uint4 *>(w.digits.p) + (int64_t)t * nblk * 64;
         hipEvent_t e0, e1;
         prof_begin(s, e0, e1);
-        int rc = dispatch_xtv(v, nr, h, dig, nblk * 64, splits, per_op, w.scal.p + 4 * u0, partial, s);
+        int rc = dispatch_xtv(v, nr, h, dig, nblk * 64, splits, dm, w.scal.p + 4 * u0, partial, s);
         prof_end(s, e0, e1);
         if (rc) return rc;
         for (int u = u0; u < (t + nr) * per_op && u < m; ++u)
@@ -693,7 +738,8 @@ int mih_set_xtv_variant(int variant)
 
 int mih_set_xtv_digits(int digits)
 {
-    if (digits != kDigits && digits != kDigitsFast) { set_error("digits must be %d (exact) or %d (fast)", kDigits, kDigitsFast); return MIH_BAD_ARG; }
+    DigitMode dm;
+    if (!digit_mode(digits, dm)) { set_error("digit mode must be 0 (default), 28, 16 or 8"); return MIH_BAD_ARG; }
     g_xtv_digits = digits;
     return MIH_OK;
 }

@@ -582,7 +582,7 @@ def test_full_size_baseline_config_p1M(mih, oracle):
         f1 = x.xtv(r1)
         F5 = x.xtv(R)
     finally:
-        mih.set_xtv_digits(28)
+        mih.set_xtv_digits(0)
     assert np.max(np.abs(f1 - o1)) < 1e-8 * np.sqrt(n) * np.abs(r1).max()
     assert np.array_equal(F5[:, 0], f1) and np.max(np.abs(F5 - O5)) < 1e-8 * np.sqrt(n) * np.abs(R).max()
 
@@ -634,19 +634,21 @@ def test_concurrent_fits_share_one_matrix(mih, normal_pair, normal_data):
         assert np.array_equal(a.beta, b.beta) and np.array_equal(a.c, b.c) and a.logl == b.logl and a.iter == b.iter
 
 
-def test_fast_digit_mode(mih, oracle, normal_pair, normal_data):
-    """mih_set_xtv_digits(16): 32-bit fixed-point residuals, two per MFMA B operand (the opt-in mode for
-    fused multi-RHS passes).  X'r stays within 1e-8 of the exact mode, is independent of how the
-    residuals are grouped into passes, and fits / cross-validation stay inside the north_star tolerance."""
+@pytest.mark.parametrize("mode,quantum", [(8, 2e-7), (16, 1e-8)])
+def test_fast_digit_mode(mih, oracle, normal_pair, normal_data, mode, quantum):
+    """mih_set_xtv_digits(8): 27-bit fixed-point residuals, four per MFMA B operand (the opt-in mode for
+    fused multi-RHS passes), and (16): 32-bit base-4 residuals, two per operand.  X'r stays within the format's
+    quantum of the exact mode, is independent of how the residuals are grouped into passes, and fits /
+    cross-validation stay inside the north_star tolerance."""
     x, ox = normal_pair
     n = x.n
     R = np.random.default_rng(5).standard_normal((n, 9))
     exact = x.xtv(R)
-    mih.set_xtv_digits(16)
+    mih.set_xtv_digits(mode)
     try:
         fast = x.xtv(R)
         scale = np.sqrt(n) * np.abs(R).max()                      # size of a null-SNP score
-        assert np.max(np.abs(fast - exact)) < 1e-8 * scale
+        assert np.max(np.abs(fast - exact)) < quantum * scale
         assert not np.array_equal(fast, exact)                    # it really is the other arithmetic
         singles = np.column_stack([x.xtv(R[:, v]) for v in range(9)])
         for m_rhs in range(1, 10):                                # pairs, padded 4-operand passes, odd tails
@@ -670,10 +672,35 @@ def test_fast_digit_mode(mih, oracle, normal_pair, normal_data):
         assert np.array_equal(rm.beta != 0, om["B"] != 0)
         np.testing.assert_allclose(rm.beta, om["B"], rtol=1e-5, atol=1e-12)
     finally:
-        mih.set_xtv_digits(28)
+        mih.set_xtv_digits(0)
     assert np.array_equal(x.xtv(R), exact)                        # back to the exact mode
     with pytest.raises(mih.MendelIHTError):
         mih.set_xtv_digits(20)
+
+
+def test_digit_modes_agree(mih, oracle, normal_pair):
+    """Every fixed-point format of the residual (mih_set_xtv_digits) against the oracle's f64 X'r: the default
+    (16 base-13 digits, two residuals per operand) and the 28 base-4 digit cross-check agree to f64 rounding;
+    the 32-bit and 27-bit formats to their quantum; each is independent of how residuals share operands."""
+    x, ox = normal_pair
+    n = x.n
+    rng = np.random.default_rng(77)
+    R = rng.standard_normal((n, 11)) * np.logspace(-3, 4, 11)      # very different scales side by side
+    O = np.column_stack([ox.xtv(R[:, v]) for v in range(11)])
+    scale = np.sqrt(n) * np.abs(R).max(axis=0)
+    out = {}
+    try:
+        for mode, tol in ((0, 2e-15), (28, 2e-15), (16, 1e-8), (8, 2e-7)):
+            mih.set_xtv_digits(mode)
+            got = x.xtv(R)
+            assert np.all(np.max(np.abs(got - O), axis=0) < tol * scale + 1e-13 * np.abs(O).max(axis=0)), mode
+            for m_rhs in (1, 2, 3, 5, 8):
+                assert np.array_equal(x.xtv(R[:, :m_rhs]), got[:, :m_rhs]), (mode, m_rhs)
+            out[mode] = got
+    finally:
+        mih.set_xtv_digits(0)
+    assert np.all(np.max(np.abs(out[0] - out[28]), axis=0) <= 2e-15 * scale)
+    assert not np.array_equal(out[0], out[8])
 
 
 @pytest.mark.parametrize("case", ["gamma_log", "invgauss_log", "bernoulli_probit", "bernoulli_cloglog", "bernoulli_cauchit",

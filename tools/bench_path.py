@@ -14,7 +14,7 @@ for digits in (28, 16):
     m.set_xtv_digits(digits)
     t0 = time.perf_counter(); ll = m.iht_run_many_models(y, x, None, path=path, verbose=False); dt = time.perf_counter() - t0
     print(f"digits={digits}: lock-step path=1:20 in {dt:.2f} s (argmax of the logl increments at k={int(np.argmax(np.diff(ll) < 1.0)) + 1})", flush=True)
-m.set_xtv_digits(28)
+m.set_xtv_digits(0)
 t0 = time.perf_counter()
 seq = [m.fit_iht(y, x, None, k=k, verbose=False, max_iter=100).logl for k in path]
 dt = time.perf_counter() - t0
