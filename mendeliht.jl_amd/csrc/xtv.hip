@@ -12,14 +12,17 @@
 // exact small-integer data, so the dot products are done EXACTLY in fixed point on the matrix pipe:
 //   * a 2-bit dosage code placed in the low bits of a nibble IS the FP4 (e2m1) number g/2, so the
 //     A operand of v_mfma_scale_f32_32x32x64_f8f6f4 is built with one AND per 8 dosages;
-//   * r is scaled by a power of two to |R| < 2^54, rounded to an integer and written as 28 balanced
-//     base-4 digits d in {-2,-1,0,1} (FP4 values -1, -0.5, 0, 0.5); the 28 digit planes are 28 of
-//     the 32 B-operand columns, so ONE MFMA multiplies a 32-column x 64-row dosage tile with all
-//     digits of the residual;
-//   * every product and every partial sum is a multiple of 1/4 below 2^22 in magnitude, so the f32
-//     accumulators are exact and the result does not depend on summation order (bit-reproducible);
-//   * the digit sums are recombined in f64 (sum_t 4^t * S_t, fixed order) and rescaled by 2^-e.
-// The inexact steps are the rounding of r to 2^-55 of max|r| and the few f64 additions that recombine the
+//   * r is scaled by a power of two to |R| < 2^57, rounded to an integer and written as 16 digits in base 13
+//     from the digit set {-8,-6,-4,...,4,6,8}: a complete residue system mod 13 whose halves (0, +-0.5, +-1,
+//     +-1.5, +-2, +-3, +-4) are all FP4 numbers.  The 16 digit planes of a residual are 16 of the 32
+//     B-operand columns, so ONE MFMA multiplies a 32-column x 64-row dosage tile with all digits of TWO
+//     residuals (the earlier format, 28 balanced base-4 digits {-2..1} = one residual per operand, is kept
+//     as mih_set_xtv_digits(28));
+//   * every product is a multiple of 1/4 of magnitude <= 4 and a row slice holds at most 2^20 rows, so every
+//     partial sum is a multiple of 1/4 below 2^22: the f32 accumulators are exact and the result does not
+//     depend on summation order (bit-reproducible);
+//   * the digit sums are recombined in f64 (sum_t 13^t * S_t, fixed order) and rescaled by 2^-e.
+// The inexact steps are the rounding of r to 2^-57 of max|r| and the few f64 operations that recombine the
 // digit sums (fixed order, so bit-reproducible for a given row slicing) -- tighter than the rounding an
 // n-term f64 dot product accumulates.  Per 2048 dosages: 1 MFMA (13.7 ns/SIMD) + ~8 VALU ops, far
 // below the 87 ns/SIMD the HBM stream allows at 6 TB/s, so the kernel is memory-bound.
@@ -33,7 +36,8 @@
 //                                (library default for 1, 2 and 4 B operands per pass);
 //   k_xtv_mfma<WAVES,CT,NR>      every wave loads its own digit planes from L2 (the earlier shapes, kept as
 //                                selectable variants and as a cross-check: same arithmetic, same bits).
-// An operand carries one 28-digit residual (exact mode) or two 16-digit residuals (opt-in fast mode).
+// An operand carries two 16-digit residuals (default), one 28-digit base-4 residual, or four 8-digit residuals
+// (opt-in fast mode): DigitMode.
 #include "common.h"
 #include <mutex>
 #include <utility>
