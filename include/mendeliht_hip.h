@@ -260,15 +260,18 @@ int mih_xtv_algorithmic_bytes(const mih_mat *h, int m, double *bytes);
  * (digit planes shared through LDS), 0..15 = the per-wave-load shapes {waves, column groups, row slices}. */
 int mih_set_xtv_variant(int variant);
 /* Fixed-point format of the residual in the X'r passes of workspaces created AFTER the call.  The residual is
- * scaled by a power of two, rounded to an integer and written as digits whose halves are FP4 numbers; the dot
- * products with the dosages are then exact and the only rounding is that of the residual.
- *   0  (default) 16 base-13 digits (digit set {-8,-6,-4..4,6,8}), |R| < 2^57: rounding 2^-57 max|r|, below that
- *      of an n-term f64 sum.  16 columns per residual, so TWO residuals share one 32-column MFMA B operand.
- *   28 28 base-4 digits {-2..1}, |R| < 2^54, one residual per operand (the cross-check; also chosen automatically
- *      above 2^24 rows, where the base-13 row slices would exceed the slice limit).
- *   16 16 base-4 digits, |R| < 2^30, two residuals per operand.
- *   8  8 base-13 digits, |R| < 2^27, FOUR residuals per operand: opt-in fast mode for fused multi-RHS passes
- *      (cv_iht, multivariate, init_beta), relative error of X'r about 2^-27 max|r| / |r|_rms. */
+ * scaled by a power of two, rounded to an integer R and written as digits that FP6 / FP4 represent exactly; each
+ * digit plane is one column of the MFMA B operand, the dot products with the dosages are exact, and the only
+ * rounding is that of the residual.  id = base * 100 + digits:
+ *   0 = 4910 (default) 10 base-49 digits d/8 in FP6 (e2m3), |R| < 2^54: rounding 2^-54 max|r|, below that of an
+ *        n-term f64 sum.  THREE residuals share one 32-column operand.  Row slices of 2^18 rows; above 2^22
+ *        rows (and for the per-wave kernel shapes, mih_set_xtv_variant >= 0) the default steps down to 1316.
+ *   1316 16 base-13 digits d/2 in FP4 (e2m1), |R| < 2^57, two residuals per operand (2^20-row slices; above 2^24
+ *        rows the default steps down to 428).
+ *   428  28 base-4 digits {-2..1}/2 in FP4, |R| < 2^54, one residual per operand (the first format; cross-check).
+ *   4908 8 base-49 FP6 digits, |R| < 2^43, FOUR residuals per operand: opt-in fast mode for fused multi-RHS
+ *        passes (cv_iht, multivariate, init_beta); relative error of X'r about 2^-43 max|r| / |r|_rms ~ 1e-12.
+ *   1308 8 base-13 FP4 digits, |R| < 2^27, four per operand (~15 % faster than 4908, error ~1e-7). */
 int mih_set_xtv_digits(int digits);
 /* Select the launch shape of the LDS-shared X'r kernels (0 = built-in defaults; ids in csrc/xtv.hip dispatch_xtv;
  * some ids are timing probes whose output is NOT X'r).  Tuning / measurement knob. */

@@ -535,9 +535,10 @@ class IHTSession:
 
 
 def set_xtv_digits(digits=0):
-    """Fixed-point format of the residual in X'r (see mih_set_xtv_digits): 0 = library default (16 base-13 digits,
-    57-bit, two residuals per MFMA operand); 28 = 28 base-4 digits, one residual per operand (54-bit cross-check);
-    16 = 16 base-4 digits (32-bit); 8 = 8 base-13 digits, four residuals per operand (27-bit, opt-in fast mode)."""
+    """Fixed-point format of the residual in X'r (see mih_set_xtv_digits), id = base * 100 + digits: 0 = library
+    default = 4910 (10 base-49 FP6 digits, 54-bit, three residuals per MFMA operand); 1316 (16 base-13 FP4 digits,
+    57-bit, two per operand); 428 (28 base-4 digits, one per operand); 4908 (43-bit, four per operand: the opt-in
+    fast mode for fused multi-RHS passes); 1308 (27-bit, four per operand)."""
     _check(lib().mih_set_xtv_digits(int(digits)))
 
 

@@ -113,22 +113,24 @@ __host__ __device__ inline int64_t xword(int64_t nbp, int64_t j, int64_t t)
     return (((cg * nbp + bp) * 64 + (h * 32 + m)) << 2) + (e << 1) + u;
 }
 
-// How a residual is written as FP4 digit planes (B-operand columns).  `base` 13 uses the digit set
-// {-8,-6,-4..4,6,8} (x 0.5 = FP4 values up to 4.0), a complete residue system mod 13; `base` 4 uses {-2,-1,0,1}.
+// How a residual is written as digit planes (B-operand columns of the block-scaled MFMA).
+//   base 49: FP6 (e2m3) digits d/8 with d in {-32..-18 even step, -16..16, 18..32 even}  (a complete residue system mod 49)
+//   base 13: FP4 (e2m1) digits d/2 with d in {-8,-6,-4..4,6,8}
+//   base  4: FP4 digits d/2 with d in {-2,-1,0,1}
 struct DigitMode {
-    int base;        // 13 or 4
+    int base;        // 49, 13 or 4
     int ndig;        // digits per residual
-    int per_op;      // residuals per 32-column B operand (32 / per_op columns each)
+    int per_op;      // residuals per 32-column B operand
+    int slots;       // columns per residual (ndig <= slots, per_op * slots <= 32)
     int ebits;       // the residual is scaled to max|r| * 2^e < 2^(ebits+1)
     int rows_log2;   // a row slice holds at most 2^rows_log2 rows (f32 accumulators stay exact)
 };
-
 struct XtvWork {            // scratch for one in-flight X'r
-    DevBuf<uint32_t> digits;   // ops * nblk * 64 lanes * 4 dwords : FP4 digit planes of r (B operands)
+    DevBuf<uint32_t> digits;   // ops * nblk * 64 lanes * 4 dwords (+ 2 dwords, stored behind, for FP6) : digit planes of r (B operands)
     DevBuf<double>   partial;  // splits * rhs * ncg*32 raw dots
     DevBuf<double>   scal;     // rhs * 4 : {max|r|, 2^-e, sum r, 2^e}
     int m_cap = 0, splits_cap = 0;
-    DigitMode dm = {13, 16, 2, 56, 20};   // fixed at init (mih_set_xtv_digits)
+    DigitMode dm = {13, 16, 2, 16, 56, 20};   // fixed at init (mih_set_xtv_digits)
     int ops_cap = 0;           // B operands the buffers hold
 };
 int  xtv_work_init(const mih_mat *h, XtvWork &w, int m);

@@ -116,21 +116,30 @@ __device__ __forceinline__ int digit13(int m)
 {
     return m <= 4 ? m : m >= 9 ? m - 13 : m == 5 ? -8 : m == 6 ? 6 : m == 7 ? -6 : 8;
 }
+// base 49: residues 0..16 and 33..48 (= -16..-1) directly, 17..32 as the even number itself or the odd number
+// minus 49 (-32..-18, even): all of them eighths that FP6 (e2m3) represents; |R| <= 2^54 has 10 digits, 2^43 has 8
+__device__ __forceinline__ int digit49(int m)
+{
+    return m <= 16 ? m : m >= 33 ? m - 49 : (m & 1) ? m - 49 : m;
+}
 
-// grid (ceil(nblk / 4), residual slots).  One thread per row turns the scaled residual into its digits (4-bit FP4
-// codes of d/2, digit t in nibble t); the 64 rows of a block are then transposed through LDS into the B-operand
-// fragment: column sub*slots + t of operand v / per_op holds digit t of residual v (slots = 32 / per_op), lane
-// 32*h + column carries the 32 rows of half h (element order identical to the A fragment built in mfma_fp4).
+// grid (ceil(nblk / 4), residual slots).  One thread per row turns the scaled residual into its digits (FP4 code of
+// d/2 or FP6 code of d/8, packed 16 x 4 or 10 x 6 bits per 64-bit word); the 64 rows of a block are then
+// transposed through LDS into the B-operand fragment: column sub*slots + t of operand v / per_op holds digit t of
+// residual v, lane 32*h + column carries the 32 rows of half h (element order identical to the A fragment built in
+// mfma_fp4; an FP6 element j sits in bits 6j..6j+5 of the lane's 192 bits, the last 64 of them in `dig2`).
 __global__ void __launch_bounds__(256)
 k_digits(const double *__restrict__ r, int64_t n, int64_t nblk, int m, DigitMode dm,
-         const double *__restrict__ scal, uint4 *__restrict__ dig /* [nops][nblk][64] */)
+         const double *__restrict__ scal, uint4 *__restrict__ dig /* [nops][nblk][64] */, uint2 *__restrict__ dig2)
 {
     __shared__ unsigned long long nib[4][64][2];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t blk = blockIdx.x * 4ll + w;
     const int vs = blockIdx.y;
-    const int slots = 32 / dm.per_op, op = vs / dm.per_op, sub = vs % dm.per_op;
-    unsigned long long lo = 0, hi = 0;
+    const int slots = dm.slots, op = vs / dm.per_op, sub = vs % dm.per_op;
+    const bool fp6 = dm.base == 49;
+    const int cw = fp6 ? 6 : 4, per = fp6 ? 10 : 16;          // code width, codes per 64-bit word
+    unsigned long long wd[2] = {0ull, 0ull};
     if (vs < m && blk < nblk) {
         const int64_t i = blk * 64 + lane;
         const double x = (i < n) ? r[(int64_t)vs * n + i] : 0.0;
@@ -141,42 +150,76 @@ k_digits(const double *__restrict__ r, int64_t n, int64_t nblk, int m, DigitMode
                 const int mm = (int)(R & 3);
                 d = mm < 2 ? mm : mm - 4;
                 R = (R - d) >> 2;
-            } else {
+            } else if (dm.base == 13) {
                 int mm = (int)(R % 13);
                 if (mm < 0) mm += 13;
                 d = digit13(mm);
                 R = (R - d) / 13;
+            } else {
+                int mm = (int)(R % 49);
+                if (mm < 0) mm += 49;
+                d = digit49(mm);
+                R = (R - d) / 49;
             }
             const unsigned a = (unsigned)(d < 0 ? -d : d);
-            const unsigned long long code = (a <= 4 ? a : a == 6 ? 5u : 6u) | (d < 0 ? 8u : 0u);   // FP4 code of d/2
-            if (t < 16) lo |= code << (4 * t); else hi |= code << (4 * (t - 16));
+            unsigned long long code;
+            if (fp6) code = (a < 8 ? a : a < 16 ? a : a <= 30 ? 8u + (a >> 1) : 16u + (a >> 2)) | (d < 0 ? 32u : 0u);   // e2m3 of a/8
+            else code = (a <= 4 ? a : a == 6 ? 5u : 6u) | (d < 0 ? 8u : 0u);                                          // e2m1 of a/2
+            wd[t / per] |= code << (cw * (t % per));
         }
     }
-    nib[w][lane][0] = lo; nib[w][lane][1] = hi;
+    nib[w][lane][0] = wd[0]; nib[w][lane][1] = wd[1];
     __syncthreads();
     if (blk < nblk && lane < 2 * slots) {
         const int h = lane / slots, dg = lane % slots;
-        uint32_t out[4] = {0u, 0u, 0u, 0u};
-        #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        const int64_t o = ((int64_t)op * nblk + blk) * 64 + h * 32 + sub * slots + dg;
+        if (!fp6) {
+            uint32_t out[4] = {0u, 0u, 0u, 0u};
             #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const uint32_t code = (uint32_t)(nib[w][h * 32 + u * 16 + s][dg >> 4] >> (4 * (dg & 15))) & 0xFu;
-                out[2 * u + (s & 1)] |= code << (4 * (s >> 1));
+            for (int u = 0; u < 2; ++u) {
+                #pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const uint32_t code = (uint32_t)(nib[w][h * 32 + u * 16 + s][dg >> 4] >> (4 * (dg & 15))) & 0xFu;
+                    out[2 * u + (s & 1)] |= code << (4 * (s >> 1));
+                }
             }
+            dig[o] = make_uint4(out[0], out[1], out[2], out[3]);
+        } else {
+            unsigned long long q[3] = {0ull, 0ull, 0ull};
+            #pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                #pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const unsigned long long code = (nib[w][h * 32 + u * 16 + s][0] >> (6 * dg)) & 0x3Full;
+                    const int bit = 6 * (8 * (2 * u + (s & 1)) + (s >> 1)), wi = bit >> 6, sh = bit & 63;
+                    q[wi] |= code << sh;
+                    if (sh > 58) q[wi + 1] |= code >> (64 - sh);
+                }
+            }
+            dig[o] = make_uint4((uint32_t)q[0], (uint32_t)(q[0] >> 32), (uint32_t)q[1], (uint32_t)(q[1] >> 32));
+            dig2[o] = make_uint2((uint32_t)q[2], (uint32_t)(q[2] >> 32));
         }
-        dig[((int64_t)op * nblk + blk) * 64 + h * 32 + sub * slots + dg] = make_uint4(out[0], out[1], out[2], out[3]);
     }
 }
 
 // ---- the matrix-pipe kernel -------------------------------------------------------------------
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // dosage tiles are read exactly once per pass: stream them past the caches (nt), so the digit
 // planes every wave re-reads stay resident in L2
 __device__ __forceinline__ uint4 ld_stream(const uint4 *p)
 {
     u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
     return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// the same dosage tile against an FP6 (e2m3) B operand: 32 digits x 6 bits = 6 dwords per lane (blgp = 2)
+__device__ __forceinline__ f32x16 mfma_fp6(uint32_t u0, uint32_t u1, const uint4 &b, const uint2 &b2, f32x16 acc)
+{
+    const uint32_t M = 0x33333333u;
+    i32x8 a = {(int)(u0 & M), (int)((u0 >> 2) & M), (int)(u1 & M), (int)((u1 >> 2) & M), 0, 0, 0, 0};
+    i32x8 bb = {(int)b.x, (int)b.y, (int)b.z, (int)b.w, (int)b2.x, (int)b2.y, 0, 0};
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bb, acc, 4, 2, 0, 127, 0, 127);
 }
 
 __device__ __forceinline__ f32x16 mfma_fp4(uint32_t u0, uint32_t u1, const uint4 &b, f32x16 acc)
@@ -189,36 +232,47 @@ __device__ __forceinline__ f32x16 mfma_fp4(uint32_t u0, uint32_t u1, const uint4
 }
 
 // D layout: column n = lane & 31, row (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5) (SNP).  Column n holds digit
-// (n % slots) of residual per_op*v + n / slots of B operand v (slots = 32 / per_op).
-// acc = (1/4) sum_i g_i d_i exactly; recombine digits: sum_t base^t * (4 acc_t), then * 2^-e.
+// n % slots of residual per_op*v + n / slots of B operand v.
+// acc = (1/unit) sum_i g_i d_i exactly (unit 4 for FP4 digits d/2, 16 for FP6 digits d/8); recombine the digits:
+// sum_t base^t * (unit * acc_t), then * 2^-e.
 template <int CT, int NR>
 __device__ __forceinline__ void xtv_epilogue(const f32x16 (&acc)[CT][NR], int lane, int64_t cg0, int64_t ncg, int split,
                                              int splits, DigitMode dm, const double *__restrict__ scal,
                                              double *__restrict__ partial)
 {
-    const int slots = 32 / dm.per_op;
-    const int dgt = lane & (slots - 1), sub = (lane & 31) / slots;
+    const int slots = dm.slots, col = lane & 31;
+    const int sub = col / slots, dgt = col - sub * slots;
+    const bool live = sub < dm.per_op;                   // columns past per_op * slots carry nothing
     double wgt = 0.0;
-    if (dgt < dm.ndig) {
-        unsigned long long w = 4;                        // 4 * base^dgt < 2^58: exact in 64 bits, one rounding to f64
+    if (live && dgt < dm.ndig) {
+        unsigned long long w = dm.base == 49 ? 16 : 4;   // unit * base^dgt < 2^58: exact in 64 bits, one rounding to f64
         for (int t = 0; t < dgt; ++t) w *= (unsigned)dm.base;
         wgt = (double)w;
     }
+    const bool tree = (slots & (slots - 1)) == 0;
+    const int src0 = (lane & 32) + sub * slots;
     #pragma unroll
     for (int v = 0; v < NR; ++v) {
-        const int rhs = v * dm.per_op + sub;
+        const int rhs = v * dm.per_op + (live ? sub : 0);
         const double inv = scal[4 * rhs + 1];
         #pragma unroll
         for (int c = 0; c < CT; ++c) {
             #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 double x = (double)acc[c][v][g] * wgt;
-                if (slots > 16) x += __shfl_xor(x, 16, 64);                          // fixed tree within each group of
-                if (slots > 8) x += __shfl_xor(x, 8, 64);                            // `slots` lanes
-                #pragma unroll
-                for (int off = 4; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+                if (tree) {                                                          // fixed tree within each group of
+                    if (slots > 16) x += __shfl_xor(x, 16, 64);                      // `slots` lanes
+                    if (slots > 8) x += __shfl_xor(x, 8, 64);
+                    #pragma unroll
+                    for (int off = 4; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+                } else {                                                             // 10 columns: digit 0 upward
+                    double sum = 0.0;
+                    #pragma unroll
+                    for (int t = 0; t < 10; ++t) sum += __shfl(x, src0 + t, 64);
+                    x = sum;
+                }
                 int row = (g & 3) + 8 * (g >> 2) + 4 * (lane >> 5);
-                if (dgt == 0 && cg0 + c < ncg)
+                if (dgt == 0 && live && cg0 + c < ncg)
                     partial[((int64_t)rhs * splits + split) * (ncg * 32) + (cg0 + c) * 32 + row] = x * inv;
             }
         }
@@ -298,16 +352,19 @@ k_xtv_mfma(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *_
 // POWER-bound, not issue- or latency-bound -- the package sits at its power cap and the shader clock
 // drops to ~1870-1935 MHz for the 4-operand pass; all-zero digit planes run 17 % faster.
 // MODE 1 / 2 (no MFMAs / no dosage loads) exist only for those timing probes.
-template <int NR, int CT, int RB, int MODE = 0, int WAVES = 8>   // MODE 1: no MFMAs, 2: no dosage loads (timing probes only)
+// FP6: the B operands are FP6 digit planes, 24 B per lane: 16 B in `dig` and 8 B in `dig2`, staged side by side.
+template <int NR, int CT, int RB, int MODE = 0, int WAVES = 8, bool FP6 = false>   // MODE 1: no MFMAs, 2: no dosage loads (timing probes only)
 __global__ void __launch_bounds__(WAVES * 64, 2)
-k_xtv_mfma_lds(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *__restrict__ dig, int64_t dig_stride,
-               int splits, DigitMode dm, const double *__restrict__ scal, double *__restrict__ partial /* [NR*per_op][splits][ncg*32] */)
+k_xtv_mfma_lds(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *__restrict__ dig, const uint2 *__restrict__ dig2,
+               int64_t dig_stride, int splits, DigitMode dm, const double *__restrict__ scal,
+               double *__restrict__ partial /* [NR*per_op][splits][ncg*32] */)
 {
     constexpr int NT = WAVES * 64;
     constexpr int BLK = NR * 2 * 64;                 // uint4 slots of one 128-row block: (operand v, 64-row half e, lane)
     constexpr int S = RB * BLK;                      // slots staged per barrier step
     constexpr int PER = (S + NT - 1) / NT;           // slots per thread (the last one may be idle)
     __shared__ uint4 btile[2][S];
+    __shared__ uint2 btile2[FP6 ? 2 : 1][FP6 ? S : 1];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int split = blockIdx.x % splits;
@@ -334,17 +391,20 @@ k_xtv_mfma_lds(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint
             ap[c] = X + (cg * nbp) * 64 + lane;
         }
         // staged slot f = threadIdx.x + u*NT: block f / BLK of the step, operand (f % BLK) >> 7, half ((f % BLK) >> 6) & 1
-        const uint4 *bsrc[PER]; int bq_[PER]; bool bon[PER];
+        const uint4 *bsrc[PER]; const uint2 *bsrc2[PER]; int bq_[PER]; bool bon[PER];
         #pragma unroll
         for (int u = 0; u < PER; ++u) {
             const int fs = threadIdx.x + u * NT;
             bon[u] = fs < S;
             const int fq = bon[u] ? fs : 0, wi = fq % BLK;
             bq_[u] = fq / BLK;
-            bsrc[u] = dig + (int64_t)(wi >> 7) * dig_stride + ((wi >> 6) & 1) * 64 + (wi & 63);
+            const int64_t off = (int64_t)(wi >> 7) * dig_stride + ((wi >> 6) & 1) * 64 + (wi & 63);
+            bsrc[u] = dig + off;
+            bsrc2[u] = dig2 + off;
         }
         uint4 acur[RB][CT], anext[RB][CT];
         u32x4 bstage[PER];          // native vector type: stays in registers across the loop edge
+        u32x2 bstage2[PER];
         #pragma unroll
         for (int q = 0; q < RB; ++q) {
             const int64_t bq = (b0 + q < last) ? b0 + q : last;
@@ -357,6 +417,10 @@ k_xtv_mfma_lds(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint
             const int64_t b2 = (b0 + RB + bq_[u] < last) ? b0 + RB + bq_[u] : last;
             if (bon[u]) btile[0][threadIdx.x + u * NT] = bsrc[u][(2 * bq) * 64];
             bstage[u] = *reinterpret_cast<const u32x4 *>(bsrc[u] + (2 * b2) * 64);
+            if (FP6) {
+                if (bon[u]) btile2[0][threadIdx.x + u * NT] = bsrc2[u][(2 * bq) * 64];
+                bstage2[u] = *reinterpret_cast<const u32x2 *>(bsrc2[u] + (2 * b2) * 64);
+            }
         }
         __syncthreads();
         int buf = 0;
@@ -366,7 +430,10 @@ k_xtv_mfma_lds(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint
         for (int64_t bp = b0; bp < b1; bp += RB) {
             #pragma unroll
             for (int u = 0; u < PER; ++u)
-                if (bon[u]) *reinterpret_cast<u32x4 *>(&btile[buf ^ 1][threadIdx.x + u * NT]) = bstage[u];
+                if (bon[u]) {
+                    *reinterpret_cast<u32x4 *>(&btile[buf ^ 1][threadIdx.x + u * NT]) = bstage[u];
+                    if (FP6) *reinterpret_cast<u32x2 *>(&btile2[buf ^ 1][threadIdx.x + u * NT]) = bstage2[u];
+                }
             #pragma unroll
             for (int q = 0; q < RB; ++q) {
                 const int64_t bn = (bp + RB + q < last) ? bp + RB + q : last;
@@ -377,13 +444,16 @@ k_xtv_mfma_lds(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint
             for (int u = 0; u < PER; ++u) {
                 const int64_t b2 = (bp + 2 * RB + bq_[u] < last) ? bp + 2 * RB + bq_[u] : last;
                 bstage[u] = *reinterpret_cast<const u32x4 *>(bsrc[u] + (2 * b2) * 64);
+                if (FP6) bstage2[u] = *reinterpret_cast<const u32x2 *>(bsrc2[u] + (2 * b2) * 64);
             }
             __builtin_amdgcn_sched_barrier(0);      // keep the prefetch loads ahead of the MFMA section
             // (block q, operand v) items in sequence; the digit fragments of item i+1 are read from LDS
             // before the MFMAs of item i are issued so the LDS latency hides behind the matrix pipe
             uint4 bfr[2][2];
+            uint2 bfr2[2][2];
             bfr[0][0] = btile[buf][lane];
             bfr[0][1] = btile[buf][64 + lane];
+            if (FP6) { bfr2[0][0] = btile2[buf][lane]; bfr2[0][1] = btile2[buf][64 + lane]; }
             #pragma unroll
             for (int i = 0; i < RB * NR; ++i) {
                 const int q = i / NR, v = i % NR;
@@ -391,11 +461,18 @@ k_xtv_mfma_lds(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint
                     const int q1 = (i + 1) / NR, v1 = (i + 1) % NR;
                     bfr[(i + 1) & 1][0] = btile[buf][q1 * BLK + (v1 * 2 + 0) * 64 + lane];
                     bfr[(i + 1) & 1][1] = btile[buf][q1 * BLK + (v1 * 2 + 1) * 64 + lane];
+                    if (FP6) {
+                        bfr2[(i + 1) & 1][0] = btile2[buf][q1 * BLK + (v1 * 2 + 0) * 64 + lane];
+                        bfr2[(i + 1) & 1][1] = btile2[buf][q1 * BLK + (v1 * 2 + 1) * 64 + lane];
+                    }
                 }
                 const uint32_t keep = (bp + q < b1) ? 0xFFFFFFFFu : 0u;     // blocks past the slice end add zero
                 #pragma unroll
                 for (int c = 0; c < CT; ++c) {
-                    if (MODE != 1) {
+                    if (FP6) {
+                        acc[c][v] = mfma_fp6(acur[q][c].x & keep, acur[q][c].y & keep, bfr[i & 1][0], bfr2[i & 1][0], acc[c][v]);
+                        acc[c][v] = mfma_fp6(acur[q][c].z & keep, acur[q][c].w & keep, bfr[i & 1][1], bfr2[i & 1][1], acc[c][v]);
+                    } else if (MODE != 1) {
                         acc[c][v] = mfma_fp4(acur[q][c].x & keep, acur[q][c].y & keep, bfr[i & 1][0], acc[c][v]);
                         acc[c][v] = mfma_fp4(acur[q][c].z & keep, acur[q][c].w & keep, bfr[i & 1][1], acc[c][v]);
                     } else {
@@ -569,13 +646,24 @@ static void launch_xtv(const mih_mat *h, const uint4 *dig, int64_t dig_stride, i
 
 // nr B operands per pass: 1 = the tuned single-operand variants; 2 / 4 = fused passes (64 / 128 accumulator
 // registers).  Each operand carries per_op residual vectors.
-static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 *dig, int64_t dig_stride, int splits,
-                        DigitMode dm, const double *scal, double *partial, hipStream_t s)
+static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 *dig, const uint2 *dig2, int64_t dig_stride,
+                        int splits, DigitMode dm, const double *scal, double *partial, hipStream_t s)
 {
+#define MIH_LDS6(NRV, C, RB, W) if (nr == NRV) { \
+        int64_t groups = (h->ncg + W * C - 1) / (W * C); \
+        hipLaunchKernelGGL((k_xtv_mfma_lds<NRV, C, RB, 0, W, true>), dim3((unsigned)(groups * splits)), dim3(W * 64), 0, s, \
+                           reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig2, dig_stride, splits, dm, scal, partial); \
+        return MIH_OK; }
+    if (dm.base == 49) {           // FP6 digit planes: one launch shape per operand count
+        MIH_LDS6(1, 1, 4, 8) MIH_LDS6(2, 4, 1, 4) MIH_LDS6(4, 2, 2, 8)
+        set_error("unsupported operand count");
+        return MIH_BAD_ARG;
+    }
+#undef MIH_LDS6
 #define MIH_LDS(NRV, ID, C, RB, MODE, W) if (nr == NRV && mv == ID) { \
         int64_t groups = (h->ncg + W * C - 1) / (W * C); \
         hipLaunchKernelGGL((k_xtv_mfma_lds<NRV, C, RB, MODE, W>), dim3((unsigned)(groups * splits)), dim3(W * 64), 0, s, \
-                           reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig_stride, splits, dm, scal, partial); \
+                           reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig2, dig_stride, splits, dm, scal, partial); \
         return MIH_OK; }
     if (nr == 4 || nr == 2) {
         const int mv = g_xtv_multi_variant;
@@ -610,19 +698,18 @@ static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 
 
 constexpr int kStatBlocks = 64;
 
-// mih_set_xtv_digits: 0 = library default (16 base-13 digits, two residuals per B operand, 57-bit fixed point);
-// 28 = 28 base-4 digits, one residual per operand (54-bit; the first exact mode, kept as a cross-check and
-// used automatically above 2^24 rows); 16 = 16 base-4 digits, two per operand (32-bit); 8 = 8 base-13 digits,
-// four per operand (27-bit, opt-in fast mode)
+// mih_set_xtv_digits (residual format ids = base * 100 + digits, see include/mendeliht_hip.h); 0 = library default
 int g_xtv_digits = 0;
 
 static bool digit_mode(int id, DigitMode &dm)
 {
     switch (id) {
-    case 0:  dm = {13, 16, 2, 56, 20}; return true;
-    case 28: dm = {4, 28, 1, 53, 22}; return true;
-    case 16: dm = {4, 16, 2, 29, 22}; return true;
-    case 8:  dm = {13, 8, 4, 26, 20}; return true;
+    case 0:
+    case 4910: dm = {49, 10, 3, 10, 53, 18}; return true;    // FP6, three residuals per operand, |R| < 2^54
+    case 4908: dm = {49, 8, 4, 8, 42, 18}; return true;      // FP6, four per operand, |R| < 2^43 (opt-in fast mode)
+    case 1316: dm = {13, 16, 2, 16, 56, 20}; return true;    // FP4, two per operand, |R| < 2^57
+    case 1308: dm = {13, 8, 4, 8, 26, 20}; return true;      // FP4, four per operand, |R| < 2^27
+    case 428:  dm = {4, 28, 1, 32, 53, 22}; return true;     // FP4, one per operand, |R| < 2^54
     }
     return false;
 }
@@ -632,18 +719,26 @@ int xtv_work_init(const mih_mat *h, XtvWork &w, int m)
     if (h->kind != 0) return MIH_OK;
     int64_t nblk = h->nbp * 2;
     digit_mode(g_xtv_digits, w.dm);
-    // the base-13 products reach 4.0, so a row slice holds 2^20 rows; beyond kMaxSplits such slices the default
-    // falls back to base-4 digits (2^22 rows per slice)
-    if (g_xtv_digits == 0 && h->n_pad > ((int64_t)kMaxSplits << w.dm.rows_log2)) digit_mode(28, w.dm);
+    if (g_xtv_digits == 0) {
+        // the FP6 kernels exist for the LDS-shared launch shapes only; larger digits mean shorter exact row slices
+        // (2^18 rows in base 49, 2^20 in base 13, 2^22 in base 4), so very tall matrices step down
+        if (g_xtv_variant >= 0 || h->n_pad > ((int64_t)kMaxSplits << w.dm.rows_log2)) digit_mode(1316, w.dm);
+        if (h->n_pad > ((int64_t)kMaxSplits << w.dm.rows_log2)) digit_mode(428, w.dm);
+    } else if (w.dm.base == 49 && g_xtv_variant >= 0) {
+        set_error("the FP6 residual formats need the default kernel (mih_set_xtv_variant(-1))");
+        return MIH_BAD_ARG;
+    }
     // operand capacity rounded up to a multiple of 4 from three operands on: three leftover operands ride a
-    // 4-operand pass with an all-zero digit plane (29 ms) instead of a 2- + a 1-operand pass (37 ms)
+    // 4-operand pass with an all-zero digit plane instead of a 2- + a 1-operand pass
     const int ops = (m + w.dm.per_op - 1) / w.dm.per_op;
     w.ops_cap = ops < 3 ? ops : (ops + 3) & ~3;
     const size_t rhs_cap = (size_t)w.ops_cap * w.dm.per_op;
-    MIH_TRY(w.digits.alloc((size_t)w.ops_cap * (size_t)nblk * 64 * 4));
+    const size_t lanes = (size_t)w.ops_cap * (size_t)nblk * 64;
+    const size_t dwords = lanes * (w.dm.base == 49 ? 6 : 4);
+    MIH_TRY(w.digits.alloc(dwords));
     MIH_TRY(w.partial.alloc((size_t)kMaxSplits * rhs_cap * (size_t)h->ncg * 32));
     MIH_TRY(w.scal.alloc(rhs_cap * 4 + (size_t)m * kStatBlocks * 2));
-    MIH_HIP(hipMemsetAsync(w.digits.p, 0, sizeof(*w.digits.p) * (size_t)w.ops_cap * (size_t)nblk * 64 * 4, h->stream));
+    MIH_HIP(hipMemsetAsync(w.digits.p, 0, sizeof(*w.digits.p) * dwords, h->stream));
     MIH_HIP(hipMemsetAsync(w.scal.p, 0, sizeof(double) * rhs_cap * 4, h->stream));
     MIH_HIP(hipStreamSynchronize(h->stream));
     w.m_cap = m; w.splits_cap = kMaxSplits;
@@ -679,17 +774,20 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
     double *part = w.scal.p + (size_t)w.ops_cap * per_op * 4;
     hipLaunchKernelGGL(k_r_stats, dim3(kStatBlocks), dim3(256), 0, s, r_dev, h->n, m, part);
     hipLaunchKernelGGL(k_r_stats_final, dim3(m), dim3(64), 0, s, part, kStatBlocks, m, dm.ebits, w.scal.p);
+    uint4 *dig_all = reinterpret_cast<uint4 *>(w.digits.p);
+    uint2 *dig2_all = reinterpret_cast<uint2 *>(w.digits.p + (size_t)w.ops_cap * (size_t)nblk * 64 * 4);   // FP6 only
     hipLaunchKernelGGL(k_digits, dim3((unsigned)((nblk + 3) / 4), (unsigned)(nops * per_op)), dim3(256), 0, s, r_dev, h->n, nblk, m, dm,
-                       w.scal.p, reinterpret_cast<uint4 *>(w.digits.p));
+                       w.scal.p, dig_all, dig2_all);
     for (int t = 0; t < nops;) {          // t counts B operands
         int nr = (nops - t >= 3 && g_xtv_max_nr >= 4 && t + 4 <= w.ops_cap) ? 4
                  : (nops - t >= 2 && g_xtv_max_nr >= 2) ? 2 : 1;
         const int u0 = t * per_op;        // first residual of this pass
         double *partial = w.partial.p + (int64_t)u0 * splits * pstride;
-        const uint4 *dig = reinterpret_cast<const uint4 *>(w.digits.p) + (int64_t)t * nblk * 64;
+        const uint4 *dig = dig_all + (int64_t)t * nblk * 64;
+        const uint2 *dig2 = dig2_all + (int64_t)t * nblk * 64;
         hipEvent_t e0, e1;
         prof_begin(s, e0, e1);
-        int rc = dispatch_xtv(v, nr, h, dig, nblk * 64, splits, dm, w.scal.p + 4 * u0, partial, s);
+        int rc = dispatch_xtv(v, nr, h, dig, dig2, nblk * 64, splits, dm, w.scal.p + 4 * u0, partial, s);
         prof_end(s, e0, e1);
         if (rc) return rc;
         for (int u = u0; u < (t + nr) * per_op && u < m; ++u)
@@ -743,7 +841,7 @@ int mih_set_xtv_variant(int variant)
 int mih_set_xtv_digits(int digits)
 {
     DigitMode dm;
-    if (!digit_mode(digits, dm)) { set_error("digit mode must be 0 (default), 28, 16 or 8"); return MIH_BAD_ARG; }
+    if (!digit_mode(digits, dm)) { set_error("residual format must be 0 (default), 4910, 4908, 1316, 1308 or 428"); return MIH_BAD_ARG; }
     g_xtv_digits = digits;
     return MIH_OK;
 }

@@ -70,7 +70,8 @@ def main():
     run("poisson_train", cols, n, yp, None, k=6, d=m.Poisson(), l=m.LogLink(), train=train)
 
     # 4. NegBin with the nuisance parameter estimated (replicated n-vector work)
-    run("negbin_newton", cols, n, yp, None, k=5, d=m.NegativeBinomial(2.0), l=m.LogLink(), est_r="Newton")
+    ynb = rng.negative_binomial(2, 2.0 / (2.0 + lam)).astype(float)        # overdispersed counts: r is identifiable
+    run("negbin_newton", cols, n, ynb, None, k=5, d=m.NegativeBinomial(2.0), l=m.LogLink(), est_r="Newton")
 
     # 5. exact ties: duplicated columns straddling the shard boundary make _choose! fire globally
     lo1, cnt1 = D.column_block(p, 0, world)

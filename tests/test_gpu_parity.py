@@ -37,8 +37,11 @@ def test_mu_sinv_and_xtv_all_variants(mih, normal_pair):
     assert np.array_equal(mu, omu) and np.array_equal(s, os_)
     r = np.random.default_rng(0).standard_normal(x.n)
     ref = ox.xtv(r)
-    base = x.xtv(r)                                                 # library default: LDS-shared digit planes
-    assert rel(base, ref) < 1e-11
+    default = x.xtv(r)                                              # library default: FP6 digit planes shared through LDS
+    assert rel(default, ref) < 1e-11
+    mih.set_xtv_digits(1316)                                        # the FP4 format every kernel shape implements
+    base = x.xtv(r)
+    assert rel(base, default) < 1e-13
     nv = 0
     same_slices = (0, 1, 2, 3, 4, 9, 10, 13, 14)                    # shapes with 8 row slices, like the default
     while mih.lib().mih_set_xtv_variant(nv) == 0:                   # the per-wave-load shapes
@@ -52,6 +55,8 @@ def test_mu_sinv_and_xtv_all_variants(mih, normal_pair):
     for mv in (10, 11, 12, 13, 14, 0):                              # other LDS shapes of the single-operand pass
         assert mih.lib().mih_set_xtv_multi_variant(mv) == 0
         assert np.array_equal(x.xtv(r), base), mv
+    mih.set_xtv_digits(0)
+    assert np.array_equal(x.xtv(r), default)
 
 
 @pytest.mark.parametrize("n,p,miss", [(1003, 257, 0.02), (77, 33, 0.1), (5000, 100, 0.0), (2049, 64, 0.05),
@@ -577,7 +582,7 @@ def test_full_size_baseline_config_p1M(mih, oracle):
     last = x.xv_sparse(idx[3:], val[3:])
     assert rel(xb - last, ox.xv_masked(mask, coef)) < 1e-10
     assert abs(last.mean()) < 1e-9 * (1 + np.abs(last).max())      # a standardized column has mean 0
-    mih.set_xtv_digits(16)                                          # the opt-in fast mode at full size
+    mih.set_xtv_digits(4908)                                        # the opt-in fast mode at full size
     try:
         f1 = x.xtv(r1)
         F5 = x.xtv(R)
@@ -634,10 +639,10 @@ def test_concurrent_fits_share_one_matrix(mih, normal_pair, normal_data):
         assert np.array_equal(a.beta, b.beta) and np.array_equal(a.c, b.c) and a.logl == b.logl and a.iter == b.iter
 
 
-@pytest.mark.parametrize("mode,quantum", [(8, 2e-7), (16, 1e-8)])
+@pytest.mark.parametrize("mode,quantum", [(4908, 1e-12), (1308, 2e-7)])
 def test_fast_digit_mode(mih, oracle, normal_pair, normal_data, mode, quantum):
-    """mih_set_xtv_digits(8): 27-bit fixed-point residuals, four per MFMA B operand (the opt-in mode for
-    fused multi-RHS passes), and (16): 32-bit base-4 residuals, two per operand.  X'r stays within the format's
+    """mih_set_xtv_digits(4908): 43-bit fixed-point residuals as 8 base-49 FP6 digits, four per MFMA B operand (the
+    opt-in mode for fused multi-RHS passes), and (1308): 27-bit residuals as 8 base-13 FP4 digits.  X'r stays within the format's
     quantum of the exact mode, is independent of how the residuals are grouped into passes, and fits /
     cross-validation stay inside the north_star tolerance."""
     x, ox = normal_pair
@@ -680,8 +685,9 @@ def test_fast_digit_mode(mih, oracle, normal_pair, normal_data, mode, quantum):
 
 def test_digit_modes_agree(mih, oracle, normal_pair):
     """Every fixed-point format of the residual (mih_set_xtv_digits) against the oracle's f64 X'r: the default
-    (16 base-13 digits, two residuals per operand) and the 28 base-4 digit cross-check agree to f64 rounding;
-    the 32-bit and 27-bit formats to their quantum; each is independent of how residuals share operands."""
+    (10 base-49 FP6 digits, three residuals per operand), 16 base-13 FP4 digits (two per operand) and 28 base-4
+    digits (one per operand) agree to f64 rounding; the 43-bit and 27-bit formats to their quantum; each is
+    independent of how residuals share operands."""
     x, ox = normal_pair
     n = x.n
     rng = np.random.default_rng(77)
@@ -690,17 +696,19 @@ def test_digit_modes_agree(mih, oracle, normal_pair):
     scale = np.sqrt(n) * np.abs(R).max(axis=0)
     out = {}
     try:
-        for mode, tol in ((0, 2e-15), (28, 2e-15), (16, 1e-8), (8, 2e-7)):
+        for mode, tol in ((0, 2e-15), (4910, 2e-15), (1316, 2e-15), (428, 2e-15), (4908, 1e-12), (1308, 2e-7)):
             mih.set_xtv_digits(mode)
             got = x.xtv(R)
             assert np.all(np.max(np.abs(got - O), axis=0) < tol * scale + 1e-13 * np.abs(O).max(axis=0)), mode
-            for m_rhs in (1, 2, 3, 5, 8):
+            for m_rhs in (1, 2, 3, 4, 5, 7, 8, 10):
                 assert np.array_equal(x.xtv(R[:, :m_rhs]), got[:, :m_rhs]), (mode, m_rhs)
             out[mode] = got
     finally:
         mih.set_xtv_digits(0)
-    assert np.all(np.max(np.abs(out[0] - out[28]), axis=0) <= 2e-15 * scale)
-    assert not np.array_equal(out[0], out[8])
+    assert np.array_equal(out[0], out[4910])
+    for mode in (1316, 428):
+        assert np.all(np.max(np.abs(out[0] - out[mode]), axis=0) <= 2e-15 * scale), mode
+    assert not np.array_equal(out[0], out[4908]) and not np.array_equal(out[0], out[1308])
 
 
 @pytest.mark.parametrize("case", ["gamma_log", "invgauss_log", "bernoulli_probit", "bernoulli_cloglog", "bernoulli_cauchit",

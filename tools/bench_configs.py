@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import mendeliht_amd as m
 from conftest import hash_folds
 
-digits = int(os.environ.get("MIH_DIGITS", 0))      # mih_set_xtv_digits: 0 default, 8 = the opt-in fast mode for fused multi-RHS passes
+digits = int(os.environ.get("MIH_DIGITS", 0))      # mih_set_xtv_digits: 0 default, 4908 = the opt-in fast mode for fused multi-RHS passes
 m.set_xtv_digits(digits)
 out = {"xtv_digits": digits}
 # ---- configs[1]

@@ -10,7 +10,7 @@ rng = np.random.default_rng(2025)
 supp = np.sort(rng.choice(p, size=10, replace=False))
 y = x.xv_sparse(supp, rng.standard_normal(10)) + 1.0 + rng.standard_normal(n)
 path = list(range(1, 21))
-for digits in (0, 8):
+for digits in (0, 4908):
     m.set_xtv_digits(digits)
     t0 = time.perf_counter(); ll = m.iht_run_many_models(y, x, None, path=path, verbose=False); dt = time.perf_counter() - t0
     print(f"digits={digits}: lock-step path=1:20 in {dt:.2f} s (argmax of the logl increments at k={int(np.argmax(np.diff(ll) < 1.0)) + 1})", flush=True)

@@ -12,7 +12,7 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
-// mode 0: A fp4, B fp4; mode 1: A fp4, B fp8(e4m3); mode 2: i8 32x32x32
+// mode 0: A fp4, B fp4; mode 1: A fp4, B fp8(e4m3); mode 2: i8 32x32x32; mode 3: A fp4, B fp6 (e2m3)
 __global__ void k_probe(const uint32_t *A, const uint32_t *B, float *D, int mode, int scale)
 {
     int l = threadIdx.x;
@@ -27,6 +27,7 @@ __global__ void k_probe(const uint32_t *A, const uint32_t *B, float *D, int mode
     }
     f32x16 c = {};
     if (mode == 0) c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 4, 4, 0, scale, 0, scale);
+    else if (mode == 3) c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 4, 2, 0, scale, 0, scale);
     else           c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 4, 0, 0, scale, 0, scale);
     for (int i = 0; i < 16; ++i) D[l * 16 + i] = c[i];
 }
@@ -42,12 +43,21 @@ static int e4m3_of_int(int v)   // exact for |v| <= 15
     return (s << 7) | ((e + 7) << 3) | mant;
 }
 
+// e2m3 code of u/8 for u in the representable set (0..16, even to 30, multiples of 4 to 60)
+static int e2m3_of_units(int v)
+{
+    int s = v < 0, u = abs(v), e, m;
+    if (u < 8) { e = 0; m = u; } else if (u < 16) { e = 1; m = u - 8; } else if (u <= 30) { e = 2; m = u / 2 - 8; } else { e = 3; m = u / 4 - 8; }
+    return (s << 5) | (e << 3) | m;
+}
+static const int E2M3U[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 26, 28, 30, 32, 36, 40, 44, 48, 52, 56, 60};
+
 int main()
 {
     uint32_t *dA, *dB; float *dD;
     CK(hipMalloc((void **)&dA, 64 * 8 * 4)); CK(hipMalloc((void **)&dB, 64 * 8 * 4)); CK(hipMalloc((void **)&dD, 64 * 16 * 4));
     srand(7);
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 4; ++mode) {
         const int K = (mode == 2) ? 32 : 64, KH = K / 2;          // K elements per lane-half
         std::vector<double> Am(32 * K), Bm(K * 32);
         std::vector<uint32_t> hA(64 * 8, 0), hB(64 * 8, 0);
@@ -69,6 +79,13 @@ int main()
                         int bc = rand() % 16; if (bc == 8) bc = 0;     // any fp4 value (avoid -0)
                         Bm[k * 32 + r] = fp4(bc);
                         hB[l * 8 + j / 8] |= (uint32_t)bc << (4 * (j % 8));
+                    } else if (mode == 3) {
+                        int bu = E2M3U[rand() % 32] * ((rand() & 1) ? -1 : 1);
+                        Bm[k * 32 + r] = bu / 8.0;
+                        uint64_t code = (uint64_t)e2m3_of_units(bu);          // hypothesis: element j in bits 6j .. 6j+5 of the lane's 192 bits
+                        int bit = 6 * j, w = bit / 32, sh = bit % 32;
+                        hB[l * 8 + w] |= (uint32_t)(code << sh);
+                        if (sh > 26) hB[l * 8 + w + 1] |= (uint32_t)(code >> (32 - sh));
                     } else {
                         int bv = rand() % 31 - 15;
                         Bm[k * 32 + r] = bv;
@@ -93,7 +110,7 @@ int main()
                 if (err > maxerr) maxerr = err;
             }
             printf("mode %d (%s) scale=0x%x: mismatches %d / 1024, max err %g%s\n", mode,
-                   mode == 0 ? "fp4 x fp4" : mode == 1 ? "fp4 x fp8" : "i8 x i8", scale, bad, maxerr, bad ? "  <-- natural hypothesis fails" : "  OK");
+                   mode == 0 ? "fp4 x fp4" : mode == 1 ? "fp4 x fp8" : mode == 3 ? "fp4 x fp6" : "i8 x i8", scale, bad, maxerr, bad ? "  <-- natural hypothesis fails" : "  OK");
             if (bad) printf("   last got/want ratio %g\n", ratio);
             if (mode == 2) break;
         }
