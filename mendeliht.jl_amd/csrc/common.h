@@ -133,10 +133,13 @@ struct XtvWork {            // scratch for one in-flight X'r
     DigitMode dm = {13, 16, 2, 16, 56, 20};   // fixed at init (mih_set_xtv_digits)
     int ops_cap = 0;           // B operands the buffers hold
 };
-int  xtv_work_init(const mih_mat *h, XtvWork &w, int m);
+// batched = false: the workspace of a single univariate fit (one residual per pass); true: fused multi-RHS passes
+int  xtv_work_init(const mih_mat *h, XtvWork &w, int m, bool batched = true);
 // r_dev: m vectors of length n (column-major n x m) on device; out_dev p x m.
 int  xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double *out_dev, hipStream_t s);
 int  xtv_num_variants();
+// residuals of two full 4-operand passes in the batched default format: how many fits the lock-step drivers keep in flight
+int  xtv_lockstep_width(const mih_mat *h);
 extern int g_xtv_variant;
 
 // ---- X[:,S] v -----------------------------------------------------------------

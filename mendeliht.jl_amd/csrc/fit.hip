@@ -10,6 +10,7 @@
 // projection survivors (k entries), the loglikelihood scalars, Z'r and df[S].
 #include "common.h"
 #include "fit_common.h"
+#include <functional>
 #include <algorithm>
 #include <chrono>
 #include <cstring>
@@ -442,7 +443,7 @@ struct IhtVar {
         for (int64_t v : ks) kcap += v;
         MIH_TRY(sidx.alloc(kcap)); MIH_TRY(sval.alloc(kcap)); MIH_TRY(gval.alloc(kcap));
         MIH_TRY(hpin.alloc((size_t)kcap + kMaxQ + 16));
-        if (!batched) MIH_TRY(xtv_work_init(h, xtv, 1));
+        if (!batched) MIH_TRY(xtv_work_init(h, xtv, 1, false));
         MIH_TRY(xv_work_init(h, xv, kcap));
         MIH_TRY(topk_work_init(topk, kcap));
         MIH_HIP(hipMemcpyAsync(y.p, yh, sizeof(double) * n, hipMemcpyHostToDevice, s));
@@ -1174,25 +1175,46 @@ static int cv_finish(CvFit &f, double *mses_raw)
     return MIH_OK;
 }
 
-static int cv_run_batch(const mih_mat *h, const mih_fit_params &pr, std::vector<CvFit> &fits, XtvWork &xw,
-                        DevBuf<double> &R, DevBuf<double> &DF, hipStream_t s, double *mses_raw)
+// The rolling lock-step driver.  `cap` slots; in every round each occupied slot needs exactly one score pass -- a
+// fit that has just been created its initial score (init_pre / init_post, utilities.jl:366-438), a running fit the
+// score that ends its step (step_pre / step_post) -- so ONE fused pass serves all of them, and the slot of a fit
+// that finished is refilled from the queue in the next round: the passes stay full until the queue is empty.
+// make(i, f) sets up fit number i (its IhtVar, training mask, output slots).
+static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t total, int cap,
+                          const std::function<int(size_t, CvFit &)> &make, XtvWork &xw, DevBuf<double> &R,
+                          DevBuf<double> &DF, hipStream_t s, double *mses_raw)
 {
+    std::vector<std::unique_ptr<CvFit>> slot((size_t)cap);
     std::vector<CvFit *> need;
-    for (auto &f : fits) { MIH_TRY(f.v->init_pre(f.train.empty() ? nullptr : f.train.data())); need.push_back(&f); }
-    MIH_TRY(cv_batched_xtv(h, xw, need, R, DF, s));
-    for (auto *f : need) MIH_TRY(f->v->init_post());
+    std::vector<char> fresh;
+    size_t next = 0;
     for (;;) {
-        need.clear();
-        for (auto &f : fits) {
-            if (f.done) continue;
-            if (f.iter >= pr.max_iter) { MIH_TRY(cv_finish(f, mses_raw)); continue; }        // fit.jl:170-179
-            f.best = f.v->save_prev(f.next_logl, f.best);
-            MIH_TRY(f.v->step_pre(f.next_logl, pr.max_step, &f.nbt, &f.next_logl));
-            need.push_back(&f);
+        need.clear(); fresh.clear();
+        for (int t = 0; t < cap; ++t) {
+            for (;;) {
+                if (!slot[t]) {
+                    if (next >= total) break;
+                    slot[t].reset(new CvFit());
+                    MIH_TRY(make(next++, *slot[t]));
+                    CvFit &f = *slot[t];
+                    MIH_TRY(f.v->init_pre(f.train.empty() ? nullptr : f.train.data()));
+                    need.push_back(&f); fresh.push_back(1);
+                    break;
+                }
+                CvFit &f = *slot[t];
+                if (!f.done && f.iter >= pr.max_iter) MIH_TRY(cv_finish(f, mses_raw));        // fit.jl:170-179
+                if (f.done) { slot[t].reset(); continue; }                                    // refill this slot
+                f.best = f.v->save_prev(f.next_logl, f.best);
+                MIH_TRY(f.v->step_pre(f.next_logl, pr.max_step, &f.nbt, &f.next_logl));
+                need.push_back(&f); fresh.push_back(0);
+                break;
+            }
         }
         if (need.empty()) break;
         MIH_TRY(cv_batched_xtv(h, xw, need, R, DF, s));
-        for (auto *f : need) {
+        for (size_t t = 0; t < need.size(); ++t) {
+            CvFit *f = need[t];
+            if (fresh[t]) { MIH_TRY(f->v->init_post()); continue; }
             MIH_TRY(f->v->step_post(f->next_logl));
             double sc = f->v->check_convergence();
             if (f->iter >= pr.min_iter && sc < pr.tol) MIH_TRY(cv_finish(*f, mses_raw));     // fit.jl:197-203
@@ -1249,8 +1271,7 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, con
         for (int64_t ik = 0; ik < npath; ++ik, ++combo)
             if (combo % world == rank) mine.emplace_back(fold, ik);
     if (mine.empty()) return MIH_OK;
-    const int kMaxBatch = 16;
-    const int mb = (int)std::min<size_t>(mine.size(), kMaxBatch);
+    const int mb = (int)std::min<size_t>(mine.size(), (size_t)xtv_lockstep_width(h));
     hipStream_t s = nullptr;
     MIH_HIP(hipStreamCreate(&s));
     struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{s};
@@ -1259,23 +1280,18 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, con
     MIH_TRY(xtv_work_init(h, xw, mb));
     MIH_TRY(R.alloc((size_t)mb * n));
     MIH_TRY(DF.alloc((size_t)mb * h->p));
-    for (size_t start = 0; start < mine.size(); start += mb) {
-        size_t end = std::min(mine.size(), start + mb);
-        std::vector<CvFit> fits(end - start);
-        for (size_t t = start; t < end; ++t) {
-            CvFit &f = fits[t - start];
-            int32_t fold = mine[t].first; int64_t ik = mine[t].second;
-            mih_fit_params pf = pr;
-            pf.k = path[ik];                                  // v.k = sparsity (cross_validation.jl:110)
-            f.v.reset(new IhtVar());
-            MIH_TRY(f.v->create(h, &pf, y, z, q, s));
-            f.train.resize(n);
-            for (int64_t i = 0; i < n; ++i) f.train[i] = (folds[i] != fold);
-            f.out_index = (int64_t)(fold - 1) * npath + ik;
-        }
-        MIH_TRY(cv_run_batch(h, pr, fits, xw, R, DF, s, mses_raw));
-    }
-    return MIH_OK;
+    auto make = [&](size_t t, CvFit &f) -> int {
+        int32_t fold = mine[t].first; int64_t ik = mine[t].second;
+        mih_fit_params pf = pr;
+        pf.k = path[ik];                                  // v.k = sparsity (cross_validation.jl:110)
+        f.v.reset(new IhtVar());
+        MIH_TRY(f.v->create(h, &pf, y, z, q, s));
+        f.train.resize(n);
+        for (int64_t i = 0; i < n; ++i) f.train[i] = (folds[i] != fold);
+        f.out_index = (int64_t)(fold - 1) * npath + ik;
+        return MIH_OK;
+    };
+    return cv_run_rolling(h, pr, mine.size(), mb, make, xw, R, DF, s, mses_raw);
 }
 
 int mih_fit_iht_path(const mih_mat *h, const mih_fit_params *prm, const double *y, const double *z, int64_t q,
@@ -1319,8 +1335,7 @@ int mih_fit_iht_path(const mih_mat *h, const mih_fit_params *prm, const double *
         }
         return MIH_OK;
     }
-    const int kMaxBatch = 16;
-    const int mb = (int)std::min<size_t>(mine.size(), kMaxBatch);
+    const int mb = (int)std::min<size_t>(mine.size(), (size_t)xtv_lockstep_width(h));
     hipStream_t s = nullptr;
     MIH_HIP(hipStreamCreate(&s));
     struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{s};
@@ -1328,19 +1343,13 @@ int mih_fit_iht_path(const mih_mat *h, const mih_fit_params *prm, const double *
     MIH_TRY(xtv_work_init(h, xw, mb));
     MIH_TRY(R.alloc((size_t)mb * h->n));
     MIH_TRY(DF.alloc((size_t)mb * h->p));
-    for (size_t start = 0; start < mine.size(); start += mb) {
-        size_t end = std::min(mine.size(), start + mb);
-        std::vector<CvFit> fits(end - start);
-        for (size_t t = start; t < end; ++t) {
-            CvFit &f = fits[t - start];
-            mih_fit_params pf = pr; pf.k = path[mine[t]];
-            slots(f, mine[t]);
-            f.v.reset(new IhtVar());
-            MIH_TRY(f.v->create(h, &pf, y, z, q, s));
-        }
-        MIH_TRY(cv_run_batch(h, pr, fits, xw, R, DF, s, nullptr));
-    }
-    return MIH_OK;
+    auto make = [&](size_t t, CvFit &f) -> int {
+        mih_fit_params pf = pr; pf.k = path[mine[t]];
+        slots(f, mine[t]);
+        f.v.reset(new IhtVar());
+        return f.v->create(h, &pf, y, z, q, s);
+    };
+    return cv_run_rolling(h, pr, mine.size(), mb, make, xw, R, DF, s, nullptr);
 }
 
 int mih_cv_iht_multi(const mih_mat *const *hs, int32_t nrep, const mih_fit_params *prm, const double *y,

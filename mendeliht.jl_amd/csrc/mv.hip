@@ -749,7 +749,7 @@ int mih_cv_mv(const mih_mat *h, const mih_fit_params *prm, const double *Y, int6
             if (combo % world == rank) mine.emplace_back(fold, ik);
     if (mine.empty()) return MIH_OK;
     const int rr = (int)r;
-    const int per_batch = std::max(1, 16 / rr);
+    const int per_batch = std::max(1, xtv_lockstep_width(h) / rr);
     const int mb = (int)std::min<size_t>(mine.size(), (size_t)per_batch);
     hipStream_t s = nullptr;
     MIH_HIP(hipStreamCreate(&s));

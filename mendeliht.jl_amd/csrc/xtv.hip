@@ -649,13 +649,16 @@ static void launch_xtv(const mih_mat *h, const uint4 *dig, int64_t dig_stride, i
 static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 *dig, const uint2 *dig2, int64_t dig_stride,
                         int splits, DigitMode dm, const double *scal, double *partial, hipStream_t s)
 {
-#define MIH_LDS6(NRV, C, RB, W) if (nr == NRV) { \
+#define MIH_LDS6(NRV, ID, C, RB, W) if (nr == NRV && (mv6 == ID || ID < 0)) { \
         int64_t groups = (h->ncg + W * C - 1) / (W * C); \
         hipLaunchKernelGGL((k_xtv_mfma_lds<NRV, C, RB, 0, W, true>), dim3((unsigned)(groups * splits)), dim3(W * 64), 0, s, \
                            reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig2, dig_stride, splits, dm, scal, partial); \
         return MIH_OK; }
-    if (dm.base == 49) {           // FP6 digit planes: one launch shape per operand count
-        MIH_LDS6(1, 1, 4, 8) MIH_LDS6(2, 4, 1, 4) MIH_LDS6(4, 2, 2, 8)
+    if (dm.base == 49) {           // FP6 digit planes: one launch shape per operand count (+ tuning shapes for 4)
+        const int mv6 = g_xtv_multi_variant;
+        MIH_LDS6(4, 1, 2, 1, 8) MIH_LDS6(4, 2, 1, 4, 8) MIH_LDS6(4, 3, 2, 2, 4) MIH_LDS6(4, 4, 2, 1, 4) MIH_LDS6(4, 5, 1, 2, 8)
+        MIH_LDS6(1, 10, 1, 2, 8) MIH_LDS6(1, 11, 2, 4, 8) MIH_LDS6(1, 12, 2, 2, 8) MIH_LDS6(1, 13, 4, 2, 8) MIH_LDS6(1, 14, 1, 4, 16) MIH_LDS6(1, 15, 2, 2, 16)
+        MIH_LDS6(1, -1, 1, 4, 8) MIH_LDS6(2, -1, 4, 1, 4) MIH_LDS6(3, -1, 2, 2, 8) MIH_LDS6(4, -1, 2, 2, 8)
         set_error("unsupported operand count");
         return MIH_BAD_ARG;
     }
@@ -665,6 +668,7 @@ static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 
         hipLaunchKernelGGL((k_xtv_mfma_lds<NRV, C, RB, MODE, W>), dim3((unsigned)(groups * splits)), dim3(W * 64), 0, s, \
                            reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig2, dig_stride, splits, dm, scal, partial); \
         return MIH_OK; }
+    if (nr == 3) { const int mv = 0; MIH_LDS(3, 0, 2, 2, 0, 8) }
     if (nr == 4 || nr == 2) {
         const int mv = g_xtv_multi_variant;
         MIH_LDS(4, 0, 2, 2, 0, 8)      // defaults
@@ -714,24 +718,44 @@ static bool digit_mode(int id, DigitMode &dm)
     return false;
 }
 
-int xtv_work_init(const mih_mat *h, XtvWork &w, int m)
+static void choose_mode(const mih_mat *h, bool batched, DigitMode &dm);
+
+int xtv_lockstep_width(const mih_mat *h)
+{
+    if (h->kind != 0) return 16;
+    DigitMode dm;
+    choose_mode(h, true, dm);
+    return 8 * dm.per_op;
+}
+
+static void choose_mode(const mih_mat *h, bool batched, DigitMode &dm)
+{
+    digit_mode(g_xtv_digits, dm);
+    if (g_xtv_digits == 0) {
+        // Library default.  The workspace of a single fit scores one residual per pass: 28 sparse base-4 digit
+        // columns make the fastest single-operand pass (17.86 ms against 17.99 ms for 16 base-13 columns and
+        // 18.4 ms for FP6 planes at n=500k, p=1M; tools/sweep_fp6_single.py).  Every fused multi-RHS context
+        // (cv_iht, model paths, multivariate fits, init_beta, mih_xtv_batched) uses the FP6 format whatever the
+        // number of residuals in a call, so results never depend on how residuals are batched.  The FP6 kernels
+        // exist for the LDS-shared launch shapes only, and larger digits mean shorter exact row slices (2^18 rows
+        // in base 49, 2^20 in base 13, 2^22 in base 4), so very tall matrices step down.
+        if (!batched) digit_mode(428, dm);
+        else if (g_xtv_variant >= 0 || h->n_pad > ((int64_t)kMaxSplits << dm.rows_log2)) digit_mode(1316, dm);
+        if (h->n_pad > ((int64_t)kMaxSplits << dm.rows_log2)) digit_mode(428, dm);
+    }
+}
+
+int xtv_work_init(const mih_mat *h, XtvWork &w, int m, bool batched)
 {
     if (h->kind != 0) return MIH_OK;
     int64_t nblk = h->nbp * 2;
-    digit_mode(g_xtv_digits, w.dm);
-    if (g_xtv_digits == 0) {
-        // the FP6 kernels exist for the LDS-shared launch shapes only; larger digits mean shorter exact row slices
-        // (2^18 rows in base 49, 2^20 in base 13, 2^22 in base 4), so very tall matrices step down
-        if (g_xtv_variant >= 0 || h->n_pad > ((int64_t)kMaxSplits << w.dm.rows_log2)) digit_mode(1316, w.dm);
-        if (h->n_pad > ((int64_t)kMaxSplits << w.dm.rows_log2)) digit_mode(428, w.dm);
-    } else if (w.dm.base == 49 && g_xtv_variant >= 0) {
+    choose_mode(h, batched, w.dm);
+    if (w.dm.base == 49 && g_xtv_variant >= 0) {         // only an explicitly requested FP6 format can get here
         set_error("the FP6 residual formats need the default kernel (mih_set_xtv_variant(-1))");
         return MIH_BAD_ARG;
     }
-    // operand capacity rounded up to a multiple of 4 from three operands on: three leftover operands ride a
-    // 4-operand pass with an all-zero digit plane instead of a 2- + a 1-operand pass
     const int ops = (m + w.dm.per_op - 1) / w.dm.per_op;
-    w.ops_cap = ops < 3 ? ops : (ops + 3) & ~3;
+    w.ops_cap = ops;
     const size_t rhs_cap = (size_t)w.ops_cap * w.dm.per_op;
     const size_t lanes = (size_t)w.ops_cap * (size_t)nblk * 64;
     const size_t dwords = lanes * (w.dm.base == 49 ? 6 : 4);
@@ -779,7 +803,7 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
     hipLaunchKernelGGL(k_digits, dim3((unsigned)((nblk + 3) / 4), (unsigned)(nops * per_op)), dim3(256), 0, s, r_dev, h->n, nblk, m, dm,
                        w.scal.p, dig_all, dig2_all);
     for (int t = 0; t < nops;) {          // t counts B operands
-        int nr = (nops - t >= 3 && g_xtv_max_nr >= 4 && t + 4 <= w.ops_cap) ? 4
+        int nr = (nops - t >= 4 && nops - t != 5 && g_xtv_max_nr >= 4) ? 4 : ((nops - t == 3 || nops - t == 5) && g_xtv_max_nr >= 4) ? 3
                  : (nops - t >= 2 && g_xtv_max_nr >= 2) ? 2 : 1;
         const int u0 = t * per_op;        // first residual of this pass
         double *partial = w.partial.p + (int64_t)u0 * splits * pstride;
@@ -922,7 +946,7 @@ int mih_bench_xtv_batched(const mih_mat *h, int variant, int m, int max_fused, i
     int saved = g_xtv_variant;
     if (variant >= 0) { if (!xtv_variant_valid(variant)) return MIH_BAD_ARG; g_xtv_variant = variant; }
     XtvWork w;
-    int rc = xtv_work_init(h, w, m);
+    int rc = xtv_work_init(h, w, m, m > 1);       // m = 1: the single-fit workspace, like IhtVar
     DevBuf<double> r, out, cs;
     if (!rc) rc = r.alloc((size_t)h->n * m);
     if (!rc) rc = out.alloc((size_t)h->p * m);
