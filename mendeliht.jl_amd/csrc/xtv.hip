@@ -12,20 +12,24 @@
 // exact small-integer data, so the dot products are done EXACTLY in fixed point on the matrix pipe:
 //   * a 2-bit dosage code placed in the low bits of a nibble IS the FP4 (e2m1) number g/2, so the
 //     A operand of v_mfma_scale_f32_32x32x64_f8f6f4 is built with one AND per 8 dosages;
-//   * r is scaled by a power of two to |R| < 2^57, rounded to an integer and written as 16 digits in base 13
-//     from the digit set {-8,-6,-4,...,4,6,8}: a complete residue system mod 13 whose halves (0, +-0.5, +-1,
-//     +-1.5, +-2, +-3, +-4) are all FP4 numbers.  The 16 digit planes of a residual are 16 of the 32
-//     B-operand columns, so ONE MFMA multiplies a 32-column x 64-row dosage tile with all digits of TWO
-//     residuals (the earlier format, 28 balanced base-4 digits {-2..1} = one residual per operand, is kept
-//     as mih_set_xtv_digits(28));
-//   * every product is a multiple of 1/4 of magnitude <= 4 and a row slice holds at most 2^20 rows, so every
-//     partial sum is a multiple of 1/4 below 2^22: the f32 accumulators are exact and the result does not
-//     depend on summation order (bit-reproducible);
-//   * the digit sums are recombined in f64 (sum_t 13^t * S_t, fixed order) and rescaled by 2^-e.
-// The inexact steps are the rounding of r to 2^-57 of max|r| and the few f64 operations that recombine the
+//   * r is scaled by a power of two, rounded to an integer R (|R| < 2^54) and written in a positional system
+//     whose digits the pipe represents exactly -- each digit set is a complete residue system of its base, so the
+//     representation exists, is unique and is found by one pass of divisions per row (DigitMode, k_digits):
+//       base  4, digits {-2,-1,0,1}/2                        FP4 e2m1, 28 columns, 1 residual per B operand
+//       base 13, digits {-8,-6,-4..4,6,8}/2                  FP4 e2m1, 16 columns (|R| < 2^57), 2 per operand
+//       base 49, digits {-32..-18 even, -16..16, 18..32 even}/8  FP6 e2m3, 10 columns, 3 per operand
+//     The digit planes of a residual are columns of the 32-column B operand, so ONE MFMA multiplies a
+//     32-SNP x 64-row dosage tile with all digits of the operand's residuals.  A single fit uses base 4 (the
+//     fastest single-operand pass), every fused multi-RHS context base 49 (fewest MFMAs per residual: those
+//     passes are bound by the matrix pipe's power);
+//   * every product is a multiple of 1/4 (FP4) or 1/16 (FP6) of magnitude <= 4 and a row slice is short enough
+//     (2^22 / 2^20 / 2^18 rows) that every partial sum stays below 2^24 such units: the f32 accumulators are exact
+//     and the result does not depend on summation order (bit-reproducible);
+//   * the digit sums are recombined in f64 (sum_t base^t * S_t, fixed order) and rescaled by 2^-e.
+// The inexact steps are the rounding of r to 2^-54 of max|r| and the few f64 operations that recombine the
 // digit sums (fixed order, so bit-reproducible for a given row slicing) -- tighter than the rounding an
 // n-term f64 dot product accumulates.  Per 2048 dosages: 1 MFMA (13.7 ns/SIMD) + ~8 VALU ops, far
-// below the 87 ns/SIMD the HBM stream allows at 6 TB/s, so the kernel is memory-bound.
+// below the 87 ns/SIMD the HBM stream allows at 6 TB/s, so the single-operand kernel is memory-bound.
 //
 // Work decomposition: a wave owns CT column groups (32 SNPs each) and walks a slice of the rows in
 // 128-row steps; per step it loads CT x 1 KB of dosages (one contiguous 16 B/lane wave-load per
@@ -36,8 +40,8 @@
 //                                (library default for 1, 2 and 4 B operands per pass);
 //   k_xtv_mfma<WAVES,CT,NR>      every wave loads its own digit planes from L2 (the earlier shapes, kept as
 //                                selectable variants and as a cross-check: same arithmetic, same bits).
-// An operand carries two 16-digit residuals (default), one 28-digit base-4 residual, or four 8-digit residuals
-// (opt-in fast mode): DigitMode.
+// An operand carries one 28-digit base-4 residual, two 16-digit base-13 residuals, three 10-digit base-49 residuals,
+// or four 8-digit residuals (opt-in fast modes): DigitMode.
 #include "common.h"
 #include <mutex>
 #include <utility>
