@@ -691,8 +691,8 @@ def test_digit_modes_agree(mih, oracle, normal_pair):
     x, ox = normal_pair
     n = x.n
     rng = np.random.default_rng(77)
-    R = rng.standard_normal((n, 11)) * np.logspace(-3, 4, 11)      # very different scales side by side
-    O = np.column_stack([ox.xtv(R[:, v]) for v in range(11)])
+    R = rng.standard_normal((n, 16)) * np.logspace(-3, 4, 16)      # very different scales side by side
+    O = np.column_stack([ox.xtv(R[:, v]) for v in range(16)])
     scale = np.sqrt(n) * np.abs(R).max(axis=0)
     out = {}
     try:
@@ -700,7 +700,7 @@ def test_digit_modes_agree(mih, oracle, normal_pair):
             mih.set_xtv_digits(mode)
             got = x.xtv(R)
             assert np.all(np.max(np.abs(got - O), axis=0) < tol * scale + 1e-13 * np.abs(O).max(axis=0)), mode
-            for m_rhs in (1, 2, 3, 4, 5, 7, 8, 10):
+            for m_rhs in (1, 2, 3, 4, 5, 7, 8, 10, 13, 15):            # 1 .. 8 operands: every pass split incl. 3+2
                 assert np.array_equal(x.xtv(R[:, :m_rhs]), got[:, :m_rhs]), (mode, m_rhs)
             out[mode] = got
     finally:
@@ -1088,14 +1088,26 @@ def test_gpu_against_committed_oracle_goldens(mih, normal_pair):
     np.testing.assert_allclose(rm.Σ, gm["Sigma"], rtol=1e-6)
 
 
-def test_forty_million_rows(mih, oracle):
-    """n = 40 000 000 samples (x 64 SNPs): more than 2^22 rows per default row slice, so the pass must raise the
-    number of slices to keep the f32 accumulators exact; 32-bit row indices and 64-bit offsets at scale."""
-    n, p = 40_000_000, 64
+@pytest.mark.parametrize("n", [40_000_000, 6_000_000])
+def test_forty_million_rows(mih, oracle, n):
+    """n = 40 000 000 samples (x 64 SNPs): more rows than 16 exact row slices of the FP6 (2^18 rows) and base-13
+    (2^20) residual formats hold, so the default steps down to base-4 digits and raises the number of slices to
+    keep the f32 accumulators exact; 32-bit row indices and 64-bit offsets at scale.  n = 6 000 000: the
+    intermediate step (base-13 digits)."""
+    p = 64
     x = mih.SnpLinAlg.synthetic(n, p, seed=99, missing_rate=0.001)
     rng = np.random.default_rng(9)
     r = rng.standard_normal(n)
     out = x.xtv(r)
+    if n < 2 ** 24:
+        mih.set_xtv_digits(1316)                                     # what the default stepped down to
+        try:
+            assert np.array_equal(x.xtv(r), out)
+        finally:
+            mih.set_xtv_digits(0)
+        R3 = np.column_stack([r, -2.0 * r, r[::-1]])
+        O3 = x.xtv(R3)
+        assert np.array_equal(O3[:, 0], out) and np.array_equal(O3[:, 1], -2.0 * out)
     ox = oracle.Mat.from_bed_columns(x.export_bed()[:8], n)          # the first 8 columns on the CPU
     ref = ox.xtv(r)
     assert rel(out[:8], ref) < 1e-10
