@@ -790,40 +790,49 @@ int mih_cv_mv(const mih_mat *h, const mih_fit_params *prm, const double *Y, int6
         f.v.reset();
         return MIH_OK;
     };
-    for (size_t start = 0; start < mine.size(); start += mb) {
-        size_t end = std::min(mine.size(), start + mb);
-        std::vector<MvFit> fits(end - start);
-        std::vector<MvFit *> need;
-        for (size_t t = start; t < end; ++t) {
-            MvFit &f = fits[t - start];
-            mih_fit_params pf = pr; pf.k = path[mine[t].second];          // v.k = sparsity (cross_validation.jl:110)
-            f.v.reset(new MvVar());
-            MIH_TRY(f.v->create(h, &pf, Y, r, Z, q, s));
-            f.train.resize(n);
-            for (int64_t i = 0; i < n; ++i) f.train[i] = (folds[i] != mine[t].first);
-            f.out_index = (int64_t)(mine[t].first - 1) * npath + mine[t].second;
-            MIH_TRY(f.v->init_pre(f.train.data()));
-            need.push_back(&f);
-        }
-        MIH_TRY(batched_xtv(need));
-        for (auto *f : need) MIH_TRY(f->v->init_post());
-        for (;;) {
-            need.clear();
-            for (auto &f : fits) {
-                if (f.done) continue;
-                if (f.iter >= pr.max_iter) { MIH_TRY(finish(f)); continue; }                  // fit.jl:170-179
+    // rolling lock-step (as cv_run_rolling in fit.hip): a new fit needs its initial score, a running fit the score that
+    // ends its step -- one fused pass serves both kinds, and a finished fit's slot is refilled in the next round
+    std::vector<std::unique_ptr<MvFit>> slot((size_t)mb);
+    std::vector<MvFit *> need;
+    std::vector<char> fresh;
+    size_t next = 0;
+    for (;;) {
+        need.clear(); fresh.clear();
+        for (int t = 0; t < mb; ++t) {
+            for (;;) {
+                if (!slot[t]) {
+                    if (next >= mine.size()) break;
+                    const size_t i = next++;
+                    slot[t].reset(new MvFit());
+                    MvFit &f = *slot[t];
+                    mih_fit_params pf = pr; pf.k = path[mine[i].second];          // v.k = sparsity (cross_validation.jl:110)
+                    f.v.reset(new MvVar());
+                    MIH_TRY(f.v->create(h, &pf, Y, r, Z, q, s));
+                    f.train.resize(n);
+                    for (int64_t l = 0; l < n; ++l) f.train[l] = (folds[l] != mine[i].first);
+                    f.out_index = (int64_t)(mine[i].first - 1) * npath + mine[i].second;
+                    MIH_TRY(f.v->init_pre(f.train.data()));
+                    need.push_back(&f); fresh.push_back(1);
+                    break;
+                }
+                MvFit &f = *slot[t];
+                if (!f.done && f.iter >= pr.max_iter) MIH_TRY(finish(f));                     // fit.jl:170-179
+                if (f.done) { slot[t].reset(); continue; }
                 f.best = f.v->save_prev(f.next_logl, f.best);
                 MIH_TRY(f.v->step_pre(f.next_logl, pr.max_step, &f.nbt, &f.next_logl));
-                need.push_back(&f);
+                need.push_back(&f); fresh.push_back(0);
+                break;
             }
-            if (need.empty()) break;
-            MIH_TRY(batched_xtv(need));
-            for (auto *f : need) {
-                MIH_TRY(f->v->step_post(f->next_logl));
-                double sc = f->v->check_convergence();
-                if (f->iter >= pr.min_iter && sc < pr.tol) MIH_TRY(finish(*f));                // fit.jl:197-203
-                else f->iter++;
-            }
+        }
+        if (need.empty()) break;
+        MIH_TRY(batched_xtv(need));
+        for (size_t t = 0; t < need.size(); ++t) {
+            MvFit *f = need[t];
+            if (fresh[t]) { MIH_TRY(f->v->init_post()); continue; }
+            MIH_TRY(f->v->step_post(f->next_logl));
+            double sc = f->v->check_convergence();
+            if (f->iter >= pr.min_iter && sc < pr.tol) MIH_TRY(finish(*f));                    // fit.jl:197-203
+            else f->iter++;
         }
     }
     return MIH_OK;
