@@ -223,7 +223,7 @@ __device__ __forceinline__ f32x16 mfma_fp6(uint32_t u0, uint32_t u1, const uint4
     const uint32_t M = 0x33333333u;
     i32x8 a = {(int)(u0 & M), (int)((u0 >> 2) & M), (int)(u1 & M), (int)((u1 >> 2) & M), 0, 0, 0, 0};
     i32x8 bb = {(int)b.x, (int)b.y, (int)b.z, (int)b.w, (int)b2.x, (int)b2.y, 0, 0};
-    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bb, acc, 4, 2, 0, 127, 0, 127);
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bb, acc, 4, 2, 0, 0, 0, 0);
 }
 
 __device__ __forceinline__ f32x16 mfma_fp4(uint32_t u0, uint32_t u1, const uint4 &b, f32x16 acc)
@@ -231,8 +231,10 @@ __device__ __forceinline__ f32x16 mfma_fp4(uint32_t u0, uint32_t u1, const uint4
     const uint32_t M = 0x33333333u;
     i32x8 a = {(int)(u0 & M), (int)((u0 >> 2) & M), (int)(u1 & M), (int)((u1 >> 2) & M), 0, 0, 0, 0};
     i32x8 bb = {(int)b.x, (int)b.y, (int)b.z, (int)b.w, 0, 0, 0, 0};
-    // cbsz = blgp = 4: A and B are FP4 (e2m1); E8M0 scales 127 = 2^0
-    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bb, acc, 4, 4, 0, 127, 0, 127);
+    // cbsz = blgp = 4: A and B are FP4 (e2m1).  Literal zero scale operands make the compiler select the UNSCALED
+    // v_mfma_f32_32x32x64_f8f6f4 (no v_mfma_ld_scale_b32 in front of every MFMA); tools/mfma_probe.hip checks that
+    // form against exact integer data
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bb, acc, 4, 4, 0, 0, 0, 0);
 }
 
 // D layout: column n = lane & 31, row (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5) (SNP).  Column n holds digit

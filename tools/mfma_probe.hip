@@ -26,6 +26,13 @@ __global__ void k_probe(const uint32_t *A, const uint32_t *B, float *D, int mode
         return;
     }
     f32x16 c = {};
+    if (scale == -1) {      // literal zero scales: the compiler selects the unscaled v_mfma_f32_32x32x64_f8f6f4
+        if (mode == 0) c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 4, 4, 0, 0, 0, 0);
+        else if (mode == 3) c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 4, 2, 0, 0, 0, 0);
+        else c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 4, 0, 0, 0, 0, 0);
+        for (int i = 0; i < 16; ++i) D[l * 16 + i] = c[i];
+        return;
+    }
     if (mode == 0) c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 4, 4, 0, scale, 0, scale);
     else if (mode == 3) c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 4, 2, 0, scale, 0, scale);
     else           c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 4, 0, 0, scale, 0, scale);
@@ -95,7 +102,7 @@ int main()
             }
         }
         CK(hipMemcpy(dA, hA.data(), 64 * 8 * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, hB.data(), 64 * 8 * 4, hipMemcpyHostToDevice));
-        for (int scale : {127, 0x7f7f7f7f, 128}) {
+        for (int scale : {127, 0x7f7f7f7f, 128, -1}) {
             hipLaunchKernelGGL(k_probe, dim3(1), dim3(64), 0, 0, dA, dB, dD, mode, scale);
             CK(hipDeviceSynchronize());
             std::vector<float> hD(64 * 16);
