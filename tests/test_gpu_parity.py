@@ -1135,3 +1135,21 @@ def test_tiny_problems(mih, oracle):
     x1 = mih.SnpLinAlg(make_bed(rng, 1, 4, maf_lo=0.3), n=1, center=True, scale=True, impute=True)
     with pytest.raises(mih.MendelIHTError, match="NaN|Inf"):             # one sample: zero deviance, NaN loglikelihood
         mih.fit_iht(np.array([0.3]), x1, None, k=1, verbose=False)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_dense_xtv_shapes(mih, dtype):
+    """Dense X'r over row counts around the 256-load step of the LDS-staged kernel (one step, exact multiples, ragged
+    tails, many steps), odd / non-multiple-of-4 row counts (the fallback kernels) and column counts that leave idle
+    waves in the last block; both storage types, several right-hand sides, run-to-run reproducible."""
+    rng = np.random.default_rng(31)
+    for n in (2, 4, 510, 512, 516, 1024, 1028, 3000, 4100, 501, 1026):
+        for p in (1, 3, 4, 9):
+            X = rng.standard_normal((n, p)).astype(dtype)
+            xd = mih.DenseMatrix(X)
+            R = rng.standard_normal((n, 3))
+            want = X.astype(np.float64).T @ R
+            got = xd.xtv(R)
+            assert rel(got, want) < 1e-12, (n, p)
+            assert np.array_equal(xd.xtv(R), got)
+            assert np.array_equal(xd.xtv(R[:, 1]), got[:, 1])
