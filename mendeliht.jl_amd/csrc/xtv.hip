@@ -771,6 +771,20 @@ static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 
 
 constexpr int kStatBlocks = 64;
 
+// Row slices of the library-default kernels.  A slice should hold about 50 000 rows or more -- every (column group,
+// slice) work item pays a prologue and a 16-accumulator epilogue, and short items lose to that: at n = 50 000 one
+// slice runs at 87 % of the HBM peak and eight at 75 %, at n = 10 000 it is 74 % against 38 % -- but there must be
+// enough workgroups to fill 256 CUs, and at n = 500 000 eight slices (one per XCD, sharing that slice of the digit
+// planes in its L2) are best (87.0 % against 83.3 % for one).
+static int auto_splits(const mih_mat *h)
+{
+    int s = 1;
+    while (s < 8 && h->n >= 100000ll * s) s *= 2;
+    const int64_t groups = (h->ncg + 15) / 16;                 // workgroups per slice of the widest launch shape
+    while (s < 16 && groups * s < 2048 && h->nbp / (2 * s) >= 8) s *= 2;
+    return s;
+}
+
 // mih_set_xtv_digits (residual format ids = base * 100 + digits, see include/mendeliht_hip.h); 0 = library default
 int g_xtv_digits = 0;
 
@@ -858,7 +872,7 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
     }
     if (m > w.m_cap) { set_error("X'r workspace too small"); return MIH_BAD_ARG; }
     Variant v = current_variant();
-    int splits = v.splits;
+    int splits = g_xtv_variant < 0 ? auto_splits(h) : v.splits;
     // exactness of the f32 accumulators: |g/2 * d/2| <= 1 (base 4) or 4 (base 13) in units of 1/4, so a row
     // slice may hold at most 2^22 / 2^20 rows
     const DigitMode dm = w.dm;

@@ -43,7 +43,7 @@ def test_mu_sinv_and_xtv_all_variants(mih, normal_pair):
     base = x.xtv(r)
     assert rel(base, default) < 1e-13
     nv = 0
-    same_slices = (0, 1, 2, 3, 4, 9, 10, 13, 14)                    # shapes with 8 row slices, like the default
+    same_slices = (5, 6, 7)                                         # shapes with one row slice, like the default at n = 1000
     while mih.lib().mih_set_xtv_variant(nv) == 0:                   # the per-wave-load shapes
         out = x.xtv(r)
         assert rel(out, base) < 1e-13, nv                           # the slice partials are rounded f64 sums of exact digit sums
