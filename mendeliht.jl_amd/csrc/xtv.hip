@@ -778,6 +778,7 @@ constexpr int kStatBlocks = 64;
 // planes in its L2) are best (87.0 % against 83.3 % for one).
 static int auto_splits(const mih_mat *h)
 {
+    if (const char *e = getenv("MENDELIHT_XTV_SLICES")) { int v = atoi(e); if (v >= 1 && v <= kMaxSplits) return v; }   // tuning override
     int s = 1;
     while (s < 8 && h->n >= 100000ll * s) s *= 2;
     const int64_t groups = (h->ncg + 15) / 16;                 // workgroups per slice of the widest launch shape
