@@ -903,7 +903,7 @@ def test_cv_iht_over_replicas_in_one_process(mih, normal_data):
 def test_randomized_fits_vs_oracle(mih, oracle):
     """A seeded sweep over shapes, missing rates, families, covariates, zkeep masks, prior weights, train masks
     and k: the GPU fit must track the oracle (same support and iteration log) on every stable trajectory."""
-    rng = np.random.default_rng(20260)
+    rng = np.random.default_rng(int(os.environ.get("MIH_SWEEP_SEED", 20260)))     # other seeds: extended sweeps by hand
     fams = [("normal", "identity", mih.Normal, mih.IdentityLink, 1e-5), ("bernoulli", "logit", mih.Bernoulli, mih.LogitLink, 1e-4),
             ("poisson", "log", mih.Poisson, mih.LogLink, 1e-4)]
     checked = 0
@@ -1019,7 +1019,7 @@ def test_simulate_and_recover(mih, fam):
 def test_randomized_multivariate_fits_vs_oracle(mih, oracle):
     """Seeded sweep of multivariate fits: traits r, covariates q (some not kept), k, missingness, train masks,
     init_beta -- against the oracle on every stable trajectory."""
-    rng = np.random.default_rng(31337)
+    rng = np.random.default_rng(int(os.environ.get("MIH_SWEEP_SEED", 31337)))
     checked = 0
     for trial in range(10):
         n = int(rng.integers(150, 1500)); p = int(rng.integers(60, 400)); r = int(rng.integers(2, 6))
@@ -1153,3 +1153,33 @@ def test_dense_xtv_shapes(mih, dtype):
             assert rel(got, want) < 1e-12, (n, p)
             assert np.array_equal(xd.xtv(R), got)
             assert np.array_equal(xd.xtv(R[:, 1]), got[:, 1])
+
+
+def test_randomized_cv_vs_oracle(mih, oracle):
+    """Seeded sweep of cross-validations through the rolling lock-step driver (fused FP6 passes, slots refilled as fits
+    finish; more combinations than slots in some trials, so two lanes run): losses against the oracle's sequential
+    fits, and the same grid split over two ranks must add up to the single-rank result exactly."""
+    rng = np.random.default_rng(int(os.environ.get("MIH_SWEEP_SEED", 777)))
+    fams = [("normal", "identity", mih.Normal, mih.IdentityLink, 1e-6), ("bernoulli", "logit", mih.Bernoulli, mih.LogitLink, 1e-5),
+            ("poisson", "log", mih.Poisson, mih.LogLink, 1e-5)]
+    for trial in range(6):
+        n = int(rng.integers(200, 1600)); p = int(rng.integers(60, 400)); q = int(rng.integers(2, 5))
+        od, ol, D, L, tol = fams[int(rng.integers(0, 3))]
+        cols = make_bed(rng, n, p, missing_rate=float(rng.choice([0.0, 0.03])))
+        x = mih.SnpLinAlg(cols, n=n, center=True, scale=True, impute=True)
+        ox = oracle.Mat.from_bed_columns(cols, n)
+        eta = 0.5 * _sim(oracle, ox, rng, 4)
+        y = {"normal": eta + 1 + rng.standard_normal(n),
+             "bernoulli": (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float),
+             "poisson": rng.poisson(np.exp(np.clip(0.5 * eta, -3, 3))).astype(float)}[od]
+        npath = int(rng.integers(2, 14))                               # up to 13 x 4 = 52 combinations: more than 24 slots
+        path = sorted(int(v) for v in rng.choice(np.arange(1, 16), npath, replace=False))
+        folds = hash_folds(n, q)
+        tag = (trial, n, p, q, od, path)
+        mse, raw = mih.cv_iht(y, x, None, d=D(), l=L(), path=path, q=q, folds=folds, verbose=False, return_raw=True)
+        omse, oraw = oracle.cv_iht(ox, y, None, path=path, q=q, folds=folds, dist=od, link=ol)
+        np.testing.assert_allclose(raw, oraw, rtol=100 * tol, err_msg=str(tag))
+        np.testing.assert_allclose(mse, omse, rtol=100 * tol, err_msg=str(tag))
+        halves = [mih.cv_iht(y, x, None, d=D(), l=L(), path=path, q=q, folds=folds, verbose=False, return_raw=True,
+                             rank=r, world=2)[1] for r in range(2)]
+        assert np.array_equal(halves[0] + halves[1], raw), tag
