@@ -611,63 +611,98 @@ k_xtv_dense_f32(const float *__restrict__ D, int64_t n, int64_t p, const double 
 // 16-B loads per column; the residual chunk of a step is staged ONCE per block in LDS (double buffered, one barrier
 // per step) instead of being re-read from L2 by every wave, and the loads of step t+1 are issued before the FMAs of
 // step t.  50 000 x 100 000 f64: 5.66 ms = 7.07 TB/s against 6.19 ms for k_xtv_dense (tools/dense_probe.hip).
+// NRHS residual vectors (n apart in r, p apart in out) ride the same pass over D; per (column, residual) the
+// arithmetic and its order are those of the NRHS = 1 kernel, so fused and single passes give the same bits.
 // Fixed lane -> row mapping, fixed final tree: bit-reproducible.  Needs n % (16 / sizeof(T)) == 0 and a 16-B aligned D.
-template <typename T>
+template <typename T, int NRHS>
 __global__ void __launch_bounds__(256)
 k_xtv_dense_lds(const T *__restrict__ D, int64_t n, int64_t p, const double *__restrict__ r, double *__restrict__ out)
 {
     constexpr int E = 16 / (int)sizeof(T);         // matrix elements per 16-B load: 2 (f64) or 4 (f32)
     constexpr int RC = 128 * E;                    // f64x2 residual pairs per step (256 loads x E rows)
+    constexpr int RK = RC / 256;                   // staged pairs per thread, step and residual
     typedef T vecT __attribute__((ext_vector_type(E)));
-    __shared__ f64x2 rt[2][RC];
+    __shared__ f64x2 rt[2][NRHS][RC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t jj = blockIdx.x * 4ll + wave, j = jj < p ? jj : p - 1;      // idle waves redo the last column
     const vecT *cx = reinterpret_cast<const vecT *>(D + j * n);
-    const f64x2 *rx = reinterpret_cast<const f64x2 *>(r);
     const int64_t nv = n / E, nr2 = n >> 1, steps = (nv + 255) / 256;
     const vecT vzero = {};
     const f64x2 rzero = {0.0, 0.0};
-    double a[4][E];
+    double a[NRHS][4][E];
     #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int v = 0; v < NRHS; ++v)
         #pragma unroll
-        for (int e = 0; e < E; ++e) a[u][e] = 0.0;
+        for (int u = 0; u < 4; ++u)
+            #pragma unroll
+            for (int e = 0; e < E; ++e) a[v][u][e] = 0.0;
     #pragma unroll
-    for (int k = 0; k < RC / 256; ++k) { const int t = threadIdx.x + 256 * k; rt[0][t] = t < nr2 ? rx[t] : rzero; }
+    for (int v = 0; v < NRHS; ++v) {
+        const f64x2 *rx = reinterpret_cast<const f64x2 *>(r + (int64_t)v * n);
+        #pragma unroll
+        for (int k = 0; k < RK; ++k) { const int t = threadIdx.x + 256 * k; rt[0][v][t] = t < nr2 ? rx[t] : rzero; }
+    }
     __syncthreads();
     vecT x[4], xn[4];
     #pragma unroll
     for (int u = 0; u < 4; ++u) { const int64_t i = lane + 64 * u; x[u] = i < nv ? __builtin_nontemporal_load(cx + i) : vzero; }
     for (int64_t st = 0; st < steps; ++st) {
         const int buf = (int)(st & 1);
-        f64x2 rn[RC / 256];
+        f64x2 rn[NRHS][RK];
         #pragma unroll
-        for (int k = 0; k < RC / 256; ++k) { const int64_t t = (st + 1) * RC + threadIdx.x + 256 * k; rn[k] = t < nr2 ? rx[t] : rzero; }
+        for (int v = 0; v < NRHS; ++v) {
+            const f64x2 *rx = reinterpret_cast<const f64x2 *>(r + (int64_t)v * n);
+            #pragma unroll
+            for (int k = 0; k < RK; ++k) { const int64_t t = (st + 1) * RC + threadIdx.x + 256 * k; rn[v][k] = t < nr2 ? rx[t] : rzero; }
+        }
         #pragma unroll
         for (int u = 0; u < 4; ++u) { const int64_t i = (st + 1) * 256 + lane + 64 * u; xn[u] = i < nv ? __builtin_nontemporal_load(cx + i) : vzero; }
         #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int v = 0; v < NRHS; ++v) {
             #pragma unroll
-            for (int h = 0; h < E / 2; ++h) {
-                const f64x2 v = rt[buf][(E / 2) * (lane + 64 * u) + h];
-                a[u][2 * h] = fma((double)x[u][2 * h], v.x, a[u][2 * h]);
-                a[u][2 * h + 1] = fma((double)x[u][2 * h + 1], v.y, a[u][2 * h + 1]);
+            for (int u = 0; u < 4; ++u) {
+                #pragma unroll
+                for (int h = 0; h < E / 2; ++h) {
+                    const f64x2 rv = rt[buf][v][(E / 2) * (lane + 64 * u) + h];
+                    a[v][u][2 * h] = fma((double)x[u][2 * h], rv.x, a[v][u][2 * h]);
+                    a[v][u][2 * h + 1] = fma((double)x[u][2 * h + 1], rv.y, a[v][u][2 * h + 1]);
+                }
             }
         }
         #pragma unroll
-        for (int k = 0; k < RC / 256; ++k) rt[buf ^ 1][threadIdx.x + 256 * k] = rn[k];
+        for (int v = 0; v < NRHS; ++v)
+            #pragma unroll
+            for (int k = 0; k < RK; ++k) rt[buf ^ 1][v][threadIdx.x + 256 * k] = rn[v][k];
         __syncthreads();
         #pragma unroll
         for (int u = 0; u < 4; ++u) x[u] = xn[u];
     }
-    double su[4];
     #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        su[u] = a[u][0] + a[u][1];
-        if (E == 4) su[u] = su[u] + (a[u][2] + a[u][3]);
+    for (int v = 0; v < NRHS; ++v) {
+        double su[4];
+        #pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            su[u] = a[v][u][0] + a[v][u][1];
+            if (E == 4) su[u] = su[u] + (a[v][u][2] + a[v][u][3]);
+        }
+        const double sum = wave_sum((su[0] + su[1]) + (su[2] + su[3]));
+        if (lane == 0 && jj < p) out[(int64_t)v * p + j] = sum;
     }
-    const double s = wave_sum((su[0] + su[1]) + (su[2] + su[3]));
-    if (lane == 0 && jj < p) out[j] = s;
+}
+
+template <typename T>
+static void launch_dense_lds(const T *D, const mih_mat *h, const double *r_dev, int m, double *out_dev, hipStream_t s)
+{
+    const dim3 grid((unsigned)((h->p + 3) / 4)), block(256);
+    int v = 0;
+    for (; v + 4 <= m; v += 4)
+        hipLaunchKernelGGL((k_xtv_dense_lds<T, 4>), grid, block, 0, s, D, h->n, h->p, r_dev + (int64_t)v * h->n, out_dev + (int64_t)v * h->p);
+    if (m - v >= 2) {
+        hipLaunchKernelGGL((k_xtv_dense_lds<T, 2>), grid, block, 0, s, D, h->n, h->p, r_dev + (int64_t)v * h->n, out_dev + (int64_t)v * h->p);
+        v += 2;
+    }
+    if (m - v == 1)
+        hipLaunchKernelGGL((k_xtv_dense_lds<T, 1>), grid, block, 0, s, D, h->n, h->p, r_dev + (int64_t)v * h->n, out_dev + (int64_t)v * h->p);
 }
 
 struct Variant { int waves, ct, splits; };
@@ -858,12 +893,14 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
     if (h->kind == 1) {
         const bool lds_ok = g_xtv_variant < 0 && (((uintptr_t)(h->Df ? (const void *)h->Df : (const void *)h->D)) & 15) == 0
                             && h->n % (h->Df ? 4 : 2) == 0;
+        if (lds_ok) {
+            if (h->Df) launch_dense_lds<float>(h->Df, h, r_dev, m, out_dev, s);
+            else launch_dense_lds<double>(h->D, h, r_dev, m, out_dev, s);
+            MIH_HIP(hipGetLastError());
+            return MIH_OK;
+        }
         for (int v = 0; v < m; ++v) {
-            if (lds_ok && h->Df) hipLaunchKernelGGL((k_xtv_dense_lds<float>), dim3((unsigned)((h->p + 3) / 4)), dim3(256), 0, s, h->Df, h->n, h->p,
-                                                    r_dev + (int64_t)v * h->n, out_dev + (int64_t)v * h->p);
-            else if (lds_ok) hipLaunchKernelGGL((k_xtv_dense_lds<double>), dim3((unsigned)((h->p + 3) / 4)), dim3(256), 0, s, h->D, h->n, h->p,
-                                                r_dev + (int64_t)v * h->n, out_dev + (int64_t)v * h->p);
-            else if (h->Df) hipLaunchKernelGGL(k_xtv_dense_f32, dim3((unsigned)((h->p + 3) / 4)), dim3(256), 0, s, h->Df, h->n, h->p,
+            if (h->Df) hipLaunchKernelGGL(k_xtv_dense_f32, dim3((unsigned)((h->p + 3) / 4)), dim3(256), 0, s, h->Df, h->n, h->p,
                                           r_dev + (int64_t)v * h->n, out_dev + (int64_t)v * h->p);
             else hipLaunchKernelGGL(k_xtv_dense, dim3((unsigned)((h->p + 3) / 4)), dim3(256), 0, s, h->D, h->n, h->p,
                                     r_dev + (int64_t)v * h->n, out_dev + (int64_t)v * h->p);
