@@ -748,7 +748,7 @@ static void launch_xtv(const mih_mat *h, const uint4 *dig, int64_t dig_stride, i
                        reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig_stride, splits, dm, scal, partial);
 }
 
-// nr B operands per pass: 1 = the tuned single-operand variants; 2 / 4 = fused passes (64 / 128 accumulator
+// nr B operands per pass: 1 = the tuned single-operand variants; 2 / 3 / 4 = fused passes (64 - 128 accumulator
 // registers).  Each operand carries per_op residual vectors.
 static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 *dig, const uint2 *dig2, int64_t dig_stride,
                         int splits, DigitMode dm, const double *scal, double *partial, hipStream_t s)
@@ -762,7 +762,9 @@ static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 
         const int mv6 = g_xtv_multi_variant;
         MIH_LDS6(4, 1, 2, 1, 8) MIH_LDS6(4, 2, 1, 4, 8) MIH_LDS6(4, 3, 2, 2, 4) MIH_LDS6(4, 4, 2, 1, 4) MIH_LDS6(4, 5, 1, 2, 8)
         MIH_LDS6(1, 10, 1, 2, 8) MIH_LDS6(1, 11, 2, 4, 8) MIH_LDS6(1, 12, 2, 2, 8) MIH_LDS6(1, 13, 4, 2, 8) MIH_LDS6(1, 14, 1, 4, 16) MIH_LDS6(1, 15, 2, 2, 16)
-        MIH_LDS6(1, -1, 1, 4, 8) MIH_LDS6(2, -1, 4, 1, 4) MIH_LDS6(3, -1, 2, 2, 8) MIH_LDS6(4, -1, 2, 2, 8)
+        // defaults (2 operands: <2,4,1,4> 22.5 ms against 23.3-26 ms for five other shapes; 3 operands: <3,2,2,4> 33.2 ms
+        // against 34.5 ms for <3,2,2,8>)
+        MIH_LDS6(1, -1, 1, 4, 8) MIH_LDS6(2, -1, 4, 1, 4) MIH_LDS6(3, -1, 2, 2, 4) MIH_LDS6(4, -1, 2, 2, 8)
         set_error("unsupported operand count");
         return MIH_BAD_ARG;
     }
