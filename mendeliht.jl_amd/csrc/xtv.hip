@@ -760,11 +760,11 @@ static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 
         return MIH_OK; }
     if (dm.base == 49) {           // FP6 digit planes: one launch shape per operand count (+ tuning shapes for 4)
         const int mv6 = g_xtv_multi_variant;
-        MIH_LDS6(4, 1, 2, 1, 8) MIH_LDS6(4, 2, 1, 4, 8) MIH_LDS6(4, 3, 2, 2, 4) MIH_LDS6(4, 4, 2, 1, 4) MIH_LDS6(4, 5, 1, 2, 8)
+        MIH_LDS6(4, 1, 2, 2, 8) MIH_LDS6(4, 2, 1, 4, 8) MIH_LDS6(4, 3, 2, 2, 4) MIH_LDS6(4, 4, 2, 1, 4) MIH_LDS6(4, 5, 1, 2, 8)
         MIH_LDS6(1, 10, 1, 2, 8) MIH_LDS6(1, 11, 2, 4, 8) MIH_LDS6(1, 12, 2, 2, 8) MIH_LDS6(1, 13, 4, 2, 8) MIH_LDS6(1, 14, 1, 4, 16) MIH_LDS6(1, 15, 2, 2, 16)
         // defaults (2 operands: <2,4,1,4> 22.5 ms against 23.3-26 ms for five other shapes; 3 operands: <3,2,2,4> 33.2 ms
-        // against 34.5 ms for <3,2,2,8>)
-        MIH_LDS6(1, -1, 1, 4, 8) MIH_LDS6(2, -1, 4, 1, 4) MIH_LDS6(3, -1, 2, 2, 4) MIH_LDS6(4, -1, 2, 2, 8)
+        // against 34.5 ms for <3,2,2,8>; 4 operands: <4,2,1,8> 39.4 ms against 40.6 ms for <4,2,2,8>, same box)
+        MIH_LDS6(1, -1, 1, 4, 8) MIH_LDS6(2, -1, 4, 1, 4) MIH_LDS6(3, -1, 2, 2, 4) MIH_LDS6(4, -1, 2, 1, 8)
         set_error("unsupported operand count");
         return MIH_BAD_ARG;
     }

@@ -1,4 +1,5 @@
-"""Launch shapes of the 4-operand FP6 X'r pass (mih_set_xtv_multi_variant 0..5 in the default residual format) and
+"""Launch shapes of the 4-operand FP6 X'r pass (mih_set_xtv_multi_variant 0..5 in the default residual format; 0 =
+<4,2,1,8>, the default, 1 = <4,2,2,8>) and
 the 3-operand passes of both digit formats."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
