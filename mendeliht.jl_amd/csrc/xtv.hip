@@ -473,17 +473,23 @@ k_xtv_mfma_lds(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint
                     }
                 }
                 const uint32_t keep = (bp + q < b1) ? 0xFFFFFFFFu : 0u;     // blocks past the slice end add zero
-                #pragma unroll
-                for (int c = 0; c < CT; ++c) {
-                    if (FP6) {
-                        acc[c][v] = mfma_fp6(acur[q][c].x & keep, acur[q][c].y & keep, bfr[i & 1][0], bfr2[i & 1][0], acc[c][v]);
-                        acc[c][v] = mfma_fp6(acur[q][c].z & keep, acur[q][c].w & keep, bfr[i & 1][1], bfr2[i & 1][1], acc[c][v]);
-                    } else if (MODE != 1) {
-                        acc[c][v] = mfma_fp4(acur[q][c].x & keep, acur[q][c].y & keep, bfr[i & 1][0], acc[c][v]);
-                        acc[c][v] = mfma_fp4(acur[q][c].z & keep, acur[q][c].w & keep, bfr[i & 1][1], acc[c][v]);
-                    } else {
-                        acc[c][v][0] += __uint_as_float((acur[q][c].x ^ acur[q][c].y ^ acur[q][c].z ^ acur[q][c].w) & keep & bfr[i & 1][0].x & bfr[i & 1][1].y);
+                // the CT tiles against one digit fragment in turn: consecutive MFMAs share the B operand and write
+                // different accumulators (2 FP6 operands, CT = 4: 23.1 ms against 23.8 ms for tile-by-tile order)
+                if (MODE != 1) {
+                    #pragma unroll
+                    for (int c = 0; c < CT; ++c) {
+                        if (FP6) acc[c][v] = mfma_fp6(acur[q][c].x & keep, acur[q][c].y & keep, bfr[i & 1][0], bfr2[i & 1][0], acc[c][v]);
+                        else acc[c][v] = mfma_fp4(acur[q][c].x & keep, acur[q][c].y & keep, bfr[i & 1][0], acc[c][v]);
                     }
+                    #pragma unroll
+                    for (int c = 0; c < CT; ++c) {
+                        if (FP6) acc[c][v] = mfma_fp6(acur[q][c].z & keep, acur[q][c].w & keep, bfr[i & 1][1], bfr2[i & 1][1], acc[c][v]);
+                        else acc[c][v] = mfma_fp4(acur[q][c].z & keep, acur[q][c].w & keep, bfr[i & 1][1], acc[c][v]);
+                    }
+                } else {
+                    #pragma unroll
+                    for (int c = 0; c < CT; ++c)
+                        acc[c][v][0] += __uint_as_float((acur[q][c].x ^ acur[q][c].y ^ acur[q][c].z ^ acur[q][c].w) & keep & bfr[i & 1][0].x & bfr[i & 1][1].y);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
