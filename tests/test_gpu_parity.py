@@ -1184,3 +1184,32 @@ def test_randomized_cv_vs_oracle(mih, oracle):
         halves = [mih.cv_iht(y, x, None, d=D(), l=L(), path=path, q=q, folds=folds, verbose=False, return_raw=True,
                              rank=r, world=2)[1] for r in range(2)]
         assert np.array_equal(halves[0] + halves[1], raw), tag
+
+
+def test_xtv_accuracy_against_exact_rational_arithmetic(mih):
+    """The fixed-point X'r against EXACT dot products (Python rationals) of the raw dosages: the only rounding is that
+    of the residual to 2^-55 max|r| (2^-58 in the base-13 format) plus the recombination in f64, so the error stays
+    at a few 1e-16 of sqrt(n) max|r| -- well inside what an n-term f64 dot product guarantees (n 2^-53 sum|g r|)."""
+    from fractions import Fraction
+
+    rng = np.random.default_rng(2718)
+    n, p = 3000, 40
+    cols = make_bed(rng, n, p, maf_lo=0.05)
+    x = mih.SnpLinAlg(cols, n=n, center=False, scale=False, impute=False)
+    bits = np.unpackbits(cols, axis=1, bitorder="little").reshape(p, -1, 2)[:, :n, :]
+    code = bits[:, :, 0] + 2 * bits[:, :, 1]
+    g = np.select([code == 0, code == 2, code == 3], [0, 1, 2], default=0)            # missing (code 1) counts as 0
+    r = rng.standard_normal(n) * np.exp(rng.uniform(-6, 6, n))                       # 5 decades of dynamic range
+    rf = [Fraction(float(v)) for v in r]
+    exact = [sum((int(gi) * ri for gi, ri in zip(g[j], rf) if gi), Fraction(0)) for j in range(p)]
+    scale = np.sqrt(n) * np.abs(r).max()
+    f64_bound = n * 2.0 ** -53 * (g * np.abs(r)).sum(axis=1)
+    try:
+        for mode, tol in ((0, 6e-16), (1316, 2e-16), (428, 6e-16)):
+            mih.set_xtv_digits(mode)
+            got = x.xtv(r)
+            err = np.array([abs(float(Fraction(float(got[j])) - exact[j])) for j in range(p)])
+            assert err.max() <= tol * scale, (mode, err.max() / scale)
+            assert np.all(err <= f64_bound), mode
+    finally:
+        mih.set_xtv_digits(0)
