@@ -1213,3 +1213,30 @@ def test_xtv_accuracy_against_exact_rational_arithmetic(mih):
             assert np.all(err <= f64_bound), mode
     finally:
         mih.set_xtv_digits(0)
+
+
+def test_fits_and_cv_at_full_row_count(mih, oracle):
+    """n = 500 000 samples (BASELINE configs[2]/[3] row count) with a column count the oracle still finishes in
+    seconds: fit_iht (Normal, Bernoulli) and a small cv_iht grid against the oracle -- n-vector reductions, the
+    fixed-point residual and the lock-step driver at the full row count."""
+    n, p = 500_000, 384
+    x = mih.SnpLinAlg.synthetic(n, p, seed=2024)
+    ox = oracle.Mat.from_bed_columns(x.export_bed(), n)
+    rng = np.random.default_rng(12)
+    eta = _sim(oracle, ox, rng, 6, scale=0.3)
+    y = eta + 1 + rng.standard_normal(n)
+    res = mih.fit_iht(y, x, None, k=8, verbose=False)
+    o = oracle.fit_iht(ox, y, None, k=8)
+    assert res.iter == o["iter"] and np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"]))
+    np.testing.assert_allclose(res.beta, o["beta"], rtol=1e-5, atol=1e-12)
+    assert res.logl == pytest.approx(o["logl"], rel=1e-10)
+    yb = (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float)
+    res = mih.fit_iht(yb, x, None, k=6, d=mih.Bernoulli(), l=mih.LogitLink(), verbose=False)
+    o = oracle.fit_iht(ox, yb, None, k=6, dist="bernoulli", link="logit")
+    assert res.iter == o["iter"] and np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"]))
+    np.testing.assert_allclose(res.beta, o["beta"], rtol=1e-4, atol=1e-12)
+    folds = hash_folds(n, 3)
+    path = [2, 5, 8, 11]
+    mse = mih.cv_iht(yb, x, None, d=mih.Bernoulli(), l=mih.LogitLink(), path=path, q=3, folds=folds, verbose=False)
+    omse, _ = oracle.cv_iht(ox, yb, None, path=path, q=3, folds=folds, dist="bernoulli", link="logit")
+    np.testing.assert_allclose(mse, omse, rtol=1e-5)
