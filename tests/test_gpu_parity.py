@@ -1240,3 +1240,18 @@ def test_fits_and_cv_at_full_row_count(mih, oracle):
     mse = mih.cv_iht(yb, x, None, d=mih.Bernoulli(), l=mih.LogitLink(), path=path, q=3, folds=folds, verbose=False)
     omse, _ = oracle.cv_iht(ox, yb, None, path=path, q=3, folds=folds, dist="bernoulli", link="logit")
     np.testing.assert_allclose(mse, omse, rtol=1e-5)
+
+
+def test_multivariate_fit_at_full_row_count(mih, oracle):
+    """Multivariate Gaussian IHT (4 traits, 2 covariates) at n = 500 000 rows against the oracle."""
+    n, p = 500_000, 256
+    x = mih.SnpLinAlg.synthetic(n, p, seed=2024)
+    ox = oracle.Mat.from_bed_columns(x.export_bed(), n)
+    rng = np.random.default_rng(14)
+    Y, Z = _mv_problem(oracle, ox, rng, 4, 9, 2)
+    res = mih.fit_iht(Y, x, Z, k=9, verbose=False)
+    o = oracle.fit_mv(ox, Y, Z, k=9)
+    assert res.iter == o["iter"] and np.array_equal(res.beta != 0, o["B"] != 0)
+    np.testing.assert_allclose(res.beta, o["B"], rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(res.c, o["C"], rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(res.Σ, o["Sigma"], rtol=1e-8)
