@@ -31,3 +31,19 @@ print(f"n={n} p={p} k={k}: GPU {res.iter} iterations in {tg:.2f} s, oracle {o['i
       f"same support: {same}; max |beta - beta_oracle| = {np.max(np.abs(res.beta - o['beta'])):.3e} "
       f"(max |beta| {np.abs(res.beta[nz]).max():.3f}); logl {res.logl!r} vs {o['logl']!r}; "
       f"true effects recovered {np.intersect1d(np.flatnonzero(res.beta), supp).size}/{k}")
+
+if os.environ.get("MIH_CV"):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import hash_folds
+    eta = x.xv_sparse(supp[:10], beta[:10] * 0.5)
+    yb = (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float)
+    folds = hash_folds(n, 3)
+    path = [5, 10, 15]
+    t0 = time.perf_counter()
+    mse = m.cv_iht(yb, x, None, d=m.Bernoulli(), l=m.LogitLink(), path=path, q=3, folds=folds, verbose=False)
+    tg = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    omse, _ = O.cv_iht(ox, yb, None, path=path, q=3, folds=folds, dist="bernoulli", link="logit")
+    tc = time.perf_counter() - t0
+    print(f"cv_iht Bernoulli/Logit path={path} q=3: GPU {tg:.2f} s, oracle {tc:.1f} s; losses {mse} vs {omse}; "
+          f"max relative difference {np.max(np.abs(mse - omse) / omse):.3e}")
