@@ -701,6 +701,9 @@ static void launch_dense_lds(const T *D, const mih_mat *h, const double *r_dev, 
 {
     const dim3 grid((unsigned)((h->p + 3) / 4)), block(256);
     int v = 0;
+    if constexpr (sizeof(T) == 8)          // eight f64 residual chunks fill the 64 KB of static LDS
+        for (; v + 8 <= m; v += 8)
+            hipLaunchKernelGGL((k_xtv_dense_lds<T, 8>), grid, block, 0, s, D, h->n, h->p, r_dev + (int64_t)v * h->n, out_dev + (int64_t)v * h->p);
     for (; v + 4 <= m; v += 4)
         hipLaunchKernelGGL((k_xtv_dense_lds<T, 4>), grid, block, 0, s, D, h->n, h->p, r_dev + (int64_t)v * h->n, out_dev + (int64_t)v * h->p);
     if (m - v >= 2) {

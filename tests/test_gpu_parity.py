@@ -1147,13 +1147,14 @@ def test_dense_xtv_shapes(mih, dtype):
         for p in (1, 3, 4, 9):
             X = rng.standard_normal((n, p)).astype(dtype)
             xd = mih.DenseMatrix(X)
-            R = rng.standard_normal((n, 7))
+            R = rng.standard_normal((n, 15))
             want = X.astype(np.float64).T @ R
-            got = xd.xtv(R)                                             # fused passes of 4 + 2 + 1 residuals
+            got = xd.xtv(R)                                             # fused passes of 8 (f64) / 4 + 4 + 2 + 1 residuals
             assert rel(got, want) < 1e-12, (n, p)
             assert np.array_equal(xd.xtv(R), got)
             assert np.array_equal(xd.xtv(R[:, 1]), got[:, 1])           # fused == single, bit for bit
             assert np.array_equal(xd.xtv(R[:, 2:5]), got[:, 2:5])
+            assert np.array_equal(xd.xtv(R[:, 3:11]), got[:, 3:11])
 
 
 def test_randomized_cv_vs_oracle(mih, oracle):
