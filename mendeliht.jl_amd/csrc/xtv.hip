@@ -505,6 +505,267 @@ k_xtv_mfma_lds(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint
     xtv_epilogue<CT, NR>(acc, lane, cg0, ncg, split, splits, dm, scal, partial);
 }
 
+// ---- X'R with every operand through an LDS-DMA ring ---------------------------------------------------------------
+// The register-staged LDS kernel above keeps ONE 128-row step of dosage tiles in flight per wave (16 KB per CU with its
+// one resident workgroup of the fused shapes) and waits for it at the top of the next step.  Here nothing is loaded
+// into registers: every wave copies its own CT dosage tiles and its share of the block's digit planes straight into
+// LDS (global_load_lds_dwordx4, 1 KB per instruction) D steps ahead of their use, so D x (WAVES*CT + 2..3 NR) KB are
+// in flight per CU and the registers hold only accumulators (AGPRs) and fragments.  Waits are counted by hand
+// (s_waitcnt vmcnt(N): LDS-DMA completes in issue order); a wave's own dosage tiles need only its own wait, the shared
+// digit planes the wait plus the step's one barrier.  Ring of D + 1 stages: the stage refilled in step t is the one
+// last read in step t - 1.  Same arithmetic, same row slicing, same summation order as the other kernels: same bits.
+// Measured at n = 500k, p = 1M (tools/sweep_dma.py, tools/probe_dma.py, profiles/r02_*): 12 residuals 34.7 ms against
+// 40.0 ms register-staged; D = 2, 3, 4 and the 4 x 4 / 8 x 2 wave shapes all land within 1 % of each other because the
+// pass is bound by the package power cap, not by latency or issue (1354 W, shader clock 1.71 GHz; the same MFMAs alone,
+// operands in registers, take 20.0 ms at 1.63 GHz: tools/mfma_rate.hip).
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+typedef int i32x2v __attribute__((ext_vector_type(2)));
+
+// lane i's 16 B at sbase + voff land at LDS byte address lds_dst + 16 i.  M0 is compiler-reserved: saved and restored.
+template <bool NT>
+__device__ __forceinline__ void glds16(uint32_t lds_dst, uint32_t voff, const void *sbase)
+{
+    uint32_t keep;
+    if (NT)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3 nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_vm_barrier()
+{
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(N) : "memory");
+}
+
+template <bool FP6>
+__device__ __forceinline__ f32x16 mfma4x(i32x4v a, const i32x8 &b, f32x16 acc)
+{
+    i32x8 aa = {a[0], a[1], a[2], a[3], 0, 0, 0, 0};
+    if (FP6) return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aa, b, acc, 4, 2, 0, 0, 0, 0);
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aa, b, acc, 4, 4, 0, 0, 0, 0);
+}
+// timing probe: consumes the fragments with one VALU operation instead of an MFMA
+__device__ __forceinline__ f32x16 fake4x(i32x4v a, const i32x8 &b, f32x16 acc)
+{
+    acc[0] += __int_as_float((a[0] ^ a[1] ^ a[2] ^ a[3]) & b[0] & b[3]);
+    return acc;
+}
+
+// Epilogue of the LDS-DMA kernel.  The 32 x 32 accumulator tile of a (column group, operand) goes through a 4.5 KB LDS
+// buffer of the wave as f32 [digit column][SNP row] (rows padded to 36 floats: conflict-free 16-B stores); lane
+// (row, residual) then adds up its residual's digit columns in exactly the order of xtv_epilogue -- digit 0 upward for
+// 10 columns, the xor tree for 8 / 16 / 32 -- so the bits are those of every other kernel, with `slots` LDS reads per
+// output instead of 10 f64 shuffles per accumulator register.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <int CT, int NR, int SLOTS>
+__device__ __forceinline__ void xtv_epilogue_lds_s(const f32x16 (&acc)[CT][NR], float *buf, int lane, int64_t cg0, int64_t ncg,
+                                                   int split, int splits, DigitMode dm, const double *__restrict__ scal,
+                                                   double *__restrict__ partial)
+{
+#pragma clang fp contract(off)      // products and sums round separately, as in xtv_epilogue (there a shuffle sits between them)
+    constexpr int RS = 36;
+    const int col = lane & 31, hi = lane >> 5;
+    const int per_op = dm.per_op;
+    double wgt[SLOTS];
+    {
+        unsigned long long w = dm.base == 49 ? 16 : 4;   // unit * base^t < 2^58: exact in 64 bits, one rounding to f64
+        #pragma unroll
+        for (int t = 0; t < SLOTS; ++t) { wgt[t] = t < dm.ndig ? (double)w : 0.0; w *= (unsigned)dm.base; }
+    }
+    #pragma unroll
+    for (int v = 0; v < NR; ++v) {
+        #pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            __builtin_amdgcn_wave_barrier();
+            #pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<f32x4v *>(buf + col * RS + 8 * q + 4 * hi) =
+                    f32x4v{acc[c][v][4 * q], acc[c][v][4 * q + 1], acc[c][v][4 * q + 2], acc[c][v][4 * q + 3]};
+            __builtin_amdgcn_wave_barrier();
+            #pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int o = lane + 64 * k, row = o & 31, sub = o >> 5;
+                if (sub < per_op) {
+                    const float *src = buf + sub * SLOTS * RS + row;
+                    double x[SLOTS];
+                    #pragma unroll
+                    for (int t = 0; t < SLOTS; ++t) x[t] = (double)src[t * RS] * wgt[t];
+                    double sum;
+                    if ((SLOTS & (SLOTS - 1)) == 0) {                // the xor tree of xtv_epilogue, lane 0's cone
+                        #pragma unroll
+                        for (int off = SLOTS / 2; off > 0; off >>= 1)
+                            #pragma unroll
+                            for (int t = 0; t < off; ++t) x[t] = x[t] + x[t + off];
+                        sum = x[0];
+                    } else {
+                        sum = 0.0;
+                        #pragma unroll
+                        for (int t = 0; t < SLOTS; ++t) sum += x[t];
+                    }
+                    const int rhs = v * per_op + sub;
+                    if (cg0 + c < ncg)
+                        partial[((int64_t)rhs * splits + split) * (ncg * 32) + (cg0 + c) * 32 + row] = sum * scal[4 * rhs + 1];
+                }
+            }
+        }
+    }
+}
+template <int CT, int NR>
+__device__ __forceinline__ void xtv_epilogue_lds(const f32x16 (&acc)[CT][NR], float *buf, int lane, int64_t cg0, int64_t ncg,
+                                                 int split, int splits, DigitMode dm, const double *__restrict__ scal,
+                                                 double *__restrict__ partial)
+{
+    if (dm.slots == 10) xtv_epilogue_lds_s<CT, NR, 10>(acc, buf, lane, cg0, ncg, split, splits, dm, scal, partial);
+    else if (dm.slots == 8) xtv_epilogue_lds_s<CT, NR, 8>(acc, buf, lane, cg0, ncg, split, splits, dm, scal, partial);
+    else if (dm.slots == 16) xtv_epilogue_lds_s<CT, NR, 16>(acc, buf, lane, cg0, ncg, split, splits, dm, scal, partial);
+    else xtv_epilogue_lds_s<CT, NR, 32>(acc, buf, lane, cg0, ncg, split, splits, dm, scal, partial);
+}
+
+template <int NR, int CT, int WAVES, int D, bool FP6, int MODE = 0>      // MODE 1: no MFMAs, 2: no copies after the prologue (timing probes only)
+__global__ void __launch_bounds__(WAVES * 64, 1)
+k_xtv_dma(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *__restrict__ dig, const uint2 *__restrict__ dig2,
+          int64_t dig_stride, int splits, DigitMode dm, const double *__restrict__ scal,
+          double *__restrict__ partial /* [NR*per_op][splits][ncg*32] */)
+{
+    constexpr int S = D + 1;                        // ring stages
+    constexpr int DOS = WAVES * CT * 1024;          // dosage bytes of a stage (wave w: tiles at w*CT KB)
+    constexpr int OPB = FP6 ? 3072 : 2048;          // digit bytes of an operand and step: 2 x 1 KB `dig` halves (+ 1 KB `dig2`)
+    constexpr int DGT = NR * OPB;
+    constexpr int STAGE = DOS + DGT;
+    constexpr int PPO = FP6 ? 3 : 2;                // 1 KB pieces per operand
+    constexpr int NP = NR * PPO;                    // digit pieces per step
+    constexpr int PW = (NP + WAVES - 1) / WAVES;    // pieces per wave (surplus slots repeat the last piece)
+    constexpr int L = CT + PW;                      // LDS-DMA instructions per wave and step
+    constexpr int NI = 2 * NR;                      // (operand, 64-row half) items of a step
+    static_assert(S * STAGE <= 160 * 1024, "LDS ring too large");
+    static_assert(D * L <= 63, "vmcnt range");
+    static_assert(S * STAGE >= WAVES * 32 * 36 * 4, "the epilogue buffers overlay the ring");
+    __shared__ uint4 lds[S * STAGE / 16];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int split = blockIdx.x % splits;
+    const int64_t grp = blockIdx.x / splits;
+    const int64_t cg0 = (grp * WAVES + wave) * CT;
+    const int64_t bps = (nbp + splits - 1) / splits;
+    const int64_t b0 = split * bps;
+    const int64_t b1 = (b0 + bps < nbp) ? b0 + bps : nbp;
+
+    f32x16 acc[CT][NR];
+    #pragma unroll
+    for (int c = 0; c < CT; ++c)
+        #pragma unroll
+        for (int v = 0; v < NR; ++v)
+            #pragma unroll
+            for (int g = 0; g < 16; ++g) acc[c][v][g] = 0.f;
+
+    // (an empty trailing slice -- nbp not a multiple of the slice count -- runs one clamped, masked-out step so that
+    // the accumulators never live across a branch: that would push all of them through scratch)
+    {
+        const bool empty = b0 >= b1;
+        const int64_t bb0 = empty ? nbp - 1 : b0;
+        const int nb = empty ? 1 : (int)(b1 - b0);
+        const int amask = empty ? 0 : -1;
+        const char *xs[CT];
+        #pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int64_t cg = cg0 + c < ncg ? cg0 + c : ncg - 1;        // idle waves redo the last group
+            xs[c] = reinterpret_cast<const char *>(X) + (cg * nbp + bb0) * 1024;
+        }
+        const char *dsrc[PW]; int dstep[PW]; int doff[PW];
+        #pragma unroll
+        for (int u = 0; u < PW; ++u) {
+            const int jj = wave + u * WAVES, j = jj < NP ? jj : NP - 1;
+            const int op = j / PPO, part = j - PPO * op;
+            if (part < 2) {
+                dsrc[u] = reinterpret_cast<const char *>(dig) + (op * dig_stride + (2 * bb0 + part) * 64) * 16;
+                dstep[u] = 2048; doff[u] = DOS + op * OPB + part * 1024;
+            } else {
+                dsrc[u] = reinterpret_cast<const char *>(dig2) + (op * dig_stride + 2 * bb0 * 64) * 8;
+                dstep[u] = 1024; doff[u] = DOS + op * OPB + 2048;
+            }
+        }
+        const uint32_t voff = lane * 16;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
+        const uint32_t mydos = wave * CT * 1024;
+        const char *ldsb = reinterpret_cast<const char *>(lds);
+
+        auto issue = [&](int ts, int st) {
+            const int tb = ts < nb ? ts : nb - 1;                        // past the slice end: copy the last block again
+            const uint32_t base = lds0 + st * STAGE;
+            #pragma unroll
+            for (int c = 0; c < CT; ++c) glds16<true>(base + mydos + c * 1024, voff, xs[c] + (int64_t)tb * 1024);
+            #pragma unroll
+            for (int u = 0; u < PW; ++u) glds16<false>(base + doff[u], voff, dsrc[u] + (int64_t)tb * dstep[u]);
+        };
+        auto read_b = [&](int st, int item, i32x8 &b) {
+            const int v = item >> 1, e = item & 1;
+            const char *q = ldsb + st * STAGE + DOS + v * OPB;
+            const i32x4v lo = *reinterpret_cast<const i32x4v *>(q + e * 1024 + lane * 16);
+            if (FP6) {
+                const i32x2v hi = *reinterpret_cast<const i32x2v *>(q + 2048 + e * 512 + lane * 8);
+                b = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], 0, 0};
+            } else b = i32x8{lo[0], lo[1], lo[2], lo[3], 0, 0, 0, 0};
+        };
+        auto read_dos = [&](int st, i32x4v (&raw)[CT]) {
+            #pragma unroll
+            for (int c = 0; c < CT; ++c) raw[c] = *reinterpret_cast<const i32x4v *>(ldsb + st * STAGE + mydos + c * 1024 + lane * 16);
+        };
+        auto expand = [&](const i32x4v (&raw)[CT], i32x4v (&a)[CT][2]) {
+            const int M = 0x33333333 & amask;
+            #pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                const unsigned x = raw[c][0], y = raw[c][1], z = raw[c][2], w = raw[c][3];
+                a[c][0] = i32x4v{(int)x & M, (int)(x >> 2) & M, (int)y & M, (int)(y >> 2) & M};
+                a[c][1] = i32x4v{(int)z & M, (int)(z >> 2) & M, (int)w & M, (int)(w >> 2) & M};
+            }
+        };
+
+        #pragma unroll
+        for (int s = 0; s < D; ++s) issue(s, s);
+        i32x4v araw[CT];
+        i32x4v A[2][CT][2];
+        i32x8 B[2];
+        wait_vm_barrier<(D - 1) * L>();
+        read_dos(0, araw);
+        read_b(0, 0, B[0]);
+        expand(araw, A[0]);
+        int st = 0;
+        // one step: the MFMAs of step T with the fragments of buffer P; fills buffer P ^ 1 for step T + 1.  The last item's
+        // MFMAs are issued after the barrier, behind the first fragment read of the next step.
+#define MIH_MM(a_, b_, c_) (MODE == 1 ? fake4x(a_, b_, c_) : mfma4x<FP6>(a_, b_, c_))
+#define MIH_DMA_STEP(P, T)                                                                                         \
+        {                                                                                                          \
+            const int st_next = st + 1 == S ? 0 : st + 1, st_ld = st == 0 ? S - 1 : st - 1;                        \
+            if (MODE != 2) issue((T) + D, st_ld);                                                                  \
+            _Pragma("unroll")                                                                                      \
+            for (int i = 0; i < NI - 1; ++i) {                                                                     \
+                read_b(st, i + 1, B[(i + 1) & 1]);                                                                 \
+                _Pragma("unroll")                                                                                  \
+                for (int c = 0; c < CT; ++c) acc[c][i >> 1] = MIH_MM(A[P][c][i & 1], B[i & 1], acc[c][i >> 1]);    \
+                if (i == (NI > 2 ? NI / 2 - 1 : 0)) { wait_vm<D * L - CT>(); read_dos(st_next, araw); }            \
+                if (i == (NI > 2 ? NI / 2 : 0)) expand(araw, A[(P) ^ 1]);                                          \
+            }                                                                                                      \
+            wait_vm_barrier<(D - 1) * L>();                                                                        \
+            read_b(st_next, 0, B[0]);                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                                     \
+            _Pragma("unroll")                                                                                      \
+            for (int c = 0; c < CT; ++c) acc[c][NR - 1] = MIH_MM(A[P][c][1], B[1], acc[c][NR - 1]);                \
+            st = st_next;                                                                                          \
+        }
+        for (int t = 0; t < nb; t += 2) {
+            MIH_DMA_STEP(0, t)
+            if (t + 1 < nb) MIH_DMA_STEP(1, t + 1)
+        }
+#undef MIH_DMA_STEP
+#undef MIH_MM
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the look-ahead copies have landed, every wave is done with the ring
+    }
+    if (cg0 >= ncg) return;
+    xtv_epilogue_lds<CT, NR>(acc, reinterpret_cast<float *>(lds) + wave * (32 * 36), lane, cg0, ncg, split, splits, dm, scal, partial);
+}
+
 // Combine slices, add the missing-entry correction, centre, scale.
 __global__ void __launch_bounds__(256)
 k_xtv_finalize(const double *__restrict__ partial, int splits, int64_t pstride, int64_t p,
@@ -767,8 +1028,27 @@ static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 
         hipLaunchKernelGGL((k_xtv_mfma_lds<NRV, C, RB, 0, W, true>), dim3((unsigned)(groups * splits)), dim3(W * 64), 0, s, \
                            reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig2, dig_stride, splits, dm, scal, partial); \
         return MIH_OK; }
-    if (dm.base == 49) {           // FP6 digit planes: one launch shape per operand count (+ tuning shapes for 4)
-        const int mv6 = g_xtv_multi_variant;
+#define MIH_LDS6(NRV, ID, C, RB, W) if (nr == NRV && (mv6 == ID || ID < 0)) { \
+        int64_t groups = (h->ncg + W * C - 1) / (W * C); \
+        hipLaunchKernelGGL((k_xtv_mfma_lds<NRV, C, RB, 0, W, true>), dim3((unsigned)(groups * splits)), dim3(W * 64), 0, s, \
+                           reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig2, dig_stride, splits, dm, scal, partial); \
+        return MIH_OK; }
+#define MIH_DMA(NRV, ID, C, W, DD, F6, MODE) if (nr == NRV && (mv6 == ID || ID < 0)) { \
+        int64_t groups = (h->ncg + W * C - 1) / (W * C); \
+        hipLaunchKernelGGL((k_xtv_dma<NRV, C, W, DD, F6, MODE>), dim3((unsigned)(groups * splits)), dim3(W * 64), 0, s, \
+                           reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig2, dig_stride, splits, dm, scal, partial); \
+        return MIH_OK; }
+    const int mv6 = g_xtv_multi_variant;
+    if (dm.base == 49) {           // FP6 digit planes
+        // LDS-DMA ring kernels: tuning shapes (ids 20..), timing probes (30..: results are NOT X'R), then the defaults
+        MIH_DMA(4, 20, 4, 4, 4, true, 0) MIH_DMA(4, 21, 4, 4, 3, true, 0) MIH_DMA(4, 22, 2, 8, 4, true, 0) MIH_DMA(4, 23, 2, 8, 3, true, 0)
+        MIH_DMA(4, 24, 4, 4, 2, true, 0) MIH_DMA(4, 25, 2, 8, 2, true, 0)
+        MIH_DMA(4, 30, 4, 4, 4, true, 1) MIH_DMA(4, 31, 4, 4, 4, true, 2) MIH_DMA(4, 32, 2, 8, 4, true, 1) MIH_DMA(4, 33, 2, 8, 4, true, 2)
+        MIH_DMA(3, 20, 4, 4, 4, true, 0) MIH_DMA(3, 22, 2, 8, 4, true, 0) MIH_DMA(2, 20, 4, 4, 4, true, 0) MIH_DMA(2, 22, 2, 8, 4, true, 0)
+        MIH_DMA(1, 20, 4, 4, 4, true, 0) MIH_DMA(1, 22, 2, 8, 4, true, 0) MIH_DMA(1, 26, 1, 8, 4, true, 0) MIH_DMA(1, 27, 1, 16, 4, true, 0)
+        if (mv6 == 0 || mv6 >= 16) {      // defaults (ids 1..15 select the register-staged LDS shapes below)
+            MIH_DMA(4, -1, 4, 4, 4, true, 0) MIH_DMA(3, -1, 4, 4, 4, true, 0) MIH_DMA(2, -1, 2, 8, 4, true, 0) MIH_DMA(1, -1, 2, 8, 4, true, 0)
+        }
         MIH_LDS6(4, 1, 2, 2, 8) MIH_LDS6(4, 2, 1, 4, 8) MIH_LDS6(4, 3, 2, 2, 4) MIH_LDS6(4, 4, 2, 1, 4) MIH_LDS6(4, 5, 1, 2, 8)
         MIH_LDS6(1, 10, 1, 2, 8) MIH_LDS6(1, 11, 2, 4, 8) MIH_LDS6(1, 12, 2, 2, 8) MIH_LDS6(1, 13, 4, 2, 8) MIH_LDS6(1, 14, 1, 4, 16) MIH_LDS6(1, 15, 2, 2, 16)
         // defaults (2 operands: <2,4,1,4> 22.5 ms against 23.3-26 ms for five other shapes; 3 operands: <3,2,2,4> 33.2 ms
@@ -783,6 +1063,17 @@ static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 
         hipLaunchKernelGGL((k_xtv_mfma_lds<NRV, C, RB, MODE, W>), dim3((unsigned)(groups * splits)), dim3(W * 64), 0, s, \
                            reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig2, dig_stride, splits, dm, scal, partial); \
         return MIH_OK; }
+    // FP4 digit planes through the LDS-DMA ring (tuning shapes; the register-staged kernels stay the defaults here)
+    MIH_DMA(4, 20, 4, 4, 4, false, 0) MIH_DMA(4, 22, 2, 8, 4, false, 0) MIH_DMA(3, 20, 4, 4, 4, false, 0) MIH_DMA(2, 20, 4, 4, 4, false, 0)
+    MIH_DMA(2, 22, 2, 8, 4, false, 0)
+    if (g_xtv_variant < 0) {
+        MIH_DMA(1, 20, 1, 8, 6, false, 0) MIH_DMA(1, 21, 2, 8, 4, false, 0) MIH_DMA(1, 22, 1, 16, 6, false, 0) MIH_DMA(1, 23, 2, 4, 8, false, 0)
+        MIH_DMA(1, 24, 4, 4, 4, false, 0) MIH_DMA(1, 25, 1, 8, 3, false, 0) MIH_DMA(1, 26, 2, 8, 6, false, 0) MIH_DMA(1, 27, 1, 8, 8, false, 0)
+        MIH_DMA(1, 28, 2, 4, 12, false, 0) MIH_DMA(1, 29, 4, 4, 6, false, 0) MIH_DMA(1, 34, 2, 4, 6, false, 0) MIH_DMA(1, 35, 2, 2, 8, false, 0)
+        // library default for one FP4 operand (the single-fit pass): 17.60 ms = 88.8 % of the HBM peak against 17.85 ms for the
+        // register-staged <1,1,4> (id 9) and 17.65 - 17.9 ms for the other ring shapes (tools/sweep_dma.py single)
+        if (mv6 == 0 || mv6 >= 16) { MIH_DMA(1, -1, 2, 4, 8, false, 0) }
+    }
     if (nr == 3) { const int mv = 0; MIH_LDS(3, 0, 2, 2, 0, 8) }
     if (nr == 4 || nr == 2) {
         const int mv = g_xtv_multi_variant;
@@ -793,21 +1084,21 @@ static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 
         MIH_LDS(4, 7, 2, 2, 1, 8) MIH_LDS(4, 8, 2, 2, 2, 8)      // timing probes (results are NOT X'r)
         MIH_LDS(2, 1, 2, 2, 0, 8) MIH_LDS(2, 2, 4, 2, 0, 8) MIH_LDS(2, 3, 2, 4, 0, 8) MIH_LDS(2, 4, 4, 1, 0, 8)
         if (nr == 2 && mv == 5) { launch_xtv<4, 2, 2>(h, dig, dig_stride, splits, dm, scal, partial, s); return MIH_OK; }   // per-wave digit loads
-        if (nr == 2) { MIH_LDS(2, mv, 4, 1, 0, 4) }            // variants that only exist for 4 operands
-        set_error("unknown multi-RHS kernel variant");
-        return MIH_BAD_ARG;
+        if (nr == 2) { MIH_LDS(2, mv, 4, 1, 0, 4) }            // ids that exist for other operand counts only: the default shapes
+        { MIH_LDS(4, mv, 2, 2, 0, 8) }
     }
     if (nr == 1 && g_xtv_variant < 0) {
         // library default for one operand: digit planes shared through LDS as well (17.86 ms against 18.47 ms for
         // the per-wave-load kernels below at n=500k, p=1M; tools/sweep_single_lds.py).  An explicit
         // mih_set_xtv_variant(v >= 0) selects the per-wave kernels instead.
         const int mv = g_xtv_multi_variant;
-        MIH_LDS(1, 0, 1, 4, 0, 8)
+        MIH_LDS(1, 9, 1, 4, 0, 8)
         MIH_LDS(1, 10, 1, 2, 0, 8) MIH_LDS(1, 11, 1, 6, 0, 8) MIH_LDS(1, 12, 1, 2, 0, 16) MIH_LDS(1, 13, 2, 4, 0, 8) MIH_LDS(1, 14, 4, 2, 0, 8)
         MIH_LDS(1, 15, 1, 4, 1, 8)                        // timing probe: loads only, no MFMAs (result is NOT X'r)
         { MIH_LDS(1, mv, 1, 4, 0, 8) }                    // multi-operand variant ids fall back to the default shape
     }
 #undef MIH_LDS
+#undef MIH_DMA
 #define MIH_CASE(W, C) if (v.waves == W && v.ct == C) { launch_xtv<W, C, 1>(h, dig, dig_stride, splits, dm, scal, partial, s); return MIH_OK; }
     MIH_CASE(4, 1) MIH_CASE(4, 2) MIH_CASE(4, 4) MIH_CASE(8, 1) MIH_CASE(8, 2) MIH_CASE(2, 2) MIH_CASE(8, 4) MIH_CASE(4, 8) MIH_CASE(2, 4)
 #undef MIH_CASE
@@ -1010,7 +1301,7 @@ int mih_set_xtv_digits(int digits)
 
 int mih_set_xtv_multi_variant(int variant)
 {
-    if (variant < 0 || variant > 15) { set_error("multi-RHS variant %d out of range", variant); return MIH_BAD_ARG; }
+    if (variant < 0 || variant > 63) { set_error("multi-RHS variant %d out of range", variant); return MIH_BAD_ARG; }
     g_xtv_multi_variant = variant;
     return MIH_OK;
 }
