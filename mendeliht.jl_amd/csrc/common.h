@@ -124,6 +124,7 @@ struct DigitMode {
     int slots;       // columns per residual (ndig <= slots, per_op * slots <= 32)
     int ebits;       // the residual is scaled to max|r| * 2^e < 2^(ebits+1)
     int rows_log2;   // a row slice holds at most 2^rows_log2 rows (f32 accumulators stay exact)
+    int lay16 = 0;   // FP6 planes stored as the B fragments of the 16x16x128 MFMA (two 16-column images per 128-row block)
 };
 struct XtvWork {            // scratch for one in-flight X'r
     DevBuf<uint32_t> digits;   // ops * nblk * 64 lanes * 4 dwords (+ 2 dwords, stored behind, for FP6) : digit planes of r (B operands)

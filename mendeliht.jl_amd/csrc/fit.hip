@@ -478,6 +478,15 @@ struct IhtVar {
     }
     ~IhtVar() { if (s && own_stream) (void)hipStreamDestroy(s); }
 
+    // v.k = sparsity (cross_validation.jl:110): with groups and a scalar k the projection reads k from the device
+    int set_k(int64_t knew)
+    {
+        k = knew;
+        if (has_group && ks.empty())
+            MIH_HIP(hipMemcpyAsync(kgrp_dev.p, &k, sizeof(int64_t), hipMemcpyHostToDevice, s));     // k outlives the copy (member)
+        return MIH_OK;
+    }
+
     int ensure_stage(int64_t nnz)
     {
         if ((size_t)nnz <= sidx.n) return MIH_OK;
@@ -1294,7 +1303,7 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, con
             for (int64_t ik = 0; ik < npath; ++ik, ++combo) {
                 if (combo % world != rank) continue;
                 for (int64_t i = 0; i < n; ++i) train[i] = (folds[i] != fold);
-                v.k = path[ik];                              // cross_validation.jl:110
+                MIH_TRY(v.set_k(path[ik]));                  // cross_validation.jl:110
                 MIH_TRY(v.init(train.data()));
                 double best; int64_t it;
                 MIH_TRY(v.fit_loop(&pr, &best, &it, nullptr, nullptr, nullptr, nullptr));

@@ -176,7 +176,11 @@ k_digits(const double *__restrict__ r, int64_t n, int64_t nblk, int m, DigitMode
     __syncthreads();
     if (blk < nblk && lane < 2 * slots) {
         const int h = lane / slots, dg = lane % slots;
-        const int64_t o = ((int64_t)op * nblk + blk) * 64 + h * 32 + sub * slots + dg;
+        int64_t o = ((int64_t)op * nblk + blk) * 64 + h * 32 + sub * slots + dg;
+        if (dm.lay16) {       // image b = column / 16 of the 128-row block, lane 16 * (e + 2h) + column % 16 (k_xtv_dma16)
+            const int col = sub * slots + dg, e = (int)(blk & 1);
+            o = ((int64_t)op * nblk + (blk - e) + (col >> 4)) * 64 + 16 * (e + 2 * h) + (col & 15);
+        }
         if (!fp6) {
             uint32_t out[4] = {0u, 0u, 0u, 0u};
             #pragma unroll
@@ -766,6 +770,225 @@ k_xtv_dma(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *__
     xtv_epilogue_lds<CT, NR>(acc, reinterpret_cast<float *>(lds) + wave * (32 * 36), lane, cg0, ncg, split, splits, dm, scal, partial);
 }
 
+// The same pass on v_mfma_f32_16x16x128_f8f6f4.  Under the package power cap the chip holds a higher clock on the
+// 16x16x128 form of the instruction (half the accumulator traffic per multiply-add): the same multiply-adds, operands in
+// registers, take 16.0 ms against 20.0 ms for 32x32x64 on dosage-like x digit-like data (tools/mfma_rate.hip).  A tile
+// (32 SNPs x 128 rows) becomes two A fragments (16 SNPs each, all 128 rows: lane (r, kq) reads the 8 bytes of row group
+// (e, h) = (kq & 1, kq >> 1) of SNP r from the LDS image -- the row-group order is free as long as both operands use it),
+// an operand's digit planes two B fragments of 16 columns (DigitMode::lay16 layout written by k_digits), and the four
+// 16 x 16 products of a (tile, operand) accumulate over the whole 128-row block in one instruction each.
+typedef float f32x4a __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4a mfma16(i32x4v a, const i32x8 &b, f32x4a acc)
+{
+    i32x8 aa = {a[0], a[1], a[2], a[3], 0, 0, 0, 0};
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(aa, b, acc, 4, 2, 0, 0, 0, 0);
+}
+
+template <int CT, int NR, int SLOTS>
+__device__ __forceinline__ void xtv_epilogue16_s(const f32x4a (&acc)[CT][NR][2][2], float *buf, int lane, int64_t cg0, int64_t ncg,
+                                                 int split, int splits, DigitMode dm, const double *__restrict__ scal,
+                                                 double *__restrict__ partial)
+{
+#pragma clang fp contract(off)      // products and sums round separately, as in xtv_epilogue
+    constexpr int RS = 36;
+    const int n16 = lane & 15, rg = lane >> 4;
+    const int per_op = dm.per_op;
+    double wgt[SLOTS];
+    {
+        unsigned long long w = 16;
+        #pragma unroll
+        for (int t = 0; t < SLOTS; ++t) { wgt[t] = t < dm.ndig ? (double)w : 0.0; w *= 49u; }
+    }
+    #pragma unroll
+    for (int v = 0; v < NR; ++v) {
+        #pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            __builtin_amdgcn_wave_barrier();
+            #pragma unroll
+            for (int a = 0; a < 2; ++a)
+                #pragma unroll
+                for (int b = 0; b < 2; ++b)      // D: column 16 b + lane % 16, SNP rows 16 a + 4 (lane / 16) + (0..3)
+                    *reinterpret_cast<f32x4v *>(buf + (16 * b + n16) * RS + 16 * a + 4 * rg) =
+                        f32x4v{acc[c][v][a][b][0], acc[c][v][a][b][1], acc[c][v][a][b][2], acc[c][v][a][b][3]};
+            __builtin_amdgcn_wave_barrier();
+            #pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int o = lane + 64 * k, row = o & 31, sub = o >> 5;
+                if (sub < per_op) {
+                    const float *src = buf + sub * SLOTS * RS + row;
+                    double x[SLOTS];
+                    #pragma unroll
+                    for (int t = 0; t < SLOTS; ++t) x[t] = (double)src[t * RS] * wgt[t];
+                    double sum;
+                    if ((SLOTS & (SLOTS - 1)) == 0) {
+                        #pragma unroll
+                        for (int off = SLOTS / 2; off > 0; off >>= 1)
+                            #pragma unroll
+                            for (int t = 0; t < off; ++t) x[t] = x[t] + x[t + off];
+                        sum = x[0];
+                    } else {
+                        sum = 0.0;
+                        #pragma unroll
+                        for (int t = 0; t < SLOTS; ++t) sum += x[t];
+                    }
+                    const int rhs = v * per_op + sub;
+                    if (cg0 + c < ncg)
+                        partial[((int64_t)rhs * splits + split) * (ncg * 32) + (cg0 + c) * 32 + row] = sum * scal[4 * rhs + 1];
+                }
+            }
+        }
+    }
+}
+
+template <int NR, int CT, int WAVES, int D>
+__global__ void __launch_bounds__(WAVES * 64, 1)
+k_xtv_dma16(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *__restrict__ dig, const uint2 *__restrict__ dig2,
+            int64_t dig_stride, int splits, DigitMode dm, const double *__restrict__ scal,
+            double *__restrict__ partial /* [NR*per_op][splits][ncg*32] */)
+{
+    constexpr int S = D + 1;
+    constexpr int DOS = WAVES * CT * 1024;
+    constexpr int OPB = 3072;
+    constexpr int DGT = NR * OPB;
+    constexpr int STAGE = DOS + DGT;
+    constexpr int NP = NR * 3;
+    constexpr int PW = (NP + WAVES - 1) / WAVES;
+    constexpr int L = CT + PW;
+    constexpr int NI = 2 * NR;                      // (operand, 16-column half) items of a step
+    static_assert(S * STAGE <= 160 * 1024, "LDS ring too large");
+    static_assert(D * L <= 63, "vmcnt range");
+    static_assert(S * STAGE >= WAVES * 32 * 36 * 4, "the epilogue buffers overlay the ring");
+    __shared__ uint4 lds[S * STAGE / 16];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int split = blockIdx.x % splits;
+    const int64_t grp = blockIdx.x / splits;
+    const int64_t cg0 = (grp * WAVES + wave) * CT;
+    const int64_t bps = (nbp + splits - 1) / splits;
+    const int64_t b0 = split * bps;
+    const int64_t b1 = (b0 + bps < nbp) ? b0 + bps : nbp;
+
+    f32x4a acc[CT][NR][2][2];
+    #pragma unroll
+    for (int c = 0; c < CT; ++c)
+        #pragma unroll
+        for (int v = 0; v < NR; ++v)
+            #pragma unroll
+            for (int q = 0; q < 4; ++q)
+                #pragma unroll
+                for (int g = 0; g < 4; ++g) acc[c][v][q >> 1][q & 1][g] = 0.f;
+    {
+        const bool empty = b0 >= b1;               // see k_xtv_dma
+        const int64_t bb0 = empty ? nbp - 1 : b0;
+        const int nb = empty ? 1 : (int)(b1 - b0);
+        const int amask = empty ? 0 : -1;
+        const char *xs[CT];
+        #pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int64_t cg = cg0 + c < ncg ? cg0 + c : ncg - 1;
+            xs[c] = reinterpret_cast<const char *>(X) + (cg * nbp + bb0) * 1024;
+        }
+        const char *dsrc[PW]; int dstep[PW]; int doff[PW];
+        #pragma unroll
+        for (int u = 0; u < PW; ++u) {
+            const int jj = wave + u * WAVES, j = jj < NP ? jj : NP - 1;
+            const int op = j / 3, part = j - 3 * op;
+            if (part < 2) {
+                dsrc[u] = reinterpret_cast<const char *>(dig) + (op * dig_stride + (2 * bb0 + part) * 64) * 16;
+                dstep[u] = 2048; doff[u] = DOS + op * OPB + part * 1024;
+            } else {
+                dsrc[u] = reinterpret_cast<const char *>(dig2) + (op * dig_stride + 2 * bb0 * 64) * 8;
+                dstep[u] = 1024; doff[u] = DOS + op * OPB + 2048;
+            }
+        }
+        const uint32_t voff = lane * 16;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
+        const uint32_t mydos = wave * CT * 1024;
+        const char *ldsb = reinterpret_cast<const char *>(lds);
+        // A fragment of SNP half a: the 8 bytes of row group (e, h) = (kq & 1, kq >> 1) of SNP 16 a + lane % 16
+        const int kq = lane >> 4;
+        const uint32_t aoff = (32 * (kq >> 1) + (lane & 15)) * 16 + 8 * (kq & 1);
+
+        auto issue = [&](int ts, int st) {
+            const int tb = ts < nb ? ts : nb - 1;
+            const uint32_t base = lds0 + st * STAGE;
+            #pragma unroll
+            for (int c = 0; c < CT; ++c) glds16<true>(base + mydos + c * 1024, voff, xs[c] + (int64_t)tb * 1024);
+            #pragma unroll
+            for (int u = 0; u < PW; ++u) glds16<false>(base + doff[u], voff, dsrc[u] + (int64_t)tb * dstep[u]);
+        };
+        auto read_b = [&](int st, int item, i32x8 &b) {
+            const int v = item >> 1, e = item & 1;
+            const char *q = ldsb + st * STAGE + DOS + v * OPB;
+            const i32x4v lo = *reinterpret_cast<const i32x4v *>(q + e * 1024 + lane * 16);
+            const i32x2v hi = *reinterpret_cast<const i32x2v *>(q + 2048 + e * 512 + lane * 8);
+            b = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], 0, 0};
+        };
+        auto read_dos = [&](int st, i32x2v (&raw)[CT][2]) {
+            #pragma unroll
+            for (int c = 0; c < CT; ++c)
+                #pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    raw[c][a] = *reinterpret_cast<const i32x2v *>(ldsb + st * STAGE + mydos + c * 1024 + a * 256 + aoff);
+        };
+        auto expand = [&](const i32x2v (&raw)[CT][2], i32x4v (&a)[CT][2]) {
+            const int M = 0x33333333 & amask;
+            #pragma unroll
+            for (int c = 0; c < CT; ++c)
+                #pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const unsigned x = raw[c][h][0], y = raw[c][h][1];
+                    a[c][h] = i32x4v{(int)x & M, (int)(x >> 2) & M, (int)y & M, (int)(y >> 2) & M};
+                }
+        };
+
+        #pragma unroll
+        for (int s = 0; s < D; ++s) issue(s, s);
+        i32x2v araw[CT][2];
+        i32x4v A[2][CT][2];
+        i32x8 B[2];
+        wait_vm_barrier<(D - 1) * L>();
+        read_dos(0, araw);
+        read_b(0, 0, B[0]);
+        expand(araw, A[0]);
+        int st = 0;
+#define MIH_DMA16_ITEM(P, I, BB)                                                                                   \
+            _Pragma("unroll")                                                                                      \
+            for (int c = 0; c < CT; ++c) {                                                                         \
+                acc[c][(I) >> 1][0][(I) & 1] = mfma16(A[P][c][0], BB, acc[c][(I) >> 1][0][(I) & 1]);              \
+                acc[c][(I) >> 1][1][(I) & 1] = mfma16(A[P][c][1], BB, acc[c][(I) >> 1][1][(I) & 1]);              \
+            }
+#define MIH_DMA16_STEP(P, T)                                                                                       \
+        {                                                                                                          \
+            const int st_next = st + 1 == S ? 0 : st + 1, st_ld = st == 0 ? S - 1 : st - 1;                        \
+            issue((T) + D, st_ld);                                                                                 \
+            _Pragma("unroll")                                                                                      \
+            for (int i = 0; i < NI - 1; ++i) {                                                                     \
+                read_b(st, i + 1, B[(i + 1) & 1]);                                                                 \
+                MIH_DMA16_ITEM(P, i, B[i & 1])                                                                     \
+                if (i == (NI > 2 ? NI / 2 - 1 : 0)) { wait_vm<D * L - CT>(); read_dos(st_next, araw); }            \
+                if (i == (NI > 2 ? NI / 2 : 0)) expand(araw, A[(P) ^ 1]);                                          \
+            }                                                                                                      \
+            wait_vm_barrier<(D - 1) * L>();                                                                        \
+            read_b(st_next, 0, B[0]);                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                                     \
+            MIH_DMA16_ITEM(P, NI - 1, B[1])                                                                        \
+            st = st_next;                                                                                          \
+        }
+        for (int t = 0; t < nb; t += 2) {
+            MIH_DMA16_STEP(0, t)
+            if (t + 1 < nb) MIH_DMA16_STEP(1, t + 1)
+        }
+#undef MIH_DMA16_STEP
+#undef MIH_DMA16_ITEM
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (cg0 >= ncg) return;
+    float *buf = reinterpret_cast<float *>(lds) + wave * (32 * 36);
+    if (dm.slots == 10) xtv_epilogue16_s<CT, NR, 10>(acc, buf, lane, cg0, ncg, split, splits, dm, scal, partial);
+    else xtv_epilogue16_s<CT, NR, 8>(acc, buf, lane, cg0, ncg, split, splits, dm, scal, partial);
+}
+
 // Combine slices, add the missing-entry correction, centre, scale.
 __global__ void __launch_bounds__(256)
 k_xtv_finalize(const double *__restrict__ partial, int splits, int64_t pstride, int64_t p,
@@ -1039,6 +1262,20 @@ static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 
                            reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig2, dig_stride, splits, dm, scal, partial); \
         return MIH_OK; }
     const int mv6 = g_xtv_multi_variant;
+#define MIH_DMA16(NRV, ID, C, W, DD) if (nr == NRV && (mv6 == ID || ID < 0)) { \
+        int64_t groups = (h->ncg + W * C - 1) / (W * C); \
+        hipLaunchKernelGGL((k_xtv_dma16<NRV, C, W, DD>), dim3((unsigned)(groups * splits)), dim3(W * 64), 0, s, \
+                           reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig2, dig_stride, splits, dm, scal, partial); \
+        return MIH_OK; }
+    if (dm.base == 49 && dm.lay16) {      // FP6 planes in the 16-column layout: the 16x16x128 kernels only
+        // library defaults for every fused multi-RHS pass (12 residuals at n=500k, p=1M: 31.5 ms against 34.3 ms for the
+        // 32x32x64 ring kernel, 36.2 ms for one wave per SIMD <4,4,4,4> here -- 64 MFMAs a step are issue-bound there -- and
+        // 40.0 ms register-staged; tools/sweep_dma.py)
+        MIH_DMA16(4, 40, 4, 4, 4) MIH_DMA16(3, 40, 4, 4, 4) MIH_DMA16(2, 40, 4, 4, 4) MIH_DMA16(1, 40, 4, 4, 4)
+        MIH_DMA16(4, 42, 2, 8, 3) MIH_DMA16(4, 43, 2, 8, 2)
+        MIH_DMA16(4, -1, 2, 8, 4) MIH_DMA16(3, -1, 2, 8, 4) MIH_DMA16(2, -1, 2, 8, 4) MIH_DMA16(1, -1, 2, 8, 4)
+    }
+#undef MIH_DMA16
     if (dm.base == 49) {           // FP6 digit planes
         // LDS-DMA ring kernels: tuning shapes (ids 20..), timing probes (30..: results are NOT X'R), then the defaults
         MIH_DMA(4, 20, 4, 4, 4, true, 0) MIH_DMA(4, 21, 4, 4, 3, true, 0) MIH_DMA(4, 22, 2, 8, 4, true, 0) MIH_DMA(4, 23, 2, 8, 3, true, 0)
@@ -1046,7 +1283,7 @@ static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 
         MIH_DMA(4, 30, 4, 4, 4, true, 1) MIH_DMA(4, 31, 4, 4, 4, true, 2) MIH_DMA(4, 32, 2, 8, 4, true, 1) MIH_DMA(4, 33, 2, 8, 4, true, 2)
         MIH_DMA(3, 20, 4, 4, 4, true, 0) MIH_DMA(3, 22, 2, 8, 4, true, 0) MIH_DMA(2, 20, 4, 4, 4, true, 0) MIH_DMA(2, 22, 2, 8, 4, true, 0)
         MIH_DMA(1, 20, 4, 4, 4, true, 0) MIH_DMA(1, 22, 2, 8, 4, true, 0) MIH_DMA(1, 26, 1, 8, 4, true, 0) MIH_DMA(1, 27, 1, 16, 4, true, 0)
-        if (mv6 == 0 || mv6 >= 16) {      // defaults (ids 1..15 select the register-staged LDS shapes below)
+        if (mv6 >= 16) {      // the 32x32x64 ring shapes of other operand counts (ids 1..15 select the register-staged LDS shapes below)
             MIH_DMA(4, -1, 4, 4, 4, true, 0) MIH_DMA(3, -1, 4, 4, 4, true, 0) MIH_DMA(2, -1, 2, 8, 4, true, 0) MIH_DMA(1, -1, 2, 8, 4, true, 0)
         }
         MIH_LDS6(4, 1, 2, 2, 8) MIH_LDS6(4, 2, 1, 4, 8) MIH_LDS6(4, 3, 2, 2, 4) MIH_LDS6(4, 4, 2, 1, 4) MIH_LDS6(4, 5, 1, 2, 8)
@@ -1140,6 +1377,11 @@ static bool digit_mode(int id, DigitMode &dm)
 }
 
 static void choose_mode(const mih_mat *h, bool batched, DigitMode &dm);
+// FP6 digit planes are written in the 16-column layout when the pass runs on the 16x16x128 kernels (ids 40..)
+static bool xtv_lay16(const DigitMode &dm)
+{
+    return dm.base == 49 && g_xtv_variant < 0 && (g_xtv_multi_variant == 0 || (g_xtv_multi_variant >= 40 && g_xtv_multi_variant < 50));
+}
 
 int xtv_lockstep_width(const mih_mat *h)
 {
@@ -1215,7 +1457,8 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
     int splits = g_xtv_variant < 0 ? auto_splits(h) : v.splits;
     // exactness of the f32 accumulators: |g/2 * d/2| <= 1 (base 4) or 4 (base 13) in units of 1/4, so a row
     // slice may hold at most 2^22 / 2^20 rows
-    const DigitMode dm = w.dm;
+    DigitMode dm = w.dm;
+    dm.lay16 = xtv_lay16(dm);
     const int64_t need = (h->n_pad + (1ll << dm.rows_log2) - 1) >> dm.rows_log2;
     if (need > w.splits_cap) { set_error("n = %lld rows needs more than %d row slices for exact accumulation", (long long)h->n, w.splits_cap); return MIH_BAD_DIM; }
     if (splits < need) splits = (int)need;

@@ -400,6 +400,30 @@ def test_fit_iht_group_projection(mih, oracle):
     np.testing.assert_allclose(res.beta, o["beta"], rtol=1e-5, atol=1e-12)
 
 
+@pytest.mark.parametrize("branch", ["rolling", "debias", "init_beta"])
+def test_cv_iht_with_groups_on_both_drivers(mih, oracle, branch):
+    """cv_iht(group=...) sets v.k = sparsity per (fold, k) fit (cross_validation.jl:110) and project_group_sparse! reads that k
+    (utilities.jl:266-268): on the rolling lock-step driver every fit has its own IHTVariable; on the sequential driver
+    (debias / init_beta) ONE variable is re-used and its device copy of k must follow the path (IhtVar::set_k)."""
+    rng = np.random.default_rng(131)
+    n, p = 500, 400
+    cols = make_bed(rng, n, p)
+    x = mih.SnpLinAlg(cols, n, center=True, scale=True, impute=True)
+    ox = oracle.Mat.from_bed_columns(cols, n)
+    group = np.repeat(np.arange(1, 21), p // 20)
+    b = np.zeros(p)
+    b[(7 - 1) * 20 + rng.choice(20, 4, replace=False)] = rng.choice([-1, 1], 4) * rng.uniform(0.5, 0.9, 4)
+    y = ox.xv_masked((b != 0).astype(np.uint8), b) + 0.3 + rng.standard_normal(n)
+    folds = hash_folds(n, 3)
+    kw = {"debias": {"debias": True}, "init_beta": {"init_beta": True}, "rolling": {}}[branch]
+    path = [1, 2, 4, 6]
+    mse, raw = mih.cv_iht(y, x, None, path=path, q=3, folds=folds, group=group, verbose=False, return_raw=True, **kw)
+    omse, oraw = oracle.cv_iht(ox, y, None, path=path, q=3, folds=folds, group=group, **kw)
+    np.testing.assert_allclose(raw, oraw, rtol=1e-6)
+    np.testing.assert_allclose(mse, omse, rtol=1e-6)
+    assert len(set(np.round(mse, 9))) == len(path)          # the model size really changed from entry to entry
+
+
 def _mv_problem(oracle, ox, rng, r, k, q=1):
     p, n = ox.p, ox.n
     B = np.zeros((r, p))

@@ -9,7 +9,7 @@ import mendeliht_amd as m
 
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
 L = m.lib()
-FP6_SHAPES = [0, 20, 21, 22, 23, 24, 25]
+FP6_SHAPES = [0, 20, 22, 40, 41, 42, 43]
 FP4_SHAPES = {428: [0, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 34, 35], 1316: [20, 22]}
 
 
