@@ -1280,3 +1280,104 @@ def test_multivariate_fit_at_full_row_count(mih, oracle):
     np.testing.assert_allclose(res.beta, o["B"], rtol=1e-5, atol=1e-12)
     np.testing.assert_allclose(res.c, o["C"], rtol=1e-5, atol=1e-12)
     np.testing.assert_allclose(res.Σ, o["Sigma"], rtol=1e-8)
+
+
+# ---- BASELINE.json configs at their own sizes / trait counts ("configs_untested") -------------------------
+def test_config0_normal_bed_k9_against_g1b(mih, normal_pair, normal_data):
+    """configs[0]: fit_iht on data/normal.bed, k = 9, Normal, intercept only (README.md:104) on the GPU against the
+    G1b numbers (an independent numpy probe of the reference algorithm; tests/test_oracle_golden.py pins the
+    oracle to the same numbers)."""
+    x, ox = normal_pair
+    res = mih.fit_iht(normal_data["y"], x, None, k=9, verbose=False)
+    assert res.iter == 10
+    assert res.logl == pytest.approx(-1612.734968, abs=1e-5)
+    assert list(np.flatnonzero(res.beta) + 1) == [1266, 3137, 4246, 4717, 6290, 7629, 7755, 8375, 9415]
+    assert res.c[0] == pytest.approx(1.65222721, abs=1e-7)
+
+
+def test_config4_multivariate_r10(mih, oracle, normal_pair):
+    """configs[4]'s trait count: MvNormal with r = 10 traits (10 x 10 pivoted Cholesky step size, ten residuals in one
+    fused four-operand pass with two idle residual slots) against oracle.fit_mv, plus cv_iht with r = 10 (two fits in
+    flight per lock-step round)."""
+    x, ox = normal_pair
+    rng = np.random.default_rng(410)
+    Y, Z = _mv_problem(oracle, ox, rng, 10, 40, 2)
+    res = mih.fit_iht(Y, x, Z, k=40, verbose=False)
+    o = oracle.fit_mv(ox, Y, Z, k=40)
+    assert res.iter == o["iter"] and res.iter >= 5
+    assert np.array_equal(res.beta != 0, o["B"] != 0)
+    np.testing.assert_allclose(res.beta, o["B"], rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(res.c, o["C"], rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(res.Σ, o["Sigma"], rtol=1e-6)
+    assert res.logl == pytest.approx(o["logl"], rel=1e-9)
+    assert list(res.trace["backtracks"]) == list(o["bt_trace"])
+    assert res.beta.shape == (10, x.p) and np.count_nonzero(res.beta) <= 40
+    folds = hash_folds(ox.n, 3)
+    path = [10, 25, 40, 60]
+    mse, raw = mih.cv_iht(Y, x, Z, path=path, q=3, folds=folds, verbose=False, return_raw=True)
+    omse, oraw = oracle.cv_mv(ox, Y, Z, path=path, q=3, folds=folds)
+    np.testing.assert_allclose(raw, oraw, rtol=1e-6)
+    np.testing.assert_allclose(mse, omse, rtol=1e-6)
+
+
+def test_config4_multivariate_r10_at_full_row_count(mih, oracle):
+    """r = 10 traits, k = 500 / 20 scaled to the column count, at n = 500 000 rows against the oracle."""
+    n, p = 500_000, 256
+    x = mih.SnpLinAlg.synthetic(n, p, seed=2024)
+    ox = oracle.Mat.from_bed_columns(x.export_bed(), n)
+    rng = np.random.default_rng(15)
+    Y, Z = _mv_problem(oracle, ox, rng, 10, 25, 1)
+    res = mih.fit_iht(Y, x, Z, k=25, verbose=False)
+    o = oracle.fit_mv(ox, Y, Z, k=25)
+    assert res.iter == o["iter"] and np.array_equal(res.beta != 0, o["B"] != 0)
+    np.testing.assert_allclose(res.beta, o["B"], rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(res.c, o["C"], rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(res.Σ, o["Sigma"], rtol=1e-8)
+    assert res.logl == pytest.approx(o["logl"], rel=1e-10)
+
+
+def test_config1_dense_f64_full_size(mih):
+    """configs[1] at its own size: Matrix{Float64} 50 000 x 100 000 (40 GB synthetic, on the device).  The oracle cannot
+    hold it, so: X'r against numpy on 64 sampled columns (fetched as X e_j), linearity, bit-reproducibility, fused
+    multi-RHS bits, and one k = 100 fit whose returned model reproduces its own loglikelihood on the host."""
+    n, p, k = 50_000, 100_000, 100
+    x = mih.DenseMatrix.synthetic(n, p, seed=7)
+    rng = np.random.default_rng(71)
+    r1, r2 = rng.standard_normal(n), rng.standard_normal(n)
+    g1, g2 = x.xtv(r1), x.xtv(r2)
+    assert np.array_equal(g1, x.xtv(r1))                                   # bit-reproducible
+    both = x.xtv(np.column_stack([r1, r2]))
+    assert np.array_equal(both[:, 0], g1) and np.array_equal(both[:, 1], g2)      # fused passes: same bits
+    np.testing.assert_allclose(x.xtv(2.0 * r1 - 0.5 * r2), 2.0 * g1 - 0.5 * g2, rtol=0, atol=1e-9 * np.abs(g1).max())
+    sample = np.sort(rng.choice(p, 64, replace=False))
+    cols = np.stack([x.xv_sparse(np.array([j]), np.array([1.0])) for j in sample], axis=1)        # n x 64
+    np.testing.assert_allclose(g1[sample], cols.T @ r1, rtol=0, atol=1e-11 * np.sqrt(n))
+    supp = np.sort(rng.choice(p, k, replace=False))
+    beta = rng.choice([-1.0, 1.0], k) * rng.uniform(0.3, 1.0, k)
+    y = x.xv_sparse(supp, beta) + 1.0 + rng.standard_normal(n)
+    res = mih.fit_iht(y, x, None, k=k, verbose=False)
+    nz = np.flatnonzero(res.beta)
+    assert nz.size == k and np.array_equal(nz, supp)                        # every effect is >= 0.3 sd: full recovery
+    np.testing.assert_allclose(res.beta[nz], beta, atol=0.03)
+    assert np.all(np.diff(res.trace["logl"]) >= -1e-9 * np.abs(res.trace["logl"][:-1]))     # monotone ascent
+    resid = y - (x.xv_sparse(nz, res.beta[nz]) + res.c[0])
+    phi = resid @ resid / n
+    logl_host = -0.5 * n * (np.log(2 * np.pi * phi) + 1.0)
+    assert res.logl == pytest.approx(logl_host, rel=1e-10)
+
+
+def test_bench_workload_fewer_columns_against_oracle(mih, oracle):
+    """The bench.py workload (configs[2]: n = 500 000, k = 200, Normal) with 60 000 of its 1 000 000 columns, GPU against
+    the oracle on the same matrix (tools/validate_large.py as a test): same iterations and support, beta to 1e-12."""
+    n, p, k = 500_000, 60_000, 200
+    x = mih.SnpLinAlg.synthetic(n, p, seed=2024)
+    rng = np.random.default_rng(2025)
+    supp = np.sort(rng.choice(p, size=k, replace=False))
+    y = x.xv_sparse(supp, rng.standard_normal(k)) + 1.0 + rng.standard_normal(n)
+    res = mih.fit_iht(y, x, None, k=k, verbose=False)
+    ox = oracle.Mat.from_bed_columns(x.export_bed(), n)
+    o = oracle.fit_iht(ox, y, None, k=k)
+    assert res.iter == o["iter"] and list(res.trace["backtracks"]) == list(o["bt_trace"])
+    assert np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"]))
+    np.testing.assert_allclose(res.beta, o["beta"], rtol=0, atol=1e-12)
+    assert res.logl == pytest.approx(o["logl"], rel=1e-12)

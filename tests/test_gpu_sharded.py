@@ -11,7 +11,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT
+from conftest import GOLD, ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -57,5 +57,14 @@ def test_sharded_fit_matches_single_process(tmp_path, world):
             assert oc[name]["sharded"]["support"] == sh["support"], name
             assert oc[name]["sharded"]["beta"] == sh["beta"], name
             assert oc[name]["sharded"]["logl"] == sh["logl"], name
-    assert len(res["cases"]["normal_k7"]["sharded"]["support"]) == 7
+    # the reference's recorded run (docs/src/man/examples.md:230-267) reproduced by the column-SHARDED fit
+    g = json.load(open(os.path.join(GOLD, "golden_normal_k7.json")))
+    sh = res["cases"]["normal_k7"]["sharded"]
+    assert sh["iter"] == g["iterations"] and sh["bt"] == g["backtracks"]
+    assert [j + 1 for j in sh["support"]] == g["positions_1based"]
+    np.testing.assert_allclose(sh["logl_trace"], g["logl"], rtol=1e-11)
+    np.testing.assert_allclose(sh["tol"], g["tol"], rtol=1e-7)
+    np.testing.assert_allclose(sh["beta"], g["beta_printed"], rtol=5e-6)
+    np.testing.assert_allclose(sh["c"], g["c_printed"], rtol=5e-6)
+    assert sh["sigma_g"] == pytest.approx(g["pve"], rel=1e-9)
     assert res["cases"]["ties_choose"]["single"]["choose_fired"]
