@@ -89,6 +89,10 @@ int mih_snp_mu_sigma(const mih_mat *h, double *mu, double *sinv);
 /* Re-encode the device matrix as PLINK .bed columns (ceil(n/4) bytes each): lets a
  * synthetic matrix be handed to any other PLINK consumer. */
 int mih_snp_export_bed(const mih_mat *h, uint8_t *bed_cols_out);
+/* naive_impute(x::SnpArray, destination) -- src/utilities.jl:862-899: the PLINK columns of the matrix with every
+ * missing entry (0x01) replaced by the most frequent genotype of its SNP (ties: 0x02, then 0x03, then 0x00, the order
+ * of the reference's if / elseif chain); non-missing entries are unchanged.  The caller writes the 3-byte .bed header. */
+int mih_snp_naive_impute(const mih_mat *h, uint8_t *bed_cols_out);
 
 /* ---- genotype linear algebra ---------------------------------------------- */
 /* mul!(out, Transpose(x), r)  -- call site src/utilities.jl:133 (score!) */

@@ -1,16 +1,26 @@
 # MendelIHTHip.jl -- Julia glue a MendelIHT.jl maintainer adds to route the IHT hot path to
 # libmendeliht_hip.so (C ABI: include/mendeliht_hip.h).  NOT executed in this repository's
-# image (no Julia toolchain); kept thin so it can be checked by eye against the header.
+# image (no Julia toolchain); kept thin so it can be checked by eye against the header.  The same
+# call sequence is exercised in plain C by tests/abi_harness.c and through ctypes by the test suite.
+#
+# Every keyword of the reference's methods (src/fit.jl:64-81, src/cross_validation.jl:64-78,
+# :239-252) is either forwarded to the library or rejected with an ArgumentError: there is no
+# `kwargs...` catch-all, so a misspelt or unsupported keyword is a MethodError, never a silently
+# different model.
 #
 # Usage:
 #   using MendelIHT, SnpArrays, MendelIHTHip
 #   x   = HipSnpLinAlg{Float64}(SnpArray("normal.bed"); center=true, scale=true, impute=true)
-#   res = fit_iht(y, x, z; k=7)          # dispatches to the GPU: same IHTResult
+#   res = fit_iht(y, x, z; k=7)                          # IHTResult
 #   mse = cv_iht(y, x, z; path=1:20, q=5, folds=folds)
+#   res = fit_iht(Y, Transpose(x), Z; k=12)              # r x n traits: mIHTResult
+#   ll  = iht_run_many_models(y, x, z; path=1:20)
 module MendelIHTHip
 
 using MendelIHT, SnpArrays, Distributions, GLM, LinearAlgebra
-import MendelIHT: fit_iht, cv_iht, IHTResult
+import MendelIHT: fit_iht, cv_iht, iht_run_many_models, IHTResult, mIHTResult, maf_weights, naive_impute
+
+export HipSnpLinAlg
 
 const LIB = get(ENV, "MENDELIHT_HIP_LIB", "libmendeliht_hip.so")
 
@@ -47,13 +57,48 @@ function HipSnpLinAlg{Float64}(s::SnpArray; center::Bool=false, scale::Bool=fals
     finalizer(x -> ccall((:mih_mat_destroy, LIB), Cint, (Ptr{Cvoid},), x.handle), x)
     return x
 end
+# SnpLinAlg{Float32} has no device counterpart (the library computes in Float64; include/mendeliht_hip.h)
+HipSnpLinAlg{Float32}(s::SnpArray; kwargs...) =
+    throw(ArgumentError("HipSnpLinAlg{Float32} is not supported: use HipSnpLinAlg{Float64} (arithmetic is Float64 on the device)"))
 Base.size(x::HipSnpLinAlg) = (x.n, x.p)
+Base.getindex(x::HipSnpLinAlg, i::Int, j::Int) = error("HipSnpLinAlg lives on the GPU: scalar indexing is not available")
 
 # mul!(out, Transpose(x), r)  (call site utilities.jl:133)
 function LinearAlgebra.mul!(out::Vector{Float64}, xt::Transpose{Float64, HipSnpLinAlg{Float64}},
-                            r::Vector{Float64})
-    check(ccall((:mih_xtv, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), xt.parent.handle, r, out))
+                            r::AbstractVector{Float64})
+    rr = Vector{Float64}(r)                      # dense, contiguous copy: views / ranges are not Ptr-convertible
+    length(rr) == xt.parent.n && length(out) == xt.parent.p || throw(DimensionMismatch("mul!: sizes do not match"))
+    check(ccall((:mih_xtv, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), xt.parent.handle, rr, out))
     return out
+end
+# SnpArrays.mul!(p_by_r, Transpose(sla), n_by_r)  (call site multivariate.jl:85)
+function LinearAlgebra.mul!(out::Matrix{Float64}, xt::Transpose{Float64, HipSnpLinAlg{Float64}},
+                            R::AbstractMatrix{Float64})
+    RR = Matrix{Float64}(R)
+    size(RR, 1) == xt.parent.n && size(out) == (xt.parent.p, size(RR, 2)) || throw(DimensionMismatch("mul!: sizes do not match"))
+    check(ccall((:mih_xtv_batched, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Cint, Ptr{Float64}),
+                xt.parent.handle, RR, size(RR, 2), out))
+    return out
+end
+
+# maf_weights(x; max_weight) (utilities.jl:682-697) from the allele means the device computed at upload (mu = 2 maf')
+function maf_weights(x::HipSnpLinAlg{Float64}; max_weight::Float64=Inf)
+    mu = zeros(x.p)
+    check(ccall((:mih_snp_mu_sigma, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), x.handle, mu, C_NULL))
+    f = mu ./ 2
+    maf = min.(f, 1 .- f)
+    return clamp.(1 ./ (2 .* sqrt.(maf .* (1 .- maf))), 1.0, max_weight)
+end
+
+# naive_impute(x, destination) (utilities.jl:862-899) on the device copy of the genotypes
+function naive_impute(x::HipSnpLinAlg{Float64}, destination::String)
+    out = Matrix{UInt8}(undef, (x.n + 3) >> 2, x.p)
+    check(ccall((:mih_snp_naive_impute, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}), x.handle, out))
+    open(destination, "w") do io
+        write(io, 0x6c, 0x1b, 0x01)
+        write(io, out)
+    end
+    return nothing
 end
 
 # ---- parameter / result structs: field order = include/mendeliht_hip.h ----------------------
@@ -76,91 +121,235 @@ mutable struct MihFitResult
     beta::Ptr{Float64}; c::Ptr{Float64}; logl_trace::Ptr{Float64}; tol_trace::Ptr{Float64}
     bt_trace::Ptr{Int32}; mu::Ptr{Float64}
 end
+mutable struct MihMvResult
+    time::Float64; logl::Float64; iter::Int64; choose_fired::Int32; n_trace::Int32
+    B::Ptr{Float64}; C::Ptr{Float64}; Sigma::Ptr{Float64}; pve::Ptr{Float64}
+    logl_trace::Ptr{Float64}; tol_trace::Ptr{Float64}; bt_trace::Ptr{Int32}
+end
 
 # refuse to run against a library whose structs differ from the mirrors above (mih_abi_sizes)
 function __init__()
     sz = zeros(Int64, 4)
     check(ccall((:mih_abi_sizes, LIB), Cint, (Ptr{Int64}, Int32), sz, 4))
-    (sz[1] == sizeof(MihFitParams) && sz[2] == sizeof(MihFitResult) && sz[4] == sizeof(MihComm)) ||
-        error("MendelIHTHip.jl struct mirrors do not match $LIB: $sz")
+    (sz[1] == sizeof(MihFitParams) && sz[2] == sizeof(MihFitResult) && sz[3] == sizeof(MihMvResult) &&
+     sz[4] == sizeof(MihComm)) || error("MendelIHTHip.jl struct mirrors do not match $LIB: $sz")
 end
 
 distcode(::Normal) = Int32(0); distcode(::Bernoulli) = Int32(1)
 distcode(::Poisson) = Int32(2); distcode(::NegativeBinomial) = Int32(3)
 distcode(::Gamma) = Int32(4); distcode(::InverseGaussian) = Int32(5)
+distcode(d::Distribution) = throw(ArgumentError("distribution $(typeof(d)) is not supported by the HIP path"))
 linkcode(::IdentityLink) = Int32(0); linkcode(::LogitLink) = Int32(1); linkcode(::LogLink) = Int32(2)
 linkcode(::ProbitLink) = Int32(3); linkcode(::CloglogLink) = Int32(4); linkcode(::CauchitLink) = Int32(5)
 linkcode(::InverseLink) = Int32(6); linkcode(::InverseSquareLink) = Int32(7); linkcode(::SqrtLink) = Int32(8)
-
-# fit_iht(y, x::HipSnpLinAlg, z; ...)  -- same keywords as src/fit.jl:60-82
-function fit_iht(y::AbstractVector{Float64}, x::HipSnpLinAlg{Float64}, z::AbstractVecOrMat{Float64};
-        k::Int=10, J::Int=1, d::UnivariateDistribution=Normal(), l::Link=IdentityLink(),
-        weight::AbstractVector{Float64}=Float64[], zkeep::BitVector=trues(size(z, 2)),
-        verbose::Bool=true, tol::Float64=1e-4, max_iter::Int=200, min_iter::Int=5, max_step::Int=3,
-        kwargs...)
-    x.center || error("x is not centered! Please construct SnpLinAlg{Float64}(::SnpArray, center=true, scale=true)")
-    q = size(z, 2)
-    zk = Vector{UInt8}(zkeep)
-    beta = zeros(x.p); c = zeros(q)
-    lt = zeros(max_iter); tt = zeros(max_iter); bt = zeros(Int32, max_iter)
-    GC.@preserve zk weight beta c lt tt bt begin
-        prm = MihFitParams(k, J, distcode(d), linkcode(l), d isa NegativeBinomial ? d.r : 1.0, tol,
-            max_iter, min_iter, max_step, 0, pointer(zk),
-            isempty(weight) ? Ptr{Float64}(C_NULL) : pointer(weight), C_NULL, C_NULL, 0, C_NULL, C_NULL,
-            Int32(get(kwargs, :init_beta, false)), get(kwargs, :comm, C_NULL), Int32(get(kwargs, :debias, false)))
-        res = MihFitResult(0, 0, 0, 0, 0, 0, 0, pointer(beta), pointer(c), pointer(lt), pointer(tt),
-            pointer(bt), C_NULL)
-        check(ccall((:mih_fit_iht, LIB), Cint,
-            (Ptr{Cvoid}, Ref{MihFitParams}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{UInt8}, Ref{MihFitResult}),
-            x.handle, prm, y, z, q, C_NULL, res))
-        if verbose
-            for i in 1:res.n_trace
-                println("Iteration $i: loglikelihood = $(lt[i]), backtracks = $(bt[i]), tol = $(tt[i])")
-            end
-        end
-        return IHTResult(res.time, res.logl, res.iter, beta, c, J, k, Int[], d, res.pve)
-    end
+linkcode(l::Link) = throw(ArgumentError("link $(typeof(l)) is not supported by the HIP path"))
+function estrcode(s::Symbol)
+    s === :None && return Int32(0)
+    s === :MM && return Int32(1)
+    s === :Newton && return Int32(2)
+    throw(ArgumentError("est_r must be :None, :MM or :Newton"))
 end
 
-# cv_iht(y, x::HipSnpLinAlg, z; path, q, folds, ...)  -- src/cross_validation.jl:60-79.
+# The host arrays a parameter block points at; kept alive by GC.@preserve around every ccall.
+struct ParamKeep
+    zk::Vector{UInt8}; w::Vector{Float64}; g::Vector{Int64}; ks::Vector{Int64}
+end
+function make_params(x::HipSnpLinAlg, k, J, d, l, group, weight, zkeep, est_r, use_maf, debias, tol,
+                     max_iter, min_iter, max_step, init_beta, comm)
+    J >= 0 || throw(ArgumentError("Value of J (max number of groups) must be nonnegative!"))
+    max_iter >= 0 || throw(ArgumentError("Value of max_iter must be nonnegative!"))
+    max_step >= 0 || throw(ArgumentError("Value of max_step must be nonnegative!"))
+    tol > eps(Float64) || throw(ArgumentError("Value of global tol must exceed machine precision!"))
+    !(d isa NegativeBinomial) && est_r !== :None &&
+        error("Only negative binomial regression currently supports nuisance parameter estimation")
+    x.center || error("x is not centered! Please construct SnpLinAlg{Float64}(::SnpArray, center=true, scale=true)")
+    x.scale || @warn("x is not scaled! We highly recommend `scale=true` in `SnpLinAlg` constructor")
+    x.impute || @warn("x does not have impute flag! We highly recommend `impute=true` in `SnpLinAlg` constructor")
+    k isa Vector && isempty(group) &&
+        throw(ArgumentError("Doubly sparse projection specified (since k is a vector) but there are no group information."))
+    w = use_maf ? maf_weights(x) : Vector{Float64}(weight)          # fit.jl / initialize: use_maf overrides `weight`
+    (isempty(w) || length(w) == x.p) || throw(DimensionMismatch("weight must have one entry per SNP"))
+    g = Vector{Int64}(group)
+    (isempty(g) || length(g) == x.p) || throw(DimensionMismatch("group must have one entry per SNP"))
+    keep = ParamKeep(Vector{UInt8}(zkeep), w, g, k isa Vector ? Vector{Int64}(k) : Int64[])
+    prm = MihFitParams(k isa Vector ? 0 : k, J, distcode(d), linkcode(l), d isa NegativeBinomial ? d.r : 1.0, tol,
+        max_iter, min_iter, max_step, estrcode(est_r), pointer(keep.zk),
+        isempty(keep.w) ? Ptr{Float64}(C_NULL) : pointer(keep.w),
+        isempty(keep.g) ? Ptr{Int64}(C_NULL) : pointer(keep.g),
+        isempty(keep.ks) ? Ptr{Int64}(C_NULL) : pointer(keep.ks), length(keep.ks),
+        C_NULL, C_NULL, Int32(init_beta), comm, Int32(debias))
+    return prm, keep
+end
+
+dense_z(z::AbstractVecOrMat{Float64}) = Matrix{Float64}(reshape(z, size(z, 1), :))
+
+# fit_iht(y, x::HipSnpLinAlg, z; ...)  -- the keywords of src/fit.jl:64-81
+function fit_iht(y::AbstractVector{Float64}, x::HipSnpLinAlg{Float64}, z::AbstractVecOrMat{Float64};
+        k::Union{Int, Vector{Int}}=10, J::Int=1, d::UnivariateDistribution=Normal(), l::Link=IdentityLink(),
+        group::AbstractVector{Int}=Int[], weight::AbstractVector{Float64}=Float64[],
+        zkeep::BitVector=trues(size(z, 2)), est_r::Symbol=:None, use_maf::Bool=false, debias::Bool=false,
+        verbose::Bool=true, tol::Float64=1e-4, max_iter::Int=200, min_iter::Int=5, max_step::Int=3,
+        io::IO=stdout, init_beta::Bool=false, memory_efficient::Bool=true,
+        comm::Ptr{Cvoid}=C_NULL)                 # comm: Ptr to a MihComm for a column-sharded fit (INTEGRATION.md)
+    memory_efficient || throw(ArgumentError("the GPU path is always memory_efficient=true"))
+    yy = Vector{Float64}(y); zz = dense_z(z)
+    q = size(zz, 2)
+    (length(yy) == x.n == size(zz, 1)) || throw(DimensionMismatch("row dimension of y, x, and z ($(length(yy)), $(x.n), $(size(zz, 1))) are not equal"))
+    length(zkeep) == q || throw(DimensionMismatch("zkeep must have one entry per covariate"))
+    prm, keep = make_params(x, k, J, d, l, group, weight, zkeep, est_r, use_maf, debias, tol, max_iter, min_iter,
+                            max_step, init_beta, comm)
+    beta = zeros(x.p); c = zeros(q)
+    lt = zeros(max_iter + 1); tt = zeros(max_iter + 1); bt = zeros(Int32, max_iter + 1)
+    res = MihFitResult(0, 0, 0, 0, 0, 0, 0, pointer(beta), pointer(c), pointer(lt), pointer(tt), pointer(bt), C_NULL)
+    GC.@preserve keep yy zz beta c lt tt bt begin
+        check(ccall((:mih_fit_iht, LIB), Cint,
+            (Ptr{Cvoid}, Ref{MihFitParams}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{UInt8}, Ref{MihFitResult}),
+            x.handle, prm, yy, zz, q, C_NULL, res))
+    end
+    if verbose
+        for i in 1:res.n_trace
+            println(io, "Iteration $i: loglikelihood = $(lt[i]), backtracks = $(bt[i]), tol = $(tt[i])")
+        end
+    end
+    dd = d isa NegativeBinomial ? NegativeBinomial(res.nb_r, 0.5) : d        # the estimated r travels back in d
+    return IHTResult(res.time, res.logl, res.iter, beta, c, J, k, Vector{Int}(group), dd, res.pve)
+end
+fit_iht(y::AbstractVector{Float64}, x::HipSnpLinAlg{Float64}; kwargs...) = fit_iht(y, x, ones(length(y)); kwargs...)
+
+# fit_iht(Y, Transpose(x), Z; ...) with r x n traits  -- src/fit.jl:60-63 on mIHTVariable (src/multivariate.jl);
+# Y is r x n, Z is q x n as in the reference (wrapper.jl:80-85)
+function fit_iht(Y::AbstractMatrix{Float64}, xt::Transpose{Float64, HipSnpLinAlg{Float64}}, Z::AbstractVecOrMat{Float64};
+        k::Int=10, J::Int=1, d::Distribution=MvNormal(Float64[]), l::Link=IdentityLink(),
+        group::AbstractVector{Int}=Int[], weight::AbstractVector{Float64}=Float64[],
+        zkeep::BitVector=trues(size(Z, 1)), est_r::Symbol=:None, use_maf::Bool=false, debias::Bool=false,
+        verbose::Bool=true, tol::Float64=1e-4, max_iter::Int=200, min_iter::Int=5, max_step::Int=3,
+        io::IO=stdout, init_beta::Bool=false, memory_efficient::Bool=true)
+    x = xt.parent
+    d isa MvNormal || throw(ArgumentError("multivariate responses need d = MvNormal"))
+    (isempty(group) && isempty(weight) && !use_maf && est_r === :None && J == 1) ||
+        throw(ArgumentError("group, weight, use_maf, est_r and J are not available for multivariate IHT (as in the reference)"))
+    debias && throw(ArgumentError("debias is disabled for multivariate traits (src/multivariate.jl:569-570)"))
+    memory_efficient || throw(ArgumentError("the GPU path is always memory_efficient=true"))
+    YY = Matrix{Float64}(Y); ZZ = Matrix{Float64}(reshape(Z, :, size(Y, 2)))
+    r, n = size(YY); q = size(ZZ, 1)
+    n == x.n || throw(DimensionMismatch("Y has $n samples, x has $(x.n)"))
+    prm, keep = make_params(x, k, 1, Normal(), IdentityLink(), Int[], Float64[], zkeep, :None, false, false, tol,
+                            max_iter, min_iter, max_step, init_beta, C_NULL)
+    B = zeros(r, x.p); C = zeros(r, q); S = zeros(r, r); pve = zeros(r)
+    lt = zeros(max_iter + 1); tt = zeros(max_iter + 1); bt = zeros(Int32, max_iter + 1)
+    res = MihMvResult(0, 0, 0, 0, 0, pointer(B), pointer(C), pointer(S), pointer(pve), pointer(lt), pointer(tt), pointer(bt))
+    GC.@preserve keep YY ZZ B C S pve lt tt bt begin
+        check(ccall((:mih_fit_mv, LIB), Cint,
+            (Ptr{Cvoid}, Ref{MihFitParams}, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ptr{UInt8}, Ref{MihMvResult}),
+            x.handle, prm, YY, r, ZZ, q, C_NULL, res))
+    end
+    if verbose
+        for i in 1:res.n_trace
+            println(io, "Iteration $i: loglikelihood = $(lt[i]), backtracks = $(bt[i]), tol = $(tt[i])")
+        end
+    end
+    return mIHTResult(res.time, res.logl, res.iter, B, C, k, r, S, pve)
+end
+
+# cv_iht(y, x::HipSnpLinAlg, z; path, q, folds, ...)  -- the keywords of src/cross_validation.jl:64-78.
 # rank/world select this process's share of the (fold,k) grid; combine with one MPI/RCCL sum.
 function cv_iht(y::AbstractVector{Float64}, x::HipSnpLinAlg{Float64}, z::AbstractVecOrMat{Float64};
         d::UnivariateDistribution=Normal(), l::Link=IdentityLink(), path::AbstractVector{<:Integer}=1:20,
-        q::Int=5, folds::AbstractVector{Int}=rand(1:q, size(x, 1)), max_iter::Int=100, min_iter::Int=5,
-        rank::Int=0, world::Int=1, kwargs...)
-    nz = size(z, 2)
+        q::Int=5, est_r::Symbol=:None, group::AbstractVector{Int}=Int[], weight::AbstractVector{Float64}=Float64[],
+        zkeep::BitVector=trues(size(z, 2)), folds::AbstractVector{Int}=rand(1:q, size(x, 1)), debias::Bool=false,
+        verbose::Bool=true, max_iter::Int=100, min_iter::Int=5, init_beta::Bool=false, memory_efficient::Bool=true,
+        rank::Int=0, world::Int=1, reduce=identity)       # reduce: sums the raw loss matrix over the ranks (e.g. MPI.Allreduce)
+    memory_efficient || throw(ArgumentError("the GPU path is always memory_efficient=true"))
+    maximum(path) > x.p && error("Sparsity level in `path` cannot be larger than total number of variables")
+    yy = Vector{Float64}(y); zz = dense_z(z)
+    nz = size(zz, 2)
     f32 = Vector{Int32}(folds); pth = Vector{Int64}(path)
     raw = zeros(q * length(pth)); mse = zeros(length(pth))
-    prm = MihFitParams(1, 1, distcode(d), linkcode(l), d isa NegativeBinomial ? d.r : 1.0, 1e-4,
-        max_iter, min_iter, 3, 0, C_NULL, C_NULL, C_NULL, C_NULL, 0, C_NULL, C_NULL, Int32(0), C_NULL, Int32(get(kwargs, :debias, false)))
-    check(ccall((:mih_cv_iht, LIB), Cint,
-        (Ptr{Cvoid}, Ref{MihFitParams}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Int32}, Int32, Ptr{Int64},
-         Int64, Int32, Int32, Ptr{Float64}),
-        x.handle, prm, y, z, nz, f32, q, pth, length(pth), rank, world, raw))
-    # world > 1: raw = MPI.Allreduce(raw, +, comm)  (each rank filled only its own combinations)
+    prm, keep = make_params(x, 1, 1, d, l, group, weight, zkeep, est_r, false, debias, 1e-4, max_iter, min_iter, 3,
+                            init_beta, C_NULL)
+    GC.@preserve keep yy zz f32 pth raw begin
+        check(ccall((:mih_cv_iht, LIB), Cint,
+            (Ptr{Cvoid}, Ref{MihFitParams}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Int32}, Int32, Ptr{Int64},
+             Int64, Int32, Int32, Ptr{Float64}),
+            x.handle, prm, yy, zz, nz, f32, q, pth, length(pth), rank, world, raw))
+    end
+    raw = reduce(raw)                            # world > 1: each rank filled only its own combinations
     check(ccall((:mih_cv_meanloss, LIB), Cint, (Ptr{Float64}, Ptr{Int32}, Int64, Int32, Int64, Ptr{Float64}),
-        raw, f32, length(folds), q, length(pth), mse))
+        raw, f32, length(f32), q, length(pth), mse))
+    verbose && println("Best k = $(pth[argmin(mse)])")
+    return mse
+end
+
+# multivariate cv_iht(Y, Transpose(x), Z; ...)
+function cv_iht(Y::AbstractMatrix{Float64}, xt::Transpose{Float64, HipSnpLinAlg{Float64}}, Z::AbstractVecOrMat{Float64};
+        d::Distribution=MvNormal(Float64[]), l::Link=IdentityLink(), path::AbstractVector{<:Integer}=1:20, q::Int=5,
+        zkeep::BitVector=trues(size(Z, 1)), folds::AbstractVector{Int}=rand(1:q, size(Y, 2)), verbose::Bool=true,
+        max_iter::Int=100, min_iter::Int=5, init_beta::Bool=false, rank::Int=0, world::Int=1, reduce=identity)
+    x = xt.parent
+    YY = Matrix{Float64}(Y); ZZ = Matrix{Float64}(reshape(Z, :, size(Y, 2)))
+    r = size(YY, 1); nz = size(ZZ, 1)
+    f32 = Vector{Int32}(folds); pth = Vector{Int64}(path)
+    raw = zeros(q * length(pth)); mse = zeros(length(pth))
+    prm, keep = make_params(x, 1, 1, Normal(), IdentityLink(), Int[], Float64[], zkeep, :None, false, false, 1e-4,
+                            max_iter, min_iter, 3, init_beta, C_NULL)
+    GC.@preserve keep YY ZZ f32 pth raw begin
+        check(ccall((:mih_cv_mv, LIB), Cint,
+            (Ptr{Cvoid}, Ref{MihFitParams}, Ptr{Float64}, Int64, Ptr{Float64}, Int64, Ptr{Int32}, Int32, Ptr{Int64},
+             Int64, Int32, Int32, Ptr{Float64}),
+            x.handle, prm, YY, r, ZZ, nz, f32, q, pth, length(pth), rank, world, raw))
+    end
+    raw = reduce(raw)
+    check(ccall((:mih_cv_meanloss, LIB), Cint, (Ptr{Float64}, Ptr{Int32}, Int64, Int32, Int64, Ptr{Float64}),
+        raw, f32, length(f32), q, length(pth), mse))
     return mse
 end
 
 # cv_iht over several GPUs from this one process: xs[g] is a replica of the matrix on GPU g-1
 function cv_iht(y::AbstractVector{Float64}, xs::Vector{HipSnpLinAlg{Float64}}, z::AbstractVecOrMat{Float64};
         d::UnivariateDistribution=Normal(), l::Link=IdentityLink(), path::AbstractVector{<:Integer}=1:20,
-        q::Int=5, folds::AbstractVector{Int}=rand(1:q, size(xs[1], 1)), max_iter::Int=100, min_iter::Int=5, kwargs...)
-    nz = size(z, 2)
+        q::Int=5, est_r::Symbol=:None, group::AbstractVector{Int}=Int[], weight::AbstractVector{Float64}=Float64[],
+        zkeep::BitVector=trues(size(z, 2)), folds::AbstractVector{Int}=rand(1:q, size(xs[1], 1)), debias::Bool=false,
+        verbose::Bool=true, max_iter::Int=100, min_iter::Int=5, init_beta::Bool=false)
+    yy = Vector{Float64}(y); zz = dense_z(z)
+    nz = size(zz, 2)
     f32 = Vector{Int32}(folds); pth = Vector{Int64}(path)
     raw = zeros(q * length(pth)); mse = zeros(length(pth))
     hs = [x.handle for x in xs]
-    prm = MihFitParams(1, 1, distcode(d), linkcode(l), d isa NegativeBinomial ? d.r : 1.0, 1e-4,
-        max_iter, min_iter, 3, 0, C_NULL, C_NULL, C_NULL, C_NULL, 0, C_NULL, C_NULL, Int32(0), C_NULL,
-        Int32(get(kwargs, :debias, false)))
-    GC.@preserve xs check(ccall((:mih_cv_iht_multi, LIB), Cint,
-        (Ptr{Ptr{Cvoid}}, Int32, Ref{MihFitParams}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Int32}, Int32, Ptr{Int64},
-         Int64, Ptr{Float64}),
-        hs, length(hs), prm, y, z, nz, f32, q, pth, length(pth), raw))
+    prm, keep = make_params(xs[1], 1, 1, d, l, group, weight, zkeep, est_r, false, debias, 1e-4, max_iter, min_iter, 3,
+                            init_beta, C_NULL)
+    GC.@preserve keep xs hs yy zz f32 pth raw begin
+        check(ccall((:mih_cv_iht_multi, LIB), Cint,
+            (Ptr{Ptr{Cvoid}}, Int32, Ref{MihFitParams}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Int32}, Int32, Ptr{Int64},
+             Int64, Ptr{Float64}),
+            hs, length(hs), prm, yy, zz, nz, f32, q, pth, length(pth), raw))
+    end
     check(ccall((:mih_cv_meanloss, LIB), Cint, (Ptr{Float64}, Ptr{Int32}, Int64, Int32, Int64, Ptr{Float64}),
-        raw, f32, length(folds), q, length(pth), mse))
+        raw, f32, length(f32), q, length(pth), mse))
     return mse
+end
+
+# iht_run_many_models(y, x, z; path, ...)  -- the keywords of src/cross_validation.jl:239-252; the model sizes advance in
+# lock-step through the same fused passes as the cross-validation fits (mih_fit_iht_path)
+function iht_run_many_models(y::AbstractVector{Float64}, x::HipSnpLinAlg{Float64}, z::AbstractVecOrMat{Float64};
+        d::UnivariateDistribution=Normal(), l::Link=canonicallink(d), path::AbstractVector{Int}=1:20,
+        est_r::Symbol=:None, group::AbstractVector{Int}=Int[], weight::AbstractVector{Float64}=Float64[],
+        use_maf::Bool=false, debias::Bool=false, verbose::Bool=true, parallel::Bool=false, max_iter::Int=100,
+        rank::Int=0, world::Int=1, reduce=identity)
+    parallel && @warn("parallel=true is ignored: the model sizes already run concurrently on the GPU")
+    yy = Vector{Float64}(y); zz = dense_z(z)
+    q = size(zz, 2)
+    pth = Vector{Int64}(path)
+    logl = zeros(length(pth))
+    prm, keep = make_params(x, 1, 1, d, l, group, weight, trues(q), est_r, use_maf, debias, 1e-4, max_iter, 5, 3, false, C_NULL)
+    GC.@preserve keep yy zz pth logl begin
+        check(ccall((:mih_fit_iht_path, LIB), Cint,
+            (Ptr{Cvoid}, Ref{MihFitParams}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Int64}, Int64, Int32, Int32,
+             Ptr{Float64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}),
+            x.handle, prm, yy, zz, q, pth, length(pth), rank, world, logl, C_NULL, C_NULL, C_NULL))
+    end
+    logl = reduce(logl)
+    verbose && MendelIHT.print_a_bunch_of_path_results(logl, path)
+    return logl
 end
 
 end # module

@@ -14,7 +14,7 @@ from .api import (  # noqa: F401
     Normal, Poisson, SnpLinAlg, DenseMatrix, cross_validate, cv_iht, device_count, fit_iht, iht,
     library_path, mIHTResult, project_group_sparse, project_k, read_bed, standardize, lib, IHTSession,
     profile_enable, profile_read, iht_run_many_models, set_xtv_digits, Gamma, InverseGaussian, ProbitLink,
-    CloglogLink, CauchitLink, InverseLink, InverseSquareLink, SqrtLink, canonicallink, maf_weights, simulate_random_snparray, simulate_random_response,
+    CloglogLink, CauchitLink, InverseLink, InverseSquareLink, SqrtLink, canonicallink, maf_weights, simulate_random_snparray, simulate_random_response, naive_impute,
 )
 from . import dist  # noqa: F401
 
@@ -23,5 +23,5 @@ __all__ = [
     "DenseMatrix", "IHTResult", "mIHTResult", "Normal", "Bernoulli", "Poisson", "NegativeBinomial",
     "MvNormal", "Gamma", "InverseGaussian", "IdentityLink", "LogitLink", "LogLink", "ProbitLink", "CloglogLink",
     "CauchitLink", "InverseLink", "InverseSquareLink", "SqrtLink", "canonicallink", "maf_weights", "simulate_random_snparray", "simulate_random_response", "read_bed", "standardize", "device_count",
-    "library_path", "MendelIHTError", "lib", "dist", "iht_run_many_models", "IHTSession",
+    "library_path", "MendelIHTError", "lib", "dist", "iht_run_many_models", "IHTSession", "naive_impute",
 ]

@@ -102,6 +102,7 @@ def lib():
         "mih_mat_dims": [vp, C.POINTER(i64), C.POINTER(i64)],
         "mih_snp_mu_sigma": [vp, vp, vp],
         "mih_snp_export_bed": [vp, vp],
+        "mih_snp_naive_impute": [vp, vp],
         "mih_xtv": [vp, vp, vp],
         "mih_xtv_batched": [vp, vp, C.c_int, vp],
         "mih_xv_sparse": [vp, vp, vp, i64, vp],
@@ -141,7 +142,7 @@ def exported_symbols():
     return ["mih_device_count", "mih_last_error", "mih_version", "mih_snp_create", "mih_snp_create_synthetic",
             "mih_snp_create_synthetic_shard",
             "mih_dense_create", "mih_dense_create_synthetic", "mih_dense_create_f32", "mih_mat_destroy", "mih_mat_dims",
-            "mih_snp_mu_sigma", "mih_snp_export_bed", "mih_xtv", "mih_xtv_batched", "mih_xv_sparse",
+            "mih_snp_mu_sigma", "mih_snp_export_bed", "mih_snp_naive_impute", "mih_xtv", "mih_xtv_batched", "mih_xv_sparse",
             "mih_project_topk", "mih_project_group_sparse", "mih_fit_iht", "mih_cv_iht", "mih_cv_meanloss", "mih_cv_iht_multi", "mih_fit_iht_path",
             "mih_fit_mv", "mih_cv_mv", "mih_bench_xtv", "mih_bench_xtv_batched", "mih_xtv_algorithmic_bytes", "mih_set_xtv_variant",
             "mih_set_xtv_multi_variant", "mih_set_xtv_digits", "mih_abi_sizes",
@@ -380,6 +381,27 @@ class SnpLinAlg(_Mat):
         out = np.empty((self.p, (self.n + 3) // 4), dtype=np.uint8)
         _check(lib().mih_snp_export_bed(self._h, _p(out)))
         return out
+
+
+def naive_impute(x, destination, n=None):
+    """naive_impute(x::SnpArray, destination) -- src/utilities.jl:862-899: writes `destination` (.bed) with every missing
+    genotype of `x` replaced by the mode of its SNP.  `x` is a PLINK .bed path or the (p, ceil(n/4)) column bytes (then
+    `n` is required), or a SnpLinAlg already on the GPU."""
+    if isinstance(x, SnpLinAlg):
+        mat = x
+    else:
+        if n is None:
+            raise ArgumentError("naive_impute needs the number of samples n with a .bed path or raw columns")
+        cols = read_bed(x, n) if isinstance(x, (str, os.PathLike)) else x
+        mat = SnpLinAlg(cols, n)
+    out = np.empty((mat.p, (mat.n + 3) // 4), dtype=np.uint8)
+    _check(lib().mih_snp_naive_impute(mat._h, _p(out)))
+    if not str(destination).endswith(".bed"):
+        destination = str(destination) + ".bed"
+    with open(destination, "wb") as f:
+        f.write(b"\x6c\x1b\x01")
+        f.write(out.tobytes())
+    return None
 
 
 class DenseMatrix(_Mat):

@@ -283,6 +283,35 @@ __global__ void k_export_missing(uint32_t *__restrict__ out, int64_t ndw, int64_
     }
 }
 
+// naive_impute (src/utilities.jl:862-899): the missing entries of a column get the column's most frequent genotype; on a
+// tie the reference's if / elseif chain prefers the heterozygote (0x02), then the 0x03 homozygote, then 0x00.
+// One wave per column over the exported PLINK codes (missing still 00 here; rows >= n are 00 padding).
+__global__ void __launch_bounds__(64)
+k_impute_mode(uint32_t *__restrict__ out, int64_t ndw, int64_t p, int64_t n,
+              const int64_t *__restrict__ miss_ptr, const int32_t *__restrict__ miss_row)
+{
+    const int64_t j = blockIdx.x;
+    if (j >= p) return;
+    const int64_t a = miss_ptr[j], b = miss_ptr[j + 1];
+    if (b == a) return;
+    long long c1 = 0, c2 = 0;
+    for (int64_t t = threadIdx.x; t < ndw; t += 64) {
+        const uint32_t d = out[j * ndw + t], hi = (d >> 1) & 0x55555555u, lo = d & 0x55555555u;
+        c1 += __popc(hi & ~lo);                          // 10: one copy
+        c2 += __popc(hi & lo);                           // 11: two copies
+    }
+    #pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { c1 += __shfl_xor(c1, off, 64); c2 += __shfl_xor(c2, off, 64); }
+    const long long c0 = n - (b - a) - c1 - c2;
+    const long long most = c0 > c1 ? (c0 > c2 ? c0 : c2) : (c1 > c2 ? c1 : c2);
+    const uint32_t code = most == c1 ? 2u : most == c2 ? 3u : 0u;
+    if (code == 0u) return;
+    for (int64_t t = a + threadIdx.x; t < b; t += 64) {
+        const int32_t i = miss_row[t];
+        atomicOr(&out[j * ndw + (i >> 4)], code << (2 * (i & 15)));
+    }
+}
+
 static int finish_missing_ptr(mih_mat *h, const std::vector<int32_t> &cnt, std::vector<int64_t> &ptr)
 {
     ptr.assign((size_t)h->p + 1, 0);
@@ -563,7 +592,10 @@ int mih_snp_mu_sigma(const mih_mat *h, double *mu, double *sinv)
     return MIH_OK;
 }
 
-int mih_snp_export_bed(const mih_mat *h, uint8_t *bed_cols_out)
+static int export_codes(const mih_mat *h, uint8_t *bed_cols_out, bool impute_mode);
+int mih_snp_export_bed(const mih_mat *h, uint8_t *bed_cols_out) { return export_codes(h, bed_cols_out, false); }
+int mih_snp_naive_impute(const mih_mat *h, uint8_t *bed_cols_out) { return export_codes(h, bed_cols_out, true); }
+static int export_codes(const mih_mat *h, uint8_t *bed_cols_out, bool impute_mode)
 {
     if (!h || h->kind != 0 || !bed_cols_out) return MIH_BAD_ARG;
     MIH_HIP(hipSetDevice(h->device));
@@ -571,7 +603,9 @@ int mih_snp_export_bed(const mih_mat *h, uint8_t *bed_cols_out)
     int64_t ndw = h->n_pad / 16;
     MIH_TRY(tmp.alloc((size_t)h->p * (size_t)ndw));
     hipLaunchKernelGGL(k_export, dim3(4096), dim3(256), 0, h->stream, reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, h->p, ndw, tmp.p);
-    if (h->total_missing > 0)
+    if (h->total_missing > 0 && impute_mode)
+        hipLaunchKernelGGL(k_impute_mode, dim3((unsigned)h->p), dim3(64), 0, h->stream, tmp.p, ndw, h->p, h->n, h->miss_ptr, h->miss_row);
+    else if (h->total_missing > 0)
         hipLaunchKernelGGL(k_export_missing, dim3((unsigned)h->p), dim3(64), 0, h->stream, tmp.p, ndw, h->p, h->miss_ptr, h->miss_row);
     MIH_HIP(hipStreamSynchronize(h->stream));
     size_t width = (size_t)((h->n + 3) / 4);

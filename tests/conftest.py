@@ -16,6 +16,27 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """gpu-marked tests are skipped (not failed) on a box without a device or without the built library, so a plain
+    `pytest` is green on CPU; `-m gpu` on a GPU box runs them.  The CPU oracle / ABI tests stay unconditional."""
+    if not any("gpu" in it.keywords for it in items):
+        return
+    reason = None
+    try:
+        import mendeliht_amd
+        if not os.path.exists(mendeliht_amd.library_path()):
+            reason = "libmendeliht_hip.so has not been built (python -c 'import __graft_entry__ as g; g.build()')"
+        elif mendeliht_amd.device_count() < 1:
+            reason = "no GPU: the HIP path has no CPU fallback"
+    except Exception as e:                      # library present but unloadable, etc.
+        reason = f"HIP library unavailable: {e}"
+    if reason:
+        skip = pytest.mark.skip(reason=reason)
+        for it in items:
+            if "gpu" in it.keywords:
+                it.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as O

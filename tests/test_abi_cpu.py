@@ -63,3 +63,31 @@ def test_fold_sharding_covers_every_combination(mih):
     for world in (1, 2, 3, 8):
         seen = sorted(i for r in range(world) for i in D.shard_combinations(q, npath, r, world))
         assert seen == list(range(q * npath))
+
+
+def _build_harness(tmp_path):
+    """tests/abi_harness.c compiled as plain C against include/mendeliht_hip.h (the symbol list is generated from the
+    header's declarations, so the harness resolves exactly what the header promises)."""
+    import subprocess
+    header = open(os.path.join(ROOT, "include", "mendeliht_hip.h")).read()
+    declared = sorted(set(re.findall(r"^int\s+(mih_\w+)\s*\(", header, flags=re.M)))
+    (tmp_path / "abi_symbols.inc").write_text(",\n".join(f'"{s}"' for s in declared) + "\n")
+    exe = tmp_path / "abi_harness"
+    # the header alone must be strictly conforming C99; the harness itself converts dlsym's void* to function
+    # pointers (POSIX, not ISO C), so it is built without -pedantic
+    (tmp_path / "hdr_only.c").write_text('#include "mendeliht_hip.h"\nint main(void) { return (int)sizeof(mih_fit_params) == 0; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
+                           str(tmp_path / "hdr_only.c")])
+    subprocess.check_call(["gcc", "-std=gnu99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", str(tmp_path),
+                           os.path.join(ROOT, "tests", "abi_harness.c"), "-o", str(exe), "-ldl", "-lm"])
+    return exe
+
+
+def test_c_harness_compiles_and_resolves_every_symbol(mih, tmp_path):
+    """The header is consumable C (gcc -std=c99 -pedantic -Werror) and the library, dlopen'ed from plain C, exports every
+    declared entry point with struct sizes equal to the C compiler's."""
+    import subprocess
+    exe = _build_harness(tmp_path)
+    r = subprocess.run([str(exe), mih.library_path(), os.path.join(ROOT, "tests", "fixtures"), "symbols-only"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "entry points resolved" in r.stdout

@@ -1381,3 +1381,53 @@ def test_bench_workload_fewer_columns_against_oracle(mih, oracle):
     assert np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"]))
     np.testing.assert_allclose(res.beta, o["beta"], rtol=0, atol=1e-12)
     assert res.logl == pytest.approx(o["logl"], rel=1e-12)
+
+
+def test_naive_impute(mih, tmp_path):
+    """naive_impute (src/utilities.jl:862-899): missing entries -> the SNP's most frequent genotype, ties resolved in the
+    order of the reference's if / elseif chain (0x02, then 0x03, then 0x00); every other entry and the file header are
+    unchanged.  Bit-exact against a direct numpy statement of that loop."""
+    rng = np.random.default_rng(862)
+    n, p = 1003, 257
+    cols = make_bed(rng, n, p, missing_rate=0.07)
+    code = np.stack([(cols[:, i // 4] >> (2 * (i % 4))) & 3 for i in range(n)], axis=1)          # p x n PLINK codes
+    # force ties: column 5 gets equal 0x00 and 0x02 counts, column 6 equal 0x02 and 0x03, column 7 equal 0x00 and 0x03
+    for j, (a, b) in ((5, (0, 2)), (6, (2, 3)), (7, (0, 3))):
+        code[j, :] = 1
+        code[j, 0:300] = a
+        code[j, 300:600] = b
+        code[j, 600:650] = ({0, 2, 3} - {a, b}).pop()
+    padded = np.zeros((p, ((n + 3) // 4) * 4), dtype=np.uint8)
+    padded[:, :n] = code
+    cols = (padded[:, 0::4] | (padded[:, 1::4] << 2) | (padded[:, 2::4] << 4) | (padded[:, 3::4] << 6)).astype(np.uint8)
+    want = code.copy()
+    for j in range(p):
+        e0, e1, e2 = (code[j] == 0).sum(), (code[j] == 2).sum(), (code[j] == 3).sum()
+        most = max(e0, e1, e2)
+        fill = 2 if most == e1 else 3 if most == e2 else 0
+        want[j, code[j] == 1] = fill
+    assert want[5, 700] == 2 and want[6, 700] == 2 and want[7, 700] == 3                       # the tie rules fired
+    dest = tmp_path / "imputed.bed"
+    mih.naive_impute(cols, str(dest), n=n)
+    raw = np.fromfile(dest, dtype=np.uint8)
+    assert bytes(raw[:3]) == b"\x6c\x1b\x01" and raw.size == 3 + p * ((n + 3) // 4)
+    got = raw[3:].reshape(p, -1)
+    gcode = np.stack([(got[:, i // 4] >> (2 * (i % 4))) & 3 for i in range(n)], axis=1)
+    assert np.array_equal(gcode, want)
+    assert not np.any(gcode == 1)
+    if n % 4:                                                                                   # padding bits of the last byte stay 0
+        assert np.all(got[:, -1] >> (2 * (n % 4)) == 0)
+    # a SnpLinAlg built from the imputed file has no missing entries and the same non-missing genotypes
+    x2 = mih.SnpLinAlg(mih.read_bed(str(dest), n), n)
+    assert np.array_equal(x2.export_bed(), got)
+
+
+def test_c_abi_harness_reproduces_the_recorded_run(mih, tmp_path):
+    """tests/abi_harness.c (plain C, dlopen, no ctypes mirrors) runs the reference's recorded fit (G1) and a small
+    cross-validation through mih_snp_create / mih_fit_iht / mih_cv_iht -- the calls a Julia ccall binding makes."""
+    import subprocess
+    from test_abi_cpu import _build_harness
+    exe = _build_harness(tmp_path)
+    r = subprocess.run([str(exe), mih.library_path(), FIX], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "PASS" in r.stdout and "5 iterations" in r.stdout
