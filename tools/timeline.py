@@ -3,7 +3,7 @@ usage: timeline.py <kernel_trace.csv> [which interval, default: the shortest]"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-ix = [i for i, r in enumerate(rows) if "k_xtv_mfma" in r["Kernel_Name"]]
+ix = [i for i, r in enumerate(rows) if "k_xtv_mfma" in r["Kernel_Name"] or "k_xtv_dma" in r["Kernel_Name"]]
 spans = [(int(rows[b]["Start_Timestamp"]) - int(rows[a]["End_Timestamp"]), a, b) for a, b in zip(ix[:-1], ix[1:])]
 spans.sort()
 span, a, b = spans[int(sys.argv[2])] if len(sys.argv) > 2 else spans[0]
