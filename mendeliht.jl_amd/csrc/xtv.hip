@@ -840,7 +840,7 @@ __device__ __forceinline__ void xtv_epilogue16_s(const f32x4a (&acc)[CT][NR][2][
     }
 }
 
-template <int NR, int CT, int WAVES, int D>
+template <int NR, int CT, int WAVES, int D, int MODE = 0>       // MODE 3: timing probe, the odd 16-column fragments are skipped (result is NOT X'R)
 __global__ void __launch_bounds__(WAVES * 64, 1)
 k_xtv_dma16(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *__restrict__ dig, const uint2 *__restrict__ dig2,
             int64_t dig_stride, int splits, DigitMode dm, const double *__restrict__ scal,
@@ -954,7 +954,7 @@ k_xtv_dma16(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *
         int st = 0;
 #define MIH_DMA16_ITEM(P, I, BB)                                                                                   \
             _Pragma("unroll")                                                                                      \
-            for (int c = 0; c < CT; ++c) {                                                                         \
+            for (int c = 0; c < CT && !(MODE == 3 && ((I) & 1)); ++c) {                                            \
                 acc[c][(I) >> 1][0][(I) & 1] = mfma16(A[P][c][0], BB, acc[c][(I) >> 1][0][(I) & 1]);              \
                 acc[c][(I) >> 1][1][(I) & 1] = mfma16(A[P][c][1], BB, acc[c][(I) >> 1][1][(I) & 1]);              \
             }
@@ -964,7 +964,7 @@ k_xtv_dma16(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *
             issue((T) + D, st_ld);                                                                                 \
             _Pragma("unroll")                                                                                      \
             for (int i = 0; i < NI - 1; ++i) {                                                                     \
-                read_b(st, i + 1, B[(i + 1) & 1]);                                                                 \
+                if (!(MODE == 3 && ((i + 1) & 1))) read_b(st, i + 1, B[(i + 1) & 1]);                              \
                 MIH_DMA16_ITEM(P, i, B[i & 1])                                                                     \
                 if (i == (NI > 2 ? NI / 2 - 1 : 0)) { wait_vm<D * L - CT>(); read_dos(st_next, araw); }            \
                 if (i == (NI > 2 ? NI / 2 : 0)) expand(araw, A[(P) ^ 1]);                                          \
@@ -1262,9 +1262,10 @@ static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 
                            reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig2, dig_stride, splits, dm, scal, partial); \
         return MIH_OK; }
     const int mv6 = g_xtv_multi_variant;
-#define MIH_DMA16(NRV, ID, C, W, DD) if (nr == NRV && (mv6 == ID || ID < 0)) { \
+#define MIH_DMA16(NRV, ID, C, W, DD) MIH_DMA16M(NRV, ID, C, W, DD, 0)
+#define MIH_DMA16M(NRV, ID, C, W, DD, MODE) if (nr == NRV && (mv6 == ID || ID < 0)) { \
         int64_t groups = (h->ncg + W * C - 1) / (W * C); \
-        hipLaunchKernelGGL((k_xtv_dma16<NRV, C, W, DD>), dim3((unsigned)(groups * splits)), dim3(W * 64), 0, s, \
+        hipLaunchKernelGGL((k_xtv_dma16<NRV, C, W, DD, MODE>), dim3((unsigned)(groups * splits)), dim3(W * 64), 0, s, \
                            reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig2, dig_stride, splits, dm, scal, partial); \
         return MIH_OK; }
     if (dm.base == 49 && dm.lay16) {      // FP6 planes in the 16-column layout: the 16x16x128 kernels only
@@ -1273,9 +1274,12 @@ static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 
         // 40.0 ms register-staged; tools/sweep_dma.py)
         MIH_DMA16(4, 40, 4, 4, 4) MIH_DMA16(3, 40, 4, 4, 4) MIH_DMA16(2, 40, 4, 4, 4) MIH_DMA16(1, 40, 4, 4, 4)
         MIH_DMA16(4, 42, 2, 8, 3) MIH_DMA16(4, 43, 2, 8, 2)
+        MIH_DMA16M(1, 49, 2, 8, 4, 3) MIH_DMA16M(4, 49, 2, 8, 4, 3)       // timing probes
+        MIH_DMA16(1, 44, 2, 4, 8) MIH_DMA16(1, 45, 1, 8, 6) MIH_DMA16(1, 46, 2, 4, 6) MIH_DMA16(1, 47, 4, 4, 4) MIH_DMA16(1, 48, 2, 8, 6)
         MIH_DMA16(4, -1, 2, 8, 4) MIH_DMA16(3, -1, 2, 8, 4) MIH_DMA16(2, -1, 2, 8, 4) MIH_DMA16(1, -1, 2, 8, 4)
     }
 #undef MIH_DMA16
+#undef MIH_DMA16M
     if (dm.base == 49) {           // FP6 digit planes
         // LDS-DMA ring kernels: tuning shapes (ids 20..), timing probes (30..: results are NOT X'R), then the defaults
         MIH_DMA(4, 20, 4, 4, 4, true, 0) MIH_DMA(4, 21, 4, 4, 3, true, 0) MIH_DMA(4, 22, 2, 8, 4, true, 0) MIH_DMA(4, 23, 2, 8, 3, true, 0)
