@@ -1138,6 +1138,8 @@ int mih_fit_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, co
 // converges on its own; a fit that finishes is scored on its held-out samples and its slot is refilled.
 struct CvFit {
     std::unique_ptr<IhtVar> v;
+    std::vector<std::unique_ptr<IhtVar>> *pool = nullptr;   // the lane's free list: a finished fit hands its IHTVariable back
+    void release() { if (v && pool) pool->push_back(std::move(v)); v.reset(); }
     std::vector<uint8_t> train;
     int64_t out_index = 0;
     int iter = 1, nbt = 0;
@@ -1174,7 +1176,7 @@ static int cv_finish(CvFit &f, double *mses_raw)
         }
         if (f.c_out) for (int l = 0; l < f.v->q; ++l) f.c_out[l] = f.v->best_c[l];
         f.done = true;
-        f.v.reset();
+        f.release();
         return MIH_OK;
     }
     MIH_TRY(f.v->set_weights(f.train.data(), 1));     // cv_wts <- test mask (cross_validation.jl:115-116)
@@ -1183,7 +1185,7 @@ static int cv_finish(CvFit &f, double *mses_raw)
     MIH_TRY(f.v->mu_loglik(1, nullptr, &dev));
     mses_raw[f.out_index] = dev;
     f.done = true;
-    f.v.reset();                                       // release the fit's device buffers
+    f.release();                                       // the IHTVariable (device buffers, column cache) goes back to the lane's pool
     return MIH_OK;
 }
 
@@ -1192,12 +1194,16 @@ static int cv_finish(CvFit &f, double *mses_raw)
 // score that ends its step (step_pre / step_post) -- so ONE fused pass serves all of them, and the slot of a fit
 // that finished is refilled from the queue in the next round: the passes stay full until the queue is empty.
 // make(i, f) sets up fit number i (its IhtVar, training mask, output slots).
+// The lane keeps the IHTVariables of finished fits and hands them to the fits it starts next (the reference re-uses one
+// IHTVariable per thread the same way, cross_validation.jl:91,110): ~25 hipMalloc / hipFree per fit otherwise, and every
+// hipFree waits for the OTHER lane's fused pass to finish.
 using MakeFit = std::function<int(size_t, CvFit &, hipStream_t)>;
 
 static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t total, std::atomic<size_t> &next, int cap,
                           const MakeFit &make, XtvWork &xw, DevBuf<double> &R,
                           DevBuf<double> &DF, hipStream_t s, double *mses_raw)
 {
+    std::vector<std::unique_ptr<IhtVar>> pool;            // declared before the slots: outlives them
     std::vector<std::unique_ptr<CvFit>> slot((size_t)cap);
     std::vector<CvFit *> need;
     std::vector<char> fresh;
@@ -1211,6 +1217,8 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
                     const size_t i = next.fetch_add(1);
                     if (i >= total) { drained = true; break; }
                     slot[t].reset(new CvFit());
+                    slot[t]->pool = &pool;
+                    if (!pool.empty()) { slot[t]->v = std::move(pool.back()); pool.pop_back(); }
                     MIH_TRY(make(i, *slot[t], s));
                     CvFit &f = *slot[t];
                     MIH_TRY(f.v->init_pre(f.train.empty() ? nullptr : f.train.data()));
@@ -1325,10 +1333,12 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, con
     if (mine.empty()) return MIH_OK;
     auto make = [&](size_t t, CvFit &f, hipStream_t s) -> int {
         int32_t fold = mine[t].first; int64_t ik = mine[t].second;
-        mih_fit_params pf = pr;
-        pf.k = path[ik];                                  // v.k = sparsity (cross_validation.jl:110)
-        f.v.reset(new IhtVar());
-        MIH_TRY(f.v->create(h, &pf, y, z, q, s));
+        if (f.v) MIH_TRY(f.v->set_k(path[ik]));           // a recycled IHTVariable: v.k = sparsity (cross_validation.jl:110)
+        else {
+            f.v.reset(new IhtVar());
+            MIH_TRY(f.v->create(h, &pr, y, z, q, s));     // sized for max(path), then
+            MIH_TRY(f.v->set_k(path[ik]));
+        }
         f.train.resize(n);
         for (int64_t i = 0; i < n; ++i) f.train[i] = (folds[i] != fold);
         f.out_index = (int64_t)(fold - 1) * npath + ik;
@@ -1354,6 +1364,7 @@ int mih_fit_iht_path(const mih_mat *h, const mih_fit_params *prm, const double *
     }
     mih_fit_params pr = *prm;
     pr.progress = nullptr;
+    pr.k = kmax;                                     // IHTVariables are sized for the largest model and re-used along the path
     std::vector<int64_t> mine;
     for (int64_t i = 0; i < npath; ++i) if (i % world == rank) mine.push_back(i);
     if (mine.empty()) return MIH_OK;
@@ -1379,10 +1390,12 @@ int mih_fit_iht_path(const mih_mat *h, const mih_fit_params *prm, const double *
         return MIH_OK;
     }
     auto make = [&](size_t t, CvFit &f, hipStream_t s) -> int {
-        mih_fit_params pf = pr; pf.k = path[mine[t]];
         slots(f, mine[t]);
-        f.v.reset(new IhtVar());
-        return f.v->create(h, &pf, y, z, q, s);
+        if (!f.v) {                                        // else: recycled from the lane's pool
+            f.v.reset(new IhtVar());
+            MIH_TRY(f.v->create(h, &pr, y, z, q, s));     // sized for max(path)
+        }
+        return f.v->set_k(path[mine[t]]);
     };
     return cv_run_lanes(h, pr, mine.size(), make, nullptr);
 }
