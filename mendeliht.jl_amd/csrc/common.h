@@ -167,6 +167,10 @@ int  xv_work_init(const mih_mat *h, XvWork &w, int64_t max_nnz);
 int  xv_sparse_device(const mih_mat *h, XvWork &w, const int64_t *idx_dev, const double *val_dev,
                       int64_t nnz, double *out_dev, int clamp20, hipStream_t s, const int64_t *idx_host = nullptr);
 
+// m coefficient vectors over the same support (vals_dev[v*nnz + t], out_dev[v*n + i]); no clamp
+int  xv_sparse_multi_device(const mih_mat *h, XvWork &w, const int64_t *idx_dev, const double *vals_dev, int64_t nnz, int m,
+                            double *out_dev, hipStream_t s, const int64_t *idx_host);
+
 // ---- top-k --------------------------------------------------------------------
 struct TopkWork {
     DevBuf<uint32_t> hist;     // 256 bins

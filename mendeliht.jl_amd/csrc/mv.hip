@@ -238,6 +238,7 @@ struct MvVar {
     Sparse B, B0, best_B;                  // linear index i + r*j
     std::vector<int64_t> cols;             // idx: columns with a non-zero (sorted)
     std::vector<double> dfcols;            // df[:, idx] as [r][ncols]
+    DevBuf<double> mcoef; std::vector<double> xbcoef;      // [r][ncols] coefficient matrices of the multi-trait X*v
     std::vector<double> C, C0, best_C, df2, G, G0, gram;
     std::vector<uint8_t> idc;
     int64_t nsamples = 0;
@@ -312,23 +313,19 @@ struct MvVar {
         update_cols();
         int64_t nc = (int64_t)cols.size();
         MIH_TRY(ensure_stage(nc));
-        std::vector<double> coef(nc);
-        if (nc) MIH_HIP(hipMemcpyAsync(sidx.p, cols.data(), sizeof(int64_t) * nc, hipMemcpyHostToDevice, s));
-        for (int i = 0; i < r; ++i) {
-            std::fill(coef.begin(), coef.end(), 0.0);
-            size_t c = 0;
-            for (size_t t = 0; t < B.idx.size(); ++t) {
-                int64_t j = B.idx[t] / r; int ii = (int)(B.idx[t] - j * r);
-                while (cols[c] != j) ++c;
-                if (ii == i) coef[c] = B.val[t];
-            }
-            if (nc) {
-                MIH_HIP(hipMemcpyAsync(sval.p, coef.data(), sizeof(double) * nc, hipMemcpyHostToDevice, s));
-                MIH_HIP(hipStreamSynchronize(s));     // coef is reused by the next trait
-            }
-            MIH_TRY(xv_sparse_device(h, xv, sidx.p, sval.p, nc, BX.p + (size_t)i * n, 0, s, cols.data()));
+        if (!nc) { MIH_HIP(hipMemsetAsync(BX.p, 0, sizeof(double) * (size_t)n * r, s)); return MIH_OK; }
+        // coefficient matrix [trait][support column] (zero where a trait does not use the column), one upload, one launch
+        xbcoef.assign((size_t)nc * r, 0.0);
+        size_t c = 0;
+        for (size_t t = 0; t < B.idx.size(); ++t) {
+            int64_t j = B.idx[t] / r; int ii = (int)(B.idx[t] - j * r);
+            while (cols[c] != j) ++c;
+            xbcoef[(size_t)ii * nc + c] = B.val[t];
         }
-        return MIH_OK;
+        if ((size_t)nc * r > mcoef.n) { MIH_HIP(hipStreamSynchronize(s)); MIH_TRY(mcoef.alloc((size_t)nc * r * 2)); }
+        MIH_HIP(hipMemcpyAsync(sidx.p, cols.data(), sizeof(int64_t) * nc, hipMemcpyHostToDevice, s));
+        MIH_HIP(hipMemcpyAsync(mcoef.p, xbcoef.data(), sizeof(double) * nc * r, hipMemcpyHostToDevice, s));
+        return xv_sparse_multi_device(h, xv, sidx.p, mcoef.p, nc, r, BX.p, s, cols.data());
     }
     // update_mu! + update_resid! (+ Gram matrix resid*resid' for solve_Sigma!/loglikelihood)
     int resid_and_gram()
@@ -411,13 +408,12 @@ struct MvVar {
         int64_t nc = (int64_t)cols.size();
         double numer = 0.0;
         for (double x : dfcols) numer += x * x;
-        for (int i = 0; i < r; ++i) {
-            if (nc) {
-                MIH_HIP(hipMemcpyAsync(sidx.p, cols.data(), sizeof(int64_t) * nc, hipMemcpyHostToDevice, s));
-                MIH_HIP(hipMemcpyAsync(sval.p, dfcols.data() + (size_t)i * nc, sizeof(double) * nc, hipMemcpyHostToDevice, s));
-            }
-            MIH_TRY(xv_sparse_device(h, xv, sidx.p, sval.p, nc, T1.p + (size_t)i * n, 0, s, cols.data()));
-        }
+        if (nc) {
+            if ((size_t)nc * r > mcoef.n) { MIH_HIP(hipStreamSynchronize(s)); MIH_TRY(mcoef.alloc((size_t)nc * r * 2)); }
+            MIH_HIP(hipMemcpyAsync(sidx.p, cols.data(), sizeof(int64_t) * nc, hipMemcpyHostToDevice, s));
+            MIH_HIP(hipMemcpyAsync(mcoef.p, dfcols.data(), sizeof(double) * nc * r, hipMemcpyHostToDevice, s));     // dfcols is [trait][column]
+            MIH_TRY(xv_sparse_multi_device(h, xv, sidx.p, mcoef.p, nc, r, T1.p, s, cols.data()));
+        } else MIH_HIP(hipMemsetAsync(T1.p, 0, sizeof(double) * (size_t)n * r, s));
         pivoted_chol_triu(G, r);                                   // Gamma is left holding U (fit.jl:230-232 recomputes it)
         hipLaunchKernelGGL(k_mv_apply, dim3(nb), dim3(256), 0, s, T1.p, n, r, rmat(G), 1, w.p, (double *)nullptr, red.p);
         hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, s, red.p, nb, 1, scal.p);

@@ -123,6 +123,92 @@ k_xv_snp_cached(const uint32_t *__restrict__ cache, int64_t ndw, int64_t n, cons
     }
 }
 
+// m coefficient vectors over the same support columns (the traits of a multivariate fit: B[:, idx] * X[idx, :],
+// multivariate.jl:21-31, and the step-size products of multivariate.jl:226-236): every cached column is read once per chunk
+// of NTR traits instead of once per trait, in ONE launch.  Per trait the sums and their order are those of k_xv_snp_cached.
+__global__ void k_xv_coef_multi(const int64_t *__restrict__ idx, const double *__restrict__ val, int64_t nnz,
+                                const double *__restrict__ mu, const double *__restrict__ sinv,
+                                int center, int scale, double *__restrict__ A, double *__restrict__ B)
+{
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= nnz) return;
+    const int64_t o = (int64_t)blockIdx.y * nnz + t, j = idx[t];
+    double sc = scale ? sinv[j] : 1.0;
+    double a = sc * val[o];
+    A[o] = a;
+    B[o] = center ? -mu[j] * a : 0.0;
+}
+template <int NTR>
+__global__ void __launch_bounds__(256)
+k_xv_snp_cached_multi(const uint32_t *__restrict__ cache, int64_t ndw, int64_t n, const int32_t *__restrict__ slots,
+                      const double *__restrict__ A, const double *__restrict__ B, int64_t nnz, int groups, int m,
+                      double *__restrict__ out)
+{
+    __shared__ double part[kXvGroups][16][17];
+    const int g = threadIdx.x >> 4, d = threadIdx.x & 15;
+    const int64_t dw = blockIdx.x * 16ll + d;
+    const int64_t per = (nnz + groups - 1) / groups;
+    const int64_t t0 = g * per, t1 = (g < groups) ? (t0 + per < nnz ? t0 + per : nnz) : t0;
+    const int v0 = blockIdx.y * NTR;
+    double acc[NTR][16], bsum[NTR];
+    #pragma unroll
+    for (int u = 0; u < NTR; ++u) {
+        bsum[u] = 0.0;
+        #pragma unroll
+        for (int q = 0; q < 16; ++q) acc[u][q] = 0.0;
+    }
+    if (dw < ndw) {
+        const double *Av[NTR], *Bv[NTR];
+        #pragma unroll
+        for (int u = 0; u < NTR; ++u) { const int v = v0 + u < m ? v0 + u : m - 1; Av[u] = A + (int64_t)v * nnz; Bv[u] = B + (int64_t)v * nnz; }
+        int64_t t = t0;
+        for (; t + 4 <= t1; t += 4) {             // four independent column loads in flight, the dosages unpacked once per NTR traits
+            uint32_t w4[4]; double a4[4][NTR];
+            #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                w4[j] = cache[(int64_t)slots[t + j] * ndw + dw];
+                #pragma unroll
+                for (int u = 0; u < NTR; ++u) { a4[j][u] = Av[u][t + j]; bsum[u] += Bv[u][t + j]; }
+            }
+            #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                #pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const double gq = (double)((w4[j] >> (2 * q)) & 3u);
+                    #pragma unroll
+                    for (int u = 0; u < NTR; ++u) acc[u][q] = fma(gq, a4[j][u], acc[u][q]);
+                }
+            }
+        }
+        for (; t < t1; ++t) {
+            const uint32_t w = cache[(int64_t)slots[t] * ndw + dw];
+            double a1[NTR];
+            #pragma unroll
+            for (int u = 0; u < NTR; ++u) { a1[u] = Av[u][t]; bsum[u] += Bv[u][t]; }
+            #pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const double gq = (double)((w >> (2 * q)) & 3u);
+                #pragma unroll
+                for (int u = 0; u < NTR; ++u) acc[u][q] = fma(gq, a1[u], acc[u][q]);
+            }
+        }
+    }
+    const int dd = threadIdx.x >> 4, q2 = threadIdx.x & 15;
+    const int64_t i = (blockIdx.x * 16ll + dd) * 16 + q2;
+    #pragma unroll
+    for (int u = 0; u < NTR; ++u) {
+        #pragma unroll
+        for (int q = 0; q < 16; ++q) part[g][d][q] = acc[u][q] + bsum[u];
+        __syncthreads();
+        if (i < n && v0 + u < m) {
+            double a = 0.0;
+            for (int gg = 0; gg < groups; ++gg) a += part[gg][dd][q2];
+            out[(int64_t)(v0 + u) * n + i] = a;
+        }
+        __syncthreads();
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_xv_dense(const T *__restrict__ D, int64_t n, const int64_t *__restrict__ idx,
@@ -275,6 +361,44 @@ int xv_sparse_device(const mih_mat *h, XvWork &w, const int64_t *idx_dev, const 
                            clamp20, out_dev);
     }
     MIH_HIP(hipGetLastError());
+    return MIH_OK;
+}
+
+// out[v*n + i] = sum_t x[i, idx[t]] * vals[v*nnz + t] for v < m (no clamp): one launch over the cached columns when the
+// cache holds the support, one single-vector pass per v otherwise.
+int xv_sparse_multi_device(const mih_mat *h, XvWork &w, const int64_t *idx_dev, const double *vals_dev, int64_t nnz, int m,
+                           double *out_dev, hipStream_t s, const int64_t *idx_host)
+{
+    const bool fix = h->kind == 0 && h->impute && h->total_missing > 0;
+    static const bool multi_on = []() { const char *e = getenv("MENDELIHT_XV_MULTI"); return !e || atoi(e) != 0; }();
+    if (multi_on && m > 1 && nnz > 0 && h->kind == 0 && !fix && idx_host && h->p < (1ll << 40)) {
+        if (nnz * m > w.cap) {
+            MIH_HIP(hipStreamSynchronize(s));
+            MIH_TRY(w.coefA.alloc((size_t)nnz * m * 2));
+            MIH_TRY(w.coefB.alloc((size_t)nnz * m * 2));
+            w.cap = nnz * m * 2;
+        }
+        std::vector<int32_t> &slots = w.h_slots; std::vector<int64_t> &fills = w.h_fills;
+        if (xv_cache_lookup(w, idx_host, nnz, slots, fills)) {
+            const int64_t ndw = h->n_pad / 16;
+            const int groups = (int)(nnz < w.groups ? nnz : w.groups);
+            hipLaunchKernelGGL(k_xv_coef_multi, dim3((unsigned)((nnz + 255) / 256), (unsigned)m), dim3(256), 0, s, idx_dev, vals_dev, nnz,
+                               h->mu, h->sinv, h->center, h->scale, w.coefA.p, w.coefB.p);
+            MIH_HIP(hipMemcpyAsync(w.slot_dev.p, slots.data(), sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, s));
+            if (!fills.empty()) {
+                MIH_HIP(hipMemcpyAsync(w.fill_dev.p, fills.data(), sizeof(int64_t) * fills.size(), hipMemcpyHostToDevice, s));
+                hipLaunchKernelGGL(k_xv_fill, dim3((unsigned)((ndw + 255) / 256), (unsigned)fills.size()), dim3(256), 0, s, h->X, h->nbp, ndw,
+                                   w.fill_dev.p, w.cache.p);
+            }
+            constexpr int NTR = 4;
+            hipLaunchKernelGGL((k_xv_snp_cached_multi<NTR>), dim3((unsigned)((ndw + 15) / 16), (unsigned)((m + NTR - 1) / NTR)), dim3(256), 0, s,
+                               w.cache.p, ndw, h->n, w.slot_dev.p, w.coefA.p, w.coefB.p, nnz, groups, m, out_dev);
+            MIH_HIP(hipGetLastError());
+            return MIH_OK;
+        }
+    }
+    for (int v = 0; v < m; ++v)
+        MIH_TRY(xv_sparse_device(h, w, idx_dev, vals_dev + (size_t)v * nnz, nnz, out_dev + (size_t)v * h->n, 0, s, idx_host));
     return MIH_OK;
 }
 
