@@ -135,6 +135,17 @@ typedef struct mih_comm {
     void *user;
 } mih_comm;
 
+/* A native exchange for the column-sharded fit: an RCCL communicator owned by the library, whose two callbacks run
+ * ncclAllReduce / ncclAllGather on a private stream (xGMI between the GPUs of a node) without re-entering the host
+ * language.  One process per GPU.  Rank 0 calls mih_rccl_unique_id and hands the 128 bytes to the other ranks by whatever
+ * the launcher offers (MPI_Bcast, torch.distributed.broadcast, a file); every rank then calls mih_comm_create_rccl and
+ * passes the returned mih_comm in mih_fit_params::comm (and frees it with mih_comm_destroy_rccl).  librccl is loaded on
+ * first use (dlopen; MENDELIHT_RCCL_LIB overrides the name).  No reference counterpart: the reference has no multi-device fit. */
+int mih_rccl_unique_id(void *id128);
+int mih_comm_create_rccl(const void *id128, int32_t rank, int32_t world, int32_t device, int64_t col_offset,
+                         int64_t p_global, mih_comm **out);
+int mih_comm_destroy_rccl(mih_comm *c);
+
 /* keyword arguments of fit_iht (src/fit.jl:64-81) */
 typedef struct mih_fit_params {
     int64_t  k;               /* sparsity (ignored when ks != NULL) */

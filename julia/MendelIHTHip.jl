@@ -115,6 +115,22 @@ struct MihComm
     rank::Int32; world::Int32; col_offset::Int64; p_global::Int64
     allreduce::Ptr{Cvoid}; allgather::Ptr{Cvoid}; user::Ptr{Cvoid}
 end
+# The library's own RCCL communicator for a column-sharded fit (one Julia process per GPU): rank 0 makes the 128-byte id
+# with `rccl_unique_id()`, the launcher broadcasts it (e.g. MPI.Bcast!), every rank calls `rccl_comm(id, rank, world, ...)` and
+# passes the pointer as `fit_iht(...; comm=ptr)`; `rccl_comm_destroy(ptr)` afterwards.
+function rccl_unique_id()
+    id = zeros(UInt8, 128)
+    check(ccall((:mih_rccl_unique_id, LIB), Cint, (Ptr{UInt8},), id))
+    return id
+end
+function rccl_comm(id::Vector{UInt8}, rank::Integer, world::Integer; device::Integer=0, col_offset::Integer, p_global::Integer)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:mih_comm_create_rccl, LIB), Cint, (Ptr{UInt8}, Int32, Int32, Int32, Int64, Int64, Ref{Ptr{Cvoid}}),
+                id, rank, world, device, col_offset, p_global, h))
+    return h[]
+end
+rccl_comm_destroy(c::Ptr{Cvoid}) = check(ccall((:mih_comm_destroy_rccl, LIB), Cint, (Ptr{Cvoid},), c))
+
 mutable struct MihFitResult
     time::Float64; logl::Float64; iter::Int64; pve::Float64; nb_r::Float64
     choose_fired::Int32; n_trace::Int32

@@ -126,6 +126,9 @@ def lib():
         "mih_session_step": [vp, C.POINTER(dbl), C.POINTER(i32), C.POINTER(dbl)],
         "mih_session_model": [vp, vp, vp],
         "mih_session_destroy": [vp],
+        "mih_rccl_unique_id": [vp],
+        "mih_comm_create_rccl": [vp, i32, i32, i32, i64, i64, C.POINTER(vp)],
+        "mih_comm_destroy_rccl": [vp],
         "mih_profile_enable": [C.c_int],
         "mih_profile_read": [C.POINTER(dbl), C.POINTER(i64), C.c_int],
     }
@@ -147,6 +150,7 @@ def exported_symbols():
             "mih_fit_mv", "mih_cv_mv", "mih_bench_xtv", "mih_bench_xtv_batched", "mih_xtv_algorithmic_bytes", "mih_set_xtv_variant",
             "mih_set_xtv_multi_variant", "mih_set_xtv_digits", "mih_abi_sizes",
             "mih_session_create", "mih_session_step", "mih_session_model", "mih_session_destroy",
+            "mih_rccl_unique_id", "mih_comm_create_rccl", "mih_comm_destroy_rccl",
             "mih_profile_enable", "mih_profile_read"]
 
 

@@ -147,6 +147,49 @@ class ColumnComm:
             return 1
 
 
+class NativeComm:
+    """The library's own RCCL communicator as the `mih_comm` of a column-sharded fit (mih_comm_create_rccl): the two
+    exchanges run inside the library (ncclAllReduce / ncclAllGather over xGMI), no callback into Python.  One process per
+    GPU; the 128-byte unique id is made by rank 0 and broadcast over the torch.distributed group (any backend)."""
+
+    def __init__(self, col_offset, p_global, device=0, group=None):
+        import torch
+        import torch.distributed as dist
+
+        from .api import _check, lib
+
+        on = dist.is_initialized()
+        self.rank = dist.get_rank(group) if on else 0
+        self.world = dist.get_world_size(group) if on else 1
+        self.error = None
+        uid = (C.c_char * 128)()
+        if self.rank == 0:
+            _check(lib().mih_rccl_unique_id(uid))
+        if self.world > 1:
+            t = torch.frombuffer(bytearray(uid.raw), dtype=torch.uint8).clone()
+            if dist.get_backend(group) == "nccl":
+                t = t.to(f"cuda:{device}")
+            dist.broadcast(t, src=0, group=group)
+            uid = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
+        self._h = C.c_void_p(None)
+        _check(lib().mih_comm_create_rccl(uid, self.rank, self.world, int(device), int(col_offset), int(p_global), C.byref(self._h)))
+
+    def pointer(self):
+        return self._h.value
+
+    def close(self):
+        if self._h:
+            from .api import lib
+            lib().mih_comm_destroy_rccl(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class _DevArray:
     """A device pointer as a CUDA-array-interface object (zero-copy view for torch.as_tensor)."""
 
@@ -165,18 +208,19 @@ def column_block(p_global, rank, world):
     return lo, hi - lo
 
 
-def fit_iht_sharded(y, x_shard, z=None, *, col_offset, p_global, weight=None, **kw):
+def fit_iht_sharded(y, x_shard, z=None, *, col_offset, p_global, weight=None, native=False, **kw):
     """fit_iht on a design matrix whose SNP columns are sharded over the ranks of the process group.
 
     x_shard holds columns [col_offset, col_offset + x_shard.p); y, z are replicated.  Returns the same
-    IHTResult on every rank with the full-length beta assembled from the shards.
+    IHTResult on every rank with the full-length beta assembled from the shards.  native=True: the exchanges run
+    inside the library over its own RCCL communicator (one GPU per rank) instead of through torch.distributed callbacks.
     """
     import torch
     import torch.distributed as dist
 
     from .api import fit_iht
 
-    comm = ColumnComm(col_offset, p_global, device=x_shard.device)
+    comm = (NativeComm if native else ColumnComm)(col_offset, p_global, device=x_shard.device)
     if weight is not None:
         weight = np.asarray(weight, dtype=np.float64)[col_offset:col_offset + x_shard.p]
     try:
