@@ -25,7 +25,7 @@ rng = np.random.default_rng(2025)                       # same stream on every r
 supp = np.sort(rng.choice(p, size=k, replace=False))
 beta = rng.standard_normal(k)
 mine = (supp >= lo) & (supp < lo + cnt)
-comm = D.ColumnComm(lo, p, device=dev)
+comm = (D.NativeComm if os.environ.get("MIH_NATIVE") else D.ColumnComm)(lo, p, device=dev)     # MIH_NATIVE=1: the library's own RCCL communicator
 xb = x.xv_sparse(supp[mine] - lo, beta[mine])
 if world > 1:
     import torch.distributed as dist
