@@ -179,11 +179,13 @@ struct TopkWork {
     DevBuf<uint64_t> sel;      // compacted survivors as (index, value bits) pairs; pair 0 holds the count
     int64_t cap = 0;           // pairs the buffer can hold after the header
     int64_t expect = 0;        // survivors expected by the caller (k + slack): fetched with the count in ONE copy
+    bool radix8 = false;       // MENDELIHT_TOPK_RADIX8=1: always the 8 x 8-bit select (the two-pass select's fallback)
 };
 int  topk_work_init(TopkWork &w, int64_t max_keep);
 // In-place project_k! on a device vector; returns threshold and survivors (sorted by index) on host.
+// zero_in_place = false: the caller only needs the survivor lists (the device vector may be left unprojected)
 int  topk_project_device(double *x_dev, int64_t len, int64_t k, TopkWork &w, hipStream_t s,
-                         std::vector<int64_t> &idx_out, std::vector<double> &val_out);
+                         std::vector<int64_t> &idx_out, std::vector<double> &val_out, bool zero_in_place = true);
 // every non-zero of a device vector as (index, value), sorted by index
 int  collect_nonzero_device(double *x_dev, int64_t len, TopkWork &w, hipStream_t s,
                             std::vector<int64_t> &idx_out, std::vector<double> &val_out);

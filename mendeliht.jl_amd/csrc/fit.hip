@@ -255,12 +255,37 @@ k_stepsize(const double *__restrict__ xgk, const double *__restrict__ z, const d
     block_sum<1>(v, partial + blockIdx.x);
 }
 
+// the same with df2 still on the device (the step size of the NEXT step is computed speculatively at the end of a step,
+// before df2 has travelled to the host): df2_idc[l] = df2_dev[l] where bit l of idc_mask is set
+__global__ void __launch_bounds__(256)
+k_stepsize_dev(const double *__restrict__ xgk, const double *__restrict__ z, const double *__restrict__ xb,
+               const double *__restrict__ zc, const double *__restrict__ mu, const double *__restrict__ w,
+               int64_t n, int q, const double *__restrict__ df2_dev, unsigned long long idc_mask, int dist, int link, double nb_r,
+               double *__restrict__ partial)
+{
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    double v[1] = {0.0};
+    if (i < n) {
+        double a = 0.0;
+        for (int l = 0; l < q; ++l) a += z[(int64_t)l * n + i] * (((idc_mask >> l) & 1ull) ? df2_dev[l] : 0.0);
+        double g = xgk[i] + a;
+        double me = d_mueta(link, xb[i] + zc[i]);
+        double sw = sqrt(me * me / d_glmvar(dist, mu[i], nb_r)) * w[i];
+        g *= sw;
+        v[0] = g * g;
+    }
+    block_sum<1>(v, partial + blockIdx.x);
+}
+
 // vectorize!(full_b, b, c, weight, zkeep) after the axpy (utilities.jl:258-263,291-315):
 // full[j] = eta*df[j]*w_j here; the k support entries are patched by k_scatter_b.
+// The covariate tail full[p .. p+qt) (c + eta df2, or Inf for zkeep slots, utilities.jl:264,313-314) rides along as a
+// kernel argument instead of a separate host-to-device copy (qt = 0: no tail).
 __global__ void k_grad_full(const double *__restrict__ df, const double *__restrict__ weight, int64_t p,
-                            double eta, double *__restrict__ full)
+                            double eta, double *__restrict__ full, QVec tail, int qt)
 {
     int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (j < qt) full[p + j] = tail.v[j];
     if (j >= p) return;
     double v = eta * df[j];
     full[j] = weight ? v * weight[j] : v;
@@ -649,11 +674,11 @@ struct IhtVar {
     }
 
     // project the (p+q) buffer `full` to k+zkeepn and split the survivors into (SNP list, covariate values)
-    int project_full(Sparse &snp, std::vector<double> &ctail, std::vector<uint8_t> &ctail_nz)
+    int project_full(Sparse &snp, std::vector<double> &ctail, std::vector<uint8_t> &ctail_nz, bool zero_in_place = true)
     {
         if (comm) return project_full_sharded(snp, ctail, ctail_nz);
         std::vector<int64_t> si; std::vector<double> sv;
-        MIH_TRY(topk_project_device(full.p, p + q, k + zkeepn, topk, s, si, sv));
+        MIH_TRY(topk_project_device(full.p, p + q, k + zkeepn, topk, s, si, sv, zero_in_place));
         snp.clear();
         ctail_nz.assign(q, 0);
         for (size_t t = 0; t < si.size(); ++t) {
@@ -700,7 +725,7 @@ struct IhtVar {
         if (has_group) {
             // utilities.jl:266-268: project_group_sparse!(v.b, v.group, J, k): no prior weights, and the
             // covariates are not projected in this branch
-            hipLaunchKernelGGL(k_grad_full, dim3(nblk(p)), dim3(256), 0, s, df.p, (const double *)nullptr, p, eta, full.p);
+            hipLaunchKernelGGL(k_grad_full, dim3(nblk(p)), dim3(256), 0, s, df.p, (const double *)nullptr, p, eta, full.p, QVec{}, 0);
             MIH_TRY(upload(bb.idx, bb.val));
             if (!bb.idx.empty())
                 hipLaunchKernelGGL(k_scatter_b, dim3(nblk((int64_t)bb.idx.size())), dim3(256), 0, s, sidx.p, sval.p, (int64_t)bb.idx.size(), df.p, (const double *)nullptr, eta, full.p);
@@ -714,18 +739,17 @@ struct IhtVar {
             return MIH_OK;
         }
         const double *wp = has_weight ? weight.p : nullptr;
-        hipLaunchKernelGGL(k_grad_full, dim3(nblk(p)), dim3(256), 0, s, df.p, wp, p, eta, full.p);
-        MIH_TRY(upload(bb.idx, bb.val));
-        if (!bb.idx.empty())
-            hipLaunchKernelGGL(k_scatter_b, dim3(nblk((int64_t)bb.idx.size())), dim3(256), 0, s, sidx.p, sval.p, (int64_t)bb.idx.size(), df.p, wp, eta, full.p);
         std::vector<double> cn(q), tail(q);
         for (int l = 0; l < q; ++l) {
             cn[l] = std::fma(eta, df2[l], cc[l]);
             tail[l] = zkeep[l] ? std::numeric_limits<double>::infinity() : cn[l];
         }
-        MIH_HIP(hipMemcpyAsync(full.p + p, tail.data(), sizeof(double) * q, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_grad_full, dim3(nblk(p)), dim3(256), 0, s, df.p, wp, p, eta, full.p, qvec(tail), q);
+        MIH_TRY(upload(bb.idx, bb.val));
+        if (!bb.idx.empty())
+            hipLaunchKernelGGL(k_scatter_b, dim3(nblk((int64_t)bb.idx.size())), dim3(256), 0, s, sidx.p, sval.p, (int64_t)bb.idx.size(), df.p, wp, eta, full.p);
         Sparse snp; std::vector<double> ct(q, 0.0); std::vector<uint8_t> cnz;
-        MIH_TRY(project_full(snp, ct, cnz));
+        MIH_TRY(project_full(snp, ct, cnz, /*zero_in_place=*/false));       // only the survivor lists are used
         if (has_weight) {           // unvectorize!: b = full / weight on the survivors
             std::vector<double> hw(snp.idx.size());
             MIH_TRY(ensure_stage((int64_t)snp.idx.size()));
@@ -759,7 +783,7 @@ struct IhtVar {
     }
     int init_pre(const uint8_t *train)
     {
-        train_cur = train;
+        train_cur = train; spec_ok = false;
         b.clear(); b0.clear(); best_b.clear(); idx.clear();
         std::fill(c.begin(), c.end(), 0.0); c0 = c; best_c = c; std::fill(df2.begin(), df2.end(), 0.0);
         for (int l = 0; l < q; ++l) { idc[l] = zkeep[l]; idc0[l] = zkeep[l]; }
@@ -860,10 +884,9 @@ struct IhtVar {
         }
         // vectorize!(full_b, df, df2) ; project_k! ; unvectorize! -> df is replaced by its own projection
         const double *wp = has_weight ? weight.p : nullptr;
-        hipLaunchKernelGGL(k_grad_full, dim3(nblk(p)), dim3(256), 0, s, df.p, wp, p, 1.0, full.p);
         std::vector<double> tail(q);
         for (int l = 0; l < q; ++l) tail[l] = zkeep[l] ? std::numeric_limits<double>::infinity() : df2[l];
-        MIH_HIP(hipMemcpyAsync(full.p + p, tail.data(), sizeof(double) * q, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_grad_full, dim3(nblk(p)), dim3(256), 0, s, df.p, wp, p, 1.0, full.p, qvec(tail), q);
         Sparse snp; std::vector<double> ct(q, 0.0); std::vector<uint8_t> cnz;
         MIH_TRY(project_full(snp, ct, cnz));
         if (comm) {          // the device copy was only projected to the LOCAL threshold: rebuild it from the survivors
@@ -905,6 +928,17 @@ struct IhtVar {
     // iht_stepsize! (utilities.jl:722-764)
     int stepsize(double *eta)
     {
+        if (spec_ok && !comm && spec_idx == idx.idx && spec_idc == idc) {      // computed at the end of the previous step
+            spec_ok = false;
+            double numer = 0.0;
+            for (size_t t = 0; t < idx.val.size(); ++t) numer += idx.val[t] * idx.val[t];
+            for (int l = 0; l < q; ++l) if (idc[l]) numer += df2[l] * df2[l];
+            double e = numer / spec_denom;
+            if (std::isinf(e) || std::isnan(e)) e = 1e-8;
+            *eta = e;
+            return MIH_OK;
+        }
+        spec_ok = false;
         MIH_TRY(upload(idx.idx, idx.val));
         MIH_TRY(xv_sparse_device(h, xv, sidx.p, sval.p, (int64_t)idx.idx.size(), xgk.p, 0, s, idx.idx.data()));
         std::vector<double> d2(q);
@@ -1030,10 +1064,44 @@ struct IhtVar {
         *bt = es; *new_logl = logl;
         return resid_only();
     }
+    // The end of a step and the beginning of the next in ONE host synchronisation: Z'r (df2), df on the support and --
+    // speculatively, it is discarded if the fit stops here -- the whole iht_stepsize! of the next step (X_S df_S straight
+    // from the device copy of df_S, the weighted sum of squares) are queued back to back and come home in one copy:
+    // [df_S | df2 | sum xgk^2].  One synchronisation and three small copies less per iteration than doing the step size
+    // on its own.
+    bool spec_ok = false; double spec_denom = 0.0; std::vector<int64_t> spec_idx; std::vector<uint8_t> spec_idc;
+    int step_post_fused()
+    {
+        const int64_t nnz = (int64_t)idx.idx.size();
+        MIH_TRY(ensure_stage(nnz + kMaxQ + 2));
+        hipLaunchKernelGGL(k_zt_r, dim3(kZtrBlocks, q), dim3(256), 0, s, z.p, r.p, n, ztr.p);
+        hipLaunchKernelGGL(k_zt_r_final, dim3(q), dim3(64), 0, s, ztr.p, gval.p + nnz);            // df2 behind df_S
+        if (nnz) {
+            MIH_HIP(hipMemcpyAsync(sidx.p, idx.idx.data(), sizeof(int64_t) * nnz, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_gather, dim3(nblk(nnz)), dim3(256), 0, s, df.p, sidx.p, nnz, gval.p);
+        }
+        MIH_TRY(xv_sparse_device(h, xv, sidx.p, gval.p, nnz, xgk.p, 0, s, idx.idx.data()));
+        unsigned long long mask = 0ull;
+        for (int l = 0; l < q; ++l) if (idc[l]) mask |= 1ull << l;
+        hipLaunchKernelGGL(k_stepsize_dev, dim3(nb), dim3(256), 0, s, xgk.p, z.p, xb.p, zc.p, mu.p, w.p, n, q, gval.p + nnz, mask,
+                           dist, link, nb_r, red.p);
+        hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, s, red.p, nb, 1, gval.p + nnz + q);
+        if ((size_t)nnz + q + 1 > hpin.n) MIH_TRY(hpin.alloc((size_t)nnz * 2 + kMaxQ + 16));
+        MIH_HIP(hipMemcpyAsync(hpin.p, gval.p, sizeof(double) * (size_t)(nnz + q + 1), hipMemcpyDeviceToHost, s));
+        MIH_HIP(hipStreamSynchronize(s));
+        idx.val.assign(hpin.p, hpin.p + nnz);
+        for (int l = 0; l < q; ++l) df2[l] = hpin.p[nnz + l];
+        df2_pending = false;
+        spec_denom = hpin.p[nnz + q]; spec_idx = idx.idx; spec_idc = idc; spec_ok = true;
+        return MIH_OK;
+    }
     int step_post(double logl)
     {
-        MIH_TRY(score_post());
-        MIH_TRY(gather_df_support());
+        if (!comm) MIH_TRY(step_post_fused());
+        else {
+            MIH_TRY(score_post());
+            MIH_TRY(gather_df_support());
+        }
         if (std::isnan(logl)) { set_error("Loglikelihood function is NaN, aborting..."); return MIH_NAN_LOGL; }
         if (std::isinf(logl)) { set_error("Loglikelihood function is Inf, aborting..."); return MIH_INF_LOGL; }
         return MIH_OK;

@@ -8,6 +8,7 @@
 #include "common.h"
 #include <algorithm>
 #include <cstring>
+#include <functional>
 
 namespace mih {
 
@@ -105,10 +106,108 @@ k_threshold(double *__restrict__ x, int64_t len, const uint64_t *__restrict__ st
     }
 }
 
+// ---- two passes of 11 bits, then the host finishes --------------------------------------------------------------------
+// The k-th largest magnitude is pinned down to its exponent and its top 11 mantissa bits by two histogram passes (2048
+// bins each); everything at or above that 22-bit prefix -- the entries certainly kept plus the handful sharing the prefix
+// with the threshold -- is gathered in one more sweep, and the host picks the exact threshold among the prefix-sharers
+// (ties kept, utilities.jl:553-559).  5 launches instead of 17; the 8 x 8-bit select above remains the fallback when the
+// prefix is shared by more entries than the gather buffer holds (massive ties).
+constexpr int kBins11 = 2048;
+__global__ void __launch_bounds__(256)
+k_hist11(const double *__restrict__ x, int64_t len, int second, const uint64_t *__restrict__ state, uint32_t *__restrict__ hist)
+{
+    __shared__ uint32_t h[4][kBins11];
+    for (int e = threadIdx.x; e < 4 * kBins11; e += 256) (&h[0][0])[e] = 0;
+    __syncthreads();
+    const uint64_t prefix = state[0];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t rounds = (len + stride - 1) / stride;
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    for (int64_t r = 0; r < rounds; ++r, i += stride) {
+        bool live = false; uint32_t bin = 0;
+        if (i < len) {
+            const uint64_t key = abs_key(x[i]);
+            live = !second || (key >> 52) == prefix;
+            bin = second ? (uint32_t)(key >> 41) & 2047u : (uint32_t)(key >> 52);
+        }
+        if (second) { if (live) atomicAdd(&h[wave][bin], 1u); continue; }
+        uint64_t todo = __ballot(live);     // exponents: a handful of bins per wave -> one add per distinct bin
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t lb = __shfl(bin, leader, 64);
+            const uint64_t same = __ballot(live && bin == lb) & todo;
+            if (lane == leader) h[wave][lb] += (uint32_t)__popcll(same);
+            todo &= ~same;
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < kBins11; b += 256) {
+        const uint32_t tot = h[0][b] + h[1][b] + h[2][b] + h[3][b];
+        if (tot) atomicAdd(&hist[b], tot);
+    }
+}
+// pick the bin holding the kth largest among 2048: thread t owns bins 8t .. 8t+7.  second = 0: kth comes as an argument
+// (no host-to-device copy of the state); second = 1: also arms the gather (lower-bound key, remaining rank, counter).
+__global__ void __launch_bounds__(256)
+k_pick11(uint32_t *__restrict__ hist, uint64_t *__restrict__ state, int second, uint64_t k_arg, uint64_t *__restrict__ sel)
+{
+    __shared__ uint64_t suf[257];      // suf[t] = sum of the bins of threads t..255
+    const int t = threadIdx.x;
+    uint32_t mine[8]; uint64_t own = 0;
+    #pragma unroll
+    for (int j = 0; j < 8; ++j) { mine[j] = hist[8 * t + j]; own += mine[j]; hist[8 * t + j] = 0; }
+    suf[t] = own;
+    if (t == 0) suf[256] = 0;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const uint64_t add = (t + off < 256) ? suf[t + off] : 0;
+        __syncthreads();
+        suf[t] += add;
+        __syncthreads();
+    }
+    const uint64_t kth = second ? state[1] : k_arg;
+    // the owning thread: entries above my bins < kth <= entries at or above my bins (thread 0 takes it if none does)
+    const bool owner = (suf[t + 1] < kth && suf[t] >= kth) || (t == 0 && suf[0] < kth);
+    if (owner) {
+        uint64_t above = suf[t + 1];
+        int bin = 8 * t;
+        for (int j = 7; j >= 0; --j) { if (above + mine[j] >= kth) { bin = 8 * t + j; break; } above += mine[j]; }
+        if (suf[0] < kth) { bin = 0; above = suf[0] - mine[0]; }      // fewer than kth entries in all: the threshold is the lowest bin
+        const uint64_t pre = second ? ((state[0] << 11) | (uint64_t)bin) : (uint64_t)bin;
+        state[0] = pre;
+        state[1] = kth > above ? kth - above : 1;
+        if (second) { state[2] = pre << 41; sel[0] = 0; sel[1] = 0; }
+    }
+}
+// everything at or above the 22-bit prefix: sel[0] = count, pairs (index, value bits) behind it
+__global__ void __launch_bounds__(256)
+k_collect(const double *__restrict__ x, int64_t len, const uint64_t *__restrict__ state, uint64_t *__restrict__ sel, uint32_t cap)
+{
+    const uint64_t lo = state[2];
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < len; i += stride) {
+        const double v = x[i];
+        if (abs_key(v) >= lo && v != 0.0) {
+            unsigned long long pos = atomicAdd((unsigned long long *)sel, 1ull);
+            if (pos < cap) { sel[2 + 2 * pos] = (uint64_t)i; sel[3 + 2 * pos] = (uint64_t)__double_as_longlong(v); }
+        }
+    }
+}
+__global__ void __launch_bounds__(256)
+k_zero_below(double *__restrict__ x, int64_t len, uint64_t thr)
+{
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < len; i += stride) { const double v = x[i]; if (abs_key(v) < thr && v != 0.0) x[i] = 0.0; }
+}
+
 int topk_work_init(TopkWork &w, int64_t max_keep)
 {
-    MIH_TRY(w.hist.alloc(256));
-    MIH_HIP(hipMemset(w.hist.p, 0, 256 * sizeof(uint32_t)));      // k_pick leaves the histogram zeroed after every pass
+    MIH_TRY(w.hist.alloc(kBins11));
+    MIH_HIP(hipMemset(w.hist.p, 0, kBins11 * sizeof(uint32_t)));  // the pick kernels leave the histogram zeroed after every pass
+    if (const char *e = getenv("MENDELIHT_TOPK_RADIX8")) w.radix8 = atoi(e) != 0;
     MIH_TRY(w.state.alloc(4));
     w.expect = max_keep + 64;
     w.cap = max_keep + 1024;
@@ -156,11 +255,63 @@ static int compact_device(double *x_dev, int64_t len, TopkWork &w, hipStream_t s
     return MIH_HIP_ERROR;
 }
 
+// the two-pass select; done = false: the prefix is shared by more entries than the gather buffer holds -> 8-bit fallback
+static int topk_two_pass(double *x_dev, int64_t len, int64_t k, TopkWork &w, hipStream_t s,
+                         std::vector<int64_t> &idx_out, std::vector<double> &val_out, bool zero_in_place, bool &done)
+{
+    done = false;
+    const int gridh = (int)std::min<int64_t>((len + 255) / 256, 512), grid = (int)std::min<int64_t>((len + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_hist11, dim3(gridh), dim3(256), 0, s, x_dev, len, 0, w.state.p, w.hist.p);
+    hipLaunchKernelGGL(k_pick11, dim3(1), dim3(256), 0, s, w.hist.p, w.state.p, 0, (uint64_t)k, w.sel.p);
+    hipLaunchKernelGGL(k_hist11, dim3(gridh), dim3(256), 0, s, x_dev, len, 1, w.state.p, w.hist.p);
+    hipLaunchKernelGGL(k_pick11, dim3(1), dim3(256), 0, s, w.hist.p, w.state.p, 1, (uint64_t)k, w.sel.p);
+    hipLaunchKernelGGL(k_collect, dim3(grid), dim3(256), 0, s, x_dev, len, w.state.p, w.sel.p, (uint32_t)w.cap);
+    const int64_t first = std::min<int64_t>(w.expect, w.cap);
+    MIH_HIP(hipMemcpyAsync(w.hsel.p, w.sel.p, sizeof(uint64_t) * (2 + 2 * (size_t)first), hipMemcpyDeviceToHost, s));
+    MIH_HIP(hipStreamSynchronize(s));
+    const int64_t cnt = (int64_t)w.hsel.p[0];
+    if (cnt > w.cap) return MIH_OK;                        // massive ties: the exact 8-bit select handles any count
+    std::vector<uint64_t> host(w.hsel.p, w.hsel.p + 2 + 2 * (size_t)std::min<int64_t>(cnt, first));
+    if (cnt > first) {
+        host.resize(2 + 2 * (size_t)cnt);
+        MIH_HIP(hipMemcpy(host.data() + 2 + 2 * first, w.sel.p + 2 + 2 * first, sizeof(uint64_t) * 2 * (size_t)(cnt - first), hipMemcpyDeviceToHost));
+    }
+    // the gathered set holds every entry at or above the threshold's 22-bit prefix, hence the k largest of the vector
+    uint64_t thr = 0;
+    {
+        std::vector<uint64_t> keys((size_t)cnt);
+        for (int64_t t = 0; t < cnt; ++t) keys[t] = host[3 + 2 * (size_t)t] & 0x7FFFFFFFFFFFFFFFull;
+        if (cnt >= k) {
+            std::nth_element(keys.begin(), keys.begin() + (k - 1), keys.end(), std::greater<uint64_t>());
+            thr = keys[k - 1];                              // |k-th largest| of the whole vector
+        }                                                    // fewer than k non-zeros: thr = 0, everything gathered survives
+    }
+    std::vector<uint32_t> ord;
+    ord.reserve((size_t)std::min<int64_t>(cnt, k + 8));
+    for (uint32_t t = 0; t < (uint32_t)cnt; ++t) if ((host[3 + 2 * (size_t)t] & 0x7FFFFFFFFFFFFFFFull) >= thr) ord.push_back(t);
+    std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return host[2 + 2 * (size_t)a] < host[2 + 2 * (size_t)b]; });
+    idx_out.resize(ord.size()); val_out.resize(ord.size());
+    for (size_t i = 0; i < ord.size(); ++i) {
+        idx_out[i] = (int64_t)host[2 + 2 * (size_t)ord[i]];
+        const uint64_t bits = host[3 + 2 * (size_t)ord[i]];
+        double v; std::memcpy(&v, &bits, sizeof(v));
+        val_out[i] = v;
+    }
+    if (zero_in_place) hipLaunchKernelGGL(k_zero_below, dim3(grid), dim3(256), 0, s, x_dev, len, thr);
+    done = true;
+    return MIH_OK;
+}
+
 int topk_project_device(double *x_dev, int64_t len, int64_t k, TopkWork &w, hipStream_t s,
-                        std::vector<int64_t> &idx_out, std::vector<double> &val_out)
+                        std::vector<int64_t> &idx_out, std::vector<double> &val_out, bool zero_in_place)
 {
     // utilities.jl:554 DomainError for k<0; partialsort(x, 0) / k>len is a BoundsError
     if (k <= 0 || k > len) { set_error("Attempted to project to sparsity level %lld (vector length %lld)", (long long)k, (long long)len); return MIH_BAD_ARG; }
+    if (!w.radix8) {
+        bool done = false;
+        MIH_TRY(topk_two_pass(x_dev, len, k, w, s, idx_out, val_out, zero_in_place, done));
+        if (done) return MIH_OK;
+    }
     uint64_t st[4] = {0ull, (uint64_t)k, 0ull, 0ull};
     MIH_HIP(hipMemcpyAsync(w.state.p, st, sizeof(st), hipMemcpyHostToDevice, s));
     int grid = (int)std::min<int64_t>((len + 255) / 256, 512);     // <= 512 blocks: 256 global adds per block at the end
