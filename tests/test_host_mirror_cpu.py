@@ -90,3 +90,15 @@ def test_struct_layout_matches_header_order(mih):
     assert fields("mih_fit_result") == [f[0] for f in api._FitResult._fields_]
     assert fields("mih_comm") == [f[0] for f in api._Comm._fields_]
     assert C.sizeof(api._Comm) == 48
+
+
+def test_bench_refuses_gpus_without_a_launcher():
+    """`bench.py --gpus N` outside torch.distributed.run used to measure ONE GPU silently: it must exit non-zero,
+    before touching any GPU, and print the launcher command."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode != 0
+    assert "torch.distributed.run" in r.stderr and "--nproc-per-node 4" in r.stderr
