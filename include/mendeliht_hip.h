@@ -291,7 +291,7 @@ int mih_set_xtv_variant(int variant);
 int mih_set_xtv_digits(int digits);
 /* Select the launch shape of the LDS-shared X'r kernels (0 = built-in defaults; ids in csrc/xtv.hip dispatch_xtv;
  * some ids are timing probes whose output is NOT X'r).  Tuning / measurement knob. */
-int mih_set_xtv_multi_variant(int variant);
+int mih_set_xtv_multi_variant(int variant);   /* 0 = defaults (LDS-DMA ring kernels); 1..15 = round-1 register-staged shapes (6 / 9: its defaults); 20.. = ring shapes; 30.., 49 = timing probes */
 
 #ifdef __cplusplus
 }
