@@ -1221,6 +1221,13 @@ constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kDefaultVariant = 2;
 constexpr int kMaxSplits = 16;
 int g_xtv_max_nr = 4;     // right-hand sides fused per pass (1, 2 or 4); 4 = LDS-shared digit planes
+// B operands per pass of the 16x16x128 ring kernel: 5 operands = 15 residuals (224 VGPRs, 155 KB of LDS at D = 4); 6 fit as well
+// (254 VGPRs, D = 3).  More residuals per pass amortise the genotype stream, the dosage staging and the barriers.
+static int fused_ops16()
+{
+    static const int v = []() { const char *e = getenv("MENDELIHT_XTV_MAX_OPS"); int x = e ? atoi(e) : 5; return x < 1 ? 1 : x > 6 ? 6 : x; }();
+    return v;
+}
 int g_xtv_multi_variant = 0;   // which 4-RHS kernel shape (tuning knob, mih_set_xtv_multi_variant)
 int xtv_num_variants() { return kNumVariants; }
 static bool xtv_variant_valid(int v) { return v < kNumVariants; }
@@ -1276,6 +1283,7 @@ static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 
         MIH_DMA16(4, 42, 2, 8, 3) MIH_DMA16(4, 43, 2, 8, 2)
         MIH_DMA16M(1, 49, 2, 8, 4, 3) MIH_DMA16M(4, 49, 2, 8, 4, 3)       // timing probes
         MIH_DMA16(1, 44, 2, 4, 8) MIH_DMA16(1, 45, 1, 8, 6) MIH_DMA16(1, 46, 2, 4, 6) MIH_DMA16(1, 47, 4, 4, 4) MIH_DMA16(1, 48, 2, 8, 6)
+        MIH_DMA16(6, -1, 2, 8, 3) MIH_DMA16(5, -1, 2, 8, 4)
         MIH_DMA16(4, -1, 2, 8, 4) MIH_DMA16(3, -1, 2, 8, 4) MIH_DMA16(2, -1, 2, 8, 4) MIH_DMA16(1, -1, 2, 8, 4)
     }
 #undef MIH_DMA16
@@ -1392,6 +1400,7 @@ int xtv_lockstep_width(const mih_mat *h)
     if (h->kind != 0) return 16;
     DigitMode dm;
     choose_mode(h, true, dm);
+    if (xtv_lay16(dm)) return 2 * fused_ops16() * dm.per_op;       // two lanes of one full pass each
     return 8 * dm.per_op;
 }
 
@@ -1481,6 +1490,10 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
     for (int t = 0; t < nops;) {          // t counts B operands
         int nr = (nops - t >= 4 && nops - t != 5 && g_xtv_max_nr >= 4) ? 4 : ((nops - t == 3 || nops - t == 5) && g_xtv_max_nr >= 4) ? 3
                  : (nops - t >= 2 && g_xtv_max_nr >= 2) ? 2 : 1;
+        if (dm.lay16 && g_xtv_max_nr >= 4) {          // up to fused_ops16() operands a pass, the remainder split evenly
+            const int rem = nops - t, mo = fused_ops16(), passes = (rem + mo - 1) / mo;
+            nr = (rem + passes - 1) / passes;
+        }
         const int u0 = t * per_op;        // first residual of this pass
         double *partial = w.partial.p + (int64_t)u0 * splits * pstride;
         const uint4 *dig = dig_all + (int64_t)t * nblk * 64;
