@@ -12,6 +12,7 @@
 #include "fit_common.h"
 #include <functional>
 #include <atomic>
+#include <mutex>
 #include <thread>
 #include <cstdlib>
 #include <algorithm>
@@ -1267,16 +1268,52 @@ static int cv_finish(CvFit &f, double *mses_raw)
 // hipFree waits for the OTHER lane's fused pass to finish.
 using MakeFit = std::function<int(size_t, CvFit &, hipStream_t)>;
 
+// Tail of the queue: once no new fits are left, the fits of both lanes thin out and two half-empty fused passes cost far more
+// than one fuller pass (6 + 6 residuals: 2 x 20.9 ms, 12 in one pass: 31.6 ms).  Lane 1 therefore hands ALL its fits over to
+// lane 0 as soon as they fit into lane 0's free slots, and ends.  A fit is handed over between two rounds, when everything it
+// queued on its lane's stream has completed; the adopting lane re-points it to its own stream and pool.
+struct CvHandover {
+    std::mutex mu;
+    std::vector<std::unique_ptr<CvFit>> orphans;    // handed over by lane 1, not yet adopted by lane 0
+    bool accepting = true;                          // lane 0 is still running rounds
+    std::atomic<int> active0{1 << 30};              // occupied slots of lane 0 (published once its view of the queue is drained)
+};
+
 static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t total, std::atomic<size_t> &next, int cap,
                           const MakeFit &make, XtvWork &xw, DevBuf<double> &R,
-                          DevBuf<double> &DF, hipStream_t s, double *mses_raw)
+                          DevBuf<double> &DF, hipStream_t s, double *mses_raw, CvHandover *ho = nullptr, int lane_id = 0)
 {
     std::vector<std::unique_ptr<IhtVar>> pool;            // declared before the slots: outlives them
     std::vector<std::unique_ptr<CvFit>> slot((size_t)cap);
     std::vector<CvFit *> need;
     std::vector<char> fresh;
     bool drained = false;                 // the shared queue is empty
+    auto occupied = [&]() { int c = 0; for (auto &sl : slot) c += sl != nullptr; return c; };
+    auto adopt = [&]() {                  // lane 0: take handed-over fits into free slots (caller holds ho->mu)
+        for (int t = 0; t < cap && !ho->orphans.empty(); ++t)
+            if (!slot[t]) {
+                slot[t] = std::move(ho->orphans.back());
+                ho->orphans.pop_back();
+                slot[t]->pool = &pool;
+                slot[t]->v->s = s;
+            }
+    };
     for (;;) {
+        if (ho && lane_id == 0) {
+            std::lock_guard<std::mutex> g(ho->mu);
+            adopt();
+            if (drained) ho->active0.store(occupied() + (int)ho->orphans.size());
+        }
+        if (ho && lane_id == 1 && drained) {             // between two rounds: every fit of this lane is quiescent
+            for (auto &sl : slot) if (sl && sl->done) sl.reset();         // finished in the last round: nothing to hand over
+            const int mine = occupied();
+            std::lock_guard<std::mutex> g(ho->mu);
+            if (mine > 0 && ho->accepting && mine + ho->active0.load() <= cap) {
+                for (auto &sl : slot) if (sl) { sl->pool = nullptr; ho->orphans.push_back(std::move(sl)); }
+                ho->active0.fetch_add(mine);
+                return MIH_OK;                           // lane 0 finishes them
+            }
+        }
         need.clear(); fresh.clear();
         for (int t = 0; t < cap; ++t) {
             for (;;) {
@@ -1302,7 +1339,14 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
                 break;
             }
         }
-        if (need.empty()) break;
+        if (need.empty()) {
+            if (ho && lane_id == 0) {                    // leave only when nothing was handed over in the meantime
+                std::lock_guard<std::mutex> g(ho->mu);
+                if (!ho->orphans.empty()) continue;
+                ho->accepting = false;
+            }
+            break;
+        }
         MIH_TRY(cv_batched_xtv(h, xw, need, R, DF, s));
         for (size_t t = 0; t < need.size(); ++t) {
             CvFit *f = need[t];
@@ -1326,7 +1370,9 @@ static int cv_run_lanes(const mih_mat *h, const mih_fit_params &pr, size_t total
     if (const char *e = getenv("MENDELIHT_CV_LANES")) { int v = atoi(e); if (v >= 1 && v <= 4) lanes = (int)std::min<size_t>((size_t)v, total); }
     const int cap = (int)std::min<size_t>((size_t)std::max(1, width / lanes), (total + lanes - 1) / lanes);
     std::atomic<size_t> next{0};
-    auto lane = [&]() -> int {
+    CvHandover handover;
+    const bool merge_tail = lanes == 2 && !getenv("MENDELIHT_CV_NO_MERGE");
+    auto lane = [&](int lane_id) -> int {
         MIH_HIP(hipSetDevice(h->device));
         hipStream_t s = nullptr;
         MIH_HIP(hipStreamCreate(&s));
@@ -1335,16 +1381,17 @@ static int cv_run_lanes(const mih_mat *h, const mih_fit_params &pr, size_t total
         MIH_TRY(xtv_work_init(h, xw, cap));
         MIH_TRY(R.alloc((size_t)cap * h->n));
         MIH_TRY(DF.alloc((size_t)cap * h->p));
-        return cv_run_rolling(h, pr, total, next, cap, make, xw, R, DF, s, mses_raw);
+        return cv_run_rolling(h, pr, total, next, cap, make, xw, R, DF, s, mses_raw, merge_tail ? &handover : nullptr, lane_id);
     };
-    if (lanes == 1) return lane();
+    if (lanes == 1) return lane(0);
     std::vector<int> rcs((size_t)lanes, MIH_OK);
     std::vector<std::string> msgs((size_t)lanes);
     std::vector<std::thread> th;
     for (int g = 0; g < lanes; ++g)
         th.emplace_back([&, g]() {
-            rcs[g] = lane();
+            rcs[g] = lane(g);
             if (rcs[g]) { char buf[512]; (void)mih_last_error(buf, sizeof(buf)); msgs[g] = buf; next.store(total); }   // the error text is thread-local
+            if (rcs[g] && g == 0) { std::lock_guard<std::mutex> lk(handover.mu); handover.accepting = false; }
         });
     for (auto &t : th) t.join();
     for (int g = 0; g < lanes; ++g)
