@@ -1366,7 +1366,7 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
 static int cv_run_lanes(const mih_mat *h, const mih_fit_params &pr, size_t total, const MakeFit &make, double *mses_raw)
 {
     const int width = xtv_lockstep_width(h);
-    int lanes = total > (size_t)width ? 2 : 1;      // measured: 100 fits 5.13 s with two lanes, 5.51 s with one, 6.15 s with three; 13 fits: no gain
+    int lanes = total > (size_t)width / 2 ? 2 : 1;  // more fits than one full pass holds: two lanes hide each other's per-fit chains (25 fits: 1.01 s against 1.06 s with one lane; 13 fits: 0.56 s with one lane, 0.65 s with two)
     if (const char *e = getenv("MENDELIHT_CV_LANES")) { int v = atoi(e); if (v >= 1 && v <= 4) lanes = (int)std::min<size_t>((size_t)v, total); }
     const int cap = (int)std::min<size_t>((size_t)std::max(1, width / lanes), (total + lanes - 1) / lanes);
     std::atomic<size_t> next{0};
