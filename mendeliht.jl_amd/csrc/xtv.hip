@@ -43,6 +43,7 @@
 // An operand carries one 28-digit base-4 residual, two 16-digit base-13 residuals, three 10-digit base-49 residuals,
 // or four 8-digit residuals (opt-in fast modes): DigitMode.
 #include "common.h"
+#include <algorithm>
 #include <mutex>
 #include <utility>
 
@@ -989,16 +990,19 @@ k_xtv_dma16(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *
     else xtv_epilogue16_s<CT, NR, 8>(acc, buf, lane, cg0, ncg, split, splits, dm, scal, partial);
 }
 
-// Combine slices, add the missing-entry correction, centre, scale.
+// Combine slices, add the missing-entry correction, centre, scale.  blockIdx.y = residual of the pass: partial, scal, r and
+// out advance by one residual's stride each (one launch per fused pass instead of one per residual).
 __global__ void __launch_bounds__(256)
 k_xtv_finalize(const double *__restrict__ partial, int splits, int64_t pstride, int64_t p,
-               const double *__restrict__ scal, const double *__restrict__ r,
+               const double *__restrict__ scal, const double *__restrict__ r, int64_t n,
                const double *__restrict__ mu, const double *__restrict__ sinv,
                const int64_t *__restrict__ miss_ptr, const int32_t *__restrict__ miss_row,
                int center, int scale, int impute, double *__restrict__ out)
 {
     int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (j >= p) return;
+    const int64_t u = blockIdx.y;
+    partial += u * splits * pstride; scal += 4 * u; r += u * n; out += u * p;
     double dot = 0.0;
     for (int s = 0; s < splits; ++s) dot += partial[(int64_t)s * pstride + j];
     double m = mu[j];
@@ -1503,11 +1507,12 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
         int rc = dispatch_xtv(v, nr, h, dig, dig2, nblk * 64, splits, dm, w.scal.p + 4 * u0, partial, s);
         prof_end(s, e0, e1);
         if (rc) return rc;
-        for (int u = u0; u < (t + nr) * per_op && u < m; ++u)
-            hipLaunchKernelGGL(k_xtv_finalize, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, s,
-                               w.partial.p + (int64_t)u * splits * pstride, splits, pstride, h->p,
-                               w.scal.p + 4 * u, r_dev + (int64_t)u * h->n, h->mu, h->sinv, h->miss_ptr, h->miss_row,
-                               h->center, h->scale, h->impute, out_dev + (int64_t)u * h->p);
+        const int u1 = std::min((t + nr) * per_op, m);
+        if (u1 > u0)
+            hipLaunchKernelGGL(k_xtv_finalize, dim3((unsigned)((h->p + 255) / 256), (unsigned)(u1 - u0)), dim3(256), 0, s,
+                               w.partial.p + (int64_t)u0 * splits * pstride, splits, pstride, h->p,
+                               w.scal.p + 4 * u0, r_dev + (int64_t)u0 * h->n, h->n, h->mu, h->sinv, h->miss_ptr, h->miss_row,
+                               h->center, h->scale, h->impute, out_dev + (int64_t)u0 * h->p);
         t += nr;
     }
     MIH_HIP(hipGetLastError());
