@@ -82,21 +82,19 @@ __global__ void __launch_bounds__(256)
 k_r_stats(const double *__restrict__ r, int64_t n, int m, double *__restrict__ part /* [m][gridDim.x][2] */)
 {
     __shared__ double smax[256], ssum[256];
-    for (int v = 0; v < m; ++v) {
-        double mx = 0.0, sm = 0.0;
-        for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-            double x = r[(int64_t)v * n + i];
-            mx = fmax(mx, fabs(x)); sm += x;
-        }
-        smax[threadIdx.x] = mx; ssum[threadIdx.x] = sm;
-        __syncthreads();
-        for (int k = 128; k > 0; k >>= 1) {
-            if ((int)threadIdx.x < k) { smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + k]); ssum[threadIdx.x] += ssum[threadIdx.x + k]; }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) { part[((int64_t)v * gridDim.x + blockIdx.x) * 2] = smax[0]; part[((int64_t)v * gridDim.x + blockIdx.x) * 2 + 1] = ssum[0]; }
+    const int v = blockIdx.y;                    // one grid row per residual
+    double mx = 0.0, sm = 0.0;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        double x = r[(int64_t)v * n + i];
+        mx = fmax(mx, fabs(x)); sm += x;
+    }
+    smax[threadIdx.x] = mx; ssum[threadIdx.x] = sm;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) { smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + k]); ssum[threadIdx.x] += ssum[threadIdx.x + k]; }
         __syncthreads();
     }
+    if (threadIdx.x == 0) { part[((int64_t)v * gridDim.x + blockIdx.x) * 2] = smax[0]; part[((int64_t)v * gridDim.x + blockIdx.x) * 2 + 1] = ssum[0]; }
 }
 
 __global__ void k_r_stats_final(const double *__restrict__ part, int nblocks, int m, int ebits, double *__restrict__ scal)
@@ -1485,7 +1483,7 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
     const int per_op = dm.per_op;
     const int nops = (m + per_op - 1) / per_op;
     double *part = w.scal.p + (size_t)w.ops_cap * per_op * 4;
-    hipLaunchKernelGGL(k_r_stats, dim3(kStatBlocks), dim3(256), 0, s, r_dev, h->n, m, part);
+    hipLaunchKernelGGL(k_r_stats, dim3(kStatBlocks, (unsigned)m), dim3(256), 0, s, r_dev, h->n, m, part);
     hipLaunchKernelGGL(k_r_stats_final, dim3(m), dim3(64), 0, s, part, kStatBlocks, m, dm.ebits, w.scal.p);
     uint4 *dig_all = reinterpret_cast<uint4 *>(w.digits.p);
     uint2 *dig2_all = reinterpret_cast<uint2 *>(w.digits.p + (size_t)w.ops_cap * (size_t)nblk * 64 * 4);   // FP6 only
