@@ -7,6 +7,7 @@
 // librccl is loaded lazily (dlopen) so that single-GPU users never need it.
 #include "common.h"
 #include <dlfcn.h>
+#include <mutex>
 
 namespace mih {
 
@@ -25,9 +26,11 @@ struct Rccl {
     const char *(*GetErrorString)(int) = nullptr;
 };
 static Rccl g_rccl;
+static std::mutex g_rccl_mu;
 
 static int rccl_load()
 {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);          // two lanes / host threads may make their first call together
     if (g_rccl.lib) return MIH_OK;
     const char *names[] = {getenv("MENDELIHT_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *lib = nullptr;

@@ -690,7 +690,7 @@ k_xtv_dma(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *__
             }
         }
         const uint32_t voff = lane * 16;
-        const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)lds;           // low 32 bits of a generic LDS address = the byte offset M0 takes
         const uint32_t mydos = wave * CT * 1024;
         const char *ldsb = reinterpret_cast<const char *>(lds);
 
@@ -901,7 +901,7 @@ k_xtv_dma16(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *
             }
         }
         const uint32_t voff = lane * 16;
-        const uint32_t lds0 = (uint32_t)(uintptr_t)lds;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)lds;           // low 32 bits of a generic LDS address = the byte offset M0 takes
         const uint32_t mydos = wave * CT * 1024;
         const char *ldsb = reinterpret_cast<const char *>(lds);
         // A fragment of SNP half a: the 8 bytes of row group (e, h) = (kq & 1, kq >> 1) of SNP 16 a + lane % 16
