@@ -783,7 +783,7 @@ __device__ __forceinline__ f32x4a mfma16(i32x4v a, const i32x8 &b, f32x4a acc)
     return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(aa, b, acc, 4, 2, 0, 0, 0, 0);
 }
 
-template <int CT, int NR, int SLOTS>
+template <int CT, int NR, int SLOTS, int HALF>
 __device__ __forceinline__ void xtv_epilogue16_s(const f32x4a (&acc)[CT][NR][2][2], float *buf, int lane, int64_t cg0, int64_t ncg,
                                                  int split, int splits, DigitMode dm, const double *__restrict__ scal,
                                                  double *__restrict__ partial)
@@ -800,20 +800,22 @@ __device__ __forceinline__ void xtv_epilogue16_s(const f32x4a (&acc)[CT][NR][2][
     }
     #pragma unroll
     for (int v = 0; v < NR; ++v) {
+        const bool cut = HALF && v == NR - 1;      // the pass's last operand: only the residuals of its first 16 columns exist
+        const int nsub = cut ? 16 / SLOTS : per_op;
         #pragma unroll
         for (int c = 0; c < CT; ++c) {
             __builtin_amdgcn_wave_barrier();
             #pragma unroll
             for (int a = 0; a < 2; ++a)
                 #pragma unroll
-                for (int b = 0; b < 2; ++b)      // D: column 16 b + lane % 16, SNP rows 16 a + 4 (lane / 16) + (0..3)
+                for (int b = 0; b < (cut ? 1 : 2); ++b)      // D: column 16 b + lane % 16, SNP rows 16 a + 4 (lane / 16) + (0..3)
                     *reinterpret_cast<f32x4v *>(buf + (16 * b + n16) * RS + 16 * a + 4 * rg) =
                         f32x4v{acc[c][v][a][b][0], acc[c][v][a][b][1], acc[c][v][a][b][2], acc[c][v][a][b][3]};
             __builtin_amdgcn_wave_barrier();
             #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const int o = lane + 64 * k, row = o & 31, sub = o >> 5;
-                if (sub < per_op) {
+                if (sub < nsub) {
                     const float *src = buf + sub * SLOTS * RS + row;
                     double x[SLOTS];
                     #pragma unroll
@@ -839,7 +841,9 @@ __device__ __forceinline__ void xtv_epilogue16_s(const f32x4a (&acc)[CT][NR][2][
     }
 }
 
-template <int NR, int CT, int WAVES, int D, int MODE = 0>       // MODE 3: timing probe, the odd 16-column fragments are skipped (result is NOT X'R)
+// HALF = 1: the second 16-column fragment of the pass's LAST operand holds no residual (1 residual of 10 digits, or 2 of 8,
+// in that operand: m = 3 j + 1 residuals in a pass) and its multiply-adds are left out -- 2 NR - 1 fragment items a step.
+template <int NR, int CT, int WAVES, int D, int MODE = 0, int HALF = 0>       // MODE 3: timing probe, the odd 16-column fragments are skipped (result is NOT X'R)
 __global__ void __launch_bounds__(WAVES * 64, 1)
 k_xtv_dma16(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *__restrict__ dig, const uint2 *__restrict__ dig2,
             int64_t dig_stride, int splits, DigitMode dm, const double *__restrict__ scal,
@@ -853,10 +857,12 @@ k_xtv_dma16(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *
     constexpr int NP = NR * 3;
     constexpr int PW = (NP + WAVES - 1) / WAVES;
     constexpr int L = CT + PW;
-    constexpr int NI = 2 * NR;                      // (operand, 16-column half) items of a step
+    constexpr int NI = 2 * NR - HALF;               // (operand, 16-column half) items of a step
+    constexpr int ODD = NI & 1;                     // odd item count: the B double buffer alternates from step to step
     static_assert(S * STAGE <= 160 * 1024, "LDS ring too large");
     static_assert(D * L <= 63, "vmcnt range");
     static_assert(S * STAGE >= WAVES * 32 * 36 * 4, "the epilogue buffers overlay the ring");
+    static_assert(HALF == 0 || MODE == 0, "probes run on full operands");
     __shared__ uint4 lds[S * STAGE / 16];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -960,18 +966,20 @@ k_xtv_dma16(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *
 #define MIH_DMA16_STEP(P, T)                                                                                       \
         {                                                                                                          \
             const int st_next = st + 1 == S ? 0 : st + 1, st_ld = st == 0 ? S - 1 : st - 1;                        \
+            constexpr int PB = (P) * ODD;          /* item i of this step sits in B[(i + PB) & 1] */               \
             issue((T) + D, st_ld);                                                                                 \
             _Pragma("unroll")                                                                                      \
             for (int i = 0; i < NI - 1; ++i) {                                                                     \
-                if (!(MODE == 3 && ((i + 1) & 1))) read_b(st, i + 1, B[(i + 1) & 1]);                              \
-                MIH_DMA16_ITEM(P, i, B[i & 1])                                                                     \
+                if (!(MODE == 3 && ((i + 1) & 1))) read_b(st, i + 1, B[(i + 1 + PB) & 1]);                         \
+                MIH_DMA16_ITEM(P, i, B[(i + PB) & 1])                                                              \
                 if (i == (NI > 2 ? NI / 2 - 1 : 0)) { wait_vm<D * L - CT>(); read_dos(st_next, araw); }            \
                 if (i == (NI > 2 ? NI / 2 : 0)) expand(araw, A[(P) ^ 1]);                                          \
             }                                                                                                      \
+            if (NI == 1) { wait_vm<D * L - CT>(); read_dos(st_next, araw); expand(araw, A[(P) ^ 1]); }             \
             wait_vm_barrier<(D - 1) * L>();                                                                        \
-            read_b(st_next, 0, B[0]);                                                                              \
+            read_b(st_next, 0, B[(NI + PB) & 1]);      /* = item 0 of the next step: ((P ^ 1) * ODD) & 1 */         \
             __builtin_amdgcn_sched_barrier(0);                                                                     \
-            MIH_DMA16_ITEM(P, NI - 1, B[1])                                                                        \
+            MIH_DMA16_ITEM(P, NI - 1, B[(NI - 1 + PB) & 1])                                                        \
             st = st_next;                                                                                          \
         }
         for (int t = 0; t < nb; t += 2) {
@@ -984,8 +992,8 @@ k_xtv_dma16(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *
     }
     if (cg0 >= ncg) return;
     float *buf = reinterpret_cast<float *>(lds) + wave * (32 * 36);
-    if (dm.slots == 10) xtv_epilogue16_s<CT, NR, 10>(acc, buf, lane, cg0, ncg, split, splits, dm, scal, partial);
-    else xtv_epilogue16_s<CT, NR, 8>(acc, buf, lane, cg0, ncg, split, splits, dm, scal, partial);
+    if (dm.slots == 10) xtv_epilogue16_s<CT, NR, 10, HALF>(acc, buf, lane, cg0, ncg, split, splits, dm, scal, partial);
+    else xtv_epilogue16_s<CT, NR, 8, HALF>(acc, buf, lane, cg0, ncg, split, splits, dm, scal, partial);
 }
 
 // Combine slices, add the missing-entry correction, centre, scale.  blockIdx.y = residual of the pass: partial, scal, r and
@@ -1252,14 +1260,9 @@ static void launch_xtv(const mih_mat *h, const uint4 *dig, int64_t dig_stride, i
 
 // nr B operands per pass: 1 = the tuned single-operand variants; 2 / 3 / 4 = fused passes (64 - 128 accumulator
 // registers).  Each operand carries per_op residual vectors.
-static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 *dig, const uint2 *dig2, int64_t dig_stride,
+static int dispatch_xtv(const Variant &v, int nr, bool half, const mih_mat *h, const uint4 *dig, const uint2 *dig2, int64_t dig_stride,
                         int splits, DigitMode dm, const double *scal, double *partial, hipStream_t s)
 {
-#define MIH_LDS6(NRV, ID, C, RB, W) if (nr == NRV && (mv6 == ID || ID < 0)) { \
-        int64_t groups = (h->ncg + W * C - 1) / (W * C); \
-        hipLaunchKernelGGL((k_xtv_mfma_lds<NRV, C, RB, 0, W, true>), dim3((unsigned)(groups * splits)), dim3(W * 64), 0, s, \
-                           reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig2, dig_stride, splits, dm, scal, partial); \
-        return MIH_OK; }
 #define MIH_LDS6(NRV, ID, C, RB, W) if (nr == NRV && (mv6 == ID || ID < 0)) { \
         int64_t groups = (h->ncg + W * C - 1) / (W * C); \
         hipLaunchKernelGGL((k_xtv_mfma_lds<NRV, C, RB, 0, W, true>), dim3((unsigned)(groups * splits)), dim3(W * 64), 0, s, \
@@ -1271,10 +1274,11 @@ static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 
                            reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig2, dig_stride, splits, dm, scal, partial); \
         return MIH_OK; }
     const int mv6 = g_xtv_multi_variant;
-#define MIH_DMA16(NRV, ID, C, W, DD) MIH_DMA16M(NRV, ID, C, W, DD, 0)
-#define MIH_DMA16M(NRV, ID, C, W, DD, MODE) if (nr == NRV && (mv6 == ID || ID < 0)) { \
+#define MIH_DMA16(NRV, ID, C, W, DD) MIH_DMA16M(NRV, ID, C, W, DD, 0, 0)
+#define MIH_DMA16H(NRV, C, W, DD) if (half) MIH_DMA16M(NRV, -1, C, W, DD, 0, 1)
+#define MIH_DMA16M(NRV, ID, C, W, DD, MODE, HF) if (nr == NRV && (mv6 == ID || ID < 0)) { \
         int64_t groups = (h->ncg + W * C - 1) / (W * C); \
-        hipLaunchKernelGGL((k_xtv_dma16<NRV, C, W, DD, MODE>), dim3((unsigned)(groups * splits)), dim3(W * 64), 0, s, \
+        hipLaunchKernelGGL((k_xtv_dma16<NRV, C, W, DD, MODE, HF>), dim3((unsigned)(groups * splits)), dim3(W * 64), 0, s, \
                            reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig2, dig_stride, splits, dm, scal, partial); \
         return MIH_OK; }
     if (dm.base == 49 && dm.lay16) {      // FP6 planes in the 16-column layout: the 16x16x128 kernels only
@@ -1283,12 +1287,15 @@ static int dispatch_xtv(const Variant &v, int nr, const mih_mat *h, const uint4 
         // 40.0 ms register-staged; tools/sweep_dma.py)
         MIH_DMA16(4, 40, 4, 4, 4) MIH_DMA16(3, 40, 4, 4, 4) MIH_DMA16(2, 40, 4, 4, 4) MIH_DMA16(1, 40, 4, 4, 4)
         MIH_DMA16(4, 42, 2, 8, 3) MIH_DMA16(4, 43, 2, 8, 2)
-        MIH_DMA16M(1, 49, 2, 8, 4, 3) MIH_DMA16M(4, 49, 2, 8, 4, 3)       // timing probes
+        MIH_DMA16M(1, 49, 2, 8, 4, 3, 0) MIH_DMA16M(4, 49, 2, 8, 4, 3, 0)       // timing probes
         MIH_DMA16(1, 44, 2, 4, 8) MIH_DMA16(1, 45, 1, 8, 6) MIH_DMA16(1, 46, 2, 4, 6) MIH_DMA16(1, 47, 4, 4, 4) MIH_DMA16(1, 48, 2, 8, 6)
+        // the last operand of the pass carries residuals in its first 16 columns only: 2 nr - 1 fragments
+        MIH_DMA16H(6, 2, 8, 3) MIH_DMA16H(5, 2, 8, 4) MIH_DMA16H(4, 2, 8, 4) MIH_DMA16H(3, 2, 8, 4) MIH_DMA16H(2, 2, 8, 4) MIH_DMA16H(1, 2, 8, 4)
         MIH_DMA16(6, -1, 2, 8, 3) MIH_DMA16(5, -1, 2, 8, 4)
         MIH_DMA16(4, -1, 2, 8, 4) MIH_DMA16(3, -1, 2, 8, 4) MIH_DMA16(2, -1, 2, 8, 4) MIH_DMA16(1, -1, 2, 8, 4)
     }
 #undef MIH_DMA16
+#undef MIH_DMA16H
 #undef MIH_DMA16M
     if (dm.base == 49) {           // FP6 digit planes
         // LDS-DMA ring kernels: tuning shapes (ids 20..), timing probes (30..: results are NOT X'R), then the defaults
@@ -1392,6 +1399,11 @@ static bool digit_mode(int id, DigitMode &dm)
 
 static void choose_mode(const mih_mat *h, bool batched, DigitMode &dm);
 // FP6 digit planes are written in the 16-column layout when the pass runs on the 16x16x128 kernels (ids 40..)
+static bool xtv_half_ok()       // MENDELIHT_XTV_NO_HALF=1: always multiply whole operands (A/B timing; same results)
+{
+    static const bool ok = [] { const char *e = getenv("MENDELIHT_XTV_NO_HALF"); return !(e && atoi(e) != 0); }();
+    return ok;
+}
 static bool xtv_lay16(const DigitMode &dm)
 {
     return dm.base == 49 && g_xtv_variant < 0 && (g_xtv_multi_variant == 0 || (g_xtv_multi_variant >= 40 && g_xtv_multi_variant < 50));
@@ -1502,10 +1514,12 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
         const uint2 *dig2 = dig2_all + (int64_t)t * nblk * 64;
         hipEvent_t e0, e1;
         prof_begin(s, e0, e1);
-        int rc = dispatch_xtv(v, nr, h, dig, dig2, nblk * 64, splits, dm, w.scal.p + 4 * u0, partial, s);
+        const int u1 = std::min((t + nr) * per_op, m);
+        // residuals in the pass's last operand; if they end within its first 16 columns the second fragment is left out
+        const bool half = dm.lay16 && xtv_half_ok() && (u1 - (t + nr - 1) * per_op) * dm.slots <= 16;
+        int rc = dispatch_xtv(v, nr, half, h, dig, dig2, nblk * 64, splits, dm, w.scal.p + 4 * u0, partial, s);
         prof_end(s, e0, e1);
         if (rc) return rc;
-        const int u1 = std::min((t + nr) * per_op, m);
         if (u1 > u0)
             hipLaunchKernelGGL(k_xtv_finalize, dim3((unsigned)((h->p + 255) / 256), (unsigned)(u1 - u0)), dim3(256), 0, s,
                                w.partial.p + (int64_t)u0 * splits * pstride, splits, pstride, h->p,
