@@ -344,11 +344,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    logl = bt = tol = None
-    nbt = 0
-    for _ in range(a.steps):
-        logl, bt, tol = sess.step()
-        nbt += bt
+    logl, nbt, tol = sess.run(a.steps)          # EXACTLY a.steps iterations, looped inside the library (mih_session_run)
     torch.cuda.synchronize()
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)

@@ -252,6 +252,9 @@ int mih_session_create(const mih_mat *h, const mih_fit_params *prm, const double
                        const double *z, int64_t q, const uint8_t *train, mih_session **out);
 /* save_prev! + iht_one_step! + check_convergence (fit.jl:182-193) */
 int mih_session_step(mih_session *s, double *logl, int32_t *backtracks, double *tol);
+/* `nsteps` such steps in one call -- the loop of fit_iht! (fit.jl:182-205) without its convergence test; logl and tol are
+ * those of the last step, *backtracks the total */
+int mih_session_run(mih_session *s, int64_t nsteps, double *logl, int64_t *backtracks, double *tol);
 /* current model (v.b, v.c), not the best-so-far copy */
 int mih_session_model(mih_session *s, double *beta, double *c);
 int mih_session_destroy(mih_session *s);

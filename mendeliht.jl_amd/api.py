@@ -124,6 +124,7 @@ def lib():
         "mih_abi_sizes": [vp, i32],
         "mih_session_create": [vp, C.POINTER(_FitParams), vp, vp, i64, vp, C.POINTER(vp)],
         "mih_session_step": [vp, C.POINTER(dbl), C.POINTER(i32), C.POINTER(dbl)],
+        "mih_session_run": [vp, i64, C.POINTER(dbl), C.POINTER(i64), C.POINTER(dbl)],
         "mih_session_model": [vp, vp, vp],
         "mih_session_destroy": [vp],
         "mih_rccl_unique_id": [vp],
@@ -149,7 +150,7 @@ def exported_symbols():
             "mih_project_topk", "mih_project_group_sparse", "mih_fit_iht", "mih_cv_iht", "mih_cv_meanloss", "mih_cv_iht_multi", "mih_fit_iht_path",
             "mih_fit_mv", "mih_cv_mv", "mih_bench_xtv", "mih_bench_xtv_batched", "mih_xtv_algorithmic_bytes", "mih_set_xtv_variant",
             "mih_set_xtv_multi_variant", "mih_set_xtv_digits", "mih_abi_sizes",
-            "mih_session_create", "mih_session_step", "mih_session_model", "mih_session_destroy",
+            "mih_session_create", "mih_session_step", "mih_session_run", "mih_session_model", "mih_session_destroy",
             "mih_rccl_unique_id", "mih_comm_create_rccl", "mih_comm_destroy_rccl",
             "mih_profile_enable", "mih_profile_read"]
 
@@ -541,6 +542,12 @@ class IHTSession:
     def step(self):
         logl, bt, tol = C.c_double(0), C.c_int32(0), C.c_double(0)
         _check(lib().mih_session_step(self._h, C.byref(logl), C.byref(bt), C.byref(tol)))
+        return logl.value, bt.value, tol.value
+
+    def run(self, nsteps):
+        """`nsteps` iterations in one library call; returns (logl, total backtracks, tol) of the last one."""
+        logl, bt, tol = C.c_double(0), C.c_int64(0), C.c_double(0)
+        _check(lib().mih_session_run(self._h, int(nsteps), C.byref(logl), C.byref(bt), C.byref(tol)))
         return logl.value, bt.value, tol.value
 
     def model(self):

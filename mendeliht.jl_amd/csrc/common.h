@@ -61,14 +61,47 @@ struct PinBuf {
     PinBuf(const PinBuf &) = delete;
     PinBuf &operator=(const PinBuf &) = delete;
     ~PinBuf() { if (p) (void)hipHostFree(p); }
-    int alloc(size_t count) {
+    // coherent = true: fine-grained host memory a kernel may write while the host polls it (SpinFlag landing areas)
+    int alloc(size_t count, bool coherent = false) {
         if (p) { (void)hipHostFree(p); p = nullptr; n = 0; }
         if (count == 0) count = 1;
-        if (hipHostMalloc((void **)&p, count * sizeof(T), hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc(%zu bytes) failed", count * sizeof(T)); (void)hipGetLastError(); p = nullptr; return MIH_OOM; }
+        if (hipHostMalloc((void **)&p, count * sizeof(T), coherent ? hipHostMallocCoherent : hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc(%zu bytes) failed", count * sizeof(T)); (void)hipGetLastError(); p = nullptr; return MIH_OOM; }
         n = count;
         return MIH_OK;
     }
 };
+
+// Small results come home without a stream synchronisation: the LAST kernel of a chain (k_publish, one block) copies them
+// into pinned host memory itself and then stores a sequence number there (system-scope release); the host spins on that
+// word.  A device-to-host copy followed by hipStreamSynchronize costs one more queued operation and 25-30 us of wake-up
+// latency per readback, three to five times per IHT iteration.  After `spin_us` without the flag the host falls back to
+// hipStreamSynchronize (a fused pass of tens of ms is in front of the chain, or something failed: the error surfaces there).
+// MENDELIHT_NO_SPIN=1: always copy + hipStreamSynchronize.
+struct SpinFlag {
+    PinBuf<uint64_t> word;          // [0] = sequence number of the last published readback
+    uint64_t seq = 0;
+};
+// dst_host[0 .. words) <- src_dev[0 .. words) (64-bit words); pairs_first >= 0: src_dev = {count, pad, pairs...} and only
+// 2 + 2 * min(count, pairs_first) words travel (the projection's survivor list).  Returns after the data has landed.
+int readback_words(hipStream_t s, SpinFlag &f, const uint64_t *src_dev, uint64_t *dst_host, size_t words, int64_t pairs_first = -1);
+
+// Small host lists (support indices, coefficients, cache slots) reach the device without copy operations: the host writes
+// them into a slot of a ring of pinned memory and the consuming kernel reads that slot itself, once per entry.  A copy from a
+// pageable std::vector costs 10-20 us of host time and a queued operation each, four to seven times per IHT iteration.
+// A slot is reused after kSlots - 1 further puts; put() synchronises the stream first unless the owner has reported a
+// synchronisation (synced(): every readback is one) since the slot was handed out.
+struct HostStage {
+    static constexpr int kSlots = 8;
+    PinBuf<uint64_t> ring;
+    size_t slot_words = 0;
+    int next = 0, since_sync = 0;
+    int init(size_t words_per_slot) { slot_words = words_per_slot; next = 0; since_sync = 0; return ring.alloc(words_per_slot * kSlots, true); }
+    // nullptr in *out: does not fit a slot (the caller copies the old way)
+    int put(hipStream_t s, const void *a, size_t bytes_a, const void *b, size_t bytes_b, const uint64_t **out);
+    void synced() { since_sync = 0; }
+};
+// dst_a[0 .. words_a) <- src[0 .. words_a), dst_b[0 .. words_b) <- src[words_a ..): one launch instead of two copies
+void stage_to_device(hipStream_t s, const uint64_t *src_pinned, uint64_t *dst_a, size_t words_a, uint64_t *dst_b, size_t words_b);
 
 }  // namespace mih
 
@@ -165,7 +198,8 @@ int  xv_work_init(const mih_mat *h, XvWork &w, int64_t max_nnz);
 // out[i] = sum_t x[i, idx[t]] * val[t]; idx/val on device; clamp20 applies clamp!(out,-20,20).  idx_host (the same
 // indices on the host) enables the column cache.
 int  xv_sparse_device(const mih_mat *h, XvWork &w, const int64_t *idx_dev, const double *val_dev,
-                      int64_t nnz, double *out_dev, int clamp20, hipStream_t s, const int64_t *idx_host = nullptr);
+                      int64_t nnz, double *out_dev, int clamp20, hipStream_t s, const int64_t *idx_host = nullptr,
+                      HostStage *st = nullptr);
 
 // m coefficient vectors over the same support (vals_dev[v*nnz + t], out_dev[v*n + i]); no clamp
 int  xv_sparse_multi_device(const mih_mat *h, XvWork &w, const int64_t *idx_dev, const double *vals_dev, int64_t nnz, int m,
@@ -180,6 +214,7 @@ struct TopkWork {
     int64_t cap = 0;           // pairs the buffer can hold after the header
     int64_t expect = 0;        // survivors expected by the caller (k + slack): fetched with the count in ONE copy
     bool radix8 = false;       // MENDELIHT_TOPK_RADIX8=1: always the 8 x 8-bit select (the two-pass select's fallback)
+    SpinFlag flag;             // the survivor list comes home through k_publish
 };
 int  topk_work_init(TopkWork &w, int64_t max_keep);
 // In-place project_k! on a device vector; returns threshold and survivors (sorted by index) on host.

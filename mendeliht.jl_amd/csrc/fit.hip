@@ -471,7 +471,8 @@ struct IhtVar {
         int64_t kcap = std::max<int64_t>(std::max<int64_t>(J, 1) * k + q, 64) + 1024;
         for (int64_t v : ks) kcap += v;
         MIH_TRY(sidx.alloc(kcap)); MIH_TRY(sval.alloc(kcap)); MIH_TRY(gval.alloc(kcap));
-        MIH_TRY(hpin.alloc((size_t)kcap + kMaxQ + 16));
+        MIH_TRY(stage.init(2 * (size_t)kcap + 8));
+        MIH_TRY(hpin.alloc((size_t)kcap + kMaxQ + 16, true));
         if (!batched) MIH_TRY(xtv_work_init(h, xtv, 1, false));
         MIH_TRY(xv_work_init(h, xv, kcap));
         MIH_TRY(topk_work_init(topk, kcap));
@@ -518,15 +519,42 @@ struct IhtVar {
         if ((size_t)nnz <= sidx.n) return MIH_OK;
         MIH_HIP(hipStreamSynchronize(s));
         MIH_TRY(sidx.alloc((size_t)nnz * 2)); MIH_TRY(sval.alloc((size_t)nnz * 2)); MIH_TRY(gval.alloc((size_t)nnz * 2));
+        MIH_TRY(stage.init((size_t)nnz * 4));
+        stage_forget();
         return MIH_OK;
     }
+    // What the staging buffers sidx / sval hold on the device.  A step re-sends the same lists several times (the support of
+    // update_xb! again in the gather of the next score and, unless the step backtracked, in the next gradient step): a list
+    // that is already there is not sent again, a new one goes through the pinned ring (HostStage) and ONE small kernel.
+    HostStage stage;
+    std::vector<int64_t> dev_idx; std::vector<double> dev_val; bool dev_idx_ok = false, dev_val_ok = false;
+    void stage_forget() { dev_idx_ok = dev_val_ok = false; }
     int upload(const std::vector<int64_t> &ix, const std::vector<double> &vl)
     {
         MIH_TRY(ensure_stage((int64_t)ix.size()));
-        if (!ix.empty()) {
+        if (ix.empty()) return MIH_OK;
+        if (dev_idx_ok && dev_val_ok && dev_idx == ix && dev_val.size() == vl.size() &&
+            std::memcmp(dev_val.data(), vl.data(), sizeof(double) * vl.size()) == 0) return MIH_OK;       // bits, not values: -0.0 != 0.0 here
+        const uint64_t *pin = nullptr;
+        MIH_TRY(stage.put(s, ix.data(), sizeof(int64_t) * ix.size(), vl.data(), sizeof(double) * vl.size(), &pin));
+        if (pin) stage_to_device(s, pin, reinterpret_cast<uint64_t *>(sidx.p), ix.size(), reinterpret_cast<uint64_t *>(sval.p), vl.size());
+        else {
             MIH_HIP(hipMemcpyAsync(sidx.p, ix.data(), sizeof(int64_t) * ix.size(), hipMemcpyHostToDevice, s));
             MIH_HIP(hipMemcpyAsync(sval.p, vl.data(), sizeof(double) * vl.size(), hipMemcpyHostToDevice, s));
         }
+        dev_idx = ix; dev_val = vl; dev_idx_ok = dev_val_ok = true;
+        return MIH_OK;
+    }
+    int upload_idx(const std::vector<int64_t> &ix)       // sidx only; sval keeps its content only if the list is unchanged
+    {
+        MIH_TRY(ensure_stage((int64_t)ix.size()));
+        if (ix.empty()) return MIH_OK;
+        if (dev_idx_ok && dev_idx == ix) return MIH_OK;
+        const uint64_t *pin = nullptr;
+        MIH_TRY(stage.put(s, ix.data(), sizeof(int64_t) * ix.size(), nullptr, 0, &pin));
+        if (pin) stage_to_device(s, pin, reinterpret_cast<uint64_t *>(sidx.p), ix.size(), nullptr, 0);
+        else MIH_HIP(hipMemcpyAsync(sidx.p, ix.data(), sizeof(int64_t) * ix.size(), hipMemcpyHostToDevice, s));
+        dev_idx = ix; dev_idx_ok = true; dev_val_ok = false;
         return MIH_OK;
     }
     QVec qvec(const std::vector<double> &v) const { QVec o; for (int l = 0; l < kMaxQ; ++l) o.v[l] = l < q ? v[l] : 0.0; return o; }
@@ -550,11 +578,11 @@ struct IhtVar {
         int clamp = (dist != MIH_NORMAL);
         MIH_TRY(upload(b.idx, b.val));
         if (comm) {          // partial X_S b_S of the local support columns, summed over the shards, then the clamp
-            MIH_TRY(xv_sparse_device(h, xv, sidx.p, sval.p, (int64_t)b.idx.size(), xb.p, 0, s, b.idx.data()));
+            MIH_TRY(xv_sparse_device(h, xv, sidx.p, sval.p, (int64_t)b.idx.size(), xb.p, 0, s, b.idx.data(), &stage));
             MIH_TRY(allreduce_dev(xb.p, n, 0));
             if (clamp) hipLaunchKernelGGL(k_clamp_pm20, dim3(nblk(n)), dim3(256), 0, s, xb.p, n);
         } else
-        MIH_TRY(xv_sparse_device(h, xv, sidx.p, sval.p, (int64_t)b.idx.size(), xb.p, clamp, s, b.idx.data()));
+        MIH_TRY(xv_sparse_device(h, xv, sidx.p, sval.p, (int64_t)b.idx.size(), xb.p, clamp, s, b.idx.data(), &stage));
         hipLaunchKernelGGL(k_zmul, dim3(nblk(n)), dim3(256), 0, s, z.p, n, q, qvec(c), clamp, zc.p);
         return MIH_OK;
     }
@@ -563,8 +591,7 @@ struct IhtVar {
     {
         hipLaunchKernelGGL(k_mu_loglik, dim3(nb), dim3(256), 0, s, xb.p, zc.p, y.p, w.p, n, dist, link, nb_r, with_zc, mu.p, red.p);
         hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, s, red.p, nb, 4, scal.p);
-        MIH_HIP(hipMemcpyAsync(hpin.p, scal.p, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
-        MIH_HIP(hipStreamSynchronize(s));
+        MIH_TRY(readback(scal.p, 4));
         MIH_HIP(hipGetLastError());                  // a failed launch anywhere in this iteration's chain surfaces here
         const double o[4] = {hpin.p[0], hpin.p[1], hpin.p[2], hpin.p[3]};
         if (dev) *dev = o[0];
@@ -604,6 +631,14 @@ struct IhtVar {
         MIH_HIP(hipMemcpyAsync(hpin.p + (hpin.n - kMaxQ), scal.p, sizeof(double) * q, hipMemcpyDeviceToHost, s));
         return MIH_OK;
     }
+    // `count` doubles of a device buffer into hpin[0..count) without a stream synchronisation (SpinFlag, common.h)
+    SpinFlag flag;
+    int readback(const double *src_dev, size_t count)
+    {
+        MIH_TRY(readback_words(s, flag, reinterpret_cast<const uint64_t *>(src_dev), reinterpret_cast<uint64_t *>(hpin.p), count));
+        stage.synced();          // everything queued before has run: the ring's slots are free again
+        return MIH_OK;
+    }
     bool df2_pending = false;
     void take_df2() { if (df2_pending) { for (int l = 0; l < q; ++l) df2[l] = hpin.p[hpin.n - kMaxQ + l]; df2_pending = false; } }
     int gather_df_support()
@@ -611,10 +646,9 @@ struct IhtVar {
         int64_t nnz = (int64_t)idx.idx.size();
         idx.val.assign(nnz, 0.0);
         if (nnz) {
-            MIH_TRY(ensure_stage(nnz));
-            MIH_HIP(hipMemcpyAsync(sidx.p, idx.idx.data(), sizeof(int64_t) * nnz, hipMemcpyHostToDevice, s));
+            MIH_TRY(upload_idx(idx.idx));
             hipLaunchKernelGGL(k_gather, dim3(nblk(nnz)), dim3(256), 0, s, df.p, sidx.p, nnz, gval.p);
-            if ((size_t)nnz + kMaxQ > hpin.n) { MIH_HIP(hipStreamSynchronize(s)); take_df2(); MIH_TRY(hpin.alloc((size_t)nnz * 2 + kMaxQ + 16)); }
+            if ((size_t)nnz + kMaxQ > hpin.n) { MIH_HIP(hipStreamSynchronize(s)); take_df2(); MIH_TRY(hpin.alloc((size_t)nnz * 2 + kMaxQ + 16, true)); }
             MIH_HIP(hipMemcpyAsync(hpin.p, gval.p, sizeof(double) * nnz, hipMemcpyDeviceToHost, s));
         }
         MIH_HIP(hipStreamSynchronize(s));
@@ -755,6 +789,7 @@ struct IhtVar {
             std::vector<double> hw(snp.idx.size());
             MIH_TRY(ensure_stage((int64_t)snp.idx.size()));
             if (!snp.idx.empty()) {
+                stage_forget();
                 MIH_HIP(hipMemcpyAsync(sidx.p, snp.idx.data(), sizeof(int64_t) * snp.idx.size(), hipMemcpyHostToDevice, s));
                 hipLaunchKernelGGL(k_gather, dim3(nblk((int64_t)snp.idx.size())), dim3(256), 0, s, weight.p, sidx.p, (int64_t)snp.idx.size(), gval.p);
                 MIH_HIP(hipMemcpyAsync(hw.data(), gval.p, sizeof(double) * hw.size(), hipMemcpyDeviceToHost, s));
@@ -854,6 +889,7 @@ struct IhtVar {
         if (has_weight && !snp.idx.empty()) {
             std::vector<double> hw(snp.idx.size());
             MIH_TRY(ensure_stage((int64_t)snp.idx.size()));
+            stage_forget();
             MIH_HIP(hipMemcpyAsync(sidx.p, snp.idx.data(), sizeof(int64_t) * snp.idx.size(), hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(k_gather, dim3(nblk((int64_t)snp.idx.size())), dim3(256), 0, s, weight.p, sidx.p, (int64_t)snp.idx.size(), gval.p);
             MIH_HIP(hipMemcpyAsync(hw.data(), gval.p, sizeof(double) * hw.size(), hipMemcpyDeviceToHost, s));
@@ -941,7 +977,7 @@ struct IhtVar {
         }
         spec_ok = false;
         MIH_TRY(upload(idx.idx, idx.val));
-        MIH_TRY(xv_sparse_device(h, xv, sidx.p, sval.p, (int64_t)idx.idx.size(), xgk.p, 0, s, idx.idx.data()));
+        MIH_TRY(xv_sparse_device(h, xv, sidx.p, sval.p, (int64_t)idx.idx.size(), xgk.p, 0, s, idx.idx.data(), &stage));
         std::vector<double> d2(q);
         double numer = 0.0;
         for (size_t t = 0; t < idx.val.size(); ++t) numer += idx.val[t] * idx.val[t];
@@ -949,8 +985,7 @@ struct IhtVar {
         for (int l = 0; l < q; ++l) { d2[l] = idc[l] ? df2[l] : 0.0; if (idc[l]) numer += df2[l] * df2[l]; }
         hipLaunchKernelGGL(k_stepsize, dim3(nb), dim3(256), 0, s, xgk.p, z.p, xb.p, zc.p, mu.p, w.p, n, q, qvec(d2), dist, link, nb_r, red.p);
         hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, s, red.p, nb, 1, scal.p);
-        MIH_HIP(hipMemcpyAsync(hpin.p, scal.p, sizeof(double), hipMemcpyDeviceToHost, s));
-        MIH_HIP(hipStreamSynchronize(s));
+        MIH_TRY(readback(scal.p, 1));
         const double denom = hpin.p[0];
         double e = numer / denom;
         if (std::isinf(e) || std::isnan(e)) e = 1e-8;
@@ -1078,18 +1113,17 @@ struct IhtVar {
         hipLaunchKernelGGL(k_zt_r, dim3(kZtrBlocks, q), dim3(256), 0, s, z.p, r.p, n, ztr.p);
         hipLaunchKernelGGL(k_zt_r_final, dim3(q), dim3(64), 0, s, ztr.p, gval.p + nnz);            // df2 behind df_S
         if (nnz) {
-            MIH_HIP(hipMemcpyAsync(sidx.p, idx.idx.data(), sizeof(int64_t) * nnz, hipMemcpyHostToDevice, s));
+            MIH_TRY(upload_idx(idx.idx));
             hipLaunchKernelGGL(k_gather, dim3(nblk(nnz)), dim3(256), 0, s, df.p, sidx.p, nnz, gval.p);
         }
-        MIH_TRY(xv_sparse_device(h, xv, sidx.p, gval.p, nnz, xgk.p, 0, s, idx.idx.data()));
+        MIH_TRY(xv_sparse_device(h, xv, sidx.p, gval.p, nnz, xgk.p, 0, s, idx.idx.data(), &stage));
         unsigned long long mask = 0ull;
         for (int l = 0; l < q; ++l) if (idc[l]) mask |= 1ull << l;
         hipLaunchKernelGGL(k_stepsize_dev, dim3(nb), dim3(256), 0, s, xgk.p, z.p, xb.p, zc.p, mu.p, w.p, n, q, gval.p + nnz, mask,
                            dist, link, nb_r, red.p);
         hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, s, red.p, nb, 1, gval.p + nnz + q);
-        if ((size_t)nnz + q + 1 > hpin.n) MIH_TRY(hpin.alloc((size_t)nnz * 2 + kMaxQ + 16));
-        MIH_HIP(hipMemcpyAsync(hpin.p, gval.p, sizeof(double) * (size_t)(nnz + q + 1), hipMemcpyDeviceToHost, s));
-        MIH_HIP(hipStreamSynchronize(s));
+        if ((size_t)nnz + q + 1 > hpin.n) MIH_TRY(hpin.alloc((size_t)nnz * 2 + kMaxQ + 16, true));
+        MIH_TRY(readback(gval.p, (size_t)(nnz + q + 1)));
         idx.val.assign(hpin.p, hpin.p + nnz);
         for (int l = 0; l < q; ++l) df2[l] = hpin.p[nnz + l];
         df2_pending = false;
@@ -1574,6 +1608,18 @@ int mih_session_step(mih_session *ss, double *logl, int32_t *backtracks, double 
     if (logl) *logl = s->next_logl;
     if (backtracks) *backtracks = nbt;
     if (tol) *tol = s->v.check_convergence();
+    return MIH_OK;
+}
+
+int mih_session_run(mih_session *ss, int64_t nsteps, double *logl, int64_t *backtracks, double *tol)
+{
+    int64_t total = 0;
+    for (int64_t t = 0; t < nsteps; ++t) {
+        int32_t nbt = 0;
+        MIH_TRY(mih_session_step(ss, logl, &nbt, tol));
+        total += nbt;
+    }
+    if (backtracks) *backtracks = total;
     return MIH_OK;
 }
 

@@ -6,6 +6,7 @@
 // histograms (exact, order-independent => the selected support is reproducible),
 // then one threshold pass that also compacts the survivors.
 #include "common.h"
+#include <chrono>
 #include <algorithm>
 #include <cstring>
 #include <functional>
@@ -203,6 +204,68 @@ k_zero_below(double *__restrict__ x, int64_t len, uint64_t thr)
     for (; i < len; i += stride) { const double v = x[i]; if (abs_key(v) < thr && v != 0.0) x[i] = 0.0; }
 }
 
+__global__ void __launch_bounds__(256)
+k_publish(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst_host, uint64_t words, long long pairs_first,
+          uint64_t *__restrict__ flag_host, uint64_t seq)
+{
+    if (pairs_first >= 0) {
+        const uint64_t cnt = src[0];
+        words = 2 + 2 * (cnt < (uint64_t)pairs_first ? cnt : (uint64_t)pairs_first);
+    }
+    for (uint64_t i = threadIdx.x; i < words; i += 256) dst_host[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int readback_words(hipStream_t s, SpinFlag &f, const uint64_t *src_dev, uint64_t *dst_host, size_t words, int64_t pairs_first)
+{
+    static const bool spin = [] { const char *e = getenv("MENDELIHT_NO_SPIN"); return !(e && atoi(e) != 0); }();
+    if (!spin || words == 0) {
+        if (words) MIH_HIP(hipMemcpyAsync(dst_host, src_dev, sizeof(uint64_t) * words, hipMemcpyDeviceToHost, s));
+        MIH_HIP(hipStreamSynchronize(s));
+        return MIH_OK;
+    }
+    if (!f.word.p) { MIH_TRY(f.word.alloc(8, true)); f.word.p[0] = 0; f.seq = 0; }
+    const uint64_t seq = ++f.seq;
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, s, src_dev, dst_host, (uint64_t)words, (long long)pairs_first, f.word.p, seq);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned it = 0;; ++it) {
+        if (__atomic_load_n(f.word.p, __ATOMIC_ACQUIRE) == seq) return MIH_OK;
+        __builtin_ia32_pause();
+        if ((it & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) break;
+    }
+    MIH_HIP(hipStreamSynchronize(s));          // a long kernel sits in front of the chain (or a launch failed: reported here)
+    if (__atomic_load_n(f.word.p, __ATOMIC_ACQUIRE) != seq) { set_error("readback kernel did not complete"); return MIH_HIP_ERROR; }
+    return MIH_OK;
+}
+
+__global__ void __launch_bounds__(256)
+k_stage(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst_a, uint64_t words_a, uint64_t *__restrict__ dst_b, uint64_t words_b)
+{
+    const uint64_t i = blockIdx.x * 256ull + threadIdx.x;
+    if (i < words_a) dst_a[i] = src[i];
+    else if (i < words_a + words_b) dst_b[i - words_a] = src[i];
+}
+void stage_to_device(hipStream_t s, const uint64_t *src_pinned, uint64_t *dst_a, size_t words_a, uint64_t *dst_b, size_t words_b)
+{
+    const size_t tot = words_a + words_b;
+    if (tot) hipLaunchKernelGGL(k_stage, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, src_pinned, dst_a, (uint64_t)words_a, dst_b, (uint64_t)words_b);
+}
+int HostStage::put(hipStream_t s, const void *a, size_t bytes_a, const void *b, size_t bytes_b, const uint64_t **out)
+{
+    *out = nullptr;
+    const size_t wa = (bytes_a + 7) / 8, wb = (bytes_b + 7) / 8;
+    if (!ring.p || wa + wb > slot_words) return MIH_OK;
+    if (since_sync >= kSlots - 1) { MIH_HIP(hipStreamSynchronize(s)); since_sync = 0; }     // the slot may still be unread
+    uint64_t *dst = ring.p + (size_t)next * slot_words;
+    if (bytes_a) std::memcpy(dst, a, bytes_a);
+    if (bytes_b) std::memcpy(dst + wa, b, bytes_b);
+    next = (next + 1) % kSlots; ++since_sync;
+    *out = dst;
+    return MIH_OK;
+}
+
 int topk_work_init(TopkWork &w, int64_t max_keep)
 {
     MIH_TRY(w.hist.alloc(kBins11));
@@ -212,7 +275,7 @@ int topk_work_init(TopkWork &w, int64_t max_keep)
     w.expect = max_keep + 64;
     w.cap = max_keep + 1024;
     MIH_TRY(w.sel.alloc(2 + 2 * (size_t)w.cap));
-    MIH_TRY(w.hsel.alloc(2 + 2 * (size_t)w.expect));
+    MIH_TRY(w.hsel.alloc(2 + 2 * (size_t)w.expect, true));
     return MIH_OK;
 }
 
@@ -267,8 +330,7 @@ static int topk_two_pass(double *x_dev, int64_t len, int64_t k, TopkWork &w, hip
     hipLaunchKernelGGL(k_pick11, dim3(1), dim3(256), 0, s, w.hist.p, w.state.p, 1, (uint64_t)k, w.sel.p);
     hipLaunchKernelGGL(k_collect, dim3(grid), dim3(256), 0, s, x_dev, len, w.state.p, w.sel.p, (uint32_t)w.cap);
     const int64_t first = std::min<int64_t>(w.expect, w.cap);
-    MIH_HIP(hipMemcpyAsync(w.hsel.p, w.sel.p, sizeof(uint64_t) * (2 + 2 * (size_t)first), hipMemcpyDeviceToHost, s));
-    MIH_HIP(hipStreamSynchronize(s));
+    MIH_TRY(readback_words(s, w.flag, w.sel.p, w.hsel.p, 2 + 2 * (size_t)first, first));
     const int64_t cnt = (int64_t)w.hsel.p[0];
     if (cnt > w.cap) return MIH_OK;                        // massive ties: the exact 8-bit select handles any count
     std::vector<uint64_t> host(w.hsel.p, w.hsel.p + 2 + 2 * (size_t)std::min<int64_t>(cnt, first));

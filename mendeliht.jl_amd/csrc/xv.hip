@@ -11,12 +11,15 @@
 
 namespace mih {
 
+// slots_pinned != nullptr: the cache slots of the support sit in pinned host memory (HostStage) and are taken along
 __global__ void k_xv_coef(const int64_t *__restrict__ idx, const double *__restrict__ val, int64_t nnz,
                           const double *__restrict__ mu, const double *__restrict__ sinv,
-                          int center, int scale, double *__restrict__ A, double *__restrict__ B)
+                          int center, int scale, double *__restrict__ A, double *__restrict__ B,
+                          const int32_t *__restrict__ slots_pinned = nullptr, int32_t *__restrict__ slots_dev = nullptr)
 {
     int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (t >= nnz) return;
+    if (slots_pinned) slots_dev[t] = slots_pinned[t];
     int64_t j = idx[t];
     double s = scale ? sinv[j] : 1.0;
     double a = s * val[t];
@@ -316,7 +319,7 @@ static bool xv_cache_lookup(XvWork &w, const int64_t *idx_host, int64_t nnz, std
 }
 
 int xv_sparse_device(const mih_mat *h, XvWork &w, const int64_t *idx_dev, const double *val_dev,
-                     int64_t nnz, double *out_dev, int clamp20, hipStream_t s, const int64_t *idx_host)
+                     int64_t nnz, double *out_dev, int clamp20, hipStream_t s, const int64_t *idx_host, HostStage *st)
 {
     if (nnz == 0) {
         MIH_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * (size_t)h->n, s));
@@ -331,17 +334,24 @@ int xv_sparse_device(const mih_mat *h, XvWork &w, const int64_t *idx_dev, const 
     int groups = (int)(nnz < w.groups ? nnz : w.groups);
     int64_t np = (h->kind == 0) ? h->n_pad : h->n;
     if (h->kind == 0) {
-        hipLaunchKernelGGL(k_xv_coef, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, s, idx_dev, val_dev, nnz,
-                           h->mu, h->sinv, h->center, h->scale, w.coefA.p, w.coefB.p);
         int64_t ndw = h->n_pad / 16;
         bool fix = h->impute && h->total_missing > 0;
         std::vector<int32_t> &slots = w.h_slots; std::vector<int64_t> &fills = w.h_fills;
-        if (idx_host && h->p < (1ll << 40) && xv_cache_lookup(w, idx_host, nnz, slots, fills)) {
-            MIH_HIP(hipMemcpyAsync(w.slot_dev.p, slots.data(), sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, s));
+        const bool cached = idx_host && h->p < (1ll << 40) && xv_cache_lookup(w, idx_host, nnz, slots, fills);
+        // the slot list and the fill list travel through the caller's pinned ring when there is one: k_xv_coef takes the
+        // slots along, k_xv_fill reads its (slot, column) pairs there -- no copy operations
+        const uint64_t *pin = nullptr;
+        if (cached && st) MIH_TRY(st->put(s, slots.data(), sizeof(int32_t) * (size_t)nnz, fills.data(), sizeof(int64_t) * fills.size(), &pin));
+        const int32_t *slots_pin = reinterpret_cast<const int32_t *>(pin);
+        const int64_t *fills_pin = pin ? reinterpret_cast<const int64_t *>(pin + ((size_t)nnz * sizeof(int32_t) + 7) / 8) : nullptr;
+        hipLaunchKernelGGL(k_xv_coef, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, s, idx_dev, val_dev, nnz,
+                           h->mu, h->sinv, h->center, h->scale, w.coefA.p, w.coefB.p, slots_pin, w.slot_dev.p);
+        if (cached) {
+            if (!pin) MIH_HIP(hipMemcpyAsync(w.slot_dev.p, slots.data(), sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, s));
             if (!fills.empty()) {
-                MIH_HIP(hipMemcpyAsync(w.fill_dev.p, fills.data(), sizeof(int64_t) * fills.size(), hipMemcpyHostToDevice, s));
+                if (!pin) MIH_HIP(hipMemcpyAsync(w.fill_dev.p, fills.data(), sizeof(int64_t) * fills.size(), hipMemcpyHostToDevice, s));
                 hipLaunchKernelGGL(k_xv_fill, dim3((unsigned)((ndw + 255) / 256), (unsigned)fills.size()), dim3(256), 0, s, h->X, h->nbp, ndw,
-                                   w.fill_dev.p, w.cache.p);
+                                   pin ? fills_pin : w.fill_dev.p, w.cache.p);
             }
             hipLaunchKernelGGL(k_xv_snp_cached, dim3((unsigned)((ndw + 15) / 16)), dim3(256), 0, s, w.cache.p, ndw, h->n,
                                w.slot_dev.p, w.coefA.p, w.coefB.p, nnz, groups, fix ? 0 : clamp20, out_dev);
