@@ -84,6 +84,21 @@ struct SpinFlag {
 // dst_host[0 .. words) <- src_dev[0 .. words) (64-bit words); pairs_first >= 0: src_dev = {count, pad, pairs...} and only
 // 2 + 2 * min(count, pairs_first) words travel (the projection's survivor list).  Returns after the data has landed.
 int readback_words(hipStream_t s, SpinFlag &f, const uint64_t *src_dev, uint64_t *dst_host, size_t words, int64_t pairs_first = -1);
+// The same in two halves, for a chain whose last kernel publishes by itself (publish_block): spin_begin hands out the sequence
+// number that kernel must store (0: polling is off, use a copy + hipStreamSynchronize), spin_wait returns once it is there.
+uint64_t spin_begin(SpinFlag &f);
+int spin_wait(hipStream_t s, SpinFlag &f, uint64_t seq);
+#if defined(__HIPCC__)
+// whole block: words of device memory -> pinned host memory, then the sequence number (system-scope release)
+__device__ __forceinline__ void publish_block(const uint64_t *src, uint64_t *dst_host, uint64_t words, uint64_t *flag_host, uint64_t seq)
+{
+    for (uint64_t i = threadIdx.x; i < words; i += blockDim.x)
+        dst_host[i] = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // past the CU's vector cache
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+#endif
 
 // Small host lists (support indices, coefficients, cache slots) reach the device without copy operations: the host writes
 // them into a slot of a ring of pinned memory and the consuming kernel reads that slot itself, once per entry.  A copy from a
@@ -163,6 +178,7 @@ struct XtvWork {            // scratch for one in-flight X'r
     DevBuf<uint32_t> digits;   // ops * nblk * 64 lanes * 4 dwords (+ 2 dwords, stored behind, for FP6) : digit planes of r (B operands)
     DevBuf<double>   partial;  // splits * rhs * ncg*32 raw dots
     DevBuf<double>   scal;     // rhs * 4 : {max|r|, 2^-e, sum r, 2^e}
+    DevBuf<unsigned> stat_done; // rhs : blocks of k_r_stats that have delivered their partial (zero between launches)
     int m_cap = 0, splits_cap = 0;
     DigitMode dm = {13, 16, 2, 16, 56, 20};   // fixed at init (mih_set_xtv_digits)
     int ops_cap = 0;           // B operands the buffers hold
@@ -199,7 +215,8 @@ int  xv_work_init(const mih_mat *h, XvWork &w, int64_t max_nnz);
 // indices on the host) enables the column cache.
 int  xv_sparse_device(const mih_mat *h, XvWork &w, const int64_t *idx_dev, const double *val_dev,
                       int64_t nnz, double *out_dev, int clamp20, hipStream_t s, const int64_t *idx_host = nullptr,
-                      HostStage *st = nullptr);
+                      HostStage *st = nullptr, const double *gather_src = nullptr, double *gather_out = nullptr);
+// gather_src != nullptr: val_dev is ignored, the coefficients are gather_src[idx[t]] and are also left in gather_out
 
 // m coefficient vectors over the same support (vals_dev[v*nnz + t], out_dev[v*n + i]); no clamp
 int  xv_sparse_multi_device(const mih_mat *h, XvWork &w, const int64_t *idx_dev, const double *vals_dev, int64_t nnz, int m,

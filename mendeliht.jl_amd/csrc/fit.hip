@@ -82,20 +82,24 @@ k_resid(const double *__restrict__ xb, const double *__restrict__ zc, const doub
 // df2 = Z' r (utilities.jl:134): kZtrBlocks workgroups per covariate (grid.y), fixed-order trees
 constexpr int kZtrBlocks = 128;
 __global__ void __launch_bounds__(256)
-k_zt_r(const double *__restrict__ z, const double *__restrict__ r, int64_t n, double *__restrict__ part)
+k_zt_r(const double *__restrict__ z, const double *__restrict__ r, int64_t n, double *__restrict__ part,
+       unsigned *__restrict__ done /* [q], zero */, double *__restrict__ out)
 {
     const double *zl = z + (int64_t)blockIdx.y * n;
     double v[1] = {0.0};
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += 256ll * kZtrBlocks) v[0] += zl[i] * r[i];
     block_sum<1>(v, part + (int64_t)blockIdx.y * kZtrBlocks + blockIdx.x);
-}
-__global__ void __launch_bounds__(64)
-k_zt_r_final(const double *__restrict__ part, double *__restrict__ out)
-{
-    if (threadIdx.x != 0) return;
-    double a = 0.0;
-    for (int b = 0; b < kZtrBlocks; ++b) a += part[(int64_t)blockIdx.x * kZtrBlocks + b];
-    out[blockIdx.x] = a;
+    if (threadIdx.x == 0) {           // the block that delivers last adds the partials in block order (k_zt_r_final's sum)
+        __threadfence();
+        if (atomicAdd(&done[blockIdx.y], 1u) == (unsigned)kZtrBlocks - 1) {
+            __threadfence();
+            double a = 0.0;
+            for (int b = 0; b < kZtrBlocks; ++b)
+                a += __hip_atomic_load(&part[(int64_t)blockIdx.y * kZtrBlocks + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out[blockIdx.y] = a;
+            done[blockIdx.y] = 0;
+        }
+    }
 }
 
 // NegBin nuisance-parameter sums over all samples (utilities.jl:158-173 MM, :186-194 Newton).
@@ -404,6 +408,7 @@ struct IhtVar {
     hipStream_t s = nullptr;
     // device
     DevBuf<double> y, z, w, xb, zc, mu, r, xgk, df, full, weight, red, scal, gval, ztr;
+    DevBuf<unsigned> ztr_done;
     DevBuf<int64_t> sidx; DevBuf<double> sval;   // staging for support lists
     DevBuf<uint8_t> mask;
     XtvWork xtv; XvWork xv; TopkWork topk;
@@ -468,6 +473,7 @@ struct IhtVar {
         MIH_TRY(zc.alloc(n)); MIH_TRY(mu.alloc(n)); MIH_TRY(r.alloc(n)); MIH_TRY(xgk.alloc(n));
         MIH_TRY(df.alloc(p)); MIH_TRY(full.alloc((size_t)p + q)); MIH_TRY(mask.alloc(n));
         MIH_TRY(red.alloc((size_t)nb * 4)); MIH_TRY(scal.alloc(kMaxQ + 8)); MIH_TRY(ztr.alloc((size_t)kMaxQ * kZtrBlocks));
+        MIH_TRY(ztr_done.alloc(kMaxQ)); MIH_HIP(hipMemsetAsync(ztr_done.p, 0, sizeof(unsigned) * kMaxQ, s));      // k_zt_r leaves the counters at zero
         int64_t kcap = std::max<int64_t>(std::max<int64_t>(J, 1) * k + q, 64) + 1024;
         for (int64_t v : ks) kcap += v;
         MIH_TRY(sidx.alloc(kcap)); MIH_TRY(sval.alloc(kcap)); MIH_TRY(gval.alloc(kcap));
@@ -590,8 +596,7 @@ struct IhtVar {
     int mu_loglik(int with_zc, double *logl, double *dev)
     {
         hipLaunchKernelGGL(k_mu_loglik, dim3(nb), dim3(256), 0, s, xb.p, zc.p, y.p, w.p, n, dist, link, nb_r, with_zc, mu.p, red.p);
-        hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, s, red.p, nb, 4, scal.p);
-        MIH_TRY(readback(scal.p, 4));
+        MIH_TRY(final_sum_home(4, scal.p, scal.p, 4));
         MIH_HIP(hipGetLastError());                  // a failed launch anywhere in this iteration's chain surfaces here
         const double o[4] = {hpin.p[0], hpin.p[1], hpin.p[2], hpin.p[3]};
         if (dev) *dev = o[0];
@@ -625,8 +630,7 @@ struct IhtVar {
     }
     int score_post()       // df is in place (own X'r pass or the batch driver's)
     {
-        hipLaunchKernelGGL(k_zt_r, dim3(kZtrBlocks, q), dim3(256), 0, s, z.p, r.p, n, ztr.p);
-        hipLaunchKernelGGL(k_zt_r_final, dim3(q), dim3(64), 0, s, ztr.p, scal.p);
+        hipLaunchKernelGGL(k_zt_r, dim3(kZtrBlocks, q), dim3(256), 0, s, z.p, r.p, n, ztr.p, ztr_done.p, scal.p);
         df2_pending = true;                       // lands in pinned memory; copied out at the next synchronisation
         MIH_HIP(hipMemcpyAsync(hpin.p + (hpin.n - kMaxQ), scal.p, sizeof(double) * q, hipMemcpyDeviceToHost, s));
         return MIH_OK;
@@ -637,6 +641,19 @@ struct IhtVar {
     {
         MIH_TRY(readback_words(s, flag, reinterpret_cast<const uint64_t *>(src_dev), reinterpret_cast<uint64_t *>(hpin.p), count));
         stage.synced();          // everything queued before has run: the ring's slots are free again
+        return MIH_OK;
+    }
+    // the second stage of a block reduction (nv sums over the nb rows of `red`) and the way home of `count` doubles in ONE kernel
+    int final_sum_home(int nv, double *out_dev, const double *src_dev, size_t count)
+    {
+        const uint64_t seq = spin_begin(flag);
+        if (!seq) {
+            hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, s, red.p, nb, nv, out_dev);
+            return readback(src_dev, count);
+        }
+        hipLaunchKernelGGL(k_final_sum_pub, dim3(1), dim3(256), 0, s, red.p, nb, nv, out_dev, src_dev, hpin.p, (uint64_t)count, flag.word.p, seq);
+        MIH_TRY(spin_wait(s, flag, seq));
+        stage.synced();
         return MIH_OK;
     }
     bool df2_pending = false;
@@ -984,8 +1001,7 @@ struct IhtVar {
         if (comm) { MIH_TRY(allreduce_dev(xgk.p, n, 0)); MIH_TRY(allreduce_host(&numer, 1, 0)); }
         for (int l = 0; l < q; ++l) { d2[l] = idc[l] ? df2[l] : 0.0; if (idc[l]) numer += df2[l] * df2[l]; }
         hipLaunchKernelGGL(k_stepsize, dim3(nb), dim3(256), 0, s, xgk.p, z.p, xb.p, zc.p, mu.p, w.p, n, q, qvec(d2), dist, link, nb_r, red.p);
-        hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, s, red.p, nb, 1, scal.p);
-        MIH_TRY(readback(scal.p, 1));
+        MIH_TRY(final_sum_home(1, scal.p, scal.p, 1));
         const double denom = hpin.p[0];
         double e = numer / denom;
         if (std::isinf(e) || std::isnan(e)) e = 1e-8;
@@ -1110,20 +1126,15 @@ struct IhtVar {
     {
         const int64_t nnz = (int64_t)idx.idx.size();
         MIH_TRY(ensure_stage(nnz + kMaxQ + 2));
-        hipLaunchKernelGGL(k_zt_r, dim3(kZtrBlocks, q), dim3(256), 0, s, z.p, r.p, n, ztr.p);
-        hipLaunchKernelGGL(k_zt_r_final, dim3(q), dim3(64), 0, s, ztr.p, gval.p + nnz);            // df2 behind df_S
-        if (nnz) {
-            MIH_TRY(upload_idx(idx.idx));
-            hipLaunchKernelGGL(k_gather, dim3(nblk(nnz)), dim3(256), 0, s, df.p, sidx.p, nnz, gval.p);
-        }
-        MIH_TRY(xv_sparse_device(h, xv, sidx.p, gval.p, nnz, xgk.p, 0, s, idx.idx.data(), &stage));
+        hipLaunchKernelGGL(k_zt_r, dim3(kZtrBlocks, q), dim3(256), 0, s, z.p, r.p, n, ztr.p, ztr_done.p, gval.p + nnz);     // df2 behind df_S
+        if (nnz) MIH_TRY(upload_idx(idx.idx));
+        MIH_TRY(xv_sparse_device(h, xv, sidx.p, gval.p, nnz, xgk.p, 0, s, idx.idx.data(), &stage, df.p, gval.p));    // df_S gathered on the way
         unsigned long long mask = 0ull;
         for (int l = 0; l < q; ++l) if (idc[l]) mask |= 1ull << l;
         hipLaunchKernelGGL(k_stepsize_dev, dim3(nb), dim3(256), 0, s, xgk.p, z.p, xb.p, zc.p, mu.p, w.p, n, q, gval.p + nnz, mask,
                            dist, link, nb_r, red.p);
-        hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, s, red.p, nb, 1, gval.p + nnz + q);
-        if ((size_t)nnz + q + 1 > hpin.n) MIH_TRY(hpin.alloc((size_t)nnz * 2 + kMaxQ + 16, true));
-        MIH_TRY(readback(gval.p, (size_t)(nnz + q + 1)));
+        if ((size_t)nnz + q + 1 > hpin.n) { MIH_HIP(hipStreamSynchronize(s)); MIH_TRY(hpin.alloc((size_t)nnz * 2 + kMaxQ + 16, true)); }
+        MIH_TRY(final_sum_home(1, gval.p + nnz + q, gval.p, (size_t)(nnz + q + 1)));
         idx.val.assign(hpin.p, hpin.p + nnz);
         for (int l = 0; l < q; ++l) df2[l] = hpin.p[nnz + l];
         df2_pending = false;

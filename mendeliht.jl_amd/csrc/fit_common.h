@@ -42,6 +42,25 @@ static __global__ void k_final_sum(const double *__restrict__ partial, int nbloc
     }
 }
 
+// k_final_sum that also brings results home (publish_block): `words` doubles from pub_src, which may contain `out`
+static __global__ void k_final_sum_pub(const double *__restrict__ partial, int nblocks, int nv, double *__restrict__ out,
+                                       const double *pub_src, double *pub_dst_host, uint64_t words, uint64_t *flag_host, uint64_t seq)
+{
+    __shared__ double red[256];
+    for (int k = 0; k < nv; ++k) {
+        double a = 0.0;
+        for (int b = threadIdx.x; b < nblocks; b += 256) a += partial[(int64_t)b * nv + k];
+        red[threadIdx.x] = a;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+        if (threadIdx.x == 0) out[k] = red[0];
+        __syncthreads();
+    }
+    __threadfence();
+    __syncthreads();
+    publish_block(reinterpret_cast<const uint64_t *>(pub_src), reinterpret_cast<uint64_t *>(pub_dst_host), words, flag_host, seq);
+}
+
 static __global__ void k_gather(const double *__restrict__ src, const int64_t *__restrict__ idx, int64_t nnz,
                          double *__restrict__ out)
 {

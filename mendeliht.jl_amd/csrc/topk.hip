@@ -212,23 +212,22 @@ k_publish(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst_host, uin
         const uint64_t cnt = src[0];
         words = 2 + 2 * (cnt < (uint64_t)pairs_first ? cnt : (uint64_t)pairs_first);
     }
-    for (uint64_t i = threadIdx.x; i < words; i += 256) dst_host[i] = src[i];
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    publish_block(src, dst_host, words, flag_host, seq);
 }
 
-int readback_words(hipStream_t s, SpinFlag &f, const uint64_t *src_dev, uint64_t *dst_host, size_t words, int64_t pairs_first)
+static bool spin_on()
 {
-    static const bool spin = [] { const char *e = getenv("MENDELIHT_NO_SPIN"); return !(e && atoi(e) != 0); }();
-    if (!spin || words == 0) {
-        if (words) MIH_HIP(hipMemcpyAsync(dst_host, src_dev, sizeof(uint64_t) * words, hipMemcpyDeviceToHost, s));
-        MIH_HIP(hipStreamSynchronize(s));
-        return MIH_OK;
-    }
-    if (!f.word.p) { MIH_TRY(f.word.alloc(8, true)); f.word.p[0] = 0; f.seq = 0; }
-    const uint64_t seq = ++f.seq;
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, s, src_dev, dst_host, (uint64_t)words, (long long)pairs_first, f.word.p, seq);
+    static const bool on = [] { const char *e = getenv("MENDELIHT_NO_SPIN"); return !(e && atoi(e) != 0); }();
+    return on;
+}
+uint64_t spin_begin(SpinFlag &f)
+{
+    if (!spin_on()) return 0;
+    if (!f.word.p) { if (f.word.alloc(8, true)) return 0; f.word.p[0] = 0; f.seq = 0; }
+    return ++f.seq;
+}
+int spin_wait(hipStream_t s, SpinFlag &f, uint64_t seq)
+{
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned it = 0;; ++it) {
         if (__atomic_load_n(f.word.p, __ATOMIC_ACQUIRE) == seq) return MIH_OK;
@@ -238,6 +237,17 @@ int readback_words(hipStream_t s, SpinFlag &f, const uint64_t *src_dev, uint64_t
     MIH_HIP(hipStreamSynchronize(s));          // a long kernel sits in front of the chain (or a launch failed: reported here)
     if (__atomic_load_n(f.word.p, __ATOMIC_ACQUIRE) != seq) { set_error("readback kernel did not complete"); return MIH_HIP_ERROR; }
     return MIH_OK;
+}
+int readback_words(hipStream_t s, SpinFlag &f, const uint64_t *src_dev, uint64_t *dst_host, size_t words, int64_t pairs_first)
+{
+    const uint64_t seq = words ? spin_begin(f) : 0;
+    if (!seq) {
+        if (words) MIH_HIP(hipMemcpyAsync(dst_host, src_dev, sizeof(uint64_t) * words, hipMemcpyDeviceToHost, s));
+        MIH_HIP(hipStreamSynchronize(s));
+        return MIH_OK;
+    }
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, s, src_dev, dst_host, (uint64_t)words, (long long)pairs_first, f.word.p, seq);
+    return spin_wait(s, f, seq);
 }
 
 __global__ void __launch_bounds__(256)

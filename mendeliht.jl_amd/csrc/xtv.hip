@@ -78,10 +78,14 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 // ---- residual -> fixed-point digit planes -------------------------------------------------
 // scal[4v + 0] = max|r_v|, scal[4v + 1] = 2^-e, scal[4v + 2] = sum r_v, scal[4v + 3] = 2^e
+// The block that finishes last (a counter per residual, left at zero again) adds up the partials in block order and
+// writes scal: one launch instead of two; the sums do not depend on which block that is.
 __global__ void __launch_bounds__(256)
-k_r_stats(const double *__restrict__ r, int64_t n, int m, double *__restrict__ part /* [m][gridDim.x][2] */)
+k_r_stats(const double *__restrict__ r, int64_t n, int m, double *__restrict__ part /* [m][gridDim.x][2] */,
+          unsigned *__restrict__ done /* [m], zero */, int ebits, double *__restrict__ scal)
 {
     __shared__ double smax[256], ssum[256];
+    __shared__ bool last;
     const int v = blockIdx.y;                    // one grid row per residual
     double mx = 0.0, sm = 0.0;
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -94,23 +98,29 @@ k_r_stats(const double *__restrict__ r, int64_t n, int m, double *__restrict__ p
         if ((int)threadIdx.x < k) { smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + k]); ssum[threadIdx.x] += ssum[threadIdx.x + k]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { part[((int64_t)v * gridDim.x + blockIdx.x) * 2] = smax[0]; part[((int64_t)v * gridDim.x + blockIdx.x) * 2 + 1] = ssum[0]; }
-}
-
-__global__ void k_r_stats_final(const double *__restrict__ part, int nblocks, int m, int ebits, double *__restrict__ scal)
-{
-    int v = blockIdx.x;
-    if (threadIdx.x != 0 || v >= m) return;
-    double mx = 0.0, sm = 0.0;
-    for (int b = 0; b < nblocks; ++b) { mx = fmax(mx, part[((int64_t)v * nblocks + b) * 2]); sm += part[((int64_t)v * nblocks + b) * 2 + 1]; }
-    // exponent e with max|r| * 2^e < 2^(ebits+1) (DigitMode::ebits); an all-zero (or non-finite) residual keeps e = 0
-    int e = 0;
-    if (mx > 0.0 && mx < 1.0e300) e = ebits - ilogb(mx);
-    if (e > 1000) e = 1000;          // a (numerically zero) residual below 2^-947: keep 2^e finite
-    scal[4 * v + 0] = mx;
-    scal[4 * v + 1] = ldexp(1.0, -e);
-    scal[4 * v + 2] = sm;
-    scal[4 * v + 3] = ldexp(1.0, e);
+    if (threadIdx.x == 0) {
+        const int nblocks = (int)gridDim.x;
+        part[((int64_t)v * nblocks + blockIdx.x) * 2] = smax[0]; part[((int64_t)v * nblocks + blockIdx.x) * 2 + 1] = ssum[0];
+        __threadfence();
+        last = atomicAdd(&done[v], 1u) == (unsigned)nblocks - 1;
+        if (last) {
+            __threadfence();
+            double fmx = 0.0, fsm = 0.0;
+            for (int b = 0; b < nblocks; ++b) {
+                fmx = fmax(fmx, __hip_atomic_load(&part[((int64_t)v * nblocks + b) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                fsm += __hip_atomic_load(&part[((int64_t)v * nblocks + b) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // exponent e with max|r| * 2^e < 2^(ebits+1) (DigitMode::ebits); an all-zero (or non-finite) residual keeps e = 0
+            int e = 0;
+            if (fmx > 0.0 && fmx < 1.0e300) e = ebits - ilogb(fmx);
+            if (e > 1000) e = 1000;          // a (numerically zero) residual below 2^-947: keep 2^e finite
+            scal[4 * v + 0] = fmx;
+            scal[4 * v + 1] = ldexp(1.0, -e);
+            scal[4 * v + 2] = fsm;
+            scal[4 * v + 3] = ldexp(1.0, e);
+            done[v] = 0;
+        }
+    }
 }
 
 // digit of residue m (0..12) in the base-13 system: {-8,-6,-4..4,6,8} is a complete residue system mod 13 whose
@@ -1452,6 +1462,8 @@ int xtv_work_init(const mih_mat *h, XtvWork &w, int m, bool batched)
     MIH_TRY(w.digits.alloc(dwords));
     MIH_TRY(w.partial.alloc((size_t)kMaxSplits * rhs_cap * (size_t)h->ncg * 32));
     MIH_TRY(w.scal.alloc(rhs_cap * 4 + (size_t)m * kStatBlocks * 2));
+    MIH_TRY(w.stat_done.alloc(rhs_cap));
+    MIH_HIP(hipMemset(w.stat_done.p, 0, sizeof(unsigned) * rhs_cap));       // k_r_stats leaves its counters at zero
     MIH_HIP(hipMemsetAsync(w.digits.p, 0, sizeof(*w.digits.p) * dwords, h->stream));
     MIH_HIP(hipMemsetAsync(w.scal.p, 0, sizeof(double) * rhs_cap * 4, h->stream));
     MIH_HIP(hipStreamSynchronize(h->stream));
@@ -1495,8 +1507,7 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
     const int per_op = dm.per_op;
     const int nops = (m + per_op - 1) / per_op;
     double *part = w.scal.p + (size_t)w.ops_cap * per_op * 4;
-    hipLaunchKernelGGL(k_r_stats, dim3(kStatBlocks, (unsigned)m), dim3(256), 0, s, r_dev, h->n, m, part);
-    hipLaunchKernelGGL(k_r_stats_final, dim3(m), dim3(64), 0, s, part, kStatBlocks, m, dm.ebits, w.scal.p);
+    hipLaunchKernelGGL(k_r_stats, dim3(kStatBlocks, (unsigned)m), dim3(256), 0, s, r_dev, h->n, m, part, w.stat_done.p, dm.ebits, w.scal.p);
     uint4 *dig_all = reinterpret_cast<uint4 *>(w.digits.p);
     uint2 *dig2_all = reinterpret_cast<uint2 *>(w.digits.p + (size_t)w.ops_cap * (size_t)nblk * 64 * 4);   // FP6 only
     hipLaunchKernelGGL(k_digits, dim3((unsigned)((nblk + 3) / 4), (unsigned)(nops * per_op)), dim3(256), 0, s, r_dev, h->n, nblk, m, dm,

@@ -11,18 +11,26 @@
 
 namespace mih {
 
+static __global__ void k_xv_gather(const double *__restrict__ src, const int64_t *__restrict__ idx, int64_t nnz, double *__restrict__ out)
+{
+    int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t < nnz) out[t] = src[idx[t]];
+}
 // slots_pinned != nullptr: the cache slots of the support sit in pinned host memory (HostStage) and are taken along
 __global__ void k_xv_coef(const int64_t *__restrict__ idx, const double *__restrict__ val, int64_t nnz,
                           const double *__restrict__ mu, const double *__restrict__ sinv,
                           int center, int scale, double *__restrict__ A, double *__restrict__ B,
-                          const int32_t *__restrict__ slots_pinned = nullptr, int32_t *__restrict__ slots_dev = nullptr)
+                          const int32_t *__restrict__ slots_pinned = nullptr, int32_t *__restrict__ slots_dev = nullptr,
+                          const double *__restrict__ gather_src = nullptr, double *__restrict__ gather_out = nullptr)
 {
     int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (t >= nnz) return;
     if (slots_pinned) slots_dev[t] = slots_pinned[t];
     int64_t j = idx[t];
     double s = scale ? sinv[j] : 1.0;
-    double a = s * val[t];
+    double v = val ? val[t] : gather_src[j];          // the coefficients are gathered on the way (df on the support)
+    if (gather_out) gather_out[t] = v;
+    double a = s * v;
     A[t] = a;
     B[t] = center ? -mu[j] * a : 0.0;
 }
@@ -319,8 +327,13 @@ static bool xv_cache_lookup(XvWork &w, const int64_t *idx_host, int64_t nnz, std
 }
 
 int xv_sparse_device(const mih_mat *h, XvWork &w, const int64_t *idx_dev, const double *val_dev,
-                     int64_t nnz, double *out_dev, int clamp20, hipStream_t s, const int64_t *idx_host, HostStage *st)
+                     int64_t nnz, double *out_dev, int clamp20, hipStream_t s, const int64_t *idx_host, HostStage *st,
+                     const double *gather_src, double *gather_out)
 {
+    if (gather_src && (h->kind != 0 || nnz == 0)) {          // only the 2-bit path gathers inside its coefficient kernel
+        if (nnz) hipLaunchKernelGGL(k_xv_gather, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, s, gather_src, idx_dev, nnz, gather_out);
+        val_dev = gather_out; gather_src = nullptr;
+    }
     if (nnz == 0) {
         MIH_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * (size_t)h->n, s));
         return MIH_OK;
@@ -344,8 +357,9 @@ int xv_sparse_device(const mih_mat *h, XvWork &w, const int64_t *idx_dev, const 
         if (cached && st) MIH_TRY(st->put(s, slots.data(), sizeof(int32_t) * (size_t)nnz, fills.data(), sizeof(int64_t) * fills.size(), &pin));
         const int32_t *slots_pin = reinterpret_cast<const int32_t *>(pin);
         const int64_t *fills_pin = pin ? reinterpret_cast<const int64_t *>(pin + ((size_t)nnz * sizeof(int32_t) + 7) / 8) : nullptr;
-        hipLaunchKernelGGL(k_xv_coef, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, s, idx_dev, val_dev, nnz,
-                           h->mu, h->sinv, h->center, h->scale, w.coefA.p, w.coefB.p, slots_pin, w.slot_dev.p);
+        hipLaunchKernelGGL(k_xv_coef, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, s, idx_dev, gather_src ? nullptr : val_dev, nnz,
+                           h->mu, h->sinv, h->center, h->scale, w.coefA.p, w.coefB.p, slots_pin, w.slot_dev.p, gather_src, gather_out);
+        if (gather_src) val_dev = gather_out;
         if (cached) {
             if (!pin) MIH_HIP(hipMemcpyAsync(w.slot_dev.p, slots.data(), sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, s));
             if (!fills.empty()) {
