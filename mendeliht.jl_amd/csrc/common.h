@@ -196,6 +196,7 @@ extern int g_xtv_variant;
 struct XvWork {
     DevBuf<double> partial;   // groups * n (dense matrices only)
     DevBuf<double> coefA, coefB;  // per support column: sinv*val, -mu*sinv*val
+    DevBuf<double> coefG;         // multi-trait products: per trait and column group, the group's sum of coefB
     int64_t cap = 0; int groups = 0;
     // Column cache (2-bit matrices): in the tile-major layout a column shares every 64 B sector with its tile
     // neighbours, so reading k support columns costs 4-8x their size.  The support changes slowly, so each

@@ -232,6 +232,27 @@ struct MvVar {
     hipStream_t s = nullptr;
     DevBuf<double> Y, Z, w, BX, MU, RES, T1, DF, full, red, scal, gval, tmpn;
     DevBuf<int64_t> sidx; DevBuf<double> sval; DevBuf<uint8_t> mask; DevBuf<int32_t> pairs;
+    // small results come home through a polled flag (SpinFlag, common.h); the column list and the [trait][column] coefficient
+    // matrix go up from pinned memory (every upload is followed by a readback before the next one overwrites the buffer)
+    SpinFlag flag; PinBuf<double> hpin; PinBuf<double> upin;
+    int readback(const double *src_dev, size_t count, double *dst)
+    {
+        if (count > hpin.n) { MIH_HIP(hipStreamSynchronize(s)); MIH_TRY(hpin.alloc(count * 2 + 64, true)); }
+        MIH_TRY(readback_words(s, flag, reinterpret_cast<const uint64_t *>(src_dev), reinterpret_cast<uint64_t *>(hpin.p), count));
+        std::memcpy(dst, hpin.p, sizeof(double) * count);
+        return MIH_OK;
+    }
+    int upload_cols_coef(const std::vector<double> &coef)      // sidx <- cols, mcoef <- coef
+    {
+        const size_t nc = cols.size(), words = nc + coef.size();
+        if (words > upin.n) { MIH_HIP(hipStreamSynchronize(s)); MIH_TRY(upin.alloc(words * 2 + 64)); }
+        std::memcpy(upin.p, cols.data(), sizeof(int64_t) * nc);
+        std::memcpy(upin.p + nc, coef.data(), sizeof(double) * coef.size());
+        MIH_HIP(hipMemcpyAsync(sidx.p, upin.p, sizeof(int64_t) * nc, hipMemcpyHostToDevice, s));
+        MIH_HIP(hipMemcpyAsync(mcoef.p, upin.p + nc, sizeof(double) * coef.size(), hipMemcpyHostToDevice, s));
+        return MIH_OK;
+    }
+    DevBuf<int32_t> pairs_s; bool pairs_ok = false, pairs_s_ok = false;      // the index-pair tables (Gram: a <= b; score: (trait, covariate)) go up once
     XtvWork xtv; XvWork xv; TopkWork topk;
     int nb = 0;
     // host
@@ -323,8 +344,7 @@ struct MvVar {
             xbcoef[(size_t)ii * nc + c] = B.val[t];
         }
         if ((size_t)nc * r > mcoef.n) { MIH_HIP(hipStreamSynchronize(s)); MIH_TRY(mcoef.alloc((size_t)nc * r * 2)); }
-        MIH_HIP(hipMemcpyAsync(sidx.p, cols.data(), sizeof(int64_t) * nc, hipMemcpyHostToDevice, s));
-        MIH_HIP(hipMemcpyAsync(mcoef.p, xbcoef.data(), sizeof(double) * nc * r, hipMemcpyHostToDevice, s));
+        MIH_TRY(upload_cols_coef(xbcoef));
         return xv_sparse_multi_device(h, xv, sidx.p, mcoef.p, nc, r, BX.p, s, cols.data());
     }
     // update_mu! + update_resid! (+ Gram matrix resid*resid' for solve_Sigma!/loglikelihood)
@@ -335,12 +355,11 @@ struct MvVar {
         for (int a = 0; a < r; ++a) for (int b = a; b < r; ++b) pr.push_back(a);
         size_t np_ = pr.size();
         for (int a = 0; a < r; ++a) for (int b = a; b < r; ++b) pr.push_back(b);
-        MIH_HIP(hipMemcpyAsync(pairs.p, pr.data(), sizeof(int32_t) * pr.size(), hipMemcpyHostToDevice, s));
+        if (!pairs_ok) { MIH_HIP(hipMemcpyAsync(pairs.p, pr.data(), sizeof(int32_t) * pr.size(), hipMemcpyHostToDevice, s)); pairs_ok = true; }
         hipLaunchKernelGGL(k_mv_dots, dim3(kRedBlocks, (unsigned)np_), dim3(256), 0, s, RES.p, RES.p, n, pairs.p, pairs.p + np_, red.p);
         hipLaunchKernelGGL(k_mv_dots_final, dim3((unsigned)np_), dim3(64), 0, s, red.p, scal.p);
         std::vector<double> g(np_);
-        MIH_HIP(hipMemcpyAsync(g.data(), scal.p, sizeof(double) * np_, hipMemcpyDeviceToHost, s));
-        MIH_HIP(hipStreamSynchronize(s));
+        MIH_TRY(readback(scal.p, np_, g.data()));
         MIH_HIP(hipGetLastError());                  // a failed launch anywhere in this iteration's chain surfaces here
         size_t t = 0;
         for (int a = 0; a < r; ++a) for (int b = a; b < r; ++b, ++t) { gram[a + r * b] = g[t]; gram[b + r * a] = g[t]; }
@@ -383,12 +402,14 @@ struct MvVar {
         for (int l = 0; l < q; ++l) for (int i = 0; i < r; ++i) pr.push_back(i);
         size_t np_ = pr.size();
         for (int l = 0; l < q; ++l) for (int i = 0; i < r; ++i) pr.push_back(l);
-        MIH_HIP(hipMemcpyAsync(pairs.p, pr.data(), sizeof(int32_t) * pr.size(), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_mv_dots, dim3(kRedBlocks, (unsigned)np_), dim3(256), 0, s, T1.p, Z.p, n, pairs.p, pairs.p + np_, red.p);
+        if (!pairs_s_ok) {
+            MIH_TRY(pairs_s.alloc(pr.size()));
+            MIH_HIP(hipMemcpyAsync(pairs_s.p, pr.data(), sizeof(int32_t) * pr.size(), hipMemcpyHostToDevice, s));
+            pairs_s_ok = true;
+        }
+        hipLaunchKernelGGL(k_mv_dots, dim3(kRedBlocks, (unsigned)np_), dim3(256), 0, s, T1.p, Z.p, n, pairs_s.p, pairs_s.p + np_, red.p);
         hipLaunchKernelGGL(k_mv_dots_final, dim3((unsigned)np_), dim3(64), 0, s, red.p, scal.p);
-        MIH_HIP(hipMemcpyAsync(df2.data(), scal.p, sizeof(double) * np_, hipMemcpyDeviceToHost, s));   // [i + r*l]
-        MIH_HIP(hipStreamSynchronize(s));
-        return MIH_OK;
+        return readback(scal.p, np_, df2.data());   // [i + r*l]
     }
     int gather_df_cols()
     {
@@ -398,9 +419,7 @@ struct MvVar {
         MIH_TRY(ensure_stage(nc));
         MIH_HIP(hipMemcpyAsync(sidx.p, cols.data(), sizeof(int64_t) * nc, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(k_mv_gather, dim3(nblk(nc * r)), dim3(256), 0, s, DF.p, p, r, sidx.p, nc, gval.p);
-        MIH_HIP(hipMemcpyAsync(dfcols.data(), gval.p, sizeof(double) * nc * r, hipMemcpyDeviceToHost, s));
-        MIH_HIP(hipStreamSynchronize(s));
-        return MIH_OK;
+        return readback(gval.p, (size_t)nc * r, dfcols.data());
     }
     // iht_stepsize! (multivariate.jl:220-254): covariates ignored, pivoted Cholesky of Gamma
     int stepsize(double *eta)
@@ -410,16 +429,14 @@ struct MvVar {
         for (double x : dfcols) numer += x * x;
         if (nc) {
             if ((size_t)nc * r > mcoef.n) { MIH_HIP(hipStreamSynchronize(s)); MIH_TRY(mcoef.alloc((size_t)nc * r * 2)); }
-            MIH_HIP(hipMemcpyAsync(sidx.p, cols.data(), sizeof(int64_t) * nc, hipMemcpyHostToDevice, s));
-            MIH_HIP(hipMemcpyAsync(mcoef.p, dfcols.data(), sizeof(double) * nc * r, hipMemcpyHostToDevice, s));     // dfcols is [trait][column]
+            MIH_TRY(upload_cols_coef(dfcols));                       // dfcols is [trait][column]
             MIH_TRY(xv_sparse_multi_device(h, xv, sidx.p, mcoef.p, nc, r, T1.p, s, cols.data()));
         } else MIH_HIP(hipMemsetAsync(T1.p, 0, sizeof(double) * (size_t)n * r, s));
         pivoted_chol_triu(G, r);                                   // Gamma is left holding U (fit.jl:230-232 recomputes it)
         hipLaunchKernelGGL(k_mv_apply, dim3(nb), dim3(256), 0, s, T1.p, n, r, rmat(G), 1, w.p, (double *)nullptr, red.p);
         hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, s, red.p, nb, 1, scal.p);
         double denom = 0.0;
-        MIH_HIP(hipMemcpyAsync(&denom, scal.p, sizeof(double), hipMemcpyDeviceToHost, s));
-        MIH_HIP(hipStreamSynchronize(s));
+        MIH_TRY(readback(scal.p, 1, &denom));
         double e = numer / denom;
         if (std::isinf(e) || std::isnan(e)) e = 1e-8;
         *eta = e;

@@ -121,26 +121,25 @@ k_hist11(const double *__restrict__ x, int64_t len, int second, const uint64_t *
     for (int e = threadIdx.x; e < 4 * kBins11; e += 256) (&h[0][0])[e] = 0;
     __syncthreads();
     const uint64_t prefix = state[0];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t rounds = (len + stride - 1) / stride;
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    for (int64_t r = 0; r < rounds; ++r, i += stride) {
-        bool live = false; uint32_t bin = 0;
-        if (i < len) {
-            const uint64_t key = abs_key(x[i]);
-            live = !second || (key >> 52) == prefix;
-            bin = second ? (uint32_t)(key >> 41) & 2047u : (uint32_t)(key >> 52);
+    // four independent loads in flight per thread; plain LDS adds into the wave's own copy (a wave's 64 keys fall into a
+    // handful of exponent bins: the LDS serialises those adds faster than a ballot loop over the distinct bins does)
+    for (; i + 3 * stride < len; i += 4 * stride) {
+        uint64_t key[4];
+        #pragma unroll
+        for (int u = 0; u < 4; ++u) key[u] = abs_key(x[i + u * stride]);
+        #pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!second) atomicAdd(&h[wave][(uint32_t)(key[u] >> 52)], 1u);
+            else if ((key[u] >> 52) == prefix) atomicAdd(&h[wave][(uint32_t)(key[u] >> 41) & 2047u], 1u);
         }
-        if (second) { if (live) atomicAdd(&h[wave][bin], 1u); continue; }
-        uint64_t todo = __ballot(live);     // exponents: a handful of bins per wave -> one add per distinct bin
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const uint32_t lb = __shfl(bin, leader, 64);
-            const uint64_t same = __ballot(live && bin == lb) & todo;
-            if (lane == leader) h[wave][lb] += (uint32_t)__popcll(same);
-            todo &= ~same;
-        }
+    }
+    for (; i < len; i += stride) {
+        const uint64_t key = abs_key(x[i]);
+        if (!second) atomicAdd(&h[wave][(uint32_t)(key >> 52)], 1u);
+        else if ((key >> 52) == prefix) atomicAdd(&h[wave][(uint32_t)(key >> 41) & 2047u], 1u);
     }
     __syncthreads();
     for (int b = threadIdx.x; b < kBins11; b += 256) {

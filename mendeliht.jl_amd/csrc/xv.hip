@@ -220,6 +220,98 @@ k_xv_snp_cached_multi(const uint32_t *__restrict__ cache, int64_t ndw, int64_t n
     }
 }
 
+// The same products with a thread per TWO rows and all traits of a chunk in registers: a cached column is unpacked once for
+// up to MT traits (the kernel above unpacks it once per 4 traits and, at 256 VGPRs, runs one wave per SIMD), the coefficients
+// of a column are wave-uniform (scalar loads), and the thread walks the column groups itself, in order: part_g = acc_g + bsum_g
+// joins the total exactly as in the LDS reduction (Bg[v][g] = the group's bsum, summed in column order by k_xv_coef_groups).
+// r = 10 traits, 500 columns, n = 500k: 350 us -> ~110 us per call.
+template <int MT>
+__global__ void __launch_bounds__(256)
+k_xv_snp_cached_mt(const uint32_t *__restrict__ cache, int64_t ndw, int64_t n, const int32_t *__restrict__ slots,
+                   const double *__restrict__ A, const double *__restrict__ Bg, int nnz, int groups, int m,
+                   double *__restrict__ out)
+{
+    const int64_t tid = blockIdx.x * 256ll + threadIdx.x;
+    const int64_t dw = tid >> 3;
+    if (dw >= ndw) return;
+    const int sh = (int)(tid & 7) * 4;
+    const int v0 = blockIdx.y * MT;
+    const int per = (nnz + groups - 1) / groups;
+    const double *Av[MT], *Gv[MT];
+    #pragma unroll
+    for (int v = 0; v < MT; ++v) { const int vv = v0 + v < m ? v0 + v : m - 1; Av[v] = A + (int64_t)vv * nnz; Gv[v] = Bg + (int64_t)vv * groups; }
+    double acc[MT][2], tot[MT][2];
+    #pragma unroll
+    for (int v = 0; v < MT; ++v) { acc[v][0] = acc[v][1] = 0.0; tot[v][0] = tot[v][1] = 0.0; }
+    int left = per, g = 0;
+    for (int t = 0; t < nnz; t += 4) {
+        uint32_t w4[4];
+        #pragma unroll
+        for (int u = 0; u < 4; ++u) w4[u] = cache[(int64_t)slots[t + u < nnz ? t + u : nnz - 1] * ndw + dw] >> sh;
+        #pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (t + u < nnz) {
+                if (left == 0) {
+                    #pragma unroll
+                    for (int v = 0; v < MT; ++v) {
+                        const double bs = Gv[v][g];
+                        tot[v][0] = tot[v][0] + (acc[v][0] + bs); tot[v][1] = tot[v][1] + (acc[v][1] + bs);
+                        acc[v][0] = acc[v][1] = 0.0;
+                    }
+                    ++g; left = per;
+                }
+                const double g0 = (double)(w4[u] & 3u), g1 = (double)((w4[u] >> 2) & 3u);
+                #pragma unroll
+                for (int v = 0; v < MT; ++v) {
+                    const double a = Av[v][t + u];
+                    acc[v][0] = fma(g0, a, acc[v][0]); acc[v][1] = fma(g1, a, acc[v][1]);
+                }
+                --left;
+            }
+        }
+    }
+    const double tail = g + 1 < groups ? 0.0 : -0.0;      // empty trailing groups each add +0.0 (only -0.0 + 0.0 differs)
+    const int64_t i = 2 * tid;
+    #pragma unroll
+    for (int v = 0; v < MT; ++v) {
+        if (v0 + v < m) {
+            const double bs = Gv[v][g];
+            const double o0 = (tot[v][0] + (acc[v][0] + bs)) + tail, o1 = (tot[v][1] + (acc[v][1] + bs)) + tail;
+            if (i < n) out[(int64_t)(v0 + v) * n + i] = o0;
+            if (i + 1 < n) out[(int64_t)(v0 + v) * n + i + 1] = o1;
+        }
+    }
+}
+// coefficients of trait blockIdx.x (k_xv_coef_multi's A) and, per column group, the sum of its centring terms in column order
+__global__ void __launch_bounds__(256)
+k_xv_coef_groups(const int64_t *__restrict__ idx, const double *__restrict__ val, int nnz,
+                 const double *__restrict__ mu, const double *__restrict__ sinv, int center, int scale, int groups,
+                 double *__restrict__ A, double *__restrict__ Bg)
+{
+#pragma clang fp contract(off)       // bsum += b must round like the stored B of k_xv_coef_multi
+    constexpr int CH = 2048;
+    __shared__ double sb[CH];
+    const int v = blockIdx.x;
+    const int per = (nnz + groups - 1) / groups;
+    const int t0 = threadIdx.x * per, t1 = t0 + per < nnz ? t0 + per : nnz;      // this thread's group (threads < groups)
+    double bsum = 0.0;
+    for (int base = 0; base < nnz; base += CH) {
+        const int end = base + CH < nnz ? base + CH : nnz;
+        for (int t = base + threadIdx.x; t < end; t += 256) {
+            const int64_t j = idx[t];
+            const double sc = scale ? sinv[j] : 1.0;
+            const double a = sc * val[(int64_t)v * nnz + t];
+            A[(int64_t)v * nnz + t] = a;
+            sb[t - base] = center ? -mu[j] * a : 0.0;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < groups)
+            for (int t = t0 > base ? t0 : base; t < (t1 < end ? t1 : end); ++t) bsum += sb[t - base];
+        __syncthreads();
+    }
+    if ((int)threadIdx.x < groups) Bg[(int64_t)v * groups + threadIdx.x] = bsum;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256)
 k_xv_dense(const T *__restrict__ D, int64_t n, const int64_t *__restrict__ idx,
@@ -406,6 +498,12 @@ int xv_sparse_multi_device(const mih_mat *h, XvWork &w, const int64_t *idx_dev, 
         if (xv_cache_lookup(w, idx_host, nnz, slots, fills)) {
             const int64_t ndw = h->n_pad / 16;
             const int groups = (int)(nnz < w.groups ? nnz : w.groups);
+            static const bool mt_on = []() { const char *e = getenv("MENDELIHT_XV_MULTI"); return !e || atoi(e) != 2; }();   // 2: the LDS-reduced kernel
+            if (mt_on && nnz < (1ll << 30)) {
+                if ((size_t)m * groups > w.coefG.n) { MIH_HIP(hipStreamSynchronize(s)); MIH_TRY(w.coefG.alloc((size_t)m * kXvGroups * 2)); }
+                hipLaunchKernelGGL(k_xv_coef_groups, dim3((unsigned)m), dim3(256), 0, s, idx_dev, vals_dev, (int)nnz,
+                                   h->mu, h->sinv, h->center, h->scale, groups, w.coefA.p, w.coefG.p);
+            } else
             hipLaunchKernelGGL(k_xv_coef_multi, dim3((unsigned)((nnz + 255) / 256), (unsigned)m), dim3(256), 0, s, idx_dev, vals_dev, nnz,
                                h->mu, h->sinv, h->center, h->scale, w.coefA.p, w.coefB.p);
             MIH_HIP(hipMemcpyAsync(w.slot_dev.p, slots.data(), sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, s));
@@ -413,6 +511,15 @@ int xv_sparse_multi_device(const mih_mat *h, XvWork &w, const int64_t *idx_dev, 
                 MIH_HIP(hipMemcpyAsync(w.fill_dev.p, fills.data(), sizeof(int64_t) * fills.size(), hipMemcpyHostToDevice, s));
                 hipLaunchKernelGGL(k_xv_fill, dim3((unsigned)((ndw + 255) / 256), (unsigned)fills.size()), dim3(256), 0, s, h->X, h->nbp, ndw,
                                    w.fill_dev.p, w.cache.p);
+            }
+            if (mt_on && nnz < (1ll << 30)) {
+                const unsigned gx = (unsigned)((8 * ndw + 255) / 256);
+#define MIH_MT(MTV) hipLaunchKernelGGL((k_xv_snp_cached_mt<MTV>), dim3(gx, (unsigned)((m + MTV - 1) / MTV)), dim3(256), 0, s, \
+                                       w.cache.p, ndw, h->n, w.slot_dev.p, w.coefA.p, w.coefG.p, (int)nnz, groups, m, out_dev)
+                if (m <= 4) MIH_MT(4); else if (m <= 6) MIH_MT(6); else if (m <= 8) MIH_MT(8); else if (m <= 10) MIH_MT(10); else MIH_MT(12);
+#undef MIH_MT
+                MIH_HIP(hipGetLastError());
+                return MIH_OK;
             }
             constexpr int NTR = 4;
             hipLaunchKernelGGL((k_xv_snp_cached_multi<NTR>), dim3((unsigned)((ndw + 15) / 16), (unsigned)((m + NTR - 1) / NTR)), dim3(256), 0, s,
