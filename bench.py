@@ -295,7 +295,7 @@ def main():
             for j in range(5):
                 mse += tot[j] * ninfold[j] / n               # meanloss (cross_validation.jl:304-320)
             passes = sum(s[0] for s in allst)
-            # one fused pass scores up to 12 residuals; an IHT iteration of one fit = one score of one residual.  The
+            # one fused pass scores up to 15 residuals; an IHT iteration of one fit = one score of one residual.  The
             # library counts launches, not residuals, so iterations are reported from the deterministic single-rank count
             out = {
                 "metric": METRIC,
@@ -307,7 +307,8 @@ def main():
                                        "ONE all-gather of the held-out losses per step inside the timed region "
                                        "(cross_validation.jl:98-121)",
                            "n": n, "p": p, "path": "1:20", "folds": 5, "generator_s": round(t_gen, 2), "best_k": int(np.argmin(mse)) + 1,
-                           "cv_iht_s": elapsed / a.steps},
+                           "cv_iht_s": elapsed / a.steps,
+                           "compare_with": "the N=1 line's cv_iht.fits_per_s (= 100 / cv_iht.cv_iht_s): same workload on one GPU"},
                 "per_rank": [{"rank": i, "fits": int(s[3]), "fused_passes_per_step": s[0], "xtv_kernel_ms_per_step": s[1],
                               "gather_ms_per_step": s[2]} for i, s in enumerate(allst)],
                 "fused_passes_per_step_total": passes,
@@ -319,7 +320,7 @@ def main():
                 alg = x.algorithmic_bytes(12)
                 kern_ms = sum(s[1] for s in allst) / max(passes, 1)
                 out["roofline"].update(achieved=alg / (kern_ms * 1e-3) / 1e9, frac=alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                       kernel="k_xtv_dma16<4,2,8,4> (mean over the fused passes of all ranks; bytes as for 12 residuals)",
+                                       kernel="k_xtv_dma16<NR,2,8,D> (mean over the fused passes of all ranks, 1 to 5 operands each; bytes as for 12 residuals)",
                                        kernel_ms=kern_ms, launches=int(passes * a.steps), algorithmic_bytes_per_launch=alg,
                                        residuals_per_pass_estimate=mres)
             print(json.dumps(out), flush=True)
@@ -405,7 +406,7 @@ def main():
             cms, cl = m.profile_read(reset=True)
             gpu_fits_per_s = 100.0 / dt
             out["cv_iht"] = {"workload": "cv_iht Bernoulli/Logit path=1:20, 5 folds (BASELINE configs[3]), all 100 fits on this GPU",
-                             "seconds": dt, "fits": int(np.count_nonzero(raw)), "fits_per_s": gpu_fits_per_s, "best_k": int(np.argmin(mse)) + 1,
+                             "seconds": dt, "cv_iht_s": dt, "fits": int(np.count_nonzero(raw)), "fits_per_s": gpu_fits_per_s, "best_k": int(np.argmin(mse)) + 1,
                              "fused_passes": int(cl), "xtv_kernel_ms_total": cms}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"], cores = cpu_baseline(m, n, p, k, seed, a.cpu_seconds)
