@@ -1455,3 +1455,65 @@ def test_native_rccl_communicator_world1(mih, normal_pair, normal_data):
     one = mih.fit_iht(yb, x, z, **kw)
     sh = D.fit_iht_sharded(yb, x, z, col_offset=0, p_global=x.p, native=True, **kw)
     assert sh.iter == one.iter and np.array_equal(sh.beta, one.beta) and sh.logl == one.logl
+
+
+def test_session_run_is_k_session_steps(mih, normal_pair, normal_data):
+    """mih_session_run(K) (what bench.py times) = K calls of mih_session_step: same loglikelihood, backtracks and model."""
+    x, _ = normal_pair
+    y, z = normal_data["y"], normal_data["z"]
+    a = mih.IHTSession(y, x, z, k=9)
+    b = mih.IHTSession(y, x, z, k=9)
+    nbt = 0
+    for _ in range(4):
+        la, bt, ta = a.step()
+        nbt += bt
+    lb, btb, tb = b.run(4)
+    assert la == lb and ta == tb and nbt == btb
+    (ba, ca), (bb, cb) = a.model(), b.model()
+    assert np.array_equal(ba, bb) and np.array_equal(ca, cb)
+    a.close(); b.close()
+
+
+_NOSPIN_SNIPPET = r"""
+import sys, json, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import mendeliht_amd as m
+from conftest import hash_folds
+x = m.SnpLinAlg.synthetic(6001, 900, seed=3, missing_rate=0.01)
+rng = np.random.default_rng(1)
+supp = np.sort(rng.choice(900, 8, replace=False))
+eta = x.xv_sparse(supp, rng.standard_normal(8) * 0.6)
+y = eta + 0.5 + rng.standard_normal(6001)
+yb = (rng.random(6001) < 1 / (1 + np.exp(-eta))).astype(float)
+z = np.column_stack([np.ones(6001), rng.standard_normal(6001)])
+out = {}
+r = m.fit_iht(y, x, z, k=8, verbose=False)
+out["beta"], out["c"], out["logl"] = r.beta, r.c, np.array([r.logl, r.iter])
+r = m.fit_iht(yb, x, z, k=5, d=m.Bernoulli(), l=m.LogitLink(), verbose=False)
+out["bbeta"], out["blogl"] = r.beta, np.array([r.logl, r.iter])
+_, raw = m.cv_iht(yb, x, z, path=range(1, 9), q=3, folds=hash_folds(6001, 3), verbose=False, return_raw=True, d=m.Bernoulli(), l=m.LogitLink())
+out["cv"] = raw
+Y = np.vstack([y, 0.5 * y + rng.standard_normal(6001), rng.standard_normal(6001)])
+r = m.fit_iht(Y, x, None, k=12, verbose=False, max_iter=10)
+out["mvbeta"], out["mvlogl"] = r.beta, np.array([r.logl, r.iter])
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_polled_readbacks_change_nothing(mih, tmp_path):
+    """The polled readbacks (k_publish / k_final_sum_pub + SpinFlag) against device-to-host copies + hipStreamSynchronize
+    (MENDELIHT_NO_SPIN=1, read once per process): univariate Normal and logistic fits, a cross-validation and a multivariate
+    fit give identical bits."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for flag in ("0", "1"):
+        f = tmp_path / f"spin_{flag}.npz"
+        r = subprocess.run([sys.executable, "-c", _NOSPIN_SNIPPET, root, str(f)], capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, MENDELIHT_NO_SPIN=flag))
+        assert r.returncode == 0, r.stdout + r.stderr
+        res.append(np.load(f))
+    assert sorted(res[0].files) == sorted(res[1].files) and len(res[0].files) == 8
+    for k in res[0].files:
+        assert np.array_equal(res[0][k].view(np.uint64), res[1][k].view(np.uint64)), k
+    assert res[0]["logl"][1] > 2 and np.count_nonzero(res[0]["cv"]) == 24
