@@ -157,22 +157,30 @@ k_digits(const double *__restrict__ r, int64_t n, int64_t nblk, int m, DigitMode
         const int64_t i = blk * 64 + lane;
         const double x = (i < n) ? r[(int64_t)vs * n + i] : 0.0;
         long long R = __double2ll_rn(x * scal[4 * vs + 3]);
+        // base 49: the standard digits of |R| come from two 5-digit limbs (49^5 < 2^29: 32-bit divisions instead of ten 64-bit
+        // ones) and carry into the balanced residue system; the system is symmetric, digits(-R) = -digits(R)
+        const bool neg = R < 0;
+        const unsigned long long aR = neg ? 0ull - (unsigned long long)R : (unsigned long long)R;
+        uint32_t limb_hi = (uint32_t)(aR / 282475249ull), limb_lo = (uint32_t)(aR - (unsigned long long)limb_hi * 282475249ull);
+        int carry = 0;
         for (int t = 0; t < dm.ndig; ++t) {
             int d;
-            if (dm.base == 4) {
+            if (dm.base == 49) {
+                const uint32_t L = t < 5 ? limb_lo : limb_hi, qd = L / 49u;
+                const int v = (int)(L - qd * 49u) + carry;
+                if (t < 5) limb_lo = qd; else limb_hi = qd;
+                if (v == 49) { d = 0; carry = 1; }
+                else { d = digit49(v); carry = d < 0; }
+                if (neg) d = -d;
+            } else if (dm.base == 4) {
                 const int mm = (int)(R & 3);
                 d = mm < 2 ? mm : mm - 4;
                 R = (R - d) >> 2;
-            } else if (dm.base == 13) {
+            } else {
                 int mm = (int)(R % 13);
                 if (mm < 0) mm += 13;
                 d = digit13(mm);
                 R = (R - d) / 13;
-            } else {
-                int mm = (int)(R % 49);
-                if (mm < 0) mm += 49;
-                d = digit49(mm);
-                R = (R - d) / 49;
             }
             const unsigned a = (unsigned)(d < 0 ? -d : d);
             unsigned long long code;
