@@ -10,6 +10,7 @@
 // projection survivors (k entries), the loglikelihood scalars, Z'r and df[S].
 #include "common.h"
 #include "fit_common.h"
+#include <map>
 #include <functional>
 #include <atomic>
 #include <mutex>
@@ -1256,6 +1257,8 @@ struct CvFit {
     void release() { if (v && pool) pool->push_back(std::move(v)); v.reset(); }
     std::vector<uint8_t> train;
     int64_t out_index = 0;
+    int init_key = -1;       // fits with the same key >= 0 have the same initial residual (same training rows; the model size
+                             // enters only after the first score): one of them rides the pass, the others copy its X'r
     int iter = 1, nbt = 0;
     double next_logl = -std::numeric_limits<double>::infinity(), best = -std::numeric_limits<double>::infinity();
     bool done = false;
@@ -1326,12 +1329,16 @@ struct CvHandover {
 
 static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t total, std::atomic<size_t> &next, int cap,
                           const MakeFit &make, XtvWork &xw, DevBuf<double> &R,
-                          DevBuf<double> &DF, hipStream_t s, double *mses_raw, CvHandover *ho = nullptr, int lane_id = 0)
+                          DevBuf<double> &DF /* (cap + init_slots) x p */, hipStream_t s, double *mses_raw, CvHandover *ho = nullptr, int lane_id = 0,
+                          int init_slots = 0)
 {
     std::vector<std::unique_ptr<IhtVar>> pool;            // declared before the slots: outlives them
     std::vector<std::unique_ptr<CvFit>> slot((size_t)cap);
-    std::vector<CvFit *> need;
+    std::vector<CvFit *> need, riders;
     std::vector<char> fresh;
+    std::map<int, double *> df0;                                         // initial X'r per init_key: slots behind the pass's outputs in DF
+    std::vector<std::pair<CvFit *, double *>> owners, followers;
+    static const bool share_init = getenv("MENDELIHT_CV_NO_INIT_SHARE") == nullptr;
     bool drained = false;                 // the shared queue is empty
     auto occupied = [&]() { int c = 0; for (auto &sl : slot) c += sl != nullptr; return c; };
     auto adopt = [&]() {                  // lane 0: take handed-over fits into free slots (caller holds ho->mu)
@@ -1392,7 +1399,28 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
             }
             break;
         }
-        MIH_TRY(cv_batched_xtv(h, xw, need, R, DF, s));
+        // Initial scores are shared: init_iht_indices! (utilities.jl:366-438) computes its first X'r from b = 0 and the intercept
+        // of the training rows before the model size k plays any role, so the 20 fits of a fold (or all fits of a model path)
+        // start from the SAME residual.  One fit per key rides the pass; its X'r is kept for the fits of that key this lane
+        // starts later (100 -> at most 10 initial scores per cross-validation, 7 % of all scores).
+        riders.clear(); followers.clear();
+        for (size_t t = 0; t < need.size(); ++t) {
+            CvFit *f = need[t];
+            const int key = (fresh[t] && share_init) ? f->init_key : -1;
+            if (key < 0) { riders.push_back(f); continue; }
+            auto it = df0.find(key);
+            if (it != df0.end()) { followers.emplace_back(f, it->second); continue; }
+            riders.push_back(f);
+            if ((int)df0.size() < init_slots) {            // room in the lane's cache (allocated with its workspace)
+                double *buf = DF.p + ((size_t)cap + df0.size()) * (size_t)h->p;
+                df0[key] = buf;
+                owners.emplace_back(f, buf);
+            }
+        }
+        MIH_TRY(cv_batched_xtv(h, xw, riders, R, DF, s));
+        for (auto &o : owners) MIH_HIP(hipMemcpyAsync(o.second, o.first->v->df.p, sizeof(double) * h->p, hipMemcpyDeviceToDevice, s));
+        owners.clear();
+        for (auto &fo : followers) MIH_HIP(hipMemcpyAsync(fo.first->v->df.p, fo.second, sizeof(double) * h->p, hipMemcpyDeviceToDevice, s));
         for (size_t t = 0; t < need.size(); ++t) {
             CvFit *f = need[t];
             if (fresh[t]) { MIH_TRY(f->v->init_post()); continue; }
@@ -1408,7 +1436,7 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
 // Two rolling drivers ("lanes"), each with its own host thread, stream and fused-pass workspace, pull fits from one
 // queue: while one lane's host thread walks the small per-fit kernel chains between two passes (about 0.5 ms per
 // fit and round), the other lane's fused pass keeps the GPU busy.  Every fit is independent of the lane it runs in.
-static int cv_run_lanes(const mih_mat *h, const mih_fit_params &pr, size_t total, const MakeFit &make, double *mses_raw)
+static int cv_run_lanes(const mih_mat *h, const mih_fit_params &pr, size_t total, const MakeFit &make, double *mses_raw, int init_keys = 0)
 {
     const int width = xtv_lockstep_width(h);
     int lanes = total > (size_t)width / 2 ? 2 : 1;  // more fits than one full pass holds: two lanes hide each other's per-fit chains (25 fits: 1.01 s against 1.06 s with one lane; 13 fits: 0.56 s with one lane, 0.65 s with two)
@@ -1425,8 +1453,9 @@ static int cv_run_lanes(const mih_mat *h, const mih_fit_params &pr, size_t total
         XtvWork xw; DevBuf<double> R, DF;
         MIH_TRY(xtv_work_init(h, xw, cap));
         MIH_TRY(R.alloc((size_t)cap * h->n));
-        MIH_TRY(DF.alloc((size_t)cap * h->p));
-        return cv_run_rolling(h, pr, total, next, cap, make, xw, R, DF, s, mses_raw, merge_tail ? &handover : nullptr, lane_id);
+        const int init_slots = std::min(init_keys, 8);          // shared initial scores (cv_run_rolling): 8 MB each at p = 1M
+        MIH_TRY(DF.alloc((size_t)(cap + init_slots) * h->p));
+        return cv_run_rolling(h, pr, total, next, cap, make, xw, R, DF, s, mses_raw, merge_tail ? &handover : nullptr, lane_id, init_slots);
     };
     if (lanes == 1) return lane(0);
     std::vector<int> rcs((size_t)lanes, MIH_OK);
@@ -1502,9 +1531,10 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, con
         f.train.resize(n);
         for (int64_t i = 0; i < n; ++i) f.train[i] = (folds[i] != fold);
         f.out_index = (int64_t)(fold - 1) * npath + ik;
+        f.init_key = fold;
         return MIH_OK;
     };
-    return cv_run_lanes(h, pr, mine.size(), make, mses_raw);
+    return cv_run_lanes(h, pr, mine.size(), make, mses_raw, nfolds);
 }
 
 int mih_fit_iht_path(const mih_mat *h, const mih_fit_params *prm, const double *y, const double *z, int64_t q,
@@ -1551,13 +1581,14 @@ int mih_fit_iht_path(const mih_mat *h, const mih_fit_params *prm, const double *
     }
     auto make = [&](size_t t, CvFit &f, hipStream_t s) -> int {
         slots(f, mine[t]);
+        f.init_key = 0;                                    // every fit of the path starts from the same residual (all rows)
         if (!f.v) {                                        // else: recycled from the lane's pool
             f.v.reset(new IhtVar());
             MIH_TRY(f.v->create(h, &pr, y, z, q, s));     // sized for max(path)
         }
         return f.v->set_k(path[mine[t]]);
     };
-    return cv_run_lanes(h, pr, mine.size(), make, nullptr);
+    return cv_run_lanes(h, pr, mine.size(), make, nullptr, 1);
 }
 
 int mih_cv_iht_multi(const mih_mat *const *hs, int32_t nrep, const mih_fit_params *prm, const double *y,
