@@ -31,19 +31,64 @@ constexpr int kChunkRows = 1024;
 
 inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
+// An IHTVariable owns ~26 device and ~5 pinned buffers.  One hipMalloc of a few MB costs ~100 us and every hipFree ~150 us
+// (it also waits for whatever the device is running): 6 ms per IHTVariable, 14 % of a GPU's 13-fit share of a cross-validation
+// (tools/pin_alloc_time.hip).  While an Arena is the thread's current one (ArenaScope), DevBuf / PinBuf allocations are carved
+// out of its single block (256-byte aligned) and do not own their memory; when the block is exhausted, or outside a scope
+// (later growth), they fall back to their own hipMalloc / hipHostMalloc.
+struct Arena {
+    char *dev = nullptr, *pin = nullptr;
+    size_t dev_bytes = 0, pin_bytes = 0, dev_off = 0, pin_off = 0;
+    Arena() = default;
+    Arena(const Arena &) = delete;
+    Arena &operator=(const Arena &) = delete;
+    ~Arena() { if (dev) (void)hipFree(dev); if (pin) (void)hipHostFree(pin); }
+    int reserve(size_t device_bytes, size_t pinned_bytes)
+    {
+        if (hipMalloc((void **)&dev, device_bytes) != hipSuccess) { (void)hipGetLastError(); dev = nullptr; device_bytes = 0; }   // fall back to single buffers
+        if (hipHostMalloc((void **)&pin, pinned_bytes, hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); pin = nullptr; pinned_bytes = 0; }
+        dev_bytes = device_bytes; pin_bytes = pinned_bytes; dev_off = pin_off = 0;
+        return MIH_OK;
+    }
+    void *take_dev(size_t bytes)
+    {
+        const size_t o = (dev_off + 255) & ~(size_t)255;
+        if (!dev || o + bytes > dev_bytes) return nullptr;
+        dev_off = o + bytes;
+        return dev + o;
+    }
+    void *take_pin(size_t bytes)
+    {
+        const size_t o = (pin_off + 255) & ~(size_t)255;
+        if (!pin || o + bytes > pin_bytes) return nullptr;
+        pin_off = o + bytes;
+        return pin + o;
+    }
+};
+inline Arena *&current_arena() { static thread_local Arena *a = nullptr; return a; }
+struct ArenaScope {
+    Arena *prev;
+    explicit ArenaScope(Arena *a) : prev(current_arena()) { current_arena() = a; }
+    ~ArenaScope() { current_arena() = prev; }
+};
+
 // RAII device buffer
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    bool own = true;           // false: carved out of an Arena (which outlives the buffer's owner)
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    void release() { if (p && own) (void)hipFree(p); p = nullptr; n = 0; own = true; }
     int alloc(size_t count) {
         release();
         if (count == 0) count = 1;
+        if (Arena *a = current_arena()) {
+            if (void *q = a->take_dev(count * sizeof(T))) { p = static_cast<T *>(q); n = count; own = false; return MIH_OK; }
+        }
         hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
         if (e != hipSuccess) { set_error("hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e)); p = nullptr; return e == hipErrorOutOfMemory ? MIH_OOM : MIH_HIP_ERROR; }
         n = count;
@@ -57,14 +102,19 @@ template <typename T>
 struct PinBuf {
     T *p = nullptr;
     size_t n = 0;
+    bool own = true;
     PinBuf() = default;
     PinBuf(const PinBuf &) = delete;
     PinBuf &operator=(const PinBuf &) = delete;
-    ~PinBuf() { if (p) (void)hipHostFree(p); }
+    ~PinBuf() { if (p && own) (void)hipHostFree(p); }
     // coherent = true: fine-grained host memory a kernel may write while the host polls it (SpinFlag landing areas)
     int alloc(size_t count, bool coherent = false) {
-        if (p) { (void)hipHostFree(p); p = nullptr; n = 0; }
+        if (p && own) (void)hipHostFree(p);
+        p = nullptr; n = 0; own = true;
         if (count == 0) count = 1;
+        if (Arena *a = current_arena()) {            // arena memory is coherent: good for either kind
+            if (void *q = a->take_pin(count * sizeof(T))) { p = static_cast<T *>(q); n = count; own = false; return MIH_OK; }
+        }
         if (hipHostMalloc((void **)&p, count * sizeof(T), coherent ? hipHostMallocCoherent : hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc(%zu bytes) failed", count * sizeof(T)); (void)hipGetLastError(); p = nullptr; return MIH_OOM; }
         n = count;
         return MIH_OK;
@@ -212,6 +262,7 @@ struct XvWork {
     std::vector<int32_t> h_slots; std::vector<int64_t> h_fills;   // host images of slot_dev / fill_dev of the last call
 };
 int  xv_work_init(const mih_mat *h, XvWork &w, int64_t max_nnz);
+size_t xv_work_bytes(const mih_mat *h, int64_t max_nnz);
 // out[i] = sum_t x[i, idx[t]] * val[t]; idx/val on device; clamp20 applies clamp!(out,-20,20).  idx_host (the same
 // indices on the host) enables the column cache.
 int  xv_sparse_device(const mih_mat *h, XvWork &w, const int64_t *idx_dev, const double *val_dev,

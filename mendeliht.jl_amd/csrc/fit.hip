@@ -399,6 +399,7 @@ int init_beta_regress_device(const mih_mat *h, const double *w_dev, const double
 }
 
 struct IhtVar {
+    Arena arena;                                  // first member: the memory outlives every buffer carved out of it
     const mih_mat *h = nullptr;
     int64_t n = 0, p = 0; int q = 0;
     int64_t k = 0, J = 1; std::vector<int64_t> ks;
@@ -470,17 +471,30 @@ struct IhtVar {
         if (shared_stream) { s = shared_stream; own_stream = false; batched = true; }
         else MIH_HIP(hipStreamCreate(&s));
         nb = (int)nblk(n);
+        int64_t kcap = std::max<int64_t>(std::max<int64_t>(J, 1) * k + q, 64) + 1024;
+        for (int64_t v : ks) kcap += v;
+        // every buffer below comes out of ONE device block and ONE pinned block (Arena, common.h)
+        {
+            size_t dev = sizeof(double) * ((size_t)n * (7 + q) + 2 * (size_t)p + q) + (size_t)n
+                         + sizeof(double) * ((size_t)nb * 4 + kMaxQ + 8 + (size_t)kMaxQ * kZtrBlocks) + sizeof(unsigned) * kMaxQ
+                         + 3 * sizeof(double) * (size_t)kcap + xv_work_bytes(h, kcap)
+                         + sizeof(uint32_t) * 2048 + 64 + 16 * ((size_t)kcap + 1025)
+                         + (prm->weight ? sizeof(double) * (size_t)p : 0) + (prm->group ? sizeof(int64_t) * ((size_t)p + ks.size() + 1) : 0)
+                         + 48 * 256;
+            size_t pin = sizeof(uint64_t) * (HostStage::kSlots * (2 * (size_t)kcap + 8) + ((size_t)kcap + kMaxQ + 16) + 2 + 2 * ((size_t)kcap + 64) + 16) + 8 * 256;
+            MIH_TRY(arena.reserve(dev, pin));
+        }
+        ArenaScope in_arena(&arena);
         MIH_TRY(y.alloc(n)); MIH_TRY(z.alloc((size_t)n * q)); MIH_TRY(w.alloc(n)); MIH_TRY(xb.alloc(n));
         MIH_TRY(zc.alloc(n)); MIH_TRY(mu.alloc(n)); MIH_TRY(r.alloc(n)); MIH_TRY(xgk.alloc(n));
         MIH_TRY(df.alloc(p)); MIH_TRY(full.alloc((size_t)p + q)); MIH_TRY(mask.alloc(n));
         MIH_TRY(red.alloc((size_t)nb * 4)); MIH_TRY(scal.alloc(kMaxQ + 8)); MIH_TRY(ztr.alloc((size_t)kMaxQ * kZtrBlocks));
         MIH_TRY(ztr_done.alloc(kMaxQ)); MIH_HIP(hipMemsetAsync(ztr_done.p, 0, sizeof(unsigned) * kMaxQ, s));      // k_zt_r leaves the counters at zero
-        int64_t kcap = std::max<int64_t>(std::max<int64_t>(J, 1) * k + q, 64) + 1024;
-        for (int64_t v : ks) kcap += v;
         MIH_TRY(sidx.alloc(kcap)); MIH_TRY(sval.alloc(kcap)); MIH_TRY(gval.alloc(kcap));
         MIH_TRY(stage.init(2 * (size_t)kcap + 8));
         MIH_TRY(hpin.alloc((size_t)kcap + kMaxQ + 16, true));
-        if (!batched) MIH_TRY(xtv_work_init(h, xtv, 1, false));
+        MIH_TRY(flag.word.alloc(8, true)); flag.word.p[0] = 0; flag.seq = 0;
+        if (!batched) { ArenaScope own_buffers(nullptr); MIH_TRY(xtv_work_init(h, xtv, 1, false)); }     // a few large buffers: their own allocations
         MIH_TRY(xv_work_init(h, xv, kcap));
         MIH_TRY(topk_work_init(topk, kcap));
         MIH_HIP(hipMemcpyAsync(y.p, yh, sizeof(double) * n, hipMemcpyHostToDevice, s));
@@ -510,7 +524,9 @@ struct IhtVar {
         c.assign(q, 0.0); c0 = c; best_c = c; df2 = c; idc.assign(q, 0); idc0 = idc;
         return MIH_OK;
     }
-    ~IhtVar() { if (s && own_stream) (void)hipStreamDestroy(s); }
+    // the last readback may have been a polled one (SpinFlag): the publishing kernel can still be retiring.  Drain the stream before
+    // its buffers go (releasing the arena under a stream that was destroyed with work in flight leaked the block).
+    ~IhtVar() { if (s) (void)hipStreamSynchronize(s); if (s && own_stream) (void)hipStreamDestroy(s); }
 
     // v.k = sparsity (cross_validation.jl:110): with groups and a scalar k the projection reads k from the device
     int set_k(int64_t knew)
@@ -1379,6 +1395,14 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
                     MIH_TRY(make(i, *slot[t], s));
                     CvFit &f = *slot[t];
                     MIH_TRY(f.v->init_pre(f.train.empty() ? nullptr : f.train.data()));
+                    if (share_init && f.init_key >= 0) {
+                        auto it = df0.find(f.init_key);
+                        if (it != df0.end()) {       // its initial X'r is known from an earlier round: no pass, straight on to its first step
+                            MIH_HIP(hipMemcpyAsync(f.v->df.p, it->second, sizeof(double) * h->p, hipMemcpyDeviceToDevice, s));
+                            MIH_TRY(f.v->init_post());
+                            continue;
+                        }
+                    }
                     need.push_back(&f); fresh.push_back(1);
                     break;
                 }

@@ -285,6 +285,7 @@ int topk_work_init(TopkWork &w, int64_t max_keep)
     w.cap = max_keep + 1024;
     MIH_TRY(w.sel.alloc(2 + 2 * (size_t)w.cap));
     MIH_TRY(w.hsel.alloc(2 + 2 * (size_t)w.expect, true));
+    MIH_TRY(w.flag.word.alloc(8, true)); w.flag.word.p[0] = 0; w.flag.seq = 0;
     return MIH_OK;
 }
 

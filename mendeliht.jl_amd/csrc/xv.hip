@@ -364,6 +364,20 @@ __global__ void k_clamp20(double *__restrict__ x, int64_t n)
     x[i] = a < -20.0 ? -20.0 : (a > 20.0 ? 20.0 : a);
 }
 
+// device bytes xv_work_init will ask for (the caller sizes its Arena with it)
+size_t xv_work_bytes(const mih_mat *h, int64_t max_nnz)
+{
+    if (max_nnz < 64) max_nnz = 64;
+    size_t b = 2 * sizeof(double) * (size_t)max_nnz + 4 * 256;
+    if (h->kind != 0) return b + sizeof(double) * (size_t)kXvGroups * (size_t)h->n;
+    const int64_t ndw = h->n_pad / 16;
+    int64_t want = 2 * max_nnz + 64;
+    const int64_t budget = (int64_t)(1ull << 31) / (ndw * 4);
+    if (want > budget) want = budget;
+    if (want >= max_nnz) b += (size_t)want * (size_t)ndw * 4 + (size_t)want * 12 + 3 * 256;
+    return b;
+}
+
 int xv_work_init(const mih_mat *h, XvWork &w, int64_t max_nnz)
 {
     w.groups = kXvGroups;
