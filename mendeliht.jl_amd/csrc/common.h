@@ -83,6 +83,7 @@ struct DevBuf {
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
     void release() { if (p && own) (void)hipFree(p); p = nullptr; n = 0; own = true; }
+    void attach(T *ptr, size_t count) { release(); p = ptr; n = count; own = false; }     // someone else's memory (read-only sharing)
     int alloc(size_t count) {
         release();
         if (count == 0) count = 1;

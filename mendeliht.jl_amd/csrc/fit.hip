@@ -449,8 +449,9 @@ struct IhtVar {
     bool own_stream = true, batched = false;
     // shared_stream != null: this variable is one of a lock-step batch (mih_cv_iht): it runs on the
     // batch's stream and leaves the X'r pass to the batch driver.
+    // y_shared / z_shared: device copies of y and z that outlive this variable (a lock-step lane uploads them once for all its fits)
     int create(const mih_mat *hh, const mih_fit_params *prm, const double *yh, const double *zh, int64_t qq,
-               hipStream_t shared_stream = nullptr)
+               hipStream_t shared_stream = nullptr, double *y_shared = nullptr, double *z_shared = nullptr)
     {
         h = hh; n = h->n; p = h->p; q = (int)qq; y_host = yh; z_host = zh; init_beta = prm->init_beta;
         comm = prm->comm; pg = p; col0 = 0; debias = prm->debias;
@@ -485,7 +486,9 @@ struct IhtVar {
             MIH_TRY(arena.reserve(dev, pin));
         }
         ArenaScope in_arena(&arena);
-        MIH_TRY(y.alloc(n)); MIH_TRY(z.alloc((size_t)n * q)); MIH_TRY(w.alloc(n)); MIH_TRY(xb.alloc(n));
+        if (y_shared && z_shared) { y.attach(y_shared, n); z.attach(z_shared, (size_t)n * q); }
+        else { MIH_TRY(y.alloc(n)); MIH_TRY(z.alloc((size_t)n * q)); }
+        MIH_TRY(w.alloc(n)); MIH_TRY(xb.alloc(n));
         MIH_TRY(zc.alloc(n)); MIH_TRY(mu.alloc(n)); MIH_TRY(r.alloc(n)); MIH_TRY(xgk.alloc(n));
         MIH_TRY(df.alloc(p)); MIH_TRY(full.alloc((size_t)p + q)); MIH_TRY(mask.alloc(n));
         MIH_TRY(red.alloc((size_t)nb * 4)); MIH_TRY(scal.alloc(kMaxQ + 8)); MIH_TRY(ztr.alloc((size_t)kMaxQ * kZtrBlocks));
@@ -497,8 +500,10 @@ struct IhtVar {
         if (!batched) { ArenaScope own_buffers(nullptr); MIH_TRY(xtv_work_init(h, xtv, 1, false)); }     // a few large buffers: their own allocations
         MIH_TRY(xv_work_init(h, xv, kcap));
         MIH_TRY(topk_work_init(topk, kcap));
-        MIH_HIP(hipMemcpyAsync(y.p, yh, sizeof(double) * n, hipMemcpyHostToDevice, s));
-        MIH_HIP(hipMemcpyAsync(z.p, zh, sizeof(double) * (size_t)n * q, hipMemcpyHostToDevice, s));
+        if (!(y_shared && z_shared)) {
+            MIH_HIP(hipMemcpyAsync(y.p, yh, sizeof(double) * n, hipMemcpyHostToDevice, s));
+            MIH_HIP(hipMemcpyAsync(z.p, zh, sizeof(double) * (size_t)n * q, hipMemcpyHostToDevice, s));
+        }
         if (prm->weight) {
             has_weight = true;
             MIH_TRY(weight.alloc(p));
@@ -1330,7 +1335,8 @@ static int cv_finish(CvFit &f, double *mses_raw)
 // The lane keeps the IHTVariables of finished fits and hands them to the fits it starts next (the reference re-uses one
 // IHTVariable per thread the same way, cross_validation.jl:91,110): ~25 hipMalloc / hipFree per fit otherwise, and every
 // hipFree waits for the OTHER lane's fused pass to finish.
-using MakeFit = std::function<int(size_t, CvFit &, hipStream_t)>;
+struct CvShared { double *y = nullptr, *z = nullptr; };      // the lane's device copies of y and z (read-only, shared by its fits)
+using MakeFit = std::function<int(size_t, CvFit &, hipStream_t, const CvShared &)>;
 
 // Tail of the queue: once no new fits are left, the fits of both lanes thin out and two half-empty fused passes cost far more
 // than one fuller pass (6 + 6 residuals: 2 x 20.9 ms, 12 in one pass: 31.6 ms).  Lane 1 therefore hands ALL its fits over to
@@ -1346,7 +1352,7 @@ struct CvHandover {
 static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t total, std::atomic<size_t> &next, int cap,
                           const MakeFit &make, XtvWork &xw, DevBuf<double> &R,
                           DevBuf<double> &DF /* (cap + init_slots) x p */, hipStream_t s, double *mses_raw, CvHandover *ho = nullptr, int lane_id = 0,
-                          int init_slots = 0)
+                          int init_slots = 0, const CvShared &shared = CvShared())
 {
     std::vector<std::unique_ptr<IhtVar>> pool;            // declared before the slots: outlives them
     std::vector<std::unique_ptr<CvFit>> slot((size_t)cap);
@@ -1392,7 +1398,7 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
                     slot[t].reset(new CvFit());
                     slot[t]->pool = &pool;
                     if (!pool.empty()) { slot[t]->v = std::move(pool.back()); pool.pop_back(); }
-                    MIH_TRY(make(i, *slot[t], s));
+                    MIH_TRY(make(i, *slot[t], s, shared));
                     CvFit &f = *slot[t];
                     MIH_TRY(f.v->init_pre(f.train.empty() ? nullptr : f.train.data()));
                     if (share_init && f.init_key >= 0) {
@@ -1460,7 +1466,8 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
 // Two rolling drivers ("lanes"), each with its own host thread, stream and fused-pass workspace, pull fits from one
 // queue: while one lane's host thread walks the small per-fit kernel chains between two passes (about 0.5 ms per
 // fit and round), the other lane's fused pass keeps the GPU busy.  Every fit is independent of the lane it runs in.
-static int cv_run_lanes(const mih_mat *h, const mih_fit_params &pr, size_t total, const MakeFit &make, double *mses_raw, int init_keys = 0)
+static int cv_run_lanes(const mih_mat *h, const mih_fit_params &pr, size_t total, const MakeFit &make, double *mses_raw, int init_keys,
+                        const double *y_host, const double *z_host, int64_t q)
 {
     const int width = xtv_lockstep_width(h);
     int lanes = total > (size_t)width / 2 ? 2 : 1;  // more fits than one full pass holds: two lanes hide each other's per-fit chains (25 fits: 1.01 s against 1.06 s with one lane; 13 fits: 0.56 s with one lane, 0.65 s with two)
@@ -1469,6 +1476,7 @@ static int cv_run_lanes(const mih_mat *h, const mih_fit_params &pr, size_t total
     std::atomic<size_t> next{0};
     CvHandover handover;
     const bool merge_tail = lanes == 2 && !getenv("MENDELIHT_CV_NO_MERGE");
+    std::vector<DevBuf<double>> yds((size_t)lanes), zds((size_t)lanes);
     auto lane = [&](int lane_id) -> int {
         MIH_HIP(hipSetDevice(h->device));
         hipStream_t s = nullptr;
@@ -1479,7 +1487,12 @@ static int cv_run_lanes(const mih_mat *h, const mih_fit_params &pr, size_t total
         MIH_TRY(R.alloc((size_t)cap * h->n));
         const int init_slots = std::min(init_keys, 8);          // shared initial scores (cv_run_rolling): 8 MB each at p = 1M
         MIH_TRY(DF.alloc((size_t)(cap + init_slots) * h->p));
-        return cv_run_rolling(h, pr, total, next, cap, make, xw, R, DF, s, mses_raw, merge_tail ? &handover : nullptr, lane_id, init_slots);
+        DevBuf<double> &yd = yds[(size_t)lane_id], &zd = zds[(size_t)lane_id];   // y and z go up once per lane, not once per fit; they
+        MIH_TRY(yd.alloc((size_t)h->n)); MIH_TRY(zd.alloc((size_t)h->n * (size_t)q));  // outlive the lane (its fits may be handed over)
+        MIH_HIP(hipMemcpyAsync(yd.p, y_host, sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice, s));
+        MIH_HIP(hipMemcpyAsync(zd.p, z_host, sizeof(double) * (size_t)h->n * (size_t)q, hipMemcpyHostToDevice, s));
+        CvShared shared; shared.y = yd.p; shared.z = zd.p;
+        return cv_run_rolling(h, pr, total, next, cap, make, xw, R, DF, s, mses_raw, merge_tail ? &handover : nullptr, lane_id, init_slots, shared);
     };
     if (lanes == 1) return lane(0);
     std::vector<int> rcs((size_t)lanes, MIH_OK);
@@ -1544,12 +1557,12 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, con
         for (int64_t ik = 0; ik < npath; ++ik, ++combo)
             if (combo % world == rank) mine.emplace_back(fold, ik);
     if (mine.empty()) return MIH_OK;
-    auto make = [&](size_t t, CvFit &f, hipStream_t s) -> int {
+    auto make = [&](size_t t, CvFit &f, hipStream_t s, const CvShared &sh) -> int {
         int32_t fold = mine[t].first; int64_t ik = mine[t].second;
         if (f.v) MIH_TRY(f.v->set_k(path[ik]));           // a recycled IHTVariable: v.k = sparsity (cross_validation.jl:110)
         else {
             f.v.reset(new IhtVar());
-            MIH_TRY(f.v->create(h, &pr, y, z, q, s));     // sized for max(path), then
+            MIH_TRY(f.v->create(h, &pr, y, z, q, s, sh.y, sh.z));     // sized for max(path), then
             MIH_TRY(f.v->set_k(path[ik]));
         }
         f.train.resize(n);
@@ -1558,7 +1571,7 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, con
         f.init_key = fold;
         return MIH_OK;
     };
-    return cv_run_lanes(h, pr, mine.size(), make, mses_raw, nfolds);
+    return cv_run_lanes(h, pr, mine.size(), make, mses_raw, nfolds, y, z, q);
 }
 
 int mih_fit_iht_path(const mih_mat *h, const mih_fit_params *prm, const double *y, const double *z, int64_t q,
@@ -1603,16 +1616,16 @@ int mih_fit_iht_path(const mih_mat *h, const mih_fit_params *prm, const double *
         }
         return MIH_OK;
     }
-    auto make = [&](size_t t, CvFit &f, hipStream_t s) -> int {
+    auto make = [&](size_t t, CvFit &f, hipStream_t s, const CvShared &sh) -> int {
         slots(f, mine[t]);
         f.init_key = 0;                                    // every fit of the path starts from the same residual (all rows)
         if (!f.v) {                                        // else: recycled from the lane's pool
             f.v.reset(new IhtVar());
-            MIH_TRY(f.v->create(h, &pr, y, z, q, s));     // sized for max(path)
+            MIH_TRY(f.v->create(h, &pr, y, z, q, s, sh.y, sh.z));     // sized for max(path)
         }
         return f.v->set_k(path[mine[t]]);
     };
-    return cv_run_lanes(h, pr, mine.size(), make, nullptr, 1);
+    return cv_run_lanes(h, pr, mine.size(), make, nullptr, 1, y, z, q);
 }
 
 int mih_cv_iht_multi(const mih_mat *const *hs, int32_t nrep, const mih_fit_params *prm, const double *y,
