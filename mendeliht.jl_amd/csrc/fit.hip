@@ -1372,7 +1372,12 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
                 slot[t]->v->s = s;
             }
     };
+    static const bool trace_rounds = getenv("MENDELIHT_CV_TRACE") != nullptr;
+    auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_round = tnow();
+    int round_no = 0;
     for (;;) {
+        if (trace_rounds) { const double t = tnow(); fprintf(stderr, "lane %d round %d: %.2f ms, %zu scores\n", lane_id, round_no++, t - t_round, need.size()); t_round = t; }
         if (ho && lane_id == 0) {
             std::lock_guard<std::mutex> g(ho->mu);
             adopt();
