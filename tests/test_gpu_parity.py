@@ -1493,6 +1493,7 @@ r = m.fit_iht(yb, x, z, k=5, d=m.Bernoulli(), l=m.LogitLink(), verbose=False)
 out["bbeta"], out["blogl"] = r.beta, np.array([r.logl, r.iter])
 _, raw = m.cv_iht(yb, x, z, path=range(1, 9), q=3, folds=hash_folds(6001, 3), verbose=False, return_raw=True, d=m.Bernoulli(), l=m.LogitLink())
 out["cv"] = raw
+out["path"] = np.asarray(m.iht_run_many_models(yb, x, z, path=range(1, 7), verbose=False, d=m.Bernoulli(), l=m.LogitLink()))
 Y = np.vstack([y, 0.5 * y + rng.standard_normal(6001), rng.standard_normal(6001)])
 r = m.fit_iht(Y, x, None, k=12, verbose=False, max_iter=10)
 out["mvbeta"], out["mvlogl"] = r.beta, np.array([r.logl, r.iter])
@@ -1500,20 +1501,25 @@ np.savez(sys.argv[2], **out)
 """
 
 
-def test_polled_readbacks_change_nothing(mih, tmp_path):
-    """The polled readbacks (k_publish / k_final_sum_pub + SpinFlag) against device-to-host copies + hipStreamSynchronize
-    (MENDELIHT_NO_SPIN=1, read once per process): univariate Normal and logistic fits, a cross-validation and a multivariate
-    fit give identical bits."""
+def test_polled_readbacks_and_shared_initial_scores_change_nothing(mih, tmp_path):
+    """Switches that must not move a bit (each is read once per process, hence one process per variant): the polled readbacks
+    (k_publish / k_final_sum_pub + SpinFlag) against device-to-host copies + hipStreamSynchronize (MENDELIHT_NO_SPIN=1); the
+    cross-validation / model-path drivers with every fit riding its own initial score and without the tail hand-over
+    (MENDELIHT_CV_NO_INIT_SHARE=1, MENDELIHT_CV_NO_MERGE=1) and with one lock-step lane instead of two.  Univariate Normal and
+    logistic fits, a cross-validation, a model path and a multivariate fit."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = []
-    for flag in ("0", "1"):
-        f = tmp_path / f"spin_{flag}.npz"
+    for i, extra in enumerate(({}, {"MENDELIHT_NO_SPIN": "1"}, {"MENDELIHT_CV_NO_INIT_SHARE": "1", "MENDELIHT_CV_NO_MERGE": "1"},
+                               {"MENDELIHT_CV_LANES": "1"})):
+        f = tmp_path / f"variant_{i}.npz"
         r = subprocess.run([sys.executable, "-c", _NOSPIN_SNIPPET, root, str(f)], capture_output=True, text=True, timeout=900,
-                           env=dict(os.environ, MENDELIHT_NO_SPIN=flag))
+                           env=dict(os.environ, **extra))
         assert r.returncode == 0, r.stdout + r.stderr
         res.append(np.load(f))
-    assert sorted(res[0].files) == sorted(res[1].files) and len(res[0].files) == 8
-    for k in res[0].files:
-        assert np.array_equal(res[0][k].view(np.uint64), res[1][k].view(np.uint64)), k
-    assert res[0]["logl"][1] > 2 and np.count_nonzero(res[0]["cv"]) == 24
+    assert len(res[0].files) == 9
+    for other in res[1:]:
+        assert sorted(res[0].files) == sorted(other.files)
+        for k in res[0].files:
+            assert np.array_equal(res[0][k].view(np.uint64), other[k].view(np.uint64)), k
+    assert res[0]["logl"][1] > 2 and np.count_nonzero(res[0]["cv"]) == 24 and res[0]["path"].size == 6
