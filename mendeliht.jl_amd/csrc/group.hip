@@ -4,16 +4,125 @@
 // walk perm accumulating each group's norm over its first k_g members; rank the groups by norm
 // (descending, ties -> lower group first); walk perm again keeping a member iff its group's rank <= J
 // and it is among the group's first k_g.  Parallel restatement with identical results:
-//   1. stable radix sort of indices by |y| bits, descending            (= perm)
+//   1. stable radix sort of indices by |y| bits, descending            (= perm; hand-written, radix_sort_pairs below)
 //   2. stable radix sort of perm by group label                        (segments, still |y|-descending)
 //   3. one thread per group sums the squares of its first k_g members IN THAT ORDER (same order as
 //      the reference's sequential walk, so the norms are bit-identical)
 //   4. stable radix sort of groups by norm bits, descending            (= group rank)
 //   5. zero every member whose rank > J or whose position in its segment >= k_g.
 #include "common.h"
-#include <hipcub/hipcub.hpp>
 
 namespace mih {
+
+// ---- stable LSD radix sort of (key, value) pairs, 8 bits a pass ----------------------------------------------------------
+// A pass is three launches: per-block digit histograms (a block owns a contiguous tile of kRsTile keys), one exclusive scan
+// over the (digit-major, block-minor) histogram -- that order makes the pass stable across blocks -- and the scatter, which
+// walks the tile in input order: 256 keys a round, a key's rank among equal digits = equal digits in earlier rounds + in earlier
+// waves of the round + in lower lanes of its wave (ballot multi-split).  `descending` sorts by the complemented digit, so equal
+// keys keep their input order in both directions (what sortperm / Base.Order.Perm does with ties, utilities.jl:613-679).
+constexpr int kRsItems = 8, kRsTile = 256 * kRsItems;
+template <typename K>
+__global__ void __launch_bounds__(256)
+k_rs_hist(const K *__restrict__ key, int64_t len, int shift, int descending, int nblk, uint32_t *__restrict__ hist /* [256][nblk] */)
+{
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kRsTile;
+    for (int r = 0; r < kRsItems; ++r) {
+        const int64_t i = base + r * 256 + threadIdx.x;
+        if (i < len) {
+            uint32_t d = (uint32_t)(key[i] >> shift) & 255u;
+            if (descending) d = 255u - d;
+            atomicAdd(&h[d], 1u);
+        }
+    }
+    __syncthreads();
+    hist[(int64_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+}
+// exclusive scan of `count` 32-bit entries in place (one block; the histogram of a 2^31-key sort is 2^28 entries at most,
+// the projection's vectors give ~10^5)
+__global__ void __launch_bounds__(1024)
+k_rs_scan(uint32_t *__restrict__ a, int64_t count)
+{
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < count; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const uint32_t v = i < count ? a[i] : 0u;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const uint32_t add = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+            __syncthreads();
+            part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < count) a[i] = carry + part[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+}
+template <typename K>
+__global__ void __launch_bounds__(256)
+k_rs_scatter(const K *__restrict__ key, const int32_t *__restrict__ val, int64_t len, int shift, int descending, int nblk,
+             const uint32_t *__restrict__ hist /* scanned */, K *__restrict__ key_out, int32_t *__restrict__ val_out)
+{
+    __shared__ uint32_t offs[256];
+    __shared__ uint32_t wcnt[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    offs[threadIdx.x] = hist[(int64_t)threadIdx.x * nblk + blockIdx.x];
+    #pragma unroll
+    for (int w = 0; w < 4; ++w) wcnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kRsTile;
+    for (int r = 0; r < kRsItems; ++r) {
+        const int64_t i = base + r * 256 + threadIdx.x;
+        const bool live = i < len;
+        K kk = 0; int32_t vv = 0; uint32_t d = 0;
+        if (live) { kk = key[i]; vv = val[i]; d = (uint32_t)(kk >> shift) & 255u; if (descending) d = 255u - d; }
+        // lanes of this wave with the same digit
+        uint64_t same = __ballot(live);
+        #pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t m = __ballot((d >> b) & 1u);
+            same &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        if (live && rank == 0) wcnt[wave][d] = (uint32_t)__popcll(same);      // the lowest lane of the digit publishes the count
+        __syncthreads();
+        if (live) {
+            uint32_t pos = offs[d] + rank;
+            for (int w = 0; w < wave; ++w) pos += wcnt[w][d];
+            key_out[pos] = kk; val_out[pos] = vv;
+        }
+        __syncthreads();
+        offs[threadIdx.x] += wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
+        #pragma unroll
+        for (int w = 0; w < 4; ++w) wcnt[w][threadIdx.x] = 0;
+        __syncthreads();
+    }
+}
+// sorts (key, val) by the low `bits` bits of key; the result is in (key, val) again (bits rounded up to whole bytes, an even
+// number of passes by construction of the callers: 64 or 32 bits).  key2 / val2 / hist: scratch of len, len, 256 * nblk entries.
+template <typename K>
+static void radix_sort_pairs(K *key, K *key2, int32_t *val, int32_t *val2, int64_t len, int bits, int descending,
+                             uint32_t *hist, hipStream_t s)
+{
+    const int nblk = (int)((len + kRsTile - 1) / kRsTile);
+    K *ka = key, *kb = key2; int32_t *va = val, *vb = val2;
+    for (int shift = 0; shift < bits; shift += 8) {
+        hipLaunchKernelGGL((k_rs_hist<K>), dim3(nblk), dim3(256), 0, s, ka, len, shift, descending, nblk, hist);
+        hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, s, hist, (int64_t)256 * nblk);
+        hipLaunchKernelGGL((k_rs_scatter<K>), dim3(nblk), dim3(256), 0, s, ka, va, len, shift, descending, nblk, hist, kb, vb);
+        std::swap(ka, kb); std::swap(va, vb);
+    }
+}
+static size_t radix_sort_hist_entries(int64_t len) { return (size_t)256 * (size_t)((len + kRsTile - 1) / kRsTile); }
+
 
 __global__ void k_grp_keys(const double *__restrict__ y, int64_t len, uint64_t *__restrict__ key, int32_t *__restrict__ idx)
 {
@@ -72,35 +181,30 @@ int group_project_device(double *y_dev, const int64_t *group_dev, int64_t len, i
                          const int64_t *k_dev, int k_is_vector, hipStream_t s)
 {
     if (len >= (1ll << 31)) { set_error("group projection supports len < 2^31"); return MIH_BAD_DIM; }
+    // all temporaries out of one block (Arena): ~14 allocations and frees per projection otherwise, every IHT step
+    Arena arena;
+    const size_t hist_n = std::max(radix_sort_hist_entries(len), radix_sort_hist_entries(G));
+    MIH_TRY(arena.reserve((size_t)len * (8 + 8 + 4 + 4 + 4 + 4 + 4 + 4) + (size_t)(G + 1) * (8 + 8 + 8 + 4 + 4 + 4 + 4) + hist_n * 4 + 32 * 256, 0));
+    ArenaScope in_arena(&arena);
     DevBuf<uint64_t> key, key2, nkey, nkey2;
-    DevBuf<int32_t> idx, perm, member, gid, gid2, rank;
-    DevBuf<uint32_t> lab, lab2;
+    DevBuf<int32_t> idx, perm, member, member2, gid, gid2, rank;
+    DevBuf<uint32_t> lab, lab2, hist;
     DevBuf<int64_t> seg;
     MIH_TRY(key.alloc(len)); MIH_TRY(key2.alloc(len)); MIH_TRY(idx.alloc(len)); MIH_TRY(perm.alloc(len));
-    MIH_TRY(member.alloc(len)); MIH_TRY(lab.alloc(len)); MIH_TRY(lab2.alloc(len)); MIH_TRY(seg.alloc(G + 1));
+    MIH_TRY(member.alloc(len)); MIH_TRY(member2.alloc(len)); MIH_TRY(lab.alloc(len)); MIH_TRY(lab2.alloc(len)); MIH_TRY(seg.alloc(G + 1));
     MIH_TRY(nkey.alloc(G)); MIH_TRY(nkey2.alloc(G)); MIH_TRY(gid.alloc(G)); MIH_TRY(gid2.alloc(G)); MIH_TRY(rank.alloc(G));
+    MIH_TRY(hist.alloc(hist_n));
     unsigned nb = (unsigned)((len + 255) / 256), gb = (unsigned)((G + 255) / 256);
     hipLaunchKernelGGL(k_grp_keys, dim3(nb), dim3(256), 0, s, y_dev, len, key.p, idx.p);
-    size_t tmp_bytes = 0, need = 0;
-    MIH_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, need, key.p, key2.p, idx.p, perm.p, (int)len, 0, 64, s));
-    tmp_bytes = need;
-    MIH_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, need, lab.p, lab2.p, perm.p, member.p, (int)len, 0, 32, s));
-    if (need > tmp_bytes) tmp_bytes = need;
-    MIH_HIP(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, need, nkey.p, nkey2.p, gid.p, gid2.p, (int)G, 0, 64, s));
-    if (need > tmp_bytes) tmp_bytes = need;
-    DevBuf<uint8_t> tmp;
-    MIH_TRY(tmp.alloc(tmp_bytes));
-    size_t tb = tmp_bytes;
-    MIH_HIP(hipcub::DeviceRadixSort::SortPairsDescending(tmp.p, tb, key.p, key2.p, idx.p, perm.p, (int)len, 0, 64, s));
-    hipLaunchKernelGGL(k_grp_labels, dim3(nb), dim3(256), 0, s, perm.p, group_dev, len, lab.p);
-    tb = tmp_bytes;
-    MIH_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, lab.p, lab2.p, perm.p, member.p, (int)len, 0, 32, s));
-    hipLaunchKernelGGL(k_grp_bounds, dim3(nb), dim3(256), 0, s, lab2.p, len, G, seg.p);
+    radix_sort_pairs<uint64_t>(key.p, key2.p, idx.p, perm.p, len, 64, 1, hist.p, s);            // idx = sortperm(|y|, rev = true)
+    hipLaunchKernelGGL(k_grp_labels, dim3(nb), dim3(256), 0, s, idx.p, group_dev, len, lab.p);
+    MIH_HIP(hipMemcpyAsync(member.p, idx.p, sizeof(int32_t) * (size_t)len, hipMemcpyDeviceToDevice, s));
+    radix_sort_pairs<uint32_t>(lab.p, lab2.p, member.p, member2.p, len, 32, 0, hist.p, s);       // segments by group, |y|-descending inside
+    hipLaunchKernelGGL(k_grp_bounds, dim3(nb), dim3(256), 0, s, lab.p, len, G, seg.p);
     hipLaunchKernelGGL(k_grp_norms, dim3(gb), dim3(256), 0, s, y_dev, member.p, seg.p, G, k_dev, k_is_vector, nkey.p, gid.p);
-    tb = tmp_bytes;
-    MIH_HIP(hipcub::DeviceRadixSort::SortPairsDescending(tmp.p, tb, nkey.p, nkey2.p, gid.p, gid2.p, (int)G, 0, 64, s));
-    hipLaunchKernelGGL(k_grp_rank, dim3(gb), dim3(256), 0, s, gid2.p, G, rank.p);
-    hipLaunchKernelGGL(k_grp_apply, dim3(nb), dim3(256), 0, s, y_dev, member.p, lab2.p, seg.p, rank.p, len, J, k_dev, k_is_vector);
+    radix_sort_pairs<uint64_t>(nkey.p, nkey2.p, gid.p, gid2.p, G, 64, 1, hist.p, s);             // groups by norm, descending
+    hipLaunchKernelGGL(k_grp_rank, dim3(gb), dim3(256), 0, s, gid.p, G, rank.p);
+    hipLaunchKernelGGL(k_grp_apply, dim3(nb), dim3(256), 0, s, y_dev, member.p, lab.p, seg.p, rank.p, len, J, k_dev, k_is_vector);
     MIH_HIP(hipGetLastError());
     MIH_HIP(hipStreamSynchronize(s));     // temporaries are released on return
     return MIH_OK;
