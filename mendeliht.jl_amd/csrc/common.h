@@ -239,7 +239,7 @@ int  xtv_work_init(const mih_mat *h, XtvWork &w, int m, bool batched = true);
 // r_dev: m vectors of length n (column-major n x m) on device; out_dev p x m.
 int  xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double *out_dev, hipStream_t s);
 int  xtv_num_variants();
-// residuals of two full 4-operand passes in the batched default format: how many fits the lock-step drivers keep in flight
+// residuals of two full fused passes (five operands each by default) in the batched format: how many fits the lock-step drivers keep in flight
 int  xtv_lockstep_width(const mih_mat *h);
 extern int g_xtv_variant;
 

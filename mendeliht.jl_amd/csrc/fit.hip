@@ -1270,7 +1270,7 @@ int mih_fit_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, co
 // ---- cv_iht: rolling lock-step -----------------------------------------------------------
 // The (fold, k) fits of cross_validation.jl:100-121 are independent; on one GPU they advance in
 // lock-step so that ONE pass over the 2-bit matrix serves the score of every fit in flight
-// (multi-RHS X'R, 12 residual vectors per 4-operand pass).  Each fit keeps its own IHTVariable, backtracks and
+// (multi-RHS X'R, up to 15 residual vectors per 5-operand pass).  Each fit keeps its own IHTVariable, backtracks and
 // converges on its own; a fit that finishes is scored on its held-out samples and its slot is refilled.
 struct CvFit {
     std::unique_ptr<IhtVar> v;
