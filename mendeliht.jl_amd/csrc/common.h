@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -45,6 +46,8 @@ struct Arena {
     ~Arena() { if (dev) (void)hipFree(dev); if (pin) (void)hipHostFree(pin); }
     int reserve(size_t device_bytes, size_t pinned_bytes)
     {
+        static const bool off = getenv("MENDELIHT_NO_ARENA") != nullptr;       // A/B: every buffer its own allocation
+        if (off) return MIH_OK;
         if (hipMalloc((void **)&dev, device_bytes) != hipSuccess) { (void)hipGetLastError(); dev = nullptr; device_bytes = 0; }   // fall back to single buffers
         if (hipHostMalloc((void **)&pin, pinned_bytes, hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); pin = nullptr; pinned_bytes = 0; }
         dev_bytes = device_bytes; pin_bytes = pinned_bytes; dev_off = pin_off = 0;

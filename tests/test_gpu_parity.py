@@ -1505,13 +1505,14 @@ def test_polled_readbacks_and_shared_initial_scores_change_nothing(mih, tmp_path
     """Switches that must not move a bit (each is read once per process, hence one process per variant): the polled readbacks
     (k_publish / k_final_sum_pub + SpinFlag) against device-to-host copies + hipStreamSynchronize (MENDELIHT_NO_SPIN=1); the
     cross-validation / model-path drivers with every fit riding its own initial score and without the tail hand-over
-    (MENDELIHT_CV_NO_INIT_SHARE=1, MENDELIHT_CV_NO_MERGE=1) and with one lock-step lane instead of two.  Univariate Normal and
+    (MENDELIHT_CV_NO_INIT_SHARE=1, MENDELIHT_CV_NO_MERGE=1), with one lock-step lane instead of two, and with every buffer
+    of an IHTVariable as its own allocation instead of a carve-out of one block (MENDELIHT_NO_ARENA=1).  Univariate Normal and
     logistic fits, a cross-validation, a model path and a multivariate fit."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = []
     for i, extra in enumerate(({}, {"MENDELIHT_NO_SPIN": "1"}, {"MENDELIHT_CV_NO_INIT_SHARE": "1", "MENDELIHT_CV_NO_MERGE": "1"},
-                               {"MENDELIHT_CV_LANES": "1"})):
+                               {"MENDELIHT_CV_LANES": "1"}, {"MENDELIHT_NO_ARENA": "1"})):
         f = tmp_path / f"variant_{i}.npz"
         r = subprocess.run([sys.executable, "-c", _NOSPIN_SNIPPET, root, str(f)], capture_output=True, text=True, timeout=900,
                            env=dict(os.environ, **extra))
