@@ -9,6 +9,7 @@
 // logdet) runs on the host exactly as the reference leaves it to LAPACK.
 #include "common.h"
 #include "fit_common.h"
+#include <map>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -269,6 +270,7 @@ static bool lu_logdet_inverse(const std::vector<double> &Ain, int r, double *log
 
 // One mIHTVariable (src/data_structures.jl:140-180), device-resident.
 struct MvVar {
+    Arena arena;                                         // first member: outlives the buffers carved out of it (common.h)
     const mih_mat *h = nullptr;
     int64_t n = 0, p = 0, k = 0; int q = 0, r = 0;
     std::vector<uint8_t> zkeep; int64_t zkeepn = 0;      // r * sum(zkeep)
@@ -311,7 +313,7 @@ struct MvVar {
     bool choose_fired = false;
 
     bool own_stream = true;
-    ~MvVar() { if (s && own_stream) (void)hipStreamDestroy(s); }
+    ~MvVar() { if (s) (void)hipStreamSynchronize(s); if (s && own_stream) (void)hipStreamDestroy(s); }       // see ~IhtVar
 
     // shared_stream != null: one of a lock-step batch (mih_cv_mv): it runs on the batch's stream and leaves the
     // X'R pass to the batch driver
@@ -328,13 +330,22 @@ struct MvVar {
         else MIH_HIP(hipStreamCreate(&s));
         nb = (int)nblk(n);
         size_t rn = (size_t)r * n;
+        int64_t kcap = std::max<int64_t>(k + (int64_t)r * q, 64) + 1024;
+        {
+            const size_t redn = std::max<size_t>((size_t)nb, (size_t)kMaxR * kMaxR * kRedBlocks);
+            size_t dev = sizeof(double) * (5 * rn + (size_t)q * n + 2 * (size_t)n + (size_t)r * p + (size_t)r * (p + q) + redn + (size_t)kMaxR * kMaxR + 64
+                                           + 2 * (size_t)kcap + (size_t)kcap * r) + (size_t)n + sizeof(int32_t) * 2 * (size_t)kMaxR * kMaxR
+                         + xv_work_bytes(h, kcap) + sizeof(uint32_t) * 2048 + 64 + 16 * ((size_t)kcap + 1025) + 40 * 256;
+            size_t pin = sizeof(uint64_t) * (2 + 2 * ((size_t)kcap + 64) + 16) + 4 * 256;
+            MIH_TRY(arena.reserve(dev, pin));
+        }
+        ArenaScope in_arena(&arena);
         MIH_TRY(Y.alloc(rn)); MIH_TRY(Z.alloc((size_t)q * n)); MIH_TRY(w.alloc(n)); MIH_TRY(BX.alloc(rn)); MIH_TRY(MU.alloc(rn));
         MIH_TRY(RES.alloc(rn)); MIH_TRY(T1.alloc(rn)); MIH_TRY(DF.alloc((size_t)r * p)); MIH_TRY(full.alloc((size_t)r * (p + q)));
         MIH_TRY(red.alloc(std::max<size_t>((size_t)nb, (size_t)kMaxR * kMaxR * kRedBlocks))); MIH_TRY(scal.alloc((size_t)kMaxR * kMaxR + 64));
         MIH_TRY(tmpn.alloc(n)); MIH_TRY(mask.alloc(n)); MIH_TRY(pairs.alloc(2 * (size_t)kMaxR * kMaxR));
-        int64_t kcap = std::max<int64_t>(k + (int64_t)r * q, 64) + 1024;
         MIH_TRY(sidx.alloc(kcap)); MIH_TRY(sval.alloc(kcap)); MIH_TRY(gval.alloc((size_t)kcap * r));
-        if (own_stream) MIH_TRY(xtv_work_init(h, xtv, r));
+        if (own_stream) { ArenaScope own_buffers(nullptr); MIH_TRY(xtv_work_init(h, xtv, r)); }
         MIH_TRY(xv_work_init(h, xv, kcap)); MIH_TRY(topk_work_init(topk, kcap));
         // Y (r x n) and Z (q x n) column-major -> planes
         std::vector<double> pl(std::max(rn, (size_t)q * n));
@@ -815,12 +826,24 @@ int mih_cv_mv(const mih_mat *h, const mih_fit_params *prm, const double *Y, int6
     XtvWork xw; DevBuf<double> R, DF;
     MIH_TRY(xtv_work_init(h, xw, mb * rr));
     MIH_TRY(R.alloc((size_t)mb * rr * n));
-    MIH_TRY(DF.alloc((size_t)mb * rr * h->p));
+    // as in cv_run_rolling (fit.hip): the fits of a fold start from the same residuals (initial score before k plays a role,
+    // multivariate.jl:376-452) -- one fit per fold rides the pass, its r x p block of X'R is kept behind the pass's outputs;
+    // finished fits hand their mIHTVariable (sized for max(path)) to the fits started next
+    const bool share_init = !prm->init_beta && getenv("MENDELIHT_CV_NO_INIT_SHARE") == nullptr;
+    const int init_slots = share_init ? (int)std::min<int64_t>(nfolds, 8) : 0;
+    MIH_TRY(DF.alloc((size_t)(mb + init_slots) * rr * h->p));
+    std::map<int, double *> df0;
+    std::vector<std::unique_ptr<MvVar>> pool;
+    int64_t kmax = 0;
+    for (int64_t i = 0; i < npath; ++i) kmax = std::max(kmax, path[i]);
     struct MvFit {
         std::unique_ptr<MvVar> v; std::vector<uint8_t> train; int64_t out_index = 0; int iter = 1, nbt = 0;
         double next_logl = -std::numeric_limits<double>::infinity(), best = -std::numeric_limits<double>::infinity();
         bool done = false;
+        int init_key = -1;
     };
+    std::vector<MvFit *> riders;
+    std::vector<std::pair<MvFit *, double *>> owners, followers;
     auto batched_xtv = [&](std::vector<MvFit *> &need) -> int {
         const int m = (int)need.size();
         if (m == 0) return MIH_OK;
@@ -845,7 +868,7 @@ int mih_cv_mv(const mih_mat *h, const mih_fit_params *prm, const double *Y, int6
         MIH_HIP(hipStreamSynchronize(v.s));
         mses_raw[f.out_index] = mse;
         f.done = true;
-        f.v.reset();
+        pool.push_back(std::move(f.v));
         return MIH_OK;
     };
     // rolling lock-step (as cv_run_rolling in fit.hip): a new fit needs its initial score, a running fit the score that
@@ -863,13 +886,26 @@ int mih_cv_mv(const mih_mat *h, const mih_fit_params *prm, const double *Y, int6
                     const size_t i = next++;
                     slot[t].reset(new MvFit());
                     MvFit &f = *slot[t];
-                    mih_fit_params pf = pr; pf.k = path[mine[i].second];          // v.k = sparsity (cross_validation.jl:110)
-                    f.v.reset(new MvVar());
-                    MIH_TRY(f.v->create(h, &pf, Y, r, Z, q, s));
+                    if (!pool.empty()) { f.v = std::move(pool.back()); pool.pop_back(); }
+                    else {
+                        mih_fit_params pf = pr; pf.k = kmax;                          // buffers sized for max(path), then
+                        f.v.reset(new MvVar());
+                        MIH_TRY(f.v->create(h, &pf, Y, r, Z, q, s));
+                    }
+                    f.v->k = path[mine[i].second];                                    // v.k = sparsity (cross_validation.jl:110)
                     f.train.resize(n);
                     for (int64_t l = 0; l < n; ++l) f.train[l] = (folds[l] != mine[i].first);
                     f.out_index = (int64_t)(mine[i].first - 1) * npath + mine[i].second;
+                    f.init_key = share_init ? (int)mine[i].first : -1;
                     MIH_TRY(f.v->init_pre(f.train.data()));
+                    if (f.init_key >= 0) {
+                        auto it = df0.find(f.init_key);
+                        if (it != df0.end()) {       // its initial X'R is known from an earlier round: straight on to its first step
+                            MIH_HIP(hipMemcpyAsync(f.v->DF.p, it->second, sizeof(double) * (size_t)rr * h->p, hipMemcpyDeviceToDevice, s));
+                            MIH_TRY(f.v->init_post());
+                            continue;
+                        }
+                    }
                     need.push_back(&f); fresh.push_back(1);
                     break;
                 }
@@ -883,7 +919,23 @@ int mih_cv_mv(const mih_mat *h, const mih_fit_params *prm, const double *Y, int6
             }
         }
         if (need.empty()) break;
-        MIH_TRY(batched_xtv(need));
+        riders.clear(); owners.clear(); followers.clear();
+        for (size_t t = 0; t < need.size(); ++t) {
+            MvFit *f = need[t];
+            const int key = fresh[t] ? f->init_key : -1;
+            if (key < 0) { riders.push_back(f); continue; }
+            auto it = df0.find(key);
+            if (it != df0.end()) { followers.emplace_back(f, it->second); continue; }      // same fold, same round: copy the rider's block
+            riders.push_back(f);
+            if ((int)df0.size() < init_slots) {
+                double *buf = DF.p + ((size_t)mb + df0.size()) * (size_t)rr * h->p;
+                df0[key] = buf;
+                owners.emplace_back(f, buf);
+            }
+        }
+        MIH_TRY(batched_xtv(riders));
+        for (auto &o : owners) MIH_HIP(hipMemcpyAsync(o.second, o.first->v->DF.p, sizeof(double) * (size_t)rr * h->p, hipMemcpyDeviceToDevice, s));
+        for (auto &fo : followers) MIH_HIP(hipMemcpyAsync(fo.first->v->DF.p, fo.second, sizeof(double) * (size_t)rr * h->p, hipMemcpyDeviceToDevice, s));
         for (size_t t = 0; t < need.size(); ++t) {
             MvFit *f = need[t];
             if (fresh[t]) { MIH_TRY(f->v->init_post()); continue; }

@@ -1497,6 +1497,8 @@ out["path"] = np.asarray(m.iht_run_many_models(yb, x, z, path=range(1, 7), verbo
 Y = np.vstack([y, 0.5 * y + rng.standard_normal(6001), rng.standard_normal(6001)])
 r = m.fit_iht(Y, x, None, k=12, verbose=False, max_iter=10)
 out["mvbeta"], out["mvlogl"] = r.beta, np.array([r.logl, r.iter])
+_, raw = m.cv_iht(Y, x, None, path=[2, 5, 9, 14], q=3, folds=hash_folds(6001, 3), verbose=False, return_raw=True)
+out["mvcv"] = raw
 np.savez(sys.argv[2], **out)
 """
 
@@ -1518,9 +1520,9 @@ def test_polled_readbacks_and_shared_initial_scores_change_nothing(mih, tmp_path
                            env=dict(os.environ, **extra))
         assert r.returncode == 0, r.stdout + r.stderr
         res.append(np.load(f))
-    assert len(res[0].files) == 9
+    assert len(res[0].files) == 10
     for other in res[1:]:
         assert sorted(res[0].files) == sorted(other.files)
         for k in res[0].files:
             assert np.array_equal(res[0][k].view(np.uint64), other[k].view(np.uint64)), k
-    assert res[0]["logl"][1] > 2 and np.count_nonzero(res[0]["cv"]) == 24 and res[0]["path"].size == 6
+    assert res[0]["logl"][1] > 2 and np.count_nonzero(res[0]["cv"]) == 24 and res[0]["path"].size == 6 and np.count_nonzero(res[0]["mvcv"]) == 12
