@@ -1,6 +1,10 @@
 // common.h -- internal declarations shared by the HIP translation units.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <chrono>
+#include <map>
+#include <mutex>
+#include <iterator>
 #include <cstdint>
 #include <cstdlib>
 #include <cstdio>
@@ -32,6 +36,71 @@ constexpr int kChunkRows = 1024;
 
 inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
+// A large matrix keeps a reserve of device memory for the fits that will run on it (DevPool): the lock-step lanes' workspaces
+// and the IHTVariables' blocks are cut out of it, so a fit never calls hipMalloc / hipFree.  Reasons: (1) on this driver the
+// first hipMalloc that lands in a large never-used block of VRAM stalls ~2.9 s while the block is cleared -- in 7 of 16 fresh
+// processes that was the creation of an IHTVariable inside the first cv_iht (6 s instead of 3 s; an allocate-and-release
+// warm-up at matrix creation cut it to 1 in 16, holding the memory removes it); (2) every hipFree waits for the device.
+// First fit with coalescing; 2 MB granularity; requests it cannot serve fall back to hipMalloc.
+struct DevPool {
+    char *base = nullptr; size_t bytes = 0;
+    std::mutex mu;
+    std::map<size_t, size_t> free_blocks;      // offset -> size
+    std::map<size_t, size_t> used;             // offset -> size
+    static constexpr size_t kGran = 2ull << 20;
+    ~DevPool() { if (base) (void)hipFree(base); }
+    bool init(size_t total)
+    {
+        total = (total + kGran - 1) / kGran * kGran;
+        if (hipMalloc((void **)&base, total) != hipSuccess) { (void)hipGetLastError(); base = nullptr; return false; }
+        bytes = total; free_blocks[0] = total;
+        return true;
+    }
+    void *take(size_t want)
+    {
+        want = (want + kGran - 1) / kGran * kGran;
+        std::lock_guard<std::mutex> g(mu);
+        for (auto it = free_blocks.begin(); it != free_blocks.end(); ++it) {
+            if (it->second < want) continue;
+            const size_t off = it->first, sz = it->second;
+            free_blocks.erase(it);
+            if (sz > want) free_blocks[off + want] = sz - want;
+            used[off] = want;
+            return base + off;
+        }
+        return nullptr;
+    }
+    bool owns(const void *q) const { return base && (const char *)q >= base && (const char *)q < base + bytes; }
+    void give_back(void *q)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        const size_t off = (size_t)((char *)q - base);
+        auto u = used.find(off);
+        if (u == used.end()) return;
+        size_t o = off, sz = u->second;
+        used.erase(u);
+        auto nx = free_blocks.lower_bound(o);
+        if (nx != free_blocks.end() && o + sz == nx->first) { sz += nx->second; nx = free_blocks.erase(nx); }
+        if (nx != free_blocks.begin()) { auto pv = std::prev(nx); if (pv->first + pv->second == o) { o = pv->first; sz += pv->second; free_blocks.erase(pv); } }
+        free_blocks[o] = sz;
+    }
+};
+inline DevPool *&current_pool() { static thread_local DevPool *q = nullptr; return q; }
+struct PoolScope {
+    DevPool *prev;
+    explicit PoolScope(DevPool *q) : prev(current_pool()) { current_pool() = q; }
+    ~PoolScope() { current_pool() = prev; }
+};
+// device memory from the thread's current pool if it has room (and the request is worth a 2 MB granule), else hipMalloc
+inline hipError_t dev_malloc(void **q, size_t bytes, DevPool **from)
+{
+    *from = nullptr;
+    if (DevPool *pl = current_pool()) {
+        if (bytes >= (1ull << 20)) { if (void *r = pl->take(bytes)) { *q = r; *from = pl; return hipSuccess; } }
+    }
+    return hipMalloc(q, bytes);
+}
+
 // An IHTVariable owns ~26 device and ~5 pinned buffers.  One hipMalloc of a few MB costs ~100 us and every hipFree ~150 us
 // (it also waits for whatever the device is running): 6 ms per IHTVariable, 14 % of a GPU's 13-fit share of a cross-validation
 // (tools/pin_alloc_time.hip).  While an Arena is the thread's current one (ArenaScope), DevBuf / PinBuf allocations are carved
@@ -39,16 +108,18 @@ inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 // (later growth), they fall back to their own hipMalloc / hipHostMalloc.
 struct Arena {
     char *dev = nullptr, *pin = nullptr;
+    DevPool *dev_pool = nullptr;
     size_t dev_bytes = 0, pin_bytes = 0, dev_off = 0, pin_off = 0;
     Arena() = default;
     Arena(const Arena &) = delete;
     Arena &operator=(const Arena &) = delete;
-    ~Arena() { if (dev) (void)hipFree(dev); if (pin) (void)hipHostFree(pin); }
+    ~Arena() { release_dev(); if (pin) (void)hipHostFree(pin); }
+    void release_dev() { if (dev) { if (dev_pool) dev_pool->give_back(dev); else (void)hipFree(dev); dev = nullptr; } }
     int reserve(size_t device_bytes, size_t pinned_bytes)
     {
         static const bool off = getenv("MENDELIHT_NO_ARENA") != nullptr;       // A/B: every buffer its own allocation
         if (off) return MIH_OK;
-        if (hipMalloc((void **)&dev, device_bytes) != hipSuccess) { (void)hipGetLastError(); dev = nullptr; device_bytes = 0; }   // fall back to single buffers
+        if (dev_malloc((void **)&dev, device_bytes, &dev_pool) != hipSuccess) { (void)hipGetLastError(); dev = nullptr; device_bytes = 0; }   // fall back to single buffers
         if (hipHostMalloc((void **)&pin, pinned_bytes, hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); pin = nullptr; pinned_bytes = 0; }
         dev_bytes = device_bytes; pin_bytes = pinned_bytes; dev_off = pin_off = 0;
         return MIH_OK;
@@ -81,11 +152,12 @@ struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
     bool own = true;           // false: carved out of an Arena (which outlives the buffer's owner)
+    DevPool *pool = nullptr;   // own && pool: a block of the matrix's DevPool
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
-    void release() { if (p && own) (void)hipFree(p); p = nullptr; n = 0; own = true; }
+    void release() { if (p && own) { if (pool) pool->give_back(p); else (void)hipFree(p); } p = nullptr; n = 0; own = true; pool = nullptr; }
     void attach(T *ptr, size_t count) { release(); p = ptr; n = count; own = false; }     // someone else's memory (read-only sharing)
     int alloc(size_t count) {
         release();
@@ -93,7 +165,7 @@ struct DevBuf {
         if (Arena *a = current_arena()) {
             if (void *q = a->take_dev(count * sizeof(T))) { p = static_cast<T *>(q); n = count; own = false; return MIH_OK; }
         }
-        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        hipError_t e = dev_malloc((void **)&p, count * sizeof(T), &pool);
         if (e != hipSuccess) { set_error("hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e)); p = nullptr; return e == hipErrorOutOfMemory ? MIH_OOM : MIH_HIP_ERROR; }
         n = count;
         return MIH_OK;
@@ -202,6 +274,7 @@ struct mih_mat {
     double   *D = nullptr;         // dense n x p (Float64 storage)
     float    *Df = nullptr;        // dense n x p (Float32 storage: `x::Matrix{Float32}`; arithmetic stays f64)
     hipStream_t stream = nullptr;  // for the stand-alone linear-algebra entry points
+    mih::DevPool *pool = nullptr;  // reserve for the fits that run on this matrix (large 2-bit matrices only)
 };
 
 namespace mih {
@@ -265,8 +338,8 @@ struct XvWork {
     uint64_t tick = 0;
     std::vector<int32_t> h_slots; std::vector<int64_t> h_fills;   // host images of slot_dev / fill_dev of the last call
 };
-int  xv_work_init(const mih_mat *h, XvWork &w, int64_t max_nnz);
-size_t xv_work_bytes(const mih_mat *h, int64_t max_nnz);
+int  xv_work_init(const mih_mat *h, XvWork &w, int64_t max_nnz, int64_t cache_nnz = 0);
+size_t xv_work_bytes(const mih_mat *h, int64_t max_nnz, int64_t cache_nnz = 0);
 // out[i] = sum_t x[i, idx[t]] * val[t]; idx/val on device; clamp20 applies clamp!(out,-20,20).  idx_host (the same
 // indices on the host) enables the column cache.
 int  xv_sparse_device(const mih_mat *h, XvWork &w, const int64_t *idx_dev, const double *val_dev,

@@ -478,7 +478,7 @@ struct IhtVar {
         {
             size_t dev = sizeof(double) * ((size_t)n * (7 + q) + 2 * (size_t)p + q) + (size_t)n
                          + sizeof(double) * ((size_t)nb * 4 + kMaxQ + 8 + (size_t)kMaxQ * kZtrBlocks) + sizeof(unsigned) * kMaxQ
-                         + 3 * sizeof(double) * (size_t)kcap + xv_work_bytes(h, kcap)
+                         + 3 * sizeof(double) * (size_t)kcap + xv_work_bytes(h, kcap, kcap - 1024)
                          + sizeof(uint32_t) * 2048 + 64 + 16 * ((size_t)kcap + 1025)
                          + (prm->weight ? sizeof(double) * (size_t)p : 0) + (prm->group ? sizeof(int64_t) * ((size_t)p + ks.size() + 1) : 0)
                          + 48 * 256;
@@ -498,7 +498,7 @@ struct IhtVar {
         MIH_TRY(hpin.alloc((size_t)kcap + kMaxQ + 16, true));
         MIH_TRY(flag.word.alloc(8, true)); flag.word.p[0] = 0; flag.seq = 0;
         if (!batched) { ArenaScope own_buffers(nullptr); MIH_TRY(xtv_work_init(h, xtv, 1, false)); }     // a few large buffers: their own allocations
-        MIH_TRY(xv_work_init(h, xv, kcap));
+        MIH_TRY(xv_work_init(h, xv, kcap, kcap - 1024));       // the cache is sized for the model, not for the tie slack of the lists
         MIH_TRY(topk_work_init(topk, kcap));
         if (!(y_shared && z_shared)) {
             MIH_HIP(hipMemcpyAsync(y.p, yh, sizeof(double) * n, hipMemcpyHostToDevice, s));
@@ -1243,6 +1243,7 @@ extern "C" {
 int mih_fit_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, const double *z,
                 int64_t q, const uint8_t *train, mih_fit_result *res)
 {
+    PoolScope from_reserve(h ? h->pool : nullptr);      // device buffers out of the matrix's reserve (DevPool, common.h)
     MIH_TRY(check_params(h, prm, q));
     if (!y || !z || !res) { set_error("null argument"); return MIH_BAD_ARG; }
     MIH_HIP(hipSetDevice(h->device));
@@ -1483,6 +1484,7 @@ static int cv_run_lanes(const mih_mat *h, const mih_fit_params &pr, size_t total
     const bool merge_tail = lanes == 2 && !getenv("MENDELIHT_CV_NO_MERGE");
     std::vector<DevBuf<double>> yds((size_t)lanes), zds((size_t)lanes);
     auto lane = [&](int lane_id) -> int {
+        PoolScope from_reserve(h->pool);                        // workspaces and IHTVariables out of the matrix's reserve (no hipMalloc)
         MIH_HIP(hipSetDevice(h->device));
         hipStream_t s = nullptr;
         MIH_HIP(hipStreamCreate(&s));
@@ -1519,6 +1521,7 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, con
                int64_t q, const int32_t *folds, int32_t nfolds, const int64_t *path, int64_t npath,
                int32_t rank, int32_t world, double *mses_raw)
 {
+    PoolScope from_reserve(h ? h->pool : nullptr);      // device buffers out of the matrix's reserve (DevPool, common.h)
     MIH_TRY(check_params(h, prm, q));
     if (prm->comm) { set_error("cross-validation shards over (fold,k) combinations (rank/world), not over columns"); return MIH_BAD_ARG; }
     if (!y || !z || !folds || !path || !mses_raw || nfolds < 1 || npath < 1 || world < 1 || rank < 0 || rank >= world) { set_error("null/invalid argument"); return MIH_BAD_ARG; }
@@ -1583,6 +1586,7 @@ int mih_fit_iht_path(const mih_mat *h, const mih_fit_params *prm, const double *
                      const int64_t *path, int64_t npath, int32_t rank, int32_t world,
                      double *logl_out, int64_t *iter_out, double *beta_out, double *c_out)
 {
+    PoolScope from_reserve(h ? h->pool : nullptr);      // device buffers out of the matrix's reserve (DevPool, common.h)
     MIH_TRY(check_params(h, prm, q));
     if (prm->comm) { set_error("model paths shard over the path entries (rank/world), not over columns"); return MIH_BAD_ARG; }
     if (!y || !z || !path || !logl_out || npath < 1 || world < 1 || rank < 0 || rank >= world) { set_error("null/invalid argument"); return MIH_BAD_ARG; }
@@ -1668,6 +1672,7 @@ struct mih_session_impl {
 int mih_session_create(const mih_mat *h, const mih_fit_params *prm, const double *y, const double *z,
                        int64_t q, const uint8_t *train, mih_session **out)
 {
+    PoolScope from_reserve(h ? h->pool : nullptr);      // device buffers out of the matrix's reserve (DevPool, common.h)
     MIH_TRY(check_params(h, prm, q));
     if (!y || !z || !out) { set_error("null argument"); return MIH_BAD_ARG; }
     MIH_HIP(hipSetDevice(h->device));

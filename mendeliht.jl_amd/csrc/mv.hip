@@ -335,7 +335,7 @@ struct MvVar {
             const size_t redn = std::max<size_t>((size_t)nb, (size_t)kMaxR * kMaxR * kRedBlocks);
             size_t dev = sizeof(double) * (5 * rn + (size_t)q * n + 2 * (size_t)n + (size_t)r * p + (size_t)r * (p + q) + redn + (size_t)kMaxR * kMaxR + 64
                                            + 2 * (size_t)kcap + (size_t)kcap * r) + (size_t)n + sizeof(int32_t) * 2 * (size_t)kMaxR * kMaxR
-                         + xv_work_bytes(h, kcap) + sizeof(uint32_t) * 2048 + 64 + 16 * ((size_t)kcap + 1025) + 40 * 256;
+                         + xv_work_bytes(h, kcap, kcap - 1024) + sizeof(uint32_t) * 2048 + 64 + 16 * ((size_t)kcap + 1025) + 40 * 256;
             size_t pin = sizeof(uint64_t) * (2 + 2 * ((size_t)kcap + 64) + 16) + 4 * 256;
             MIH_TRY(arena.reserve(dev, pin));
         }
@@ -346,7 +346,7 @@ struct MvVar {
         MIH_TRY(tmpn.alloc(n)); MIH_TRY(mask.alloc(n)); MIH_TRY(pairs.alloc(2 * (size_t)kMaxR * kMaxR));
         MIH_TRY(sidx.alloc(kcap)); MIH_TRY(sval.alloc(kcap)); MIH_TRY(gval.alloc((size_t)kcap * r));
         if (own_stream) { ArenaScope own_buffers(nullptr); MIH_TRY(xtv_work_init(h, xtv, r)); }
-        MIH_TRY(xv_work_init(h, xv, kcap)); MIH_TRY(topk_work_init(topk, kcap));
+        MIH_TRY(xv_work_init(h, xv, kcap, kcap - 1024)); MIH_TRY(topk_work_init(topk, kcap));
         // Y (r x n) and Z (q x n) column-major -> planes
         std::vector<double> pl(std::max(rn, (size_t)q * n));
         for (int64_t sidx_ = 0; sidx_ < n; ++sidx_) for (int i = 0; i < r; ++i) pl[(size_t)i * n + sidx_] = Yh[i + (size_t)r * sidx_];
@@ -763,6 +763,7 @@ extern "C" {
 int mih_fit_mv(const mih_mat *h, const mih_fit_params *prm, const double *Y, int64_t r, const double *Z, int64_t q,
                const uint8_t *train, mih_mv_result *res)
 {
+    PoolScope from_reserve(h ? h->pool : nullptr);      // device buffers out of the matrix's reserve (DevPool, common.h)
     MIH_TRY(mv_check(h, prm));
     if (!Y || !Z || !res) { set_error("null argument"); return MIH_BAD_ARG; }
     MIH_HIP(hipSetDevice(h->device));
@@ -800,6 +801,7 @@ int mih_cv_mv(const mih_mat *h, const mih_fit_params *prm, const double *Y, int6
               const int32_t *folds, int32_t nfolds, const int64_t *path, int64_t npath, int32_t rank, int32_t world,
               double *mses_raw)
 {
+    PoolScope from_reserve(h ? h->pool : nullptr);      // device buffers out of the matrix's reserve (DevPool, common.h)
     MIH_TRY(mv_check(h, prm));
     if (!Y || !Z || !folds || !path || !mses_raw || nfolds < 1 || npath < 1 || world < 1 || rank < 0 || rank >= world) { set_error("null/invalid argument"); return MIH_BAD_ARG; }
     if (r < 1 || r > kMaxR) { set_error("number of traits r=%lld must be in 1..%d", (long long)r, kMaxR); return MIH_BAD_DIM; }

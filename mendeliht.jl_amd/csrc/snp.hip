@@ -3,6 +3,7 @@
 // generators, export.  Replaces the SnpLinAlg constructor the reference calls at
 // src/wrapper.jl:68-69 (SnpArrays.jl linalg_direct.jl; semantics SURVEY.md 8c).
 #include "common.h"
+#include <memory>
 #include <cstdarg>
 #include <cmath>
 #include <cstdlib>
@@ -388,6 +389,25 @@ static int select_device(int device)
     return MIH_OK;
 }
 
+// A large matrix reserves the device memory its fits will work in (DevPool, common.h): about what a cross-validation asks for
+// -- four fused-pass workspaces and 64 IHTVariable blocks, 15.7 GB beside a 125 GB matrix.  Whatever the driver has to do to
+// hand out never-used VRAM (one stall of ~2.9 s was measured) it does here, when the matrix is created, and no fit ever calls
+// hipMalloc / hipFree.  MENDELIHT_NO_RESERVE=1: no reserve (every buffer from hipMalloc).
+static void reserve_fit_memory(mih_mat *h)
+{
+    static const bool off = getenv("MENDELIHT_NO_RESERVE") != nullptr;
+    const size_t x_bytes = (size_t)h->ncg * (size_t)h->nbp * 1024;
+    if (off || h->kind != 0 || x_bytes < (4ull << 30)) return;
+    size_t big = (size_t)1920 * (size_t)h->p;                    // the row-slice partials of a 15-residual pass
+    big = std::min<size_t>(std::max<size_t>(big, 256ull << 20), 4ull << 30);
+    const size_t want = 4 * big + 64 * (128ull << 20);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (free_b < 4 * want) return;                               // not on a crowded device
+    std::unique_ptr<DevPool> pool(new DevPool());
+    if (pool->init(want)) h->pool = pool.release();
+}
+
 int mih_snp_create(const uint8_t *bed_cols, int64_t n, int64_t p, int64_t col_stride_bytes,
                    int center, int scale, int impute, int dtype, int device, mih_mat **out)
 {
@@ -469,6 +489,7 @@ int mih_snp_create(const uint8_t *bed_cols, int64_t n, int64_t p, int64_t col_st
         hipLaunchKernelGGL(k_missing_from_tiles, dim3((unsigned)h->ncg), dim3(64), 0, h->stream, reinterpret_cast<uint4 *>(h->X), h->nbp, p,
                            h->miss_ptr, h->miss_row);
     if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(MIH_HIP_ERROR);
+    reserve_fit_memory(h);
     *out = h;
     return MIH_OK;
 }
@@ -509,6 +530,7 @@ int mih_snp_create_synthetic_shard(int64_t n, int64_t p, int64_t col_offset, uin
         hipLaunchKernelGGL(k_fill_missing_synth, dim3((unsigned)p), dim3(64), 0, h->stream, n, p, col_offset, seed, miss_thr, h->miss_ptr, h->miss_row);
         if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(MIH_HIP_ERROR);
     }
+    reserve_fit_memory(h);
     *out = h;
     return MIH_OK;
 }
@@ -571,6 +593,7 @@ int mih_mat_destroy(mih_mat *h)
     if (h->D) (void)hipFree(h->D);
     if (h->Df) (void)hipFree(h->Df);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h->pool;
     delete h;
     return MIH_OK;
 }

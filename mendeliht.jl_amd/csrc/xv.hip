@@ -365,34 +365,38 @@ __global__ void k_clamp20(double *__restrict__ x, int64_t n)
 }
 
 // device bytes xv_work_init will ask for (the caller sizes its Arena with it)
-size_t xv_work_bytes(const mih_mat *h, int64_t max_nnz)
+size_t xv_work_bytes(const mih_mat *h, int64_t max_nnz, int64_t cache_nnz)
 {
     if (max_nnz < 64) max_nnz = 64;
+    if (cache_nnz <= 0 || cache_nnz > max_nnz) cache_nnz = max_nnz;
     size_t b = 2 * sizeof(double) * (size_t)max_nnz + 4 * 256;
     if (h->kind != 0) return b + sizeof(double) * (size_t)kXvGroups * (size_t)h->n;
     const int64_t ndw = h->n_pad / 16;
-    int64_t want = 2 * max_nnz + 64;
+    int64_t want = 2 * cache_nnz + 64;
     const int64_t budget = (int64_t)(1ull << 31) / (ndw * 4);
     if (want > budget) want = budget;
-    if (want >= max_nnz) b += (size_t)want * (size_t)ndw * 4 + (size_t)want * 12 + 3 * 256;
+    if (want >= cache_nnz) b += (size_t)want * (size_t)ndw * 4 + (size_t)want * 12 + 3 * 256;
     return b;
 }
 
-int xv_work_init(const mih_mat *h, XvWork &w, int64_t max_nnz)
+// max_nnz: the longest support list the staging buffers must take (ties included); cache_nnz: the support size the column cache is
+// built for (2 x that + 64 slots: a longer list falls back to reading the tile-major matrix directly)
+int xv_work_init(const mih_mat *h, XvWork &w, int64_t max_nnz, int64_t cache_nnz)
 {
     w.groups = kXvGroups;
     int64_t np = (h->kind == 0) ? h->n_pad : h->n;
     if (h->kind != 0) MIH_TRY(w.partial.alloc((size_t)w.groups * (size_t)np));      // the dense path still reduces through HBM
     if (max_nnz < 64) max_nnz = 64;
+    if (cache_nnz <= 0 || cache_nnz > max_nnz) cache_nnz = max_nnz;
     MIH_TRY(w.coefA.alloc((size_t)max_nnz));
     MIH_TRY(w.coefB.alloc((size_t)max_nnz));
     w.cap = max_nnz;
     if (h->kind == 0) {
         const int64_t ndw = h->n_pad / 16;
-        int64_t want = 2 * max_nnz + 64;
+        int64_t want = 2 * cache_nnz + 64;
         const int64_t budget = (int64_t)(1ull << 31) / (ndw * 4);          // at most 2 GB of cached columns
         if (want > budget) want = budget;
-        if (want >= max_nnz) {
+        if (want >= cache_nnz) {
             MIH_TRY(w.cache.alloc((size_t)want * (size_t)ndw));
             MIH_TRY(w.slot_dev.alloc((size_t)want));
             MIH_TRY(w.fill_dev.alloc((size_t)want));
