@@ -83,8 +83,8 @@ int mih_dense_create(const double *x, int64_t n, int64_t p, int device, mih_mat 
  * reference's all-Float32 run. */
 int mih_dense_create_f32(const float *x, int64_t n, int64_t p, int device, mih_mat **out);
 int mih_dense_create_synthetic(int64_t n, int64_t p, uint64_t seed, int device, mih_mat **out);
-/* Releases the matrix and, for large 2-bit matrices, the reserve of device memory its fits work in: every mih_session
- * created on the matrix must have been destroyed before (fits and cross-validations release theirs on return). */
+/* Releases the matrix.  A mih_session must not be stepped after its matrix is gone, but it may be destroyed later: the
+ * reserve of device memory a large matrix keeps for its fits lives until its last user. */
 int mih_mat_destroy(mih_mat *h);
 int mih_mat_dims(const mih_mat *h, int64_t *n, int64_t *p);
 /* `x.μ`, `x.σinv` of the SnpLinAlg */

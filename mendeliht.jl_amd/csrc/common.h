@@ -5,6 +5,7 @@
 #include <map>
 #include <mutex>
 #include <iterator>
+#include <memory>
 #include <cstdint>
 #include <cstdlib>
 #include <cstdio>
@@ -275,6 +276,7 @@ struct mih_mat {
     float    *Df = nullptr;        // dense n x p (Float32 storage: `x::Matrix{Float32}`; arithmetic stays f64)
     hipStream_t stream = nullptr;  // for the stand-alone linear-algebra entry points
     mih::DevPool *pool = nullptr;  // reserve for the fits that run on this matrix (large 2-bit matrices only)
+    std::shared_ptr<mih::DevPool> pool_owner;      // a session keeps a reference: the reserve outlives a matrix destroyed first
 };
 
 namespace mih {

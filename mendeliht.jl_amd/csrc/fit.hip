@@ -399,7 +399,8 @@ int init_beta_regress_device(const mih_mat *h, const double *w_dev, const double
 }
 
 struct IhtVar {
-    Arena arena;                                  // first member: the memory outlives every buffer carved out of it
+    std::shared_ptr<DevPool> reserve;             // very first member: the matrix's reserve outlives this variable's blocks
+    Arena arena;                                  // the memory outlives every buffer carved out of it
     const mih_mat *h = nullptr;
     int64_t n = 0, p = 0; int q = 0;
     int64_t k = 0, J = 1; std::vector<int64_t> ks;
@@ -454,6 +455,7 @@ struct IhtVar {
                hipStream_t shared_stream = nullptr, double *y_shared = nullptr, double *z_shared = nullptr)
     {
         h = hh; n = h->n; p = h->p; q = (int)qq; y_host = yh; z_host = zh; init_beta = prm->init_beta;
+        reserve = h->pool_owner;
         comm = prm->comm; pg = p; col0 = 0; debias = prm->debias;
         if (comm) {
             if (!comm->allreduce || !comm->allgather || comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world ||

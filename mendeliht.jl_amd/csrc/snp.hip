@@ -404,8 +404,8 @@ static void reserve_fit_memory(mih_mat *h)
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return; }
     if (free_b < 4 * want) return;                               // not on a crowded device
-    std::unique_ptr<DevPool> pool(new DevPool());
-    if (pool->init(want)) h->pool = pool.release();
+    std::shared_ptr<DevPool> pool(new DevPool());
+    if (pool->init(want)) { h->pool_owner = pool; h->pool = pool.get(); }
 }
 
 int mih_snp_create(const uint8_t *bed_cols, int64_t n, int64_t p, int64_t col_stride_bytes,
@@ -593,8 +593,7 @@ int mih_mat_destroy(mih_mat *h)
     if (h->D) (void)hipFree(h->D);
     if (h->Df) (void)hipFree(h->Df);
     if (h->stream) (void)hipStreamDestroy(h->stream);
-    delete h->pool;
-    delete h;
+    delete h;                                  // the reserve goes with its last owner (pool_owner)
     return MIH_OK;
 }
 
