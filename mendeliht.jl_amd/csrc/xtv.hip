@@ -541,6 +541,13 @@ k_xtv_mfma_lds(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint
 // operands in registers, take 20.0 ms at 1.63 GHz: tools/mfma_rate.hip).
 typedef int i32x4v __attribute__((ext_vector_type(4)));
 typedef int i32x2v __attribute__((ext_vector_type(2)));
+// One ds_read_b64 (64 banks, 2 LDS cycles per wave) that the compiler may not pair with a neighbour: two plain 8-byte loads at
+// constant distance become ds_read2_b64 / ds_read2st64_b64, which bank modulo 32 in 16-lane groups -- 8 cycles per instruction,
+// and on the A-fragment address map (16-byte lane stride) 2-way conflicts on top: 16 LDS cycles per dosage tile instead of 4
+// (round 2's SQ_LDS_BANK_CONFLICT = 8 cycles per tile in every k_xtv_dma16 shape).  Volatile on an LDS-qualified pointer keeps
+// the loads apart and in the LDS address space.
+typedef __attribute__((address_space(3))) const volatile i32x2v *lds_b64_ptr;
+__device__ __forceinline__ i32x2v lds_read_b64(const char *p) { return *(lds_b64_ptr)(p); }
 
 // lane i's 16 B at sbase + voff land at LDS byte address lds_dst + 16 i.  M0 is compiler-reserved: saved and restored.
 template <bool NT>
@@ -725,7 +732,7 @@ k_xtv_dma(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *__
             const char *q = ldsb + st * STAGE + DOS + v * OPB;
             const i32x4v lo = *reinterpret_cast<const i32x4v *>(q + e * 1024 + lane * 16);
             if (FP6) {
-                const i32x2v hi = *reinterpret_cast<const i32x2v *>(q + 2048 + e * 512 + lane * 8);
+                const i32x2v hi = lds_read_b64(q + 2048 + e * 512 + lane * 8);
                 b = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], 0, 0};
             } else b = i32x8{lo[0], lo[1], lo[2], lo[3], 0, 0, 0, 0};
         };
@@ -944,7 +951,7 @@ k_xtv_dma16(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *
             const int v = item >> 1, e = item & 1;
             const char *q = ldsb + st * STAGE + DOS + v * OPB;
             const i32x4v lo = *reinterpret_cast<const i32x4v *>(q + e * 1024 + lane * 16);
-            const i32x2v hi = *reinterpret_cast<const i32x2v *>(q + 2048 + e * 512 + lane * 8);
+            const i32x2v hi = lds_read_b64(q + 2048 + e * 512 + lane * 8);
             b = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], 0, 0};
         };
         auto read_dos = [&](int st, i32x2v (&raw)[CT][2]) {
@@ -952,7 +959,7 @@ k_xtv_dma16(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *
             for (int c = 0; c < CT; ++c)
                 #pragma unroll
                 for (int a = 0; a < 2; ++a)
-                    raw[c][a] = *reinterpret_cast<const i32x2v *>(ldsb + st * STAGE + mydos + c * 1024 + a * 256 + aoff);
+                    raw[c][a] = lds_read_b64(ldsb + st * STAGE + mydos + c * 1024 + a * 256 + aoff);
         };
         auto expand = [&](const i32x2v (&raw)[CT][2], i32x4v (&a)[CT][2]) {
             const int M = 0x33333333 & amask;
