@@ -5,21 +5,27 @@ N = 1 (default): BASELINE configs[2].  A "step" is one IHT iteration (iht_one_st
 synthetic 2-bit SnpArray resident in HBM (n=500k, p=1M, k=200, Normal): step size (k-column X v), gradient step +
 top-k projection, X beta, mean / loglikelihood, backtracking if needed, and the full X'r score pass.  `roofline` is
 measured live: HIP events around every launch of the dominant kernel (the X'r pass) inside the timed region, on the
-stream it runs on.  Secondary objects in the same line: `cv_iht` (BASELINE configs[3] -- Bernoulli/Logit, path=1:20,
-5 folds, all 100 fits -- on this one GPU, same matrix), `cpu_baseline` (the CPU oracle's whole iht_one_step on a bounded
-column sample of the same matrix) and `cpu_baseline_cv` (the oracle's cv_iht on a reduced grid of configs[3]).
+stream it runs on, recorded by the library together with the NAME of the kernel it dispatched and the number of residuals
+the launch scored (mih_profile_passes).  Secondary objects in the same line: `cv_iht` (BASELINE configs[3] --
+Bernoulli/Logit, path=1:20, 5 folds, all 100 fits -- on this one GPU, same matrix), `cpu_baseline` (the CPU oracle's
+whole iht_one_step on a bounded column sample of the same matrix) and `cpu_baseline_cv` (the oracle's cv_iht on a reduced
+grid of configs[3]).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the path's real shard, BASELINE configs[3] --
-cross_validation.jl:98-121.  Every rank holds an identical replica of X; a step is ONE whole cv_iht (100 (fold,k) fits)
-strong-scaled over the ranks (combination i -> rank i mod N) with the single RCCL all-gather of the held-out losses
-inside the timed region.  `value` = IHT iterations (summed over the fits of all ranks) per second; fits/s, passes per
-rank and the gather time are reported beside it.  `--mode replicas` keeps round 1's independent replicas of configs[2].
+N > 1: the path's real shard, BASELINE configs[3] -- cross_validation.jl:98-121.  `python bench.py --gpus N` starts its N
+ranks itself (a child `python -m torch.distributed.run`, before anything touches a GPU) and relays rank 0's line; started
+under a launcher (WORLD_SIZE set) it is one of the ranks.  Every rank holds an identical replica of X; a step is ONE whole
+cv_iht (100 (fold,k) fits) strong-scaled over the ranks with the single RCCL all-gather of the held-out losses inside the
+timed region.  `value` keeps the metric's unit at every N: IHT iterations (= residual scores, counted by the library,
+summed over the fits of all ranks) per second; fits/s, passes per rank and the gather time are reported beside it.
+`--mode replicas` keeps round 1's independent replicas of configs[2].
 
 Prints ONE JSON line (rank 0).  The CPU baselines are a port (the repo's oracle), not MendelIHT.jl: no Julia here.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,12 +34,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 METRIC = "IHT iterations/sec + X'r GB/s vs HBM roofline, n=500k p=1M k=200"
 DTYPE = "f64 (residual as a 54-bit fixed-point number, exact accumulation on the matrix cores, f64 recombination)"
-XTV_KERNEL = "k_xtv_dma<1,2,4,8,false,0>"      # library default of the single-fit pass (csrc/xtv.hip dispatch_xtv)
+TRAFFIC_FILE = os.path.join("profiles", "r03_traffic.json")    # separate rocprofv3 --pmc passes of this command (tools/prof_bench.sh)
 
 
 def parse():
@@ -46,7 +51,9 @@ def parse():
     ap.add_argument("--n", type=int, default=int(os.environ.get("MIH_BENCH_N", 500_000)))
     ap.add_argument("--p", type=int, default=int(os.environ.get("MIH_BENCH_P", 1_000_000)))
     ap.add_argument("--k", type=int, default=200)
-    ap.add_argument("--variant", type=int, default=-1, help="X'r kernel variant (-1 = library default)")
+    ap.add_argument("--variant", type=int, default=-1, help="measurement build only (MENDELIHT_HIP_PROBES=1): a round-1 per-wave kernel shape")
+    ap.add_argument("--dry-run", action="store_true", help="print each rank's launcher environment and exit (no GPU call)")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-started ranks (0 = a free one)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of each baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cv", action="store_true", help="skip the secondary cv_iht measurement at N=1")
@@ -65,6 +72,32 @@ def host_cpus():
     except (OSError, ValueError):
         pass
     return ncpu, quota
+
+
+def cores_used(threads):
+    """`cores` of a CPU baseline = the CPUs that actually ran it: min(OpenMP threads, cgroup quota)."""
+    _, quota = host_cpus()
+    return threads if quota is None else int(min(threads, max(1, round(quota))))
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child `python -m torch.distributed.run` BEFORE this
+    process touches a GPU (it never does), relay the child's stdout (rank 0's JSON line) and return its exit code."""
+    port = a.master_port
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")                  # torchrun's default, stated so that it does not warn
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
 
 
 def cpu_baseline(m, n, p, k, seed, target_s):
@@ -127,7 +160,7 @@ def cpu_baseline(m, n, p, k, seed, target_s):
     t_step = (tb - ta) / 3.0                                # three more steps
     t_rest = max(t_step - t_xtv, 0.0)
     t_full = t_xtv * p / pc + t_rest
-    return {"value": 1.0 / t_full, "unit": "iterations/s", "cores": cores, "kind": "port",
+    return {"value": 1.0 / t_full, "unit": "iterations/s", "cores": cores_used(cores), "omp_threads": cores, "kind": "port",
             "sample": f"one whole oracle iht_one_step (iht_stepsize!, _iht_gradstep!, update_xb!, loglikelihood, score!) with k={kk} "
                       f"on the first {pc} of {p} SNP columns, n={n}: {t_step:.3f} s per step, of which the X'r pass {t_xtv:.3f} s "
                       f"(scaled by p/{pc}; the remaining {t_rest:.3f} s per step does not grow with p); {cores} OpenMP threads = the "
@@ -142,7 +175,7 @@ def cpu_baseline_cv(m, n, p, seed, cores, gpu_fits_per_s):
     passes grow with the column count: full-size time = passes * t_pass(sample) * p / pc + (measured time - passes *
     t_pass(sample)); fits/s at full size follows."""
     from oracle import oracle as O
-    from conftest import hash_folds
+    hash_folds = m.hash_folds
 
     O.set_threads(cores)
     pc = 2048
@@ -173,7 +206,7 @@ def cpu_baseline_cv(m, n, p, seed, cores, gpu_fits_per_s):
     full = passes * t_pass * p / pc + rest
     v = fits / full
     ncpu, quota = host_cpus()
-    return {"value": v, "unit": "fits/s", "cores": cores, "kind": "port",
+    return {"value": v, "unit": "fits/s", "cores": cores_used(cores), "omp_threads": cores, "kind": "port",
             "sample": f"oracle fits of cv_iht Bernoulli/Logit, 5 folds x path={path} ({fits} fits, {passes} X'r passes) on n={n} x the first "
                       f"{pc} of {p} columns: {dt:.2f} s, of which {passes * t_pass:.2f} s in X'r passes ({t_pass * 1e3:.1f} ms each; scaled by "
                       f"p/{pc}) and {rest:.2f} s in work that does not grow with p; {cores} OpenMP threads on {ncpu} logical CPUs"
@@ -183,7 +216,7 @@ def cpu_baseline_cv(m, n, p, seed, cores, gpu_fits_per_s):
 
 
 def cv_problem(m, x, n, p):
-    from conftest import hash_folds
+    hash_folds = m.hash_folds
     rng = np.random.default_rng(2025)
     supp = np.sort(rng.choice(p, 10, replace=False))
     eta = x.xv_sparse(supp, rng.standard_normal(10) * 0.5)
@@ -191,16 +224,44 @@ def cv_problem(m, x, n, p):
     return yb, hash_folds(n, 5)
 
 
+def pass_stats(m, x, passes):
+    """Per-launch records of the dominant kernel -> what the roofline object needs: launches, summed and union busy time,
+    ALGORITHMIC bytes of exactly those launches (algorithmic_bytes(residuals) each), residual scores, the kernel's name."""
+    if not passes:
+        return {"launches": 0, "ms_sum": 0.0, "ms_union": 0.0, "bytes": 0.0, "residuals": 0, "kernel": None, "kernels": {}}
+    by_m = {}
+    names = {}
+    for q in passes:
+        by_m[q["residuals"]] = by_m.get(q["residuals"], 0) + 1
+        names[q["kernel"]] = names.get(q["kernel"], 0) + 1
+    alg = {mm: x.algorithmic_bytes(mm) for mm in by_m}
+    return {"launches": len(passes), "ms_sum": sum(q["ms"] for q in passes), "ms_union": m.busy_union_ms(passes),
+            "bytes": float(sum(alg[q["residuals"]] for q in passes)), "residuals": int(sum(q["residuals"] for q in passes)),
+            "kernel": max(names, key=names.get), "kernels": names}
+
+
 def main():
     a = parse()
+    if a.gpus < 1:
+        sys.exit("--gpus must be >= 1")
+    launched = "WORLD_SIZE" in os.environ
+    if a.gpus > 1 and not launched:
+        # (VERDICT r2) the plain command is the one the driver runs: start the ranks here, before any GPU call
+        sys.exit(self_launch(a))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        # `--gpus 8` without a launcher used to measure one GPU silently.  (Checked before any GPU call.)
-        sys.exit(f"bench.py --gpus {a.gpus} needs {a.gpus} ranks but WORLD_SIZE={world}: launch it as\n"
+        # an inconsistent launcher environment must not measure something else silently (ADVICE r1)
+        sys.exit(f"bench.py --gpus {a.gpus} was started by a launcher with WORLD_SIZE={world}: start it as\n"
+                 f"  python bench.py --gpus {a.gpus} [--steps K --warmup W]      (it starts its own ranks), or\n"
                  f"  python -m torch.distributed.run --nnodes=1 --nproc-per-node {a.gpus} --master-addr 127.0.0.1 "
                  f"--master-port 29500 bench.py --gpus {a.gpus} [--steps K --warmup W]")
+    if a.dry_run:
+        print(json.dumps({"dry_run": True, "rank": rank, "local_rank": local, "world_size": world,
+                          "master_addr": os.environ.get("MASTER_ADDR"), "master_port": os.environ.get("MASTER_PORT"),
+                          "n_gpus": a.gpus}), flush=True)
+        return
     mode = a.mode if a.mode != "auto" else ("fit" if world == 1 else "cv")
     if a.steps is None:
         a.steps = 100 if mode in ("fit", "replicas") else 5
@@ -242,7 +303,7 @@ def main():
 
     n, p, k = a.n, a.p, a.k
     if a.variant >= 0:
-        m.lib().mih_set_xtv_variant(a.variant)
+        m.probe_set(variant=a.variant)                      # raises unless the measurement build is loaded
     seed = 2024 + (rank if mode == "replicas" else 0)       # cv: identical replicas of X on every rank
     t_gen = time.perf_counter()
     x = m.SnpLinAlg.synthetic(n, p, seed=seed, device=local)
@@ -264,8 +325,9 @@ def main():
             return tot, t1 - t0, time.perf_counter() - t1
         for _ in range(a.warmup):
             one_cv()
-        m.profile_read(reset=True)
-        m.profile_enable(True)
+        m.profile_read(x, reset=True)
+        m.profile_counters(x, reset=True)
+        m.profile_enable(x, True)
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -277,52 +339,64 @@ def main():
         torch.cuda.synchronize()
         barrier()
         elapsed = max_over_ranks(time.perf_counter() - t0)
-        m.profile_enable(False)
-        xtv_ms, launches = m.profile_read(reset=True)
-        fits_mine = len(D.shard_combinations(5, 20, rank, world))
-        stats = torch.tensor([launches / a.steps, xtv_ms / a.steps, 1e3 * t_gather / a.steps, fits_mine],
+        m.profile_enable(x, False)
+        st = pass_stats(m, x, m.profile_passes(x, reset=True))
+        cnt = m.profile_counters(x, reset=True)
+        stats = torch.tensor([st["launches"], st["ms_sum"], st["ms_union"], st["bytes"], st["residuals"], cnt["scores"], cnt["fits"],
+                              1e3 * t_gather, 1e3 * t_fit],
                              dtype=torch.float64, device="cuda" if backend == "nccl" and world > 1 else "cpu")
         if world > 1:
             allst = [torch.empty_like(stats) for _ in range(world)]
             dist.all_gather(allst, stats)
-            allst = [s.cpu().tolist() for s in allst]
+            allst = [q.cpu().tolist() for q in allst]
+            names = [None] * world
+            dist.all_gather_object(names, st["kernels"])
         else:
             allst = [stats.tolist()]
+            names = [st["kernels"]]
         if rank == 0:
-            from conftest import hash_folds  # noqa: F401
             mse = np.zeros(20)
             ninfold = np.bincount(folds - 1, minlength=5)
             for j in range(5):
                 mse += tot[j] * ninfold[j] / n               # meanloss (cross_validation.jl:304-320)
-            passes = sum(s[0] for s in allst)
-            # one fused pass scores up to 15 residuals; an IHT iteration of one fit = one score of one residual.  The
-            # library counts launches, not residuals, so iterations are reported from the deterministic single-rank count
+            K = a.steps
+            launches = sum(q[0] for q in allst)
+            ms_sum = sum(q[1] for q in allst)
+            nbytes = sum(q[3] for q in allst)
+            scores = sum(q[5] for q in allst)               # IHT iterations incl. the initial score of every fit, all ranks, all steps
+            fits = sum(q[6] for q in allst)
+            kern = {}
+            for d_ in names:
+                for kn, c in d_.items():
+                    kern[kn] = kern.get(kn, 0) + c
             out = {
                 "metric": METRIC,
-                "value": 100 * a.steps / elapsed, "unit": "fits/s",
-                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+                "value": scores / elapsed, "unit": "iterations/s",
+                "n_gpus": world, "steps": K, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / K,
                 "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
                 "config": {"workload": f"cv_iht Bernoulli/Logit path=1:20, 5 folds on synthetic SnpArray n={n} p={p} (BASELINE configs[3]): "
-                                       f"100 (fold,k) fits per step, combination i on rank i mod {world}, identical X replica per GPU, "
+                                       f"100 (fold,k) fits per step sharded over {world} ranks (mih_cv_assignment), identical X replica per GPU, "
                                        "ONE all-gather of the held-out losses per step inside the timed region "
-                                       "(cross_validation.jl:98-121)",
+                                       "(cross_validation.jl:98-121); value = IHT iterations of all fits per second "
+                                       "(an iteration = one residual score; up to 15 fits share one fused X'R pass)",
                            "n": n, "p": p, "path": "1:20", "folds": 5, "generator_s": round(t_gen, 2), "best_k": int(np.argmin(mse)) + 1,
-                           "cv_iht_s": elapsed / a.steps,
-                           "compare_with": "the N=1 line's cv_iht.fits_per_s (= 100 / cv_iht.cv_iht_s): same workload on one GPU"},
-                "per_rank": [{"rank": i, "fits": int(s[3]), "fused_passes_per_step": s[0], "xtv_kernel_ms_per_step": s[1],
-                              "gather_ms_per_step": s[2]} for i, s in enumerate(allst)],
-                "fused_passes_per_step_total": passes,
-                "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None,
-                             "note": "fused multi-RHS passes: see the N=1 line for the single-fit pass and DESIGN.md 3.1b"},
+                           "cv_iht_s": elapsed / K, "fits_per_s": fits / elapsed, "fits_per_step": fits / K,
+                           "iterations_per_step": scores / K,
+                           "compare_with": "the N=1 line's cv_iht object (same workload on one GPU: cv_iht.iterations_per_s, "
+                                           "cv_iht.fits_per_s); the N=1 `value` is the single-fit workload configs[2]"},
+                "per_rank": [{"rank": i, "fits_per_step": q[6] / K, "iterations_per_step": q[5] / K, "fused_passes_per_step": q[0] / K,
+                              "xtv_kernel_ms_per_step": q[1] / K, "xtv_busy_union_ms_per_step": q[2] / K,
+                              "cv_iht_ms_per_step": q[8] / K, "gather_ms_per_step": q[7] / K} for i, q in enumerate(allst)],
+                "fused_passes_per_step_total": launches / K,
+                "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None},
             }
             if launches:
-                mres = 100.0 * 12.5 / max(passes, 1)         # ~12.5 residual scores per fit (1247 per 100 fits, deterministic at N=1)
-                alg = x.algorithmic_bytes(12)
-                kern_ms = sum(s[1] for s in allst) / max(passes, 1)
-                out["roofline"].update(achieved=alg / (kern_ms * 1e-3) / 1e9, frac=alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                       kernel="k_xtv_dma16<NR,2,8,D> (mean over the fused passes of all ranks, 1 to 5 operands each; bytes as for 12 residuals)",
-                                       kernel_ms=kern_ms, launches=int(passes * a.steps), algorithmic_bytes_per_launch=alg,
-                                       residuals_per_pass_estimate=mres)
+                out["roofline"].update(
+                    achieved=nbytes / (ms_sum * 1e-3) / 1e9, frac=nbytes / (ms_sum * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                    kernel=max(kern, key=kern.get), kernels=kern, kernel_ms=ms_sum / launches, launches=int(launches),
+                    algorithmic_bytes_per_launch=nbytes / launches, residuals_per_launch=sum(q[4] for q in allst) / launches,
+                    note="measured: sum over the launches of all ranks of algorithmic_bytes(residuals of that launch) / sum of their "
+                         "HIP-event durations; the fused passes carry 1 to 15 residuals each (kernels = launches per dispatched kernel)")
             print(json.dumps(out), flush=True)
         del x
         if world > 1:
@@ -340,8 +414,8 @@ def main():
     sess = m.IHTSession(y, x, None, k=k, d=m.Normal(), l=m.IdentityLink())
     for _ in range(a.warmup):
         sess.step()
-    m.profile_read(reset=True)
-    m.profile_enable(True)
+    m.profile_read(x, reset=True)
+    m.profile_enable(x, True)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -349,8 +423,9 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
-    m.profile_enable(False)
-    xtv_ms, launches = m.profile_read(reset=True)
+    m.profile_enable(x, False)
+    st = pass_stats(m, x, m.profile_passes(x, reset=True))
+    xtv_ms, launches = st["ms_sum"], st["launches"]
 
     bhat, _ = sess.model()
     recovered = int(np.intersect1d(np.flatnonzero(bhat), supp).size)
@@ -360,15 +435,16 @@ def main():
         traffic_src = None
         if a.traffic_bytes is None:      # PMC traffic comes from a separate rocprofv3 pass of this command (profiles/)
             try:
-                t = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
-                if t["workload"] == {"n": n, "p": p} and t["kernel"] == XTV_KERNEL and a.variant < 0:
+                t = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
+                if t["workload"] == {"n": n, "p": p} and t["kernel"] == st["kernel"]:
                     a.traffic_bytes = t["hbm_bytes_per_launch"]
-                    traffic_src = "profiles/r02_traffic.json (separate rocprofv3 --pmc passes of this command, kernel " + t["kernel"] + ")"
+                    traffic_src = (f"{TRAFFIC_FILE} (separate rocprofv3 --pmc passes of this command, kernel {t['kernel']}; "
+                                   "not collected by this run)")
             except (OSError, KeyError, ValueError):
                 pass
         else:
             traffic_src = "--traffic-bytes"
-        alg_bytes = x.algorithmic_bytes(1)
+        alg_bytes = st["bytes"] / launches if launches else x.algorithmic_bytes(1)
         kern_ms = xtv_ms / max(launches, 1)
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if launches else 0.0
         out = {
@@ -389,25 +465,37 @@ def main():
                        "final_logl": logl, "host_and_small_kernels_ms_per_step": 1e3 * elapsed / a.steps - kern_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": a.traffic_bytes, "traffic_source": traffic_src,
-                         "kernel": XTV_KERNEL if a.variant < 0 else "k_xtv_mfma", "kernel_ms": kern_ms, "launches": launches,
+                         "kernel": st["kernel"], "kernel_ms": kern_ms, "launches": launches,
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
         gpu_fits_per_s = None
         if world == 1 and not a.no_cv:
             # configs[3] on this one GPU (the N>1 mode's workload at N=1), same matrix
             yb, folds = cv_problem(m, x, n, p)
-            m.profile_read(reset=True)
-            m.profile_enable(True)
+            m.profile_read(x, reset=True)
+            m.profile_counters(x, reset=True)
+            m.profile_enable(x, True)
             t0 = time.perf_counter()
             mse, raw = m.cv_iht(yb, x, None, path=range(1, 21), q=5, folds=folds, verbose=False, return_raw=True,
                                 d=m.Bernoulli(), l=m.LogitLink())
             dt = time.perf_counter() - t0
-            m.profile_enable(False)
-            cms, cl = m.profile_read(reset=True)
+            m.profile_enable(x, False)
+            cst = pass_stats(m, x, m.profile_passes(x, reset=True))
+            cnt = m.profile_counters(x, reset=True)
             gpu_fits_per_s = 100.0 / dt
             out["cv_iht"] = {"workload": "cv_iht Bernoulli/Logit path=1:20, 5 folds (BASELINE configs[3]), all 100 fits on this GPU",
-                             "seconds": dt, "cv_iht_s": dt, "fits": int(np.count_nonzero(raw)), "fits_per_s": gpu_fits_per_s, "best_k": int(np.argmin(mse)) + 1,
-                             "fused_passes": int(cl), "xtv_kernel_ms_total": cms}
+                             "seconds": dt, "cv_iht_s": dt, "fits": int(np.count_nonzero(raw)), "fits_per_s": gpu_fits_per_s,
+                             "iterations": cnt["scores"], "iterations_per_s": cnt["scores"] / dt, "best_k": int(np.argmin(mse)) + 1,
+                             "fused_passes": cst["launches"], "residuals_scored_by_passes": cst["residuals"],
+                             "xtv_busy_union_ms": cst["ms_union"], "xtv_kernel_ms_sum_over_lanes": cst["ms_sum"],
+                             "lockstep": cnt, "kernels": cst["kernels"],
+                             "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+                                          "achieved": cst["bytes"] / (cst["ms_sum"] * 1e-3) / 1e9 if cst["launches"] else None,
+                                          "frac": cst["bytes"] / (cst["ms_sum"] * 1e-3) / 1e9 / HBM_PEAK_GBPS if cst["launches"] else None,
+                                          "kernel": cst["kernel"], "kernel_ms": cst["ms_sum"] / max(cst["launches"], 1),
+                                          "algorithmic_bytes_per_launch": cst["bytes"] / max(cst["launches"], 1),
+                                          "note": "sum of algorithmic_bytes(residuals of the launch) / sum of HIP-event durations; the two "
+                                                  "lock-step lanes' passes overlap, so the sum exceeds the union (and may exceed the wall time)"}}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"], cores = cpu_baseline(m, n, p, k, seed, a.cpu_seconds)
             if gpu_fits_per_s is not None:

@@ -103,6 +103,21 @@ int mih_xtv(const mih_mat *h, const double *r, double *out);
 /* SnpArrays.mul!(p_by_r, Transpose(sla), n_by_r) -- call site src/multivariate.jl:85;
  * R is n x m column-major, OUT is p x m column-major. */
 int mih_xtv_batched(const mih_mat *h, const double *R, int m, double *OUT);
+/* The same with an explicit fixed-point format of the residuals.  A residual is scaled by a power of two, rounded to an
+ * integer R and written as digits that FP6 / FP4 represent exactly; each digit plane is one column of the MFMA B operand,
+ * the dot products with the dosages are exact, and the only rounding is that of the residual.  digits = base * 100 + digits:
+ *   0 = library default: 4910 for every multi-residual context (this call, cv_iht, model paths, multivariate fits,
+ *        init_beta) whatever the number of residuals, 428 for the workspace of a single univariate fit.
+ *   4910 10 base-49 digits d/8 in FP6 (e2m3), |R| < 2^54: rounding 2^-54 max|r|, below that of an n-term f64 sum.  THREE
+ *        residuals share one 32-column operand.  Row slices of 2^18 rows; above 2^22 rows the default steps down to 1316.
+ *   1316 16 base-13 digits d/2 in FP4 (e2m1), |R| < 2^57, two residuals per operand (2^20-row slices; above 2^24
+ *        rows the default steps down to 428).
+ *   428  28 base-4 digits {-2..1}/2 in FP4, |R| < 2^54, one residual per operand (the first format; cross-check).
+ *   4908 8 base-49 FP6 digits, |R| < 2^43, FOUR residuals per operand: opt-in fast mode for fused multi-RHS
+ *        passes (cv_iht, multivariate, init_beta); relative error of X'r about 2^-43 max|r| / |r|_rms ~ 1e-12.
+ *   1308 8 base-13 FP4 digits, |R| < 2^27, four per operand (~15 % faster than 4908, error ~1e-7).
+ * A result never depends on which other residuals share a pass or on the kernel shape, only on the format. */
+int mih_xtv_batched_fmt(const mih_mat *h, const double *R, int m, int digits, double *OUT);
 /* out = sum_t x[:, idx[t]] * val[t]  -- the column loops of update_xb!
  * (src/utilities.jl:98-106) and iht_stepsize! (:731-739); idx 0-based. */
 int mih_xv_sparse(const mih_mat *h, const int64_t *idx, const double *val, int64_t nnz, double *out);
@@ -173,6 +188,9 @@ typedef struct mih_fit_params {
     int32_t  debias;          /* fit.jl:73,188 debias: after a step (iter >= 5) that kept the support, refit the
                                  support columns by GLM (debias!, src/utilities.jl:1014-1020; the reference needs
                                  memory_efficient=false for it, the device builds the n x k panel on the fly) */
+    int32_t  xtv_digits;      /* fixed-point format of the residual in this call's X'r passes (no reference counterpart):
+                                 0 = library default; 4910, 4908, 1316, 1308, 428 -- see mih_xtv_batched_fmt.  A property
+                                 of the CALL: concurrent fits on one matrix may use different formats. */
 } mih_fit_params;
 
 /* IHTResult (src/data_structures.jl:245-256) + the per-iteration log */
@@ -200,14 +218,19 @@ int mih_fit_iht(const mih_mat *h, const mih_fit_params *prm, const double *y,
 
 /* cv_iht(y, x, z; path, q, folds, ...) src/cross_validation.jl:60-131.
  * folds: n labels in 1..nfolds.  The (fold,k) combinations are enumerated
- * fold-major (cross_validation.jl:217-223); this call evaluates those with
- * index % world == rank and writes their held-out deviance sums into
+ * fold-major (cross_validation.jl:217-223); this call evaluates those that
+ * mih_cv_assignment gives to `rank` and writes their held-out deviance sums into
  * mses_raw[nfolds*npath] (others left 0), so ranks combine with ONE sum-reduce /
  * gather.  mih_cv_meanloss then applies meanloss (:304-320). */
 int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y,
                const double *z, int64_t q, const int32_t *folds, int32_t nfolds,
                const int64_t *path, int64_t npath, int32_t rank, int32_t world,
                double *mses_raw);
+/* The sharding rule of mih_cv_iht / mih_cv_mv (the reference's pmap / @threads hands combinations to workers as they come,
+ * cross_validation.jl:98-121): rank_of[fold * npath + ik] = the rank of `world` that evaluates combination (fold, path[ik]).
+ * Combinations are dealt out round-robin in the order (k descending, fold ascending), so every rank gets a stratified sample
+ * of the model sizes (a fit's iteration count depends mostly on k).  No device needed. */
+int mih_cv_assignment(const int64_t *path, int64_t npath, int32_t nfolds, int32_t world, int32_t *rank_of);
 int mih_cv_meanloss(const double *mses_raw, const int32_t *folds, int64_t n, int32_t nfolds,
                     int64_t npath, double *mse_out);
 /* iht_run_many_models(y, x, z; path, ...) src/cross_validation.jl:232-273: fit_iht on the FULL data for every
@@ -262,41 +285,40 @@ int mih_session_model(mih_session *s, double *beta, double *c);
 int mih_session_destroy(mih_session *s);
 
 /* ---- measurement hooks (bench.py; no reference counterpart) ----------------- */
-/* When enabled, every launch of the dominant X'r kernel is bracketed by HIP events on
- * the stream it is launched on; mih_profile_read synchronises and returns the totals
- * since the last reset. */
-int mih_profile_enable(int on);
-int mih_profile_read(double *xtv_kernel_ms, int64_t *xtv_launches, int reset);
-/* Runs `iters` X'r passes back to back on the handle's stream with r resident
- * in HBM, bracketed by HIP events; *ms_per_pass = average kernel-chain time. */
-int mih_bench_xtv(const mih_mat *h, int variant, int iters, int warmup, uint64_t seed,
+/* The hook hangs on the matrix handle (no process-wide state).  While enabled, every launch of the dominant X'r kernel on
+ * this matrix is bracketed by HIP events on the stream it is launched on and recorded with the name of the kernel that was
+ * dispatched and the number of residuals it scored; the lock-step drivers (cv_iht, model paths) count what they did. */
+typedef struct mih_pass_record {
+    double  start_ms;         /* kernel start, relative to the mih_profile_enable(h, 1) call */
+    double  ms;               /* kernel duration (HIP events on its own stream) */
+    int32_t residuals;        /* residual vectors scored by this launch */
+    int32_t operands;         /* B operands of the launch (3 residuals each in the default format) */
+    int32_t stream_tag;       /* 0 = the handle's / a single fit's stream; 1, 2 = lock-step lanes */
+    int32_t reserved;
+    char    kernel[48];       /* e.g. "k_xtv_dma<1,2,4,8,fp4>" or "k_xtv_dma16<5,2,8,4,half>" */
+} mih_pass_record;
+enum { MIH_CNT_LANES = 0,          /* lock-step lanes started (summed over calls) */
+       MIH_CNT_MAX_IN_FLIGHT = 1,  /* most fits in flight at once over all lanes */
+       MIH_CNT_HANDOVERS = 2,      /* tail hand-overs (lane 1's fits adopted by lane 0) */
+       MIH_CNT_SHARED_INIT = 3,    /* fits that started from another fit's initial score */
+       MIH_CNT_ROUNDS = 4,         /* lock-step rounds */
+       MIH_CNT_FITS = 5,           /* fits completed by the lock-step drivers */
+       MIH_CNT_SCORES = 6,         /* residual scores (= IHT iterations incl. the initial score) those fits asked for */
+       MIH_CNT_MAX_LANE_SLOTS = 7, /* most fits in flight on ONE lane */
+       MIH_PROFILE_NCOUNTERS = 8 };
+int mih_profile_enable(const mih_mat *h, int on);
+/* synchronises the recorded launches; totals since the last reset */
+int mih_profile_read(const mih_mat *h, double *xtv_kernel_ms, int64_t *xtv_launches, int reset);
+/* the launches themselves, oldest first: up to cap records into out (may be NULL to ask for the count), *n = available */
+int mih_profile_passes(const mih_mat *h, mih_pass_record *out, int64_t cap, int64_t *n, int reset);
+int mih_profile_counters(const mih_mat *h, int64_t *out /* [MIH_PROFILE_NCOUNTERS] */, int reset);
+/* Runs `iters` X'r passes of m residuals back to back on the handle's stream with R resident in HBM, bracketed by HIP
+ * events; *ms_per_pass = average time of the whole chain (statistics, digit planes, pass, finalize).  m = 1 uses the
+ * workspace of a single univariate fit, m > 1 the fused multi-residual one; digits as in mih_xtv_batched_fmt. */
+int mih_bench_xtv(const mih_mat *h, int digits, int m, int iters, int warmup, uint64_t seed,
                   float *ms_per_pass, double *checksum);
-/* Same for m right-hand sides; at most max_fused (1, 2 or 4) B operands (one residual each in the exact mode,
- * two in the 16-digit mode) share one pass over X. */
-int mih_bench_xtv_batched(const mih_mat *h, int variant, int m, int max_fused, int iters, int warmup,
-                          uint64_t seed, float *ms_per_pass, double *checksum);
 /* Algorithmic bytes of one X'r pass: p*ceil(n/4) + 8*m*(n+p) + 16*p. */
 int mih_xtv_algorithmic_bytes(const mih_mat *h, int m, double *bytes);
-/* Select the single-operand X'r kernel used by every subsequent call (tuning knob): -1 = library default
- * (digit planes shared through LDS), 0..15 = the per-wave-load shapes {waves, column groups, row slices}. */
-int mih_set_xtv_variant(int variant);
-/* Fixed-point format of the residual in the X'r passes of workspaces created AFTER the call.  The residual is
- * scaled by a power of two, rounded to an integer R and written as digits that FP6 / FP4 represent exactly; each
- * digit plane is one column of the MFMA B operand, the dot products with the dosages are exact, and the only
- * rounding is that of the residual.  id = base * 100 + digits:
- *   0 = 4910 (default) 10 base-49 digits d/8 in FP6 (e2m3), |R| < 2^54: rounding 2^-54 max|r|, below that of an
- *        n-term f64 sum.  THREE residuals share one 32-column operand.  Row slices of 2^18 rows; above 2^22
- *        rows (and for the per-wave kernel shapes, mih_set_xtv_variant >= 0) the default steps down to 1316.
- *   1316 16 base-13 digits d/2 in FP4 (e2m1), |R| < 2^57, two residuals per operand (2^20-row slices; above 2^24
- *        rows the default steps down to 428).
- *   428  28 base-4 digits {-2..1}/2 in FP4, |R| < 2^54, one residual per operand (the first format; cross-check).
- *   4908 8 base-49 FP6 digits, |R| < 2^43, FOUR residuals per operand: opt-in fast mode for fused multi-RHS
- *        passes (cv_iht, multivariate, init_beta); relative error of X'r about 2^-43 max|r| / |r|_rms ~ 1e-12.
- *   1308 8 base-13 FP4 digits, |R| < 2^27, four per operand (~15 % faster than 4908, error ~1e-7). */
-int mih_set_xtv_digits(int digits);
-/* Select the launch shape of the LDS-shared X'r kernels (0 = built-in defaults; ids in csrc/xtv.hip dispatch_xtv;
- * some ids are timing probes whose output is NOT X'r).  Tuning / measurement knob. */
-int mih_set_xtv_multi_variant(int variant);   /* 0 = defaults (LDS-DMA ring kernels); 1..15 = round-1 register-staged shapes (6 / 9: its defaults); 20.. = ring shapes; 30.., 49 = timing probes */
 
 #ifdef __cplusplus
 }

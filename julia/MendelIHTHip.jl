@@ -15,12 +15,14 @@
 #   mse = cv_iht(y, x, z; path=1:20, q=5, folds=folds)
 #   res = fit_iht(Y, Transpose(x), Z; k=12)              # r x n traits: mIHTResult
 #   ll  = iht_run_many_models(y, x, z; path=1:20)
+#   res = MendelIHTHip.iht("normal", 7, Normal; covariates="covariates.txt")      # file-level wrappers (src/wrapper.jl)
+#   mse = MendelIHTHip.cross_validate("normal", Normal; path=1:20, q=5)
 module MendelIHTHip
 
-using MendelIHT, SnpArrays, Distributions, GLM, LinearAlgebra
+using MendelIHT, SnpArrays, Distributions, GLM, LinearAlgebra, DelimitedFiles
 import MendelIHT: fit_iht, cv_iht, iht_run_many_models, IHTResult, mIHTResult, maf_weights, naive_impute
 
-export HipSnpLinAlg
+export HipSnpLinAlg, hip_iht, hip_cross_validate
 
 const LIB = get(ENV, "MENDELIHT_HIP_LIB", "libmendeliht_hip.so")
 
@@ -109,6 +111,7 @@ struct MihFitParams
     progress::Ptr{Cvoid}; progress_user::Ptr{Cvoid}; init_beta::Int32
     comm::Ptr{Cvoid}      # Ptr{MihComm} for a column-sharded fit, C_NULL otherwise
     debias::Int32
+    xtv_digits::Int32     # fixed-point format of the residual in this call's X'r passes (0 = library default)
 end
 # mih_comm: exchange callbacks of a column-sharded fit (one Julia process per GPU, e.g. under mpiexec)
 struct MihComm
@@ -171,7 +174,7 @@ struct ParamKeep
     zk::Vector{UInt8}; w::Vector{Float64}; g::Vector{Int64}; ks::Vector{Int64}
 end
 function make_params(x::HipSnpLinAlg, k, J, d, l, group, weight, zkeep, est_r, use_maf, debias, tol,
-                     max_iter, min_iter, max_step, init_beta, comm)
+                     max_iter, min_iter, max_step, init_beta, comm, xtv_digits=0)
     J >= 0 || throw(ArgumentError("Value of J (max number of groups) must be nonnegative!"))
     max_iter >= 0 || throw(ArgumentError("Value of max_iter must be nonnegative!"))
     max_step >= 0 || throw(ArgumentError("Value of max_step must be nonnegative!"))
@@ -193,7 +196,7 @@ function make_params(x::HipSnpLinAlg, k, J, d, l, group, weight, zkeep, est_r, u
         isempty(keep.w) ? Ptr{Float64}(C_NULL) : pointer(keep.w),
         isempty(keep.g) ? Ptr{Int64}(C_NULL) : pointer(keep.g),
         isempty(keep.ks) ? Ptr{Int64}(C_NULL) : pointer(keep.ks), length(keep.ks),
-        C_NULL, C_NULL, Int32(init_beta), comm, Int32(debias))
+        C_NULL, C_NULL, Int32(init_beta), comm, Int32(debias), Int32(xtv_digits))
     return prm, keep
 end
 
@@ -206,14 +209,15 @@ function fit_iht(y::AbstractVector{Float64}, x::HipSnpLinAlg{Float64}, z::Abstra
         zkeep::BitVector=trues(size(z, 2)), est_r::Symbol=:None, use_maf::Bool=false, debias::Bool=false,
         verbose::Bool=true, tol::Float64=1e-4, max_iter::Int=200, min_iter::Int=5, max_step::Int=3,
         io::IO=stdout, init_beta::Bool=false, memory_efficient::Bool=true,
-        comm::Ptr{Cvoid}=C_NULL)                 # comm: Ptr to a MihComm for a column-sharded fit (INTEGRATION.md)
+        comm::Ptr{Cvoid}=C_NULL,                 # comm: Ptr to a MihComm for a column-sharded fit (INTEGRATION.md)
+        xtv_digits::Int=0)                       # residual format of this call's X'r passes (include/mendeliht_hip.h)
     memory_efficient || throw(ArgumentError("the GPU path is always memory_efficient=true"))
     yy = Vector{Float64}(y); zz = dense_z(z)
     q = size(zz, 2)
     (length(yy) == x.n == size(zz, 1)) || throw(DimensionMismatch("row dimension of y, x, and z ($(length(yy)), $(x.n), $(size(zz, 1))) are not equal"))
     length(zkeep) == q || throw(DimensionMismatch("zkeep must have one entry per covariate"))
     prm, keep = make_params(x, k, J, d, l, group, weight, zkeep, est_r, use_maf, debias, tol, max_iter, min_iter,
-                            max_step, init_beta, comm)
+                            max_step, init_beta, comm, xtv_digits)
     beta = zeros(x.p); c = zeros(q)
     lt = zeros(max_iter + 1); tt = zeros(max_iter + 1); bt = zeros(Int32, max_iter + 1)
     res = MihFitResult(0, 0, 0, 0, 0, 0, 0, pointer(beta), pointer(c), pointer(lt), pointer(tt), pointer(bt), C_NULL)
@@ -239,7 +243,7 @@ function fit_iht(Y::AbstractMatrix{Float64}, xt::Transpose{Float64, HipSnpLinAlg
         group::AbstractVector{Int}=Int[], weight::AbstractVector{Float64}=Float64[],
         zkeep::BitVector=trues(size(Z, 1)), est_r::Symbol=:None, use_maf::Bool=false, debias::Bool=false,
         verbose::Bool=true, tol::Float64=1e-4, max_iter::Int=200, min_iter::Int=5, max_step::Int=3,
-        io::IO=stdout, init_beta::Bool=false, memory_efficient::Bool=true)
+        io::IO=stdout, init_beta::Bool=false, memory_efficient::Bool=true, xtv_digits::Int=0)
     x = xt.parent
     d isa MvNormal || throw(ArgumentError("multivariate responses need d = MvNormal"))
     (isempty(group) && isempty(weight) && !use_maf && est_r === :None && J == 1) ||
@@ -250,7 +254,7 @@ function fit_iht(Y::AbstractMatrix{Float64}, xt::Transpose{Float64, HipSnpLinAlg
     r, n = size(YY); q = size(ZZ, 1)
     n == x.n || throw(DimensionMismatch("Y has $n samples, x has $(x.n)"))
     prm, keep = make_params(x, k, 1, Normal(), IdentityLink(), Int[], Float64[], zkeep, :None, false, false, tol,
-                            max_iter, min_iter, max_step, init_beta, C_NULL)
+                            max_iter, min_iter, max_step, init_beta, C_NULL, xtv_digits)
     B = zeros(r, x.p); C = zeros(r, q); S = zeros(r, r); pve = zeros(r)
     lt = zeros(max_iter + 1); tt = zeros(max_iter + 1); bt = zeros(Int32, max_iter + 1)
     res = MihMvResult(0, 0, 0, 0, 0, pointer(B), pointer(C), pointer(S), pointer(pve), pointer(lt), pointer(tt), pointer(bt))
@@ -274,7 +278,8 @@ function cv_iht(y::AbstractVector{Float64}, x::HipSnpLinAlg{Float64}, z::Abstrac
         q::Int=5, est_r::Symbol=:None, group::AbstractVector{Int}=Int[], weight::AbstractVector{Float64}=Float64[],
         zkeep::BitVector=trues(size(z, 2)), folds::AbstractVector{Int}=rand(1:q, size(x, 1)), debias::Bool=false,
         verbose::Bool=true, max_iter::Int=100, min_iter::Int=5, init_beta::Bool=false, memory_efficient::Bool=true,
-        rank::Int=0, world::Int=1, reduce=identity)       # reduce: sums the raw loss matrix over the ranks (e.g. MPI.Allreduce)
+        rank::Int=0, world::Int=1, reduce=identity,       # reduce: sums the raw loss matrix over the ranks (e.g. MPI.Allreduce)
+        xtv_digits::Int=0)
     memory_efficient || throw(ArgumentError("the GPU path is always memory_efficient=true"))
     maximum(path) > x.p && error("Sparsity level in `path` cannot be larger than total number of variables")
     yy = Vector{Float64}(y); zz = dense_z(z)
@@ -282,7 +287,7 @@ function cv_iht(y::AbstractVector{Float64}, x::HipSnpLinAlg{Float64}, z::Abstrac
     f32 = Vector{Int32}(folds); pth = Vector{Int64}(path)
     raw = zeros(q * length(pth)); mse = zeros(length(pth))
     prm, keep = make_params(x, 1, 1, d, l, group, weight, zkeep, est_r, false, debias, 1e-4, max_iter, min_iter, 3,
-                            init_beta, C_NULL)
+                            init_beta, C_NULL, xtv_digits)
     GC.@preserve keep yy zz f32 pth raw begin
         check(ccall((:mih_cv_iht, LIB), Cint,
             (Ptr{Cvoid}, Ref{MihFitParams}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Int32}, Int32, Ptr{Int64},
@@ -292,7 +297,7 @@ function cv_iht(y::AbstractVector{Float64}, x::HipSnpLinAlg{Float64}, z::Abstrac
     raw = reduce(raw)                            # world > 1: each rank filled only its own combinations
     check(ccall((:mih_cv_meanloss, LIB), Cint, (Ptr{Float64}, Ptr{Int32}, Int64, Int32, Int64, Ptr{Float64}),
         raw, f32, length(f32), q, length(pth), mse))
-    verbose && println("Best k = $(pth[argmin(mse)])")
+    verbose && MendelIHT.print_cv_results(mse, path, pth[argmin(mse)])      # cross_validation.jl:128-129
     return mse
 end
 
@@ -367,5 +372,85 @@ function iht_run_many_models(y::AbstractVector{Float64}, x::HipSnpLinAlg{Float64
     verbose && MendelIHT.print_a_bunch_of_path_results(logl, path)
     return logl
 end
+
+# ---- file-level wrappers: iht / cross_validate (src/wrapper.jl:52-120, 301-349) ---------------------------------------
+# The reference's own parsers and writers, unchanged (parse_genotypes, parse_phenotypes, parse_covariates, is_multivariate,
+# show(::IHTResult), print_cv_results); the ONE difference is the matrix type built from the PLINK trio: HipSnpLinAlg where
+# wrapper.jl:66-69 / :316-319 build SnpLinAlg, so fit_iht / cv_iht dispatch to the methods above and the whole IHT loop runs
+# on the GPU.  VCF / BGEN inputs are numeric matrices in the reference (wrapper.jl:70-71): they are handed to the reference's
+# own iht / cross_validate.  MendelIHT.iht has the same positional signature, so these are MendelIHTHip.iht /
+# MendelIHTHip.cross_validate (or the exported aliases hip_iht / hip_cross_validate), not new methods of MendelIHT.iht.
+is_plink(filename::AbstractString) = isfile(filename * ".bed") && isfile(filename * ".bim") && isfile(filename * ".fam")
+
+function iht(filename::AbstractString, k::Int, d::UnionAll;
+        phenotypes::Union{AbstractString, Int, AbstractVector{Int}}=6, covariates::AbstractString="",
+        summaryfile::AbstractString="iht.summary.txt", betafile::AbstractString="iht.beta.txt",
+        covariancefile::AbstractString="iht.cov.txt", exclude_std_idx::AbstractVector{<:Integer}=Int[],
+        dosage::Bool=false, device::Integer=0, kwargs...)
+    is_plink(filename) || return MendelIHT.iht(filename, k, d; phenotypes=phenotypes, covariates=covariates,
+        summaryfile=summaryfile, betafile=betafile, covariancefile=covariancefile, exclude_std_idx=exclude_std_idx,
+        dosage=dosage, kwargs...)
+    X, X_sampleID, X_chr, X_pos, X_ids, X_ref, X_alt = MendelIHT.parse_genotypes(filename, dosage)
+    xla = HipSnpLinAlg{Float64}(X.snparray; center=true, scale=true, impute=true, device=device)     # wrapper.jl:68-69
+    y = MendelIHT.parse_phenotypes(X, phenotypes, d())
+    z = covariates == "" ? ones(size(xla, 1)) :
+        MendelIHT.parse_covariates(covariates, exclude_std_idx, standardize=true)
+    MendelIHT.is_multivariate(y) && (z = convert(Matrix{Float64}, Transpose(z)))
+    io = open(summaryfile, "w")
+    if MendelIHT.is_multivariate(y)
+        result = fit_iht(y, Transpose(xla), z; k=k, io=io, kwargs...)
+    else
+        l = d == NegativeBinomial ? LogLink() : canonicallink(d())                                     # wrapper.jl:87
+        result = fit_iht(y, xla, z; k=k, d=d(), l=l, io=io, kwargs...)
+    end
+    show(io, result)
+    close(io)
+    if MendelIHT.is_multivariate(y)                                                                     # wrapper.jl:100-111
+        open(betafile, "w") do fio
+            print(fio, "chr\tpos\tSNPid\tref\talt")
+            for i in 1:size(y, 1)
+                print(fio, '\t', "beta_$i")
+            end
+            print(fio, '\n')
+            writedlm(fio, [X_chr X_pos X_ids X_ref X_alt result.beta'])
+        end
+        writedlm(covariancefile, result.Σ)
+    else
+        open(betafile, "w") do fio                                                                      # wrapper.jl:112-116
+            println(fio, "chr\tpos\tSNPid\tref\talt\tEstimated_beta")
+            writedlm(fio, [X_chr X_pos X_ids X_ref X_alt result.beta])
+        end
+    end
+    return result
+end
+
+function cross_validate(filename::AbstractString, d::UnionAll;
+        path::AbstractVector{<:Integer}=1:20, phenotypes::Union{AbstractString, Int, AbstractVector{Int}}=6,
+        covariates::AbstractString="", cv_summaryfile::AbstractString="cviht.summary.txt", q::Int=5,
+        exclude_std_idx::AbstractVector{<:Integer}=Int[], dosage::Bool=false, device::Integer=0, kwargs...)
+    is_plink(filename) || return MendelIHT.cross_validate(filename, d; path=path, phenotypes=phenotypes,
+        covariates=covariates, cv_summaryfile=cv_summaryfile, q=q, exclude_std_idx=exclude_std_idx, dosage=dosage, kwargs...)
+    start_time = time()
+    X, = MendelIHT.parse_genotypes(filename, dosage)
+    x = HipSnpLinAlg{Float64}(X.snparray; center=true, scale=true, impute=true, device=device)       # wrapper.jl:316-319
+    y = MendelIHT.parse_phenotypes(X, phenotypes, d())
+    z = covariates == "" ? ones(size(x, 1)) :
+        MendelIHT.parse_covariates(covariates, exclude_std_idx, standardize=true)
+    MendelIHT.is_multivariate(y) && (z = convert(Matrix{Float64}, Transpose(z)))
+    if MendelIHT.is_multivariate(y)
+        mse = cv_iht(y, Transpose(x), z; path=path, q=q, kwargs...)
+    else
+        l = d == NegativeBinomial ? LogLink() : canonicallink(d())
+        mse = cv_iht(y, x, z; path=path, q=q, d=d(), l=l, kwargs...)
+    end
+    open(cv_summaryfile, "w") do io                                                                     # wrapper.jl:339-345
+        MendelIHT.print_cv_results(io, mse, path, path[argmin(mse)])
+        println(io, "Total cross validation time = $(time() - start_time) seconds")
+    end
+    return mse
+end
+
+const hip_iht = iht
+const hip_cross_validate = cross_validate
 
 end # module

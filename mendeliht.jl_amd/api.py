@@ -16,6 +16,10 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBNAME = "libmendeliht_hip.so"
+# the measurement build of the same sources (-DMIH_PROBES: launch-shape sweeps, round-1 kernel families, timing probes, the
+# MENDELIHT_* A/B switches).  tools/ and the "this switch changes nothing" tests select it with MENDELIHT_HIP_PROBES=1 in the
+# environment (read once, at the first lib() call); the product never does.
+_PROBES_LIBNAME = "libmendeliht_hip_probes.so"
 
 
 class MendelIHTError(RuntimeError):
@@ -38,13 +42,22 @@ def library_path():
     return os.path.join(_HERE, _LIBNAME)
 
 
+def probes_library_path():
+    return os.path.join(_HERE, _PROBES_LIBNAME)
+
+
+def using_probes():
+    e = os.environ.get("MENDELIHT_HIP_PROBES", "")
+    return e not in ("", "0")
+
+
 class _FitParams(C.Structure):
     _fields_ = [("k", C.c_int64), ("J", C.c_int64), ("dist", C.c_int32), ("link", C.c_int32),
                 ("nb_r", C.c_double), ("tol", C.c_double),
                 ("max_iter", C.c_int32), ("min_iter", C.c_int32), ("max_step", C.c_int32), ("est_r", C.c_int32),
                 ("zkeep", C.c_void_p), ("weight", C.c_void_p), ("group", C.c_void_p), ("ks", C.c_void_p),
                 ("nks", C.c_int64), ("progress", C.c_void_p), ("progress_user", C.c_void_p),
-                ("init_beta", C.c_int32), ("comm", C.c_void_p), ("debias", C.c_int32)]
+                ("init_beta", C.c_int32), ("comm", C.c_void_p), ("debias", C.c_int32), ("xtv_digits", C.c_int32)]
 
 
 class _Comm(C.Structure):
@@ -71,6 +84,14 @@ class _MvResult(C.Structure):
                 ("logl_trace", C.c_void_p), ("tol_trace", C.c_void_p), ("bt_trace", C.c_void_p)]
 
 
+class _PassRecord(C.Structure):
+    """mih_pass_record: one launch of the dominant X'r kernel as the measurement hook of a matrix recorded it."""
+    _fields_ = [("start_ms", C.c_double), ("ms", C.c_double), ("residuals", C.c_int32), ("operands", C.c_int32),
+                ("stream_tag", C.c_int32), ("reserved", C.c_int32), ("kernel", C.c_char * 48)]
+
+
+PROFILE_COUNTERS = ("lanes", "max_in_flight", "handovers", "shared_init", "rounds", "fits", "scores", "max_lane_slots")
+
 _PROGRESS = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double)
 
 _lib = None
@@ -81,7 +102,7 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    path = library_path()
+    path = probes_library_path() if using_probes() else library_path()
     if not os.path.exists(path):
         raise MendelIHTError(
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -105,22 +126,20 @@ def lib():
         "mih_snp_naive_impute": [vp, vp],
         "mih_xtv": [vp, vp, vp],
         "mih_xtv_batched": [vp, vp, C.c_int, vp],
+        "mih_xtv_batched_fmt": [vp, vp, C.c_int, C.c_int, vp],
         "mih_xv_sparse": [vp, vp, vp, i64, vp],
         "mih_project_topk": [vp, i64, i64, C.POINTER(i64)],
         "mih_project_group_sparse": [vp, vp, i64, i64, vp, C.c_int],
         "mih_fit_iht": [vp, C.POINTER(_FitParams), vp, vp, i64, vp, C.POINTER(_FitResult)],
         "mih_cv_iht": [vp, C.POINTER(_FitParams), vp, vp, i64, vp, i32, vp, i64, i32, i32, vp],
         "mih_cv_meanloss": [vp, vp, i64, i32, i64, vp],
+        "mih_cv_assignment": [vp, i64, i32, i32, vp],
         "mih_fit_iht_path": [vp, C.POINTER(_FitParams), vp, vp, i64, vp, i64, i32, i32, vp, vp, vp, vp],
         "mih_cv_iht_multi": [vp, i32, C.POINTER(_FitParams), vp, vp, i64, vp, i32, vp, i64, vp],
         "mih_fit_mv": [vp, C.POINTER(_FitParams), vp, i64, vp, i64, vp, C.POINTER(_MvResult)],
         "mih_cv_mv": [vp, C.POINTER(_FitParams), vp, i64, vp, i64, vp, i32, vp, i64, i32, i32, vp],
-        "mih_bench_xtv": [vp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_float), C.POINTER(dbl)],
-        "mih_bench_xtv_batched": [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_float), C.POINTER(dbl)],
+        "mih_bench_xtv": [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.POINTER(C.c_float), C.POINTER(dbl)],
         "mih_xtv_algorithmic_bytes": [vp, C.c_int, C.POINTER(dbl)],
-        "mih_set_xtv_variant": [C.c_int],
-        "mih_set_xtv_multi_variant": [C.c_int],
-        "mih_set_xtv_digits": [C.c_int],
         "mih_abi_sizes": [vp, i32],
         "mih_session_create": [vp, C.POINTER(_FitParams), vp, vp, i64, vp, C.POINTER(vp)],
         "mih_session_step": [vp, C.POINTER(dbl), C.POINTER(i32), C.POINTER(dbl)],
@@ -130,9 +149,14 @@ def lib():
         "mih_rccl_unique_id": [vp],
         "mih_comm_create_rccl": [vp, i32, i32, i32, i64, i64, C.POINTER(vp)],
         "mih_comm_destroy_rccl": [vp],
-        "mih_profile_enable": [C.c_int],
-        "mih_profile_read": [C.POINTER(dbl), C.POINTER(i64), C.c_int],
+        "mih_profile_enable": [vp, C.c_int],
+        "mih_profile_read": [vp, C.POINTER(dbl), C.POINTER(i64), C.c_int],
+        "mih_profile_passes": [vp, C.POINTER(_PassRecord), i64, C.POINTER(i64), C.c_int],
+        "mih_profile_counters": [vp, C.POINTER(i64), C.c_int],
     }
+    if using_probes():       # include/mendeliht_hip_probes.h
+        sig.update({"mih_probe_set_xtv_variant": [C.c_int], "mih_probe_set_xtv_multi_variant": [C.c_int],
+                    "mih_probe_set_max_fused": [C.c_int]})
     for name, args in sig.items():
         f = getattr(L, name)
         f.argtypes = args
@@ -147,12 +171,16 @@ def exported_symbols():
             "mih_snp_create_synthetic_shard",
             "mih_dense_create", "mih_dense_create_synthetic", "mih_dense_create_f32", "mih_mat_destroy", "mih_mat_dims",
             "mih_snp_mu_sigma", "mih_snp_export_bed", "mih_snp_naive_impute", "mih_xtv", "mih_xtv_batched", "mih_xv_sparse",
-            "mih_project_topk", "mih_project_group_sparse", "mih_fit_iht", "mih_cv_iht", "mih_cv_meanloss", "mih_cv_iht_multi", "mih_fit_iht_path",
-            "mih_fit_mv", "mih_cv_mv", "mih_bench_xtv", "mih_bench_xtv_batched", "mih_xtv_algorithmic_bytes", "mih_set_xtv_variant",
-            "mih_set_xtv_multi_variant", "mih_set_xtv_digits", "mih_abi_sizes",
+            "mih_project_topk", "mih_project_group_sparse", "mih_fit_iht", "mih_cv_iht", "mih_cv_meanloss", "mih_cv_assignment", "mih_cv_iht_multi", "mih_fit_iht_path",
+            "mih_fit_mv", "mih_cv_mv", "mih_bench_xtv", "mih_xtv_algorithmic_bytes", "mih_xtv_batched_fmt", "mih_abi_sizes",
             "mih_session_create", "mih_session_step", "mih_session_run", "mih_session_model", "mih_session_destroy",
             "mih_rccl_unique_id", "mih_comm_create_rccl", "mih_comm_destroy_rccl",
-            "mih_profile_enable", "mih_profile_read"]
+            "mih_profile_enable", "mih_profile_read", "mih_profile_passes", "mih_profile_counters"]
+
+
+def probe_symbols():
+    """What include/mendeliht_hip_probes.h declares: exported by the measurement build only."""
+    return ["mih_probe_set_xtv_variant", "mih_probe_set_xtv_multi_variant", "mih_probe_set_max_fused"]
 
 
 def _check(rc):
@@ -303,20 +331,24 @@ class _Mat:
         self.n, self.p = n.value, p.value
 
     # mul!(out, Transpose(x), r)
-    def xtv(self, r):
+    def xtv(self, r, xtv_digits=None):
         r = np.asarray(r, dtype=np.float64)
+        dg = _digits(xtv_digits)
         if r.ndim == 1:
             if r.size != self.n:
                 raise DimensionMismatch(f"r has length {r.size}, expected {self.n}")
             r = np.ascontiguousarray(r)
             out = np.empty(self.p)
-            _check(lib().mih_xtv(self._h, _p(r), _p(out)))
+            if dg == 0:
+                _check(lib().mih_xtv(self._h, _p(r), _p(out)))
+            else:
+                _check(lib().mih_xtv_batched_fmt(self._h, _p(r), 1, dg, _p(out)))
             return out
         if r.shape[0] != self.n:
             raise DimensionMismatch(f"R has {r.shape[0]} rows, expected {self.n}")
         R = np.asfortranarray(r)
         out = np.empty((self.p, R.shape[1]), order="F")
-        _check(lib().mih_xtv_batched(self._h, _p(R), R.shape[1], _p(out)))
+        _check(lib().mih_xtv_batched_fmt(self._h, _p(R), R.shape[1], dg, _p(out)))
         return out
 
     def xv_sparse(self, idx, val):
@@ -326,14 +358,20 @@ class _Mat:
         _check(lib().mih_xv_sparse(self._h, _p(idx), _p(val), idx.size, _p(out)))
         return out
 
-    def bench_xtv(self, variant=-1, iters=10, warmup=2, seed=1):
-        ms, cs = C.c_float(0), C.c_double(0)
-        _check(lib().mih_bench_xtv(self._h, variant, iters, warmup, seed, C.byref(ms), C.byref(cs)))
-        return ms.value, cs.value
+    def bench_xtv(self, variant=-1, iters=10, warmup=2, seed=1, xtv_digits=None):
+        """ms per single-residual pass (the workspace of a single fit) and a checksum of the result."""
+        return self.bench_xtv_batched(1, variant=variant, iters=iters, warmup=warmup, seed=seed, xtv_digits=xtv_digits)
 
-    def bench_xtv_batched(self, m, max_fused=4, variant=-1, iters=5, warmup=1, seed=1):
+    def bench_xtv_batched(self, m, max_fused=4, variant=-1, iters=5, warmup=1, seed=1, xtv_digits=None):
+        """`variant` / `max_fused` other than the defaults are knobs of the measurement build (MENDELIHT_HIP_PROBES=1)."""
+        if variant != -1 or max_fused != 4 or using_probes():
+            probe_set(variant=variant, max_fused=max_fused)
         ms, cs = C.c_float(0), C.c_double(0)
-        _check(lib().mih_bench_xtv_batched(self._h, variant, m, max_fused, iters, warmup, seed, C.byref(ms), C.byref(cs)))
+        try:
+            _check(lib().mih_bench_xtv(self._h, _digits(xtv_digits), m, iters, warmup, seed, C.byref(ms), C.byref(cs)))
+        finally:
+            if using_probes():
+                probe_set(variant=-1, max_fused=4)
         return ms.value, cs.value
 
     def algorithmic_bytes(self, m=1):
@@ -521,7 +559,7 @@ class IHTSession:
     """An IHTVariable kept alive on the GPU: `initialize` once, then `step()` = one iht_one_step!."""
 
     def __init__(self, y, x, z=None, *, k=10, J=1, d=None, l=None, zkeep=None, weight=None, max_step=3, train=None,
-                 comm=None):
+                 comm=None, xtv_digits=None):
         x = _as_mat(x)
         d = _inst(d) if d is not None else Normal()
         l = _inst(l) if l is not None else IdentityLink()
@@ -534,7 +572,7 @@ class IHTSession:
         self.q = z.shape[1]
         self._keep = [y, z]
         prm = _params(k, J, d, l, 1e-4, 1 << 30, 5, max_step, "None", zkeep, weight, None, self.q, x.p, self._keep,
-                      comm=comm)
+                      comm=comm, xtv_digits=xtv_digits)
         tr = None if train is None else np.ascontiguousarray(train, dtype=np.uint8)
         self._h = C.c_void_p(None)
         _check(lib().mih_session_create(x._h, C.byref(prm), _p(y), _p(z), self.q, _p(tr), C.byref(self._h)))
@@ -567,22 +605,110 @@ class IHTSession:
             pass
 
 
+_XTV_FORMATS = (0, 4910, 4908, 1316, 1308, 428)
+_default_digits = 0
+
+
 def set_xtv_digits(digits=0):
-    """Fixed-point format of the residual in X'r (see mih_set_xtv_digits), id = base * 100 + digits: 0 = library
-    default = 4910 (10 base-49 FP6 digits, 54-bit, three residuals per MFMA operand); 1316 (16 base-13 FP4 digits,
-    57-bit, two per operand); 428 (28 base-4 digits, one per operand); 4908 (43-bit, four per operand: the opt-in
-    fast mode for fused multi-RHS passes); 1308 (27-bit, four per operand)."""
-    _check(lib().mih_set_xtv_digits(int(digits)))
+    """Default of the `xtv_digits=` keyword of this mirror's calls (fit_iht, cv_iht, iht_run_many_models, IHTSession,
+    SnpLinAlg.xtv, ...): the fixed-point format of the residual in X'r, id = base * 100 + digits -- 0 = library default =
+    4910 (10 base-49 FP6 digits, 54-bit, three residuals per MFMA operand) for fused passes and 428 (28 base-4 digits) for
+    a single fit; 1316 (16 base-13 FP4 digits, 57-bit, two per operand); 4908 (43-bit, four per operand: the opt-in fast
+    mode for fused multi-RHS passes); 1308 (27-bit, four per operand).  The LIBRARY has no such global: the format travels
+    with every call (mih_fit_params::xtv_digits, mih_xtv_batched_fmt), so concurrent calls may differ."""
+    global _default_digits
+    if int(digits) not in _XTV_FORMATS:
+        raise ArgumentError("residual format must be 0 (default), 4910, 4908, 1316, 1308 or 428")
+    _default_digits = int(digits)
 
 
-def profile_enable(on=True):
-    _check(lib().mih_profile_enable(int(on)))
+def _digits(xtv_digits=None):
+    d = _default_digits if xtv_digits is None else int(xtv_digits)
+    if d not in _XTV_FORMATS:
+        raise ArgumentError("residual format must be 0 (default), 4910, 4908, 1316, 1308 or 428")
+    return d
 
 
-def profile_read(reset=True):
+def probe_set(variant=None, multi_variant=None, max_fused=None):
+    """Knobs of the measurement build (libmendeliht_hip_probes.so, MENDELIHT_HIP_PROBES=1): the per-wave single-operand
+    kernel shapes, the launch shape / probe id of the LDS-shared and ring kernels, operands fused per register-staged pass."""
+    if not using_probes():
+        if (variant in (None, -1)) and (multi_variant in (None, 0)) and (max_fused in (None, 4)):
+            return
+        raise MendelIHTError("kernel-shape knobs exist in the measurement build only: set MENDELIHT_HIP_PROBES=1 before "
+                             "the first call (the product library has one kernel per format and operand count)")
+    L = lib()
+    if variant is not None:
+        _check(L.mih_probe_set_xtv_variant(int(variant)))
+    if multi_variant is not None:
+        _check(L.mih_probe_set_xtv_multi_variant(int(multi_variant)))
+    if max_fused is not None:
+        _check(L.mih_probe_set_max_fused(int(max_fused)))
+
+
+def profile_enable(x, on=True):
+    """Measurement hook of matrix `x` (mih_profile_*): record every launch of the dominant X'r kernel on it."""
+    _check(lib().mih_profile_enable(_as_mat(x)._h, int(on)))
+
+
+def profile_read(x, reset=True):
+    """(total kernel ms, launches) since the last reset."""
     ms, n = C.c_double(0), C.c_int64(0)
-    _check(lib().mih_profile_read(C.byref(ms), C.byref(n), int(reset)))
+    _check(lib().mih_profile_read(_as_mat(x)._h, C.byref(ms), C.byref(n), int(reset)))
     return ms.value, n.value
+
+
+def profile_passes(x, reset=True):
+    """The recorded launches, oldest first: dicts with kernel, residuals, operands, stream_tag, start_ms, ms."""
+    h = _as_mat(x)._h
+    n = C.c_int64(0)
+    _check(lib().mih_profile_passes(h, None, 0, C.byref(n), 0))
+    buf = (_PassRecord * max(n.value, 1))()
+    _check(lib().mih_profile_passes(h, buf, n.value, C.byref(n), int(reset)))
+    return [dict(kernel=buf[i].kernel.decode(), residuals=buf[i].residuals, operands=buf[i].operands,
+                 stream_tag=buf[i].stream_tag, start_ms=buf[i].start_ms, ms=buf[i].ms) for i in range(n.value)]
+
+
+def profile_counters(x, reset=True):
+    """What the lock-step drivers did on `x` while its hook was on (PROFILE_COUNTERS)."""
+    out = (C.c_int64 * len(PROFILE_COUNTERS))()
+    _check(lib().mih_profile_counters(_as_mat(x)._h, out, int(reset)))
+    return dict(zip(PROFILE_COUNTERS, [int(v) for v in out]))
+
+
+def busy_union_ms(passes):
+    """Time during which at least one of the recorded launches was running (launches of different lanes overlap)."""
+    iv = sorted((q["start_ms"], q["start_ms"] + q["ms"]) for q in passes)
+    tot, cur_a, cur_b = 0.0, None, None
+    for a, b in iv:
+        if cur_b is None or a > cur_b:
+            if cur_b is not None:
+                tot += cur_b - cur_a
+            cur_a, cur_b = a, b
+        else:
+            cur_b = max(cur_b, b)
+    if cur_b is not None:
+        tot += cur_b - cur_a
+    return tot
+
+
+def cv_assignment(path, q, world):
+    """rank_of[fold, ik] of the library's sharding rule for cv_iht (mih_cv_assignment): a (q, len(path)) int32 array."""
+    path = np.ascontiguousarray(list(path), dtype=np.int64)
+    out = np.zeros((int(q), path.size), dtype=np.int32)
+    _check(lib().mih_cv_assignment(_p(path), path.size, int(q), int(world), _p(out)))
+    return out
+
+
+def hash_folds(n, q, seed=2026):
+    """folds_i = 1 + (hash(seed, i) mod q): explicit, RNG-free fold labels for benchmarks and tests (the
+    reference's default is rand(1:q, n), cross_validation.jl:72)."""
+    i = np.arange(n, dtype=np.uint64)
+    x = (i + np.uint64(seed)) * np.uint64(0x9E3779B97F4A7C15)
+    x ^= x >> np.uint64(31)
+    x *= np.uint64(0xBF58476D1CE4E5B9)
+    x ^= x >> np.uint64(29)
+    return (1 + (x % np.uint64(q))).astype(np.int32)
 
 
 def _is_multivariate(y):
@@ -613,9 +739,10 @@ def _print_parameters(io, k, d, l, use_maf, group, debias, tol, max_iter, min_it
 
 
 def _params(k, J, d, l, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, q, p, keep, progress=None,
-            init_beta=False, comm=None, debias=False):
+            init_beta=False, comm=None, debias=False, xtv_digits=None):
     prm = _FitParams()
     prm.debias = int(bool(debias))
+    prm.xtv_digits = _digits(xtv_digits)
     if comm is not None:            # column-sharded fit: mendeliht.jl_amd.dist.ColumnComm
         prm.comm = comm.pointer()
         keep.append(comm)
@@ -668,8 +795,10 @@ def _params(k, J, d, l, tol, max_iter, min_iter, max_step, est_r, zkeep, weight,
 
 def fit_iht(y, x, z=None, *, k=10, J=1, d=None, l=None, group=None, weight=None, zkeep=None, est_r="None",
             use_maf=False, debias=False, verbose=True, tol=1e-4, max_iter=200, min_iter=5, max_step=3,
-            io=None, init_beta=False, memory_efficient=True, train=None, comm=None):
+            io=None, init_beta=False, memory_efficient=True, train=None, comm=None, xtv_digits=None):
     """fit_iht(y, x, z; k, J, d, l, ...) -- src/fit.jl:60-118.
+
+    xtv_digits (no reference counterpart): fixed-point format of the residual in this call's X'r passes (set_xtv_digits).
 
     comm: a `dist.ColumnComm` when x holds only this process's block of SNP columns (column-sharded fit
     over several GPUs; beta in the result then covers the local columns -- see dist.fit_iht_sharded).
@@ -698,7 +827,7 @@ def fit_iht(y, x, z=None, *, k=10, J=1, d=None, l=None, group=None, weight=None,
     if verbose:
         _print_signature(io)
     if mv:
-        return _fit_mv(y, x, z, k, d, l, zkeep, verbose, tol, max_iter, min_iter, max_step, io, train, init_beta)
+        return _fit_mv(y, x, z, k, d, l, zkeep, verbose, tol, max_iter, min_iter, max_step, io, train, init_beta, xtv_digits)
     y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).ravel())
     n = x.n
     z = np.ones((n, 1)) if z is None else np.asarray(z, dtype=np.float64)
@@ -717,7 +846,7 @@ def fit_iht(y, x, z=None, *, k=10, J=1, d=None, l=None, group=None, weight=None,
 
     keep = []
     prm = _params(k, J, d, l, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, q, x.p, keep, progress,
-                  init_beta=init_beta, comm=comm, debias=debias)
+                  init_beta=init_beta, comm=comm, debias=debias, xtv_digits=xtv_digits)
     if verbose:
         _print_parameters(io, k, d, l, use_maf, group, debias, tol, max_iter, min_iter)
     tr = None if train is None else np.ascontiguousarray(train, dtype=np.uint8)
@@ -746,7 +875,7 @@ def _checky(y, d):
         raise ArgumentError("Gamma/InverseGaussian data must be positive")
 
 
-def _fit_mv(Y, x, Z, k, d, l, zkeep, verbose, tol, max_iter, min_iter, max_step, io, train, init_beta=False):
+def _fit_mv(Y, x, Z, k, d, l, zkeep, verbose, tol, max_iter, min_iter, max_step, io, train, init_beta=False, xtv_digits=None):
     Y = np.asfortranarray(np.asarray(Y, dtype=np.float64))
     r, n = Y.shape
     Z = np.ones((1, n)) if Z is None else np.asarray(Z, dtype=np.float64)
@@ -766,7 +895,7 @@ def _fit_mv(Y, x, Z, k, d, l, zkeep, verbose, tol, max_iter, min_iter, max_step,
 
     keep = []
     prm = _params(k, 1, Normal(), l, tol, max_iter, min_iter, max_step, "None", zkeep, None, None, q, x.p, keep, progress,
-                  init_beta=init_beta)
+                  init_beta=init_beta, xtv_digits=xtv_digits)
     if verbose:
         _print_parameters(io, k, MvNormal(), l, False, None, False, tol, max_iter, min_iter)
     tr = None if train is None else np.ascontiguousarray(train, dtype=np.uint8)
@@ -786,7 +915,7 @@ def _fit_mv(Y, x, Z, k, d, l, zkeep, verbose, tol, max_iter, min_iter, max_step,
 
 def cv_iht(y, x, z=None, *, d=None, l=None, path=range(1, 21), q=5, est_r="None", group=None, weight=None,
            zkeep=None, folds=None, debias=False, verbose=True, max_iter=100, min_iter=5, init_beta=False,
-           memory_efficient=True, tol=1e-4, max_step=3, rank=0, world=1, reduce=None, return_raw=False):
+           memory_efficient=True, tol=1e-4, max_step=3, rank=0, world=1, reduce=None, return_raw=False, xtv_digits=None):
     """cv_iht(y, x, z; path, q, folds, ...) -- src/cross_validation.jl:60-131.
 
     `x` may be a list of replicas of the matrix (one per GPU): the combinations are then spread over them
@@ -834,7 +963,7 @@ def cv_iht(y, x, z=None, *, d=None, l=None, path=range(1, 21), q=5, est_r="None"
         Z = np.ones((1, n)) if z is None else np.asarray(z, dtype=np.float64)
         Z = np.asfortranarray(Z.reshape(-1, Z.shape[-1]) if Z.ndim > 1 else Z.reshape(1, -1))
         prm = _params(1, 1, Normal(), l, tol, max_iter, min_iter, max_step, "None", zkeep, None, None, Z.shape[0], x.p, keep,
-                      init_beta=init_beta)
+                      init_beta=init_beta, xtv_digits=xtv_digits)
         _check(lib().mih_cv_mv(x._h, C.byref(prm), _p(Y), r, _p(Z), Z.shape[0], _p(folds), q, _p(path), path.size,
                                rank, world, _p(raw)))
     else:
@@ -845,7 +974,7 @@ def cv_iht(y, x, z=None, *, d=None, l=None, path=range(1, 21), q=5, est_r="None"
             raise DimensionMismatch(f"row dimension of y, x, and z ({yv.size}, {n}, {zz.shape[0]}) are not equal")
         _checky(yv, d)
         prm = _params(1, 1, d, l, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, zz.shape[1], x.p, keep,
-                      init_beta=init_beta, debias=debias)
+                      init_beta=init_beta, debias=debias, xtv_digits=xtv_digits)
         if replicas is not None:
             hs = (C.c_void_p * len(replicas))(*[r._h for r in replicas])
             _check(lib().mih_cv_iht_multi(hs, len(replicas), C.byref(prm), _p(yv), _p(zz), zz.shape[1], _p(folds), q,
@@ -924,7 +1053,7 @@ def maf_weights(x, max_weight=np.inf):
 
 def iht_run_many_models(y, x, z=None, *, d=None, l=None, path=range(1, 21), est_r="None", group=None, weight=None,
                         use_maf=False, debias=False, verbose=True, parallel=False, max_iter=100, rank=0, world=1,
-                        reduce=None):
+                        reduce=None, xtv_digits=None):
     """iht_run_many_models(y, x, z; path, ...) -- src/cross_validation.jl:232-273: fit_iht on the FULL data
     for every model size in `path` (no hold-out), returns the loglikelihoods.  `parallel` (pmap in the
     reference) is accepted and ignored: the fits of one process run back to back on its GPU; `rank` /
@@ -943,7 +1072,8 @@ def iht_run_many_models(y, x, z=None, *, d=None, l=None, path=range(1, 21), est_
         raise DimensionMismatch(f"row dimension of y, x, and z ({yv.size}, {n}, {zz.shape[0]}) are not equal")
     _checky(yv, d)
     keep = []
-    prm = _params(1, 1, d, l, 1e-4, max_iter, 5, 3, est_r, None, weight, group, zz.shape[1], x.p, keep, debias=debias)
+    prm = _params(1, 1, d, l, 1e-4, max_iter, 5, 3, est_r, None, weight, group, zz.shape[1], x.p, keep, debias=debias,
+                  xtv_digits=xtv_digits)
     logl = np.zeros(path.size)
     _check(lib().mih_fit_iht_path(x._h, C.byref(prm), _p(yv), _p(zz), zz.shape[1], _p(path), path.size, rank, world,
                                   _p(logl), None, None, None))

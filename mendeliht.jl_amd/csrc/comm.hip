@@ -71,6 +71,9 @@ static int nccl_fail(int rc, const char *what)
 static int ensure_stage(NativeComm *nc, size_t doubles)
 {
     if (doubles <= nc->stage_cap) return MIH_OK;
+    //  the callbacks run inside mih_fit_iht, whose pool / arena scopes are active: the communicator may outlive the
+    // matrix, so its staging buffer must not come out of the matrix's reserve
+    PoolScope no_pool(nullptr); ArenaScope no_arena(nullptr);
     MIH_TRY(nc->stage.alloc(doubles * 2));
     nc->stage_cap = doubles * 2;
     return MIH_OK;

@@ -20,6 +20,18 @@ namespace mih {
 void set_error(const char *fmt, ...);
 int  hip_fail(hipError_t e, const char *what, const char *file, int line);
 
+// A/B switches and tuning knobs of the MEASUREMENT build (-DMIH_PROBES: libmendeliht_hip_probes.so, used by tools/ and by the
+// "this switch changes nothing" tests).  The release library does not read them: its behaviour is fixed by its arguments.
+inline const char *probe_env(const char *name)
+{
+#ifdef MIH_PROBES
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 #define MIH_HIP(expr)                                                         \
     do {                                                                      \
         hipError_t e_ = (expr);                                               \
@@ -118,7 +130,7 @@ struct Arena {
     void release_dev() { if (dev) { if (dev_pool) dev_pool->give_back(dev); else (void)hipFree(dev); dev = nullptr; } }
     int reserve(size_t device_bytes, size_t pinned_bytes)
     {
-        static const bool off = getenv("MENDELIHT_NO_ARENA") != nullptr;       // A/B: every buffer its own allocation
+        static const bool off = probe_env("MENDELIHT_NO_ARENA") != nullptr;       // A/B: every buffer its own allocation
         if (off) return MIH_OK;
         if (dev_malloc((void **)&dev, device_bytes, &dev_pool) != hipSuccess) { (void)hipGetLastError(); dev = nullptr; device_bytes = 0; }   // fall back to single buffers
         if (hipHostMalloc((void **)&pin, pinned_bytes, hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); pin = nullptr; pinned_bytes = 0; }
@@ -247,6 +259,25 @@ void stage_to_device(hipStream_t s, const uint64_t *src_pinned, uint64_t *dst_a,
 
 }  // namespace mih
 
+namespace mih {
+// Measurement hook of a matrix handle (mih_profile_*): when enabled, every launch of the dominant X'r kernel on this matrix is
+// bracketed by HIP events on the stream it runs on and recorded with its kernel name and residual count; the lock-step drivers
+// also count what they did (lanes, slots, hand-overs, shared initial scores).  Lives behind the handle, not in the process.
+struct PassRecord { hipEvent_t e0 = nullptr, e1 = nullptr; int residuals = 0, operands = 0, stream_tag = 0; char kernel[48] = {0}; };
+struct Profile {
+    std::mutex mu;
+    bool on = false;
+    hipEvent_t origin = nullptr;                 // recorded when profiling was switched on: start offsets are relative to it
+    std::vector<PassRecord> open;                // launches whose events have not been read yet
+    std::vector<mih_pass_record> done;
+    int64_t counters[MIH_PROFILE_NCOUNTERS] = {0};
+    void count(int which, int64_t add) { if (!on) return; std::lock_guard<std::mutex> g(mu); counters[which] += add; }
+    void count_max(int which, int64_t v) { if (!on) return; std::lock_guard<std::mutex> g(mu); if (v > counters[which]) counters[which] = v; }
+    void drain();                                // synchronise the open records into `done`
+    ~Profile();
+};
+}  // namespace mih
+
 // Device-resident design matrix.
 //
 // kind 0 (SnpLinAlg): 2-bit dosage codes in a TILE-MAJOR layout built for the matrix cores.
@@ -277,6 +308,7 @@ struct mih_mat {
     hipStream_t stream = nullptr;  // for the stand-alone linear-algebra entry points
     mih::DevPool *pool = nullptr;  // reserve for the fits that run on this matrix (large 2-bit matrices only)
     std::shared_ptr<mih::DevPool> pool_owner;      // a session keeps a reference: the reserve outlives a matrix destroyed first
+    std::shared_ptr<mih::Profile> prof = std::make_shared<mih::Profile>();    // measurement hook (mih_profile_*), off by default
 };
 
 namespace mih {
@@ -303,23 +335,40 @@ struct DigitMode {
     int rows_log2;   // a row slice holds at most 2^rows_log2 rows (f32 accumulators stay exact)
     int lay16 = 0;   // FP6 planes stored as the B fragments of the 16x16x128 MFMA (two 16-column images per 128-row block)
 };
+// How the X'r passes of a workspace run.  Fixed when the workspace is built, from the CALL's arguments (mih_fit_params::
+// xtv_digits, the digits argument of mih_xtv_batched_fmt / mih_bench_xtv): there is no process-wide kernel or format selector.
+// Everything but `digits` is a knob of the measurement build (mih_probe_*; constant in the release library).
+struct XtvTune {
+    int digits = 0;          // residual format id (include/mendeliht_hip.h), 0 = library default
+    int variant = -1;        // >= 0: a per-wave-load single-operand shape (round-1 kernels)
+    int multi_variant = 0;   // launch-shape / probe id of the LDS-shared and ring kernels
+    int max_nr = 4;          // B operands fused per pass of the register-staged kernels (1, 2 or 4)
+    int max_ops = 5;         // B operands per pass of the 16x16x128 ring kernel (5 = 15 residuals)
+    int slices = 0;          // row slices, 0 = auto_splits
+    bool half = true;        // leave out the empty second fragment of a pass's last operand
+};
+// the tuning of a call: digits from the caller, the rest defaults (release) or the probe knobs (measurement build)
+XtvTune xtv_tune(int digits);
+inline XtvTune xtv_tune(const mih_fit_params *prm) { return xtv_tune(prm ? prm->xtv_digits : 0); }
+bool xtv_digits_valid(int digits);
+
 struct XtvWork {            // scratch for one in-flight X'r
     DevBuf<uint32_t> digits;   // ops * nblk * 64 lanes * 4 dwords (+ 2 dwords, stored behind, for FP6) : digit planes of r (B operands)
     DevBuf<double>   partial;  // splits * rhs * ncg*32 raw dots
     DevBuf<double>   scal;     // rhs * 4 : {max|r|, 2^-e, sum r, 2^e}
     DevBuf<unsigned> stat_done; // rhs : blocks of k_r_stats that have delivered their partial (zero between launches)
     int m_cap = 0, splits_cap = 0;
-    DigitMode dm = {13, 16, 2, 16, 56, 20};   // fixed at init (mih_set_xtv_digits)
+    DigitMode dm = {13, 16, 2, 16, 56, 20};   // fixed at init (tune.digits and the matrix height)
     int ops_cap = 0;           // B operands the buffers hold
+    XtvTune tune;              // fixed at init
+    int stream_tag = 0;        // which lock-step lane launches on this workspace (profile records)
 };
 // batched = false: the workspace of a single univariate fit (one residual per pass); true: fused multi-RHS passes
-int  xtv_work_init(const mih_mat *h, XtvWork &w, int m, bool batched = true);
+int  xtv_work_init(const mih_mat *h, XtvWork &w, int m, const XtvTune &tune, bool batched = true);
 // r_dev: m vectors of length n (column-major n x m) on device; out_dev p x m.
 int  xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double *out_dev, hipStream_t s);
-int  xtv_num_variants();
 // residuals of two full fused passes (five operands each by default) in the batched format: how many fits the lock-step drivers keep in flight
-int  xtv_lockstep_width(const mih_mat *h);
-extern int g_xtv_variant;
+int  xtv_lockstep_width(const mih_mat *h, const XtvTune &tune);
 
 // ---- X[:,S] v -----------------------------------------------------------------
 struct XvWork {
@@ -378,9 +427,11 @@ int  group_project_device(double *y_dev, const int64_t *group_dev, int64_t len, 
 // debias! (utilities.jl:1014-1020): GLM refit of y on the k support columns (debias.hip); beta_out[k] on the host
 int  debias_glm_device(const mih_mat *h, const int64_t *idx_host, int64_t k, const double *y_dev, int dist, int link,
                        double nb_r, double *beta_out, hipStream_t s);
+// rank_of[fold * npath + ik]: which rank of `world` evaluates that (fold, k) combination (mih_cv_assignment; fit.hip)
+void cv_assign(const int64_t *path, int64_t npath, int32_t nfolds, int32_t world, std::vector<int32_t> &rank_of);
 // initialize_beta! regressions for m response planes (fit.hip); shared by the univariate and multivariate fits
 int  init_beta_regress_device(const mih_mat *h, const double *w_dev, const double *Y_dev, int m, double N,
                               const double *Sy_host, double *beta_dev, double *icpt_sum_host,
-                              DevBuf<double> &red, DevBuf<double> &scal, hipStream_t s);
+                              DevBuf<double> &red, DevBuf<double> &scal, hipStream_t s, const XtvTune &tune);
 
 }  // namespace mih

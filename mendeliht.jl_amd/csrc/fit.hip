@@ -365,11 +365,11 @@ static double h_mueta(int link, double eta)
 // SNP) and a popcount pass (sum x^2 from exact dosage counts).
 int init_beta_regress_device(const mih_mat *h, const double *w_dev, const double *Y_dev, int m, double N,
                              const double *Sy_host, double *beta_dev, double *icpt_sum_host,
-                             DevBuf<double> &red, DevBuf<double> &scal, hipStream_t s)
+                             DevBuf<double> &red, DevBuf<double> &scal, hipStream_t s, const XtvTune &tune)
 {
     const int64_t n = h->n, p = h->p;
     XtvWork xw; DevBuf<double> R, S, icpt, sxxd; DevBuf<uint32_t> M; DevBuf<int32_t> cnt;
-    MIH_TRY(xtv_work_init(h, xw, 1 + m));
+    MIH_TRY(xtv_work_init(h, xw, 1 + m, tune));
     MIH_TRY(R.alloc((size_t)(1 + m) * n)); MIH_TRY(S.alloc((size_t)(1 + m) * p)); MIH_TRY(icpt.alloc(p));
     hipLaunchKernelGGL(k_ib_rhs, dim3(nblk(n)), dim3(256), 0, s, Y_dev, w_dev, n, m, R.p);
     MIH_TRY(xtv_device(h, xw, R.p, 1 + m, S.p, s));
@@ -408,6 +408,7 @@ struct IhtVar {
     std::vector<uint8_t> zkeep; int64_t zkeepn = 0;
     const double *y_host = nullptr, *z_host = nullptr;
     int init_beta = 0, debias = 0;
+    XtvTune tune;                 // how this fit's X'r passes run (mih_fit_params::xtv_digits)
     hipStream_t s = nullptr;
     // device
     DevBuf<double> y, z, w, xb, zc, mu, r, xgk, df, full, weight, red, scal, gval, ztr;
@@ -454,7 +455,7 @@ struct IhtVar {
     int create(const mih_mat *hh, const mih_fit_params *prm, const double *yh, const double *zh, int64_t qq,
                hipStream_t shared_stream = nullptr, double *y_shared = nullptr, double *z_shared = nullptr)
     {
-        h = hh; n = h->n; p = h->p; q = (int)qq; y_host = yh; z_host = zh; init_beta = prm->init_beta;
+        h = hh; n = h->n; p = h->p; q = (int)qq; y_host = yh; z_host = zh; init_beta = prm->init_beta; tune = xtv_tune(prm);
         reserve = h->pool_owner;
         comm = prm->comm; pg = p; col0 = 0; debias = prm->debias;
         if (comm) {
@@ -499,7 +500,7 @@ struct IhtVar {
         MIH_TRY(stage.init(2 * (size_t)kcap + 8));
         MIH_TRY(hpin.alloc((size_t)kcap + kMaxQ + 16, true));
         MIH_TRY(flag.word.alloc(8, true)); flag.word.p[0] = 0; flag.seq = 0;
-        if (!batched) { ArenaScope own_buffers(nullptr); MIH_TRY(xtv_work_init(h, xtv, 1, false)); }     // a few large buffers: their own allocations
+        if (!batched) { ArenaScope own_buffers(nullptr); MIH_TRY(xtv_work_init(h, xtv, 1, tune, false)); }     // a few large buffers: their own allocations
         MIH_TRY(xv_work_init(h, xv, kcap, kcap - 1024));       // the cache is sized for the model, not for the tie slack of the lists
         MIH_TRY(topk_work_init(topk, kcap));
         if (!(y_shared && z_shared)) {
@@ -900,7 +901,7 @@ struct IhtVar {
             std::vector<double> ys;
             for (int64_t i = 0; i < n; ++i) if (!train || train[i]) { Sy += y_host[i]; N += 1.0; ys.push_back(y_host[i]); }
             double c0sum = 0.0;
-            MIH_TRY(init_beta_regress_device(h, w.p, y.p, 1, N, &Sy, betad.p, &c0sum, red, scal, s));
+            MIH_TRY(init_beta_regress_device(h, w.p, y.p, 1, N, &Sy, betad.p, &c0sum, red, scal, s, tune));
             ib_c.assign(q, 0.0);
             // non-genetic covariates 2..q on the host (utilities.jl:799-806)
             for (int l = 1; l < q; ++l) {
@@ -1317,6 +1318,7 @@ static int cv_finish(CvFit &f, double *mses_raw)
         }
         if (f.c_out) for (int l = 0; l < f.v->q; ++l) f.c_out[l] = f.v->best_c[l];
         f.done = true;
+        f.v->h->prof->count(MIH_CNT_FITS, 1);
         f.release();
         return MIH_OK;
     }
@@ -1326,6 +1328,7 @@ static int cv_finish(CvFit &f, double *mses_raw)
     MIH_TRY(f.v->mu_loglik(1, nullptr, &dev));
     mses_raw[f.out_index] = dev;
     f.done = true;
+    f.v->h->prof->count(MIH_CNT_FITS, 1);
     f.release();                                       // the IHTVariable (device buffers, column cache) goes back to the lane's pool
     return MIH_OK;
 }
@@ -1355,7 +1358,7 @@ struct CvHandover {
 static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t total, std::atomic<size_t> &next, int cap,
                           const MakeFit &make, XtvWork &xw, DevBuf<double> &R,
                           DevBuf<double> &DF /* (cap + init_slots) x p */, hipStream_t s, double *mses_raw, CvHandover *ho = nullptr, int lane_id = 0,
-                          int init_slots = 0, const CvShared &shared = CvShared())
+                          int init_slots = 0, const CvShared &shared = CvShared(), std::atomic<int> *inflight = nullptr)
 {
     std::vector<std::unique_ptr<IhtVar>> pool;            // declared before the slots: outlives them
     std::vector<std::unique_ptr<CvFit>> slot((size_t)cap);
@@ -1363,7 +1366,7 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
     std::vector<char> fresh;
     std::map<int, double *> df0;                                         // initial X'r per init_key: slots behind the pass's outputs in DF
     std::vector<std::pair<CvFit *, double *>> owners, followers;
-    static const bool share_init = getenv("MENDELIHT_CV_NO_INIT_SHARE") == nullptr;
+    static const bool share_init = probe_env("MENDELIHT_CV_NO_INIT_SHARE") == nullptr;
     bool drained = false;                 // the shared queue is empty
     auto occupied = [&]() { int c = 0; for (auto &sl : slot) c += sl != nullptr; return c; };
     auto adopt = [&]() {                  // lane 0: take handed-over fits into free slots (caller holds ho->mu)
@@ -1375,11 +1378,12 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
                 slot[t]->v->s = s;
             }
     };
-    static const bool trace_rounds = getenv("MENDELIHT_CV_TRACE") != nullptr;
+    static const bool trace_rounds = probe_env("MENDELIHT_CV_TRACE") != nullptr;
     auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_round = tnow();
     int round_no = 0;
     for (;;) {
+        h->prof->count(MIH_CNT_ROUNDS, 1);
         if (trace_rounds) { const double t = tnow(); fprintf(stderr, "lane %d round %d: %.2f ms, %zu scores\n", lane_id, round_no++, t - t_round, need.size()); t_round = t; }
         if (ho && lane_id == 0) {
             std::lock_guard<std::mutex> g(ho->mu);
@@ -1391,8 +1395,12 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
             const int mine = occupied();
             std::lock_guard<std::mutex> g(ho->mu);
             if (mine > 0 && ho->accepting && mine + ho->active0.load() <= cap) {
-                for (auto &sl : slot) if (sl) { sl->pool = nullptr; ho->orphans.push_back(std::move(sl)); }
+                //  a handed-over fit is quiescent: it forgets this lane's stream, which is destroyed when the lane returns
+                // (an orphan that is never adopted -- lane 0 failed -- must not synchronise a dead stream in ~IhtVar)
+                for (auto &sl : slot) if (sl) { sl->pool = nullptr; sl->v->s = nullptr; ho->orphans.push_back(std::move(sl)); }
                 ho->active0.fetch_add(mine);
+                h->prof->count(MIH_CNT_HANDOVERS, 1);
+                if (inflight) inflight[lane_id].store(0);
                 return MIH_OK;                           // lane 0 finishes them
             }
         }
@@ -1414,6 +1422,7 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
                         if (it != df0.end()) {       // its initial X'r is known from an earlier round: no pass, straight on to its first step
                             MIH_HIP(hipMemcpyAsync(f.v->df.p, it->second, sizeof(double) * h->p, hipMemcpyDeviceToDevice, s));
                             MIH_TRY(f.v->init_post());
+                            h->prof->count(MIH_CNT_SHARED_INIT, 1);
                             continue;
                         }
                     }
@@ -1447,13 +1456,20 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
             const int key = (fresh[t] && share_init) ? f->init_key : -1;
             if (key < 0) { riders.push_back(f); continue; }
             auto it = df0.find(key);
-            if (it != df0.end()) { followers.emplace_back(f, it->second); continue; }
+            if (it != df0.end()) { followers.emplace_back(f, it->second); h->prof->count(MIH_CNT_SHARED_INIT, 1); continue; }
             riders.push_back(f);
             if ((int)df0.size() < init_slots) {            // room in the lane's cache (allocated with its workspace)
                 double *buf = DF.p + ((size_t)cap + df0.size()) * (size_t)h->p;
                 df0[key] = buf;
                 owners.emplace_back(f, buf);
             }
+        }
+        if (h->prof->on) {
+            const int mine_now = occupied();
+            h->prof->count_max(MIH_CNT_MAX_LANE_SLOTS, mine_now);
+            if (inflight) { inflight[lane_id].store(mine_now); h->prof->count_max(MIH_CNT_MAX_IN_FLIGHT, inflight[0].load() + inflight[1].load()); }
+            else h->prof->count_max(MIH_CNT_MAX_IN_FLIGHT, mine_now);
+            h->prof->count(MIH_CNT_SCORES, (int64_t)need.size());
         }
         MIH_TRY(cv_batched_xtv(h, xw, riders, R, DF, s));
         for (auto &o : owners) MIH_HIP(hipMemcpyAsync(o.second, o.first->v->df.p, sizeof(double) * h->p, hipMemcpyDeviceToDevice, s));
@@ -1477,13 +1493,17 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
 static int cv_run_lanes(const mih_mat *h, const mih_fit_params &pr, size_t total, const MakeFit &make, double *mses_raw, int init_keys,
                         const double *y_host, const double *z_host, int64_t q)
 {
-    const int width = xtv_lockstep_width(h);
+    const XtvTune tune = xtv_tune(&pr);
+    if (!xtv_digits_valid(tune.digits)) { set_error("residual format must be 0 (default), 4910, 4908, 1316, 1308 or 428"); return MIH_BAD_ARG; }
+    const int width = xtv_lockstep_width(h, tune);
     int lanes = total > (size_t)width / 2 ? 2 : 1;  // more fits than one full pass holds: two lanes hide each other's per-fit chains (25 fits: 1.01 s against 1.06 s with one lane; 13 fits: 0.56 s with one lane, 0.65 s with two)
-    if (const char *e = getenv("MENDELIHT_CV_LANES")) { int v = atoi(e); if (v >= 1 && v <= 4) lanes = (int)std::min<size_t>((size_t)v, total); }
+    if (const char *e = probe_env("MENDELIHT_CV_LANES")) { int v = atoi(e); if (v >= 1 && v <= 4) lanes = (int)std::min<size_t>((size_t)v, total); }
     const int cap = (int)std::min<size_t>((size_t)std::max(1, width / lanes), (total + lanes - 1) / lanes);
     std::atomic<size_t> next{0};
     CvHandover handover;
-    const bool merge_tail = lanes == 2 && !getenv("MENDELIHT_CV_NO_MERGE");
+    std::atomic<int> inflight[2];
+    inflight[0].store(0); inflight[1].store(0);
+    const bool merge_tail = lanes == 2 && !probe_env("MENDELIHT_CV_NO_MERGE");
     std::vector<DevBuf<double>> yds((size_t)lanes), zds((size_t)lanes);
     auto lane = [&](int lane_id) -> int {
         PoolScope from_reserve(h->pool);                        // workspaces and IHTVariables out of the matrix's reserve (no hipMalloc)
@@ -1492,7 +1512,12 @@ static int cv_run_lanes(const mih_mat *h, const mih_fit_params &pr, size_t total
         MIH_HIP(hipStreamCreate(&s));
         struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{s};
         XtvWork xw; DevBuf<double> R, DF;
-        MIH_TRY(xtv_work_init(h, xw, cap));
+        //  the workspace goes back to the matrix's reserve when this scope ends, on error returns too: nothing of this
+        // lane may still be queued on the device then, or the other lane would be handed memory that kernels are writing
+        struct DrainOnExit { hipStream_t s; ~DrainOnExit() { (void)hipStreamSynchronize(s); } } drain{s};
+        MIH_TRY(xtv_work_init(h, xw, cap, tune));
+        xw.stream_tag = lane_id + 1;
+        h->prof->count(MIH_CNT_LANES, 1);
         MIH_TRY(R.alloc((size_t)cap * h->n));
         const int init_slots = std::min(init_keys, 8);          // shared initial scores (cv_run_rolling): 8 MB each at p = 1M
         MIH_TRY(DF.alloc((size_t)(cap + init_slots) * h->p));
@@ -1501,7 +1526,7 @@ static int cv_run_lanes(const mih_mat *h, const mih_fit_params &pr, size_t total
         MIH_HIP(hipMemcpyAsync(yd.p, y_host, sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice, s));
         MIH_HIP(hipMemcpyAsync(zd.p, z_host, sizeof(double) * (size_t)h->n * (size_t)q, hipMemcpyHostToDevice, s));
         CvShared shared; shared.y = yd.p; shared.z = zd.p;
-        return cv_run_rolling(h, pr, total, next, cap, make, xw, R, DF, s, mses_raw, merge_tail ? &handover : nullptr, lane_id, init_slots, shared);
+        return cv_run_rolling(h, pr, total, next, cap, make, xw, R, DF, s, mses_raw, merge_tail ? &handover : nullptr, lane_id, init_slots, shared, lanes == 2 ? inflight : nullptr);
     };
     if (lanes == 1) return lane(0);
     std::vector<int> rcs((size_t)lanes, MIH_OK);
@@ -1516,6 +1541,42 @@ static int cv_run_lanes(const mih_mat *h, const mih_fit_params &pr, size_t total
     for (auto &t : th) t.join();
     for (int g = 0; g < lanes; ++g)
         if (rcs[g]) { set_error("%s", msgs[g].c_str()); return rcs[g]; }
+    return MIH_OK;
+}
+
+}  // extern "C"
+
+// Which rank evaluates which (fold, k) combination.  The fits of a rank advance in lock-step, so its time is set by how many
+// rounds its LONGEST fit needs and by how many fits ride each round; the iteration count of a fit depends mostly on its model
+// size k (5 to 17 at BASELINE configs[3], about the same in every fold).  `index mod world` in fold-major order hands a rank the
+// same two or three residues of k in every fold (20 = 4 mod 8): some ranks collect the slow model sizes of all folds.  Instead
+// the combinations are dealt out round-robin in the order (k descending, fold ascending): every rank gets a stratified sample
+// of the model sizes, 12 or 13 fits each at 100 / 8 ("round-robin by expected cost").  Every fit is independent of
+// the rank that runs it, so the losses do not depend on the rule.
+void mih::cv_assign(const int64_t *path, int64_t npath, int32_t nfolds, int32_t world, std::vector<int32_t> &rank_of)
+{
+    const int64_t total = (int64_t)nfolds * npath;
+    rank_of.assign((size_t)total, 0);
+    const char *e = probe_env("MENDELIHT_CV_ASSIGN");               // measurement build: 0 = round 2's fold-major `index mod world`
+    if (e && atoi(e) == 0) { for (int64_t i = 0; i < total; ++i) rank_of[(size_t)i] = (int32_t)(i % world); return; }
+    std::vector<int64_t> order((size_t)total);
+    for (int64_t i = 0; i < total; ++i) order[(size_t)i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) {
+        const int64_t ka = path[a % npath], kb = path[b % npath];
+        if (ka != kb) return ka > kb;
+        return a / npath < b / npath;
+    });
+    for (int64_t t = 0; t < total; ++t) rank_of[(size_t)order[(size_t)t]] = (int32_t)(t % world);
+}
+
+extern "C" {
+
+int mih_cv_assignment(const int64_t *path, int64_t npath, int32_t nfolds, int32_t world, int32_t *rank_of)
+{
+    if (!path || !rank_of || npath < 1 || nfolds < 1 || world < 1) { set_error("null/invalid argument"); return MIH_BAD_ARG; }
+    std::vector<int32_t> r;
+    cv_assign(path, npath, nfolds, world, r);
+    std::copy(r.begin(), r.end(), rank_of);
     return MIH_OK;
 }
 
@@ -1535,6 +1596,8 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, con
     for (int64_t i = 0; i < (int64_t)nfolds * npath; ++i) mses_raw[i] = 0.0;
     mih_fit_params pr = *prm;
     pr.k = kmax; pr.progress = nullptr;
+    std::vector<int32_t> rank_of;
+    cv_assign(path, npath, nfolds, world, rank_of);
 
     if (prm->est_r != MIH_ESTR_NONE || prm->init_beta || prm->debias) {
         // init_beta needs two extra passes per fit and debias a GLM refit (not batched yet); the NegBin nuisance parameter is carried from one fit to the next in the reference (v.d is
@@ -1545,7 +1608,7 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, con
         int64_t combo = 0;
         for (int32_t fold = 1; fold <= nfolds; ++fold)
             for (int64_t ik = 0; ik < npath; ++ik, ++combo) {
-                if (combo % world != rank) continue;
+                if (rank_of[(size_t)combo] != rank) continue;
                 for (int64_t i = 0; i < n; ++i) train[i] = (folds[i] != fold);
                 MIH_TRY(v.set_k(path[ik]));                  // cross_validation.jl:110
                 MIH_TRY(v.init(train.data()));
@@ -1565,7 +1628,7 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, con
     int64_t combo = 0;
     for (int32_t fold = 1; fold <= nfolds; ++fold)
         for (int64_t ik = 0; ik < npath; ++ik, ++combo)
-            if (combo % world == rank) mine.emplace_back(fold, ik);
+            if (rank_of[(size_t)combo] == rank) mine.emplace_back(fold, ik);
     if (mine.empty()) return MIH_OK;
     auto make = [&](size_t t, CvFit &f, hipStream_t s, const CvShared &sh) -> int {
         int32_t fold = mine[t].first; int64_t ik = mine[t].second;

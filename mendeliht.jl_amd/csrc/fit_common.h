@@ -43,7 +43,8 @@ static __global__ void k_final_sum(const double *__restrict__ partial, int nbloc
 }
 
 // k_final_sum that also brings results home (publish_block): `words` doubles from pub_src, which may contain `out`
-static __global__ void k_final_sum_pub(const double *__restrict__ partial, int nblocks, int nv, double *__restrict__ out,
+// (so `out` is not restrict-qualified: the publishing loads must see the sums stored above)
+static __global__ void k_final_sum_pub(const double *__restrict__ partial, int nblocks, int nv, double *out,
                                        const double *pub_src, double *pub_dst_host, uint64_t words, uint64_t *flag_host, uint64_t seq)
 {
     __shared__ double red[256];

@@ -276,6 +276,7 @@ struct MvVar {
     std::vector<uint8_t> zkeep; int64_t zkeepn = 0;      // r * sum(zkeep)
     const double *Y_host = nullptr, *Z_host = nullptr;
     int init_beta = 0;
+    XtvTune tune;
     hipStream_t s = nullptr;
     DevBuf<double> Y, Z, w, BX, MU, RES, T1, DF, full, red, scal, gval, tmpn;
     DevBuf<int64_t> sidx; DevBuf<double> sval; DevBuf<uint8_t> mask; DevBuf<int32_t> pairs;
@@ -320,7 +321,7 @@ struct MvVar {
     int create(const mih_mat *hh, const mih_fit_params *prm, const double *Yh, int64_t rr, const double *Zh, int64_t qq,
                hipStream_t shared_stream = nullptr)
     {
-        h = hh; n = h->n; p = h->p; r = (int)rr; q = (int)qq; k = prm->k; Y_host = Yh; Z_host = Zh; init_beta = prm->init_beta;
+        h = hh; n = h->n; p = h->p; r = (int)rr; q = (int)qq; k = prm->k; Y_host = Yh; Z_host = Zh; init_beta = prm->init_beta; tune = xtv_tune(prm);
         if (r < 1 || r > kMaxR) { set_error("number of traits r=%d must be in 1..%d", r, kMaxR); return MIH_BAD_DIM; }
         if (q < 1 || r * q > kMaxRQ) { set_error("r*q = %d exceeds %d", r * q, kMaxRQ); return MIH_BAD_DIM; }
         zkeep.resize(q); int64_t zs = 0;
@@ -345,7 +346,7 @@ struct MvVar {
         MIH_TRY(red.alloc(std::max<size_t>((size_t)nb, (size_t)kMaxR * kMaxR * kRedBlocks))); MIH_TRY(scal.alloc((size_t)kMaxR * kMaxR + 64));
         MIH_TRY(tmpn.alloc(n)); MIH_TRY(mask.alloc(n)); MIH_TRY(pairs.alloc(2 * (size_t)kMaxR * kMaxR));
         MIH_TRY(sidx.alloc(kcap)); MIH_TRY(sval.alloc(kcap)); MIH_TRY(gval.alloc((size_t)kcap * r));
-        if (own_stream) { ArenaScope own_buffers(nullptr); MIH_TRY(xtv_work_init(h, xtv, r)); }
+        if (own_stream) { ArenaScope own_buffers(nullptr); MIH_TRY(xtv_work_init(h, xtv, r, tune)); }
         MIH_TRY(xv_work_init(h, xv, kcap, kcap - 1024)); MIH_TRY(topk_work_init(topk, kcap));
         // Y (r x n) and Z (q x n) column-major -> planes
         std::vector<double> pl(std::max(rn, (size_t)q * n));
@@ -567,7 +568,7 @@ struct MvVar {
         const double N = (double)nsamples;
         std::vector<double> Sy(r, 0.0), c0sum(r, 0.0);
         for (int64_t j = 0; j < n; ++j) if (!train || train[j]) for (int i = 0; i < r; ++i) Sy[i] += Y_host[i + (size_t)r * j];
-        MIH_TRY(init_beta_regress_device(h, w.p, Y.p, r, N, Sy.data(), betad.p, c0sum.data(), red, scal, s));
+        MIH_TRY(init_beta_regress_device(h, w.p, Y.p, r, N, Sy.data(), betad.p, c0sum.data(), red, scal, s, tune));
         for (int l = 1; l < q; ++l) {             // non-genetic covariates 2..q on the host (:547-553)
             double sx = 0.0, sxx = 0.0;
             std::vector<double> sxy(r, 0.0);
@@ -814,24 +815,28 @@ int mih_cv_mv(const mih_mat *h, const mih_fit_params *prm, const double *Y, int6
     // this rank's combinations, fold-major (cross_validation.jl:217-223), advanced in lock-step batches: every
     // round issues ONE fused X'R pass for the r traits of every fit that needs a score (as mih_cv_iht does)
     std::vector<std::pair<int32_t, int64_t>> mine;
+    std::vector<int32_t> rank_of;
+    cv_assign(path, npath, nfolds, world, rank_of);          // the same sharding rule as mih_cv_iht (fit.hip)
     int64_t combo = 0;
     for (int32_t fold = 1; fold <= nfolds; ++fold)
         for (int64_t ik = 0; ik < npath; ++ik, ++combo)
-            if (combo % world == rank) mine.emplace_back(fold, ik);
+            if (rank_of[(size_t)combo] == rank) mine.emplace_back(fold, ik);
     if (mine.empty()) return MIH_OK;
     const int rr = (int)r;
-    const int per_batch = std::max(1, xtv_lockstep_width(h) / rr);
+    const XtvTune tune = xtv_tune(prm);
+    const int per_batch = std::max(1, xtv_lockstep_width(h, tune) / rr);
     const int mb = (int)std::min<size_t>(mine.size(), (size_t)per_batch);
     hipStream_t s = nullptr;
     MIH_HIP(hipStreamCreate(&s));
     struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{s};
     XtvWork xw; DevBuf<double> R, DF;
-    MIH_TRY(xtv_work_init(h, xw, mb * rr));
+    MIH_TRY(xtv_work_init(h, xw, mb * rr, tune));
+    xw.stream_tag = 1;
     MIH_TRY(R.alloc((size_t)mb * rr * n));
     // as in cv_run_rolling (fit.hip): the fits of a fold start from the same residuals (initial score before k plays a role,
     // multivariate.jl:376-452) -- one fit per fold rides the pass, its r x p block of X'R is kept behind the pass's outputs;
     // finished fits hand their mIHTVariable (sized for max(path)) to the fits started next
-    const bool share_init = !prm->init_beta && getenv("MENDELIHT_CV_NO_INIT_SHARE") == nullptr;
+    const bool share_init = !prm->init_beta && probe_env("MENDELIHT_CV_NO_INIT_SHARE") == nullptr;
     const int init_slots = share_init ? (int)std::min<int64_t>(nfolds, 8) : 0;
     MIH_TRY(DF.alloc((size_t)(mb + init_slots) * rr * h->p));
     std::map<int, double *> df0;

@@ -392,15 +392,24 @@ static int select_device(int device)
 // A large matrix reserves the device memory its fits will work in (DevPool, common.h): about what a cross-validation asks for
 // -- four fused-pass workspaces and 64 IHTVariable blocks, 15.7 GB beside a 125 GB matrix.  Whatever the driver has to do to
 // hand out never-used VRAM (one stall of ~2.9 s was measured) it does here, when the matrix is created, and no fit ever calls
-// hipMalloc / hipFree.  MENDELIHT_NO_RESERVE=1: no reserve (every buffer from hipMalloc).
+// hipMalloc / hipFree.  Memory policy knobs (environment, read once): MENDELIHT_NO_RESERVE=1 -- no reserve (every buffer from
+// hipMalloc); MENDELIHT_RESERVE_MIN_BYTES=<bytes> -- the smallest 2-bit matrix that gets a reserve (default 4 GiB; the test
+// suite sets 0 so that its small matrices exercise the pool, the arenas and the lock-step hand-over exactly as a 125 GB
+// matrix does -- ADVICE r2).  The reserve of a small matrix is sized from its dimensions.
 static void reserve_fit_memory(mih_mat *h)
 {
     static const bool off = getenv("MENDELIHT_NO_RESERVE") != nullptr;
+    static const size_t min_bytes = [] { const char *e = getenv("MENDELIHT_RESERVE_MIN_BYTES"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)(4ull << 30); }();
     const size_t x_bytes = (size_t)h->ncg * (size_t)h->nbp * 1024;
-    if (off || h->kind != 0 || x_bytes < (4ull << 30)) return;
+    if (off || h->kind != 0 || x_bytes < min_bytes) return;
     size_t big = (size_t)1920 * (size_t)h->p;                    // the row-slice partials of a 15-residual pass
-    big = std::min<size_t>(std::max<size_t>(big, 256ull << 20), 4ull << 30);
-    const size_t want = 4 * big + 64 * (128ull << 20);
+    size_t var = 128ull << 20;                                   // one IHTVariable block at n = 500k, p = 1M
+    if (x_bytes >= (4ull << 30)) big = std::min<size_t>(std::max<size_t>(big, 256ull << 20), 4ull << 30);
+    else {                                                       // a small matrix: the same structure at its own scale
+        big = std::max<size_t>(big + (size_t)30 * 8 * (size_t)h->n_pad, 4ull << 20);
+        var = std::min<size_t>(var, std::max<size_t>((size_t)8 * (40 * (size_t)h->n_pad + 6 * (size_t)h->p) + (2ull << 20), 4ull << 20));
+    }
+    const size_t want = 4 * big + 64 * var;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return; }
     if (free_b < 4 * want) return;                               // not on a crowded device

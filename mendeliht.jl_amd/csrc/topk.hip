@@ -216,7 +216,7 @@ k_publish(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst_host, uin
 
 static bool spin_on()
 {
-    static const bool on = [] { const char *e = getenv("MENDELIHT_NO_SPIN"); return !(e && atoi(e) != 0); }();
+    static const bool on = [] { const char *e = probe_env("MENDELIHT_NO_SPIN"); return !(e && atoi(e) != 0); }();
     return on;
 }
 uint64_t spin_begin(SpinFlag &f)
@@ -279,7 +279,7 @@ int topk_work_init(TopkWork &w, int64_t max_keep)
 {
     MIH_TRY(w.hist.alloc(kBins11));
     MIH_HIP(hipMemset(w.hist.p, 0, kBins11 * sizeof(uint32_t)));  // the pick kernels leave the histogram zeroed after every pass
-    if (const char *e = getenv("MENDELIHT_TOPK_RADIX8")) w.radix8 = atoi(e) != 0;
+    if (const char *e = probe_env("MENDELIHT_TOPK_RADIX8")) w.radix8 = atoi(e) != 0;
     MIH_TRY(w.state.alloc(4));
     w.expect = max_keep + 64;
     w.cap = max_keep + 1024;

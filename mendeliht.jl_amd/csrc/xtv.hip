@@ -49,28 +49,42 @@
 
 namespace mih {
 
-int g_xtv_variant = -1;   // -1: built-in default
-
-// ---- optional per-launch HIP-event timing of the dominant kernel (bench.py roofline) ----
-static bool g_profile = false;
-static std::mutex g_prof_mu;
-static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_events;
-static double g_prof_ms = 0.0;
-static int64_t g_prof_launches = 0;
-
-static void prof_begin(hipStream_t s, hipEvent_t &e0, hipEvent_t &e1)
+// ---- per-launch HIP-event timing of the dominant kernel, on the matrix handle (mih_profile_*; bench.py roofline) ----
+static bool prof_begin(const mih_mat *h, hipStream_t s, PassRecord &rec)
 {
-    e0 = e1 = nullptr;
-    if (!g_profile) return;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }
-    (void)hipEventRecord(e0, s);
+    Profile &pf = *h->prof;
+    if (!pf.on) return false;
+    if (hipEventCreate(&rec.e0) != hipSuccess || hipEventCreate(&rec.e1) != hipSuccess) { rec.e0 = rec.e1 = nullptr; (void)hipGetLastError(); return false; }
+    (void)hipEventRecord(rec.e0, s);
+    return true;
 }
-static void prof_end(hipStream_t s, hipEvent_t e0, hipEvent_t e1)
+static void prof_end(const mih_mat *h, hipStream_t s, PassRecord &rec)
 {
-    if (!e0) return;
-    (void)hipEventRecord(e1, s);
-    std::lock_guard<std::mutex> g(g_prof_mu);
-    g_prof_events.emplace_back(e0, e1);
+    (void)hipEventRecord(rec.e1, s);
+    Profile &pf = *h->prof;
+    std::lock_guard<std::mutex> g(pf.mu);
+    pf.open.push_back(rec);
+}
+void Profile::drain()
+{
+    for (auto &r : open) {
+        float ms = 0.f, st = 0.f;
+        mih_pass_record out;
+        memset(&out, 0, sizeof(out));
+        if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+            if (origin && hipEventElapsedTime(&st, origin, r.e0) != hipSuccess) { st = 0.f; (void)hipGetLastError(); }
+            out.start_ms = st; out.ms = ms; out.residuals = r.residuals; out.operands = r.operands; out.stream_tag = r.stream_tag;
+            memcpy(out.kernel, r.kernel, sizeof(out.kernel));
+            done.push_back(out);
+        } else (void)hipGetLastError();
+        (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
+    }
+    open.clear();
+}
+Profile::~Profile()
+{
+    for (auto &r : open) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    if (origin) (void)hipEventDestroy(origin);
 }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1233,182 +1247,10 @@ static void launch_dense_lds(const T *D, const mih_mat *h, const double *r_dev, 
         hipLaunchKernelGGL((k_xtv_dense_lds<T, 1>), grid, block, 0, s, D, h->n, h->p, r_dev + (int64_t)v * h->n, out_dev + (int64_t)v * h->p);
 }
 
-struct Variant { int waves, ct, splits; };
-static const Variant kVariants[] = {
-    {4, 2, 8},    // 0
-    {4, 1, 8},    // 1
-    {4, 4, 8},    // 2: default
-    {8, 2, 8},    // 3
-    {8, 1, 8},    // 4
-    {4, 2, 1},    // 5: no row slicing
-    {4, 1, 1},    // 6
-    {4, 4, 1},    // 7
-    {4, 2, 16},   // 8
-    {2, 2, 8},    // 9
-    {8, 4, 8},    // 10
-    {4, 4, 4},    // 11
-    {4, 4, 16},   // 12
-    {4, 8, 8},    // 13
-    {2, 4, 8},    // 14
-    {8, 4, 16},   // 15
-};
-constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
-constexpr int kDefaultVariant = 2;
 constexpr int kMaxSplits = 16;
-int g_xtv_max_nr = 4;     // right-hand sides fused per pass (1, 2 or 4); 4 = LDS-shared digit planes
-// B operands per pass of the 16x16x128 ring kernel: 5 operands = 15 residuals (224 VGPRs, 155 KB of LDS at D = 4); 6 fit as well
-// (254 VGPRs, D = 3).  More residuals per pass amortise the genotype stream, the dosage staging and the barriers.
-static int fused_ops16()
-{
-    static const int v = []() { const char *e = getenv("MENDELIHT_XTV_MAX_OPS"); int x = e ? atoi(e) : 5; return x < 1 ? 1 : x > 6 ? 6 : x; }();
-    return v;
-}
-int g_xtv_multi_variant = 0;   // which 4-RHS kernel shape (tuning knob, mih_set_xtv_multi_variant)
-int xtv_num_variants() { return kNumVariants; }
-static bool xtv_variant_valid(int v) { return v < kNumVariants; }
-
-static Variant current_variant()
-{
-    int v = g_xtv_variant;
-    if (v < 0 || v >= kNumVariants) v = kDefaultVariant;
-    return kVariants[v];
-}
-
-template <int WAVES, int CT, int NR>
-static void launch_xtv(const mih_mat *h, const uint4 *dig, int64_t dig_stride, int splits, DigitMode dm, const double *scal,
-                       double *partial, hipStream_t s)
-{
-    int64_t groups = (h->ncg + WAVES * CT - 1) / (WAVES * CT);
-    hipLaunchKernelGGL((k_xtv_mfma<WAVES, CT, NR>), dim3((unsigned)(groups * splits)), dim3(WAVES * 64), 0, s,
-                       reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig_stride, splits, dm, scal, partial);
-}
-
-// nr B operands per pass: 1 = the tuned single-operand variants; 2 / 3 / 4 = fused passes (64 - 128 accumulator
-// registers).  Each operand carries per_op residual vectors.
-static int dispatch_xtv(const Variant &v, int nr, bool half, const mih_mat *h, const uint4 *dig, const uint2 *dig2, int64_t dig_stride,
-                        int splits, DigitMode dm, const double *scal, double *partial, hipStream_t s)
-{
-#define MIH_LDS6(NRV, ID, C, RB, W) if (nr == NRV && (mv6 == ID || ID < 0)) { \
-        int64_t groups = (h->ncg + W * C - 1) / (W * C); \
-        hipLaunchKernelGGL((k_xtv_mfma_lds<NRV, C, RB, 0, W, true>), dim3((unsigned)(groups * splits)), dim3(W * 64), 0, s, \
-                           reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig2, dig_stride, splits, dm, scal, partial); \
-        return MIH_OK; }
-#define MIH_DMA(NRV, ID, C, W, DD, F6, MODE) if (nr == NRV && (mv6 == ID || ID < 0)) { \
-        int64_t groups = (h->ncg + W * C - 1) / (W * C); \
-        hipLaunchKernelGGL((k_xtv_dma<NRV, C, W, DD, F6, MODE>), dim3((unsigned)(groups * splits)), dim3(W * 64), 0, s, \
-                           reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig2, dig_stride, splits, dm, scal, partial); \
-        return MIH_OK; }
-    const int mv6 = g_xtv_multi_variant;
-#define MIH_DMA16(NRV, ID, C, W, DD) MIH_DMA16M(NRV, ID, C, W, DD, 0, 0)
-#define MIH_DMA16H(NRV, C, W, DD) if (half) MIH_DMA16M(NRV, -1, C, W, DD, 0, 1)
-#define MIH_DMA16M(NRV, ID, C, W, DD, MODE, HF) if (nr == NRV && (mv6 == ID || ID < 0)) { \
-        int64_t groups = (h->ncg + W * C - 1) / (W * C); \
-        hipLaunchKernelGGL((k_xtv_dma16<NRV, C, W, DD, MODE, HF>), dim3((unsigned)(groups * splits)), dim3(W * 64), 0, s, \
-                           reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig2, dig_stride, splits, dm, scal, partial); \
-        return MIH_OK; }
-    if (dm.base == 49 && dm.lay16) {      // FP6 planes in the 16-column layout: the 16x16x128 kernels only
-        // library defaults for every fused multi-RHS pass (12 residuals at n=500k, p=1M: 31.5 ms against 34.3 ms for the
-        // 32x32x64 ring kernel, 36.2 ms for one wave per SIMD <4,4,4,4> here -- 64 MFMAs a step are issue-bound there -- and
-        // 40.0 ms register-staged; tools/sweep_dma.py)
-        MIH_DMA16(4, 40, 4, 4, 4) MIH_DMA16(3, 40, 4, 4, 4) MIH_DMA16(2, 40, 4, 4, 4) MIH_DMA16(1, 40, 4, 4, 4)
-        MIH_DMA16(4, 42, 2, 8, 3) MIH_DMA16(4, 43, 2, 8, 2)
-        MIH_DMA16M(1, 49, 2, 8, 4, 3, 0) MIH_DMA16M(4, 49, 2, 8, 4, 3, 0)       // timing probes
-        MIH_DMA16(1, 44, 2, 4, 8) MIH_DMA16(1, 45, 1, 8, 6) MIH_DMA16(1, 46, 2, 4, 6) MIH_DMA16(1, 47, 4, 4, 4) MIH_DMA16(1, 48, 2, 8, 6)
-        // the last operand of the pass carries residuals in its first 16 columns only: 2 nr - 1 fragments
-        MIH_DMA16H(6, 2, 8, 3) MIH_DMA16H(5, 2, 8, 4) MIH_DMA16H(4, 2, 8, 4) MIH_DMA16H(3, 2, 8, 4) MIH_DMA16H(2, 2, 8, 4) MIH_DMA16H(1, 2, 8, 4)
-        MIH_DMA16(6, -1, 2, 8, 3) MIH_DMA16(5, -1, 2, 8, 4)
-        MIH_DMA16(4, -1, 2, 8, 4) MIH_DMA16(3, -1, 2, 8, 4) MIH_DMA16(2, -1, 2, 8, 4) MIH_DMA16(1, -1, 2, 8, 4)
-    }
-#undef MIH_DMA16
-#undef MIH_DMA16H
-#undef MIH_DMA16M
-    if (dm.base == 49) {           // FP6 digit planes
-        // LDS-DMA ring kernels: tuning shapes (ids 20..), timing probes (30..: results are NOT X'R), then the defaults
-        MIH_DMA(4, 20, 4, 4, 4, true, 0) MIH_DMA(4, 21, 4, 4, 3, true, 0) MIH_DMA(4, 22, 2, 8, 4, true, 0) MIH_DMA(4, 23, 2, 8, 3, true, 0)
-        MIH_DMA(4, 24, 4, 4, 2, true, 0) MIH_DMA(4, 25, 2, 8, 2, true, 0)
-        MIH_DMA(4, 30, 4, 4, 4, true, 1) MIH_DMA(4, 31, 4, 4, 4, true, 2) MIH_DMA(4, 32, 2, 8, 4, true, 1) MIH_DMA(4, 33, 2, 8, 4, true, 2)
-        MIH_DMA(3, 20, 4, 4, 4, true, 0) MIH_DMA(3, 22, 2, 8, 4, true, 0) MIH_DMA(2, 20, 4, 4, 4, true, 0) MIH_DMA(2, 22, 2, 8, 4, true, 0)
-        MIH_DMA(1, 20, 4, 4, 4, true, 0) MIH_DMA(1, 22, 2, 8, 4, true, 0) MIH_DMA(1, 26, 1, 8, 4, true, 0) MIH_DMA(1, 27, 1, 16, 4, true, 0)
-        if (mv6 >= 16) {      // the 32x32x64 ring shapes of other operand counts (ids 1..15 select the register-staged LDS shapes below)
-            MIH_DMA(4, -1, 4, 4, 4, true, 0) MIH_DMA(3, -1, 4, 4, 4, true, 0) MIH_DMA(2, -1, 2, 8, 4, true, 0) MIH_DMA(1, -1, 2, 8, 4, true, 0)
-        }
-        MIH_LDS6(4, 1, 2, 2, 8) MIH_LDS6(4, 2, 1, 4, 8) MIH_LDS6(4, 3, 2, 2, 4) MIH_LDS6(4, 4, 2, 1, 4) MIH_LDS6(4, 5, 1, 2, 8)
-        MIH_LDS6(1, 10, 1, 2, 8) MIH_LDS6(1, 11, 2, 4, 8) MIH_LDS6(1, 12, 2, 2, 8) MIH_LDS6(1, 13, 4, 2, 8) MIH_LDS6(1, 14, 1, 4, 16) MIH_LDS6(1, 15, 2, 2, 16)
-        // defaults (2 operands: <2,4,1,4> 22.5 ms against 23.3-26 ms for five other shapes; 3 operands: <3,2,2,4> 33.2 ms
-        // against 34.5 ms for <3,2,2,8>; 4 operands: <4,2,1,8> 39.4 ms against 40.6 ms for <4,2,2,8>, same box)
-        MIH_LDS6(1, -1, 1, 4, 8) MIH_LDS6(2, -1, 4, 1, 4) MIH_LDS6(3, -1, 2, 2, 4) MIH_LDS6(4, -1, 2, 1, 8)
-        set_error("unsupported operand count");
-        return MIH_BAD_ARG;
-    }
-#undef MIH_LDS6
-#define MIH_LDS(NRV, ID, C, RB, MODE, W) if (nr == NRV && mv == ID) { \
-        int64_t groups = (h->ncg + W * C - 1) / (W * C); \
-        hipLaunchKernelGGL((k_xtv_mfma_lds<NRV, C, RB, MODE, W>), dim3((unsigned)(groups * splits)), dim3(W * 64), 0, s, \
-                           reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig2, dig_stride, splits, dm, scal, partial); \
-        return MIH_OK; }
-    // FP4 digit planes through the LDS-DMA ring (tuning shapes; the register-staged kernels stay the defaults here)
-    MIH_DMA(4, 20, 4, 4, 4, false, 0) MIH_DMA(4, 22, 2, 8, 4, false, 0) MIH_DMA(3, 20, 4, 4, 4, false, 0) MIH_DMA(2, 20, 4, 4, 4, false, 0)
-    MIH_DMA(2, 22, 2, 8, 4, false, 0)
-    if (g_xtv_variant < 0) {
-        MIH_DMA(1, 20, 1, 8, 6, false, 0) MIH_DMA(1, 21, 2, 8, 4, false, 0) MIH_DMA(1, 22, 1, 16, 6, false, 0) MIH_DMA(1, 23, 2, 4, 8, false, 0)
-        MIH_DMA(1, 24, 4, 4, 4, false, 0) MIH_DMA(1, 25, 1, 8, 3, false, 0) MIH_DMA(1, 26, 2, 8, 6, false, 0) MIH_DMA(1, 27, 1, 8, 8, false, 0)
-        MIH_DMA(1, 28, 2, 4, 12, false, 0) MIH_DMA(1, 29, 4, 4, 6, false, 0) MIH_DMA(1, 34, 2, 4, 6, false, 0) MIH_DMA(1, 35, 2, 2, 8, false, 0)
-        // library default for one FP4 operand (the single-fit pass): 17.60 ms = 88.8 % of the HBM peak against 17.85 ms for the
-        // register-staged <1,1,4> (id 9) and 17.65 - 17.9 ms for the other ring shapes (tools/sweep_dma.py single)
-        if (mv6 == 0 || mv6 >= 16) { MIH_DMA(1, -1, 2, 4, 8, false, 0) }
-    }
-    if (nr == 3) { const int mv = 0; MIH_LDS(3, 0, 2, 2, 0, 8) }
-    if (nr == 4 || nr == 2) {
-        const int mv = g_xtv_multi_variant;
-        MIH_LDS(4, 0, 2, 2, 0, 8)      // defaults
-        MIH_LDS(2, 0, 4, 1, 0, 4)
-        MIH_LDS(4, 1, 2, 1, 0, 8) MIH_LDS(4, 2, 2, 3, 0, 8) MIH_LDS(4, 3, 2, 4, 0, 8) MIH_LDS(4, 4, 1, 4, 0, 8)
-        MIH_LDS(4, 5, 2, 1, 0, 4) MIH_LDS(4, 6, 2, 2, 0, 4)
-        MIH_LDS(4, 7, 2, 2, 1, 8) MIH_LDS(4, 8, 2, 2, 2, 8)      // timing probes (results are NOT X'r)
-        MIH_LDS(2, 1, 2, 2, 0, 8) MIH_LDS(2, 2, 4, 2, 0, 8) MIH_LDS(2, 3, 2, 4, 0, 8) MIH_LDS(2, 4, 4, 1, 0, 8)
-        if (nr == 2 && mv == 5) { launch_xtv<4, 2, 2>(h, dig, dig_stride, splits, dm, scal, partial, s); return MIH_OK; }   // per-wave digit loads
-        if (nr == 2) { MIH_LDS(2, mv, 4, 1, 0, 4) }            // ids that exist for other operand counts only: the default shapes
-        { MIH_LDS(4, mv, 2, 2, 0, 8) }
-    }
-    if (nr == 1 && g_xtv_variant < 0) {
-        // library default for one operand: digit planes shared through LDS as well (17.86 ms against 18.47 ms for
-        // the per-wave-load kernels below at n=500k, p=1M; tools/sweep_single_lds.py).  An explicit
-        // mih_set_xtv_variant(v >= 0) selects the per-wave kernels instead.
-        const int mv = g_xtv_multi_variant;
-        MIH_LDS(1, 9, 1, 4, 0, 8)
-        MIH_LDS(1, 10, 1, 2, 0, 8) MIH_LDS(1, 11, 1, 6, 0, 8) MIH_LDS(1, 12, 1, 2, 0, 16) MIH_LDS(1, 13, 2, 4, 0, 8) MIH_LDS(1, 14, 4, 2, 0, 8)
-        MIH_LDS(1, 15, 1, 4, 1, 8)                        // timing probe: loads only, no MFMAs (result is NOT X'r)
-        { MIH_LDS(1, mv, 1, 4, 0, 8) }                    // multi-operand variant ids fall back to the default shape
-    }
-#undef MIH_LDS
-#undef MIH_DMA
-#define MIH_CASE(W, C) if (v.waves == W && v.ct == C) { launch_xtv<W, C, 1>(h, dig, dig_stride, splits, dm, scal, partial, s); return MIH_OK; }
-    MIH_CASE(4, 1) MIH_CASE(4, 2) MIH_CASE(4, 4) MIH_CASE(8, 1) MIH_CASE(8, 2) MIH_CASE(2, 2) MIH_CASE(8, 4) MIH_CASE(4, 8) MIH_CASE(2, 4)
-#undef MIH_CASE
-    set_error("unknown X'r kernel variant");
-    return MIH_BAD_ARG;
-}
-
 constexpr int kStatBlocks = 64;
 
-// Row slices of the library-default kernels.  A slice should hold about 50 000 rows or more -- every (column group,
-// slice) work item pays a prologue and a 16-accumulator epilogue, and short items lose to that: at n = 50 000 one
-// slice runs at 87 % of the HBM peak and eight at 75 %, at n = 10 000 it is 74 % against 38 % -- but there must be
-// enough workgroups to fill 256 CUs, and at n = 500 000 eight slices (one per XCD, sharing that slice of the digit
-// planes in its L2) are best (87.0 % against 83.3 % for one).
-static int auto_splits(const mih_mat *h)
-{
-    if (const char *e = getenv("MENDELIHT_XTV_SLICES")) { int v = atoi(e); if (v >= 1 && v <= kMaxSplits) return v; }   // tuning override
-    int s = 1;
-    while (s < 8 && h->n >= 100000ll * s) s *= 2;
-    const int64_t groups = (h->ncg + 15) / 16;                 // workgroups per slice of the widest launch shape
-    while (s < 16 && groups * s < 2048 && h->nbp / (2 * s) >= 8) s *= 2;
-    return s;
-}
-
-// mih_set_xtv_digits (residual format ids = base * 100 + digits, see include/mendeliht_hip.h); 0 = library default
-int g_xtv_digits = 0;
-
+// mih_fit_params::xtv_digits / the digits argument of mih_xtv_batched_fmt (ids = base * 100 + digits, include/mendeliht_hip.h)
 static bool digit_mode(int id, DigitMode &dm)
 {
     switch (id) {
@@ -1421,52 +1263,123 @@ static bool digit_mode(int id, DigitMode &dm)
     }
     return false;
 }
+bool xtv_digits_valid(int digits) { DigitMode dm; return digit_mode(digits, dm); }
 
-static void choose_mode(const mih_mat *h, bool batched, DigitMode &dm);
-// FP6 digit planes are written in the 16-column layout when the pass runs on the 16x16x128 kernels (ids 40..)
-static bool xtv_half_ok()       // MENDELIHT_XTV_NO_HALF=1: always multiply whole operands (A/B timing; same results)
+#ifdef MIH_PROBES
+#include "xtv_probes.inc"       // launch-shape sweeps, round-1 kernel families, timing probes: measurement build only
+#else
+XtvTune xtv_tune(int digits) { XtvTune t; t.digits = digits; return t; }
+static int dispatch_probe(const XtvTune &, int, bool, const mih_mat *, const uint4 *, const uint2 *, int64_t, int, DigitMode,
+                          const double *, double *, hipStream_t, char *) { return -1; }
+static int probe_splits(const XtvTune &) { return 0; }
+#endif
+
+// nr B operands per pass, each carrying per_op residuals.  The release library has ONE kernel per (format family, operand
+// count):
+//   FP6 planes (4910 / 4908):  k_xtv_dma16<nr,2,8,D,0,half>  -- the 16x16x128 LDS-DMA ring (12 residuals at n=500k, p=1M:
+//                              28.5 ms against 34.3 ms for the 32x32x64 ring kernel and 40.0 ms register-staged)
+//   FP4 planes, one operand:   k_xtv_dma<1,2,4,8,fp4>         -- the single-fit pass (17.6 ms = 88.8 % of the HBM peak)
+//   FP4 planes, 2-4 operands:  k_xtv_mfma_lds<nr,..>          -- register-staged; only matrices too tall for FP6 slices
+//                                                                (> 2^22 rows) or an explicit 1316 / 1308 / 428 get here
+// `name` receives the dispatched kernel's name (profile records).
+static int dispatch_xtv(const XtvTune &tn, int nr, bool half, const mih_mat *h, const uint4 *dig, const uint2 *dig2, int64_t dig_stride,
+                        int splits, DigitMode dm, const double *scal, double *partial, hipStream_t s, char *name)
 {
-    static const bool ok = [] { const char *e = getenv("MENDELIHT_XTV_NO_HALF"); return !(e && atoi(e) != 0); }();
-    return ok;
-}
-static bool xtv_lay16(const DigitMode &dm)
-{
-    return dm.base == 49 && g_xtv_variant < 0 && (g_xtv_multi_variant == 0 || (g_xtv_multi_variant >= 40 && g_xtv_multi_variant < 50));
+    {
+        const int rc = dispatch_probe(tn, nr, half, h, dig, dig2, dig_stride, splits, dm, scal, partial, s, name);
+        if (rc >= 0) return rc;
+    }
+#define MIH_DMA16(NRV, C, W, DD, HF) if (nr == NRV && (int)half == HF) { \
+        int64_t groups = (h->ncg + W * C - 1) / (W * C); \
+        hipLaunchKernelGGL((k_xtv_dma16<NRV, C, W, DD, 0, HF>), dim3((unsigned)(groups * splits)), dim3(W * 64), 0, s, \
+                           reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig2, dig_stride, splits, dm, scal, partial); \
+        snprintf(name, 48, "k_xtv_dma16<%d,%d,%d,%d%s>", NRV, C, W, DD, HF ? ",half" : ""); \
+        return MIH_OK; }
+    if (dm.base == 49) {
+        if (!dm.lay16) { set_error("FP6 digit planes need the 16-column layout"); return MIH_BAD_ARG; }
+        // 5 operands = 15 residuals: 224 VGPRs, 155 KB of LDS at D = 4; 6 fit as well (254 VGPRs, D = 3: measurement build)
+        MIH_DMA16(6, 2, 8, 3, 1) MIH_DMA16(5, 2, 8, 4, 1) MIH_DMA16(4, 2, 8, 4, 1) MIH_DMA16(3, 2, 8, 4, 1) MIH_DMA16(2, 2, 8, 4, 1) MIH_DMA16(1, 2, 8, 4, 1)
+        MIH_DMA16(6, 2, 8, 3, 0) MIH_DMA16(5, 2, 8, 4, 0) MIH_DMA16(4, 2, 8, 4, 0) MIH_DMA16(3, 2, 8, 4, 0) MIH_DMA16(2, 2, 8, 4, 0) MIH_DMA16(1, 2, 8, 4, 0)
+        set_error("unsupported operand count %d", nr);
+        return MIH_BAD_ARG;
+    }
+#undef MIH_DMA16
+    if (nr == 1) {
+        int64_t groups = (h->ncg + 4 * 2 - 1) / (4 * 2);
+        hipLaunchKernelGGL((k_xtv_dma<1, 2, 4, 8, false, 0>), dim3((unsigned)(groups * splits)), dim3(4 * 64), 0, s,
+                           reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig2, dig_stride, splits, dm, scal, partial);
+        snprintf(name, 48, "k_xtv_dma<1,2,4,8,fp4>");
+        return MIH_OK;
+    }
+#define MIH_LDS(NRV, C, RB, W) if (nr == NRV) { \
+        int64_t groups = (h->ncg + W * C - 1) / (W * C); \
+        hipLaunchKernelGGL((k_xtv_mfma_lds<NRV, C, RB, 0, W>), dim3((unsigned)(groups * splits)), dim3(W * 64), 0, s, \
+                           reinterpret_cast<const uint4 *>(h->X), h->nbp, h->ncg, dig, dig2, dig_stride, splits, dm, scal, partial); \
+        snprintf(name, 48, "k_xtv_mfma_lds<%d,%d,%d,%d,fp4>", NRV, C, RB, W); \
+        return MIH_OK; }
+    MIH_LDS(4, 2, 2, 8) MIH_LDS(3, 2, 2, 8) MIH_LDS(2, 4, 1, 4)
+#undef MIH_LDS
+    set_error("unsupported operand count %d", nr);
+    return MIH_BAD_ARG;
 }
 
-int xtv_lockstep_width(const mih_mat *h)
+// Row slices of the library-default kernels.  A slice should hold about 50 000 rows or more -- every (column group,
+// slice) work item pays a prologue and a 16-accumulator epilogue, and short items lose to that: at n = 50 000 one
+// slice runs at 87 % of the HBM peak and eight at 75 %, at n = 10 000 it is 74 % against 38 % -- but there must be
+// enough workgroups to fill 256 CUs, and at n = 500 000 eight slices (one per XCD, sharing that slice of the digit
+// planes in its L2) are best (87.0 % against 83.3 % for one).
+static int auto_splits(const mih_mat *h, const XtvTune &tn)
 {
-    if (h->kind != 0) return 16;
-    DigitMode dm;
-    choose_mode(h, true, dm);
-    if (xtv_lay16(dm)) return 2 * fused_ops16() * dm.per_op;       // two lanes of one full pass each
-    return 8 * dm.per_op;
+    if (tn.slices >= 1 && tn.slices <= kMaxSplits) return tn.slices;       // measurement build only
+    int s = 1;
+    while (s < 8 && h->n >= 100000ll * s) s *= 2;
+    const int64_t groups = (h->ncg + 15) / 16;                 // workgroups per slice of the widest launch shape
+    while (s < 16 && groups * s < 2048 && h->nbp / (2 * s) >= 8) s *= 2;
+    return s;
 }
 
-static void choose_mode(const mih_mat *h, bool batched, DigitMode &dm)
+// FP6 digit planes are written in the 16-column layout when the pass runs on the 16x16x128 kernels (always, in the release
+// library; the measurement build also has 32x32x64 shapes)
+static bool xtv_lay16(const DigitMode &dm, const XtvTune &tn)
 {
-    digit_mode(g_xtv_digits, dm);
-    if (g_xtv_digits == 0) {
+    return dm.base == 49 && tn.variant < 0 && (tn.multi_variant == 0 || (tn.multi_variant >= 40 && tn.multi_variant < 50));
+}
+
+static void choose_mode(const mih_mat *h, const XtvTune &tn, bool batched, DigitMode &dm)
+{
+    digit_mode(tn.digits, dm);
+    if (tn.digits == 0) {
         // Library default.  The workspace of a single fit scores one residual per pass: 28 sparse base-4 digit
         // columns make the fastest single-operand pass (17.86 ms against 17.99 ms for 16 base-13 columns and
         // 18.4 ms for FP6 planes at n=500k, p=1M; tools/sweep_fp6_single.py).  Every fused multi-RHS context
         // (cv_iht, model paths, multivariate fits, init_beta, mih_xtv_batched) uses the FP6 format whatever the
-        // number of residuals in a call, so results never depend on how residuals are batched.  The FP6 kernels
-        // exist for the LDS-shared launch shapes only, and larger digits mean shorter exact row slices (2^18 rows
-        // in base 49, 2^20 in base 13, 2^22 in base 4), so very tall matrices step down.
+        // number of residuals in a call, so results never depend on how residuals are batched.  Larger digits mean
+        // shorter exact row slices (2^18 rows in base 49, 2^20 in base 13, 2^22 in base 4), so very tall matrices
+        // step down.
         if (!batched) digit_mode(428, dm);
-        else if (g_xtv_variant >= 0 || h->n_pad > ((int64_t)kMaxSplits << dm.rows_log2)) digit_mode(1316, dm);
+        else if (tn.variant >= 0 || h->n_pad > ((int64_t)kMaxSplits << dm.rows_log2)) digit_mode(1316, dm);
         if (h->n_pad > ((int64_t)kMaxSplits << dm.rows_log2)) digit_mode(428, dm);
     }
 }
 
-int xtv_work_init(const mih_mat *h, XtvWork &w, int m, bool batched)
+int xtv_lockstep_width(const mih_mat *h, const XtvTune &tn)
 {
+    if (h->kind != 0) return 16;
+    DigitMode dm;
+    choose_mode(h, tn, true, dm);
+    if (xtv_lay16(dm, tn)) return 2 * tn.max_ops * dm.per_op;       // two lanes of one full pass each
+    return 8 * dm.per_op;
+}
+
+int xtv_work_init(const mih_mat *h, XtvWork &w, int m, const XtvTune &tune, bool batched)
+{
+    w.tune = tune;
     if (h->kind != 0) return MIH_OK;
+    if (!xtv_digits_valid(tune.digits)) { set_error("residual format must be 0 (default), 4910, 4908, 1316, 1308 or 428"); return MIH_BAD_ARG; }
     int64_t nblk = h->nbp * 2;
-    choose_mode(h, batched, w.dm);
-    if (w.dm.base == 49 && g_xtv_variant >= 0) {         // only an explicitly requested FP6 format can get here
-        set_error("the FP6 residual formats need the default kernel (mih_set_xtv_variant(-1))");
+    choose_mode(h, tune, batched, w.dm);
+    if (w.dm.base == 49 && tune.variant >= 0) {         // only an explicitly requested FP6 format can get here (measurement build)
+        set_error("the FP6 residual formats need the default kernel (variant -1)");
         return MIH_BAD_ARG;
     }
     const int ops = (m + w.dm.per_op - 1) / w.dm.per_op;
@@ -1488,31 +1401,38 @@ int xtv_work_init(const mih_mat *h, XtvWork &w, int m, bool batched)
 
 int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double *out_dev, hipStream_t s)
 {
+    const XtvTune &tn = w.tune;
     if (h->kind == 1) {
-        const bool lds_ok = g_xtv_variant < 0 && (((uintptr_t)(h->Df ? (const void *)h->Df : (const void *)h->D)) & 15) == 0
+        const bool lds_ok = tn.variant < 0 && (((uintptr_t)(h->Df ? (const void *)h->Df : (const void *)h->D)) & 15) == 0
                             && h->n % (h->Df ? 4 : 2) == 0;
+        PassRecord rec;
+        const bool prof = prof_begin(h, s, rec);
         if (lds_ok) {
             if (h->Df) launch_dense_lds<float>(h->Df, h, r_dev, m, out_dev, s);
             else launch_dense_lds<double>(h->D, h, r_dev, m, out_dev, s);
-            MIH_HIP(hipGetLastError());
-            return MIH_OK;
+        } else {
+            for (int v = 0; v < m; ++v) {
+                if (h->Df) hipLaunchKernelGGL(k_xtv_dense_f32, dim3((unsigned)((h->p + 3) / 4)), dim3(256), 0, s, h->Df, h->n, h->p,
+                                              r_dev + (int64_t)v * h->n, out_dev + (int64_t)v * h->p);
+                else hipLaunchKernelGGL(k_xtv_dense, dim3((unsigned)((h->p + 3) / 4)), dim3(256), 0, s, h->D, h->n, h->p,
+                                        r_dev + (int64_t)v * h->n, out_dev + (int64_t)v * h->p);
+            }
         }
-        for (int v = 0; v < m; ++v) {
-            if (h->Df) hipLaunchKernelGGL(k_xtv_dense_f32, dim3((unsigned)((h->p + 3) / 4)), dim3(256), 0, s, h->Df, h->n, h->p,
-                                          r_dev + (int64_t)v * h->n, out_dev + (int64_t)v * h->p);
-            else hipLaunchKernelGGL(k_xtv_dense, dim3((unsigned)((h->p + 3) / 4)), dim3(256), 0, s, h->D, h->n, h->p,
-                                    r_dev + (int64_t)v * h->n, out_dev + (int64_t)v * h->p);
+        if (prof) {
+            rec.residuals = m; rec.operands = m; rec.stream_tag = w.stream_tag;
+            snprintf(rec.kernel, sizeof(rec.kernel), "%s<%s>", lds_ok ? "k_xtv_dense_lds" : "k_xtv_dense", h->Df ? "f32" : "f64");
+            prof_end(h, s, rec);
         }
         MIH_HIP(hipGetLastError());
         return MIH_OK;
     }
     if (m > w.m_cap) { set_error("X'r workspace too small"); return MIH_BAD_ARG; }
-    Variant v = current_variant();
-    int splits = g_xtv_variant < 0 ? auto_splits(h) : v.splits;
+    int splits = probe_splits(tn);
+    if (splits <= 0) splits = auto_splits(h, tn);
     // exactness of the f32 accumulators: |g/2 * d/2| <= 1 (base 4) or 4 (base 13) in units of 1/4, so a row
     // slice may hold at most 2^22 / 2^20 rows
     DigitMode dm = w.dm;
-    dm.lay16 = xtv_lay16(dm);
+    dm.lay16 = xtv_lay16(dm, tn);
     const int64_t need = (h->n_pad + (1ll << dm.rows_log2) - 1) >> dm.rows_log2;
     if (need > w.splits_cap) { set_error("n = %lld rows needs more than %d row slices for exact accumulation", (long long)h->n, w.splits_cap); return MIH_BAD_DIM; }
     if (splits < need) splits = (int)need;
@@ -1528,23 +1448,28 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
     hipLaunchKernelGGL(k_digits, dim3((unsigned)((nblk + 3) / 4), (unsigned)(nops * per_op)), dim3(256), 0, s, r_dev, h->n, nblk, m, dm,
                        w.scal.p, dig_all, dig2_all);
     for (int t = 0; t < nops;) {          // t counts B operands
-        int nr = (nops - t >= 4 && nops - t != 5 && g_xtv_max_nr >= 4) ? 4 : ((nops - t == 3 || nops - t == 5) && g_xtv_max_nr >= 4) ? 3
-                 : (nops - t >= 2 && g_xtv_max_nr >= 2) ? 2 : 1;
-        if (dm.lay16 && g_xtv_max_nr >= 4) {          // up to fused_ops16() operands a pass, the remainder split evenly
-            const int rem = nops - t, mo = fused_ops16(), passes = (rem + mo - 1) / mo;
+        int nr = (nops - t >= 4 && nops - t != 5 && tn.max_nr >= 4) ? 4 : ((nops - t == 3 || nops - t == 5) && tn.max_nr >= 4) ? 3
+                 : (nops - t >= 2 && tn.max_nr >= 2) ? 2 : 1;
+        if (dm.lay16 && tn.max_nr >= 4) {          // up to max_ops operands a pass, the remainder split evenly
+            const int rem = nops - t, mo = tn.max_ops, passes = (rem + mo - 1) / mo;
             nr = (rem + passes - 1) / passes;
         }
         const int u0 = t * per_op;        // first residual of this pass
         double *partial = w.partial.p + (int64_t)u0 * splits * pstride;
         const uint4 *dig = dig_all + (int64_t)t * nblk * 64;
         const uint2 *dig2 = dig2_all + (int64_t)t * nblk * 64;
-        hipEvent_t e0, e1;
-        prof_begin(s, e0, e1);
+        PassRecord rec;
+        const bool prof = prof_begin(h, s, rec);
         const int u1 = std::min((t + nr) * per_op, m);
         // residuals in the pass's last operand; if they end within its first 16 columns the second fragment is left out
-        const bool half = dm.lay16 && xtv_half_ok() && (u1 - (t + nr - 1) * per_op) * dm.slots <= 16;
-        int rc = dispatch_xtv(v, nr, half, h, dig, dig2, nblk * 64, splits, dm, w.scal.p + 4 * u0, partial, s);
-        prof_end(s, e0, e1);
+        const bool half = dm.lay16 && tn.half && (u1 - (t + nr - 1) * per_op) * dm.slots <= 16;
+        char name[48] = {0};
+        int rc = dispatch_xtv(tn, nr, half, h, dig, dig2, nblk * 64, splits, dm, w.scal.p + 4 * u0, partial, s, name);
+        if (prof) {
+            rec.residuals = u1 - u0; rec.operands = nr; rec.stream_tag = w.stream_tag;
+            memcpy(rec.kernel, name, sizeof(rec.kernel));
+            prof_end(h, s, rec);
+        }
         if (rc) return rc;
         if (u1 > u0)
             hipLaunchKernelGGL(k_xtv_finalize, dim3((unsigned)((h->p + 255) / 256), (unsigned)(u1 - u0)), dim3(256), 0, s,
@@ -1563,49 +1488,53 @@ using namespace mih;
 
 extern "C" {
 
-int mih_profile_enable(int on)
+int mih_profile_enable(const mih_mat *h, int on)
 {
-    g_profile = on != 0;
-    return MIH_OK;
-}
-
-int mih_profile_read(double *xtv_kernel_ms, int64_t *xtv_launches, int reset)
-{
-    std::lock_guard<std::mutex> g(g_prof_mu);
-    for (auto &pr : g_prof_events) {
-        float ms = 0.f;
-        if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
-            g_prof_ms += ms; g_prof_launches++;
-        }
-        (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
+    if (!h) { set_error("null matrix handle"); return MIH_BAD_ARG; }
+    Profile &pf = *h->prof;
+    std::lock_guard<std::mutex> g(pf.mu);
+    if (on && !pf.on) {
+        MIH_HIP(hipSetDevice(h->device));
+        if (pf.origin) { (void)hipEventDestroy(pf.origin); pf.origin = nullptr; }
+        MIH_HIP(hipEventCreate(&pf.origin));
+        MIH_HIP(hipEventRecord(pf.origin, h->stream));
     }
-    g_prof_events.clear();
-    if (xtv_kernel_ms) *xtv_kernel_ms = g_prof_ms;
-    if (xtv_launches) *xtv_launches = g_prof_launches;
-    if (reset) { g_prof_ms = 0.0; g_prof_launches = 0; }
+    pf.on = on != 0;
     return MIH_OK;
 }
 
-int mih_set_xtv_variant(int variant)
+int mih_profile_read(const mih_mat *h, double *xtv_kernel_ms, int64_t *xtv_launches, int reset)
 {
-    if (variant == -1) { g_xtv_variant = -1; return MIH_OK; }      // back to the library default
-    if (variant < -1 || !xtv_variant_valid(variant)) { set_error("variant %d out of range", variant); return MIH_BAD_ARG; }
-    g_xtv_variant = variant;          // -1: library default (LDS-shared digit planes); >= 0: a per-wave-load shape
+    if (!h) { set_error("null matrix handle"); return MIH_BAD_ARG; }
+    Profile &pf = *h->prof;
+    std::lock_guard<std::mutex> g(pf.mu);
+    pf.drain();
+    double ms = 0.0;
+    for (const auto &r : pf.done) ms += r.ms;
+    if (xtv_kernel_ms) *xtv_kernel_ms = ms;
+    if (xtv_launches) *xtv_launches = (int64_t)pf.done.size();
+    if (reset) pf.done.clear();
     return MIH_OK;
 }
 
-int mih_set_xtv_digits(int digits)
+int mih_profile_passes(const mih_mat *h, mih_pass_record *out, int64_t cap, int64_t *n, int reset)
 {
-    DigitMode dm;
-    if (!digit_mode(digits, dm)) { set_error("residual format must be 0 (default), 4910, 4908, 1316, 1308 or 428"); return MIH_BAD_ARG; }
-    g_xtv_digits = digits;
+    if (!h || !n) { set_error("null argument"); return MIH_BAD_ARG; }
+    Profile &pf = *h->prof;
+    std::lock_guard<std::mutex> g(pf.mu);
+    pf.drain();
+    *n = (int64_t)pf.done.size();
+    if (out) for (int64_t i = 0; i < cap && i < *n; ++i) out[i] = pf.done[(size_t)i];
+    if (reset) pf.done.clear();
     return MIH_OK;
 }
 
-int mih_set_xtv_multi_variant(int variant)
+int mih_profile_counters(const mih_mat *h, int64_t *out, int reset)
 {
-    if (variant < 0 || variant > 63) { set_error("multi-RHS variant %d out of range", variant); return MIH_BAD_ARG; }
-    g_xtv_multi_variant = variant;
+    if (!h || !out) { set_error("null argument"); return MIH_BAD_ARG; }
+    Profile &pf = *h->prof;
+    std::lock_guard<std::mutex> g(pf.mu);
+    for (int i = 0; i < MIH_PROFILE_NCOUNTERS; ++i) { out[i] = pf.counters[i]; if (reset) pf.counters[i] = 0; }
     return MIH_OK;
 }
 
@@ -1619,12 +1548,12 @@ int mih_xtv_algorithmic_bytes(const mih_mat *h, int m, double *bytes)
     return MIH_OK;
 }
 
-int mih_xtv_batched(const mih_mat *h, const double *R, int m, double *OUT)
+int mih_xtv_batched_fmt(const mih_mat *h, const double *R, int m, int digits, double *OUT)
 {
     if (!h || !R || !OUT || m < 1) { set_error("null/invalid argument"); return MIH_BAD_ARG; }
     MIH_HIP(hipSetDevice(h->device));
     XtvWork w;
-    MIH_TRY(xtv_work_init(h, w, m));
+    MIH_TRY(xtv_work_init(h, w, m, xtv_tune(digits)));
     DevBuf<double> r, out;
     MIH_TRY(r.alloc((size_t)m * h->n));
     MIH_TRY(out.alloc((size_t)m * h->p));
@@ -1635,9 +1564,14 @@ int mih_xtv_batched(const mih_mat *h, const double *R, int m, double *OUT)
     return MIH_OK;
 }
 
+int mih_xtv_batched(const mih_mat *h, const double *R, int m, double *OUT)
+{
+    return mih_xtv_batched_fmt(h, R, m, 0, OUT);
+}
+
 int mih_xtv(const mih_mat *h, const double *r, double *out)
 {
-    return mih_xtv_batched(h, r, 1, out);
+    return mih_xtv_batched_fmt(h, r, 1, 0, out);
 }
 
 __global__ void k_fill_random(double *r, int64_t n, uint64_t seed)
@@ -1661,30 +1595,18 @@ __global__ void k_checksum(const double *x, int64_t p, double *out)
     if (threadIdx.x == 0) *out = red[0];
 }
 
-int mih_bench_xtv(const mih_mat *h, int variant, int iters, int warmup, uint64_t seed,
-                  float *ms_per_pass, double *checksum)
-{
-    return mih_bench_xtv_batched(h, variant, 1, 4, iters, warmup, seed, ms_per_pass, checksum);
-}
-
-int mih_bench_xtv_batched(const mih_mat *h, int variant, int m, int max_fused, int iters, int warmup, uint64_t seed,
-                          float *ms_per_pass, double *checksum)
+int mih_bench_xtv(const mih_mat *h, int digits, int m, int iters, int warmup, uint64_t seed, float *ms_per_pass, double *checksum)
 {
     if (!h || iters < 1 || !ms_per_pass || m < 1) return MIH_BAD_ARG;
-    int saved_nr = g_xtv_max_nr;
-    g_xtv_max_nr = max_fused;
-    struct Restore { int v; ~Restore() { g_xtv_max_nr = v; } } restore{saved_nr};
     MIH_HIP(hipSetDevice(h->device));
-    int saved = g_xtv_variant;
-    if (variant >= 0) { if (!xtv_variant_valid(variant)) return MIH_BAD_ARG; g_xtv_variant = variant; }
     XtvWork w;
-    int rc = xtv_work_init(h, w, m, m > 1);       // m = 1: the single-fit workspace, like IhtVar
+    MIH_TRY(xtv_work_init(h, w, m, xtv_tune(digits), m > 1));       // m = 1: the single-fit workspace, like IhtVar
     DevBuf<double> r, out, cs;
-    if (!rc) rc = r.alloc((size_t)h->n * m);
-    if (!rc) rc = out.alloc((size_t)h->p * m);
-    if (!rc) rc = cs.alloc(1);
-    if (rc) { g_xtv_variant = saved; return rc; }
+    MIH_TRY(r.alloc((size_t)h->n * m));
+    MIH_TRY(out.alloc((size_t)h->p * m));
+    MIH_TRY(cs.alloc(1));
     hipStream_t s = h->stream;
+    int rc = MIH_OK;
     hipLaunchKernelGGL(k_fill_random, dim3((unsigned)((h->n * m + 255) / 256)), dim3(256), 0, s, r.p, h->n * m, seed);
     for (int i = 0; i < warmup && !rc; ++i) rc = xtv_device(h, w, r.p, m, out.p, s);
     hipEvent_t e0, e1;
@@ -1696,7 +1618,6 @@ int mih_bench_xtv_batched(const mih_mat *h, int variant, int m, int max_fused, i
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    g_xtv_variant = saved;
     if (rc) return rc;
     if (e != hipSuccess) return hip_fail(e, "bench sync", __FILE__, __LINE__);
     *ms_per_pass = ms / iters;

@@ -504,7 +504,7 @@ int xv_sparse_multi_device(const mih_mat *h, XvWork &w, const int64_t *idx_dev, 
                            double *out_dev, hipStream_t s, const int64_t *idx_host)
 {
     const bool fix = h->kind == 0 && h->impute && h->total_missing > 0;
-    static const bool multi_on = []() { const char *e = getenv("MENDELIHT_XV_MULTI"); return !e || atoi(e) != 0; }();
+    static const bool multi_on = []() { const char *e = probe_env("MENDELIHT_XV_MULTI"); return !e || atoi(e) != 0; }();
     if (multi_on && m > 1 && nnz > 0 && h->kind == 0 && !fix && idx_host && h->p < (1ll << 40)) {
         if (nnz * m > w.cap) {
             MIH_HIP(hipStreamSynchronize(s));
@@ -516,7 +516,7 @@ int xv_sparse_multi_device(const mih_mat *h, XvWork &w, const int64_t *idx_dev, 
         if (xv_cache_lookup(w, idx_host, nnz, slots, fills)) {
             const int64_t ndw = h->n_pad / 16;
             const int groups = (int)(nnz < w.groups ? nnz : w.groups);
-            static const bool mt_on = []() { const char *e = getenv("MENDELIHT_XV_MULTI"); return !e || atoi(e) != 2; }();   // 2: the LDS-reduced kernel
+            static const bool mt_on = []() { const char *e = probe_env("MENDELIHT_XV_MULTI"); return !e || atoi(e) != 2; }();   // 2: the LDS-reduced kernel
             if (mt_on && nnz < (1ll << 30)) {
                 if ((size_t)m * groups > w.coefG.n) { MIH_HIP(hipStreamSynchronize(s)); MIH_TRY(w.coefG.alloc((size_t)m * kXvGroups * 2)); }
                 hipLaunchKernelGGL(k_xv_coef_groups, dim3((unsigned)m), dim3(256), 0, s, idx_dev, vals_dev, (int)nnz,

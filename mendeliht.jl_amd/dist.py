@@ -15,9 +15,13 @@ import os
 import numpy as np
 
 
-def shard_combinations(q, npath, rank, world):
-    """Indices (fold-major, cross_validation.jl:217-223) of the combinations a rank owns."""
-    return [i for i in range(q * npath) if i % world == rank]
+def shard_combinations(q, npath, rank, world, path=None):
+    """Indices (fold-major, cross_validation.jl:217-223) of the combinations a rank owns under the library's sharding rule
+    (mih_cv_assignment: round-robin over the combinations sorted by model size, so every rank gets every size class).
+    `path` defaults to 1:npath."""
+    from .api import cv_assignment
+    rank_of = cv_assignment(range(1, npath + 1) if path is None else path, q, world).ravel()
+    return [i for i in range(q * npath) if rank_of[i] == rank]
 
 
 def init_from_env(backend=None):
@@ -229,6 +233,11 @@ def fit_iht_sharded(y, x_shard, z=None, *, col_offset, p_global, weight=None, na
         if comm.error is not None:
             raise comm.error
         raise
+    finally:
+        #  the native communicator is torn down here, collectively and while every rank is still alive -- not by the
+        # garbage collector at interpreter exit (ncclCommDestroy after the other ranks have gone can hang)
+        if native:
+            comm.close()
     beta = np.zeros(p_global)
     nz = np.flatnonzero(res.beta)
     mine = (nz + col_offset, res.beta[nz])

@@ -8,6 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# every 2-bit matrix of the test suite gets the device-memory reserve a 125 GB matrix gets (csrc/snp.hip reserve_fit_memory): the
+# pool, the per-IHTVariable arenas and the lock-step hand-over run in CI exactly as at full size
+os.environ.setdefault("MENDELIHT_RESERVE_MIN_BYTES", "0")
+
 FIX = os.path.join(ROOT, "tests", "fixtures")
 GOLD = os.path.join(ROOT, "tests", "golden")
 
@@ -82,10 +86,6 @@ def make_bed(rng, n, p, missing_rate=0.0, maf_lo=0.02, maf_hi=0.5):
 
 
 def hash_folds(n, q, seed=2026):
-    """folds_i = 1 + (hash(seed, i) mod q): explicit, RNG-free folds."""
-    i = np.arange(n, dtype=np.uint64)
-    x = (i + np.uint64(seed)) * np.uint64(0x9E3779B97F4A7C15)
-    x ^= x >> np.uint64(31)
-    x *= np.uint64(0xBF58476D1CE4E5B9)
-    x ^= x >> np.uint64(29)
-    return (1 + (x % np.uint64(q))).astype(np.int32)
+    """folds_i = 1 + (hash(seed, i) mod q): explicit, RNG-free folds.  Lives in the package (bench.py uses it too)."""
+    from mendeliht_amd import hash_folds as hf
+    return hf(n, q, seed)

@@ -20,6 +20,33 @@ def test_library_exports_every_declared_symbol(mih):
         assert getattr(L, s) is not None
 
 
+def test_probe_entry_points_live_in_the_measurement_build_only(mih):
+    """Kernel-shape knobs and timing probes are not part of the product: libmendeliht_hip.so exports exactly the header's
+    functions, the measurement build (-DMIH_PROBES) those plus include/mendeliht_hip_probes.h; the product has no mutable
+    process-wide selectors (mih_set_*) and reads none of the MENDELIHT_* A/B switches."""
+    import ctypes as C
+    import subprocess
+    from mendeliht_amd import api
+    probes_h = open(os.path.join(ROOT, "include", "mendeliht_hip_probes.h")).read()
+    probe_syms = set(re.findall(r"^int\s+(mih_\w+)\s*\(", probes_h, flags=re.M))
+    assert probe_syms == set(api.probe_symbols())
+
+    def exported(path):
+        out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+        return {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("mih_")}
+    prod, meas = exported(mih.library_path()), exported(mih.probes_library_path())
+    assert prod == set(api.exported_symbols())
+    assert meas == prod | probe_syms
+    assert not any(s.startswith("mih_set_") or s.startswith("mih_probe_") for s in prod)
+    blob = open(mih.library_path(), "rb").read()
+    for switch in (b"MENDELIHT_XTV_MAX_OPS", b"MENDELIHT_XTV_SLICES", b"MENDELIHT_XTV_NO_HALF", b"MENDELIHT_CV_LANES", b"MENDELIHT_CV_NO_MERGE",
+                   b"MENDELIHT_CV_NO_INIT_SHARE", b"MENDELIHT_CV_TRACE", b"MENDELIHT_NO_SPIN", b"MENDELIHT_NO_ARENA", b"MENDELIHT_TOPK_RADIX8",
+                   b"MENDELIHT_XV_MULTI", b"MENDELIHT_CV_ASSIGN"):
+        assert switch not in blob, switch
+        assert switch in open(mih.probes_library_path(), "rb").read(), switch
+    assert C.sizeof(api._PassRecord) == 80
+
+
 def test_struct_mirrors_match_the_library(mih):
     """ctypes mirrors of the C structs have the library's sizes (catches a field added on one side only)."""
     import ctypes as C

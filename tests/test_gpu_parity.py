@@ -30,33 +30,112 @@ def test_device_present_and_native_library_loaded(mih):
     assert os.path.exists(mih.library_path())
 
 
-def test_mu_sinv_and_xtv_all_variants(mih, normal_pair):
+_ROUND1_SNIPPET = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import mendeliht_amd as m
+assert m.using_probes()
+n = 1000
+x = m.SnpLinAlg(m.read_bed(os.path.join(sys.argv[1], "tests", "fixtures", "normal.bed"), n), n, center=True, scale=True, impute=True)
+r = np.random.default_rng(0).standard_normal(n)
+out = {"default": x.xtv(r), "base1316": x.xtv(r, xtv_digits=1316)}
+nv = 0
+while True:                                                  # round 1's per-wave-load shapes
+    try:
+        m.probe_set(variant=nv)
+    except m.MendelIHTError:
+        break
+    out[f"variant{nv}"] = x.xtv(r, xtv_digits=1316)
+    nv += 1
+m.probe_set(variant=-1)
+for mv in (9, 10, 11, 12, 13, 14):                           # the register-staged single-operand shapes
+    m.probe_set(multi_variant=mv)
+    out[f"multi{mv}"] = x.xtv(r, xtv_digits=1316)
+m.probe_set(multi_variant=0)
+R = np.asfortranarray(np.random.default_rng(1).standard_normal((n, 7)))
+out["R7_default"] = x.xtv(R)
+m.probe_set(multi_variant=6)                                 # round 1's register-staged FP6 kernels (32x32x64)
+out["R7_regstaged"] = x.xtv(R)
+m.probe_set(multi_variant=20)                                # the 32x32x64 LDS-DMA ring
+out["R7_ring32"] = x.xtv(R)
+m.probe_set(multi_variant=0)
+xs = m.SnpLinAlg.synthetic(500_000, 64, seed=2024)           # full row count (eight row slices)
+r1 = np.random.default_rng(5).standard_normal(500_000)
+out["big_default"] = xs.xtv(r1)
+nb = 0
+while True:
+    try:
+        m.probe_set(variant=nb)
+    except m.MendelIHTError:
+        break
+    out[f"big_variant{nb}"] = xs.xtv(r1)
+    nb += 1
+m.probe_set(variant=-1)
+np.savez(sys.argv[2], **out)
+"""
+
+
+def _run_probe_snippet(snippet, out_file, extra_env=None, probes=True, timeout=900):
+    """A python snippet in its own process, on the measurement build of the library (MENDELIHT_HIP_PROBES=1) or on the product."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "MENDELIHT_HIP_PROBES"}
+    if probes:
+        env["MENDELIHT_HIP_PROBES"] = "1"
+    env.update(extra_env or {})
+    r = subprocess.run([sys.executable, "-c", snippet, root, str(out_file)], capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return np.load(out_file)
+
+
+def test_mu_sinv_and_xtv_against_oracle(mih, normal_pair):
     x, ox = normal_pair
+    assert not mih.using_probes()                                   # the tests run on the product library
     mu, s = x.mu_sigma()
     omu, os_ = ox.mu_sinv()
     assert np.array_equal(mu, omu) and np.array_equal(s, os_)
     r = np.random.default_rng(0).standard_normal(x.n)
     ref = ox.xtv(r)
-    default = x.xtv(r)                                              # library default: FP6 digit planes shared through LDS
+    default = x.xtv(r)                                              # library default: FP6 digit planes through the LDS-DMA ring
     assert rel(default, ref) < 1e-11
-    mih.set_xtv_digits(1316)                                        # the FP4 format every kernel shape implements
-    base = x.xtv(r)
+    base = x.xtv(r, xtv_digits=1316)
     assert rel(base, default) < 1e-13
-    nv = 0
-    same_slices = (5, 6, 7)                                         # shapes with one row slice, like the default at n = 1000
-    while mih.lib().mih_set_xtv_variant(nv) == 0:                   # the per-wave-load shapes
-        out = x.xtv(r)
-        assert rel(out, base) < 1e-13, nv                           # the slice partials are rounded f64 sums of exact digit sums
-        if nv in same_slices:
-            assert np.array_equal(out, base), nv                    # same slicing: every kernel shape agrees bit for bit
-        nv += 1
-    assert nv >= 3
-    assert mih.lib().mih_set_xtv_variant(-1) == 0
-    for mv in (10, 11, 12, 13, 14, 0):                              # other LDS shapes of the single-operand pass
-        assert mih.lib().mih_set_xtv_multi_variant(mv) == 0
-        assert np.array_equal(x.xtv(r), base), mv
-    mih.set_xtv_digits(0)
     assert np.array_equal(x.xtv(r), default)
+
+
+def test_product_kernels_equal_the_round1_kernel_families(mih, normal_pair, oracle, tmp_path):
+    """The product library has one kernel per (format family, operand count).  The measurement build (same sources,
+    -DMIH_PROBES) still carries round 1's kernel families -- per-wave digit loads, digit planes staged through registers -- and
+    the 32x32x64 ring: with the same row slicing they must give the product's bits, on the reference's shipped data and at the
+    full row count of the benchmark (against the oracle there)."""
+    x, ox = normal_pair
+    got = _run_probe_snippet(_ROUND1_SNIPPET, tmp_path / "round1.npz")
+    r = np.random.default_rng(0).standard_normal(x.n)
+    default, base = x.xtv(r), x.xtv(r, xtv_digits=1316)            # this process: the product library
+    assert np.array_equal(got["default"], default) and np.array_equal(got["base1316"], base)
+    nv = sum(1 for k in got.files if k.startswith("variant"))
+    assert nv >= 3
+    same_slices = (5, 6, 7)                                         # shapes with one row slice, like the default at n = 1000
+    for v in range(nv):
+        assert rel(got[f"variant{v}"], base) < 1e-13, v             # the slice partials are rounded f64 sums of exact digit sums
+        if v in same_slices:
+            assert np.array_equal(got[f"variant{v}"], base), v      # same slicing: every kernel shape agrees bit for bit
+    for mv in (9, 10, 11, 12, 13, 14):
+        assert np.array_equal(got[f"multi{mv}"], base), mv
+    R = np.asfortranarray(np.random.default_rng(1).standard_normal((x.n, 7)))
+    mine = x.xtv(R)
+    for k in ("R7_default", "R7_regstaged", "R7_ring32"):
+        assert np.array_equal(got[k], mine), k
+    xs = mih.SnpLinAlg.synthetic(500_000, 64, seed=2024)
+    r1 = np.random.default_rng(5).standard_normal(500_000)
+    oxs = oracle.Mat.from_bed_columns(xs.export_bed(), 500_000)
+    want = oxs.xtv(r1)
+    assert np.array_equal(got["big_default"], xs.xtv(r1))
+    nb = sum(1 for k in got.files if k.startswith("big_variant"))
+    assert nb >= 3
+    for v in range(nb):
+        assert rel(got[f"big_variant{v}"], want) < 1e-10, v
 
 
 @pytest.mark.parametrize("n,p,miss", [(1003, 257, 0.02), (77, 33, 0.1), (5000, 100, 0.0), (2049, 64, 0.05),
@@ -331,11 +410,6 @@ def test_full_size_properties_n500k(mih, oracle):
     xs = mih.SnpLinAlg.synthetic(n, 64, seed=2024)                 # oracle on a column sample
     ox = oracle.Mat.from_bed_columns(xs.export_bed(), n)
     assert rel(o1[:64], ox.xtv(r1)) < 1e-10
-    nv = 0
-    while mih.lib().mih_set_xtv_variant(nv) == 0:                  # every kernel variant, full row count
-        assert rel(x.xtv(r1)[:64], ox.xtv(r1)) < 1e-10, nv
-        nv += 1
-    mih.lib().mih_set_xtv_variant(-1)
     idx = np.sort(rng.choice(64, 9, replace=False))
     val = rng.standard_normal(9)
     mask = np.zeros(64, np.uint8)
@@ -1476,9 +1550,9 @@ def test_session_run_is_k_session_steps(mih, normal_pair, normal_data):
 
 _NOSPIN_SNIPPET = r"""
 import sys, json, numpy as np
-sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+sys.path.insert(0, sys.argv[1])
 import mendeliht_amd as m
-from conftest import hash_folds
+hash_folds = m.hash_folds
 x = m.SnpLinAlg.synthetic(6001, 900, seed=3, missing_rate=0.01)
 rng = np.random.default_rng(1)
 supp = np.sort(rng.choice(900, 8, replace=False))
@@ -1510,19 +1584,137 @@ def test_polled_readbacks_and_shared_initial_scores_change_nothing(mih, tmp_path
     (MENDELIHT_CV_NO_INIT_SHARE=1, MENDELIHT_CV_NO_MERGE=1), with one lock-step lane instead of two, and with every buffer
     of an IHTVariable as its own allocation instead of a carve-out of one block (MENDELIHT_NO_ARENA=1).  Univariate Normal and
     logistic fits, a cross-validation, a model path and a multivariate fit."""
-    import subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = []
-    for i, extra in enumerate(({}, {"MENDELIHT_NO_SPIN": "1"}, {"MENDELIHT_CV_NO_INIT_SHARE": "1", "MENDELIHT_CV_NO_MERGE": "1"},
+    # the first run is the PRODUCT library (which reads none of the switches), the others the measurement build of the same
+    # sources: the product's bits are also those of the measurement build's defaults
+    for i, extra in enumerate((None, {}, {"MENDELIHT_NO_SPIN": "1"}, {"MENDELIHT_CV_NO_INIT_SHARE": "1", "MENDELIHT_CV_NO_MERGE": "1"},
                                {"MENDELIHT_CV_LANES": "1"}, {"MENDELIHT_NO_ARENA": "1"})):
-        f = tmp_path / f"variant_{i}.npz"
-        r = subprocess.run([sys.executable, "-c", _NOSPIN_SNIPPET, root, str(f)], capture_output=True, text=True, timeout=900,
-                           env=dict(os.environ, **extra))
-        assert r.returncode == 0, r.stdout + r.stderr
-        res.append(np.load(f))
+        res.append(_run_probe_snippet(_NOSPIN_SNIPPET, tmp_path / f"variant_{i}.npz", extra_env=extra or {}, probes=extra is not None))
     assert len(res[0].files) == 10
     for other in res[1:]:
         assert sorted(res[0].files) == sorted(other.files)
         for k in res[0].files:
             assert np.array_equal(res[0][k].view(np.uint64), other[k].view(np.uint64)), k
     assert res[0]["logl"][1] > 2 and np.count_nonzero(res[0]["cv"]) == 24 and res[0]["path"].size == 6 and np.count_nonzero(res[0]["mvcv"]) == 12
+
+
+def _config3_problem(mih, n, p, seed=2024):
+    """BASELINE configs[3] in small: Bernoulli/Logit response with 10 true effects on a synthetic SnpArray, explicit hash folds."""
+    x = mih.SnpLinAlg.synthetic(n, p, seed=seed)
+    rng = np.random.default_rng(2025)
+    supp = np.sort(rng.choice(p, 10, replace=False))
+    eta = x.xv_sparse(supp, rng.standard_normal(10) * 0.5)
+    yb = (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float)
+    return x, yb, hash_folds(n, 5)
+
+
+def test_config3_full_grid_against_oracle(mih, oracle):
+    """The EXACT driver shape of BASELINE configs[3]: cv_iht Bernoulli/Logit, path = 1:20, q = 5 = 100
+    (fold, k) fits on one rank -- two lock-step lanes of 15 slots (30 fits in flight), the tail hand-over from lane 1 to lane 0
+    and the 20 fits of a fold sharing one initial score all fire (asserted from the driver's own counters) -- with ALL 100
+    held-out losses against oracle.cv_iht (cross_validation.jl:98-131), and the eight `rank = r, world = 8` shards of the same
+    grid summing bit-exactly to the single-rank matrix (each rank: 12 or 13 fits in one lane, as one GPU of 8 runs it)."""
+    n, p = 20_000, 4_000
+    x, yb, folds = _config3_problem(mih, n, p)
+    path = range(1, 21)
+    mih.profile_counters(x, reset=True)
+    mih.profile_read(x, reset=True)
+    mih.profile_enable(x, True)
+    mse, raw = mih.cv_iht(yb, x, None, path=path, q=5, folds=folds, verbose=False, return_raw=True,
+                          d=mih.Bernoulli(), l=mih.LogitLink())
+    mih.profile_enable(x, False)
+    cnt = mih.profile_counters(x, reset=True)
+    passes = mih.profile_passes(x, reset=True)
+    # the driver shape of the full-size run
+    assert cnt["fits"] == 100 and cnt["lanes"] == 2
+    assert cnt["max_lane_slots"] == 15 and cnt["max_in_flight"] == 30          # two lanes x five operands x three residuals
+    assert cnt["handovers"] == 1                                                # lane 1 handed its tail to lane 0
+    assert cnt["shared_init"] >= 80                                             # at most 2 lanes x 5 folds ride their own initial score
+    assert cnt["scores"] >= 100 * 5 and cnt["rounds"] >= 10
+    assert {q["stream_tag"] for q in passes} == {1, 2}
+    assert max(q["residuals"] for q in passes) == 15 and all(q["kernel"].startswith("k_xtv_dma16<") for q in passes)
+    assert sum(q["residuals"] for q in passes) == cnt["scores"] - cnt["shared_init"]
+    assert np.count_nonzero(raw) == 100
+    # all 100 losses against the oracle
+    ox = oracle.Mat.from_bed_columns(x.export_bed(), n)
+    omse, oraw = oracle.cv_iht(ox, yb, None, path=path, q=5, folds=folds, dist="bernoulli", link="logit")
+    np.testing.assert_allclose(raw, oraw, rtol=1e-4)                            # north_star: 1e-4 for GLM links
+    np.testing.assert_allclose(raw, oraw, rtol=1e-9)                            # what it actually is
+    np.testing.assert_allclose(mse, omse, rtol=1e-9)
+    assert int(np.argmin(mse)) == int(np.argmin(omse))
+    # eight shards, as 8 GPUs would run them (here one after the other on this GPU)
+    rank_of = mih.cv_assignment(path, 5, 8)
+    tot = np.zeros_like(raw)
+    for r in range(8):
+        mih.profile_enable(x, True)
+        _, part = mih.cv_iht(yb, x, None, path=path, q=5, folds=folds, verbose=False, return_raw=True, rank=r, world=8,
+                             d=mih.Bernoulli(), l=mih.LogitLink())
+        mih.profile_enable(x, False)
+        c = mih.profile_counters(x, reset=True)
+        mih.profile_read(x, reset=True)
+        assert np.array_equal(part != 0, rank_of == r)
+        assert c["fits"] == int((rank_of == r).sum()) and c["fits"] in (12, 13) and c["lanes"] == 1
+        tot += part
+    assert np.array_equal(tot.view(np.uint64), raw.view(np.uint64))             # bit-exact: a fit does not depend on its rank
+
+
+def test_config4_multivariate_r10_k500_against_oracle(mih, oracle):
+    """BASELINE configs[4]'s model size: MvNormal with r = 10 traits and k = 500 non-zero entries at
+    p = 20 000 SNPs against oracle.fit_mv (multivariate.jl:99-127: top-k over all r * p entries): same iterations, backtracks
+    and support, B and C to 1e-5, Sigma and the loglikelihood."""
+    n, p, r, k = 3_000, 20_000, 10, 500
+    x = mih.SnpLinAlg.synthetic(n, p, seed=41)
+    ox = oracle.Mat.from_bed_columns(x.export_bed(), n)
+    rng = np.random.default_rng(4100)
+    Y, Z = _mv_problem(oracle, ox, rng, r, k, 2)
+    res = mih.fit_iht(Y, x, Z, k=k, verbose=False, max_iter=60)
+    o = oracle.fit_mv(ox, Y, Z, k=k, max_iter=60)
+    assert res.iter == o["iter"] and res.iter >= 5
+    assert list(res.trace["backtracks"]) == list(o["bt_trace"])
+    assert np.count_nonzero(res.beta) == np.count_nonzero(o["B"]) and 400 <= np.count_nonzero(res.beta) <= k
+    assert np.array_equal(res.beta != 0, o["B"] != 0)
+    np.testing.assert_allclose(res.beta, o["B"], rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(res.c, o["C"], rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(res.Σ, o["Sigma"], rtol=1e-6)
+    assert res.logl == pytest.approx(o["logl"], rel=1e-9)
+
+
+def test_concurrent_fits_with_different_digit_formats(mih):
+    """The library has no process-wide kernel or format selector: the residual format travels with the call.
+    Two host threads fitting CONCURRENTLY on one shared matrix, one in the default 54-bit format and one in the 43-bit fast
+    format (plus a cross-validation in a third), must give the bits of the same calls run one after the other."""
+    import threading
+    n, p = 12_000, 3_000
+    x = mih.SnpLinAlg.synthetic(n, p, seed=77, missing_rate=0.01)
+    rng = np.random.default_rng(78)
+    supp = np.sort(rng.choice(p, 12, replace=False))
+    eta = x.xv_sparse(supp, rng.standard_normal(12) * 0.5)
+    Y = np.vstack([eta + rng.standard_normal(n), 0.5 * eta + rng.standard_normal(n), rng.standard_normal(n)])
+    yb = (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float)
+    folds = hash_folds(n, 3)
+    jobs = {
+        "mv_default": lambda: mih.fit_iht(Y, x, None, k=20, verbose=False, max_iter=30, xtv_digits=0).beta,
+        "mv_fast": lambda: mih.fit_iht(Y, x, None, k=20, verbose=False, max_iter=30, xtv_digits=4908).beta,
+        "cv_1316": lambda: mih.cv_iht(yb, x, None, path=range(1, 9), q=3, folds=folds, verbose=False, return_raw=True,
+                                      d=mih.Bernoulli(), l=mih.LogitLink(), xtv_digits=1316)[1],
+        "xtv_fast": lambda: x.xtv(Y.T.copy(), xtv_digits=4908),
+        "xtv_default": lambda: x.xtv(Y.T.copy()),
+    }
+    serial = {k: f() for k, f in jobs.items()}
+    assert not np.array_equal(serial["xtv_fast"], serial["xtv_default"])        # the formats really differ
+    for _ in range(3):
+        out, errs = {}, []
+
+        def run(name):
+            try:
+                out[name] = jobs[name]()
+            except Exception as e:                                              # noqa: BLE001
+                errs.append((name, e))
+        th = [threading.Thread(target=run, args=(k,)) for k in jobs]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        for k in jobs:
+            assert np.array_equal(np.asarray(out[k]).view(np.uint64), np.asarray(serial[k]).view(np.uint64)), k

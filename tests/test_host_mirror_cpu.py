@@ -92,13 +92,192 @@ def test_struct_layout_matches_header_order(mih):
     assert C.sizeof(api._Comm) == 48
 
 
-def test_bench_refuses_gpus_without_a_launcher():
-    """`bench.py --gpus N` outside torch.distributed.run used to measure ONE GPU silently: it must exit non-zero,
-    before touching any GPU, and print the launcher command."""
+
+# ---- the Julia glue (julia/MendelIHTHip.jl) against the header: it cannot be executed here (no Julia in the image), so its
+# struct mirrors and every ccall are parsed and compared with include/mendeliht_hip.h -------------------------------------
+def _header_structs_and_functions():
+    import re
+
+    from conftest import ROOT
+    header = open(os.path.join(ROOT, "include", "mendeliht_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+
+    def cls(ctype):
+        t = ctype.strip()
+        if "*" in t or "(" in t:
+            return "ptr"
+        if re.search(r"\b(double|float)\b", t):
+            return "f64" if "double" in t else "f32"
+        if re.search(r"\b(int64_t|uint64_t|size_t)\b", t):
+            return "i64"
+        if re.search(r"\b(int32_t|uint32_t|int)\b", t):
+            return "i32"
+        raise AssertionError(f"unclassified C type {ctype!r}")
+
+    structs = {}
+    for name in ("mih_fit_params", "mih_fit_result", "mih_mv_result", "mih_comm"):
+        body = header[header.index("typedef struct " + name):]
+        body = body[body.index("{") + 1:body.index("} " + name)]
+        fields = []
+        for decl in body.split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            m = re.search(r"\(\*\s*(\w+)\)\s*\(", decl)
+            if m:
+                fields.append((m.group(1), "ptr"))
+                continue
+            base = re.match(r"((?:const\s+)?(?:struct\s+)?\w+)", decl).group(1)
+            rest = decl[len(base):]
+            for part in rest.split(","):
+                part = part.strip()
+                nm = re.findall(r"(\w+)$", part)[0]
+                fields.append((nm, "ptr" if "*" in part else cls(base)))
+        structs[name] = fields
+    funcs = {}
+    for m in re.finditer(r"^int\s+(mih_\w+)\s*\((.*?)\)\s*;", header, flags=re.M | re.S):
+        args = " ".join(m.group(2).split())
+        params = []
+        if args and args != "void":
+            depth, cur = 0, ""
+            for ch in args:
+                if ch == "(":
+                    depth += 1
+                if ch == ")":
+                    depth -= 1
+                if ch == "," and depth == 0:
+                    params.append(cur)
+                    cur = ""
+                else:
+                    cur += ch
+            params.append(cur)
+        out = []
+        for prm in params:
+            prm = prm.strip()
+            ty = prm if ("*" in prm or "(" in prm) else re.sub(r"\s*\w+$", "", prm)      # drop the parameter name
+            out.append(cls(ty))
+        funcs[m.group(1)] = out
+    return structs, funcs
+
+
+def _julia_class(t):
+    t = t.strip()
+    if t.startswith(("Ptr{", "Ref{")):
+        return "ptr"
+    return {"Int64": "i64", "UInt64": "i64", "Csize_t": "i64", "Int32": "i32", "Cint": "i32", "UInt32": "i32",
+            "Float64": "f64", "Cdouble": "f64", "Float32": "f32", "Cfloat": "f32"}[t]
+
+
+def _split_top(s):
+    parts, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "({[":
+            depth += 1
+        if ch in ")}]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            parts.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        parts.append(cur)
+    return [q.strip() for q in parts]
+
+
+def test_julia_glue_struct_mirrors_match_the_header():
+    """Field order AND field types (pointer / Int64 / Int32 / Float64) of the Julia struct mirrors = include/mendeliht_hip.h."""
+    import re
+
+    from conftest import ROOT
+    structs, _ = _header_structs_and_functions()
+    jl = open(os.path.join(ROOT, "julia", "MendelIHTHip.jl")).read()
+    jl = re.sub(r"#[^\n]*", "", jl)
+    for jname, cname in (("MihFitParams", "mih_fit_params"), ("MihFitResult", "mih_fit_result"), ("MihMvResult", "mih_mv_result"),
+                         ("MihComm", "mih_comm")):
+        m = re.search(r"(?:mutable\s+)?struct\s+" + jname + r"\b(.*?)\nend", jl, flags=re.S)
+        assert m, jname
+        fields = []
+        for decl in re.split(r"[;\n]", m.group(1)):
+            decl = decl.strip()
+            if decl:
+                nm, ty = decl.split("::")
+                fields.append((nm.strip(), _julia_class(ty)))
+        assert fields == structs[cname], (jname, fields, structs[cname])
+
+
+def test_julia_glue_ccalls_match_the_header():
+    """Every ccall of the glue names a function the header declares, with the same number of arguments and the same argument
+    classes (pointer / 64-bit integer / 32-bit integer / double) in the same order, and returns Cint."""
+    import re
+
+    from conftest import ROOT
+    _, funcs = _header_structs_and_functions()
+    jl = open(os.path.join(ROOT, "julia", "MendelIHTHip.jl")).read()
+    jl = "\n".join(line.split("#")[0] if "ccall" not in line.split("#")[0] else line.split(" #")[0] for line in jl.split("\n"))
+    seen = set()
+    for m in re.finditer(r"ccall\(\(:(\w+),\s*LIB\),\s*(\w+),\s*\(", jl):
+        name, ret = m.group(1), m.group(2)
+        i, depth = m.end(), 1
+        while depth:                                                  # the argument-type tuple
+            depth += {"(": 1, ")": -1}.get(jl[i], 0)
+            i += 1
+        types = _split_top(jl[m.end():i - 1])
+        j, depth = i, 1                                               # the remaining call arguments, up to the ccall's ")"
+        while depth:
+            depth += {"(": 1, ")": -1}.get(jl[j], 0)
+            j += 1
+        values = _split_top(jl[i:j - 1].lstrip(", \n"))
+        assert name in funcs, f"ccall of {name}: not declared in include/mendeliht_hip.h"
+        assert ret == "Cint", name
+        got = [_julia_class(t) for t in types]
+        assert got == funcs[name], (name, got, funcs[name])
+        assert len(values) == len(types), (name, values, types)
+        seen.add(name)
+    # the path's entry points are all bound
+    for must in ("mih_snp_create", "mih_mat_destroy", "mih_xtv", "mih_xtv_batched", "mih_fit_iht", "mih_fit_mv", "mih_cv_iht",
+                 "mih_cv_mv", "mih_cv_iht_multi", "mih_cv_meanloss", "mih_fit_iht_path", "mih_abi_sizes", "mih_last_error"):
+        assert must in seen, must
+
+
+def test_julia_glue_has_the_file_level_wrappers():
+    """iht(plinkfile, k, d; ...) / cross_validate(plinkfile, d; ...) (src/wrapper.jl:52-120, 301-349) exist in the glue, build a
+    HipSnpLinAlg where the reference builds a SnpLinAlg, and reuse the reference's parsers."""
+    from conftest import ROOT
+    jl = open(os.path.join(ROOT, "julia", "MendelIHTHip.jl")).read()
+    for sig in ("function iht(filename::AbstractString, k::Int, d::UnionAll;", "function cross_validate(filename::AbstractString, d::UnionAll;"):
+        assert sig in jl
+        body = jl[jl.index(sig):]
+        body = body[:body.index("\nend\n")]
+        assert "HipSnpLinAlg{Float64}(X.snparray; center=true, scale=true, impute=true" in body
+        for parser in ("MendelIHT.parse_genotypes", "MendelIHT.parse_phenotypes", "MendelIHT.parse_covariates", "MendelIHT.is_multivariate"):
+            assert parser in body, (sig, parser)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` without a launcher starts N ranks itself (a child torch.distributed.run, before any GPU call)
+    and relays their output; --dry-run prints each rank's launcher environment.  Under a launcher whose WORLD_SIZE disagrees
+    with --gpus it still fails loudly."""
+    import json
     import subprocess
     import sys
     from conftest import ROOT
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, env=env, timeout=120)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [json.loads(q) for q in r.stdout.splitlines() if q.startswith("{")]
+    assert sorted(q["rank"] for q in lines) == [0, 1]
+    assert all(q["world_size"] == 2 and q["n_gpus"] == 2 and q["master_addr"] == "127.0.0.1" for q in lines)
+    assert len({q["master_port"] for q in lines}) == 1
+    assert sorted(q["local_rank"] for q in lines) == [0, 1]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+    # a failing rank's exit code comes back through the launcher (no GPU here: every rank exits with "bench.py needs a GPU")
+    import torch
+    if torch.cuda.is_available():
+        return
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
+                       env=env, timeout=600)
     assert r.returncode != 0
-    assert "torch.distributed.run" in r.stderr and "--nproc-per-node 4" in r.stderr

@@ -1,3 +1,4 @@
+import os
 """All BASELINE.json configs beside the bench.py headline (configs[2]) in one run; writes one JSON object.
 
   configs[1]  dense Float64 50 000 x 100 000, k=100, Normal          (X'r GB/s, ms/iteration)
@@ -9,8 +10,9 @@ import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("MENDELIHT_HIP_PROBES", "1")     # kernel-shape knobs / A-B switches: the measurement build
 import mendeliht_amd as m
-from conftest import hash_folds
+hash_folds = m.hash_folds
 
 digits = int(os.environ.get("MIH_DIGITS", 0))      # mih_set_xtv_digits: 0 default, 4908 = the opt-in fast mode for fused multi-RHS passes
 m.set_xtv_digits(digits)

@@ -1,11 +1,13 @@
+import os
 """cv_iht wall time on the BASELINE configs[3] geometry: path=1:20, 5 folds, Bernoulli/Logit.
 --world W --rank R runs the share of (fold,k) combinations GPU R of W would own."""
 import argparse, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("MENDELIHT_HIP_PROBES", "1")     # kernel-shape knobs / A-B switches: the measurement build
 import mendeliht_amd as m
-from conftest import hash_folds
+hash_folds = m.hash_folds
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=500_000); ap.add_argument("--p", type=int, default=1_000_000)
 ap.add_argument("--k", type=int, default=10); ap.add_argument("--world", type=int, default=8); ap.add_argument("--rank", type=int, default=0)

@@ -4,8 +4,9 @@ import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("MENDELIHT_HIP_PROBES", "1")     # kernel-shape knobs / A-B switches: the measurement build
 import mendeliht_amd as m
-from conftest import hash_folds
+hash_folds = m.hash_folds
 n, p = 500_000, 1_000_000
 x = m.SnpLinAlg.synthetic(n, p, seed=2024)
 rng = np.random.default_rng(2025)
@@ -16,13 +17,13 @@ folds = hash_folds(n, 5)
 ref = None
 for rep in range(2):
     for world in (1, 8):
-        m.profile_read(reset=True); m.profile_enable(True)
+        m.profile_read(x, reset=True); m.profile_enable(x, True)
         t0 = time.perf_counter()
         mse, raw = m.cv_iht(yb, x, None, path=range(1, 21), q=5, folds=folds, verbose=False, return_raw=True, rank=0, world=world,
                             d=m.Bernoulli(), l=m.LogitLink())
         dt = time.perf_counter() - t0
-        m.profile_enable(False)
-        ms, launches = m.profile_read(reset=True)
+        m.profile_enable(x, False)
+        ms, launches = m.profile_read(x, reset=True)
         if world == 1:
             if ref is None: ref = raw.copy()
             assert np.array_equal(raw, ref)

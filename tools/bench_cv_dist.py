@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import mendeliht_amd as m
 from mendeliht_amd import dist as D
-from conftest import hash_folds
+hash_folds = m.hash_folds
 
 n, p = int(os.environ.get("MIH_N", 500_000)), int(os.environ.get("MIH_P", 1_000_000))
 rank, world, local = D.init_from_env(backend=os.environ.get("MIH_BACKEND"))

@@ -4,7 +4,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import mendeliht_amd as m
-from conftest import hash_folds
+hash_folds = m.hash_folds
 n, p, r = 500_000, int(os.environ.get("MIH_P", 1_000_000)), 10
 x = m.SnpLinAlg.synthetic(n, p, seed=2024)
 rng = np.random.default_rng(3)

@@ -1,5 +1,6 @@
 import os, sys, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+os.environ.setdefault("MENDELIHT_HIP_PROBES", "1")     # kernel-shape knobs / A-B switches: the measurement build
 import mendeliht_amd as m
 out = {}
 for (n, p, r, k) in ((3001, 800, 10, 40), (20000, 1500, 7, 100), (5003, 400, 3, 9), (40000, 600, 12, 60)):

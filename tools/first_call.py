@@ -7,8 +7,9 @@ import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("MENDELIHT_HIP_PROBES", "1")     # kernel-shape knobs / A-B switches: the measurement build
 import mendeliht_amd as m
-from conftest import hash_folds
+hash_folds = m.hash_folds
 n, p = 500_000, int(os.environ.get("MIH_P", 200_000))
 x = m.SnpLinAlg.synthetic(n, p, seed=2024)
 rng = np.random.default_rng(2025)

@@ -1,7 +1,8 @@
 import os, sys, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo")); sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/tests")
 import torch, mendeliht_amd as m
-from conftest import make_bed, hash_folds
+from conftest import make_bed
+from mendeliht_amd import hash_folds
 rng = np.random.default_rng(0)
 n, p = 2000, 1500
 cols = make_bed(rng, n, p, 0.02)

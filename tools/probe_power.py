@@ -4,6 +4,7 @@ import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("MENDELIHT_HIP_PROBES", "1")     # kernel-shape knobs / A-B switches: the measurement build
 import mendeliht_amd as m
 n, p = 500_000, 1_000_000
 x = m.SnpLinAlg.synthetic(n, p, seed=2024)
@@ -13,12 +14,12 @@ Rz = np.zeros((n, NC), order="F")
 Rr = np.asfortranarray(rng.standard_normal((n, NC)))
 Rs = np.asfortranarray(np.round(rng.standard_normal((n, NC))))      # few non-zero digits
 for mv in [int(a) for a in sys.argv[1:]] or [0, 8, 7]:
-    m.lib().mih_set_xtv_multi_variant(mv)
+    m.probe_set(multi_variant=mv)
     for name, R in (("zeros", Rz), ("small-int", Rs), ("random", Rr)):
         x.xtv(R)
-        m.profile_read(reset=True); m.profile_enable(True)
+        m.profile_read(x, reset=True); m.profile_enable(x, True)
         for _ in range(3):
             x.xtv(R)
-        m.profile_enable(False)
-        ms, k = m.profile_read(reset=True)
+        m.profile_enable(x, False)
+        ms, k = m.profile_read(x, reset=True)
         print(f"multi-variant {mv}: r={name:9s} {ms / k:7.2f} ms per pass ({k} launches)", flush=True)

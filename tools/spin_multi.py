@@ -2,10 +2,11 @@
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("MENDELIHT_HIP_PROBES", "1")     # kernel-shape knobs / A-B switches: the measurement build
 import mendeliht_amd as m
 nrhs, mv, secs = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3])
 x = m.SnpLinAlg.synthetic(500_000, 1_000_000, seed=2024)
-m.lib().mih_set_xtv_multi_variant(mv)
+m.probe_set(multi_variant=mv)
 print("ready", flush=True)
 t0 = time.time()
 while time.time() - t0 < secs:

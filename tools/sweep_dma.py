@@ -5,6 +5,7 @@ import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("MENDELIHT_HIP_PROBES", "1")     # kernel-shape knobs / A-B switches: the measurement build
 import mendeliht_amd as m
 
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
@@ -25,10 +26,10 @@ def check():
             shapes = FP6_SHAPES if fp6 else FP4_SHAPES[digits]
             for mm in ((13, 12, 10, 9, 7, 6, 4, 3, 1) if digits != 428 else (1, 2, 4)):
                 R = np.asfortranarray(rng.standard_normal((n, mm)) * np.exp(rng.uniform(-20, 20, mm)))
-                L.mih_set_xtv_multi_variant(ref_variant)
+                m.probe_set(multi_variant=ref_variant)
                 ref = x.xtv(R)
                 for mv in shapes:
-                    L.mih_set_xtv_multi_variant(mv)
+                    m.probe_set(multi_variant=mv)
                     out = x.xtv(R)
                     same = np.array_equal(out, ref)
                     bad += not same
@@ -37,7 +38,7 @@ def check():
                         print(f"n={n} p={p} digits={digits} m={mm} variant {mv}: MISMATCH max rel {d:.3e}", flush=True)
         print(f"checked n={n} p={p} miss={miss}", flush=True)
     m.set_xtv_digits(0)
-    L.mih_set_xtv_multi_variant(0)
+    m.probe_set(multi_variant=0)
     print("bit-equality:", "OK" if bad == 0 else f"{bad} MISMATCHES", flush=True)
     return bad
 
@@ -45,12 +46,12 @@ def check():
 def time_(x):
     for rnd in range(2):                  # interleaved rounds in one process
         for mv in [6] + FP6_SHAPES:
-            L.mih_set_xtv_multi_variant(mv)
+            m.probe_set(multi_variant=mv)
             for mm in (12, 9, 6, 3):
                 ms, cs = x.bench_xtv_batched(mm, max_fused=4, iters=4, warmup=1)
                 B = x.algorithmic_bytes(mm)
                 print(f"round {rnd} variant {mv:2d} m={mm:2d}: {ms:7.2f} ms  {B / ms / 1e6:6.0f} GB/s ({B / ms / 8e9 * 100:5.1f} % of 8 TB/s)  checksum {cs:.12e}", flush=True)
-    L.mih_set_xtv_multi_variant(0)
+    m.probe_set(multi_variant=0)
 
 
 def single(x):
@@ -58,10 +59,10 @@ def single(x):
     B = x.algorithmic_bytes(1)
     for rnd in range(3):
         for mv in [9] + FP4_SHAPES[428]:
-            L.mih_set_xtv_multi_variant(mv)
+            m.probe_set(multi_variant=mv)
             ms, cs = x.bench_xtv_batched(1, max_fused=4, iters=6, warmup=1)
             print(f"round {rnd} single-fit pass, variant {mv:2d}: {ms:7.3f} ms  {B / ms / 1e6:6.0f} GB/s ({B / ms / 8e9 * 100:5.1f} % of 8 TB/s)  checksum {cs:.12e}", flush=True)
-    L.mih_set_xtv_multi_variant(0)
+    m.probe_set(multi_variant=0)
 
 
 if what in ("check", "all"):

@@ -4,6 +4,7 @@ usage: sweep_half.py            (run it twice, with and without the environment 
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("MENDELIHT_HIP_PROBES", "1")     # kernel-shape knobs / A-B switches: the measurement build
 import mendeliht_amd as m
 
 x = m.SnpLinAlg.synthetic(500_000, 1_000_000, seed=2024)

@@ -5,6 +5,7 @@ import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("MENDELIHT_HIP_PROBES", "1")     # kernel-shape knobs / A-B switches: the measurement build
 import mendeliht_amd as m
 x = m.SnpLinAlg.synthetic(500_000, 1_000_000, seed=2024)
 for rnd in range(2):

@@ -2,6 +2,7 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("MENDELIHT_HIP_PROBES", "1")     # kernel-shape knobs / A-B switches: the measurement build
 import mendeliht_amd as m
 n, p = 500_000, 1_000_000
 x = m.SnpLinAlg.synthetic(n, p, seed=2024)

@@ -34,7 +34,7 @@ print(f"n={n} p={p} k={k}: GPU {res.iter} iterations in {tg:.2f} s, oracle {o['i
 
 if os.environ.get("MIH_CV"):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from conftest import hash_folds
+    hash_folds = m.hash_folds
     eta = x.xv_sparse(supp[:10], beta[:10] * 0.5)
     yb = (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float)
     folds = hash_folds(n, 3)
