@@ -1423,6 +1423,7 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
                             MIH_HIP(hipMemcpyAsync(f.v->df.p, it->second, sizeof(double) * h->p, hipMemcpyDeviceToDevice, s));
                             MIH_TRY(f.v->init_post());
                             h->prof->count(MIH_CNT_SHARED_INIT, 1);
+                            h->prof->count(MIH_CNT_SCORES, 1);          // its initial score, served by a copy
                             continue;
                         }
                     }

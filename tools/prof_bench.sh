@@ -12,3 +12,5 @@ echo "fetch rc=$?"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/prof_${tag}_write -o pmc -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-cv > $R/gpurun_out/prof_${tag}_write.json 2> $R/gpurun_out/prof_${tag}_write.err
 echo "write rc=$?"
 find $R/gpurun_out/prof_${tag}_stats -name "*.csv" | head
+python3 $R/tools/traffic_from_rocpd.py "k_xtv_dma<1, 2, 4, 8, false" "k_xtv_dma<1,2,4,8,fp4>" $(find $R/gpurun_out/prof_${tag}_fetch -name "*results.db" | head -1) $(find $R/gpurun_out/prof_${tag}_write -name "*results.db" | head -1) 500000 1000000 > $R/gpurun_out/${tag}_traffic.json
+cat $R/gpurun_out/${tag}_traffic.json
