@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <thread>
 
 namespace mih {
@@ -425,69 +426,94 @@ int mih_snp_create(const uint8_t *bed_cols, int64_t n, int64_t p, int64_t col_st
     if (n >= (1ll << 31)) { set_error("n must be < 2^31"); return MIH_BAD_DIM; }
     if (dtype != 64) { set_error("only dtype=64 (Float64) is implemented"); return MIH_BAD_ARG; }
     MIH_TRY(select_device(device));
+    const bool trace = probe_env("MENDELIHT_INGEST_TRACE") != nullptr;         // measurement build: where the time of a create goes
+    auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_mark = tnow();
+    auto lap = [&](const char *what) { if (trace) { const double t = tnow(); fprintf(stderr, "ingest: %-28s %8.2f ms\n", what, t - t_mark); t_mark = t; } };
     mih_mat *h = new mih_mat();
     h->kind = 0; h->device = device; h->n = n; h->p = p;
     h->center = center; h->scale = scale; h->impute = impute;
     int rc = alloc_snp(h);
     if (rc) { mih_mat_destroy(h); return rc; }
     if (hipStreamCreate(&h->stream) != hipSuccess) { mih_mat_destroy(h); return MIH_HIP_ERROR; }
+    lap("matrix allocation");
 
-    // Upload pipeline: the caller's (pageable, possibly mmapped) columns are copied by a few host threads into one
-    // of two pinned staging buffers, DMA'd to one of two device buffers on a copy stream and transcoded on the
-    // matrix's stream, so host copy, PCIe transfer and transcode of consecutive chunks overlap.
-    const int64_t chunk_bytes = 256ll << 20;
+    // Upload pipeline (round 3).  T worker threads, each with its own HIP stream, two pinned staging buffers and two device
+    // buffers, pull 16 MB chunks of whole column groups from one queue (small chunks: pinning host memory costs ~0.28 ms per MB, so
+    // the 256 MB of staging are 70 ms of every create -- 1 GB of it was 280 ms, more than the transfer of an 8 GB matrix): copy the caller's (pageable, possibly mmapped) columns into
+    // the pinned buffer, DMA, transcode -- all on the worker's stream, so the only wait is for the worker's OWN buffer of two
+    // chunks ago.  Host copies, PCIe transfers and transcodes of different chunks overlap across the workers; no thread is created
+    // per chunk and nothing synchronises the workers with each other.  (Round 2 staged 256 MB chunks through ONE pair of buffers
+    // with a fork-join copy per chunk: 34 GB/s against the 56-57 GB/s that tools/ingest_probe.hip measures for every scheme that
+    // keeps the link busy -- in-place hipHostRegister in chunks included, so registering the caller's memory buys nothing.)
+    auto fail = [&](int code) { mih_mat_destroy(h); return code; };
+    const int64_t chunk_bytes = 16ll << 20;
     int64_t cols_per_chunk = chunk_bytes / col_stride_bytes / 32 * 32;   // whole column groups
     if (cols_per_chunk < 32) cols_per_chunk = 32;
     if (cols_per_chunk > round_up(p, 32)) cols_per_chunk = round_up(p, 32);
     const size_t buf_bytes = (size_t)(cols_per_chunk * col_stride_bytes);
-    DevBuf<uint8_t> raw[2]; DevBuf<int32_t> cnt;
-    struct Pinned {
-        uint8_t *p[2] = {nullptr, nullptr}; hipStream_t copy = nullptr; hipEvent_t up[2] = {nullptr, nullptr}, used[2] = {nullptr, nullptr};
-        ~Pinned() {
-            for (int i = 0; i < 2; ++i) { if (p[i]) (void)hipHostFree(p[i]); if (up[i]) (void)hipEventDestroy(up[i]); if (used[i]) (void)hipEventDestroy(used[i]); }
-            if (copy) (void)hipStreamDestroy(copy);
-        }
-    } pin;
-    auto fail = [&](int code) { mih_mat_destroy(h); return code; };
-    if ((rc = raw[0].alloc(buf_bytes)) || (rc = raw[1].alloc(buf_bytes)) || (rc = cnt.alloc((size_t)(3 * p)))) return fail(rc);
-    for (int i = 0; i < 2; ++i) {
-        if (hipHostMalloc((void **)&pin.p[i], buf_bytes, hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc of the staging buffer failed"); (void)hipGetLastError(); return fail(MIH_OOM); }
-        if (hipEventCreateWithFlags(&pin.up[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&pin.used[i], hipEventDisableTiming) != hipSuccess) return fail(MIH_HIP_ERROR);
-    }
-    if (hipStreamCreate(&pin.copy) != hipSuccess) return fail(MIH_HIP_ERROR);
+    const int64_t nchunks = (p + cols_per_chunk - 1) / cols_per_chunk;
+    DevBuf<int32_t> cnt;
+    if ((rc = cnt.alloc((size_t)(3 * p)))) return fail(rc);
     if (hipMemsetAsync(cnt.p, 0, sizeof(int32_t) * 3 * (size_t)p, h->stream) != hipSuccess) return fail(MIH_HIP_ERROR);
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(MIH_HIP_ERROR);
     unsigned nth = std::thread::hardware_concurrency();
     nth = nth >= 16 ? 8 : (nth >= 4 ? nth / 2 : 1);
     if (const char *e = getenv("MENDELIHT_INGEST_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 64) nth = (unsigned)v; }
-    auto host_copy = [&](uint8_t *dst, const uint8_t *src, size_t bytes) {
-        if (nth <= 1 || bytes < (8u << 20)) { std::memcpy(dst, src, bytes); return; }
-        std::vector<std::thread> th;
-        size_t per = (bytes + nth - 1) / nth;
-        for (unsigned t = 0; t < nth; ++t) {
-            size_t o = (size_t)t * per; if (o >= bytes) break;
-            size_t len = std::min(per, bytes - o);
-            th.emplace_back([=]() { std::memcpy(dst + o, src + o, len); });
+    if ((int64_t)nth > nchunks) nth = (unsigned)nchunks;
+    std::atomic<int64_t> next_chunk{0};
+    std::atomic<int> failed{0};
+    std::mutex err_mu; std::string err_msg;
+    // one pinned block and one device block for all workers (the runtime serialises allocations anyway)
+    struct Staging {
+        uint8_t *pin = nullptr, *raw = nullptr;
+        ~Staging() { if (pin) (void)hipHostFree(pin); if (raw) (void)hipFree(raw); }
+    } stg;
+    if (hipHostMalloc((void **)&stg.pin, buf_bytes * 2 * nth, hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc of the staging buffers failed"); (void)hipGetLastError(); return fail(MIH_OOM); }
+    if (hipMalloc((void **)&stg.raw, buf_bytes * 2 * nth) != hipSuccess) { set_error("hipMalloc of the staging buffers failed"); (void)hipGetLastError(); return fail(MIH_OOM); }
+    lap("staging buffers");
+    std::atomic<unsigned> worker_no{0};
+    auto worker = [&]() {
+        const unsigned me = worker_no.fetch_add(1);
+        struct Res {
+            uint8_t *pin[2] = {nullptr, nullptr}, *raw[2] = {nullptr, nullptr}; hipStream_t st = nullptr; hipEvent_t done[2] = {nullptr, nullptr};
+            ~Res() {
+                if (st) (void)hipStreamSynchronize(st);
+                for (int i = 0; i < 2; ++i) if (done[i]) (void)hipEventDestroy(done[i]);
+                if (st) (void)hipStreamDestroy(st);
+            }
+        } r;
+        auto bad = [&](const char *what) { std::lock_guard<std::mutex> g(err_mu); if (err_msg.empty()) err_msg = what; failed.store(1); };
+        if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&r.st) != hipSuccess) return bad("ingest worker: stream");
+        for (int i = 0; i < 2; ++i) {
+            r.pin[i] = stg.pin + buf_bytes * (2 * me + i);
+            r.raw[i] = stg.raw + buf_bytes * (2 * me + i);
+            if (hipEventCreateWithFlags(&r.done[i], hipEventDisableTiming) != hipSuccess) return bad("ingest worker: event");
         }
-        for (auto &t : th) t.join();
+        for (int64_t it = 0; !failed.load(); ++it) {
+            const int64_t c = next_chunk.fetch_add(1);
+            if (c >= nchunks) break;
+            const int b = (int)(it & 1);
+            if (it >= 2 && hipEventSynchronize(r.done[b]) != hipSuccess) return bad("ingest worker: wait");      // buffers b are free again
+            const int64_t c0 = c * cols_per_chunk, nc = std::min<int64_t>(cols_per_chunk, p - c0);
+            const size_t bytes = (size_t)(nc * col_stride_bytes);
+            std::memcpy(r.pin[b], bed_cols + c0 * col_stride_bytes, bytes);
+            if (hipMemcpyAsync(r.raw[b], r.pin[b], bytes, hipMemcpyHostToDevice, r.st) != hipSuccess) return bad("ingest worker: H2D copy");
+            dim3 grid((unsigned)((h->nbp + kBpPerBlock - 1) / kBpPerBlock), (unsigned)((nc + 31) / 32));
+            hipLaunchKernelGGL(k_transcode, grid, dim3(256), 0, r.st, r.raw[b], col_stride_bytes, n, p, c0, nc,
+                               reinterpret_cast<uint4 *>(h->X), h->nbp, cnt.p);
+            if (hipEventRecord(r.done[b], r.st) != hipSuccess) return bad("ingest worker: event record");
+        }
+        if (hipStreamSynchronize(r.st) != hipSuccess) return bad("transcode kernel failed");
     };
-    int64_t chunk = 0;
-    for (int64_t c0 = 0; c0 < p; c0 += cols_per_chunk, ++chunk) {
-        const int b = (int)(chunk & 1);
-        int64_t nc = (p - c0 < cols_per_chunk) ? p - c0 : cols_per_chunk;
-        const size_t bytes = (size_t)(nc * col_stride_bytes);
-        if (chunk >= 2) {      // staging buffer b: its DMA must have finished; device buffer b: its transcode must have finished
-            if (hipEventSynchronize(pin.up[b]) != hipSuccess) return fail(MIH_HIP_ERROR);
-            if (hipStreamWaitEvent(pin.copy, pin.used[b], 0) != hipSuccess) return fail(MIH_HIP_ERROR);
-        }
-        host_copy(pin.p[b], bed_cols + c0 * col_stride_bytes, bytes);
-        if (hipMemcpyAsync(raw[b].p, pin.p[b], bytes, hipMemcpyHostToDevice, pin.copy) != hipSuccess) return fail(MIH_HIP_ERROR);
-        if (hipEventRecord(pin.up[b], pin.copy) != hipSuccess) return fail(MIH_HIP_ERROR);
-        if (hipStreamWaitEvent(h->stream, pin.up[b], 0) != hipSuccess) return fail(MIH_HIP_ERROR);
-        dim3 grid((unsigned)((h->nbp + kBpPerBlock - 1) / kBpPerBlock), (unsigned)((nc + 31) / 32));
-        hipLaunchKernelGGL(k_transcode, grid, dim3(256), 0, h->stream, raw[b].p, col_stride_bytes, n, p, c0, nc,
-                           reinterpret_cast<uint4 *>(h->X), h->nbp, cnt.p);
-        if (hipEventRecord(pin.used[b], h->stream) != hipSuccess) return fail(MIH_HIP_ERROR);
+    if (nth <= 1) worker();
+    else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nth; ++t) th.emplace_back(worker);
+        for (auto &t : th) t.join();
     }
+    if (failed.load()) { set_error("%s", err_msg.c_str()); (void)hipGetLastError(); return fail(MIH_HIP_ERROR); }
+    lap("copy + DMA + transcode");
     if (hipStreamSynchronize(h->stream) != hipSuccess) { set_error("transcode kernel failed"); return fail(MIH_HIP_ERROR); }
     hipLaunchKernelGGL(k_col_stats, dim3((unsigned)((p + 255) / 256)), dim3(256), 0, h->stream, cnt.p, n, p, h->mu, h->sinv);
     std::vector<int32_t> hcnt((size_t)(3 * p));
@@ -498,7 +524,9 @@ int mih_snp_create(const uint8_t *bed_cols, int64_t n, int64_t p, int64_t col_st
         hipLaunchKernelGGL(k_missing_from_tiles, dim3((unsigned)h->ncg), dim3(64), 0, h->stream, reinterpret_cast<uint4 *>(h->X), h->nbp, p,
                            h->miss_ptr, h->miss_row);
     if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(MIH_HIP_ERROR);
+    lap("statistics + missing lists");
     reserve_fit_memory(h);
+    lap("reserve for the fits");
     *out = h;
     return MIH_OK;
 }
