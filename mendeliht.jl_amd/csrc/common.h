@@ -99,7 +99,7 @@ struct DevPool {
     }
 };
 inline DevPool *&current_pool() { static thread_local DevPool *q = nullptr; return q; }
-struct PoolScope {
+struct PoolScope {          // (a lane opens ONE for its whole thread, before any coroutine starts: not a coop_blocked scope)
     DevPool *prev;
     explicit PoolScope(DevPool *q) : prev(current_pool()) { current_pool() = q; }
     ~PoolScope() { current_pool() = prev; }
@@ -153,10 +153,19 @@ struct Arena {
     }
 };
 inline Arena *&current_arena() { static thread_local Arena *a = nullptr; return a; }
+// Cooperative waits.  In a lock-step round the fits of a lane are coroutines of ONE host thread (CoopSched, fit.hip): a fit that
+// reaches a readback does not spin -- it yields, and the thread queues the next fit's kernels meanwhile.  Allocation scopes are
+// thread-local state living on a coroutine's stack, so nothing may yield while one is open (coop_blocked).
+struct CoopSched { virtual void yield() = 0; virtual ~CoopSched() {} };
+inline CoopSched *&current_coop() { static thread_local CoopSched *c = nullptr; return c; }
+inline int &coop_blocked() { static thread_local int d = 0; return d; }
+inline bool coop_can_yield() { return current_coop() != nullptr && coop_blocked() == 0; }
+// hipStreamSynchronize that lets the lane's other fits run while this one's stream drains
+int stream_sync_coop(hipStream_t s);
 struct ArenaScope {
     Arena *prev;
-    explicit ArenaScope(Arena *a) : prev(current_arena()) { current_arena() = a; }
-    ~ArenaScope() { current_arena() = prev; }
+    explicit ArenaScope(Arena *a) : prev(current_arena()) { current_arena() = a; ++coop_blocked(); }
+    ~ArenaScope() { current_arena() = prev; --coop_blocked(); }
 };
 
 // RAII device buffer
@@ -309,7 +318,16 @@ struct mih_mat {
     mih::DevPool *pool = nullptr;  // reserve for the fits that run on this matrix (large 2-bit matrices only)
     std::shared_ptr<mih::DevPool> pool_owner;      // a session keeps a reference: the reserve outlives a matrix destroyed first
     std::shared_ptr<mih::Profile> prof = std::make_shared<mih::Profile>();    // measurement hook (mih_profile_*), off by default
+    // Streams for the small per-fit kernel chains of the lock-step drivers (worker_stream below): created on first use, kept for
+    // the life of the matrix -- hipStreamCreate costs ~4 ms, a fresh set per cross-validation would cost more than it saves.
+    mutable std::mutex ws_mu;
+    mutable std::vector<hipStream_t> worker_streams;
 };
+namespace mih {
+constexpr int kWorkerStreamsPerLane = 4;       // the runtime maps streams onto a handful of hardware queues anyway
+// stream i of the matrix's worker set (i < 2 * kWorkerStreamsPerLane); nullptr if it cannot be created
+hipStream_t worker_stream(const mih_mat *h, int i);
+}
 
 namespace mih {
 

@@ -12,6 +12,7 @@
 #include "fit_common.h"
 #include <map>
 #include <functional>
+#include <ucontext.h>
 #include <atomic>
 #include <mutex>
 #include <thread>
@@ -452,8 +453,11 @@ struct IhtVar {
     // shared_stream != null: this variable is one of a lock-step batch (mih_cv_iht): it runs on the
     // batch's stream and leaves the X'r pass to the batch driver.
     // y_shared / z_shared: device copies of y and z that outlive this variable (a lock-step lane uploads them once for all its fits)
+    // fit_stream: a lock-step fit that queues its small kernels on one of the matrix's worker streams instead of the lane's (the
+    // chains of a lane's fits overlap on the device); `ev` orders it against the lane's stream around the fused pass
+    hipEvent_t ev = nullptr;
     int create(const mih_mat *hh, const mih_fit_params *prm, const double *yh, const double *zh, int64_t qq,
-               hipStream_t shared_stream = nullptr, double *y_shared = nullptr, double *z_shared = nullptr)
+               hipStream_t shared_stream = nullptr, double *y_shared = nullptr, double *z_shared = nullptr, hipStream_t fit_stream = nullptr)
     {
         h = hh; n = h->n; p = h->p; q = (int)qq; y_host = yh; z_host = zh; init_beta = prm->init_beta; tune = xtv_tune(prm);
         reserve = h->pool_owner;
@@ -472,7 +476,11 @@ struct IhtVar {
         if (prm->ks && prm->nks > 0) { ks.assign(prm->ks, prm->ks + prm->nks); k = 0; }
         zkeep.resize(q); zkeepn = 0;
         for (int l = 0; l < q; ++l) { zkeep[l] = prm->zkeep ? (prm->zkeep[l] != 0) : 1; zkeepn += zkeep[l]; }
-        if (shared_stream) { s = shared_stream; own_stream = false; batched = true; }
+        if (shared_stream && fit_stream) {
+            s = fit_stream; own_stream = false; batched = true;           // the stream belongs to the matrix (worker_stream)
+            MIH_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        }
+        else if (shared_stream) { s = shared_stream; own_stream = false; batched = true; }
         else MIH_HIP(hipStreamCreate(&s));
         nb = (int)nblk(n);
         int64_t kcap = std::max<int64_t>(std::max<int64_t>(J, 1) * k + q, 64) + 1024;
@@ -534,7 +542,7 @@ struct IhtVar {
     }
     // the last readback may have been a polled one (SpinFlag): the publishing kernel can still be retiring.  Drain the stream before
     // its buffers go (releasing the arena under a stream that was destroyed with work in flight leaked the block).
-    ~IhtVar() { if (s) (void)hipStreamSynchronize(s); if (s && own_stream) (void)hipStreamDestroy(s); }
+    ~IhtVar() { if (s) (void)hipStreamSynchronize(s); if (s && own_stream) (void)hipStreamDestroy(s); if (ev) (void)hipEventDestroy(ev); }
 
     // v.k = sparsity (cross_validation.jl:110): with groups and a scalar k the projection reads k from the device
     int set_k(int64_t knew)
@@ -693,7 +701,7 @@ struct IhtVar {
             if ((size_t)nnz + kMaxQ > hpin.n) { MIH_HIP(hipStreamSynchronize(s)); take_df2(); MIH_TRY(hpin.alloc((size_t)nnz * 2 + kMaxQ + 16, true)); }
             MIH_HIP(hipMemcpyAsync(hpin.p, gval.p, sizeof(double) * nnz, hipMemcpyDeviceToHost, s));
         }
-        MIH_HIP(hipStreamSynchronize(s));
+        MIH_TRY(stream_sync_coop(s));                // (a lane's other fits go on meanwhile)
         for (int64_t t = 0; t < nnz; ++t) idx.val[t] = hpin.p[t];
         take_df2();
         return MIH_OK;
@@ -950,7 +958,7 @@ struct IhtVar {
     int init_post()
     {
         MIH_TRY(score_post());
-        MIH_HIP(hipStreamSynchronize(s));
+        MIH_TRY(stream_sync_coop(s));
         take_df2();
         if (init_beta) return init_beta_phase(train_cur);
         if (!ks.empty()) {
@@ -1292,13 +1300,78 @@ struct CvFit {
     double *logl_out = nullptr; int64_t *iter_out = nullptr; double *beta_out = nullptr, *c_out = nullptr;
 };
 
+// One host thread, many fits: the per-fit parts of a lock-step round run as coroutines (ucontext) of the lane's thread.  A fit
+// that reaches a readback (spin_wait / stream_sync_coop, common.h) yields, and the thread goes on queueing the next fit's
+// kernels -- each fit on a stream of its own, so the chains also overlap on the device.  Round 2 walked the fits one after
+// the other on the lane's stream: 13 fits x (26 launches + 3 waits) = 3.3 - 3.5 ms between two fused passes of a GPU's share.
+// Tasks run to completion even when one fails (their stacks hold objects with destructors); the first error is returned.
+struct LaneSched : CoopSched {
+    struct Task { ucontext_t ctx; std::function<int()> fn; int rc = MIH_OK; bool done = false; };
+    static constexpr size_t kStack = 1u << 20;
+    ucontext_t main_ctx;
+    Task *cur = nullptr;
+    std::vector<std::unique_ptr<char[]>> stacks;           // reused from round to round
+    bool enabled = true;
+    void yield() override { Task *t = cur; swapcontext(&t->ctx, &main_ctx); }
+    static void entry(unsigned lo, unsigned hi)
+    {
+        Task *t = reinterpret_cast<Task *>(((uintptr_t)hi << 32) | (uintptr_t)lo);
+        t->rc = t->fn();
+        t->done = true;                                    // returning switches to uc_link = the scheduler
+    }
+    int run(std::vector<std::function<int()>> &fns)
+    {
+        int first = MIH_OK;
+        std::string first_msg;
+        auto note = [&](int rc) {
+            if (rc != MIH_OK && first == MIH_OK) { first = rc; char buf[512]; (void)mih_last_error(buf, sizeof(buf)); first_msg = buf; }
+        };
+        if (!enabled || fns.size() < 2) {
+            for (auto &f : fns) { const int rc = f(); note(rc); if (rc) break; }
+        } else {
+            std::vector<Task> tasks(fns.size());           // fixed size: the contexts hold pointers into it
+            while (stacks.size() < fns.size()) stacks.emplace_back(new char[kStack]);
+            for (size_t i = 0; i < fns.size(); ++i) {
+                Task &t = tasks[i];
+                t.fn = fns[i];
+                getcontext(&t.ctx);
+                t.ctx.uc_stack.ss_sp = stacks[i].get();
+                t.ctx.uc_stack.ss_size = kStack;
+                t.ctx.uc_link = &main_ctx;
+                const uintptr_t q = reinterpret_cast<uintptr_t>(&t);
+                makecontext(&t.ctx, reinterpret_cast<void (*)()>(entry), 2, (unsigned)(q & 0xFFFFFFFFu), (unsigned)(q >> 32));
+            }
+            CoopSched *prev = current_coop();
+            current_coop() = this;
+            for (size_t left = tasks.size(); left > 0;) {
+                for (auto &t : tasks) {
+                    if (t.done) continue;
+                    cur = &t;
+                    swapcontext(&main_ctx, &t.ctx);
+                    if (t.done) { --left; note(t.rc); }
+                }
+            }
+            cur = nullptr;
+            current_coop() = prev;
+        }
+        if (first != MIH_OK) set_error("%s", first_msg.c_str());
+        return first;
+    }
+};
+
+// the lane's stream waits for everything fit f has queued on its own stream (f.v->s != lane stream only with private streams)
+static int fit_to_lane(CvFit &f, hipStream_t lane_s);
+static int lane_to_fit(CvFit &f, hipStream_t lane_s, hipEvent_t lane_ev);
+
 static int cv_batched_xtv(const mih_mat *h, XtvWork &xw, std::vector<CvFit *> &fits, DevBuf<double> &R, DevBuf<double> &DF,
                           hipStream_t s)
 {
     const int m = (int)fits.size();
     if (m == 0) return MIH_OK;
-    for (int t = 0; t < m; ++t)
+    for (int t = 0; t < m; ++t) {
+        MIH_TRY(fit_to_lane(*fits[t], s));                 // its residual is ready
         MIH_HIP(hipMemcpyAsync(R.p + (size_t)t * h->n, fits[t]->v->r.p, sizeof(double) * h->n, hipMemcpyDeviceToDevice, s));
+    }
     MIH_TRY(xtv_device(h, xw, R.p, m, DF.p, s));
     for (int t = 0; t < m; ++t)
         MIH_HIP(hipMemcpyAsync(fits[t]->v->df.p, DF.p + (size_t)t * h->p, sizeof(double) * h->p, hipMemcpyDeviceToDevice, s));
@@ -1333,6 +1406,20 @@ static int cv_finish(CvFit &f, double *mses_raw)
     return MIH_OK;
 }
 
+static int fit_to_lane(CvFit &f, hipStream_t lane_s)
+{
+    if (f.v->s == lane_s || !f.v->ev) return MIH_OK;
+    MIH_HIP(hipEventRecord(f.v->ev, f.v->s));
+    MIH_HIP(hipStreamWaitEvent(lane_s, f.v->ev, 0));
+    return MIH_OK;
+}
+static int lane_to_fit(CvFit &f, hipStream_t lane_s, hipEvent_t lane_ev)        // lane_ev has been recorded on lane_s
+{
+    if (f.v->s == lane_s || !f.v->ev) return MIH_OK;
+    MIH_HIP(hipStreamWaitEvent(f.v->s, lane_ev, 0));
+    return MIH_OK;
+}
+
 // The rolling lock-step driver.  `cap` slots; in every round each occupied slot needs exactly one score pass -- a
 // fit that has just been created its initial score (init_pre / init_post, utilities.jl:366-438), a running fit the
 // score that ends its step (step_pre / step_post) -- so ONE fused pass serves all of them, and the slot of a fit
@@ -1341,7 +1428,12 @@ static int cv_finish(CvFit &f, double *mses_raw)
 // The lane keeps the IHTVariables of finished fits and hands them to the fits it starts next (the reference re-uses one
 // IHTVariable per thread the same way, cross_validation.jl:91,110): ~25 hipMalloc / hipFree per fit otherwise, and every
 // hipFree waits for the OTHER lane's fused pass to finish.
-struct CvShared { double *y = nullptr, *z = nullptr; };      // the lane's device copies of y and z (read-only, shared by its fits)
+struct CvShared {                 // what a lane shares with its fits
+    double *y = nullptr, *z = nullptr;       // the lane's device copies of y and z (read-only)
+    std::vector<hipStream_t> streams;        // non-empty: the fits queue their small kernels on these, round-robin (LaneSched)
+    mutable size_t rr = 0;
+    hipStream_t next_stream() const { return streams.empty() ? nullptr : streams[rr++ % streams.size()]; }
+};
 using MakeFit = std::function<int(size_t, CvFit &, hipStream_t, const CvShared &)>;
 
 // Tail of the queue: once no new fits are left, the fits of both lanes thin out and two half-empty fused passes cost far more
@@ -1368,6 +1460,14 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
     std::vector<std::pair<CvFit *, double *>> owners, followers;
     static const bool share_init = probe_env("MENDELIHT_CV_NO_INIT_SHARE") == nullptr;
     bool drained = false;                 // the shared queue is empty
+    LaneSched sched;
+    sched.enabled = !shared.streams.empty();
+    hipEvent_t lane_ev = nullptr;         // "the lane's stream has got this far": the fits' streams wait for it behind the pass
+    MIH_HIP(hipEventCreateWithFlags(&lane_ev, hipEventDisableTiming));
+    struct EvGuard { hipEvent_t e; ~EvGuard() { (void)hipEventDestroy(e); } } ev_guard{lane_ev};
+    struct SlotOut { CvFit *f = nullptr; char fresh = 0; };
+    std::vector<SlotOut> outs((size_t)cap);
+    std::vector<std::function<int()>> tasks;
     auto occupied = [&]() { int c = 0; for (auto &sl : slot) c += sl != nullptr; return c; };
     auto adopt = [&]() {                  // lane 0: take handed-over fits into free slots (caller holds ho->mu)
         for (int t = 0; t < cap && !ho->orphans.empty(); ++t)
@@ -1375,16 +1475,65 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
                 slot[t] = std::move(ho->orphans.back());
                 ho->orphans.pop_back();
                 slot[t]->pool = &pool;
-                slot[t]->v->s = s;
+                if (!slot[t]->v->ev) slot[t]->v->s = s;            // it ran on lane 1's own stream (worker streams belong to the matrix)
             }
     };
     static const bool trace_rounds = probe_env("MENDELIHT_CV_TRACE") != nullptr;
     auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t_round = tnow();
+    double t_round = tnow(), t_pre = 0.0, t_post = 0.0;
     int round_no = 0;
+    // everything of a round that one slot does BEFORE the fused pass: finish or refill, then the step up to its residual
+    auto slot_pre = [&](int t) -> int {
+        for (;;) {
+            if (!slot[t]) {
+                if (drained) return MIH_OK;
+                const size_t i = next.fetch_add(1);
+                if (i >= total) { drained = true; return MIH_OK; }
+                slot[t].reset(new CvFit());
+                slot[t]->pool = &pool;
+                if (!pool.empty()) { slot[t]->v = std::move(pool.back()); pool.pop_back(); }
+                MIH_TRY(make(i, *slot[t], s, shared));
+                CvFit &f = *slot[t];
+                MIH_TRY(f.v->init_pre(f.train.empty() ? nullptr : f.train.data()));
+                if (share_init && f.init_key >= 0) {
+                    auto it = df0.find(f.init_key);
+                    if (it != df0.end()) {       // its initial X'r is known from an earlier round: no pass, straight on to its first step
+                        MIH_HIP(hipMemcpyAsync(f.v->df.p, it->second, sizeof(double) * h->p, hipMemcpyDeviceToDevice, f.v->s));    // (written on the lane's stream rounds ago)
+                        MIH_TRY(f.v->init_post());
+                        h->prof->count(MIH_CNT_SHARED_INIT, 1);
+                        h->prof->count(MIH_CNT_SCORES, 1);          // its initial score, served by a copy
+                        continue;
+                    }
+                }
+                outs[(size_t)t] = SlotOut{&f, 1};
+                return MIH_OK;
+            }
+            CvFit &f = *slot[t];
+            if (!f.done && f.iter >= pr.max_iter) MIH_TRY(cv_finish(f, mses_raw));        // fit.jl:170-179
+            if (f.done) { slot[t].reset(); continue; }                                    // refill this slot
+            f.best = f.v->save_prev(f.next_logl, f.best);
+            MIH_TRY(f.v->step_pre(f.next_logl, pr.max_step, &f.nbt, &f.next_logl));
+            outs[(size_t)t] = SlotOut{&f, 0};
+            return MIH_OK;
+        }
+    };
+    // ... and AFTER it: the fit takes its X'r, ends the step (or its initialisation) and decides whether it is done
+    auto slot_post = [&](CvFit *f, char is_fresh) -> int {
+        if (is_fresh) return f->v->init_post();
+        MIH_TRY(f->v->step_post(f->next_logl));
+        double sc = f->v->check_convergence();
+        if (f->iter >= pr.min_iter && sc < pr.tol) MIH_TRY(cv_finish(*f, mses_raw));     // fit.jl:197-203
+        else f->iter++;
+        return MIH_OK;
+    };
     for (;;) {
         h->prof->count(MIH_CNT_ROUNDS, 1);
-        if (trace_rounds) { const double t = tnow(); fprintf(stderr, "lane %d round %d: %.2f ms, %zu scores\n", lane_id, round_no++, t - t_round, need.size()); t_round = t; }
+        if (trace_rounds) {
+            const double t = tnow();
+            fprintf(stderr, "lane %d round %d: %.2f ms (before the pass %.2f ms, behind it %.2f ms of host time), %zu scores\n", lane_id, round_no++,
+                    t - t_round, t_pre, t_post, need.size());
+            t_round = t;
+        }
         if (ho && lane_id == 0) {
             std::lock_guard<std::mutex> g(ho->mu);
             adopt();
@@ -1395,9 +1544,9 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
             const int mine = occupied();
             std::lock_guard<std::mutex> g(ho->mu);
             if (mine > 0 && ho->accepting && mine + ho->active0.load() <= cap) {
-                //  a handed-over fit is quiescent: it forgets this lane's stream, which is destroyed when the lane returns
-                // (an orphan that is never adopted -- lane 0 failed -- must not synchronise a dead stream in ~IhtVar)
-                for (auto &sl : slot) if (sl) { sl->pool = nullptr; sl->v->s = nullptr; ho->orphans.push_back(std::move(sl)); }
+                //  a handed-over fit is quiescent: if it ran on this lane's stream it forgets it -- the stream is destroyed
+                // when the lane returns, and an orphan that is never adopted (lane 0 failed) must not synchronise a dead stream
+                for (auto &sl : slot) if (sl) { sl->pool = nullptr; if (!sl->v->ev) sl->v->s = nullptr; ho->orphans.push_back(std::move(sl)); }
                 ho->active0.fetch_add(mine);
                 h->prof->count(MIH_CNT_HANDOVERS, 1);
                 if (inflight) inflight[lane_id].store(0);
@@ -1405,40 +1554,12 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
             }
         }
         need.clear(); fresh.clear();
-        for (int t = 0; t < cap; ++t) {
-            for (;;) {
-                if (!slot[t]) {
-                    if (drained) break;
-                    const size_t i = next.fetch_add(1);
-                    if (i >= total) { drained = true; break; }
-                    slot[t].reset(new CvFit());
-                    slot[t]->pool = &pool;
-                    if (!pool.empty()) { slot[t]->v = std::move(pool.back()); pool.pop_back(); }
-                    MIH_TRY(make(i, *slot[t], s, shared));
-                    CvFit &f = *slot[t];
-                    MIH_TRY(f.v->init_pre(f.train.empty() ? nullptr : f.train.data()));
-                    if (share_init && f.init_key >= 0) {
-                        auto it = df0.find(f.init_key);
-                        if (it != df0.end()) {       // its initial X'r is known from an earlier round: no pass, straight on to its first step
-                            MIH_HIP(hipMemcpyAsync(f.v->df.p, it->second, sizeof(double) * h->p, hipMemcpyDeviceToDevice, s));
-                            MIH_TRY(f.v->init_post());
-                            h->prof->count(MIH_CNT_SHARED_INIT, 1);
-                            h->prof->count(MIH_CNT_SCORES, 1);          // its initial score, served by a copy
-                            continue;
-                        }
-                    }
-                    need.push_back(&f); fresh.push_back(1);
-                    break;
-                }
-                CvFit &f = *slot[t];
-                if (!f.done && f.iter >= pr.max_iter) MIH_TRY(cv_finish(f, mses_raw));        // fit.jl:170-179
-                if (f.done) { slot[t].reset(); continue; }                                    // refill this slot
-                f.best = f.v->save_prev(f.next_logl, f.best);
-                MIH_TRY(f.v->step_pre(f.next_logl, pr.max_step, &f.nbt, &f.next_logl));
-                need.push_back(&f); fresh.push_back(0);
-                break;
-            }
-        }
+        const double t_a = tnow();
+        tasks.clear();
+        for (int t = 0; t < cap; ++t) { outs[(size_t)t] = SlotOut(); tasks.emplace_back([&slot_pre, t]() { return slot_pre(t); }); }
+        MIH_TRY(sched.run(tasks));
+        for (int t = 0; t < cap; ++t) if (outs[(size_t)t].f) { need.push_back(outs[(size_t)t].f); fresh.push_back(outs[(size_t)t].fresh); }
+        t_pre = tnow() - t_a;
         if (need.empty()) {
             if (ho && lane_id == 0) {                    // leave only when nothing was handed over in the meantime
                 std::lock_guard<std::mutex> g(ho->mu);
@@ -1475,15 +1596,17 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
         MIH_TRY(cv_batched_xtv(h, xw, riders, R, DF, s));
         for (auto &o : owners) MIH_HIP(hipMemcpyAsync(o.second, o.first->v->df.p, sizeof(double) * h->p, hipMemcpyDeviceToDevice, s));
         owners.clear();
-        for (auto &fo : followers) MIH_HIP(hipMemcpyAsync(fo.first->v->df.p, fo.second, sizeof(double) * h->p, hipMemcpyDeviceToDevice, s));
-        for (size_t t = 0; t < need.size(); ++t) {
-            CvFit *f = need[t];
-            if (fresh[t]) { MIH_TRY(f->v->init_post()); continue; }
-            MIH_TRY(f->v->step_post(f->next_logl));
-            double sc = f->v->check_convergence();
-            if (f->iter >= pr.min_iter && sc < pr.tol) MIH_TRY(cv_finish(*f, mses_raw));     // fit.jl:197-203
-            else f->iter++;
+        for (auto &fo : followers) {
+            MIH_TRY(fit_to_lane(*fo.first, s));            // (its stream has nothing pending on df, but keep the order explicit)
+            MIH_HIP(hipMemcpyAsync(fo.first->v->df.p, fo.second, sizeof(double) * h->p, hipMemcpyDeviceToDevice, s));
         }
+        MIH_HIP(hipEventRecord(lane_ev, s));
+        for (CvFit *f : need) MIH_TRY(lane_to_fit(*f, s, lane_ev));
+        const double t_b = tnow();
+        tasks.clear();
+        for (size_t t = 0; t < need.size(); ++t) { CvFit *f = need[t]; const char fr = fresh[t]; tasks.emplace_back([&slot_post, f, fr]() { return slot_post(f, fr); }); }
+        MIH_TRY(sched.run(tasks));
+        t_post = tnow() - t_b;
     }
     return MIH_OK;
 }
@@ -1526,7 +1649,13 @@ static int cv_run_lanes(const mih_mat *h, const mih_fit_params &pr, size_t total
         MIH_TRY(yd.alloc((size_t)h->n)); MIH_TRY(zd.alloc((size_t)h->n * (size_t)q));  // outlive the lane (its fits may be handed over)
         MIH_HIP(hipMemcpyAsync(yd.p, y_host, sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice, s));
         MIH_HIP(hipMemcpyAsync(zd.p, z_host, sizeof(double) * (size_t)h->n * (size_t)q, hipMemcpyHostToDevice, s));
+        MIH_HIP(hipStreamSynchronize(s));                         // the fits read y and z from their own streams
         CvShared shared; shared.y = yd.p; shared.z = zd.p;
+        if (probe_env("MENDELIHT_CV_NO_COOP") == nullptr)             // A/B (measurement build): round 2's walk, one fit after the other on the lane's stream
+            for (int i = 0; i < kWorkerStreamsPerLane; ++i) {
+                hipStream_t ws = worker_stream(h, (lane_id % 2) * kWorkerStreamsPerLane + i);
+                if (ws) shared.streams.push_back(ws);
+            }
         return cv_run_rolling(h, pr, total, next, cap, make, xw, R, DF, s, mses_raw, merge_tail ? &handover : nullptr, lane_id, init_slots, shared, lanes == 2 ? inflight : nullptr);
     };
     if (lanes == 1) return lane(0);
@@ -1636,7 +1765,7 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, con
         if (f.v) MIH_TRY(f.v->set_k(path[ik]));           // a recycled IHTVariable: v.k = sparsity (cross_validation.jl:110)
         else {
             f.v.reset(new IhtVar());
-            MIH_TRY(f.v->create(h, &pr, y, z, q, s, sh.y, sh.z));     // sized for max(path), then
+            MIH_TRY(f.v->create(h, &pr, y, z, q, s, sh.y, sh.z, sh.next_stream()));     // sized for max(path), then
             MIH_TRY(f.v->set_k(path[ik]));
         }
         f.train.resize(n);
@@ -1696,7 +1825,7 @@ int mih_fit_iht_path(const mih_mat *h, const mih_fit_params *prm, const double *
         f.init_key = 0;                                    // every fit of the path starts from the same residual (all rows)
         if (!f.v) {                                        // else: recycled from the lane's pool
             f.v.reset(new IhtVar());
-            MIH_TRY(f.v->create(h, &pr, y, z, q, s, sh.y, sh.z));     // sized for max(path)
+            MIH_TRY(f.v->create(h, &pr, y, z, q, s, sh.y, sh.z, sh.next_stream()));     // sized for max(path)
         }
         return f.v->set_k(path[mine[t]]);
     };

@@ -338,6 +338,19 @@ static int alloc_snp(mih_mat *h)
     return MIH_OK;
 }
 
+hipStream_t worker_stream(const mih_mat *h, int i)
+{
+    std::lock_guard<std::mutex> g(h->ws_mu);
+    if (i < 0 || i >= 2 * kWorkerStreamsPerLane) return nullptr;
+    if ((int)h->worker_streams.size() <= i) h->worker_streams.resize((size_t)i + 1, nullptr);
+    if (!h->worker_streams[(size_t)i]) {
+        hipStream_t st = nullptr;
+        if (hipStreamCreate(&st) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        h->worker_streams[(size_t)i] = st;
+    }
+    return h->worker_streams[(size_t)i];
+}
+
 }  // namespace mih
 
 using namespace mih;
@@ -622,6 +635,8 @@ int mih_mat_destroy(mih_mat *h)
 {
     if (!h) return MIH_OK;
     (void)hipSetDevice(h->device);
+    for (hipStream_t ws : h->worker_streams) if (ws) { (void)hipStreamSynchronize(ws); (void)hipStreamDestroy(ws); }
+    h->worker_streams.clear();
     if (h->X) (void)hipFree(h->X);
     if (h->mu) (void)hipFree(h->mu);
     if (h->sinv) (void)hipFree(h->sinv);

@@ -225,10 +225,29 @@ uint64_t spin_begin(SpinFlag &f)
     if (!f.word.p) { if (f.word.alloc(8, true)) return 0; f.word.p[0] = 0; f.seq = 0; }
     return ++f.seq;
 }
+int stream_sync_coop(hipStream_t s)
+{
+    if (!coop_can_yield()) { MIH_HIP(hipStreamSynchronize(s)); return MIH_OK; }
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e == hipSuccess) return MIH_OK;
+        if (e != hipErrorNotReady) return hip_fail(e, "hipStreamQuery", __FILE__, __LINE__);
+        current_coop()->yield();
+    }
+}
 int spin_wait(hipStream_t s, SpinFlag &f, uint64_t seq)
 {
     const auto t0 = std::chrono::steady_clock::now();
-    for (unsigned it = 0;; ++it) {
+    if (coop_can_yield()) {
+        // a lane's fit: let the thread queue the other fits' chains while this readback is on its way; when every fit of the lane
+        // waits, the scheduler's round-robin is the spin.  After 10 s something is wrong: the synchronise below reports it.
+        for (unsigned it = 0;; ++it) {
+            if (__atomic_load_n(f.word.p, __ATOMIC_ACQUIRE) == seq) return MIH_OK;
+            current_coop()->yield();
+            if ((it & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) break;
+        }
+    }
+    else for (unsigned it = 0;; ++it) {
         if (__atomic_load_n(f.word.p, __ATOMIC_ACQUIRE) == seq) return MIH_OK;
         __builtin_ia32_pause();
         if ((it & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300)) break;
