@@ -882,7 +882,7 @@ __device__ __forceinline__ void xtv_epilogue16_s(const f32x4a (&acc)[CT][NR][2][
 
 // HALF = 1: the second 16-column fragment of the pass's LAST operand holds no residual (1 residual of 10 digits, or 2 of 8,
 // in that operand: m = 3 j + 1 residuals in a pass) and its multiply-adds are left out -- 2 NR - 1 fragment items a step.
-template <int NR, int CT, int WAVES, int D, int MODE = 0, int HALF = 0>       // MODE 3: timing probe, the odd 16-column fragments are skipped (result is NOT X'R)
+template <int NR, int CT, int WAVES, int D, int MODE = 0, int HALF = 0>       // MODE 3: timing probe, the odd 16-column fragments are skipped (result is NOT X'R); MODE 4: round 2's plain 8-byte LDS loads, which the compiler pairs into ds_read2_b64 (A/B for the bank-conflict fix; same result)
 __global__ void __launch_bounds__(WAVES * 64, 1)
 k_xtv_dma16(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *__restrict__ dig, const uint2 *__restrict__ dig2,
             int64_t dig_stride, int splits, DigitMode dm, const double *__restrict__ scal,
@@ -965,15 +965,17 @@ k_xtv_dma16(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *
             const int v = item >> 1, e = item & 1;
             const char *q = ldsb + st * STAGE + DOS + v * OPB;
             const i32x4v lo = *reinterpret_cast<const i32x4v *>(q + e * 1024 + lane * 16);
-            const i32x2v hi = lds_read_b64(q + 2048 + e * 512 + lane * 8);
+            const i32x2v hi = MODE == 4 ? *reinterpret_cast<const i32x2v *>(q + 2048 + e * 512 + lane * 8) : lds_read_b64(q + 2048 + e * 512 + lane * 8);
             b = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], 0, 0};
         };
         auto read_dos = [&](int st, i32x2v (&raw)[CT][2]) {
             #pragma unroll
             for (int c = 0; c < CT; ++c)
                 #pragma unroll
-                for (int a = 0; a < 2; ++a)
-                    raw[c][a] = lds_read_b64(ldsb + st * STAGE + mydos + c * 1024 + a * 256 + aoff);
+                for (int a = 0; a < 2; ++a) {
+                    const char *q = ldsb + st * STAGE + mydos + c * 1024 + a * 256 + aoff;
+                    raw[c][a] = MODE == 4 ? *reinterpret_cast<const i32x2v *>(q) : lds_read_b64(q);
+                }
         };
         auto expand = [&](const i32x2v (&raw)[CT][2], i32x4v (&a)[CT][2]) {
             const int M = 0x33333333 & amask;

@@ -1,4 +1,3 @@
-import os
 """All BASELINE.json configs beside the bench.py headline (configs[2]) in one run; writes one JSON object.
 
   configs[1]  dense Float64 50 000 x 100 000, k=100, Normal          (X'r GB/s, ms/iteration)

@@ -1,4 +1,3 @@
-import os
 """cv_iht wall time on the BASELINE configs[3] geometry: path=1:20, 5 folds, Bernoulli/Logit.
 --world W --rank R runs the share of (fold,k) combinations GPU R of W would own."""
 import argparse, os, sys, time
