@@ -61,8 +61,10 @@ int mih_abi_sizes(int64_t *sizes, int32_t n);
  *      center, scale, impute) as constructed at src/wrapper.jl:68-69 and test/L0_reg_test.jl:11.
  * bed_cols: p columns of PLINK .bed body (after the 3-byte header), each
  * col_stride_bytes >= ceil(n/4) bytes, codes 00->0, 01->missing, 10->1, 11->2.
- * dtype must be 64 (Float64): SnpLinAlg{Float32} is deliberately unsupported -- the 2-bit matrix has no element type on
- * the device and every dot product is exact fixed point recombined in Float64 (MIH_BAD_ARG otherwise).  Uploads once; computes mu_j (mean of non-missing
+ * dtype is the caller's element type T, 64 or 32 (src/MendelIHT.jl:39: Float = Union{Float64, Float32}; MIH_BAD_ARG otherwise).  It
+ * changes nothing on the device -- the 2-bit matrix has no element type there and every dot product is exact fixed point
+ * recombined in Float64 -- so a SnpLinAlg{Float32} caller gets results at least as accurate as the reference's all-Float32 run:
+ * the binding converts y, z to Float64 on the way in and the model to Float32 on the way out.  Uploads once; computes mu_j (mean of non-missing
  * dosages) and sinv_j = 1/sqrt(mu_j(1-mu_j/2)) (1 when that sqrt is 0) on device. */
 int mih_snp_create(const uint8_t *bed_cols, int64_t n, int64_t p, int64_t col_stride_bytes,
                    int center, int scale, int impute, int dtype, int device, mih_mat **out);

@@ -47,21 +47,21 @@ mutable struct HipSnpLinAlg{T} <: AbstractMatrix{T}
     impute::Bool
 end
 
-function HipSnpLinAlg{Float64}(s::SnpArray; center::Bool=false, scale::Bool=false,
-                               impute::Bool=true, device::Integer=0)
+# T = Float64 or Float32 (src/MendelIHT.jl:39).  The device matrix has no element type: T only decides what the fits hand back
+function HipSnpLinAlg{T}(s::SnpArray; center::Bool=false, scale::Bool=false,
+                         impute::Bool=true, device::Integer=0) where {T <: Union{Float64, Float32}}
     n, p = size(s)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     # s.data is the mmapped .bed body: ceil(n/4) x p UInt8, column-major = p columns of stride bytes
     check(ccall((:mih_snp_create, LIB), Cint,
         (Ptr{UInt8}, Int64, Int64, Int64, Cint, Cint, Cint, Cint, Cint, Ref{Ptr{Cvoid}}),
-        s.data, n, p, size(s.data, 1), center, scale, impute, 64, device, h))
-    x = HipSnpLinAlg{Float64}(h[], n, p, center, scale, impute)
+        s.data, n, p, size(s.data, 1), center, scale, impute, 8 * sizeof(T), device, h))
+    x = HipSnpLinAlg{T}(h[], n, p, center, scale, impute)
     finalizer(x -> ccall((:mih_mat_destroy, LIB), Cint, (Ptr{Cvoid},), x.handle), x)
     return x
 end
-# SnpLinAlg{Float32} has no device counterpart (the library computes in Float64; include/mendeliht_hip.h)
-HipSnpLinAlg{Float32}(s::SnpArray; kwargs...) =
-    throw(ArgumentError("HipSnpLinAlg{Float32} is not supported: use HipSnpLinAlg{Float64} (arithmetic is Float64 on the device)"))
+# a Float64 view of the same device matrix (no second upload, no finalizer: the Float32 object owns the handle)
+as64(x::HipSnpLinAlg{Float32}) = HipSnpLinAlg{Float64}(x.handle, x.n, x.p, x.center, x.scale, x.impute)
 Base.size(x::HipSnpLinAlg) = (x.n, x.p)
 Base.getindex(x::HipSnpLinAlg, i::Int, j::Int) = error("HipSnpLinAlg lives on the GPU: scalar indexing is not available")
 
@@ -235,6 +235,15 @@ function fit_iht(y::AbstractVector{Float64}, x::HipSnpLinAlg{Float64}, z::Abstra
     return IHTResult(res.time, res.logl, res.iter, beta, c, J, k, Vector{Int}(group), dd, res.pve)
 end
 fit_iht(y::AbstractVector{Float64}, x::HipSnpLinAlg{Float64}; kwargs...) = fit_iht(y, x, ones(length(y)); kwargs...)
+# SnpLinAlg{Float32} callers: Float64 arithmetic on the device, the model back in Float32 (IHTResult{Float32})
+function fit_iht(y::AbstractVector{Float32}, x::HipSnpLinAlg{Float32}, z::AbstractVecOrMat{Float32}=ones(Float32, length(y));
+                 weight::AbstractVector{Float32}=Float32[], tol::Float32=1f-4, kwargs...)
+    r = GC.@preserve x fit_iht(Vector{Float64}(y), as64(x), Float64.(z); weight=Float64.(weight), tol=Float64(tol), kwargs...)
+    d32 = r.d isa NegativeBinomial ? NegativeBinomial(Float32(r.d.r), 0.5f0) : r.d
+    return IHTResult(r.time, Float32(r.logl), r.iter, Float32.(r.beta), Float32.(r.c), r.J, r.k, r.group, d32, Float32(r.σg))
+end
+cv_iht(y::AbstractVector{Float32}, x::HipSnpLinAlg{Float32}, z::AbstractVecOrMat{Float32}; weight::AbstractVector{Float32}=Float32[], kwargs...) =
+    Float32.(GC.@preserve x cv_iht(Vector{Float64}(y), as64(x), Float64.(z); weight=Float64.(weight), kwargs...))
 
 # fit_iht(Y, Transpose(x), Z; ...) with r x n traits  -- src/fit.jl:60-63 on mIHTVariable (src/multivariate.jl);
 # Y is r x n, Z is q x n as in the reference (wrapper.jl:80-85)

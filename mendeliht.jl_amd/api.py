@@ -383,10 +383,15 @@ class _Mat:
 class SnpLinAlg(_Mat):
     """SnpLinAlg{Float64}(s::SnpArray; model=ADDITIVE_MODEL, center, scale, impute) on the GPU."""
 
-    def __init__(self, bed, n=None, center=False, scale=False, impute=True, device=0, _handle=None):
+    def __init__(self, bed, n=None, center=False, scale=False, impute=True, device=0, _handle=None, dtype=np.float64):
+        """dtype: the element type T of SnpLinAlg{T} (np.float64 or np.float32, src/MendelIHT.jl:39).  The device arithmetic is
+        the same for both (exact fixed point + Float64); with float32 the models fit_iht / cv_iht return are cast to float32."""
         super().__init__()
         self.center, self.scale, self.impute = bool(center), bool(scale), bool(impute)
         self.device = device
+        self.dtype = np.dtype(dtype).type
+        if self.dtype not in (np.float64, np.float32):
+            raise ArgumentError("SnpLinAlg{T}: T must be Float64 or Float32")
         if _handle is not None:
             self._h = _handle
             self._dims()
@@ -402,7 +407,7 @@ class SnpLinAlg(_Mat):
             raise ArgumentError("n (number of samples) is required")
         h = C.c_void_p(None)
         _check(lib().mih_snp_create(_p(cols), n, cols.shape[0], cols.shape[1], int(center), int(scale),
-                                    int(impute), 64, device, C.byref(h)))
+                                    int(impute), 32 if self.dtype is np.float32 else 64, device, C.byref(h)))
         self._h = h
         self._dims()
 
@@ -861,6 +866,8 @@ def fit_iht(y, x, z=None, *, k=10, J=1, d=None, l=None, group=None, weight=None,
     if verbose and res.iter >= max_iter:
         print(f"Did not converge after {max_iter} iterations! IHT run time was {res.time} seconds", file=io)
     dd = NegativeBinomial(res.nb_r) if isinstance(d, NegativeBinomial) else d
+    if getattr(x, "dtype", np.float64) is np.float32:          # SnpLinAlg{Float32}: the model comes back in the caller's T
+        beta, c, mu = beta.astype(np.float32), c.astype(np.float32), mu.astype(np.float32)
     return IHTResult(res.time, res.logl, res.iter, beta, c, J, k, np.array([] if group is None else group), dd, res.pve,
                      trace=dict(logl=lt[:m].copy(), tol=tt[:m].copy(), backtracks=bt[:m].copy(), lines=lines),
                      choose_fired=bool(res.choose_fired), mu=mu)

@@ -437,7 +437,10 @@ int mih_snp_create(const uint8_t *bed_cols, int64_t n, int64_t p, int64_t col_st
     if (!bed_cols || !out) { set_error("null argument"); return MIH_BAD_ARG; }
     if (n <= 0 || p <= 0 || col_stride_bytes < (n + 3) / 4) { set_error("bad dimensions n=%lld p=%lld stride=%lld", (long long)n, (long long)p, (long long)col_stride_bytes); return MIH_BAD_DIM; }
     if (n >= (1ll << 31)) { set_error("n must be < 2^31"); return MIH_BAD_DIM; }
-    if (dtype != 64) { set_error("only dtype=64 (Float64) is implemented"); return MIH_BAD_ARG; }
+    if (dtype != 64 && dtype != 32) { set_error("dtype must be 64 (SnpLinAlg{Float64}) or 32 (SnpLinAlg{Float32})"); return MIH_BAD_ARG; }
+    // dtype only records the caller's element type T (src/MendelIHT.jl:39: Float = Union{Float64, Float32}): the 2-bit matrix has no
+    // element type on the device and every dot product is exact fixed point recombined in Float64, whatever T is; a binding for
+    // T = Float32 converts y, z to Float64 on the way in and the model to Float32 on the way out
     MIH_TRY(select_device(device));
     const bool trace = probe_env("MENDELIHT_INGEST_TRACE") != nullptr;         // measurement build: where the time of a create goes
     auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };

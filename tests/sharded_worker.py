@@ -23,8 +23,42 @@ def summary(res):
                 tol=res.trace["tol"].tolist(), choose_fired=bool(res.choose_fired), sigma_g=res.σg)
 
 
+def native_main(out_path):
+    """MIH_NATIVE=1 (needs one GPU per rank): the library's own RCCL exchange (mih_comm_create_rccl: ncclAllReduce / ncclAllGather
+    on a private stream) against the torch.distributed callbacks, rank by rank, bit for bit."""
+    rank, world, local = D.init_from_env(backend="nccl")
+    import torch.distributed as dist
+    n = 1000
+    cols = m.read_bed(os.path.join(FIX, "normal.bed"), n)
+    y = np.loadtxt(os.path.join(FIX, "normal_y_fam6.txt"))
+    z = np.loadtxt(os.path.join(FIX, "covariates.txt"), delimiter=",")
+    z[:, 1:] = (z[:, 1:] - z[:, 1:].mean(axis=0)) / z[:, 1:].std(axis=0, ddof=1)
+    rng = np.random.default_rng(42)
+    n2, p2 = 1501, 2300
+    cols2 = make_bed(rng, n2, p2, missing_rate=0.02)
+    x2 = m.SnpLinAlg(cols2, n=n2, center=True, scale=True, impute=True, device=local)
+    supp = np.sort(rng.choice(p2, 8, replace=False))
+    eta = x2.xv_sparse(supp, rng.standard_normal(8) * 0.7)
+    yb = (rng.random(n2) < 1 / (1 + np.exp(-eta))).astype(float)
+    out = {}
+    for name, (cc, nn, yy, zz, kw) in {"normal_k7": (cols, n, y, z, dict(k=7)),
+                                       "logistic": (cols2, n2, yb, None, dict(k=9, d=m.Bernoulli(), l=m.LogitLink()))}.items():
+        p = cc.shape[0]
+        lo, cnt = D.column_block(p, rank, world)
+        xs = m.SnpLinAlg(cc[lo:lo + cnt], n=nn, center=True, scale=True, impute=True, device=local)
+        a = summary(D.fit_iht_sharded(yy, xs, zz, col_offset=lo, p_global=p, verbose=False, native=True, **kw))
+        b = summary(D.fit_iht_sharded(yy, xs, zz, col_offset=lo, p_global=p, verbose=False, native=False, **kw))
+        out[name] = dict(native=a, callbacks=b)
+    dist.barrier()
+    with open(out_path + f".native.r{rank}", "w") as f:
+        json.dump(dict(world=world, cases=out), f)
+    dist.destroy_process_group()
+
+
 def main():
     out_path = sys.argv[1]
+    if os.environ.get("MIH_NATIVE"):
+        return native_main(out_path)
     rank, world, _ = D.init_from_env(backend="gloo")
     import torch.distributed as dist
 

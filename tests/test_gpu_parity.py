@@ -1719,3 +1719,21 @@ def test_concurrent_fits_with_different_digit_formats(mih):
         assert not errs, errs
         for k in jobs:
             assert np.array_equal(np.asarray(out[k]).view(np.uint64), np.asarray(serial[k]).view(np.uint64)), k
+
+
+def test_snplinalg_float32_callers(mih, normal_data):
+    """T = Float32 (src/MendelIHT.jl:39: Float = Union{Float64, Float32}): SnpLinAlg{Float32} on the 2-bit path.  The device
+    arithmetic does not depend on T, so the Float32 caller gets the Float64 fit, cast: same support, same iterations, beta equal
+    to the Float64 beta rounded to Float32 -- at least as accurate as an all-Float32 run."""
+    n = normal_data["n"]
+    bed = mih.read_bed(normal_data["bed"], n)
+    y, z = normal_data["y"], normal_data["z"]
+    x64 = mih.SnpLinAlg(bed, n, center=True, scale=True, impute=True)
+    x32 = mih.SnpLinAlg(bed, n, center=True, scale=True, impute=True, dtype=np.float32)
+    r64 = mih.fit_iht(y, x64, z, k=7, verbose=False)
+    r32 = mih.fit_iht(y.astype(np.float32).astype(np.float64), x32, z.astype(np.float32).astype(np.float64), k=7, verbose=False)
+    assert r32.beta.dtype == np.float32 and r32.c.dtype == np.float32
+    assert np.array_equal(np.flatnonzero(r32.beta), np.flatnonzero(r64.beta)) and r32.iter == r64.iter
+    np.testing.assert_allclose(r32.beta, r64.beta, rtol=2e-5, atol=1e-7)        # y, z themselves were rounded to Float32
+    with pytest.raises(mih.MendelIHTError):
+        mih.SnpLinAlg(bed, n, dtype=np.float16)

@@ -68,3 +68,26 @@ def test_sharded_fit_matches_single_process(tmp_path, world):
     np.testing.assert_allclose(sh["c"], g["c_printed"], rtol=5e-6)
     assert sh["sigma_g"] == pytest.approx(g["pve"], rel=1e-9)
     assert res["cases"]["ties_choose"]["single"]["choose_fired"]
+
+
+def test_native_rccl_exchange_matches_the_callbacks_on_two_gpus(tmp_path):
+    """The library's own RCCL communicator (mih_comm_create_rccl) with MORE than one rank -- ncclAllReduce / ncclAllGather over
+    xGMI, the hand-declared enum values, the all-gather layout, the ordering against the fit's stream -- against the
+    torch.distributed callbacks: identical results on every rank.  Needs two GPUs (one per rank): skipped on the one-GPU test
+    box, where the native path is covered with a one-rank communicator (test_native_rccl_communicator_world1)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs one GPU per rank (two GPUs)")
+    out = tmp_path / "res.json"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "sharded_worker.py"), str(out)]
+    r = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="4", MIH_NATIVE="1", HSA_ENABLE_IPC_MODE_LEGACY="0"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = [json.load(open(str(out) + f".native.r{k}")) for k in range(2)]
+    for name in res[0]["cases"]:
+        for k in range(2):
+            a, b = res[k]["cases"][name]["native"], res[k]["cases"][name]["callbacks"]
+            assert a == b, (name, k)                                     # every field, bit for bit (json round-trips doubles)
+        assert res[0]["cases"][name]["native"] == res[1]["cases"][name]["native"], name
