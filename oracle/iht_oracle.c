@@ -1028,6 +1028,17 @@ done:
     return rc;
 }
 
+/* The GLM refit of debias! on its own: b[j] for idx[j] != 0 <- the coefficients of fit(GeneralizedLinearModel, x[:, idx], y, d, l).
+ * Exposed so that tests/test_oracle_golden.py can pin this restated IRLS against an independent GLM solver (scikit-learn). */
+int orc_debias_glm(const orc_mat *x, const uint8_t *idx, const double *y, int dist, int link, double nb_r, double *b)
+{
+    ihtvar v;
+    memset(&v, 0, sizeof(v));
+    v.x = x; v.y = y; v.n = x->n; v.p = x->p; v.dist = dist; v.link = link; v.nb_r = nb_r;
+    v.idx = (uint8_t *)idx; v.b = b;
+    return debias(&v);
+}
+
 static int fit_loop(ihtvar *v, const orc_params *prm, double *best_logl_out, int64_t *iter_out,
                     double *lt, double *tt, int32_t *bt, int32_t *ntrace)
 {

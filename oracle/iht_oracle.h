@@ -109,6 +109,10 @@ double orc_loglikelihood(int dist, double nb_r, const double *y, const double *m
 double orc_deviance(int dist, double nb_r, const double *y, const double *mu,
                     const double *wts, int64_t n);
 
+/* debias! (utilities.jl:1014-1020) on its own: the GLM refit of y on the columns with idx[j] != 0 (no intercept, unit
+ * weights); b[j] receives the coefficients.  For pinning the restated GLM.jl IRLS against an independent solver. */
+int orc_debias_glm(const orc_mat *x, const uint8_t *idx, const double *y, int dist, int link, double nb_r, double *b);
+
 /* ---- drivers ------------------------------------------------------------ */
 /* fit_iht (fit.jl:60-118); z is n x q column-major; train = NULL or n flags. */
 int orc_fit_iht(const orc_mat *x, const orc_params *prm, const double *y,

@@ -97,6 +97,7 @@ def lib():
                                    C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64,
                                    C.c_void_p, C.c_void_p]
         _lib.orc_set_threads.argtypes = [C.c_int]
+        _lib.orc_debias_glm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]
     return _lib
 
 
@@ -321,6 +322,21 @@ def cv_mv(x, Y, Z=None, path=range(1, 21), q=5, folds=None, tol=1e-4, max_iter=1
     if rc:
         raise RuntimeError(f"orc_cv_mv rc={rc}")
     return mse, raw.reshape(q, path.size)
+
+
+_DIST = {"normal": 0, "bernoulli": 1, "poisson": 2, "negbin": 3, "gamma": 4, "invgauss": 5}
+_LINK = {"identity": 0, "logit": 1, "log": 2, "probit": 3, "cloglog": 4, "cauchit": 5, "inverse": 6, "invsquare": 7, "sqrt": 8}
+
+
+def debias_glm(x, support_mask, y, dist, link, nb_r=1.0):
+    """debias! (utilities.jl:1014-1020) on its own: GLM refit of y on the columns of the mask; returns the length-p coefficient vector."""
+    m = np.ascontiguousarray(support_mask, dtype=np.uint8)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    b = np.zeros(x.p)
+    rc = lib().orc_debias_glm(x.h, _p(m), _p(y), _DIST[dist], _LINK[link], float(nb_r), _p(b))
+    if rc:
+        raise RuntimeError(f"orc_debias_glm rc={rc}")
+    return b
 
 
 def standardize_columns(z):

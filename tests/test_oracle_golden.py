@@ -274,3 +274,41 @@ def test_oracle_reproduces_its_committed_goldens(oracle):
         assert o["logl"] == pytest.approx(g["logl"], rel=1e-12), name
     mse, _ = oracle.cv_iht(ox, y, z, path=range(1, 9), q=3, folds=hash_folds(n, 3))
     np.testing.assert_allclose(mse, gold["cv_normal_path1_8_q3"]["mse"], rtol=1e-10)
+
+
+def test_glm_refit_of_debias_against_scikit_learn(oracle):
+    """debias! refits the support by GLM (utilities.jl:1014-1020); GLM.jl is not vendored in the reference, so the oracle RESTATES
+    its IRLS (mustart, working response, step halving, rtol = atol = 1e-6 on the deviance).  Pin that restatement against an
+    independent implementation: scikit-learn's unpenalised GLM solvers converge to the same maximum-likelihood coefficients -- to
+    the 1e-6 the IRLS stopping rule allows (Normal/Identity, one exact WLS step: 1e-10 against numpy's least squares)."""
+    from sklearn.linear_model import GammaRegressor, LogisticRegression, PoissonRegressor
+    rng = np.random.default_rng(2026)
+    n, p = 5000, 40
+    X = rng.standard_normal((n, p)) * 0.7
+    ox = oracle.Mat.from_dense(np.asfortranarray(X))
+    mask = np.zeros(p, np.uint8)
+    supp = np.sort(rng.choice(p, 7, replace=False))
+    mask[supp] = 1
+    beta = rng.standard_normal(7) * 0.4
+    eta = X[:, supp] @ beta
+    Xs = X[:, supp]
+    # Normal / Identity: ordinary least squares
+    y = eta + rng.standard_normal(n)
+    b = oracle.debias_glm(ox, mask, y, "normal", "identity")
+    assert np.all(b[mask == 0] == 0)
+    np.testing.assert_allclose(b[supp], np.linalg.lstsq(Xs, y, rcond=None)[0], rtol=1e-10, atol=1e-12)
+    # Bernoulli / Logit
+    yb = (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float)
+    b = oracle.debias_glm(ox, mask, yb, "bernoulli", "logit")
+    ref = LogisticRegression(penalty=None, fit_intercept=False, tol=1e-12, max_iter=2000).fit(Xs, yb).coef_.ravel()
+    np.testing.assert_allclose(b[supp], ref, rtol=0, atol=2e-6)
+    # Poisson / Log
+    yp = rng.poisson(np.exp(0.5 * eta)).astype(float)
+    b = oracle.debias_glm(ox, mask, yp, "poisson", "log")
+    ref = PoissonRegressor(alpha=0, fit_intercept=False, tol=1e-12, max_iter=2000).fit(Xs, yp).coef_
+    np.testing.assert_allclose(b[supp], ref, rtol=0, atol=2e-6)
+    # Gamma / Log (the coefficients of a Gamma GLM do not depend on the dispersion)
+    yg = rng.gamma(2.0, np.exp(0.5 * eta) / 2.0)
+    b = oracle.debias_glm(ox, mask, yg, "gamma", "log")
+    ref = GammaRegressor(alpha=0, fit_intercept=False, tol=1e-12, max_iter=2000).fit(Xs, yg).coef_
+    np.testing.assert_allclose(b[supp], ref, rtol=0, atol=5e-5)        # the deviance of a Gamma fit is flat near the optimum: the 1e-6 stopping rule leaves ~1e-5 in beta
