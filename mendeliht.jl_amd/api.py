@@ -1094,75 +1094,179 @@ def iht_run_many_models(y, x, z=None, *, d=None, l=None, path=range(1, 21), est_
 
 
 # ---- file-level wrappers (src/wrapper.jl) ----------------------------------------------------
-def _read_fam_phenotypes(prefix, col):
-    vals = []
+def _phenotype_is_missing(tok):
+    return tok in ("-9", "NA")                                   # wrapper.jl:251-253
+
+
+def _fam_column(prefix, col, d, n):
+    """parse_phenotypes(x::SnpData, col, d) -- wrapper.jl:171-214: column `col` (1-based) of the .fam file; missing ("-9", "NA")
+    phenotypes are imputed by the mean of the observed ones for quantitative traits and refused for binary / count traits."""
+    toks = []
     with open(prefix + ".fam") as f:
         for line in f:
             parts = line.split()
-            vals.append(float(parts[col - 1]))
-    return np.array(vals)
+            if parts:
+                toks.append(parts[col - 1])
+    if len(toks) != n:
+        raise DimensionMismatch(f"{prefix}.fam has {len(toks)} samples, expected {n}")
+    miss = np.array([_phenotype_is_missing(t) for t in toks])
+    if miss.any() and not isinstance(d, (Normal, MvNormal)):
+        i = int(np.flatnonzero(miss)[0]) + 1
+        raise ArgumentError(f"Missing phenotype detected for sample {i}. Automatic phenotype imputation are only possible for "
+                            "quantitative traits. Please exclude missing phenotypes or impute them first.")
+    y = np.array([0.0 if m_ else float(t) for t, m_ in zip(toks, miss)])
+    if miss.any():
+        y[miss] = y[~miss].sum() / (n - miss.sum())
+    return y
 
 
 def _count_lines(path):
     with open(path) as f:
-        return sum(1 for _ in f)
+        return sum(1 for line in f if line.strip())
 
 
-def _parse_inputs(plinkfile, phenotypes, covariates):
+def parse_phenotypes(plinkfile, phenotypes, d, n):
+    """parse_phenotypes (wrapper.jl:136-224): .fam column(s) or a comma-separated file, one sample per row."""
+    if isinstance(phenotypes, (int, np.integer)):
+        if isinstance(d, MvNormal):
+            raise ArgumentError("Multivariate analysis requires multiple phenotypes! Please specify e.g. phenotypes=[6, 7] or save each "
+                                "sample's phenotypes in a comma-separated file where each sample occupies a different row and each "
+                                "phenotype is separated by a single comma.")
+        return _fam_column(plinkfile, int(phenotypes), d, n)
+    if isinstance(phenotypes, (list, tuple, np.ndarray)):
+        return np.stack([_fam_column(plinkfile, int(c), MvNormal(), n) for c in phenotypes])      # r x n
+    y = np.loadtxt(phenotypes, delimiter=",", ndmin=2)                                            # readdlm(file, ',', Float64)
+    return y.T.copy() if y.shape[1] > 1 else y[:, 0].copy()
+
+
+def parse_covariates(filename, exclude_std_idx=(), standardize_columns=True):
+    """parse_covariates (wrapper.jl:226-249): comma-separated, one sample per row, first column the intercept; every column not in
+    exclude_std_idx (1-based indices or a boolean mask) is standardized, the intercept never."""
+    z = np.loadtxt(filename, delimiter=",", ndmin=2)
+    ex = np.asarray(list(exclude_std_idx))
+    std = np.ones(z.shape[1], dtype=bool)
+    if ex.dtype == bool:
+        std = ~ex
+    elif ex.size:
+        std[ex.astype(int) - 1] = False
+    if np.all(z[:, 0] == 1):
+        std[0] = False
+    else:
+        print("Warning: Covariate file provided but did not detect an intercept. An intercept will NOT be included in IHT!", file=sys.stderr)
+    if standardize_columns and std.any():
+        z[:, std] = standardize(z[:, std])
+    return z
+
+
+def _read_bim(prefix):
+    """chromosome, SNP id, position, allele1, allele2 of the .bim file (what SnpData.snp_info holds, wrapper.jl:451-485)."""
+    chrom, ids, pos, a1, a2 = [], [], [], [], []
+    with open(prefix + ".bim") as f:
+        for line in f:
+            t = line.split()
+            if not t:
+                continue
+            chrom.append(t[0]); ids.append(t[1]); pos.append(t[3]); a1.append(t[4]); a2.append(t[5])
+    return chrom, pos, ids, a1, a2
+
+
+def _parse_inputs(plinkfile, phenotypes, covariates, d, exclude_std_idx=(), dosage=False, device=0):
+    if str(plinkfile).endswith((".vcf", ".vcf.gz", ".bgen")):
+        raise ArgumentError("the GPU path reads binary PLINK trios; VCF / BGEN inputs are numeric matrices in the reference "
+                            "(wrapper.jl:70-71): convert them to a DenseMatrix and call fit_iht / cv_iht")
+    for ext in (".bed", ".bim", ".fam"):
+        if not os.path.exists(plinkfile + ext):
+            raise ArgumentError(f"{plinkfile}{ext} not found: binary PLINK files should exclude .bim/.bed/.fam trailings and the trio "
+                                "must be present in the same directory")
     n = _count_lines(plinkfile + ".fam")
-    x = SnpLinAlg(plinkfile + ".bed", n, center=True, scale=True, impute=True)   # wrapper.jl:68-69
-    if isinstance(phenotypes, int):
-        y = _read_fam_phenotypes(plinkfile, phenotypes)                            # wrapper.jl:136-218
-    elif isinstance(phenotypes, (list, tuple)):
-        y = np.stack([_read_fam_phenotypes(plinkfile, c) for c in phenotypes])
-    else:
-        y = np.loadtxt(phenotypes, delimiter=",", ndmin=1)
-        if y.ndim == 2:
-            y = y.T if y.shape[1] > 1 else y.ravel()
-    if covariates:
-        z = np.loadtxt(covariates, delimiter=",", ndmin=2)                          # wrapper.jl:228-247
-        if z.shape[1] > 1:
-            z[:, 1:] = standardize(z[:, 1:])
-    else:
-        z = np.ones((n, 1))
+    x = SnpLinAlg(plinkfile + ".bed", n, center=True, scale=True, impute=True, device=device)     # wrapper.jl:68-69
+    y = parse_phenotypes(plinkfile, phenotypes, d, n)
+    z = parse_covariates(covariates, exclude_std_idx) if covariates else np.ones((n, 1))
     return x, y, z
 
 
+def _show_result(io, res):
+    """show(io, ::IHTResult / ::mIHTResult) -- data_structures.jl:280-325 (the tables are DataFrames in the reference)."""
+    if isinstance(res, IHTResult):
+        io.write(repr(res) + "\n")
+        return
+    r = res.traits
+    io.write(f"\nCompute time (sec):     {res.time}\nFinal loglikelihood:    {res.logl}\nIterations:             {res.iter}\n")
+    for t in range(r):
+        io.write(f"Trait {t + 1}'s SNP PVE:      {res.σg[t]}\n")
+    io.write("\nEstimated trait covariance:\n")
+    io.write("\t".join(f"trait{t + 1}" for t in range(r)) + "\n")
+    for row in np.asarray(res.Σ):
+        io.write("\t".join(repr(float(v)) for v in row) + "\n")
+    for t in range(r):
+        for what, arr in (("nonzero SNP predictors", res.beta[t]), ("non-genetic predictors", res.c[t])):
+            nz = np.flatnonzero(arr)
+            io.write(f"\nTrait {t + 1}: IHT estimated {nz.size} {what}\n Position  Estimated_β\n")
+            for j in nz:
+                io.write(f" {j + 1:8d}  {arr[j]: .6g}\n")
+
+
 def iht(plinkfile, k, d, *, phenotypes=6, covariates="", summaryfile="iht.summary.txt", betafile="iht.beta.txt",
-        covariancefile="iht.cov.txt", **kwargs):
-    """iht(filename, k, d; phenotypes, covariates, ...) -- src/wrapper.jl:52-120 (PLINK input)."""
-    x, y, z = _parse_inputs(plinkfile, phenotypes, covariates)
+        covariancefile="iht.cov.txt", exclude_std_idx=(), dosage=False, device=0, **kwargs):
+    """iht(filename, k, d; phenotypes, covariates, summaryfile, betafile, covariancefile, exclude_std_idx, dosage, kwargs...) --
+    src/wrapper.jl:52-120 for binary PLINK input: SnpLinAlg{Float64}(center=true, scale=true, impute=true) on the GPU, the
+    reference's phenotype / covariate parsing, fit_iht with the canonical link (LogLink for NegativeBinomial, wrapper.jl:87),
+    the summary file (the fit's log + show(result)) and the beta file `chr pos SNPid ref alt Estimated_beta` (one row per SNP,
+    tab-separated; `beta_1 .. beta_r` columns and the covariance file for multivariate traits, wrapper.jl:100-116).  (v1.4.11
+    then overwrites the beta file with an empty CSV header, wrapper.jl:117 `CSV.write(betafile, df)` on an empty DataFrame;
+    that accident is not reproduced.)"""
     d = _inst(d)
-    if _is_multivariate(y):
-        result = fit_iht(y, x, z.T, k=k, d=d, **kwargs)
-    else:
-        l = kwargs.pop("l", None) or canonicallink(d)     # wrapper.jl:87 (LogLink for NegativeBinomial, else canonical)
-        result = fit_iht(y, x, z, k=k, d=d, l=l, **kwargs)
-    if summaryfile:
-        with open(summaryfile, "w") as f:
-            f.write(repr(result) if isinstance(result, IHTResult) else f"logl = {result.logl}\niter = {result.iter}\n")
+    x, y, z = _parse_inputs(plinkfile, phenotypes, covariates, d, exclude_std_idx, dosage, device)
+    mv = _is_multivariate(y)
+    user_io = kwargs.pop("io", None)
+    with open(summaryfile, "w") if summaryfile else open(os.devnull, "w") as io:
+        if mv:
+            result = fit_iht(y, x, z.T, k=k, d=MvNormal(), io=io, **kwargs)
+        else:
+            l = kwargs.pop("l", None) or (LogLink() if isinstance(d, NegativeBinomial) else canonicallink(d))     # wrapper.jl:87
+            result = fit_iht(y, x, z, k=k, d=d, l=l, io=io, **kwargs)
+        _show_result(io, result)
+    if user_io is not None:
+        _show_result(user_io, result)
     if betafile:
-        np.savetxt(betafile, result.beta.T if isinstance(result, mIHTResult) else result.beta)
-    if covariancefile and isinstance(result, mIHTResult):
-        np.savetxt(covariancefile, result.Σ, delimiter=",")
+        chrom, pos, ids, a1, a2 = _read_bim(plinkfile)
+        with open(betafile, "w") as f:
+            if mv:
+                f.write("chr\tpos\tSNPid\tref\talt" + "".join(f"\tbeta_{t + 1}" for t in range(y.shape[0])) + "\n")
+                for j in range(x.p):
+                    f.write(f"{chrom[j]}\t{pos[j]}\t{ids[j]}\t{a1[j]}\t{a2[j]}\t" + "\t".join(repr(float(v)) for v in result.beta[:, j]) + "\n")
+            else:
+                f.write("chr\tpos\tSNPid\tref\talt\tEstimated_beta\n")
+                for j in range(x.p):
+                    f.write(f"{chrom[j]}\t{pos[j]}\t{ids[j]}\t{a1[j]}\t{a2[j]}\t{float(result.beta[j])!r}\n")
+    if covariancefile and mv:
+        np.savetxt(covariancefile, np.asarray(result.Σ), delimiter="\t")          # writedlm(covariancefile, result.Σ)
     return result
 
 
+def print_cv_results(io, errors, path, k):
+    """print_cv_results (data_structures.jl:327-335)."""
+    io.write("\n\nCrossvalidation Results:\n\tk\tMSE\n")
+    for kk, e in zip(path, errors):
+        io.write(f"\t{int(kk)}\t{float(e)!r}\n")
+    io.write(f"\nBest k = {int(k)}\n\n")
+
+
 def cross_validate(plinkfile, d, *, path=range(1, 21), q=5, phenotypes=6, covariates="",
-                   cv_summaryfile="cviht.summary.txt", **kwargs):
-    """cross_validate(filename, d; path, q, ...) -- src/wrapper.jl:301-349 (PLINK input)."""
-    x, y, z = _parse_inputs(plinkfile, phenotypes, covariates)
-    d = _inst(d)
+                   cv_summaryfile="cviht.summary.txt", exclude_std_idx=(), dosage=False, device=0, **kwargs):
+    """cross_validate(filename, d; path, phenotypes, covariates, cv_summaryfile, q, exclude_std_idx, dosage, kwargs...) --
+    src/wrapper.jl:301-349 for binary PLINK input; the summary file is print_cv_results + the total time, as the reference's."""
     t0 = time.time()
+    d = _inst(d)
+    x, y, z = _parse_inputs(plinkfile, phenotypes, covariates, d, exclude_std_idx, dosage, device)
+    path = list(path)
     if _is_multivariate(y):
-        mse = cv_iht(y, x, z.T, d=d, path=path, q=q, **kwargs)
+        mse = cv_iht(y, x, z.T, d=MvNormal(), path=path, q=q, **kwargs)
     else:
-        l = kwargs.pop("l", None) or canonicallink(d)     # wrapper.jl:87 (LogLink for NegativeBinomial, else canonical)
+        l = kwargs.pop("l", None) or (LogLink() if isinstance(d, NegativeBinomial) else canonicallink(d))
         mse = cv_iht(y, x, z, d=d, l=l, path=path, q=q, **kwargs)
     if cv_summaryfile:
-        with open(cv_summaryfile, "w") as f:
-            f.write("k,mse\n")
-            for kk, m in zip(path, mse):
-                f.write(f"{kk},{m}\n")
-            f.write(f"\ntotal time (sec) = {time.time() - t0}\n")
+        with open(cv_summaryfile, "w") as io:
+            print_cv_results(io, mse, path, path[int(np.argmin(mse))])
+            io.write(f"Total cross validation time = {time.time() - t0} seconds\n")
     return mse

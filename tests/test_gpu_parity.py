@@ -375,23 +375,72 @@ def test_cv_iht_vs_oracle_and_sharding(mih, oracle, normal_pair, normal_data, fa
 
 
 def test_file_level_wrappers(mih, tmp_path, normal_data):
-    """iht(...) / cross_validate(...) on a PLINK trio (src/wrapper.jl:52-120, 301-349)."""
+    """iht(...) / cross_validate(...) on a PLINK trio (src/wrapper.jl:52-120, 301-349): the reference's recorded run through the
+    file-level API -- .fam phenotypes, covariate file, summary file (the fit's log + show(result)), the beta file with the .bim
+    columns, the cross-validation summary in print_cv_results' format."""
     import shutil
     prefix = str(tmp_path / "normal")
     shutil.copy(normal_data["bed"], prefix + ".bed")
     with open(prefix + ".fam", "w") as f:
         for i, v in enumerate(normal_data["y"]):
             f.write(f"{i + 1}\t1\t0\t0\t1\t{float(v)!r}\n")
+    with open(prefix + ".bim", "w") as f:
+        for j in range(10_000):
+            f.write(f"1\tsnp{j + 1}\t0\t{j + 1}\t1\t2\n")
     g = json.load(open(os.path.join(GOLD, "golden_normal_k7.json")))
     res = mih.iht(prefix, 7, mih.Normal, covariates=os.path.join(FIX, "covariates.txt"), phenotypes=6,
-                  summaryfile=str(tmp_path / "s.txt"), betafile=str(tmp_path / "b.txt"), verbose=False)
+                  summaryfile=str(tmp_path / "s.txt"), betafile=str(tmp_path / "b.txt"))
     assert list(np.flatnonzero(res.beta) + 1) == g["positions_1based"]
     assert res.logl == pytest.approx(g["final_logl"], rel=1e-11)
-    assert np.count_nonzero(np.loadtxt(tmp_path / "b.txt")) == 7
+    # beta file: header + one tab-separated row per SNP with the .bim columns (wrapper.jl:112-116)
+    rows = open(tmp_path / "b.txt").read().splitlines()
+    assert rows[0] == "chr\tpos\tSNPid\tref\talt\tEstimated_beta" and len(rows) == 10_001
+    cols = [r.split("\t") for r in rows[1:]]
+    assert cols[3136][:5] == ["1", "3137", "snp3137", "1", "2"]
+    bfile = np.array([float(c[5]) for c in cols])
+    assert np.array_equal(bfile, res.beta)
+    # summary file: the per-iteration log the reference recorded (docs/src/man/examples.md:230-234) and show(result)
+    summ = open(tmp_path / "s.txt").read()
+    its = [ln for ln in summ.splitlines() if ln.startswith("Iteration ")]
+    assert len(its) == g["iterations"]
+    for ln, want in zip(its, g["logl"]):
+        assert float(ln.split("loglikelihood = ")[1].split(",")[0]) == pytest.approx(want, rel=1e-11)
+    assert "IHT estimated 7 nonzero SNP predictors and 2 non-genetic predictors." in summ and "Selected genetic predictors:" in summ
+    assert "Link functin = IdentityLink()" in summ and "Sparsity parameter (k) = 7" in summ
+    # missing phenotypes: "-9" / "NA" are imputed by the mean for quantitative traits, refused for binary ones (wrapper.jl:171-214)
+    y = normal_data["y"]
+    with open(prefix + ".fam", "w") as f:
+        for i, v in enumerate(y):
+            tok = "-9" if i == 4 else ("NA" if i == 17 else repr(float(v)))
+            f.write(f"{i + 1}\t1\t0\t0\t1\t{tok}\n")
+    from mendeliht_amd import api
+    yy = api.parse_phenotypes(prefix, 6, mih.Normal(), 1000)
+    keep = np.ones(1000, bool); keep[[4, 17]] = False
+    assert yy[4] == yy[17] == pytest.approx(y[keep].mean(), rel=1e-15) and np.array_equal(yy[keep], y[keep])
+    with pytest.raises(mih.MendelIHTError):
+        mih.iht(prefix, 3, mih.Bernoulli, summaryfile="", betafile="")
+    with open(prefix + ".fam", "w") as f:
+        for i, v in enumerate(y):
+            f.write(f"{i + 1}\t1\t0\t0\t1\t{float(v)!r}\n")
     mse = mih.cross_validate(prefix, mih.Normal, path=range(5, 9), q=3, folds=hash_folds(1000, 3),
                              covariates=os.path.join(FIX, "covariates.txt"), cv_summaryfile=str(tmp_path / "cv.txt"),
                              verbose=False)
     assert mse.shape == (4,) and np.all(mse > 0)
+    cvs = open(tmp_path / "cv.txt").read().splitlines()
+    assert cvs[2] == "Crossvalidation Results:" and cvs[3] == "\tk\tMSE"
+    assert [float(ln.split("\t")[2]) for ln in cvs[4:8]] == list(mse) and cvs[9] == f"Best k = {5 + int(np.argmin(mse))}"
+    assert cvs[-1].startswith("Total cross validation time = ")
+    # multivariate: two .fam columns -> mIHTResult, beta_1 / beta_2 columns, the covariance file
+    with open(prefix + ".fam", "w") as f:
+        for i, v in enumerate(y):
+            f.write(f"{i + 1}\t1\t0\t0\t1\t{float(v)!r}\t{float(normal_data['y2'][i])!r}\n")
+    rm = mih.iht(prefix, 10, mih.MvNormal, phenotypes=[6, 7], summaryfile=str(tmp_path / "ms.txt"), betafile=str(tmp_path / "mb.txt"),
+                 covariancefile=str(tmp_path / "cov.txt"), verbose=False)
+    assert rm.beta.shape == (2, 10_000) and np.count_nonzero(rm.beta) <= 10
+    head = open(tmp_path / "mb.txt").readline().rstrip("\n")
+    assert head == "chr\tpos\tSNPid\tref\talt\tbeta_1\tbeta_2"
+    np.testing.assert_allclose(np.loadtxt(tmp_path / "cov.txt"), rm.Σ)
+    assert "Trait 2's SNP PVE:" in open(tmp_path / "ms.txt").read()
 
 
 def test_full_size_properties_n500k(mih, oracle):

@@ -281,3 +281,38 @@ def test_bench_starts_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
                        env=env, timeout=600)
     assert r.returncode != 0
+
+
+def test_wrapper_parsers_follow_the_reference(mih, tmp_path):
+    """parse_phenotypes / parse_covariates of the host mirror (src/wrapper.jl:136-249) -- no GPU needed."""
+    from mendeliht_amd import api
+    prefix = str(tmp_path / "t")
+    rows = [("1.5", "0"), ("-9", "1"), ("2.5", "1"), ("NA", "0"), ("-1.0", "1")]
+    with open(prefix + ".fam", "w") as f:
+        for i, (a, b) in enumerate(rows):
+            f.write(f"f{i} i{i} 0 0 1 {a} {b}\n")
+    y = api.parse_phenotypes(prefix, 6, mih.Normal(), 5)
+    np.testing.assert_allclose(y, [1.5, 1.0, 2.5, 1.0, -1.0])                    # missing -> mean of the observed (wrapper.jl:171-192)
+    assert np.array_equal(api.parse_phenotypes(prefix, 7, mih.Bernoulli(), 5), [0, 1, 1, 0, 1])
+    with pytest.raises(mih.MendelIHTError):
+        api.parse_phenotypes(prefix, 6, mih.Poisson(), 5)                         # no imputation for count / binary traits
+    with pytest.raises(mih.MendelIHTError):
+        api.parse_phenotypes(prefix, 6, mih.MvNormal(), 5)                        # one column is not multivariate
+    Y = api.parse_phenotypes(prefix, [6, 7], mih.MvNormal(), 5)
+    assert Y.shape == (2, 5) and Y[0, 1] == 1.0 and Y[1, 1] == 1.0
+    (tmp_path / "ph.csv").write_text("1.0,2.0\n3.0,4.0\n5.0,6.0\n")
+    assert api.parse_phenotypes(prefix, str(tmp_path / "ph.csv"), mih.MvNormal(), 3).shape == (2, 3)
+    (tmp_path / "ph1.csv").write_text("1.0\n3.0\n5.0\n")
+    assert api.parse_phenotypes(prefix, str(tmp_path / "ph1.csv"), mih.Normal(), 3).shape == (3,)
+    (tmp_path / "cov.csv").write_text("1,2.0,10\n1,4.0,20\n1,6.0,60\n")
+    z = api.parse_covariates(str(tmp_path / "cov.csv"))
+    assert np.array_equal(z[:, 0], [1, 1, 1])                                     # the intercept is never standardized
+    np.testing.assert_allclose(z[:, 1], [-1.0, 0.0, 1.0])                        # (x - mean) / sample sd (utilities.jl:494-530)
+    z = api.parse_covariates(str(tmp_path / "cov.csv"), exclude_std_idx=[3])
+    assert np.array_equal(z[:, 2], [10, 20, 60]) and abs(z[:, 1].mean()) < 1e-15
+    z = api.parse_covariates(str(tmp_path / "cov.csv"), exclude_std_idx=[False, True, False])
+    assert np.array_equal(z[:, 1], [2, 4, 6])
+    import io
+    buf = io.StringIO()
+    api.print_cv_results(buf, np.array([3.5, 2.25]), [4, 9], 9)
+    assert buf.getvalue() == "\n\nCrossvalidation Results:\n\tk\tMSE\n\t4\t3.5\n\t9\t2.25\n\nBest k = 9\n\n"   # data_structures.jl:327-335
