@@ -1786,3 +1786,42 @@ def test_snplinalg_float32_callers(mih, normal_data):
     np.testing.assert_allclose(r32.beta, r64.beta, rtol=2e-5, atol=1e-7)        # y, z themselves were rounded to Float32
     with pytest.raises(mih.MendelIHTError):
         mih.SnpLinAlg(bed, n, dtype=np.float16)
+
+
+@pytest.mark.parametrize("fam", ["normal", "bernoulli", "poisson"])
+def test_wrapper_three_input_routes_agree(mih, tmp_path, fam):
+    """test/wrapper_test.jl:44-77: `iht` / `cross_validate` on a PLINK trio give the same result whether the phenotype comes
+    from the .fam file or a phenotype file and whether the intercept comes from a covariate file of ones or the default."""
+    n, p = 800, 1500
+    x = mih.SnpLinAlg.synthetic(n, p, seed=12)
+    rng = np.random.default_rng(13)
+    supp = np.sort(rng.choice(p, 6, replace=False))
+    eta = x.xv_sparse(supp, rng.standard_normal(6) * 0.5)
+    d = {"normal": mih.Normal, "bernoulli": mih.Bernoulli, "poisson": mih.Poisson}[fam]
+    y = {"normal": eta + rng.standard_normal(n), "bernoulli": (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float),
+         "poisson": rng.poisson(np.exp(0.5 * eta)).astype(float)}[fam]
+    prefix = str(tmp_path / f"uni{fam}")
+    with open(prefix + ".bed", "wb") as f:
+        f.write(b"\x6c\x1b\x01")
+        f.write(x.export_bed().tobytes())
+    with open(prefix + ".bim", "w") as f:
+        for j in range(p):
+            f.write(f"1\tsnp{j + 1}\t0\t{j + 1}\t1\t2\n")
+    with open(prefix + ".fam", "w") as f:
+        for i in range(n):
+            f.write(f"{i + 1}\t1\t0\t0\t1\t{float(y[i])!r}\n")
+    (tmp_path / "cov.txt").write_text("".join("1.0\n" for _ in range(n)))
+    (tmp_path / "phen.txt").write_text("".join(f"{float(v)!r}\n" for v in y))
+    kw = dict(verbose=False, summaryfile=str(tmp_path / "s.txt"), betafile=str(tmp_path / "b.txt"), max_iter=5)
+    r1 = mih.iht(prefix, 11, d, **kw)
+    r2 = mih.iht(prefix, 11, d, covariates=str(tmp_path / "cov.txt"), **kw)
+    r3 = mih.iht(prefix, 11, d, covariates=str(tmp_path / "cov.txt"), phenotypes=str(tmp_path / "phen.txt"), **kw)
+    for r in (r2, r3):
+        assert np.array_equal(r.beta, r1.beta) and r.logl == r1.logl and r.iter == r1.iter and r.σg == r1.σg
+    assert np.count_nonzero(r1.beta) == 11 and r1.c[0] != 0
+    folds = hash_folds(n, 3)
+    ckw = dict(verbose=False, max_iter=5, q=3, folds=folds, path=range(0, 8), cv_summaryfile=str(tmp_path / "cv.txt"))
+    m1 = mih.cross_validate(prefix, d, **ckw)
+    m2 = mih.cross_validate(prefix, d, covariates=str(tmp_path / "cov.txt"), **ckw)
+    m3 = mih.cross_validate(prefix, d, covariates=str(tmp_path / "cov.txt"), phenotypes=str(tmp_path / "phen.txt"), **ckw)
+    assert np.array_equal(m1, m2) and np.array_equal(m1, m3) and np.all(m1 > 0)           # test/cv_iht_test.jl: all(mses .> 0), path = 0:..
