@@ -359,6 +359,15 @@ static double h_mueta(int link, double eta)
     }
 }
 
+// initialize_beta! results shared by the fits of a lock-step lane: the p univariate regressions depend on the training rows only
+// (the fold), not on the model size, so the first fit of a fold computes them (two extra passes over X) and the other fits of
+// that fold in the lane take them from here.  One lane = one host thread: no locking; a fit that finds an entry still being
+// computed by another coroutine of its lane yields until it is ready.
+struct IbShared {
+    struct Entry { int state = 0; DevBuf<double> beta; std::vector<double> c; };      // state 1: being computed, 2: ready
+    std::map<int, std::unique_ptr<Entry>> by_key;
+};
+
 // One IHTVariable (src/data_structures.jl:4-43), device-resident.
 // initialize_beta! regressions (utilities.jl:776-812, multivariate.jl:519-558) for m responses kept as
 // planes of n doubles: beta_dev[t][j] = slope of y_t ~ 1 + x_j over the training rows (clamped to +-2),
@@ -894,23 +903,40 @@ struct IhtVar {
     // initialize_beta!(v, cv_idx) + project_k!(v) (utilities.jl:412-414, 776-812, 561-573).  Two extra
     // passes over X: the fused 2-RHS X'R (sum x, x'y per SNP over the training rows) and a popcount
     // pass (sum x^2 from exact dosage counts).  df stays the dense intercept-only gradient.
+    // a lock-step lane's cache of the regressions, keyed by the fit's training rows (fold); null outside the lock-step drivers
+    IbShared *ib_shared = nullptr; int ib_key = -1;
     int init_beta_phase(const uint8_t *train)
     {
         if (dist != MIH_NORMAL) { set_error("Intializing beta values only work for Gaussian phenotypes! Sorry!"); return MIH_BAD_ARG; }
         // The regressions depend on the training mask only: cv_iht visits the (fold, k) combinations fold-major,
         // so every k of a fold after the first reuses them (two passes over X saved per fit).
-        DevBuf<double> &betad = ib_beta;
-        const bool reuse = ib_valid && ((train == nullptr) == ib_train.empty()) &&
-                           (train == nullptr || std::memcmp(ib_train.data(), train, (size_t)n) == 0);
+        IbShared::Entry *shared_entry = nullptr;
+        if (ib_shared && ib_key >= 0) {
+            auto &slot_ = ib_shared->by_key[ib_key];
+            if (!slot_) slot_.reset(new IbShared::Entry());
+            shared_entry = slot_.get();
+            while (shared_entry->state == 1 && coop_can_yield()) current_coop()->yield();     // another fit of this lane is computing it
+        }
+        DevBuf<double> &betad = (shared_entry && shared_entry->state != 1) ? shared_entry->beta : ib_beta;
+        const bool from_shared = &betad != &ib_beta;
+        const bool reuse = from_shared ? shared_entry->state == 2
+                                       : (ib_valid && ((train == nullptr) == ib_train.empty()) &&
+                                          (train == nullptr || std::memcmp(ib_train.data(), train, (size_t)n) == 0));
+        std::vector<double> &ibc = from_shared ? shared_entry->c : ib_c;
         if (!reuse) {
-            ib_valid = false;
-            if (ib_beta.n < (size_t)p) MIH_TRY(ib_beta.alloc(p));
+            struct Computing {        // a failure must not leave the lane's other fits waiting for this entry
+                IbShared::Entry *e; bool ok = false;
+                ~Computing() { if (e) e->state = ok ? 2 : 0; }
+            } computing{from_shared ? shared_entry : nullptr};
+            if (from_shared) shared_entry->state = 1;
+            else ib_valid = false;
+            if (betad.n < (size_t)p) { ArenaScope own_buffer(nullptr); MIH_TRY(betad.alloc(p)); }
             double Sy = 0.0, N = 0.0;
             std::vector<double> ys;
             for (int64_t i = 0; i < n; ++i) if (!train || train[i]) { Sy += y_host[i]; N += 1.0; ys.push_back(y_host[i]); }
             double c0sum = 0.0;
             MIH_TRY(init_beta_regress_device(h, w.p, y.p, 1, N, &Sy, betad.p, &c0sum, red, scal, s, tune));
-            ib_c.assign(q, 0.0);
+            ibc.assign(q, 0.0);
             // non-genetic covariates 2..q on the host (utilities.jl:799-806)
             for (int l = 1; l < q; ++l) {
                 double sx = 0, sxx = 0, sxy = 0;
@@ -919,14 +945,15 @@ struct IhtVar {
                 double u11 = std::sqrt(N), u12 = sx / u11, d = sxx - u12 * u12, b0v, b1v;
                 if (!(N > 0.0) || !(d > 0.0)) { b0v = Sy; b1v = sxy; }
                 else { double u22 = std::sqrt(d), w1 = Sy / u11, w2 = (sxy - u12 * w1) / u22; b1v = w2 / u22; b0v = (w1 - u12 * b1v) / u11; }
-                c0sum += b0v; ib_c[l] = b1v;
+                c0sum += b0v; ibc[l] = b1v;
             }
-            ib_c[0] = c0sum / (double)(p + q - 1);
-            for (int l = 0; l < q; ++l) ib_c[l] = ib_c[l] < -2.0 ? -2.0 : (ib_c[l] > 2.0 ? 2.0 : ib_c[l]);
-            if (train) ib_train.assign(train, train + n); else ib_train.clear();
-            ib_valid = true;
+            ibc[0] = c0sum / (double)(p + q - 1);
+            for (int l = 0; l < q; ++l) ibc[l] = ibc[l] < -2.0 ? -2.0 : (ibc[l] > 2.0 ? 2.0 : ibc[l]);
+            if (!from_shared) { if (train) ib_train.assign(train, train + n); else ib_train.clear(); ib_valid = true; }
+            else MIH_TRY(stream_sync_coop(s));         // the shared regressions are complete before any other stream reads them
+            computing.ok = true;
         }
-        c = ib_c;
+        c = ibc;
         c0 = c;
         // project_k!(v): vectorize (weights, Inf for kept covariates), top-(k + zkeepn), unvectorize
         const double *wp = has_weight ? weight.p : nullptr;
@@ -1430,6 +1457,7 @@ static int lane_to_fit(CvFit &f, hipStream_t lane_s, hipEvent_t lane_ev)        
 // hipFree waits for the OTHER lane's fused pass to finish.
 struct CvShared {                 // what a lane shares with its fits
     double *y = nullptr, *z = nullptr;       // the lane's device copies of y and z (read-only)
+    IbShared *ib = nullptr;                  // the lane's cache of the initialize_beta! regressions (init_beta = true)
     std::vector<hipStream_t> streams;        // non-empty: the fits queue their small kernels on these, round-robin (LaneSched)
     mutable size_t rr = 0;
     hipStream_t next_stream() const { return streams.empty() ? nullptr : streams[rr++ % streams.size()]; }
@@ -1650,7 +1678,8 @@ static int cv_run_lanes(const mih_mat *h, const mih_fit_params &pr, size_t total
         MIH_HIP(hipMemcpyAsync(yd.p, y_host, sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice, s));
         MIH_HIP(hipMemcpyAsync(zd.p, z_host, sizeof(double) * (size_t)h->n * (size_t)q, hipMemcpyHostToDevice, s));
         MIH_HIP(hipStreamSynchronize(s));                         // the fits read y and z from their own streams
-        CvShared shared; shared.y = yd.p; shared.z = zd.p;
+        IbShared ib_cache;
+        CvShared shared; shared.y = yd.p; shared.z = zd.p; shared.ib = &ib_cache;
         if (probe_env("MENDELIHT_CV_NO_COOP") == nullptr)             // A/B (measurement build): round 2's walk, one fit after the other on the lane's stream
             for (int i = 0; i < kWorkerStreamsPerLane; ++i) {
                 hipStream_t ws = worker_stream(h, (lane_id % 2) * kWorkerStreamsPerLane + i);
@@ -1729,9 +1758,10 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, con
     std::vector<int32_t> rank_of;
     cv_assign(path, npath, nfolds, world, rank_of);
 
-    if (prm->est_r != MIH_ESTR_NONE || prm->init_beta || prm->debias) {
-        // init_beta needs two extra passes per fit and debias a GLM refit (not batched yet); the NegBin nuisance parameter is carried from one fit to the next in the reference (v.d is
-        // never reset, cross_validation.jl:91,110): keep the sequential order for that case
+    if (prm->est_r != MIH_ESTR_NONE || prm->debias) {
+        // debias needs a GLM refit per step (not batched); the NegBin nuisance parameter is carried from one fit to the next in the
+        // reference (v.d is never reset, cross_validation.jl:91,110): keep the sequential order for those.  init_beta rides the
+        // lock-step driver since round 3: the regressions are computed once per fold and lane (IbShared)
         IhtVar v;
         MIH_TRY(v.create(h, &pr, y, z, q));
         std::vector<uint8_t> train(n);
@@ -1772,6 +1802,7 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, con
         for (int64_t i = 0; i < n; ++i) f.train[i] = (folds[i] != fold);
         f.out_index = (int64_t)(fold - 1) * npath + ik;
         f.init_key = fold;
+        f.v->ib_shared = sh.ib; f.v->ib_key = fold;        // (a recycled IHTVariable may come from the other lane: re-point it)
         return MIH_OK;
     };
     return cv_run_lanes(h, pr, mine.size(), make, mses_raw, nfolds, y, z, q);
@@ -1803,7 +1834,7 @@ int mih_fit_iht_path(const mih_mat *h, const mih_fit_params *prm, const double *
         f.full_data = true; f.logl_out = logl_out + i; f.iter_out = iter_out ? iter_out + i : nullptr;
         f.beta_out = beta_out ? beta_out + (size_t)i * h->p : nullptr; f.c_out = c_out ? c_out + (size_t)i * q : nullptr;
     };
-    if (prm->est_r != MIH_ESTR_NONE || prm->init_beta || prm->debias) {      // not batched: one fit after the other
+    if (prm->est_r != MIH_ESTR_NONE || prm->debias) {      // not batched: one fit after the other
         for (int64_t i : mine) {
             mih_fit_params pf = pr; pf.k = path[i];
             CvFit f; slots(f, i);
@@ -1827,6 +1858,7 @@ int mih_fit_iht_path(const mih_mat *h, const mih_fit_params *prm, const double *
             f.v.reset(new IhtVar());
             MIH_TRY(f.v->create(h, &pr, y, z, q, s, sh.y, sh.z, sh.next_stream()));     // sized for max(path)
         }
+        f.v->ib_shared = sh.ib; f.v->ib_key = 0;
         return f.v->set_k(path[mine[t]]);
     };
     return cv_run_lanes(h, pr, mine.size(), make, nullptr, 1, y, z, q);

@@ -526,8 +526,8 @@ def test_fit_iht_group_projection(mih, oracle):
 @pytest.mark.parametrize("branch", ["rolling", "debias", "init_beta"])
 def test_cv_iht_with_groups_on_both_drivers(mih, oracle, branch):
     """cv_iht(group=...) sets v.k = sparsity per (fold, k) fit (cross_validation.jl:110) and project_group_sparse! reads that k
-    (utilities.jl:266-268): on the rolling lock-step driver every fit has its own IHTVariable; on the sequential driver
-    (debias / init_beta) ONE variable is re-used and its device copy of k must follow the path (IhtVar::set_k)."""
+    (utilities.jl:266-268): on the rolling lock-step driver (also with init_beta since round 3) every fit has its own IHTVariable;
+    on the sequential driver (debias) ONE variable is re-used and its device copy of k must follow the path (IhtVar::set_k)."""
     rng = np.random.default_rng(131)
     n, p = 500, 400
     cols = make_bed(rng, n, p)
@@ -1622,6 +1622,8 @@ r = m.fit_iht(Y, x, None, k=12, verbose=False, max_iter=10)
 out["mvbeta"], out["mvlogl"] = r.beta, np.array([r.logl, r.iter])
 _, raw = m.cv_iht(Y, x, None, path=[2, 5, 9, 14], q=3, folds=hash_folds(6001, 3), verbose=False, return_raw=True)
 out["mvcv"] = raw
+_, raw = m.cv_iht(y, x, z, path=range(1, 9), q=3, folds=hash_folds(6001, 3), verbose=False, return_raw=True, init_beta=True)
+out["cv_init_beta"] = raw
 np.savez(sys.argv[2], **out)
 """
 
@@ -1640,7 +1642,7 @@ def test_polled_readbacks_and_shared_initial_scores_change_nothing(mih, tmp_path
     for i, extra in enumerate((None, {}, {"MENDELIHT_NO_SPIN": "1"}, {"MENDELIHT_CV_NO_INIT_SHARE": "1", "MENDELIHT_CV_NO_MERGE": "1"},
                                {"MENDELIHT_CV_LANES": "1"}, {"MENDELIHT_NO_ARENA": "1"}, {"MENDELIHT_CV_NO_COOP": "1"})):
         res.append(_run_probe_snippet(_NOSPIN_SNIPPET, tmp_path / f"variant_{i}.npz", extra_env=extra or {}, probes=extra is not None))
-    assert len(res[0].files) == 10
+    assert len(res[0].files) == 11
     for other in res[1:]:
         assert sorted(res[0].files) == sorted(other.files)
         for k in res[0].files:
@@ -1825,3 +1827,32 @@ def test_wrapper_three_input_routes_agree(mih, tmp_path, fam):
     m2 = mih.cross_validate(prefix, d, covariates=str(tmp_path / "cov.txt"), **ckw)
     m3 = mih.cross_validate(prefix, d, covariates=str(tmp_path / "cov.txt"), phenotypes=str(tmp_path / "phen.txt"), **ckw)
     assert np.array_equal(m1, m2) and np.array_equal(m1, m3) and np.all(m1 > 0)           # test/cv_iht_test.jl: all(mses .> 0), path = 0:..
+
+
+def test_cv_init_beta_full_grid_against_oracle(mih, oracle):
+    """cv_iht(init_beta = true) -- the setting of the reference's large real runs (manuscript/UKBB_hyptertension/ukbb.jl:16-18) --
+    on the LOCK-STEP driver (round 3): path = 1:20, q = 5, Normal, two lanes; the p univariate regressions of initialize_beta!
+    (utilities.jl:776-812) are computed once per fold and lane and shared by the fold's fits (IbShared).  All 100 losses against
+    the oracle's sequential cv_iht, and far fewer passes than 100 fits x 2 regressions."""
+    n, p = 6000, 2000
+    x = mih.SnpLinAlg.synthetic(n, p, seed=91)
+    rng = np.random.default_rng(92)
+    supp = np.sort(rng.choice(p, 9, replace=False))
+    z = np.column_stack([np.ones(n), rng.standard_normal(n)])
+    y = x.xv_sparse(supp, rng.standard_normal(9) * 0.5) + 0.7 + 0.3 * z[:, 1] + rng.standard_normal(n)
+    folds = hash_folds(n, 5)
+    mih.profile_read(x, reset=True); mih.profile_counters(x, reset=True)
+    mih.profile_enable(x, True)
+    mse, raw = mih.cv_iht(y, x, z, path=range(1, 21), q=5, folds=folds, init_beta=True, verbose=False, return_raw=True)
+    mih.profile_enable(x, False)
+    cnt = mih.profile_counters(x, reset=True)
+    passes = mih.profile_passes(x, reset=True)
+    assert cnt["fits"] == 100 and cnt["lanes"] == 2
+    two_rhs = [q for q in passes if q["stream_tag"] == 0 and q["residuals"] == 2]       # the fused 2-RHS pass of initialize_beta!
+    assert 5 <= len(two_rhs) <= 10                                                       # once per fold and lane, not once per fit
+    ox = oracle.Mat.from_bed_columns(x.export_bed(), n)
+    omse, oraw = oracle.cv_iht(ox, y, z, path=range(1, 21), q=5, folds=folds, init_beta=True)
+    np.testing.assert_allclose(raw, oraw, rtol=1e-9)
+    np.testing.assert_allclose(mse, omse, rtol=1e-9)
+    logl = mih.iht_run_many_models(y, x, z, path=range(1, 9), verbose=False)            # model path on the same driver
+    assert np.all(np.diff(logl) > 0)
