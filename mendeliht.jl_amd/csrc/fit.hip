@@ -1549,6 +1549,9 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
     auto slot_post = [&](CvFit *f, char is_fresh) -> int {
         if (is_fresh) return f->v->init_post();
         MIH_TRY(f->v->step_post(f->next_logl));
+        IhtVar &v = *f->v;
+        if (v.debias && f->iter >= 5 && v.b.idx == v.b0.idx && !v.b.idx.empty())          // fit.jl:188: v.idx == v.idx0 && debias!(v)
+            MIH_TRY(debias_glm_device(h, v.b.idx.data(), (int64_t)v.b.idx.size(), v.y.p, v.dist, v.link, v.nb_r, v.b.val.data(), v.s));
         double sc = f->v->check_convergence();
         if (f->iter >= pr.min_iter && sc < pr.tol) MIH_TRY(cv_finish(*f, mses_raw));     // fit.jl:197-203
         else f->iter++;
@@ -1758,10 +1761,11 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, con
     std::vector<int32_t> rank_of;
     cv_assign(path, npath, nfolds, world, rank_of);
 
-    if (prm->est_r != MIH_ESTR_NONE || prm->debias) {
-        // debias needs a GLM refit per step (not batched); the NegBin nuisance parameter is carried from one fit to the next in the
-        // reference (v.d is never reset, cross_validation.jl:91,110): keep the sequential order for those.  init_beta rides the
-        // lock-step driver since round 3: the regressions are computed once per fold and lane (IbShared)
+    if (prm->est_r != MIH_ESTR_NONE) {
+        // the NegBin nuisance parameter is carried from one fit to the next in the reference (v.d is never reset,
+        // cross_validation.jl:91,110): keep the sequential order for that.  init_beta and debias ride the lock-step driver since
+        // round 3: the regressions are computed once per fold and lane (IbShared), the GLM refit of a debiased step runs on the
+        // fit's own stream between its step_post and its convergence test, exactly where fit_iht! has it (fit.jl:188)
         IhtVar v;
         MIH_TRY(v.create(h, &pr, y, z, q));
         std::vector<uint8_t> train(n);
@@ -1834,7 +1838,7 @@ int mih_fit_iht_path(const mih_mat *h, const mih_fit_params *prm, const double *
         f.full_data = true; f.logl_out = logl_out + i; f.iter_out = iter_out ? iter_out + i : nullptr;
         f.beta_out = beta_out ? beta_out + (size_t)i * h->p : nullptr; f.c_out = c_out ? c_out + (size_t)i * q : nullptr;
     };
-    if (prm->est_r != MIH_ESTR_NONE || prm->debias) {      // not batched: one fit after the other
+    if (prm->est_r != MIH_ESTR_NONE) {      // not batched: one fit after the other
         for (int64_t i : mine) {
             mih_fit_params pf = pr; pf.k = path[i];
             CvFit f; slots(f, i);

@@ -526,8 +526,8 @@ def test_fit_iht_group_projection(mih, oracle):
 @pytest.mark.parametrize("branch", ["rolling", "debias", "init_beta"])
 def test_cv_iht_with_groups_on_both_drivers(mih, oracle, branch):
     """cv_iht(group=...) sets v.k = sparsity per (fold, k) fit (cross_validation.jl:110) and project_group_sparse! reads that k
-    (utilities.jl:266-268): on the rolling lock-step driver (also with init_beta since round 3) every fit has its own IHTVariable;
-    on the sequential driver (debias) ONE variable is re-used and its device copy of k must follow the path (IhtVar::set_k)."""
+    (utilities.jl:266-268): on the rolling lock-step driver (also with init_beta and debias since round 3) every fit has its own
+    IHTVariable, recycled from fit to fit: its device copy of k must follow the path (IhtVar::set_k)."""
     rng = np.random.default_rng(131)
     n, p = 500, 400
     cols = make_bed(rng, n, p)
@@ -1624,6 +1624,8 @@ _, raw = m.cv_iht(Y, x, None, path=[2, 5, 9, 14], q=3, folds=hash_folds(6001, 3)
 out["mvcv"] = raw
 _, raw = m.cv_iht(y, x, z, path=range(1, 9), q=3, folds=hash_folds(6001, 3), verbose=False, return_raw=True, init_beta=True)
 out["cv_init_beta"] = raw
+_, raw = m.cv_iht(yb, x, z, path=range(2, 8), q=3, folds=hash_folds(6001, 3), verbose=False, return_raw=True, d=m.Bernoulli(), l=m.LogitLink(), debias=True, max_iter=30)
+out["cv_debias"] = raw
 np.savez(sys.argv[2], **out)
 """
 
@@ -1642,7 +1644,7 @@ def test_polled_readbacks_and_shared_initial_scores_change_nothing(mih, tmp_path
     for i, extra in enumerate((None, {}, {"MENDELIHT_NO_SPIN": "1"}, {"MENDELIHT_CV_NO_INIT_SHARE": "1", "MENDELIHT_CV_NO_MERGE": "1"},
                                {"MENDELIHT_CV_LANES": "1"}, {"MENDELIHT_NO_ARENA": "1"}, {"MENDELIHT_CV_NO_COOP": "1"})):
         res.append(_run_probe_snippet(_NOSPIN_SNIPPET, tmp_path / f"variant_{i}.npz", extra_env=extra or {}, probes=extra is not None))
-    assert len(res[0].files) == 11
+    assert len(res[0].files) == 12
     for other in res[1:]:
         assert sorted(res[0].files) == sorted(other.files)
         for k in res[0].files:
