@@ -1858,3 +1858,26 @@ def test_cv_init_beta_full_grid_against_oracle(mih, oracle):
     np.testing.assert_allclose(mse, omse, rtol=1e-9)
     logl = mih.iht_run_many_models(y, x, z, path=range(1, 9), verbose=False)            # model path on the same driver
     assert np.all(np.diff(logl) > 0)
+
+
+def test_lockstep_error_paths_leave_the_library_usable(mih):
+    """A fit that fails inside a lock-step round (NaN loglikelihood, fit.jl:259) fails the whole cross-validation with the
+    reference's error -- from a coroutine of a lane, with the other fits of both lanes in flight -- and leaves nothing behind: the
+    next call on the same matrix gives the bits of the call before (pool blocks returned, streams drained, no stuck flag)."""
+    n, p = 5000, 1200
+    x = mih.SnpLinAlg.synthetic(n, p, seed=21)
+    rng = np.random.default_rng(22)
+    supp = np.sort(rng.choice(p, 6, replace=False))
+    y = x.xv_sparse(supp, rng.standard_normal(6)) + rng.standard_normal(n)
+    folds = hash_folds(n, 4)
+    kw = dict(path=range(1, 11), q=4, folds=folds, verbose=False, return_raw=True)
+    before = mih.cv_iht(y, x, None, **kw)[1]
+    bad = y.copy()
+    bad[17] = np.nan
+    for _ in range(3):
+        with pytest.raises(mih.MendelIHTError, match="NaN"):
+            mih.cv_iht(bad, x, None, **kw)
+        with pytest.raises(mih.MendelIHTError, match="NaN"):
+            mih.iht_run_many_models(bad, x, None, path=range(1, 9), verbose=False)
+    after = mih.cv_iht(y, x, None, **kw)[1]
+    assert np.array_equal(before.view(np.uint64), after.view(np.uint64))
