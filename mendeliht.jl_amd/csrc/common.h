@@ -361,7 +361,9 @@ struct XtvTune {
     int variant = -1;        // >= 0: a per-wave-load single-operand shape (round-1 kernels)
     int multi_variant = 0;   // launch-shape / probe id of the LDS-shared and ring kernels
     int max_nr = 4;          // B operands fused per pass of the register-staged kernels (1, 2 or 4)
-    int max_ops = 5;         // B operands per pass of the 16x16x128 ring kernel (5 = 15 residuals)
+    int max_ops = 6;         // B operands per pass of the 16x16x128 ring kernel: 6 = 18 residuals (254 VGPRs, ring depth 3).  Round 3,
+                             // after the LDS fix: 18 residuals 38.0 ms = 2.11 ms each against 15 in 33.9 ms = 2.26 ms each; the
+                             // 100-fit cv_iht 2.82-2.84 s against 2.95-3.03 s with 5 (74 instead of 88 fused passes, same box)
     int slices = 0;          // row slices, 0 = auto_splits
     bool half = true;        // leave out the empty second fragment of a pass's last operand
 };
@@ -385,7 +387,7 @@ struct XtvWork {            // scratch for one in-flight X'r
 int  xtv_work_init(const mih_mat *h, XtvWork &w, int m, const XtvTune &tune, bool batched = true);
 // r_dev: m vectors of length n (column-major n x m) on device; out_dev p x m.
 int  xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double *out_dev, hipStream_t s);
-// residuals of two full fused passes (five operands each by default) in the batched format: how many fits the lock-step drivers keep in flight
+// residuals of two full fused passes (six operands each by default) in the batched format: how many fits the lock-step drivers keep in flight
 int  xtv_lockstep_width(const mih_mat *h, const XtvTune &tune);
 
 // ---- X[:,S] v -----------------------------------------------------------------

@@ -1664,7 +1664,7 @@ def _config3_problem(mih, n, p, seed=2024):
 
 def test_config3_full_grid_against_oracle(mih, oracle):
     """The EXACT driver shape of BASELINE configs[3]: cv_iht Bernoulli/Logit, path = 1:20, q = 5 = 100
-    (fold, k) fits on one rank -- two lock-step lanes of 15 slots (30 fits in flight), the tail hand-over from lane 1 to lane 0
+    (fold, k) fits on one rank -- two lock-step lanes of 18 slots (36 fits in flight), the tail hand-over from lane 1 to lane 0
     and the 20 fits of a fold sharing one initial score all fire (asserted from the driver's own counters) -- with ALL 100
     held-out losses against oracle.cv_iht (cross_validation.jl:98-131), and the eight `rank = r, world = 8` shards of the same
     grid summing bit-exactly to the single-rank matrix (each rank: 12 or 13 fits in one lane, as one GPU of 8 runs it)."""
@@ -1681,12 +1681,12 @@ def test_config3_full_grid_against_oracle(mih, oracle):
     passes = mih.profile_passes(x, reset=True)
     # the driver shape of the full-size run
     assert cnt["fits"] == 100 and cnt["lanes"] == 2
-    assert cnt["max_lane_slots"] == 15 and cnt["max_in_flight"] == 30          # two lanes x five operands x three residuals
+    assert cnt["max_lane_slots"] == 18 and cnt["max_in_flight"] == 36          # two lanes x six operands x three residuals
     assert cnt["handovers"] == 1                                                # lane 1 handed its tail to lane 0
     assert cnt["shared_init"] >= 80                                             # at most 2 lanes x 5 folds ride their own initial score
     assert cnt["scores"] >= 100 * 5 and cnt["rounds"] >= 10
     assert {q["stream_tag"] for q in passes} == {1, 2}
-    assert max(q["residuals"] for q in passes) == 15 and all(q["kernel"].startswith("k_xtv_dma16<") for q in passes)
+    assert max(q["residuals"] for q in passes) == 18 and all(q["kernel"].startswith("k_xtv_dma16<") for q in passes)
     assert sum(q["residuals"] for q in passes) == cnt["scores"] - cnt["shared_init"]
     assert np.count_nonzero(raw) == 100
     # all 100 losses against the oracle
