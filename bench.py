@@ -488,6 +488,7 @@ def main():
                              "iterations": cnt["scores"], "iterations_per_s": cnt["scores"] / dt, "best_k": int(np.argmin(mse)) + 1,
                              "fused_passes": cst["launches"], "residuals_scored_by_passes": cst["residuals"],
                              "xtv_busy_union_ms": cst["ms_union"], "xtv_kernel_ms_sum_over_lanes": cst["ms_sum"],
+                             "xtv_kernel_ms_per_residual_scored": cst["ms_sum"] / max(cst["residuals"], 1),
                              "lockstep": cnt, "kernels": cst["kernels"],
                              "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
                                           "achieved": cst["bytes"] / (cst["ms_sum"] * 1e-3) / 1e9 if cst["launches"] else None,
@@ -495,7 +496,10 @@ def main():
                                           "kernel": cst["kernel"], "kernel_ms": cst["ms_sum"] / max(cst["launches"], 1),
                                           "algorithmic_bytes_per_launch": cst["bytes"] / max(cst["launches"], 1),
                                           "note": "sum of algorithmic_bytes(residuals of the launch) / sum of HIP-event durations; the two "
-                                                  "lock-step lanes' passes overlap, so the sum exceeds the union (and may exceed the wall time)"}}
+                                                  "lock-step lanes' passes overlap, so the sum exceeds the union (and may exceed the wall time). "
+                                                  "A fused pass streams X once for up to 18 residuals and is bound by the matrix pipe under the "
+                                                  "power cap, not by HBM: wider passes LOWER this fraction while the cost per residual falls "
+                                                  "(xtv_kernel_ms_per_residual_scored; DESIGN.md 3.1b)"}}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"], cores = cpu_baseline(m, n, p, k, seed, a.cpu_seconds)
             if gpu_fits_per_s is not None:
