@@ -12,7 +12,6 @@
 #include "fit_common.h"
 #include <map>
 #include <functional>
-#include <ucontext.h>
 #include <atomic>
 #include <mutex>
 #include <thread>
@@ -1325,65 +1324,6 @@ struct CvFit {
     // iht_run_many_models mode (no hold-out): where to put the finished model instead of a held-out deviance
     bool full_data = false;
     double *logl_out = nullptr; int64_t *iter_out = nullptr; double *beta_out = nullptr, *c_out = nullptr;
-};
-
-// One host thread, many fits: the per-fit parts of a lock-step round run as coroutines (ucontext) of the lane's thread.  A fit
-// that reaches a readback (spin_wait / stream_sync_coop, common.h) yields, and the thread goes on queueing the next fit's
-// kernels -- each fit on a stream of its own, so the chains also overlap on the device.  Round 2 walked the fits one after
-// the other on the lane's stream: 13 fits x (26 launches + 3 waits) = 3.3 - 3.5 ms between two fused passes of a GPU's share.
-// Tasks run to completion even when one fails (their stacks hold objects with destructors); the first error is returned.
-struct LaneSched : CoopSched {
-    struct Task { ucontext_t ctx; std::function<int()> fn; int rc = MIH_OK; bool done = false; };
-    static constexpr size_t kStack = 1u << 20;
-    ucontext_t main_ctx;
-    Task *cur = nullptr;
-    std::vector<std::unique_ptr<char[]>> stacks;           // reused from round to round
-    bool enabled = true;
-    void yield() override { Task *t = cur; swapcontext(&t->ctx, &main_ctx); }
-    static void entry(unsigned lo, unsigned hi)
-    {
-        Task *t = reinterpret_cast<Task *>(((uintptr_t)hi << 32) | (uintptr_t)lo);
-        t->rc = t->fn();
-        t->done = true;                                    // returning switches to uc_link = the scheduler
-    }
-    int run(std::vector<std::function<int()>> &fns)
-    {
-        int first = MIH_OK;
-        std::string first_msg;
-        auto note = [&](int rc) {
-            if (rc != MIH_OK && first == MIH_OK) { first = rc; char buf[512]; (void)mih_last_error(buf, sizeof(buf)); first_msg = buf; }
-        };
-        if (!enabled || fns.size() < 2) {
-            for (auto &f : fns) { const int rc = f(); note(rc); if (rc) break; }
-        } else {
-            std::vector<Task> tasks(fns.size());           // fixed size: the contexts hold pointers into it
-            while (stacks.size() < fns.size()) stacks.emplace_back(new char[kStack]);
-            for (size_t i = 0; i < fns.size(); ++i) {
-                Task &t = tasks[i];
-                t.fn = fns[i];
-                getcontext(&t.ctx);
-                t.ctx.uc_stack.ss_sp = stacks[i].get();
-                t.ctx.uc_stack.ss_size = kStack;
-                t.ctx.uc_link = &main_ctx;
-                const uintptr_t q = reinterpret_cast<uintptr_t>(&t);
-                makecontext(&t.ctx, reinterpret_cast<void (*)()>(entry), 2, (unsigned)(q & 0xFFFFFFFFu), (unsigned)(q >> 32));
-            }
-            CoopSched *prev = current_coop();
-            current_coop() = this;
-            for (size_t left = tasks.size(); left > 0;) {
-                for (auto &t : tasks) {
-                    if (t.done) continue;
-                    cur = &t;
-                    swapcontext(&main_ctx, &t.ctx);
-                    if (t.done) { --left; note(t.rc); }
-                }
-            }
-            cur = nullptr;
-            current_coop() = prev;
-        }
-        if (first != MIH_OK) set_error("%s", first_msg.c_str());
-        return first;
-    }
 };
 
 // the lane's stream waits for everything fit f has queued on its own stream (f.v->s != lane stream only with private streams)
