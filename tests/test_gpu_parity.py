@@ -838,8 +838,8 @@ def test_digit_modes_agree(mih, oracle, normal_pair):
     x, ox = normal_pair
     n = x.n
     rng = np.random.default_rng(77)
-    R = rng.standard_normal((n, 16)) * np.logspace(-3, 4, 16)      # very different scales side by side
-    O = np.column_stack([ox.xtv(R[:, v]) for v in range(16)])
+    R = rng.standard_normal((n, 18)) * np.logspace(-3, 4, 18)      # very different scales side by side
+    O = np.column_stack([ox.xtv(R[:, v]) for v in range(18)])
     scale = np.sqrt(n) * np.abs(R).max(axis=0)
     out = {}
     try:
@@ -847,7 +847,7 @@ def test_digit_modes_agree(mih, oracle, normal_pair):
             mih.set_xtv_digits(mode)
             got = x.xtv(R)
             assert np.all(np.max(np.abs(got - O), axis=0) < tol * scale + 1e-13 * np.abs(O).max(axis=0)), mode
-            for m_rhs in (1, 2, 3, 4, 5, 7, 8, 10, 13, 15):            # 1 .. 8 operands: every pass split incl. 3+2
+            for m_rhs in (1, 2, 3, 4, 5, 7, 8, 10, 13, 15, 16, 17):   # 1 .. 9 operands: every pass split, 6-operand passes with and without a half-empty last operand
                 assert np.array_equal(x.xtv(R[:, :m_rhs]), got[:, :m_rhs]), (mode, m_rhs)
             out[mode] = got
     finally:

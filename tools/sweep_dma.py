@@ -24,7 +24,7 @@ def check():
             fp6 = digits in (0, 4908)
             ref_variant = 6 if fp6 else 9                 # the register-staged default shapes
             shapes = FP6_SHAPES if fp6 else FP4_SHAPES[digits]
-            for mm in ((13, 12, 10, 9, 7, 6, 4, 3, 1) if digits != 428 else (1, 2, 4)):
+            for mm in ((18, 16, 13, 12, 10, 9, 7, 6, 4, 3, 1) if digits != 428 else (1, 2, 4)):
                 R = np.asfortranarray(rng.standard_normal((n, mm)) * np.exp(rng.uniform(-20, 20, mm)))
                 m.probe_set(multi_variant=ref_variant)
                 ref = x.xtv(R)
