@@ -312,3 +312,53 @@ def test_glm_refit_of_debias_against_scikit_learn(oracle):
     b = oracle.debias_glm(ox, mask, yg, "gamma", "log")
     ref = GammaRegressor(alpha=0, fit_intercept=False, tol=1e-12, max_iter=2000).fit(Xs, yg).coef_
     np.testing.assert_allclose(b[supp], ref, rtol=0, atol=5e-5)        # the deviance of a Gamma fit is flat near the optimum: the 1e-6 stopping rule leaves ~1e-5 in beta
+
+
+def test_score_is_the_gradient_of_the_loglikelihood(oracle):
+    """score! (utilities.jl:126-135) forms X'r with r_i = mu'(eta_i) / Var(mu_i) * (y_i - mu_i); for every family / link pair the
+    path supports that must be the gradient of loglikelihood (utilities.jl:9-43) with respect to beta (for the dispersion
+    families: of the loglikelihood at fixed phi, times phi).  The reference checks its multivariate gradient against ForwardDiff
+    in a notebook (test/multivariate_gradient.ipynb); this pins the restated GLM.jl / Distributions.jl closed forms -- linkinv,
+    mueta, glmvar, loglik_obs -- against each other by central differences, independently of any of them being right by itself."""
+    import ctypes as C
+    L = oracle.lib()
+    rng = np.random.default_rng(7)
+    n, p = 60, 5
+    X = rng.standard_normal((n, p)) * 0.5
+    beta = rng.standard_normal(p) * 0.3
+    DIST = {"normal": 0, "bernoulli": 1, "poisson": 2, "negbin": 3, "gamma": 4, "invgauss": 5}
+    LINK = {"identity": 0, "logit": 1, "log": 2, "probit": 3, "cloglog": 4, "cauchit": 5, "inverse": 6, "invsquare": 7, "sqrt": 8}
+    cases = [("bernoulli", "logit"), ("bernoulli", "probit"), ("bernoulli", "cloglog"), ("bernoulli", "cauchit"),
+             ("poisson", "log"), ("poisson", "sqrt"), ("negbin", "log"), ("normal", "identity"), ("gamma", "log"), ("invgauss", "log")]
+    nb_r = 3.5
+    for dist, link in cases:
+        d, l = DIST[dist], LINK[link]
+        off = 2.0 if link in ("sqrt",) else 0.0                        # keep sqrt-link means away from 0
+        eta0 = X @ beta + off
+        mu0 = np.array([L.orc_linkinv(l, float(e)) for e in eta0])
+        if dist == "bernoulli":
+            y = (rng.random(n) < mu0).astype(float)
+        elif dist in ("poisson", "negbin"):
+            y = rng.poisson(mu0).astype(float)
+        elif dist == "normal":
+            y = mu0 + rng.standard_normal(n)
+        else:
+            y = rng.gamma(2.0, mu0 / 2.0)
+        w = np.ones(n)
+
+        def mu_of(b):
+            return np.array([L.orc_linkinv(l, float(e)) for e in X @ b + off])
+
+        phi = L.orc_deviance(d, nb_r, y.ctypes.data_as(C.c_void_p), mu0.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p), n) / n
+
+        def loglik(b):                                                   # sum_i loglik_obs(d, y_i, mu_i, 1, phi) at FIXED phi
+            m = mu_of(b)
+            return sum(L.orc_loglik_obs(d, float(y[i]), float(m[i]), 1.0, float(phi), nb_r) for i in range(n))
+
+        r = np.array([L.orc_mueta(l, float(eta0[i])) / L.orc_glmvar(d, float(mu0[i]), nb_r) * (y[i] - mu0[i]) for i in range(n)])
+        score = X.T @ r
+        h = 1e-6
+        num = np.array([(loglik(beta + h * np.eye(p)[j]) - loglik(beta - h * np.eye(p)[j])) / (2 * h) for j in range(p)])
+        # dispersion families: d loglik / d eta = r / phi' with phi' = phi (Normal), phi (Gamma: shape 1/phi), phi (InverseGaussian)
+        scale = phi if dist in ("normal", "gamma", "invgauss") else 1.0
+        np.testing.assert_allclose(num * scale, score, rtol=2e-5, atol=1e-6, err_msg=f"{dist}/{link}")
