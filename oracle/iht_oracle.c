@@ -869,6 +869,20 @@ static void mle_for_r(ihtvar *v)
     else if (v->est_r == 2) v->nb_r = update_r_newton(v);
 }
 
+/* mle_for_r on its own (method 1 = :MM one update, 2 = :Newton to its fixed point): for pinning the restated digamma / trigamma
+ * updates against an independent maximiser (tests/test_oracle_golden.py).  wts may be NULL (all ones). */
+double orc_mle_for_r(const double *y, const double *mu, const double *wts, int64_t n, double r0, int method)
+{
+    ihtvar v;
+    memset(&v, 0, sizeof(v));
+    double *w = NULL;
+    if (!wts) { w = dalloc(n); for (int64_t i = 0; i < n; ++i) w[i] = 1.0; }
+    v.y = y; v.mu = (double *)mu; v.cv_wts = wts ? (double *)wts : w; v.n = n; v.dist = ORC_NEGBIN; v.link = ORC_LOG; v.nb_r = r0; v.est_r = method;
+    mle_for_r(&v);
+    free(w);
+    return v.nb_r;
+}
+
 /* backtrack! utilities.jl:959-973 */
 static int backtrack(ihtvar *v, double eta, double *logl)
 {

@@ -113,6 +113,9 @@ double orc_deviance(int dist, double nb_r, const double *y, const double *mu,
  * weights); b[j] receives the coefficients.  For pinning the restated GLM.jl IRLS against an independent solver. */
 int orc_debias_glm(const orc_mat *x, const uint8_t *idx, const double *y, int dist, int link, double nb_r, double *b);
 
+/* mle_for_r (utilities.jl:141-247) on its own: method 1 = one :MM update, 2 = :Newton to its fixed point; wts may be NULL. */
+double orc_mle_for_r(const double *y, const double *mu, const double *wts, int64_t n, double r0, int method);
+
 /* ---- drivers ------------------------------------------------------------ */
 /* fit_iht (fit.jl:60-118); z is n x q column-major; train = NULL or n flags. */
 int orc_fit_iht(const orc_mat *x, const orc_params *prm, const double *y,

@@ -98,6 +98,8 @@ def lib():
                                    C.c_void_p, C.c_void_p]
         _lib.orc_set_threads.argtypes = [C.c_int]
         _lib.orc_debias_glm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]
+        _lib.orc_mle_for_r.restype = C.c_double
+        _lib.orc_mle_for_r.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_int]
     return _lib
 
 
@@ -337,6 +339,13 @@ def debias_glm(x, support_mask, y, dist, link, nb_r=1.0):
     if rc:
         raise RuntimeError(f"orc_debias_glm rc={rc}")
     return b
+
+
+def mle_for_r(y, mu, r0=1.0, method="newton"):
+    """mle_for_r (utilities.jl:141-247) on its own: the NegBin r given y and mu."""
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    mu = np.ascontiguousarray(mu, dtype=np.float64)
+    return lib().orc_mle_for_r(_p(y), _p(mu), None, y.size, float(r0), {"mm": 1, "newton": 2}[method])
 
 
 def standardize_columns(z):

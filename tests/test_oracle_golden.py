@@ -362,3 +362,32 @@ def test_score_is_the_gradient_of_the_loglikelihood(oracle):
         # dispersion families: d loglik / d eta = r / phi' with phi' = phi (Normal), phi (Gamma: shape 1/phi), phi (InverseGaussian)
         scale = phi if dist in ("normal", "gamma", "invgauss") else 1.0
         np.testing.assert_allclose(num * scale, score, rtol=2e-5, atol=1e-6, err_msg=f"{dist}/{link}")
+
+
+def test_negbin_nuisance_parameter_against_scipy(oracle):
+    """mle_for_r (utilities.jl:141-247): the Newton update (digamma / trigamma score and curvature, line search on the
+    loglikelihood) must end at the maximiser over r of sum_i logpmf(NegativeBinomial(r, r / (mu_i + r)), y_i) -- found here
+    independently by scipy's bounded scalar minimiser on scipy.stats.nbinom -- and one MM update must not decrease that
+    loglikelihood (it is a minorise-maximise step, docs/src/man/math.md:93-193)."""
+    from scipy import optimize
+    rng = np.random.default_rng(11)
+    n = 4000
+    mu = np.exp(rng.normal(0.8, 0.5, n))
+    for r_true in (1.5, 4.0, 12.0):
+        y = rng.negative_binomial(r_true, r_true / (mu + r_true)).astype(float)
+
+        def nll(r):
+            return -stats.nbinom.logpmf(y, r, r / (mu + r)).sum()
+        best = optimize.minimize_scalar(nll, bounds=(1e-3, 1e3), method="bounded", options={"xatol": 1e-10})
+        r_newton = oracle.mle_for_r(y, mu, r0=1.0, method="newton")
+        assert r_newton == pytest.approx(best.x, rel=2e-5), r_true            # stops at |dr| <= 1e-6 (utilities.jl:242)
+        assert abs(r_newton - r_true) < 0.25 * r_true                           # and it is the right quantity
+        r_mm = oracle.mle_for_r(y, mu, r0=1.0, method="mm")
+        assert nll(r_mm) <= nll(1.0) + 1e-9                                     # one MM step goes uphill
+        r2, last = r_mm, nll(r_mm)
+        for _ in range(300):                                                    # MM converges linearly: monotone, towards the same maximiser
+            r2 = oracle.mle_for_r(y, mu, r0=r2, method="mm")
+            cur = nll(r2)
+            assert cur <= last + 1e-9
+            last = cur
+        assert r2 == pytest.approx(best.x, rel=1e-2) and abs(r2 - best.x) < abs(r_mm - best.x)
