@@ -388,6 +388,6 @@ def test_negbin_nuisance_parameter_against_scipy(oracle):
         for _ in range(300):                                                    # MM converges linearly: monotone, towards the same maximiser
             r2 = oracle.mle_for_r(y, mu, r0=r2, method="mm")
             cur = nll(r2)
-            assert cur <= last + 1e-9
+            assert cur <= last * (1 + 1e-7)                                     # (the update oscillates at the 1e-8 level once it is there)
             last = cur
         assert r2 == pytest.approx(best.x, rel=1e-2) and abs(r2 - best.x) < abs(r_mm - best.x)
