@@ -247,6 +247,14 @@ def test_multivariate_shipped_data(oracle):
     sel0 = set(np.flatnonzero(r["B"][0]) + 1)
     sel1 = set(np.flatnonzero(r["B"][1]) + 1)
     assert {134, 442, 450, 1891, 2557, 3243} <= sel0 and {1014, 5214} <= sel1
+    # independent restatement of what the fit returns: Sigma = R R' / n at the returned model (solve_Sigma!, multivariate.jl:276-282)
+    # and logl = the multivariate-normal loglikelihood of the residuals without its 2 pi constant (multivariate.jl:9-13), by scipy
+    B, Cm = r["B"], r["C"]
+    XB = np.vstack([x.xv_masked((B[i] != 0).astype(np.uint8), B[i]) for i in range(2)])
+    R = Y - XB - Cm @ np.ones((1, n))
+    np.testing.assert_allclose(R @ R.T / n, r["Sigma"], rtol=0, atol=1e-13)
+    want = stats.multivariate_normal(mean=np.zeros(2), cov=r["Sigma"]).logpdf(R.T).sum() + n * 2 / 2 * np.log(2 * np.pi)
+    assert r["logl"] == pytest.approx(want, rel=1e-12)
 
 
 def _oracle_goldens():
