@@ -316,3 +316,18 @@ def test_wrapper_parsers_follow_the_reference(mih, tmp_path):
     buf = io.StringIO()
     api.print_cv_results(buf, np.array([3.5, 2.25]), [4, 9], 9)
     assert buf.getvalue() == "\n\nCrossvalidation Results:\n\tk\tMSE\n\t4\t3.5\n\t9\t2.25\n\nBest k = 9\n\n"   # data_structures.jl:327-335
+
+
+def test_lockstep_coroutine_scheduler_on_cpu(mih, tmp_path):
+    """LaneSched (csrc/fit_common.h) -- the coroutines the fits of a lock-step lane run as -- is host logic: round-robin
+    interleaving at yields, no switch inside an allocation scope, every task completes even when one fails, the first error is
+    the one reported, stacks reused.  tests/lanesched_harness.cpp, built with hipcc as host code against the product library."""
+    import subprocess
+    from conftest import ROOT
+    exe = tmp_path / "lanesched_harness"
+    libdir = os.path.join(ROOT, "mendeliht.jl_amd")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", "-O1", "-I", os.path.join(libdir, "csrc"),
+                           os.path.join(ROOT, "tests", "lanesched_harness.cpp"), "-o", str(exe), "-L", libdir, "-lmendeliht_hip",
+                           f"-Wl,-rpath,{libdir}", "-Wno-unused-result"], stderr=subprocess.DEVNULL)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "lanesched: OK" in r.stdout, r.stdout + r.stderr
