@@ -90,6 +90,20 @@ def test_fold_sharding_covers_every_combination(mih):
     for world in (1, 2, 3, 8):
         seen = sorted(i for r in range(world) for i in D.shard_combinations(q, npath, r, world))
         assert seen == list(range(q * npath))
+    # the rule (mih_cv_assignment): round-robin over the combinations sorted by model size -- every rank gets a stratified
+    # sample of the model sizes, 12 or 13 of the 100 fits at world = 8, and a single rank gets everything
+    rank_of = mih.cv_assignment(range(1, 21), 5, 8)
+    assert rank_of.shape == (5, 20)
+    for r in range(8):
+        fold, ik = np.nonzero(rank_of == r)
+        assert fold.size in (12, 13)
+        ks = np.sort(ik + 1)
+        assert ks[0] <= 2 and ks[-1] >= 19 and np.max(np.diff(ks)) <= 3          # no rank collects only large or only small models
+        assert len(set(fold)) == 5                                              # and every rank works on every fold
+    assert np.all(mih.cv_assignment([5, 1, 9], 4, 1) == 0)
+    # a path that is not sorted: the rule sorts by the model size, not by the position in the path
+    a = mih.cv_assignment([3, 50, 7], 2, 2)
+    assert sorted(a[:, 1]) == [0, 1] and sorted(a[:, 2]) == [0, 1] and sorted(a[:, 0]) == [0, 1]
 
 
 def _build_harness(tmp_path):
