@@ -396,3 +396,33 @@ def test_negbin_nuisance_parameter_against_scipy(oracle):
         num = sum((r0 / (r0 + np.arange(int(v)))).sum() for v in y)
         den = np.log(r0 / (r0 + mu)).sum()
         assert oracle.mle_for_r(y, mu, r0=r0, method="mm") == pytest.approx(-num / den, rel=1e-12)
+
+
+def test_project_group_sparse_against_a_set_based_statement(oracle):
+    """project_group_sparse! (utilities.jl:613-679) is written as two passes over a sort permutation.  The same projection stated
+    as sets, in numpy: within each group keep its k_g largest |y| (k_g scalar or per group); rank the groups by the squared norm
+    of what they kept; keep the J best groups, zero everything else.  Continuous random data (no ties): the two must agree."""
+    rng = np.random.default_rng(613)
+    for trial in range(20):
+        p = int(rng.integers(30, 400))
+        G = int(rng.integers(1, 12))
+        group = rng.integers(1, G + 1, p)
+        group[:G] = np.arange(1, G + 1)                      # labels 1..G all present
+        y = rng.standard_normal(p) * np.exp(rng.normal(0, 1, p))
+        J = int(rng.integers(1, G + 1))
+        vector_k = trial % 2 == 1
+        k = rng.integers(0, 6, G) if vector_k else int(rng.integers(1, 6))
+        want = np.zeros(p)
+        norms = np.zeros(G)
+        kept = {}
+        for g in range(1, G + 1):
+            idx = np.flatnonzero(group == g)
+            kg = int(k[g - 1]) if vector_k else k
+            top = idx[np.argsort(-np.abs(y[idx]), kind="stable")[:kg]]
+            kept[g] = top
+            norms[g - 1] = np.sum(y[top] ** 2)
+        best = np.argsort(-norms, kind="stable")[:J] + 1
+        for g in best:
+            want[kept[g]] = y[kept[g]]
+        got = oracle.project_group_sparse(y, group, J, k)
+        assert np.array_equal(got, want), (trial, p, G, J, k)
