@@ -214,6 +214,12 @@ k_publish(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst_host, uin
     publish_block(src, dst_host, words, flag_host, seq);
 }
 
+// how long a lane's fit polls (switching to the lane's other fits in between) before the thread goes to sleep in hipStreamSynchronize
+static long coop_spin_us()
+{
+    static const long us = [] { const char *e = probe_env("MENDELIHT_COOP_SPIN_US"); return e ? atol(e) : 300l; }();
+    return us;
+}
 static bool spin_on()
 {
     static const bool on = [] { const char *e = probe_env("MENDELIHT_NO_SPIN"); return !(e && atoi(e) != 0); }();
@@ -227,24 +233,31 @@ uint64_t spin_begin(SpinFlag &f)
 }
 int stream_sync_coop(hipStream_t s)
 {
-    if (!coop_can_yield()) { MIH_HIP(hipStreamSynchronize(s)); return MIH_OK; }
-    for (;;) {
-        const hipError_t e = hipStreamQuery(s);
-        if (e == hipSuccess) return MIH_OK;
-        if (e != hipErrorNotReady) return hip_fail(e, "hipStreamQuery", __FILE__, __LINE__);
-        current_coop()->yield();
+    if (coop_can_yield()) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned it = 0;; ++it) {
+            const hipError_t e = hipStreamQuery(s);
+            if (e == hipSuccess) return MIH_OK;
+            if (e != hipErrorNotReady) return hip_fail(e, "hipStreamQuery", __FILE__, __LINE__);
+            current_coop()->yield();
+            if ((it & 15u) == 15u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(coop_spin_us())) break;      // see spin_wait
+        }
     }
+    MIH_HIP(hipStreamSynchronize(s));
+    return MIH_OK;
 }
 int spin_wait(hipStream_t s, SpinFlag &f, uint64_t seq)
 {
     const auto t0 = std::chrono::steady_clock::now();
     if (coop_can_yield()) {
         // a lane's fit: let the thread queue the other fits' chains while this readback is on its way; when every fit of the lane
-        // waits, the scheduler's round-robin is the spin.  After 10 s something is wrong: the synchronise below reports it.
+        // waits, the scheduler's round-robin is the spin.  A readback that is not there after 300 us sits behind a fused pass of
+        // tens of ms (every fit of the lane then waits for the same pass): stop switching contexts -- every switch is two
+        // sigprocmask system calls -- and let the thread sleep in the synchronise below.
         for (unsigned it = 0;; ++it) {
             if (__atomic_load_n(f.word.p, __ATOMIC_ACQUIRE) == seq) return MIH_OK;
             current_coop()->yield();
-            if ((it & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) break;
+            if ((it & 15u) == 15u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(coop_spin_us())) break;
         }
     }
     else for (unsigned it = 0;; ++it) {

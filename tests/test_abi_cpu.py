@@ -41,7 +41,7 @@ def test_probe_entry_points_live_in_the_measurement_build_only(mih):
     blob = open(mih.library_path(), "rb").read()
     for switch in (b"MENDELIHT_XTV_MAX_OPS", b"MENDELIHT_XTV_SLICES", b"MENDELIHT_XTV_NO_HALF", b"MENDELIHT_CV_LANES", b"MENDELIHT_CV_NO_MERGE",
                    b"MENDELIHT_CV_NO_INIT_SHARE", b"MENDELIHT_CV_TRACE", b"MENDELIHT_NO_SPIN", b"MENDELIHT_NO_ARENA", b"MENDELIHT_TOPK_RADIX8",
-                   b"MENDELIHT_XV_MULTI", b"MENDELIHT_CV_ASSIGN", b"MENDELIHT_CV_NO_COOP", b"MENDELIHT_INGEST_TRACE"):
+                   b"MENDELIHT_XV_MULTI", b"MENDELIHT_CV_ASSIGN", b"MENDELIHT_CV_NO_COOP", b"MENDELIHT_COOP_SPIN_US", b"MENDELIHT_INGEST_TRACE"):
         assert switch not in blob, switch
         assert switch in open(mih.probes_library_path(), "rb").read(), switch
     assert C.sizeof(api._PassRecord) == 80
