@@ -884,7 +884,8 @@ struct IhtVar {
         choose_fired = false;
         MIH_TRY(set_weights(train, 0));
         ntrain = 0; double ybar = 0.0;
-        for (int64_t i = 0; i < n; ++i) if (!train || train[i]) { ybar += y_host[i]; ntrain++; }
+        if (train_sums_valid) { ntrain = train_count; ybar = train_ysum; train_sums_valid = false; }      // the lock-step driver has them per fold
+        else for (int64_t i = 0; i < n; ++i) if (!train || train[i]) { ybar += y_host[i]; ntrain++; }
         if (ntrain == 0) { set_error("no training samples"); return MIH_BAD_ARG; }
         ybar /= (double)ntrain;
         for (int it = 0; it < 20; ++it) {          // utilities.jl:400-405
@@ -979,6 +980,9 @@ struct IhtVar {
         return MIH_OK;
     }
     const uint8_t *train_cur = nullptr;
+    // sum of y over the training rows and their count, in the order of init_pre's own loop, when the caller has them already
+    // (cv_iht computes them once per fold instead of once per (fold, k) fit: two sweeps over n on the host per fit otherwise)
+    bool train_sums_valid = false; int64_t train_count = 0; double train_ysum = 0.0;
     // initialize_beta! results of the last training mask (reused across the k of one CV fold)
     DevBuf<double> ib_beta; std::vector<double> ib_c; std::vector<uint8_t> ib_train; bool ib_valid = false;
     int init_post()
@@ -1314,7 +1318,7 @@ struct CvFit {
     std::unique_ptr<IhtVar> v;
     std::vector<std::unique_ptr<IhtVar>> *pool = nullptr;   // the lane's free list: a finished fit hands its IHTVariable back
     void release() { if (v && pool) pool->push_back(std::move(v)); v.reset(); }
-    std::vector<uint8_t> train;
+    const uint8_t *train = nullptr;  // training mask of its fold (owned by the driver, shared by the fold's fits); null: all rows
     int64_t out_index = 0;
     int init_key = -1;       // fits with the same key >= 0 have the same initial residual (same training rows; the model size
                              // enters only after the first score): one of them rides the pass, the others copy its X'r
@@ -1362,7 +1366,7 @@ static int cv_finish(CvFit &f, double *mses_raw)
         f.release();
         return MIH_OK;
     }
-    MIH_TRY(f.v->set_weights(f.train.data(), 1));     // cv_wts <- test mask (cross_validation.jl:115-116)
+    MIH_TRY(f.v->set_weights(f.train, 1));            // cv_wts <- test mask (cross_validation.jl:115-116)
     MIH_TRY(f.v->update_xb());                        // predict! (:279-286)
     double dev;
     MIH_TRY(f.v->mu_loglik(1, nullptr, &dev));
@@ -1462,7 +1466,7 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
                 if (!pool.empty()) { slot[t]->v = std::move(pool.back()); pool.pop_back(); }
                 MIH_TRY(make(i, *slot[t], s, shared));
                 CvFit &f = *slot[t];
-                MIH_TRY(f.v->init_pre(f.train.empty() ? nullptr : f.train.data()));
+                MIH_TRY(f.v->init_pre(f.train));
                 if (share_init && f.init_key >= 0) {
                     auto it = df0.find(f.init_key);
                     if (it != df0.end()) {       // its initial X'r is known from an earlier round: no pass, straight on to its first step
@@ -1727,6 +1731,16 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, con
         return MIH_OK;
     }
 
+    // training masks, training-row counts and sums of y: once per fold, not once per (fold, k) fit
+    std::vector<std::vector<uint8_t>> fold_train((size_t)nfolds, std::vector<uint8_t>((size_t)n));
+    std::vector<int64_t> fold_count((size_t)nfolds, 0);
+    std::vector<double> fold_ysum((size_t)nfolds, 0.0);
+    for (int32_t fold = 1; fold <= nfolds; ++fold) {
+        uint8_t *t = fold_train[(size_t)fold - 1].data();
+        int64_t cnt = 0; double ys = 0.0;
+        for (int64_t i = 0; i < n; ++i) { t[i] = (folds[i] != fold); if (t[i]) { ys += y[i]; ++cnt; } }      // the order of IhtVar::init_pre's loop
+        fold_count[(size_t)fold - 1] = cnt; fold_ysum[(size_t)fold - 1] = ys;
+    }
     // this rank's combinations, fold-major (cross_validation.jl:217-223), in batches
     std::vector<std::pair<int32_t, int64_t>> mine;
     int64_t combo = 0;
@@ -1742,8 +1756,8 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, con
             MIH_TRY(f.v->create(h, &pr, y, z, q, s, sh.y, sh.z, sh.next_stream()));     // sized for max(path), then
             MIH_TRY(f.v->set_k(path[ik]));
         }
-        f.train.resize(n);
-        for (int64_t i = 0; i < n; ++i) f.train[i] = (folds[i] != fold);
+        f.train = fold_train[(size_t)fold - 1].data();
+        f.v->train_count = fold_count[(size_t)fold - 1]; f.v->train_ysum = fold_ysum[(size_t)fold - 1]; f.v->train_sums_valid = true;
         f.out_index = (int64_t)(fold - 1) * npath + ik;
         f.init_key = fold;
         f.v->ib_shared = sh.ib; f.v->ib_key = fold;        // (a recycled IHTVariable may come from the other lane: re-point it)
