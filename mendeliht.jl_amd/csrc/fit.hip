@@ -1809,6 +1809,8 @@ int mih_fit_iht_path(const mih_mat *h, const mih_fit_params *prm, const double *
         }
         return MIH_OK;
     }
+    double ysum_all = 0.0;
+    for (int64_t i = 0; i < h->n; ++i) ysum_all += y[i];                      // the order of IhtVar::init_pre's loop
     auto make = [&](size_t t, CvFit &f, hipStream_t s, const CvShared &sh) -> int {
         slots(f, mine[t]);
         f.init_key = 0;                                    // every fit of the path starts from the same residual (all rows)
@@ -1817,6 +1819,7 @@ int mih_fit_iht_path(const mih_mat *h, const mih_fit_params *prm, const double *
             MIH_TRY(f.v->create(h, &pr, y, z, q, s, sh.y, sh.z, sh.next_stream()));     // sized for max(path)
         }
         f.v->ib_shared = sh.ib; f.v->ib_key = 0;
+        f.v->train_count = h->n; f.v->train_ysum = ysum_all; f.v->train_sums_valid = true;      // (all rows: once per path, not once per fit)
         return f.v->set_k(path[mine[t]]);
     };
     return cv_run_lanes(h, pr, mine.size(), make, nullptr, 1, y, z, q);
