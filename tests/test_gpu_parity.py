@@ -788,7 +788,7 @@ def test_concurrent_fits_share_one_matrix(mih, normal_pair, normal_data):
 
 @pytest.mark.parametrize("mode,quantum", [(4908, 1e-12), (1308, 2e-7)])
 def test_fast_digit_mode(mih, oracle, normal_pair, normal_data, mode, quantum):
-    """mih_set_xtv_digits(4908): 43-bit fixed-point residuals as 8 base-49 FP6 digits, four per MFMA B operand (the
+    """xtv_digits = 4908: 43-bit fixed-point residuals as 8 base-49 FP6 digits, four per MFMA B operand (the
     opt-in mode for fused multi-RHS passes), and (1308): 27-bit residuals as 8 base-13 FP4 digits.  X'r stays within the format's
     quantum of the exact mode, is independent of how the residuals are grouped into passes, and fits /
     cross-validation stay inside the north_star tolerance."""
@@ -831,7 +831,7 @@ def test_fast_digit_mode(mih, oracle, normal_pair, normal_data, mode, quantum):
 
 
 def test_digit_modes_agree(mih, oracle, normal_pair):
-    """Every fixed-point format of the residual (mih_set_xtv_digits) against the oracle's f64 X'r: the default
+    """Every fixed-point format of the residual (xtv_digits) against the oracle's f64 X'r: the default
     (10 base-49 FP6 digits, three residuals per operand), 16 base-13 FP4 digits (two per operand) and 28 base-4
     digits (one per operand) agree to f64 rounding; the 43-bit and 27-bit formats to their quantum; each is
     independent of how residuals share operands."""

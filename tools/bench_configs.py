@@ -13,7 +13,7 @@ os.environ.setdefault("MENDELIHT_HIP_PROBES", "1")     # kernel-shape knobs / A-
 import mendeliht_amd as m
 hash_folds = m.hash_folds
 
-digits = int(os.environ.get("MIH_DIGITS", 0))      # mih_set_xtv_digits: 0 default, 4908 = the opt-in fast mode for fused multi-RHS passes
+digits = int(os.environ.get("MIH_DIGITS", 0))      # xtv_digits: 0 default, 4908 = the opt-in fast mode for fused multi-RHS passes
 m.set_xtv_digits(digits)
 out = {"xtv_digits": digits}
 # ---- configs[1]

@@ -1,4 +1,4 @@
-"""Multi-RHS X'r passes in every residual format (mih_set_xtv_digits): 0 = 10 base-49 FP6 digits, three residuals per B
+"""Multi-RHS X'r passes in every residual format (the xtv_digits of a call): 0 = 10 base-49 FP6 digits, three residuals per B
 operand (default); 1316 = 16 base-13 FP4 digits, two per operand; 428 = 28 base-4 digits, one per operand;
 4908 / 1308 = the four-per-operand fast formats."""
 import os, sys

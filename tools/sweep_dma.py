@@ -1,4 +1,4 @@
-"""The LDS-DMA ring kernels (k_xtv_dma, mih_set_xtv_multi_variant 20.. and the FP6 defaults) against the register-staged
+"""The LDS-DMA ring kernels (k_xtv_dma, mih_probe_set_xtv_multi_variant 20.. and the FP6 defaults) against the register-staged
 LDS kernels: bit-equality on small ragged matrices in every residual format, then timings at n=500k, p=1M.
 usage: sweep_dma.py [check|time|single|all]"""
 import os, sys

@@ -1,4 +1,4 @@
-"""Round-1 launch shapes of the 4-operand FP6 X'r pass (mih_set_xtv_multi_variant 1..6 = register-staged shapes, 6 =
+"""Round-1 launch shapes of the 4-operand FP6 X'r pass (mih_probe_set_xtv_multi_variant 1..6 = register-staged shapes, 6 =
 round 1's default <4,2,1,8>; 0 = the round-2 library default k_xtv_dma16<4,2,8,4>, see tools/sweep_dma.py).  Round 1 read: 0 =
 <4,2,1,8>, the default, 1 = <4,2,2,8>) and
 the 3-operand passes of both digit formats."""

@@ -1,4 +1,4 @@
-"""Time fused multi-operand X'r passes for every kernel shape (mih_set_xtv_multi_variant).
+"""Time fused multi-operand X'r passes for every kernel shape (mih_probe_set_xtv_multi_variant).
 usage: sweep_multi.py [nops] [variants...]   (nops = 2 or 4 B operands per pass)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

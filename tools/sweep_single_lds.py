@@ -1,6 +1,6 @@
-"""Single-operand X'r pass: the round-1 register-staged LDS shapes (mih_set_xtv_multi_variant 9 = round 1's default
+"""Single-operand X'r pass: the round-1 register-staged LDS shapes (mih_probe_set_xtv_multi_variant 9 = round 1's default
 <1,1,4>, 10..14; 0 = the round-2 library default, the LDS-DMA ring k_xtv_dma<1,2,4,8>; tools/sweep_dma.py sweeps the ring shapes)
-against the best per-wave-load shape (mih_set_xtv_variant 2)."""
+against the best per-wave-load shape (mih_probe_set_xtv_variant 2)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("MENDELIHT_HIP_PROBES", "1")     # kernel-shape knobs / A-B switches: the measurement build
