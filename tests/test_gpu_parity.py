@@ -1881,3 +1881,25 @@ def test_lockstep_error_paths_leave_the_library_usable(mih):
             mih.iht_run_many_models(bad, x, None, path=range(1, 9), verbose=False)
     after = mih.cv_iht(y, x, None, **kw)[1]
     assert np.array_equal(before.view(np.uint64), after.view(np.uint64))
+
+
+def test_ingest_pipeline_at_full_row_count(mih):
+    """mih_snp_create's upload pipeline (round 3: eight workers with their own streams pulling 16 MB chunks of whole column groups
+    from one queue) at the row count of the benchmark: 3000 columns of n = 500 000 (375 MB, 24 chunks, a ragged last one) with
+    missing genotypes must give the matrix the on-device generator built -- same bytes back out, same column statistics, same
+    X'r bits."""
+    n, p = 500_000, 3000
+    xs = mih.SnpLinAlg.synthetic(n, p, seed=31, missing_rate=0.01)
+    cols = xs.export_bed()
+    x = mih.SnpLinAlg(cols, n=n, center=True, scale=True, impute=True)
+    assert np.array_equal(x.export_bed(), cols)
+    mu_s, sv_s = xs.mu_sigma()
+    mu, sv = x.mu_sigma()
+    assert np.array_equal(mu, mu_s) and np.array_equal(sv, sv_s)
+    r = np.random.default_rng(3).standard_normal(n)
+    assert np.array_equal(x.xtv(r), xs.xtv(r))
+    # a strided source (col_stride_bytes > ceil(n/4)) through the same pipeline
+    wide = np.zeros((p, cols.shape[1] + 37), dtype=np.uint8)
+    wide[:, :cols.shape[1]] = cols
+    x2 = mih.SnpLinAlg(wide, n=n, center=True, scale=True, impute=True)
+    assert np.array_equal(x2.export_bed(), cols)
