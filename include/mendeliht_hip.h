@@ -52,7 +52,7 @@ typedef struct mih_mat mih_mat;     /* device-resident design matrix */
 int mih_device_count(int *count);
 /* thread-local message of the last failing call on this host thread */
 int mih_last_error(char *buf, size_t len);
-int mih_version(int *major, int *minor);
+int mih_version(int *major, int *minor);     /* 0.3: round 3 of this header (per-call residual format, per-handle measurement hook) */
 /* sizeof(mih_fit_params), sizeof(mih_fit_result), sizeof(mih_mv_result), sizeof(mih_comm): lets a binding
  * check its struct mirrors against the library it loaded. */
 int mih_abi_sizes(int64_t *sizes, int32_t n);
