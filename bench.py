@@ -83,6 +83,12 @@ def cores_used(threads):
 def self_launch(a):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a child `python -m torch.distributed.run` BEFORE this
     process touches a GPU (it never does), relay the child's stdout (rank 0's JSON line) and return its exit code."""
+    if not os.environ.get("MIH_BENCH_ONE_DEVICE"):
+        import torch                                             # counting devices does not initialise the GPU
+        have = torch.cuda.device_count()
+        if have < a.gpus:
+            sys.exit(f"bench.py --gpus {a.gpus}: this node has {have} GPU(s); one rank per GPU is needed "
+                     "(MIH_BENCH_BACKEND=gloo MIH_BENCH_ONE_DEVICE=1 runs all ranks on one device as a functional check)")
     port = a.master_port
     if not port:
         with socket.socket() as sk:

@@ -280,7 +280,10 @@ def test_bench_starts_its_own_ranks():
         return
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
                        env=env, timeout=600)
-    assert r.returncode != 0
+    assert r.returncode != 0 and "GPU(s)" in r.stderr              # fewer GPUs than ranks: said so before anything is started
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
+                       env=dict(env, MIH_BENCH_ONE_DEVICE="1", MIH_BENCH_BACKEND="gloo"), timeout=600)
+    assert r.returncode != 0                                       # the ranks start, find no GPU, and their exit code comes back
 
 
 def test_wrapper_parsers_follow_the_reference(mih, tmp_path):
