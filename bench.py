@@ -83,7 +83,7 @@ def cores_used(threads):
 def self_launch(a):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a child `python -m torch.distributed.run` BEFORE this
     process touches a GPU (it never does), relay the child's stdout (rank 0's JSON line) and return its exit code."""
-    if not os.environ.get("MIH_BENCH_ONE_DEVICE"):
+    if not a.dry_run and not os.environ.get("MIH_BENCH_ONE_DEVICE"):
         import torch                                             # counting devices does not initialise the GPU
         have = torch.cuda.device_count()
         if have < a.gpus:
