@@ -1329,13 +1329,15 @@ static int dispatch_xtv(const XtvTune &tn, int nr, bool half, const mih_mat *h, 
 // Row slices of the library-default kernels.  A slice should hold about 50 000 rows or more -- every (column group,
 // slice) work item pays a prologue and a 16-accumulator epilogue, and short items lose to that: at n = 50 000 one
 // slice runs at 87 % of the HBM peak and eight at 75 %, at n = 10 000 it is 74 % against 38 % -- but there must be
-// enough workgroups to fill 256 CUs, and at n = 500 000 eight slices (one per XCD, sharing that slice of the digit
-// planes in its L2) are best (87.0 % against 83.3 % for one).
+// enough workgroups to fill 256 CUs.  At n = 500 000 round 1's kernels were best with eight slices (87.0 % against 83.3 % for
+// one); with the LDS-DMA ring kernels FOUR are (round 3, tools/sweep_slices*.py, alternated in one process: single-fit pass
+// 17.57 ms against 17.63 ms with eight, 18 residuals 38.9-39.1 against 39.2-39.4 ms) -- and the count must divide the 8 XCDs
+// (slice = blockIdx % slices; five slices: 18.76 ms).
 static int auto_splits(const mih_mat *h, const XtvTune &tn)
 {
     if (tn.slices >= 1 && tn.slices <= kMaxSplits) return tn.slices;       // measurement build only
     int s = 1;
-    while (s < 8 && h->n >= 100000ll * s) s *= 2;
+    while (s < 4 && h->n >= 100000ll * s) s *= 2;
     const int64_t groups = (h->ncg + 15) / 16;                 // workgroups per slice of the widest launch shape
     while (s < 16 && groups * s < 2048 && h->nbp / (2 * s) >= 8) s *= 2;
     return s;
