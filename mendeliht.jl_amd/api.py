@@ -103,6 +103,7 @@ def lib():
     if _lib is not None:
         return _lib
     path = probes_library_path() if using_probes() else library_path()
+    path = os.environ.get("MENDELIHT_HIP_LIB", path)          # an explicit build of the library (the Julia glue reads the same variable)
     if not os.path.exists(path):
         raise MendelIHTError(
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
