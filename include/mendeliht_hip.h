@@ -193,7 +193,25 @@ typedef struct mih_fit_params {
     int32_t  xtv_digits;      /* fixed-point format of the residual in this call's X'r passes (no reference counterpart):
                                  0 = library default; 4910, 4908, 1316, 1308, 428 -- see mih_xtv_batched_fmt.  A property
                                  of the CALL: concurrent fits on one matrix may use different formats. */
+    /* The reference's RANDOM tie-break, _choose! (src/utilities.jl:444-458, src/multivariate.jl:310-351): when a projection
+     * leaves more than k non-zero effects (exact ties in |b|) the reference removes the excess at random with the caller's
+     * RNG.  NULL: the library removes the smallest |b| (ties: highest index) and raises choose_fired in the result.
+     * Otherwise the library asks the caller, so a Julia binding that answers with the reference's own two calls reproduces
+     * the reference's draw from the same RNG state (the only RNG use on the path besides the default `folds`):
+     *   kind MIH_CHOOSE_SAMPLE    `sample(non_zero_idx, excess, replace=false)` (utilities.jl:453): list = the n positions of
+     *                             non-zero SNP effects (findall order, 0-based); write the `excess` positions to zero to out.
+     *   kind MIH_CHOOSE_SHUFFLE_B `shuffle!(B_nz_idx)` (multivariate.jl:336): list = the n linear indices (trait + r * SNP,
+     *                             eachindex order) of the non-zero entries of B; write ALL n in shuffled order to out.
+     *   kind MIH_CHOOSE_SHUFFLE_C `shuffle!(C_nz_idx)` (multivariate.jl:337), called right after _B: the non-zero entries of
+     *                             the covariates NOT in zkeep (trait + r * covariate); write all n in shuffled order to out.
+     * The library then zeroes what the reference's loop zeroes (multivariate.jl:338-348).  Called on the thread that called
+     * mih_fit_iht / mih_session_* / mih_fit_mv; a non-zero return aborts the fit with MIH_BAD_ARG.  Ignored by the lock-step
+     * drivers (cv_iht, model paths: their fits run on the library's threads -- the reference's own threaded loop draws from
+     * task-local RNGs there) and by column-sharded fits (comm != NULL). */
+    int (*choose)(void *user, int32_t kind, const int64_t *list, int64_t n, int64_t excess, int64_t *out);
+    void    *choose_user;
 } mih_fit_params;
+enum { MIH_CHOOSE_SAMPLE = 0, MIH_CHOOSE_SHUFFLE_B = 1, MIH_CHOOSE_SHUFFLE_C = 2 };
 
 /* IHTResult (src/data_structures.jl:245-256) + the per-iteration log */
 typedef struct mih_fit_result {

@@ -20,6 +20,8 @@
 module MendelIHTHip
 
 using MendelIHT, SnpArrays, Distributions, GLM, LinearAlgebra, DelimitedFiles
+using StatsBase: sample
+using Random: shuffle!
 import MendelIHT: fit_iht, cv_iht, iht_run_many_models, IHTResult, mIHTResult, maf_weights, naive_impute
 
 export HipSnpLinAlg, hip_iht, hip_cross_validate
@@ -112,6 +114,7 @@ struct MihFitParams
     comm::Ptr{Cvoid}      # Ptr{MihComm} for a column-sharded fit, C_NULL otherwise
     debias::Int32
     xtv_digits::Int32     # fixed-point format of the residual in this call's X'r passes (0 = library default)
+    choose::Ptr{Cvoid}; choose_user::Ptr{Cvoid}       # the RNG draw of _choose! (choose_cb below)
 end
 # mih_comm: exchange callbacks of a column-sharded fit (one Julia process per GPU, e.g. under mpiexec)
 struct MihComm
@@ -169,6 +172,23 @@ function estrcode(s::Symbol)
     throw(ArgumentError("est_r must be :None, :MM or :Newton"))
 end
 
+# _choose! (src/utilities.jl:444-458, src/multivariate.jl:310-351) breaks exact ties with the caller's RNG.  The library hands
+# the draw back (mih_fit_params::choose), so it is made here by the reference's own two calls, from the same global RNG
+# state, on the thread that called fit_iht: `sample(non_zero_idx, excess, replace=false)` (utilities.jl:453) for kind 0,
+# `shuffle!(B_nz_idx)` / `shuffle!(C_nz_idx)` (multivariate.jl:336-337) for kinds 1 and 2.  Both draws pick POSITIONS of the
+# list, so the 0-based entries the library passes give the same draw as the reference's 1-based ones.
+function choose_cb(user::Ptr{Cvoid}, kind::Int32, list::Ptr{Int64}, n::Int64, excess::Int64, out::Ptr{Int64})::Cint
+    try
+        l = unsafe_wrap(Array, list, n)
+        o = kind == 0 ? sample(l, excess, replace=false) : shuffle!(copy(l))
+        unsafe_copyto!(out, pointer(o), length(o))
+        return Cint(0)
+    catch
+        return Cint(1)             # no exception may cross the C frames: the fit ends with an ArgumentError instead
+    end
+end
+choose_ptr() = @cfunction(choose_cb, Cint, (Ptr{Cvoid}, Int32, Ptr{Int64}, Int64, Int64, Ptr{Int64}))
+
 # The host arrays a parameter block points at; kept alive by GC.@preserve around every ccall.
 struct ParamKeep
     zk::Vector{UInt8}; w::Vector{Float64}; g::Vector{Int64}; ks::Vector{Int64}
@@ -196,7 +216,7 @@ function make_params(x::HipSnpLinAlg, k, J, d, l, group, weight, zkeep, est_r, u
         isempty(keep.w) ? Ptr{Float64}(C_NULL) : pointer(keep.w),
         isempty(keep.g) ? Ptr{Int64}(C_NULL) : pointer(keep.g),
         isempty(keep.ks) ? Ptr{Int64}(C_NULL) : pointer(keep.ks), length(keep.ks),
-        C_NULL, C_NULL, Int32(init_beta), comm, Int32(debias), Int32(xtv_digits))
+        C_NULL, C_NULL, Int32(init_beta), comm, Int32(debias), Int32(xtv_digits), choose_ptr(), C_NULL)
     return prm, keep
 end
 

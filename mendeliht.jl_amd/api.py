@@ -57,13 +57,37 @@ class _FitParams(C.Structure):
                 ("max_iter", C.c_int32), ("min_iter", C.c_int32), ("max_step", C.c_int32), ("est_r", C.c_int32),
                 ("zkeep", C.c_void_p), ("weight", C.c_void_p), ("group", C.c_void_p), ("ks", C.c_void_p),
                 ("nks", C.c_int64), ("progress", C.c_void_p), ("progress_user", C.c_void_p),
-                ("init_beta", C.c_int32), ("comm", C.c_void_p), ("debias", C.c_int32), ("xtv_digits", C.c_int32)]
+                ("init_beta", C.c_int32), ("comm", C.c_void_p), ("debias", C.c_int32), ("xtv_digits", C.c_int32),
+                ("choose", C.c_void_p), ("choose_user", C.c_void_p)]
 
 
 class _Comm(C.Structure):
     """mih_comm (include/mendeliht_hip.h): the exchange callbacks of a column-sharded fit."""
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("col_offset", C.c_int64), ("p_global", C.c_int64),
                 ("allreduce", C.c_void_p), ("allgather", C.c_void_p), ("user", C.c_void_p)]
+
+
+_CHOOSE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.c_int64, C.c_int64, C.POINTER(C.c_int64))
+CHOOSE_SAMPLE, CHOOSE_SHUFFLE_B, CHOOSE_SHUFFLE_C = 0, 1, 2      # mih_fit_params::choose kinds (include/mendeliht_hip.h)
+
+
+def _choose_callback(fn):
+    """mih_fit_params::choose from a Python callable fn(kind, list, excess) -> positions: the caller's stand-in for the
+    reference's RNG draw in _choose! (`sample(non_zero_idx, excess, replace=false)`, src/utilities.jl:453; `shuffle!`,
+    src/multivariate.jl:336-337).  kind CHOOSE_SAMPLE: return `excess` distinct entries of list; CHOOSE_SHUFFLE_*: return
+    the whole list in shuffled order."""
+    def cb(_user, kind, lst, n, excess, out):
+        try:
+            got = np.asarray(fn(int(kind), np.array(lst[:n], dtype=np.int64), int(excess)), dtype=np.int64).ravel()
+            want = excess if kind == CHOOSE_SAMPLE else n
+            if got.size != want:
+                return 1
+            for t in range(want):
+                out[t] = int(got[t])
+            return 0
+        except Exception:       # an exception must not unwind through the C frames
+            return 1
+    return _CHOOSE(cb)
 
 
 _ALLREDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32)
@@ -745,8 +769,12 @@ def _print_parameters(io, k, d, l, use_maf, group, debias, tol, max_iter, min_it
 
 
 def _params(k, J, d, l, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, q, p, keep, progress=None,
-            init_beta=False, comm=None, debias=False, xtv_digits=None):
+            init_beta=False, comm=None, debias=False, xtv_digits=None, choose=None):
     prm = _FitParams()
+    if choose is not None:
+        ccb = _choose_callback(choose)
+        prm.choose = C.cast(ccb, C.c_void_p)
+        keep.append(ccb)
     prm.debias = int(bool(debias))
     prm.xtv_digits = _digits(xtv_digits)
     if comm is not None:            # column-sharded fit: mendeliht.jl_amd.dist.ColumnComm
@@ -801,8 +829,12 @@ def _params(k, J, d, l, tol, max_iter, min_iter, max_step, est_r, zkeep, weight,
 
 def fit_iht(y, x, z=None, *, k=10, J=1, d=None, l=None, group=None, weight=None, zkeep=None, est_r="None",
             use_maf=False, debias=False, verbose=True, tol=1e-4, max_iter=200, min_iter=5, max_step=3,
-            io=None, init_beta=False, memory_efficient=True, train=None, comm=None, xtv_digits=None):
+            io=None, init_beta=False, memory_efficient=True, train=None, comm=None, xtv_digits=None, choose=None):
     """fit_iht(y, x, z; k, J, d, l, ...) -- src/fit.jl:60-118.
+
+    choose (no keyword in the reference, which draws from the global RNG): fn(kind, list, excess) making the random draw of
+    _choose! (src/utilities.jl:444-458, src/multivariate.jl:310-351) when a projection leaves exact ties -- see
+    _choose_callback; None = the library's deterministic rule, flagged by result.choose_fired.
 
     xtv_digits (no reference counterpart): fixed-point format of the residual in this call's X'r passes (set_xtv_digits).
 
@@ -833,7 +865,7 @@ def fit_iht(y, x, z=None, *, k=10, J=1, d=None, l=None, group=None, weight=None,
     if verbose:
         _print_signature(io)
     if mv:
-        return _fit_mv(y, x, z, k, d, l, zkeep, verbose, tol, max_iter, min_iter, max_step, io, train, init_beta, xtv_digits)
+        return _fit_mv(y, x, z, k, d, l, zkeep, verbose, tol, max_iter, min_iter, max_step, io, train, init_beta, xtv_digits, choose)
     y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).ravel())
     n = x.n
     z = np.ones((n, 1)) if z is None else np.asarray(z, dtype=np.float64)
@@ -852,7 +884,7 @@ def fit_iht(y, x, z=None, *, k=10, J=1, d=None, l=None, group=None, weight=None,
 
     keep = []
     prm = _params(k, J, d, l, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, q, x.p, keep, progress,
-                  init_beta=init_beta, comm=comm, debias=debias, xtv_digits=xtv_digits)
+                  init_beta=init_beta, comm=comm, debias=debias, xtv_digits=xtv_digits, choose=choose)
     if verbose:
         _print_parameters(io, k, d, l, use_maf, group, debias, tol, max_iter, min_iter)
     tr = None if train is None else np.ascontiguousarray(train, dtype=np.uint8)
@@ -883,7 +915,8 @@ def _checky(y, d):
         raise ArgumentError("Gamma/InverseGaussian data must be positive")
 
 
-def _fit_mv(Y, x, Z, k, d, l, zkeep, verbose, tol, max_iter, min_iter, max_step, io, train, init_beta=False, xtv_digits=None):
+def _fit_mv(Y, x, Z, k, d, l, zkeep, verbose, tol, max_iter, min_iter, max_step, io, train, init_beta=False, xtv_digits=None,
+            choose=None):
     Y = np.asfortranarray(np.asarray(Y, dtype=np.float64))
     r, n = Y.shape
     Z = np.ones((1, n)) if Z is None else np.asarray(Z, dtype=np.float64)
@@ -903,7 +936,7 @@ def _fit_mv(Y, x, Z, k, d, l, zkeep, verbose, tol, max_iter, min_iter, max_step,
 
     keep = []
     prm = _params(k, 1, Normal(), l, tol, max_iter, min_iter, max_step, "None", zkeep, None, None, q, x.p, keep, progress,
-                  init_beta=init_beta, xtv_digits=xtv_digits)
+                  init_beta=init_beta, xtv_digits=xtv_digits, choose=choose)
     if verbose:
         _print_parameters(io, k, MvNormal(), l, False, None, False, tol, max_iter, min_iter)
     tr = None if train is None else np.ascontiguousarray(train, dtype=np.uint8)

@@ -417,6 +417,8 @@ struct IhtVar {
     std::vector<uint8_t> zkeep; int64_t zkeepn = 0;
     const double *y_host = nullptr, *z_host = nullptr;
     int init_beta = 0, debias = 0;
+    int (*choose_cb)(void *, int32_t, const int64_t *, int64_t, int64_t, int64_t *) = nullptr;   // mih_fit_params::choose
+    void *choose_user = nullptr;
     XtvTune tune;                 // how this fit's X'r passes run (mih_fit_params::xtv_digits)
     hipStream_t s = nullptr;
     // device
@@ -470,6 +472,7 @@ struct IhtVar {
         h = hh; n = h->n; p = h->p; q = (int)qq; y_host = yh; z_host = zh; init_beta = prm->init_beta; tune = xtv_tune(prm);
         reserve = h->pool_owner;
         comm = prm->comm; pg = p; col0 = 0; debias = prm->debias;
+        choose_cb = prm->comm ? nullptr : prm->choose; choose_user = prm->choose_user;
         if (comm) {
             if (!comm->allreduce || !comm->allgather || comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world ||
                 comm->col_offset < 0 || comm->col_offset + p > comm->p_global) {
@@ -715,7 +718,29 @@ struct IhtVar {
         return MIH_OK;
     }
 
-    // _choose! (utilities.jl:444-458): RNG tie-break in the reference; deterministic here
+    // the caller draws, as the reference does: `for pos in sample(non_zero_idx, excess, replace=false)` (utilities.jl:453-456)
+    int choose_by_caller(Sparse &sp, int64_t excess, bool with_values = true)
+    {
+        const int64_t nn = (int64_t)sp.idx.size();
+        if (excess > nn) { set_error("_choose!: %lld entries to remove out of %lld non-zero SNP effects", (long long)excess, (long long)nn); return MIH_BAD_ARG; }
+        std::vector<int64_t> out((size_t)excess, -1);
+        if (choose_cb(choose_user, MIH_CHOOSE_SAMPLE, sp.idx.data(), nn, excess, out.data()) != 0) { set_error("the choose callback failed"); return MIH_BAD_ARG; }
+        std::vector<char> drop((size_t)nn, 0);
+        for (int64_t t = 0; t < excess; ++t) {
+            auto it = std::lower_bound(sp.idx.begin(), sp.idx.end(), out[(size_t)t]);
+            if (it == sp.idx.end() || *it != out[(size_t)t] || drop[(size_t)(it - sp.idx.begin())]) {
+                set_error("the choose callback must return %lld DISTINCT positions out of its list", (long long)excess); return MIH_BAD_ARG;
+            }
+            drop[(size_t)(it - sp.idx.begin())] = 1;
+        }
+        Sparse kept;
+        for (int64_t i = 0; i < nn; ++i)
+            if (!drop[(size_t)i]) { kept.idx.push_back(sp.idx[(size_t)i]); if (with_values) kept.val.push_back(sp.val[(size_t)i]); }
+        sp = kept;
+        return MIH_OK;
+    }
+
+    // _choose! (utilities.jl:444-458): RNG tie-break in the reference; without a callback deterministic here
     // (drop the smallest |b|, ties highest index) and flagged.
     int choose()
     {
@@ -727,6 +752,7 @@ struct IhtVar {
         if (nz <= groups * sparsity) return MIH_OK;
         int64_t excess = nz - groups * sparsity;
         choose_fired = true;
+        if (choose_cb) return choose_by_caller(b, excess);
         std::vector<size_t> ord(b.idx.size());
         for (size_t i = 0; i < ord.size(); ++i) ord[i] = i;
         std::sort(ord.begin(), ord.end(), [&](size_t a, size_t bb) {
@@ -1025,7 +1051,9 @@ struct IhtVar {
             if (nz > ((J == 0) ? 1 : J) * (k + zkeepn)) {
                 choose_fired = true;
                 int64_t excess = nz - ((J == 0) ? 1 : J) * (k + zkeepn);
-                if (!comm) {
+                if (choose_cb) {                   // v.b is all zero here: only v.idx[pos] = false has an effect (utilities.jl:454-456)
+                    MIH_TRY(choose_by_caller(idx, excess, false));
+                } else if (!comm) {
                     for (int64_t t = 0; t < excess && !idx.idx.empty(); ++t) idx.idx.pop_back();
                 } else {         // drop the `excess` highest GLOBAL indices
                     std::vector<double> mine((size_t)excess, -1.0), all;
@@ -1701,7 +1729,7 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, con
     MIH_HIP(hipSetDevice(h->device));
     for (int64_t i = 0; i < (int64_t)nfolds * npath; ++i) mses_raw[i] = 0.0;
     mih_fit_params pr = *prm;
-    pr.k = kmax; pr.progress = nullptr;
+    pr.k = kmax; pr.progress = nullptr; pr.choose = nullptr;      // (the caller's tie-break callback is for single fits: see the header)
     std::vector<int32_t> rank_of;
     cv_assign(path, npath, nfolds, world, rank_of);
 
@@ -1793,7 +1821,7 @@ int mih_fit_iht_path(const mih_mat *h, const mih_fit_params *prm, const double *
         if (c_out) for (int64_t l = 0; l < q; ++l) c_out[i * q + l] = 0.0;
     }
     mih_fit_params pr = *prm;
-    pr.progress = nullptr;
+    pr.progress = nullptr; pr.choose = nullptr;
     pr.k = kmax;                                     // IHTVariables are sized for the largest model and re-used along the path
     std::vector<int64_t> mine;
     for (int64_t i = 0; i < npath; ++i) if (i % world == rank) mine.push_back(i);

@@ -312,6 +312,8 @@ struct MvVar {
     std::vector<uint8_t> idc;
     int64_t nsamples = 0;
     bool choose_fired = false;
+    int (*choose_cb)(void *, int32_t, const int64_t *, int64_t, int64_t, int64_t *) = nullptr;   // mih_fit_params::choose
+    void *choose_user = nullptr;
 
     bool own_stream = true;
     ~MvVar() { if (s) (void)hipStreamSynchronize(s); if (s && own_stream) (void)hipStreamDestroy(s); }       // see ~IhtVar
@@ -322,6 +324,7 @@ struct MvVar {
                hipStream_t shared_stream = nullptr)
     {
         h = hh; n = h->n; p = h->p; r = (int)rr; q = (int)qq; k = prm->k; Y_host = Yh; Z_host = Zh; init_beta = prm->init_beta; tune = xtv_tune(prm);
+        choose_cb = prm->choose; choose_user = prm->choose_user;
         if (r < 1 || r > kMaxR) { set_error("number of traits r=%d must be in 1..%d", r, kMaxR); return MIH_BAD_DIM; }
         if (q < 1 || r * q > kMaxRQ) { set_error("r*q = %d exceeds %d", r * q, kMaxRQ); return MIH_BAD_DIM; }
         zkeep.resize(q); int64_t zs = 0;
@@ -499,14 +502,44 @@ struct MvVar {
         *eta = e;
         return MIH_OK;
     }
-    // _choose!(v::mIHTVariable) (multivariate.jl:310-351): RNG in the reference; deterministic + flag here
-    void choose()
+    // the caller shuffles, as the reference does (multivariate.jl:336-348): both lists, then the first `excess` entries go --
+    // out of B while it has non-zeros left, then C_nz_idx[i] with the SAME running i
+    int choose_by_caller(int64_t excess)
+    {
+        const int64_t nB = (int64_t)B.idx.size();
+        std::vector<int64_t> clist;
+        for (int l = 0; l < q; ++l) if (!zkeep[l]) for (int i = 0; i < r; ++i) if (C[i + r * l] != 0.0) clist.push_back(i + (int64_t)r * l);
+        const int64_t nC = (int64_t)clist.size();
+        std::vector<int64_t> bs((size_t)nB, -1), cs((size_t)nC, -1);
+        if (choose_cb(choose_user, MIH_CHOOSE_SHUFFLE_B, B.idx.data(), nB, excess, bs.data()) != 0 ||
+            choose_cb(choose_user, MIH_CHOOSE_SHUFFLE_C, clist.data(), nC, excess, cs.data()) != 0) { set_error("the choose callback failed"); return MIH_BAD_ARG; }
+        auto is_perm = [](std::vector<int64_t> a, std::vector<int64_t> b) { std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end()); return a == b; };
+        if (!is_perm(bs, B.idx) || !is_perm(cs, clist)) { set_error("the choose callback must return its list in shuffled order"); return MIH_BAD_ARG; }
+        std::vector<char> drop((size_t)nB, 0);
+        int64_t b_left = nB;
+        for (int64_t i = 0; i < excess; ++i) {
+            if (b_left > 0) {
+                drop[(size_t)(std::lower_bound(B.idx.begin(), B.idx.end(), bs[(size_t)i]) - B.idx.begin())] = 1;
+                --b_left;
+            } else {
+                if (i >= nC) { set_error("_choose!: BoundsError, C_nz_idx[%lld] of %lld (multivariate.jl:344)", (long long)(i + 1), (long long)nC); return MIH_BAD_ARG; }
+                C[(size_t)cs[(size_t)i]] = 0.0;
+            }
+        }
+        Sparse kept;
+        for (int64_t i = 0; i < nB; ++i) if (!drop[(size_t)i]) { kept.idx.push_back(B.idx[(size_t)i]); kept.val.push_back(B.val[(size_t)i]); }
+        B = kept;
+        return MIH_OK;
+    }
+    // _choose!(v::mIHTVariable) (multivariate.jl:310-351): RNG in the reference; without a callback deterministic + flag here
+    int choose()
     {
         int64_t cnz = 0;
         for (int l = 0; l < q; ++l) if (!zkeep[l]) for (int i = 0; i < r; ++i) cnz += (C[i + r * l] != 0.0);
         int64_t excess = (int64_t)B.idx.size() + cnz - (k + zkeepn);
-        if (excess <= 0) return;
+        if (excess <= 0) return MIH_OK;
         choose_fired = true;
+        if (choose_cb) return choose_by_caller(excess);
         std::vector<size_t> ord(B.idx.size());
         for (size_t i = 0; i < ord.size(); ++i) ord[i] = i;
         std::sort(ord.begin(), ord.end(), [&](size_t a, size_t b) {
@@ -521,6 +554,7 @@ struct MvVar {
         for (size_t i = 0; i < B.idx.size(); ++i) if (!drop[i]) { nb2.idx.push_back(B.idx[i]); nb2.val.push_back(B.val[i]); }
         B = nb2;
         for (int l = 0; l < q && t < excess; ++l) if (!zkeep[l]) for (int i = 0; i < r && t < excess; ++i) if (C[i + r * l] != 0.0) { C[i + r * l] = 0.0; ++t; }
+        return MIH_OK;
     }
     // project the r(p+q) buffer and split survivors; tail = covariate part of the vector
     int project_full(Sparse &snp, std::vector<double> &ctail, std::vector<uint8_t> &cnz)
@@ -555,7 +589,7 @@ struct MvVar {
         B = snp;
         for (int l = 0; l < q; ++l) for (int i = 0; i < r; ++i)
             C[i + r * l] = zkeep[l] ? cn[i + r * l] : (cnz[i + r * l] ? ct[i + r * l] : 0.0);
-        choose();
+        MIH_TRY(choose());
         update_cols();
         for (int l = 0; l < q; ++l) { idc[l] = 0; for (int i = 0; i < r; ++i) if (C[i + r * l] != 0.0) idc[l] = 1; }
         return MIH_OK;
@@ -597,7 +631,7 @@ struct MvVar {
         MIH_TRY(project_full(snp, ct, cnz));
         B = snp;
         for (int l = 0; l < q; ++l) if (!zkeep[l]) for (int i = 0; i < r; ++i) C[i + r * l] = cnz[i + r * l] ? ct[i + r * l] : 0.0;
-        choose();
+        MIH_TRY(choose());
         update_cols();
         for (int l = 0; l < q; ++l) { idc[l] = 0; for (int i = 0; i < r; ++i) if (C[i + r * l] != 0.0) idc[l] = 1; }
         return update_xb();
@@ -811,7 +845,7 @@ int mih_cv_mv(const mih_mat *h, const mih_fit_params *prm, const double *Y, int6
     MIH_HIP(hipSetDevice(h->device));
     for (int64_t i = 0; i < (int64_t)nfolds * npath; ++i) mses_raw[i] = 0.0;
     mih_fit_params pr = *prm;
-    pr.progress = nullptr;
+    pr.progress = nullptr; pr.choose = nullptr;
     // this rank's combinations, fold-major (cross_validation.jl:217-223), advanced in lock-step batches: every
     // round issues ONE fused X'R pass for the r traits of every fit that needs a score (as mih_cv_iht does)
     std::vector<std::pair<int32_t, int64_t>> mine;

@@ -475,6 +475,8 @@ typedef struct {
     int64_t zkeepn;
     const int64_t *group; const double *weight;
     int choose_fired;
+    int (*choose_cb)(void *, int32_t, const int64_t *, int64_t, int64_t, int64_t *);
+    void *choose_user;
     int init_beta;
 } ihtvar;
 
@@ -491,6 +493,7 @@ static ihtvar *iv_create(const orc_mat *x, const orc_params *prm, const double *
     if (v->nks > 0) v->k = 0;                         /* data_structures.jl:75-81 */
     v->dist = prm->dist; v->link = prm->link; v->nb_r = prm->nb_r; v->est_r = prm->est_r;
     v->group = prm->group; v->weight = prm->weight; v->init_beta = prm->init_beta;
+    v->choose_cb = prm->choose; v->choose_user = prm->choose_user;
     v->b = dalloc(p); v->b0 = dalloc(p); v->best_b = dalloc(p); v->df = dalloc(p);
     v->xb = dalloc(n); v->xgk = dalloc(n); v->r = dalloc(n); v->zc = dalloc(n);
     v->zdf2 = dalloc(n); v->mu = dalloc(n); v->cv_wts = dalloc(n);
@@ -585,10 +588,12 @@ static void unvectorize(const ihtvar *v, const double *a, double *b, double *c)
 }
 
 /* _choose! utilities.jl:444-458.  The reference removes `excess` RANDOM
- * non-zero SNPs (StatsBase.sample); RNG parity with Julia is impossible, so the
- * restatement removes the smallest-|b| ones (ties: highest index first) and
- * raises choose_fired so a caller can tell the reference would have sampled. */
-static void choose(ihtvar *v)
+ * non-zero SNPs (StatsBase.sample).  With a callback (orc_params.choose) the caller
+ * makes that draw: `for pos in sample(non_zero_idx, excess, replace=false)`
+ * (utilities.jl:453).  Without one -- RNG parity with Julia is impossible -- the
+ * restatement removes the smallest-|b| ones (ties: highest index first).  Either
+ * way choose_fired tells a caller that the reference would have sampled. */
+static int choose(ihtvar *v)
 {
     int64_t sparsity = v->k + v->zkeepn;
     int64_t groups = (v->J == 0) ? 1 : v->J;
@@ -596,9 +601,22 @@ static void choose(ihtvar *v)
     for (int64_t j = 0; j < v->p; ++j) nzb += v->idx[j];
     for (int64_t j = 0; j < v->q; ++j) nz += v->idc[j];
     nz += nzb;
-    if (nz <= groups * sparsity) return;
+    if (nz <= groups * sparsity) return ORC_OK;
     int64_t excess = nz - groups * sparsity;
     v->choose_fired = 1;
+    if (v->choose_cb) {
+        if (excess > nzb) return ORC_BAD_ARG;
+        int64_t *list = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nzb + excess + 1)), *out = list + nzb, m = 0;
+        for (int64_t j = 0; j < v->p; ++j) if (v->idx[j]) list[m++] = j;      /* findall(!iszero, v.idx) */
+        int rc = v->choose_cb(v->choose_user, 0, list, nzb, excess, out);
+        for (int64_t t = 0; t < excess && !rc; ++t) {
+            int64_t pos = out[t];
+            if (pos < 0 || pos >= v->p || !v->idx[pos]) { rc = 1; break; }     /* not in the list, or drawn twice */
+            v->b[pos] = 0.0; v->idx[pos] = 0;
+        }
+        free(list);
+        return rc ? ORC_BAD_ARG : ORC_OK;
+    }
     keyidx *cand = (keyidx *)malloc(sizeof(keyidx) * (size_t)nzb);
     int64_t m = 0;
     for (int64_t j = 0; j < v->p; ++j)
@@ -609,6 +627,7 @@ static void choose(ihtvar *v)
         v->b[pos] = 0.0; v->idx[pos] = 0;
     }
     free(cand);
+    return ORC_OK;
 }
 
 /* _iht_gradstep! utilities.jl:252-280 */
@@ -630,7 +649,7 @@ static int gradstep(ihtvar *v, double eta)
     }
     for (int64_t j = 0; j < v->p; ++j) v->idx[j] = (v->b[j] != 0.0);
     for (int64_t j = 0; j < v->q; ++j) v->idc[j] = (v->c[j] != 0.0);
-    if (k_is_int) choose(v);
+    if (k_is_int) return choose(v);
     return ORC_OK;
 }
 
@@ -732,7 +751,8 @@ static int init_iht_indices(ihtvar *v, const uint8_t *train)
         unvectorize(v, v->full_b, v->df, v->df2);
         for (int64_t j = 0; j < p; ++j) v->idx[j] = (v->df[j] != 0.0);
         memcpy(v->idc, v->zkeep, q);
-        choose(v);
+        rc = choose(v);
+        if (rc) return rc;
     } else {
         /* utilities.jl:427-429: idx is taken from b (all zero) -> empty support */
         int rc = orc_project_group_sparse(v->df, v->group, p, v->J, v->ks, 1);
@@ -1154,6 +1174,7 @@ int orc_cv_iht(const orc_mat *x, const orc_params *prm, const double *y,
     double *mses = (double *)malloc(sizeof(double) * (size_t)(nfolds * npath));
     uint8_t *train = balloc(n);
     orc_params pr = *prm;
+    pr.choose = NULL;                                 /* the callback is for single fits (iht_oracle.h) */
     ihtvar *v = iv_create(x, &pr, y, z, q);
     for (int32_t fold = 1; fold <= nfolds && !rc; ++fold) {
         for (int64_t ik = 0; ik < npath && !rc; ++ik) {

@@ -61,6 +61,11 @@ typedef struct orc_params {
     int64_t  nks;
     int32_t  init_beta;       /* fit.jl:80: start from univariate regression estimates (Normal only) */
     int32_t  debias;          /* fit.jl:73,188: refit the support by GLM after a step that kept it */
+    /* _choose! draws from the caller's RNG in the reference (utilities.jl:453 `sample`, multivariate.jl:336-337 `shuffle!`): a test
+     * hands the restatement and the library the same draw through this callback (kind 0: write the `excess` sampled entries of
+     * list to out; kind 1 / 2: write the whole list, shuffled, to out).  NULL = deterministic rule of choose().  Single fits only. */
+    int (*choose)(void *user, int32_t kind, const int64_t *list, int64_t n, int64_t excess, int64_t *out);
+    void    *choose_user;
 } orc_params;
 
 typedef struct orc_result {

@@ -35,7 +35,27 @@ class _Params(C.Structure):
                 ("max_iter", C.c_int32), ("min_iter", C.c_int32), ("max_step", C.c_int32),
                 ("est_r", C.c_int32),
                 ("zkeep", C.c_void_p), ("weight", C.c_void_p), ("group", C.c_void_p),
-                ("ks", C.c_void_p), ("nks", C.c_int64), ("init_beta", C.c_int32), ("debias", C.c_int32)]
+                ("ks", C.c_void_p), ("nks", C.c_int64), ("init_beta", C.c_int32), ("debias", C.c_int32),
+                ("choose", C.c_void_p), ("choose_user", C.c_void_p)]
+
+
+_CHOOSE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.c_int64, C.c_int64, C.POINTER(C.c_int64))
+
+
+def _choose_callback(fn):
+    """orc_params.choose from fn(kind, list, excess) -> positions (iht_oracle.h): the draw _choose! makes with the caller's RNG."""
+    def cb(_user, kind, lst, n, excess, out):
+        try:
+            got = np.asarray(fn(int(kind), np.array(lst[:n], dtype=np.int64), int(excess)), dtype=np.int64).ravel()
+            want = excess if kind == 0 else n
+            if got.size != want:
+                return 1
+            for t in range(want):
+                out[t] = int(got[t])
+            return 0
+        except Exception:
+            return 1
+    return _CHOOSE(cb)
 
 
 class _Result(C.Structure):
@@ -205,8 +225,12 @@ def project_group_sparse(y, group, J, k):
 
 
 def _params(k, J, dist, link, nb_r, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, keep, init_beta=False,
-            debias=False):
+            debias=False, choose=None):
     prm = _Params()
+    if choose is not None:
+        ccb = _choose_callback(choose)
+        prm.choose = C.cast(ccb, C.c_void_p)
+        keep.append(ccb)
     ks = None
     if np.ndim(k) > 0:
         ks = np.ascontiguousarray(k, dtype=np.int64)
@@ -239,10 +263,10 @@ def _z(z, n):
 
 def fit_iht(x, y, z=None, k=10, J=1, dist="normal", link="identity", nb_r=1.0, tol=1e-4,
             max_iter=200, min_iter=5, max_step=3, est_r=None, zkeep=None, weight=None,
-            group=None, train=None, init_beta=False, debias=False):
+            group=None, train=None, init_beta=False, debias=False, choose=None):
     keep = []
     prm = _params(k, J, dist, link, nb_r, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, keep, init_beta,
-                  debias)
+                  debias, choose)
     y = np.ascontiguousarray(y, dtype=np.float64)
     z = _z(z, x.n)
     q = z.shape[1]
@@ -280,11 +304,11 @@ def cv_iht(x, y, z=None, path=range(1, 21), q=5, folds=None, dist="normal", link
 
 
 def fit_mv(x, Y, Z=None, k=10, tol=1e-4, max_iter=200, min_iter=5, max_step=3, zkeep=None, train=None,
-           init_beta=False):
+           init_beta=False, choose=None):
     """Y is r x n (traits x samples), Z is q x n; returns B (r x p), C (r x q)."""
     keep = []
     prm = _params(k, 1, "normal", "identity", 1.0, tol, max_iter, min_iter, max_step, None, zkeep, None, None, keep,
-                  init_beta)
+                  init_beta, choose=choose)
     Y = np.asfortranarray(Y, dtype=np.float64)
     r, n = Y.shape
     if Z is None:

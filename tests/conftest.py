@@ -89,3 +89,32 @@ def hash_folds(n, q, seed=2026):
     """folds_i = 1 + (hash(seed, i) mod q): explicit, RNG-free folds.  Lives in the package (bench.py uses it too)."""
     from mendeliht_amd import hash_folds as hf
     return hf(n, q, seed)
+
+
+def tied_case(n=1000, src=4246, copies=(17, 4247, 9000), noise_seed=3):
+    """Exact ties for _choose! (src/utilities.jl:444-458): SNP `src` (0-based) of the shipped normal.bed copied over `copies`,
+    a phenotype driven by that SNP alone -- the copies have the same score and the same effect after every step, so a projection
+    to k < 1 + len(copies) keeps all of them and the tie-break has to remove the excess.  Returns (PLINK columns, y)."""
+    raw = np.fromfile(os.path.join(FIX, "normal.bed"), dtype=np.uint8)[3:]
+    stride = (n + 3) // 4
+    cols = raw.reshape(-1, stride).copy()
+    for j in copies:
+        cols[j] = cols[src]
+    code = np.stack([(cols[src] >> (2 * t)) & 3 for t in range(4)], axis=1).ravel()[:n]
+    g = np.array([0.0, 0.0, 1.0, 2.0])[code]
+    y = 0.8 * (g - g.mean()) / g.std() + 0.3 * np.random.default_rng(noise_seed).standard_normal(n) + 1.0
+    return cols, y
+
+
+def seeded_draw(seed, log):
+    """A stand-in for the reference's RNG in _choose!: fn(kind, list, excess) as mih_fit_params::choose / orc_params.choose take
+    it, drawing from a seeded numpy generator and logging every call, so two implementations that ask the same questions in
+    the same order get the same answers."""
+    rng = np.random.default_rng(seed)
+
+    def choose(kind, lst, excess):
+        log.append((int(kind), [int(v) for v in lst], int(excess)))
+        if kind == 0:                                      # sample(non_zero_idx, excess, replace=false), utilities.jl:453
+            return rng.choice(lst, size=excess, replace=False)
+        return rng.permutation(lst)                        # shuffle!(B_nz_idx) / shuffle!(C_nz_idx), multivariate.jl:336-337
+    return choose

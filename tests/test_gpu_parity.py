@@ -1903,3 +1903,63 @@ def test_ingest_pipeline_at_full_row_count(mih):
     wide[:, :cols.shape[1]] = cols
     x2 = mih.SnpLinAlg(wide, n=n, center=True, scale=True, impute=True)
     assert np.array_equal(x2.export_bed(), cols)
+
+
+def test_choose_callback_makes_the_references_random_draw(mih, oracle):
+    """_choose! (src/utilities.jl:444-458, src/multivariate.jl:310-351): the one place on the path where the reference draws
+    from the caller's RNG.  mih_fit_params::choose hands the draw to the caller (the Julia glue answers with the reference's own
+    `sample` / `shuffle!`); the restatement has the same hook.  Given the same stand-in RNG the library and the restatement ask
+    the same questions in the same order and return the same model; without a callback both apply the same deterministic rule
+    and flag it; a bad draw is an ArgumentError."""
+    from conftest import seeded_draw, tied_case
+    m = mih
+    cols, y = tied_case()
+    n = 1000
+    x = m.SnpLinAlg(cols, n=n, center=True, scale=True, impute=True)
+    xo = oracle.Mat.from_bed_columns(cols, n)
+    z = np.ones((n, 1))
+    for k in (2, 1):
+        for seed in (11, 12, 13):
+            lh, lo = [], []
+            rh = m.fit_iht(y, x, z, k=k, verbose=False, choose=seeded_draw(seed, lh))
+            ro = oracle.fit_iht(xo, y, None, k=k, choose=seeded_draw(seed, lo))
+            assert lh == lo and len(lh) >= 1 and rh.choose_fired and ro["choose_fired"]
+            assert sorted(np.flatnonzero(rh.beta)) == sorted(np.flatnonzero(ro["beta"]))
+            assert rh.iter == ro["iter"]
+            np.testing.assert_allclose(rh.beta, ro["beta"], rtol=0, atol=1e-10)
+            np.testing.assert_allclose(rh.trace["logl"], ro["logl_trace"], rtol=1e-11)
+            np.testing.assert_array_equal(rh.trace["backtracks"], ro["bt_trace"])
+        plain_h, plain_o = m.fit_iht(y, x, z, k=k, verbose=False), oracle.fit_iht(xo, y, None, k=k)
+        assert plain_h.choose_fired and sorted(np.flatnonzero(plain_h.beta)) == sorted(np.flatnonzero(plain_o["beta"]))
+    supports = {tuple(np.flatnonzero(m.fit_iht(y, x, z, k=2, verbose=False, choose=seeded_draw(s, [])).beta)) for s in range(8)}
+    assert len(supports) > 1                                   # the draw decides which of the interchangeable copies stay
+    with pytest.raises(m.ArgumentError):
+        m.fit_iht(y, x, z, k=2, verbose=False, choose=lambda kind, lst, excess: np.array([5]))            # not in the list
+    with pytest.raises(m.ArgumentError):
+        m.fit_iht(y, x, z, k=1, verbose=False, choose=lambda kind, lst, excess: lst[:1].repeat(excess))   # one SNP twice
+    with pytest.raises(m.ArgumentError):
+        m.fit_iht(y, x, z, k=2, verbose=False, choose=lambda kind, lst, excess: 1 / 0)                     # the callback fails
+    # Bernoulli with a second, unprotected covariate: the draw is asked for at other steps too
+    rng = np.random.default_rng(8)
+    z2 = np.column_stack([np.ones(n), rng.standard_normal(n)])
+    yb = (y > np.median(y)).astype(float)
+    lh, lo = [], []
+    rh = m.fit_iht(yb, x, z2, k=2, d=m.Bernoulli(), l=m.LogitLink(), zkeep=[1, 0], verbose=False, choose=seeded_draw(21, lh))
+    ro = oracle.fit_iht(xo, yb, z2, k=2, dist="bernoulli", link="logit", zkeep=[1, 0], choose=seeded_draw(21, lo))
+    assert lh == lo and lh and rh.iter == ro["iter"]
+    np.testing.assert_allclose(rh.beta, ro["beta"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(rh.c, ro["c"], rtol=0, atol=1e-9)
+    # multivariate: shuffle!(B_nz_idx), shuffle!(C_nz_idx), then the first `excess` entries go
+    Y = np.vstack([y, np.random.default_rng(5).standard_normal(n)])
+    for seed in (12, 14):
+        lh, lo = [], []
+        rh = m.fit_iht(Y, x, None, k=1, verbose=False, choose=seeded_draw(seed, lh))
+        ro = oracle.fit_mv(xo, Y, None, k=1, choose=seeded_draw(seed, lo))
+        assert lh == lo and len(lh) == 2 and rh.choose_fired
+        np.testing.assert_allclose(rh.beta, ro["B"], rtol=0, atol=1e-10)
+        assert rh.iter == ro["iter"]
+    # the lock-step drivers apply the deterministic rule (their fits run on the library's own threads): equal to the restatement's
+    folds = hash_folds(n, 3)
+    a = m.cv_iht(y, x, z, path=[1, 2, 3], q=3, folds=folds, verbose=False)
+    b, _ = oracle.cv_iht(xo, y, None, path=[1, 2, 3], q=3, folds=folds)
+    np.testing.assert_allclose(a, b, rtol=1e-9)

@@ -426,3 +426,50 @@ def test_project_group_sparse_against_a_set_based_statement(oracle):
             want[kept[g]] = y[kept[g]]
         got = oracle.project_group_sparse(y, group, J, k)
         assert np.array_equal(got, want), (trial, p, G, J, k)
+
+
+def test_choose_callback_takes_the_place_of_the_references_rng(oracle):
+    """_choose! (src/utilities.jl:444-458) removes the excess of a tied projection with `sample(non_zero_idx, excess,
+    replace=false)`; the restatement hands that draw to the caller.  Pinned here: the callback sees the non-zero positions in
+    findall order with the reference's excess -- nonzero - (k + zkeepn) with the kept covariates NOT counted in nonzero
+    (:448-451), so four tied SNPs at k = 2 with an intercept lose ONE, not two; what it returns is what goes; a draw that
+    repeats the restatement's own deterministic rule (the highest index, all |b| being tied) gives the identical fit; a draw
+    outside the list is an error, not a silently different model."""
+    from conftest import seeded_draw, tied_case
+    cols, y = tied_case()
+    tied = sorted([4246, 17, 4247, 9000])
+    x = oracle.Mat.from_bed_columns(cols, 1000)
+    plain = oracle.fit_iht(x, y, None, k=2)
+    assert plain["choose_fired"]
+    log = []
+    same = oracle.fit_iht(x, y, None, k=2, choose=lambda kind, lst, excess: (log.append((kind, lst.tolist(), excess)), lst[-excess:])[1])
+    assert log == [(0, tied, 1)] * 2                 # at the initial support and after the first step; later steps have no tie at the cut
+    np.testing.assert_array_equal(same["beta"], plain["beta"])
+    assert same["iter"] == plain["iter"] and same["logl"] == plain["logl"]
+    assert sorted(np.flatnonzero(plain["beta"])) == tied[:3]
+    log2 = []
+    drawn = oracle.fit_iht(x, y, None, k=2, choose=seeded_draw(11, log2))
+    assert log2 == log and drawn["choose_fired"]
+    rng = np.random.default_rng(11)
+    picks = [int(rng.choice(tied, size=1, replace=False)[0]) for _ in log2]
+    assert sorted(np.flatnonzero(drawn["beta"])) == sorted(set(tied) - {picks[1]})   # the SNP drawn after the first step is the one left out
+    assert drawn["logl"] == pytest.approx(plain["logl"], rel=1e-12)                    # the copies are interchangeable
+    with pytest.raises(RuntimeError):
+        oracle.fit_iht(x, y, None, k=2, choose=lambda kind, lst, excess: np.array([5]))              # not in the list
+    with pytest.raises(RuntimeError):
+        oracle.fit_iht(x, y, None, k=1, choose=lambda kind, lst, excess: lst[:1].repeat(excess))     # excess = 2: the same SNP twice
+    # multivariate (src/multivariate.jl:310-351): shuffle!(B_nz_idx), shuffle!(C_nz_idx), then the first `excess` go
+    Y = np.vstack([y, np.random.default_rng(5).standard_normal(1000)])
+    mplain = oracle.fit_mv(x, Y, None, k=1)
+    assert mplain["choose_fired"]
+    mlog = []
+    mdrawn = oracle.fit_mv(x, Y, None, k=1, choose=seeded_draw(12, mlog))
+    assert mlog and len(mlog) % 2 == 0 and all(c[0] == 1 for c in mlog[0::2]) and all(c[0] == 2 for c in mlog[1::2])   # B list, then C list
+    assert mlog[0] == (1, [2 * j for j in tied], 1)      # trait 0 of the four tied SNPs in eachindex order; excess = 4 - (k + r)
+    assert all(c[1] == [] for c in mlog[1::2])           # the intercept is in zkeep: nothing to shuffle
+    rng = np.random.default_rng(12)
+    first = rng.permutation(mlog[0][1])
+    rng.permutation([])
+    assert mdrawn["choose_fired"] and np.count_nonzero(mdrawn["B"]) <= 3
+    assert len(mlog) == 2                                # one tied projection: the first step (the initial support is not projected through project_k!(v), multivariate.jl:436-445)
+    assert sorted(np.flatnonzero(mdrawn["B"].ravel(order="F"))) == sorted(set(mlog[0][1]) - {int(first[0])})
