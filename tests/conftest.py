@@ -91,10 +91,11 @@ def hash_folds(n, q, seed=2026):
     return hf(n, q, seed)
 
 
-def tied_case(n=1000, src=4246, copies=(17, 4247, 9000), noise_seed=3):
+def tied_case(n=1000, src=300, copies=(17, 4247, 9000), noise_seed=3):
     """Exact ties for _choose! (src/utilities.jl:444-458): SNP `src` (0-based) of the shipped normal.bed copied over `copies`,
     a phenotype driven by that SNP alone -- the copies have the same score and the same effect after every step, so a projection
-    to k < 1 + len(copies) keeps all of them and the tie-break has to remove the excess.  Returns (PLINK columns, y)."""
+    to k < 1 + len(copies) keeps all of them and the tie-break has to remove the excess.  SNP 300 is common (maf 0.47), so a
+    dichotomised phenotype still ranks it first.  Returns (PLINK columns, y, the tied positions in ascending order)."""
     raw = np.fromfile(os.path.join(FIX, "normal.bed"), dtype=np.uint8)[3:]
     stride = (n + 3) // 4
     cols = raw.reshape(-1, stride).copy()
@@ -103,7 +104,7 @@ def tied_case(n=1000, src=4246, copies=(17, 4247, 9000), noise_seed=3):
     code = np.stack([(cols[src] >> (2 * t)) & 3 for t in range(4)], axis=1).ravel()[:n]
     g = np.array([0.0, 0.0, 1.0, 2.0])[code]
     y = 0.8 * (g - g.mean()) / g.std() + 0.3 * np.random.default_rng(noise_seed).standard_normal(n) + 1.0
-    return cols, y
+    return cols, y, sorted([src, *copies])
 
 
 def seeded_draw(seed, log):

@@ -436,8 +436,7 @@ def test_choose_callback_takes_the_place_of_the_references_rng(oracle):
     repeats the restatement's own deterministic rule (the highest index, all |b| being tied) gives the identical fit; a draw
     outside the list is an error, not a silently different model."""
     from conftest import seeded_draw, tied_case
-    cols, y = tied_case()
-    tied = sorted([4246, 17, 4247, 9000])
+    cols, y, tied = tied_case()
     x = oracle.Mat.from_bed_columns(cols, 1000)
     plain = oracle.fit_iht(x, y, None, k=2)
     assert plain["choose_fired"]
