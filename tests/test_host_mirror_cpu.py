@@ -334,3 +334,60 @@ def test_lockstep_coroutine_scheduler_on_cpu(mih, tmp_path):
                            f"-Wl,-rpath,{libdir}", "-Wno-unused-result"], stderr=subprocess.DEVNULL)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "lanesched: OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_callback_signatures_of_the_bindings_match_the_header():
+    """The function-pointer fields of the header (progress, choose; the exchange callbacks of mih_comm) against what the bindings
+    hand in: the glue's @cfunction tuples and the mirror's CFUNCTYPE declarations -- return class and every argument class."""
+    import ctypes as C
+    import re
+
+    from conftest import ROOT
+    header = open(os.path.join(ROOT, "include", "mendeliht_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+
+    def cls(t):
+        t = t.strip()
+        if "*" in t:
+            return "ptr"
+        if re.search(r"\b(double)\b", t):
+            return "f64"
+        if re.search(r"\b(int64_t|uint64_t|size_t)\b", t):
+            return "i64"
+        if re.search(r"\b(int32_t|uint32_t|int)\b", t):
+            return "i32"
+        if t == "void":
+            return "void"
+        raise AssertionError(t)
+
+    sigs = {}
+    for m in re.finditer(r"(\w+)\s*\(\*\s*(\w+)\)\s*\((.*?)\)\s*;", header, flags=re.S):
+        args = [" ".join(a.split()) for a in m.group(3).split(",")]
+        sigs[m.group(2)] = (cls(m.group(1)), [cls(a if "*" in a else re.sub(r"\s*\w+$", "", a)) for a in args])
+    assert {"progress", "choose", "allreduce", "allgather"} <= set(sigs), sigs.keys()
+    assert sigs["choose"] == ("i32", ["ptr", "i32", "ptr", "i64", "i64", "ptr"])
+    # Julia: @cfunction(name, Ret, (Args...))
+    jl = re.sub(r"#[^\n]*", "", open(os.path.join(ROOT, "julia", "MendelIHTHip.jl")).read())
+    jcls = {"Cint": "i32", "Int32": "i32", "Int64": "i64", "Cvoid": "void", "Float64": "f64", "Cdouble": "f64"}
+    found = {}
+    for m in re.finditer(r"@cfunction\(\s*(\w+)\s*,\s*(\w+)\s*,\s*\((.*?)\)\s*\)", jl, flags=re.S):
+        args = [a.strip() for a in _split_top(m.group(3))]
+        found[m.group(1)] = (jcls[m.group(2)], ["ptr" if a.startswith(("Ptr{", "Ref{")) else jcls[a] for a in args])
+    assert found.get("choose_cb") == sigs["choose"], found
+    # ... and the Julia function behind it takes exactly those argument types and returns Cint
+    m = re.search(r"function choose_cb\((.*?)\)::(\w+)", jl)
+    assert m and m.group(2) == "Cint"
+    jargs = [a.split("::")[1].strip() for a in _split_top(m.group(1))]
+    assert ["ptr" if a.startswith("Ptr{") else jcls[a] for a in jargs] == sigs["choose"][1]
+    # ctypes mirror
+    from mendeliht_amd import api
+
+    def ccls(t):
+        if t is None:
+            return "void"
+        if t in (C.c_void_p,) or hasattr(t, "contents") or (isinstance(t, type) and issubclass(t, C._Pointer)):
+            return "ptr"
+        return {C.c_int: "i32", C.c_int32: "i32", C.c_int64: "i64", C.c_double: "f64"}[t]
+    for name, proto in (("choose", api._CHOOSE), ("progress", api._PROGRESS), ("allreduce", api._ALLREDUCE), ("allgather", api._ALLGATHER)):
+        got = (ccls(proto._restype_), [ccls(a) for a in proto._argtypes_])
+        assert got == sigs[name], (name, got, sigs[name])
