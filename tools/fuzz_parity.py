@@ -1,0 +1,22 @@
+"""Extended randomized parity sweep: the three seeded sweeps of tests/test_gpu_parity.py (univariate fits, multivariate fits,
+cross-validation grids against the oracle) re-run under other seeds (MIH_SWEEP_SEED), one pytest process per seed.
+
+  python tools/fuzz_parity.py [first_seed] [count]        # writes one line per seed, a summary at the end
+"""
+import os, subprocess, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+bad = []
+t0 = time.time()
+for seed in range(first, first + count):
+    env = dict(os.environ, MIH_SWEEP_SEED=str(seed))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-m", "gpu", "-x",
+                        "-k", "randomized", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True)
+    tail = [l for l in r.stdout.strip().splitlines() if l.strip()][-1] if r.stdout.strip() else "(no output)"
+    print(f"seed {seed}: rc={r.returncode} {tail}", flush=True)
+    if r.returncode:
+        bad.append(seed)
+        print(r.stdout[-3000:], flush=True)
+print(f"{count} seeds from {first}: {count - len(bad)} green, failing seeds {bad}; {time.time() - t0:.0f} s")
+sys.exit(1 if bad else 0)
