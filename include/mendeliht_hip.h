@@ -205,7 +205,8 @@ typedef struct mih_fit_params {
      *   kind MIH_CHOOSE_SHUFFLE_C `shuffle!(C_nz_idx)` (multivariate.jl:337), called right after _B: the non-zero entries of
      *                             the covariates NOT in zkeep (trait + r * covariate); write all n in shuffled order to out.
      * The library then zeroes what the reference's loop zeroes (multivariate.jl:338-348).  Called on the thread that called
-     * mih_fit_iht / mih_session_* / mih_fit_mv; a non-zero return aborts the fit with MIH_BAD_ARG.  Ignored by the lock-step
+     * mih_fit_iht / mih_session_* / mih_fit_mv (a session keeps the pointer: it must stay valid until mih_session_destroy);
+     * a non-zero return aborts the fit with MIH_BAD_ARG.  Ignored by the lock-step
      * drivers (cv_iht, model paths: their fits run on the library's threads -- the reference's own threaded loop draws from
      * task-local RNGs there) and by column-sharded fits (comm != NULL). */
     int (*choose)(void *user, int32_t kind, const int64_t *list, int64_t n, int64_t excess, int64_t *out);

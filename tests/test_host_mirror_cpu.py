@@ -391,3 +391,86 @@ def test_callback_signatures_of_the_bindings_match_the_header():
     for name, proto in (("choose", api._CHOOSE), ("progress", api._PROGRESS), ("allreduce", api._ALLREDUCE), ("allgather", api._ALLGATHER)):
         got = (ccls(proto._restype_), [ccls(a) for a in proto._argtypes_])
         assert got == sigs[name], (name, got, sigs[name])
+
+
+def _julia_block_balance(src):
+    """(openers, ends, final bracket depth) of Julia source: strings, chars and comments skipped; `for` / `if` / `end` / `begin`
+    inside brackets are comprehension / indexing tokens, not blocks."""
+    i, n = 0, len(src)
+    depth_br = []          # stack of '(' '[' '{'
+    opens = ends = 0
+    stack = []
+    import re
+    toks = re.compile(r"[A-Za-z_@][A-Za-z_0-9!]*")
+    line = 1
+    while i < n:
+        ch = src[i]
+        if ch == "\n":
+            line += 1; i += 1; continue
+        if ch == "#":
+            if src.startswith("#=", i):
+                j = src.index("=#", i) + 2
+                line += src.count("\n", i, j); i = j
+            else:
+                while i < n and src[i] != "\n": i += 1
+            continue
+        if ch == '"':
+            if src.startswith('"""', i):
+                j = src.index('"""', i + 3) + 3
+                line += src.count("\n", i, j); i = j; continue
+            i += 1
+            while src[i] != '"':
+                if src[i] == "\\": i += 1
+                elif src[i] == "$" and src[i+1] == "(":       # interpolation: skip to the matching paren
+                    d = 0
+                    while True:
+                        if src[i] == "(": d += 1
+                        if src[i] == ")":
+                            d -= 1
+                            if d == 0: break
+                        i += 1
+                i += 1
+            i += 1; continue
+        if ch == "'" and (i == 0 or not (src[i-1].isalnum() or src[i-1] in ")]}_'")):     # a character literal, not a transpose
+            j = i + 1
+            if src[j] == "\\": j += 1
+            j += 1
+            if j < n and src[j] == "'": i = j + 1; continue
+        if ch in "([{":
+            depth_br.append(ch); i += 1; continue
+        if ch in ")]}":
+            depth_br.pop(); i += 1; continue
+        m = toks.match(src, i)
+        if m:
+            w = m.group(0)
+            prev = src[i-1] if i else "\n"
+            i = m.end()
+            if prev in ".:" and w in ("end", "begin", "if", "for"):       # a.end / :end symbols
+                continue
+            in_idx = "[" in depth_br
+            in_par = bool(depth_br)
+            if w in ("function", "struct", "while", "try", "let", "module", "quote", "macro", "do", "baremodule"):
+                opens += 1; stack.append((w, line))
+            elif w == "begin" and not in_idx:
+                opens += 1; stack.append((w, line))
+            elif w in ("if", "for") and not in_par:
+                opens += 1; stack.append((w, line))
+            elif w == "end" and not in_idx:
+                ends += 1
+                if stack: stack.pop()
+            continue
+        i += 1
+    return opens, ends, len(depth_br), stack
+
+
+def test_julia_glue_blocks_and_brackets_balance():
+    """No Julia toolchain in the image: at least every function / struct / if / for / do / begin / try of the glue has its `end`
+    and every bracket closes (strings, comments, comprehension `for` / `if` and indexing `end` are not counted) -- and the
+    checker notices when one is taken away."""
+    from conftest import ROOT
+    src = open(os.path.join(ROOT, "julia", "MendelIHTHip.jl")).read()
+    opens, ends, brackets, unclosed = _julia_block_balance(src)
+    assert opens == ends and opens > 40 and brackets == 0 and not unclosed, (opens, ends, brackets, unclosed)
+    cut = src.rindex("\nend", 0, src.index("function make_params"))          # drop the `end` of the function before make_params
+    o2, e2, _, left = _julia_block_balance(src[:cut] + src[cut + 4:])
+    assert o2 == e2 + 1 and left
