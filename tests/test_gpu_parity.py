@@ -1047,6 +1047,30 @@ def test_cv_iht_over_replicas_in_one_process(mih, normal_data):
         mih.cv_iht(y, [xa, mih.SnpLinAlg(bed[:100], n, center=True, scale=True)], z, path=path, q=3, folds=folds, verbose=False)
 
 
+_NUDGES = [1.0 + e * 2.0 ** -51 for e in (2, 1, 3, 4, 6, 8)]      # a few ulps: one nudge can land on the same branch by luck (seed 2449)
+
+
+def _set_aside(tag):
+    """tools/fuzz_parity.py counts the trials a sweep set aside as unstable (MIH_SWEEP_LOG names its tally file)."""
+    if os.environ.get("MIH_SWEEP_LOG"):
+        with open(os.environ["MIH_SWEEP_LOG"], "a") as f:
+            f.write(f"unstable {tag}\n")
+
+
+def _unstable(a, b, rtol, atol=1e-10):
+    """The oracle against ITSELF on covariates scaled by 1 + a few 2^-51 (a: the run on the original input, b: a nudged one, dicts
+    of arrays / scalars): True when an ulp-sized change of the input moves the oracle's own answer by more than the tolerance.
+    Such a trajectory amplifies rounding from step to step (seed 2121 of tools/fuzz_parity.py: the intercepts of a multivariate
+    fit drift apart by x1.87 per iteration, 1e-15 -> 4e-7 over 40 steps; seed 2275: a Bernoulli fit that backtracks three
+    times in most steps) -- no two floating-point implementations agree on it, the reference under another BLAS included,
+    so the sweeps do not hold the GPU to it."""
+    for key in a:
+        va, vb = np.asarray(a[key], dtype=float), np.asarray(b[key], dtype=float)
+        if va.shape != vb.shape or not np.allclose(va, vb, rtol=rtol, atol=atol):
+            return True
+    return False
+
+
 def test_randomized_fits_vs_oracle(mih, oracle):
     """A seeded sweep over shapes, missing rates, families, covariates, zkeep masks, prior weights, train masks
     and k: the GPU fit must track the oracle (same support and iteration log) on every stable trajectory."""
@@ -1078,11 +1102,18 @@ def test_randomized_fits_vs_oracle(mih, oracle):
         if o["bt_trace"].max(initial=0) >= 3:
             continue                                  # chaotic trajectory (likelihood dropped after max_step backtracks)
         tag = (trial, n, p, k, od, q, miss, sorted(kw))
-        assert res.iter == o["iter"], tag
-        assert np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"])), tag
-        np.testing.assert_allclose(res.beta, o["beta"], rtol=tol, atol=1e-10, err_msg=str(tag))
-        np.testing.assert_allclose(res.c, o["c"], rtol=tol, atol=1e-10, err_msg=str(tag))
-        assert res.logl == pytest.approx(o["logl"], rel=1e-8), tag
+        try:
+            assert res.iter == o["iter"], tag
+            assert np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"])), tag
+            np.testing.assert_allclose(res.beta, o["beta"], rtol=tol, atol=1e-10, err_msg=str(tag))
+            np.testing.assert_allclose(res.c, o["c"], rtol=tol, atol=1e-10, err_msg=str(tag))
+            assert res.logl == pytest.approx(o["logl"], rel=1e-8), tag
+        except AssertionError:
+            pick = lambda d, g=1.0: dict(iter=d["iter"], beta=d["beta"], c=d["c"] * g, logl=d["logl"])
+            if any(_unstable(pick(o), pick(oracle.fit_iht(ox, y, z * g, k=k, dist=od, link=ol, max_iter=60, **kw), g), tol) for g in _NUDGES):
+                _set_aside(("fit",) + tag)
+                continue                              # the oracle does not agree with itself on this one
+            raise
         checked += 1
     assert checked >= 8
 
@@ -1187,11 +1218,18 @@ def test_randomized_multivariate_fits_vs_oracle(mih, oracle):
         if o["bt_trace"].max(initial=0) >= 3:
             continue
         tag = (trial, n, p, r, q, k, miss, sorted(kw))
-        assert res.iter == o["iter"], tag
-        assert np.array_equal(res.beta != 0, o["B"] != 0), tag
-        np.testing.assert_allclose(res.beta, o["B"], rtol=1e-5, atol=1e-10, err_msg=str(tag))
-        np.testing.assert_allclose(res.c, o["C"], rtol=1e-5, atol=1e-10, err_msg=str(tag))
-        np.testing.assert_allclose(res.Σ, o["Sigma"], rtol=1e-6, err_msg=str(tag))
+        try:
+            assert res.iter == o["iter"], tag
+            assert np.array_equal(res.beta != 0, o["B"] != 0), tag
+            np.testing.assert_allclose(res.beta, o["B"], rtol=1e-5, atol=1e-10, err_msg=str(tag))
+            np.testing.assert_allclose(res.c, o["C"], rtol=1e-5, atol=1e-10, err_msg=str(tag))
+            np.testing.assert_allclose(res.Σ, o["Sigma"], rtol=1e-6, err_msg=str(tag))
+        except AssertionError:
+            pick = lambda d, g=1.0: dict(iter=d["iter"], B=d["B"], C=d["C"] * g, Sigma=d["Sigma"])
+            if any(_unstable(pick(o), pick(oracle.fit_mv(ox, Y, Z * g, k=k, max_iter=60, **kw), g), 1e-5) for g in _NUDGES):
+                _set_aside(("mv",) + tag)
+                continue
+            raise
         checked += 1
     assert checked >= 6
 
@@ -1327,8 +1365,18 @@ def test_randomized_cv_vs_oracle(mih, oracle):
         tag = (trial, n, p, q, od, path)
         mse, raw = mih.cv_iht(y, x, None, d=D(), l=L(), path=path, q=q, folds=folds, verbose=False, return_raw=True)
         omse, oraw = oracle.cv_iht(ox, y, None, path=path, q=q, folds=folds, dist=od, link=ol)
-        np.testing.assert_allclose(raw, oraw, rtol=100 * tol, err_msg=str(tag))
-        np.testing.assert_allclose(mse, omse, rtol=100 * tol, err_msg=str(tag))
+        ok = np.isclose(raw, oraw, rtol=100 * tol, atol=0)
+        if not ok.all():                  # entries the oracle itself does not reproduce after ulp-sized nudges of the intercept column are set aside (_unstable)
+            stable = np.ones_like(ok)
+            for g in _NUDGES:
+                _, oraw2 = oracle.cv_iht(ox, y, np.full((n, 1), g), path=path, q=q, folds=folds, dist=od, link=ol)
+                stable &= np.isclose(oraw2, oraw, rtol=100 * tol, atol=0)
+            assert (ok | ~stable).all() and stable.mean() > 0.8, (tag, np.argwhere(~ok & stable))
+            _set_aside(("cv", int((~stable).sum()), "of", stable.size) + tag)
+            whole = stable.all(axis=0)                                    # model sizes with every fold stable
+            np.testing.assert_allclose(mse[whole], omse[whole], rtol=100 * tol, err_msg=str(tag))
+        else:
+            np.testing.assert_allclose(mse, omse, rtol=100 * tol, err_msg=str(tag))
         halves = [mih.cv_iht(y, x, None, d=D(), l=L(), path=path, q=q, folds=folds, verbose=False, return_raw=True,
                              rank=r, world=2)[1] for r in range(2)]
         assert np.array_equal(halves[0] + halves[1], raw), tag
