@@ -475,6 +475,7 @@ typedef struct {
     int64_t zkeepn;
     const int64_t *group; const double *weight;
     int choose_fired;
+    double eta_cond;      /* orc_result.eta_cond */
     int (*choose_cb)(void *, int32_t, const int64_t *, int64_t, int64_t, int64_t *);
     void *choose_user;
     int init_beta;
@@ -494,6 +495,7 @@ static ihtvar *iv_create(const orc_mat *x, const orc_params *prm, const double *
     v->dist = prm->dist; v->link = prm->link; v->nb_r = prm->nb_r; v->est_r = prm->est_r;
     v->group = prm->group; v->weight = prm->weight; v->init_beta = prm->init_beta;
     v->choose_cb = prm->choose; v->choose_user = prm->choose_user;
+    v->eta_cond = 1.0;
     v->b = dalloc(p); v->b0 = dalloc(p); v->best_b = dalloc(p); v->df = dalloc(p);
     v->xb = dalloc(n); v->xgk = dalloc(n); v->r = dalloc(n); v->zc = dalloc(n);
     v->zdf2 = dalloc(n); v->mu = dalloc(n); v->cv_wts = dalloc(n);
@@ -785,6 +787,14 @@ static double stepsize(ihtvar *v)
     for (int64_t j = 0; j < v->q; ++j) if (v->idc[j]) numer += v->df2[j] * v->df2[j];
     double eta = numer / denom;
     if (isinf(eta) || isnan(eta)) eta = 1e-8;
+    {   /* diagnostic only (orc_result.eta_cond) */
+        double total = 0.0;
+        int64_t dirs = 0;             /* with ONE direction the ratio is df^2 / (df^2 |x|^2): the residue cancels, eta is well defined */
+        for (int64_t j = 0; j < v->p; ++j) { total += v->df[j] * v->df[j]; dirs += v->idx[j] != 0; }
+        for (int64_t j = 0; j < v->q; ++j) { total += v->df2[j] * v->df2[j]; dirs += v->idc[j] != 0; }
+        double share = total > 0.0 ? numer / total : 1.0;
+        if (dirs >= 2 && share < v->eta_cond) v->eta_cond = share;
+    }
     return eta;
 }
 
@@ -1138,7 +1148,7 @@ int orc_fit_iht(const orc_mat *x, const orc_params *prm, const double *y,
                            res->bt_trace, &res->n_trace);
     if (!rc) {
         res->pve = sample_var(v->mu, v->n) / sample_var(v->y, v->n);  /* pve.jl:22,32 */
-        res->nb_r = v->nb_r; res->choose_fired = v->choose_fired;
+        res->nb_r = v->nb_r; res->choose_fired = v->choose_fired; res->eta_cond = v->eta_cond;
         if (res->beta) memcpy(res->beta, v->best_b, sizeof(double) * v->p);
         if (res->c) memcpy(res->c, v->best_c, sizeof(double) * v->q);
         if (res->mu) memcpy(res->mu, v->mu, sizeof(double) * v->n);

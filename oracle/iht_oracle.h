@@ -81,6 +81,12 @@ typedef struct orc_result {
     double  *tol_trace;
     int32_t *bt_trace;
     double  *mu;              /* caller-allocated n or NULL: final v.mu */
+    double   eta_cond;        /* diagnostic, not in the reference: the smallest, over the steps, of
+                                 (|df[idx]|^2 + |df2[idc]|^2) / (|df|^2 + |df2|^2), the share of the squared score that lies on
+                                 the support (steps with at least two active directions).  iht_stepsize! divides exactly that numerator by |X_S df_S + Z df2|^2
+                                 (utilities.jl:754-757): when the share is ~1e-20 -- the previous step was an exact line search
+                                 on this support -- eta is a ratio of two rounding residues and any two floating-point
+                                 implementations get a different step (tests set such a trajectory aside) */
 } orc_result;
 
 /* ---- SnpLinAlg restatement (SnpArrays.jl linalg_direct.jl) ------------- */

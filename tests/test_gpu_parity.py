@@ -1118,6 +1118,120 @@ def test_randomized_fits_vs_oracle(mih, oracle):
     assert checked >= 8
 
 
+def _options_case(mih, oracle, rng, trial):
+    """One random case of test_randomized_options_vs_oracle (also replayed by hand when a seed of tools/fuzz_parity.py fails)."""
+    from scipy import stats
+    n = int(rng.integers(120, 1800)); p = int(rng.integers(60, 500)); q = int(rng.integers(1, 4))
+    miss = float(rng.choice([0.0, 0.02]))
+    cols = make_bed(rng, n, p, missing_rate=miss, maf_lo=0.05)
+    x = mih.SnpLinAlg(cols, n=n, center=True, scale=True, impute=True)
+    ox = oracle.Mat.from_bed_columns(cols, n)
+    z = np.column_stack([np.ones(n)] + [rng.standard_normal(n) for _ in range(q - 1)])
+    eta = 0.4 * _sim(oracle, ox, rng, 5) + z @ np.concatenate([[0.3], rng.standard_normal(q - 1) * 0.2])
+    fam = str(rng.choice(["normal", "bernoulli_probit", "bernoulli_cloglog", "poisson", "poisson_sqrt", "negbin", "negbin_mm",
+                          "negbin_newton", "gamma", "invgauss"]))
+    kw, okw, tol = {}, {}, 1e-4
+    if fam == "normal":
+        y, tol = eta + rng.standard_normal(n), 1e-5
+    elif fam == "bernoulli_probit":
+        y = (rng.random(n) < stats.norm.cdf(eta)).astype(float)
+        kw, okw = dict(d=mih.Bernoulli(), l=mih.ProbitLink()), dict(dist="bernoulli", link="probit")
+    elif fam == "bernoulli_cloglog":
+        y = (rng.random(n) < 1 - np.exp(-np.exp(eta - 0.5))).astype(float)
+        kw, okw = dict(d=mih.Bernoulli(), l=mih.CloglogLink()), dict(dist="bernoulli", link="cloglog")
+    elif fam == "poisson":
+        y = rng.poisson(np.exp(np.clip(eta, -3, 3))).astype(float)
+        kw, okw = dict(d=mih.Poisson(), l=mih.LogLink()), dict(dist="poisson", link="log")
+    elif fam == "poisson_sqrt":
+        y = rng.poisson((1.5 + np.clip(0.5 * eta, -1, 3)) ** 2).astype(float)
+        kw, okw = dict(d=mih.Poisson(), l=mih.SqrtLink()), dict(dist="poisson", link="sqrt")
+    elif fam.startswith("negbin"):
+        mu = np.exp(0.5 + np.clip(0.5 * eta, -3, 3))
+        y = rng.negative_binomial(4, 4 / (mu + 4)).astype(float)
+        est = {"negbin": None, "negbin_mm": "MM", "negbin_newton": "Newton"}[fam]
+        r0 = float(rng.choice([1.0, 4.0]))
+        kw, okw = dict(d=mih.NegativeBinomial(r0), l=mih.LogLink()), dict(dist="negbin", link="log", nb_r=r0)
+        if est:
+            kw["est_r"], okw["est_r"] = est, est.lower()
+    elif fam == "gamma":
+        y = rng.gamma(5.0, np.exp(np.clip(0.5 * eta, -3, 3) + 0.5) / 5.0)
+        kw, okw = dict(d=mih.Gamma(), l=mih.LogLink()), dict(dist="gamma", link="log")
+    else:
+        y = rng.wald(np.exp(np.clip(0.5 * eta, -3, 3) + 0.5), 8.0)
+        kw, okw = dict(d=mih.InverseGaussian(), l=mih.LogLink()), dict(dist="invgauss", link="log")
+    both = {}
+    mode = str(rng.choice(["plain", "group", "group_ks", "debias", "init_beta"]))
+    k = int(rng.integers(1, 9))
+    if mode.startswith("group"):
+        G = int(rng.integers(3, 12))
+        group = np.sort(rng.integers(1, G + 1, p))
+        group[:G] = np.arange(1, G + 1)                     # every label 1..G occurs (project_group_sparse! wants 1..G)
+        group = np.sort(group)
+        both["group"], both["J"] = group, int(rng.integers(1, G + 1))
+        k = rng.integers(1, 4, G) if mode == "group_ks" else int(rng.integers(1, 4))
+    elif mode == "debias":
+        both["debias"] = True
+    elif mode == "init_beta" and fam == "normal":
+        both["init_beta"] = True
+    if q > 1 and rng.random() < 0.4:
+        both["zkeep"] = [1] + [int(v) for v in rng.integers(0, 2, q - 1)]
+    if rng.random() < 0.3 and not mode.startswith("group"):
+        both["weight"] = rng.uniform(0.5, 2.0, p)
+    tag = (trial, n, p, q, miss, fam, mode, np.ravel(k).tolist(), sorted(both))
+    return x, ox, y, z, k, kw, okw, both, tol, fam, tag
+
+
+def test_randomized_options_vs_oracle(mih, oracle):
+    """Seeded sweep over the keyword surface the first sweep leaves out: group / J / vector k (doubly sparse projection), debias,
+    init_beta, NegativeBinomial with est_r, Gamma / InverseGaussian, non-canonical links -- combined at random, on random
+    shapes with missing genotypes, against the oracle on every trajectory the oracle itself reproduces (_unstable)."""
+    rng = np.random.default_rng(int(os.environ.get("MIH_SWEEP_SEED", 4242)))
+    checked = errors = 0
+    for trial in range(12):
+        x, ox, y, z, k, kw, okw, both, tol, fam, tag = _options_case(mih, oracle, rng, trial)
+
+        def orc(yy, zz, g=1.0):                              # None: the reference algorithm itself ends in an error
+            try:                                             # (NaN / Inf loglikelihood, fit.jl:259-260; GLM.jl's refit failing inside debias!)
+                d = oracle.fit_iht(ox, yy, zz, k=k, max_iter=40, **okw, **both)
+            except RuntimeError:
+                return None
+            return dict(iter=d["iter"], beta=d["beta"], c=d["c"] * g, logl=d["logl"], nb_r=d["nb_r"], bt=d["bt_trace"], eta_cond=d["eta_cond"])
+        o = orc(y, z)
+        try:
+            res = mih.fit_iht(y, x, z, k=k, max_iter=40, verbose=False, **kw, **both)
+        except mih.MendelIHTError:
+            res = None
+        if o is None and res is None:
+            errors += 1
+            continue
+        if o is not None and o["bt"].max(initial=0) >= 3:
+            continue                                         # chaotic (the likelihood dropped after max_step backtracks)
+        try:
+            assert o is not None and res is not None, (tag, "only one side ended in an error", o is None, res is None)
+            assert res.iter == o["iter"], tag
+            assert np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"])), tag
+            np.testing.assert_allclose(res.beta, o["beta"], rtol=tol, atol=1e-9, err_msg=str(tag))
+            np.testing.assert_allclose(res.c, o["c"], rtol=tol, atol=1e-9, err_msg=str(tag))
+            assert res.logl == pytest.approx(o["logl"], rel=1e-7), tag
+            if fam in ("negbin_mm", "negbin_newton"):
+                assert res.d.r == pytest.approx(o["nb_r"], rel=1e-5), tag
+        except AssertionError:
+            # Is the ORACLE's own answer conditioned well enough to hold anybody to it?  Ulp-sized scalings of the covariates
+            # re-draw its rounding noise.  They cannot see one case, which the oracle reports itself (eta_cond, iht_oracle.h):
+            # seed 3087 -- after an exact line search on a one-SNP support (group initialisation, utilities.jl:427-429) the
+            # score on the support is a rounding residue, 1e-12 in one implementation and 5e-14 in the other, the intercept's
+            # 3e-14, and iht_stepsize!'s ratio of such numbers comes out anywhere between 1/|x|^2 = 1/811 and 1/n = 1/792.
+            variants = [orc(y, z * g, g) for g in _NUDGES]
+            strip = lambda d: {key: d[key] for key in ("iter", "beta", "c", "logl")}
+            if (o is not None and o["eta_cond"] < 1e-18) or \
+               any((v is None) != (o is None) or (v is not None and _unstable(strip(o), strip(v), tol, atol=1e-9)) for v in variants):
+                _set_aside(("options",) + tag)
+                continue
+            raise
+        checked += 1
+    assert checked + errors >= 4
+
+
 def test_error_paths_nan_loglikelihood_and_bad_arguments(mih, normal_pair, normal_data):
     """fit.jl:259-260 (NaN/Inf loglikelihood aborts), fit.jl:87-94 argument errors, k > p."""
     x, _ = normal_pair
