@@ -1212,9 +1212,10 @@ def test_randomized_options_vs_oracle(mih, oracle):
             assert np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"])), tag
             np.testing.assert_allclose(res.beta, o["beta"], rtol=tol, atol=1e-9, err_msg=str(tag))
             np.testing.assert_allclose(res.c, o["c"], rtol=tol, atol=1e-9, err_msg=str(tag))
-            assert res.logl == pytest.approx(o["logl"], rel=1e-7), tag
-            if fam in ("negbin_mm", "negbin_newton"):
-                assert res.d.r == pytest.approx(o["nb_r"], rel=1e-5), tag
+            estr = fam in ("negbin_mm", "negbin_newton")       # r's updates stop at |dr| <= 1e-6 (utilities.jl:242): rounding moves r, and the loglikelihood with it, by that much
+            assert res.logl == pytest.approx(o["logl"], rel=1e-5 if estr else 1e-7), tag
+            if estr:                                           # (counts that are not overdispersed send r to 1e8 and beyond, where it no longer matters: compare 1/r)
+                assert 1.0 / res.d.r == pytest.approx(1.0 / o["nb_r"], rel=1e-5, abs=1e-7), tag
         except AssertionError:
             # Is the ORACLE's own answer conditioned well enough to hold anybody to it?  Ulp-sized scalings of the covariates
             # re-draw its rounding noise.  They cannot see one case, which the oracle reports itself (eta_cond, iht_oracle.h):
@@ -1230,6 +1231,52 @@ def test_randomized_options_vs_oracle(mih, oracle):
             raise
         checked += 1
     assert checked + errors >= 4
+
+
+def test_randomized_genotype_linear_algebra(mih, oracle):
+    """Seeded sweep of the genotype linear algebra itself: row counts around every tile boundary of the kernels (the 4-per-byte
+    packing, the 128-row MFMA step, the 2^18-row slices), a single SNP up to a few thousand, missing rates up to 30 %, the
+    center / scale / impute flags, 1..40 residuals per fused pass with scales from 1e-200 to 1e+200 in ONE pass, every
+    residual format -- mu, sigma^-1, X'R and X b against the oracle, the fused pass against the single pass bit for bit."""
+    rng = np.random.default_rng(int(os.environ.get("MIH_SWEEP_SEED", 9001)))
+    edges = np.array([1, 2, 3, 4, 5, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 513, 1023, 1025, 4095, 4097])
+    for trial in range(10):
+        n = int(rng.choice(edges)) if rng.random() < 0.5 else int(rng.integers(1, 20000))
+        if trial == 0 and os.environ.get("MIH_SWEEP_SEED") is None:
+            n = (1 << 18) + int(rng.integers(-3, 4))                       # one committed case straddling a row slice
+        p = int(rng.choice([1, 2, 3, 15, 16, 17, 31, 33, 64, 100, 257])) if rng.random() < 0.6 else int(rng.integers(1, 3000))
+        if n * p > 6e7:
+            p = max(1, int(6e7 // n))
+        miss = float(rng.choice([0.0, 0.0, 0.01, 0.3])) if n >= 64 else 0.0   # (a SNP with every sample missing has no mean: not a case of the reference)
+        flags = dict(center=bool(rng.random() < 0.8), scale=bool(rng.random() < 0.8), impute=bool(rng.random() < 0.8))
+        cols = make_bed(rng, n, p, missing_rate=miss, maf_lo=0.0)          # maf 0: monomorphic SNPs (sigma^-1 = 1) included
+        x = mih.SnpLinAlg(cols, n=n, **flags)
+        ox = oracle.Mat.from_bed_columns(cols, n, **flags)
+        tag = (trial, n, p, miss, flags)
+        mu, sinv = x.mu_sigma()
+        omu, osinv = ox.mu_sinv()
+        assert np.array_equal(mu, omu) and np.array_equal(sinv, osinv), tag
+        m = int(rng.integers(1, 41))
+        R = rng.standard_normal((n, m)) * 10.0 ** rng.integers(-200, 201, m).astype(float) if rng.random() < 0.3 else rng.standard_normal((n, m))
+        if rng.random() < 0.3:
+            R[:, int(rng.integers(0, m))] = 0.0                            # an all-zero residual among the others
+        R = np.asfortranarray(R)
+        want = ox.xtv_multi(R)
+        scale = np.abs(want).max(axis=0) + np.sqrt(n) * np.abs(R).max(axis=0) * 1e-3 + 1e-300
+        for dg in (None, 1316, 428, 4910):
+            if dg == 428 and m > 1 and rng.random() < 0.5:
+                continue
+            got = x.xtv(R, xtv_digits=dg)
+            assert np.all(np.isfinite(got)), (tag, dg)
+            assert (np.abs(got - want).max(axis=0) / scale).max() < 1e-11, (tag, m, dg)
+            j = int(rng.integers(0, m))
+            assert np.array_equal(x.xtv(R[:, j].copy(), xtv_digits=dg if dg else 4910), x.xtv(R, xtv_digits=dg if dg else 4910)[:, j]) or dg == 428, (tag, m, dg, j)
+        kk = int(rng.integers(0, min(p, 40) + 1))
+        idx = np.sort(rng.choice(p, kk, replace=False))
+        val = rng.standard_normal(kk)
+        mask = np.zeros(p, np.uint8); mask[idx] = 1
+        coef = np.zeros(p); coef[idx] = val
+        np.testing.assert_allclose(x.xv_sparse(idx, val), ox.xv_masked(mask, coef), rtol=1e-12, atol=1e-12 * (1 + np.abs(val).sum()), err_msg=str(tag))
 
 
 def test_error_paths_nan_loglikelihood_and_bad_arguments(mih, normal_pair, normal_data):
