@@ -1095,6 +1095,8 @@ struct IhtVar {
         MIH_TRY(final_sum_home(1, scal.p, scal.p, 1));
         const double denom = hpin.p[0];
         double e = numer / denom;
+        if (probe_env("MENDELIHT_TRACE_ETA"))            // measurement build: what iht_stepsize! divides (tests/test_gpu_parity.py, the 0/0 cases of the sweeps)
+            fprintf(stderr, "stepsize: numer %.17g denom %.17g eta %.17g support %zu df2[0] %.17g\n", numer, denom, e, idx.idx.size(), q ? df2[0] : 0.0);
         if (std::isinf(e) || std::isnan(e)) e = 1e-8;
         *eta = e;
         return MIH_OK;

@@ -789,11 +789,10 @@ static double stepsize(ihtvar *v)
     if (isinf(eta) || isnan(eta)) eta = 1e-8;
     {   /* diagnostic only (orc_result.eta_cond) */
         double total = 0.0;
-        int64_t dirs = 0;             /* with ONE direction the ratio is df^2 / (df^2 |x|^2): the residue cancels, eta is well defined */
-        for (int64_t j = 0; j < v->p; ++j) { total += v->df[j] * v->df[j]; dirs += v->idx[j] != 0; }
-        for (int64_t j = 0; j < v->q; ++j) { total += v->df2[j] * v->df2[j]; dirs += v->idc[j] != 0; }
+        for (int64_t j = 0; j < v->p; ++j) total += v->df[j] * v->df[j];
+        for (int64_t j = 0; j < v->q; ++j) total += v->df2[j] * v->df2[j];
         double share = total > 0.0 ? numer / total : 1.0;
-        if (dirs >= 2 && share < v->eta_cond) v->eta_cond = share;
+        if (share < v->eta_cond) v->eta_cond = share;
     }
     return eta;
 }

@@ -83,10 +83,15 @@ typedef struct orc_result {
     double  *mu;              /* caller-allocated n or NULL: final v.mu */
     double   eta_cond;        /* diagnostic, not in the reference: the smallest, over the steps, of
                                  (|df[idx]|^2 + |df2[idc]|^2) / (|df|^2 + |df2|^2), the share of the squared score that lies on
-                                 the support (steps with at least two active directions).  iht_stepsize! divides exactly that numerator by |X_S df_S + Z df2|^2
-                                 (utilities.jl:754-757): when the share is ~1e-20 -- the previous step was an exact line search
-                                 on this support -- eta is a ratio of two rounding residues and any two floating-point
-                                 implementations get a different step (tests set such a trajectory aside) */
+                                 the support.  iht_stepsize! divides exactly that numerator by |X_S df_S + Z df2|^2
+                                 (utilities.jl:754-757).  A share of ~1e-20 means the score on the support is a rounding residue
+                                 (the previous step was an exact line search on this support; or the support is empty -- initial
+                                 support with a vector k, utilities.jl:427-429 -- and the intercept has just been solved for).
+                                 With two or more active directions eta is then a ratio of two residues; with one direction
+                                 it is well defined unless the residue happens to round to exactly 0, when the guard of
+                                 utilities.jl:760-761 makes the step 1e-8 instead (seed 4036 of tools/fuzz_parity.py: the sum of
+                                 y - mu came out as 0 on the GPU and as 1e-13 here).  Either way two floating-point
+                                 implementations take different steps; the sweeps set such a trajectory aside. */
 } orc_result;
 
 /* ---- SnpLinAlg restatement (SnpArrays.jl linalg_direct.jl) ------------- */

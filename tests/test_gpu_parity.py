@@ -1204,8 +1204,8 @@ def test_randomized_options_vs_oracle(mih, oracle):
         if o is None and res is None:
             errors += 1
             continue
-        if o is not None and o["bt"].max(initial=0) >= 3:
-            continue                                         # chaotic (the likelihood dropped after max_step backtracks)
+        if (o is not None and o["bt"].max(initial=0) >= 3) or (res is not None and res.trace["backtracks"].max(initial=0) >= 3):
+            continue                                         # chaotic (the likelihood dropped after max_step backtracks) -- on whichever side got that far
         try:
             assert o is not None and res is not None, (tag, "only one side ended in an error", o is None, res is None)
             assert res.iter == o["iter"], tag
@@ -1215,13 +1215,15 @@ def test_randomized_options_vs_oracle(mih, oracle):
             estr = fam in ("negbin_mm", "negbin_newton")       # r's updates stop at |dr| <= 1e-6 (utilities.jl:242): rounding moves r, and the loglikelihood with it, by that much
             assert res.logl == pytest.approx(o["logl"], rel=1e-5 if estr else 1e-7), tag
             if estr:                                           # (counts that are not overdispersed send r to 1e8 and beyond, where it no longer matters: compare 1/r)
-                assert 1.0 / res.d.r == pytest.approx(1.0 / o["nb_r"], rel=1e-5, abs=1e-7), tag
+                assert 1.0 / res.d.r == pytest.approx(1.0 / o["nb_r"], rel=1e-5, abs=1e-5), tag
         except AssertionError:
             # Is the ORACLE's own answer conditioned well enough to hold anybody to it?  Ulp-sized scalings of the covariates
             # re-draw its rounding noise.  They cannot see one case, which the oracle reports itself (eta_cond, iht_oracle.h):
             # seed 3087 -- after an exact line search on a one-SNP support (group initialisation, utilities.jl:427-429) the
             # score on the support is a rounding residue, 1e-12 in one implementation and 5e-14 in the other, the intercept's
-            # 3e-14, and iht_stepsize!'s ratio of such numbers comes out anywhere between 1/|x|^2 = 1/811 and 1/n = 1/792.
+            # 3e-14, and iht_stepsize!'s ratio of such numbers comes out anywhere between 1/|x|^2 = 1/811 and 1/n = 1/792; seed 4036 --
+            # empty initial support (vector k) and an intercept score that sums to exactly 0 on the GPU, 1e-13 in the oracle: 0/0 -> the
+            # 1e-8 guard of utilities.jl:760-761 on one side, a step of 1/sum(w) on the other.
             variants = [orc(y, z * g, g) for g in _NUDGES]
             strip = lambda d: {key: d[key] for key in ("iter", "beta", "c", "logl")}
             if (o is not None and o["eta_cond"] < 1e-18) or \
@@ -1523,15 +1525,40 @@ def test_randomized_cv_vs_oracle(mih, oracle):
         npath = int(rng.integers(2, 14))                               # up to 13 x 4 = 52 combinations: more than 24 slots
         path = sorted(int(v) for v in rng.choice(np.arange(1, 16), npath, replace=False))
         folds = hash_folds(n, q)
-        tag = (trial, n, p, q, od, path)
-        mse, raw = mih.cv_iht(y, x, None, d=D(), l=L(), path=path, q=q, folds=folds, verbose=False, return_raw=True)
-        omse, oraw = oracle.cv_iht(ox, y, None, path=path, q=q, folds=folds, dist=od, link=ol)
+        extra, roll = {}, rng.random()                                 # a third of the grids with one of the options the lock-step driver carries since round 3
+        if roll < 0.12 and od == "normal":
+            extra["init_beta"] = True
+        elif roll < 0.24:
+            extra["debias"] = True
+        elif roll < 0.36:
+            G = int(rng.integers(3, 9))
+            group = rng.integers(1, G + 1, p)
+            group[:G] = np.arange(1, G + 1)                            # every label occurs; cv_iht fixes J = 1 (cross_validation.jl:91)
+            extra["group"] = np.sort(group)
+        tag = (trial, n, p, q, od, path, sorted(extra))
+        def orc(g=1.0):                                                # None: one of the reference's fits ends in an error (GLM.jl's refit inside debias!)
+            try:
+                return oracle.cv_iht(ox, y, np.full((n, 1), g), path=path, q=q, folds=folds, dist=od, link=ol, **extra)
+            except RuntimeError:
+                return None
+        first = orc()
+        try:
+            mse, raw = mih.cv_iht(y, x, None, d=D(), l=L(), path=path, q=q, folds=folds, verbose=False, return_raw=True, **extra)
+        except mih.MendelIHTError:
+            mse = raw = None
+        if first is None or raw is None:
+            if (first is None) != (raw is None):                       # only one side failed: a real finding unless the oracle wavers itself
+                kinds = {orc(g) is None for g in _NUDGES} | {first is None}
+                assert len(kinds) == 2, (tag, "only one side ended in an error", first is None, raw is None)
+                _set_aside(("cv-error",) + tag)
+            continue
+        omse, oraw = first
         ok = np.isclose(raw, oraw, rtol=100 * tol, atol=0)
         if not ok.all():                  # entries the oracle itself does not reproduce after ulp-sized nudges of the intercept column are set aside (_unstable)
             stable = np.ones_like(ok)
             for g in _NUDGES:
-                _, oraw2 = oracle.cv_iht(ox, y, np.full((n, 1), g), path=path, q=q, folds=folds, dist=od, link=ol)
-                stable &= np.isclose(oraw2, oraw, rtol=100 * tol, atol=0)
+                again = orc(g)
+                stable &= np.isclose(again[1], oraw, rtol=100 * tol, atol=0) if again is not None else False
             assert (ok | ~stable).all() and stable.mean() > 0.8, (tag, np.argwhere(~ok & stable))
             _set_aside(("cv", int((~stable).sum()), "of", stable.size) + tag)
             whole = stable.all(axis=0)                                    # model sizes with every fold stable
@@ -1539,7 +1566,7 @@ def test_randomized_cv_vs_oracle(mih, oracle):
         else:
             np.testing.assert_allclose(mse, omse, rtol=100 * tol, err_msg=str(tag))
         halves = [mih.cv_iht(y, x, None, d=D(), l=L(), path=path, q=q, folds=folds, verbose=False, return_raw=True,
-                             rank=r, world=2)[1] for r in range(2)]
+                             rank=r, world=2, **extra)[1] for r in range(2)]
         assert np.array_equal(halves[0] + halves[1], raw), tag
 
 
