@@ -1281,6 +1281,46 @@ def test_randomized_genotype_linear_algebra(mih, oracle):
         np.testing.assert_allclose(x.xv_sparse(idx, val), ox.xv_masked(mask, coef), rtol=1e-12, atol=1e-12 * (1 + np.abs(val).sum()), err_msg=str(tag))
 
 
+def test_randomized_projections(mih, oracle):
+    """Seeded sweep of the two projections (utilities.jl:553-559, :613-679) on their own: lengths from 1 to a few hundred thousand
+    (around the 2 x 11-bit histogram passes of the device top-k and its 64 Ki-candidate host finish), k from 1 to the length,
+    heavy ties (values rounded to one or two digits, blocks of equal magnitudes with mixed signs), zeros, +-Inf, denormals;
+    group labels dense or sparse with empty groups, J and k (scalar / vector) at random -- bit for bit against the oracle."""
+    rng = np.random.default_rng(int(os.environ.get("MIH_SWEEP_SEED", 515)))
+    for trial in range(16):
+        n = int(rng.choice([1, 2, 3, 31, 64, 1000, 2047, 2049, 65535, 65537])) if rng.random() < 0.4 else int(rng.integers(1, 300000))
+        v = rng.standard_normal(n) * 10.0 ** float(rng.integers(-3, 4))
+        style = int(rng.integers(0, 6))
+        if style == 1:
+            v = np.round(v, int(rng.integers(0, 3)))                  # many exact ties, many zeros
+        elif style == 2:
+            v = rng.choice([-2.5, -1.0, 0.0, 1.0, 2.5, 7.0], n)       # six distinct magnitudes
+        elif style == 3:
+            v[rng.random(n) < 0.01] = np.inf
+            v[rng.random(n) < 0.01] = -np.inf
+        elif style == 4:
+            v *= 1e-310                                               # denormals
+        elif style == 5:
+            v[rng.random(n) < 0.7] = 0.0
+        k = int(rng.choice([1, 2, n, max(1, n - 1), max(1, n // 2)])) if rng.random() < 0.4 else int(rng.integers(1, n + 1))
+        tag = (trial, n, style, k)
+        assert np.array_equal(mih.project_k(v, k), oracle.project_k(v, k)), tag
+        if n < 2:
+            continue
+        G = int(rng.integers(1, min(n, 3000) + 1))
+        if rng.random() < 0.5:
+            group = np.sort(rng.integers(1, G + 1, n))                 # contiguous blocks (some labels may not occur)
+        else:
+            group = rng.integers(1, G + 1, n)                          # scattered labels
+        group[rng.integers(0, n)] = G                                  # the largest label occurs: the reference sizes its tables by maximum(group)
+        J = int(rng.integers(1, G + 1))
+        kg = rng.integers(0, 5, G) if rng.random() < 0.5 else int(rng.integers(1, 5))
+        w = v.copy()
+        w[~np.isfinite(w)] = 1e6                                       # (the group norms of the reference are sums of squares: keep them finite)
+        got, want = mih.project_group_sparse(w, group, J, kg), oracle.project_group_sparse(w, group, J, kg)
+        assert np.array_equal(got, want), tag + (G, J, np.ravel(kg)[:8].tolist(), np.flatnonzero(got != want)[:5])
+
+
 def test_error_paths_nan_loglikelihood_and_bad_arguments(mih, normal_pair, normal_data):
     """fit.jl:259-260 (NaN/Inf loglikelihood aborts), fit.jl:87-94 argument errors, k > p."""
     x, _ = normal_pair
