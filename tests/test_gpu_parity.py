@@ -1082,11 +1082,20 @@ def test_randomized_fits_vs_oracle(mih, oracle):
         n = int(rng.integers(60, 2500)); p = int(rng.integers(40, 600)); k = int(rng.integers(1, 10))
         miss = float(rng.choice([0.0, 0.02, 0.1])); q = int(rng.integers(1, 4))
         od, ol, D, L, tol = fams[int(rng.integers(0, 3))]
-        cols = make_bed(rng, n, p, missing_rate=miss)
-        x = mih.SnpLinAlg(cols, n=n, center=True, scale=True, impute=True)
-        ox = oracle.Mat.from_bed_columns(cols, n)
+        kind = str(rng.choice(["snp", "snp", "snp", "dense64", "dense32"]))       # (the reference's x::Matrix{Float64} / Matrix{Float32} callers too)
+        if kind == "snp":
+            cols = make_bed(rng, n, p, missing_rate=miss)
+            x = mih.SnpLinAlg(cols, n=n, center=True, scale=True, impute=True)
+            ox = oracle.Mat.from_bed_columns(cols, n)
+        else:
+            X = rng.standard_normal((n, p)).astype(np.float32 if kind == "dense32" else np.float64)
+            x = mih.DenseMatrix(X)
+            ox = oracle.Mat.from_dense(X.astype(np.float64))              # the upcast is exact: same matrix on both sides
+            miss = kind
         z = np.column_stack([np.ones(n)] + [rng.standard_normal(n) for _ in range(q - 1)])
         eta = 0.5 * _sim(oracle, ox, rng, min(k, 5)) + z @ (rng.standard_normal(q) * 0.3)
+        if kind != "snp":
+            eta *= 0.5                                                   # (unit-variance columns with unbounded entries: keep the counts moderate)
         y = {"normal": eta + rng.standard_normal(n),
              "bernoulli": (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float),
              "poisson": rng.poisson(np.exp(np.clip(0.5 * eta, -3, 3))).astype(float)}[od]
