@@ -1661,6 +1661,62 @@ def test_randomized_multivariate_cv_vs_oracle(mih, oracle):
             np.testing.assert_allclose(mse, omse, rtol=1e-5, err_msg=str(tag))
 
 
+def test_randomized_model_paths_vs_oracle(mih, oracle):
+    """Seeded sweep of iht_run_many_models (cross_validation.jl:232-273; the lock-step path driver, the sequential branch for
+    est_r): families, covariates, groups, prior weights, debias, NegBin est_r -- the loglikelihood of every model size against
+    the oracle's fit of that size, and the path split over two ranks adds up exactly."""
+    rng = np.random.default_rng(int(os.environ.get("MIH_SWEEP_SEED", 6502)))
+    fams = [("normal", "identity", mih.Normal, mih.IdentityLink), ("bernoulli", "logit", mih.Bernoulli, mih.LogitLink),
+            ("poisson", "log", mih.Poisson, mih.LogLink), ("negbin", "log", mih.NegativeBinomial, mih.LogLink)]
+    for trial in range(5):
+        n = int(rng.integers(150, 1500)); p = int(rng.integers(60, 400)); q = int(rng.integers(1, 4))
+        od, ol, D, L = fams[int(rng.integers(0, 4))]
+        cols = make_bed(rng, n, p, missing_rate=float(rng.choice([0.0, 0.03])))
+        x = mih.SnpLinAlg(cols, n=n, center=True, scale=True, impute=True)
+        ox = oracle.Mat.from_bed_columns(cols, n)
+        z = np.column_stack([np.ones(n)] + [rng.standard_normal(n) for _ in range(q - 1)])
+        eta = 0.5 * _sim(oracle, ox, rng, 4) + z @ np.concatenate([[0.3], rng.standard_normal(q - 1) * 0.2])
+        y = {"normal": eta + rng.standard_normal(n),
+             "bernoulli": (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float),
+             "poisson": rng.poisson(np.exp(np.clip(0.5 * eta, -3, 3))).astype(float),
+             "negbin": rng.negative_binomial(4, 4 / (np.exp(0.5 + np.clip(0.5 * eta, -3, 3)) + 4)).astype(float)}[od]
+        path = sorted(int(v) for v in rng.choice(np.arange(1, 13), int(rng.integers(2, 8)), replace=False))
+        kw, okw = {}, {}
+        roll = rng.random()
+        if roll < 0.2:
+            kw["debias"] = okw["debias"] = True
+        elif roll < 0.4:
+            G = int(rng.integers(3, 8))
+            group = rng.integers(1, G + 1, p); group[:G] = np.arange(1, G + 1)
+            kw["group"] = okw["group"] = np.sort(group)
+        elif roll < 0.55:
+            kw["weight"] = okw["weight"] = rng.uniform(0.5, 2.0, p)
+        d = D(float(rng.choice([1.0, 4.0]))) if od == "negbin" else D()
+        if od == "negbin":
+            okw["nb_r"] = d.r
+            est = rng.choice(["None", "MM", "Newton"])
+            if est != "None":
+                kw["est_r"], okw["est_r"] = str(est), str(est).lower()
+        tag = (trial, n, p, q, od, path, sorted(kw))
+        ll = np.asarray(mih.iht_run_many_models(y, x, z, path=path, d=d, l=L(), verbose=False, **kw))
+        runs = [oracle.fit_iht(ox, y, z, k=k, dist=od, link=ol, max_iter=100, **okw) for k in path]
+        want = np.array([o["logl"] for o in runs])
+        tol = 1e-5 if "est_r" in kw else 1e-7
+        ok = np.isclose(ll, want, rtol=tol, atol=0)
+        for j in np.flatnonzero(~ok):                 # the single-fit sweeps' rules for a trajectory nobody can be held to
+            o = runs[j]
+            unstable = o["bt_trace"].max(initial=0) >= 3 or o["eta_cond"] < 1e-18
+            for g in _NUDGES:
+                if unstable:
+                    break
+                o2 = oracle.fit_iht(ox, y, z * g, k=path[j], dist=od, link=ol, max_iter=100, **okw)
+                unstable = o2["iter"] != o["iter"] or not np.isclose(o2["logl"], o["logl"], rtol=tol, atol=0)
+            assert unstable, (tag, path[j], ll[j], want[j])
+            _set_aside(("path", path[j]) + tag)
+        halves = [np.asarray(mih.iht_run_many_models(y, x, z, path=path, d=d, l=L(), verbose=False, rank=r, world=2, **kw)) for r in range(2)]
+        assert np.array_equal(halves[0] + halves[1], ll), tag
+
+
 def test_xtv_accuracy_against_exact_rational_arithmetic(mih):
     """The fixed-point X'r against EXACT dot products (Python rationals) of the raw dosages: the only rounding is that
     of the residual to 2^-55 max|r| (2^-58 in the base-13 format) plus the recombination in f64, so the error stays

@@ -1,6 +1,6 @@
-"""Extended randomized parity sweep: the seven seeded sweeps of tests/test_gpu_parity.py (univariate fits, multivariate fits,
+"""Extended randomized parity sweep: the eight seeded sweeps of tests/test_gpu_parity.py (univariate fits, multivariate fits,
 cross-validation grids, the keyword surface -- groups, debias, init_beta, NegBin est_r, Gamma / InverseGaussian, other links --
-the genotype linear algebra itself, the two projections and multivariate cross-validation grids, all against the oracle) re-run under other seeds (MIH_SWEEP_SEED), one pytest process
+the genotype linear algebra itself, the two projections, multivariate cross-validation grids and model paths, all against the oracle) re-run under other seeds (MIH_SWEEP_SEED), one pytest process
 per seed.
 
   python tools/fuzz_parity.py [first_seed] [count]        # writes one line per seed, a summary at the end
@@ -26,6 +26,6 @@ for seed in range(first, first + count):
 aside = open(tally).read().strip().splitlines()
 for l in aside:
     print(l)
-print(f"{count} seeds from {first} (14 + 10 + 6 + 12 + 10 + 16 + 4 trials each): {count - len(bad)} green, failing seeds {bad}; "
+print(f"{count} seeds from {first} (14 + 10 + 6 + 12 + 10 + 16 + 4 + 5 trials each): {count - len(bad)} green, failing seeds {bad}; "
       f"{len(aside)} trials set aside as unstable (the oracle disagrees with itself under ulp-sized nudges, or reports a 0/0 step size); {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
