@@ -203,13 +203,22 @@ class _DevArray:
 
 
 def column_block(p_global, rank, world):
-    """(offset, size) of the contiguous block of SNP columns a rank owns; blocks are multiples of 32
-    columns (one MFMA column group) except the last."""
+    """(offset, size) of the contiguous block of SNP columns a rank owns: the 32-column groups (one MFMA column group) dealt out
+    as evenly as they go, the earlier ranks taking the remainder; with fewer groups than ranks the columns themselves are dealt
+    out, so that no rank is left without a column as long as p_global >= world (a shard of no columns is not a matrix:
+    mih_snp_create refuses it)."""
+    if p_global < world:
+        from .api import ArgumentError
+        raise ArgumentError(f"{world} ranks for {p_global} SNP columns: every rank needs at least one column")
     groups = (p_global + 31) // 32
-    per = (groups + world - 1) // world
-    lo = min(rank * per * 32, p_global)
-    hi = min((rank + 1) * per * 32, p_global)
-    return lo, hi - lo
+    if groups >= world:
+        base, rem = divmod(groups, world)
+        lo = 32 * (rank * base + min(rank, rem))
+        hi = 32 * ((rank + 1) * base + min(rank + 1, rem))
+        return min(lo, p_global), min(hi, p_global) - min(lo, p_global)
+    base, rem = divmod(p_global, world)
+    lo = rank * base + min(rank, rem)
+    return lo, base + (1 if rank < rem else 0)
 
 
 def fit_iht_sharded(y, x_shard, z=None, *, col_offset, p_global, weight=None, native=False, **kw):

@@ -117,6 +117,30 @@ def main():
     run("ties_choose", dup, n, xo.xv_sparse(np.array([lo1 + cnt1 - 1]), np.array([1.0])) + 0.01 * rng.standard_normal(n),
         None, k=2)
 
+    # 5b. seeded random cases (MIH_SWEEP_SEED for other draws): shapes down to fewer columns than one 32-column tile per rank,
+    #     families, covariates in and out of zkeep, prior weights, train masks -- sharded == single, as above
+    srng = np.random.default_rng(int(os.environ.get("MIH_SWEEP_SEED", 1234)))
+    fams = [(m.Normal, m.IdentityLink), (m.Bernoulli, m.LogitLink), (m.Poisson, m.LogLink)]
+    for t in range(4):
+        rn = int(srng.integers(100, 1500)); rp = int(srng.integers(max(8, world), 700)); rq = int(srng.integers(1, 4))
+        rk = int(srng.integers(1, 9)); fi = int(srng.integers(0, 3))
+        rcols = make_bed(srng, rn, rp, missing_rate=float(srng.choice([0.0, 0.03])))
+        xr_ = m.SnpLinAlg(rcols, n=rn, center=True, scale=True, impute=True)
+        rs = np.sort(srng.choice(rp, min(4, rp), replace=False))
+        rz = np.column_stack([np.ones(rn)] + [srng.standard_normal(rn) for _ in range(rq - 1)])
+        reta = xr_.xv_sparse(rs, srng.standard_normal(rs.size) * 0.5) + rz @ np.concatenate([[0.3], srng.standard_normal(rq - 1) * 0.2])
+        ry = [reta + srng.standard_normal(rn), (srng.random(rn) < 1 / (1 + np.exp(-reta))).astype(float),
+              srng.poisson(np.exp(np.clip(0.5 * reta, -3, 3))).astype(float)][fi]
+        rkw = dict(k=rk, d=fams[fi][0](), l=fams[fi][1](), max_iter=60)
+        if rq > 1 and srng.random() < 0.5:
+            rkw["zkeep"] = [True] + [bool(v) for v in srng.integers(0, 2, rq - 1)]
+        if srng.random() < 0.4:
+            rkw["weight"] = srng.uniform(0.5, 2.0, rp)
+        if srng.random() < 0.4:
+            rkw["train"] = (srng.random(rn) < 0.8).astype(np.uint8)
+        del xr_
+        run(f"random{t}", rcols, rn, ry, rz, **rkw)
+
     # 6. cross-validation with the (fold, k) grid sharded over the same ranks (one all-gather of the losses)
     from conftest import hash_folds
     n = 1000

@@ -84,3 +84,27 @@ def test_column_comm_callbacks_two_ranks(tmp_path):
     blocks = [np.load(tmp_path / f"c{r}.npy")[12:] for r in range(world)]
     assert blocks[0][0] == 0 and blocks[0][0] + blocks[0][1] == blocks[1][0] and blocks[1][0] + blocks[1][1] == 1000
     assert blocks[0][1] % 32 == 0
+
+
+def test_column_block_covers_every_column_and_leaves_no_rank_empty():
+    """The column sharding of a single fit: contiguous blocks that tile 0..p, on 32-column boundaries whenever there are at least
+    as many column groups as ranks, and never an empty block while p >= world (found by the seeded random cases of
+    tests/sharded_worker.py: p = 40 on 3 ranks used to give the last rank no column, which mih_snp_create refuses)."""
+    import pytest
+
+    from mendeliht_amd import dist as D
+    from mendeliht_amd.api import MendelIHTError
+    for p in (1, 2, 3, 5, 31, 32, 33, 40, 64, 65, 100, 127, 128, 129, 1000, 2300, 10_000, 1_000_003):
+        for w in (1, 2, 3, 4, 8):
+            if p < w:
+                with pytest.raises(MendelIHTError):
+                    D.column_block(p, 0, w)
+                continue
+            blocks = [D.column_block(p, r, w) for r in range(w)]
+            assert blocks[0][0] == 0 and blocks[-1][0] + blocks[-1][1] == p, (p, w, blocks)
+            assert all(blocks[i][0] + blocks[i][1] == blocks[i + 1][0] for i in range(w - 1)), (p, w, blocks)
+            assert all(c > 0 for _, c in blocks), (p, w, blocks)
+            if (p + 31) // 32 >= w:
+                assert all(lo % 32 == 0 for lo, _ in blocks), (p, w, blocks)
+                sizes = [c for _, c in blocks]
+                assert max(sizes) - min(sizes) <= 32 + 31, (p, w, blocks)
