@@ -1717,6 +1717,26 @@ def test_randomized_model_paths_vs_oracle(mih, oracle):
         assert np.array_equal(halves[0] + halves[1], ll), tag
 
 
+def test_more_ranks_than_work_items(mih):
+    """Sharding with more ranks than (fold, k) combinations / path entries (8 GPUs, a 2 x 2 grid): the ranks without work return
+    zeros and the parts still add up to the single-process result bit for bit -- univariate and multivariate cross-validation,
+    model paths."""
+    rng = np.random.default_rng(0)
+    n, p = 400, 120
+    x = mih.SnpLinAlg(make_bed(rng, n, p), n=n, center=True, scale=True, impute=True)
+    y, Y = rng.standard_normal(n), rng.standard_normal((2, n))
+    folds = hash_folds(n, 2)
+    for resp, world in ((y, 8), (Y, 7)):
+        full = mih.cv_iht(resp, x, None, path=[1, 2], q=2, folds=folds, verbose=False, return_raw=True)[1]
+        parts = [mih.cv_iht(resp, x, None, path=[1, 2], q=2, folds=folds, verbose=False, return_raw=True, rank=r, world=world)[1] for r in range(world)]
+        assert np.array_equal(sum(parts), full) and sum(np.count_nonzero(q_) == 0 for q_ in parts) == world - 4
+    ll = np.asarray(mih.iht_run_many_models(y, x, None, path=[1, 3], verbose=False))
+    pp = [np.asarray(mih.iht_run_many_models(y, x, None, path=[1, 3], verbose=False, rank=r, world=5)) for r in range(5)]
+    assert np.array_equal(sum(pp), ll)
+    with pytest.raises(mih.MendelIHTError, match="no training samples"):
+        mih.cv_iht(y, x, None, path=[1], q=2, folds=np.ones(n, dtype=np.int32), verbose=False)      # every sample in fold 1: nothing to train fold 1's model on
+
+
 def test_xtv_accuracy_against_exact_rational_arithmetic(mih):
     """The fixed-point X'r against EXACT dot products (Python rationals) of the raw dosages: the only rounding is that
     of the residual to 2^-55 max|r| (2^-58 in the base-13 format) plus the recombination in f64, so the error stays
