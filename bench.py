@@ -264,9 +264,10 @@ def main():
                  f"  python -m torch.distributed.run --nnodes=1 --nproc-per-node {a.gpus} --master-addr 127.0.0.1 "
                  f"--master-port 29500 bench.py --gpus {a.gpus} [--steps K --warmup W]")
     if a.dry_run:
-        print(json.dumps({"dry_run": True, "rank": rank, "local_rank": local, "world_size": world,
-                          "master_addr": os.environ.get("MASTER_ADDR"), "master_port": os.environ.get("MASTER_PORT"),
-                          "n_gpus": a.gpus}), flush=True)
+        sys.stdout.write(json.dumps({"dry_run": True, "rank": rank, "local_rank": local, "world_size": world,
+                                     "master_addr": os.environ.get("MASTER_ADDR"), "master_port": os.environ.get("MASTER_PORT"),
+                                     "n_gpus": a.gpus}) + "\n")      # one write per rank: the ranks share the launcher's pipe
+        sys.stdout.flush()
         return
     mode = a.mode if a.mode != "auto" else ("fit" if world == 1 else "cv")
     if a.steps is None:

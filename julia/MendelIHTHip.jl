@@ -236,6 +236,7 @@ function fit_iht(y::AbstractVector{Float64}, x::HipSnpLinAlg{Float64}, z::Abstra
     q = size(zz, 2)
     (length(yy) == x.n == size(zz, 1)) || throw(DimensionMismatch("row dimension of y, x, and z ($(length(yy)), $(x.n), $(size(zz, 1))) are not equal"))
     length(zkeep) == q || throw(DimensionMismatch("zkeep must have one entry per covariate"))
+    GLM.checky(yy, d)                            # fit.jl:91: the response must suit the distribution (0 / 1 for Bernoulli, ...)
     prm, keep = make_params(x, k, J, d, l, group, weight, zkeep, est_r, use_maf, debias, tol, max_iter, min_iter,
                             max_step, init_beta, comm, xtv_digits)
     beta = zeros(x.p); c = zeros(q)

@@ -1293,6 +1293,8 @@ static int check_params(const mih_mat *h, const mih_fit_params *prm, int64_t q)
     if (h->kind == 0 && !h->center) { set_error("x is not centered! Please construct SnpLinAlg{Float64}(::SnpArray, center=true, scale=true)"); return MIH_NOT_CENTERED; }
     if (prm->est_r != MIH_ESTR_NONE && prm->dist != MIH_NEGBIN) { set_error("Only negative binomial regression currently supports nuisance parameter estimation"); return MIH_BAD_ARG; }
     if (!prm->ks && prm->k < 0) { set_error("Value of k (max predictors per group) must be nonnegative!"); return MIH_BAD_ARG; }
+    if (prm->ks) for (int64_t g = 0; g < prm->nks; ++g)                 // fit.jl:87 for a vector k: the same bound on every entry
+        if (prm->ks[g] < 0) { set_error("Value of k (max predictors per group) must be nonnegative!"); return MIH_BAD_ARG; }
     if (q < 1 || q > kMaxQ) { set_error("number of covariates q=%lld must be in 1..%d", (long long)q, kMaxQ); return MIH_BAD_DIM; }
     if (prm->dist < 0 || prm->dist > MIH_INVGAUSS || prm->link < 0 || prm->link > MIH_SQRT) { set_error("unknown distribution/link"); return MIH_BAD_ARG; }
     return MIH_OK;

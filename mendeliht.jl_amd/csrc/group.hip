@@ -225,6 +225,8 @@ extern "C" int mih_project_group_sparse(double *y, const int64_t *group, int64_t
         if (group[i] < 1) { set_error("group labels must be 1..G"); return MIH_BAD_ARG; }
         if (group[i] > G) G = group[i];
     }
+    for (int64_t g = 0; g < (k_is_vector ? G : 1); ++g)
+        if (k[g] < 0) { set_error("project_group_sparse!: the number of predictors per group must be nonnegative"); return MIH_BAD_ARG; }
     DevBuf<double> dy; DevBuf<int64_t> dg, dk;
     MIH_TRY(dy.alloc(len)); MIH_TRY(dg.alloc(len)); MIH_TRY(dk.alloc(k_is_vector ? G : 1));
     MIH_HIP(hipMemcpy(dy.p, y, sizeof(double) * len, hipMemcpyHostToDevice));

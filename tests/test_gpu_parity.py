@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import FIX, GOLD, hash_folds, make_bed
+from conftest import FIX, GOLD, ROOT, hash_folds, make_bed
 
 pytestmark = pytest.mark.gpu
 
@@ -1735,6 +1735,18 @@ def test_more_ranks_than_work_items(mih):
     assert np.array_equal(sum(pp), ll)
     with pytest.raises(mih.MendelIHTError, match="no training samples"):
         mih.cv_iht(y, x, None, path=[1], q=2, folds=np.ones(n, dtype=np.int32), verbose=False)      # every sample in fold 1: nothing to train fold 1's model on
+
+
+def test_c_abi_refuses_bad_arguments_without_crashing(mih):
+    """85 calls with bad arguments straight at the C ABI (tools/abi_edge_probe.py, in a child process so that a crash would be
+    seen as one): NULL pointers, zero / negative / oversized dimensions, out-of-range indices, labels, folds, ranks, unknown
+    codes -- every one comes back with a status and a message, two documented ones are accepted, and the library fits a model
+    afterwards."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "abi_edge_probe.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "probe finished" in r.stdout and "ACCEPTED: []" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count(": rc=") >= 80
 
 
 def test_xtv_accuracy_against_exact_rational_arithmetic(mih):
