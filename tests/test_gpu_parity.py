@@ -1749,6 +1749,51 @@ def test_c_abi_refuses_bad_arguments_without_crashing(mih):
     assert r.stdout.count(": rc=") >= 80
 
 
+def test_mirror_accepts_any_array_layout(mih):
+    """The host mirror hands the library contiguous Float64 / Int64 / UInt8 buffers whatever it is given: C- or Fortran-ordered
+    and strided covariates, strided / list / column-vector responses, genotype columns out of a strided view, paths as ranges
+    or Int32 arrays, folds as lists or floats, weights, groups and train masks in other dtypes -- always the same model, bit
+    for bit (a C-ordered z read as column-major would be a silently different design)."""
+    rng = np.random.default_rng(0)
+    n, p = 500, 150
+    cols = make_bed(rng, n, p)
+    x = mih.SnpLinAlg(cols, n=n, center=True, scale=True, impute=True)
+    z = np.column_stack([np.ones(n), rng.standard_normal(n), rng.standard_normal(n)])
+    y = rng.standard_normal(n) + 0.5 * z[:, 1]
+    base = mih.fit_iht(y, x, np.asfortranarray(z), k=4, verbose=False)
+    assert base.c[1] == pytest.approx(0.5, abs=0.15)                       # the covariate was read as the covariate
+    same = lambda res, ref=base: np.array_equal(res.beta, ref.beta) and np.array_equal(res.c, ref.c)
+    big = np.zeros((n, 6)); big[:, ::2] = z
+    yy = np.zeros(2 * n); yy[::2] = y
+    cols_big = np.zeros((p, cols.shape[1] * 2), dtype=np.uint8); cols_big[:, ::2] = cols
+    x2 = mih.SnpLinAlg(cols_big[:, ::2], n=n, center=True, scale=True, impute=True)
+    for name, res in (("z C-order", mih.fit_iht(y, x, np.ascontiguousarray(z), k=4, verbose=False)),
+                      ("z strided", mih.fit_iht(y, x, big[:, ::2], k=4, verbose=False)),
+                      ("z nested lists", mih.fit_iht(y, x, z.tolist(), k=4, verbose=False)),
+                      ("y strided", mih.fit_iht(yy[::2], x, z, k=4, verbose=False)),
+                      ("y list", mih.fit_iht(y.tolist(), x, z, k=4, verbose=False)),
+                      ("y column vector", mih.fit_iht(y.reshape(-1, 1), x, z, k=4, verbose=False)),
+                      ("strided genotype columns", mih.fit_iht(y, x2, z, k=4, verbose=False))):
+        assert same(res), name
+    folds = hash_folds(n, 3)
+    a = mih.cv_iht(y, x, z, path=[1, 2, 3], q=3, folds=folds, verbose=False)
+    assert np.array_equal(a, mih.cv_iht(y, x, z, path=range(1, 4), q=3, folds=folds.astype(np.int64).tolist(), verbose=False))
+    assert np.array_equal(a, mih.cv_iht(y, x, z, path=np.array([1, 2, 3], dtype=np.int32), q=3, folds=folds.astype(np.float64), verbose=False))
+    Y = np.vstack([y, rng.standard_normal(n)])
+    m1 = mih.fit_iht(Y, x, z.T.copy(), k=4, verbose=False)
+    assert np.array_equal(m1.beta, mih.fit_iht(np.asfortranarray(Y), x, np.asfortranarray(z.T), k=4, verbose=False).beta)
+    assert np.array_equal(m1.beta, mih.fit_iht(np.ascontiguousarray(Y), x, np.ascontiguousarray(z.T), k=4, verbose=False).beta)
+    w = rng.uniform(0.5, 2, p); wbig = np.zeros(2 * p); wbig[::2] = w
+    w1 = mih.fit_iht(y, x, z, k=4, weight=w, verbose=False)
+    assert same(mih.fit_iht(y, x, z, k=4, weight=wbig[::2], verbose=False), w1) and same(mih.fit_iht(y, x, z, k=4, weight=w.tolist(), verbose=False), w1)
+    g = (np.arange(p) % 5 + 1)
+    g1 = mih.fit_iht(y, x, z, k=2, J=2, group=g, verbose=False)
+    assert same(mih.fit_iht(y, x, z, k=2, J=2, group=g.astype(np.int32), verbose=False), g1) and same(mih.fit_iht(y, x, z, k=2, J=2, group=g.tolist(), verbose=False), g1)
+    t = rng.random(n) < 0.8
+    t1 = mih.fit_iht(y, x, z, k=4, train=t, verbose=False)
+    assert same(mih.fit_iht(y, x, z, k=4, train=t.astype(np.uint8), verbose=False), t1) and same(mih.fit_iht(y, x, z, k=4, train=t.astype(np.int64), verbose=False), t1)
+
+
 def test_xtv_accuracy_against_exact_rational_arithmetic(mih):
     """The fixed-point X'r against EXACT dot products (Python rationals) of the raw dosages: the only rounding is that
     of the residual to 2^-55 max|r| (2^-58 in the base-13 format) plus the recombination in f64, so the error stays
