@@ -52,7 +52,7 @@ typedef struct mih_mat mih_mat;     /* device-resident design matrix */
 int mih_device_count(int *count);
 /* thread-local message of the last failing call on this host thread */
 int mih_last_error(char *buf, size_t len);
-int mih_version(int *major, int *minor);     /* 0.3: round 3 of this header (per-call residual format, per-handle measurement hook) */
+int mih_version(int *major, int *minor);     /* 0.4: round 4 of this header (cv_threads, mih_cv_allgather, column-sharded lock-step drivers) */
 /* sizeof(mih_fit_params), sizeof(mih_fit_result), sizeof(mih_mv_result), sizeof(mih_comm): lets a binding
  * check its struct mirrors against the library it loaded. */
 int mih_abi_sizes(int64_t *sizes, int32_t n);
@@ -211,6 +211,15 @@ typedef struct mih_fit_params {
      * task-local RNGs there) and by column-sharded fits (comm != NULL). */
     int (*choose)(void *user, int32_t kind, const int64_t *list, int64_t n, int64_t excess, int64_t *out);
     void    *choose_user;
+    /* mih_cv_iht with est_r != MIH_ESTR_NONE only.  The reference keeps one IHTVariable per Julia thread and re-uses it for every
+     * (fold, k) combination `Threads.@threads :static` hands that thread (cross_validation.jl:91,100-110): the NegBin r left by
+     * one fit is where the thread's next fit starts, so the losses depend on JULIA_NUM_THREADS.  cv_threads = that number: the
+     * fold-major combinations are cut into cv_threads contiguous blocks (the first total % cv_threads one longer, as :static
+     * does), each block is a chain of fits handing r on, and the chains advance in lock-step.  0 = nfolds (one chain per fold
+     * when nfolds divides nfolds * npath, i.e. always for a full grid); 1 = the single-thread order.  With world > 1 chain c is
+     * evaluated by rank c mod world (mih_cv_assignment does not apply).  Ignored without est_r: those fits are independent. */
+    int32_t  cv_threads;
+    int32_t  reserved0;
 } mih_fit_params;
 enum { MIH_CHOOSE_SAMPLE = 0, MIH_CHOOSE_SHUFFLE_B = 1, MIH_CHOOSE_SHUFFLE_C = 2 };
 
@@ -256,16 +265,18 @@ int mih_cv_meanloss(const double *mses_raw, const int32_t *folds, int64_t n, int
                     int64_t npath, double *mse_out);
 /* iht_run_many_models(y, x, z; path, ...) src/cross_validation.jl:232-273: fit_iht on the FULL data for every
  * model size in path (no hold-out).  The fits advance in lock-step like the cross-validation fits (one fused
- * multi-RHS X'r pass per round).  Entries with index % world == rank are fitted; logl_out[npath] (others 0),
- * and optionally iter_out[npath], beta_out[npath*p], c_out[npath*q] (may be NULL). */
+ * multi-RHS X'r pass per round), est_r included (every fit starts from prm->nb_r, as each fit_iht call of the reference builds
+ * its own IHTVariable, :254-258).  Entry i is fitted by rank mih_cv_assignment(path, npath, 1, world)[i] (largest models first,
+ * round-robin); logl_out[npath] (others 0), and optionally iter_out[npath], beta_out[npath*p], c_out[npath*q] (may be NULL). */
 int mih_fit_iht_path(const mih_mat *h, const mih_fit_params *prm, const double *y, const double *z,
                      int64_t q, const int64_t *path, int64_t npath, int32_t rank, int32_t world,
                      double *logl_out, int64_t *iter_out, double *beta_out, double *c_out);
 /* The same cross-validation driven from ONE process over several GPUs, the way the reference drives it
  * from several threads of one Julia process (Threads.@threads over the (fold,k) combinations on a shared x,
  * cross_validation.jl:100-112): hs[g] is a replica of the matrix on GPU g (they may also share a device),
- * one host thread per replica evaluates the combinations with index % nrep == g, and mses_raw receives the
- * complete nfolds x npath matrix (no separate reduction step). */
+ * one host thread per replica runs mih_cv_iht(hs[g], ..., rank = g, world = nrep) -- the combinations mih_cv_assignment gives
+ * to g, or with est_r the chains c with c mod nrep == g -- and mses_raw receives the complete nfolds x npath matrix (no
+ * separate reduction step). */
 int mih_cv_iht_multi(const mih_mat *const *hs, int32_t nrep, const mih_fit_params *prm, const double *y,
                      const double *z, int64_t q, const int32_t *folds, int32_t nfolds,
                      const int64_t *path, int64_t npath, double *mses_raw);
@@ -324,9 +335,10 @@ enum { MIH_CNT_LANES = 0,          /* lock-step lanes started (summed over calls
        MIH_CNT_SHARED_INIT = 3,    /* fits that started from another fit's initial score */
        MIH_CNT_ROUNDS = 4,         /* lock-step rounds */
        MIH_CNT_FITS = 5,           /* fits completed by the lock-step drivers */
-       MIH_CNT_SCORES = 6,         /* residual scores (= IHT iterations incl. the initial score) those fits asked for */
+       MIH_CNT_SCORES = 6,         /* residual scores that END A STEP (= IHT iterations as fit.jl counts them) of those fits */
        MIH_CNT_MAX_LANE_SLOTS = 7, /* most fits in flight on ONE lane */
-       MIH_PROFILE_NCOUNTERS = 8 };
+       MIH_CNT_INIT_SCORES = 8,    /* initial scores (init_iht_indices!, one per fit): rode a pass or were served by a copy */
+       MIH_PROFILE_NCOUNTERS = 9 };
 int mih_profile_enable(const mih_mat *h, int on);
 /* synchronises the recorded launches; totals since the last reset */
 int mih_profile_read(const mih_mat *h, double *xtv_kernel_ms, int64_t *xtv_launches, int reset);

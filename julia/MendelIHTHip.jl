@@ -115,6 +115,8 @@ struct MihFitParams
     debias::Int32
     xtv_digits::Int32     # fixed-point format of the residual in this call's X'r passes (0 = library default)
     choose::Ptr{Cvoid}; choose_user::Ptr{Cvoid}       # the RNG draw of _choose! (choose_cb below)
+    cv_threads::Int32     # cv_iht with est_r: the Threads.nthreads() whose :static chains of v.d the library follows (0 = q)
+    reserved0::Int32
 end
 # mih_comm: exchange callbacks of a column-sharded fit (one Julia process per GPU, e.g. under mpiexec)
 struct MihComm
@@ -194,7 +196,7 @@ struct ParamKeep
     zk::Vector{UInt8}; w::Vector{Float64}; g::Vector{Int64}; ks::Vector{Int64}
 end
 function make_params(x::HipSnpLinAlg, k, J, d, l, group, weight, zkeep, est_r, use_maf, debias, tol,
-                     max_iter, min_iter, max_step, init_beta, comm, xtv_digits=0)
+                     max_iter, min_iter, max_step, init_beta, comm, xtv_digits=0, cv_threads=0)
     J >= 0 || throw(ArgumentError("Value of J (max number of groups) must be nonnegative!"))
     max_iter >= 0 || throw(ArgumentError("Value of max_iter must be nonnegative!"))
     max_step >= 0 || throw(ArgumentError("Value of max_step must be nonnegative!"))
@@ -216,7 +218,7 @@ function make_params(x::HipSnpLinAlg, k, J, d, l, group, weight, zkeep, est_r, u
         isempty(keep.w) ? Ptr{Float64}(C_NULL) : pointer(keep.w),
         isempty(keep.g) ? Ptr{Int64}(C_NULL) : pointer(keep.g),
         isempty(keep.ks) ? Ptr{Int64}(C_NULL) : pointer(keep.ks), length(keep.ks),
-        C_NULL, C_NULL, Int32(init_beta), comm, Int32(debias), Int32(xtv_digits), choose_ptr(), C_NULL)
+        C_NULL, C_NULL, Int32(init_beta), comm, Int32(debias), Int32(xtv_digits), choose_ptr(), C_NULL, Int32(cv_threads), Int32(0))
     return prm, keep
 end
 
@@ -309,7 +311,9 @@ function cv_iht(y::AbstractVector{Float64}, x::HipSnpLinAlg{Float64}, z::Abstrac
         zkeep::BitVector=trues(size(z, 2)), folds::AbstractVector{Int}=rand(1:q, size(x, 1)), debias::Bool=false,
         verbose::Bool=true, max_iter::Int=100, min_iter::Int=5, init_beta::Bool=false, memory_efficient::Bool=true,
         rank::Int=0, world::Int=1, reduce=identity,       # reduce: sums the raw loss matrix over the ranks (e.g. MPI.Allreduce)
-        xtv_digits::Int=0)
+        xtv_digits::Int=0,
+        cv_threads::Int=Threads.nthreads())      # est_r only: the reference hands v.d (the NegBin r) from one fit of a thread to that
+                                                 # thread's next one (cross_validation.jl:91,100-110); the library follows the same chains
     memory_efficient || throw(ArgumentError("the GPU path is always memory_efficient=true"))
     maximum(path) > x.p && error("Sparsity level in `path` cannot be larger than total number of variables")
     yy = Vector{Float64}(y); zz = dense_z(z)
@@ -317,7 +321,7 @@ function cv_iht(y::AbstractVector{Float64}, x::HipSnpLinAlg{Float64}, z::Abstrac
     f32 = Vector{Int32}(folds); pth = Vector{Int64}(path)
     raw = zeros(q * length(pth)); mse = zeros(length(pth))
     prm, keep = make_params(x, 1, 1, d, l, group, weight, zkeep, est_r, false, debias, 1e-4, max_iter, min_iter, 3,
-                            init_beta, C_NULL, xtv_digits)
+                            init_beta, C_NULL, xtv_digits, cv_threads)
     GC.@preserve keep yy zz f32 pth raw begin
         check(ccall((:mih_cv_iht, LIB), Cint,
             (Ptr{Cvoid}, Ref{MihFitParams}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Int32}, Int32, Ptr{Int64},

@@ -58,7 +58,7 @@ class _FitParams(C.Structure):
                 ("zkeep", C.c_void_p), ("weight", C.c_void_p), ("group", C.c_void_p), ("ks", C.c_void_p),
                 ("nks", C.c_int64), ("progress", C.c_void_p), ("progress_user", C.c_void_p),
                 ("init_beta", C.c_int32), ("comm", C.c_void_p), ("debias", C.c_int32), ("xtv_digits", C.c_int32),
-                ("choose", C.c_void_p), ("choose_user", C.c_void_p)]
+                ("choose", C.c_void_p), ("choose_user", C.c_void_p), ("cv_threads", C.c_int32), ("reserved0", C.c_int32)]
 
 
 class _Comm(C.Structure):
@@ -114,7 +114,7 @@ class _PassRecord(C.Structure):
                 ("stream_tag", C.c_int32), ("reserved", C.c_int32), ("kernel", C.c_char * 48)]
 
 
-PROFILE_COUNTERS = ("lanes", "max_in_flight", "handovers", "shared_init", "rounds", "fits", "scores", "max_lane_slots")
+PROFILE_COUNTERS = ("lanes", "max_in_flight", "handovers", "shared_init", "rounds", "fits", "scores", "max_lane_slots", "init_scores")
 
 _PROGRESS = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double)
 
@@ -956,7 +956,8 @@ def _fit_mv(Y, x, Z, k, d, l, zkeep, verbose, tol, max_iter, min_iter, max_step,
 
 def cv_iht(y, x, z=None, *, d=None, l=None, path=range(1, 21), q=5, est_r="None", group=None, weight=None,
            zkeep=None, folds=None, debias=False, verbose=True, max_iter=100, min_iter=5, init_beta=False,
-           memory_efficient=True, tol=1e-4, max_step=3, rank=0, world=1, reduce=None, return_raw=False, xtv_digits=None):
+           memory_efficient=True, tol=1e-4, max_step=3, rank=0, world=1, reduce=None, return_raw=False, xtv_digits=None,
+           cv_threads=0):
     """cv_iht(y, x, z; path, q, folds, ...) -- src/cross_validation.jl:60-131.
 
     `x` may be a list of replicas of the matrix (one per GPU): the combinations are then spread over them
@@ -964,6 +965,9 @@ def cv_iht(y, x, z=None, *, d=None, l=None, path=range(1, 21), q=5, est_r="None"
     `rank`/`world` shard the (fold, k) combinations over processes (one GPU each); `reduce`
     is a callable that sum-reduces the raw q x len(path) loss matrix across ranks (see
     mendeliht.jl_amd.dist.cv_iht_distributed for the torch.distributed/RCCL version).
+    `cv_threads` (est_r only): the reference re-uses one IHTVariable per Julia thread, so the NegBin r of one fit is the starting
+    value of that thread's next fit (cross_validation.jl:91,100-110) and its losses depend on Threads.nthreads(); the library
+    follows the chains of `cv_threads` threads in lock-step (0 = q threads: one chain per fold; 1 = the single-thread order).
     """
     replicas = None
     if isinstance(x, (list, tuple)):                 # one replica of the matrix per GPU, driven from this process
@@ -1016,6 +1020,7 @@ def cv_iht(y, x, z=None, *, d=None, l=None, path=range(1, 21), q=5, est_r="None"
         _checky(yv, d)
         prm = _params(1, 1, d, l, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, zz.shape[1], x.p, keep,
                       init_beta=init_beta, debias=debias, xtv_digits=xtv_digits)
+        prm.cv_threads = int(cv_threads)
         if replicas is not None:
             hs = (C.c_void_p * len(replicas))(*[r._h for r in replicas])
             _check(lib().mih_cv_iht_multi(hs, len(replicas), C.byref(prm), _p(yv), _p(zz), zz.shape[1], _p(folds), q,

@@ -1,6 +1,7 @@
 // common.h -- internal declarations shared by the HIP translation units.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <chrono>
 #include <map>
 #include <mutex>
@@ -275,7 +276,7 @@ namespace mih {
 struct PassRecord { hipEvent_t e0 = nullptr, e1 = nullptr; int residuals = 0, operands = 0, stream_tag = 0; char kernel[48] = {0}; };
 struct Profile {
     std::mutex mu;
-    bool on = false;
+    std::atomic<bool> on{false};                 // read by the lanes' threads without the mutex
     hipEvent_t origin = nullptr;                 // recorded when profiling was switched on: start offsets are relative to it
     std::vector<PassRecord> open;                // launches whose events have not been read yet
     std::vector<mih_pass_record> done;

@@ -1141,9 +1141,8 @@ struct IhtVar {
     int nb_sums(int which, double rr, double *out2)
     {
         hipLaunchKernelGGL(k_nb_sums, dim3(nb), dim3(256), 0, s, y.p, mu.p, n, rr, which, red.p);
-        hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, s, red.p, nb, 2, scal.p);
-        MIH_HIP(hipMemcpyAsync(out2, scal.p, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
-        MIH_HIP(hipStreamSynchronize(s));
+        MIH_TRY(final_sum_home(2, scal.p, scal.p, 2));       // (in a lock-step lane the other fits go on while this comes home)
+        out2[0] = hpin.p[0]; out2[1] = hpin.p[1];
         return MIH_OK;
     }
     int mle_for_r()
@@ -1289,6 +1288,7 @@ static int check_params(const mih_mat *h, const mih_fit_params *prm, int64_t q)
     if (prm->J < 0) { set_error("Value of J (max number of groups) must be nonnegative!"); return MIH_BAD_ARG; }
     if (prm->max_iter < 0) { set_error("Value of max_iter must be nonnegative!"); return MIH_BAD_ARG; }
     if (prm->max_step < 0) { set_error("Value of max_step must be nonnegative!"); return MIH_BAD_ARG; }
+    if (prm->cv_threads < 0) { set_error("cv_threads must be nonnegative (0 = one chain per fold)"); return MIH_BAD_ARG; }
     if (!(prm->tol > 2.220446049250313e-16)) { set_error("Value of global tol must exceed machine precision!"); return MIH_BAD_ARG; }
     if (h->kind == 0 && !h->center) { set_error("x is not centered! Please construct SnpLinAlg{Float64}(::SnpArray, center=true, scale=true)"); return MIH_NOT_CENTERED; }
     if (prm->est_r != MIH_ESTR_NONE && prm->dist != MIH_NEGBIN) { set_error("Only negative binomial regression currently supports nuisance parameter estimation"); return MIH_BAD_ARG; }
@@ -1357,6 +1357,8 @@ struct CvFit {
     int iter = 1, nbt = 0;
     double next_logl = -std::numeric_limits<double>::infinity(), best = -std::numeric_limits<double>::infinity();
     bool done = false;
+    // est_r in cv_iht: this fit is number chain_pos of chain `chain` (CvChains); when it ends it leaves its NegBin r in *chain_r
+    int64_t chain = -1; size_t chain_pos = 0; double *chain_r = nullptr;
     // iht_run_many_models mode (no hold-out): where to put the finished model instead of a held-out deviance
     bool full_data = false;
     double *logl_out = nullptr; int64_t *iter_out = nullptr; double *beta_out = nullptr, *c_out = nullptr;
@@ -1385,6 +1387,7 @@ static int cv_finish(CvFit &f, double *mses_raw)
 {
     f.best = f.v->save_prev(f.next_logl, f.best);
     MIH_TRY(f.v->save_best_model());
+    if (f.chain_r) *f.chain_r = f.v->nb_r;             // v.d stays as the last mle_for_r left it (cross_validation.jl:91,110)
     if (f.full_data) {                                 // iht_run_many_models: the fitted model itself is the result
         if (f.logl_out) *f.logl_out = f.best;
         if (f.iter_out) *f.iter_out = f.iter;
@@ -1440,6 +1443,17 @@ struct CvShared {                 // what a lane shares with its fits
 };
 using MakeFit = std::function<int(size_t, CvFit &, hipStream_t, const CvShared &)>;
 
+// est_r != :None in cv_iht.  The reference builds ONE IHTVariable per Julia thread and re-uses it for every (fold, k) combination
+// the thread is given (cross_validation.jl:91,103,110); init_iht_indices! resets everything but v.d, so the NegBin r that
+// mle_for_r left at the end of one fit is the starting value of the thread's next fit.  `Threads.@threads :static` gives thread t
+// a contiguous block of the fold-major combinations, so the fits form one CHAIN per thread: the chains are independent of each
+// other and advance in lock-step (the queue hands out chains instead of fits; a slot that finishes a fit starts the next fit of
+// its chain), the fits of a chain run one after the other.
+struct CvChains {
+    std::vector<std::vector<size_t>> fits;       // fits[c]: the fit numbers (arguments of make) of chain c in the thread's order
+    std::vector<double> r;                       // r[c]: what the chain's next fit starts from
+};
+
 // Tail of the queue: once no new fits are left, the fits of both lanes thin out and two half-empty fused passes cost far more
 // than one fuller pass (6 + 6 residuals: 2 x 20.9 ms, 12 in one pass: 31.6 ms).  Lane 1 therefore hands ALL its fits over to
 // lane 0 as soon as they fit into lane 0's free slots, and ends.  A fit is handed over between two rounds, when everything it
@@ -1454,8 +1468,11 @@ struct CvHandover {
 static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t total, std::atomic<size_t> &next, int cap,
                           const MakeFit &make, XtvWork &xw, DevBuf<double> &R,
                           DevBuf<double> &DF /* (cap + init_slots) x p */, hipStream_t s, double *mses_raw, CvHandover *ho = nullptr, int lane_id = 0,
-                          int init_slots = 0, const CvShared &shared = CvShared(), std::atomic<int> *inflight = nullptr)
+                          int init_slots = 0, const CvShared &shared = CvShared(), std::atomic<int> *inflight = nullptr,
+                          CvChains *chains = nullptr /* total = number of chains */)
 {
+    std::vector<int64_t> cont_chain((size_t)cap, -1);     // the chain a free slot goes on with, and the position of its next fit
+    std::vector<size_t> cont_pos((size_t)cap, 0);
     std::vector<std::unique_ptr<IhtVar>> pool;            // declared before the slots: outlives them
     std::vector<std::unique_ptr<CvFit>> slot((size_t)cap);
     std::vector<CvFit *> need, riders;
@@ -1490,14 +1507,24 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
     auto slot_pre = [&](int t) -> int {
         for (;;) {
             if (!slot[t]) {
-                if (drained) return MIH_OK;
-                const size_t i = next.fetch_add(1);
-                if (i >= total) { drained = true; return MIH_OK; }
+                size_t i; int64_t ch = -1;
+                if (chains && cont_chain[(size_t)t] >= 0) { ch = cont_chain[(size_t)t]; i = chains->fits[(size_t)ch][cont_pos[(size_t)t]]; }
+                else {
+                    if (drained) return MIH_OK;
+                    i = next.fetch_add(1);
+                    if (i >= total) { drained = true; return MIH_OK; }
+                    if (chains) { ch = (int64_t)i; cont_pos[(size_t)t] = 0; i = chains->fits[(size_t)ch][0]; }
+                }
                 slot[t].reset(new CvFit());
                 slot[t]->pool = &pool;
                 if (!pool.empty()) { slot[t]->v = std::move(pool.back()); pool.pop_back(); }
                 MIH_TRY(make(i, *slot[t], s, shared));
                 CvFit &f = *slot[t];
+                if (chains) {
+                    f.chain = ch; f.chain_pos = cont_pos[(size_t)t]; f.chain_r = &chains->r[(size_t)ch];
+                    f.v->nb_r = chains->r[(size_t)ch];
+                    cont_chain[(size_t)t] = -1;
+                }
                 MIH_TRY(f.v->init_pre(f.train));
                 if (share_init && f.init_key >= 0) {
                     auto it = df0.find(f.init_key);
@@ -1505,7 +1532,7 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
                         MIH_HIP(hipMemcpyAsync(f.v->df.p, it->second, sizeof(double) * h->p, hipMemcpyDeviceToDevice, f.v->s));    // (written on the lane's stream rounds ago)
                         MIH_TRY(f.v->init_post());
                         h->prof->count(MIH_CNT_SHARED_INIT, 1);
-                        h->prof->count(MIH_CNT_SCORES, 1);          // its initial score, served by a copy
+                        h->prof->count(MIH_CNT_INIT_SCORES, 1);     // its initial score, served by a copy
                         continue;
                     }
                 }
@@ -1514,7 +1541,12 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
             }
             CvFit &f = *slot[t];
             if (!f.done && f.iter >= pr.max_iter) MIH_TRY(cv_finish(f, mses_raw));        // fit.jl:170-179
-            if (f.done) { slot[t].reset(); continue; }                                    // refill this slot
+            if (f.done) {                                                                 // refill this slot
+                if (chains && f.chain >= 0 && f.chain_pos + 1 < chains->fits[(size_t)f.chain].size()) {
+                    cont_chain[(size_t)t] = f.chain; cont_pos[(size_t)t] = f.chain_pos + 1;      // ... with the next fit of its chain
+                }
+                slot[t].reset(); continue;
+            }
             f.best = f.v->save_prev(f.next_logl, f.best);
             MIH_TRY(f.v->step_pre(f.next_logl, pr.max_step, &f.nbt, &f.next_logl));
             outs[(size_t)t] = SlotOut{&f, 0};
@@ -1553,7 +1585,9 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
             if (mine > 0 && ho->accepting && mine + ho->active0.load() <= cap) {
                 //  a handed-over fit is quiescent: if it ran on this lane's stream it forgets it -- the stream is destroyed
                 // when the lane returns, and an orphan that is never adopted (lane 0 failed) must not synchronise a dead stream
-                for (auto &sl : slot) if (sl) { sl->pool = nullptr; if (!sl->v->ev) sl->v->s = nullptr; ho->orphans.push_back(std::move(sl)); }
+                //  ... and the lane's cache of the initialize_beta! regressions, which lives on this lane's stack (the fit
+                // is past init_beta_phase; make() re-points a recycled IHTVariable)
+                for (auto &sl : slot) if (sl) { sl->pool = nullptr; if (!sl->v->ev) sl->v->s = nullptr; sl->v->ib_shared = nullptr; sl->v->ib_key = -1; ho->orphans.push_back(std::move(sl)); }
                 ho->active0.fetch_add(mine);
                 h->prof->count(MIH_CNT_HANDOVERS, 1);
                 if (inflight) inflight[lane_id].store(0);
@@ -1598,7 +1632,12 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
             h->prof->count_max(MIH_CNT_MAX_LANE_SLOTS, mine_now);
             if (inflight) { inflight[lane_id].store(mine_now); h->prof->count_max(MIH_CNT_MAX_IN_FLIGHT, inflight[0].load() + inflight[1].load()); }
             else h->prof->count_max(MIH_CNT_MAX_IN_FLIGHT, mine_now);
-            h->prof->count(MIH_CNT_SCORES, (int64_t)need.size());
+            //  an IHT iteration is a STEP's score (fit.jl counts no iteration for init_iht_indices!'s score): the initial
+            // scores -- most of them served by a copy -- are counted on their own
+            int64_t nfresh = 0;
+            for (char fr : fresh) nfresh += fr != 0;
+            h->prof->count(MIH_CNT_SCORES, (int64_t)need.size() - nfresh);
+            h->prof->count(MIH_CNT_INIT_SCORES, nfresh);
         }
         MIH_TRY(cv_batched_xtv(h, xw, riders, R, DF, s));
         for (auto &o : owners) MIH_HIP(hipMemcpyAsync(o.second, o.first->v->df.p, sizeof(double) * h->p, hipMemcpyDeviceToDevice, s));
@@ -1622,8 +1661,9 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
 // queue: while one lane's host thread walks the small per-fit kernel chains between two passes (about 0.5 ms per
 // fit and round), the other lane's fused pass keeps the GPU busy.  Every fit is independent of the lane it runs in.
 static int cv_run_lanes(const mih_mat *h, const mih_fit_params &pr, size_t total, const MakeFit &make, double *mses_raw, int init_keys,
-                        const double *y_host, const double *z_host, int64_t q)
+                        const double *y_host, const double *z_host, int64_t q, CvChains *chains = nullptr)
 {
+    if (chains) total = chains->fits.size();               // the queue hands out chains
     const XtvTune tune = xtv_tune(&pr);
     if (!xtv_digits_valid(tune.digits)) { set_error("residual format must be 0 (default), 4910, 4908, 1316, 1308 or 428"); return MIH_BAD_ARG; }
     const int width = xtv_lockstep_width(h, tune);
@@ -1634,7 +1674,7 @@ static int cv_run_lanes(const mih_mat *h, const mih_fit_params &pr, size_t total
     CvHandover handover;
     std::atomic<int> inflight[2];
     inflight[0].store(0); inflight[1].store(0);
-    const bool merge_tail = lanes == 2 && !probe_env("MENDELIHT_CV_NO_MERGE");
+    const bool merge_tail = lanes == 2 && !chains && !probe_env("MENDELIHT_CV_NO_MERGE");     // (a chain stays with its lane)
     std::vector<DevBuf<double>> yds((size_t)lanes), zds((size_t)lanes);
     auto lane = [&](int lane_id) -> int {
         PoolScope from_reserve(h->pool);                        // workspaces and IHTVariables out of the matrix's reserve (no hipMalloc)
@@ -1664,7 +1704,7 @@ static int cv_run_lanes(const mih_mat *h, const mih_fit_params &pr, size_t total
                 hipStream_t ws = worker_stream(h, (lane_id % 2) * kWorkerStreamsPerLane + i);
                 if (ws) shared.streams.push_back(ws);
             }
-        return cv_run_rolling(h, pr, total, next, cap, make, xw, R, DF, s, mses_raw, merge_tail ? &handover : nullptr, lane_id, init_slots, shared, lanes == 2 ? inflight : nullptr);
+        return cv_run_rolling(h, pr, total, next, cap, make, xw, R, DF, s, mses_raw, merge_tail ? &handover : nullptr, lane_id, init_slots, shared, lanes == 2 ? inflight : nullptr, chains);
     };
     if (lanes == 1) return lane(0);
     std::vector<int> rcs((size_t)lanes, MIH_OK);
@@ -1737,32 +1777,6 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, con
     std::vector<int32_t> rank_of;
     cv_assign(path, npath, nfolds, world, rank_of);
 
-    if (prm->est_r != MIH_ESTR_NONE) {
-        // the NegBin nuisance parameter is carried from one fit to the next in the reference (v.d is never reset,
-        // cross_validation.jl:91,110): keep the sequential order for that.  init_beta and debias ride the lock-step driver since
-        // round 3: the regressions are computed once per fold and lane (IbShared), the GLM refit of a debiased step runs on the
-        // fit's own stream between its step_post and its convergence test, exactly where fit_iht! has it (fit.jl:188)
-        IhtVar v;
-        MIH_TRY(v.create(h, &pr, y, z, q));
-        std::vector<uint8_t> train(n);
-        int64_t combo = 0;
-        for (int32_t fold = 1; fold <= nfolds; ++fold)
-            for (int64_t ik = 0; ik < npath; ++ik, ++combo) {
-                if (rank_of[(size_t)combo] != rank) continue;
-                for (int64_t i = 0; i < n; ++i) train[i] = (folds[i] != fold);
-                MIH_TRY(v.set_k(path[ik]));                  // cross_validation.jl:110
-                MIH_TRY(v.init(train.data()));
-                double best; int64_t it;
-                MIH_TRY(v.fit_loop(&pr, &best, &it, nullptr, nullptr, nullptr, nullptr));
-                MIH_TRY(v.set_weights(train.data(), 1));
-                MIH_TRY(v.update_xb());
-                double dev;
-                MIH_TRY(v.mu_loglik(1, nullptr, &dev));
-                mses_raw[(int64_t)(fold - 1) * npath + ik] = dev;
-            }
-        return MIH_OK;
-    }
-
     // training masks, training-row counts and sums of y: once per fold, not once per (fold, k) fit
     std::vector<std::vector<uint8_t>> fold_train((size_t)nfolds, std::vector<uint8_t>((size_t)n));
     std::vector<int64_t> fold_count((size_t)nfolds, 0);
@@ -1785,10 +1799,31 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, con
     }
     // this rank's combinations, fold-major (cross_validation.jl:217-223), in batches
     std::vector<std::pair<int32_t, int64_t>> mine;
-    int64_t combo = 0;
-    for (int32_t fold = 1; fold <= nfolds; ++fold)
-        for (int64_t ik = 0; ik < npath; ++ik, ++combo)
-            if (rank_of[(size_t)combo] == rank) mine.emplace_back(fold, ik);
+    const bool chained = prm->est_r != MIH_ESTR_NONE;
+    CvChains chains;
+    if (!chained) {
+        int64_t combo = 0;
+        for (int32_t fold = 1; fold <= nfolds; ++fold)
+            for (int64_t ik = 0; ik < npath; ++ik, ++combo)
+                if (rank_of[(size_t)combo] == rank) mine.emplace_back(fold, ik);
+    } else {
+        // The NegBin nuisance parameter travels from one fit of a Julia thread to that thread's next fit (CvChains):
+        // `Threads.@threads :static for i in eachindex(combinations)` (cross_validation.jl:100) gives thread t of T the block
+        // [t*len + min(t, rem), ...) with len, rem = divrem(total, T).  T = mih_fit_params::cv_threads, 0 = nfolds (with
+        // nfolds | total, e.g. always for the full grid, every fold is one chain); T = 1 is the single-thread order.  A chain is
+        // evaluated whole by one rank (chain c by rank c mod world): the losses do not depend on `world`.
+        const int64_t total = (int64_t)nfolds * npath, T = prm->cv_threads > 0 ? prm->cv_threads : nfolds;
+        const int64_t len = total / T, rem = total % T;
+        int64_t c = 0;
+        for (int64_t t = 0; t < T; ++t) {
+            const int64_t lo = t * len + std::min(t, rem), cnt = len + (t < rem ? 1 : 0);
+            if (cnt == 0) continue;
+            if (c++ % world != rank) continue;
+            chains.fits.emplace_back();
+            for (int64_t i = lo; i < lo + cnt; ++i) { chains.fits.back().push_back(mine.size()); mine.emplace_back((int32_t)(i / npath) + 1, i % npath); }
+        }
+        chains.r.assign(chains.fits.size(), prm->nb_r);
+    }
     if (mine.empty()) return MIH_OK;
     auto make = [&](size_t t, CvFit &f, hipStream_t s, const CvShared &sh) -> int {
         int32_t fold = mine[t].first; int64_t ik = mine[t].second;
@@ -1801,11 +1836,11 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, con
         f.train = fold_train[(size_t)fold - 1].data();
         f.v->train_count = fold_count[(size_t)fold - 1]; f.v->train_ysum = fold_ysum[(size_t)fold - 1]; f.v->train_sums_valid = true;
         f.out_index = (int64_t)(fold - 1) * npath + ik;
-        f.init_key = fold;
+        f.init_key = chained ? -1 : fold;                  // (the initial residual of a NegBin fit depends on the r it starts from)
         f.v->ib_shared = sh.ib; f.v->ib_key = fold;        // (a recycled IHTVariable may come from the other lane: re-point it)
         return MIH_OK;
     };
-    return cv_run_lanes(h, pr, mine.size(), make, mses_raw, nfolds, y, z, q);
+    return cv_run_lanes(h, pr, mine.size(), make, mses_raw, nfolds, y, z, q, chained ? &chains : nullptr);
 }
 
 int mih_fit_iht_path(const mih_mat *h, const mih_fit_params *prm, const double *y, const double *z, int64_t q,
@@ -1828,29 +1863,14 @@ int mih_fit_iht_path(const mih_mat *h, const mih_fit_params *prm, const double *
     pr.progress = nullptr; pr.choose = nullptr;
     pr.k = kmax;                                     // IHTVariables are sized for the largest model and re-used along the path
     std::vector<int64_t> mine;
-    for (int64_t i = 0; i < npath; ++i) if (i % world == rank) mine.push_back(i);
+    std::vector<int32_t> rank_of;
+    cv_assign(path, npath, 1, world, rank_of);      // the rule of mih_cv_assignment with one fold: largest models first, round-robin
+    for (int64_t i = 0; i < npath; ++i) if (rank_of[(size_t)i] == rank) mine.push_back(i);
     if (mine.empty()) return MIH_OK;
     auto slots = [&](CvFit &f, int64_t i) {
         f.full_data = true; f.logl_out = logl_out + i; f.iter_out = iter_out ? iter_out + i : nullptr;
         f.beta_out = beta_out ? beta_out + (size_t)i * h->p : nullptr; f.c_out = c_out ? c_out + (size_t)i * q : nullptr;
     };
-    if (prm->est_r != MIH_ESTR_NONE) {      // not batched: one fit after the other
-        for (int64_t i : mine) {
-            mih_fit_params pf = pr; pf.k = path[i];
-            CvFit f; slots(f, i);
-            f.v.reset(new IhtVar());
-            MIH_TRY(f.v->create(h, &pf, y, z, q));
-            MIH_TRY(f.v->init(nullptr));
-            int64_t it = 0;
-            MIH_TRY(f.v->fit_loop(&pf, &f.best, &it, nullptr, nullptr, nullptr, nullptr));
-            // fit_loop already saved the best model: publish it
-            if (f.logl_out) *f.logl_out = f.best;
-            if (f.iter_out) *f.iter_out = it;
-            if (f.beta_out) { std::memset(f.beta_out, 0, sizeof(double) * (size_t)h->p); for (size_t t = 0; t < f.v->best_b.idx.size(); ++t) f.beta_out[f.v->best_b.idx[t]] = f.v->best_b.val[t]; }
-            if (f.c_out) for (int l = 0; l < (int)q; ++l) f.c_out[l] = f.v->best_c[l];
-        }
-        return MIH_OK;
-    }
     double ysum_all = 0.0;
     for (int64_t i = 0; i < h->n; ++i) ysum_all += y[i];                      // the order of IhtVar::init_pre's loop
     auto make = [&](size_t t, CvFit &f, hipStream_t s, const CvShared &sh) -> int {
@@ -1861,6 +1881,7 @@ int mih_fit_iht_path(const mih_mat *h, const mih_fit_params *prm, const double *
             MIH_TRY(f.v->create(h, &pr, y, z, q, s, sh.y, sh.z, sh.next_stream()));     // sized for max(path)
         }
         f.v->ib_shared = sh.ib; f.v->ib_key = 0;
+        f.v->nb_r = pr.nb_r;                               // every fit_iht of the path builds its own IHTVariable (cross_validation.jl:254-258): est_r starts from d.r
         f.v->train_count = h->n; f.v->train_ysum = ysum_all; f.v->train_sums_valid = true;      // (all rows: once per path, not once per fit)
         return f.v->set_k(path[mine[t]]);
     };

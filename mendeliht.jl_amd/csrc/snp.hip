@@ -377,7 +377,7 @@ int mih_last_error(char *buf, size_t len)
 int mih_version(int *major, int *minor)
 {
     if (major) *major = 0;
-    if (minor) *minor = 3;        // round 3: mih_fit_params::xtv_digits, mih_xtv_batched_fmt, mih_profile_* per handle, mih_cv_assignment; mih_set_* gone
+    if (minor) *minor = 4;        // round 4: mih_fit_params::cv_threads, mih_cv_allgather, MIH_CNT_INIT_SCORES; round 3: mih_fit_params::xtv_digits, mih_xtv_batched_fmt, mih_profile_* per handle, mih_cv_assignment; mih_set_* gone
     return MIH_OK;
 }
 

@@ -1185,8 +1185,16 @@ int orc_cv_iht(const orc_mat *x, const orc_params *prm, const double *y,
     orc_params pr = *prm;
     pr.choose = NULL;                                 /* the callback is for single fits (iht_oracle.h) */
     ihtvar *v = iv_create(x, &pr, y, z, q);
+    /* Threads.@threads :static (cross_validation.jl:100): thread t of T takes the contiguous block of len (+1 for the first
+     * rem threads) fold-major combinations, len, rem = divrem(total, T), with its own V[t] (cross_validation.jl:91): at the
+     * start of a block the variable is a fresh one -- init_iht_indices! resets everything else, so only v.d has to be */
+    int64_t total = (int64_t)nfolds * npath, T = prm->cv_threads > 1 ? prm->cv_threads : 1;
+    int64_t blen = total / T, brem = total % T;
     for (int32_t fold = 1; fold <= nfolds && !rc; ++fold) {
         for (int64_t ik = 0; ik < npath && !rc; ++ik) {
+            int64_t combo = (int64_t)(fold - 1) * npath + ik;
+            for (int64_t t = 0; t < T; ++t)
+                if (combo == t * blen + (t < brem ? t : brem)) { v->nb_r = prm->nb_r; break; }
             for (int64_t i = 0; i < n; ++i) train[i] = (folds[i] != fold);
             v->k = path[ik];
             rc = init_iht_indices(v, train); if (rc) break;

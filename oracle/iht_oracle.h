@@ -66,6 +66,10 @@ typedef struct orc_params {
      * list to out; kind 1 / 2: write the whole list, shuffled, to out).  NULL = deterministic rule of choose().  Single fits only. */
     int (*choose)(void *user, int32_t kind, const int64_t *list, int64_t n, int64_t excess, int64_t *out);
     void    *choose_user;
+    /* cv_iht: Threads.nthreads() of the reference run being restated.  V[threadid()] is re-used for every combination a
+     * thread gets from `Threads.@threads :static` (cross_validation.jl:91,100-110), so with est_r the NegBin r of one fit is
+     * where the thread's next fit starts.  0 or 1 = one thread (one chain over all combinations). */
+    int32_t  cv_threads;
 } orc_params;
 
 typedef struct orc_result {

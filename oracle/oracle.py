@@ -36,7 +36,7 @@ class _Params(C.Structure):
                 ("est_r", C.c_int32),
                 ("zkeep", C.c_void_p), ("weight", C.c_void_p), ("group", C.c_void_p),
                 ("ks", C.c_void_p), ("nks", C.c_int64), ("init_beta", C.c_int32), ("debias", C.c_int32),
-                ("choose", C.c_void_p), ("choose_user", C.c_void_p)]
+                ("choose", C.c_void_p), ("choose_user", C.c_void_p), ("cv_threads", C.c_int32)]
 
 
 _CHOOSE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.c_int64, C.c_int64, C.POINTER(C.c_int64))
@@ -287,10 +287,12 @@ def fit_iht(x, y, z=None, k=10, J=1, dist="normal", link="identity", nb_r=1.0, t
 
 def cv_iht(x, y, z=None, path=range(1, 21), q=5, folds=None, dist="normal", link="identity", nb_r=1.0,
            tol=1e-4, max_iter=100, min_iter=5, max_step=3, est_r=None, zkeep=None, weight=None,
-           group=None, J=1, init_beta=False, debias=False):
+           group=None, J=1, init_beta=False, debias=False, cv_threads=1):
+    """cv_threads: Threads.nthreads() of the reference run (matters with est_r only: iht_oracle.h)."""
     keep = []
     prm = _params(1, J, dist, link, nb_r, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, keep, init_beta,
                   debias)
+    prm.cv_threads = int(cv_threads)
     y = np.ascontiguousarray(y, dtype=np.float64)
     z = _z(z, x.n)
     folds = np.ascontiguousarray(folds, dtype=np.int32)

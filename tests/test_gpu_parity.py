@@ -664,6 +664,53 @@ def test_negbin_nuisance_estimation(mih, oracle, normal_pair, method):
         mih.fit_iht(y, x, None, k=6, d=mih.Poisson(), l=mih.LogLink(), est_r="MM", verbose=False)   # fit.jl:93-94
 
 
+@pytest.mark.parametrize("method", ["MM", "Newton"])
+def test_cv_negbin_est_r_chains_in_lockstep(mih, oracle, method):
+    """cv_iht with est_r.  The reference keeps ONE IHTVariable per Julia thread (cross_validation.jl:91) and
+    never resets v.d, so the NegBin r that mle_for_r (utilities.jl:141-247) left at the end of a fit is where the thread's next
+    fit starts; `Threads.@threads :static` (:100) gives each thread a contiguous block of the fold-major combinations.  The
+    library runs one CHAIN of fits per emulated thread and advances the chains in lock-step: every loss against the oracle's
+    restatement with the same number of threads -- q threads (the default: one chain per fold), 1 thread (one chain over the
+    whole grid), and thread counts that cut folds in the middle (2, 4, 7) -- and the chains dealt out over two ranks must add
+    up to the single-rank matrix bit for bit (a chain stays whole on one rank)."""
+    rng = np.random.default_rng(61)
+    n, p, q = 900, 260, 3
+    cols = make_bed(rng, n, p, missing_rate=0.01)
+    x = mih.SnpLinAlg(cols, n=n, center=True, scale=True, impute=True)
+    ox = oracle.Mat.from_bed_columns(cols, n)
+    eta = _sim(oracle, ox, rng, 5, 0.4)
+    mu = np.exp(0.5 + 0.3 * eta)
+    y = rng.negative_binomial(4, 4 / (mu + 4)).astype(float)
+    folds = hash_folds(n, q)
+    path = [2, 3, 5, 6, 8]                                           # 15 combinations
+    seen = {}
+    for T in (0, 1, 2, 4, 7):
+        mse, raw = mih.cv_iht(y, x, None, d=mih.NegativeBinomial(1.0), l=mih.LogLink(), est_r=method, path=path, q=q, folds=folds,
+                              verbose=False, return_raw=True, cv_threads=T)
+        omse, oraw = oracle.cv_iht(ox, y, None, path=path, q=q, folds=folds, dist="negbin", link="log", nb_r=1.0,
+                                   est_r=method.lower(), cv_threads=(q if T == 0 else T))
+        assert np.count_nonzero(raw) == q * len(path)
+        # the Newton update stops at |dr| <= 1e-6 (utilities.jl:242): rounding-level differences move r by up to that much
+        np.testing.assert_allclose(raw, oraw, rtol=1e-5, err_msg=f"cv_threads={T}")
+        np.testing.assert_allclose(mse, omse, rtol=1e-5)
+        halves = [mih.cv_iht(y, x, None, d=mih.NegativeBinomial(1.0), l=mih.LogLink(), est_r=method, path=path, q=q, folds=folds,
+                             verbose=False, return_raw=True, cv_threads=T, rank=r, world=2)[1] for r in range(2)]
+        assert np.array_equal(halves[0] + halves[1], raw), T
+        assert all(np.count_nonzero(hh) > 0 for hh in halves) or T == 1
+        seen[T] = raw
+    assert np.array_equal(seen[0], mih.cv_iht(y, x, None, d=mih.NegativeBinomial(1.0), l=mih.LogLink(), est_r=method, path=path, q=q,
+                                              folds=folds, verbose=False, return_raw=True, cv_threads=q)[1])
+    # the chains matter: the first fit of a chain starts from d.r = 1, a later one from its predecessor's estimate
+    assert not np.array_equal(seen[1], seen[0])
+    assert np.array_equal(seen[1][0, 0], seen[0][0, 0])              # (fold 1, first k) opens a chain under either count
+    # model paths with est_r ride the lock-step driver too: every fit_iht call of the reference builds its own IHTVariable
+    # (cross_validation.jl:254-258), so each starts from d.r
+    ll = mih.iht_run_many_models(y, x, None, d=mih.NegativeBinomial(1.0), l=mih.LogLink(), est_r=method, path=path, verbose=False)
+    for kk, got in zip(path, ll):
+        o = oracle.fit_iht(ox, y, None, k=kk, dist="negbin", link="log", nb_r=1.0, est_r=method.lower(), max_iter=100)
+        assert got == pytest.approx(o["logl"], rel=1e-7), kk
+
+
 def test_init_beta(mih, oracle, normal_pair, normal_data):
     """init_beta=true (fit.jl:80; utilities.jl:776-842; test/L0_reg_test.jl:299-320)."""
     x, ox = normal_pair
@@ -2147,7 +2194,8 @@ def test_config3_full_grid_against_oracle(mih, oracle):
     assert cnt["scores"] >= 100 * 5 and cnt["rounds"] >= 10
     assert {q["stream_tag"] for q in passes} == {1, 2}
     assert max(q["residuals"] for q in passes) == 18 and all(q["kernel"].startswith("k_xtv_dma16<") for q in passes)
-    assert sum(q["residuals"] for q in passes) == cnt["scores"] - cnt["shared_init"]
+    assert cnt["init_scores"] == 100                                            # one initial score per fit, counted apart from the steps' 
+    assert sum(q["residuals"] for q in passes) == cnt["scores"] + cnt["init_scores"] - cnt["shared_init"]
     assert np.count_nonzero(raw) == 100
     # all 100 losses against the oracle
     ox = oracle.Mat.from_bed_columns(x.export_bed(), n)
