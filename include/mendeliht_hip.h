@@ -164,6 +164,13 @@ int mih_rccl_unique_id(void *id128);
 int mih_comm_create_rccl(const void *id128, int32_t rank, int32_t world, int32_t device, int64_t col_offset,
                          int64_t p_global, mih_comm **out);
 int mih_comm_destroy_rccl(mih_comm *c);
+/* The ONE exchange of a cross-validation run by one process per GPU (the reference combines its threads' losses in the shared
+ * `mses` vector, cross_validation.jl:99,113,124-127): every rank passes the nfolds * npath losses mih_cv_iht / mih_cv_mv /
+ * mih_fit_iht_path left it (zeros for the combinations of other ranks); on return every rank holds their sum over the ranks
+ * = the complete matrix, ready for mih_cv_meanloss.  One all-gather through `c` (ncclAllGather over xGMI for a communicator
+ * made by mih_comm_create_rccl -- col_offset / p_global play no role here, pass 0 and 1 -- or the caller's own callbacks),
+ * summed in rank order.  No MPI, no host-language collective. */
+int mih_cv_allgather(const mih_comm *c, double *mses_raw, int64_t count);
 
 /* keyword arguments of fit_iht (src/fit.jl:64-81) */
 typedef struct mih_fit_params {

@@ -138,6 +138,12 @@ function rccl_comm(id::Vector{UInt8}, rank::Integer, world::Integer; device::Int
     return h[]
 end
 rccl_comm_destroy(c::Ptr{Cvoid}) = check(ccall((:mih_comm_destroy_rccl, LIB), Cint, (Ptr{Cvoid},), c))
+# The one exchange of a multi-process cross-validation (cross_validation.jl:124-127 combines the losses of all workers): the
+# library's own all-gather over the communicator above -- no MPI needed.  `raw` holds this rank's losses, zeros elsewhere.
+function cv_allgather!(comm::Ptr{Cvoid}, raw::Vector{Float64})
+    check(ccall((:mih_cv_allgather, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64), comm, raw, length(raw)))
+    return raw
+end
 
 mutable struct MihFitResult
     time::Float64; logl::Float64; iter::Int64; pve::Float64; nb_r::Float64
@@ -311,6 +317,7 @@ function cv_iht(y::AbstractVector{Float64}, x::HipSnpLinAlg{Float64}, z::Abstrac
         zkeep::BitVector=trues(size(z, 2)), folds::AbstractVector{Int}=rand(1:q, size(x, 1)), debias::Bool=false,
         verbose::Bool=true, max_iter::Int=100, min_iter::Int=5, init_beta::Bool=false, memory_efficient::Bool=true,
         rank::Int=0, world::Int=1, reduce=identity,       # reduce: sums the raw loss matrix over the ranks (e.g. MPI.Allreduce)
+        comm::Ptr{Cvoid}=C_NULL,                          # ... or `rccl_comm(...)`: the library gathers the losses itself (cv_allgather!)
         xtv_digits::Int=0,
         cv_threads::Int=Threads.nthreads())      # est_r only: the reference hands v.d (the NegBin r) from one fit of a thread to that
                                                  # thread's next one (cross_validation.jl:91,100-110); the library follows the same chains
@@ -328,7 +335,8 @@ function cv_iht(y::AbstractVector{Float64}, x::HipSnpLinAlg{Float64}, z::Abstrac
              Int64, Int32, Int32, Ptr{Float64}),
             x.handle, prm, yy, zz, nz, f32, q, pth, length(pth), rank, world, raw))
     end
-    raw = reduce(raw)                            # world > 1: each rank filled only its own combinations
+    comm != C_NULL && cv_allgather!(comm, raw)   # world > 1: each rank filled only its own combinations
+    raw = reduce(raw)
     check(ccall((:mih_cv_meanloss, LIB), Cint, (Ptr{Float64}, Ptr{Int32}, Int64, Int32, Int64, Ptr{Float64}),
         raw, f32, length(f32), q, length(pth), mse))
     verbose && MendelIHT.print_cv_results(mse, path, pth[argmin(mse)])      # cross_validation.jl:128-129

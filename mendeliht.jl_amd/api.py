@@ -174,6 +174,7 @@ def lib():
         "mih_rccl_unique_id": [vp],
         "mih_comm_create_rccl": [vp, i32, i32, i32, i64, i64, C.POINTER(vp)],
         "mih_comm_destroy_rccl": [vp],
+        "mih_cv_allgather": [vp, vp, i64],
         "mih_profile_enable": [vp, C.c_int],
         "mih_profile_read": [vp, C.POINTER(dbl), C.POINTER(i64), C.c_int],
         "mih_profile_passes": [vp, C.POINTER(_PassRecord), i64, C.POINTER(i64), C.c_int],
@@ -199,7 +200,7 @@ def exported_symbols():
             "mih_project_topk", "mih_project_group_sparse", "mih_fit_iht", "mih_cv_iht", "mih_cv_meanloss", "mih_cv_assignment", "mih_cv_iht_multi", "mih_fit_iht_path",
             "mih_fit_mv", "mih_cv_mv", "mih_bench_xtv", "mih_xtv_algorithmic_bytes", "mih_xtv_batched_fmt", "mih_abi_sizes",
             "mih_session_create", "mih_session_step", "mih_session_run", "mih_session_model", "mih_session_destroy",
-            "mih_rccl_unique_id", "mih_comm_create_rccl", "mih_comm_destroy_rccl",
+            "mih_rccl_unique_id", "mih_comm_create_rccl", "mih_comm_destroy_rccl", "mih_cv_allgather",
             "mih_profile_enable", "mih_profile_read", "mih_profile_passes", "mih_profile_counters"]
 
 

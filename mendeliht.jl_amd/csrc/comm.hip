@@ -8,6 +8,7 @@
 #include "common.h"
 #include <dlfcn.h>
 #include <mutex>
+#include <vector>
 
 namespace mih {
 
@@ -146,6 +147,23 @@ int mih_comm_create_rccl(const void *id128, int32_t rank, int32_t world, int32_t
     nc->c.rank = rank; nc->c.world = world; nc->c.col_offset = col_offset; nc->c.p_global = p_global;
     nc->c.allreduce = native_allreduce; nc->c.allgather = native_allgather; nc->c.user = nc;
     *out = &nc->c;
+    return MIH_OK;
+}
+
+// The single exchange of a cross-validation run by one process per GPU: every rank holds the losses of its own (fold, k)
+// combinations (zeros elsewhere, mih_cv_iht); one all-gather, summed in rank order on every rank.
+int mih_cv_allgather(const mih_comm *c, double *mses_raw, int64_t count)
+{
+    if (!c || !mses_raw || count < 0 || !c->allgather || c->world < 1) { set_error("null/invalid argument"); return MIH_BAD_ARG; }
+    if (c->world == 1 || count == 0) return MIH_OK;
+    std::vector<double> all((size_t)count * (size_t)c->world);
+    const int rc = c->allgather(c->user, mses_raw, count, all.data());
+    if (rc) { set_error("communicator all-gather failed (%d)", rc); return MIH_HIP_ERROR; }
+    for (int64_t i = 0; i < count; ++i) {
+        double s = 0.0;
+        for (int32_t r = 0; r < c->world; ++r) s += all[(size_t)r * (size_t)count + (size_t)i];
+        mses_raw[i] = s;
+    }
     return MIH_OK;
 }
 

@@ -58,8 +58,19 @@ def gather_losses(raw):
     return out.view(dist.get_world_size(), -1).sum(dim=0).cpu().numpy().reshape(raw.shape)
 
 
-def cv_iht_distributed(y, x, z=None, **kw):
-    """cv_iht with the (fold, k) loop sharded over the ranks of the current process group."""
+def gather_losses_native(comm):
+    """reduce= for cv_iht over the library's own communicator (mih_cv_allgather: one ncclAllGather, no torch collective)."""
+    def reduce(raw):
+        from .api import _check, _p, lib
+        out = np.ascontiguousarray(raw, dtype=np.float64).copy()
+        _check(lib().mih_cv_allgather(comm.pointer(), _p(out), out.size))
+        return out.reshape(np.shape(raw))
+    return reduce
+
+
+def cv_iht_distributed(y, x, z=None, native=False, **kw):
+    """cv_iht with the (fold, k) loop sharded over the ranks of the current process group.  native=True: the one exchange
+    runs inside the library over its own RCCL communicator (mih_cv_allgather) -- what a Julia multi-process run uses."""
     import torch.distributed as dist
 
     from .api import cv_iht
@@ -68,7 +79,13 @@ def cv_iht_distributed(y, x, z=None, **kw):
         rank, world = dist.get_rank(), dist.get_world_size()
     else:
         rank, world = 0, 1
-    return cv_iht(y, x, z, rank=rank, world=world, reduce=gather_losses, **kw)
+    if not native:
+        return cv_iht(y, x, z, rank=rank, world=world, reduce=gather_losses, **kw)
+    comm = NativeComm(0, 1, device=getattr(x, "device", 0))
+    try:
+        return cv_iht(y, x, z, rank=rank, world=world, reduce=gather_losses_native(comm), **kw)
+    finally:
+        comm.close()
 
 
 class ColumnComm:
@@ -78,13 +95,17 @@ class ColumnComm:
     reduced by RCCL; with the gloo backend they are staged through host memory.
     """
 
-    def __init__(self, col_offset, p_global, device=0, group=None):
+    def __init__(self, col_offset, p_global, device=0, group=None, ordered_sum=False):
+        """ordered_sum: sums are taken in RANK ORDER on every rank (one all-gather + a local sum) instead of by the backend's
+        all-reduce, whose ring sums every chunk in a different order -- results then do not depend on the backend or its
+        algorithm (for more than two ranks a floating-point sum depends on the order), at world times the traffic."""
         import torch.distributed as dist
 
         from .api import _ALLGATHER, _ALLREDUCE, _Comm
 
         self.group = group
         self.device = device
+        self.ordered_sum = bool(ordered_sum)
         self.error = None
         on = dist.is_initialized()
         self.rank = dist.get_rank(group) if on else 0
@@ -107,6 +128,8 @@ class ColumnComm:
             if self.world == 1:
                 return 0
             rop = dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX
+            if self.ordered_sum and op == 0:
+                return self._allreduce_ordered(buf, count, on_device)
             if on_device:
                 t = torch.as_tensor(_DevArray(buf, count), device=f"cuda:{self.device}")
                 if self.backend == "nccl":
@@ -129,6 +152,31 @@ class ColumnComm:
         except Exception as e:      # noqa: BLE001
             self.error = e
             return 1
+
+    def _allreduce_ordered(self, buf, count, on_device):
+        import torch
+        import torch.distributed as dist
+
+        dev = f"cuda:{self.device}" if self.backend == "nccl" else "cpu"
+        if on_device:
+            t = torch.as_tensor(_DevArray(buf, count), device=f"cuda:{self.device}")
+            mine = t if self.backend == "nccl" else t.cpu()
+        else:
+            arr = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_double)), shape=(count,))
+            t = None
+            mine = torch.from_numpy(arr.copy()).to(dev)
+        out = torch.empty(count * self.world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(out, mine.contiguous(), group=self.group)
+        parts = out.view(self.world, count)
+        acc = parts[0].clone()
+        for r in range(1, self.world):                      # rank 0 first, then 1, 2, ...: the same order on every rank
+            acc += parts[r]
+        if on_device:
+            t.copy_(acc)
+            torch.cuda.synchronize(self.device)
+        else:
+            arr[:] = acc.cpu().numpy()
+        return 0
 
     def _allgather(self, _user, send, count, recv):
         try:
@@ -221,7 +269,7 @@ def column_block(p_global, rank, world):
     return lo, base + (1 if rank < rem else 0)
 
 
-def fit_iht_sharded(y, x_shard, z=None, *, col_offset, p_global, weight=None, native=False, **kw):
+def fit_iht_sharded(y, x_shard, z=None, *, col_offset, p_global, weight=None, native=False, ordered_sum=False, **kw):
     """fit_iht on a design matrix whose SNP columns are sharded over the ranks of the process group.
 
     x_shard holds columns [col_offset, col_offset + x_shard.p); y, z are replicated.  Returns the same
@@ -233,7 +281,8 @@ def fit_iht_sharded(y, x_shard, z=None, *, col_offset, p_global, weight=None, na
 
     from .api import fit_iht
 
-    comm = (NativeComm if native else ColumnComm)(col_offset, p_global, device=x_shard.device)
+    comm = (NativeComm(col_offset, p_global, device=x_shard.device) if native else
+            ColumnComm(col_offset, p_global, device=x_shard.device, ordered_sum=ordered_sum))
     if weight is not None:
         weight = np.asarray(weight, dtype=np.float64)[col_offset:col_offset + x_shard.p]
     try:

@@ -24,9 +24,15 @@ def summary(res):
 
 
 def native_main(out_path):
-    """MIH_NATIVE=1 (needs one GPU per rank): the library's own RCCL exchange (mih_comm_create_rccl: ncclAllReduce / ncclAllGather
-    on a private stream) against the torch.distributed callbacks, rank by rank, bit for bit."""
-    rank, world, local = D.init_from_env(backend="nccl")
+    """MIH_NATIVE=1: the library's own exchange (mih_comm_create_rccl: ncclAllReduce / ncclAllGather on a private stream) against
+    the torch.distributed callbacks, rank by rank, bit for bit.  With one GPU per rank that is the real librccl over
+    xGMI; MIH_NATIVE_ONE_DEVICE=1 (the one-GPU test box): every rank on device 0, torch.distributed over gloo, and the library
+    loads the test-only stand-in tests/libfake_rccl.so through MENDELIHT_RCCL_LIB (set by the test) -- the same comm.hip code
+    with more than one rank.  The callbacks sum in rank order (ordered_sum) as the stand-in does, so three ranks agree bit for bit."""
+    one_dev = bool(os.environ.get("MIH_NATIVE_ONE_DEVICE"))
+    rank, world, local = D.init_from_env(backend="gloo" if one_dev else "nccl")
+    if one_dev:
+        local = 0
     import torch.distributed as dist
     n = 1000
     cols = m.read_bed(os.path.join(FIX, "normal.bed"), n)
@@ -47,8 +53,32 @@ def native_main(out_path):
         lo, cnt = D.column_block(p, rank, world)
         xs = m.SnpLinAlg(cc[lo:lo + cnt], n=nn, center=True, scale=True, impute=True, device=local)
         a = summary(D.fit_iht_sharded(yy, xs, zz, col_offset=lo, p_global=p, verbose=False, native=True, **kw))
-        b = summary(D.fit_iht_sharded(yy, xs, zz, col_offset=lo, p_global=p, verbose=False, native=False, **kw))
+        b = summary(D.fit_iht_sharded(yy, xs, zz, col_offset=lo, p_global=p, verbose=False, native=False, ordered_sum=True, **kw))
         out[name] = dict(native=a, callbacks=b)
+        if rank == 0:                                        # ... and the unsharded fit on the whole matrix
+            xf = m.SnpLinAlg(cc, n=nn, center=True, scale=True, impute=True, device=local)
+            out[name]["single"] = summary(m.fit_iht(yy, xf, zz, verbose=False, **kw))
+    # a large model first and small ones after it: the communicator's staging buffer grows (ensure_stage) and is re-used
+    lo, cnt = D.column_block(p2, rank, world)
+    xs = m.SnpLinAlg(cols2[lo:lo + cnt], n=n2, center=True, scale=True, impute=True, device=local)
+    ynorm = eta + rng.standard_normal(n2)
+    from mendeliht_amd import dist as DD
+    comm = DD.NativeComm(lo, p2, device=local)
+    grow = []
+    for kk in (40, 3, 90, 5):
+        r1 = m.fit_iht(ynorm, xs, None, k=kk, comm=comm, verbose=False, max_iter=30)
+        grow.append(dict(k=kk, logl=r1.logl, iter=int(r1.iter), nnz=int(np.count_nonzero(r1.beta))))
+    comm.close()
+    out["staging_growth"] = grow
+    # the one exchange of a cross-validation through the library's communicator (mih_cv_allgather) against the torch all-gather
+    from conftest import hash_folds
+    xr = m.SnpLinAlg(cols, n=n, center=True, scale=True, impute=True, device=local)
+    folds = hash_folds(n, 3)
+    cv_native = D.cv_iht_distributed(y, xr, z, native=True, path=range(1, 9), q=3, folds=folds, verbose=False)
+    cv_torch = D.cv_iht_distributed(y, xr, z, native=False, path=range(1, 9), q=3, folds=folds, verbose=False)
+    out["cv_gather"] = dict(native=cv_native.tolist(), torch=cv_torch.tolist())
+    if rank == 0:
+        out["cv_gather"]["single"] = m.cv_iht(y, xr, z, path=range(1, 9), q=3, folds=folds, verbose=False).tolist()
     dist.barrier()
     with open(out_path + f".native.r{rank}", "w") as f:
         json.dump(dict(world=world, cases=out), f)

@@ -132,3 +132,24 @@ def test_c_harness_compiles_and_resolves_every_symbol(mih, tmp_path):
     r = subprocess.run([str(exe), mih.library_path(), os.path.join(ROOT, "tests", "fixtures"), "symbols-only"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "entry points resolved" in r.stdout
+
+
+def test_stand_in_rccl_matches_the_real_prototypes_and_codes(tmp_path):
+    """tests/fake_rccl.c (the test-only stand-in the one-GPU box loads through MENDELIHT_RCCL_LIB so that csrc/comm.hip runs with
+    more than one rank) includes the REAL <rccl/rccl.h>: it only compiles if its six definitions match the real prototypes, and
+    the codes comm.hip declares by hand must be the header's (the stand-in rejects anything else at run time).  No GPU call."""
+    import subprocess
+    src = os.path.join(ROOT, "tests", "fake_rccl.c")
+    lib = tmp_path / "libfake_rccl.so"
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", src,
+                           "-o", str(lib), "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-lpthread"])
+    out = subprocess.check_output(["nm", "-D", "--defined-only", str(lib)], text=True)
+    have = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    assert {"ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclAllReduce", "ncclAllGather", "ncclGetErrorString"} <= have
+    comm = open(os.path.join(ROOT, "mendeliht.jl_amd", "csrc", "comm.hip")).read()
+    hdr = open("/opt/rocm/include/rccl/rccl.h").read()
+    mine = dict(re.findall(r"(kNccl\w+)\s*=\s*(\d+)", comm))
+    for ours, theirs in (("kNcclFloat64", "ncclFloat64"), ("kNcclSum", "ncclSum"), ("kNcclMax", "ncclMax"), ("kNcclSuccess", "ncclSuccess")):
+        real = re.search(rf"\b{theirs}\s*=\s*(\d+)", hdr)
+        assert real and int(mine[ours]) == int(real.group(1)), (ours, theirs)
+    assert "NCCL_UNIQUE_ID_BYTES 128" in hdr

@@ -72,6 +72,53 @@ def test_sharded_fit_matches_single_process(tmp_path, world):
     assert res["cases"]["ties_choose"]["single"]["choose_fired"]
 
 
+def _build_fake_rccl():
+    """tests/libfake_rccl.so from tests/fake_rccl.c (gcc against the real <rccl/rccl.h>: the stand-in's definitions must match
+    the real prototypes to compile)."""
+    src, lib = os.path.join(ROOT, "tests", "fake_rccl.c"), os.path.join(ROOT, "tests", "libfake_rccl.so")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", src, "-o", lib,
+                               "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-lpthread"])
+    return lib
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_native_exchange_with_more_than_one_rank_on_one_gpu(tmp_path, world):
+    """csrc/comm.hip with world > 1 on the one-GPU box: the ranks share device 0 and the library loads the
+    test-only stand-in librccl (tests/fake_rccl.c: shared memory + hipMemcpy, the real header's prototypes and enum names)
+    through MENDELIHT_RCCL_LIB.  The native exchange -- hand-declared data type / reduction codes, the all-gather layout, the
+    growth and re-use of the staging buffer, the private stream against the fit's stream, collective teardown -- must give
+    the callbacks' results bit for bit on every rank, the single-process fit to rounding, and mih_cv_allgather the torch
+    all-gather's losses exactly."""
+    lib = _build_fake_rccl()
+    out = tmp_path / "res.json"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tests", "sharded_worker.py"), str(out)]
+    env = dict(os.environ, OMP_NUM_THREADS="4", MIH_NATIVE="1", MIH_NATIVE_ONE_DEVICE="1", MENDELIHT_RCCL_LIB=lib)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = [json.load(open(str(out) + f".native.r{k}")) for k in range(world)]
+    for name in ("normal_k7", "logistic"):
+        for k in range(world):
+            a, b = res[k]["cases"][name]["native"], res[k]["cases"][name]["callbacks"]
+            assert a == b, (name, k)                                     # every field, bit for bit (json round-trips doubles)
+            assert a == res[0]["cases"][name]["native"], (name, k)       # ... and the same on every rank
+        one, sh = res[0]["cases"][name]["single"], res[0]["cases"][name]["native"]
+        assert sh["support"] == one["support"] and sh["iter"] == one["iter"] and sh["bt"] == one["bt"], name
+        np.testing.assert_allclose(sh["beta"], one["beta"], rtol=0, atol=1e-9, err_msg=name)
+        np.testing.assert_allclose(sh["logl_trace"], one["logl_trace"], rtol=1e-11, err_msg=name)
+    g = json.load(open(os.path.join(GOLD, "golden_normal_k7.json")))     # the reference's recorded run through the native exchange
+    sh = res[0]["cases"]["normal_k7"]["native"]
+    assert sh["iter"] == g["iterations"] and [j + 1 for j in sh["support"]] == g["positions_1based"]
+    np.testing.assert_allclose(sh["logl_trace"], g["logl"], rtol=1e-11)
+    for k in range(world):
+        assert res[k]["cases"]["staging_growth"] == res[0]["cases"]["staging_growth"]
+        cv = res[k]["cases"]["cv_gather"]
+        assert cv["native"] == cv["torch"] == res[0]["cases"]["cv_gather"]["single"], k
+    assert [d["nnz"] for d in res[0]["cases"]["staging_growth"]] == [40, 3, 90, 5]
+
+
 def test_native_rccl_exchange_matches_the_callbacks_on_two_gpus(tmp_path):
     """The library's own RCCL communicator (mih_comm_create_rccl) with MORE than one rank -- ncclAllReduce / ncclAllGather over
     xGMI, the hand-declared enum values, the all-gather layout, the ordering against the fit's stream -- against the
@@ -88,8 +135,12 @@ def test_native_rccl_exchange_matches_the_callbacks_on_two_gpus(tmp_path):
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     res = [json.load(open(str(out) + f".native.r{k}")) for k in range(2)]
-    for name in res[0]["cases"]:
+    for name in ("normal_k7", "logistic"):
         for k in range(2):
             a, b = res[k]["cases"][name]["native"], res[k]["cases"][name]["callbacks"]
             assert a == b, (name, k)                                     # every field, bit for bit (json round-trips doubles)
         assert res[0]["cases"][name]["native"] == res[1]["cases"][name]["native"], name
+    for k in range(2):
+        assert res[k]["cases"]["staging_growth"] == res[0]["cases"]["staging_growth"]
+        cv = res[k]["cases"]["cv_gather"]
+        assert cv["native"] == cv["torch"] == res[0]["cases"]["cv_gather"]["single"], k
