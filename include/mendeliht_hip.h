@@ -88,6 +88,11 @@ int mih_dense_create_synthetic(int64_t n, int64_t p, uint64_t seed, int device, 
 /* Releases the matrix.  A mih_session must not be stepped after its matrix is gone, but it may be destroyed later: the
  * reserve of device memory a large matrix keeps for its fits lives until its last user. */
 int mih_mat_destroy(mih_mat *h);
+/* The reserve of device memory a matrix keeps for the fits that run on it (lock-step workspaces, IHTVariable blocks: no fit then
+ * calls hipMalloc / hipFree).  A 2-bit matrix of 4 GiB or more gets one when it is created; this call gives one to ANY 2-bit
+ * matrix -- bytes = 0: sized from its dimensions by the library's rule, bytes > 0: that size -- or releases it (bytes < 0).
+ * Not to be called while a fit is running on the matrix.  MIH_OOM if the device has less than four times the size free. */
+int mih_mat_reserve(mih_mat *h, int64_t bytes);
 int mih_mat_dims(const mih_mat *h, int64_t *n, int64_t *p);
 /* `x.μ`, `x.σinv` of the SnpLinAlg */
 int mih_snp_mu_sigma(const mih_mat *h, double *mu, double *sinv);

@@ -94,6 +94,9 @@ function maf_weights(x::HipSnpLinAlg{Float64}; max_weight::Float64=Inf)
     return clamp.(1 ./ (2 .* sqrt.(maf .* (1 .- maf))), 1.0, max_weight)
 end
 
+# the reserve of device memory a matrix keeps for its fits (automatic from 4 GiB; bytes = 0: the library's sizing, < 0: release)
+reserve!(x::HipSnpLinAlg; bytes::Integer=0) = (check(ccall((:mih_mat_reserve, LIB), Cint, (Ptr{Cvoid}, Int64), x.handle, bytes)); x)
+
 # naive_impute(x, destination) (utilities.jl:862-899) on the device copy of the genotypes
 function naive_impute(x::HipSnpLinAlg{Float64}, destination::String)
     out = Matrix{UInt8}(undef, (x.n + 3) >> 2, x.p)

@@ -146,6 +146,7 @@ def lib():
         "mih_dense_create_f32": [vp, i64, i64, C.c_int, C.POINTER(vp)],
         "mih_mat_destroy": [vp],
         "mih_mat_dims": [vp, C.POINTER(i64), C.POINTER(i64)],
+        "mih_mat_reserve": [vp, i64],
         "mih_snp_mu_sigma": [vp, vp, vp],
         "mih_snp_export_bed": [vp, vp],
         "mih_snp_naive_impute": [vp, vp],
@@ -195,7 +196,7 @@ def exported_symbols():
     """Every symbol include/mendeliht_hip.h declares (checked by the CPU test-suite)."""
     return ["mih_device_count", "mih_last_error", "mih_version", "mih_snp_create", "mih_snp_create_synthetic",
             "mih_snp_create_synthetic_shard",
-            "mih_dense_create", "mih_dense_create_synthetic", "mih_dense_create_f32", "mih_mat_destroy", "mih_mat_dims",
+            "mih_dense_create", "mih_dense_create_synthetic", "mih_dense_create_f32", "mih_mat_destroy", "mih_mat_dims", "mih_mat_reserve",
             "mih_snp_mu_sigma", "mih_snp_export_bed", "mih_snp_naive_impute", "mih_xtv", "mih_xtv_batched", "mih_xv_sparse",
             "mih_project_topk", "mih_project_group_sparse", "mih_fit_iht", "mih_cv_iht", "mih_cv_meanloss", "mih_cv_assignment", "mih_cv_iht_multi", "mih_fit_iht_path",
             "mih_fit_mv", "mih_cv_mv", "mih_bench_xtv", "mih_xtv_algorithmic_bytes", "mih_xtv_batched_fmt", "mih_abi_sizes",
@@ -406,12 +407,25 @@ class _Mat:
         return b.value
 
 
+# The `reserve` argument of SnpLinAlg when the caller leaves it out.  False: the library's own policy (a 2-bit matrix of 4 GiB or
+# more keeps a reserve of device memory for its fits, smaller ones allocate per fit).  True: every matrix asks for a reserve
+# (mih_mat_reserve) -- tests/conftest.py sets it so that small test matrices run the pool / arena code of a 125 GB matrix.
+RESERVE_BY_DEFAULT = False
+
+
 class SnpLinAlg(_Mat):
     """SnpLinAlg{Float64}(s::SnpArray; model=ADDITIVE_MODEL, center, scale, impute) on the GPU."""
 
-    def __init__(self, bed, n=None, center=False, scale=False, impute=True, device=0, _handle=None, dtype=np.float64):
+    def _reserve(self, reserve):
+        if reserve:
+            _check(lib().mih_mat_reserve(self._h, 0))
+        elif reserve is None and RESERVE_BY_DEFAULT:
+            lib().mih_mat_reserve(self._h, 0)          # best effort: a crowded device keeps the per-fit allocations
+
+    def __init__(self, bed, n=None, center=False, scale=False, impute=True, device=0, _handle=None, dtype=np.float64, reserve=None):
         """dtype: the element type T of SnpLinAlg{T} (np.float64 or np.float32, src/MendelIHT.jl:39).  The device arithmetic is
-        the same for both (exact fixed point + Float64); with float32 the models fit_iht / cv_iht return are cast to float32."""
+        the same for both (exact fixed point + Float64); with float32 the models fit_iht / cv_iht return are cast to float32.
+        reserve: True asks for the reserve of device memory a large matrix keeps for its fits (mih_mat_reserve), None = RESERVE_BY_DEFAULT."""
         super().__init__()
         self.center, self.scale, self.impute = bool(center), bool(scale), bool(impute)
         self.device = device
@@ -436,15 +450,18 @@ class SnpLinAlg(_Mat):
                                     int(impute), 32 if self.dtype is np.float32 else 64, device, C.byref(h)))
         self._h = h
         self._dims()
+        self._reserve(reserve)
 
     @classmethod
     def synthetic(cls, n, p, seed=2024, missing_rate=0.0, center=True, scale=True, impute=True, device=0,
-                  col_offset=0):
+                  col_offset=0, reserve=None):
         """Columns [col_offset, col_offset + p) of the seeded synthetic SnpArray (col_offset > 0: one shard)."""
         h = C.c_void_p(None)
         _check(lib().mih_snp_create_synthetic_shard(n, p, int(col_offset), seed, float(missing_rate), int(center),
                                                     int(scale), int(impute), device, C.byref(h)))
-        return cls(None, center=center, scale=scale, impute=impute, device=device, _handle=h)
+        x = cls(None, center=center, scale=scale, impute=impute, device=device, _handle=h)
+        x._reserve(reserve)
+        return x
 
     def mu_sigma(self):
         mu, s = np.empty(self.p), np.empty(self.p)

@@ -406,16 +406,17 @@ static int select_device(int device)
 // A large matrix reserves the device memory its fits will work in (DevPool, common.h): about what a cross-validation asks for
 // -- four fused-pass workspaces and 64 IHTVariable blocks, 15.7 GB beside a 125 GB matrix.  Whatever the driver has to do to
 // hand out never-used VRAM (one stall of ~2.9 s was measured) it does here, when the matrix is created, and no fit ever calls
-// hipMalloc / hipFree.  Memory policy knobs (environment, read once): MENDELIHT_NO_RESERVE=1 -- no reserve (every buffer from
-// hipMalloc); MENDELIHT_RESERVE_MIN_BYTES=<bytes> -- the smallest 2-bit matrix that gets a reserve (default 4 GiB; the test
-// suite sets 0 so that its small matrices exercise the pool, the arenas and the lock-step hand-over exactly as a 125 GB
-// matrix does -- ADVICE r2).  The reserve of a small matrix is sized from its dimensions.
-static void reserve_fit_memory(mih_mat *h)
+// hipMalloc / hipFree.  The policy is fixed -- a 2-bit matrix of 4 GiB or more gets a reserve when it is created -- and a caller
+// changes it with an ARGUMENT, not through the environment: mih_mat_reserve(h, bytes) gives any matrix a reserve
+// (bytes = 0: sized by the rule below from its dimensions -- the test suite asks for it on its small matrices so that the pool,
+// the arenas and the lock-step hand-over run exactly as beside a 125 GB matrix) or takes it away (bytes < 0).
+// MENDELIHT_NO_RESERVE=1 is an A/B switch of the measurement build.
+static void reserve_fit_memory(mih_mat *h, bool asked = false, size_t asked_bytes = 0)
 {
-    static const bool off = getenv("MENDELIHT_NO_RESERVE") != nullptr;
-    static const size_t min_bytes = [] { const char *e = getenv("MENDELIHT_RESERVE_MIN_BYTES"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)(4ull << 30); }();
+    static const bool off = probe_env("MENDELIHT_NO_RESERVE") != nullptr;
+    const size_t min_bytes = (size_t)(4ull << 30);
     const size_t x_bytes = (size_t)h->ncg * (size_t)h->nbp * 1024;
-    if (off || h->kind != 0 || x_bytes < min_bytes) return;
+    if (h->kind != 0 || (!asked && (off || x_bytes < min_bytes))) return;
     size_t big = (size_t)2304 * (size_t)h->p;                    // the row-slice partials of an 18-residual pass (16 slices x 18 x 8 B per column)
     size_t var = 128ull << 20;                                   // one IHTVariable block at n = 500k, p = 1M
     if (x_bytes >= (4ull << 30)) big = std::min<size_t>(std::max<size_t>(big, 256ull << 20), 4ull << 30);
@@ -423,7 +424,7 @@ static void reserve_fit_memory(mih_mat *h)
         big = std::max<size_t>(big + (size_t)30 * 8 * (size_t)h->n_pad, 4ull << 20);
         var = std::min<size_t>(var, std::max<size_t>((size_t)8 * (40 * (size_t)h->n_pad + 6 * (size_t)h->p) + (2ull << 20), 4ull << 20));
     }
-    const size_t want = 4 * big + 64 * var;
+    const size_t want = asked_bytes ? asked_bytes : 4 * big + 64 * var;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return; }
     if (free_b < 4 * want) return;                               // not on a crowded device
@@ -475,8 +476,13 @@ int mih_snp_create(const uint8_t *bed_cols, int64_t n, int64_t p, int64_t col_st
     if (hipStreamSynchronize(h->stream) != hipSuccess) return fail(MIH_HIP_ERROR);
     unsigned nth = std::thread::hardware_concurrency();
     nth = nth >= 16 ? 8 : (nth >= 4 ? nth / 2 : 1);
-    if (const char *e = getenv("MENDELIHT_INGEST_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 64) nth = (unsigned)v; }
+    if (const char *e = probe_env("MENDELIHT_INGEST_THREADS")) { int v = atoi(e); if (v >= 1 && v <= 64) nth = (unsigned)v; }     // measurement build
     if ((int64_t)nth > nchunks) nth = (unsigned)nchunks;
+    //  a chunk is at least one group of 32 columns, so above a 512 KB column stride (n > 2M rows) it outgrows the 16 MB
+    // target: n = 40M gives 320 MB chunks, and eight workers with two buffers each would pin 5 GB of host memory (0.28 ms per MB)
+    // and take as much VRAM.  The staging of ALL workers stays within a fixed budget: fewer workers for tall matrices
+    const size_t staging_budget = 512ull << 20;
+    if (buf_bytes * 2 * nth > staging_budget) nth = (unsigned)std::max<size_t>(1, staging_budget / (buf_bytes * 2));
     std::atomic<int64_t> next_chunk{0};
     std::atomic<int> failed{0};
     std::mutex err_mu; std::string err_msg;
@@ -485,8 +491,16 @@ int mih_snp_create(const uint8_t *bed_cols, int64_t n, int64_t p, int64_t col_st
         uint8_t *pin = nullptr, *raw = nullptr;
         ~Staging() { if (pin) (void)hipHostFree(pin); if (raw) (void)hipFree(raw); }
     } stg;
-    if (hipHostMalloc((void **)&stg.pin, buf_bytes * 2 * nth, hipHostMallocDefault) != hipSuccess) { set_error("hipHostMalloc of the staging buffers failed"); (void)hipGetLastError(); return fail(MIH_OOM); }
-    if (hipMalloc((void **)&stg.raw, buf_bytes * 2 * nth) != hipSuccess) { set_error("hipMalloc of the staging buffers failed"); (void)hipGetLastError(); return fail(MIH_OOM); }
+    for (;;) {                         // a failed allocation degrades to one worker before it fails the create
+        const bool ok = hipHostMalloc((void **)&stg.pin, buf_bytes * 2 * nth, hipHostMallocDefault) == hipSuccess &&
+                        hipMalloc((void **)&stg.raw, buf_bytes * 2 * nth) == hipSuccess;
+        if (ok) break;
+        (void)hipGetLastError();
+        if (stg.pin) { (void)hipHostFree(stg.pin); stg.pin = nullptr; }
+        if (stg.raw) { (void)hipFree(stg.raw); stg.raw = nullptr; }
+        if (nth == 1) { set_error("allocation of the upload staging buffers (2 x %zu bytes pinned + device) failed", buf_bytes); return fail(MIH_OOM); }
+        nth = 1;
+    }
     lap("staging buffers");
     std::atomic<unsigned> worker_no{0};
     auto worker = [&]() {
@@ -649,6 +663,18 @@ int mih_mat_destroy(mih_mat *h)
     if (h->Df) (void)hipFree(h->Df);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;                                  // the reserve goes with its last owner (pool_owner)
+    return MIH_OK;
+}
+
+int mih_mat_reserve(mih_mat *h, int64_t bytes)
+{
+    if (!h) { set_error("null handle"); return MIH_BAD_ARG; }
+    if (h->kind != 0) return MIH_OK;                       // dense matrices keep no reserve
+    MIH_HIP(hipSetDevice(h->device));
+    if (bytes < 0) { h->pool = nullptr; h->pool_owner.reset(); return MIH_OK; }      // (a running session keeps its own reference)
+    if (h->pool) return MIH_OK;                            // it has one already
+    reserve_fit_memory(h, true, (size_t)bytes);
+    if (!h->pool) { set_error("the device has no room for a reserve of the asked size beside this matrix"); return MIH_OOM; }
     return MIH_OK;
 }
 

@@ -8,9 +8,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# every 2-bit matrix of the test suite gets the device-memory reserve a 125 GB matrix gets (csrc/snp.hip reserve_fit_memory): the
-# pool, the per-IHTVariable arenas and the lock-step hand-over run in CI exactly as at full size
-os.environ.setdefault("MENDELIHT_RESERVE_MIN_BYTES", "0")
+# Every 2-bit matrix of the test suite asks for the device-memory reserve a 125 GB matrix gets (mih_mat_reserve): the pool, the
+# per-IHTVariable arenas and the lock-step hand-over run in CI exactly as at full size.  An ARGUMENT of the
+# mirror's constructor, not an environment switch of the library; tests/test_gpu_default_alloc.py runs a
+# representative subset on the path a caller with a small matrix gets (no reserve: every buffer from hipMalloc).
+import mendeliht_amd.api as _api   # noqa: E402  (ROOT is on sys.path by now)
+_api.RESERVE_BY_DEFAULT = True
 
 FIX = os.path.join(ROOT, "tests", "fixtures")
 GOLD = os.path.join(ROOT, "tests", "golden")

@@ -41,9 +41,14 @@ def test_probe_entry_points_live_in_the_measurement_build_only(mih):
     blob = open(mih.library_path(), "rb").read()
     for switch in (b"MENDELIHT_XTV_MAX_OPS", b"MENDELIHT_XTV_SLICES", b"MENDELIHT_XTV_NO_HALF", b"MENDELIHT_CV_LANES", b"MENDELIHT_CV_NO_MERGE",
                    b"MENDELIHT_CV_NO_INIT_SHARE", b"MENDELIHT_CV_TRACE", b"MENDELIHT_NO_SPIN", b"MENDELIHT_NO_ARENA", b"MENDELIHT_TOPK_RADIX8",
-                   b"MENDELIHT_XV_MULTI", b"MENDELIHT_CV_ASSIGN", b"MENDELIHT_CV_NO_COOP", b"MENDELIHT_COOP_SPIN_US", b"MENDELIHT_INGEST_TRACE"):
+                   b"MENDELIHT_XV_MULTI", b"MENDELIHT_CV_ASSIGN", b"MENDELIHT_CV_NO_COOP", b"MENDELIHT_COOP_SPIN_US", b"MENDELIHT_INGEST_TRACE",
+                   b"MENDELIHT_NO_RESERVE", b"MENDELIHT_INGEST_THREADS"):
         assert switch not in blob, switch
         assert switch in open(mih.probes_library_path(), "rb").read(), switch
+    #  the product reads ONE environment variable: where to find librccl.  The reserve of device memory is an
+    # argument now (mih_mat_reserve), the number of upload workers is fixed by the library
+    assert set(re.findall(rb"MENDELIHT_[A-Z0-9_]+", blob)) == {b"MENDELIHT_RCCL_LIB"}
+    assert b"MENDELIHT_RESERVE_MIN_BYTES" not in open(mih.probes_library_path(), "rb").read()
     assert C.sizeof(api._PassRecord) == 80
 
 

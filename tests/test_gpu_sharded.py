@@ -72,6 +72,19 @@ def test_sharded_fit_matches_single_process(tmp_path, world):
     assert res["cases"]["ties_choose"]["single"]["choose_fired"]
 
 
+def _check_growth_and_gather(res, world):
+    """a large model, a small one, a larger one, a small one over ONE communicator (its staging buffer grows and is re-used):
+    every rank reports the same fit, the local supports add up to k; and the library's gather of the CV losses
+    (mih_cv_allgather) equals the torch.distributed one and the single-process matrix exactly"""
+    for k in range(world):
+        for a, b in zip(res[k]["cases"]["staging_growth"], res[0]["cases"]["staging_growth"]):
+            assert (a["k"], a["logl"], a["iter"]) == (b["k"], b["logl"], b["iter"]), k
+        cv = res[k]["cases"]["cv_gather"]
+        assert cv["native"] == cv["torch"] == res[0]["cases"]["cv_gather"]["single"], k
+    for t, kk in enumerate((40, 3, 90, 5)):
+        assert sum(res[k]["cases"]["staging_growth"][t]["nnz"] for k in range(world)) == kk
+
+
 def _build_fake_rccl():
     """tests/libfake_rccl.so from tests/fake_rccl.c (gcc against the real <rccl/rccl.h>: the stand-in's definitions must match
     the real prototypes to compile)."""
@@ -112,11 +125,7 @@ def test_native_exchange_with_more_than_one_rank_on_one_gpu(tmp_path, world):
     sh = res[0]["cases"]["normal_k7"]["native"]
     assert sh["iter"] == g["iterations"] and [j + 1 for j in sh["support"]] == g["positions_1based"]
     np.testing.assert_allclose(sh["logl_trace"], g["logl"], rtol=1e-11)
-    for k in range(world):
-        assert res[k]["cases"]["staging_growth"] == res[0]["cases"]["staging_growth"]
-        cv = res[k]["cases"]["cv_gather"]
-        assert cv["native"] == cv["torch"] == res[0]["cases"]["cv_gather"]["single"], k
-    assert [d["nnz"] for d in res[0]["cases"]["staging_growth"]] == [40, 3, 90, 5]
+    _check_growth_and_gather(res, world)
 
 
 def test_native_rccl_exchange_matches_the_callbacks_on_two_gpus(tmp_path):
@@ -140,7 +149,4 @@ def test_native_rccl_exchange_matches_the_callbacks_on_two_gpus(tmp_path):
             a, b = res[k]["cases"][name]["native"], res[k]["cases"][name]["callbacks"]
             assert a == b, (name, k)                                     # every field, bit for bit (json round-trips doubles)
         assert res[0]["cases"][name]["native"] == res[1]["cases"][name]["native"], name
-    for k in range(2):
-        assert res[k]["cases"]["staging_growth"] == res[0]["cases"]["staging_growth"]
-        cv = res[k]["cases"]["cv_gather"]
-        assert cv["native"] == cv["torch"] == res[0]["cases"]["cv_gather"]["single"], k
+    _check_growth_and_gather(res, 2)

@@ -5,7 +5,8 @@ import os, sys, threading
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("MENDELIHT_RESERVE_MIN_BYTES", "0")
+import mendeliht_amd.api as _api
+_api.RESERVE_BY_DEFAULT = True          # small matrices with the reserve a 125 GB matrix keeps (mih_mat_reserve)
 import mendeliht_amd as m
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 cases = []
