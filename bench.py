@@ -1,23 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- IHT iterations/s and X'r GB/s vs the HBM roofline (BASELINE.json metric).
 
-N = 1 (default): BASELINE configs[2].  A "step" is one IHT iteration (iht_one_step!, src/fit.jl:213-263) over a
-synthetic 2-bit SnpArray resident in HBM (n=500k, p=1M, k=200, Normal): step size (k-column X v), gradient step +
-top-k projection, X beta, mean / loglikelihood, backtracking if needed, and the full X'r score pass.  `roofline` is
-measured live: HIP events around every launch of the dominant kernel (the X'r pass) inside the timed region, on the
-stream it runs on, recorded by the library together with the NAME of the kernel it dispatched and the number of residuals
-the launch scored (mih_profile_passes).  Secondary objects in the same line: `cv_iht` (BASELINE configs[3] --
-Bernoulli/Logit, path=1:20, 5 folds, all 100 fits -- on this one GPU, same matrix), `cpu_baseline` (the CPU oracle's
-whole iht_one_step on a bounded column sample of the same matrix) and `cpu_baseline_cv` (the oracle's cv_iht on a reduced
-grid of configs[3]).
+The SAME workload at every N: BASELINE configs[2].  A "step" is one IHT iteration (iht_one_step!, src/fit.jl:213-263) of ONE fit
+over a synthetic 2-bit SnpArray resident in HBM (n=500k, p=1M, k=200, Normal): step size (k-column X v), gradient step + top-k
+projection, X beta, mean / loglikelihood, backtracking if needed, and the full X'r score pass.  `value` = iterations of that one
+fit per second, `"scaling": "strong"`: at N > 1 the SNP columns are split over the ranks (column-sharded fit, SURVEY 8e row 2:
+every rank streams p/N columns, the exchanges -- two n-vector sums, one small all-gather, a few scalars per iteration -- run
+inside the library over its own RCCL communicator, csrc/comm.hip) and `--steps K` still means K iterations of the one fit.
+`roofline` is measured live: HIP events around every launch of the dominant kernel (the X'r pass) inside the timed region, on
+the stream it runs on, recorded by the library together with the NAME of the kernel it dispatched (mih_profile_passes); at
+N > 1 it is the per-GPU figure (each rank's launches stream its own p/N columns; all ranks' launches are pooled).
 
-N > 1: the path's real shard, BASELINE configs[3] -- cross_validation.jl:98-121.  `python bench.py --gpus N` starts its N
-ranks itself (a child `python -m torch.distributed.run`, before anything touches a GPU) and relays rank 0's line; started
-under a launcher (WORLD_SIZE set) it is one of the ranks.  Every rank holds an identical replica of X; a step is ONE whole
-cv_iht (100 (fold,k) fits) strong-scaled over the ranks with the single RCCL all-gather of the held-out losses inside the
-timed region.  `value` keeps the metric's unit at every N: IHT iterations (= residual scores, counted by the library,
-summed over the fits of all ranks) per second; fits/s, passes per rank and the gather time are reported beside it.
-`--mode replicas` keeps round 1's independent replicas of configs[2].
+Secondary object `cv_iht` at every N: BASELINE configs[3] -- Bernoulli/Logit, path=1:20, 5 folds, all 100 fits -- the path's
+natural shard (cross_validation.jl:98-121): every rank holds a full replica of X and evaluates its share of the (fold, k)
+combinations, ONE gather of the held-out losses.  At N > 1 rank 0 first times the whole 100-fit cross-validation ALONE, so
+the line carries its own N = 1 reference (`cv_iht.one_gpu_s`) and `cv_iht.cv_speedup`; the N-rank losses must equal rank 0's
+bit for bit.  `cpu_baseline` (N = 1): the CPU oracle's whole iht_one_step on a bounded column sample of the same matrix;
+`cpu_baseline_cv`: the oracle's cv_iht on a reduced grid.  The run FAILS (exit 1) if the fit recovers fewer than 99 % of the
+planted effects or the cross-validation does not select the planted model size.
+
+`python bench.py --gpus N` starts its N ranks itself (a child `python -m torch.distributed.run`, before anything touches a GPU)
+and relays rank 0's line; started under a launcher (WORLD_SIZE set) it is one of the ranks.  `--mode replicas` keeps round 1's
+independent replicas of configs[2] (weak scaling, no exchange).
 
 Prints ONE JSON line (rank 0).  The CPU baselines are a port (the repo's oracle), not MendelIHT.jl: no Julia here.
 """
@@ -38,16 +42,16 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 METRIC = "IHT iterations/sec + X'r GB/s vs HBM roofline, n=500k p=1M k=200"
 DTYPE = "f64 (residual as a 54-bit fixed-point number, exact accumulation on the matrix cores, f64 recombination)"
-TRAFFIC_FILE = os.path.join("profiles", "r03_traffic.json")    # separate rocprofv3 --pmc passes of this command (tools/prof_bench.sh)
+TRAFFIC_FILE = os.path.join("profiles", "r04_traffic.json")    # separate rocprofv3 --pmc passes of this command (tools/prof_bench.sh)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 100 at N=1, 5 whole cv_iht runs at N>1)")
+    ap.add_argument("--steps", type=int, default=None, help="timed IHT iterations of the one fit (default 100)")
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--mode", choices=["auto", "fit", "cv", "replicas"], default="auto",
-                    help="auto: fit (configs[2]) at N=1, cv (configs[3], strong-scaled) at N>1")
+    ap.add_argument("--mode", choices=["auto", "fit", "replicas"], default="auto",
+                    help="auto = fit: configs[2], one fit, column-sharded over the ranks at N>1; replicas: one independent fit per GPU")
     ap.add_argument("--n", type=int, default=int(os.environ.get("MIH_BENCH_N", 500_000)))
     ap.add_argument("--p", type=int, default=int(os.environ.get("MIH_BENCH_P", 1_000_000)))
     ap.add_argument("--k", type=int, default=200)
@@ -56,7 +60,8 @@ def parse():
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-started ranks (0 = a free one)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of each baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-cv", action="store_true", help="skip the secondary cv_iht measurement at N=1")
+    ap.add_argument("--no-cv", action="store_true", help="skip the secondary cv_iht measurement (configs[3])")
+    ap.add_argument("--cv-steps", type=int, default=2, help="timed whole cross-validations of the secondary object at N>1")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per X'r launch from a separate rocprofv3 --pmc pass (corrected)")
     return ap.parse_args()
@@ -80,13 +85,33 @@ def cores_used(threads):
     return threads if quota is None else int(min(threads, max(1, round(quota))))
 
 
+def kfd_gpu_count():
+    """GPUs of this node from the kernel driver's topology (no HIP call: the launching process must not open the device).
+    None when the topology cannot be read."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.isdir("/sys/class/kfd"):
+        return 0                                         # no amdgpu compute driver on this node
+    try:
+        cnt = 0
+        for node in os.listdir(base):
+            props = dict(ln.split()[:2] for ln in open(os.path.join(base, node, "properties")) if len(ln.split()) >= 2)
+            cnt += int(props.get("simd_count", "0")) > 0          # CPU nodes have no SIMDs
+        vis = os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES"))
+        if vis is not None and vis.strip() != "":
+            cnt = min(cnt, len([v for v in vis.split(",") if v.strip() != ""]))
+        return cnt
+    except (OSError, ValueError):
+        return None
+
+
 def self_launch(a):
-    """`python bench.py --gpus N` without a launcher: start the N ranks as a child `python -m torch.distributed.run` BEFORE this
-    process touches a GPU (it never does), relay the child's stdout (rank 0's JSON line) and return its exit code."""
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child `python -m torch.distributed.run` (Popen, no
+    exec), relay the child's stdout (rank 0's JSON line) and return its exit code.  This process makes no HIP call (ADVICE r3:
+    the devices are counted from the kfd topology in sysfs, not with torch.cuda.device_count(), which falls back to
+    hipGetDeviceCount and opens the runtime)."""
     if not a.dry_run and not os.environ.get("MIH_BENCH_ONE_DEVICE"):
-        import torch                                             # counting devices does not initialise the GPU
-        have = torch.cuda.device_count()
-        if have < a.gpus:
+        have = kfd_gpu_count()
+        if have is not None and have < a.gpus:
             sys.exit(f"bench.py --gpus {a.gpus}: this node has {have} GPU(s); one rank per GPU is needed "
                      "(MIH_BENCH_BACKEND=gloo MIH_BENCH_ONE_DEVICE=1 runs all ranks on one device as a functional check)")
     port = a.master_port
@@ -171,7 +196,9 @@ def cpu_baseline(m, n, p, k, seed, target_s):
                       f"on the first {pc} of {p} SNP columns, n={n}: {t_step:.3f} s per step, of which the X'r pass {t_xtv:.3f} s "
                       f"(scaled by p/{pc}; the remaining {t_rest:.3f} s per step does not grow with p); {cores} OpenMP threads = the "
                       f"fastest of {sorted(trials)} on {ncpu} logical CPUs{'' if quota is None else f', cgroup CPU quota {quota:g}'}; "
-                      "CPU restatement (oracle/), not MendelIHT.jl",
+                      "CPU restatement (oracle/), not MendelIHT.jl.  Context, not a measurement of this run: the reference's closest "
+                      "published point is 2530 s / 4 iterations = 632 s per iteration at n=100k, p=1M, Normal, on one Intel E5-2670 core "
+                      "(pre-1.0 code; figures/benchmark/normal_results_nodebias, BASELINE.md)",
             "xtv_GBps": ((n + 3) // 4) * pc / t_xtv / 1e9, "step_s_on_sample": t_step, "xtv_s_on_sample": t_xtv}, cores
 
 
@@ -230,6 +257,9 @@ def cv_problem(m, x, n, p):
     return yb, hash_folds(n, 5)
 
 
+CV_PLANTED_K = 10          # cv_problem plants 10 effects; at the default sizes the cross-validation selects exactly that model size
+
+
 def pass_stats(m, x, passes):
     """Per-launch records of the dominant kernel -> what the roofline object needs: launches, summed and union busy time,
     ALGORITHMIC bytes of exactly those launches (algorithmic_bytes(residuals) each), residual scores, the kernel's name."""
@@ -244,6 +274,18 @@ def pass_stats(m, x, passes):
     return {"launches": len(passes), "ms_sum": sum(q["ms"] for q in passes), "ms_union": m.busy_union_ms(passes),
             "bytes": float(sum(alg[q["residuals"]] for q in passes)), "residuals": int(sum(q["residuals"] for q in passes)),
             "kernel": max(names, key=names.get), "kernels": names}
+
+
+def cv_roofline(cst):
+    return {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+            "achieved": cst["bytes"] / (cst["ms_sum"] * 1e-3) / 1e9 if cst["launches"] else None,
+            "frac": cst["bytes"] / (cst["ms_sum"] * 1e-3) / 1e9 / HBM_PEAK_GBPS if cst["launches"] else None,
+            "kernel": cst["kernel"], "kernel_ms": cst["ms_sum"] / max(cst["launches"], 1),
+            "algorithmic_bytes_per_launch": cst["bytes"] / max(cst["launches"], 1),
+            "note": "sum of algorithmic_bytes(residuals of the launch) / sum of HIP-event durations; the two lock-step lanes' passes "
+                    "overlap, so the sum exceeds the union (and may exceed the wall time). A fused pass streams X once for up to 18 "
+                    "residuals and is bound by the matrix pipe under the power cap, not by HBM: wider passes LOWER this fraction while "
+                    "the cost per residual falls (xtv_kernel_ms_per_residual_scored; DESIGN.md 3.1b)"}
 
 
 def main():
@@ -266,14 +308,14 @@ def main():
     if a.dry_run:
         sys.stdout.write(json.dumps({"dry_run": True, "rank": rank, "local_rank": local, "world_size": world,
                                      "master_addr": os.environ.get("MASTER_ADDR"), "master_port": os.environ.get("MASTER_PORT"),
-                                     "n_gpus": a.gpus}) + "\n")      # one write per rank: the ranks share the launcher's pipe
-        sys.stdout.flush()
+                                     "n_gpus": a.gpus, "workload": "configs[2], one fit" + (", column-sharded" if world > 1 else "")}) + "\n")
+        sys.stdout.flush()      # one write per rank: the ranks share the launcher's pipe
         return
-    mode = a.mode if a.mode != "auto" else ("fit" if world == 1 else "cv")
+    mode = "fit" if a.mode == "auto" else a.mode
     if a.steps is None:
-        a.steps = 100 if mode in ("fit", "replicas") else 5
+        a.steps = 100
     if a.warmup is None:
-        a.warmup = 5 if mode in ("fit", "replicas") else 1
+        a.warmup = 5
     import torch
     import torch.distributed as dist
 
@@ -281,7 +323,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # MIH_BENCH_BACKEND=gloo + MIH_BENCH_ONE_DEVICE=1: multi-rank smoke test on a single-GPU box
     backend = os.environ.get("MIH_BENCH_BACKEND", "nccl")
-    if os.environ.get("MIH_BENCH_ONE_DEVICE"):
+    one_device = bool(os.environ.get("MIH_BENCH_ONE_DEVICE"))
+    if one_device:
         local = 0
     torch.cuda.set_device(local)
     if world > 1:
@@ -290,12 +333,14 @@ def main():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     import mendeliht_amd as m
+    from mendeliht_amd import dist as D
     if not os.path.exists(m.library_path()):       # fresh checkout: compile the HIP library first
         if rank == 0:
             import __graft_entry__
             __graft_entry__.build()
         if world > 1:
             dist.barrier()
+    tdev = "cuda" if backend == "nccl" and world > 1 else "cpu"
 
     def barrier():
         if world > 1:
@@ -304,121 +349,59 @@ def main():
     def max_over_ranks(v):
         if world == 1:
             return v
-        t = torch.tensor([v], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        t = torch.tensor([v], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
+
+    def sum_over_ranks(arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        if world == 1:
+            return arr
+        t = torch.from_numpy(arr.copy()).to(tdev)
+        dist.all_reduce(t)
+        return t.cpu().numpy()
+
+    def gather_rows(row):
+        """every rank's list of floats, as a list of lists on every rank"""
+        if world == 1:
+            return [list(row)]
+        t = torch.tensor(row, dtype=torch.float64, device=tdev)
+        allr = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(allr, t)
+        return [q.cpu().tolist() for q in allr]
 
     n, p, k = a.n, a.p, a.k
     if a.variant >= 0:
         m.probe_set(variant=a.variant)                      # raises unless the measurement build is loaded
-    seed = 2024 + (rank if mode == "replicas" else 0)       # cv: identical replicas of X on every rank
+    sharded = mode == "fit" and world > 1
+    seed = 2024 + (rank if mode == "replicas" else 0)
+    lo, cnt = D.column_block(p, rank, world) if sharded else (0, p)
     t_gen = time.perf_counter()
-    x = m.SnpLinAlg.synthetic(n, p, seed=seed, device=local)
+    x = m.SnpLinAlg.synthetic(n, cnt, seed=seed, device=local, col_offset=lo)     # this rank's block of the SAME matrix (keyed by global column)
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t_gen
 
-    if mode == "cv":
-        # ---- BASELINE configs[3], strong-scaled over the ranks ---------------------------------------------------------
-        from mendeliht_amd import dist as D
-        yb, folds = cv_problem(m, x, n, p)
-        path = range(1, 21)
-
-        def one_cv():
-            t0 = time.perf_counter()
-            _, raw = m.cv_iht(yb, x, None, path=path, q=5, folds=folds, verbose=False, return_raw=True, rank=rank, world=world,
-                              d=m.Bernoulli(), l=m.LogitLink())
-            t1 = time.perf_counter()
-            tot = D.gather_losses(raw)                      # the path's one exchange: all-gather of the held-out losses
-            return tot, t1 - t0, time.perf_counter() - t1
-        for _ in range(a.warmup):
-            one_cv()
-        m.profile_read(x, reset=True)
-        m.profile_counters(x, reset=True)
-        m.profile_enable(x, True)
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        t_fit = t_gather = 0.0
-        for _ in range(a.steps):
-            tot, tf, tg = one_cv()
-            t_fit += tf
-            t_gather += tg
-        torch.cuda.synchronize()
-        barrier()
-        elapsed = max_over_ranks(time.perf_counter() - t0)
-        m.profile_enable(x, False)
-        st = pass_stats(m, x, m.profile_passes(x, reset=True))
-        cnt = m.profile_counters(x, reset=True)
-        stats = torch.tensor([st["launches"], st["ms_sum"], st["ms_union"], st["bytes"], st["residuals"], cnt["scores"], cnt["fits"],
-                              1e3 * t_gather, 1e3 * t_fit],
-                             dtype=torch.float64, device="cuda" if backend == "nccl" and world > 1 else "cpu")
-        if world > 1:
-            allst = [torch.empty_like(stats) for _ in range(world)]
-            dist.all_gather(allst, stats)
-            allst = [q.cpu().tolist() for q in allst]
-            names = [None] * world
-            dist.all_gather_object(names, st["kernels"])
-        else:
-            allst = [stats.tolist()]
-            names = [st["kernels"]]
-        if rank == 0:
-            mse = np.zeros(20)
-            ninfold = np.bincount(folds - 1, minlength=5)
-            for j in range(5):
-                mse += tot[j] * ninfold[j] / n               # meanloss (cross_validation.jl:304-320)
-            K = a.steps
-            launches = sum(q[0] for q in allst)
-            ms_sum = sum(q[1] for q in allst)
-            nbytes = sum(q[3] for q in allst)
-            scores = sum(q[5] for q in allst)               # IHT iterations incl. the initial score of every fit, all ranks, all steps
-            fits = sum(q[6] for q in allst)
-            kern = {}
-            for d_ in names:
-                for kn, c in d_.items():
-                    kern[kn] = kern.get(kn, 0) + c
-            out = {
-                "metric": METRIC,
-                "value": scores / elapsed, "unit": "iterations/s",
-                "n_gpus": world, "steps": K, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / K,
-                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
-                "config": {"workload": f"cv_iht Bernoulli/Logit path=1:20, 5 folds on synthetic SnpArray n={n} p={p} (BASELINE configs[3]): "
-                                       f"100 (fold,k) fits per step sharded over {world} ranks (mih_cv_assignment), identical X replica per GPU, "
-                                       "ONE all-gather of the held-out losses per step inside the timed region "
-                                       "(cross_validation.jl:98-121); value = IHT iterations of all fits per second "
-                                       "(an iteration = one residual score; up to 15 fits share one fused X'R pass)",
-                           "n": n, "p": p, "path": "1:20", "folds": 5, "generator_s": round(t_gen, 2), "best_k": int(np.argmin(mse)) + 1,
-                           "cv_iht_s": elapsed / K, "fits_per_s": fits / elapsed, "fits_per_step": fits / K,
-                           "iterations_per_step": scores / K,
-                           "compare_with": "the N=1 line's cv_iht object (same workload on one GPU: cv_iht.iterations_per_s, "
-                                           "cv_iht.fits_per_s); the N=1 `value` is the single-fit workload configs[2]"},
-                "per_rank": [{"rank": i, "fits_per_step": q[6] / K, "iterations_per_step": q[5] / K, "fused_passes_per_step": q[0] / K,
-                              "xtv_kernel_ms_per_step": q[1] / K, "xtv_busy_union_ms_per_step": q[2] / K,
-                              "cv_iht_ms_per_step": q[8] / K, "gather_ms_per_step": q[7] / K} for i, q in enumerate(allst)],
-                "fused_passes_per_step_total": launches / K,
-                "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None},
-            }
-            if launches:
-                out["roofline"].update(
-                    achieved=nbytes / (ms_sum * 1e-3) / 1e9, frac=nbytes / (ms_sum * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                    kernel=max(kern, key=kern.get), kernels=kern, kernel_ms=ms_sum / launches, launches=int(launches),
-                    algorithmic_bytes_per_launch=nbytes / launches, residuals_per_launch=sum(q[4] for q in allst) / launches,
-                    note="measured: sum over the launches of all ranks of algorithmic_bytes(residuals of that launch) / sum of their "
-                         "HIP-event durations; the fused passes carry 1 to 15 residuals each (kernels = launches per dispatched kernel)")
-            print(json.dumps(out), flush=True)
-        del x
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
-
-    # ---- BASELINE configs[2]: one fit, step = iht_one_step! ---------------------------------------------------------------
-    # phenotype: y = X beta + 1 + N(0,1), k true effects ~ N(0,1)  (simulate_utilities.jl:215-228)
+    # ---- BASELINE configs[2]: one fit, step = iht_one_step! --------------------------------------------------------------
+    # phenotype: y = X beta + 1 + N(0,1), k true effects ~ N(0,1)  (simulate_utilities.jl:215-228); replicated on every rank
     rng = np.random.default_rng(2025 + (rank if mode == "replicas" else 0))
     supp = np.sort(rng.choice(p, size=k, replace=False))
     beta = rng.standard_normal(k)
-    y = x.xv_sparse(supp, beta) + 1.0 + rng.standard_normal(n)
+    mine = (supp >= lo) & (supp < lo + cnt)
+    xb = x.xv_sparse(supp[mine] - lo, beta[mine])
+    if sharded:
+        xb = sum_over_ranks(xb)                             # set-up, untimed: the planted X beta over all shards
+    y = xb + 1.0 + rng.standard_normal(n)
 
-    sess = m.IHTSession(y, x, None, k=k, d=m.Normal(), l=m.IdentityLink())
+    comm = None
+    exchange = None
+    if sharded:
+        # the library's own RCCL communicator (one GPU per rank); on the one-GPU smoke box the torch.distributed callbacks over
+        # gloo -- or, with MENDELIHT_RCCL_LIB pointing at tests/libfake_rccl.so, the same native code over the stand-in
+        native = backend == "nccl" or bool(os.environ.get("MENDELIHT_RCCL_LIB"))
+        comm = D.NativeComm(lo, p, device=local) if native else D.ColumnComm(lo, p, device=local)
+        exchange = ("native RCCL inside the library (mih_comm_create_rccl: ncclAllReduce / ncclAllGather on a private stream)" if native
+                    else f"torch.distributed callbacks ({backend})")
+    sess = m.IHTSession(y, x, None, k=k, d=m.Normal(), l=m.IdentityLink(), comm=comm)
     for _ in range(a.warmup):
         sess.step()
     m.profile_read(x, reset=True)
@@ -432,15 +415,21 @@ def main():
     elapsed = max_over_ranks(time.perf_counter() - t0)
     m.profile_enable(x, False)
     st = pass_stats(m, x, m.profile_passes(x, reset=True))
-    xtv_ms, launches = st["ms_sum"], st["launches"]
 
     bhat, _ = sess.model()
-    recovered = int(np.intersect1d(np.flatnonzero(bhat), supp).size)
+    found = float(np.intersect1d(np.flatnonzero(bhat) + lo, supp).size)
+    recovered = int(sum_over_ranks([found])[0]) if sharded else int(found)
     sess.close()
+    if comm is not None and hasattr(comm, "close"):
+        comm.close()                                        # collectively, while every rank is alive
+    rows = gather_rows([st["launches"], st["ms_sum"], st["bytes"], float(cnt)]) if sharded else [[st["launches"], st["ms_sum"], st["bytes"], float(cnt)]]
+    kernel_name = st["kernel"]
+    failures = []
 
+    out = None
     if rank == 0:
         traffic_src = None
-        if a.traffic_bytes is None:      # PMC traffic comes from a separate rocprofv3 pass of this command (profiles/)
+        if a.traffic_bytes is None and world == 1:      # PMC traffic comes from a separate rocprofv3 pass of this command (profiles/)
             try:
                 t = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
                 if t["workload"] == {"n": n, "p": p} and t["kernel"] == st["kernel"]:
@@ -449,73 +438,154 @@ def main():
                                    "not collected by this run)")
             except (OSError, KeyError, ValueError):
                 pass
-        else:
+        elif a.traffic_bytes is not None:
             traffic_src = "--traffic-bytes"
-        alg_bytes = st["bytes"] / launches if launches else x.algorithmic_bytes(1)
-        kern_ms = xtv_ms / max(launches, 1)
+        launches = sum(r[0] for r in rows)
+        ms_sum = sum(r[1] for r in rows)
+        nbytes = sum(r[2] for r in rows)
+        alg_bytes = nbytes / launches if launches else x.algorithmic_bytes(1)
+        kern_ms = ms_sum / max(launches, 1)                # per launch of ONE rank (each rank streams its own columns)
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if launches else 0.0
+        nfit = world if mode == "replicas" else 1
         out = {
             "metric": METRIC,
-            "value": world * a.steps / elapsed,
+            "value": nfit * a.steps / elapsed,
             "unit": "iterations/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if mode == "replicas" else "strong",
             "vs_baseline": None,
             "dtype": DTYPE,
             "data": "synthetic",
             "config": {"workload": f"iht on synthetic SnpArray n={n} p={p} k={k} Normal/Identity (BASELINE configs[2])"
-                                   + (", one independent replica per GPU" if world > 1 else ""),
+                                   + (f": ONE fit, SNP columns sharded over {world} GPUs" if sharded else "")
+                                   + (", one independent replica per GPU" if mode == "replicas" and world > 1 else ""),
                        "n": n, "p": p, "k": k, "xtv_variant": a.variant, "generator_s": round(t_gen, 2),
                        "backtracks_in_timed_steps": nbt, "true_effects_recovered": f"{recovered}/{k}",
-                       "final_logl": logl, "host_and_small_kernels_ms_per_step": 1e3 * elapsed / a.steps - kern_ms},
+                       "final_logl": logl, "host_small_kernels_and_exchange_ms_per_step": 1e3 * elapsed / a.steps - kern_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": a.traffic_bytes, "traffic_source": traffic_src,
-                         "kernel": st["kernel"], "kernel_ms": kern_ms, "launches": launches,
+                         "kernel": kernel_name, "kernel_ms": kern_ms, "launches": int(launches),
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
-        gpu_fits_per_s = None
-        if world == 1 and not a.no_cv:
-            # configs[3] on this one GPU (the N>1 mode's workload at N=1), same matrix
-            yb, folds = cv_problem(m, x, n, p)
+        if sharded:
+            out["config"].update(columns_per_rank=[int(r[3]) for r in rows], exchange=exchange,
+                                 exchanges_per_iteration="two all-reduces of an n-vector (X_S b_S of update_xb!, X_S g_S of iht_stepsize!), one "
+                                                         "all-gather of k top-k candidates per rank (project_k!), a few scalars")
+            out["roofline"]["note"] = (f"per GPU: every rank's launches stream its own {cnt} of {p} columns; algorithmic bytes and HIP-event "
+                                       "durations pooled over the launches of all ranks")
+            out["per_rank"] = [{"rank": i, "columns": int(r[3]), "xtv_launches": int(r[0]), "xtv_kernel_ms": r[1] / max(r[0], 1),
+                                "xtv_GBps": r[2] / max(r[1], 1e-9) / 1e6} for i, r in enumerate(rows)]
+        if mode != "replicas" and recovered < 0.99 * k:
+            failures.append(f"the fit recovered {recovered} of {k} planted effects (< 99 %)")
+
+    # ---- secondary: BASELINE configs[3] on full replicas of X (the path's natural shard), with its own one-GPU reference ----
+    gpu_fits_per_s = None
+    run_cv = mode == "fit" and not a.no_cv
+    if run_cv and one_device and world > 1:
+        _free, tot = torch.cuda.mem_get_info()
+        if world * (p * ((n + 3) // 4)) * 1.3 > tot:             # the ranks share ONE device: full replicas may not fit beside each other
+            run_cv = False
+            if rank == 0:
+                out["cv_iht"] = {"skipped": f"{world} full replicas of X do not fit the one shared device of this smoke run"}
+    if run_cv:
+        if sharded:
+            del x
+            import gc
+            gc.collect()
+            x = m.SnpLinAlg.synthetic(n, p, seed=2024, device=local)          # every rank: the whole matrix
+            torch.cuda.synchronize()
+        yb, folds = cv_problem(m, x, n, p)
+        path = range(1, 21)
+
+        def one_cv(rk, wd, reduce):
+            t0 = time.perf_counter()
+            mse, raw = m.cv_iht(yb, x, None, path=path, q=5, folds=folds, verbose=False, return_raw=True, rank=rk, world=wd,
+                                reduce=reduce, d=m.Bernoulli(), l=m.LogitLink())
+            return mse, raw, time.perf_counter() - t0
+
+        # (1) the whole cross-validation on ONE GPU: the N = 1 line's object, and the in-run reference of an N > 1 line
+        solo = None
+        if rank == 0:
+            one_cv(0, 1, None)                                  # warm-up: first-call work (worker streams, workspaces out of the reserve)
             m.profile_read(x, reset=True)
             m.profile_counters(x, reset=True)
             m.profile_enable(x, True)
-            t0 = time.perf_counter()
-            mse, raw = m.cv_iht(yb, x, None, path=range(1, 21), q=5, folds=folds, verbose=False, return_raw=True,
-                                d=m.Bernoulli(), l=m.LogitLink())
-            dt = time.perf_counter() - t0
+            mse1, raw1, dt1 = one_cv(0, 1, None)
             m.profile_enable(x, False)
             cst = pass_stats(m, x, m.profile_passes(x, reset=True))
-            cnt = m.profile_counters(x, reset=True)
-            gpu_fits_per_s = 100.0 / dt
-            out["cv_iht"] = {"workload": "cv_iht Bernoulli/Logit path=1:20, 5 folds (BASELINE configs[3]), all 100 fits on this GPU",
-                             "seconds": dt, "cv_iht_s": dt, "fits": int(np.count_nonzero(raw)), "fits_per_s": gpu_fits_per_s,
-                             "iterations": cnt["scores"], "iterations_per_s": cnt["scores"] / dt, "best_k": int(np.argmin(mse)) + 1,
-                             "fused_passes": cst["launches"], "residuals_scored_by_passes": cst["residuals"],
-                             "xtv_busy_union_ms": cst["ms_union"], "xtv_kernel_ms_sum_over_lanes": cst["ms_sum"],
-                             "xtv_kernel_ms_per_residual_scored": cst["ms_sum"] / max(cst["residuals"], 1),
-                             "lockstep": cnt, "kernels": cst["kernels"],
-                             "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
-                                          "achieved": cst["bytes"] / (cst["ms_sum"] * 1e-3) / 1e9 if cst["launches"] else None,
-                                          "frac": cst["bytes"] / (cst["ms_sum"] * 1e-3) / 1e9 / HBM_PEAK_GBPS if cst["launches"] else None,
-                                          "kernel": cst["kernel"], "kernel_ms": cst["ms_sum"] / max(cst["launches"], 1),
-                                          "algorithmic_bytes_per_launch": cst["bytes"] / max(cst["launches"], 1),
-                                          "note": "sum of algorithmic_bytes(residuals of the launch) / sum of HIP-event durations; the two "
-                                                  "lock-step lanes' passes overlap, so the sum exceeds the union (and may exceed the wall time). "
-                                                  "A fused pass streams X once for up to 18 residuals and is bound by the matrix pipe under the "
-                                                  "power cap, not by HBM: wider passes LOWER this fraction while the cost per residual falls "
-                                                  "(xtv_kernel_ms_per_residual_scored; DESIGN.md 3.1b)"}}
+            cnt1 = m.profile_counters(x, reset=True)
+            gpu_fits_per_s = 100.0 / dt1
+            best_k = int(np.argmin(mse1)) + 1
+            solo = {"workload": "cv_iht Bernoulli/Logit path=1:20, 5 folds (BASELINE configs[3]), all 100 fits on ONE GPU",
+                    "seconds": dt1, "cv_iht_s": dt1, "warmup_runs": 1, "fits": int(np.count_nonzero(raw1)), "fits_per_s": gpu_fits_per_s,
+                    "iterations": cnt1["scores"], "iterations_per_s": cnt1["scores"] / dt1,
+                    "initial_scores": cnt1["init_scores"], "best_k": best_k,
+                    "fused_passes": cst["launches"], "residuals_scored_by_passes": cst["residuals"],
+                    "xtv_busy_union_ms": cst["ms_union"], "xtv_kernel_ms_sum_over_lanes": cst["ms_sum"],
+                    "xtv_kernel_ms_per_residual_scored": cst["ms_sum"] / max(cst["residuals"], 1),
+                    "lockstep": cnt1, "kernels": cst["kernels"], "roofline": cv_roofline(cst)}
+            if (n, p) == (500_000, 1_000_000) and best_k != CV_PLANTED_K:
+                failures.append(f"cv_iht selected k = {best_k}, the planted model has {CV_PLANTED_K} effects")
+        if world == 1:
+            out["cv_iht"] = solo
+        else:
+            # (2) the same cross-validation over the N ranks: (fold, k) combinations dealt out by mih_cv_assignment, one gather
+            native_cv = backend == "nccl" or bool(os.environ.get("MENDELIHT_RCCL_LIB"))
+            gcomm = D.NativeComm(0, 1, device=local) if native_cv else None
+            reduce = D.gather_losses_native(gcomm) if native_cv else D.gather_losses
+            barrier()
+            one_cv(rank, world, reduce)                         # warm-up (first-call workspaces on the other ranks)
+            m.profile_read(x, reset=True)
+            m.profile_counters(x, reset=True)
+            m.profile_enable(x, True)
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(max(1, a.cv_steps)):
+                mseN, rawN, _dt = one_cv(rank, world, reduce)
+            torch.cuda.synchronize()
+            barrier()
+            dtN = max_over_ranks(time.perf_counter() - t0) / max(1, a.cv_steps)
+            m.profile_enable(x, False)
+            cstN = pass_stats(m, x, m.profile_passes(x, reset=True))
+            cntN = m.profile_counters(x, reset=True)
+            if gcomm is not None:
+                gcomm.close()
+            rowsN = gather_rows([cstN["launches"], cstN["ms_sum"], cstN["bytes"], cstN["residuals"], cntN["scores"], cntN["fits"]])
+            if rank == 0:
+                K = max(1, a.cv_steps)
+                same = bool(np.array_equal(rawN, raw1))
+                out["cv_iht"] = {
+                    "workload": f"cv_iht Bernoulli/Logit path=1:20, 5 folds (BASELINE configs[3]): 100 (fold,k) fits sharded over {world} ranks "
+                                "(mih_cv_assignment), identical X replica per GPU, ONE gather of the held-out losses per run inside the "
+                                "timed region (cross_validation.jl:98-121)",
+                    "scaling": "strong", "cv_iht_s": dtN, "one_gpu_s": solo["cv_iht_s"], "cv_speedup": solo["cv_iht_s"] / dtN,
+                    "fits_per_s": 100.0 / dtN, "iterations_per_s": sum(r[4] for r in rowsN) / K / dtN,
+                    "best_k": int(np.argmin(mseN)) + 1, "losses_equal_one_gpu_run_bit_for_bit": same,
+                    "gather": "mih_cv_allgather (ncclAllGather inside the library)" if native_cv else f"torch.distributed all-gather ({backend})",
+                    "per_rank": [{"rank": i, "fits": r[5] / K, "iterations": r[4] / K, "fused_passes": r[0] / K,
+                                  "xtv_kernel_ms": r[1] / K} for i, r in enumerate(rowsN)],
+                    "one_gpu": solo,
+                }
+                if not same:
+                    failures.append("the losses of the sharded cross-validation differ from the one-GPU run")
+    if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"], cores = cpu_baseline(m, n, p, k, seed, a.cpu_seconds)
             if gpu_fits_per_s is not None:
                 out["cpu_baseline_cv"] = cpu_baseline_cv(m, n, p, seed, cores, gpu_fits_per_s)
+        if failures:
+            out["failed"] = failures
         print(json.dumps(out), flush=True)
+    nfail = int(sum_over_ranks([float(len(failures))])[0]) if world > 1 else len(failures)
     del x
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if nfail:
+        sys.exit(1)
 
 
 if __name__ == "__main__":
