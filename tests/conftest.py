@@ -23,6 +23,49 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# ---- randomized sweeps: what was checked, what was set aside (VERDICT r3 "silent skips") ------------------------------------
+SWEEP_TALLIES = []
+
+
+class SweepTally:
+    """Book-keeping of one randomized sweep.  A trial whose trajectory the ORACLE does not reproduce itself under ulp-sized nudges
+    of its input is set aside (no floating-point implementation can be held to it) -- but never silently: every sweep counts
+    what it set aside, fails above a ceiling fixed at the committed seed (a regression that turned a third of the trials
+    "unstable" must not pass), and its tally is printed at the end of the pytest run."""
+
+    def __init__(self, name, ceiling, floor=0):
+        self.name, self.ceiling, self.floor = name, ceiling, floor
+        self.checked, self.aside = 0, []
+
+    def ok(self, count=1):
+        self.checked += count
+
+    def set_aside(self, why, tag, count=1):
+        self.aside.extend([(why, tag)] * count)
+        if os.environ.get("MIH_SWEEP_LOG"):                 # tools/fuzz_parity.py keeps a tally file over many seeds
+            with open(os.environ["MIH_SWEEP_LOG"], "a") as f:
+                f.write(f"unstable {(self.name, why) + tuple(tag)}\n")
+
+    def finish(self):
+        reasons = {}
+        for why, _ in self.aside:
+            reasons[why] = reasons.get(why, 0) + 1
+        line = (f"sweep {self.name}: {self.checked} checked against the oracle, {len(self.aside)} set aside "
+                f"(ceiling {self.ceiling}{', ' + ', '.join(f'{k}: {v}' for k, v in sorted(reasons.items())) if reasons else ''})")
+        SWEEP_TALLIES.append(line)
+        if os.environ.get("MIH_SWEEP_SEED") is None:        # the ceilings belong to the committed seeds; other seeds: tools/fuzz_parity.py
+            assert len(self.aside) <= self.ceiling, line + " -- " + "; ".join(str(t) for _, t in self.aside)
+            assert self.checked >= self.floor, line
+        return line
+
+
+def pytest_terminal_summary(terminalreporter):
+    if SWEEP_TALLIES:
+        terminalreporter.write_sep("-", "randomized sweeps: checked / set aside")
+        for line in SWEEP_TALLIES:
+            terminalreporter.write_line(line)
+
+
 def pytest_collection_modifyitems(config, items):
     """gpu-marked tests are skipped (not failed) on a box without a device or without the built library, so a plain
     `pytest` is green on CPU; `-m gpu` on a GPU box runs them.  The CPU oracle / ABI tests stay unconditional."""

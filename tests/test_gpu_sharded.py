@@ -11,7 +11,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import GOLD, ROOT
+from conftest import GOLD, ROOT, SweepTally
 
 pytestmark = pytest.mark.gpu
 
@@ -40,25 +40,34 @@ def test_sharded_fit_matches_single_process(tmp_path, world):
     assert cv["distributed"] == cv["single"]                               # (fold,k) grid over the ranks == one process
     for oc in others:
         assert oc.pop("cv_grid")["distributed"] == cv["single"]
+    tally = SweepTally(f"column-sharded fits, world {world}", ceiling=1, floor=8)
     for name, case in res["cases"].items():
         sh, one = case["sharded"], case["single"]
-        if name.startswith("random") and max(one["bt"], default=0) >= 3:
-            continue                                                        # a chaotic trajectory (max_step backtracks): rounding decides it
         # the Newton update of the NegBin r stops at |dr| <= 1e-6 (utilities.jl:242): rounding-level
         # differences in xb move r by up to that much, so that case is held to 1e-5 instead of 1e-9
         tb, tl = (1e-5, 1e-6) if name == "negbin_newton" else (1e-9, 1e-11)
-        assert sh["support"] == one["support"], name                       # bit-exact support at fixed k
-        assert sh["iter"] == one["iter"] and sh["bt"] == one["bt"], name
-        np.testing.assert_allclose(sh["beta"], one["beta"], rtol=0, atol=tb, err_msg=name)
-        np.testing.assert_allclose(sh["c"], one["c"], rtol=0, atol=tb, err_msg=name)
-        np.testing.assert_allclose(sh["logl_trace"], one["logl_trace"], rtol=tl, err_msg=name)
-        np.testing.assert_allclose(sh["tol"], one["tol"], rtol=1e4 * tb, atol=1e-12, err_msg=name)
-        assert abs(sh["sigma_g"] - one["sigma_g"]) < tb, name
-        assert sh["choose_fired"] == one["choose_fired"], name
+        try:
+            assert sh["support"] == one["support"], name                       # bit-exact support at fixed k
+            assert sh["iter"] == one["iter"] and sh["bt"] == one["bt"], name
+            np.testing.assert_allclose(sh["beta"], one["beta"], rtol=0, atol=tb, err_msg=name)
+            np.testing.assert_allclose(sh["c"], one["c"], rtol=0, atol=tb, err_msg=name)
+            np.testing.assert_allclose(sh["logl_trace"], one["logl_trace"], rtol=tl, err_msg=name)
+            np.testing.assert_allclose(sh["tol"], one["tol"], rtol=1e4 * tb, atol=1e-12, err_msg=name)
+            assert abs(sh["sigma_g"] - one["sigma_g"]) < tb, name
+            assert sh["choose_fired"] == one["choose_fired"], name
+        except AssertionError:
+            #  a random trajectory that used up max_step backtracks is chaotic -- the order of the shards' partial sums
+            # decides it -- but it is compared first and set aside (counted, with a ceiling) only when it differs
+            if name.startswith("random") and max(one["bt"], default=0) >= 3:
+                tally.set_aside("max_step backtracks: rounding decides the trajectory", (name,))
+                continue
+            raise
+        tally.ok()
         for oc in others:                                                   # every rank returns the same model
             assert oc[name]["sharded"]["support"] == sh["support"], name
             assert oc[name]["sharded"]["beta"] == sh["beta"], name
             assert oc[name]["sharded"]["logl"] == sh["logl"], name
+    tally.finish()
     # the reference's recorded run (docs/src/man/examples.md:230-267) reproduced by the column-SHARDED fit
     g = json.load(open(os.path.join(GOLD, "golden_normal_k7.json")))
     sh = res["cases"]["normal_k7"]["sharded"]
