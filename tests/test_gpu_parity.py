@@ -2171,6 +2171,60 @@ def _config3_problem(mih, n, p, seed=2024):
     return x, yb, hash_folds(n, 5)
 
 
+def test_config3_full_size(mih, oracle):
+    """BASELINE configs[3] at its OWN size (VERDICT r3 "weak" 4): cv_iht Bernoulli/Logit, path = 1:20, 5 folds, all 100 fits on
+    the n = 500 000 x p = 1 000 000 synthetic SnpArray -- the run bench.py times, asserted here.  (1) the cross-validation
+    selects the planted model size; (2) the eight `rank = r, world = 8` shards -- what each GPU of a node runs -- add up to the
+    single-rank loss matrix bit for bit; (3) on the sub-problem of the first 100 000 columns of the SAME matrix (the generator is
+    keyed by (seed, column)) a 3 x 3 grid of held-out losses equals the oracle's (tools/validate_large.py promoted to a test;
+    the oracle needs ~0.4 s per X'r pass there, so the grid is what the CPU finishes in about a minute)."""
+    n, p = 500_000, 1_000_000
+    free_b = __import__("torch").cuda.mem_get_info()[0]
+    if free_b < 170e9:
+        pytest.skip("needs 170 GB of free HBM")
+    x, yb, folds = _config3_problem(mih, n, p)
+    path = range(1, 21)
+    mse, raw = mih.cv_iht(yb, x, None, path=path, q=5, folds=folds, verbose=False, return_raw=True, d=mih.Bernoulli(), l=mih.LogitLink())
+    assert np.count_nonzero(raw) == 100 and np.all(raw > 0)
+    assert int(np.argmin(mse)) + 1 == 10                                    # ten planted effects (bench.py asserts the same)
+    total = np.zeros_like(raw)
+    for r in range(8):
+        part = mih.cv_iht(yb, x, None, path=path, q=5, folds=folds, verbose=False, return_raw=True, d=mih.Bernoulli(), l=mih.LogitLink(),
+                          rank=r, world=8)[1]
+        assert 12 <= np.count_nonzero(part) <= 13
+        assert np.array_equal(part[part != 0], raw[part != 0])
+        total += part
+    assert np.array_equal(total, raw)
+    del x
+    # the first 100 000 columns against the oracle (fewer if the host is short of memory: 12.5 GB of PLINK columns + the oracle's copy)
+    avail = 0
+    for ln in open("/proc/meminfo"):
+        if ln.startswith("MemAvailable"):
+            avail = int(ln.split()[1]) * 1024
+    ps = 100_000 if avail > 60e9 else 40_000
+    xs = mih.SnpLinAlg.synthetic(n, ps, seed=2024)
+    rng = np.random.default_rng(77)
+    supp = np.sort(rng.choice(ps, 10, replace=False))
+    eta = xs.xv_sparse(supp, rng.standard_normal(10) * 0.5)
+    ys = (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float)
+    f3 = hash_folds(n, 3)
+    sub = [5, 10, 15]
+    gm, graw = mih.cv_iht(ys, xs, None, path=sub, q=3, folds=f3, verbose=False, return_raw=True, d=mih.Bernoulli(), l=mih.LogitLink())
+    cols = xs.export_bed()
+    del xs
+    ox = oracle.Mat.from_bed_columns(cols, n)
+    del cols
+    nthreads = oracle.lib().orc_get_threads()
+    oracle.set_threads(16)                                                  # (more OpenMP threads than the container's CPU quota only slow it down)
+    try:
+        om, oraw = oracle.cv_iht(ox, ys, None, path=sub, q=3, folds=f3, dist="bernoulli", link="logit")
+    finally:
+        oracle.set_threads(nthreads)
+    np.testing.assert_allclose(graw, oraw, rtol=1e-4)                       # north_star: 1e-4 for GLM links
+    np.testing.assert_allclose(graw, oraw, rtol=1e-8)                       # what it is
+    np.testing.assert_allclose(gm, om, rtol=1e-8)
+
+
 def test_config3_full_grid_against_oracle(mih, oracle):
     """The EXACT driver shape of BASELINE configs[3]: cv_iht Bernoulli/Logit, path = 1:20, q = 5 = 100
     (fold, k) fits on one rank -- two lock-step lanes of 18 slots (36 fits in flight), the tail hand-over from lane 1 to lane 0
