@@ -216,6 +216,7 @@ typedef struct mih_fit_params {
      *                             eachindex order) of the non-zero entries of B; write ALL n in shuffled order to out.
      *   kind MIH_CHOOSE_SHUFFLE_C `shuffle!(C_nz_idx)` (multivariate.jl:337), called right after _B: the non-zero entries of
      *                             the covariates NOT in zkeep (trait + r * covariate); write all n in shuffled order to out.
+     * An EMPTY list is not handed over (shuffle! of an empty vector draws nothing from the RNG).
      * The library then zeroes what the reference's loop zeroes (multivariate.jl:338-348).  Called on the thread that called
      * mih_fit_iht / mih_session_* / mih_fit_mv (a session keeps the pointer: it must stay valid until mih_session_destroy);
      * a non-zero return aborts the fit with MIH_BAD_ARG.  Ignored by the lock-step

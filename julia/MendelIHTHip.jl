@@ -190,6 +190,7 @@ end
 # list, so the 0-based entries the library passes give the same draw as the reference's 1-based ones.
 function choose_cb(user::Ptr{Cvoid}, kind::Int32, list::Ptr{Int64}, n::Int64, excess::Int64, out::Ptr{Int64})::Cint
     try
+        n == 0 && return Cint(0)        # (the library does not hand over empty lists; unsafe_wrap of a NULL pointer must never happen)
         l = unsafe_wrap(Array, list, n)
         o = kind == 0 ? sample(l, excess, replace=false) : shuffle!(copy(l))
         unsafe_copyto!(out, pointer(o), length(o))

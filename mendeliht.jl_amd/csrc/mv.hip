@@ -511,8 +511,10 @@ struct MvVar {
         for (int l = 0; l < q; ++l) if (!zkeep[l]) for (int i = 0; i < r; ++i) if (C[i + r * l] != 0.0) clist.push_back(i + (int64_t)r * l);
         const int64_t nC = (int64_t)clist.size();
         std::vector<int64_t> bs((size_t)nB, -1), cs((size_t)nC, -1);
-        if (choose_cb(choose_user, MIH_CHOOSE_SHUFFLE_B, B.idx.data(), nB, excess, bs.data()) != 0 ||
-            choose_cb(choose_user, MIH_CHOOSE_SHUFFLE_C, clist.data(), nC, excess, cs.data()) != 0) { set_error("the choose callback failed"); return MIH_BAD_ARG; }
+        //  an empty list is not handed over: its data pointer may be NULL, and shuffle! of an empty vector draws nothing
+        // from the RNG (its loop runs over 2:length), so the caller's RNG state is what the reference's would be
+        if ((nB > 0 && choose_cb(choose_user, MIH_CHOOSE_SHUFFLE_B, B.idx.data(), nB, excess, bs.data()) != 0) ||
+            (nC > 0 && choose_cb(choose_user, MIH_CHOOSE_SHUFFLE_C, clist.data(), nC, excess, cs.data()) != 0)) { set_error("the choose callback failed"); return MIH_BAD_ARG; }
         auto is_perm = [](std::vector<int64_t> a, std::vector<int64_t> b) { std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end()); return a == b; };
         if (!is_perm(bs, B.idx) || !is_perm(cs, clist)) { set_error("the choose callback must return its list in shuffled order"); return MIH_BAD_ARG; }
         std::vector<char> drop((size_t)nB, 0);
