@@ -398,9 +398,21 @@ def main():
         # the library's own RCCL communicator (one GPU per rank); on the one-GPU smoke box the torch.distributed callbacks over
         # gloo -- or, with MENDELIHT_RCCL_LIB pointing at tests/libfake_rccl.so, the same native code over the stand-in
         native = backend == "nccl" or bool(os.environ.get("MENDELIHT_RCCL_LIB"))
-        comm = D.NativeComm(lo, p, device=local) if native else D.ColumnComm(lo, p, device=local)
+        native_error = None
+        if native:
+            try:
+                comm = D.NativeComm(lo, p, device=local)
+            except Exception as e:      # noqa: BLE001 -- e.g. librccl not loadable: every rank falls back together, and the line says so
+                native_error = repr(e)
+            if sum_over_ranks([0.0 if native_error is None else 1.0])[0] > 0:
+                if comm is not None:
+                    comm.close()
+                native, comm = False, None
+        if not native:
+            comm = D.ColumnComm(lo, p, device=local)
         exchange = ("native RCCL inside the library (mih_comm_create_rccl: ncclAllReduce / ncclAllGather on a private stream)" if native
-                    else f"torch.distributed callbacks ({backend})")
+                    else f"torch.distributed callbacks ({backend})"
+                         + (f" -- the library's own communicator could not be created: {native_error}" if native_error else ""))
     sess = m.IHTSession(y, x, None, k=k, d=m.Normal(), l=m.IdentityLink(), comm=comm)
     for _ in range(a.warmup):
         sess.step()
@@ -532,7 +544,7 @@ def main():
             out["cv_iht"] = solo
         else:
             # (2) the same cross-validation over the N ranks: (fold, k) combinations dealt out by mih_cv_assignment, one gather
-            native_cv = backend == "nccl" or bool(os.environ.get("MENDELIHT_RCCL_LIB"))
+            native_cv = native if sharded else (backend == "nccl" or bool(os.environ.get("MENDELIHT_RCCL_LIB")))
             gcomm = D.NativeComm(0, 1, device=local) if native_cv else None
             reduce = D.gather_losses_native(gcomm) if native_cv else D.gather_losses
             barrier()

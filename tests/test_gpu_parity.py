@@ -1117,7 +1117,7 @@ def test_randomized_fits_vs_oracle(mih, oracle):
     rng = np.random.default_rng(int(os.environ.get("MIH_SWEEP_SEED", 20260)))     # other seeds: extended sweeps by hand
     fams = [("normal", "identity", mih.Normal, mih.IdentityLink, 1e-5), ("bernoulli", "logit", mih.Bernoulli, mih.LogitLink, 1e-4),
             ("poisson", "log", mih.Poisson, mih.LogLink, 1e-4)]
-    tally = SweepTally("fits", ceiling=2, floor=12)
+    tally = SweepTally("fits", ceiling=1, floor=13)
     for trial in range(14):
         n = int(rng.integers(60, 2500)); p = int(rng.integers(40, 600)); k = int(rng.integers(1, 10))
         miss = float(rng.choice([0.0, 0.02, 0.1])); q = int(rng.integers(1, 4))
@@ -1235,7 +1235,7 @@ def test_randomized_options_vs_oracle(mih, oracle):
     init_beta, NegativeBinomial with est_r, Gamma / InverseGaussian, non-canonical links -- combined at random, on random
     shapes with missing genotypes, against the oracle on every trajectory the oracle itself reproduces (_unstable)."""
     rng = np.random.default_rng(int(os.environ.get("MIH_SWEEP_SEED", 4242)))
-    tally = SweepTally("options", ceiling=2, floor=9)
+    tally = SweepTally("options", ceiling=1, floor=11)
     for trial in range(12):
         x, ox, y, z, k, kw, okw, both, tol, fam, tag = _options_case(mih, oracle, rng, trial)
 
@@ -1448,7 +1448,7 @@ def test_randomized_multivariate_fits_vs_oracle(mih, oracle):
     """Seeded sweep of multivariate fits: traits r, covariates q (some not kept), k, missingness, train masks,
     init_beta -- against the oracle on every stable trajectory."""
     rng = np.random.default_rng(int(os.environ.get("MIH_SWEEP_SEED", 31337)))
-    tally = SweepTally("multivariate fits", ceiling=2, floor=8)
+    tally = SweepTally("multivariate fits", ceiling=1, floor=9)
     for trial in range(10):
         n = int(rng.integers(150, 1500)); p = int(rng.integers(60, 400)); r = int(rng.integers(2, 6))
         q = int(rng.integers(1, 4)); k = int(rng.integers(2, 14)); miss = float(rng.choice([0.0, 0.03]))
@@ -1597,7 +1597,7 @@ def test_randomized_cv_vs_oracle(mih, oracle):
     rng = np.random.default_rng(int(os.environ.get("MIH_SWEEP_SEED", 777)))
     fams = [("normal", "identity", mih.Normal, mih.IdentityLink, 1e-6), ("bernoulli", "logit", mih.Bernoulli, mih.LogitLink, 1e-5),
             ("poisson", "log", mih.Poisson, mih.LogLink, 1e-5)]
-    tally = SweepTally("cv_iht (entries of the loss matrices)", ceiling=4, floor=100)
+    tally = SweepTally("cv_iht (entries of the loss matrices)", ceiling=2, floor=125)
     for trial in range(6):
         n = int(rng.integers(200, 1600)); p = int(rng.integers(60, 400)); q = int(rng.integers(2, 5))
         od, ol, D, L, tol = fams[int(rng.integers(0, 3))]
@@ -1673,7 +1673,7 @@ def test_randomized_multivariate_cv_vs_oracle(mih, oracle):
     round): traits, covariates (some not kept), folds, paths, missing genotypes, init_beta -- the held-out losses against the
     oracle's sequential fits, entry by entry; entries the oracle does not reproduce itself (_unstable) are set aside."""
     rng = np.random.default_rng(int(os.environ.get("MIH_SWEEP_SEED", 8086)))
-    tally = SweepTally("multivariate cv (entries)", ceiling=2, floor=20)
+    tally = SweepTally("multivariate cv (entries)", ceiling=1, floor=44)
     for trial in range(4):
         n = int(rng.integers(200, 1200)); p = int(rng.integers(60, 300)); r = int(rng.integers(2, 5))
         qz = int(rng.integers(1, 3)); q = int(rng.integers(2, 4))
@@ -1714,7 +1714,7 @@ def test_randomized_model_paths_vs_oracle(mih, oracle):
     rng = np.random.default_rng(int(os.environ.get("MIH_SWEEP_SEED", 6502)))
     fams = [("normal", "identity", mih.Normal, mih.IdentityLink), ("bernoulli", "logit", mih.Bernoulli, mih.LogitLink),
             ("poisson", "log", mih.Poisson, mih.LogLink), ("negbin", "log", mih.NegativeBinomial, mih.LogLink)]
-    tally = SweepTally("model paths (entries)", ceiling=2, floor=15)
+    tally = SweepTally("model paths (entries)", ceiling=1, floor=26)
     for trial in range(5):
         n = int(rng.integers(150, 1500)); p = int(rng.integers(60, 400)); q = int(rng.integers(1, 4))
         od, ol, D, L = fams[int(rng.integers(0, 4))]
