@@ -2519,7 +2519,8 @@ def test_choose_callback_makes_the_references_random_draw(mih, oracle):
         lh, lo = [], []
         rh = m.fit_iht(Y, x, None, k=1, verbose=False, choose=seeded_draw(seed, lh))
         ro = oracle.fit_mv(xo, Y, None, k=1, choose=seeded_draw(seed, lo))
-        assert lh == lo and len(lh) == 2 and rh.choose_fired
+        assert lh == lo and len(lh) >= 1 and rh.choose_fired           # (an empty C_nz_idx is not handed over: shuffle! of it draws nothing)
+        assert all(len(call[1]) > 0 for call in lh)
         np.testing.assert_allclose(rh.beta, ro["B"], rtol=0, atol=1e-10)
         assert rh.iter == ro["iter"]
     # the lock-step drivers apply the deterministic rule (their fits run on the library's own threads): equal to the restatement's
