@@ -121,10 +121,12 @@ static void launch_mv_apply(unsigned nb, hipStream_t s, const double *IN, int64_
 }
 
 // vectorize!(full_b, B, C) after the axpy (multivariate.jl:99-113): full[i + r*j] = eta * df[i][j]
+// The covariate tail full[r*p .. r*p + rq) rides along as a kernel argument (block 0 writes it) instead of a separate copy.
 __global__ void __launch_bounds__(256)
-k_mv_full(const double *__restrict__ DF, int64_t p, int r, double eta, double *__restrict__ full)
+k_mv_full(const double *__restrict__ DF, int64_t p, int r, double eta, double *__restrict__ full, CMat tail, int rq)
 {
     extern __shared__ double tile[];                       // [r][257]: 256 SNPs of every trait plane, read and written coalesced
+    if (blockIdx.x == 0) for (int t = threadIdx.x; t < rq; t += 256) full[(int64_t)r * p + t] = tail.v[t];
     const int64_t j0 = blockIdx.x * 256ll;
     const int cnt = (int)(p - j0 < 256 ? p - j0 : 256);
     for (int i = 0; i < r; ++i)
@@ -287,19 +289,34 @@ struct MvVar {
     {
         if (count > hpin.n) { MIH_HIP(hipStreamSynchronize(s)); MIH_TRY(hpin.alloc(count * 2 + 64, true)); }
         MIH_TRY(readback_words(s, flag, reinterpret_cast<const uint64_t *>(src_dev), reinterpret_cast<uint64_t *>(hpin.p), count));
+        stage.synced();                                     // everything queued before has run: the staging ring's slots are free again
         std::memcpy(dst, hpin.p, sizeof(double) * count);
+        return MIH_OK;
+    }
+    // Two small host arrays reach the device through a slot of a pinned ring and ONE small kernel (HostStage, common.h) instead of two
+    // copy operations; lists that do not fit a slot go the old way.
+    HostStage stage;
+    int upload_pair(const void *a, size_t bytes_a, void *dst_a, const void *b, size_t bytes_b, void *dst_b)
+    {
+        const uint64_t *pin = nullptr;
+        MIH_TRY(stage.put(s, a, bytes_a, b, bytes_b, &pin));
+        if (pin) { stage_to_device(s, pin, reinterpret_cast<uint64_t *>(dst_a), (bytes_a + 7) / 8, reinterpret_cast<uint64_t *>(dst_b), (bytes_b + 7) / 8); return MIH_OK; }
+        const size_t words = (bytes_a + 7) / 8 + (bytes_b + 7) / 8;
+        if (words > upin.n) { MIH_HIP(hipStreamSynchronize(s)); MIH_TRY(upin.alloc(words * 2 + 64)); }
+        else MIH_HIP(hipStreamSynchronize(s));              // (rare path: the one pinned buffer may still be in flight)
+        if (bytes_a) std::memcpy(upin.p, a, bytes_a);
+        if (bytes_b) std::memcpy(upin.p + (bytes_a + 7) / 8, b, bytes_b);
+        if (bytes_a) MIH_HIP(hipMemcpyAsync(dst_a, upin.p, bytes_a, hipMemcpyHostToDevice, s));
+        if (bytes_b) MIH_HIP(hipMemcpyAsync(dst_b, upin.p + (bytes_a + 7) / 8, bytes_b, hipMemcpyHostToDevice, s));
         return MIH_OK;
     }
     int upload_cols_coef(const std::vector<double> &coef)      // sidx <- cols, mcoef <- coef
     {
-        const size_t nc = cols.size(), words = nc + coef.size();
-        if (words > upin.n) { MIH_HIP(hipStreamSynchronize(s)); MIH_TRY(upin.alloc(words * 2 + 64)); }
-        std::memcpy(upin.p, cols.data(), sizeof(int64_t) * nc);
-        std::memcpy(upin.p + nc, coef.data(), sizeof(double) * coef.size());
-        MIH_HIP(hipMemcpyAsync(sidx.p, upin.p, sizeof(int64_t) * nc, hipMemcpyHostToDevice, s));
-        MIH_HIP(hipMemcpyAsync(mcoef.p, upin.p + nc, sizeof(double) * coef.size(), hipMemcpyHostToDevice, s));
-        return MIH_OK;
+        return upload_pair(cols.data(), sizeof(int64_t) * cols.size(), sidx.p, coef.data(), sizeof(double) * coef.size(), mcoef.p);
     }
+    // The step size of the NEXT step is computed at the end of a step (step_tail): everything iht_stepsize! needs -- the support,
+    // df on it, Gamma -- is final then.  What came home: the denominator, for which support, with which factor of Gamma.
+    bool spec_ok = false; double spec_denom = 0.0; std::vector<int64_t> spec_cols; std::vector<double> spec_U;
     DevBuf<int32_t> pairs_s; bool pairs_ok = false, pairs_s_ok = false;      // the index-pair tables (Gram: a <= b; score: (trait, covariate)) go up once
     XtvWork xtv; XvWork xv; TopkWork topk;
     int nb = 0;
@@ -340,7 +357,7 @@ struct MvVar {
             size_t dev = sizeof(double) * (5 * rn + (size_t)q * n + 2 * (size_t)n + (size_t)r * p + (size_t)r * (p + q) + redn + (size_t)kMaxR * kMaxR + 64
                                            + 2 * (size_t)kcap + (size_t)kcap * r) + (size_t)n + sizeof(int32_t) * 2 * (size_t)kMaxR * kMaxR
                          + xv_work_bytes(h, kcap, kcap - 1024) + sizeof(uint32_t) * 2048 + 64 + 16 * ((size_t)kcap + 1025) + 40 * 256;
-            size_t pin = sizeof(uint64_t) * (2 + 2 * ((size_t)kcap + 64) + 16) + 4 * 256;
+            size_t pin = sizeof(uint64_t) * (2 + 2 * ((size_t)kcap + 64) + 16 + HostStage::kSlots * ((size_t)kcap * (r + 1) + 8)) + 6 * 256;
             MIH_TRY(arena.reserve(dev, pin));
         }
         ArenaScope in_arena(&arena);
@@ -349,6 +366,7 @@ struct MvVar {
         MIH_TRY(red.alloc(std::max<size_t>((size_t)nb, (size_t)kMaxR * kMaxR * kRedBlocks))); MIH_TRY(scal.alloc((size_t)kMaxR * kMaxR + 64));
         MIH_TRY(tmpn.alloc(n)); MIH_TRY(mask.alloc(n)); MIH_TRY(pairs.alloc(2 * (size_t)kMaxR * kMaxR));
         MIH_TRY(sidx.alloc(kcap)); MIH_TRY(sval.alloc(kcap)); MIH_TRY(gval.alloc((size_t)kcap * r));
+        MIH_TRY(stage.init((size_t)kcap * (r + 1) + 8));
         if (own_stream) { ArenaScope own_buffers(nullptr); MIH_TRY(xtv_work_init(h, xtv, r, tune)); }
         MIH_TRY(xv_work_init(h, xv, kcap, kcap - 1024)); MIH_TRY(topk_work_init(topk, kcap));
         // Y (r x n) and Z (q x n) column-major -> planes
@@ -471,6 +489,50 @@ struct MvVar {
         hipLaunchKernelGGL(k_mv_dots_final, dim3((unsigned)np_), dim3(64), 0, s, red.p, scal.p);
         return readback(scal.p, np_, df2.data());   // [i + r*l]
     }
+    // The end of a step (or of the initialisation) and the beginning of the next step in ONE host synchronisation (the univariate
+    // step_post_fused, fit.hip): [with_df2: df2 = T1 Z' (score!, multivariate.jl:88-91)], df on the support (gathered on the
+    // device, [trait][column]) and the whole iht_stepsize! of the next step -- X_S df_S straight from the device copy of df_S,
+    // the pivoted Cholesky factor of Gamma, the weighted sum of squares -- are queued back to back and come home in one copy:
+    // [df_S | df2 | sum].  Two synchronisations and three small copies less per iteration than three separate round trips; the
+    // step-size product is wasted only when the fit stops here.  T1 (= Gamma * resid, the pass's input) is read by the df2 dots
+    // before the product overwrites it: same stream.
+    int step_tail(bool with_df2)
+    {
+        const int64_t nc = (int64_t)cols.size();
+        const size_t rq = (size_t)r * q, ncr = (size_t)nc * r;
+        MIH_TRY(ensure_stage(nc));
+        if (ncr + rq + 2 > gval.n) { MIH_HIP(hipStreamSynchronize(s)); MIH_TRY(gval.alloc((ncr + rq + 2) * 2)); }
+        double *d_df2 = gval.p + ncr, *d_sum = gval.p + ncr + rq;
+        if (with_df2) {
+            std::vector<int32_t> pr;
+            for (int l = 0; l < q; ++l) for (int i = 0; i < r; ++i) pr.push_back(i);
+            size_t np_ = pr.size();
+            for (int l = 0; l < q; ++l) for (int i = 0; i < r; ++i) pr.push_back(l);
+            if (!pairs_s_ok) {
+                MIH_TRY(pairs_s.alloc(pr.size()));
+                MIH_HIP(hipMemcpyAsync(pairs_s.p, pr.data(), sizeof(int32_t) * pr.size(), hipMemcpyHostToDevice, s));
+                MIH_HIP(hipStreamSynchronize(s));           // (once per variable: `pr` is a local)
+                pairs_s_ok = true;
+            }
+            hipLaunchKernelGGL(k_mv_dots, dim3(kRedBlocks, (unsigned)np_), dim3(256), 0, s, T1.p, Z.p, n, pairs_s.p, pairs_s.p + np_, red.p);
+            hipLaunchKernelGGL(k_mv_dots_final, dim3((unsigned)np_), dim3(64), 0, s, red.p, d_df2);
+        }
+        spec_U = G;
+        pivoted_chol_triu(spec_U, r);
+        if (nc) {
+            MIH_TRY(upload_pair(cols.data(), sizeof(int64_t) * (size_t)nc, sidx.p, nullptr, 0, nullptr));
+            hipLaunchKernelGGL(k_mv_gather, dim3(nblk(nc * r)), dim3(256), 0, s, DF.p, p, r, sidx.p, nc, gval.p);
+            MIH_TRY(xv_sparse_multi_device(h, xv, sidx.p, gval.p, nc, r, T1.p, s, cols.data()));
+        } else MIH_HIP(hipMemsetAsync(T1.p, 0, sizeof(double) * (size_t)n * r, s));
+        launch_mv_apply((unsigned)nb, s, T1.p, n, r, rmat(spec_U), 1, w.p, (double *)nullptr, red.p);
+        hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, s, red.p, nb, 1, d_sum);
+        std::vector<double> home(ncr + rq + 1);
+        MIH_TRY(readback(gval.p, ncr + rq + 1, home.data()));
+        dfcols.assign(home.begin(), home.begin() + (std::ptrdiff_t)ncr);
+        if (with_df2) for (size_t t = 0; t < rq; ++t) df2[t] = home[ncr + t];
+        spec_denom = home[ncr + rq]; spec_cols = cols; spec_ok = true;
+        return MIH_OK;
+    }
     int gather_df_cols()
     {
         int64_t nc = (int64_t)cols.size();
@@ -487,6 +549,15 @@ struct MvVar {
         int64_t nc = (int64_t)cols.size();
         double numer = 0.0;
         for (double x : dfcols) numer += x * x;
+        if (spec_ok && spec_cols == cols) {                           // computed behind the X'R pass of the previous step (step_tail)
+            spec_ok = false;
+            G = spec_U;                                               // Gamma is left holding U, as below
+            double e = numer / spec_denom;
+            if (std::isinf(e) || std::isnan(e)) e = 1e-8;
+            *eta = e;
+            return MIH_OK;
+        }
+        spec_ok = false;
         if (nc) {
             if ((size_t)nc * r > mcoef.n) { MIH_HIP(hipStreamSynchronize(s)); MIH_TRY(mcoef.alloc((size_t)nc * r * 2)); }
             MIH_TRY(upload_cols_coef(dfcols));                       // dfcols is [trait][column]
@@ -559,10 +630,10 @@ struct MvVar {
         return MIH_OK;
     }
     // project the r(p+q) buffer and split survivors; tail = covariate part of the vector
-    int project_full(Sparse &snp, std::vector<double> &ctail, std::vector<uint8_t> &cnz)
+    int project_full(Sparse &snp, std::vector<double> &ctail, std::vector<uint8_t> &cnz, bool zero_in_place = true)
     {
         std::vector<int64_t> si; std::vector<double> sv;
-        MIH_TRY(topk_project_device(full.p, (int64_t)r * (p + q), k + zkeepn, topk, s, si, sv));
+        MIH_TRY(topk_project_device(full.p, (int64_t)r * (p + q), k + zkeepn, topk, s, si, sv, zero_in_place));
         snp.clear(); cnz.assign((size_t)r * q, 0); ctail.assign((size_t)r * q, 0.0);
         for (size_t t = 0; t < si.size(); ++t) {
             if (si[t] < (int64_t)r * p) { snp.idx.push_back(si[t]); snp.val.push_back(sv[t]); }
@@ -573,21 +644,19 @@ struct MvVar {
     // _iht_gradstep! + project_k!(v) (multivariate.jl:99-127) from base (Bb, Cb)
     int gradstep(const Sparse &Bb, const std::vector<double> &Cb, double eta)
     {
-        hipLaunchKernelGGL(k_mv_full, dim3(nblk(p)), dim3(256), sizeof(double) * 257 * (size_t)r, s, DF.p, p, r, eta, full.p);
-        MIH_TRY(ensure_stage((int64_t)Bb.idx.size()));
-        if (!Bb.idx.empty()) {
-            MIH_HIP(hipMemcpyAsync(sidx.p, Bb.idx.data(), sizeof(int64_t) * Bb.idx.size(), hipMemcpyHostToDevice, s));
-            MIH_HIP(hipMemcpyAsync(sval.p, Bb.val.data(), sizeof(double) * Bb.val.size(), hipMemcpyHostToDevice, s));
-            hipLaunchKernelGGL(k_mv_scatter, dim3(nblk((int64_t)Bb.idx.size())), dim3(256), 0, s, sidx.p, sval.p, (int64_t)Bb.idx.size(), DF.p, p, r, eta, full.p);
-        }
         std::vector<double> cn((size_t)r * q), tail((size_t)r * q);
         for (int l = 0; l < q; ++l) for (int i = 0; i < r; ++i) {
             cn[i + r * l] = std::fma(eta, df2[i + r * l], Cb[i + r * l]);
             tail[i + r * l] = zkeep[l] ? std::numeric_limits<double>::infinity() : cn[i + r * l];
         }
-        MIH_HIP(hipMemcpyAsync(full.p + (size_t)r * p, tail.data(), sizeof(double) * r * q, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_mv_full, dim3(nblk(p)), dim3(256), sizeof(double) * 257 * (size_t)r, s, DF.p, p, r, eta, full.p, cmat(tail), r * q);
+        MIH_TRY(ensure_stage((int64_t)Bb.idx.size()));
+        if (!Bb.idx.empty()) {
+            MIH_TRY(upload_pair(Bb.idx.data(), sizeof(int64_t) * Bb.idx.size(), sidx.p, Bb.val.data(), sizeof(double) * Bb.val.size(), sval.p));
+            hipLaunchKernelGGL(k_mv_scatter, dim3(nblk((int64_t)Bb.idx.size())), dim3(256), 0, s, sidx.p, sval.p, (int64_t)Bb.idx.size(), DF.p, p, r, eta, full.p);
+        }
         Sparse snp; std::vector<double> ct; std::vector<uint8_t> cnz;
-        MIH_TRY(project_full(snp, ct, cnz));
+        MIH_TRY(project_full(snp, ct, cnz, /*zero_in_place=*/false));       // only the survivor lists are used
         B = snp;
         for (int l = 0; l < q; ++l) for (int i = 0; i < r; ++i)
             C[i + r * l] = zkeep[l] ? cn[i + r * l] : (cnz[i + r * l] ? ct[i + r * l] : 0.0);
@@ -625,10 +694,9 @@ struct MvVar {
         for (auto &x : C) x = x < -2.0 ? -2.0 : (x > 2.0 ? 2.0 : x);
         C0 = C;
         // project_k!(v): vec(B) with the covariate tail (Inf for kept covariates), top-(k + zkeepn)
-        hipLaunchKernelGGL(k_mv_full, dim3(nblk(p)), dim3(256), sizeof(double) * 257 * (size_t)r, s, betad.p, p, r, 1.0, full.p);
         std::vector<double> tail((size_t)r * q);
         for (int l = 0; l < q; ++l) for (int i = 0; i < r; ++i) tail[i + r * l] = zkeep[l] ? std::numeric_limits<double>::infinity() : C[i + r * l];
-        MIH_HIP(hipMemcpyAsync(full.p + (size_t)r * p, tail.data(), sizeof(double) * r * q, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_mv_full, dim3(nblk(p)), dim3(256), sizeof(double) * 257 * (size_t)r, s, betad.p, p, r, 1.0, full.p, cmat(tail), r * q);
         Sparse snp; std::vector<double> ct; std::vector<uint8_t> cnz;
         MIH_TRY(project_full(snp, ct, cnz));
         B = snp;
@@ -648,7 +716,7 @@ struct MvVar {
     int init_pre(const uint8_t *train)
     {
         if (k < 1) { set_error("Multivariate IHT requires k >= 1!"); return MIH_BAD_ARG; }
-        B.clear(); B0.clear(); best_B.clear(); cols.clear(); dfcols.clear();
+        B.clear(); B0.clear(); best_B.clear(); cols.clear(); dfcols.clear(); spec_ok = false;
         std::fill(C.begin(), C.end(), 0.0); C0 = C; best_C = C; std::fill(df2.begin(), df2.end(), 0.0);
         for (int l = 0; l < q; ++l) idc[l] = zkeep[l];
         std::fill(G.begin(), G.end(), 0.0);
@@ -672,12 +740,11 @@ struct MvVar {
     int init_post()
     {
         MIH_TRY(score_post());
-        if (init_beta) return gather_df_cols();      // the support stays the one project_k!(v) chose; df stays dense
+        if (init_beta) return step_tail(false);      // the support stays the one project_k!(v) chose; df stays dense
         // vectorize!(full_b, df, df2); project_k!; unvectorize! (:438-440): df replaced by its projection
-        hipLaunchKernelGGL(k_mv_full, dim3(nblk(p)), dim3(256), sizeof(double) * 257 * (size_t)r, s, DF.p, p, r, 1.0, full.p);
         std::vector<double> tail((size_t)r * q);
         for (int l = 0; l < q; ++l) for (int i = 0; i < r; ++i) tail[i + r * l] = zkeep[l] ? std::numeric_limits<double>::infinity() : df2[i + r * l];
-        MIH_HIP(hipMemcpyAsync(full.p + (size_t)r * p, tail.data(), sizeof(double) * r * q, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_mv_full, dim3(nblk(p)), dim3(256), sizeof(double) * 257 * (size_t)r, s, DF.p, p, r, 1.0, full.p, cmat(tail), r * q);
         Sparse snp; std::vector<double> ct; std::vector<uint8_t> cnz;
         MIH_TRY(project_full(snp, ct, cnz));
         hipLaunchKernelGGL(k_mv_unvec, dim3(nblk(p * r)), dim3(256), 0, s, full.p, p, r, DF.p);
@@ -685,8 +752,7 @@ struct MvVar {
         cols.clear();
         for (size_t t = 0; t < snp.idx.size(); ++t) { int64_t j = snp.idx[t] / r; if (cols.empty() || cols.back() != j) cols.push_back(j); }
         for (int l = 0; l < q; ++l) { idc[l] = 0; for (int i = 0; i < r; ++i) if (df2[i + r * l] != 0.0) idc[l] = 1; }
-        MIH_TRY(gather_df_cols());
-        return MIH_OK;
+        return step_tail(false);
     }
     double save_prev(double cur, double best)
     {
@@ -745,8 +811,7 @@ struct MvVar {
     }
     int step_post(double logl)
     {
-        MIH_TRY(score_post());
-        MIH_TRY(gather_df_cols());
+        MIH_TRY(step_tail(true));
         if (std::isnan(logl)) { set_error("Loglikelihood function is NaN, aborting..."); return MIH_NAN_LOGL; }
         if (std::isinf(logl)) { set_error("Loglikelihood function is Inf, aborting..."); return MIH_INF_LOGL; }
         return MIH_OK;
