@@ -112,6 +112,18 @@ static int native_allgather(void *user, const double *send, int64_t count, doubl
     return hipStreamSynchronize(nc->stream) == hipSuccess ? 0 : 3;
 }
 
+// The n-vector sums of a column-sharded fit (X_S b_S, X_S g_S) when the communicator is the library's own: ncclAllReduce is queued
+// on the FIT's stream, behind the kernel that produced the partial sums and in front of the kernels that read the totals --
+// no host synchronisation on either side (the callback contract of mih_comm::allreduce needs two).  -1: not a native communicator.
+int comm_native_allreduce_on_stream(const mih_comm *c, double *buf_dev, int64_t count, int32_t op, hipStream_t s)
+{
+    if (!c || c->allreduce != native_allreduce || c->user != (void *)c) return -1;
+    NativeComm *nc = static_cast<NativeComm *>(c->user);
+    const int rc = g_rccl.AllReduce(buf_dev, buf_dev, (size_t)count, kNcclFloat64, op == 0 ? kNcclSum : kNcclMax, nc->comm, s);
+    if (rc != kNcclSuccess) return nccl_fail(rc, "ncclAllReduce");
+    return MIH_OK;
+}
+
 }  // namespace mih
 
 using namespace mih;

@@ -313,6 +313,9 @@ __global__ void k_scatter_set(const int64_t *__restrict__ idx, const double *__r
     if (t < nnz) out[idx[t]] = val[t];
 }
 
+__global__ void k_set_scalar(double *__restrict__ dst, double v) { *dst = v; }
+__global__ void k_copy_scalar(double *__restrict__ dst, const double *__restrict__ src) { *dst = *src; }
+
 __global__ void k_clamp_pm20(double *__restrict__ x, int64_t n)
 {
     int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -443,6 +446,8 @@ struct IhtVar {
     int comm_fail(int rc) { set_error("communicator callback failed (%d)", rc); return MIH_BAD_ARG; }
     int allreduce_dev(double *buf, int64_t cnt, int op)
     {
+        const int nrc = comm_native_allreduce_on_stream(comm, buf, cnt, op, s);      // the library's own communicator: queued on this stream
+        if (nrc >= 0) return nrc;
         MIH_HIP(hipStreamSynchronize(s));
         int rc = comm->allreduce(comm->user, buf, cnt, op, 1);
         return rc ? comm_fail(rc) : MIH_OK;
@@ -498,7 +503,7 @@ struct IhtVar {
         for (int64_t v : ks) kcap += v;
         // every buffer below comes out of ONE device block and ONE pinned block (Arena, common.h)
         {
-            size_t dev = sizeof(double) * ((size_t)n * (7 + q) + 2 * (size_t)p + q) + (size_t)n
+            size_t dev = sizeof(double) * ((size_t)n * (7 + q) + 2 * (size_t)p + q + 8) + (size_t)n
                          + sizeof(double) * ((size_t)nb * 4 + kMaxQ + 8 + (size_t)kMaxQ * kZtrBlocks) + sizeof(unsigned) * kMaxQ
                          + 3 * sizeof(double) * (size_t)kcap + xv_work_bytes(h, kcap, kcap - 1024)
                          + sizeof(uint32_t) * 2048 + 64 + 16 * ((size_t)kcap + 1025)
@@ -511,7 +516,7 @@ struct IhtVar {
         if (y_shared && z_shared) { y.attach(y_shared, n); z.attach(z_shared, (size_t)n * q); }
         else { MIH_TRY(y.alloc(n)); MIH_TRY(z.alloc((size_t)n * q)); }
         MIH_TRY(w.alloc(n)); MIH_TRY(xb.alloc(n));
-        MIH_TRY(zc.alloc(n)); MIH_TRY(mu.alloc(n)); MIH_TRY(r.alloc(n)); MIH_TRY(xgk.alloc(n));
+        MIH_TRY(zc.alloc(n)); MIH_TRY(mu.alloc(n)); MIH_TRY(r.alloc(n)); MIH_TRY(xgk.alloc((size_t)n + 8));     // (+ the scalar that rides the all-reduce of a sharded fit)
         MIH_TRY(df.alloc(p)); MIH_TRY(full.alloc((size_t)p + q)); MIH_TRY(mask.alloc(n));
         MIH_TRY(red.alloc((size_t)nb * 4)); MIH_TRY(scal.alloc(kMaxQ + 8)); MIH_TRY(ztr.alloc((size_t)kMaxQ * kZtrBlocks));
         MIH_TRY(ztr_done.alloc(kMaxQ)); MIH_HIP(hipMemsetAsync(ztr_done.p, 0, sizeof(unsigned) * kMaxQ, s));      // k_zt_r leaves the counters at zero
@@ -1089,11 +1094,19 @@ struct IhtVar {
         std::vector<double> d2(q);
         double numer = 0.0;
         for (size_t t = 0; t < idx.val.size(); ++t) numer += idx.val[t] * idx.val[t];
-        if (comm) { MIH_TRY(allreduce_dev(xgk.p, n, 0)); MIH_TRY(allreduce_host(&numer, 1, 0)); }
-        for (int l = 0; l < q; ++l) { d2[l] = idc[l] ? df2[l] : 0.0; if (idc[l]) numer += df2[l] * df2[l]; }
+        if (comm) {
+            // the shards' shares of |df_S|^2 ride the all-reduce of X_S g_S as element n of the vector (one collective instead of two)
+            // and come home with the denominator
+            hipLaunchKernelGGL(k_set_scalar, dim3(1), dim3(1), 0, s, xgk.p + n, numer);
+            MIH_TRY(allreduce_dev(xgk.p, n + 1, 0));
+            hipLaunchKernelGGL(k_copy_scalar, dim3(1), dim3(1), 0, s, scal.p + 1, xgk.p + n);
+        }
+        for (int l = 0; l < q; ++l) d2[l] = idc[l] ? df2[l] : 0.0;
         hipLaunchKernelGGL(k_stepsize, dim3(nb), dim3(256), 0, s, xgk.p, z.p, xb.p, zc.p, mu.p, w.p, n, q, qvec(d2), dist, link, nb_r, red.p);
-        MIH_TRY(final_sum_home(1, scal.p, scal.p, 1));
+        MIH_TRY(final_sum_home(1, scal.p, scal.p, comm ? 2 : 1));
         const double denom = hpin.p[0];
+        if (comm) numer = hpin.p[1];
+        for (int l = 0; l < q; ++l) if (idc[l]) numer += df2[l] * df2[l];
         double e = numer / denom;
         if (probe_env("MENDELIHT_TRACE_ETA"))            // measurement build: what iht_stepsize! divides (tests/test_gpu_parity.py, the 0/0 cases of the sweeps)
             fprintf(stderr, "stepsize: numer %.17g denom %.17g eta %.17g support %zu df2[0] %.17g\n", numer, denom, e, idx.idx.size(), q ? df2[0] : 0.0);
