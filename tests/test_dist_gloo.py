@@ -108,3 +108,53 @@ def test_column_block_covers_every_column_and_leaves_no_rank_empty():
                 assert all(lo % 32 == 0 for lo, _ in blocks), (p, w, blocks)
                 sizes = [c for _, c in blocks]
                 assert max(sizes) - min(sizes) <= 32 + 31, (p, w, blocks)
+
+
+def _allgather_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import ctypes as C
+
+    import torch.distributed as dist
+    import mendeliht_amd as m
+    from mendeliht_amd import api
+    from mendeliht_amd import dist as D
+
+    D.init_from_env(backend="gloo")
+    q, npath = 5, 20
+    full = np.arange(1.0, q * npath + 1).reshape(q, npath) * 1.000000123
+    mine = np.zeros_like(full)
+    for i in D.shard_combinations(q, npath, rank, world):
+        mine.flat[i] = full.flat[i]
+    # mih_cv_allgather (the library's gather of the cross-validation losses) through a communicator whose two exchanges are the
+    # torch.distributed callbacks: the entry point itself makes no HIP call, so it runs here without a GPU
+    comm = D.ColumnComm(0, 1)
+    got = D.gather_losses_native(comm)(mine)
+    # ordered sums: rank 0 + rank 1 + ... on EVERY rank, whatever the backend's all-reduce does
+    oc = D.ColumnComm(0, 1, ordered_sum=True)
+    v = np.array([0.1, 1e16, -1e16, 3.0]) * (rank + 1) + np.array([rank * 1e-3, 1.0, 2.0, -rank])
+    w = v.copy()
+    assert oc._ar(None, w.ctypes.data_as(C.c_void_p), w.size, 0, 0) == 0
+    assert api.lib().mih_cv_allgather(None, None, 0) != 0                 # null communicator: refused, not crashed
+    np.save(os.path.join(out_dir, f"g{rank}.npy"), got)
+    np.save(os.path.join(out_dir, f"o{rank}.npy"), np.concatenate([w, v]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_library_gather_of_cv_losses_and_ordered_sums_on_cpu(tmp_path):
+    """mih_cv_allgather at world 2 and 3 over gloo (the N > 1 path of a cross-validation whose one exchange runs inside the
+    library), and ColumnComm(ordered_sum=True): the sum every rank ends up with is rank 0 + rank 1 + rank 2 in that order."""
+    for world in (2, 3):
+        d = tmp_path / f"w{world}"
+        d.mkdir()
+        mp.spawn(_allgather_worker, args=(world, _free_port(), str(d)), nprocs=world, join=True)
+        full = np.arange(1.0, 101.0).reshape(5, 20) * 1.000000123
+        parts = [np.load(d / f"o{r}.npy") for r in range(world)]
+        want = parts[0][4:].copy()
+        for r in range(1, world):
+            want = want + parts[r][4:]                                    # rank order
+        for r in range(world):
+            assert np.array_equal(np.load(d / f"g{r}.npy"), full)
+            assert np.array_equal(parts[r][:4], want), (world, r)
