@@ -8,6 +8,7 @@
 #include "common.h"
 #include <dlfcn.h>
 #include <mutex>
+#include <string>
 #include <vector>
 
 namespace mih {
@@ -33,7 +34,20 @@ static int rccl_load()
 {
     std::lock_guard<std::mutex> lk(g_rccl_mu);          // two lanes / host threads may make their first call together
     if (g_rccl.lib) return MIH_OK;
-    const char *names[] = {getenv("MENDELIHT_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // RCCL must drive the SAME HIP runtime this library is bound to.  A host process may hold two (PyTorch ships its own copies of
+    // libamdhip64 / libhsa-runtime64 / librccl next to the system's): asked for by its soname, dlopen hands back whichever librccl is
+    // loaded already -- possibly the one bound to the OTHER runtime, which then finds "no ROCm-capable device" because that runtime
+    // was never initialised (seen when this library is loaded before `import torch`).  So the first candidates are the librccl in
+    // the directory of the libamdhip64 that hipGetDeviceCount resolves to, by full path.
+    std::string beside[2];
+    Dl_info info;
+    if (dladdr((void *)&hipGetDeviceCount, &info) && info.dli_fname) {
+        std::string dir(info.dli_fname);
+        const size_t slash = dir.rfind('/');
+        if (slash != std::string::npos) { dir.resize(slash + 1); beside[0] = dir + "librccl.so.1"; beside[1] = dir + "librccl.so"; }
+    }
+    const char *names[] = {getenv("MENDELIHT_RCCL_LIB"), beside[0].empty() ? nullptr : beside[0].c_str(),
+                           beside[1].empty() ? nullptr : beside[1].c_str(), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *lib = nullptr;
     for (const char *nm : names) { if (nm && (lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break; }
     if (!lib) { set_error("cannot load librccl (%s): set MENDELIHT_RCCL_LIB", dlerror()); return MIH_BAD_ARG; }

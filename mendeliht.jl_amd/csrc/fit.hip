@@ -314,6 +314,13 @@ __global__ void k_scatter_set(const int64_t *__restrict__ idx, const double *__r
 }
 
 __global__ void k_set_scalar(double *__restrict__ dst, double v) { *dst = v; }
+// sum of squares of a short list in list order (the host loop of iht_stepsize!'s numerator, utilities.jl:754, on the device copy)
+__global__ void k_sumsq_seq(const double *__restrict__ v, int64_t cnt, double *__restrict__ dst)
+{
+    double a = 0.0;
+    for (int64_t t = 0; t < cnt; ++t) a += v[t] * v[t];
+    *dst = a;
+}
 __global__ void k_copy_scalar(double *__restrict__ dst, const double *__restrict__ src) { *dst = *src; }
 
 __global__ void k_clamp_pm20(double *__restrict__ x, int64_t n)
@@ -751,12 +758,35 @@ struct IhtVar {
     {
         int64_t sparsity = k + zkeepn, groups = (J == 0) ? 1 : J;
         int64_t nsnp = (int64_t)b.idx.size();
-        if (comm) { double t = (double)nsnp; MIH_TRY(allreduce_host(&t, 1, 0)); nsnp = (int64_t)t; }
+        if (comm && bg_ok) nsnp = (int64_t)bg.idx.size();         // every rank holds the whole model of this step (project_full_sharded)
+        else if (comm) { double t = (double)nsnp; MIH_TRY(allreduce_host(&t, 1, 0)); nsnp = (int64_t)t; }
         int64_t nz = nsnp - zkeepn;
         for (int l = 0; l < q; ++l) nz += idc[l];
         if (nz <= groups * sparsity) return MIH_OK;
         int64_t excess = nz - groups * sparsity;
         choose_fired = true;
+        if (comm && bg_ok) {
+            // the deterministic rule on the global list, identically on every rank: the `excess` smallest |b| go (ties: the highest
+            // global index first); each shard then keeps what is left of its own columns
+            std::vector<size_t> og(bg.idx.size());
+            for (size_t i = 0; i < og.size(); ++i) og[i] = i;
+            std::sort(og.begin(), og.end(), [&](size_t x, size_t y) {
+                const double fx = std::fabs(bg.val[x]), fy = std::fabs(bg.val[y]);
+                if (fx != fy) return fx < fy;
+                return bg.idx[x] > bg.idx[y];
+            });
+            std::vector<char> dropg(bg.idx.size(), 0);
+            for (int64_t t = 0; t < excess && t < (int64_t)og.size(); ++t) dropg[og[(size_t)t]] = 1;
+            Sparse keptg, keptl;
+            for (size_t i = 0; i < bg.idx.size(); ++i) {
+                if (dropg[i]) continue;
+                keptg.idx.push_back(bg.idx[i]); keptg.val.push_back(bg.val[i]);
+                const int64_t loc = bg.idx[i] - col0;
+                if (loc >= 0 && loc < p) { keptl.idx.push_back(loc); keptl.val.push_back(bg.val[i]); }
+            }
+            bg = keptg; b = keptl;
+            return MIH_OK;
+        }
         if (choose_cb) return choose_by_caller(b, excess);
         std::vector<size_t> ord(b.idx.size());
         for (size_t i = 0; i < ord.size(); ++i) ord[i] = i;
@@ -815,6 +845,14 @@ struct IhtVar {
     // the union of every shard's own top-K (plus the covariate tail, which every rank holds); ties at
     // that value are kept, as in utilities.jl:553-559.  Local survivors of the local projection are a
     // superset of the global survivors because the global threshold is >= every local one.
+    // Round 4: a shard sends its candidates as (global index, value) pairs -- 1 + 2K doubles instead of K -- so that every rank ends up
+    // with the WHOLE k-sparse model of the step (`bg`): the support count of _choose! and the two maxima of check_convergence are
+    // then computed locally and identically on every rank instead of through two more collectives per iteration.  A shard with
+    // more than K local survivors (exact ties at its own threshold) can only send K of them: if its smallest sent magnitude
+    // still reaches the global threshold the global list may be incomplete, and the step falls back to the collectives (bg_ok).
+    // With prior weights the projected values are b * weight (utilities.jl:305-309) and the shards do not hold each other's
+    // weights: fallback as well.
+    Sparse bg, b0g; bool bg_ok = false, b0g_ok = false;
     int project_full_sharded(Sparse &snp, std::vector<double> &ctail, std::vector<uint8_t> &ctail_nz)
     {
         const int64_t K = k + zkeepn;
@@ -825,21 +863,49 @@ struct IhtVar {
         const int64_t Kloc = std::min<int64_t>(K, p);
         if (Kloc > 0) MIH_TRY(topk_project_device(full.p, p, Kloc, topk, s, si, sv));
         MIH_HIP(hipStreamSynchronize(s));
-        std::vector<double> mags(sv.size());
-        for (size_t t = 0; t < sv.size(); ++t) mags[t] = std::fabs(sv[t]);
-        std::sort(mags.begin(), mags.end(), std::greater<double>());
-        std::vector<double> mine((size_t)K, -1.0), all;        // -1 = no entry (magnitudes are >= 0)
-        for (int64_t t = 0; t < K && t < (int64_t)mags.size(); ++t) mine[t] = mags[t];
-        MIH_TRY(allgather_host(mine.data(), K, all));
-        for (int l = 0; l < q; ++l) all.push_back(std::fabs(tail[l]));
-        std::nth_element(all.begin(), all.begin() + (K - 1), all.end(), std::greater<double>());
-        const double a = all[K - 1];
+        std::vector<size_t> ord(sv.size());
+        for (size_t t = 0; t < ord.size(); ++t) ord[t] = t;
+        std::sort(ord.begin(), ord.end(), [&](size_t x, size_t y) {
+            const double fx = std::fabs(sv[x]), fy = std::fabs(sv[y]);
+            if (fx != fy) return fx > fy;
+            return si[x] < si[y];
+        });
+        const int64_t slot = 1 + 2 * K;
+        std::vector<double> mine((size_t)slot, -1.0), all;        // index -1 = no entry
+        mine[0] = (double)sv.size();
+        for (int64_t t = 0; t < K && t < (int64_t)ord.size(); ++t) { mine[1 + 2 * t] = (double)(col0 + si[ord[(size_t)t]]); mine[2 + 2 * t] = sv[ord[(size_t)t]]; }
+        MIH_TRY(allgather_host(mine.data(), slot, all));
+        std::vector<double> mags;
+        for (int32_t r = 0; r < comm->world; ++r)
+            for (int64_t t = 0; t < K; ++t) { const double *e = &all[(size_t)r * slot + 1 + 2 * t]; if (e[0] >= 0.0) mags.push_back(std::fabs(e[1])); }
+        for (int l = 0; l < q; ++l) mags.push_back(std::fabs(tail[l]));
+        if ((int64_t)mags.size() < K) { set_error("projection to %lld entries of a vector with %zu non-empty candidates", (long long)K, mags.size()); return MIH_BAD_ARG; }
+        std::nth_element(mags.begin(), mags.begin() + (K - 1), mags.end(), std::greater<double>());
+        const double a = mags[K - 1];
         snp.clear();
         ctail_nz.assign(q, 0);
         for (size_t t = 0; t < si.size(); ++t)
             if (std::fabs(sv[t]) >= a) { snp.idx.push_back(si[t]); snp.val.push_back(sv[t]); }
         for (int l = 0; l < q; ++l)
             if (std::fabs(tail[l]) >= a) { ctail[l] = tail[l]; ctail_nz[l] = 1; }
+        // the whole model, identical on every rank
+        bg.clear(); bg_ok = !has_weight;
+        std::vector<std::pair<int64_t, double>> glob;
+        for (int32_t r = 0; r < comm->world && bg_ok; ++r) {
+            const double *msg = &all[(size_t)r * slot];
+            double smallest = std::numeric_limits<double>::infinity();
+            for (int64_t t = 0; t < K; ++t) {
+                if (msg[1 + 2 * t] < 0.0) continue;
+                const double mg = std::fabs(msg[2 + 2 * t]);
+                smallest = std::min(smallest, mg);
+                if (mg >= a) glob.emplace_back((int64_t)msg[1 + 2 * t], msg[2 + 2 * t]);
+            }
+            if (msg[0] > (double)K && smallest >= a) bg_ok = false;      // ties cut off at the message size
+        }
+        if (bg_ok) {
+            std::sort(glob.begin(), glob.end());
+            for (auto &e : glob) { bg.idx.push_back(e.first); bg.val.push_back(e.second); }
+        }
         return MIH_OK;
     }
 
@@ -910,6 +976,7 @@ struct IhtVar {
     {
         train_cur = train; spec_ok = false;
         b.clear(); b0.clear(); best_b.clear(); idx.clear();
+        bg.clear(); b0g.clear(); bg_ok = b0g_ok = true;        // (b = 0 on every shard)
         std::fill(c.begin(), c.end(), 0.0); c0 = c; best_c = c; std::fill(df2.begin(), df2.end(), 0.0);
         for (int l = 0; l < q; ++l) { idc[l] = zkeep[l]; idc0[l] = zkeep[l]; }
         choose_fired = false;
@@ -1037,6 +1104,7 @@ struct IhtVar {
         hipLaunchKernelGGL(k_grad_full, dim3(nblk(p)), dim3(256), 0, s, df.p, wp, p, 1.0, full.p, qvec(tail), q);
         Sparse snp; std::vector<double> ct(q, 0.0); std::vector<uint8_t> cnz;
         MIH_TRY(project_full(snp, ct, cnz));
+        if (comm) { bg.clear(); bg_ok = true; }            // (what was projected here is the gradient: the model itself is still 0 on every shard)
         if (comm) {          // the device copy was only projected to the LOCAL threshold: rebuild it from the survivors
             MIH_HIP(hipMemsetAsync(full.p, 0, sizeof(double) * p, s));
             MIH_TRY(upload(snp.idx, snp.val));
@@ -1078,10 +1146,11 @@ struct IhtVar {
     // iht_stepsize! (utilities.jl:722-764)
     int stepsize(double *eta)
     {
-        if (spec_ok && !comm && spec_idx == idx.idx && spec_idc == idc) {      // computed at the end of the previous step
+        if (spec_ok && spec_idx == idx.idx && spec_idc == idc) {      // computed at the end of the previous step
             spec_ok = false;
             double numer = 0.0;
-            for (size_t t = 0; t < idx.val.size(); ++t) numer += idx.val[t] * idx.val[t];
+            if (comm) numer = spec_numer_snp;                  // |df_S|^2 over ALL shards came home with the denominator
+            else for (size_t t = 0; t < idx.val.size(); ++t) numer += idx.val[t] * idx.val[t];
             for (int l = 0; l < q; ++l) if (idc[l]) numer += df2[l] * df2[l];
             double e = numer / spec_denom;
             if (std::isinf(e) || std::isnan(e)) e = 1e-8;
@@ -1118,12 +1187,14 @@ struct IhtVar {
     double save_prev(double cur, double best)        // utilities.jl:702-712
     {
         b0 = b; c0 = c; idc0 = idc;
+        b0g = bg; b0g_ok = bg_ok;
         if (cur > best) { best_b = b; best_c = c; }
         return cur > best ? cur : best;
     }
     int save_best_model()                            // utilities.jl:995-1006
     {
         b = best_b; c = best_c; idx.idx = b.idx;
+        bg_ok = false;                                         // (the best model is kept per shard only)
         for (int l = 0; l < q; ++l) idc[l] = (c[l] != 0.0);
         MIH_TRY(update_xb());
         MIH_TRY(mu_loglik(0, nullptr, nullptr));     // mu = linkinv(xb): genetic part only
@@ -1132,15 +1203,17 @@ struct IhtVar {
     double check_convergence()                       // utilities.jl:953-957
     {
         double d = 0.0, nbm = 0.0;
+        const bool global = comm && bg_ok && b0g_ok;      // both whole models are here: no exchange
+        const Sparse &cb = global ? bg : b, &cb0 = global ? b0g : b0;
         size_t i = 0, j = 0;
-        while (i < b.idx.size() || j < b0.idx.size()) {
+        while (i < cb.idx.size() || j < cb0.idx.size()) {
             double vb = 0.0, v0 = 0.0;
-            if (j >= b0.idx.size() || (i < b.idx.size() && b.idx[i] < b0.idx[j])) vb = b.val[i++];
-            else if (i >= b.idx.size() || b0.idx[j] < b.idx[i]) v0 = b0.val[j++];
-            else { vb = b.val[i++]; v0 = b0.val[j++]; }
+            if (j >= cb0.idx.size() || (i < cb.idx.size() && cb.idx[i] < cb0.idx[j])) vb = cb.val[i++];
+            else if (i >= cb.idx.size() || cb0.idx[j] < cb.idx[i]) v0 = cb0.val[j++];
+            else { vb = cb.val[i++]; v0 = cb0.val[j++]; }
             d = std::max(d, std::fabs(vb - v0)); nbm = std::max(nbm, std::fabs(v0));
         }
-        if (comm) {
+        if (comm && !global) {
             double two[2] = {d, nbm};
             if (allreduce_host(two, 2, 1)) return std::numeric_limits<double>::quiet_NaN();
             d = two[0]; nbm = two[1];
@@ -1226,33 +1299,39 @@ struct IhtVar {
     // from the device copy of df_S, the weighted sum of squares) are queued back to back and come home in one copy:
     // [df_S | df2 | sum xgk^2].  One synchronisation and three small copies less per iteration than doing the step size
     // on its own.
-    bool spec_ok = false; double spec_denom = 0.0; std::vector<int64_t> spec_idx; std::vector<uint8_t> spec_idc;
+    // Column-sharded fit: the shards' partial X_S df_S and their shares of |df_S|^2 (element n of the vector) are summed by ONE
+    // all-reduce in the middle of the chain -- queued on this stream when the communicator is the library's own -- so a sharded step
+    // ends with one wait like an unsharded one.
+    bool spec_ok = false; double spec_denom = 0.0, spec_numer_snp = 0.0; std::vector<int64_t> spec_idx; std::vector<uint8_t> spec_idc;
     int step_post_fused()
     {
         const int64_t nnz = (int64_t)idx.idx.size();
-        MIH_TRY(ensure_stage(nnz + kMaxQ + 2));
+        MIH_TRY(ensure_stage(nnz + kMaxQ + 3));
         hipLaunchKernelGGL(k_zt_r, dim3(kZtrBlocks, q), dim3(256), 0, s, z.p, r.p, n, ztr.p, ztr_done.p, gval.p + nnz);     // df2 behind df_S
         if (nnz) MIH_TRY(upload_idx(idx.idx));
         MIH_TRY(xv_sparse_device(h, xv, sidx.p, gval.p, nnz, xgk.p, 0, s, idx.idx.data(), &stage, df.p, gval.p));    // df_S gathered on the way
+        if (comm) {
+            hipLaunchKernelGGL(k_sumsq_seq, dim3(1), dim3(1), 0, s, gval.p, nnz, xgk.p + n);
+            MIH_TRY(allreduce_dev(xgk.p, n + 1, 0));
+            hipLaunchKernelGGL(k_copy_scalar, dim3(1), dim3(1), 0, s, gval.p + nnz + q + 1, xgk.p + n);
+        }
         unsigned long long mask = 0ull;
         for (int l = 0; l < q; ++l) if (idc[l]) mask |= 1ull << l;
         hipLaunchKernelGGL(k_stepsize_dev, dim3(nb), dim3(256), 0, s, xgk.p, z.p, xb.p, zc.p, mu.p, w.p, n, q, gval.p + nnz, mask,
                            dist, link, nb_r, red.p);
-        if ((size_t)nnz + q + 1 > hpin.n) { MIH_HIP(hipStreamSynchronize(s)); MIH_TRY(hpin.alloc((size_t)nnz * 2 + kMaxQ + 16, true)); }
-        MIH_TRY(final_sum_home(1, gval.p + nnz + q, gval.p, (size_t)(nnz + q + 1)));
+        const size_t home = (size_t)(nnz + q + 1 + (comm ? 1 : 0));
+        if (home > hpin.n) { MIH_HIP(hipStreamSynchronize(s)); MIH_TRY(hpin.alloc((size_t)nnz * 2 + kMaxQ + 16, true)); }
+        MIH_TRY(final_sum_home(1, gval.p + nnz + q, gval.p, home));
         idx.val.assign(hpin.p, hpin.p + nnz);
         for (int l = 0; l < q; ++l) df2[l] = hpin.p[nnz + l];
         df2_pending = false;
         spec_denom = hpin.p[nnz + q]; spec_idx = idx.idx; spec_idc = idc; spec_ok = true;
+        if (comm) spec_numer_snp = hpin.p[nnz + q + 1];
         return MIH_OK;
     }
     int step_post(double logl)
     {
-        if (!comm) MIH_TRY(step_post_fused());
-        else {
-            MIH_TRY(score_post());
-            MIH_TRY(gather_df_support());
-        }
+        MIH_TRY(step_post_fused());
         if (std::isnan(logl)) { set_error("Loglikelihood function is NaN, aborting..."); return MIH_NAN_LOGL; }
         if (std::isinf(logl)) { set_error("Loglikelihood function is Inf, aborting..."); return MIH_INF_LOGL; }
         return MIH_OK;
