@@ -142,8 +142,11 @@ int mih_project_group_sparse(double *y, const int64_t *group, int64_t len, int64
  * of the SNP columns as its own mih_mat; y, z and all n-vectors are replicated.  The reference has no
  * multi-device fit, so there is no line to cite for the exchange itself: the library calls back into
  * the host at the points where iht_stepsize!/update_xb! (src/utilities.jl:722-764, 93-118) sum over
- * the support columns, where project_k! (utilities.jl:553-559) needs the global k-th largest entry,
- * and where check_convergence (utilities.jl:953-957) takes a max over beta.  The host implements the
+ * the support columns (all-reduce of n+1 / n doubles on the device) and where project_k! (utilities.jl:553-559)
+ * needs the global k-th largest entry (all-gather of 1 + 2K doubles per rank: the shards' candidates as
+ * (global index, value) pairs, from which every rank also rebuilds the whole k-sparse model, so that _choose!
+ * and check_convergence, utilities.jl:444-458, 953-957, need no exchange; with prior weights or ties beyond the
+ * message size two scalar reductions remain).  The host implements the
  * two collectives with its own communicator (RCCL through torch.distributed in the Python mirror,
  * MPI.Allreduce in the Julia glue).  Both must return 0 on success, on every rank, in the same order. */
 typedef struct mih_comm {
