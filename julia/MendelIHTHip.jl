@@ -376,14 +376,15 @@ function cv_iht(y::AbstractVector{Float64}, xs::Vector{HipSnpLinAlg{Float64}}, z
         d::UnivariateDistribution=Normal(), l::Link=IdentityLink(), path::AbstractVector{<:Integer}=1:20,
         q::Int=5, est_r::Symbol=:None, group::AbstractVector{Int}=Int[], weight::AbstractVector{Float64}=Float64[],
         zkeep::BitVector=trues(size(z, 2)), folds::AbstractVector{Int}=rand(1:q, size(xs[1], 1)), debias::Bool=false,
-        verbose::Bool=true, max_iter::Int=100, min_iter::Int=5, init_beta::Bool=false)
+        verbose::Bool=true, max_iter::Int=100, min_iter::Int=5, init_beta::Bool=false,
+        cv_threads::Int=Threads.nthreads())      # est_r only: the chains of v.d the reference's threads would form (see cv_iht above)
     yy = Vector{Float64}(y); zz = dense_z(z)
     nz = size(zz, 2)
     f32 = Vector{Int32}(folds); pth = Vector{Int64}(path)
     raw = zeros(q * length(pth)); mse = zeros(length(pth))
     hs = [x.handle for x in xs]
     prm, keep = make_params(xs[1], 1, 1, d, l, group, weight, zkeep, est_r, false, debias, 1e-4, max_iter, min_iter, 3,
-                            init_beta, C_NULL)
+                            init_beta, C_NULL, 0, cv_threads)
     GC.@preserve keep xs hs yy zz f32 pth raw begin
         check(ccall((:mih_cv_iht_multi, LIB), Cint,
             (Ptr{Ptr{Cvoid}}, Int32, Ref{MihFitParams}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Int32}, Int32, Ptr{Int64},
