@@ -283,7 +283,7 @@ def cv_roofline(cst):
             "kernel": cst["kernel"], "kernel_ms": cst["ms_sum"] / max(cst["launches"], 1),
             "algorithmic_bytes_per_launch": cst["bytes"] / max(cst["launches"], 1),
             "note": "sum of algorithmic_bytes(residuals of the launch) / sum of HIP-event durations; the two lock-step lanes' passes "
-                    "overlap, so the sum exceeds the union (and may exceed the wall time). A fused pass streams X once for up to 18 "
+                    "overlap, so the sum exceeds the union (and may exceed the wall time). A fused pass streams X once for up to 19 "
                     "residuals and is bound by the matrix pipe under the power cap, not by HBM: wider passes LOWER this fraction while "
                     "the cost per residual falls (xtv_kernel_ms_per_residual_scored; DESIGN.md 3.1b)"}
 

@@ -115,8 +115,8 @@ int mih_xtv_batched(const mih_mat *h, const double *R, int m, double *OUT);
  * the dot products with the dosages are exact, and the only rounding is that of the residual.  digits = base * 100 + digits:
  *   0 = library default: 4910 for every multi-residual context (this call, cv_iht, model paths, multivariate fits,
  *        init_beta) whatever the number of residuals, 428 for the workspace of a single univariate fit.
- *   4910 10 base-49 digits d/8 in FP6 (e2m3), |R| < 2^54: rounding 2^-54 max|r|, below that of an n-term f64 sum.  THREE
- *        residuals share one 32-column operand.  Row slices of 2^18 rows; above 2^22 rows the default steps down to 1316.
+ *   4910 10 base-49 digits d/8 in FP6 (e2m3), |R| < 2^54: rounding 2^-54 max|r|, below that of an n-term f64 sum.  The digit
+ *        columns of a pass's residuals are packed back to back over its 32-column operands (19 residuals in six operands).  Row slices of 2^18 rows; above 2^22 rows the default steps down to 1316.
  *   1316 16 base-13 digits d/2 in FP4 (e2m1), |R| < 2^57, two residuals per operand (2^20-row slices; above 2^24
  *        rows the default steps down to 428).
  *   428  28 base-4 digits {-2..1}/2 in FP4, |R| < 2^54, one residual per operand (the first format; cross-check).
@@ -340,7 +340,7 @@ typedef struct mih_pass_record {
     double  start_ms;         /* kernel start, relative to the mih_profile_enable(h, 1) call */
     double  ms;               /* kernel duration (HIP events on its own stream) */
     int32_t residuals;        /* residual vectors scored by this launch */
-    int32_t operands;         /* B operands of the launch (3 residuals each in the default format) */
+    int32_t operands;         /* B operands of the launch (32 digit columns each; a residual takes 10 in the default format) */
     int32_t stream_tag;       /* 0 = the handle's / a single fit's stream; 1, 2 = lock-step lanes */
     int32_t reserved;
     char    kernel[48];       /* e.g. "k_xtv_dma<1,2,4,8,fp4>" or "k_xtv_dma16<5,2,8,4,half>" */

@@ -353,7 +353,13 @@ struct DigitMode {
     int ebits;       // the residual is scaled to max|r| * 2^e < 2^(ebits+1)
     int rows_log2;   // a row slice holds at most 2^rows_log2 rows (f32 accumulators stay exact)
     int lay16 = 0;   // FP6 planes stored as the B fragments of the 16x16x128 MFMA (two 16-column images per 128-row block)
+    int flat = 0;    // (round 4) the residuals of a pass occupy digit columns 10 j .. 10 j + 9 of the pass's operands back to back,
+                     // across operand boundaries: 19 ten-digit residuals in the 192 columns of six operands instead of 18
+    int nres = 0;    // flat: residuals in this pass
 };
+// flat packing: which pass a residual rides and where the pass's operands start (k_digits)
+constexpr int kMaxFlatPasses = 16;
+struct FlatPasses { int npass; int u0[kMaxFlatPasses + 1]; int t0[kMaxFlatPasses + 1]; };
 // How the X'r passes of a workspace run.  Fixed when the workspace is built, from the CALL's arguments (mih_fit_params::
 // xtv_digits, the digits argument of mih_xtv_batched_fmt / mih_bench_xtv): there is no process-wide kernel or format selector.
 // Everything but `digits` is a knob of the measurement build (mih_probe_*; constant in the release library).
@@ -362,7 +368,7 @@ struct XtvTune {
     int variant = -1;        // >= 0: a per-wave-load single-operand shape (round-1 kernels)
     int multi_variant = 0;   // launch-shape / probe id of the LDS-shared and ring kernels
     int max_nr = 4;          // B operands fused per pass of the register-staged kernels (1, 2 or 4)
-    int max_ops = 6;         // B operands per pass of the 16x16x128 ring kernel: 6 = 18 residuals (254 VGPRs, ring depth 3).  Round 3,
+    int max_ops = 6;         // B operands per pass of the 16x16x128 ring kernel: 6 = 18 residuals, 19 with the digit columns packed flat (round 4) (254 VGPRs, ring depth 3).  Round 3,
                              // after the LDS fix: 18 residuals 38.0 ms = 2.11 ms each against 15 in 33.9 ms = 2.26 ms each; the
                              // 100-fit cv_iht 2.82-2.84 s against 2.95-3.03 s with 5 (74 instead of 88 fused passes, same box)
     int slices = 0;          // row slices, 0 = auto_splits
@@ -381,6 +387,7 @@ struct XtvWork {            // scratch for one in-flight X'r
     int m_cap = 0, splits_cap = 0;
     DigitMode dm = {13, 16, 2, 16, 56, 20};   // fixed at init (tune.digits and the matrix height)
     int ops_cap = 0;           // B operands the buffers hold
+    size_t rhs_cap = 0;        // residuals the statistics / partial buffers hold
     XtvTune tune;              // fixed at init
     int stream_tag = 0;        // which lock-step lane launches on this workspace (profile records)
 };

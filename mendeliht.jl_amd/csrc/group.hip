@@ -152,11 +152,14 @@ __global__ void k_grp_norms(const double *__restrict__ y, const int32_t *__restr
                             int64_t G, const int64_t *__restrict__ k, int k_is_vector, uint64_t *__restrict__ norm_key,
                             int32_t *__restrict__ gid)
 {
+#pragma clang fp contract(off)       // group_norm[n] + y[j]^2 (utilities.jl:626) rounds the square, then the sum.  __dmul_rn / __dadd_rn are plain
+                                     // `*` and `+` in HIP, and the compiler fused them: 2.2^2 + 1.8^2 + 1.3^2 came out as 9.77 instead of
+                                     // 9.770000000000001, tied with another group's norm and ranked behind it (seed 9079 of tools/fuzz_parity.py)
     int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (g >= G) return;
     int64_t a = seg_start[g], b = seg_start[g + 1], kg = k_is_vector ? k[g] : k[0];
     double nrm = 0.0;
-    for (int64_t t = a; t < b && t - a < kg; ++t) { double v = y[member[t]]; nrm = __dadd_rn(nrm, __dmul_rn(v, v)); }   // unfused, as utilities.jl:626
+    for (int64_t t = a; t < b && t - a < kg; ++t) { const double v = y[member[t]]; const double sq = v * v; nrm = nrm + sq; }
     norm_key[g] = (uint64_t)__double_as_longlong(nrm);     // nrm >= 0: bit order == numeric order
     gid[g] = (int32_t)g;
 }

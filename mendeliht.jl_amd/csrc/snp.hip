@@ -417,7 +417,7 @@ static void reserve_fit_memory(mih_mat *h, bool asked = false, size_t asked_byte
     const size_t min_bytes = (size_t)(4ull << 30);
     const size_t x_bytes = (size_t)h->ncg * (size_t)h->nbp * 1024;
     if (h->kind != 0 || (!asked && (off || x_bytes < min_bytes))) return;
-    size_t big = (size_t)2304 * (size_t)h->p;                    // the row-slice partials of an 18-residual pass (16 slices x 18 x 8 B per column)
+    size_t big = (size_t)2432 * (size_t)h->p;                    // the row-slice partials of a 19-residual pass (16 slices x 19 x 8 B per column)
     size_t var = 128ull << 20;                                   // one IHTVariable block at n = 500k, p = 1M
     if (x_bytes >= (4ull << 30)) big = std::min<size_t>(std::max<size_t>(big, 256ull << 20), 4ull << 30);
     else {                                                       // a small matrix: the same structure at its own scale

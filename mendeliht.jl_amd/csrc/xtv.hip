@@ -157,7 +157,7 @@ __device__ __forceinline__ int digit49(int m)
 // mfma_fp4; an FP6 element j sits in bits 6j..6j+5 of the lane's 192 bits, the last 64 of them in `dig2`).
 __global__ void __launch_bounds__(256)
 k_digits(const double *__restrict__ r, int64_t n, int64_t nblk, int m, DigitMode dm,
-         const double *__restrict__ scal, uint4 *__restrict__ dig /* [nops][nblk][64] */, uint2 *__restrict__ dig2)
+         const double *__restrict__ scal, uint4 *__restrict__ dig /* [nops][nblk][64] */, uint2 *__restrict__ dig2, FlatPasses fp)
 {
     __shared__ unsigned long long nib[4][64][2];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -209,8 +209,15 @@ k_digits(const double *__restrict__ r, int64_t n, int64_t nblk, int m, DigitMode
         const int h = lane / slots, dg = lane % slots;
         int64_t o = ((int64_t)op * nblk + blk) * 64 + h * 32 + sub * slots + dg;
         if (dm.lay16) {       // image b = column / 16 of the 128-row block, lane 16 * (e + 2h) + column % 16 (k_xtv_dma16)
-            const int col = sub * slots + dg, e = (int)(blk & 1);
-            o = ((int64_t)op * nblk + (blk - e) + (col >> 4)) * 64 + 16 * (e + 2 * h) + (col & 15);
+            int col = sub * slots + dg, opc = op;
+            if (dm.flat) {    // digit dg of residual vs sits in column 10 (vs - u0) + dg of its pass, counted across the pass's operands
+                int q = 0;
+                while (q + 1 < fp.npass && vs >= fp.u0[q + 1]) ++q;
+                const int cg = (vs - fp.u0[q]) * slots + dg;
+                opc = fp.t0[q] + (cg >> 5); col = cg & 31;
+            }
+            const int e = (int)(blk & 1);
+            o = ((int64_t)opc * nblk + (blk - e) + (col >> 4)) * 64 + 16 * (e + 2 * h) + (col & 15);
         }
         if (!fp6) {
             uint32_t out[4] = {0u, 0u, 0u, 0u};
@@ -880,6 +887,66 @@ __device__ __forceinline__ void xtv_epilogue16_s(const f32x4a (&acc)[CT][NR][2][
     }
 }
 
+// Flat packing (DigitMode::flat, ten-digit format): residual j of the pass owns digit columns 10 j .. 10 j + 9 counted across the
+// pass's operands, so a residual may begin in operand v and end in operand v + 1.  The operands' 32 x 32 tiles go through the
+// wave's LDS buffer one after the other, as above; lane (row, q) takes the q-th residual that touches operand v, adds up ITS
+// columns of this tile in digit order -- starting from 0 if the residual begins here, from the running sum it left in
+// `carry[row]` in the previous operand otherwise -- and either stores the finished dot product or leaves the running sum for the
+// next operand.  Products first, then one addition per digit from digit 0 upward: the operations, and their order, are those
+// of xtv_epilogue16_s<.., 10, ..>, so the bits are the same wherever a residual sits.
+template <int CT, int NR, int HALF>
+__device__ __forceinline__ void xtv_epilogue16_flat(const f32x4a (&acc)[CT][NR][2][2], float *buf, int lane, int64_t cg0, int64_t ncg,
+                                                    int split, int splits, DigitMode dm, const double *__restrict__ scal,
+                                                    double *__restrict__ partial)
+{
+#pragma clang fp contract(off)      // products and sums round separately, as in xtv_epilogue
+    constexpr int RS = 36, ND = 10;
+    const int n16 = lane & 15, rg = lane >> 4;
+    const int nres = dm.nres;
+    double wgt[ND];
+    {
+        unsigned long long w = 16;
+        #pragma unroll
+        for (int t = 0; t < ND; ++t) { wgt[t] = (double)w; w *= 49u; }
+    }
+    double *carry = reinterpret_cast<double *>(buf + 32 * RS);       // [32 SNP rows], behind the tile
+    #pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        #pragma unroll
+        for (int v = 0; v < NR; ++v) {
+            const bool cut = HALF && v == NR - 1;      // the pass's last operand: only its first 16 columns exist
+            __builtin_amdgcn_wave_barrier();
+            #pragma unroll
+            for (int a = 0; a < 2; ++a)
+                #pragma unroll
+                for (int b = 0; b < (cut ? 1 : 2); ++b)
+                    *reinterpret_cast<f32x4v *>(buf + (16 * b + n16) * RS + 16 * a + 4 * rg) =
+                        f32x4v{acc[c][v][a][b][0], acc[c][v][a][b][1], acc[c][v][a][b][2], acc[c][v][a][b][3]};
+            __builtin_amdgcn_wave_barrier();
+            const int jlo = (32 * v) / ND, jhi = (32 * v + 31) / ND;       // residuals with a column in [32 v, 32 v + 32)
+            #pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int o = lane + 64 * k, row = o & 31, j = jlo + (o >> 5);
+                if (j <= jhi && j < nres) {
+                    const int c0 = ND * j - 32 * v;                // column of digit 0 in this tile (negative: it began in the previous one)
+                    const int tf = c0 < 0 ? -c0 : 0, tl = c0 + ND - 1 > 31 ? 31 - c0 : ND - 1;
+                    double sum = tf == 0 ? 0.0 : carry[row];
+                    #pragma unroll
+                    for (int t = 0; t < ND; ++t)
+                        if (t >= tf && t <= tl) {
+                            const double x = (double)buf[(c0 + t) * RS + row] * wgt[t];
+                            sum += x;
+                        }
+                    if (tl == ND - 1) {
+                        if (cg0 + c < ncg)
+                            partial[((int64_t)j * splits + split) * (ncg * 32) + (cg0 + c) * 32 + row] = sum * scal[4 * j + 1];
+                    } else carry[row] = sum;           // (read in round k = 0 of the next operand; written here in a later round or after it)
+                }
+            }
+        }
+    }
+}
+
 // HALF = 1: the second 16-column fragment of the pass's LAST operand holds no residual (1 residual of 10 digits, or 2 of 8,
 // in that operand: m = 3 j + 1 residuals in a pass) and its multiply-adds are left out -- 2 NR - 1 fragment items a step.
 template <int NR, int CT, int WAVES, int D, int MODE = 0, int HALF = 0>       // MODE 3: timing probe, the odd 16-column fragments are skipped (result is NOT X'R); MODE 4: round 2's plain 8-byte LDS loads, which the compiler pairs into ds_read2_b64 (A/B for the bank-conflict fix; same result)
@@ -900,7 +967,7 @@ k_xtv_dma16(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *
     constexpr int ODD = NI & 1;                     // odd item count: the B double buffer alternates from step to step
     static_assert(S * STAGE <= 160 * 1024, "LDS ring too large");
     static_assert(D * L <= 63, "vmcnt range");
-    static_assert(S * STAGE >= WAVES * 32 * 36 * 4, "the epilogue buffers overlay the ring");
+    static_assert(S * STAGE >= WAVES * (32 * 36 + 64) * 4, "the epilogue buffers overlay the ring");
     static_assert(HALF == 0 || MODE == 0, "probes run on full operands");
     __shared__ uint4 lds[S * STAGE / 16];
     const int lane = threadIdx.x & 63;
@@ -1032,8 +1099,9 @@ k_xtv_dma16(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     if (cg0 >= ncg) return;
-    float *buf = reinterpret_cast<float *>(lds) + wave * (32 * 36);
-    if (dm.slots == 10) xtv_epilogue16_s<CT, NR, 10, HALF>(acc, buf, lane, cg0, ncg, split, splits, dm, scal, partial);
+    float *buf = reinterpret_cast<float *>(lds) + wave * (32 * 36 + 64);      // a 32 x 36 f32 tile + 32 running sums (flat packing)
+    if (dm.flat) xtv_epilogue16_flat<CT, NR, HALF>(acc, buf, lane, cg0, ncg, split, splits, dm, scal, partial);
+    else if (dm.slots == 10) xtv_epilogue16_s<CT, NR, 10, HALF>(acc, buf, lane, cg0, ncg, split, splits, dm, scal, partial);
     else xtv_epilogue16_s<CT, NR, 8, HALF>(acc, buf, lane, cg0, ncg, split, splits, dm, scal, partial);
 }
 
@@ -1350,6 +1418,20 @@ static bool xtv_lay16(const DigitMode &dm, const XtvTune &tn)
     return dm.base == 49 && tn.variant < 0 && (tn.multi_variant == 0 || (tn.multi_variant >= 40 && tn.multi_variant < 50));
 }
 
+// Flat packing of the digit columns (DigitMode::flat): the ten-digit format on the product's 16x16x128 kernels.  Three residuals
+// per operand leave 2 of 32 columns idle; packed back to back, 19 residuals fit the 192 columns of a six-operand pass instead of
+// 18, 16 fit five operands instead of five and a half.  (The other launch shapes of the measurement build keep the per-operand
+// layout: same bits, they are the cross-check.)
+static bool xtv_flat(const DigitMode &dm, const XtvTune &tn)
+{
+    return xtv_lay16(dm, tn) && tn.multi_variant == 0 && dm.slots * dm.per_op < 32 && tn.max_nr >= 4;
+}
+// residuals a full pass of the fused kernel scores
+static int xtv_pass_residuals(const DigitMode &dm, const XtvTune &tn)
+{
+    return xtv_flat(dm, tn) ? (tn.max_ops * 32) / dm.slots : tn.max_ops * dm.per_op;
+}
+
 static void choose_mode(const mih_mat *h, const XtvTune &tn, bool batched, DigitMode &dm)
 {
     digit_mode(tn.digits, dm);
@@ -1372,7 +1454,7 @@ int xtv_lockstep_width(const mih_mat *h, const XtvTune &tn)
     if (h->kind != 0) return 16;
     DigitMode dm;
     choose_mode(h, tn, true, dm);
-    if (xtv_lay16(dm, tn)) return 2 * tn.max_ops * dm.per_op;       // two lanes of one full pass each
+    if (xtv_lay16(dm, tn)) return 2 * xtv_pass_residuals(dm, tn);    // two lanes of one full pass each
     return 8 * dm.per_op;
 }
 
@@ -1387,9 +1469,13 @@ int xtv_work_init(const mih_mat *h, XtvWork &w, int m, const XtvTune &tune, bool
         set_error("the FP6 residual formats need the default kernel (variant -1)");
         return MIH_BAD_ARG;
     }
-    const int ops = (m + w.dm.per_op - 1) / w.dm.per_op;
-    w.ops_cap = ops;
-    const size_t rhs_cap = (size_t)w.ops_cap * w.dm.per_op;
+    int ops = (m + w.dm.per_op - 1) / w.dm.per_op;
+    size_t rhs_cap = (size_t)ops * w.dm.per_op;
+    if (xtv_flat(w.dm, tune)) {          // flat packing: ceil(10 m' / 32) operands plus at most one partly used per pass, for any m' <= m
+        const int cap = xtv_pass_residuals(w.dm, tune), npass = (m + cap - 1) / cap;
+        if (npass <= kMaxFlatPasses) { ops = (m * w.dm.slots + 31) / 32 + npass; rhs_cap = (size_t)m; }
+    }
+    w.ops_cap = ops; w.rhs_cap = rhs_cap;
     const size_t lanes = (size_t)w.ops_cap * (size_t)nblk * 64;
     const size_t dwords = lanes * (w.dm.base == 49 ? 6 : 4);
     MIH_TRY(w.digits.alloc(dwords));
@@ -1446,12 +1532,51 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
     const int64_t nblk = h->nbp * 2, pstride = h->ncg * 32;
     const int per_op = dm.per_op;
     const int nops = (m + per_op - 1) / per_op;
-    double *part = w.scal.p + (size_t)w.ops_cap * per_op * 4;
+    double *part = w.scal.p + w.rhs_cap * 4;
     hipLaunchKernelGGL(k_r_stats, dim3(kStatBlocks, (unsigned)m), dim3(256), 0, s, r_dev, h->n, m, part, w.stat_done.p, dm.ebits, w.scal.p);
     uint4 *dig_all = reinterpret_cast<uint4 *>(w.digits.p);
     uint2 *dig2_all = reinterpret_cast<uint2 *>(w.digits.p + (size_t)w.ops_cap * (size_t)nblk * 64 * 4);   // FP6 only
-    hipLaunchKernelGGL(k_digits, dim3((unsigned)((nblk + 3) / 4), (unsigned)(nops * per_op)), dim3(256), 0, s, r_dev, h->n, nblk, m, dm,
-                       w.scal.p, dig_all, dig2_all);
+    FlatPasses fp{};
+    if (xtv_flat(dm, tn)) {
+        // the residuals are dealt out evenly over as few passes as hold them; pass q scores residuals u0[q] .. u0[q+1] from the
+        // operands t0[q] .. t0[q+1] (ceil(10 cnt / 32) of them: never more than the per-operand layout needs)
+        const int cap = xtv_pass_residuals(dm, tn), npass = (m + cap - 1) / cap;
+        if (npass <= kMaxFlatPasses) {
+            dm.flat = 1;
+            fp.npass = npass;
+            int u = 0, t = 0;
+            for (int q = 0; q < npass; ++q) {
+                const int cnt = m / npass + (q < m % npass ? 1 : 0);
+                fp.u0[q] = u; fp.t0[q] = t;
+                u += cnt; t += (cnt * dm.slots + 31) / 32;
+            }
+            fp.u0[npass] = u; fp.t0[npass] = t;
+        }
+    }
+    hipLaunchKernelGGL(k_digits, dim3((unsigned)((nblk + 3) / 4), (unsigned)(dm.flat ? m : nops * per_op)), dim3(256), 0, s, r_dev, h->n, nblk, m, dm,
+                       w.scal.p, dig_all, dig2_all, fp);
+    for (int q = 0; dm.flat && q < fp.npass; ++q) {
+        const int u0 = fp.u0[q], u1 = fp.u0[q + 1], t = fp.t0[q], nr = fp.t0[q + 1] - t;
+        DigitMode dq = dm;
+        dq.nres = u1 - u0;
+        double *partial = w.partial.p + (int64_t)u0 * splits * pstride;
+        PassRecord rec;
+        const bool prof = prof_begin(h, s, rec);
+        const bool half = tn.half && (u1 - u0) * dm.slots - 32 * (nr - 1) <= 16;      // the last operand's second fragment holds no column
+        char name[48] = {0};
+        int rc = dispatch_xtv(tn, nr, half, h, dig_all + (int64_t)t * nblk * 64, dig2_all + (int64_t)t * nblk * 64, nblk * 64, splits, dq,
+                              w.scal.p + 4 * u0, partial, s, name);
+        if (prof) {
+            rec.residuals = u1 - u0; rec.operands = nr; rec.stream_tag = w.stream_tag;
+            memcpy(rec.kernel, name, sizeof(rec.kernel));
+            prof_end(h, s, rec);
+        }
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_xtv_finalize, dim3((unsigned)((h->p + 255) / 256), (unsigned)(u1 - u0)), dim3(256), 0, s,
+                           partial, splits, pstride, h->p, w.scal.p + 4 * u0, r_dev + (int64_t)u0 * h->n, h->n, h->mu, h->sinv,
+                           h->miss_ptr, h->miss_row, h->center, h->scale, h->impute, out_dev + (int64_t)u0 * h->p);
+    }
+    if (dm.flat) { MIH_HIP(hipGetLastError()); return MIH_OK; }
     for (int t = 0; t < nops;) {          // t counts B operands
         int nr = (nops - t >= 4 && nops - t != 5 && tn.max_nr >= 4) ? 4 : ((nops - t == 3 || nops - t == 5) && tn.max_nr >= 4) ? 3
                  : (nops - t >= 2 && tn.max_nr >= 2) ? 2 : 1;

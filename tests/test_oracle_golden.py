@@ -472,3 +472,13 @@ def test_choose_callback_takes_the_place_of_the_references_rng(oracle):
     assert mdrawn["choose_fired"] and np.count_nonzero(mdrawn["B"]) <= 3
     assert len(mlog) == 1                                # one tied projection: the first step (the initial support is not projected through project_k!(v), multivariate.jl:436-445)
     assert sorted(np.flatnonzero(mdrawn["B"].ravel(order="F"))) == sorted(set(mlog[0][1]) - {int(first[0])})
+
+
+def test_group_norms_round_the_square_then_the_sum(oracle):
+    """utilities.jl:626 `group_norm[n] + y[j]^2`: square rounded, then the sum (no fma): 2.2^2 + 1.8^2 + 1.3^2 = 9.770000000000001 beats
+    2.0^2 + 1.7^2 + 1.2^2 + 1.2^2 = 9.77; fused, they tie and the lower label wins (the GPU test of the same name)."""
+    y = np.array([-2.0, 1.7, -1.2, 1.2, 2.2, -1.8, 1.3, 0.05])
+    group = np.array([1, 1, 1, 1, 2, 2, 2, 3])
+    want = np.array([0, 0, 0, 0, 2.2, -1.8, 1.3, 0])
+    assert np.array_equal(oracle.project_group_sparse(y, group, 1, 4), want)
+    assert np.array_equal(oracle.project_group_sparse(y, group, 1, np.array([4, 3, 1])), want)
