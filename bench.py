@@ -432,6 +432,7 @@ def main():
     found = float(np.intersect1d(np.flatnonzero(bhat) + lo, supp).size)
     recovered = int(sum_over_ranks([found])[0]) if sharded else int(found)
     sess.close()
+    del sess                                                # (it holds a reference to the matrix: the shard must be gone before the full replica comes)
     if comm is not None and hasattr(comm, "close"):
         comm.close()                                        # collectively, while every rank is alive
     rows = gather_rows([st["launches"], st["ms_sum"], st["bytes"], float(cnt)]) if sharded else [[st["launches"], st["ms_sum"], st["bytes"], float(cnt)]]

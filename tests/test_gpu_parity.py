@@ -2524,6 +2524,36 @@ def test_ingest_pipeline_at_full_row_count(mih):
     assert np.array_equal(x2.export_bed(), cols)
 
 
+def test_ingest_of_a_tall_matrix_stays_within_the_staging_budget(mih):
+    """ A chunk of the upload pipeline is at least one group of 32 columns, so above a 512 KB column stride it outgrows
+    the 16 MB target: at n = 4.4M rows (1.1 MB per column) a chunk is 35 MB and eight workers with two buffers each would pin 560 MB
+    of host memory and take as much VRAM; mih_snp_create caps the staging of all workers at 512 MB (fewer workers) and degrades
+    to one worker if the allocation fails.  The matrix must be the one the on-device generator builds: same bytes back out, same
+    column statistics, same X'r bits (n > 2^22 rows: the fused formats step down, §3.1), incl. a strided source and a ragged
+    last chunk (70 columns = 32 + 32 + 6)."""
+    n, p = 4_400_000, 70
+    xs = mih.SnpLinAlg.synthetic(n, p, seed=77, missing_rate=0.002)
+    cols = xs.export_bed()
+    assert cols.shape == (p, (n + 3) // 4)
+    x = mih.SnpLinAlg(cols, n=n, center=True, scale=True, impute=True)
+    assert np.array_equal(x.export_bed(), cols)
+    mu_s, sv_s = xs.mu_sigma()
+    mu, sv = x.mu_sigma()
+    assert np.array_equal(mu, mu_s) and np.array_equal(sv, sv_s)
+    r = np.random.default_rng(4).standard_normal(n)
+    got = x.xtv(r)
+    assert np.array_equal(got, xs.xtv(r))
+    # column 3 against numpy (dosage codes 00 -> 0, 10 -> 1, 11 -> 2, 01 -> missing = the column mean)
+    j = 3
+    code = np.stack([(cols[j] >> (2 * t)) & 3 for t in range(4)], axis=1).ravel()[:n]
+    g = np.array([0.0, np.nan, 1.0, 2.0])[code]
+    g[np.isnan(g)] = mu[j]
+    assert got[j] == pytest.approx(float(np.dot((g - mu[j]) * sv[j], r)), rel=1e-10)
+    wide = np.zeros((p, cols.shape[1] + 5), dtype=np.uint8)
+    wide[:, :cols.shape[1]] = cols
+    assert np.array_equal(mih.SnpLinAlg(wide, n=n, center=True, scale=True, impute=True).export_bed(), cols)
+
+
 def test_choose_callback_makes_the_references_random_draw(mih, oracle):
     """_choose! (src/utilities.jl:444-458, src/multivariate.jl:310-351): the one place on the path where the reference draws
     from the caller's RNG.  mih_fit_params::choose hands the draw to the caller (the Julia glue answers with the reference's own

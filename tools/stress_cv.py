@@ -18,12 +18,18 @@ for (n, p, q, path, seed) in ((6001, 900, 3, range(1, 9), 3), (20_000, 4000, 5, 
     yb = (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float)
     y = eta + rng.standard_normal(n)
     folds = m.hash_folds(n, q)
-    cases.append((x, yb, y, folds, q, list(path)))
+    ynb = rng.negative_binomial(4, 4 / (np.exp(0.5 + 0.3 * eta) + 4)).astype(float)      # (round 4: est_r chains on the lock-step driver)
+    cases.append((x, yb, y, folds, q, list(path), ynb))
 
 
 def run_all():
     out = []
-    for x, yb, y, folds, q, path in cases:
+    for x, yb, y, folds, q, path, ynb in cases:
+        nb = dict(d=m.NegativeBinomial(1.0), l=m.LogLink(), verbose=False)
+        if x.p <= 4000:                                        # chains of NegBin fits handing r on, in lock-step (every chain shape), and est_r model paths
+            for T, est in ((0, "Newton"), (1, "MM"), (7, "Newton")):
+                out.append(m.cv_iht(ynb, x, None, path=path[:6], q=q, folds=folds, return_raw=True, est_r=est, cv_threads=T, **nb)[1])
+            out.append(np.asarray(m.iht_run_many_models(ynb, x, None, path=path[:6], est_r="Newton", **nb)))
         out.append(m.cv_iht(yb, x, None, path=path, q=q, folds=folds, verbose=False, return_raw=True, d=m.Bernoulli(), l=m.LogitLink())[1])
         out.append(m.cv_iht(y, x, None, path=path, q=q, folds=folds, verbose=False, return_raw=True)[1])
         out.append(np.asarray(m.iht_run_many_models(y, x, None, path=path, verbose=False)))
