@@ -476,6 +476,7 @@ typedef struct {
     const int64_t *group; const double *weight;
     int choose_fired;
     double eta_cond;      /* orc_result.eta_cond */
+    double ib_cond;       /* orc_result.ib_cond */
     int (*choose_cb)(void *, int32_t, const int64_t *, int64_t, int64_t, int64_t *);
     void *choose_user;
     int init_beta;
@@ -495,7 +496,7 @@ static ihtvar *iv_create(const orc_mat *x, const orc_params *prm, const double *
     v->dist = prm->dist; v->link = prm->link; v->nb_r = prm->nb_r; v->est_r = prm->est_r;
     v->group = prm->group; v->weight = prm->weight; v->init_beta = prm->init_beta;
     v->choose_cb = prm->choose; v->choose_user = prm->choose_user;
-    v->eta_cond = 1.0;
+    v->eta_cond = 1.0; v->ib_cond = 1.0;
     v->b = dalloc(p); v->b0 = dalloc(p); v->best_b = dalloc(p); v->df = dalloc(p);
     v->xb = dalloc(n); v->xgk = dalloc(n); v->r = dalloc(n); v->zc = dalloc(n);
     v->zdf2 = dalloc(n); v->mu = dalloc(n); v->cv_wts = dalloc(n);
@@ -657,11 +658,12 @@ static int gradstep(ihtvar *v, double eta)
 
 /* linreg! utilities.jl:823-842: regress y on [1 x]; on a Cholesky failure (e.g. a constant x) the
  * reference's `catch` returns xty_store UNSOLVED, i.e. (sum y, x'y) */
-static void linreg(const double *x, const double *y, int64_t N, double *b0, double *b1)
+static void linreg(const double *x, const double *y, int64_t N, double *b0, double *b1, double *cond)
 {
     double sx = 0.0, sxx = 0.0, sy = 0.0, sxy = 0.0;
     for (int64_t i = 0; i < N; ++i) { sx += x[i]; sxx += x[i] * x[i]; sy += y[i]; sxy += x[i] * y[i]; }
     double u11 = sqrt((double)N), u12 = sx / u11, d = sxx - u12 * u12;
+    if (cond && sxx > 0.0) { double c = fabs(d) / sxx; if (c < *cond) *cond = c; }     /* diagnostic only (orc_result.ib_cond) */
     if (!(N > 0) || !(d > 0.0)) { *b0 = sy; *b1 = sxy; return; }
     double u22 = sqrt(d);
     double w1 = sy / u11, w2 = (sxy - u12 * w1) / u22;
@@ -683,13 +685,13 @@ static int initialize_beta(ihtvar *v)
         axpy_col(v->x, j, 1.0, col);
         t = 0;
         for (int64_t i = 0; i < n; ++i) if (v->cv_wts[i] != 0.0) xs[t++] = col[i];
-        linreg(xs, ys, nt, &b0, &b1);
+        linreg(xs, ys, nt, &b0, &b1, &v->ib_cond);
         c0 += b0; v->b[j] = b1;
     }
     for (int64_t l = 1; l < q; ++l) {
         t = 0;
         for (int64_t i = 0; i < n; ++i) if (v->cv_wts[i] != 0.0) xs[t++] = v->z[l * n + i];
-        linreg(xs, ys, nt, &b0, &b1);
+        linreg(xs, ys, nt, &b0, &b1, &v->ib_cond);
         c0 += b0; v->c[l] = b1;
     }
     v->c[0] = c0 / (double)(p + q - 1);
@@ -1147,7 +1149,7 @@ int orc_fit_iht(const orc_mat *x, const orc_params *prm, const double *y,
                            res->bt_trace, &res->n_trace);
     if (!rc) {
         res->pve = sample_var(v->mu, v->n) / sample_var(v->y, v->n);  /* pve.jl:22,32 */
-        res->nb_r = v->nb_r; res->choose_fired = v->choose_fired; res->eta_cond = v->eta_cond;
+        res->nb_r = v->nb_r; res->choose_fired = v->choose_fired; res->eta_cond = v->eta_cond; res->ib_cond = v->ib_cond;
         if (res->beta) memcpy(res->beta, v->best_b, sizeof(double) * v->p);
         if (res->c) memcpy(res->c, v->best_c, sizeof(double) * v->q);
         if (res->mu) memcpy(res->mu, v->mu, sizeof(double) * v->n);

@@ -96,6 +96,14 @@ typedef struct orc_result {
                                  utilities.jl:760-761 makes the step 1e-8 instead (seed 4036 of tools/fuzz_parity.py: the sum of
                                  y - mu came out as 0 on the GPU and as 1e-13 here).  Either way two floating-point
                                  implementations take different steps; the sweeps set such a trajectory aside. */
+    double   ib_cond;         /* diagnostic, not in the reference: with init_beta, the smallest over the univariate regressions of
+                                 |sum x^2 - (sum x)^2 / N| / sum x^2, the relative second pivot of linreg!'s 2 x 2 Cholesky
+                                 (utilities.jl:823-842); 1 without init_beta.  A predictor that is CONSTANT over the training rows
+                                 (a SNP monomorphic in a fold) makes that pivot a rounding residue: if it comes out <= 0 the
+                                 reference's `catch` returns the unsolved right-hand side (beta = x'y, clamped to +-2), if it comes
+                                 out as +1e-14 the "solution" is a ratio of two residues -- Julia's pairwise sums, this file's
+                                 running sums and the device's exact integer counts each land somewhere else (seed 9568 of
+                                 tools/fuzz_parity.py).  The sweeps set such a fit aside. */
 } orc_result;
 
 /* ---- SnpLinAlg restatement (SnpArrays.jl linalg_direct.jl) ------------- */

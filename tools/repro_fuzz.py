@@ -60,3 +60,53 @@ if what == "projections":
     for r in range(3):
         again = mih.project_group_sparse(w, group, J, kg)
         print("  rerun", r, "differs from the oracle at", np.flatnonzero(again != want).size, "positions; equal to the first GPU result:", np.array_equal(again, got, equal_nan=True))
+if what == "cv":
+    want = int(sys.argv[3])
+    fams = [("normal", "identity", mih.Normal, mih.IdentityLink, 1e-6), ("bernoulli", "logit", mih.Bernoulli, mih.LogitLink, 1e-5),
+            ("poisson", "log", mih.Poisson, mih.LogLink, 1e-5)]
+    for trial in range(want + 1):
+        n, p, q, od, ol, D, L, tol, x, ox, y, path, folds, extra = T._cv_case(mih, oracle, rng, trial, fams)
+    print("n", n, "p", p, "q", q, od, "path", path, "extra", {k: (v if not hasattr(v, "shape") else f"array{v.shape}") for k, v in extra.items()})
+    mse, raw = mih.cv_iht(y, x, None, d=D(), l=L(), path=path, q=q, folds=folds, verbose=False, return_raw=True, **extra)
+    omse, oraw = oracle.cv_iht(ox, y, None, path=path, q=q, folds=folds, dist=od, link=ol, **extra)
+    bad = np.argwhere(~np.isclose(raw, oraw, rtol=100 * tol, atol=0))
+    print("entries that differ:", bad.tolist())
+    for f, j in bad[:4]:
+        tr = (folds != f + 1).astype(np.uint8)
+        one_o = oracle.fit_iht(ox, y, None, k=path[j], dist=od, link=ol, max_iter=100, train=tr, **extra)
+        one_g = mih.fit_iht(y, x, None, k=path[j], d=D(), l=L(), max_iter=100, train=tr, verbose=False, **extra)
+        print(f" fold {f + 1} k {path[j]}: cv gpu {raw[f, j]!r} oracle {oraw[f, j]!r}")
+        print("   single fits: oracle iter", one_o["iter"], "logl", one_o["logl"], "bt", one_o["bt_trace"].tolist(), "| gpu iter", one_g.iter, "logl", one_g.logl, "bt", one_g.trace["backtracks"].tolist())
+        print("   supports equal:", np.array_equal(np.flatnonzero(one_o["beta"]), np.flatnonzero(one_g.beta)), "max |beta diff|", float(np.max(np.abs(one_o["beta"] - one_g.beta))))
+    for rr in range(2):
+        again = mih.cv_iht(y, x, None, d=D(), l=L(), path=path, q=q, folds=folds, verbose=False, return_raw=True, **extra)[1]
+        print(" rerun equal to the first GPU run:", np.array_equal(again, raw))
+    two = [mih.cv_iht(y, x, None, d=D(), l=L(), path=path, q=q, folds=folds, verbose=False, return_raw=True, rank=r, world=2, **extra)[1] for r in range(2)]
+    print(" two shards add up to the single-rank matrix:", np.array_equal(two[0] + two[1], raw))
+    if extra.get("init_beta") and len(bad):
+        f, j = bad[0]
+        tr = (folds != f + 1).astype(np.uint8)
+        for kk in path[:3]:
+            for mi in (2, 3):
+                o = oracle.fit_iht(ox, y, None, k=kk, dist=od, link=ol, max_iter=mi, train=tr, init_beta=True)
+                g = mih.fit_iht(y, x, None, k=kk, d=D(), l=L(), max_iter=mi, train=tr, verbose=False, init_beta=True)
+                so, sg = np.flatnonzero(o["beta"]), np.flatnonzero(g.beta)
+                print(f"  k {kk} max_iter {mi}: oracle support {so.tolist()} beta {o['beta'][so].round(6).tolist()} c {o['c'].round(6).tolist()} logl {o['logl']:.6f} | gpu support {sg.tolist()} beta {g.beta[sg].round(6).tolist()} c {np.round(g.c, 6).tolist()} logl {g.logl:.6f}")
+        # the univariate regressions themselves on the training rows (numpy)
+        cols = x.export_bed()
+        mu, sv = x.mu_sigma()
+        tri = np.flatnonzero(tr)
+        ys = y[tri]
+        b1 = np.zeros(p); b0 = np.zeros(p); fail = 0
+        for jj in range(p):
+            code = np.stack([(cols[jj] >> (2 * t)) & 3 for t in range(4)], axis=1).ravel()[:n]
+            gdos = np.array([0.0, np.nan, 1.0, 2.0])[code]
+            gdos[np.isnan(gdos)] = mu[jj]
+            xs = ((gdos - mu[jj]) * sv[jj])[tri]
+            N = xs.size; sx = xs.sum(); sxx = (xs * xs).sum(); sxy = xs @ ys; sy = ys.sum()
+            d = sxx - sx * sx / N
+            if not d > 0: fail += 1; b0[jj], b1[jj] = sy, sxy
+            else: b1[jj] = (sxy - sx * sy / N) / d; b0[jj] = (sy - b1[jj] * sx) / N
+        cl = np.clip(b1, -2, 2)
+        print("  numpy regressions: failed Cholesky", fail, "clamped to +-2:", int(np.sum(np.abs(cl) == 2.0)), "top |beta|:", np.sort(np.abs(cl))[::-1][:6].round(6).tolist(),
+              "argsort top:", np.argsort(-np.abs(cl), kind="stable")[:6].tolist())
