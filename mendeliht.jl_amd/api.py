@@ -660,7 +660,7 @@ _default_digits = 0
 def set_xtv_digits(digits=0):
     """Default of the `xtv_digits=` keyword of this mirror's calls (fit_iht, cv_iht, iht_run_many_models, IHTSession,
     SnpLinAlg.xtv, ...): the fixed-point format of the residual in X'r, id = base * 100 + digits -- 0 = library default =
-    4910 (10 base-49 FP6 digits, 54-bit, three residuals per MFMA operand) for fused passes and 428 (28 base-4 digits) for
+    4910 (10 base-49 FP6 digits, 54-bit, 19 residuals in the six operands of a full pass) for fused passes and 428 (28 base-4 digits) for
     a single fit; 1316 (16 base-13 FP4 digits, 57-bit, two per operand); 4908 (43-bit, four per operand: the opt-in fast
     mode for fused multi-RHS passes); 1308 (27-bit, four per operand).  The LIBRARY has no such global: the format travels
     with every call (mih_fit_params::xtv_digits, mih_xtv_batched_fmt), so concurrent calls may differ."""
