@@ -228,7 +228,7 @@ k_xv_snp_cached_multi(const uint32_t *__restrict__ cache, int64_t ndw, int64_t n
 template <int MT>
 __global__ void __launch_bounds__(256)
 k_xv_snp_cached_mt(const uint32_t *__restrict__ cache, int64_t ndw, int64_t n, const int32_t *__restrict__ slots,
-                   const double *__restrict__ A, const double *__restrict__ Bg, int nnz, int groups, int m,
+                   const double *__restrict__ A, const double *__restrict__ Bg, int nnz, int groups, int m, int rs,
                    double *__restrict__ out)
 {
     const int64_t tid = blockIdx.x * 256ll + threadIdx.x;
@@ -237,17 +237,34 @@ k_xv_snp_cached_mt(const uint32_t *__restrict__ cache, int64_t ndw, int64_t n, c
     const int sh = (int)(tid & 7) * 4;
     const int v0 = blockIdx.y * MT;
     const int per = (nnz + groups - 1) / groups;
-    const double *Av[MT], *Gv[MT];
+    // (round 4) the coefficients of a column are ONE record of rs = m rounded up to 4 doubles (trait v at A[t * rs + v]): two wide scalar loads
+    // and one address per column instead of ten narrow loads with ten addresses (24.7 SALU + 11.3 SMEM instructions per column and
+    // wave before, the waves parked at lgkmcnt 43 % of their cycles: counters of tools/pmc_mv.sh), requested one column ahead
+    const double *Gv[MT];
     #pragma unroll
-    for (int v = 0; v < MT; ++v) { const int vv = v0 + v < m ? v0 + v : m - 1; Av[v] = A + (int64_t)vv * nnz; Gv[v] = Bg + (int64_t)vv * groups; }
+    for (int v = 0; v < MT; ++v) { const int vv = v0 + v < m ? v0 + v : m - 1; Gv[v] = Bg + (int64_t)vv * groups; }
+    const double *rec0 = A + v0;
+    // (trait slots past m read the record's padding or the next record: their sums are not stored; the buffer has the slack)
     double acc[MT][2], tot[MT][2];
     #pragma unroll
     for (int v = 0; v < MT; ++v) { acc[v][0] = acc[v][1] = 0.0; tot[v][0] = tot[v][1] = 0.0; }
     int left = per, g = 0;
+    // The dwords of the NEXT four columns are requested before the multiply-adds of the current four (double buffer w4 / wn): with
+    // four waves per SIMD the ~1 us load latency of a batch was exposed 125 times per call at 500 columns.
+    uint32_t wn[4];
+    #pragma unroll
+    for (int u = 0; u < 4; ++u) wn[u] = cache[(int64_t)slots[u < nnz ? u : nnz - 1] * ndw + dw];
+    double a_cur[MT];
+    #pragma unroll
+    for (int v = 0; v < MT; ++v) a_cur[v] = static_cast<const double *>(__builtin_assume_aligned(rec0, 32))[v];
     for (int t = 0; t < nnz; t += 4) {
         uint32_t w4[4];
         #pragma unroll
-        for (int u = 0; u < 4; ++u) w4[u] = cache[(int64_t)slots[t + u < nnz ? t + u : nnz - 1] * ndw + dw] >> sh;
+        for (int u = 0; u < 4; ++u) w4[u] = wn[u] >> sh;
+        if (t + 4 < nnz) {
+            #pragma unroll
+            for (int u = 0; u < 4; ++u) wn[u] = cache[(int64_t)slots[t + 4 + u < nnz ? t + 4 + u : nnz - 1] * ndw + dw];
+        }
         #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (t + u < nnz) {
@@ -260,12 +277,17 @@ k_xv_snp_cached_mt(const uint32_t *__restrict__ cache, int64_t ndw, int64_t n, c
                     }
                     ++g; left = per;
                 }
+                const double *recn = static_cast<const double *>(__builtin_assume_aligned(rec0 + (int64_t)(t + u + 1 < nnz ? t + u + 1 : nnz - 1) * rs, 32));
+                double a_nxt[MT];
+                #pragma unroll
+                for (int v = 0; v < MT; ++v) a_nxt[v] = recn[v];
                 const double g0 = (double)(w4[u] & 3u), g1 = (double)((w4[u] >> 2) & 3u);
                 #pragma unroll
                 for (int v = 0; v < MT; ++v) {
-                    const double a = Av[v][t + u];
-                    acc[v][0] = fma(g0, a, acc[v][0]); acc[v][1] = fma(g1, a, acc[v][1]);
+                    acc[v][0] = fma(g0, a_cur[v], acc[v][0]); acc[v][1] = fma(g1, a_cur[v], acc[v][1]);
                 }
+                #pragma unroll
+                for (int v = 0; v < MT; ++v) a_cur[v] = a_nxt[v];
                 --left;
             }
         }
@@ -286,7 +308,7 @@ k_xv_snp_cached_mt(const uint32_t *__restrict__ cache, int64_t ndw, int64_t n, c
 __global__ void __launch_bounds__(256)
 k_xv_coef_groups(const int64_t *__restrict__ idx, const double *__restrict__ val, int nnz,
                  const double *__restrict__ mu, const double *__restrict__ sinv, int center, int scale, int groups,
-                 double *__restrict__ A, double *__restrict__ Bg)
+                 double *__restrict__ A, double *__restrict__ Bg, int64_t a_trait_stride, int64_t a_col_stride)
 {
 #pragma clang fp contract(off)       // bsum += b must round like the stored B of k_xv_coef_multi
     constexpr int CH = 2048;
@@ -301,7 +323,7 @@ k_xv_coef_groups(const int64_t *__restrict__ idx, const double *__restrict__ val
             const int64_t j = idx[t];
             const double sc = scale ? sinv[j] : 1.0;
             const double a = sc * val[(int64_t)v * nnz + t];
-            A[(int64_t)v * nnz + t] = a;
+            A[(int64_t)v * a_trait_stride + (int64_t)t * a_col_stride] = a;       // trait-major, or one record of kXvRec doubles per column
             sb[t - base] = center ? -mu[j] * a : 0.0;
         }
         __syncthreads();
@@ -508,7 +530,7 @@ int xv_sparse_multi_device(const mih_mat *h, XvWork &w, const int64_t *idx_dev, 
     if (multi_on && m > 1 && nnz > 0 && h->kind == 0 && !fix && idx_host && h->p < (1ll << 40)) {
         if (nnz * m > w.cap) {
             MIH_HIP(hipStreamSynchronize(s));
-            MIH_TRY(w.coefA.alloc((size_t)nnz * m * 2));
+            MIH_TRY(w.coefA.alloc((size_t)nnz * (m + 3) * 2 + 32));      // (trait-major, or one record of m rounded up to 4 doubles per column)
             MIH_TRY(w.coefB.alloc((size_t)nnz * m * 2));
             w.cap = nnz * m * 2;
         }
@@ -519,8 +541,10 @@ int xv_sparse_multi_device(const mih_mat *h, XvWork &w, const int64_t *idx_dev, 
             static const bool mt_on = []() { const char *e = probe_env("MENDELIHT_XV_MULTI"); return !e || atoi(e) != 2; }();   // 2: the LDS-reduced kernel
             if (mt_on && nnz < (1ll << 30)) {
                 if ((size_t)m * groups > w.coefG.n) { MIH_HIP(hipStreamSynchronize(s)); MIH_TRY(w.coefG.alloc((size_t)m * kXvGroups * 2)); }
+                const int rs = (m + 3) & ~3;               // one record per column: the traits side by side (k_xv_snp_cached_mt)
+                if ((size_t)nnz * rs + 32 > w.coefA.n) { MIH_HIP(hipStreamSynchronize(s)); MIH_TRY(w.coefA.alloc((size_t)nnz * rs * 2 + 32)); }
                 hipLaunchKernelGGL(k_xv_coef_groups, dim3((unsigned)m), dim3(256), 0, s, idx_dev, vals_dev, (int)nnz,
-                                   h->mu, h->sinv, h->center, h->scale, groups, w.coefA.p, w.coefG.p);
+                                   h->mu, h->sinv, h->center, h->scale, groups, w.coefA.p, w.coefG.p, (int64_t)1, (int64_t)rs);
             } else
             hipLaunchKernelGGL(k_xv_coef_multi, dim3((unsigned)((nnz + 255) / 256), (unsigned)m), dim3(256), 0, s, idx_dev, vals_dev, nnz,
                                h->mu, h->sinv, h->center, h->scale, w.coefA.p, w.coefB.p);
@@ -533,7 +557,7 @@ int xv_sparse_multi_device(const mih_mat *h, XvWork &w, const int64_t *idx_dev, 
             if (mt_on && nnz < (1ll << 30)) {
                 const unsigned gx = (unsigned)((8 * ndw + 255) / 256);
 #define MIH_MT(MTV) hipLaunchKernelGGL((k_xv_snp_cached_mt<MTV>), dim3(gx, (unsigned)((m + MTV - 1) / MTV)), dim3(256), 0, s, \
-                                       w.cache.p, ndw, h->n, w.slot_dev.p, w.coefA.p, w.coefG.p, (int)nnz, groups, m, out_dev)
+                                       w.cache.p, ndw, h->n, w.slot_dev.p, w.coefA.p, w.coefG.p, (int)nnz, groups, m, (m + 3) & ~3, out_dev)
                 if (m <= 4) MIH_MT(4); else if (m <= 6) MIH_MT(6); else if (m <= 8) MIH_MT(8); else if (m <= 10) MIH_MT(10); else MIH_MT(12);
 #undef MIH_MT
                 MIH_HIP(hipGetLastError());
