@@ -477,6 +477,7 @@ typedef struct {
     int choose_fired;
     double eta_cond;      /* orc_result.eta_cond */
     double ib_cond;       /* orc_result.ib_cond */
+    double bt_cond;       /* orc_result.bt_cond */
     int (*choose_cb)(void *, int32_t, const int64_t *, int64_t, int64_t, int64_t *);
     void *choose_user;
     int init_beta;
@@ -496,7 +497,7 @@ static ihtvar *iv_create(const orc_mat *x, const orc_params *prm, const double *
     v->dist = prm->dist; v->link = prm->link; v->nb_r = prm->nb_r; v->est_r = prm->est_r;
     v->group = prm->group; v->weight = prm->weight; v->init_beta = prm->init_beta;
     v->choose_cb = prm->choose; v->choose_user = prm->choose_user;
-    v->eta_cond = 1.0; v->ib_cond = 1.0;
+    v->eta_cond = 1.0; v->ib_cond = 1.0; v->bt_cond = 1.0;
     v->b = dalloc(p); v->b0 = dalloc(p); v->best_b = dalloc(p); v->df = dalloc(p);
     v->xb = dalloc(n); v->xgk = dalloc(n); v->r = dalloc(n); v->zc = dalloc(n);
     v->zdf2 = dalloc(n); v->mu = dalloc(n); v->cv_wts = dalloc(n);
@@ -925,6 +926,15 @@ static int backtrack(ihtvar *v, double eta, double *logl)
     return ORC_OK;
 }
 
+/* diagnostic only (orc_result.bt_cond): how far apart the two loglikelihoods of a backtracking decision are */
+static void bt_margin(ihtvar *v, double old_logl, double new_logl)
+{
+    if (!isfinite(old_logl) || !isfinite(new_logl)) return;
+    double scale = fabs(old_logl) > 1e-300 ? fabs(old_logl) : 1e-300;
+    double m = fabs(old_logl - new_logl) / scale;
+    if (m < v->bt_cond) v->bt_cond = m;
+}
+
 /* iht_one_step! fit.jl:213-263 */
 static int one_step(ihtvar *v, double old_logl, int nstep, int *bt, double *new_logl_out)
 {
@@ -934,10 +944,12 @@ static int one_step(ihtvar *v, double old_logl, int nstep, int *bt, double *new_
     if (v->est_r) mle_for_r(v);
     double new_logl = loglik(v);
     int eta_step = 0;
+    bt_margin(v, old_logl, new_logl);
     while (old_logl > new_logl && eta_step < nstep) {   /* _iht_backtrack_ utilities.jl:484 */
         eta /= 2;
         rc = backtrack(v, eta, &new_logl); if (rc) return rc;
         eta_step++;
+        if (eta_step < nstep) bt_margin(v, old_logl, new_logl);
     }
     score(v);
     if (isnan(new_logl)) return ORC_NAN_LOGL;
@@ -1149,7 +1161,7 @@ int orc_fit_iht(const orc_mat *x, const orc_params *prm, const double *y,
                            res->bt_trace, &res->n_trace);
     if (!rc) {
         res->pve = sample_var(v->mu, v->n) / sample_var(v->y, v->n);  /* pve.jl:22,32 */
-        res->nb_r = v->nb_r; res->choose_fired = v->choose_fired; res->eta_cond = v->eta_cond; res->ib_cond = v->ib_cond;
+        res->nb_r = v->nb_r; res->choose_fired = v->choose_fired; res->eta_cond = v->eta_cond; res->ib_cond = v->ib_cond; res->bt_cond = v->bt_cond;
         if (res->beta) memcpy(res->beta, v->best_b, sizeof(double) * v->p);
         if (res->c) memcpy(res->c, v->best_c, sizeof(double) * v->q);
         if (res->mu) memcpy(res->mu, v->mu, sizeof(double) * v->n);

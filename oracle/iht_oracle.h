@@ -104,6 +104,13 @@ typedef struct orc_result {
                                  out as +1e-14 the "solution" is a ratio of two residues -- Julia's pairwise sums, this file's
                                  running sums and the device's exact integer counts each land somewhere else (seed 9568 of
                                  tools/fuzz_parity.py).  The sweeps set such a fit aside. */
+    double   bt_cond;         /* diagnostic, not in the reference: the smallest, over the evaluations of _iht_backtrack_'s
+                                 `old_logl > new_logl` (utilities.jl:484) that had another halving left to decide, of
+                                 |old_logl - new_logl| / |old_logl|; 1 when none was evaluated.  A converging fit proposes a step whose
+                                 loglikelihood equals the previous one to the last bit or two (seed 9878 of tools/fuzz_parity.py:
+                                 -2492.3159915021474 against ...480): whether that counts as "lower" -- two halvings of the
+                                 step here, none on the device, estimates 7e-7 apart -- is decided by the order of the n terms
+                                 of the loglikelihood sum.  The sweeps set a fit that DIFFERS and has bt_cond below 1e-13 aside. */
 } orc_result;
 
 /* ---- SnpLinAlg restatement (SnpArrays.jl linalg_direct.jl) ------------- */

@@ -1094,6 +1094,7 @@ def test_cv_iht_over_replicas_in_one_process(mih, normal_data):
         mih.cv_iht(y, [xa, mih.SnpLinAlg(bed[:100], n, center=True, scale=True)], z, path=path, q=3, folds=folds, verbose=False)
 
 
+_BT_TIE = 1e-13      # orc_result.bt_cond below this: `old_logl > new_logl` compared two sums of n terms that agree to their rounding error
 _NUDGES = [1.0 + e * 2.0 ** -51 for e in (2, 1, 3, 4, 6, 8)]      # a few ulps: one nudge can land on the same branch by luck (seed 2449)
 
 
@@ -1111,6 +1112,38 @@ def _unstable(a, b, rtol, atol=1e-10):
     return False
 
 
+def _fits_case(mih, oracle, rng, trial, fams):
+    """One random fit of test_randomized_fits_vs_oracle (replayed by tools/repro_fuzz.py)."""
+    n = int(rng.integers(60, 2500)); p = int(rng.integers(40, 600)); k = int(rng.integers(1, 10))
+    miss = float(rng.choice([0.0, 0.02, 0.1])); q = int(rng.integers(1, 4))
+    od, ol, D, L, tol = fams[int(rng.integers(0, 3))]
+    kind = str(rng.choice(["snp", "snp", "snp", "dense64", "dense32"]))       # (the reference's x::Matrix{Float64} / Matrix{Float32} callers too)
+    if kind == "snp":
+        cols = make_bed(rng, n, p, missing_rate=miss)
+        x = mih.SnpLinAlg(cols, n=n, center=True, scale=True, impute=True)
+        ox = oracle.Mat.from_bed_columns(cols, n)
+    else:
+        X = rng.standard_normal((n, p)).astype(np.float32 if kind == "dense32" else np.float64)
+        x = mih.DenseMatrix(X)
+        ox = oracle.Mat.from_dense(X.astype(np.float64))              # the upcast is exact: same matrix on both sides
+        miss = kind
+    z = np.column_stack([np.ones(n)] + [rng.standard_normal(n) for _ in range(q - 1)])
+    eta = 0.5 * _sim(oracle, ox, rng, min(k, 5)) + z @ (rng.standard_normal(q) * 0.3)
+    if kind != "snp":
+        eta *= 0.5                                                   # (unit-variance columns with unbounded entries: keep the counts moderate)
+    y = {"normal": eta + rng.standard_normal(n),
+         "bernoulli": (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float),
+         "poisson": rng.poisson(np.exp(np.clip(0.5 * eta, -3, 3))).astype(float)}[od]
+    kw = {}
+    if q > 1 and rng.random() < 0.5:
+        kw["zkeep"] = [1] + [int(v) for v in rng.integers(0, 2, q - 1)]
+    if rng.random() < 0.4:
+        kw["weight"] = rng.uniform(0.5, 2.0, p)
+    if rng.random() < 0.4:
+        kw["train"] = (rng.random(n) < 0.8).astype(np.uint8)
+    return n, p, k, miss, q, od, ol, D, L, tol, x, ox, y, z, kw
+
+
 def test_randomized_fits_vs_oracle(mih, oracle):
     """A seeded sweep over shapes, missing rates, families, covariates, zkeep masks, prior weights, train masks
     and k: the GPU fit must track the oracle (same support and iteration log) on every stable trajectory."""
@@ -1119,33 +1152,7 @@ def test_randomized_fits_vs_oracle(mih, oracle):
             ("poisson", "log", mih.Poisson, mih.LogLink, 1e-4)]
     tally = SweepTally("fits", ceiling=1, floor=13)
     for trial in range(14):
-        n = int(rng.integers(60, 2500)); p = int(rng.integers(40, 600)); k = int(rng.integers(1, 10))
-        miss = float(rng.choice([0.0, 0.02, 0.1])); q = int(rng.integers(1, 4))
-        od, ol, D, L, tol = fams[int(rng.integers(0, 3))]
-        kind = str(rng.choice(["snp", "snp", "snp", "dense64", "dense32"]))       # (the reference's x::Matrix{Float64} / Matrix{Float32} callers too)
-        if kind == "snp":
-            cols = make_bed(rng, n, p, missing_rate=miss)
-            x = mih.SnpLinAlg(cols, n=n, center=True, scale=True, impute=True)
-            ox = oracle.Mat.from_bed_columns(cols, n)
-        else:
-            X = rng.standard_normal((n, p)).astype(np.float32 if kind == "dense32" else np.float64)
-            x = mih.DenseMatrix(X)
-            ox = oracle.Mat.from_dense(X.astype(np.float64))              # the upcast is exact: same matrix on both sides
-            miss = kind
-        z = np.column_stack([np.ones(n)] + [rng.standard_normal(n) for _ in range(q - 1)])
-        eta = 0.5 * _sim(oracle, ox, rng, min(k, 5)) + z @ (rng.standard_normal(q) * 0.3)
-        if kind != "snp":
-            eta *= 0.5                                                   # (unit-variance columns with unbounded entries: keep the counts moderate)
-        y = {"normal": eta + rng.standard_normal(n),
-             "bernoulli": (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float),
-             "poisson": rng.poisson(np.exp(np.clip(0.5 * eta, -3, 3))).astype(float)}[od]
-        kw = {}
-        if q > 1 and rng.random() < 0.5:
-            kw["zkeep"] = [1] + [int(v) for v in rng.integers(0, 2, q - 1)]
-        if rng.random() < 0.4:
-            kw["weight"] = rng.uniform(0.5, 2.0, p)
-        if rng.random() < 0.4:
-            kw["train"] = (rng.random(n) < 0.8).astype(np.uint8)
+        n, p, k, miss, q, od, ol, D, L, tol, x, ox, y, z, kw = _fits_case(mih, oracle, rng, trial, fams)
         tag = (trial, n, p, k, od, q, miss, sorted(kw))
 
         def orc(g=1.0):                                  # None: the reference algorithm itself ends in an error (NaN / Inf loglikelihood, fit.jl:259-260)
@@ -1183,6 +1190,11 @@ def test_randomized_fits_vs_oracle(mih, oracle):
                 # a step used up max_step backtracks and the likelihood still dropped: which of two nearly equal loglikelihoods is
                 # "lower" is decided in the last bit, and six nudges do not always hit the other branch (seed 2449)
                 tally.set_aside("differs after a step that used up max_step backtracks", tag)
+                continue
+            if o["bt_cond"] < _BT_TIE and not np.array_equal(o["bt_trace"], res.trace["backtracks"][:len(o["bt_trace"])]):
+                # the two loglikelihoods of a backtracking decision agree to the last bits (iht_oracle.h, bt_cond) and the two
+                # sides decided it differently: the converging step of seed 9878, halved twice here and not at all on the device
+                tally.set_aside("a backtracking decision between loglikelihoods equal to rounding", tag)
                 continue
             raise
         tally.ok()
@@ -1266,7 +1278,7 @@ def test_randomized_options_vs_oracle(mih, oracle):
                 d = oracle.fit_iht(ox, yy, zz, k=k, max_iter=40, **okw, **both)
             except RuntimeError:
                 return None
-            return dict(iter=d["iter"], beta=d["beta"], c=d["c"] * g, logl=d["logl"], nb_r=d["nb_r"], bt=d["bt_trace"], eta_cond=d["eta_cond"], ib_cond=d["ib_cond"])
+            return dict(iter=d["iter"], beta=d["beta"], c=d["c"] * g, logl=d["logl"], nb_r=d["nb_r"], bt=d["bt_trace"], eta_cond=d["eta_cond"], ib_cond=d["ib_cond"], bt_cond=d["bt_cond"])
         o = orc(y, z)
         try:
             res = mih.fit_iht(y, x, z, k=k, max_iter=40, verbose=False, **kw, **both)
@@ -1304,6 +1316,9 @@ def test_randomized_options_vs_oracle(mih, oracle):
                 continue
             if (o is not None and o["bt"].max(initial=0) >= 3) or (res is not None and res.trace["backtracks"].max(initial=0) >= 3):
                 tally.set_aside("differs after a step that used up max_step backtracks", tag)      # on whichever side got that far (Poisson with the sqrt link: seeds 9009 .. 9071)
+                continue
+            if o is not None and res is not None and o["bt_cond"] < _BT_TIE and not np.array_equal(o["bt"], res.trace["backtracks"][:len(o["bt"])]):
+                tally.set_aside("a backtracking decision between loglikelihoods equal to rounding", tag)      # (seed 9878 of the first sweep)
                 continue
             raise
         tally.ok()
@@ -1730,6 +1745,24 @@ def test_randomized_cv_vs_oracle(mih, oracle):
     tally.finish()
 
 
+def _mvcv_case(mih, oracle, rng, trial):
+    """One random grid of test_randomized_multivariate_cv_vs_oracle (replayed by tools/repro_fuzz.py)."""
+    n = int(rng.integers(200, 1200)); p = int(rng.integers(60, 300)); r = int(rng.integers(2, 5))
+    qz = int(rng.integers(1, 3)); q = int(rng.integers(2, 4))
+    cols = make_bed(rng, n, p, missing_rate=float(rng.choice([0.0, 0.03])))
+    x = mih.SnpLinAlg(cols, n=n, center=True, scale=True, impute=True)
+    ox = oracle.Mat.from_bed_columns(cols, n)
+    Y, Z = _mv_problem(oracle, ox, rng, r, 6, qz)
+    path = sorted(int(v) for v in rng.choice(np.arange(1, 13), int(rng.integers(2, 6)), replace=False))
+    folds = hash_folds(n, q)
+    extra = {}
+    if qz > 1 and rng.random() < 0.5:
+        extra["zkeep"] = [1] + [int(v) for v in rng.integers(0, 2, qz - 1)]
+    if rng.random() < 0.25:
+        extra["init_beta"] = True
+    return n, p, r, qz, q, x, ox, Y, Z, path, folds, extra
+
+
 def test_randomized_multivariate_cv_vs_oracle(mih, oracle):
     """Seeded sweep of multivariate cross-validations (mih_cv_mv: the lock-step batches of r-trait fits, one fused X'R pass per
     round): traits, covariates (some not kept), folds, paths, missing genotypes, init_beta -- the held-out losses against the
@@ -1737,19 +1770,7 @@ def test_randomized_multivariate_cv_vs_oracle(mih, oracle):
     rng = np.random.default_rng(int(os.environ.get("MIH_SWEEP_SEED", 8086)))
     tally = SweepTally("multivariate cv (entries)", ceiling=1, floor=44)
     for trial in range(4):
-        n = int(rng.integers(200, 1200)); p = int(rng.integers(60, 300)); r = int(rng.integers(2, 5))
-        qz = int(rng.integers(1, 3)); q = int(rng.integers(2, 4))
-        cols = make_bed(rng, n, p, missing_rate=float(rng.choice([0.0, 0.03])))
-        x = mih.SnpLinAlg(cols, n=n, center=True, scale=True, impute=True)
-        ox = oracle.Mat.from_bed_columns(cols, n)
-        Y, Z = _mv_problem(oracle, ox, rng, r, 6, qz)
-        path = sorted(int(v) for v in rng.choice(np.arange(1, 13), int(rng.integers(2, 6)), replace=False))
-        folds = hash_folds(n, q)
-        extra = {}
-        if qz > 1 and rng.random() < 0.5:
-            extra["zkeep"] = [1] + [int(v) for v in rng.integers(0, 2, qz - 1)]
-        if rng.random() < 0.25:
-            extra["init_beta"] = True
+        n, p, r, qz, q, x, ox, Y, Z, path, folds, extra = _mvcv_case(mih, oracle, rng, trial)
         tag = (trial, n, p, r, qz, q, path, sorted(extra))
         mse, raw = mih.cv_iht(Y, x, Z, path=path, q=q, folds=folds, verbose=False, return_raw=True, **extra)
         omse, oraw = oracle.cv_mv(ox, Y, Z, path=path, q=q, folds=folds, **extra)
@@ -1758,6 +1779,11 @@ def test_randomized_multivariate_cv_vs_oracle(mih, oracle):
             stable = np.ones_like(ok)
             for g in _NUDGES:
                 stable &= np.isclose(oracle.cv_mv(ox, Y, Z * g, path=path, q=q, folds=folds, **extra)[1], oraw, rtol=1e-5, atol=0)
+            if extra.get("init_beta"):          # a SNP monomorphic in a fold's training rows (ib_cond, iht_oracle.h; seed 10137): the univariate
+                for f in range(q):              # regressions of initialize_beta! (multivariate.jl:519-560) see the same constant predictor
+                    one = oracle.fit_iht(ox, Y[0], None, k=1, max_iter=1, train=(folds != f + 1).astype(np.uint8), init_beta=True)
+                    if one["ib_cond"] < 1e-10:
+                        stable[f, :] = False
             assert (ok | ~stable).all() and (~stable).sum() <= max(2, stable.size // 5), (tag, np.argwhere(~ok & stable), raw, oraw)
             tally.set_aside("entry unstable in the oracle itself", tag, count=int((~ok).sum()))
             tally.ok(int(ok.sum()))
@@ -1769,6 +1795,39 @@ def test_randomized_multivariate_cv_vs_oracle(mih, oracle):
     tally.finish()
 
 
+def _path_case(mih, oracle, rng, trial, fams):
+    """One random model path of test_randomized_model_paths_vs_oracle (replayed by tools/repro_fuzz.py)."""
+    n = int(rng.integers(150, 1500)); p = int(rng.integers(60, 400)); q = int(rng.integers(1, 4))
+    od, ol, D, L = fams[int(rng.integers(0, 4))]
+    cols = make_bed(rng, n, p, missing_rate=float(rng.choice([0.0, 0.03])))
+    x = mih.SnpLinAlg(cols, n=n, center=True, scale=True, impute=True)
+    ox = oracle.Mat.from_bed_columns(cols, n)
+    z = np.column_stack([np.ones(n)] + [rng.standard_normal(n) for _ in range(q - 1)])
+    eta = 0.5 * _sim(oracle, ox, rng, 4) + z @ np.concatenate([[0.3], rng.standard_normal(q - 1) * 0.2])
+    y = {"normal": eta + rng.standard_normal(n),
+         "bernoulli": (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float),
+         "poisson": rng.poisson(np.exp(np.clip(0.5 * eta, -3, 3))).astype(float),
+         "negbin": rng.negative_binomial(4, 4 / (np.exp(0.5 + np.clip(0.5 * eta, -3, 3)) + 4)).astype(float)}[od]
+    path = sorted(int(v) for v in rng.choice(np.arange(1, 13), int(rng.integers(2, 8)), replace=False))
+    kw, okw = {}, {}
+    roll = rng.random()
+    if roll < 0.2:
+        kw["debias"] = okw["debias"] = True
+    elif roll < 0.4:
+        G = int(rng.integers(3, 8))
+        group = rng.integers(1, G + 1, p); group[:G] = np.arange(1, G + 1)
+        kw["group"] = okw["group"] = np.sort(group)
+    elif roll < 0.55:
+        kw["weight"] = okw["weight"] = rng.uniform(0.5, 2.0, p)
+    d = D(float(rng.choice([1.0, 4.0]))) if od == "negbin" else D()
+    if od == "negbin":
+        okw["nb_r"] = d.r
+        est = rng.choice(["None", "MM", "Newton"])
+        if est != "None":
+            kw["est_r"], okw["est_r"] = str(est), str(est).lower()
+    return n, p, q, od, ol, D, L, x, ox, y, z, path, kw, okw, d
+
+
 def test_randomized_model_paths_vs_oracle(mih, oracle):
     """Seeded sweep of iht_run_many_models (cross_validation.jl:232-273; the lock-step path driver, the sequential branch for
     est_r): families, covariates, groups, prior weights, debias, NegBin est_r -- the loglikelihood of every model size against
@@ -1778,34 +1837,7 @@ def test_randomized_model_paths_vs_oracle(mih, oracle):
             ("poisson", "log", mih.Poisson, mih.LogLink), ("negbin", "log", mih.NegativeBinomial, mih.LogLink)]
     tally = SweepTally("model paths (entries)", ceiling=1, floor=26)
     for trial in range(5):
-        n = int(rng.integers(150, 1500)); p = int(rng.integers(60, 400)); q = int(rng.integers(1, 4))
-        od, ol, D, L = fams[int(rng.integers(0, 4))]
-        cols = make_bed(rng, n, p, missing_rate=float(rng.choice([0.0, 0.03])))
-        x = mih.SnpLinAlg(cols, n=n, center=True, scale=True, impute=True)
-        ox = oracle.Mat.from_bed_columns(cols, n)
-        z = np.column_stack([np.ones(n)] + [rng.standard_normal(n) for _ in range(q - 1)])
-        eta = 0.5 * _sim(oracle, ox, rng, 4) + z @ np.concatenate([[0.3], rng.standard_normal(q - 1) * 0.2])
-        y = {"normal": eta + rng.standard_normal(n),
-             "bernoulli": (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float),
-             "poisson": rng.poisson(np.exp(np.clip(0.5 * eta, -3, 3))).astype(float),
-             "negbin": rng.negative_binomial(4, 4 / (np.exp(0.5 + np.clip(0.5 * eta, -3, 3)) + 4)).astype(float)}[od]
-        path = sorted(int(v) for v in rng.choice(np.arange(1, 13), int(rng.integers(2, 8)), replace=False))
-        kw, okw = {}, {}
-        roll = rng.random()
-        if roll < 0.2:
-            kw["debias"] = okw["debias"] = True
-        elif roll < 0.4:
-            G = int(rng.integers(3, 8))
-            group = rng.integers(1, G + 1, p); group[:G] = np.arange(1, G + 1)
-            kw["group"] = okw["group"] = np.sort(group)
-        elif roll < 0.55:
-            kw["weight"] = okw["weight"] = rng.uniform(0.5, 2.0, p)
-        d = D(float(rng.choice([1.0, 4.0]))) if od == "negbin" else D()
-        if od == "negbin":
-            okw["nb_r"] = d.r
-            est = rng.choice(["None", "MM", "Newton"])
-            if est != "None":
-                kw["est_r"], okw["est_r"] = str(est), str(est).lower()
+        n, p, q, od, ol, D, L, x, ox, y, z, path, kw, okw, d = _path_case(mih, oracle, rng, trial, fams)
         tag = (trial, n, p, q, od, path, sorted(kw))
         ll = np.asarray(mih.iht_run_many_models(y, x, z, path=path, d=d, l=L(), verbose=False, **kw))
         runs = [oracle.fit_iht(ox, y, z, k=k, dist=od, link=ol, max_iter=100, **okw) for k in path]
@@ -1815,13 +1847,18 @@ def test_randomized_model_paths_vs_oracle(mih, oracle):
         for j in np.flatnonzero(~ok):                 # the single-fit sweeps' rules for a trajectory nobody can be held to
             o = runs[j]
             unstable = o["eta_cond"] < 1e-18 or o["bt_trace"].max(initial=0) >= 3      # (only looked at after the comparison has failed)
+            why = "oracle unstable under ulp nudges"
+            if "est_r" in kw and o["nb_r"] > 1e6:
+                # counts without overdispersion: r runs off (1e7 .. 5e10 on seed 10168, from one ulp-sized nudge to the next) and the
+                # loglikelihood's lgamma(y + r) - lgamma(r) cancels n * eps * r log r ~ 1e-2 of absolute rounding error
+                unstable, why = True, "NegBin r ran off: the loglikelihood is lgamma cancellation noise"
             for g in _NUDGES:
                 if unstable:
                     break
                 o2 = oracle.fit_iht(ox, y, z * g, k=path[j], dist=od, link=ol, max_iter=100, **okw)
                 unstable = o2["iter"] != o["iter"] or not np.isclose(o2["logl"], o["logl"], rtol=tol, atol=0)
             assert unstable, (tag, path[j], ll[j], want[j])
-            tally.set_aside("oracle unstable under ulp nudges", (path[j],) + tag)
+            tally.set_aside(why, (path[j],) + tag)
         tally.ok(int(ok.sum()))
         halves = [np.asarray(mih.iht_run_many_models(y, x, z, path=path, d=d, l=L(), verbose=False, rank=r, world=2, **kw)) for r in range(2)]
         assert np.array_equal(halves[0] + halves[1], ll), tag

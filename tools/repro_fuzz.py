@@ -110,3 +110,47 @@ if what == "cv":
         cl = np.clip(b1, -2, 2)
         print("  numpy regressions: failed Cholesky", fail, "clamped to +-2:", int(np.sum(np.abs(cl) == 2.0)), "top |beta|:", np.sort(np.abs(cl))[::-1][:6].round(6).tolist(),
               "argsort top:", np.argsort(-np.abs(cl), kind="stable")[:6].tolist())
+if what == "mvcv":
+    want = int(sys.argv[3])
+    for trial in range(want + 1):
+        n, p, r, qz, q, x, ox, Y, Z, path, folds, extra = T._mvcv_case(mih, oracle, rng, trial)
+    print("n", n, "p", p, "r", r, "qz", qz, "q", q, "path", path, "extra", extra)
+    mse, raw = mih.cv_iht(Y, x, Z, path=path, q=q, folds=folds, verbose=False, return_raw=True, **extra)
+    omse, oraw = oracle.cv_mv(ox, Y, Z, path=path, q=q, folds=folds, **extra)
+    print("gpu", raw.tolist()); print("oracle", oraw.tolist())
+    if extra.get("init_beta"):
+        for f in range(q):
+            tr = (folds != f + 1).astype(np.uint8)
+            one = oracle.fit_iht(ox, Y[0], None, k=path[0], max_iter=2, train=tr, init_beta=True)
+            print(" fold", f + 1, "ib_cond of the univariate regressions on its training rows:", one["ib_cond"])
+if what == "paths":
+    want = int(sys.argv[3])
+    fams = [("normal", "identity", mih.Normal, mih.IdentityLink), ("bernoulli", "logit", mih.Bernoulli, mih.LogitLink),
+            ("poisson", "log", mih.Poisson, mih.LogLink), ("negbin", "log", mih.NegativeBinomial, mih.LogLink)]
+    for trial in range(want + 1):
+        n, p, q, od, ol, D, L, x, ox, y, z, path, kw, okw, d = T._path_case(mih, oracle, rng, trial, fams)
+    print("n", n, "p", p, "q", q, od, "path", path, "kw", {k: (v if not hasattr(v, "shape") else "array") for k, v in kw.items()}, "d", d)
+    ll = np.asarray(mih.iht_run_many_models(y, x, z, path=path, d=d, l=L(), verbose=False, **kw))
+    for k, got in zip(path, ll):
+        o = oracle.fit_iht(ox, y, z, k=k, dist=od, link=ol, max_iter=100, **okw)
+        g1 = mih.fit_iht(y, x, z, k=k, d=d, l=L(), max_iter=100, verbose=False, **kw)
+        print(f" k {k}: path {got!r} single gpu fit {g1.logl!r} (iter {g1.iter}, r {getattr(g1.d, 'r', None)}) oracle {o['logl']!r} (iter {o['iter']}, r {o['nb_r']}, bt max {o['bt_trace'].max(initial=0)})")
+        for g in T._NUDGES[:3]:
+            o2 = oracle.fit_iht(ox, y, z * g, k=k, dist=od, link=ol, max_iter=100, **okw)
+            print(f"     nudge {g}: oracle logl {o2['logl']!r} iter {o2['iter']} r {o2['nb_r']}")
+if what == "fits":
+    want = int(sys.argv[3])
+    fams = [("normal", "identity", mih.Normal, mih.IdentityLink, 1e-5), ("bernoulli", "logit", mih.Bernoulli, mih.LogitLink, 1e-4),
+            ("poisson", "log", mih.Poisson, mih.LogLink, 1e-4)]
+    for trial in range(want + 1):
+        n, p, k, miss, q, od, ol, D, L, tol, x, ox, y, z, kw = T._fits_case(mih, oracle, rng, trial, fams)
+    print("n", n, "p", p, "k", k, od, "q", q, miss, sorted(kw))
+    o = oracle.fit_iht(ox, y, z, k=k, dist=od, link=ol, max_iter=60, **kw)
+    res = mih.fit_iht(y, x, z, k=k, d=D(), l=L(), max_iter=60, verbose=False, **kw)
+    nz = np.flatnonzero(o["beta"])
+    print("iter", res.iter, o["iter"], "logl", res.logl, o["logl"], "bt", o["bt_trace"].tolist())
+    print("beta gpu", res.beta[nz].tolist(), "\nbeta orc", o["beta"][nz].tolist(), "\n diff", (res.beta[nz] - o["beta"][nz]).tolist())
+    print("c gpu", res.c.tolist(), "orc", o["c"].tolist(), "diff", (res.c - o["c"]).tolist())
+    for g in T._NUDGES:
+        o2 = oracle.fit_iht(ox, y, z * g, k=k, dist=od, link=ol, max_iter=60, **kw)
+        print(f"  nudge {g!r}: iter {o2['iter']} beta diff {(o2['beta'][nz] - o['beta'][nz]).tolist()} c diff {(o2['c'] * g - o['c']).tolist()}")
