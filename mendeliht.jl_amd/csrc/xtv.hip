@@ -159,18 +159,31 @@ __global__ void __launch_bounds__(256)
 k_digits(const double *__restrict__ r, int64_t n, int64_t nblk, int m, DigitMode dm,
          const double *__restrict__ scal, uint4 *__restrict__ dig /* [nops][nblk][64] */, uint2 *__restrict__ dig2, FlatPasses fp)
 {
-    __shared__ unsigned long long nib[4][64][2];
+    // The wave's 64 rows go into the B-operand image of their block directly: img[wave][half][digit] is the 128 (FP4) or 192 (FP6)
+    // bits lane (half, digit) of the fragment carries, and every row ORs its code into its element's place (LDS atomics; round 4 --
+    // before, the 2 x slots lanes that own an image gathered it with 32 LDS reads and 64-bit shifts each while the other 44 idled:
+    // 60 % of the kernel's time at ten digits).
+    __shared__ uint32_t img[4][2][32][6];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t blk = blockIdx.x * 4ll + w;
     const int vs = blockIdx.y;
     const int slots = dm.slots, op = vs / dm.per_op, sub = vs % dm.per_op;
     const bool fp6 = dm.base == 49;
-    const int cw = fp6 ? 6 : 4, per = fp6 ? 10 : 16;          // code width, codes per 64-bit word
-    unsigned long long wd[2] = {0ull, 0ull};
+    {
+        uint32_t *z = &img[w][0][0][0];
+        #pragma unroll
+        for (int e = 0; e < 6; ++e) z[e * 64 + lane] = 0u;
+    }
+    __syncthreads();
     if (vs < m && blk < nblk) {
         const int64_t i = blk * 64 + lane;
         const double x = (i < n) ? r[(int64_t)vs * n + i] : 0.0;
         long long R = __double2ll_rn(x * scal[4 * vs + 3]);
+        // element of this row in its half's fragment (the A fragment's order, mfma_fp4): 8 (2u + (s & 1)) + (s >> 1) for row 16u + s
+        const int hh = lane >> 5, uu = (lane >> 4) & 1, ss = lane & 15;
+        const int el = 8 * (2 * uu + (ss & 1)) + (ss >> 1);
+        const int bit = (fp6 ? 6 : 4) * el, dwd = bit >> 5, sh = bit & 31;
+        uint32_t *mine = &img[w][hh][0][0];
         // base 49: the standard digits of |R| come from two 5-digit limbs (49^5 < 2^29: 32-bit divisions instead of ten 64-bit
         // ones) and carry into the balanced residue system; the system is symmetric, digits(-R) = -digits(R)
         const bool neg = R < 0;
@@ -197,13 +210,15 @@ k_digits(const double *__restrict__ r, int64_t n, int64_t nblk, int m, DigitMode
                 R = (R - d) / 13;
             }
             const unsigned a = (unsigned)(d < 0 ? -d : d);
-            unsigned long long code;
+            uint32_t code;
             if (fp6) code = (a < 8 ? a : a < 16 ? a : a <= 30 ? 8u + (a >> 1) : 16u + (a >> 2)) | (d < 0 ? 32u : 0u);   // e2m3 of a/8
             else code = (a <= 4 ? a : a == 6 ? 5u : 6u) | (d < 0 ? 8u : 0u);                                          // e2m1 of a/2
-            wd[t / per] |= code << (cw * (t % per));
+            if (code) {
+                atomicOr(mine + t * 6 + dwd, code << sh);
+                if (sh > 26) atomicOr(mine + t * 6 + dwd + 1, code >> (32 - sh));       // (an FP6 code across a dword boundary)
+            }
         }
     }
-    nib[w][lane][0] = wd[0]; nib[w][lane][1] = wd[1];
     __syncthreads();
     if (blk < nblk && lane < 2 * slots) {
         const int h = lane / slots, dg = lane % slots;
@@ -219,32 +234,9 @@ k_digits(const double *__restrict__ r, int64_t n, int64_t nblk, int m, DigitMode
             const int e = (int)(blk & 1);
             o = ((int64_t)opc * nblk + (blk - e) + (col >> 4)) * 64 + 16 * (e + 2 * h) + (col & 15);
         }
-        if (!fp6) {
-            uint32_t out[4] = {0u, 0u, 0u, 0u};
-            #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                #pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const uint32_t code = (uint32_t)(nib[w][h * 32 + u * 16 + s][dg >> 4] >> (4 * (dg & 15))) & 0xFu;
-                    out[2 * u + (s & 1)] |= code << (4 * (s >> 1));
-                }
-            }
-            dig[o] = make_uint4(out[0], out[1], out[2], out[3]);
-        } else {
-            unsigned long long q[3] = {0ull, 0ull, 0ull};
-            #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                #pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const unsigned long long code = (nib[w][h * 32 + u * 16 + s][0] >> (6 * dg)) & 0x3Full;
-                    const int bit = 6 * (8 * (2 * u + (s & 1)) + (s >> 1)), wi = bit >> 6, sh = bit & 63;
-                    q[wi] |= code << sh;
-                    if (sh > 58) q[wi + 1] |= code >> (64 - sh);
-                }
-            }
-            dig[o] = make_uint4((uint32_t)q[0], (uint32_t)(q[0] >> 32), (uint32_t)q[1], (uint32_t)(q[1] >> 32));
-            dig2[o] = make_uint2((uint32_t)q[2], (uint32_t)(q[2] >> 32));
-        }
+        const uint32_t *q = &img[w][h][dg][0];
+        dig[o] = make_uint4(q[0], q[1], q[2], q[3]);
+        if (fp6) dig2[o] = make_uint2(q[4], q[5]);
     }
 }
 
@@ -1105,10 +1097,12 @@ k_xtv_dma16(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *
     else xtv_epilogue16_s<CT, NR, 8, HALF>(acc, buf, lane, cg0, ncg, split, splits, dm, scal, partial);
 }
 
-// Combine slices, add the missing-entry correction, centre, scale.  blockIdx.y = residual of the pass: partial, scal, r and
-// out advance by one residual's stride each (one launch per fused pass instead of one per residual).
+// Combine slices, add the missing-entry correction, centre, scale -- for the `nres` residuals of a pass in one launch: partial,
+// scal, r and out advance by one residual's stride each.  A thread keeps its column and walks the residuals (round 4; before,
+// one grid row per residual read mu, sinv and the two missing-list bounds once per residual: 64 MB per residual at p = 1M and
+// four slices, 40 MB now); the arithmetic of every (residual, column) is unchanged.
 __global__ void __launch_bounds__(256)
-k_xtv_finalize(const double *__restrict__ partial, int splits, int64_t pstride, int64_t p,
+k_xtv_finalize(const double *__restrict__ partial, int splits, int64_t pstride, int64_t p, int nres,
                const double *__restrict__ scal, const double *__restrict__ r, int64_t n,
                const double *__restrict__ mu, const double *__restrict__ sinv,
                const int64_t *__restrict__ miss_ptr, const int32_t *__restrict__ miss_row,
@@ -1116,22 +1110,23 @@ k_xtv_finalize(const double *__restrict__ partial, int splits, int64_t pstride, 
 {
     int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (j >= p) return;
-    const int64_t u = blockIdx.y;
-    partial += u * splits * pstride; scal += 4 * u; r += u * n; out += u * p;
-    double dot = 0.0;
-    for (int s = 0; s < splits; ++s) dot += partial[(int64_t)s * pstride + j];
-    double m = mu[j];
-    if (impute) {
-        int64_t a = miss_ptr[j], b = miss_ptr[j + 1];
+    const double m = mu[j], si = scale ? sinv[j] : 1.0;
+    int64_t a = 0, b = 0;
+    if (impute) { a = miss_ptr[j]; b = miss_ptr[j + 1]; }
+    for (int u = 0; u < nres; ++u) {
+        const double *pu = partial + (int64_t)u * splits * pstride;
+        double dot = 0.0;
+        for (int s = 0; s < splits; ++s) dot += pu[(int64_t)s * pstride + j];
         if (b > a) {
+            const double *ru = r + (int64_t)u * n;
             double ms = 0.0;
-            for (int64_t t = a; t < b; ++t) ms += r[miss_row[t]];
+            for (int64_t t = a; t < b; ++t) ms += ru[miss_row[t]];
             dot += m * ms;
         }
+        if (center) dot -= m * scal[4 * u + 2];
+        if (scale) dot *= si;
+        out[(int64_t)u * p + j] = dot;
     }
-    if (center) dot -= m * scal[2];
-    if (scale) dot *= sinv[j];
-    out[j] = dot;
 }
 
 // ---- dense design matrix: out_j = sum_i D[i,j] r_i (one wave per column) ---------------
@@ -1572,8 +1567,8 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
             prof_end(h, s, rec);
         }
         if (rc) return rc;
-        hipLaunchKernelGGL(k_xtv_finalize, dim3((unsigned)((h->p + 255) / 256), (unsigned)(u1 - u0)), dim3(256), 0, s,
-                           partial, splits, pstride, h->p, w.scal.p + 4 * u0, r_dev + (int64_t)u0 * h->n, h->n, h->mu, h->sinv,
+        hipLaunchKernelGGL(k_xtv_finalize, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, s,
+                           partial, splits, pstride, h->p, u1 - u0, w.scal.p + 4 * u0, r_dev + (int64_t)u0 * h->n, h->n, h->mu, h->sinv,
                            h->miss_ptr, h->miss_row, h->center, h->scale, h->impute, out_dev + (int64_t)u0 * h->p);
     }
     if (dm.flat) { MIH_HIP(hipGetLastError()); return MIH_OK; }
@@ -1602,8 +1597,8 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
         }
         if (rc) return rc;
         if (u1 > u0)
-            hipLaunchKernelGGL(k_xtv_finalize, dim3((unsigned)((h->p + 255) / 256), (unsigned)(u1 - u0)), dim3(256), 0, s,
-                               w.partial.p + (int64_t)u0 * splits * pstride, splits, pstride, h->p,
+            hipLaunchKernelGGL(k_xtv_finalize, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, s,
+                               w.partial.p + (int64_t)u0 * splits * pstride, splits, pstride, h->p, u1 - u0,
                                w.scal.p + 4 * u0, r_dev + (int64_t)u0 * h->n, h->n, h->mu, h->sinv, h->miss_ptr, h->miss_row,
                                h->center, h->scale, h->impute, out_dev + (int64_t)u0 * h->p);
         t += nr;

@@ -154,3 +154,22 @@ if what == "fits":
     for g in T._NUDGES:
         o2 = oracle.fit_iht(ox, y, z * g, k=k, dist=od, link=ol, max_iter=60, **kw)
         print(f"  nudge {g!r}: iter {o2['iter']} beta diff {(o2['beta'][nz] - o['beta'][nz]).tolist()} c diff {(o2['c'] * g - o['c']).tolist()}")
+if what == "mvfits":
+    want = int(sys.argv[3])
+    for trial in range(want + 1):
+        n, p, r, q, k, miss, x, ox, Y, Z, kw = T._mvfit_case(mih, oracle, rng, trial)
+    print("n", n, "p", p, "r", r, "q", q, "k", k, miss, {a: (b if not hasattr(b, "shape") else "array") for a, b in kw.items()})
+    o = oracle.fit_mv(ox, Y, Z, k=k, max_iter=60, **kw)
+    res = mih.fit_iht(Y, x, Z, k=k, max_iter=60, verbose=False, **kw)
+    print("iter", res.iter, o["iter"], "bt gpu", res.trace["backtracks"].tolist(), "bt orc", o["bt_trace"].tolist())
+    m_ = min(len(res.trace["logl"]), len(o["logl_trace"]))
+    for i in range(m_):
+        print(f"  {i}: logl {res.trace['logl'][i]!r} {o['logl_trace'][i]!r} tol {res.trace['tol'][i]!r} {o['tol_trace'][i]!r}")
+    for extra in (res.trace["tol"][m_:], o["tol_trace"][m_:]):
+        print("  further tol", list(extra))
+    if kw.get("init_beta"):
+        one = oracle.fit_iht(ox, Y[0], None, k=1, max_iter=1, train=kw.get("train"), init_beta=True)
+        print("  ib_cond of the univariate regressions on the training rows:", one["ib_cond"])
+    for g in T._NUDGES:
+        o2 = oracle.fit_mv(ox, Y, Z * g, k=k, max_iter=60, **kw)
+        print(f"  nudge {g!r}: iter {o2['iter']} last tol {o2['tol_trace'][-1]!r} bt {o2['bt_trace'].tolist()}")
