@@ -410,11 +410,13 @@ struct XvWork {
     DevBuf<uint32_t> cache;   // slots * ndw
     DevBuf<int32_t>  slot_dev;
     DevBuf<int64_t>  fill_dev;
+    DevBuf<int64_t>  off_dev;            // k_xv_snp_cached_mt: byte offsets of the support columns' cache slots, padded (kXvPadCols)
     int64_t slots = 0;
     std::unordered_map<int64_t, int32_t> slot_of;
     std::vector<int64_t> col_of;
     std::vector<uint64_t> stamp;
     uint64_t tick = 0;
+    std::vector<int64_t> h_offs;
     std::vector<int32_t> h_slots; std::vector<int64_t> h_fills;   // host images of slot_dev / fill_dev of the last call
 };
 int  xv_work_init(const mih_mat *h, XvWork &w, int64_t max_nnz, int64_t cache_nnz = 0);

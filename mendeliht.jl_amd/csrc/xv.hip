@@ -39,6 +39,7 @@ __global__ void k_xv_coef(const int64_t *__restrict__ idx, const double *__restr
 // g for the 16 rows of dword d in registers, the 16 group partials meet in LDS and are added in group
 // order (fixed order => bit-reproducible), so no n x groups partial array goes through HBM.
 constexpr int kXvGroups = 16;
+constexpr int kXvPadCols = 16;        // k_xv_snp_cached_mt reads up to the next multiple of eight columns and eight beyond: zero records, repeated offsets
 __global__ void __launch_bounds__(256)
 k_xv_snp(const uint32_t *__restrict__ X, int64_t nbp, int64_t ndw, int64_t n,
          const int64_t *__restrict__ idx, const double *__restrict__ A, const double *__restrict__ B,
@@ -227,7 +228,7 @@ k_xv_snp_cached_multi(const uint32_t *__restrict__ cache, int64_t ndw, int64_t n
 // r = 10 traits, 500 columns, n = 500k: 350 us -> ~110 us per call.
 template <int MT>
 __global__ void __launch_bounds__(256)
-k_xv_snp_cached_mt(const uint32_t *__restrict__ cache, int64_t ndw, int64_t n, const int32_t *__restrict__ slots,
+k_xv_snp_cached_mt(const uint32_t *__restrict__ cache, int64_t ndw, int64_t n, const int64_t *__restrict__ offs,
                    const double *__restrict__ A, const double *__restrict__ Bg, int nnz, int groups, int m, int rs,
                    double *__restrict__ out)
 {
@@ -238,37 +239,50 @@ k_xv_snp_cached_mt(const uint32_t *__restrict__ cache, int64_t ndw, int64_t n, c
     const int v0 = blockIdx.y * MT;
     const int per = (nnz + groups - 1) / groups;
     // (round 4) the coefficients of a column are ONE record of rs = m rounded up to 4 doubles (trait v at A[t * rs + v]): two wide scalar loads
-    // and one address per column instead of ten narrow loads with ten addresses (24.7 SALU + 11.3 SMEM instructions per column and
-    // wave before, the waves parked at lgkmcnt 43 % of their cycles: counters of tools/pmc_mv.sh), requested one column ahead
+    // and one address per column instead of ten narrow loads with ten addresses, requested one column ahead.  The scalar unit is
+    // shared by the CU's four SIMDs and a wave issues one instruction per four cycles whatever its kind: with 30 scalar
+    // instructions per column beside the 25 vector ones (counters of tools/pmc_mv.sh: SQ_INSTS_SALU 57.9 M against SQ_INSTS_VALU
+    // 56.3 M, the waves 17 % of their time in scalar instructions, 15 % in vector ones) the loop was bound by its bookkeeping.  So:
+    // the records and the columns' cache offsets (BYTES, offs[t] = slot * 4 ndw, computed on the host) are PADDED -- records of
+    // zeros, the last offset repeated, up to the next multiple of eight and eight beyond -- and the loop neither clamps an
+    // index nor tests the column count; pointers advance by a constant.  (A zero record adds +0.0 to sums that are never -0.0.)
     const double *Gv[MT];
     #pragma unroll
     for (int v = 0; v < MT; ++v) { const int vv = v0 + v < m ? v0 + v : m - 1; Gv[v] = Bg + (int64_t)vv * groups; }
-    const double *rec0 = A + v0;
+    const double *rec = static_cast<const double *>(__builtin_assume_aligned(A + v0, 32));
     // (trait slots past m read the record's padding or the next record: their sums are not stored; the buffer has the slack)
     double acc[MT][2], tot[MT][2];
     #pragma unroll
     for (int v = 0; v < MT; ++v) { acc[v][0] = acc[v][1] = 0.0; tot[v][0] = tot[v][1] = 0.0; }
     int left = per, g = 0;
-    // The dwords of the NEXT four columns are requested before the multiply-adds of the current four (double buffer w4 / wn): with
-    // four waves per SIMD the ~1 us load latency of a batch was exposed 125 times per call at 500 columns.
-    uint32_t wn[4];
+    // The dwords of a batch of four columns are requested EIGHT columns ahead, into the registers the batch before last has just been
+    // taken from (two batches in flight, no copies at the loop's back edge): with four waves per SIMD the 1 - 2 us latency of a
+    // batch (the support's 62 MB of columns live in MALL, not in L2) was exposed 125 times per call at 500 columns.
+    const char *cbase = reinterpret_cast<const char *>(cache);
+    const uint32_t voff = (uint32_t)dw * 4u;
+    const int64_t *on = static_cast<const int64_t *>(__builtin_assume_aligned(offs, 64));
+    uint32_t wq[2][4];
     #pragma unroll
-    for (int u = 0; u < 4; ++u) wn[u] = cache[(int64_t)slots[u < nnz ? u : nnz - 1] * ndw + dw];
+    for (int u = 0; u < 4; ++u) wq[0][u] = *reinterpret_cast<const uint32_t *>(cbase + on[u] + voff);
+    asm volatile("" ::: "memory");          // (the first batch is the older one on entry too: the loop waits with vmcnt(4), never for everything)
+    #pragma unroll
+    for (int u = 0; u < 4; ++u) wq[1][u] = *reinterpret_cast<const uint32_t *>(cbase + on[4 + u] + voff);
     double a_cur[MT];
     #pragma unroll
-    for (int v = 0; v < MT; ++v) a_cur[v] = static_cast<const double *>(__builtin_assume_aligned(rec0, 32))[v];
-    for (int t = 0; t < nnz; t += 4) {
-        uint32_t w4[4];
+    for (int v = 0; v < MT; ++v) a_cur[v] = rec[v];
+    for (int t = 0; t < nnz; t += 8) {
         #pragma unroll
-        for (int u = 0; u < 4; ++u) w4[u] = wn[u] >> sh;
-        if (t + 4 < nnz) {
+        for (int hb = 0; hb < 2; ++hb) {
+            uint32_t w4[4];
             #pragma unroll
-            for (int u = 0; u < 4; ++u) wn[u] = cache[(int64_t)slots[t + 4 + u < nnz ? t + 4 + u : nnz - 1] * ndw + dw];
-        }
-        #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (t + u < nnz) {
-                if (left == 0) {
+            for (int u = 0; u < 4; ++u) { w4[u] = wq[hb][u] >> sh; asm volatile("" : "+v"(w4[u]) :: "memory"); }
+            // (the shifted words exist before the requests below are issued: those land in the registers they free, and the loop's
+            // back edge needs neither copies nor a wait for everything in flight)
+            #pragma unroll
+            for (int u = 0; u < 4; ++u) wq[hb][u] = *reinterpret_cast<const uint32_t *>(cbase + on[8 + 4 * hb + u] + voff);
+            #pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (left == 0 && t + 4 * hb + u < nnz) {
                     #pragma unroll
                     for (int v = 0; v < MT; ++v) {
                         const double bs = Gv[v][g];
@@ -277,20 +291,26 @@ k_xv_snp_cached_mt(const uint32_t *__restrict__ cache, int64_t ndw, int64_t n, c
                     }
                     ++g; left = per;
                 }
-                const double *recn = static_cast<const double *>(__builtin_assume_aligned(rec0 + (int64_t)(t + u + 1 < nnz ? t + u + 1 : nnz - 1) * rs, 32));
+                rec = static_cast<const double *>(__builtin_assume_aligned(rec + rs, 32));
                 double a_nxt[MT];
                 #pragma unroll
-                for (int v = 0; v < MT; ++v) a_nxt[v] = recn[v];
+                for (int v = 0; v < MT; ++v) a_nxt[v] = rec[v];
                 const double g0 = (double)(w4[u] & 3u), g1 = (double)((w4[u] >> 2) & 3u);
                 #pragma unroll
                 for (int v = 0; v < MT; ++v) {
                     acc[v][0] = fma(g0, a_cur[v], acc[v][0]); acc[v][1] = fma(g1, a_cur[v], acc[v][1]);
                 }
+                // SMEM returns out of order, so any wait on it is lgkmcnt(0): left to the compiler, that wait lands in FRONT of the next
+                // column's multiply-adds and covers the record requested a moment before (the waves 40 % of their time at
+                // s_waitcnt).  Waiting here, behind this column's multiply-adds, gives the request their 100 cycles.
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0xC07F);        // lgkmcnt(0), vmcnt / expcnt untouched
                 #pragma unroll
                 for (int v = 0; v < MT; ++v) a_cur[v] = a_nxt[v];
                 --left;
             }
         }
+        on = static_cast<const int64_t *>(__builtin_assume_aligned(on + 8, 64));
     }
     const double tail = g + 1 < groups ? 0.0 : -0.0;      // empty trailing groups each add +0.0 (only -0.0 + 0.0 differs)
     const int64_t i = 2 * tid;
@@ -308,12 +328,13 @@ k_xv_snp_cached_mt(const uint32_t *__restrict__ cache, int64_t ndw, int64_t n, c
 __global__ void __launch_bounds__(256)
 k_xv_coef_groups(const int64_t *__restrict__ idx, const double *__restrict__ val, int nnz,
                  const double *__restrict__ mu, const double *__restrict__ sinv, int center, int scale, int groups,
-                 double *__restrict__ A, double *__restrict__ Bg, int64_t a_trait_stride, int64_t a_col_stride)
+                 double *__restrict__ A, double *__restrict__ Bg, int64_t a_trait_stride, int64_t a_col_stride, int pad_cols)
 {
 #pragma clang fp contract(off)       // bsum += b must round like the stored B of k_xv_coef_multi
     constexpr int CH = 2048;
     __shared__ double sb[CH];
     const int v = blockIdx.x;
+    if ((int)threadIdx.x < pad_cols) A[(int64_t)v * a_trait_stride + (int64_t)(nnz + threadIdx.x) * a_col_stride] = 0.0;    // k_xv_snp_cached_mt's padding records
     const int per = (nnz + groups - 1) / groups;
     const int t0 = threadIdx.x * per, t1 = t0 + per < nnz ? t0 + per : nnz;      // this thread's group (threads < groups)
     double bsum = 0.0;
@@ -323,7 +344,7 @@ k_xv_coef_groups(const int64_t *__restrict__ idx, const double *__restrict__ val
             const int64_t j = idx[t];
             const double sc = scale ? sinv[j] : 1.0;
             const double a = sc * val[(int64_t)v * nnz + t];
-            A[(int64_t)v * a_trait_stride + (int64_t)t * a_col_stride] = a;       // trait-major, or one record of kXvRec doubles per column
+            A[(int64_t)v * a_trait_stride + (int64_t)t * a_col_stride] = a;       // trait-major, or one record per column
             sb[t - base] = center ? -mu[j] * a : 0.0;
         }
         __syncthreads();
@@ -542,22 +563,30 @@ int xv_sparse_multi_device(const mih_mat *h, XvWork &w, const int64_t *idx_dev, 
             if (mt_on && nnz < (1ll << 30)) {
                 if ((size_t)m * groups > w.coefG.n) { MIH_HIP(hipStreamSynchronize(s)); MIH_TRY(w.coefG.alloc((size_t)m * kXvGroups * 2)); }
                 const int rs = (m + 3) & ~3;               // one record per column: the traits side by side (k_xv_snp_cached_mt)
-                if ((size_t)nnz * rs + 32 > w.coefA.n) { MIH_HIP(hipStreamSynchronize(s)); MIH_TRY(w.coefA.alloc((size_t)nnz * rs * 2 + 32)); }
+                if ((size_t)(nnz + kXvPadCols) * rs + 32 > w.coefA.n) { MIH_HIP(hipStreamSynchronize(s)); MIH_TRY(w.coefA.alloc((size_t)(nnz + kXvPadCols) * rs * 2 + 32)); }
                 hipLaunchKernelGGL(k_xv_coef_groups, dim3((unsigned)m), dim3(256), 0, s, idx_dev, vals_dev, (int)nnz,
-                                   h->mu, h->sinv, h->center, h->scale, groups, w.coefA.p, w.coefG.p, (int64_t)1, (int64_t)rs);
+                                   h->mu, h->sinv, h->center, h->scale, groups, w.coefA.p, w.coefG.p, (int64_t)1, (int64_t)rs, kXvPadCols);
             } else
             hipLaunchKernelGGL(k_xv_coef_multi, dim3((unsigned)((nnz + 255) / 256), (unsigned)m), dim3(256), 0, s, idx_dev, vals_dev, nnz,
                                h->mu, h->sinv, h->center, h->scale, w.coefA.p, w.coefB.p);
+            const bool mt = mt_on && nnz < (1ll << 30);
+            if (mt) {          // byte offsets of the columns' cache slots, the last one repeated over the padding (kXvPadCols)
+                std::vector<int64_t> &offs = w.h_offs;
+                offs.resize((size_t)(nnz + kXvPadCols));
+                for (int64_t t = 0; t < nnz + kXvPadCols; ++t) offs[(size_t)t] = (int64_t)slots[(size_t)(t < nnz ? t : nnz - 1)] * ndw * 4;
+                if (offs.size() > w.off_dev.n) { MIH_HIP(hipStreamSynchronize(s)); MIH_TRY(w.off_dev.alloc(offs.size() * 2)); }
+                MIH_HIP(hipMemcpyAsync(w.off_dev.p, offs.data(), sizeof(int64_t) * offs.size(), hipMemcpyHostToDevice, s));
+            } else
             MIH_HIP(hipMemcpyAsync(w.slot_dev.p, slots.data(), sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, s));
             if (!fills.empty()) {
                 MIH_HIP(hipMemcpyAsync(w.fill_dev.p, fills.data(), sizeof(int64_t) * fills.size(), hipMemcpyHostToDevice, s));
                 hipLaunchKernelGGL(k_xv_fill, dim3((unsigned)((ndw + 255) / 256), (unsigned)fills.size()), dim3(256), 0, s, h->X, h->nbp, ndw,
                                    w.fill_dev.p, w.cache.p);
             }
-            if (mt_on && nnz < (1ll << 30)) {
+            if (mt) {
                 const unsigned gx = (unsigned)((8 * ndw + 255) / 256);
 #define MIH_MT(MTV) hipLaunchKernelGGL((k_xv_snp_cached_mt<MTV>), dim3(gx, (unsigned)((m + MTV - 1) / MTV)), dim3(256), 0, s, \
-                                       w.cache.p, ndw, h->n, w.slot_dev.p, w.coefA.p, w.coefG.p, (int)nnz, groups, m, (m + 3) & ~3, out_dev)
+                                       w.cache.p, ndw, h->n, w.off_dev.p, w.coefA.p, w.coefG.p, (int)nnz, groups, m, (m + 3) & ~3, out_dev)
                 if (m <= 4) MIH_MT(4); else if (m <= 6) MIH_MT(6); else if (m <= 8) MIH_MT(8); else if (m <= 10) MIH_MT(10); else MIH_MT(12);
 #undef MIH_MT
                 MIH_HIP(hipGetLastError());

@@ -2062,6 +2062,26 @@ def test_config4_multivariate_r10(mih, oracle, normal_pair):
     np.testing.assert_allclose(mse, omse, rtol=1e-6)
 
 
+@pytest.mark.parametrize("r", [6, 7, 8, 9, 11, 12])
+def test_multivariate_trait_counts_of_every_product_kernel_shape(mih, oracle, normal_pair, r):
+    """The multi-trait X*B kernel is instantiated for 4, 6, 8, 10 and 12 traits per thread (csrc/xv.hip, k_xv_snp_cached_mt:
+    padded coefficient records and column offsets, batches of eight columns): trait counts the sweeps (2 .. 5) and configs[4]
+    (10) do not reach, with support sizes that are not multiples of eight, against oracle.fit_mv."""
+    x, ox = normal_pair
+    rng = np.random.default_rng(600 + r)
+    k = 13 + r                                        # 19 .. 25 entries: supports of 8 m + 1 .. 8 m + 7 columns among them
+    Y, Z = _mv_problem(oracle, ox, rng, r, 9, 2)
+    res = mih.fit_iht(Y, x, Z, k=k, verbose=False, max_iter=30)
+    o = oracle.fit_mv(ox, Y, Z, k=k, max_iter=30)
+    assert res.iter == o["iter"] and res.iter >= 4
+    assert np.array_equal(res.beta != 0, o["B"] != 0)
+    np.testing.assert_allclose(res.beta, o["B"], rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(res.c, o["C"], rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(res.Σ, o["Sigma"], rtol=1e-6)
+    assert res.logl == pytest.approx(o["logl"], rel=1e-9)
+    assert list(res.trace["backtracks"]) == list(o["bt_trace"])
+
+
 def test_config4_multivariate_r10_at_full_row_count(mih, oracle):
     """r = 10 traits, k = 500 / 20 scaled to the column count, at n = 500 000 rows against the oracle."""
     n, p = 500_000, 256
