@@ -1851,12 +1851,23 @@ def test_randomized_model_paths_vs_oracle(mih, oracle):
         n, p, q, od, ol, D, L, x, ox, y, z, path, kw, okw, d = _path_case(mih, oracle, rng, trial, fams)
         tag = (trial, n, p, q, od, path, sorted(kw))
         ll = np.asarray(mih.iht_run_many_models(y, x, z, path=path, d=d, l=L(), verbose=False, **kw))
-        runs = [oracle.fit_iht(ox, y, z, k=k, dist=od, link=ol, max_iter=100, **okw) for k in path]
-        want = np.array([o["logl"] for o in runs])
+        def orc(kk, g=1.0):                            # None: the reference algorithm itself ends in an error (GLM.jl's refit failing inside debias!)
+            try:
+                return oracle.fit_iht(ox, y, z * g, k=kk, dist=od, link=ol, max_iter=100, **okw)
+            except RuntimeError:
+                return None
+        runs = [orc(k) for k in path]
+        want = np.array([o["logl"] if o is not None else np.nan for o in runs])
         tol = 1e-5 if "est_r" in kw else 1e-7
         ok = np.isclose(ll, want, rtol=tol, atol=0)
         for j in np.flatnonzero(~ok):                 # the single-fit sweeps' rules for a trajectory nobody can be held to
             o = runs[j]
+            if o is None:                             # the device finished the path, the oracle's fit of this size did not: a finding unless the
+                # oracle wavers itself (seed 10864: NegBin est_r with debias, r running off to 1e7 .. 6e12 -- the refit's step-halving
+                # fails on the original input and not under any of the six nudges)
+                assert any(orc(path[j], g) is not None for g in _NUDGES), (tag, path[j], "only the oracle ended in an error")
+                tally.set_aside("only the oracle ends in an error, and wavers under nudges", (path[j],) + tag)
+                continue
             unstable = o["eta_cond"] < 1e-18 or o["bt_trace"].max(initial=0) >= 3      # (only looked at after the comparison has failed)
             why = "oracle unstable under ulp nudges"
             if "est_r" in kw and o["nb_r"] > 1e6:
@@ -1866,8 +1877,8 @@ def test_randomized_model_paths_vs_oracle(mih, oracle):
             for g in _NUDGES:
                 if unstable:
                     break
-                o2 = oracle.fit_iht(ox, y, z * g, k=path[j], dist=od, link=ol, max_iter=100, **okw)
-                unstable = o2["iter"] != o["iter"] or not np.isclose(o2["logl"], o["logl"], rtol=tol, atol=0)
+                o2 = orc(path[j], g)
+                unstable = o2 is None or o2["iter"] != o["iter"] or not np.isclose(o2["logl"], o["logl"], rtol=tol, atol=0)
             assert unstable, (tag, path[j], ll[j], want[j])
             tally.set_aside(why, (path[j],) + tag)
         tally.ok(int(ok.sum()))
