@@ -123,15 +123,10 @@ static void launch_mv_apply(unsigned nb, hipStream_t s, const double *IN, int64_
 // vectorize!(full_b, B, C) after the axpy (multivariate.jl:99-113): full[i + r*j] = eta * df[i][j]
 // The covariate tail full[r*p .. r*p + rq) rides along as a kernel argument (block 0 writes it) instead of a separate copy.
 __global__ void __launch_bounds__(256)
-k_mv_full(const double *__restrict__ DF, int64_t p, int r, double eta, double *__restrict__ full, CMat tail, int rq,
-          const double *__restrict__ eta_dev, const double *__restrict__ df2_dev)
+k_mv_full(const double *__restrict__ DF, int64_t p, int r, double eta, double *__restrict__ full, CMat tail, int rq)
 {
     extern __shared__ double tile[];                       // [r][257]: 256 SNPs of every trait plane, read and written coalesced
-    // eta_dev: the step size is still on its way to the host (k_mv_eta); `tail` then holds C (Inf for kept covariates) and the
-    // covariate entries C + eta * df2 are formed here, with the fma the host forms them with once eta has arrived (gradstep)
-    if (eta_dev) eta = *eta_dev;
-    if (blockIdx.x == 0) for (int t = threadIdx.x; t < rq; t += 256)
-        full[(int64_t)r * p + t] = (eta_dev && !isinf(tail.v[t])) ? fma(eta, df2_dev[t], tail.v[t]) : tail.v[t];
+    if (blockIdx.x == 0) for (int t = threadIdx.x; t < rq; t += 256) full[(int64_t)r * p + t] = tail.v[t];
     const int64_t j0 = blockIdx.x * 256ll;
     const int cnt = (int)(p - j0 < 256 ? p - j0 : 256);
     for (int i = 0; i < r; ++i)
@@ -143,41 +138,12 @@ k_mv_full(const double *__restrict__ DF, int64_t p, int r, double eta, double *_
     }
 }
 __global__ void k_mv_scatter(const int64_t *__restrict__ li, const double *__restrict__ val, int64_t nnz,
-                             const double *__restrict__ DF, int64_t p, int r, double eta, double *__restrict__ full,
-                             const double *__restrict__ eta_dev)
+                             const double *__restrict__ DF, int64_t p, int r, double eta, double *__restrict__ full)
 {
     int64_t t = blockIdx.x * 256ll + threadIdx.x;
     if (t >= nnz) return;
-    if (eta_dev) eta = *eta_dev;
     int64_t l = li[t], j = l / r; int i = (int)(l - j * r);
     full[l] = fma(eta, DF[(int64_t)i * p + j], val[t]);
-}
-// iht_stepsize!'s quotient on the device (multivariate.jl:220-254): numerator = the sum of squares of df on the support (a fixed tree
-// over 256 strided partial sums -- Julia's own sum is pairwise, no order is the reference's), denominator = the weighted sum of
-// squares k_final_sum left, the 1e-8 guard of :251; and [df2 | denominator | eta] on their way to pinned host memory WITHOUT a flag:
-// the host reads them behind its next wait on this stream (the projection's survivors), by which time this kernel has run.
-__global__ void __launch_bounds__(256)
-k_mv_eta(const double *__restrict__ dfs, int64_t ncr, const double *__restrict__ d_sum, const double *__restrict__ d_df2, int rq,
-         double *__restrict__ d_eta, double *__restrict__ tail_host, uint64_t seq)
-{
-#pragma clang fp contract(off)
-    __shared__ double sh[256];
-    double a = 0.0;
-    for (int64_t i = threadIdx.x; i < ncr; i += 256) { const double x = dfs[i]; const double sq = x * x; a = a + sq; }
-    sh[threadIdx.x] = a;
-    __syncthreads();
-    for (int k = 128; k > 0; k >>= 1) {
-        if ((int)threadIdx.x < k) sh[threadIdx.x] = sh[threadIdx.x] + sh[threadIdx.x + k];
-        __syncthreads();
-    }
-    const double den = __hip_atomic_load(d_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    double e = sh[0] / den;
-    if (isinf(e) || isnan(e)) e = 1e-8;
-    if (threadIdx.x == 0) { *d_eta = e; tail_host[rq] = den; tail_host[rq + 1] = e; }
-    for (int t = threadIdx.x; t < rq; t += 256) tail_host[t] = __hip_atomic_load(&d_df2[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(reinterpret_cast<uint64_t *>(tail_host) + rq + 2, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // unvectorize! of the projected gradient at init (multivariate.jl:438-440): df[i][j] = full[i + r*j]
 __global__ void k_mv_unvec(const double *__restrict__ full, int64_t p, int r, double *__restrict__ DF)
@@ -351,10 +317,6 @@ struct MvVar {
     // The step size of the NEXT step is computed at the end of a step (step_tail): everything iht_stepsize! needs -- the support,
     // df on it, Gamma -- is final then.  What came home: the denominator, for which support, with which factor of Gamma.
     bool spec_ok = false; double spec_denom = 0.0; std::vector<int64_t> spec_cols; std::vector<double> spec_U;
-    // ... and since round 4 nothing of it comes home at the end of the step: the quotient is formed on the device (k_mv_eta), the
-    // gradient step takes it from there, and [df2 | denominator | eta] land in pinned memory to be read behind the projection's
-    // wait (collect_tail): two host waits per iteration instead of three.
-    PinBuf<double> tail_pin; uint64_t tail_seq = 0; bool tail_pending = false, tail_has_df2 = false; size_t tail_ncr = 0;
     DevBuf<int32_t> pairs_s; bool pairs_ok = false, pairs_s_ok = false;      // the index-pair tables (Gram: a <= b; score: (trait, covariate)) go up once
     XtvWork xtv; XvWork xv; TopkWork topk;
     int nb = 0;
@@ -405,7 +367,6 @@ struct MvVar {
         MIH_TRY(tmpn.alloc(n)); MIH_TRY(mask.alloc(n)); MIH_TRY(pairs.alloc(2 * (size_t)kMaxR * kMaxR));
         MIH_TRY(sidx.alloc(kcap)); MIH_TRY(sval.alloc(kcap)); MIH_TRY(gval.alloc((size_t)kcap * r));
         MIH_TRY(stage.init((size_t)kcap * (r + 1) + 8));
-        MIH_TRY(tail_pin.alloc((size_t)r * q + 4, true)); reinterpret_cast<uint64_t *>(tail_pin.p)[(size_t)r * q + 2] = 0; tail_seq = 0; tail_pending = false;
         if (own_stream) { ArenaScope own_buffers(nullptr); MIH_TRY(xtv_work_init(h, xtv, r, tune)); }
         MIH_TRY(xv_work_init(h, xv, kcap, kcap - 1024)); MIH_TRY(topk_work_init(topk, kcap));
         // Y (r x n) and Z (q x n) column-major -> planes
@@ -565,28 +526,11 @@ struct MvVar {
         } else MIH_HIP(hipMemsetAsync(T1.p, 0, sizeof(double) * (size_t)n * r, s));
         launch_mv_apply((unsigned)nb, s, T1.p, n, r, rmat(spec_U), 1, w.p, (double *)nullptr, red.p);
         hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, s, red.p, nb, 1, d_sum);
-        if (!with_df2) MIH_TRY(upload_pair(df2.data(), sizeof(double) * rq, d_df2, nullptr, 0, nullptr));     // (initialisation: df2 is the host's)
-        hipLaunchKernelGGL(k_mv_eta, dim3(1), dim3(256), 0, s, gval.p, (int64_t)ncr, d_sum, d_df2, (int)rq, d_sum + 1, tail_pin.p, ++tail_seq);
-        tail_pending = true; tail_has_df2 = with_df2; tail_ncr = ncr;
-        spec_cols = cols; spec_ok = true;
-        return MIH_OK;
-    }
-    // what k_mv_eta sent: df2 (when the step computed it), the denominator, the step size.  Called behind a wait on the stream
-    // (the projection's survivors); should the words not be there -- no wait happened -- the stream is synchronised.
-    int collect_tail(double *eta)
-    {
-        if (!tail_pending) return MIH_OK;
-        const size_t rq = (size_t)r * q;
-        const uint64_t *word = reinterpret_cast<const uint64_t *>(tail_pin.p) + rq + 2;
-        if (__atomic_load_n(word, __ATOMIC_ACQUIRE) != tail_seq) {
-            MIH_HIP(hipStreamSynchronize(s));
-            stage.synced();
-            if (__atomic_load_n(word, __ATOMIC_ACQUIRE) != tail_seq) { set_error("the step-size kernel did not complete"); return MIH_HIP_ERROR; }
-        }
-        if (tail_has_df2) for (size_t t = 0; t < rq; ++t) df2[t] = tail_pin.p[t];
-        spec_denom = tail_pin.p[rq];
-        if (eta) *eta = tail_pin.p[rq + 1];
-        tail_pending = false;
+        std::vector<double> home(ncr + rq + 1);
+        MIH_TRY(readback(gval.p, ncr + rq + 1, home.data()));
+        dfcols.assign(home.begin(), home.begin() + (std::ptrdiff_t)ncr);
+        if (with_df2) for (size_t t = 0; t < rq; ++t) df2[t] = home[ncr + t];
+        spec_denom = home[ncr + rq]; spec_cols = cols; spec_ok = true;
         return MIH_OK;
     }
     int gather_df_cols()
@@ -605,7 +549,15 @@ struct MvVar {
         int64_t nc = (int64_t)cols.size();
         double numer = 0.0;
         for (double x : dfcols) numer += x * x;
-        spec_ok = false;                                              // (the usual case -- step_tail's quotient on the device -- never comes here: step_pre)
+        if (spec_ok && spec_cols == cols) {                           // computed behind the X'R pass of the previous step (step_tail)
+            spec_ok = false;
+            G = spec_U;                                               // Gamma is left holding U, as below
+            double e = numer / spec_denom;
+            if (std::isinf(e) || std::isnan(e)) e = 1e-8;
+            *eta = e;
+            return MIH_OK;
+        }
+        spec_ok = false;
         if (nc) {
             if ((size_t)nc * r > mcoef.n) { MIH_HIP(hipStreamSynchronize(s)); MIH_TRY(mcoef.alloc((size_t)nc * r * 2)); }
             MIH_TRY(upload_cols_coef(dfcols));                       // dfcols is [trait][column]
@@ -690,31 +642,21 @@ struct MvVar {
         return MIH_OK;
     }
     // _iht_gradstep! + project_k!(v) (multivariate.jl:99-127) from base (Bb, Cb)
-    // on_device: eta (and this step's df2) are still on their way from k_mv_eta -- the kernels take eta from the device, the host
-    // picks both up behind the projection's wait and forms C + eta * df2 then (same fma as the kernel's); *eta comes back filled in
-    int gradstep(const Sparse &Bb, const std::vector<double> &Cb, double *eta_io, bool on_device = false)
+    int gradstep(const Sparse &Bb, const std::vector<double> &Cb, double eta)
     {
-        double eta = *eta_io;
-        const double *eta_dev = on_device ? gval.p + tail_ncr + (size_t)r * q + 1 : nullptr;
         std::vector<double> cn((size_t)r * q), tail((size_t)r * q);
         for (int l = 0; l < q; ++l) for (int i = 0; i < r; ++i) {
-            if (on_device) { tail[i + r * l] = zkeep[l] ? std::numeric_limits<double>::infinity() : Cb[i + r * l]; continue; }
             cn[i + r * l] = std::fma(eta, df2[i + r * l], Cb[i + r * l]);
             tail[i + r * l] = zkeep[l] ? std::numeric_limits<double>::infinity() : cn[i + r * l];
         }
-        hipLaunchKernelGGL(k_mv_full, dim3(nblk(p)), dim3(256), sizeof(double) * 257 * (size_t)r, s, DF.p, p, r, eta, full.p, cmat(tail), r * q, eta_dev, eta_dev ? gval.p + tail_ncr : nullptr);
+        hipLaunchKernelGGL(k_mv_full, dim3(nblk(p)), dim3(256), sizeof(double) * 257 * (size_t)r, s, DF.p, p, r, eta, full.p, cmat(tail), r * q);
         MIH_TRY(ensure_stage((int64_t)Bb.idx.size()));
         if (!Bb.idx.empty()) {
             MIH_TRY(upload_pair(Bb.idx.data(), sizeof(int64_t) * Bb.idx.size(), sidx.p, Bb.val.data(), sizeof(double) * Bb.val.size(), sval.p));
-            hipLaunchKernelGGL(k_mv_scatter, dim3(nblk((int64_t)Bb.idx.size())), dim3(256), 0, s, sidx.p, sval.p, (int64_t)Bb.idx.size(), DF.p, p, r, eta, full.p, eta_dev);
+            hipLaunchKernelGGL(k_mv_scatter, dim3(nblk((int64_t)Bb.idx.size())), dim3(256), 0, s, sidx.p, sval.p, (int64_t)Bb.idx.size(), DF.p, p, r, eta, full.p);
         }
         Sparse snp; std::vector<double> ct; std::vector<uint8_t> cnz;
         MIH_TRY(project_full(snp, ct, cnz, /*zero_in_place=*/false));       // only the survivor lists are used
-        if (on_device) {
-            MIH_TRY(collect_tail(&eta));
-            *eta_io = eta;
-            for (int l = 0; l < q; ++l) for (int i = 0; i < r; ++i) cn[i + r * l] = std::fma(eta, df2[i + r * l], Cb[i + r * l]);
-        }
         B = snp;
         for (int l = 0; l < q; ++l) for (int i = 0; i < r; ++i)
             C[i + r * l] = zkeep[l] ? cn[i + r * l] : (cnz[i + r * l] ? ct[i + r * l] : 0.0);
@@ -754,7 +696,7 @@ struct MvVar {
         // project_k!(v): vec(B) with the covariate tail (Inf for kept covariates), top-(k + zkeepn)
         std::vector<double> tail((size_t)r * q);
         for (int l = 0; l < q; ++l) for (int i = 0; i < r; ++i) tail[i + r * l] = zkeep[l] ? std::numeric_limits<double>::infinity() : C[i + r * l];
-        hipLaunchKernelGGL(k_mv_full, dim3(nblk(p)), dim3(256), sizeof(double) * 257 * (size_t)r, s, betad.p, p, r, 1.0, full.p, cmat(tail), r * q, (const double *)nullptr, (const double *)nullptr);
+        hipLaunchKernelGGL(k_mv_full, dim3(nblk(p)), dim3(256), sizeof(double) * 257 * (size_t)r, s, betad.p, p, r, 1.0, full.p, cmat(tail), r * q);
         Sparse snp; std::vector<double> ct; std::vector<uint8_t> cnz;
         MIH_TRY(project_full(snp, ct, cnz));
         B = snp;
@@ -774,7 +716,7 @@ struct MvVar {
     int init_pre(const uint8_t *train)
     {
         if (k < 1) { set_error("Multivariate IHT requires k >= 1!"); return MIH_BAD_ARG; }
-        B.clear(); B0.clear(); best_B.clear(); cols.clear(); dfcols.clear(); spec_ok = false; tail_pending = false;
+        B.clear(); B0.clear(); best_B.clear(); cols.clear(); dfcols.clear(); spec_ok = false;
         std::fill(C.begin(), C.end(), 0.0); C0 = C; best_C = C; std::fill(df2.begin(), df2.end(), 0.0);
         for (int l = 0; l < q; ++l) idc[l] = zkeep[l];
         std::fill(G.begin(), G.end(), 0.0);
@@ -802,7 +744,7 @@ struct MvVar {
         // vectorize!(full_b, df, df2); project_k!; unvectorize! (:438-440): df replaced by its projection
         std::vector<double> tail((size_t)r * q);
         for (int l = 0; l < q; ++l) for (int i = 0; i < r; ++i) tail[i + r * l] = zkeep[l] ? std::numeric_limits<double>::infinity() : df2[i + r * l];
-        hipLaunchKernelGGL(k_mv_full, dim3(nblk(p)), dim3(256), sizeof(double) * 257 * (size_t)r, s, DF.p, p, r, 1.0, full.p, cmat(tail), r * q, (const double *)nullptr, (const double *)nullptr);
+        hipLaunchKernelGGL(k_mv_full, dim3(nblk(p)), dim3(256), sizeof(double) * 257 * (size_t)r, s, DF.p, p, r, 1.0, full.p, cmat(tail), r * q);
         Sparse snp; std::vector<double> ct; std::vector<uint8_t> cnz;
         MIH_TRY(project_full(snp, ct, cnz));
         hipLaunchKernelGGL(k_mv_unvec, dim3(nblk(p * r)), dim3(256), 0, s, full.p, p, r, DF.p);
@@ -848,14 +790,9 @@ struct MvVar {
     // everything of iht_one_step! before the X'R pass (ends with T1 = Gamma * resid)
     int step_pre(double old_logl, int nstep, int *bt, double *new_logl)
     {
-        double eta = 0.0;
-        bool on_device = false;
-        if (tail_pending) {
-            if (spec_ok && spec_cols == cols) { on_device = true; spec_ok = false; G = spec_U; }      // Gamma is left holding U (fit.jl:230-232 recomputes it)
-            else { MIH_TRY(collect_tail(nullptr)); MIH_TRY(gather_df_cols()); }                       // (another support since: the long way)
-        }
-        if (!on_device) MIH_TRY(stepsize(&eta));
-        MIH_TRY(gradstep(B, C, &eta, on_device));
+        double eta;
+        MIH_TRY(stepsize(&eta));
+        MIH_TRY(gradstep(B, C, eta));
         MIH_TRY(update_xb());
         MIH_TRY(solve_sigma());
         double logl = loglik();
@@ -863,7 +800,7 @@ struct MvVar {
         while (old_logl > logl && es < nstep) {
             eta /= 2;
             G = G0;                                                  // backtrack! (multivariate.jl:460-473)
-            MIH_TRY(gradstep(B0, C0, &eta));
+            MIH_TRY(gradstep(B0, C0, eta));
             MIH_TRY(update_xb());
             MIH_TRY(solve_sigma());
             logl = loglik();

@@ -29,7 +29,9 @@ m.profile_enable(x, False)
 passes = m.profile_passes(x, reset=True)
 kern = sum(q["ms"] for q in passes[1:])                  # (the first launch is the initial score, outside res.time)
 steps = len(passes) - 1
+gaps = [passes[i + 1]["start_ms"] - passes[i]["start_ms"] - passes[i]["ms"] for i in range(1, len(passes) - 1)]      # end of a step's pass -> start of the next step's
 out["config4"] = dict(ms_per_iteration=1e3 * res.time / steps, pass_kernel_ms=kern / steps, outside_the_pass_kernel_ms=(1e3 * res.time - kern) / steps,
+                      pass_to_pass_ms=sum(gaps) / max(len(gaps), 1),
                       iters=int(res.iter), hash=h(res.beta, res.c, res.Sigma, res.trace["logl"], res.trace["tol"]),
                       backtracks=int(res.trace["backtracks"].sum()))
 del x
@@ -61,5 +63,7 @@ strip = lambda d: {k: ({kk: vv for kk, vv in v.items() if not kk.endswith("_ms")
 same = strip(res["old"]) == strip(res["new"]) == strip(res["new2"])
 print("bit-identical:", same, " config4 ms outside the pass kernel (finalize, statistics and digit planes included): old",
       [round(res[k]["config4"]["outside_the_pass_kernel_ms"], 3) for k in ("old", "old2")],
-      "new", [round(res[k]["config4"]["outside_the_pass_kernel_ms"], 3) for k in ("new", "new2")])
+      "new", [round(res[k]["config4"]["outside_the_pass_kernel_ms"], 3) for k in ("new", "new2")],
+      " from the end of a step's pass to the start of the next step's (HIP events, no end effects): old",
+      [round(res[k]["config4"]["pass_to_pass_ms"], 3) for k in ("old", "old2")], "new", [round(res[k]["config4"]["pass_to_pass_ms"], 3) for k in ("new", "new2")])
 sys.exit(0 if same else 1)

@@ -60,11 +60,18 @@ for t in range(r):
     cols = np.unique(cols)
     Y[t] += x.xv_sparse(cols, rng.standard_normal(cols.size) * 0.3) + 1.0
 t0 = time.perf_counter()
+m.profile_read(x, reset=True); m.profile_enable(x, True)
 res = m.fit_iht(Y, x, None, k=k, verbose=False, max_iter=8)
 wall = time.perf_counter() - t0
+m.profile_enable(x, False)
+ps = m.profile_passes(x, reset=True)                 # [0] = the initial score; HIP events around every pass kernel
+gaps = [ps[i + 1]["start_ms"] - ps[i]["start_ms"] - ps[i]["ms"] for i in range(1, len(ps) - 1)]
 out["configs[4] MvNormal r=10 k=500 n=500k p=1M"] = dict(
     xtR_ms=ms10, flop_equiv_TFLOPs=2.0 * n * p * r / (ms10 * 1e-3) / 1e12, iterations=int(res.iter),
-    ms_per_iteration=1e3 * res.time / res.iter, wall_s=wall, nonzero=int(np.count_nonzero(res.beta)))
+    ms_per_iteration=1e3 * res.time / res.iter, wall_s=wall, nonzero=int(np.count_nonzero(res.beta)),
+    pass_ms_in_the_fit=sum(q["ms"] for q in ps[1:]) / max(len(ps) - 1, 1),
+    outside_the_pass_ms=sum(gaps) / max(len(gaps), 1),      # end of a step's pass -> start of the next step's pass, steady state
+    note="outside_the_pass_ms is measured between the HIP events of consecutive pass kernels; ms_per_iteration = fit time / iterations also carries the fit's end (the last score, which nothing waits for until the fit returns)")
 print(json.dumps(out), flush=True)
 with open(os.path.join(ROOT, "gpurun_out", f"configs_digits{digits}.json"), "w") as f:
     json.dump(out, f, indent=1)
