@@ -1,0 +1,88 @@
+"""The classes of ill-conditioned input the randomized GPU sweeps set aside, pinned on the CPU: every seed of
+tools/fuzz_parity.py that ended red on an input no floating-point implementation can be held to is replayed here against the ORACLE
+ALONE -- the case generators of tests/test_gpu_parity.py with a stand-in for the device matrix -- and the diagnostic the sweeps'
+rule rests on must fire: the oracle's own report (orc_result.bt_cond / ib_cond) or its disagreement with itself under
+ulp-sized nudges of the input.  No GPU, no device library: the oracle is the subject here."""
+import types
+
+import numpy as np
+import pytest
+
+import mendeliht_amd as _real
+import test_gpu_parity as T
+
+
+class _NoDevice:                                   # the generators build a device matrix beside the oracle's; nothing here uses it
+    def __init__(self, *a, **k):
+        pass
+
+
+FAKE = types.SimpleNamespace(SnpLinAlg=_NoDevice, DenseMatrix=_NoDevice,
+                             **{name: getattr(_real, name) for name in ("Normal", "Bernoulli", "Poisson", "NegativeBinomial", "IdentityLink",
+                                                                        "LogitLink", "LogLink")})
+FAMS3 = [("normal", "identity", FAKE.Normal, FAKE.IdentityLink, 1e-5), ("bernoulli", "logit", FAKE.Bernoulli, FAKE.LogitLink, 1e-4),
+         ("poisson", "log", FAKE.Poisson, FAKE.LogLink, 1e-4)]
+FAMS4 = [f[:4] for f in FAMS3] + [("negbin", "log", FAKE.NegativeBinomial, FAKE.LogLink)]
+
+
+def _replay(gen, seed, trial, *extra):
+    rng = np.random.default_rng(seed)
+    for t in range(trial + 1):
+        case = gen(FAKE, _ORACLE[0], rng, t, *extra)
+    return case
+
+
+_ORACLE = [None]
+
+
+@pytest.fixture(autouse=True)
+def _bind(oracle):
+    _ORACLE[0] = oracle
+
+
+def test_backtracking_decision_between_equal_loglikelihoods(oracle):
+    """Seed 9878 (first sweep, trial 8): the converging step's loglikelihood equals the previous one to the last bits; the oracle
+    halves the step twice, reports the margin of that decision (bt_cond), and is perfectly stable under nudges -- which is why the
+    sweep needs the diagnostic."""
+    n, p, k, miss, q, od, ol, D, L, tol, x, ox, y, z, kw = _replay(T._fits_case, 9878, 8, FAMS3)
+    assert (n, p, k, od, miss) == (2142, 186, 2, "normal", "dense64") and sorted(kw) == ["train", "weight"]
+    o = oracle.fit_iht(ox, y, z, k=k, dist=od, link=ol, max_iter=60, **kw)
+    assert o["iter"] == 5 and list(o["bt_trace"]) == [0, 0, 0, 0, 2]
+    assert o["bt_cond"] < T._BT_TIE
+    for g in T._NUDGES[:3]:                        # the nudges do not see it: same iterations, estimates equal to 1e-15
+        o2 = oracle.fit_iht(ox, y, z * g, k=k, dist=od, link=ol, max_iter=60, **kw)
+        assert o2["iter"] == 5 and np.abs(o2["beta"] - o["beta"]).max() < 1e-15
+    plain = oracle.fit_iht(ox, y, z, k=k, dist=od, link=ol, max_iter=4, **kw)      # a fit that never compares two close loglikelihoods
+    assert plain["bt_cond"] > 1000 * T._BT_TIE      # (its closest decision: a relative gain of 2.6e-10, far from a tie)
+
+
+def test_negbin_r_running_off(oracle):
+    """Seeds 10168 (model paths, trial 4, k = 12) and 10864 (trial 1, k = 8, with debias): counts without overdispersion, r runs off
+    to 1e7 and beyond and differs by orders of magnitude from one ulp-sized nudge to the next; with debias the fit of the original
+    input even ends in the reference's error while every nudged one finishes."""
+    n, p, q, od, ol, D, L, x, ox, y, z, path, kw, okw, d = _replay(T._path_case, 10168, 4, FAMS4)
+    assert od == "negbin" and path == [5, 6, 12] and okw.get("est_r") == "newton"
+    rs = [oracle.fit_iht(ox, y, z * g, k=12, dist=od, link=ol, max_iter=100, **okw)["nb_r"] for g in [1.0] + T._NUDGES]
+    assert min(rs) > 1e6 and max(rs) / min(rs) > 3.0
+    small = oracle.fit_iht(ox, y, z, k=5, dist=od, link=ol, max_iter=100, **okw)     # the same data at k = 5: r settles (13.29), the sweep compares it
+    assert small["nb_r"] < 100.0
+    n, p, q, od, ol, D, L, x, ox, y, z, path, kw, okw, d = _replay(T._path_case, 10864, 1, FAMS4)
+    assert od == "negbin" and path == [2, 7, 8] and okw.get("debias")
+    with pytest.raises(RuntimeError):
+        oracle.fit_iht(ox, y, z, k=8, dist=od, link=ol, max_iter=100, **okw)
+    for g in T._NUDGES:
+        o = oracle.fit_iht(ox, y, z * g, k=8, dist=od, link=ol, max_iter=100, **okw)
+        assert o["iter"] == 100 and o["nb_r"] > 1e6
+
+
+def test_init_beta_with_a_predictor_constant_over_the_training_rows(oracle):
+    """Seeds 10545 (multivariate fits, trial 6) and 10137 (multivariate CV, trial 0, fold 1): a SNP monomorphic in the training rows
+    makes the second pivot of linreg!'s Cholesky a rounding residue; the univariate oracle on those rows reports it (ib_cond)."""
+    n, p, r, q, k, miss, x, ox, Y, Z, kw = _replay(T._mvfit_case, 10545, 6)
+    assert (n, p, r) == (193, 392, 4) and kw.get("init_beta")
+    one = oracle.fit_iht(ox, Y[0], None, k=1, max_iter=1, train=kw.get("train"), init_beta=True)
+    assert one["ib_cond"] < 1e-10
+    n, p, r, qz, q, x, ox, Y, Z, path, folds, extra = _replay(T._mvcv_case, 10137, 0)
+    assert (n, p, r, q) == (201, 173, 4, 2) and extra.get("init_beta")
+    conds = [oracle.fit_iht(ox, Y[0], None, k=1, max_iter=1, train=(folds != f + 1).astype(np.uint8), init_beta=True)["ib_cond"] for f in range(q)]
+    assert conds[0] < 1e-10 and conds[1] > 0.1      # fold 1's training rows hold the constant SNP, fold 2's do not
