@@ -3,8 +3,6 @@ tools/fuzz_parity.py that ended red on an input no floating-point implementation
 ALONE -- the case generators of tests/test_gpu_parity.py with a stand-in for the device matrix -- and the diagnostic the sweeps'
 rule rests on must fire: the oracle's own report (orc_result.bt_cond / ib_cond) or its disagreement with itself under
 ulp-sized nudges of the input.  No GPU, no device library: the oracle is the subject here."""
-import types
-
 import numpy as np
 import pytest
 
@@ -17,9 +15,15 @@ class _NoDevice:                                   # the generators build a devi
         pass
 
 
-FAKE = types.SimpleNamespace(SnpLinAlg=_NoDevice, DenseMatrix=_NoDevice,
-                             **{name: getattr(_real, name) for name in ("Normal", "Bernoulli", "Poisson", "NegativeBinomial", "IdentityLink",
-                                                                        "LogitLink", "LogLink")})
+class _Mirror:                                     # the mirror's distribution / link classes are plain Python; only the matrices need a device
+    SnpLinAlg = _NoDevice
+    DenseMatrix = _NoDevice
+
+    def __getattr__(self, name):
+        return getattr(_real, name)
+
+
+FAKE = _Mirror()
 FAMS3 = [("normal", "identity", FAKE.Normal, FAKE.IdentityLink, 1e-5), ("bernoulli", "logit", FAKE.Bernoulli, FAKE.LogitLink, 1e-4),
          ("poisson", "log", FAKE.Poisson, FAKE.LogLink, 1e-4)]
 FAMS4 = [f[:4] for f in FAMS3] + [("negbin", "log", FAKE.NegativeBinomial, FAKE.LogLink)]
@@ -86,3 +90,20 @@ def test_init_beta_with_a_predictor_constant_over_the_training_rows(oracle):
     assert (n, p, r, q) == (201, 173, 4, 2) and extra.get("init_beta")
     conds = [oracle.fit_iht(ox, Y[0], None, k=1, max_iter=1, train=(folds != f + 1).astype(np.uint8), init_beta=True)["ib_cond"] for f in range(q)]
     assert conds[0] < 1e-10 and conds[1] > 0.1      # fold 1's training rows hold the constant SNP, fold 2's do not
+
+
+def test_zero_over_zero_step_size(oracle):
+    """Seed 10328 (keyword sweep, trial 6: Gamma / log with debias, k = 1): after debias! has refitted the one-SNP support the score on
+    it is a rounding residue -- the share of the squared score on the support (eta_cond) is 5e-19 -- and iht_stepsize! divides two such
+    residues; the loglikelihoods of the step that follows tie exactly (bt_cond = 0)."""
+    rng = np.random.default_rng(10328)
+    for t in range(7):
+        x, ox, y, z, k, kw, okw, both, tol, fam, tag = T._options_case(FAKE, oracle, rng, t)
+    assert tag[1:3] == (209, 280) and fam == "gamma" and both.get("debias")
+    o = oracle.fit_iht(ox, y, z, k=k, max_iter=40, **okw, **both)
+    assert o["eta_cond"] < 1e-18 and o["bt_cond"] < T._BT_TIE
+    rng = np.random.default_rng(10328)
+    for t in range(2):
+        x, ox, y, z, k, kw, okw, both, tol, fam, tag = T._options_case(FAKE, oracle, rng, t)   # an ordinary trial of the same seed (NegBin, :MM): neither fires
+    o = oracle.fit_iht(ox, y, z, k=k, max_iter=40, **okw, **both)
+    assert o["eta_cond"] > 1e-12 and o["bt_cond"] > 1000 * T._BT_TIE
