@@ -158,3 +158,20 @@ def test_stand_in_rccl_matches_the_real_prototypes_and_codes(tmp_path):
         real = re.search(rf"\b{theirs}\s*=\s*(\d+)", hdr)
         assert real and int(mine[ours]) == int(real.group(1)), (ours, theirs)
     assert "NCCL_UNIQUE_ID_BYTES 128" in hdr
+
+
+def test_every_python_file_of_the_tree_compiles():
+    """tools/ holds seventy measurement scripts that only ever run on the GPU box: a syntax error in one of them would surface in
+    the middle of a profiling call.  Byte-compile every .py of the tree (nothing is imported or executed)."""
+    import glob
+    import py_compile
+    import tempfile
+    bad = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for pat in ("*.py", "tools/*.py", "tests/*.py", "tests/golden/*.py", "oracle/*.py", "mendeliht.jl_amd/*.py"):
+            for f in sorted(glob.glob(os.path.join(ROOT, pat))):
+                try:
+                    py_compile.compile(f, cfile=os.path.join(tmp, "x.pyc"), doraise=True)
+                except py_compile.PyCompileError as e:
+                    bad.append((os.path.relpath(f, ROOT), str(e).splitlines()[-1]))
+    assert not bad, bad
