@@ -47,6 +47,20 @@ def test_two_rank_gather_of_fold_losses(tmp_path):
         assert np.array_equal(np.load(tmp_path / f"r{r}.npy"), full)
 
 
+def test_eight_rank_gather_of_fold_losses(tmp_path):
+    """The shape of the driver's 8-GPU run (BASELINE configs[3]: 5 folds x 20 sparsity levels over eight ranks): every (fold, k)
+    combination is owned by exactly one rank, 13 or 12 each, and every rank ends up with the whole loss matrix."""
+    from mendeliht_amd import dist as D
+    q, npath, world = 5, 20, 8
+    shares = [list(D.shard_combinations(q, npath, r, world)) for r in range(world)]
+    assert sorted(len(s_) for s_ in shares) == [12, 12, 12, 12, 13, 13, 13, 13]
+    assert sorted(i for s_ in shares for i in s_) == list(range(q * npath))
+    mp.spawn(_worker, args=(world, _free_port(), q, npath, str(tmp_path)), nprocs=world, join=True)
+    full = np.arange(1.0, q * npath + 1).reshape(q, npath)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"r{r}.npy"), full)
+
+
 def _comm_worker(rank, world, port, out_dir):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
