@@ -137,6 +137,27 @@ def hash_folds(n, q, seed=2026):
     return hf(n, q, seed)
 
 
+def perm_folds(n, q, seed):
+    """Balanced random folds, the shape of the reference's own draw (cross_validation.jl:72 `rand(1:q, n)` is unbalanced; its
+    wrapper's record was made with whatever the RNG gave): a seeded permutation dealt out round-robin."""
+    return (np.random.default_rng(seed).permutation(n) % q + 1).astype(np.int32)
+
+
+def check_recorded_cv_curve(mse, gold, rel=0.12):
+    """A cross-validation curve of OUR folds against a curve the REFERENCE recorded with ITS (random, unrecorded) folds
+    (tests/golden/golden_cv_normal.json): same minimiser, every entry within `rel` of the record (the oracle's fold-to-fold
+    spread, measured over six seeds per curve, is 6.3 % / 6.9 % at worst), the descent to the minimum and the rise behind it."""
+    mse, ref = np.asarray(mse, dtype=float), np.asarray(gold["mse"], dtype=float)
+    kb = gold["best_k"]
+    assert int(gold["path"][int(np.argmin(mse))]) == kb, (int(np.argmin(mse)) + 1, kb)
+    np.testing.assert_allclose(mse, ref, rtol=rel)
+    ib = gold["path"].index(kb)
+    assert mse[0] / mse[ib] == pytest.approx(ref[0] / ref[ib], rel=0.15)          # scale of meanloss relative to its minimum
+    assert np.all(np.diff(mse[:ib + 1]) < 0)                                     # strictly down to the minimum ...
+    assert mse[-1] > mse[ib + 3] > mse[ib]                                       # ... and rising over the plateau behind it
+    assert mse[-1] / mse[ib] == pytest.approx(ref[-1] / ref[ib], rel=0.10)
+
+
 def tied_case(n=1000, src=300, copies=(17, 4247, 9000), noise_seed=3):
     """Exact ties for _choose! (src/utilities.jl:444-458): SNP `src` (0-based) of the shipped normal.bed copied over `copies`,
     a phenotype driven by that SNP alone -- the copies have the same score and the same effect after every step, so a projection

@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import FIX, GOLD, ROOT, SweepTally, hash_folds, make_bed
+from conftest import FIX, GOLD, ROOT, SweepTally, check_recorded_cv_curve, hash_folds, make_bed, perm_folds
 
 pytestmark = pytest.mark.gpu
 
@@ -226,6 +226,23 @@ def test_g1_golden_log_on_gpu(mih, normal_pair, normal_data):
     np.testing.assert_allclose(res.c, g["c_printed"], rtol=5e-6)
     assert res.σg == pytest.approx(g["pve"], rel=1e-9)
     assert res.trace["lines"][0].startswith("Iteration 1: loglikelihood = -1403.60851544")
+
+
+@pytest.mark.parametrize("curve", ["docs_curve", "shipped_summary_curve"])
+def test_cv_curves_the_reference_recorded_on_gpu(mih, oracle, normal_pair, normal_data, curve):
+    """cv_iht of the HIP path against the reference's OWN recorded curves (docs/src/man/examples.md:169-192 and
+    data/cviht.summary.txt; tests/golden/golden_cv_normal.json) -- loose (the reference's folds are random), but held by the
+    reference, not by the restatement -- and, on the same folds, against the oracle."""
+    gold = json.load(open(os.path.join(GOLD, "golden_cv_normal.json")))
+    g = gold[curve]
+    x, ox = normal_pair
+    y = normal_data["y"] if g["y"] == "normal_y_fam6.txt" else normal_data["y2"]
+    for seed in gold["fold_seeds"]:
+        folds = perm_folds(normal_data["n"], g["q"], seed)
+        mse = mih.cv_iht(y, x, normal_data["z"], path=g["path"], q=g["q"], folds=folds, zkeep=g["zkeep"], verbose=False)
+        check_recorded_cv_curve(mse, g)
+        omse, _ = oracle.cv_iht(ox, y, normal_data["z"], path=g["path"], q=g["q"], folds=folds, zkeep=g["zkeep"])
+        np.testing.assert_allclose(mse, omse, rtol=1e-8)
 
 
 def _sim(oracle, ox, rng, k, scale=0.5):

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 from scipy import stats
 
-from conftest import FIX, GOLD, hash_folds, make_bed
+from conftest import FIX, GOLD, check_recorded_cv_curve, hash_folds, make_bed, perm_folds
 
 
 def test_g1_recorded_log_normal_k7(oracle, normal_data):
@@ -48,6 +48,24 @@ def test_g1b_k9_intercept_only(oracle, normal_data):
     assert r["logl"] == pytest.approx(-1612.734968, abs=1e-5)
     assert list(np.flatnonzero(r["beta"]) + 1) == [1266, 3137, 4246, 4717, 6290, 7629, 7755, 8375, 9415]
     assert r["c"][0] == pytest.approx(1.65222721, abs=1e-7)
+
+
+@pytest.mark.parametrize("curve", ["docs_curve", "shipped_summary_curve"])
+def test_cv_curves_the_reference_recorded(oracle, normal_data, curve):
+    """cross_validate on the shipped data against the two curves the reference itself holds (docs/src/man/examples.md:169-192,
+    data/cviht.summary.txt): the only reference-held evidence for predict!'s deviance sum and meanloss's fold weights
+    (cross_validation.jl:279-286, 304-320).  The reference's folds are random and unrecorded: three explicit fold seeds each."""
+    gold = json.load(open(os.path.join(GOLD, "golden_cv_normal.json")))
+    g = gold[curve]
+    x = oracle.Mat.from_bed_file(normal_data["bed"], normal_data["n"])
+    y = normal_data["y"] if g["y"] == "normal_y_fam6.txt" else normal_data["y2"]
+    for seed in gold["fold_seeds"]:
+        folds = perm_folds(normal_data["n"], g["q"], seed)
+        mse, raw = oracle.cv_iht(x, y, normal_data["z"], path=g["path"], q=g["q"], folds=folds, zkeep=g["zkeep"])
+        check_recorded_cv_curve(mse, g)
+        # meanloss (cross_validation.jl:312-317): fold j's deviance sum weighted by its share of the samples
+        wts = np.bincount(folds, minlength=g["q"] + 1)[1:] / normal_data["n"]
+        np.testing.assert_allclose(mse, wts @ raw, rtol=1e-13)
 
 
 def test_snplinalg_semantics(oracle):
