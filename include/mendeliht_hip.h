@@ -231,8 +231,10 @@ typedef struct mih_fit_params {
      * (fold, k) combination `Threads.@threads :static` hands that thread (cross_validation.jl:91,100-110): the NegBin r left by
      * one fit is where the thread's next fit starts, so the losses depend on JULIA_NUM_THREADS.  cv_threads = that number: the
      * fold-major combinations are cut into cv_threads contiguous blocks (the first total % cv_threads one longer, as :static
-     * does), each block is a chain of fits handing r on, and the chains advance in lock-step.  0 = nfolds (one chain per fold
-     * when nfolds divides nfolds * npath, i.e. always for a full grid); 1 = the single-thread order.  With world > 1 chain c is
+     * does), each block is a chain of fits handing r on, and the chains advance in lock-step.  0 or 1 = ONE chain over the whole
+     * grid: what the reference does at its default Threads.nthreads() == 1, and what both bindings (and the tests' CPU checker) mean by the
+     * same value; nfolds = one chain per fold (five times faster at configs[3]'s shape: an explicit choice, because
+     * the losses differ from a default reference run).  With world > 1 chain c is
      * evaluated by rank c mod world (mih_cv_assignment does not apply).  Ignored without est_r: those fits are independent. */
     int32_t  cv_threads;
     int32_t  reserved0;

@@ -22,6 +22,11 @@ int mih_probe_set_xtv_variant(int variant);
 int mih_probe_set_xtv_multi_variant(int variant);
 /* B operands fused per pass of the register-staged kernels (1, 2 or 4) */
 int mih_probe_set_max_fused(int max_nr);
+/* X'r of the first ms[i] columns of R (n x mcap, column-major) for i = 0 .. nms-1, one call after the other on ONE fused-pass
+ * workspace sized for mcap residuals -- what a lock-step lane does from round to round.  OUT: the results back to back
+ * (p * ms[0] doubles, then p * ms[1], ...).  For the test that a pass ignores what an earlier pass with another residual
+ * count left in the unused digit columns of its last operand (flat packing, csrc/xtv.hip). */
+int mih_probe_xtv_sequence(const mih_mat *h, const double *R, int mcap, const int *ms, int nms, int digits, double *OUT);
 #ifdef __cplusplus
 }
 #endif

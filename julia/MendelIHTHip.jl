@@ -118,7 +118,7 @@ struct MihFitParams
     debias::Int32
     xtv_digits::Int32     # fixed-point format of the residual in this call's X'r passes (0 = library default)
     choose::Ptr{Cvoid}; choose_user::Ptr{Cvoid}       # the RNG draw of _choose! (choose_cb below)
-    cv_threads::Int32     # cv_iht with est_r: the Threads.nthreads() whose :static chains of v.d the library follows (0 = q)
+    cv_threads::Int32     # cv_iht with est_r: the Threads.nthreads() whose :static chains of v.d the library follows (0 = 1 = one chain)
     reserved0::Int32
 end
 # mih_comm: exchange callbacks of a column-sharded fit (one Julia process per GPU, e.g. under mpiexec)

@@ -183,7 +183,8 @@ def lib():
     }
     if using_probes():       # include/mendeliht_hip_probes.h
         sig.update({"mih_probe_set_xtv_variant": [C.c_int], "mih_probe_set_xtv_multi_variant": [C.c_int],
-                    "mih_probe_set_max_fused": [C.c_int]})
+                    "mih_probe_set_max_fused": [C.c_int],
+                    "mih_probe_xtv_sequence": [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]})
     for name, args in sig.items():
         f = getattr(L, name)
         f.argtypes = args
@@ -207,7 +208,7 @@ def exported_symbols():
 
 def probe_symbols():
     """What include/mendeliht_hip_probes.h declares: exported by the measurement build only."""
-    return ["mih_probe_set_xtv_variant", "mih_probe_set_xtv_multi_variant", "mih_probe_set_max_fused"]
+    return ["mih_probe_set_xtv_variant", "mih_probe_set_xtv_multi_variant", "mih_probe_set_max_fused", "mih_probe_xtv_sequence"]
 
 
 def _check(rc):
@@ -985,7 +986,9 @@ def cv_iht(y, x, z=None, *, d=None, l=None, path=range(1, 21), q=5, est_r="None"
     mendeliht.jl_amd.dist.cv_iht_distributed for the torch.distributed/RCCL version).
     `cv_threads` (est_r only): the reference re-uses one IHTVariable per Julia thread, so the NegBin r of one fit is the starting
     value of that thread's next fit (cross_validation.jl:91,100-110) and its losses depend on Threads.nthreads(); the library
-    follows the chains of `cv_threads` threads in lock-step (0 = q threads: one chain per fold; 1 = the single-thread order).
+    follows the chains of `cv_threads` threads in lock-step.  0 (the default) = 1 = one chain over the whole grid = the reference at
+    its default Threads.nthreads() == 1 -- the same meaning in mih_fit_params, the CPU checker of the tests and the Julia glue (which passes
+    Threads.nthreads()); cv_threads=q gives one chain per fold (faster, but not a default reference run's losses).
     """
     replicas = None
     if isinstance(x, (list, tuple)):                 # one replica of the matrix per GPU, driven from this process

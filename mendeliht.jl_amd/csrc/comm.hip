@@ -128,11 +128,18 @@ static int native_allgather(void *user, const double *send, int64_t count, doubl
 
 // The n-vector sums of a column-sharded fit (X_S b_S, X_S g_S) when the communicator is the library's own: ncclAllReduce is queued
 // on the FIT's stream, behind the kernel that produced the partial sums and in front of the kernels that read the totals --
-// no host synchronisation on either side (the callback contract of mih_comm::allreduce needs two).  -1: not a native communicator.
-int comm_native_allreduce_on_stream(const mih_comm *c, double *buf_dev, int64_t count, int32_t op, hipStream_t s)
+// no host synchronisation on either side (the callback contract of mih_comm::allreduce needs two).  -1: not a native communicator,
+// or the fit's stream lives on another device than the communicator: the caller then takes the callback route, which
+// synchronises the fit's stream and runs the collective on the communicator's own stream.
+// INVARIANT the caller keeps: a collective queued here on the fit's stream is followed by a HOST WAIT on that stream before the next
+// collective of this communicator is issued from any other stream (the all-gather of project_full_sharded runs on nc->stream):
+// every such all-reduce sits in front of a final_sum_home / hipStreamSynchronize of the same chain (IhtVar::update_xb -> mu_loglik,
+// stepsize / step_post_fused -> final_sum_home), so two collectives of one communicator are never in flight on two streams.
+int comm_native_allreduce_on_stream(const mih_comm *c, double *buf_dev, int64_t count, int32_t op, hipStream_t s, int device)
 {
     if (!c || c->allreduce != native_allreduce || c->user != (void *)c) return -1;
     NativeComm *nc = static_cast<NativeComm *>(c->user);
+    if (device != nc->device) return -1;
     const int rc = g_rccl.AllReduce(buf_dev, buf_dev, (size_t)count, kNcclFloat64, op == 0 ? kNcclSum : kNcclMax, nc->comm, s);
     if (rc != kNcclSuccess) return nccl_fail(rc, "ncclAllReduce");
     return MIH_OK;

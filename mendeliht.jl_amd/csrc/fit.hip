@@ -453,7 +453,7 @@ struct IhtVar {
     int comm_fail(int rc) { set_error("communicator callback failed (%d)", rc); return MIH_BAD_ARG; }
     int allreduce_dev(double *buf, int64_t cnt, int op)
     {
-        const int nrc = comm_native_allreduce_on_stream(comm, buf, cnt, op, s);      // the library's own communicator: queued on this stream
+        const int nrc = comm_native_allreduce_on_stream(comm, buf, cnt, op, s, h->device);      // the library's own communicator: queued on this stream
         if (nrc >= 0) return nrc;
         MIH_HIP(hipStreamSynchronize(s));
         int rc = comm->allreduce(comm->user, buf, cnt, op, 1);
@@ -1146,7 +1146,11 @@ struct IhtVar {
     // iht_stepsize! (utilities.jl:722-764)
     int stepsize(double *eta)
     {
-        if (spec_ok && spec_idx == idx.idx && spec_idc == idc) {      // computed at the end of the previous step
+        //  Column-sharded fit: the branch taken here decides whether this rank enters the n+1 all-reduce below, so it must
+        // be the same on every rank.  spec_ok is: it is set by step_post_fused (every rank runs it in every step) and cleared by
+        // init_pre and save_best_model, the only other places that change idx / b / mu -- all of them in lock-step.  The rank-LOCAL
+        // comparison of the supports is therefore not part of the decision under comm (it holds whenever spec_ok does).
+        if (spec_ok && (comm || (spec_idx == idx.idx && spec_idc == idc))) {      // computed at the end of the previous step
             spec_ok = false;
             double numer = 0.0;
             if (comm) numer = spec_numer_snp;                  // |df_S|^2 over ALL shards came home with the denominator
@@ -1193,7 +1197,7 @@ struct IhtVar {
     }
     int save_best_model()                            // utilities.jl:995-1006
     {
-        b = best_b; c = best_c; idx.idx = b.idx;
+        b = best_b; c = best_c; idx.idx = b.idx; spec_ok = false;
         bg_ok = false;                                         // (the best model is kept per shard only)
         for (int l = 0; l < q; ++l) idc[l] = (c[l] != 0.0);
         MIH_TRY(update_xb());
@@ -1380,7 +1384,7 @@ static int check_params(const mih_mat *h, const mih_fit_params *prm, int64_t q)
     if (prm->J < 0) { set_error("Value of J (max number of groups) must be nonnegative!"); return MIH_BAD_ARG; }
     if (prm->max_iter < 0) { set_error("Value of max_iter must be nonnegative!"); return MIH_BAD_ARG; }
     if (prm->max_step < 0) { set_error("Value of max_step must be nonnegative!"); return MIH_BAD_ARG; }
-    if (prm->cv_threads < 0) { set_error("cv_threads must be nonnegative (0 = one chain per fold)"); return MIH_BAD_ARG; }
+    if (prm->cv_threads < 0) { set_error("cv_threads must be nonnegative (0 = 1 = one chain, the reference at Threads.nthreads() == 1)"); return MIH_BAD_ARG; }
     if (!(prm->tol > 2.220446049250313e-16)) { set_error("Value of global tol must exceed machine precision!"); return MIH_BAD_ARG; }
     if (h->kind == 0 && !h->center) { set_error("x is not centered! Please construct SnpLinAlg{Float64}(::SnpArray, center=true, scale=true)"); return MIH_NOT_CENTERED; }
     if (prm->est_r != MIH_ESTR_NONE && prm->dist != MIH_NEGBIN) { set_error("Only negative binomial regression currently supports nuisance parameter estimation"); return MIH_BAD_ARG; }
@@ -1901,10 +1905,10 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, con
     } else {
         // The NegBin nuisance parameter travels from one fit of a Julia thread to that thread's next fit (CvChains):
         // `Threads.@threads :static for i in eachindex(combinations)` (cross_validation.jl:100) gives thread t of T the block
-        // [t*len + min(t, rem), ...) with len, rem = divrem(total, T).  T = mih_fit_params::cv_threads, 0 = nfolds (with
+        // [t*len + min(t, rem), ...) with len, rem = divrem(total, T).  T = mih_fit_params::cv_threads, 0 = 1 = the single-thread order, the reference's default (with T = nfolds and
         // nfolds | total, e.g. always for the full grid, every fold is one chain); T = 1 is the single-thread order.  A chain is
         // evaluated whole by one rank (chain c by rank c mod world): the losses do not depend on `world`.
-        const int64_t total = (int64_t)nfolds * npath, T = prm->cv_threads > 0 ? prm->cv_threads : nfolds;
+        const int64_t total = (int64_t)nfolds * npath, T = prm->cv_threads > 0 ? prm->cv_threads : 1;
         const int64_t len = total / T, rem = total % T;
         int64_t c = 0;
         for (int64_t t = 0; t < T; ++t) {

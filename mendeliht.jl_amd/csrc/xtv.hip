@@ -1548,6 +1548,12 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
             fp.u0[npass] = u; fp.t0[npass] = t;
         }
     }
+    // INVARIANT of the flat packing: k_digits writes only the digit columns of THIS call's m residuals; the unused tail
+    // columns of a pass's last operand keep whatever an earlier call with another m left there.  That is harmless because (1) the
+    // columns of the MFMA's B operand are independent -- a stale column only produces accumulator columns nobody reads -- and
+    // (2) xtv_epilogue16_flat stops at j >= nres.  The lock-step lanes exercise exactly this in every cross-validation (one workspace,
+    // a falling residual count from round to round, every loss checked by the tests of the full configs[3] grid),
+    // and test_flat_packing_ignores_what_an_earlier_pass_left_in_the_tail_columns runs 19 residuals and then 1 .. 18 on ONE workspace.
     hipLaunchKernelGGL(k_digits, dim3((unsigned)((nblk + 3) / 4), (unsigned)(dm.flat ? m : nops * per_op)), dim3(256), 0, s, r_dev, h->n, nblk, m, dm,
                        w.scal.p, dig_all, dig2_all, fp);
     for (int q = 0; dm.flat && q < fp.npass; ++q) {
@@ -1698,6 +1704,30 @@ int mih_xtv(const mih_mat *h, const double *r, double *out)
 {
     return mih_xtv_batched_fmt(h, r, 1, 0, out);
 }
+
+#ifdef MIH_PROBES
+// include/mendeliht_hip_probes.h: a sequence of residual counts on ONE fused-pass workspace (what a lock-step lane does)
+int mih_probe_xtv_sequence(const mih_mat *h, const double *R, int mcap, const int *ms, int nms, int digits, double *OUT)
+{
+    if (!h || !R || !ms || !OUT || mcap < 1 || nms < 1) { set_error("null/invalid argument"); return MIH_BAD_ARG; }
+    for (int i = 0; i < nms; ++i) if (ms[i] < 1 || ms[i] > mcap) { set_error("ms[%d] = %d outside 1..%d", i, ms[i], mcap); return MIH_BAD_ARG; }
+    MIH_HIP(hipSetDevice(h->device));
+    XtvWork w;
+    MIH_TRY(xtv_work_init(h, w, mcap, xtv_tune(digits)));
+    DevBuf<double> r, out;
+    MIH_TRY(r.alloc((size_t)mcap * h->n));
+    MIH_TRY(out.alloc((size_t)mcap * h->p));
+    MIH_HIP(hipMemcpyAsync(r.p, R, sizeof(double) * (size_t)mcap * h->n, hipMemcpyHostToDevice, h->stream));
+    size_t off = 0;
+    for (int i = 0; i < nms; ++i) {
+        MIH_TRY(xtv_device(h, w, r.p, ms[i], out.p, h->stream));
+        MIH_HIP(hipMemcpyAsync(OUT + off, out.p, sizeof(double) * (size_t)ms[i] * h->p, hipMemcpyDeviceToHost, h->stream));
+        MIH_HIP(hipStreamSynchronize(h->stream));
+        off += (size_t)ms[i] * h->p;
+    }
+    return MIH_OK;
+}
+#endif
 
 __global__ void k_fill_random(double *r, int64_t n, uint64_t seed)
 {

@@ -199,6 +199,13 @@ class ColumnComm:
             return 1
 
 
+def _last_error_text():
+    from .api import lib
+    buf = C.create_string_buffer(512)
+    lib().mih_last_error(buf, 512)
+    return buf.value.decode(errors="replace")
+
+
 class NativeComm:
     """The library's own RCCL communicator as the `mih_comm` of a column-sharded fit (mih_comm_create_rccl): the two
     exchanges run inside the library (ncclAllReduce / ncclAllGather over xGMI), no callback into Python.  One process per
@@ -214,17 +221,36 @@ class NativeComm:
         self.rank = dist.get_rank(group) if on else 0
         self.world = dist.get_world_size(group) if on else 1
         self.error = None
+        self._h = C.c_void_p(None)
+        on_gpu = on and dist.get_backend(group) == "nccl"
+
+        def everyone(ok):
+            #  a rank-local failure must not leave the other ranks inside the next collective: agree first
+            if self.world == 1:
+                return bool(ok)
+            f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=f"cuda:{device}" if on_gpu else "cpu")
+            dist.all_reduce(f, op=dist.ReduceOp.MIN, group=group)
+            return bool(int(f.item()))
+
+        # 1. every rank proves that it can load librccl and ask it for an id (a local call; only rank 0's id is used)
         uid = (C.c_char * 128)()
-        if self.rank == 0:
-            _check(lib().mih_rccl_unique_id(uid))
+        rc = lib().mih_rccl_unique_id(uid)
+        mine = None if rc == 0 else _last_error_text()
+        if not everyone(rc == 0):
+            raise RuntimeError("mih_rccl_unique_id failed on " + ("this rank: " + mine if mine else "another rank"))
+        # 2. rank 0's id to everyone
         if self.world > 1:
             t = torch.frombuffer(bytearray(uid.raw), dtype=torch.uint8).clone()
-            if dist.get_backend(group) == "nccl":
+            if on_gpu:
                 t = t.to(f"cuda:{device}")
             dist.broadcast(t, src=0, group=group)
             uid = (C.c_char * 128).from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
-        self._h = C.c_void_p(None)
-        _check(lib().mih_comm_create_rccl(uid, self.rank, self.world, int(device), int(col_offset), int(p_global), C.byref(self._h)))
+        # 3. ncclCommInitRank is itself collective; a rank on which it RETURNS an error (rather than hanging) is reported to all
+        rc = lib().mih_comm_create_rccl(uid, self.rank, self.world, int(device), int(col_offset), int(p_global), C.byref(self._h))
+        mine = None if rc == 0 else _last_error_text()
+        if not everyone(rc == 0):
+            self.close()
+            raise RuntimeError("mih_comm_create_rccl failed on " + ("this rank: " + mine if mine else "another rank"))
 
     def pointer(self):
         return self._h.value

@@ -287,8 +287,9 @@ def fit_iht(x, y, z=None, k=10, J=1, dist="normal", link="identity", nb_r=1.0, t
 
 def cv_iht(x, y, z=None, path=range(1, 21), q=5, folds=None, dist="normal", link="identity", nb_r=1.0,
            tol=1e-4, max_iter=100, min_iter=5, max_step=3, est_r=None, zkeep=None, weight=None,
-           group=None, J=1, init_beta=False, debias=False, cv_threads=1):
-    """cv_threads: Threads.nthreads() of the reference run (matters with est_r only: iht_oracle.h)."""
+           group=None, J=1, init_beta=False, debias=False, cv_threads=0):
+    """cv_threads: Threads.nthreads() of the reference run (matters with est_r only: iht_oracle.h); 0 = 1 = one chain, as in
+    mih_fit_params and both bindings."""
     keep = []
     prm = _params(1, J, dist, link, nb_r, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, keep, init_beta,
                   debias)

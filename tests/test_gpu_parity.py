@@ -89,6 +89,41 @@ def _run_probe_snippet(snippet, out_file, extra_env=None, probes=True, timeout=9
     return np.load(out_file)
 
 
+_TAIL_COLUMNS_SNIPPET = r"""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import mendeliht_amd as m
+from mendeliht_amd import api
+assert m.using_probes()
+n, mcap = 1000, 19
+x = m.SnpLinAlg(m.read_bed(os.path.join(sys.argv[1], "tests", "fixtures", "normal.bed"), n), n, center=True, scale=True, impute=True)
+rng = np.random.default_rng(7)
+R = np.asfortranarray(rng.standard_normal((n, mcap)) * np.exp(rng.uniform(-3, 3, mcap)))      # a different scale per residual
+ms = np.array([19] + list(range(1, 19)) + [19], dtype=np.int32)       # a full pass first, then every shorter count, then full again
+out = np.zeros(int(ms.sum()) * x.p)
+api._check(api.lib().mih_probe_xtv_sequence(x._h, api._p(R), mcap, api._p(ms), ms.size, 0, api._p(out)))
+np.savez(sys.argv[2], R=R, ms=ms, out=out)
+"""
+
+
+def test_flat_packing_ignores_what_an_earlier_pass_left_in_the_tail_columns(mih, normal_pair, tmp_path):
+    """ With the flat digit packing k_digits writes only the columns of the call's m residuals; the unused tail columns
+    of the last operand keep the digits of an earlier call.  A lock-step lane does exactly that from round to round.  Here: 19
+    residuals, then 1 .. 18, then 19 again on ONE workspace (measurement build: mih_probe_xtv_sequence) -- every result must be
+    bit for bit what a FRESH workspace gives for the same residuals (mih_xtv_batched_fmt, product library, this process)."""
+    x, _ = normal_pair
+    got = _run_probe_snippet(_TAIL_COLUMNS_SNIPPET, tmp_path / "tail.npz")
+    R, ms, out = got["R"], got["ms"], got["out"]
+    fresh = {int(mm): x.xtv(np.asfortranarray(R[:, :mm])).reshape(x.p, -1, order="F") for mm in sorted(set(ms.tolist()))}
+    off = 0
+    for mm in ms.tolist():
+        blk = out[off:off + mm * x.p].reshape(x.p, mm, order="F")
+        assert np.array_equal(blk, fresh[mm]), mm
+        off += mm * x.p
+    assert np.array_equal(fresh[19][:, :7], fresh[7])              # and a residual's X'r does not depend on the company it rides with
+
+
 def test_mu_sinv_and_xtv_against_oracle(mih, normal_pair):
     x, ox = normal_pair
     assert not mih.using_probes()                                   # the tests run on the product library
@@ -687,8 +722,8 @@ def test_cv_negbin_est_r_chains_in_lockstep(mih, oracle, method):
     never resets v.d, so the NegBin r that mle_for_r (utilities.jl:141-247) left at the end of a fit is where the thread's next
     fit starts; `Threads.@threads :static` (:100) gives each thread a contiguous block of the fold-major combinations.  The
     library runs one CHAIN of fits per emulated thread and advances the chains in lock-step: every loss against the oracle's
-    restatement with the same number of threads -- q threads (the default: one chain per fold), 1 thread (one chain over the
-    whole grid), and thread counts that cut folds in the middle (2, 4, 7) -- and the chains dealt out over two ranks must add
+    restatement with the same number of threads -- 1 thread (the default, 0 = 1: one chain over the whole grid, the reference at
+    Threads.nthreads() == 1), q threads (one chain per fold), and thread counts that cut folds in the middle (2, 4, 7) -- and the chains dealt out over two ranks must add
     up to the single-rank matrix bit for bit (a chain stays whole on one rank)."""
     rng = np.random.default_rng(61)
     n, p, q = 900, 260, 3
@@ -701,11 +736,11 @@ def test_cv_negbin_est_r_chains_in_lockstep(mih, oracle, method):
     folds = hash_folds(n, q)
     path = [2, 3, 5, 6, 8]                                           # 15 combinations
     seen = {}
-    for T in (0, 1, 2, 4, 7):
+    for T in (0, 1, 2, q, 4, 7):
         mse, raw = mih.cv_iht(y, x, None, d=mih.NegativeBinomial(1.0), l=mih.LogLink(), est_r=method, path=path, q=q, folds=folds,
                               verbose=False, return_raw=True, cv_threads=T)
         omse, oraw = oracle.cv_iht(ox, y, None, path=path, q=q, folds=folds, dist="negbin", link="log", nb_r=1.0,
-                                   est_r=method.lower(), cv_threads=(q if T == 0 else T))
+                                   est_r=method.lower(), cv_threads=T)        # the same value means the same on both sides
         assert np.count_nonzero(raw) == q * len(path)
         # the Newton update stops at |dr| <= 1e-6 (utilities.jl:242): rounding-level differences move r by up to that much
         np.testing.assert_allclose(raw, oraw, rtol=1e-5, err_msg=f"cv_threads={T}")
@@ -713,13 +748,17 @@ def test_cv_negbin_est_r_chains_in_lockstep(mih, oracle, method):
         halves = [mih.cv_iht(y, x, None, d=mih.NegativeBinomial(1.0), l=mih.LogLink(), est_r=method, path=path, q=q, folds=folds,
                              verbose=False, return_raw=True, cv_threads=T, rank=r, world=2)[1] for r in range(2)]
         assert np.array_equal(halves[0] + halves[1], raw), T
-        assert all(np.count_nonzero(hh) > 0 for hh in halves) or T == 1
+        assert all(np.count_nonzero(hh) > 0 for hh in halves) or T in (0, 1)
         seen[T] = raw
-    assert np.array_equal(seen[0], mih.cv_iht(y, x, None, d=mih.NegativeBinomial(1.0), l=mih.LogLink(), est_r=method, path=path, q=q,
-                                              folds=folds, verbose=False, return_raw=True, cv_threads=q)[1])
+    # the DEFAULT is the reference's default: no cv_threads argument = 0 = 1 = Threads.nthreads() == 1, one chain over the grid
+    default = mih.cv_iht(y, x, None, d=mih.NegativeBinomial(1.0), l=mih.LogLink(), est_r=method, path=path, q=q,
+                         folds=folds, verbose=False, return_raw=True)[1]
+    assert np.array_equal(default, seen[0]) and np.array_equal(seen[0], seen[1])
+    odefault = oracle.cv_iht(ox, y, None, path=path, q=q, folds=folds, dist="negbin", link="log", nb_r=1.0, est_r=method.lower())[1]
+    np.testing.assert_allclose(default, odefault, rtol=1e-5)
     # the chains matter: the first fit of a chain starts from d.r = 1, a later one from its predecessor's estimate
-    assert not np.array_equal(seen[1], seen[0])
-    assert np.array_equal(seen[1][0, 0], seen[0][0, 0])              # (fold 1, first k) opens a chain under either count
+    assert not np.array_equal(seen[1], seen[q])
+    assert np.array_equal(seen[1][0, 0], seen[q][0, 0])              # (fold 1, first k) opens a chain under either count
     # model paths with est_r ride the lock-step driver too: every fit_iht call of the reference builds its own IHTVariable
     # (cross_validation.jl:254-258), so each starts from d.r
     ll = mih.iht_run_many_models(y, x, None, d=mih.NegativeBinomial(1.0), l=mih.LogLink(), est_r=method, path=path, verbose=False)
