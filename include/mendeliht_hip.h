@@ -237,7 +237,12 @@ typedef struct mih_fit_params {
      * the losses differ from a default reference run).  With world > 1 chain c is
      * evaluated by rank c mod world (mih_cv_assignment does not apply).  Ignored without est_r: those fits are independent. */
     int32_t  cv_threads;
-    int32_t  reserved0;
+    /* How iht_one_step! (fit.jl:213-263) is driven.  0 = the step is resident on the device wherever the fit allows it (a plain 2-bit
+     * univariate fit: no column shard, group projection, est_r or debias): the k-sparse iterate, the exact finish of project_k!,
+     * the backtracking decision and the stopping rule live in device memory, the host queues the kernels of a step without
+     * waiting and reads one record per step, one step behind.  Exact ties that need _choose! hand the step back to the host-driven
+     * path.  1 = every step host-driven (rounds 1-4: 26 launches, three waits).  Same results either way, bit for bit. */
+    int32_t  step_mode;
 } mih_fit_params;
 enum { MIH_CHOOSE_SAMPLE = 0, MIH_CHOOSE_SHUFFLE_B = 1, MIH_CHOOSE_SHUFFLE_C = 2 };
 

@@ -119,7 +119,7 @@ struct MihFitParams
     xtv_digits::Int32     # fixed-point format of the residual in this call's X'r passes (0 = library default)
     choose::Ptr{Cvoid}; choose_user::Ptr{Cvoid}       # the RNG draw of _choose! (choose_cb below)
     cv_threads::Int32     # cv_iht with est_r: the Threads.nthreads() whose :static chains of v.d the library follows (0 = 1 = one chain)
-    reserved0::Int32
+    step_mode::Int32
 end
 # mih_comm: exchange callbacks of a column-sharded fit (one Julia process per GPU, e.g. under mpiexec)
 struct MihComm

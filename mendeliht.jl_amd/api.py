@@ -58,7 +58,7 @@ class _FitParams(C.Structure):
                 ("zkeep", C.c_void_p), ("weight", C.c_void_p), ("group", C.c_void_p), ("ks", C.c_void_p),
                 ("nks", C.c_int64), ("progress", C.c_void_p), ("progress_user", C.c_void_p),
                 ("init_beta", C.c_int32), ("comm", C.c_void_p), ("debias", C.c_int32), ("xtv_digits", C.c_int32),
-                ("choose", C.c_void_p), ("choose_user", C.c_void_p), ("cv_threads", C.c_int32), ("reserved0", C.c_int32)]
+                ("choose", C.c_void_p), ("choose_user", C.c_void_p), ("cv_threads", C.c_int32), ("step_mode", C.c_int32)]
 
 
 class _Comm(C.Structure):
@@ -608,7 +608,7 @@ class IHTSession:
     """An IHTVariable kept alive on the GPU: `initialize` once, then `step()` = one iht_one_step!."""
 
     def __init__(self, y, x, z=None, *, k=10, J=1, d=None, l=None, zkeep=None, weight=None, max_step=3, train=None,
-                 comm=None, xtv_digits=None):
+                 comm=None, xtv_digits=None, step_mode=None):
         x = _as_mat(x)
         d = _inst(d) if d is not None else Normal()
         l = _inst(l) if l is not None else IdentityLink()
@@ -621,7 +621,7 @@ class IHTSession:
         self.q = z.shape[1]
         self._keep = [y, z]
         prm = _params(k, J, d, l, 1e-4, 1 << 30, 5, max_step, "None", zkeep, weight, None, self.q, x.p, self._keep,
-                      comm=comm, xtv_digits=xtv_digits)
+                      comm=comm, xtv_digits=xtv_digits, step_mode=step_mode)
         tr = None if train is None else np.ascontiguousarray(train, dtype=np.uint8)
         self._h = C.c_void_p(None)
         _check(lib().mih_session_create(x._h, C.byref(prm), _p(y), _p(z), self.q, _p(tr), C.byref(self._h)))
@@ -787,9 +787,22 @@ def _print_parameters(io, k, d, l, use_maf, group, debias, tol, max_iter, min_it
     print(f"Converging when tol < {tol} and iteration ≥ {min_iter}:\n", file=io)
 
 
+_default_step_mode = 0
+
+
+def set_step_mode(mode=0):
+    """Default of the `step_mode=` keyword (mih_fit_params::step_mode): 0 = iht_one_step! resident on the device wherever the fit
+    allows it, 1 = every step host-driven (the path of rounds 1-4).  Same results bit for bit; the switch exists for A/B runs."""
+    global _default_step_mode
+    if int(mode) not in (0, 1):
+        raise ArgumentError("step_mode must be 0 (device-resident steps) or 1 (host-driven steps)")
+    _default_step_mode = int(mode)
+
+
 def _params(k, J, d, l, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, q, p, keep, progress=None,
-            init_beta=False, comm=None, debias=False, xtv_digits=None, choose=None):
+            init_beta=False, comm=None, debias=False, xtv_digits=None, choose=None, step_mode=None):
     prm = _FitParams()
+    prm.step_mode = _default_step_mode if step_mode is None else int(step_mode)
     if choose is not None:
         ccb = _choose_callback(choose)
         prm.choose = C.cast(ccb, C.c_void_p)
@@ -848,8 +861,10 @@ def _params(k, J, d, l, tol, max_iter, min_iter, max_step, est_r, zkeep, weight,
 
 def fit_iht(y, x, z=None, *, k=10, J=1, d=None, l=None, group=None, weight=None, zkeep=None, est_r="None",
             use_maf=False, debias=False, verbose=True, tol=1e-4, max_iter=200, min_iter=5, max_step=3,
-            io=None, init_beta=False, memory_efficient=True, train=None, comm=None, xtv_digits=None, choose=None):
+            io=None, init_beta=False, memory_efficient=True, train=None, comm=None, xtv_digits=None, choose=None, step_mode=None):
     """fit_iht(y, x, z; k, J, d, l, ...) -- src/fit.jl:60-118.
+
+    step_mode (no reference counterpart): how iht_one_step! is driven (set_step_mode); None = the mirror's default.
 
     choose (no keyword in the reference, which draws from the global RNG): fn(kind, list, excess) making the random draw of
     _choose! (src/utilities.jl:444-458, src/multivariate.jl:310-351) when a projection leaves exact ties -- see
@@ -903,7 +918,7 @@ def fit_iht(y, x, z=None, *, k=10, J=1, d=None, l=None, group=None, weight=None,
 
     keep = []
     prm = _params(k, J, d, l, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, q, x.p, keep, progress,
-                  init_beta=init_beta, comm=comm, debias=debias, xtv_digits=xtv_digits, choose=choose)
+                  init_beta=init_beta, comm=comm, debias=debias, xtv_digits=xtv_digits, choose=choose, step_mode=step_mode)
     if verbose:
         _print_parameters(io, k, d, l, use_maf, group, debias, tol, max_iter, min_iter)
     tr = None if train is None else np.ascontiguousarray(train, dtype=np.uint8)

@@ -356,6 +356,9 @@ struct DigitMode {
     int flat = 0;    // (round 4) the residuals of a pass occupy digit columns 10 j .. 10 j + 9 of the pass's operands back to back,
                      // across operand boundaries: 19 ten-digit residuals in the 192 columns of six operands instead of 18
     int nres = 0;    // flat: residuals in this pass
+    // device-resident steps (fit.hip): the digit kernel and the single-fit pass run only while *gate == gate_val -- a chain queued
+    // ahead of the host's knowledge (a step that turned out to need backtracking, a fit that converged) then does nothing
+    const int32_t *gate = nullptr; int32_t gate_val = 0;
 };
 // flat packing: which pass a residual rides and where the pass's operands start (k_digits)
 constexpr int kMaxFlatPasses = 16;
@@ -390,6 +393,7 @@ struct XtvWork {            // scratch for one in-flight X'r
     size_t rhs_cap = 0;        // residuals the statistics / partial buffers hold
     XtvTune tune;              // fixed at init
     int stream_tag = 0;        // which lock-step lane launches on this workspace (profile records)
+    const int32_t *gate = nullptr; int32_t gate_val = 0;   // see DigitMode::gate; set by the caller around one xtv_device call
 };
 // batched = false: the workspace of a single univariate fit (one residual per pass); true: fused multi-RHS passes
 int  xtv_work_init(const mih_mat *h, XtvWork &w, int m, const XtvTune &tune, bool batched = true);

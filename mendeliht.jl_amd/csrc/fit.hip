@@ -368,6 +368,8 @@ static double h_mueta(int link, double eta)
     }
 }
 
+#include "resident.inc"        // iht_one_step! resident on the device: the kernels of IhtVar::res_*
+
 // initialize_beta! results shared by the fits of a lock-step lane: the p univariate regressions depend on the training rows only
 // (the fold), not on the model size, so the first fit of a fold computes them (two extra passes over X) and the other fits of
 // that fold in the lane take them from here.  One lane = one host thread: no locking; a fit that finds an entry still being
@@ -515,8 +517,10 @@ struct IhtVar {
                          + 3 * sizeof(double) * (size_t)kcap + xv_work_bytes(h, kcap, kcap - 1024)
                          + sizeof(uint32_t) * 2048 + 64 + 16 * ((size_t)kcap + 1025)
                          + (prm->weight ? sizeof(double) * (size_t)p : 0) + (prm->group ? sizeof(int64_t) * ((size_t)p + ks.size() + 1) : 0)
-                         + 48 * 256;
-            size_t pin = sizeof(uint64_t) * (HostStage::kSlots * (2 * (size_t)kcap + 8) + ((size_t)kcap + kMaxQ + 16) + 2 + 2 * ((size_t)kcap + 64) + 16) + 8 * 256;
+                         + 48 * 256
+                         + sizeof(ResCtl) + (size_t)kcap * (3 * 16 + 4 * 4) + 4096 * sizeof(uint32_t) + 8 * 256;       // resident steps
+            size_t pin = sizeof(uint64_t) * (HostStage::kSlots * (2 * (size_t)kcap + 8) + ((size_t)kcap + kMaxQ + 16) + 2 + 2 * ((size_t)kcap + 64) + 16) + 8 * 256
+                         + sizeof(ResCtl) + kResRing * sizeof(ResRecord) + (size_t)kcap * (3 * 16 + 4 * 4) + 8 * 256;
             MIH_TRY(arena.reserve(dev, pin));
         }
         ArenaScope in_arena(&arena);
@@ -561,11 +565,18 @@ struct IhtVar {
             return MIH_BAD_ARG;
         }
         c.assign(q, 0.0); c0 = c; best_c = c; df2 = c; idc.assign(q, 0); idc0 = idc;
+        MIH_TRY(res_setup(prm, kcap));
         return MIH_OK;
     }
     // the last readback may have been a polled one (SpinFlag): the publishing kernel can still be retiring.  Drain the stream before
     // its buffers go (releasing the arena under a stream that was destroyed with work in flight leaked the block).
-    ~IhtVar() { if (s) (void)hipStreamSynchronize(s); if (s && own_stream) (void)hipStreamDestroy(s); if (ev) (void)hipEventDestroy(ev); }
+    ~IhtVar()
+    {
+        if (s) (void)hipStreamSynchronize(s);
+        for (int i = 0; i < kResRing; ++i) if (res_ev[i]) (void)hipEventDestroy(res_ev[i]);
+        if (s && own_stream) (void)hipStreamDestroy(s);
+        if (ev) (void)hipEventDestroy(ev);
+    }
 
     // v.k = sparsity (cross_validation.jl:110): with groups and a scalar k the projection reads k from the device
     int set_k(int64_t knew)
@@ -1341,37 +1352,304 @@ struct IhtVar {
         return MIH_OK;
     }
 
+
+    // ---- iht_one_step! resident on the device (resident.inc) ------------------------------------------------------------------
+    // The host-driven members above stay the library's statement of the step (and serve every fit the resident chain does not:
+    // column shards, groups, est_r, debias, dense matrices, lock-step lanes); a fit that qualifies runs its steps through
+    // res_next().  Between res_begin() and res_end() the iterate lives on the device only.
+    bool res_ok = false, res_active = false, res_zero_list = false;
+    int res_epoch = 0; uint64_t res_seq = 0; int64_t res_kcap = 0;
+    std::vector<uint64_t> res_out;                       // sequence numbers of the steps in flight, oldest first
+    DevBuf<ResCtl> rctl; DevBuf<int64_t> ridx; DevBuf<double> rval; DevBuf<int32_t> rslot; DevBuf<uint32_t> rhist;
+    PinBuf<ResCtl> rctl_h; PinBuf<ResRecord> rrec; PinBuf<int64_t> ridx_h; PinBuf<double> rval_h; PinBuf<int32_t> rslot_h;
+    hipEvent_t res_ev[kResRing] = {nullptr};
+    struct ResRun { int64_t limit = 0, issued = 0, done = 0; };
+
+    int res_setup(const mih_fit_params *prm, int64_t kcap)
+    {
+        res_ok = false;
+        const int64_t K = k + zkeepn;
+        if (h->kind != 0 || comm || has_group || !ks.empty() || est_r != MIH_ESTR_NONE || debias || batched || prm->step_mode != 0) return MIH_OK;
+        if (probe_env("MENDELIHT_NO_RESIDENT")) return MIH_OK;              // measurement build: A/B against the host-driven step
+        if (xv.slots <= 0 || xv.slots > 160 * 32 || K < 1 || K > p + q || h->p >= (1ll << 40)) return MIH_OK;
+        res_kcap = std::min<int64_t>(kcap, (int64_t)xv.coefA.n);
+        MIH_TRY(rctl.alloc(1)); MIH_TRY(ridx.alloc((size_t)res_kcap * 3)); MIH_TRY(rval.alloc((size_t)res_kcap * 3));
+        MIH_TRY(rslot.alloc((size_t)res_kcap * 4)); MIH_TRY(rhist.alloc(4096));
+        MIH_TRY(rctl_h.alloc(1, true)); MIH_TRY(rrec.alloc(kResRing, true));
+        MIH_TRY(ridx_h.alloc((size_t)res_kcap * 3, true)); MIH_TRY(rval_h.alloc((size_t)res_kcap * 3, true)); MIH_TRY(rslot_h.alloc((size_t)res_kcap * 4, true));
+        MIH_HIP(hipMemsetAsync(rhist.p, 0, sizeof(uint32_t) * 4096, s));
+        std::memset(rrec.p, 0, sizeof(ResRecord) * kResRing);
+        for (int i = 0; i < kResRing; ++i) MIH_HIP(hipEventCreateWithFlags(&res_ev[i], hipEventDisableTiming | hipEventBlockingSync));
+        res_ok = true;
+        return MIH_OK;
+    }
+    ResPtrs res_ptrs() const
+    {
+        ResPtrs P;
+        P.ctl = rctl.p;
+        for (int i = 0; i < 3; ++i) { P.idx[i] = ridx.p + (size_t)i * res_kcap; P.val[i] = rval.p + (size_t)i * res_kcap; }
+        for (int i = 0; i < 2; ++i) { P.slot[i] = rslot.p + (size_t)i * res_kcap; P.fresh[i] = rslot.p + (size_t)(2 + i) * res_kcap; }
+        P.gval = gval.p; P.coefA = xv.coefA.p; P.coefB = xv.coefB.p;
+        P.hist = rhist.p; P.sel = topk.sel.p; P.sel_cap = (uint32_t)topk.cap; P.kcap = res_kcap; P.rec = rrec.p;
+        return P;
+    }
+    ResMat res_mat() const
+    {
+        ResMat M;
+        M.X = h->X; M.nbp = h->nbp; M.ndw = h->n_pad / 16; M.n = n; M.p = p;
+        M.cache = xv.cache.p; M.slots = (int32_t)xv.slots;
+        M.mu = h->mu; M.sinv = h->sinv; M.center = h->center; M.scale = h->scale;
+        M.miss_ptr = h->miss_ptr; M.miss_row = h->miss_row;
+        return M;
+    }
+    uint64_t res_zkeep_mask() const { uint64_t m = 0; for (int l = 0; l < q; ++l) if (zkeep[l]) m |= 1ull << l; return m; }
+    bool res_fix() const { return h->impute && h->total_missing > 0; }
+    void xv_cache_forget()           // the host's map of the column cache no longer describes it (the device kept the books), or vice versa
+    {
+        xv.slot_of.clear(); std::fill(xv.col_of.begin(), xv.col_of.end(), (int64_t)-1); std::fill(xv.stamp.begin(), xv.stamp.end(), (uint64_t)0); xv.tick = 0;
+    }
+
+    // the host-side iterate -> the device.  next_logl / best: the loglikelihoods fit_iht! carries (fit.jl:163-164)
+    int res_begin(double next_logl, double best, int64_t iter_done, int arm_stop, const mih_fit_params *prm)
+    {
+        if (!res_ok) return MIH_BAD_ARG;
+        // the list iht_stepsize! and _iht_gradstep! work on: b's support; after init_iht_indices! b is still zero and the list is the
+        // support of the projected gradient (utilities.jl:432) -- then those entries ride as explicit zeros of b
+        const bool zero_list = b.idx.empty() && !idx.idx.empty();
+        if (!zero_list && b.idx != idx.idx) return MIH_BAD_ARG;
+        const std::vector<int64_t> &lst = zero_list ? idx.idx : b.idx;
+        const int64_t cnt = (int64_t)lst.size(), cb = (int64_t)best_b.idx.size();
+        if (cnt > res_kcap || cnt > xv.slots || cb > res_kcap) return MIH_BAD_ARG;
+        MIH_HIP(hipStreamSynchronize(s));                    // the pinned staging below may still be read by an earlier upload
+        ResCtl &C = *rctl_h.p;
+        std::memset(&C, 0, sizeof(C));
+        C.live_epoch = res_epoch; C.cur = 0; C.es = 0; C.iter = (int32_t)iter_done;
+        C.arm_stop = arm_stop; C.min_iter = prm->min_iter; C.max_step = prm->max_step; C.tol_stop = prm->tol;
+        C.logl_cur = next_logl; C.best_logl = best;
+        for (int l = 0; l < q; ++l) C.df2[l] = df2[l];
+        C.m[0].cnt = cnt; C.best.cnt = cb;
+        for (int l = 0; l < q; ++l) { C.m[0].c[l] = c[l]; if (idc[l]) C.m[0].idc |= 1ull << l; C.best.c[l] = best_c[l]; }
+        C.nfresh[0] = (int32_t)cnt;                          // the device keeps the cache's books from here: every column is copied in afresh
+        for (int64_t t = 0; t < cnt; ++t) {
+            ridx_h.p[t] = lst[(size_t)t]; rval_h.p[t] = zero_list ? 0.0 : b.val[(size_t)t];
+            rslot_h.p[t] = (int32_t)t; rslot_h.p[2 * res_kcap + t] = (int32_t)t;
+        }
+        for (int64_t t = 0; t < cb; ++t) { ridx_h.p[2 * res_kcap + t] = best_b.idx[(size_t)t]; rval_h.p[2 * res_kcap + t] = best_b.val[(size_t)t]; }
+        MIH_HIP(hipMemcpyAsync(rctl.p, &C, sizeof(C), hipMemcpyHostToDevice, s));
+        if (cnt) {
+            MIH_HIP(hipMemcpyAsync(ridx.p, ridx_h.p, sizeof(int64_t) * cnt, hipMemcpyHostToDevice, s));
+            MIH_HIP(hipMemcpyAsync(rval.p, rval_h.p, sizeof(double) * cnt, hipMemcpyHostToDevice, s));
+            MIH_HIP(hipMemcpyAsync(rslot.p, rslot_h.p, sizeof(int32_t) * cnt, hipMemcpyHostToDevice, s));
+            MIH_HIP(hipMemcpyAsync(rslot.p + 2 * res_kcap, rslot_h.p + 2 * res_kcap, sizeof(int32_t) * cnt, hipMemcpyHostToDevice, s));
+        }
+        if (cb) {
+            MIH_HIP(hipMemcpyAsync(ridx.p + 2 * res_kcap, ridx_h.p + 2 * res_kcap, sizeof(int64_t) * cb, hipMemcpyHostToDevice, s));
+            MIH_HIP(hipMemcpyAsync(rval.p + 2 * res_kcap, rval_h.p + 2 * res_kcap, sizeof(double) * cb, hipMemcpyHostToDevice, s));
+        }
+        res_zero_list = zero_list; res_iter0 = iter_done;
+        res_out.clear();
+        xv_cache_forget(); stage_forget(); spec_ok = false;
+        res_active = true;
+        MIH_TRY(res_enqueue_support());
+        return MIH_OK;
+    }
+    // ... and back: b, c, idc, the list, df on it, df2, the best model; *next_logl / *best as fit_iht! carries them
+    int res_end(double *next_logl, double *best)
+    {
+        if (!res_active) return MIH_OK;
+        res_active = false;
+        res_out.clear();
+        ++res_epoch;                                         // whatever is still queued does nothing
+        {
+            // (a one-word store through the stream: the chain's gate closes in order, behind the kernels that are running)
+            const int32_t e = res_epoch;
+            MIH_HIP(hipMemcpyAsync(&rctl.p->live_epoch, &e, sizeof(e), hipMemcpyHostToDevice, s));
+        }
+        MIH_HIP(hipMemcpyAsync(rctl_h.p, rctl.p, sizeof(ResCtl), hipMemcpyDeviceToHost, s));
+        MIH_HIP(hipMemcpyAsync(ridx_h.p, ridx.p, sizeof(int64_t) * 3 * res_kcap, hipMemcpyDeviceToHost, s));
+        MIH_HIP(hipMemcpyAsync(rval_h.p, rval.p, sizeof(double) * 3 * res_kcap, hipMemcpyDeviceToHost, s));
+        MIH_HIP(hipMemcpyAsync(hpin.p, gval.p, sizeof(double) * std::min<size_t>((size_t)res_kcap, hpin.n), hipMemcpyDeviceToHost, s));
+        MIH_HIP(hipStreamSynchronize(s));
+        const ResCtl &C = *rctl_h.p;
+        const int cur = C.cur;
+        const int64_t cnt = C.m[cur].cnt, cb = C.best.cnt;
+        const int64_t *li = ridx_h.p + (size_t)cur * res_kcap; const double *lv = rval_h.p + (size_t)cur * res_kcap;
+        const bool still_zero = res_zero_list && C.iter == (int32_t)res_iter0 && cur == 0;
+        idx.idx.assign(li, li + cnt);
+        if (still_zero) b.clear();
+        else { b.idx = idx.idx; b.val.assign(lv, lv + cnt); }
+        idx.val.assign(hpin.p, hpin.p + std::min<int64_t>(cnt, (int64_t)hpin.n));
+        idx.val.resize((size_t)cnt, 0.0);
+        for (int l = 0; l < q; ++l) { c[l] = C.m[cur].c[l]; idc[l] = (uint8_t)((C.m[cur].idc >> l) & 1ull); df2[l] = C.df2[l]; best_c[l] = C.best.c[l]; }
+        best_b.idx.assign(ridx_h.p + 2 * res_kcap, ridx_h.p + 2 * res_kcap + cb);
+        best_b.val.assign(rval_h.p + 2 * res_kcap, rval_h.p + 2 * res_kcap + cb);
+        b0 = b; c0 = c; idc0 = idc;
+        if (next_logl) *next_logl = C.logl_cur;
+        if (best) *best = C.best_logl;
+        xv_cache_forget(); stage_forget(); spec_ok = false; df2_pending = false;
+        return MIH_OK;
+    }
+    int64_t res_iter0 = 0;
+
+    int res_enqueue_support()
+    {
+        const ResPtrs P = res_ptrs();
+        hipLaunchKernelGGL(k_res_support, dim3(nblk(res_kcap)), dim3(256), 0, s, P, res_epoch, res_mat(), df.p);
+        return MIH_OK;
+    }
+    // start of a step: the best model so far, X_S df_S, the step-size denominator
+    int res_enqueue_front()
+    {
+        const ResPtrs P = res_ptrs(); const ResMat M = res_mat();
+        if (!res_fix())
+            hipLaunchKernelGGL(k_res_xgk<false>, dim3(nb), dim3(256), 0, s, P, res_epoch, M, z.p, xb.p, zc.p, mu.p, w.p, q, dist, link, nb_r, xgk.p, red.p);
+        else {
+            hipLaunchKernelGGL(k_res_xgk<true>, dim3(nb), dim3(256), 0, s, P, res_epoch, M, z.p, xb.p, zc.p, mu.p, w.p, q, dist, link, nb_r, xgk.p, red.p);
+            hipLaunchKernelGGL(k_res_missing, dim3(1), dim3(1024), 0, s, P, res_epoch, 0, M, xgk.p);
+            hipLaunchKernelGGL(k_res_stepsize, dim3(nb), dim3(256), 0, s, P, res_epoch, xgk.p, z.p, xb.p, zc.p, mu.p, w.p, n, q, dist, link, nb_r, red.p);
+        }
+        return MIH_OK;
+    }
+    // one attempt of the step (the first, or a backtracking one): gradient step, projection, update_xb!, loglikelihood, decision
+    int res_enqueue_attempt(uint64_t seq)
+    {
+        const ResPtrs P = res_ptrs(); const ResMat M = res_mat();
+        const double *wp = has_weight ? weight.p : nullptr;
+        const uint64_t zk = res_zkeep_mask();
+        const int64_t len = p + q, groups = (J == 0) ? 1 : J;
+        hipLaunchKernelGGL(k_res_grad, dim3(kResGradBlocks), dim3(256), 0, s, P, res_epoch, df.p, wp, p, q, zk, red.p, nb, full.p);
+        hipLaunchKernelGGL(k_res_hist2, dim3(kResHistBlocks), dim3(256), 0, s, P, res_epoch, full.p, len, (uint64_t)(k + zkeepn));
+        hipLaunchKernelGGL(k_res_collect, dim3(kResCollectBlocks), dim3(256), 0, s, P, res_epoch, full.p, len);
+        hipLaunchKernelGGL(k_res_select, dim3(1), dim3(1024), 0, s, P, res_epoch, seq, M, wp, p, q, zk, (int)zkeepn, groups * (k + zkeepn));
+        if (!res_fix())
+            hipLaunchKernelGGL(k_res_xb<false>, dim3(nb), dim3(256), 0, s, P, res_epoch, M, z.p, y.p, w.p, q, dist, link, nb_r, xb.p, zc.p, mu.p, red.p);
+        else {
+            hipLaunchKernelGGL(k_res_xb<true>, dim3(nb), dim3(256), 0, s, P, res_epoch, M, z.p, y.p, w.p, q, dist, link, nb_r, xb.p, zc.p, mu.p, red.p);
+            hipLaunchKernelGGL(k_res_missing, dim3(1), dim3(1024), 0, s, P, res_epoch, 1, M, xb.p);
+            hipLaunchKernelGGL(k_res_mu, dim3(nb), dim3(256), 0, s, P, res_epoch, z.p, y.p, w.p, n, q, dist, link, nb_r, xb.p, zc.p, mu.p, red.p);
+        }
+        hipLaunchKernelGGL(k_res_decide, dim3(nb), dim3(256), 0, s, P, res_epoch, seq, red.p, nb, xb.p, zc.p, y.p, mu.p, w.p, n, dist, link, nb_r, r.p);
+        MIH_HIP(hipEventRecord(res_ev[seq % kResRing], s));
+        MIH_HIP(hipGetLastError());
+        return MIH_OK;
+    }
+    // the score that ends the step: Z'r, the gated X'r pass, df on the new support
+    int res_enqueue_back()
+    {
+        const ResPtrs P = res_ptrs();
+        hipLaunchKernelGGL(k_res_zt_r, dim3(kZtrBlocks, q), dim3(256), 0, s, P, res_epoch, z.p, r.p, n, ztr.p, ztr_done.p);
+        xtv.gate = &rctl.p->live_epoch; xtv.gate_val = res_epoch;
+        const int rc = xtv_device(h, xtv, r.p, 1, df.p, s);
+        xtv.gate = nullptr; xtv.gate_val = 0;
+        MIH_TRY(rc);
+        return res_enqueue_support();
+    }
+    int res_wait(uint64_t seq, ResRecord *out)
+    {
+        volatile ResRecord *slot_ = rrec.p + (seq % kResRing);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned it = 0;; ++it) {
+            if (__atomic_load_n(&slot_->seq, __ATOMIC_ACQUIRE) == seq) break;
+            __builtin_ia32_pause();
+            if ((it & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(100)) {
+                MIH_HIP(hipEventSynchronize(res_ev[seq % kResRing]));         // (a pass of tens of ms sits in front: sleep)
+                if (__atomic_load_n(&slot_->seq, __ATOMIC_ACQUIRE) != seq) {
+                    MIH_HIP(hipGetLastError());
+                    set_error("device-resident step %llu left no record", (unsigned long long)seq);
+                    return MIH_HIP_ERROR;
+                }
+                break;
+            }
+        }
+        *out = *const_cast<ResRecord *>(slot_);
+        return MIH_OK;
+    }
+    // One accepted step of the resident chain (the chain itself runs up to two steps ahead of this call, never past rr.limit
+    // steps in all).  *aborted: the device met a case it leaves to the host-driven step (ties for _choose!, lists beyond its
+    // buffers): the iterate is back on the host as it was when that step began, nothing of it has been applied.
+    int res_next(ResRun &rr, ResRecord *rec, bool *aborted)
+    {
+        *aborted = false;
+        for (;;) {
+            while (rr.issued < rr.limit && res_out.size() < 2) {
+                const uint64_t seq = ++res_seq;
+                MIH_TRY(res_enqueue_front()); MIH_TRY(res_enqueue_attempt(seq)); MIH_TRY(res_enqueue_back());
+                res_out.push_back(seq); ++rr.issued;
+            }
+            if (res_out.empty()) { set_error("no device-resident step in flight"); return MIH_BAD_ARG; }
+            const uint64_t seq = res_out.front();
+            res_out.erase(res_out.begin());
+            MIH_TRY(res_wait(seq, rec));
+            switch (rec->status) {
+            case RES_ACCEPT: ++rr.done; return MIH_OK;
+            case RES_BACKTRACK: {            // the chain behind that attempt is dead: queue the next attempt and the rest of the step
+                ++res_epoch; res_out.clear(); rr.issued = rr.done;
+                const uint64_t s2 = ++res_seq;
+                MIH_TRY(res_enqueue_attempt(s2)); MIH_TRY(res_enqueue_back());
+                res_out.push_back(s2); ++rr.issued;
+                break;
+            }
+            case RES_STOP_CONVERGED: ++res_epoch; res_out.clear(); ++rr.done; rr.issued = rr.done; return MIH_OK;
+            case RES_STOP_NAN: case RES_STOP_INF: ++res_epoch; res_out.clear(); ++rr.done; rr.issued = rr.done; return MIH_OK;
+            case RES_ABORT:
+                res_out.clear(); rr.issued = rr.done;      // (res_end moves the epoch on)
+                *aborted = true;
+                return MIH_OK;
+            default: set_error("device-resident step: unknown record status %d", rec->status); return MIH_HIP_ERROR;
+            }
+        }
+    }
+
     // fit_iht! (fit.jl:145-207)
     int fit_loop(const mih_fit_params *prm, double *best_out, int64_t *iter_out, double *lt, double *tt,
                  int32_t *btt, int32_t *ntrace)
     {
         double next_logl = -std::numeric_limits<double>::infinity(), best = next_logl;
         int64_t mm = 0; int32_t nt = 0;
-        for (int iter = 1; iter <= prm->max_iter; ++iter) {
-            if (iter >= prm->max_iter) {             // fit.jl:170: max_iter=N performs N-1 steps
-                best = save_prev(next_logl, best);
-                MIH_TRY(save_best_model());
-                mm = iter;
-                break;
-            }
+        ResRun rr; rr.limit = std::max<int64_t>(0, (int64_t)prm->max_iter - 1);       // fit.jl:170: max_iter = N performs N - 1 steps
+        auto finish = [&](int iter) -> int {
+            if (res_active) MIH_TRY(res_end(&next_logl, &best));
             best = save_prev(next_logl, best);
-            int nbt = 0;
-            MIH_TRY(one_step(next_logl, prm->max_step, &nbt, &next_logl));
-            if (debias && iter >= 5 && b.idx == b0.idx && !b.idx.empty())      // fit.jl:188: v.idx == v.idx0 && debias!(v)
-                MIH_TRY(debias_glm_device(h, b.idx.data(), (int64_t)b.idx.size(), y.p, dist, link, nb_r, b.val.data(), s));
-            double sc = check_convergence();
+            MIH_TRY(save_best_model());
+            mm = iter;
+            return MIH_OK;
+        };
+        for (int iter = 1; iter <= prm->max_iter; ++iter) {
+            if (iter >= prm->max_iter) { MIH_TRY(finish(iter)); break; }
+            int nbt = 0; double sc = 0.0;
+            bool stepped = false;
+            if (res_ok && !res_active) {                 // (first step, or the step after one the device handed back)
+                if (res_begin(next_logl, best, iter - 1, 1, prm) == MIH_OK) rr.issued = rr.done = iter - 1;
+                else res_ok = false;
+            }
+            if (res_active) {
+                ResRecord rec; bool aborted = false;
+                MIH_TRY(res_next(rr, &rec, &aborted));
+                if (aborted) MIH_TRY(res_end(&next_logl, &best));
+                else {
+                    if (rec.status == RES_STOP_NAN || rec.status == RES_STOP_INF) {
+                        MIH_TRY(res_end(nullptr, nullptr));
+                        if (rec.status == RES_STOP_NAN) { set_error("Loglikelihood function is NaN, aborting..."); return MIH_NAN_LOGL; }
+                        set_error("Loglikelihood function is Inf, aborting..."); return MIH_INF_LOGL;
+                    }
+                    next_logl = rec.logl; nbt = rec.nbt; sc = rec.tol; stepped = true;
+                }
+            }
+            if (!stepped) {
+                best = save_prev(next_logl, best);
+                MIH_TRY(one_step(next_logl, prm->max_step, &nbt, &next_logl));
+                if (debias && iter >= 5 && b.idx == b0.idx && !b.idx.empty())      // fit.jl:188: v.idx == v.idx0 && debias!(v)
+                    MIH_TRY(debias_glm_device(h, b.idx.data(), (int64_t)b.idx.size(), y.p, dist, link, nb_r, b.val.data(), s));
+                sc = check_convergence();
+            }
             if (lt) lt[nt] = next_logl;
             if (tt) tt[nt] = sc;
             if (btt) btt[nt] = nbt;
             nt++;
             if (prm->progress) prm->progress(prm->progress_user, iter, next_logl, nbt, sc);
-            if (iter >= prm->min_iter && sc < prm->tol) {
-                best = save_prev(next_logl, best);
-                MIH_TRY(save_best_model());
-                mm = iter;
-                break;
-            }
+            if (iter >= prm->min_iter && sc < prm->tol) { MIH_TRY(finish(iter)); break; }
         }
+        if (res_active) MIH_TRY(res_end(&next_logl, &best));       // (max_iter = 0: no iteration at all)
         *best_out = best; *iter_out = mm;
         if (ntrace) *ntrace = nt;
         return MIH_OK;
@@ -2014,6 +2292,7 @@ struct mih_session_impl {
     IhtVar v;
     mih_fit_params prm;
     double next_logl, best;
+    int64_t steps = 0;                  // iht_one_step! calls so far
 };
 
 int mih_session_create(const mih_mat *h, const mih_fit_params *prm, const double *y, const double *z,
@@ -2033,36 +2312,76 @@ int mih_session_create(const mih_mat *h, const mih_fit_params *prm, const double
     return MIH_OK;
 }
 
+// `nsteps` iht_one_step! calls.  A fit that qualifies keeps its iterate on the device between calls (IhtVar::res_*): the steps of one
+// call are queued back to back, up to two ahead of the records the host reads.  No stopping rule here: the caller decides.
+static int session_steps(mih_session_impl *s, int64_t nsteps, double *logl, int64_t *backtracks, double *tol)
+{
+    IhtVar &v = s->v;
+    int64_t total = 0;
+    IhtVar::ResRun rr;
+    rr.issued = rr.done = s->steps; rr.limit = s->steps + nsteps;
+    double sc = 0.0;
+    for (int64_t t = 0; t < nsteps; ++t) {
+        bool stepped = false;
+        int nbt = 0;
+        if (v.res_ok && !v.res_active) {
+            if (v.res_begin(s->next_logl, s->best, s->steps, 0, &s->prm) == MIH_OK) rr.issued = rr.done = s->steps;
+            else v.res_ok = false;
+        }
+        if (v.res_active) {
+            ResRecord rec; bool aborted = false;
+            MIH_TRY(v.res_next(rr, &rec, &aborted));
+            if (aborted) MIH_TRY(v.res_end(&s->next_logl, &s->best));
+            else {
+                if (rec.status == RES_STOP_NAN || rec.status == RES_STOP_INF) {
+                    MIH_TRY(v.res_end(nullptr, nullptr));
+                    if (rec.status == RES_STOP_NAN) { set_error("Loglikelihood function is NaN, aborting..."); return MIH_NAN_LOGL; }
+                    set_error("Loglikelihood function is Inf, aborting..."); return MIH_INF_LOGL;
+                }
+                s->next_logl = rec.logl; nbt = rec.nbt; sc = rec.tol; stepped = true;
+            }
+        }
+        if (!stepped) {
+            s->best = v.save_prev(s->next_logl, s->best);
+            MIH_TRY(v.one_step(s->next_logl, s->prm.max_step, &nbt, &s->next_logl));
+            sc = v.check_convergence();
+        }
+        ++s->steps;
+        total += nbt;
+    }
+    if (logl) *logl = s->next_logl;
+    if (backtracks) *backtracks = total;
+    if (tol) *tol = sc;
+    return MIH_OK;
+}
+
 int mih_session_step(mih_session *ss, double *logl, int32_t *backtracks, double *tol)
 {
     if (!ss) return MIH_BAD_ARG;
     mih_session_impl *s = reinterpret_cast<mih_session_impl *>(ss);
     MIH_HIP(hipSetDevice(s->v.h->device));
-    s->best = s->v.save_prev(s->next_logl, s->best);
-    int nbt = 0;
-    MIH_TRY(s->v.one_step(s->next_logl, s->prm.max_step, &nbt, &s->next_logl));
-    if (logl) *logl = s->next_logl;
-    if (backtracks) *backtracks = nbt;
-    if (tol) *tol = s->v.check_convergence();
+    int64_t nbt = 0;
+    MIH_TRY(session_steps(s, 1, logl, &nbt, tol));
+    if (backtracks) *backtracks = (int32_t)nbt;
     return MIH_OK;
 }
 
 int mih_session_run(mih_session *ss, int64_t nsteps, double *logl, int64_t *backtracks, double *tol)
 {
-    int64_t total = 0;
-    for (int64_t t = 0; t < nsteps; ++t) {
-        int32_t nbt = 0;
-        MIH_TRY(mih_session_step(ss, logl, &nbt, tol));
-        total += nbt;
-    }
-    if (backtracks) *backtracks = total;
-    return MIH_OK;
+    if (!ss) return MIH_BAD_ARG;
+    mih_session_impl *s = reinterpret_cast<mih_session_impl *>(ss);
+    MIH_HIP(hipSetDevice(s->v.h->device));
+    if (backtracks) *backtracks = 0;
+    if (nsteps <= 0) return MIH_OK;
+    return session_steps(s, nsteps, logl, backtracks, tol);
 }
 
 int mih_session_model(mih_session *ss, double *beta, double *c)
 {
     if (!ss) return MIH_BAD_ARG;
     mih_session_impl *s = reinterpret_cast<mih_session_impl *>(ss);
+    MIH_HIP(hipSetDevice(s->v.h->device));
+    if (s->v.res_active) MIH_TRY(s->v.res_end(&s->next_logl, &s->best));       // the iterate comes home; the next step takes it back
     if (beta) {
         std::memset(beta, 0, sizeof(double) * s->v.p);
         for (size_t t = 0; t < s->v.b.idx.size(); ++t) beta[s->v.b.idx[t]] = s->v.b.val[t];

@@ -96,8 +96,10 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 // writes scal: one launch instead of two; the sums do not depend on which block that is.
 __global__ void __launch_bounds__(256)
 k_r_stats(const double *__restrict__ r, int64_t n, int m, double *__restrict__ part /* [m][gridDim.x][2] */,
-          unsigned *__restrict__ done /* [m], zero */, int ebits, double *__restrict__ scal)
+          unsigned *__restrict__ done /* [m], zero */, int ebits, double *__restrict__ scal,
+          const int32_t *__restrict__ gate, int32_t gate_val)
 {
+    if (gate && *gate != gate_val) return;
     __shared__ double smax[256], ssum[256];
     __shared__ bool last;
     const int v = blockIdx.y;                    // one grid row per residual
@@ -163,6 +165,7 @@ k_digits(const double *__restrict__ r, int64_t n, int64_t nblk, int m, DigitMode
     // bits lane (half, digit) of the fragment carries, and every row ORs its code into its element's place (LDS atomics; round 4 --
     // before, the 2 x slots lanes that own an image gathered it with 32 LDS reads and 64-bit shifts each while the other 44 idled:
     // 60 % of the kernel's time at ten digits).
+    if (dm.gate && *dm.gate != dm.gate_val) return;
     __shared__ uint32_t img[4][2][32][6];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t blk = blockIdx.x * 4ll + w;
@@ -683,6 +686,7 @@ k_xtv_dma(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *__
     static_assert(S * STAGE <= 160 * 1024, "LDS ring too large");
     static_assert(D * L <= 63, "vmcnt range");
     static_assert(S * STAGE >= WAVES * 32 * 36 * 4, "the epilogue buffers overlay the ring");
+    if (dm.gate && *dm.gate != dm.gate_val) return;      // (uniform: one scalar load and a branch in front of everything)
     __shared__ uint4 lds[S * STAGE / 16];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1106,8 +1110,10 @@ k_xtv_finalize(const double *__restrict__ partial, int splits, int64_t pstride, 
                const double *__restrict__ scal, const double *__restrict__ r, int64_t n,
                const double *__restrict__ mu, const double *__restrict__ sinv,
                const int64_t *__restrict__ miss_ptr, const int32_t *__restrict__ miss_row,
-               int center, int scale, int impute, double *__restrict__ out)
+               int center, int scale, int impute, double *__restrict__ out,
+               const int32_t *__restrict__ gate, int32_t gate_val)
 {
+    if (gate && *gate != gate_val) return;
     int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (j >= p) return;
     const double m = mu[j], si = scale ? sinv[j] : 1.0;
@@ -1528,7 +1534,8 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
     const int per_op = dm.per_op;
     const int nops = (m + per_op - 1) / per_op;
     double *part = w.scal.p + w.rhs_cap * 4;
-    hipLaunchKernelGGL(k_r_stats, dim3(kStatBlocks, (unsigned)m), dim3(256), 0, s, r_dev, h->n, m, part, w.stat_done.p, dm.ebits, w.scal.p);
+    dm.gate = w.gate; dm.gate_val = w.gate_val;
+    hipLaunchKernelGGL(k_r_stats, dim3(kStatBlocks, (unsigned)m), dim3(256), 0, s, r_dev, h->n, m, part, w.stat_done.p, dm.ebits, w.scal.p, w.gate, w.gate_val);
     uint4 *dig_all = reinterpret_cast<uint4 *>(w.digits.p);
     uint2 *dig2_all = reinterpret_cast<uint2 *>(w.digits.p + (size_t)w.ops_cap * (size_t)nblk * 64 * 4);   // FP6 only
     FlatPasses fp{};
@@ -1575,7 +1582,7 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
         if (rc) return rc;
         hipLaunchKernelGGL(k_xtv_finalize, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, s,
                            partial, splits, pstride, h->p, u1 - u0, w.scal.p + 4 * u0, r_dev + (int64_t)u0 * h->n, h->n, h->mu, h->sinv,
-                           h->miss_ptr, h->miss_row, h->center, h->scale, h->impute, out_dev + (int64_t)u0 * h->p);
+                           h->miss_ptr, h->miss_row, h->center, h->scale, h->impute, out_dev + (int64_t)u0 * h->p, w.gate, w.gate_val);
     }
     if (dm.flat) { MIH_HIP(hipGetLastError()); return MIH_OK; }
     for (int t = 0; t < nops;) {          // t counts B operands
@@ -1606,7 +1613,7 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
             hipLaunchKernelGGL(k_xtv_finalize, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, s,
                                w.partial.p + (int64_t)u0 * splits * pstride, splits, pstride, h->p, u1 - u0,
                                w.scal.p + 4 * u0, r_dev + (int64_t)u0 * h->n, h->n, h->mu, h->sinv, h->miss_ptr, h->miss_row,
-                               h->center, h->scale, h->impute, out_dev + (int64_t)u0 * h->p);
+                               h->center, h->scale, h->impute, out_dev + (int64_t)u0 * h->p, w.gate, w.gate_val);
         t += nr;
     }
     MIH_HIP(hipGetLastError());

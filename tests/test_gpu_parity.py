@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import FIX, GOLD, ROOT, SweepTally, check_recorded_cv_curve, hash_folds, make_bed, perm_folds
+from conftest import FIX, GOLD, ROOT, SweepTally, check_recorded_cv_curve, hash_folds, make_bed, perm_folds, tied_case
 
 pytestmark = pytest.mark.gpu
 
@@ -2386,6 +2386,93 @@ def test_session_run_is_k_session_steps(mih, normal_pair, normal_data):
         nbt += bt
     lb, btb, tb = b.run(4)
     assert la == lb and ta == tb and nbt == btb
+    (ba, ca), (bb, cb) = a.model(), b.model()
+    assert np.array_equal(ba, bb) and np.array_equal(ca, cb)
+    a.close(); b.close()
+
+
+def _same_fit(a, b, what):
+    assert a.iter == b.iter, (what, a.iter, b.iter)
+    assert list(a.trace["backtracks"]) == list(b.trace["backtracks"]), what
+    assert np.array_equal(np.flatnonzero(a.beta), np.flatnonzero(b.beta)), what
+    # every sum of the resident chain is formed in the host-driven kernels' order; only the scalar log / lgamma of the
+    # loglikelihood's closed form comes from another libm (device against host): the last bit of the trace may differ
+    np.testing.assert_allclose(a.trace["logl"], b.trace["logl"], rtol=4e-16, atol=0, err_msg=what)
+    assert np.array_equal(a.trace["tol"], b.trace["tol"]), what
+    assert np.array_equal(a.beta, b.beta) and np.array_equal(a.c, b.c), what
+    assert np.array_equal(a.mu, b.mu), what
+    assert a.choose_fired == b.choose_fired, what
+
+
+def test_resident_steps_equal_host_driven_steps(mih, oracle, normal_pair, normal_data):
+    """(VERDICT r4 item 1) iht_one_step! resident on the device (mih_fit_params::step_mode = 0: the iterate, the finish of
+    project_k!, the backtracking decision and the stopping rule in device memory, one record per step for the host) against
+    the host-driven step of rounds 1-4 (step_mode = 1): the same iteration log, support, estimates and fitted means -- bit for
+    bit, since every sum is formed in the same order -- over families, covariates with and without zkeep, prior weights,
+    init_beta, imputed missing entries, steps that backtrack, a step budget that runs out, and exact ties (the device hands
+    those steps back: _choose!)."""
+    x, ox = normal_pair
+    y, z, n = normal_data["y"], normal_data["z"], normal_data["n"]
+    rng = np.random.default_rng(4242)
+    cases = []
+    cases.append(("G1 normal + covariates", dict(y=y, x=x, z=z, k=7)))
+    cases.append(("normal k=12 intercept only", dict(y=y, x=x, z=None, k=12)))
+    cases.append(("zkeep = [1, 0]", dict(y=y, x=x, z=z, k=9, zkeep=[1, 0])))
+    cases.append(("zkeep = [0, 0]", dict(y=normal_data["y2"], x=x, z=z, k=9, zkeep=[0, 0])))
+    wts = 0.5 + rng.random(x.p)
+    cases.append(("prior weights", dict(y=y, x=x, z=z, k=8, weight=wts)))
+    cases.append(("init_beta", dict(y=y, x=x, z=z, k=7, init_beta=True)))
+    cases.append(("max_iter = 3", dict(y=y, x=x, z=z, k=7, max_iter=3)))
+    cases.append(("max_iter = 1", dict(y=y, x=x, z=z, k=7, max_iter=1)))
+    cases.append(("min_iter = 9, tight tol", dict(y=y, x=x, z=z, k=7, min_iter=9, tol=1e-9)))
+    eta = _sim(oracle, ox, rng, 8)
+    yb = (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float)
+    cases.append(("bernoulli/logit", dict(y=yb, x=x, z=None, k=8, d=mih.Bernoulli(), l=mih.LogitLink())))
+    cases.append(("bernoulli/probit", dict(y=yb, x=x, z=z, k=6, d=mih.Bernoulli(), l=mih.ProbitLink())))
+    yp = rng.poisson(np.exp(0.3 * eta)).astype(float)
+    cases.append(("poisson/log", dict(y=yp, x=x, z=None, k=8, d=mih.Poisson(), l=mih.LogLink())))
+    cases.append(("poisson/log max_step=1", dict(y=yp, x=x, z=z, k=10, d=mih.Poisson(), l=mih.LogLink(), max_step=1)))
+    ynb = rng.negative_binomial(10, 10 / (np.exp(0.3 * eta) + 10)).astype(float)
+    cases.append(("negbin/log fixed r", dict(y=ynb, x=x, z=None, k=8, d=mih.NegativeBinomial(10.0), l=mih.LogLink())))
+    yg = rng.gamma(2.0, np.exp(0.2 * eta) / 2.0)
+    cases.append(("gamma/log", dict(y=yg, x=x, z=None, k=6, d=mih.Gamma(), l=mih.LogLink())))
+    xm = mih.SnpLinAlg.synthetic(6001, 900, seed=3, missing_rate=0.01)           # imputed entries: the split kernels
+    supp = np.sort(rng.choice(900, 8, replace=False))
+    em = xm.xv_sparse(supp, rng.standard_normal(8) * 0.6)
+    zm = np.column_stack([np.ones(6001), rng.standard_normal(6001)])
+    cases.append(("missing entries, normal", dict(y=em + 0.5 + rng.standard_normal(6001), x=xm, z=zm, k=8)))
+    cases.append(("missing entries, bernoulli", dict(y=(rng.random(6001) < 1 / (1 + np.exp(-em))).astype(float), x=xm, z=zm, k=6,
+                                                     d=mih.Bernoulli(), l=mih.LogitLink())))
+    cols, yt, tied = tied_case()
+    xt = mih.SnpLinAlg(cols, n=1000, center=True, scale=True, impute=True)
+    cases.append(("exact ties: _choose!", dict(y=yt, x=xt, z=None, k=2)))
+    nbt_seen = 0
+    for what, kw in cases:
+        kw = dict(kw)
+        yy, xx, zz = kw.pop("y"), kw.pop("x"), kw.pop("z")
+        a = mih.fit_iht(yy, xx, zz, verbose=False, step_mode=0, **kw)
+        b = mih.fit_iht(yy, xx, zz, verbose=False, step_mode=1, **kw)
+        _same_fit(a, b, what)
+        nbt_seen += int(np.sum(a.trace["backtracks"]))
+    assert nbt_seen > 0                       # some of those steps backtracked: the re-queued attempts were exercised
+    assert mih.fit_iht(yt, xt, None, k=2, verbose=False, step_mode=0).choose_fired
+
+
+def test_resident_session_keeps_the_iterate_on_the_device(mih, normal_pair, normal_data):
+    """mih_session_step / _run / _model with the iterate resident on the device: single steps, a run of steps, the model read in
+    between (the iterate comes home and goes back) -- all equal to the host-driven session, step for step."""
+    x, _ = normal_pair
+    y, z = normal_data["y"], normal_data["z"]
+    a = mih.IHTSession(y, x, z, k=9, step_mode=0)
+    b = mih.IHTSession(y, x, z, k=9, step_mode=1)
+    for _ in range(2):
+        assert a.step() == b.step()
+    (ba, ca), (bb, cb) = a.model(), b.model()
+    assert np.array_equal(ba, bb) and np.array_equal(ca, cb)
+    la, bta, ta = a.run(5)
+    lb, btb, tb = b.run(5)
+    assert abs(la - lb) <= 4e-16 * abs(lb) and bta == btb and ta == tb
+    assert a.step()[1:] == b.step()[1:]
     (ba, ca), (bb, cb) = a.model(), b.model()
     assert np.array_equal(ba, bb) and np.array_equal(ca, cb)
     a.close(); b.close()
