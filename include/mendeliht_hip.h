@@ -361,7 +361,10 @@ enum { MIH_CNT_LANES = 0,          /* lock-step lanes started (summed over calls
        MIH_CNT_SCORES = 6,         /* residual scores that END A STEP (= IHT iterations as fit.jl counts them) of those fits */
        MIH_CNT_MAX_LANE_SLOTS = 7, /* most fits in flight on ONE lane */
        MIH_CNT_INIT_SCORES = 8,    /* initial scores (init_iht_indices!, one per fit): rode a pass or were served by a copy */
-       MIH_PROFILE_NCOUNTERS = 9 };
+       MIH_CNT_RESIDENT_STEPS = 9, /* iht_one_step! calls that ran resident on the device (step_mode 0; single fits and sessions) */
+       MIH_CNT_RESIDENT_ATTEMPTS = 10, /* backtracking attempts the host re-queued for them */
+       MIH_CNT_RESIDENT_HANDBACKS = 11, /* steps the device handed back to the host-driven path (_choose! ties, lists beyond its buffers) */
+       MIH_PROFILE_NCOUNTERS = 12 };
 int mih_profile_enable(const mih_mat *h, int on);
 /* synchronises the recorded launches; totals since the last reset */
 int mih_profile_read(const mih_mat *h, double *xtv_kernel_ms, int64_t *xtv_launches, int reset);

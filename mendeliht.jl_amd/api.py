@@ -114,7 +114,8 @@ class _PassRecord(C.Structure):
                 ("stream_tag", C.c_int32), ("reserved", C.c_int32), ("kernel", C.c_char * 48)]
 
 
-PROFILE_COUNTERS = ("lanes", "max_in_flight", "handovers", "shared_init", "rounds", "fits", "scores", "max_lane_slots", "init_scores")
+PROFILE_COUNTERS = ("lanes", "max_in_flight", "handovers", "shared_init", "rounds", "fits", "scores", "max_lane_slots", "init_scores",
+                    "resident_steps", "resident_attempts", "resident_handbacks")
 
 _PROGRESS = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double)
 

@@ -394,6 +394,7 @@ struct XtvWork {            // scratch for one in-flight X'r
     XtvTune tune;              // fixed at init
     int stream_tag = 0;        // which lock-step lane launches on this workspace (profile records)
     const int32_t *gate = nullptr; int32_t gate_val = 0;   // see DigitMode::gate; set by the caller around one xtv_device call
+    bool stats_done = false;   // ... whose residual statistics (scal) the caller has computed already (k_res_stats, fit.hip)
 };
 // batched = false: the workspace of a single univariate fit (one residual per pass); true: fused multi-RHS passes
 int  xtv_work_init(const mih_mat *h, XtvWork &w, int m, const XtvTune &tune, bool batched = true);

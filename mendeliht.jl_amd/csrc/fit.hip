@@ -518,7 +518,8 @@ struct IhtVar {
                          + sizeof(uint32_t) * 2048 + 64 + 16 * ((size_t)kcap + 1025)
                          + (prm->weight ? sizeof(double) * (size_t)p : 0) + (prm->group ? sizeof(int64_t) * ((size_t)p + ks.size() + 1) : 0)
                          + 48 * 256
-                         + sizeof(ResCtl) + (size_t)kcap * (3 * 16 + 4 * 4) + 4096 * sizeof(uint32_t) + 8 * 256;       // resident steps
+                         + sizeof(ResCtl) + (size_t)kcap * (3 * 16 + 4 * 4) + 4096 * sizeof(uint32_t) + 8 * 256       // resident steps
+                         + sizeof(uint64_t) * (size_t)kResCollectBlocks * (1 + 2 * kResCollectSlots);
             size_t pin = sizeof(uint64_t) * (HostStage::kSlots * (2 * (size_t)kcap + 8) + ((size_t)kcap + kMaxQ + 16) + 2 + 2 * ((size_t)kcap + 64) + 16) + 8 * 256
                          + sizeof(ResCtl) + kResRing * sizeof(ResRecord) + (size_t)kcap * (3 * 16 + 4 * 4) + 8 * 256;
             MIH_TRY(arena.reserve(dev, pin));
@@ -1360,10 +1361,10 @@ struct IhtVar {
     bool res_ok = false, res_active = false, res_zero_list = false;
     int res_epoch = 0; uint64_t res_seq = 0; int64_t res_kcap = 0;
     std::vector<uint64_t> res_out;                       // sequence numbers of the steps in flight, oldest first
-    DevBuf<ResCtl> rctl; DevBuf<int64_t> ridx; DevBuf<double> rval; DevBuf<int32_t> rslot; DevBuf<uint32_t> rhist;
+    DevBuf<ResCtl> rctl; DevBuf<int64_t> ridx; DevBuf<double> rval; DevBuf<int32_t> rslot; DevBuf<uint32_t> rhist; DevBuf<uint64_t> rsel;
     PinBuf<ResCtl> rctl_h; PinBuf<ResRecord> rrec; PinBuf<int64_t> ridx_h; PinBuf<double> rval_h; PinBuf<int32_t> rslot_h;
     hipEvent_t res_ev[kResRing] = {nullptr};
-    struct ResRun { int64_t limit = 0, issued = 0, done = 0; };
+    struct ResRun { int64_t limit = 0, issued = 0, done = 0; int max_step = 3; };
 
     int res_setup(const mih_fit_params *prm, int64_t kcap)
     {
@@ -1375,6 +1376,7 @@ struct IhtVar {
         res_kcap = std::min<int64_t>(kcap, (int64_t)xv.coefA.n);
         MIH_TRY(rctl.alloc(1)); MIH_TRY(ridx.alloc((size_t)res_kcap * 3)); MIH_TRY(rval.alloc((size_t)res_kcap * 3));
         MIH_TRY(rslot.alloc((size_t)res_kcap * 4)); MIH_TRY(rhist.alloc(4096));
+        MIH_TRY(rsel.alloc((size_t)kResCollectBlocks * (1 + 2 * kResCollectSlots)));
         MIH_TRY(rctl_h.alloc(1, true)); MIH_TRY(rrec.alloc(kResRing, true));
         MIH_TRY(ridx_h.alloc((size_t)res_kcap * 3, true)); MIH_TRY(rval_h.alloc((size_t)res_kcap * 3, true)); MIH_TRY(rslot_h.alloc((size_t)res_kcap * 4, true));
         MIH_HIP(hipMemsetAsync(rhist.p, 0, sizeof(uint32_t) * 4096, s));
@@ -1390,7 +1392,7 @@ struct IhtVar {
         for (int i = 0; i < 3; ++i) { P.idx[i] = ridx.p + (size_t)i * res_kcap; P.val[i] = rval.p + (size_t)i * res_kcap; }
         for (int i = 0; i < 2; ++i) { P.slot[i] = rslot.p + (size_t)i * res_kcap; P.fresh[i] = rslot.p + (size_t)(2 + i) * res_kcap; }
         P.gval = gval.p; P.coefA = xv.coefA.p; P.coefB = xv.coefB.p;
-        P.hist = rhist.p; P.sel = topk.sel.p; P.sel_cap = (uint32_t)topk.cap; P.kcap = res_kcap; P.rec = rrec.p;
+        P.hist = rhist.p; P.sel = rsel.p; P.sel_cap = 0; P.kcap = res_kcap; P.rec = rrec.p;
         return P;
     }
     ResMat res_mat() const
@@ -1458,6 +1460,7 @@ struct IhtVar {
     {
         if (!res_active) return MIH_OK;
         res_active = false;
+        res_dead_passes((int)res_out.size());                // (steps queued ahead of the last record read: not to be run)
         res_out.clear();
         ++res_epoch;                                         // whatever is still queued does nothing
         {
@@ -1490,6 +1493,19 @@ struct IhtVar {
         return MIH_OK;
     }
     int64_t res_iter0 = 0;
+    // the X'r passes of the last `count` step chains were queued behind a kernel that closed the gate: they did nothing, and their
+    // profile records (mih_profile_passes) go
+    void res_dead_passes(int count)
+    {
+        Profile &pf = *h->prof;
+        if (!pf.on || count <= 0) return;
+        std::lock_guard<std::mutex> g(pf.mu);
+        for (; count > 0 && !pf.open.empty(); --count) {
+            PassRecord &r = pf.open.back();
+            (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
+            pf.open.pop_back();
+        }
+    }
 
     int res_enqueue_support()
     {
@@ -1505,42 +1521,54 @@ struct IhtVar {
             hipLaunchKernelGGL(k_res_xgk<false>, dim3(nb), dim3(256), 0, s, P, res_epoch, M, z.p, xb.p, zc.p, mu.p, w.p, q, dist, link, nb_r, xgk.p, red.p);
         else {
             hipLaunchKernelGGL(k_res_xgk<true>, dim3(nb), dim3(256), 0, s, P, res_epoch, M, z.p, xb.p, zc.p, mu.p, w.p, q, dist, link, nb_r, xgk.p, red.p);
-            hipLaunchKernelGGL(k_res_missing, dim3(1), dim3(1024), 0, s, P, res_epoch, 0, M, xgk.p);
+            hipLaunchKernelGGL(k_res_missing, dim3(1), dim3(1024), 0, s, P, res_epoch, -1, 0, M, xgk.p);
             hipLaunchKernelGGL(k_res_stepsize, dim3(nb), dim3(256), 0, s, P, res_epoch, xgk.p, z.p, xb.p, zc.p, mu.p, w.p, n, q, dist, link, nb_r, red.p);
         }
+        hipLaunchKernelGGL(k_res_eta, dim3(1), dim3(256), 0, s, P, res_epoch, red.p, nb, q);
         return MIH_OK;
     }
-    // one attempt of the step (the first, or a backtracking one): gradient step, projection, update_xb!, loglikelihood, decision
-    int res_enqueue_attempt(uint64_t seq)
+    // one attempt of the step (attempt 0: the first, a >= 1: the a-th backtracking one): gradient step, projection, update_xb!,
+    // loglikelihood, decision.  more: the kernels of attempt a + 1 are queued right behind (a forecast; they run only if needed)
+    int res_enqueue_attempt(uint64_t seq, int a, bool more)
     {
         const ResPtrs P = res_ptrs(); const ResMat M = res_mat();
         const double *wp = has_weight ? weight.p : nullptr;
         const uint64_t zk = res_zkeep_mask();
         const int64_t len = p + q, groups = (J == 0) ? 1 : J;
-        hipLaunchKernelGGL(k_res_grad, dim3(kResGradBlocks), dim3(256), 0, s, P, res_epoch, df.p, wp, p, q, zk, red.p, nb, full.p);
-        hipLaunchKernelGGL(k_res_hist2, dim3(kResHistBlocks), dim3(256), 0, s, P, res_epoch, full.p, len, (uint64_t)(k + zkeepn));
-        hipLaunchKernelGGL(k_res_collect, dim3(kResCollectBlocks), dim3(256), 0, s, P, res_epoch, full.p, len);
-        hipLaunchKernelGGL(k_res_select, dim3(1), dim3(1024), 0, s, P, res_epoch, seq, M, wp, p, q, zk, (int)zkeepn, groups * (k + zkeepn));
+        hipLaunchKernelGGL(k_res_grad, dim3(kResGradBlocks), dim3(256), 0, s, P, res_epoch, a, df.p, wp, p, q, zk, full.p);
+        hipLaunchKernelGGL(k_res_hist2, dim3(kResHistBlocks), dim3(256), 0, s, P, res_epoch, a, full.p, len, (uint64_t)(k + zkeepn));
+        hipLaunchKernelGGL(k_res_collect, dim3(kResCollectBlocks), dim3(256), 0, s, P, res_epoch, a, full.p, len);
+        hipLaunchKernelGGL(k_res_select, dim3(1), dim3(1024), 0, s, P, res_epoch, a, seq, M, wp, p, q, zk, (int)zkeepn, groups * (k + zkeepn));
         if (!res_fix())
-            hipLaunchKernelGGL(k_res_xb<false>, dim3(nb), dim3(256), 0, s, P, res_epoch, M, z.p, y.p, w.p, q, dist, link, nb_r, xb.p, zc.p, mu.p, red.p);
+            hipLaunchKernelGGL(k_res_xb<false>, dim3(nb), dim3(256), 0, s, P, res_epoch, a, M, z.p, y.p, w.p, q, dist, link, nb_r, xb.p, zc.p, mu.p, red.p);
         else {
-            hipLaunchKernelGGL(k_res_xb<true>, dim3(nb), dim3(256), 0, s, P, res_epoch, M, z.p, y.p, w.p, q, dist, link, nb_r, xb.p, zc.p, mu.p, red.p);
-            hipLaunchKernelGGL(k_res_missing, dim3(1), dim3(1024), 0, s, P, res_epoch, 1, M, xb.p);
-            hipLaunchKernelGGL(k_res_mu, dim3(nb), dim3(256), 0, s, P, res_epoch, z.p, y.p, w.p, n, q, dist, link, nb_r, xb.p, zc.p, mu.p, red.p);
+            hipLaunchKernelGGL(k_res_xb<true>, dim3(nb), dim3(256), 0, s, P, res_epoch, a, M, z.p, y.p, w.p, q, dist, link, nb_r, xb.p, zc.p, mu.p, red.p);
+            hipLaunchKernelGGL(k_res_missing, dim3(1), dim3(1024), 0, s, P, res_epoch, a, 1, M, xb.p);
+            hipLaunchKernelGGL(k_res_mu, dim3(nb), dim3(256), 0, s, P, res_epoch, a, z.p, y.p, w.p, n, q, dist, link, nb_r, xb.p, zc.p, mu.p, red.p);
         }
-        hipLaunchKernelGGL(k_res_decide, dim3(nb), dim3(256), 0, s, P, res_epoch, seq, red.p, nb, xb.p, zc.p, y.p, mu.p, w.p, n, dist, link, nb_r, r.p);
-        MIH_HIP(hipEventRecord(res_ev[seq % kResRing], s));
+        hipLaunchKernelGGL(k_res_decide, dim3(1), dim3(256), 0, s, P, res_epoch, a, more ? 1 : 0, seq, red.p, nb, n, dist);
+        if (!more) MIH_HIP(hipEventRecord(res_ev[seq % kResRing], s));
         MIH_HIP(hipGetLastError());
+        return MIH_OK;
+    }
+    // attempts a0 .. a0 + res_spec of a step (res_spec: how many backtracks the last step needed, the forecast for this one)
+    int res_spec = 0;
+    int res_enqueue_attempts(uint64_t seq, int a0, int max_step)
+    {
+        const int last = std::min(max_step, a0 + res_spec);          // (attempt max_step always stands: utilities.jl:484)
+        for (int a = a0; a <= last; ++a) MIH_TRY(res_enqueue_attempt(seq, a, a < last));
         return MIH_OK;
     }
     // the score that ends the step: Z'r, the gated X'r pass, df on the new support
     int res_enqueue_back()
     {
         const ResPtrs P = res_ptrs();
-        hipLaunchKernelGGL(k_res_zt_r, dim3(kZtrBlocks, q), dim3(256), 0, s, P, res_epoch, z.p, r.p, n, ztr.p, ztr_done.p);
-        xtv.gate = &rctl.p->live_epoch; xtv.gate_val = res_epoch;
+        hipLaunchKernelGGL(k_res_resid, dim3(nb), dim3(256), 0, s, P, res_epoch, xb.p, zc.p, y.p, mu.p, w.p, n, dist, link, nb_r, r.p);
+        hipLaunchKernelGGL(k_res_stats, dim3(kZtrBlocks, q + 1), dim3(256), 0, s, P, res_epoch, z.p, r.p, n, q, ztr.p, ztr_done.p,
+                           xtv.scal.p + xtv.rhs_cap * 4, xtv.stat_done.p, xtv.dm.ebits, xtv.scal.p);
+        xtv.gate = &rctl.p->live_epoch; xtv.gate_val = res_epoch; xtv.stats_done = true;
         const int rc = xtv_device(h, xtv, r.p, 1, df.p, s);
-        xtv.gate = nullptr; xtv.gate_val = 0;
+        xtv.gate = nullptr; xtv.gate_val = 0; xtv.stats_done = false;
         MIH_TRY(rc);
         return res_enqueue_support();
     }
@@ -1573,7 +1601,7 @@ struct IhtVar {
         for (;;) {
             while (rr.issued < rr.limit && res_out.size() < 2) {
                 const uint64_t seq = ++res_seq;
-                MIH_TRY(res_enqueue_front()); MIH_TRY(res_enqueue_attempt(seq)); MIH_TRY(res_enqueue_back());
+                MIH_TRY(res_enqueue_front()); MIH_TRY(res_enqueue_attempts(seq, 0, rr.max_step)); MIH_TRY(res_enqueue_back());
                 res_out.push_back(seq); ++rr.issued;
             }
             if (res_out.empty()) { set_error("no device-resident step in flight"); return MIH_BAD_ARG; }
@@ -1581,18 +1609,22 @@ struct IhtVar {
             res_out.erase(res_out.begin());
             MIH_TRY(res_wait(seq, rec));
             switch (rec->status) {
-            case RES_ACCEPT: ++rr.done; return MIH_OK;
+            case RES_ACCEPT: ++rr.done; res_spec = rec->nbt; h->prof->count(MIH_CNT_RESIDENT_STEPS, 1); return MIH_OK;
             case RES_BACKTRACK: {            // the chain behind that attempt is dead: queue the next attempt and the rest of the step
+                res_dead_passes(1 + (int)res_out.size());
                 ++res_epoch; res_out.clear(); rr.issued = rr.done;
+                h->prof->count(MIH_CNT_RESIDENT_ATTEMPTS, 1);
                 const uint64_t s2 = ++res_seq;
-                MIH_TRY(res_enqueue_attempt(s2)); MIH_TRY(res_enqueue_back());
+                MIH_TRY(res_enqueue_attempts(s2, rec->nbt, rr.max_step)); MIH_TRY(res_enqueue_back());
                 res_out.push_back(s2); ++rr.issued;
                 break;
             }
-            case RES_STOP_CONVERGED: ++res_epoch; res_out.clear(); ++rr.done; rr.issued = rr.done; return MIH_OK;
-            case RES_STOP_NAN: case RES_STOP_INF: ++res_epoch; res_out.clear(); ++rr.done; rr.issued = rr.done; return MIH_OK;
+            case RES_STOP_CONVERGED: res_dead_passes(1 + (int)res_out.size()); ++res_epoch; res_out.clear(); ++rr.done; rr.issued = rr.done; h->prof->count(MIH_CNT_RESIDENT_STEPS, 1); return MIH_OK;
+            case RES_STOP_NAN: case RES_STOP_INF: res_dead_passes(1 + (int)res_out.size()); ++res_epoch; res_out.clear(); ++rr.done; rr.issued = rr.done; return MIH_OK;
             case RES_ABORT:
+                res_dead_passes(1 + (int)res_out.size());
                 res_out.clear(); rr.issued = rr.done;      // (res_end moves the epoch on)
+                h->prof->count(MIH_CNT_RESIDENT_HANDBACKS, 1);
                 *aborted = true;
                 return MIH_OK;
             default: set_error("device-resident step: unknown record status %d", rec->status); return MIH_HIP_ERROR;
@@ -1606,7 +1638,7 @@ struct IhtVar {
     {
         double next_logl = -std::numeric_limits<double>::infinity(), best = next_logl;
         int64_t mm = 0; int32_t nt = 0;
-        ResRun rr; rr.limit = std::max<int64_t>(0, (int64_t)prm->max_iter - 1);       // fit.jl:170: max_iter = N performs N - 1 steps
+        ResRun rr; rr.limit = std::max<int64_t>(0, (int64_t)prm->max_iter - 1); rr.max_step = prm->max_step;       // fit.jl:170: max_iter = N performs N - 1 steps
         auto finish = [&](int iter) -> int {
             if (res_active) MIH_TRY(res_end(&next_logl, &best));
             best = save_prev(next_logl, best);
@@ -2319,7 +2351,7 @@ static int session_steps(mih_session_impl *s, int64_t nsteps, double *logl, int6
     IhtVar &v = s->v;
     int64_t total = 0;
     IhtVar::ResRun rr;
-    rr.issued = rr.done = s->steps; rr.limit = s->steps + nsteps;
+    rr.issued = rr.done = s->steps; rr.limit = s->steps + nsteps; rr.max_step = s->prm.max_step;
     double sc = 0.0;
     for (int64_t t = 0; t < nsteps; ++t) {
         bool stepped = false;

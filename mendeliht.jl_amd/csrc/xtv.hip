@@ -1535,7 +1535,8 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
     const int nops = (m + per_op - 1) / per_op;
     double *part = w.scal.p + w.rhs_cap * 4;
     dm.gate = w.gate; dm.gate_val = w.gate_val;
-    hipLaunchKernelGGL(k_r_stats, dim3(kStatBlocks, (unsigned)m), dim3(256), 0, s, r_dev, h->n, m, part, w.stat_done.p, dm.ebits, w.scal.p, w.gate, w.gate_val);
+    if (!w.stats_done)
+        hipLaunchKernelGGL(k_r_stats, dim3(kStatBlocks, (unsigned)m), dim3(256), 0, s, r_dev, h->n, m, part, w.stat_done.p, dm.ebits, w.scal.p, w.gate, w.gate_val);
     uint4 *dig_all = reinterpret_cast<uint4 *>(w.digits.p);
     uint2 *dig2_all = reinterpret_cast<uint2 *>(w.digits.p + (size_t)w.ops_cap * (size_t)nblk * 64 * 4);   // FP6 only
     FlatPasses fp{};

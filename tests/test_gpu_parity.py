@@ -2108,8 +2108,8 @@ def test_xtv_fixed_point_under_adversarial_dynamic_range(mih, shape):
                 rel = err[~with_out] / np.abs(ex[~with_out])
                 assert rel.max() <= 1e-6, (mode, rel.max())          # inside north_star's 1e-4 / 1e-5 on beta ...
                 if mode != 1316:                                     # (1316 carries 3 more bits)
-                    assert rel.max() >= 1e-12, (mode, rel.max())     # ... but NOT f64-grade: numpy keeps ~1e-16 here
-                assert np.all(err_np[~with_out] <= 2.0 ** -48 * np.abs(ex[~with_out]))
+                    assert rel.max() >= 1e-12, (mode, rel.max())     # ... but NOT f64-grade: numpy's pairwise sum stays within a few
+                assert np.all(err_np[~with_out] <= 8 * 2.0 ** -53 * (g * np.abs(r)).sum(axis=1)[~with_out])   # ulps of sum|g r| there
             else:
                 ulp_sums = 2.0 ** -53 * (g * np.abs(r)).sum(axis=1)
                 assert np.all(err <= 8 * ulp_sums), (mode, float((err / ulp_sums).max()))
@@ -2134,7 +2134,10 @@ def test_poisson_fit_with_a_planted_count_outlier(mih, oracle, normal_pair):
         assert list(res.trace["backtracks"]) == list(o["bt_trace"])
         assert np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"]))
         np.testing.assert_allclose(res.beta, o["beta"], rtol=1e-4, atol=1e-12)
-        np.testing.assert_allclose(res.trace["logl"], o["logl_trace"], rtol=1e-9)
+        # the first iterates of this fit are wild (loglikelihoods of -4e9 while the outlier's mean sits at the +-20 clamp) and the fit
+        # creeps to its optimum (it ends on max_iter): the 2^-45 relative rounding the outlier leaves X'r with shows as 5e-8 in the
+        # loglikelihood trace (measured), three orders inside north_star's 1e-4 on beta -- but not the 1e-12 of a tame residual
+        np.testing.assert_allclose(res.trace["logl"], o["logl_trace"], rtol=1e-6)
 
 
 def test_fits_and_cv_at_full_row_count(mih, oracle):
@@ -2446,15 +2449,32 @@ def test_resident_steps_equal_host_driven_steps(mih, oracle, normal_pair, normal
     cols, yt, tied = tied_case()
     xt = mih.SnpLinAlg(cols, n=1000, center=True, scale=True, impute=True)
     cases.append(("exact ties: _choose!", dict(y=yt, x=xt, z=None, k=2)))
-    nbt_seen = 0
+    nbt_seen, tally = 0, dict(resident_steps=0, resident_attempts=0, resident_handbacks=0)
     for what, kw in cases:
         kw = dict(kw)
         yy, xx, zz = kw.pop("y"), kw.pop("x"), kw.pop("z")
+        mih.profile_enable(xx, True)
+        mih.profile_counters(xx, reset=True)
         a = mih.fit_iht(yy, xx, zz, verbose=False, step_mode=0, **kw)
+        cnt = mih.profile_counters(xx, reset=True)
         b = mih.fit_iht(yy, xx, zz, verbose=False, step_mode=1, **kw)
+        host = mih.profile_counters(xx, reset=True)
+        mih.profile_enable(xx, False)
         _same_fit(a, b, what)
         nbt_seen += int(np.sum(a.trace["backtracks"]))
-    assert nbt_seen > 0                       # some of those steps backtracked: the re-queued attempts were exercised
+        # the steps of the step_mode = 0 fit really ran on the device (all but those it handed back), none of the other fit's did
+        steps = len(a.trace["logl"])
+        assert cnt["resident_steps"] + cnt["resident_handbacks"] == steps, (what, cnt, steps)
+        assert cnt["resident_attempts"] <= int(np.sum(a.trace["backtracks"])), (what, cnt)
+        assert host["resident_steps"] == 0 and host["resident_handbacks"] == 0, (what, host)
+        if "ties" in what:
+            assert cnt["resident_handbacks"] >= 1, (what, cnt)
+        else:
+            assert cnt["resident_handbacks"] == 0, (what, cnt)       # (attempts the forecast had queued in advance are not counted)
+        for key in tally:
+            tally[key] += cnt[key]
+    assert nbt_seen > 0 and tally["resident_attempts"] > 0        # some of those steps backtracked: the re-queued attempts were exercised
+    assert tally["resident_steps"] > 60, tally
     assert mih.fit_iht(yt, xt, None, k=2, verbose=False, step_mode=0).choose_fired
 
 
