@@ -364,7 +364,9 @@ enum { MIH_CNT_LANES = 0,          /* lock-step lanes started (summed over calls
        MIH_CNT_RESIDENT_STEPS = 9, /* iht_one_step! calls that ran resident on the device (step_mode 0; single fits and sessions) */
        MIH_CNT_RESIDENT_ATTEMPTS = 10, /* backtracking attempts the host re-queued for them */
        MIH_CNT_RESIDENT_HANDBACKS = 11, /* steps the device handed back to the host-driven path (_choose! ties, lists beyond its buffers) */
-       MIH_PROFILE_NCOUNTERS = 12 };
+       MIH_CNT_RESIDENT_DIRECT = 12, /* attempts whose projection was queued as a direct gather (threshold forecast, verified) */
+       MIH_CNT_RESIDENT_REDOS = 13,  /* ... of which the forecast failed: re-queued with the two histogram sweeps */
+       MIH_PROFILE_NCOUNTERS = 14 };
 int mih_profile_enable(const mih_mat *h, int on);
 /* synchronises the recorded launches; totals since the last reset */
 int mih_profile_read(const mih_mat *h, double *xtv_kernel_ms, int64_t *xtv_launches, int reset);

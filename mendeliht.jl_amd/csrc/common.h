@@ -382,6 +382,22 @@ XtvTune xtv_tune(int digits);
 inline XtvTune xtv_tune(const mih_fit_params *prm) { return xtv_tune(prm ? prm->xtv_digits : 0); }
 bool xtv_digits_valid(int digits);
 
+// Device-resident steps (fit.hip): the finalize kernel of a single-residual pass also leaves df on the support of the current iterate
+// and k_xv_coef's coefficients of X_S df_S (iht_stepsize!) -- extra workgroups that redo the finalize arithmetic of those columns.
+struct XtvSupportHook {
+    const int32_t *cur = nullptr;                 // which of the two lists is the current iterate's (nullptr: no hook)
+    const int64_t *idx[2] = {nullptr, nullptr};
+    const int64_t *cnt[2] = {nullptr, nullptr};   // the lists' lengths, in device memory
+    double *gval = nullptr, *A = nullptr, *B = nullptr;
+    int blocks = 0;                               // extra workgroups of 256 entries
+};
+// ... and the digit kernel finishes the residual statistics (the second stage of k_r_stats over its 64 block partials) and Z'r (the
+// second stage of k_zt_r over 128 block partials per covariate) that k_res_stats left as partials
+struct XtvStatsHook {
+    const double *spart = nullptr;                // [64][2] max |r|, sum r per block (nullptr: no hook)
+    const double *zpart = nullptr; double *df2 = nullptr; int q = 0, zblocks = 0;
+    int ebits = 0;
+};
 struct XtvWork {            // scratch for one in-flight X'r
     DevBuf<uint32_t> digits;   // ops * nblk * 64 lanes * 4 dwords (+ 2 dwords, stored behind, for FP6) : digit planes of r (B operands)
     DevBuf<double>   partial;  // splits * rhs * ncg*32 raw dots
@@ -395,6 +411,8 @@ struct XtvWork {            // scratch for one in-flight X'r
     int stream_tag = 0;        // which lock-step lane launches on this workspace (profile records)
     const int32_t *gate = nullptr; int32_t gate_val = 0;   // see DigitMode::gate; set by the caller around one xtv_device call
     bool stats_done = false;   // ... whose residual statistics (scal) the caller has computed already (k_res_stats, fit.hip)
+    XtvSupportHook hook;       // ... and whose finalize kernel also serves the support of the iterate
+    XtvStatsHook shook;        // ... and whose digit kernel finishes those statistics
 };
 // batched = false: the workspace of a single univariate fit (one residual per pass); true: fused multi-RHS passes
 int  xtv_work_init(const mih_mat *h, XtvWork &w, int m, const XtvTune &tune, bool batched = true);

@@ -574,7 +574,6 @@ struct IhtVar {
     ~IhtVar()
     {
         if (s) (void)hipStreamSynchronize(s);
-        for (int i = 0; i < kResRing; ++i) if (res_ev[i]) (void)hipEventDestroy(res_ev[i]);
         if (s && own_stream) (void)hipStreamDestroy(s);
         if (ev) (void)hipEventDestroy(ev);
     }
@@ -1363,7 +1362,6 @@ struct IhtVar {
     std::vector<uint64_t> res_out;                       // sequence numbers of the steps in flight, oldest first
     DevBuf<ResCtl> rctl; DevBuf<int64_t> ridx; DevBuf<double> rval; DevBuf<int32_t> rslot; DevBuf<uint32_t> rhist; DevBuf<uint64_t> rsel;
     PinBuf<ResCtl> rctl_h; PinBuf<ResRecord> rrec; PinBuf<int64_t> ridx_h; PinBuf<double> rval_h; PinBuf<int32_t> rslot_h;
-    hipEvent_t res_ev[kResRing] = {nullptr};
     struct ResRun { int64_t limit = 0, issued = 0, done = 0; int max_step = 3; };
 
     int res_setup(const mih_fit_params *prm, int64_t kcap)
@@ -1381,7 +1379,6 @@ struct IhtVar {
         MIH_TRY(ridx_h.alloc((size_t)res_kcap * 3, true)); MIH_TRY(rval_h.alloc((size_t)res_kcap * 3, true)); MIH_TRY(rslot_h.alloc((size_t)res_kcap * 4, true));
         MIH_HIP(hipMemsetAsync(rhist.p, 0, sizeof(uint32_t) * 4096, s));
         std::memset(rrec.p, 0, sizeof(ResRecord) * kResRing);
-        for (int i = 0; i < kResRing; ++i) MIH_HIP(hipEventCreateWithFlags(&res_ev[i], hipEventDisableTiming | hipEventBlockingSync));
         res_ok = true;
         return MIH_OK;
     }
@@ -1448,7 +1445,7 @@ struct IhtVar {
             MIH_HIP(hipMemcpyAsync(ridx.p + 2 * res_kcap, ridx_h.p + 2 * res_kcap, sizeof(int64_t) * cb, hipMemcpyHostToDevice, s));
             MIH_HIP(hipMemcpyAsync(rval.p + 2 * res_kcap, rval_h.p + 2 * res_kcap, sizeof(double) * cb, hipMemcpyHostToDevice, s));
         }
-        res_zero_list = zero_list; res_iter0 = iter_done;
+        res_zero_list = zero_list; res_iter0 = iter_done; res_known = 0; res_fast_fails = 0;      // (no threshold on the device yet)
         res_out.clear();
         xv_cache_forget(); stage_forget(); spec_ok = false;
         res_active = true;
@@ -1529,16 +1526,21 @@ struct IhtVar {
     }
     // one attempt of the step (attempt 0: the first, a >= 1: the a-th backtracking one): gradient step, projection, update_xb!,
     // loglikelihood, decision.  more: the kernels of attempt a + 1 are queued right behind (a forecast; they run only if needed)
-    int res_enqueue_attempt(uint64_t seq, int a, bool more)
+    int res_enqueue_attempt(uint64_t seq, int a, bool more, bool fast)
     {
         const ResPtrs P = res_ptrs(); const ResMat M = res_mat();
         const double *wp = has_weight ? weight.p : nullptr;
         const uint64_t zk = res_zkeep_mask();
         const int64_t len = p + q, groups = (J == 0) ? 1 : J;
-        hipLaunchKernelGGL(k_res_grad, dim3(kResGradBlocks), dim3(256), 0, s, P, res_epoch, a, df.p, wp, p, q, zk, full.p);
-        hipLaunchKernelGGL(k_res_hist2, dim3(kResHistBlocks), dim3(256), 0, s, P, res_epoch, a, full.p, len, (uint64_t)(k + zkeepn));
-        hipLaunchKernelGGL(k_res_collect, dim3(kResCollectBlocks), dim3(256), 0, s, P, res_epoch, a, full.p, len);
-        hipLaunchKernelGGL(k_res_select, dim3(1), dim3(1024), 0, s, P, res_epoch, a, seq, M, wp, p, q, zk, (int)zkeepn, groups * (k + zkeepn));
+        const uint64_t K = (uint64_t)(k + zkeepn);
+        if (fast)            // the direct gather: the threshold of the last attempt `a` as forecast, verified by the select
+            hipLaunchKernelGGL(k_res_grad<true>, dim3(kResGradBlocks), dim3(256), 0, s, P, res_epoch, a, df.p, wp, p, q, zk, full.p);
+        else {
+            hipLaunchKernelGGL(k_res_grad<false>, dim3(kResGradBlocks), dim3(256), 0, s, P, res_epoch, a, df.p, wp, p, q, zk, full.p);
+            hipLaunchKernelGGL(k_res_hist2, dim3(kResHistBlocks), dim3(256), 0, s, P, res_epoch, a, full.p, len, K);
+            hipLaunchKernelGGL(k_res_collect, dim3(kResCollectBlocks), dim3(256), 0, s, P, res_epoch, a, full.p, len);
+        }
+        hipLaunchKernelGGL(k_res_select, dim3(1), dim3(1024), 0, s, P, res_epoch, a, fast ? 1 : 0, K, seq, M, wp, p, q, zk, (int)zkeepn, groups * (k + zkeepn));
         if (!res_fix())
             hipLaunchKernelGGL(k_res_xb<false>, dim3(nb), dim3(256), 0, s, P, res_epoch, a, M, z.p, y.p, w.p, q, dist, link, nb_r, xb.p, zc.p, mu.p, red.p);
         else {
@@ -1547,46 +1549,66 @@ struct IhtVar {
             hipLaunchKernelGGL(k_res_mu, dim3(nb), dim3(256), 0, s, P, res_epoch, a, z.p, y.p, w.p, n, q, dist, link, nb_r, xb.p, zc.p, mu.p, red.p);
         }
         hipLaunchKernelGGL(k_res_decide, dim3(1), dim3(256), 0, s, P, res_epoch, a, more ? 1 : 0, seq, red.p, nb, n, dist);
-        if (!more) MIH_HIP(hipEventRecord(res_ev[seq % kResRing], s));
         MIH_HIP(hipGetLastError());
         return MIH_OK;
     }
     // attempts a0 .. a0 + res_spec of a step (res_spec: how many backtracks the last step needed, the forecast for this one)
-    int res_spec = 0;
-    int res_enqueue_attempts(uint64_t seq, int a0, int max_step)
+    // res_known: attempts 0 .. res_known - 1 have a forecast on the device (a step with that many attempts has stood since
+    // res_begin): their projections take the direct gather, unless the forecast has failed three times in this run of steps.
+    // first_slow: the attempt being re-queued because its forecast failed.
+    int res_spec = 0, res_fast_fails = 0, res_known = 0;
+    int res_enqueue_attempts(uint64_t seq, int a0, int max_step, bool first_slow = false)
     {
         const int last = std::min(max_step, a0 + res_spec);          // (attempt max_step always stands: utilities.jl:484)
-        for (int a = a0; a <= last; ++a) MIH_TRY(res_enqueue_attempt(seq, a, a < last));
+        for (int a = a0; a <= last; ++a) {
+            const bool fast = a < res_known && a < kResMaxAttempts && res_fast_fails < 3 && !(first_slow && a == a0);
+            if (fast) h->prof->count(MIH_CNT_RESIDENT_DIRECT, 1);
+            MIH_TRY(res_enqueue_attempt(seq, a, a < last, fast));
+        }
         return MIH_OK;
     }
-    // the score that ends the step: Z'r, the gated X'r pass, df on the new support
+    // the score that ends the step: the residual with Z'r and its statistics, the gated X'r pass (its digit kernel finishes those
+    // sums, its finalize kernel also leaves df on the new support and the coefficients of X_S df_S)
     int res_enqueue_back()
     {
         const ResPtrs P = res_ptrs();
-        hipLaunchKernelGGL(k_res_resid, dim3(nb), dim3(256), 0, s, P, res_epoch, xb.p, zc.p, y.p, mu.p, w.p, n, dist, link, nb_r, r.p);
-        hipLaunchKernelGGL(k_res_stats, dim3(kZtrBlocks, q + 1), dim3(256), 0, s, P, res_epoch, z.p, r.p, n, q, ztr.p, ztr_done.p,
-                           xtv.scal.p + xtv.rhs_cap * 4, xtv.stat_done.p, xtv.dm.ebits, xtv.scal.p);
+        hipLaunchKernelGGL(k_res_stats, dim3(kZtrBlocks, q + 1), dim3(256), 0, s, P, res_epoch, z.p, xb.p, zc.p, y.p, mu.p, w.p, n, q, dist, link, nb_r,
+                           r.p, ztr.p, xtv.scal.p + xtv.rhs_cap * 4);
         xtv.gate = &rctl.p->live_epoch; xtv.gate_val = res_epoch; xtv.stats_done = true;
+        xtv.shook.spart = xtv.scal.p + xtv.rhs_cap * 4; xtv.shook.zpart = ztr.p; xtv.shook.df2 = rctl.p->df2; xtv.shook.q = q;
+        xtv.shook.zblocks = kZtrBlocks; xtv.shook.ebits = xtv.dm.ebits;
+        xtv.hook.cur = &rctl.p->cur;
+        for (int i = 0; i < 2; ++i) { xtv.hook.idx[i] = P.idx[i]; xtv.hook.cnt[i] = &rctl.p->m[i].cnt; }
+        xtv.hook.gval = P.gval; xtv.hook.A = P.coefA; xtv.hook.B = P.coefB; xtv.hook.blocks = (int)nblk(res_kcap);
         const int rc = xtv_device(h, xtv, r.p, 1, df.p, s);
-        xtv.gate = nullptr; xtv.gate_val = 0; xtv.stats_done = false;
-        MIH_TRY(rc);
-        return res_enqueue_support();
+        xtv.gate = nullptr; xtv.gate_val = 0; xtv.stats_done = false; xtv.hook = XtvSupportHook(); xtv.shook = XtvStatsHook();
+        return rc;
     }
+    // The record of step chain `seq`.  No event sits in the stream for it (an event record is a queue operation of its own, several us
+    // between two kernels of the chain): the host polls the pinned ring -- briefly, then with short sleeps (it runs a step ahead of
+    // the records it reads, and an X'r pass of tens of ms is in front of most of them), looking at the stream now and then so that a
+    // failed launch does not leave it waiting.
     int res_wait(uint64_t seq, ResRecord *out)
     {
         volatile ResRecord *slot_ = rrec.p + (seq % kResRing);
         const auto t0 = std::chrono::steady_clock::now();
+        auto next_query = t0 + std::chrono::milliseconds(50);
         for (unsigned it = 0;; ++it) {
             if (__atomic_load_n(&slot_->seq, __ATOMIC_ACQUIRE) == seq) break;
+            if (coop_can_yield()) { current_coop()->yield(); continue; }
             __builtin_ia32_pause();
-            if ((it & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(100)) {
-                MIH_HIP(hipEventSynchronize(res_ev[seq % kResRing]));         // (a pass of tens of ms sits in front: sleep)
-                if (__atomic_load_n(&slot_->seq, __ATOMIC_ACQUIRE) != seq) {
-                    MIH_HIP(hipGetLastError());
+            if ((it & 255u) != 255u) continue;
+            const auto now = std::chrono::steady_clock::now();
+            if (now - t0 > std::chrono::microseconds(200)) std::this_thread::sleep_for(std::chrono::microseconds(100));
+            if (now > next_query) {
+                next_query = now + std::chrono::milliseconds(50);
+                const hipError_t e = hipStreamQuery(s);
+                if (e == hipSuccess) {                     // everything queued has run: the record is there, or never will be
+                    if (__atomic_load_n(&slot_->seq, __ATOMIC_ACQUIRE) == seq) break;
                     set_error("device-resident step %llu left no record", (unsigned long long)seq);
                     return MIH_HIP_ERROR;
                 }
-                break;
+                if (e != hipErrorNotReady) return hip_fail(e, "hipStreamQuery", __FILE__, __LINE__);
             }
         }
         *out = *const_cast<ResRecord *>(slot_);
@@ -1609,13 +1631,26 @@ struct IhtVar {
             res_out.erase(res_out.begin());
             MIH_TRY(res_wait(seq, rec));
             switch (rec->status) {
-            case RES_ACCEPT: ++rr.done; res_spec = rec->nbt; h->prof->count(MIH_CNT_RESIDENT_STEPS, 1); return MIH_OK;
+            case RES_ACCEPT:
+                ++rr.done; res_spec = rec->nbt; res_known = std::max(res_known, rec->nbt + 1);
+                h->prof->count(MIH_CNT_RESIDENT_STEPS, 1);
+                return MIH_OK;
             case RES_BACKTRACK: {            // the chain behind that attempt is dead: queue the next attempt and the rest of the step
                 res_dead_passes(1 + (int)res_out.size());
                 ++res_epoch; res_out.clear(); rr.issued = rr.done;
                 h->prof->count(MIH_CNT_RESIDENT_ATTEMPTS, 1);
                 const uint64_t s2 = ++res_seq;
                 MIH_TRY(res_enqueue_attempts(s2, rec->nbt, rr.max_step)); MIH_TRY(res_enqueue_back());
+                res_out.push_back(s2); ++rr.issued;
+                break;
+            }
+            case RES_REDO_SLOW: {            // the direct gather's forecast failed: the same attempt again, with the histograms
+                res_dead_passes(1 + (int)res_out.size());
+                ++res_epoch; res_out.clear(); rr.issued = rr.done;
+                ++res_fast_fails;
+                h->prof->count(MIH_CNT_RESIDENT_REDOS, 1);
+                const uint64_t s2 = ++res_seq;
+                MIH_TRY(res_enqueue_attempts(s2, rec->nbt, rr.max_step, true)); MIH_TRY(res_enqueue_back());
                 res_out.push_back(s2); ++rr.issued;
                 break;
             }

@@ -159,7 +159,7 @@ __device__ __forceinline__ int digit49(int m)
 // mfma_fp4; an FP6 element j sits in bits 6j..6j+5 of the lane's 192 bits, the last 64 of them in `dig2`).
 __global__ void __launch_bounds__(256)
 k_digits(const double *__restrict__ r, int64_t n, int64_t nblk, int m, DigitMode dm,
-         const double *__restrict__ scal, uint4 *__restrict__ dig /* [nops][nblk][64] */, uint2 *__restrict__ dig2, FlatPasses fp)
+         double *scal, uint4 *__restrict__ dig /* [nops][nblk][64] */, uint2 *__restrict__ dig2, FlatPasses fp, XtvStatsHook sh)
 {
     // The wave's 64 rows go into the B-operand image of their block directly: img[wave][half][digit] is the 128 (FP4) or 192 (FP6)
     // bits lane (half, digit) of the fragment carries, and every row ORs its code into its element's place (LDS atomics; round 4 --
@@ -167,6 +167,25 @@ k_digits(const double *__restrict__ r, int64_t n, int64_t nblk, int m, DigitMode
     // 60 % of the kernel's time at ten digits).
     if (dm.gate && *dm.gate != dm.gate_val) return;
     __shared__ uint32_t img[4][2][32][6];
+    __shared__ double s_scale;
+    if (sh.spart) {           // (device-resident steps, one residual) k_r_stats's second stage, by every block for itself; block 0 also leaves it -- and Z'r
+        if (threadIdx.x == 0) {
+            double fmx = 0.0, fsm = 0.0;
+            for (int b = 0; b < 64; ++b) { fmx = fmax(fmx, sh.spart[2 * b]); fsm += sh.spart[2 * b + 1]; }
+            int e = 0;
+            if (fmx > 0.0 && fmx < 1.0e300) e = sh.ebits - ilogb(fmx);
+            if (e > 1000) e = 1000;
+            s_scale = ldexp(1.0, e);
+            if (blockIdx.x == 0) { scal[0] = fmx; scal[1] = ldexp(1.0, -e); scal[2] = fsm; scal[3] = ldexp(1.0, e); }
+        }
+        if (blockIdx.x == 0 && (int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + sh.q) {
+            const int l = threadIdx.x - 64;
+            double a = 0.0;
+            for (int b = 0; b < sh.zblocks; ++b) a += sh.zpart[(int64_t)l * sh.zblocks + b];
+            sh.df2[l] = a;
+        }
+        __syncthreads();
+    }
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t blk = blockIdx.x * 4ll + w;
     const int vs = blockIdx.y;
@@ -181,7 +200,7 @@ k_digits(const double *__restrict__ r, int64_t n, int64_t nblk, int m, DigitMode
     if (vs < m && blk < nblk) {
         const int64_t i = blk * 64 + lane;
         const double x = (i < n) ? r[(int64_t)vs * n + i] : 0.0;
-        long long R = __double2ll_rn(x * scal[4 * vs + 3]);
+        long long R = __double2ll_rn(x * (sh.spart ? s_scale : scal[4 * vs + 3]));
         // element of this row in its half's fragment (the A fragment's order, mfma_fp4): 8 (2u + (s & 1)) + (s >> 1) for row 16u + s
         const int hh = lane >> 5, uu = (lane >> 4) & 1, ss = lane & 15;
         const int el = 8 * (2 * uu + (ss & 1)) + (ss >> 1);
@@ -1105,34 +1124,52 @@ k_xtv_dma16(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *
 // scal, r and out advance by one residual's stride each.  A thread keeps its column and walks the residuals (round 4; before,
 // one grid row per residual read mu, sinv and the two missing-list bounds once per residual: 64 MB per residual at p = 1M and
 // four slices, 40 MB now); the arithmetic of every (residual, column) is unchanged.
+__device__ __forceinline__ double xtv_finalize_col(int64_t j, const double *__restrict__ pu, int splits, int64_t pstride, double sum_r,
+                                                   const double *__restrict__ ru, double m, double si, int64_t a, int64_t b,
+                                                   const int32_t *__restrict__ miss_row, int center, int scale)
+{
+    double dot = 0.0;
+    for (int s = 0; s < splits; ++s) dot += pu[(int64_t)s * pstride + j];
+    if (b > a) {
+        double ms = 0.0;
+        for (int64_t t = a; t < b; ++t) ms += ru[miss_row[t]];
+        dot += m * ms;
+    }
+    if (center) dot -= m * sum_r;
+    if (scale) dot *= si;
+    return dot;
+}
 __global__ void __launch_bounds__(256)
 k_xtv_finalize(const double *__restrict__ partial, int splits, int64_t pstride, int64_t p, int nres,
                const double *__restrict__ scal, const double *__restrict__ r, int64_t n,
                const double *__restrict__ mu, const double *__restrict__ sinv,
                const int64_t *__restrict__ miss_ptr, const int32_t *__restrict__ miss_row,
                int center, int scale, int impute, double *__restrict__ out,
-               const int32_t *__restrict__ gate, int32_t gate_val)
+               const int32_t *__restrict__ gate, int32_t gate_val, XtvSupportHook hook)
 {
     if (gate && *gate != gate_val) return;
+    const int64_t pblocks = (p + 255) / 256;
+    if ((int64_t)blockIdx.x >= pblocks) {          // the support of the current iterate (device-resident steps; nres == 1)
+        const int c = *hook.cur;
+        const int64_t t = ((int64_t)blockIdx.x - pblocks) * 256 + threadIdx.x;
+        if (t >= *hook.cnt[c]) return;
+        const int64_t j = hook.idx[c][t];
+        const double m = mu[j], si = scale ? sinv[j] : 1.0;
+        int64_t a = 0, b = 0;
+        if (impute) { a = miss_ptr[j]; b = miss_ptr[j + 1]; }
+        const double dot = xtv_finalize_col(j, partial, splits, pstride, scal[2], r, m, si, a, b, miss_row, center, scale);
+        const double av = si * dot;
+        hook.gval[t] = dot; hook.A[t] = av; hook.B[t] = center ? -m * av : 0.0;
+        return;
+    }
     int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (j >= p) return;
     const double m = mu[j], si = scale ? sinv[j] : 1.0;
     int64_t a = 0, b = 0;
     if (impute) { a = miss_ptr[j]; b = miss_ptr[j + 1]; }
-    for (int u = 0; u < nres; ++u) {
-        const double *pu = partial + (int64_t)u * splits * pstride;
-        double dot = 0.0;
-        for (int s = 0; s < splits; ++s) dot += pu[(int64_t)s * pstride + j];
-        if (b > a) {
-            const double *ru = r + (int64_t)u * n;
-            double ms = 0.0;
-            for (int64_t t = a; t < b; ++t) ms += ru[miss_row[t]];
-            dot += m * ms;
-        }
-        if (center) dot -= m * scal[4 * u + 2];
-        if (scale) dot *= si;
-        out[(int64_t)u * p + j] = dot;
-    }
+    for (int u = 0; u < nres; ++u)
+        out[(int64_t)u * p + j] = xtv_finalize_col(j, partial + (int64_t)u * splits * pstride, splits, pstride, scal[4 * u + 2],
+                                                   r + (int64_t)u * n, m, si, a, b, miss_row, center, scale);
 }
 
 // ---- dense design matrix: out_j = sum_i D[i,j] r_i (one wave per column) ---------------
@@ -1563,7 +1600,7 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
     // a falling residual count from round to round, every loss checked by the tests of the full configs[3] grid),
     // and test_flat_packing_ignores_what_an_earlier_pass_left_in_the_tail_columns runs 19 residuals and then 1 .. 18 on ONE workspace.
     hipLaunchKernelGGL(k_digits, dim3((unsigned)((nblk + 3) / 4), (unsigned)(dm.flat ? m : nops * per_op)), dim3(256), 0, s, r_dev, h->n, nblk, m, dm,
-                       w.scal.p, dig_all, dig2_all, fp);
+                       w.scal.p, dig_all, dig2_all, fp, (w.stats_done && m == 1) ? w.shook : XtvStatsHook());
     for (int q = 0; dm.flat && q < fp.npass; ++q) {
         const int u0 = fp.u0[q], u1 = fp.u0[q + 1], t = fp.t0[q], nr = fp.t0[q + 1] - t;
         DigitMode dq = dm;
@@ -1583,7 +1620,7 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
         if (rc) return rc;
         hipLaunchKernelGGL(k_xtv_finalize, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, s,
                            partial, splits, pstride, h->p, u1 - u0, w.scal.p + 4 * u0, r_dev + (int64_t)u0 * h->n, h->n, h->mu, h->sinv,
-                           h->miss_ptr, h->miss_row, h->center, h->scale, h->impute, out_dev + (int64_t)u0 * h->p, w.gate, w.gate_val);
+                           h->miss_ptr, h->miss_row, h->center, h->scale, h->impute && h->total_missing > 0, out_dev + (int64_t)u0 * h->p, w.gate, w.gate_val, XtvSupportHook());
     }
     if (dm.flat) { MIH_HIP(hipGetLastError()); return MIH_OK; }
     for (int t = 0; t < nops;) {          // t counts B operands
@@ -1610,11 +1647,14 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
             prof_end(h, s, rec);
         }
         if (rc) return rc;
-        if (u1 > u0)
-            hipLaunchKernelGGL(k_xtv_finalize, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, s,
+        if (u1 > u0) {
+            const bool hooked = w.hook.cur != nullptr && m == 1;
+            hipLaunchKernelGGL(k_xtv_finalize, dim3((unsigned)((h->p + 255) / 256 + (hooked ? w.hook.blocks : 0))), dim3(256), 0, s,
                                w.partial.p + (int64_t)u0 * splits * pstride, splits, pstride, h->p, u1 - u0,
                                w.scal.p + 4 * u0, r_dev + (int64_t)u0 * h->n, h->n, h->mu, h->sinv, h->miss_ptr, h->miss_row,
-                               h->center, h->scale, h->impute, out_dev + (int64_t)u0 * h->p, w.gate, w.gate_val);
+                               h->center, h->scale, h->impute && h->total_missing > 0, out_dev + (int64_t)u0 * h->p, w.gate, w.gate_val,
+                               hooked ? w.hook : XtvSupportHook());
+        }
         t += nr;
     }
     MIH_HIP(hipGetLastError());

@@ -2449,7 +2449,7 @@ def test_resident_steps_equal_host_driven_steps(mih, oracle, normal_pair, normal
     cols, yt, tied = tied_case()
     xt = mih.SnpLinAlg(cols, n=1000, center=True, scale=True, impute=True)
     cases.append(("exact ties: _choose!", dict(y=yt, x=xt, z=None, k=2)))
-    nbt_seen, tally = 0, dict(resident_steps=0, resident_attempts=0, resident_handbacks=0)
+    nbt_seen, tally = 0, dict(resident_steps=0, resident_attempts=0, resident_handbacks=0, resident_direct=0, resident_redos=0)
     for what, kw in cases:
         kw = dict(kw)
         yy, xx, zz = kw.pop("y"), kw.pop("x"), kw.pop("z")
@@ -2475,6 +2475,9 @@ def test_resident_steps_equal_host_driven_steps(mih, oracle, normal_pair, normal
             tally[key] += cnt[key]
     assert nbt_seen > 0 and tally["resident_attempts"] > 0        # some of those steps backtracked: the re-queued attempts were exercised
     assert tally["resident_steps"] > 60, tally
+    # most projections after a fit's first steps take the direct gather (a verified forecast of the threshold); some forecasts fail
+    # and are redone with the histogram sweeps -- same results either way (the comparisons above)
+    assert tally["resident_direct"] > 40 and tally["resident_redos"] < tally["resident_direct"] // 4, tally
     assert mih.fit_iht(yt, xt, None, k=2, verbose=False, step_mode=0).choose_fired
 
 
