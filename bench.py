@@ -42,7 +42,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 METRIC = "IHT iterations/sec + X'r GB/s vs HBM roofline, n=500k p=1M k=200"
 DTYPE = "f64 (residual as a 54-bit fixed-point number, exact accumulation on the matrix cores, f64 recombination)"
-TRAFFIC_FILE = os.path.join("profiles", "r04_traffic.json")    # separate rocprofv3 --pmc passes of this command (tools/prof_bench.sh)
+TRAFFIC_FILE = os.path.join("profiles", "r05_traffic.json")    # separate rocprofv3 --pmc passes of this command (tools/prof_bench.sh)
 
 
 def parse():
@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of each baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cv", action="store_true", help="skip the secondary cv_iht measurement (configs[3])")
+    ap.add_argument("--no-mv", action="store_true", help="skip the secondary multivariate measurement (configs[4], N = 1 only)")
+    ap.add_argument("--step-mode", type=int, default=0, choices=[0, 1],
+                    help="0: iht_one_step! resident on the device (default), 1: host-driven steps (the path of rounds 1-4)")
     ap.add_argument("--cv-steps", type=int, default=2, help="timed whole cross-validations of the secondary object at N>1")
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per X'r launch from a separate rocprofv3 --pmc pass (corrected)")
@@ -169,7 +172,18 @@ def cpu_baseline(m, n, p, k, seed, target_s):
     t = trials[cores]
     del ox
     pc = int(min(p, max(probe, probe * (target_s / 4.0) / max(t, 1e-6))))
-    pc = min(pc, max(probe, int(2e9 // ((n + 3) // 4))))    # keep the sample under ~2 GB of host memory
+    #  at least 10 % of the columns when host memory allows: the sample is held twice for a moment (the exported
+    # PLINK columns and the oracle's copy)
+    avail = 0
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable"):
+                avail = int(ln.split()[1]) * 1024
+    except OSError:
+        pass
+    cap_bytes = max(2e9, min(0.25 * avail, 16e9))
+    pc = max(pc, int(min(p // 10, cap_bytes // ((n + 3) // 4))))
+    pc = min(pc, max(probe, int(cap_bytes // ((n + 3) // 4))))
     ox = load(pc)
     t_xtv = time_pass(ox, target_s / 4.0)
     # whole iterations: fit_iht with max_iter = M performs M - 1 steps after the initial score pass (fit.jl:170)
@@ -193,7 +207,7 @@ def cpu_baseline(m, n, p, k, seed, target_s):
     t_full = t_xtv * p / pc + t_rest
     return {"value": 1.0 / t_full, "unit": "iterations/s", "cores": cores_used(cores), "omp_threads": cores, "kind": "port",
             "sample": f"one whole oracle iht_one_step (iht_stepsize!, _iht_gradstep!, update_xb!, loglikelihood, score!) with k={kk} "
-                      f"on the first {pc} of {p} SNP columns, n={n}: {t_step:.3f} s per step, of which the X'r pass {t_xtv:.3f} s "
+                      f"on the first {pc} of {p} SNP columns ({100.0 * pc / p:.1f} % of them), n={n}: {t_step:.3f} s per step, of which the X'r pass {t_xtv:.3f} s "
                       f"(scaled by p/{pc}; the remaining {t_rest:.3f} s per step does not grow with p); {cores} OpenMP threads = the "
                       f"fastest of {sorted(trials)} on {ncpu} logical CPUs{'' if quota is None else f', cgroup CPU quota {quota:g}'}; "
                       "CPU restatement (oracle/), not MendelIHT.jl.  Context, not a measurement of this run: the reference's closest "
@@ -286,6 +300,44 @@ def cv_roofline(cst):
                     "overlap, so the sum exceeds the union (and may exceed the wall time). A fused pass streams X once for up to 19 "
                     "residuals and is bound by the matrix pipe under the power cap, not by HBM: wider passes LOWER this fraction while "
                     "the cost per residual falls (xtv_kernel_ms_per_residual_scored; DESIGN.md 3.1b)"}
+
+
+FP64_VECTOR_PEAK_TFLOPS = 78.6     # MI355X dense FP64 vector peak (MI355X_MICROARCH.md): the ruler for "f64-equivalent" multiply-adds
+
+
+def mv_object(m, x, n, p, torch, r=10, k=500):
+    """BASELINE configs[4]: multivariate IHT (MvNormal, r = 10 traits, k = 500) on the resident matrix -- the 10-residual fused
+    X'(Y - mu) pass and a whole iteration, timed inside a short fit (the library's HIP events around every pass)."""
+    rng = np.random.default_rng(3)
+    lin = rng.choice(r * p, k, replace=False)
+    Y = rng.standard_normal((r, n))
+    for t in range(r):
+        cols = np.unique(lin[lin % r == t] // r)
+        Y[t] += x.xv_sparse(cols, rng.choice([-1.0, 1.0], cols.size) * rng.uniform(0.15, 0.45, cols.size)) + 1.0
+    m.fit_iht(Y, x, None, k=k, verbose=False, max_iter=3)                  # warm-up
+    m.profile_read(x, reset=True)
+    m.profile_enable(x, True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = m.fit_iht(Y, x, None, k=k, verbose=False, max_iter=12)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    m.profile_enable(x, False)
+    ps = m.profile_passes(x, reset=True)                                   # [0] = the initial score
+    steady = ps[1:]
+    pass_ms = sum(q["ms"] for q in steady) / max(len(steady), 1)
+    gaps = [ps[i + 1]["start_ms"] - ps[i]["start_ms"] - ps[i]["ms"] for i in range(1, len(ps) - 1)]
+    alg = x.algorithmic_bytes(r)
+    return {"workload": f"fit_iht MvNormal r={r} traits k={k} on the same SnpArray n={n} p={p} (BASELINE configs[4]), max_iter=12",
+            "iterations": int(res.iter), "ms_per_iteration": 1e3 * res.time / max(res.iter, 1), "fit_wall_s": wall,
+            "pass_ms": pass_ms, "outside_the_pass_ms": sum(gaps) / max(len(gaps), 1), "pass_kernel": steady[0]["kernel"] if steady else None,
+            "nonzero": int(np.count_nonzero(res.beta)),
+            "roofline": {"bound": "mfma (matrix pipe under the package power cap; DESIGN.md 3.1b)", "hbm_GBps": alg / pass_ms / 1e6,
+                         "frac_of_hbm_peak": alg / pass_ms / 1e6 / HBM_PEAK_GBPS,
+                         "f64_equivalent_TFLOPs": 2.0 * n * p * r / (pass_ms * 1e-3) / 1e12,
+                         "frac_of_fp64_vector_peak": 2.0 * n * p * r / (pass_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                         "note": "2 n p r multiply-adds per pass, each exact (fixed-point residual digits on the matrix cores): what a "
+                                 "dense f64 X'R would need 78.6 TFLOP/s of vector FMAs for"}}
 
 
 def main():
@@ -413,10 +465,12 @@ def main():
         exchange = ("native RCCL inside the library (mih_comm_create_rccl: ncclAllReduce / ncclAllGather on a private stream)" if native
                     else f"torch.distributed callbacks ({backend})"
                          + (f" -- the library's own communicator could not be created: {native_error}" if native_error else ""))
-    sess = m.IHTSession(y, x, None, k=k, d=m.Normal(), l=m.IdentityLink(), comm=comm)
+    sess = m.IHTSession(y, x, None, k=k, d=m.Normal(), l=m.IdentityLink(), comm=comm, step_mode=a.step_mode)
     for _ in range(a.warmup):
         sess.step()
     m.profile_read(x, reset=True)
+    m.profile_counters(x, reset=True)
+    m.profile_exchange(x, reset=True)
     m.profile_enable(x, True)
     barrier()
     torch.cuda.synchronize()
@@ -427,6 +481,32 @@ def main():
     elapsed = max_over_ranks(time.perf_counter() - t0)
     m.profile_enable(x, False)
     st = pass_stats(m, x, m.profile_passes(x, reset=True))
+    step_counters = m.profile_counters(x, reset=True)
+    exch = m.profile_exchange(x, reset=True)
+    comm_info = comm.info() if (comm is not None and hasattr(comm, "info")) else None
+
+    # same-box A/B of the two ways a step is driven (N = 1): a short run of host-driven steps on a fresh session
+    ab = None
+    if world == 1 and a.step_mode == 0:
+        s2 = m.IHTSession(y, x, None, k=k, d=m.Normal(), l=m.IdentityLink(), step_mode=1)
+        for _ in range(a.warmup):
+            s2.step()
+        nab = min(a.steps, 20)
+        m.profile_read(x, reset=True)
+        m.profile_enable(x, True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        _l2, nbt2, _t2 = s2.run(nab)
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t1
+        m.profile_enable(x, False)
+        st2 = pass_stats(m, x, m.profile_passes(x, reset=True))
+        s2.close()
+        del s2
+        k2 = st2["ms_sum"] / max(st2["launches"], 1)
+        ab = {"steps": nab, "ms_per_step": 1e3 * el2 / nab, "xtv_kernel_ms": k2, "outside_the_pass_ms_per_step": 1e3 * el2 / nab - k2,
+              "backtracks": int(nbt2), "what": "mih_fit_params::step_mode = 1: the host-driven step of rounds 1-4 (26 launches, three host "
+              "waits per step without backtracking), same box, same fit, a fresh session"}
 
     bhat, _ = sess.model()
     found = float(np.intersect1d(np.flatnonzero(bhat) + lo, supp).size)
@@ -476,12 +556,29 @@ def main():
                                    + (", one independent replica per GPU" if mode == "replicas" and world > 1 else ""),
                        "n": n, "p": p, "k": k, "xtv_variant": a.variant, "generator_s": round(t_gen, 2),
                        "backtracks_in_timed_steps": nbt, "true_effects_recovered": f"{recovered}/{k}",
-                       "final_logl": logl, "host_small_kernels_and_exchange_ms_per_step": 1e3 * elapsed / a.steps - kern_ms},
+                       "final_logl": logl, "host_small_kernels_and_exchange_ms_per_step": 1e3 * elapsed / a.steps - kern_ms,
+                       "step_mode": ("0: iht_one_step! resident on the device -- iterate, top-k finish, backtracking decision in device "
+                                     "memory, the kernels of a step queued without a host wait" if a.step_mode == 0 and not sharded else
+                                     "1: host-driven steps" + (" (a column-sharded fit has no device-resident step yet)" if sharded and a.step_mode == 0 else "")),
+                       "resident_steps": {kk: step_counters[kk] for kk in ("resident_steps", "resident_attempts", "resident_handbacks",
+                                                                            "resident_direct", "resident_redos")}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": a.traffic_bytes, "traffic_source": traffic_src,
                          "kernel": kernel_name, "kernel_ms": kern_ms, "launches": int(launches),
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
+        if ab is not None:
+            out["config"]["host_driven_steps_same_box"] = ab
+        # what is outside the pass, split: the exchanges (per kind, timed on the fit's stream / the host clock by the library's hook)
+        # and the chain of small kernels
+        ex_ms = sum(v["ms"] for v in exch.values()) / a.steps
+        out["config"]["exchange_ms_per_step"] = ex_ms
+        out["config"]["chain_ms_per_step"] = out["config"]["host_small_kernels_and_exchange_ms_per_step"] - ex_ms
+        if sharded:
+            out["config"]["collectives_rank0"] = {kk: {"per_step": v["count"] / a.steps, "mean_us": 1e3 * v["ms"] / max(v["count"], 1)}
+                                                  for kk, v in exch.items()}
+            out["config"]["rccl_ranks_seen"] = comm_info[0] if comm_info else None
+            out["config"]["librccl"] = comm_info[1] if comm_info else None
         if sharded:
             out["config"].update(columns_per_rank=[int(r[3]) for r in rows], exchange=exchange,
                                  exchanges_per_iteration="two all-reduces of an n-vector (X_S b_S of update_xb!, X_S g_S of iht_stepsize!), one "
@@ -584,6 +681,9 @@ def main():
                 }
                 if not same:
                     failures.append("the losses of the sharded cross-validation differ from the one-GPU run")
+    # ---- secondary: BASELINE configs[4] (N = 1): MvNormal, r = 10 traits, k = 500 on the same matrix ------------------------
+    if world == 1 and mode == "fit" and not a.no_mv and (n, p) == (500_000, 1_000_000):
+        out["mv"] = mv_object(m, x, n, p, torch)
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"], cores = cpu_baseline(m, n, p, k, seed, a.cpu_seconds)

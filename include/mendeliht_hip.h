@@ -171,6 +171,9 @@ typedef struct mih_comm {
 int mih_rccl_unique_id(void *id128);
 int mih_comm_create_rccl(const void *id128, int32_t rank, int32_t world, int32_t device, int64_t col_offset,
                          int64_t p_global, mih_comm **out);
+/* diagnostics: the rank count RCCL itself reports for the communicator (ncclCommCount; -1 if unavailable) and the librccl file that
+ * was loaded (a process may hold two: comm.hip picks the one beside its own libamdhip64) */
+int mih_comm_info(const mih_comm *c, int32_t *ranks_seen, char *librccl_path, int64_t cap);
 int mih_comm_destroy_rccl(mih_comm *c);
 /* The ONE exchange of a cross-validation run by one process per GPU (the reference combines its threads' losses in the shared
  * `mses` vector, cross_validation.jl:99,113,124-127): every rank passes the nfolds * npath losses mih_cv_iht / mih_cv_mv /
@@ -372,6 +375,11 @@ int mih_profile_enable(const mih_mat *h, int on);
 int mih_profile_read(const mih_mat *h, double *xtv_kernel_ms, int64_t *xtv_launches, int reset);
 /* the launches themselves, oldest first: up to cap records into out (may be NULL to ask for the count), *n = available */
 int mih_profile_passes(const mih_mat *h, mih_pass_record *out, int64_t cap, int64_t *n, int reset);
+/* exchanges of the column-sharded fits run on h while the hook was on, by kind: [0] all-reduce of n + 1 doubles (X_S g_S of
+ * iht_stepsize! with the shards' |df_S|^2 riding along), [1] all-reduce of n doubles (X_S b_S of update_xb!), [2] all-gather of the
+ * projection's candidates, [3] scalar exchanges on the host.  ms4 = summed duration (HIP events on the fit's stream for the
+ * collectives queued there, the host clock for those the host waits for), count4 = how many. */
+int mih_profile_exchange(const mih_mat *h, double *ms4, int64_t *count4, int reset);
 int mih_profile_counters(const mih_mat *h, int64_t *out /* [MIH_PROFILE_NCOUNTERS] */, int reset);
 /* Runs `iters` X'r passes of m residuals back to back on the handle's stream with R resident in HBM, bracketed by HIP
  * events; *ms_per_pass = average time of the whole chain (statistics, digit planes, pass, finalize).  m = 1 uses the

@@ -13,7 +13,7 @@ from .api import (  # noqa: F401
     Bernoulli, IdentityLink, IHTResult, LogitLink, LogLink, MendelIHTError, MvNormal, NegativeBinomial,
     Normal, Poisson, SnpLinAlg, DenseMatrix, cross_validate, cv_iht, device_count, fit_iht, iht,
     library_path, mIHTResult, project_group_sparse, project_k, read_bed, standardize, lib, IHTSession,
-    profile_enable, profile_read, profile_passes, cv_assignment, profile_counters, busy_union_ms, hash_folds, probe_set, using_probes,
+    profile_enable, profile_read, profile_passes, cv_assignment, profile_counters, profile_exchange, EXCHANGE_KINDS, busy_union_ms, hash_folds, probe_set, using_probes,
     probes_library_path, iht_run_many_models, set_xtv_digits, set_step_mode, Gamma, InverseGaussian, ProbitLink,
     CloglogLink, CauchitLink, InverseLink, InverseSquareLink, SqrtLink, canonicallink, maf_weights, simulate_random_snparray, simulate_random_response, naive_impute,
 )

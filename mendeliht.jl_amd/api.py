@@ -176,11 +176,13 @@ def lib():
         "mih_rccl_unique_id": [vp],
         "mih_comm_create_rccl": [vp, i32, i32, i32, i64, i64, C.POINTER(vp)],
         "mih_comm_destroy_rccl": [vp],
+        "mih_comm_info": [vp, C.POINTER(i32), vp, i64],
         "mih_cv_allgather": [vp, vp, i64],
         "mih_profile_enable": [vp, C.c_int],
         "mih_profile_read": [vp, C.POINTER(dbl), C.POINTER(i64), C.c_int],
         "mih_profile_passes": [vp, C.POINTER(_PassRecord), i64, C.POINTER(i64), C.c_int],
         "mih_profile_counters": [vp, C.POINTER(i64), C.c_int],
+        "mih_profile_exchange": [vp, C.POINTER(dbl), C.POINTER(i64), C.c_int],
     }
     if using_probes():       # include/mendeliht_hip_probes.h
         sig.update({"mih_probe_set_xtv_variant": [C.c_int], "mih_probe_set_xtv_multi_variant": [C.c_int],
@@ -203,8 +205,8 @@ def exported_symbols():
             "mih_project_topk", "mih_project_group_sparse", "mih_fit_iht", "mih_cv_iht", "mih_cv_meanloss", "mih_cv_assignment", "mih_cv_iht_multi", "mih_fit_iht_path",
             "mih_fit_mv", "mih_cv_mv", "mih_bench_xtv", "mih_xtv_algorithmic_bytes", "mih_xtv_batched_fmt", "mih_abi_sizes",
             "mih_session_create", "mih_session_step", "mih_session_run", "mih_session_model", "mih_session_destroy",
-            "mih_rccl_unique_id", "mih_comm_create_rccl", "mih_comm_destroy_rccl", "mih_cv_allgather",
-            "mih_profile_enable", "mih_profile_read", "mih_profile_passes", "mih_profile_counters"]
+            "mih_rccl_unique_id", "mih_comm_create_rccl", "mih_comm_info", "mih_comm_destroy_rccl", "mih_cv_allgather",
+            "mih_profile_enable", "mih_profile_read", "mih_profile_passes", "mih_profile_counters", "mih_profile_exchange"]
 
 
 def probe_symbols():
@@ -724,6 +726,16 @@ def profile_counters(x, reset=True):
     out = (C.c_int64 * len(PROFILE_COUNTERS))()
     _check(lib().mih_profile_counters(_as_mat(x)._h, out, int(reset)))
     return dict(zip(PROFILE_COUNTERS, [int(v) for v in out]))
+
+
+EXCHANGE_KINDS = ("allreduce_n_plus_1", "allreduce_n", "allgather_candidates", "host_scalars")
+
+
+def profile_exchange(x, reset=True):
+    """Exchanges of the column-sharded fits on `x` while its hook was on (mih_profile_exchange): {kind: (count, summed ms)}."""
+    ms, cnt = (C.c_double * 4)(), (C.c_int64 * 4)()
+    _check(lib().mih_profile_exchange(_as_mat(x)._h, ms, cnt, int(reset)))
+    return {kk: dict(count=int(cnt[i]), ms=float(ms[i])) for i, kk in enumerate(EXCHANGE_KINDS)}
 
 
 def busy_union_ms(passes):

@@ -26,6 +26,8 @@ struct Rccl {
     int (*AllReduce)(const void *, void *, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, nccl_comm, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*CommCount)(nccl_comm, int *) = nullptr;      // optional (diagnostics: mih_comm_info)
+    std::string path;                                   // what dlopen was given
 };
 static Rccl g_rccl;
 static std::mutex g_rccl_mu;
@@ -49,7 +51,8 @@ static int rccl_load()
     const char *names[] = {getenv("MENDELIHT_RCCL_LIB"), beside[0].empty() ? nullptr : beside[0].c_str(),
                            beside[1].empty() ? nullptr : beside[1].c_str(), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *lib = nullptr;
-    for (const char *nm : names) { if (nm && (lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break; }
+    const char *opened = nullptr;
+    for (const char *nm : names) { if (nm && (lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) { opened = nm; break; } }
     if (!lib) { set_error("cannot load librccl (%s): set MENDELIHT_RCCL_LIB", dlerror()); return MIH_BAD_ARG; }
     Rccl r;
     r.lib = lib;
@@ -59,6 +62,9 @@ static int rccl_load()
     r.AllReduce = (int (*)(const void *, void *, size_t, int, int, nccl_comm, hipStream_t))dlsym(lib, "ncclAllReduce");
     r.AllGather = (int (*)(const void *, void *, size_t, int, nccl_comm, hipStream_t))dlsym(lib, "ncclAllGather");
     r.GetErrorString = (const char *(*)(int))dlsym(lib, "ncclGetErrorString");
+    r.CommCount = (int (*)(nccl_comm, int *))dlsym(lib, "ncclCommCount");
+    r.path = opened ? opened : "";
+    { Dl_info li; if (r.GetUniqueId && dladdr((void *)r.GetUniqueId, &li) && li.dli_fname) r.path = li.dli_fname; }      // the file that answered
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.AllGather) {
         set_error("librccl lacks an expected entry point");
         dlclose(lib);
@@ -197,6 +203,21 @@ int mih_cv_allgather(const mih_comm *c, double *mses_raw, int64_t count)
         for (int32_t r = 0; r < c->world; ++r) s += all[(size_t)r * (size_t)count + (size_t)i];
         mses_raw[i] = s;
     }
+    return MIH_OK;
+}
+
+// diagnostics of the library's own communicator: the rank count RCCL itself reports (ncclCommCount; -1 if the library lacks it) and
+// the librccl file that was loaded (dladdr of its ncclGetUniqueId)
+int mih_comm_info(const mih_comm *c, int32_t *ranks_seen, char *librccl_path, int64_t cap)
+{
+    if (!c || c->allreduce != native_allreduce || c->user != (void *)c) { set_error("not a communicator made by mih_comm_create_rccl"); return MIH_BAD_ARG; }
+    NativeComm *nc = static_cast<NativeComm *>(c->user);
+    if (ranks_seen) {
+        int cnt = -1;
+        if (g_rccl.CommCount && g_rccl.CommCount(nc->comm, &cnt) != kNcclSuccess) cnt = -1;
+        *ranks_seen = cnt;
+    }
+    if (librccl_path && cap > 0) { snprintf(librccl_path, (size_t)cap, "%s", g_rccl.path.c_str()); }
     return MIH_OK;
 }
 

@@ -274,6 +274,9 @@ namespace mih {
 // bracketed by HIP events on the stream it runs on and recorded with its kernel name and residual count; the lock-step drivers
 // also count what they did (lanes, slots, hand-overs, shared initial scores).  Lives behind the handle, not in the process.
 struct PassRecord { hipEvent_t e0 = nullptr, e1 = nullptr; int residuals = 0, operands = 0, stream_tag = 0; char kernel[48] = {0}; };
+// exchanges of a column-sharded fit (mih_profile_exchange): [0] all-reduce of n + 1 doubles (X_S g_S with |df_S|^2 riding along),
+// [1] all-reduce of n doubles (X_S b_S), [2] all-gather of the projection's candidates, [3] scalar exchanges on the host
+struct ExchRecord { hipEvent_t e0 = nullptr, e1 = nullptr; int kind = 0; };
 struct Profile {
     std::mutex mu;
     std::atomic<bool> on{false};                 // read by the lanes' threads without the mutex
@@ -281,6 +284,9 @@ struct Profile {
     std::vector<PassRecord> open;                // launches whose events have not been read yet
     std::vector<mih_pass_record> done;
     int64_t counters[MIH_PROFILE_NCOUNTERS] = {0};
+    std::vector<ExchRecord> xopen;               // collectives queued on a fit's stream, events not read yet
+    double xms[4] = {0.0, 0.0, 0.0, 0.0}; int64_t xcount[4] = {0, 0, 0, 0};
+    void exch_host(int kind, double ms) { if (!on) return; std::lock_guard<std::mutex> g(mu); xms[kind] += ms; ++xcount[kind]; }
     void count(int which, int64_t add) { if (!on) return; std::lock_guard<std::mutex> g(mu); counters[which] += add; }
     void count_max(int which, int64_t v) { if (!on) return; std::lock_guard<std::mutex> g(mu); if (v > counters[which]) counters[which] = v; }
     void drain();                                // synchronise the open records into `done`

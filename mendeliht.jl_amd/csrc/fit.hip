@@ -453,23 +453,41 @@ struct IhtVar {
     const mih_comm *comm = nullptr;
     int64_t col0 = 0, pg = 0;
     int comm_fail(int rc) { set_error("communicator callback failed (%d)", rc); return MIH_BAD_ARG; }
+    // (measurement hook on: every exchange is timed -- HIP events around a collective queued on this stream, the host clock
+    // around one the host waits for -- and kept per kind: mih_profile_exchange)
+    static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     int allreduce_dev(double *buf, int64_t cnt, int op)
     {
+        Profile &pf = *h->prof;
+        const int kind = cnt == n + 1 ? 0 : 1;
+        ExchRecord rec; rec.kind = kind;
+        const bool timed = pf.on && hipEventCreate(&rec.e0) == hipSuccess && hipEventCreate(&rec.e1) == hipSuccess;
+        if (timed) (void)hipEventRecord(rec.e0, s);
         const int nrc = comm_native_allreduce_on_stream(comm, buf, cnt, op, s, h->device);      // the library's own communicator: queued on this stream
-        if (nrc >= 0) return nrc;
+        if (nrc >= 0) {
+            if (timed) { (void)hipEventRecord(rec.e1, s); std::lock_guard<std::mutex> g(pf.mu); pf.xopen.push_back(rec); }
+            return nrc;
+        }
+        if (timed) { (void)hipEventDestroy(rec.e0); (void)hipEventDestroy(rec.e1); }
+        const double t0 = now_ms();
         MIH_HIP(hipStreamSynchronize(s));
         int rc = comm->allreduce(comm->user, buf, cnt, op, 1);
+        pf.exch_host(kind, now_ms() - t0);
         return rc ? comm_fail(rc) : MIH_OK;
     }
     int allreduce_host(double *buf, int64_t cnt, int op)
     {
+        const double t0 = now_ms();
         int rc = comm->allreduce(comm->user, buf, cnt, op, 0);
+        h->prof->exch_host(3, now_ms() - t0);
         return rc ? comm_fail(rc) : MIH_OK;
     }
     int allgather_host(const double *send, int64_t cnt, std::vector<double> &recv)
     {
         recv.assign((size_t)cnt * comm->world, 0.0);
+        const double t0 = now_ms();
         int rc = comm->allgather(comm->user, send, cnt, recv.data());
+        h->prof->exch_host(2, now_ms() - t0);
         return rc ? comm_fail(rc) : MIH_OK;
     }
 

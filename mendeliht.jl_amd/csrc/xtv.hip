@@ -84,6 +84,7 @@ void Profile::drain()
 Profile::~Profile()
 {
     for (auto &r : open) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    for (auto &r : xopen) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     if (origin) (void)hipEventDestroy(origin);
 }
 
@@ -1705,6 +1706,22 @@ int mih_profile_passes(const mih_mat *h, mih_pass_record *out, int64_t cap, int6
     *n = (int64_t)pf.done.size();
     if (out) for (int64_t i = 0; i < cap && i < *n; ++i) out[i] = pf.done[(size_t)i];
     if (reset) pf.done.clear();
+    return MIH_OK;
+}
+
+int mih_profile_exchange(const mih_mat *h, double *ms4, int64_t *count4, int reset)
+{
+    if (!h || !ms4 || !count4) { set_error("null argument"); return MIH_BAD_ARG; }
+    Profile &pf = *h->prof;
+    std::lock_guard<std::mutex> g(pf.mu);
+    for (auto &r : pf.xopen) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { pf.xms[r.kind] += ms; ++pf.xcount[r.kind]; }
+        else (void)hipGetLastError();
+        (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
+    }
+    pf.xopen.clear();
+    for (int i = 0; i < 4; ++i) { ms4[i] = pf.xms[i]; count4[i] = pf.xcount[i]; if (reset) { pf.xms[i] = 0.0; pf.xcount[i] = 0; } }
     return MIH_OK;
 }
 

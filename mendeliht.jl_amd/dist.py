@@ -255,6 +255,13 @@ class NativeComm:
     def pointer(self):
         return self._h.value
 
+    def info(self):
+        """(ranks RCCL itself reports for this communicator, the librccl file that was loaded) -- mih_comm_info"""
+        from .api import _check, lib
+        seen, path = C.c_int32(-1), C.create_string_buffer(1024)
+        _check(lib().mih_comm_info(self._h, C.byref(seen), path, 1024))
+        return int(seen.value), path.value.decode(errors="replace")
+
     def close(self):
         if self._h:
             from .api import lib

@@ -160,6 +160,13 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm)
     return ncclSuccess;
 }
 
+ncclResult_t ncclCommCount(const ncclComm_t comm, int *count)
+{
+    if (!comm || !count) return ncclInvalidArgument;
+    *count = comm->hdr->nranks;
+    return ncclSuccess;
+}
+
 const char *ncclGetErrorString(ncclResult_t result)
 {
     switch (result) {
