@@ -361,7 +361,7 @@ enum { MIH_CNT_LANES = 0,          /* lock-step lanes started (summed over calls
        MIH_CNT_SHARED_INIT = 3,    /* fits that started from another fit's initial score */
        MIH_CNT_ROUNDS = 4,         /* lock-step rounds */
        MIH_CNT_FITS = 5,           /* fits completed by the lock-step drivers */
-       MIH_CNT_SCORES = 6,         /* residual scores that END A STEP (= IHT iterations as fit.jl counts them) of those fits */
+       MIH_CNT_SCORES = 6,         /* IHT iterations of those fits as fit.jl counts them (one score ends each -- except a fit's last, see [14]) */
        MIH_CNT_MAX_LANE_SLOTS = 7, /* most fits in flight on ONE lane */
        MIH_CNT_INIT_SCORES = 8,    /* initial scores (init_iht_indices!, one per fit): rode a pass or were served by a copy */
        MIH_CNT_RESIDENT_STEPS = 9, /* iht_one_step! calls that ran resident on the device (step_mode 0; single fits and sessions) */
@@ -369,7 +369,8 @@ enum { MIH_CNT_LANES = 0,          /* lock-step lanes started (summed over calls
        MIH_CNT_RESIDENT_HANDBACKS = 11, /* steps the device handed back to the host-driven path (_choose! ties, lists beyond its buffers) */
        MIH_CNT_RESIDENT_DIRECT = 12, /* attempts whose projection was queued as a direct gather (threshold forecast, verified) */
        MIH_CNT_RESIDENT_REDOS = 13,  /* ... of which the forecast failed: re-queued with the two histogram sweeps */
-       MIH_PROFILE_NCOUNTERS = 14 };
+       MIH_CNT_SKIPPED_LAST_SCORES = 14, /* lock-step fits that converged: their last step's score (which the reference computes and never reads) was not computed */
+       MIH_PROFILE_NCOUNTERS = 15 };
 int mih_profile_enable(const mih_mat *h, int on);
 /* synchronises the recorded launches; totals since the last reset */
 int mih_profile_read(const mih_mat *h, double *xtv_kernel_ms, int64_t *xtv_launches, int reset);
