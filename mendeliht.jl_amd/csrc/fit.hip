@@ -1811,6 +1811,7 @@ struct CvFit {
     void release() { if (v && pool) pool->push_back(std::move(v)); v.reset(); }
     const uint8_t *train = nullptr;  // training mask of its fold (owned by the driver, shared by the fold's fits); null: all rows
     int64_t out_index = 0;
+    size_t qidx = 0;         // its number in the lanes' queue (CvQueue)
     int init_key = -1;       // fits with the same key >= 0 have the same initial residual (same training rows; the model size
                              // enters only after the first score): one of them rides the pass, the others copy its X'r
     int iter = 1, nbt = 0;
@@ -1915,6 +1916,51 @@ struct CvChains {
     std::vector<double> r;                       // r[c]: what the chain's next fit starts from
 };
 
+// The queue the lanes draw their fits from.  Plain order (the caller's: fold-major) until something is known; then longest first:
+// the fits of a cross-validation that share a model size k take nearly the same number of iterations in every fold (5 .. 17 at
+// configs[3], the same to within one or two across the folds), so once a fit of some k has finished, the remaining fits of that
+// k have a forecast -- and a k none of whose fits has finished yet is one whose first fit is STILL RUNNING: the longest kind.
+// Unknown first, then by descending forecast, ties in the caller's order.  The order changes which fits share a pass, never a
+// result (every fit is independent of its company: DESIGN.md 3.4).  The longest fits then start early and the tail, where the
+// passes run half empty, is short.
+struct CvQueue {
+    std::mutex mu;
+    size_t total = 0, ntaken = 0;
+    std::vector<char> taken;
+    std::vector<int> key;            // key[i]: what fit i shares its length with (the index of its k in the path); empty: plain order
+    std::vector<int> seen;           // seen[key]: most iterations a finished fit of that key took (0: none finished)
+    bool stop = false;               // an error somewhere: hand out nothing more
+    void init(size_t n, std::vector<int> keys)
+    {
+        total = n; ntaken = 0; taken.assign(n, 0); key = std::move(keys);
+        int kmax = -1; for (int v : key) kmax = std::max(kmax, v);
+        seen.assign((size_t)(kmax + 1), 0);
+    }
+    bool pick(size_t *out)
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (stop || ntaken >= total) return false;
+        size_t best = total; long bestp = -1;
+        for (size_t i = 0; i < total; ++i) {
+            if (taken[i]) continue;
+            const long pr = key.empty() ? 0 : (seen[(size_t)key[i]] == 0 ? (1l << 30) : (long)seen[(size_t)key[i]]);
+            if (pr > bestp) { bestp = pr; best = i; }
+            if (key.empty()) break;
+        }
+        taken[best] = 1; ++ntaken;
+        *out = best;
+        return true;
+    }
+    void report(size_t i, int iterations)
+    {
+        if (key.empty()) return;
+        std::lock_guard<std::mutex> g(mu);
+        int &sv = seen[(size_t)key[i]];
+        sv = std::max(sv, iterations);
+    }
+    void halt() { std::lock_guard<std::mutex> g(mu); stop = true; }
+};
+
 // Tail of the queue: once no new fits are left, the fits of both lanes thin out and two half-empty fused passes cost far more
 // than one fuller pass (6 + 6 residuals: 2 x 20.9 ms, 12 in one pass: 31.6 ms).  Lane 1 therefore hands ALL its fits over to
 // lane 0 as soon as they fit into lane 0's free slots, and ends.  A fit is handed over between two rounds, when everything it
@@ -1926,7 +1972,7 @@ struct CvHandover {
     std::atomic<int> active0{1 << 30};              // occupied slots of lane 0 (published once its view of the queue is drained)
 };
 
-static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t total, std::atomic<size_t> &next, int cap,
+static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t total, CvQueue &queue, int cap,
                           const MakeFit &make, XtvWork &xw, DevBuf<double> &R,
                           DevBuf<double> &DF /* (cap + init_slots) x p */, hipStream_t s, double *mses_raw, CvHandover *ho = nullptr, int lane_id = 0,
                           int init_slots = 0, const CvShared &shared = CvShared(), std::atomic<int> *inflight = nullptr,
@@ -1972,8 +2018,7 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
                 if (chains && cont_chain[(size_t)t] >= 0) { ch = cont_chain[(size_t)t]; i = chains->fits[(size_t)ch][cont_pos[(size_t)t]]; }
                 else {
                     if (drained) return MIH_OK;
-                    i = next.fetch_add(1);
-                    if (i >= total) { drained = true; return MIH_OK; }
+                    if (!queue.pick(&i)) { drained = true; return MIH_OK; }
                     if (chains) { ch = (int64_t)i; cont_pos[(size_t)t] = 0; i = chains->fits[(size_t)ch][0]; }
                 }
                 slot[t].reset(new CvFit());
@@ -1981,6 +2026,7 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
                 if (!pool.empty()) { slot[t]->v = std::move(pool.back()); pool.pop_back(); }
                 MIH_TRY(make(i, *slot[t], s, shared));
                 CvFit &f = *slot[t];
+                f.qidx = i;
                 if (chains) {
                     f.chain = ch; f.chain_pos = cont_pos[(size_t)t]; f.chain_r = &chains->r[(size_t)ch];
                     f.v->nb_r = chains->r[(size_t)ch];
@@ -2003,6 +2049,7 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
             CvFit &f = *slot[t];
             if (!f.done && f.iter >= pr.max_iter) MIH_TRY(cv_finish(f, mses_raw));        // fit.jl:170-179
             if (f.done) {                                                                 // refill this slot
+                if (!chains) queue.report(f.qidx, f.iter);                                // (how long fits of its model size take: CvQueue)
                 if (chains && f.chain >= 0 && f.chain_pos + 1 < chains->fits[(size_t)f.chain].size()) {
                     cont_chain[(size_t)t] = f.chain; cont_pos[(size_t)t] = f.chain_pos + 1;      // ... with the next fit of its chain
                 }
@@ -2132,7 +2179,8 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
 // queue: while one lane's host thread walks the small per-fit kernel chains between two passes (about 0.5 ms per
 // fit and round), the other lane's fused pass keeps the GPU busy.  Every fit is independent of the lane it runs in.
 static int cv_run_lanes(const mih_mat *h, const mih_fit_params &pr, size_t total, const MakeFit &make, double *mses_raw, int init_keys,
-                        const double *y_host, const double *z_host, int64_t q, CvChains *chains = nullptr)
+                        const double *y_host, const double *z_host, int64_t q, CvChains *chains = nullptr,
+                        const std::vector<int> &queue_keys = std::vector<int>() /* per fit: what it shares its length with (CvQueue) */)
 {
     if (chains) total = chains->fits.size();               // the queue hands out chains
     const XtvTune tune = xtv_tune(&pr);
@@ -2141,7 +2189,8 @@ static int cv_run_lanes(const mih_mat *h, const mih_fit_params &pr, size_t total
     int lanes = total > (size_t)width / 2 ? 2 : 1;  // more fits than one full pass holds: two lanes hide each other's per-fit chains (25 fits: 1.01 s against 1.06 s with one lane; 13 fits: 0.56 s with one lane, 0.65 s with two)
     if (const char *e = probe_env("MENDELIHT_CV_LANES")) { int v = atoi(e); if (v >= 1 && v <= 4) lanes = (int)std::min<size_t>((size_t)v, total); }
     const int cap = (int)std::min<size_t>((size_t)std::max(1, width / lanes), (total + lanes - 1) / lanes);
-    std::atomic<size_t> next{0};
+    CvQueue queue;
+    queue.init(total, (chains || probe_env("MENDELIHT_CV_PLAIN_ORDER")) ? std::vector<int>() : queue_keys);
     CvHandover handover;
     std::atomic<int> inflight[2];
     inflight[0].store(0); inflight[1].store(0);
@@ -2175,7 +2224,7 @@ static int cv_run_lanes(const mih_mat *h, const mih_fit_params &pr, size_t total
                 hipStream_t ws = worker_stream(h, (lane_id % 2) * kWorkerStreamsPerLane + i);
                 if (ws) shared.streams.push_back(ws);
             }
-        return cv_run_rolling(h, pr, total, next, cap, make, xw, R, DF, s, mses_raw, merge_tail ? &handover : nullptr, lane_id, init_slots, shared, lanes == 2 ? inflight : nullptr, chains);
+        return cv_run_rolling(h, pr, total, queue, cap, make, xw, R, DF, s, mses_raw, merge_tail ? &handover : nullptr, lane_id, init_slots, shared, lanes == 2 ? inflight : nullptr, chains);
     };
     if (lanes == 1) return lane(0);
     std::vector<int> rcs((size_t)lanes, MIH_OK);
@@ -2184,7 +2233,7 @@ static int cv_run_lanes(const mih_mat *h, const mih_fit_params &pr, size_t total
     for (int g = 0; g < lanes; ++g)
         th.emplace_back([&, g]() {
             rcs[g] = lane(g);
-            if (rcs[g]) { char buf[512]; (void)mih_last_error(buf, sizeof(buf)); msgs[g] = buf; next.store(total); }   // the error text is thread-local
+            if (rcs[g]) { char buf[512]; (void)mih_last_error(buf, sizeof(buf)); msgs[g] = buf; queue.halt(); }   // the error text is thread-local
             if (rcs[g] && g == 0) { std::lock_guard<std::mutex> lk(handover.mu); handover.accepting = false; }
         });
     for (auto &t : th) t.join();
@@ -2311,7 +2360,9 @@ int mih_cv_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, con
         f.v->ib_shared = sh.ib; f.v->ib_key = fold;        // (a recycled IHTVariable may come from the other lane: re-point it)
         return MIH_OK;
     };
-    return cv_run_lanes(h, pr, mine.size(), make, mses_raw, nfolds, y, z, q, chained ? &chains : nullptr);
+    std::vector<int> keys;                                   // fits of one model size take about as long in every fold (CvQueue)
+    if (!chained) for (auto &fk : mine) keys.push_back((int)fk.second);
+    return cv_run_lanes(h, pr, mine.size(), make, mses_raw, nfolds, y, z, q, chained ? &chains : nullptr, keys);
 }
 
 int mih_fit_iht_path(const mih_mat *h, const mih_fit_params *prm, const double *y, const double *z, int64_t q,
