@@ -1,10 +1,15 @@
-// topk.hip -- project_k!(x, k) on the device (src/utilities.jl:553-559):
-// a = |k-th largest by magnitude|, then every |x_i| < a is zeroed; entries tied
-// with a are KEPT.  Radix select over the IEEE-754 bit pattern of |x| (monotone for
-// non-negative doubles, +Inf sorts last so the `zkeep` slots of vectorize!
-// (utilities.jl:313-314) always survive): 8 passes of 8 bits with integer
-// histograms (exact, order-independent => the selected support is reproducible),
-// then one threshold pass that also compacts the survivors.
+// topk.hip -- project_k!(x, k) on the device (src/utilities.jl:553-559): a = |k-th largest by magnitude|, then every |x_i| < a is
+// zeroed; entries tied with a are KEPT.  Keys are the IEEE-754 bit patterns of |x| (monotone for non-negative doubles, +Inf sorts
+// last so the `zkeep` slots of vectorize! (utilities.jl:313-314) always survive); all counting is in integers, so the selected
+// support is exact and reproducible.
+//   * the stand-alone / host-driven select (topk_project_device): TWO histogram sweeps of 11 bits each (exponent, then the top
+//     mantissa bits: k_hist11 / k_pick11) pin the threshold down to a 22-bit prefix, k_collect gathers everything at or above
+//     that prefix, and the host finishes among the few entries that share it (std::nth_element on the keys, ties kept).  Eight
+//     sweeps of 8 bits (k_hist / k_pick / k_threshold) remain as the fallback for massive ties (more prefix-sharers than the
+//     gather buffer holds).
+//   * a device-resident fit (fit.hip, resident.inc) does NOT come here: its select -- the same two sweeps or a verified direct
+//     gather, and the exact finish by rank counting in one workgroup -- never leaves the device (k_res_grad .. k_res_select).
+// Also here: the polled readback (SpinFlag / k_publish) and the pinned upload ring (HostStage / k_stage) of the host-driven step.
 #include "common.h"
 #include <chrono>
 #include <algorithm>

@@ -241,17 +241,25 @@ def test_julia_glue_ccalls_match_the_header():
 
 
 def test_julia_glue_has_the_file_level_wrappers():
-    """iht(plinkfile, k, d; ...) / cross_validate(plinkfile, d; ...) (src/wrapper.jl:52-120, 301-349) exist in the glue, build a
-    HipSnpLinAlg where the reference builds a SnpLinAlg, and reuse the reference's parsers."""
+    """iht(plinkfile, k, d; ...) / cross_validate(plinkfile, d; ...) (src/wrapper.jl:52-120, 301-349) are the REFERENCE's own
+    functions: the glue restates none of their parsing or file writing -- it adds methods of MendelIHT.fit_iht /
+    MendelIHT.cv_iht that are more specific than the reference's (x::SnpLinAlg{Float64} and its Transpose), which build the
+    device matrix from the SAME SnpArray with the SAME center / scale / impute switches and call the GPU methods."""
+    import re
     from conftest import ROOT
     jl = open(os.path.join(ROOT, "julia", "MendelIHTHip.jl")).read()
-    for sig in ("function iht(filename::AbstractString, k::Int, d::UnionAll;", "function cross_validate(filename::AbstractString, d::UnionAll;"):
-        assert sig in jl
-        body = jl[jl.index(sig):]
-        body = body[:body.index("\nend\n")]
-        assert "HipSnpLinAlg{Float64}(X.snparray; center=true, scale=true, impute=true" in body
-        for parser in ("MendelIHT.parse_genotypes", "MendelIHT.parse_phenotypes", "MendelIHT.parse_covariates", "MendelIHT.is_multivariate"):
-            assert parser in body, (sig, parser)
+    code = re.sub(r"#[^\n]*", "", jl)
+    for restated in ("writedlm", "parse_genotypes", "parse_phenotypes", "parse_covariates", "Estimated_beta", "cviht.summary"):
+        assert restated not in code, restated                      # the wrappers' bodies are not restated any more
+    for sig in ("function MendelIHT.fit_iht(y::AbstractVector{Float64}, x::SnpLinAlg{Float64}, z::AbstractVecOrMat{Float64}; kwargs...)",
+                "function MendelIHT.fit_iht(y::AbstractMatrix{Float64}, x::Transpose{Float64, <:SnpLinAlg{Float64}}, z::AbstractVecOrMat{Float64}; kwargs...)",
+                "function MendelIHT.cv_iht(y::AbstractVector{Float64}, x::SnpLinAlg{Float64}, z::AbstractVecOrMat{Float64}; kwargs...)",
+                "function MendelIHT.cv_iht(y::AbstractMatrix{Float64}, x::Transpose{Float64, <:SnpLinAlg{Float64}}, z::AbstractVecOrMat{Float64}; kwargs...)"):
+        assert sig in jl, sig
+    assert "HipSnpLinAlg{Float64}(x.s; center=x.center, scale=x.scale, impute=x.impute, device=device)" in jl
+    assert "const hip_iht = MendelIHT.iht" in jl and "const hip_cross_validate = MendelIHT.cross_validate" in jl
+    # the reference's methods these specialise (src/fit.jl:60-63, src/cross_validation.jl:60-63): x::AbstractMatrix{T}
+    assert "Tuple{AbstractVecOrMat{Float64}, AbstractMatrix{Float64}, AbstractVecOrMat{Float64}}" in jl
 
 
 def test_bench_starts_its_own_ranks():
