@@ -10,8 +10,10 @@ sub, libname, fdb, wdb, n, p = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4
 def mean_counter(db, counter):
     cur = sqlite3.connect(db).cursor()
     per, names = {}, set()
-    for did, kname, cname, val in cur.execute("select dispatch_id, name, counter_name, counter_value from pmc_events"):
-        if sub in kname and cname == counter:
+    for did, kname, cname, val, dur in cur.execute("select dispatch_id, name, counter_name, counter_value, duration from pmc_events"):
+        # (round 5) launches of a device-resident fit are gated: one queued behind a step that turned out to need backtracking
+        # does nothing (a few microseconds, no traffic) -- only launches that ran (> 1 ms) are averaged
+        if sub in kname and cname == counter and float(dur) > 1e6:
             per[did] = per.get(did, 0.0) + float(val)
             names.add(kname.split("(")[0])
     return sum(per.values()) / len(per), len(per), sorted(names)
