@@ -123,7 +123,14 @@ int mih_xtv_batched(const mih_mat *h, const double *R, int m, double *OUT);
  *   4908 8 base-49 FP6 digits, |R| < 2^43, FOUR residuals per operand: opt-in fast mode for fused multi-RHS
  *        passes (cv_iht, multivariate, init_beta); relative error of X'r about 2^-43 max|r| / |r|_rms ~ 1e-12.
  *   1308 8 base-13 FP4 digits, |R| < 2^27, four per operand (~15 % faster than 4908, error ~1e-7).
- * A result never depends on which other residuals share a pass or on the kernel shape, only on the format. */
+ * A result never depends on which other residuals share a pass or on the kernel shape, only on the format.
+ * What the fixed point costs: the quantum is 2^-54 max|r| (2^-53 at worst), so entry r_i keeps 54 + log2(|r_i| / max|r|) bits, and the
+ * error of a column's X'r is at most sum_i g_ij 2^-54 max|r| (plus 64 ulp of the result for the f64 recombination) -- for residuals
+ * without heavy tails that is tighter than an n-term f64 dot product.  With ONE entry 10^8 x the rest the columns that carry it are
+ * still f64-grade relative to their result; the columns that do not keep 27 bits of the other entries: relative error up to ~2e-7
+ * there (numpy's pairwise sum keeps 1e-16).  A Poisson fit with a planted count of 500 among counts of ~1 (9 bits to the outlier)
+ * keeps the CPU restatement's support, iteration and backtracking log, its loglikelihood trace to 5e-8.
+ * (tests/test_gpu_parity.py: test_xtv_fixed_point_under_adversarial_dynamic_range, test_poisson_fit_with_a_planted_count_outlier) */
 int mih_xtv_batched_fmt(const mih_mat *h, const double *R, int m, int digits, double *OUT);
 /* out = sum_t x[:, idx[t]] * val[t]  -- the column loops of update_xb!
  * (src/utilities.jl:98-106) and iht_stepsize! (:731-739); idx 0-based. */
