@@ -638,6 +638,30 @@ def main():
                     "lockstep": cnt1, "kernels": cst["kernels"], "roofline": cv_roofline(cst)}
             if (n, p) == (500_000, 1_000_000) and best_k != CV_PLANTED_K:
                 failures.append(f"cv_iht selected k = {best_k}, the planted model has {CV_PLANTED_K} effects")
+            solo["dtype"] = DTYPE
+            # the same cross-validation with xtv_digits = -1: every residual whose max |r| <= 128 rms(r) is scored in the 43-bit format
+            # (all of them here: |y - mu| < 1), four per operand instead of three
+            t0 = time.perf_counter()
+            m.cv_iht(yb, x, None, path=path, q=5, folds=folds, verbose=False, return_raw=True, d=m.Bernoulli(), l=m.LogitLink(), xtv_digits=-1)
+            m.profile_counters(x, reset=True)
+            m.profile_read(x, reset=True)
+            m.profile_enable(x, True)
+            t0 = time.perf_counter()
+            mseA, rawA = m.cv_iht(yb, x, None, path=path, q=5, folds=folds, verbose=False, return_raw=True, d=m.Bernoulli(), l=m.LogitLink(),
+                                  xtv_digits=-1)
+            dtA = time.perf_counter() - t0
+            m.profile_enable(x, False)
+            cstA = pass_stats(m, x, m.profile_passes(x, reset=True))
+            cntA = m.profile_counters(x, reset=True)
+            solo["auto_digits"] = {
+                "what": "mih_fit_params::xtv_digits = -1: per residual, the 43-bit fixed-point format (8 base-49 FP6 digits, four residuals per "
+                        "operand) when max|r| <= 128 rms(r), the 54-bit format otherwise; warm-up + 1 run",
+                "dtype": "f64 results from residuals rounded to 43 bits of max|r| where the residual's range allows it (else 54 bits); exact "
+                         "accumulation on the matrix cores, f64 recombination",
+                "cv_iht_s": dtA, "fits_per_s": 100.0 / dtA, "best_k": int(np.argmin(mseA)) + 1, "fused_passes": cstA["launches"],
+                "residuals_scored_by_passes": cstA["residuals"], "residuals_in_the_43_bit_format": cntA["residuals_43bit"],
+                "xtv_kernel_ms_per_residual_scored": cstA["ms_sum"] / max(cstA["residuals"], 1), "kernels": cstA["kernels"],
+                "largest_relative_difference_of_a_loss_to_the_54_bit_run": float(np.max(np.abs(rawA - raw1) / np.abs(raw1)))}
         if world == 1:
             out["cv_iht"] = solo
         else:

@@ -217,7 +217,14 @@ typedef struct mih_fit_params {
                                  memory_efficient=false for it, the device builds the n x k panel on the fly) */
     int32_t  xtv_digits;      /* fixed-point format of the residual in this call's X'r passes (no reference counterpart):
                                  0 = library default; 4910, 4908, 1316, 1308, 428 -- see mih_xtv_batched_fmt.  A property
-                                 of the CALL: concurrent fits on one matrix may use different formats. */
+                                 of the CALL: concurrent fits on one matrix may use different formats.
+                                 -1 = auto, for the lock-step drivers (mih_cv_iht, mih_fit_iht_path) with a GLM link
+                                 (Bernoulli / Poisson / NegBin / Gamma / InverseGaussian: the reference tolerance there is
+                                 1e-4): every residual is looked at on its own -- if max |r| <= 128 rms(r) it is scored in the
+                                 43-bit format (4908: four residuals per operand, ~19 % less pass time at configs[3]; its
+                                 rounding then stays ~1e-11 of a column's X'r), otherwise in the 54-bit format.  The choice
+                                 depends on that residual alone, so a fit still gives the same bits whatever its company.
+                                 Normal fits, single fits, multivariate fits and initial scores: as 0. */
     /* The reference's RANDOM tie-break, _choose! (src/utilities.jl:444-458, src/multivariate.jl:310-351): when a projection
      * leaves more than k non-zero effects (exact ties in |b|) the reference removes the excess at random with the caller's
      * RNG.  NULL: the library removes the smallest |b| (ties: highest index) and raises choose_fired in the result.
@@ -377,7 +384,8 @@ enum { MIH_CNT_LANES = 0,          /* lock-step lanes started (summed over calls
        MIH_CNT_RESIDENT_DIRECT = 12, /* attempts whose projection was queued as a direct gather (threshold forecast, verified) */
        MIH_CNT_RESIDENT_REDOS = 13,  /* ... of which the forecast failed: re-queued with the two histogram sweeps */
        MIH_CNT_SKIPPED_LAST_SCORES = 14, /* lock-step fits that converged: their last step's score (which the reference computes and never reads) was not computed */
-       MIH_PROFILE_NCOUNTERS = 15 };
+       MIH_CNT_RESIDUALS_43BIT = 15, /* xtv_digits = -1: residuals the lock-step drivers scored in the 43-bit format (the rest: 54-bit) */
+       MIH_PROFILE_NCOUNTERS = 16 };
 int mih_profile_enable(const mih_mat *h, int on);
 /* synchronises the recorded launches; totals since the last reset */
 int mih_profile_read(const mih_mat *h, double *xtv_kernel_ms, int64_t *xtv_launches, int reset);

@@ -115,7 +115,7 @@ class _PassRecord(C.Structure):
 
 
 PROFILE_COUNTERS = ("lanes", "max_in_flight", "handovers", "shared_init", "rounds", "fits", "scores", "max_lane_slots", "init_scores",
-                    "resident_steps", "resident_attempts", "resident_handbacks", "resident_direct", "resident_redos", "skipped_last_scores")
+                    "resident_steps", "resident_attempts", "resident_handbacks", "resident_direct", "resident_redos", "skipped_last_scores", "residuals_43bit")
 
 _PROGRESS = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double)
 
@@ -657,7 +657,7 @@ class IHTSession:
             pass
 
 
-_XTV_FORMATS = (0, 4910, 4908, 1316, 1308, 428)
+_XTV_FORMATS = (0, -1, 4910, 4908, 1316, 1308, 428)
 _default_digits = 0
 
 
@@ -670,14 +670,14 @@ def set_xtv_digits(digits=0):
     with every call (mih_fit_params::xtv_digits, mih_xtv_batched_fmt), so concurrent calls may differ."""
     global _default_digits
     if int(digits) not in _XTV_FORMATS:
-        raise ArgumentError("residual format must be 0 (default), 4910, 4908, 1316, 1308 or 428")
+        raise ArgumentError("residual format must be 0 (default), -1 (auto), 4910, 4908, 1316, 1308 or 428")
     _default_digits = int(digits)
 
 
 def _digits(xtv_digits=None):
     d = _default_digits if xtv_digits is None else int(xtv_digits)
     if d not in _XTV_FORMATS:
-        raise ArgumentError("residual format must be 0 (default), 4910, 4908, 1316, 1308 or 428")
+        raise ArgumentError("residual format must be 0 (default), -1 (auto), 4910, 4908, 1316, 1308 or 428")
     return d
 
 

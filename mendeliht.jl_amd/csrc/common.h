@@ -417,6 +417,9 @@ struct XtvWork {            // scratch for one in-flight X'r
     int stream_tag = 0;        // which lock-step lane launches on this workspace (profile records)
     const int32_t *gate = nullptr; int32_t gate_val = 0;   // see DigitMode::gate; set by the caller around one xtv_device call
     bool stats_done = false;   // ... whose residual statistics (scal) the caller has computed already (k_res_stats, fit.hip)
+    // xtv_digits = -1 (auto): the lock-step drivers score a residual whose max |r| / rms(r) is small in the 43-bit format, the others
+    // in the 54-bit one -- per RESIDUAL (a fit's bits never depend on its company); use_alt selects the format of ONE xtv_device call
+    DigitMode dm_alt = {49, 8, 4, 8, 42, 18}; bool has_alt = false, use_alt = false;
     XtvSupportHook hook;       // ... and whose finalize kernel also serves the support of the iterate
     XtvStatsHook shook;        // ... and whose digit kernel finishes those statistics
 };

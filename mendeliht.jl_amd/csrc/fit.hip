@@ -331,6 +331,42 @@ __global__ void k_clamp_pm20(double *__restrict__ x, int64_t n)
     x[i] = a < -20.0 ? -20.0 : (a > 20.0 ? 20.0 : a);
 }
 
+// xtv_digits = -1: may this residual ride the 43-bit format?  max |r| and sum r^2 per 256-row block, then one workgroup: yes iff
+// max |r| <= 128 rms(r) (rms over all n rows; held-out rows count as zeros, which only makes the test stricter) -- the format's
+// quantum 2^-43 max|r| then stays below 2^-36 rms(r) per entry, ~1e-11 of a column's X'r.  Fixed order: a fit's answer is its own.
+constexpr double kAutoDigitsRatio = 128.0;
+__global__ void __launch_bounds__(256)
+k_r_guard(const double *__restrict__ r, int64_t n, double *__restrict__ partial /* [blocks][2] */)
+{
+    __shared__ double smax[256], ssum[256];
+    const int64_t i = blockIdx.x * 256ll + threadIdx.x;
+    const double x = i < n ? r[i] : 0.0;
+    smax[threadIdx.x] = fabs(x); ssum[threadIdx.x] = x * x;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) { smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + k]); ssum[threadIdx.x] += ssum[threadIdx.x + k]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { partial[2 * blockIdx.x] = smax[0]; partial[2 * blockIdx.x + 1] = ssum[0]; }
+}
+__global__ void __launch_bounds__(256)
+k_r_guard_final(const double *__restrict__ partial, int nblocks, int64_t n, double *__restrict__ out /* [0] = 1.0: the 43-bit format will do */)
+{
+    __shared__ double smax[256], ssum[256];
+    double mx = 0.0, sm = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) { mx = fmax(mx, partial[2 * b]); sm += partial[2 * b + 1]; }
+    smax[threadIdx.x] = mx; ssum[threadIdx.x] = sm;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) { smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + k]); ssum[threadIdx.x] += ssum[threadIdx.x + k]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double rms = sqrt(ssum[0] / (double)n);
+        out[0] = (smax[0] > 0.0 && smax[0] <= kAutoDigitsRatio * rms && smax[0] < 1.0e300) ? 1.0 : 0.0;
+    }
+}
+
 __global__ void k_unvec(const double *__restrict__ full, const double *__restrict__ weight, int64_t p,
                         double *__restrict__ df)
 {
@@ -707,6 +743,17 @@ struct IhtVar {
         MIH_TRY(resid_only());
         MIH_TRY(xtv_device(h, xtv, r.p, 1, df.p, s));
         return score_post();
+    }
+    // xtv_digits = -1 in a lock-step driver: does the residual just formed qualify for the 43-bit format?  (GLM links only: the
+    // reference's tolerance for them is 1e-4, north_star; Normal / Identity fits keep the 54-bit format.)
+    bool auto_digits() const { return batched && tune.digits == -1 && dist != MIH_NORMAL; }
+    int residual_rides_43_bits(bool *yes)
+    {
+        hipLaunchKernelGGL(k_r_guard, dim3(nb), dim3(256), 0, s, r.p, n, red.p);
+        hipLaunchKernelGGL(k_r_guard_final, dim3(1), dim3(256), 0, s, red.p, nb, n, scal.p);
+        MIH_TRY(readback(scal.p, 1));
+        *yes = hpin.p[0] == 1.0;
+        return MIH_OK;
     }
     int resid_only()
     {
@@ -1812,6 +1859,7 @@ struct CvFit {
     const uint8_t *train = nullptr;  // training mask of its fold (owned by the driver, shared by the fold's fits); null: all rows
     int64_t out_index = 0;
     size_t qidx = 0;         // its number in the lanes' queue (CvQueue)
+    bool fast43 = false;     // xtv_digits = -1: this round's residual rides the 43-bit format (IhtVar::residual_rides_43_bits)
     int init_key = -1;       // fits with the same key >= 0 have the same initial residual (same training rows; the model size
                              // enters only after the first score): one of them rides the pass, the others copy its X'r
     int iter = 1, nbt = 0;
@@ -1833,13 +1881,27 @@ static int cv_batched_xtv(const mih_mat *h, XtvWork &xw, std::vector<CvFit *> &f
 {
     const int m = (int)fits.size();
     if (m == 0) return MIH_OK;
+    // xtv_digits = -1: the residuals that qualified for the 43-bit format ride passes of their own (four per operand instead of
+    // three); the others -- and every initial score -- the 54-bit passes.  Which group a residual is in depends on itself alone.
+    std::vector<CvFit *> order;
+    order.reserve((size_t)m);
+    for (CvFit *f : fits) if (!(xw.has_alt && f->fast43)) order.push_back(f);
+    const int m54 = (int)order.size();
+    for (CvFit *f : fits) if (xw.has_alt && f->fast43) order.push_back(f);
     for (int t = 0; t < m; ++t) {
-        MIH_TRY(fit_to_lane(*fits[t], s));                 // its residual is ready
-        MIH_HIP(hipMemcpyAsync(R.p + (size_t)t * h->n, fits[t]->v->r.p, sizeof(double) * h->n, hipMemcpyDeviceToDevice, s));
+        MIH_TRY(fit_to_lane(*order[(size_t)t], s));                 // its residual is ready
+        MIH_HIP(hipMemcpyAsync(R.p + (size_t)t * h->n, order[(size_t)t]->v->r.p, sizeof(double) * h->n, hipMemcpyDeviceToDevice, s));
     }
-    MIH_TRY(xtv_device(h, xw, R.p, m, DF.p, s));
+    if (m54) MIH_TRY(xtv_device(h, xw, R.p, m54, DF.p, s));
+    if (m > m54) {
+        xw.use_alt = true;
+        const int rc = xtv_device(h, xw, R.p + (size_t)m54 * h->n, m - m54, DF.p + (size_t)m54 * h->p, s);
+        xw.use_alt = false;
+        MIH_TRY(rc);
+        h->prof->count(MIH_CNT_RESIDUALS_43BIT, m - m54);
+    }
     for (int t = 0; t < m; ++t)
-        MIH_HIP(hipMemcpyAsync(fits[t]->v->df.p, DF.p + (size_t)t * h->p, sizeof(double) * h->p, hipMemcpyDeviceToDevice, s));
+        MIH_HIP(hipMemcpyAsync(order[(size_t)t]->v->df.p, DF.p + (size_t)t * h->p, sizeof(double) * h->p, hipMemcpyDeviceToDevice, s));
     return MIH_OK;
 }
 
@@ -2073,6 +2135,8 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
                 MIH_TRY(cv_finish(f, mses_raw));                                          // fit.jl:197-203
                 continue;                                                                 // (f.done: the slot is refilled above)
             }
+            f.fast43 = false;
+            if (v.auto_digits()) MIH_TRY(v.residual_rides_43_bits(&f.fast43));
             outs[(size_t)t] = SlotOut{&f, 0};
             return MIH_OK;
         }
@@ -2184,7 +2248,7 @@ static int cv_run_lanes(const mih_mat *h, const mih_fit_params &pr, size_t total
 {
     if (chains) total = chains->fits.size();               // the queue hands out chains
     const XtvTune tune = xtv_tune(&pr);
-    if (!xtv_digits_valid(tune.digits)) { set_error("residual format must be 0 (default), 4910, 4908, 1316, 1308 or 428"); return MIH_BAD_ARG; }
+    if (!xtv_digits_valid(tune.digits)) { set_error("residual format must be 0 (default), -1 (auto in lock-step drivers), 4910, 4908, 1316, 1308 or 428"); return MIH_BAD_ARG; }
     const int width = xtv_lockstep_width(h, tune);
     int lanes = total > (size_t)width / 2 ? 2 : 1;  // more fits than one full pass holds: two lanes hide each other's per-fit chains (25 fits: 1.01 s against 1.06 s with one lane; 13 fits: 0.56 s with one lane, 0.65 s with two)
     if (const char *e = probe_env("MENDELIHT_CV_LANES")) { int v = atoi(e); if (v >= 1 && v <= 4) lanes = (int)std::min<size_t>((size_t)v, total); }

@@ -1363,6 +1363,7 @@ constexpr int kStatBlocks = 64;
 static bool digit_mode(int id, DigitMode &dm)
 {
     switch (id) {
+    case -1:                                                  // auto (lock-step drivers): 4910, and 4908 for the residuals whose range allows it
     case 0:
     case 4910: dm = {49, 10, 3, 10, 53, 18}; return true;    // FP6, three residuals per operand, |R| < 2^54
     case 4908: dm = {49, 8, 4, 8, 42, 18}; return true;      // FP6, four per operand, |R| < 2^43 (opt-in fast mode)
@@ -1474,7 +1475,7 @@ static int xtv_pass_residuals(const DigitMode &dm, const XtvTune &tn)
 static void choose_mode(const mih_mat *h, const XtvTune &tn, bool batched, DigitMode &dm)
 {
     digit_mode(tn.digits, dm);
-    if (tn.digits == 0) {
+    if (tn.digits == 0 || tn.digits == -1) {
         // Library default.  The workspace of a single fit scores one residual per pass: 28 sparse base-4 digit
         // columns make the fastest single-operand pass (17.86 ms against 17.99 ms for 16 base-13 columns and
         // 18.4 ms for FP6 planes at n=500k, p=1M; tools/sweep_fp6_single.py).  Every fused multi-RHS context
@@ -1501,9 +1502,11 @@ int xtv_work_init(const mih_mat *h, XtvWork &w, int m, const XtvTune &tune, bool
 {
     w.tune = tune;
     if (h->kind != 0) return MIH_OK;
-    if (!xtv_digits_valid(tune.digits)) { set_error("residual format must be 0 (default), 4910, 4908, 1316, 1308 or 428"); return MIH_BAD_ARG; }
+    if (!xtv_digits_valid(tune.digits)) { set_error("residual format must be 0 (default), -1 (auto in lock-step drivers), 4910, 4908, 1316, 1308 or 428"); return MIH_BAD_ARG; }
     int64_t nblk = h->nbp * 2;
     choose_mode(h, tune, batched, w.dm);
+    w.has_alt = tune.digits == -1 && batched && w.dm.base == 49 && w.dm.ndig == 10;      // (a matrix too tall for FP6 slices stepped down: no 43-bit twin)
+    w.use_alt = false;
     if (w.dm.base == 49 && tune.variant >= 0) {         // only an explicitly requested FP6 format can get here (measurement build)
         set_error("the FP6 residual formats need the default kernel (variant -1)");
         return MIH_BAD_ARG;
@@ -1561,7 +1564,7 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
     if (splits <= 0) splits = auto_splits(h, tn);
     // exactness of the f32 accumulators: |g/2 * d/2| <= 1 (base 4) or 4 (base 13) in units of 1/4, so a row
     // slice may hold at most 2^22 / 2^20 rows
-    DigitMode dm = w.dm;
+    DigitMode dm = (w.use_alt && w.has_alt) ? w.dm_alt : w.dm;
     dm.lay16 = xtv_lay16(dm, tn);
     const int64_t need = (h->n_pad + (1ll << dm.rows_log2) - 1) >> dm.rows_log2;
     if (need > w.splits_cap) { set_error("n = %lld rows needs more than %d row slices for exact accumulation", (long long)h->n, w.splits_cap); return MIH_BAD_DIM; }

@@ -2140,6 +2140,60 @@ def test_poisson_fit_with_a_planted_count_outlier(mih, oracle, normal_pair):
         np.testing.assert_allclose(res.trace["logl"], o["logl_trace"], rtol=1e-6)
 
 
+def test_auto_digit_mode_in_the_lockstep_drivers(mih, oracle):
+    """ xtv_digits = -1: the lock-step drivers score a residual of a GLM fit in the 43-bit format when ITS
+    max |r| / rms(r) <= 128 and in the 54-bit format otherwise -- per residual, so a fit's bits do not depend on its company.
+    Bernoulli / Logit (every residual qualifies: |y - mu| < 1): all 40 losses within 1e-9 of the oracle, the eight shards add up
+    to the single-rank matrix bit for bit; Poisson with planted count outliers: some residuals qualify and some do not, losses
+    within 1e-9 of the oracle; Normal fits and single fits: the default format, bit for bit."""
+    n, p = 20_000, 2_000
+    x, yb, folds = _config3_problem(mih, n, p)
+    ox = oracle.Mat.from_bed_columns(x.export_bed(), n)
+    path = list(range(3, 11))
+    kw = dict(path=path, q=5, folds=folds, verbose=False, return_raw=True, d=mih.Bernoulli(), l=mih.LogitLink())
+    mih.profile_enable(x, True)
+    mih.profile_counters(x, reset=True)
+    mse_a, raw_a = mih.cv_iht(yb, x, None, xtv_digits=-1, **kw)
+    cnt = mih.profile_counters(x, reset=True)
+    mse_d, raw_d = mih.cv_iht(yb, x, None, **kw)
+    cnt_d = mih.profile_counters(x, reset=True)
+    mih.profile_enable(x, False)
+    assert cnt["residuals_43bit"] > 200 and cnt_d["residuals_43bit"] == 0
+    assert not np.array_equal(raw_a, raw_d)                               # it really is the other arithmetic ...
+    np.testing.assert_allclose(raw_a, raw_d, rtol=1e-10)                  # ... to ~1e-12
+    omse, oraw = oracle.cv_iht(ox, yb, None, path=path, q=5, folds=folds, dist="bernoulli", link="logit")
+    np.testing.assert_allclose(raw_a, oraw, rtol=1e-9)
+    np.testing.assert_allclose(mse_a, omse, rtol=1e-9)
+    tot = np.zeros_like(raw_a)
+    for r in range(8):
+        tot += mih.cv_iht(yb, x, None, xtv_digits=-1, rank=r, world=8, **kw)[1]
+    assert np.array_equal(tot, raw_a)                                     # a fit's bits do not depend on which fits it rides with
+    # heavy tails: Poisson counts with planted outliers -- those fits' residuals fail the test and keep 54 bits
+    rng = np.random.default_rng(8)
+    supp = np.sort(rng.choice(p, 6, replace=False))
+    eta = x.xv_sparse(supp, rng.standard_normal(6) * 0.3)
+    yp = rng.poisson(np.exp(eta)).astype(float)
+    yp[rng.choice(n, 3, replace=False)] = 4000.0
+    kwp = dict(path=[2, 4, 6], q=3, folds=hash_folds(n, 3), verbose=False, return_raw=True, d=mih.Poisson(), l=mih.LogLink())
+    mih.profile_enable(x, True)
+    mih.profile_counters(x, reset=True)
+    _, raw_p = mih.cv_iht(yp, x, None, xtv_digits=-1, **kwp)
+    cntp = mih.profile_counters(x, reset=True)
+    passes = mih.profile_passes(x, reset=True)
+    mih.profile_enable(x, False)
+    scored = sum(q["residuals"] for q in passes)
+    assert 0 <= cntp["residuals_43bit"] < scored                          # (the outliers' residuals are 54-bit ones)
+    _, oraw_p = oracle.cv_iht(ox, yp, None, path=[2, 4, 6], q=3, folds=hash_folds(n, 3), dist="poisson", link="log")
+    np.testing.assert_allclose(raw_p, oraw_p, rtol=1e-6)
+    # Normal / Identity and single fits: -1 is the default format
+    yn = eta + 1.0 + rng.standard_normal(n)
+    kn = dict(path=[3, 6], q=3, folds=hash_folds(n, 3), verbose=False, return_raw=True)
+    assert np.array_equal(mih.cv_iht(yn, x, None, xtv_digits=-1, **kn)[1], mih.cv_iht(yn, x, None, **kn)[1])
+    a = mih.fit_iht(yb, x, None, k=6, d=mih.Bernoulli(), l=mih.LogitLink(), verbose=False, xtv_digits=-1)
+    b = mih.fit_iht(yb, x, None, k=6, d=mih.Bernoulli(), l=mih.LogitLink(), verbose=False)
+    assert np.array_equal(a.beta, b.beta) and a.iter == b.iter
+
+
 def test_fits_and_cv_at_full_row_count(mih, oracle):
     """n = 500 000 samples (BASELINE configs[2]/[3] row count) with a column count the oracle still finishes in
     seconds: fit_iht (Normal, Bernoulli) and a small cv_iht grid against the oracle -- n-vector reductions, the
