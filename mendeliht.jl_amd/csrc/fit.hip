@@ -1882,7 +1882,7 @@ static int cv_batched_xtv(const mih_mat *h, XtvWork &xw, std::vector<CvFit *> &f
     const int m = (int)fits.size();
     if (m == 0) return MIH_OK;
     // xtv_digits = -1: the residuals that qualified for the 43-bit format ride passes of their own (four per operand instead of
-    // three); the others -- and every initial score -- the 54-bit passes.  Which group a residual is in depends on itself alone.
+    // three); the others the 54-bit passes.  Which group a residual is in depends on itself alone.
     std::vector<CvFit *> order;
     order.reserve((size_t)m);
     for (CvFit *f : fits) if (!(xw.has_alt && f->fast43)) order.push_back(f);
@@ -2105,6 +2105,7 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
                         continue;
                     }
                 }
+                if (f.v->auto_digits()) MIH_TRY(f.v->residual_rides_43_bits(&f.fast43));      // (the initial residual: y - mu of the intercept)
                 outs[(size_t)t] = SlotOut{&f, 1};
                 return MIH_OK;
             }
