@@ -1768,11 +1768,21 @@ struct IhtVar {
                 }
             }
             if (!stepped) {
+                // the host-driven step.  debias! (fit.jl:188) and the convergence test (fit.jl:197) read b, b0, c, c0 only, so they run
+                // in front of the X'r pass that ends the step; a fit that converges here skips that pass (the reference computes the
+                // score inside iht_one_step! and never reads it) -- as the device-resident chain and the lock-step drivers do
                 best = save_prev(next_logl, best);
-                MIH_TRY(one_step(next_logl, prm->max_step, &nbt, &next_logl));
+                MIH_TRY(step_pre(next_logl, prm->max_step, &nbt, &next_logl));
                 if (debias && iter >= 5 && b.idx == b0.idx && !b.idx.empty())      // fit.jl:188: v.idx == v.idx0 && debias!(v)
                     MIH_TRY(debias_glm_device(h, b.idx.data(), (int64_t)b.idx.size(), y.p, dist, link, nb_r, b.val.data(), s));
                 sc = check_convergence();
+                if (iter >= prm->min_iter && sc < prm->tol) {
+                    if (std::isnan(next_logl)) { set_error("Loglikelihood function is NaN, aborting..."); return MIH_NAN_LOGL; }
+                    if (std::isinf(next_logl)) { set_error("Loglikelihood function is Inf, aborting..."); return MIH_INF_LOGL; }
+                } else {
+                    MIH_TRY(xtv_device(h, xtv, r.p, 1, df.p, s));
+                    MIH_TRY(step_post(next_logl));
+                }
             }
             if (lt) lt[nt] = next_logl;
             if (tt) tt[nt] = sc;

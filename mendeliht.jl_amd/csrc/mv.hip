@@ -824,8 +824,18 @@ struct MvVar {
             if (iter >= prm->max_iter) { best = save_prev(next_logl, best); MIH_TRY(save_best_model()); mm = iter; break; }
             best = save_prev(next_logl, best);
             int nbt = 0;
-            MIH_TRY(one_step(next_logl, prm->max_step, &nbt, &next_logl));
-            double sc = check_convergence();
+            // (round 5) check_convergence (multivariate.jl:475-483) reads B, B0, C, C0 only: it is evaluated in front of the X'R pass that
+            // ends the step, and a fit that converges here skips that pass -- the reference computes the score inside
+            // iht_one_step! and never reads it (26 ms of a 10-trait fit at configs[4])
+            MIH_TRY(step_pre(next_logl, prm->max_step, &nbt, &next_logl));
+            const double sc = check_convergence();
+            if (iter >= prm->min_iter && sc < prm->tol) {
+                if (std::isnan(next_logl)) { set_error("Loglikelihood function is NaN, aborting..."); return MIH_NAN_LOGL; }
+                if (std::isinf(next_logl)) { set_error("Loglikelihood function is Inf, aborting..."); return MIH_INF_LOGL; }
+            } else {
+                MIH_TRY(xtv_device(h, xtv, T1.p, r, DF.p, s));
+                MIH_TRY(step_post(next_logl));
+            }
             if (lt) lt[nt] = next_logl;
             if (tt) tt[nt] = sc;
             if (btt) btt[nt] = nbt;
@@ -1022,6 +1032,16 @@ int mih_cv_mv(const mih_mat *h, const mih_fit_params *prm, const double *Y, int6
                 if (f.done) { slot[t].reset(); continue; }
                 f.best = f.v->save_prev(f.next_logl, f.best);
                 MIH_TRY(f.v->step_pre(f.next_logl, pr.max_step, &f.nbt, &f.next_logl));
+                {   // (round 5) the convergence test needs nothing of the score that ends this step: a fit that converges is finished
+                    // without riding the pass, its slot is refilled in this same round (as in the univariate driver, fit.hip)
+                    const double sc = f.v->check_convergence();
+                    if (f.iter >= pr.min_iter && sc < pr.tol) {
+                        if (std::isnan(f.next_logl)) { set_error("Loglikelihood function is NaN, aborting..."); return MIH_NAN_LOGL; }
+                        if (std::isinf(f.next_logl)) { set_error("Loglikelihood function is Inf, aborting..."); return MIH_INF_LOGL; }
+                        MIH_TRY(finish(f));                                               // fit.jl:197-203
+                        continue;
+                    }
+                }
                 need.push_back(&f); fresh.push_back(0);
                 break;
             }
@@ -1047,10 +1067,8 @@ int mih_cv_mv(const mih_mat *h, const mih_fit_params *prm, const double *Y, int6
         for (size_t t = 0; t < need.size(); ++t) {
             MvFit *f = need[t];
             if (fresh[t]) { MIH_TRY(f->v->init_post()); continue; }
-            MIH_TRY(f->v->step_post(f->next_logl));
-            double sc = f->v->check_convergence();
-            if (f->iter >= pr.min_iter && sc < pr.tol) MIH_TRY(finish(*f));                    // fit.jl:197-203
-            else f->iter++;
+            MIH_TRY(f->v->step_post(f->next_logl));           // (the convergence test of this step ran in front of the pass)
+            f->iter++;
         }
     }
     return MIH_OK;

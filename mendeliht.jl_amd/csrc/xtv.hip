@@ -213,6 +213,18 @@ k_digits(const double *__restrict__ r, int64_t n, int64_t nblk, int m, DigitMode
         const unsigned long long aR = neg ? 0ull - (unsigned long long)R : (unsigned long long)R;
         uint32_t limb_hi = (uint32_t)(aR / 282475249ull), limb_lo = (uint32_t)(aR - (unsigned long long)limb_hi * 282475249ull);
         int carry = 0;
+        if (dm.base == 4) {
+            // (round 5) all 28 balanced base-4 digits at once: with d_t in {-2,-1,0,1}, R + sum_t 2 * 4^t = sum_t (d_t + 2) 4^t has the
+            // ORDINARY base-4 digits u_t = d_t + 2 in {0..3} -- the representation is unique, so these are the digits the division
+            // loop below produces -- and the FP4 (e2m1) code of d_t / 2 is a four-entry table: u = 0 -> -1.0 (1010), 1 -> -0.5 (1001),
+            // 2 -> 0, 3 -> +0.5 (0001).  No loop-carried dependency.
+            const unsigned long long U = (unsigned long long)R + 0x00AAAAAAAAAAAAAAull;
+            for (int t = 0; t < dm.ndig; ++t) {
+                const uint32_t u = (uint32_t)(U >> (2 * t)) & 3u;
+                const uint32_t code = (0x109Au >> (4u * u)) & 15u;
+                if (code) atomicOr(mine + t * 6 + dwd, code << sh);
+            }
+        } else
         for (int t = 0; t < dm.ndig; ++t) {
             int d;
             if (dm.base == 49) {
