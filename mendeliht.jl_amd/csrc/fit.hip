@@ -1436,6 +1436,7 @@ struct IhtVar {
         if (h->kind != 0 || comm || has_group || !ks.empty() || est_r != MIH_ESTR_NONE || debias || batched || prm->step_mode != 0) return MIH_OK;
         if (probe_env("MENDELIHT_NO_RESIDENT")) return MIH_OK;              // measurement build: A/B against the host-driven step
         if (xv.slots <= 0 || xv.slots > 160 * 32 || K < 1 || K > p + q || h->p >= (1ll << 40)) return MIH_OK;
+        if (K + 64 > kResMaxList) return MIH_OK;               // (k_res_select orders the survivors in LDS: models beyond ~2000 effects take the host-driven step)
         res_kcap = std::min<int64_t>(kcap, (int64_t)xv.coefA.n);
         MIH_TRY(rctl.alloc(1)); MIH_TRY(ridx.alloc((size_t)res_kcap * 3)); MIH_TRY(rval.alloc((size_t)res_kcap * 3));
         MIH_TRY(rslot.alloc((size_t)res_kcap * 4)); MIH_TRY(rhist.alloc(4096));
