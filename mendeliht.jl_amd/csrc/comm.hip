@@ -151,6 +151,23 @@ int comm_native_allreduce_on_stream(const mih_comm *c, double *buf_dev, int64_t 
     return MIH_OK;
 }
 
+// ... and the all-gather of a device-resident sharded step (every shard's top-K candidates of project_k!): device buffers on both
+// sides, queued on the fit's stream like the all-reduces above (same invariant: the chain that follows reads the result in stream
+// order, and the host issues the collectives of every rank in the same order).  -1: not the library's communicator / another device.
+int comm_native_allgather_on_stream(const mih_comm *c, const double *send_dev, double *recv_dev, int64_t count, hipStream_t s, int device)
+{
+    if (!c || c->allreduce != native_allreduce || c->user != (void *)c) return -1;
+    NativeComm *nc = static_cast<NativeComm *>(c->user);
+    if (device != nc->device) return -1;
+    const int rc = g_rccl.AllGather(send_dev, recv_dev, (size_t)count, kNcclFloat64, nc->comm, s);
+    if (rc != kNcclSuccess) return nccl_fail(rc, "ncclAllGather");
+    return MIH_OK;
+}
+bool comm_is_native(const mih_comm *c, int device)
+{
+    return c && c->allreduce == native_allreduce && c->user == (void *)c && static_cast<NativeComm *>(c->user)->device == device;
+}
+
 }  // namespace mih
 
 using namespace mih;

@@ -491,6 +491,8 @@ int  debias_glm_device(const mih_mat *h, const int64_t *idx_host, int64_t k, con
                        double nb_r, double *beta_out, hipStream_t s);
 // ncclAllReduce on the fit's own stream when `c` is the library's communicator (comm.hip); -1 otherwise
 int  comm_native_allreduce_on_stream(const mih_comm *c, double *buf_dev, int64_t count, int32_t op, hipStream_t s, int device);
+int  comm_native_allgather_on_stream(const mih_comm *c, const double *send_dev, double *recv_dev, int64_t count, hipStream_t s, int device);
+bool comm_is_native(const mih_comm *c, int device);       // the library's own RCCL communicator, on that device
 // rank_of[fold * npath + ik]: which rank of `world` evaluates that (fold, k) combination (mih_cv_assignment; fit.hip)
 void cv_assign(const int64_t *path, int64_t npath, int32_t nfolds, int32_t world, std::vector<int32_t> &rank_of);
 // initialize_beta! regressions for m response planes (fit.hip); shared by the univariate and multivariate fits

@@ -1426,6 +1426,7 @@ struct IhtVar {
     int res_epoch = 0; uint64_t res_seq = 0; int64_t res_kcap = 0;
     std::vector<uint64_t> res_out;                       // sequence numbers of the steps in flight, oldest first
     DevBuf<ResCtl> rctl; DevBuf<int64_t> ridx; DevBuf<double> rval; DevBuf<int32_t> rslot; DevBuf<uint32_t> rhist; DevBuf<uint64_t> rsel;
+    bool res_sharded = false; DevBuf<int64_t> rgidx; DevBuf<double> rgval, rmsg; PinBuf<double> rg_h;        // column shard: whole models, messages
     PinBuf<ResCtl> rctl_h; PinBuf<ResRecord> rrec; PinBuf<int64_t> ridx_h; PinBuf<double> rval_h; PinBuf<int32_t> rslot_h;
     struct ResRun { int64_t limit = 0, issued = 0, done = 0; int max_step = 3; };
 
@@ -1433,14 +1434,25 @@ struct IhtVar {
     {
         res_ok = false;
         const int64_t K = k + zkeepn;
-        if (h->kind != 0 || comm || has_group || !ks.empty() || est_r != MIH_ESTR_NONE || debias || batched || prm->step_mode != 0) return MIH_OK;
+        if (h->kind != 0 || has_group || !ks.empty() || est_r != MIH_ESTR_NONE || debias || batched || prm->step_mode != 0) return MIH_OK;
         if (probe_env("MENDELIHT_NO_RESIDENT")) return MIH_OK;              // measurement build: A/B against the host-driven step
-        if (xv.slots <= 0 || xv.slots > 160 * 32 || K < 1 || K > p + q || h->p >= (1ll << 40)) return MIH_OK;
+        // a column shard: only with the library's own communicator (its collectives are queued INSIDE the gated chain; callbacks of
+        // the host language need the host), no prior weights (the shards do not hold each other's), and a pool of candidates
+        // (world x K and the covariate tail) the second stage of the select can rank
+        res_sharded = comm != nullptr;
+        if (comm && (!comm_is_native(comm, h->device) || has_weight || (int64_t)comm->world * K + q > kResMaxInBin || K + 64 > kResShardList)) return MIH_OK;
+        if (xv.slots <= 0 || xv.slots > 160 * 32 || K < 1 || K > pg + q || h->p >= (1ll << 40)) return MIH_OK;
         if (K + 64 > kResMaxList) return MIH_OK;               // (k_res_select orders the survivors in LDS: models beyond ~2000 effects take the host-driven step)
         res_kcap = std::min<int64_t>(kcap, (int64_t)xv.coefA.n);
         MIH_TRY(rctl.alloc(1)); MIH_TRY(ridx.alloc((size_t)res_kcap * 3)); MIH_TRY(rval.alloc((size_t)res_kcap * 3));
         MIH_TRY(rslot.alloc((size_t)res_kcap * 4)); MIH_TRY(rhist.alloc(4096));
         MIH_TRY(rsel.alloc((size_t)kResCollectBlocks * (1 + 2 * kResCollectSlots)));
+        if (res_sharded) {
+            const size_t mlen = 2 + 2 * (size_t)K;
+            MIH_TRY(rgidx.alloc((size_t)res_kcap * 3)); MIH_TRY(rgval.alloc((size_t)res_kcap * 3));          // the two whole models + the shard's own survivors
+            MIH_TRY(rmsg.alloc(mlen * (size_t)(comm->world + 1)));
+            MIH_TRY(rg_h.alloc((size_t)res_kcap * 2, true));
+        }
         MIH_TRY(rctl_h.alloc(1, true)); MIH_TRY(rrec.alloc(kResRing, true));
         MIH_TRY(ridx_h.alloc((size_t)res_kcap * 3, true)); MIH_TRY(rval_h.alloc((size_t)res_kcap * 3, true)); MIH_TRY(rslot_h.alloc((size_t)res_kcap * 4, true));
         MIH_HIP(hipMemsetAsync(rhist.p, 0, sizeof(uint32_t) * 4096, s));
@@ -1456,6 +1468,13 @@ struct IhtVar {
         for (int i = 0; i < 2; ++i) { P.slot[i] = rslot.p + (size_t)i * res_kcap; P.fresh[i] = rslot.p + (size_t)(2 + i) * res_kcap; }
         P.gval = gval.p; P.coefA = xv.coefA.p; P.coefB = xv.coefB.p;
         P.hist = rhist.p; P.sel = rsel.p; P.sel_cap = 0; P.kcap = res_kcap; P.rec = rrec.p;
+        P.gidx[0] = P.gidx[1] = P.lc_idx = nullptr; P.gvals[0] = P.gvals[1] = P.lc_val = P.msg = P.msgs = nullptr; P.world = 1; P.rank = 0; P.col0 = 0;
+        if (res_sharded) {
+            for (int i = 0; i < 2; ++i) { P.gidx[i] = rgidx.p + (size_t)i * res_kcap; P.gvals[i] = rgval.p + (size_t)i * res_kcap; }
+            P.lc_idx = rgidx.p + 2 * (size_t)res_kcap; P.lc_val = rgval.p + 2 * (size_t)res_kcap;
+            P.msg = rmsg.p; P.msgs = rmsg.p + (2 + 2 * (size_t)(k + zkeepn));
+            P.world = comm->world; P.rank = comm->rank; P.col0 = col0;
+        }
         return P;
     }
     ResMat res_mat() const
@@ -1484,7 +1503,14 @@ struct IhtVar {
         if (!zero_list && b.idx != idx.idx) return MIH_BAD_ARG;
         const std::vector<int64_t> &lst = zero_list ? idx.idx : b.idx;
         const int64_t cnt = (int64_t)lst.size(), cb = (int64_t)best_b.idx.size();
-        if (cnt > res_kcap || cnt > xv.slots || cb > res_kcap) return MIH_BAD_ARG;
+        bool fits = !(cnt > res_kcap || cnt > xv.slots || cb > res_kcap);
+        if (res_sharded) {            // every shard or none: the chain's collectives must be issued by all (one exchange of a flag)
+            fits = fits && bg_ok && (int64_t)bg.idx.size() <= res_kcap;
+            double decline = fits ? 0.0 : 1.0;
+            MIH_TRY(allreduce_host(&decline, 1, 1));
+            fits = decline == 0.0;
+        }
+        if (!fits) return MIH_BAD_ARG;
         MIH_HIP(hipStreamSynchronize(s));                    // the pinned staging below may still be read by an earlier upload
         ResCtl &C = *rctl_h.p;
         std::memset(&C, 0, sizeof(C));
@@ -1510,6 +1536,18 @@ struct IhtVar {
         if (cb) {
             MIH_HIP(hipMemcpyAsync(ridx.p + 2 * res_kcap, ridx_h.p + 2 * res_kcap, sizeof(int64_t) * cb, hipMemcpyHostToDevice, s));
             MIH_HIP(hipMemcpyAsync(rval.p + 2 * res_kcap, rval_h.p + 2 * res_kcap, sizeof(double) * cb, hipMemcpyHostToDevice, s));
+        }
+        if (res_sharded) {            // the whole model of the iterate (every shard holds it: project_full_sharded)
+            const int64_t gn = (int64_t)bg.idx.size();
+            int64_t *gi = reinterpret_cast<int64_t *>(rg_h.p); double *gv = rg_h.p + res_kcap;
+            for (int64_t t = 0; t < gn; ++t) { gi[t] = bg.idx[(size_t)t]; gv[t] = bg.val[(size_t)t]; }
+            if (gn) {
+                MIH_HIP(hipMemcpyAsync(rgidx.p, gi, sizeof(int64_t) * gn, hipMemcpyHostToDevice, s));
+                MIH_HIP(hipMemcpyAsync(rgval.p, gv, sizeof(double) * gn, hipMemcpyHostToDevice, s));
+            }
+            const int64_t g2[2] = {gn, 0};
+            rg_cnt_h[0] = g2[0]; rg_cnt_h[1] = g2[1];
+            MIH_HIP(hipMemcpyAsync(rctl.p->gcnt, rg_cnt_h, sizeof(int64_t) * 2, hipMemcpyHostToDevice, s));
         }
         res_zero_list = zero_list; res_iter0 = iter_done; res_known = 0; res_fast_fails = 0;      // (no threshold on the device yet)
         res_out.clear();
@@ -1550,12 +1588,23 @@ struct IhtVar {
         best_b.idx.assign(ridx_h.p + 2 * res_kcap, ridx_h.p + 2 * res_kcap + cb);
         best_b.val.assign(rval_h.p + 2 * res_kcap, rval_h.p + 2 * res_kcap + cb);
         b0 = b; c0 = c; idc0 = idc;
+        if (res_sharded) {
+            const int64_t gn = C.gcnt[cur];
+            int64_t *gi = reinterpret_cast<int64_t *>(rg_h.p); double *gv = rg_h.p + res_kcap;
+            if (gn) {
+                MIH_HIP(hipMemcpy(gi, rgidx.p + (size_t)cur * res_kcap, sizeof(int64_t) * gn, hipMemcpyDeviceToHost));
+                MIH_HIP(hipMemcpy(gv, rgval.p + (size_t)cur * res_kcap, sizeof(double) * gn, hipMemcpyDeviceToHost));
+            }
+            bg.idx.assign(gi, gi + gn); bg.val.assign(gv, gv + gn); bg_ok = true;
+            b0g = bg; b0g_ok = true;
+        }
         if (next_logl) *next_logl = C.logl_cur;
         if (best) *best = C.best_logl;
         xv_cache_forget(); stage_forget(); spec_ok = false; df2_pending = false;
         return MIH_OK;
     }
     int64_t res_iter0 = 0;
+    int64_t rg_cnt_h[2] = {0, 0};
     // the X'r passes of the last `count` step chains were queued behind a kernel that closed the gate: they did nothing, and their
     // profile records (mih_profile_passes) go
     void res_dead_passes(int count)
@@ -1576,18 +1625,23 @@ struct IhtVar {
         hipLaunchKernelGGL(k_res_support, dim3(nblk(res_kcap)), dim3(256), 0, s, P, res_epoch, res_mat(), df.p);
         return MIH_OK;
     }
-    // start of a step: the best model so far, X_S df_S, the step-size denominator
+    // start of a step: the best model so far, X_S df_S, the step size.  Column shard: the shards' partial products and their
+    // shares of |df_S|^2 (element n) meet in ONE all-reduce queued on this stream, between the product and the step-size terms.
     int res_enqueue_front()
     {
         const ResPtrs P = res_ptrs(); const ResMat M = res_mat();
-        if (!res_fix())
+        if (!res_fix() && !res_sharded)
             hipLaunchKernelGGL(k_res_xgk<false>, dim3(nb), dim3(256), 0, s, P, res_epoch, M, z.p, xb.p, zc.p, mu.p, w.p, q, dist, link, nb_r, xgk.p, red.p);
         else {
             hipLaunchKernelGGL(k_res_xgk<true>, dim3(nb), dim3(256), 0, s, P, res_epoch, M, z.p, xb.p, zc.p, mu.p, w.p, q, dist, link, nb_r, xgk.p, red.p);
-            hipLaunchKernelGGL(k_res_missing, dim3(1), dim3(1024), 0, s, P, res_epoch, -1, 0, M, xgk.p);
+            if (res_fix()) hipLaunchKernelGGL(k_res_missing, dim3(1), dim3(1024), 0, s, P, res_epoch, -1, 0, M, xgk.p);
+            if (res_sharded) {
+                hipLaunchKernelGGL(k_res_sumsq, dim3(1), dim3(1), 0, s, P, res_epoch, xgk.p + n);
+                MIH_TRY(allreduce_dev(xgk.p, n + 1, 0));
+            }
             hipLaunchKernelGGL(k_res_stepsize, dim3(nb), dim3(256), 0, s, P, res_epoch, xgk.p, z.p, xb.p, zc.p, mu.p, w.p, n, q, dist, link, nb_r, red.p);
         }
-        hipLaunchKernelGGL(k_res_eta, dim3(1), dim3(256), 0, s, P, res_epoch, red.p, nb, q);
+        hipLaunchKernelGGL(k_res_eta, dim3(1), dim3(256), 0, s, P, res_epoch, red.p, nb, q, res_sharded ? xgk.p + n : (const double *)nullptr);
         return MIH_OK;
     }
     // one attempt of the step (attempt 0: the first, a >= 1: the a-th backtracking one): gradient step, projection, update_xb!,
@@ -1599,24 +1653,51 @@ struct IhtVar {
         const uint64_t zk = res_zkeep_mask();
         const int64_t len = p + q, groups = (J == 0) ? 1 : J;
         const uint64_t K = (uint64_t)(k + zkeepn);
+        // column shard: the shard selects among its own p columns (its top Kloc), the covariate tail and the threshold are judged
+        // over all shards in k_res_select_global, behind the all-gather of the shards' messages
+        const uint64_t Ksel = res_sharded ? (uint64_t)std::min<int64_t>((int64_t)K, p) : K;
+        const int64_t sel_len = res_sharded ? p : len;
         if (fast)            // the direct gather: the threshold of the last attempt `a` as forecast, verified by the select
-            hipLaunchKernelGGL(k_res_grad<true>, dim3(kResGradBlocks), dim3(256), 0, s, P, res_epoch, a, df.p, wp, p, q, zk, full.p);
+            hipLaunchKernelGGL(k_res_grad<true>, dim3(kResGradBlocks), dim3(256), 0, s, P, res_epoch, a, df.p, wp, p, q, zk, sel_len, full.p);
         else {
-            hipLaunchKernelGGL(k_res_grad<false>, dim3(kResGradBlocks), dim3(256), 0, s, P, res_epoch, a, df.p, wp, p, q, zk, full.p);
-            hipLaunchKernelGGL(k_res_hist2, dim3(kResHistBlocks), dim3(256), 0, s, P, res_epoch, a, full.p, len, K);
-            hipLaunchKernelGGL(k_res_collect, dim3(kResCollectBlocks), dim3(256), 0, s, P, res_epoch, a, full.p, len);
+            hipLaunchKernelGGL(k_res_grad<false>, dim3(kResGradBlocks), dim3(256), 0, s, P, res_epoch, a, df.p, wp, p, q, zk, sel_len, full.p);
+            hipLaunchKernelGGL(k_res_hist2, dim3(kResHistBlocks), dim3(256), 0, s, P, res_epoch, a, full.p, sel_len, Ksel);
+            hipLaunchKernelGGL(k_res_collect, dim3(kResCollectBlocks), dim3(256), 0, s, P, res_epoch, a, full.p, sel_len);
         }
-        hipLaunchKernelGGL(k_res_select, dim3(1), dim3(1024), 0, s, P, res_epoch, a, fast ? 1 : 0, K, seq, M, wp, p, q, zk, (int)zkeepn, groups * (k + zkeepn));
-        if (!res_fix())
+        if (!res_sharded)
+            hipLaunchKernelGGL(k_res_select, dim3(1), dim3(1024), 0, s, P, res_epoch, a, fast ? 1 : 0, K, seq, M, wp, p, q, zk, (int)zkeepn, groups * (k + zkeepn));
+        else {
+            hipLaunchKernelGGL(k_res_select_local, dim3(1), dim3(1024), 0, s, P, res_epoch, a, fast ? 1 : 0, Ksel, K, (int32_t)xv.slots);
+            MIH_TRY(res_allgather_messages(2 + 2 * (int64_t)K));
+            hipLaunchKernelGGL(k_res_select_global, dim3(1), dim3(1024), 0, s, P, res_epoch, a, K, seq, M, full.p, p, q, zk, (int)zkeepn, groups * (k + zkeepn));
+        }
+        if (!res_fix() && !res_sharded)
             hipLaunchKernelGGL(k_res_xb<false>, dim3(nb), dim3(256), 0, s, P, res_epoch, a, M, z.p, y.p, w.p, q, dist, link, nb_r, xb.p, zc.p, mu.p, red.p);
         else {
-            hipLaunchKernelGGL(k_res_xb<true>, dim3(nb), dim3(256), 0, s, P, res_epoch, a, M, z.p, y.p, w.p, q, dist, link, nb_r, xb.p, zc.p, mu.p, red.p);
-            hipLaunchKernelGGL(k_res_missing, dim3(1), dim3(1024), 0, s, P, res_epoch, a, 1, M, xb.p);
-            hipLaunchKernelGGL(k_res_mu, dim3(nb), dim3(256), 0, s, P, res_epoch, a, z.p, y.p, w.p, n, q, dist, link, nb_r, xb.p, zc.p, mu.p, red.p);
+            // (the partial product goes to a scratch vector -- xgk is free here -- so that a chain whose gate is closed, whose
+            // collectives run all the same, leaves xb alone)
+            double *part = res_sharded ? xgk.p : xb.p;
+            hipLaunchKernelGGL(k_res_xb<true>, dim3(nb), dim3(256), 0, s, P, res_epoch, a, M, z.p, y.p, w.p, q, dist, link, nb_r, part, zc.p, mu.p, red.p);
+            if (res_fix()) hipLaunchKernelGGL(k_res_missing, dim3(1), dim3(1024), 0, s, P, res_epoch, a, 1, M, part);
+            if (res_sharded) MIH_TRY(allreduce_dev(part, n, 0));
+            hipLaunchKernelGGL(k_res_mu, dim3(nb), dim3(256), 0, s, P, res_epoch, a, (const double *)part, z.p, y.p, w.p, n, q, dist, link, nb_r, xb.p, zc.p, mu.p, red.p);
         }
         hipLaunchKernelGGL(k_res_decide, dim3(1), dim3(256), 0, s, P, res_epoch, a, more ? 1 : 0, seq, red.p, nb, n, dist);
         MIH_HIP(hipGetLastError());
         return MIH_OK;
+    }
+    // the shards' messages of the projection (k_res_select_local -> k_res_select_global): one ncclAllGather queued on this stream
+    int res_allgather_messages(int64_t mlen)
+    {
+        const ResPtrs P = res_ptrs();
+        Profile &pf = *h->prof;
+        ExchRecord rec; rec.kind = 2;
+        const bool timed = pf.on && hipEventCreate(&rec.e0) == hipSuccess && hipEventCreate(&rec.e1) == hipSuccess;
+        if (timed) (void)hipEventRecord(rec.e0, s);
+        const int rc = comm_native_allgather_on_stream(comm, P.msg, P.msgs, mlen, s, h->device);
+        if (rc < 0) { set_error("the device-resident sharded step needs the library's own communicator"); return MIH_BAD_ARG; }
+        if (timed) { (void)hipEventRecord(rec.e1, s); std::lock_guard<std::mutex> g(pf.mu); pf.xopen.push_back(rec); }
+        return rc;
     }
     // attempts a0 .. a0 + res_spec of a step (res_spec: how many backtracks the last step needed, the forecast for this one)
     // res_known: attempts 0 .. res_known - 1 have a forecast on the device (a step with that many attempts has stood since

@@ -52,9 +52,17 @@ def native_main(out_path):
         p = cc.shape[0]
         lo, cnt = D.column_block(p, rank, world)
         xs = m.SnpLinAlg(cc[lo:lo + cnt], n=nn, center=True, scale=True, impute=True, device=local)
+        m.profile_enable(xs, True)
+        m.profile_counters(xs, reset=True)
         a = summary(D.fit_iht_sharded(yy, xs, zz, col_offset=lo, p_global=p, verbose=False, native=True, **kw))
+        cnt_native = m.profile_counters(xs, reset=True)
         b = summary(D.fit_iht_sharded(yy, xs, zz, col_offset=lo, p_global=p, verbose=False, native=False, ordered_sum=True, **kw))
-        out[name] = dict(native=a, callbacks=b)
+        cnt_callbacks = m.profile_counters(xs, reset=True)
+        m.profile_enable(xs, False)
+        # (round 5) with the library's own communicator the sharded fit's steps are resident on the device too (collectives queued
+        # inside the gated chain); the callbacks of the host language keep the host-driven step
+        out[name] = dict(native=a, callbacks=b, resident_steps_native=cnt_native["resident_steps"] + cnt_native["resident_handbacks"],
+                         resident_steps_callbacks=cnt_callbacks["resident_steps"])
         if rank == 0:                                        # ... and the unsharded fit on the whole matrix
             xf = m.SnpLinAlg(cc, n=nn, center=True, scale=True, impute=True, device=local)
             out[name]["single"] = summary(m.fit_iht(yy, xf, zz, verbose=False, **kw))
