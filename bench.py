@@ -559,7 +559,9 @@ def main():
                        "final_logl": logl, "host_small_kernels_and_exchange_ms_per_step": 1e3 * elapsed / a.steps - kern_ms,
                        "step_mode": ("0: iht_one_step! resident on the device -- iterate, top-k finish, backtracking decision in device "
                                      "memory, the kernels of a step queued without a host wait" if a.step_mode == 0 and not sharded else
-                                     "1: host-driven steps" + (" (a column-sharded fit has no device-resident step yet)" if sharded and a.step_mode == 0 else "")),
+                                     ("0: iht_one_step! resident on the device, the shards' all-reduces and the projection's all-gather queued inside "
+                                      "the gated chain (the library's own communicator)" if sharded and a.step_mode == 0 and step_counters["resident_steps"] > 0
+                                      else "1: host-driven steps" + (" (callbacks of the host language need the host)" if sharded and a.step_mode == 0 else ""))),
                        "resident_steps": {kk: step_counters[kk] for kk in ("resident_steps", "resident_attempts", "resident_handbacks",
                                                                             "resident_direct", "resident_redos")}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
