@@ -1514,7 +1514,7 @@ struct IhtVar {
         MIH_HIP(hipStreamSynchronize(s));                    // the pinned staging below may still be read by an earlier upload
         ResCtl &C = *rctl_h.p;
         std::memset(&C, 0, sizeof(C));
-        C.live_epoch = res_epoch; C.cur = 0; C.es = 0; C.iter = (int32_t)iter_done;
+        C.live_epoch = res_gate_step(res_epoch); C.cur = 0; C.es = 0; C.iter = (int32_t)iter_done;
         C.arm_stop = arm_stop; C.min_iter = prm->min_iter; C.max_step = prm->max_step; C.tol_stop = prm->tol;
         C.logl_cur = next_logl; C.best_logl = best;
         for (int l = 0; l < q; ++l) C.df2[l] = df2[l];
@@ -1549,7 +1549,7 @@ struct IhtVar {
             rg_cnt_h[0] = g2[0]; rg_cnt_h[1] = g2[1];
             MIH_HIP(hipMemcpyAsync(rctl.p->gcnt, rg_cnt_h, sizeof(int64_t) * 2, hipMemcpyHostToDevice, s));
         }
-        res_zero_list = zero_list; res_iter0 = iter_done; res_known = 0; res_fast_fails = 0;      // (no threshold on the device yet)
+        res_zero_list = zero_list; res_iter0 = iter_done; res_known = 0; res_fast_fails = 0; res_spec = 0; res_last[0] = res_last[1] = res_last[2] = 0;      // (no threshold on the device yet)
         res_out.clear();
         xv_cache_forget(); stage_forget(); spec_ok = false;
         res_active = true;
@@ -1566,7 +1566,7 @@ struct IhtVar {
         ++res_epoch;                                         // whatever is still queued does nothing
         {
             // (a one-word store through the stream: the chain's gate closes in order, behind the kernels that are running)
-            const int32_t e = res_epoch;
+            const int32_t e = res_gate_step(res_epoch);
             MIH_HIP(hipMemcpyAsync(&rctl.p->live_epoch, &e, sizeof(e), hipMemcpyHostToDevice, s));
         }
         MIH_HIP(hipMemcpyAsync(rctl_h.p, rctl.p, sizeof(ResCtl), hipMemcpyDeviceToHost, s));
@@ -1617,6 +1617,17 @@ struct IhtVar {
             (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
             pf.open.pop_back();
         }
+    }
+    // ... of the series `behind` places before the last one queued (a series that ended without a step: its pass found phase 1)
+    void res_dead_pass_at(int behind)
+    {
+        Profile &pf = *h->prof;
+        if (!pf.on || behind < 0) return;
+        std::lock_guard<std::mutex> g(pf.mu);
+        if ((size_t)behind >= pf.open.size()) return;
+        const size_t at = pf.open.size() - 1 - (size_t)behind;
+        (void)hipEventDestroy(pf.open[at].e0); (void)hipEventDestroy(pf.open[at].e1);
+        pf.open.erase(pf.open.begin() + (std::ptrdiff_t)at);
     }
 
     int res_enqueue_support()
@@ -1699,18 +1710,19 @@ struct IhtVar {
         if (timed) { (void)hipEventRecord(rec.e1, s); std::lock_guard<std::mutex> g(pf.mu); pf.xopen.push_back(rec); }
         return rc;
     }
-    // attempts a0 .. a0 + res_spec of a step (res_spec: how many backtracks the last step needed, the forecast for this one)
+    // A series of attempt slots: 1 + res_spec of them (res_spec: the most backtracks one of the last three steps needed, the forecast
+    // for this one: a slot too many is four empty launches, one too few leaves the step's end and the next one's start empty).  A slot serves whichever attempt ctl->es says is due; a0 is only the host's guess of the first one's number.
     // res_known: attempts 0 .. res_known - 1 have a forecast on the device (a step with that many attempts has stood since
     // res_begin): their projections take the direct gather, unless the forecast has failed three times in this run of steps.
     // first_slow: the attempt being re-queued because its forecast failed.
-    int res_spec = 0, res_fast_fails = 0, res_known = 0;
+    int res_spec = 0, res_fast_fails = 0, res_known = 0, res_last[3] = {0, 0, 0};
     int res_enqueue_attempts(uint64_t seq, int a0, int max_step, bool first_slow = false)
     {
-        const int last = std::min(max_step, a0 + res_spec);          // (attempt max_step always stands: utilities.jl:484)
-        for (int a = a0; a <= last; ++a) {
-            const bool fast = a < res_known && a < kResMaxAttempts && res_fast_fails < 3 && !(first_slow && a == a0);
+        const int slots = 1 + std::max(0, std::min(max_step - std::min(a0, max_step), res_spec));      // (attempt max_step always stands: utilities.jl:484)
+        for (int j = 0; j < slots; ++j) {
+            const bool fast = res_known > 0 && res_fast_fails < 3 && !(first_slow && j == 0);
             if (fast) h->prof->count(MIH_CNT_RESIDENT_DIRECT, 1);
-            MIH_TRY(res_enqueue_attempt(seq, a, a < last, fast));
+            MIH_TRY(res_enqueue_attempt(seq, 0, j + 1 < slots, fast));
         }
         return MIH_OK;
     }
@@ -1721,7 +1733,7 @@ struct IhtVar {
         const ResPtrs P = res_ptrs();
         hipLaunchKernelGGL(k_res_stats, dim3(kZtrBlocks, q + 1), dim3(256), 0, s, P, res_epoch, z.p, xb.p, zc.p, y.p, mu.p, w.p, n, q, dist, link, nb_r,
                            r.p, ztr.p, xtv.scal.p + xtv.rhs_cap * 4);
-        xtv.gate = &rctl.p->live_epoch; xtv.gate_val = res_epoch; xtv.stats_done = true;
+        xtv.gate = &rctl.p->live_epoch; xtv.gate_val = res_gate_step(res_epoch); xtv.stats_done = true;
         xtv.shook.spart = xtv.scal.p + xtv.rhs_cap * 4; xtv.shook.zpart = ztr.p; xtv.shook.df2 = rctl.p->df2; xtv.shook.q = q;
         xtv.shook.zblocks = kZtrBlocks; xtv.shook.ebits = xtv.dm.ebits;
         xtv.hook.cur = &rctl.p->cur;
@@ -1779,18 +1791,16 @@ struct IhtVar {
             MIH_TRY(res_wait(seq, rec));
             switch (rec->status) {
             case RES_ACCEPT:
-                ++rr.done; res_spec = rec->nbt; res_known = std::max(res_known, rec->nbt + 1);
+                ++rr.done; res_known = std::max(res_known, rec->nbt + 1);
+                res_last[2] = res_last[1]; res_last[1] = res_last[0]; res_last[0] = rec->nbt;
+                res_spec = std::min(2, std::max(res_last[0], std::max(res_last[1], res_last[2])));       // (three slots at most: a longer series is rare and goes on in the next)
                 h->prof->count(MIH_CNT_RESIDENT_STEPS, 1);
                 return MIH_OK;
-            case RES_BACKTRACK: {            // the chain behind that attempt is dead: queue the next attempt and the rest of the step
-                res_dead_passes(1 + (int)res_out.size());
-                ++res_epoch; res_out.clear(); rr.issued = rr.done;
+            case RES_PENDING:                // the series ended with the step still backtracking: the series queued behind goes on with it
+                res_dead_pass_at((int)res_out.size());       // (the step-end kernels in between, the X'r pass among them, did nothing)
+                --rr.issued;
                 h->prof->count(MIH_CNT_RESIDENT_ATTEMPTS, 1);
-                const uint64_t s2 = ++res_seq;
-                MIH_TRY(res_enqueue_attempts(s2, rec->nbt, rr.max_step)); MIH_TRY(res_enqueue_back());
-                res_out.push_back(s2); ++rr.issued;
                 break;
-            }
             case RES_REDO_SLOW: {            // the direct gather's forecast failed: the same attempt again, with the histograms
                 res_dead_passes(1 + (int)res_out.size());
                 ++res_epoch; res_out.clear(); rr.issued = rr.done;
