@@ -210,8 +210,8 @@ typedef struct mih_fit_params {
     int32_t  init_beta;       /* fit.jl:80 init_beta: start from the p univariate regressions
                                  (initialize_beta!, src/utilities.jl:776-812; Normal only) */
     const mih_comm *comm;     /* NULL = single process; else this process's shard of a column-sharded
-                                 fit: h, weight, res->beta cover the LOCAL columns only (mih_fit_iht and
-                                 mih_session_* only; no group / init_beta / debias / cross-validation) */
+                                 fit: h, weight, res->beta (mih_mv_result::B) cover the LOCAL columns only (mih_fit_iht,
+                                 mih_session_* and mih_fit_mv; no group / init_beta / debias / cross-validation) */
     int32_t  debias;          /* fit.jl:73,188 debias: after a step (iter >= 5) that kept the support, refit the
                                  support columns by GLM (debias!, src/utilities.jl:1014-1020; the reference needs
                                  memory_efficient=false for it, the device builds the n x k panel on the fly) */
@@ -333,7 +333,12 @@ typedef struct mih_mv_result {
     double  *logl_trace, *tol_trace;
     int32_t *bt_trace;
 } mih_mv_result;
-/* fit_iht(Y, Transpose(x), Z; d=MvNormal) : Y r x n, Z q x n column-major */
+/* fit_iht(Y, Transpose(x), Z; d=MvNormal) : Y r x n, Z q x n column-major.
+ * prm->comm != NULL: this process's shard of a column-sharded multivariate fit (round 5) -- h and B (r x local p) cover the local
+ * columns, Y, Z, C, Sigma, the traces are replicated; per iteration one all-reduce of n r + 1 doubles (X_S df_S of iht_stepsize!,
+ * multivariate.jl:220-254), one of n r doubles per update_xb! (:21-31) and one all-gather of 1 + 2K doubles per project_k! (the
+ * shards' top-K entries of vec(B) as (global linear index, value) pairs).  init_beta and more than K exact ties at one shard's
+ * threshold are refused. */
 int mih_fit_mv(const mih_mat *h, const mih_fit_params *prm, const double *Y, int64_t r,
                const double *Z, int64_t q, const uint8_t *train, mih_mv_result *res);
 int mih_cv_mv(const mih_mat *h, const mih_fit_params *prm, const double *Y, int64_t r,

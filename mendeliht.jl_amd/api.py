@@ -912,7 +912,7 @@ def fit_iht(y, x, z=None, *, k=10, J=1, d=None, l=None, group=None, weight=None,
     if verbose:
         _print_signature(io)
     if mv:
-        return _fit_mv(y, x, z, k, d, l, zkeep, verbose, tol, max_iter, min_iter, max_step, io, train, init_beta, xtv_digits, choose)
+        return _fit_mv(y, x, z, k, d, l, zkeep, verbose, tol, max_iter, min_iter, max_step, io, train, init_beta, xtv_digits, choose, comm)
     y = np.ascontiguousarray(np.asarray(y, dtype=np.float64).ravel())
     n = x.n
     z = np.ones((n, 1)) if z is None else np.asarray(z, dtype=np.float64)
@@ -963,7 +963,7 @@ def _checky(y, d):
 
 
 def _fit_mv(Y, x, Z, k, d, l, zkeep, verbose, tol, max_iter, min_iter, max_step, io, train, init_beta=False, xtv_digits=None,
-            choose=None):
+            choose=None, comm=None):
     Y = np.asfortranarray(np.asarray(Y, dtype=np.float64))
     r, n = Y.shape
     Z = np.ones((1, n)) if Z is None else np.asarray(Z, dtype=np.float64)
@@ -983,7 +983,7 @@ def _fit_mv(Y, x, Z, k, d, l, zkeep, verbose, tol, max_iter, min_iter, max_step,
 
     keep = []
     prm = _params(k, 1, Normal(), l, tol, max_iter, min_iter, max_step, "None", zkeep, None, None, q, x.p, keep, progress,
-                  init_beta=init_beta, xtv_digits=xtv_digits, choose=choose)
+                  init_beta=init_beta, xtv_digits=xtv_digits, choose=choose, comm=comm)
     if verbose:
         _print_parameters(io, k, MvNormal(), l, False, None, False, tol, max_iter, min_iter)
     tr = None if train is None else np.ascontiguousarray(train, dtype=np.uint8)

@@ -161,6 +161,29 @@ __global__ void k_mv_gather(const double *__restrict__ DF, int64_t p, int r, con
     int64_t i = t / nc, c = t - i * nc;
     out[t] = DF[i * p + cols[c]];
 }
+// column shard: the projected gradient of init_iht_indices! rebuilt from the survivors of the GLOBAL threshold (the local projection
+// only knows the shard's own): df[i][j] = value of the entry i + r*j
+__global__ void k_mv_put_df(const int64_t *__restrict__ li, const double *__restrict__ val, int64_t nnz, int64_t p, int r, double *__restrict__ DF)
+{
+    int64_t t = blockIdx.x * 256ll + threadIdx.x;
+    if (t >= nnz) return;
+    int64_t l = li[t], j = l / r; int i = (int)(l - j * r);
+    DF[(int64_t)i * p + j] = val[t];
+}
+// column shard: this shard's share of |df_S|^2 (the numerator of iht_stepsize!, multivariate.jl:247), left behind the n*r
+// partial products so that ONE all-reduce sums both over the shards
+__global__ void __launch_bounds__(256) k_mv_sumsq(const double *__restrict__ v, int64_t cnt, double *__restrict__ out)
+{
+#pragma clang fp contract(off)
+    __shared__ double sh[256];
+    double a = 0.0;
+    for (int64_t t = threadIdx.x; t < cnt; t += 256) a += v[t] * v[t];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) { if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off]; __syncthreads(); }
+    if (threadIdx.x == 0) *out = sh[0];
+}
+__global__ void k_mv_copy1(const double *__restrict__ src, double *__restrict__ dst) { *dst = *src; }
 // predict!(v::mIHTVariable) (cross_validation.jl:288-299): sum (Y - mu)^2 * cv_wts
 __global__ void __launch_bounds__(256)
 k_mv_mse(const double *__restrict__ Y, const double *__restrict__ MU, const double *__restrict__ w, int64_t n, int r,
@@ -335,13 +358,66 @@ struct MvVar {
     bool own_stream = true;
     ~MvVar() { if (s) (void)hipStreamSynchronize(s); if (s && own_stream) (void)hipStreamDestroy(s); }       // see ~IhtVar
 
+    // Column-sharded fit (mih_comm, as the univariate IhtVar of fit.hip): this process owns columns [col0, col0 + p) of pg; Y, Z
+    // and every n x r matrix are replicated, so the residuals, the Gram matrix, Gamma, the loglikelihood and T1 = Gamma * resid are
+    // computed redundantly and identically on every rank and the X'R pass needs no exchange.  Per iteration: one all-reduce of
+    // n r + 1 doubles (X_S df_S of iht_stepsize!, the shards' |df_S|^2 riding as the last element), one of n r doubles per
+    // update_xb!, and one all-gather of 1 + 2K doubles per projection -- the shards' top-K entries of vec(B) as (global linear
+    // index, value) pairs, after which every rank holds the WHOLE k-sparse model of the step (Bg): _choose!'s count and rule and
+    // check_convergence's maxima are then computed locally and identically everywhere.
+    const mih_comm *comm = nullptr;
+    int64_t col0 = 0, pg = 0;
+    Sparse Bg, B0g;                        // the whole model, global linear index i + r*(col0 + j); identical on every rank
+    double spec_numer = 0.0;               // |df_S|^2 over all shards, home with the step-size denominator
+    static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    int comm_fail(int rc) { set_error("communicator callback failed (%d)", rc); return MIH_BAD_ARG; }
+    // sum over the shards of a device vector: queued on this stream when the communicator is the library's own, else through
+    // the caller's callback (which is handed the device pointer) after a stream synchronisation.  Timed by kind as in fit.hip
+    // (0: with the step size's numerator riding along, 1: plain products)
+    int allreduce_dev(double *buf, int64_t cnt, int kind)
+    {
+        Profile &pf = *h->prof;
+        ExchRecord rec; rec.kind = kind;
+        const bool timed = pf.on && hipEventCreate(&rec.e0) == hipSuccess && hipEventCreate(&rec.e1) == hipSuccess;
+        if (timed) (void)hipEventRecord(rec.e0, s);
+        const int nrc = comm_native_allreduce_on_stream(comm, buf, cnt, 0, s, h->device);
+        if (nrc >= 0) {
+            if (timed) { (void)hipEventRecord(rec.e1, s); std::lock_guard<std::mutex> g(pf.mu); pf.xopen.push_back(rec); }
+            return nrc;
+        }
+        if (timed) { (void)hipEventDestroy(rec.e0); (void)hipEventDestroy(rec.e1); }
+        const double t0 = now_ms();
+        MIH_HIP(hipStreamSynchronize(s));
+        int rc = comm->allreduce(comm->user, buf, cnt, 0, 1);
+        pf.exch_host(kind, now_ms() - t0);
+        return rc ? comm_fail(rc) : MIH_OK;
+    }
+    int allgather_host(const double *send, int64_t cnt, std::vector<double> &recv)
+    {
+        recv.assign((size_t)cnt * comm->world, 0.0);
+        const double t0 = now_ms();
+        int rc = comm->allgather(comm->user, send, cnt, recv.data());
+        h->prof->exch_host(2, now_ms() - t0);
+        return rc ? comm_fail(rc) : MIH_OK;
+    }
+
     // shared_stream != null: one of a lock-step batch (mih_cv_mv): it runs on the batch's stream and leaves the
     // X'R pass to the batch driver
     int create(const mih_mat *hh, const mih_fit_params *prm, const double *Yh, int64_t rr, const double *Zh, int64_t qq,
                hipStream_t shared_stream = nullptr)
     {
         h = hh; n = h->n; p = h->p; r = (int)rr; q = (int)qq; k = prm->k; Y_host = Yh; Z_host = Zh; init_beta = prm->init_beta; tune = xtv_tune(prm);
-        choose_cb = prm->choose; choose_user = prm->choose_user;
+        choose_cb = prm->comm ? nullptr : prm->choose; choose_user = prm->choose_user;
+        comm = prm->comm; pg = p; col0 = 0;
+        if (comm) {
+            if (!comm->allreduce || !comm->allgather || comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world ||
+                comm->col_offset < 0 || comm->col_offset + p > comm->p_global) {
+                set_error("invalid mih_comm (callbacks, rank/world or column range)"); return MIH_BAD_ARG;
+            }
+            if (shared_stream) { set_error("cross-validation shards over (fold,k) combinations (rank/world), not over columns"); return MIH_BAD_ARG; }
+            if (init_beta) { set_error("init_beta is not available for a column-sharded multivariate fit"); return MIH_BAD_ARG; }
+            col0 = comm->col_offset; pg = comm->p_global;
+        }
         if (r < 1 || r > kMaxR) { set_error("number of traits r=%d must be in 1..%d", r, kMaxR); return MIH_BAD_DIM; }
         if (q < 1 || r * q > kMaxRQ) { set_error("r*q = %d exceeds %d", r * q, kMaxRQ); return MIH_BAD_DIM; }
         zkeep.resize(q); int64_t zs = 0;
@@ -354,7 +430,7 @@ struct MvVar {
         int64_t kcap = std::max<int64_t>(k + (int64_t)r * q, 64) + 1024;
         {
             const size_t redn = std::max<size_t>((size_t)nb, (size_t)kMaxR * kMaxR * kRedBlocks);
-            size_t dev = sizeof(double) * (5 * rn + (size_t)q * n + 2 * (size_t)n + (size_t)r * p + (size_t)r * (p + q) + redn + (size_t)kMaxR * kMaxR + 64
+            size_t dev = sizeof(double) * (5 * rn + 8 + (size_t)q * n + 2 * (size_t)n + (size_t)r * p + (size_t)r * (p + q) + redn + (size_t)kMaxR * kMaxR + 64
                                            + 2 * (size_t)kcap + (size_t)kcap * r) + (size_t)n + sizeof(int32_t) * 2 * (size_t)kMaxR * kMaxR
                          + xv_work_bytes(h, kcap, kcap - 1024) + sizeof(uint32_t) * 2048 + 64 + 16 * ((size_t)kcap + 1025) + 40 * 256;
             size_t pin = sizeof(uint64_t) * (2 + 2 * ((size_t)kcap + 64) + 16 + HostStage::kSlots * ((size_t)kcap * (r + 1) + 8)) + 6 * 256;
@@ -362,7 +438,7 @@ struct MvVar {
         }
         ArenaScope in_arena(&arena);
         MIH_TRY(Y.alloc(rn)); MIH_TRY(Z.alloc((size_t)q * n)); MIH_TRY(w.alloc(n)); MIH_TRY(BX.alloc(rn)); MIH_TRY(MU.alloc(rn));
-        MIH_TRY(RES.alloc(rn)); MIH_TRY(T1.alloc(rn)); MIH_TRY(DF.alloc((size_t)r * p)); MIH_TRY(full.alloc((size_t)r * (p + q)));
+        MIH_TRY(RES.alloc(rn)); MIH_TRY(T1.alloc(rn + 8) /* + the step size's numerator behind a shard's partial products */); MIH_TRY(DF.alloc((size_t)r * p)); MIH_TRY(full.alloc((size_t)r * (p + q)));
         MIH_TRY(red.alloc(std::max<size_t>((size_t)nb, (size_t)kMaxR * kMaxR * kRedBlocks))); MIH_TRY(scal.alloc((size_t)kMaxR * kMaxR + 64));
         MIH_TRY(tmpn.alloc(n)); MIH_TRY(mask.alloc(n)); MIH_TRY(pairs.alloc(2 * (size_t)kMaxR * kMaxR));
         MIH_TRY(sidx.alloc(kcap)); MIH_TRY(sval.alloc(kcap)); MIH_TRY(gval.alloc((size_t)kcap * r));
@@ -412,7 +488,10 @@ struct MvVar {
         update_cols();
         int64_t nc = (int64_t)cols.size();
         MIH_TRY(ensure_stage(nc));
-        if (!nc) { MIH_HIP(hipMemsetAsync(BX.p, 0, sizeof(double) * (size_t)n * r, s)); return MIH_OK; }
+        if (!nc) {
+            MIH_HIP(hipMemsetAsync(BX.p, 0, sizeof(double) * (size_t)n * r, s));
+            return comm ? allreduce_dev(BX.p, n * r, 1) : MIH_OK;          // (a shard without a support column still joins the sum)
+        }
         // coefficient matrix [trait][support column] (zero where a trait does not use the column), one upload, one launch
         xbcoef.assign((size_t)nc * r, 0.0);
         size_t c = 0;
@@ -423,7 +502,8 @@ struct MvVar {
         }
         if ((size_t)nc * r > mcoef.n) { MIH_HIP(hipStreamSynchronize(s)); MIH_TRY(mcoef.alloc((size_t)nc * r * 2)); }
         MIH_TRY(upload_cols_coef(xbcoef));
-        return xv_sparse_multi_device(h, xv, sidx.p, mcoef.p, nc, r, BX.p, s, cols.data());
+        MIH_TRY(xv_sparse_multi_device(h, xv, sidx.p, mcoef.p, nc, r, BX.p, s, cols.data()));
+        return comm ? allreduce_dev(BX.p, n * r, 1) : MIH_OK;              // the shards' partial products
     }
     // update_mu! + update_resid! (+ Gram matrix resid*resid' for solve_Sigma!/loglikelihood)
     int resid_and_gram()
@@ -501,7 +581,7 @@ struct MvVar {
         const int64_t nc = (int64_t)cols.size();
         const size_t rq = (size_t)r * q, ncr = (size_t)nc * r;
         MIH_TRY(ensure_stage(nc));
-        if (ncr + rq + 2 > gval.n) { MIH_HIP(hipStreamSynchronize(s)); MIH_TRY(gval.alloc((ncr + rq + 2) * 2)); }
+        if (ncr + rq + 3 > gval.n) { MIH_HIP(hipStreamSynchronize(s)); MIH_TRY(gval.alloc((ncr + rq + 3) * 2)); }
         double *d_df2 = gval.p + ncr, *d_sum = gval.p + ncr + rq;
         if (with_df2) {
             std::vector<int32_t> pr;
@@ -524,10 +604,16 @@ struct MvVar {
             hipLaunchKernelGGL(k_mv_gather, dim3(nblk(nc * r)), dim3(256), 0, s, DF.p, p, r, sidx.p, nc, gval.p);
             MIH_TRY(xv_sparse_multi_device(h, xv, sidx.p, gval.p, nc, r, T1.p, s, cols.data()));
         } else MIH_HIP(hipMemsetAsync(T1.p, 0, sizeof(double) * (size_t)n * r, s));
+        if (comm) {
+            hipLaunchKernelGGL(k_mv_sumsq, dim3(1), dim3(256), 0, s, gval.p, (int64_t)ncr, T1.p + (size_t)n * r);
+            MIH_TRY(allreduce_dev(T1.p, n * r + 1, 0));
+            hipLaunchKernelGGL(k_mv_copy1, dim3(1), dim3(1), 0, s, T1.p + (size_t)n * r, d_sum + 1);
+        }
         launch_mv_apply((unsigned)nb, s, T1.p, n, r, rmat(spec_U), 1, w.p, (double *)nullptr, red.p);
         hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, s, red.p, nb, 1, d_sum);
-        std::vector<double> home(ncr + rq + 1);
-        MIH_TRY(readback(gval.p, ncr + rq + 1, home.data()));
+        std::vector<double> home(ncr + rq + 2);
+        MIH_TRY(readback(gval.p, ncr + rq + (comm ? 2 : 1), home.data()));
+        if (comm) spec_numer = home[ncr + rq + 1];
         dfcols.assign(home.begin(), home.begin() + (std::ptrdiff_t)ncr);
         if (with_df2) for (size_t t = 0; t < rq; ++t) df2[t] = home[ncr + t];
         spec_denom = home[ncr + rq]; spec_cols = cols; spec_ok = true;
@@ -549,9 +635,13 @@ struct MvVar {
         int64_t nc = (int64_t)cols.size();
         double numer = 0.0;
         for (double x : dfcols) numer += x * x;
-        if (spec_ok && spec_cols == cols) {                           // computed behind the X'R pass of the previous step (step_tail)
+        // (column shard: every rank must take the same branch -- the collectives below are issued by all or none -- so the decision
+        // rests on spec_ok alone, which every rank sets and clears at the same places; the comparison of the LOCAL column lists
+        // holds whenever it does)
+        if (spec_ok && (comm || spec_cols == cols)) {                 // computed behind the X'R pass of the previous step (step_tail)
             spec_ok = false;
             G = spec_U;                                               // Gamma is left holding U, as below
+            if (comm) numer = spec_numer;
             double e = numer / spec_denom;
             if (std::isinf(e) || std::isnan(e)) e = 1e-8;
             *eta = e;
@@ -563,11 +653,18 @@ struct MvVar {
             MIH_TRY(upload_cols_coef(dfcols));                       // dfcols is [trait][column]
             MIH_TRY(xv_sparse_multi_device(h, xv, sidx.p, mcoef.p, nc, r, T1.p, s, cols.data()));
         } else MIH_HIP(hipMemsetAsync(T1.p, 0, sizeof(double) * (size_t)n * r, s));
+        if (comm) {
+            hipLaunchKernelGGL(k_mv_sumsq, dim3(1), dim3(256), 0, s, mcoef.p, nc * r, T1.p + (size_t)n * r);
+            MIH_TRY(allreduce_dev(T1.p, n * r + 1, 0));
+            hipLaunchKernelGGL(k_mv_copy1, dim3(1), dim3(1), 0, s, T1.p + (size_t)n * r, scal.p + 1);
+        }
         pivoted_chol_triu(G, r);                                   // Gamma is left holding U (fit.jl:230-232 recomputes it)
         launch_mv_apply((unsigned)nb, s, T1.p, n, r, rmat(G), 1, w.p, (double *)nullptr, red.p);
         hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, s, red.p, nb, 1, scal.p);
-        double denom = 0.0;
-        MIH_TRY(readback(scal.p, 1, &denom));
+        double dn[2] = {0.0, 0.0};
+        MIH_TRY(readback(scal.p, comm ? 2 : 1, dn));
+        const double denom = dn[0];
+        if (comm) numer = dn[1];
         double e = numer / denom;
         if (std::isinf(e) || std::isnan(e)) e = 1e-8;
         *eta = e;
@@ -609,10 +706,28 @@ struct MvVar {
     {
         int64_t cnz = 0;
         for (int l = 0; l < q; ++l) if (!zkeep[l]) for (int i = 0; i < r; ++i) cnz += (C[i + r * l] != 0.0);
-        int64_t excess = (int64_t)B.idx.size() + cnz - (k + zkeepn);
+        int64_t excess = (int64_t)(comm ? Bg.idx.size() : B.idx.size()) + cnz - (k + zkeepn);
         if (excess <= 0) return MIH_OK;
         choose_fired = true;
         if (choose_cb) return choose_by_caller(excess);
+        if (comm) {          // the same deterministic rule over the WHOLE model, which every rank holds; then this shard's part of what is left
+            std::vector<size_t> og(Bg.idx.size());
+            for (size_t i = 0; i < og.size(); ++i) og[i] = i;
+            std::sort(og.begin(), og.end(), [&](size_t a, size_t b) {
+                double fa = std::fabs(Bg.val[a]), fb = std::fabs(Bg.val[b]);
+                if (fa != fb) return fa < fb;
+                return Bg.idx[a] > Bg.idx[b];
+            });
+            std::vector<char> dg(Bg.idx.size(), 0);
+            int64_t t = 0;
+            for (; t < excess && t < (int64_t)og.size(); ++t) dg[og[(size_t)t]] = 1;
+            Sparse kept;
+            for (size_t i = 0; i < Bg.idx.size(); ++i) if (!dg[i]) { kept.idx.push_back(Bg.idx[i]); kept.val.push_back(Bg.val[i]); }
+            Bg = kept;
+            local_from_global();
+            for (int l = 0; l < q && t < excess; ++l) if (!zkeep[l]) for (int i = 0; i < r && t < excess; ++i) if (C[i + r * l] != 0.0) { C[i + r * l] = 0.0; ++t; }
+            return MIH_OK;
+        }
         std::vector<size_t> ord(B.idx.size());
         for (size_t i = 0; i < ord.size(); ++i) ord[i] = i;
         std::sort(ord.begin(), ord.end(), [&](size_t a, size_t b) {
@@ -632,6 +747,7 @@ struct MvVar {
     // project the r(p+q) buffer and split survivors; tail = covariate part of the vector
     int project_full(Sparse &snp, std::vector<double> &ctail, std::vector<uint8_t> &cnz, bool zero_in_place = true)
     {
+        if (comm) return project_full_sharded(snp, ctail, cnz);
         std::vector<int64_t> si; std::vector<double> sv;
         MIH_TRY(topk_project_device(full.p, (int64_t)r * (p + q), k + zkeepn, topk, s, si, sv, zero_in_place));
         snp.clear(); cnz.assign((size_t)r * q, 0); ctail.assign((size_t)r * q, 0.0);
@@ -640,6 +756,74 @@ struct MvVar {
             else { ctail[si[t] - (int64_t)r * p] = sv[t]; cnz[si[t] - (int64_t)r * p] = 1; }
         }
         return MIH_OK;
+    }
+    // project_k!(v) over the shards (IhtVar::project_full_sharded of fit.hip for vec(B)): the K-th largest |entry| of the whole
+    // r(pg + q) vector is the K-th largest of the union of every shard's own top-K and the covariate tail (which every rank
+    // holds); ties at that value are kept.  A shard sends its candidates as (global linear index, value) pairs, so every rank ends
+    // up with the whole model of the step (Bg).  A shard with more than K entries at or above its own threshold (exact ties
+    // there) can send only K: if its smallest sent magnitude still reaches the global threshold the whole model may be
+    // incomplete -- the fit stops with an error rather than continue with ranks that disagree.  `full` itself is left as it is.
+    int project_full_sharded(Sparse &snp, std::vector<double> &ctail, std::vector<uint8_t> &cnz)
+    {
+        const int64_t K = k + zkeepn, rq = (int64_t)r * q, lenl = (int64_t)r * p;
+        if (K <= 0 || K > (int64_t)r * (pg + q)) { set_error("Attempted to project to sparsity level %lld (vector length %lld)", (long long)K, (long long)((int64_t)r * (pg + q))); return MIH_BAD_ARG; }
+        std::vector<double> tail((size_t)rq);
+        MIH_HIP(hipMemcpyAsync(tail.data(), full.p + lenl, sizeof(double) * (size_t)rq, hipMemcpyDeviceToHost, s));
+        std::vector<int64_t> si; std::vector<double> sv;
+        const int64_t Kloc = std::min<int64_t>(K, lenl);
+        if (Kloc > 0) MIH_TRY(topk_project_device(full.p, lenl, Kloc, topk, s, si, sv, /*zero_in_place=*/false));
+        MIH_HIP(hipStreamSynchronize(s));
+        std::vector<size_t> ord(sv.size());
+        for (size_t t = 0; t < ord.size(); ++t) ord[t] = t;
+        std::sort(ord.begin(), ord.end(), [&](size_t x, size_t y) {
+            const double fx = std::fabs(sv[x]), fy = std::fabs(sv[y]);
+            if (fx != fy) return fx > fy;
+            return si[x] < si[y];
+        });
+        const int64_t slot = 1 + 2 * K;
+        std::vector<double> mine((size_t)slot, -1.0), all;        // index -1 = no entry
+        mine[0] = (double)sv.size();
+        for (int64_t t = 0; t < K && t < (int64_t)ord.size(); ++t) { mine[1 + 2 * t] = (double)(col0 * r + si[ord[(size_t)t]]); mine[2 + 2 * t] = sv[ord[(size_t)t]]; }
+        MIH_TRY(allgather_host(mine.data(), slot, all));
+        std::vector<double> mags;
+        for (int32_t rk = 0; rk < comm->world; ++rk)
+            for (int64_t t = 0; t < K; ++t) { const double *e = &all[(size_t)rk * slot + 1 + 2 * t]; if (e[0] >= 0.0) mags.push_back(std::fabs(e[1])); }
+        for (int64_t l = 0; l < rq; ++l) mags.push_back(std::fabs(tail[(size_t)l]));
+        if ((int64_t)mags.size() < K) { set_error("projection to %lld entries of a vector with %zu non-empty candidates", (long long)K, mags.size()); return MIH_BAD_ARG; }
+        std::nth_element(mags.begin(), mags.begin() + (K - 1), mags.end(), std::greater<double>());
+        const double a = mags[(size_t)K - 1];
+        snp.clear(); cnz.assign((size_t)rq, 0); ctail.assign((size_t)rq, 0.0);
+        for (size_t t = 0; t < si.size(); ++t)
+            if (std::fabs(sv[t]) >= a) { snp.idx.push_back(si[t]); snp.val.push_back(sv[t]); }
+        for (int64_t l = 0; l < rq; ++l)
+            if (std::fabs(tail[(size_t)l]) >= a) { ctail[(size_t)l] = tail[(size_t)l]; cnz[(size_t)l] = 1; }
+        Bg.clear();
+        std::vector<std::pair<int64_t, double>> glob;
+        for (int32_t rk = 0; rk < comm->world; ++rk) {
+            const double *msg = &all[(size_t)rk * slot];
+            double smallest = std::numeric_limits<double>::infinity();
+            for (int64_t t = 0; t < K; ++t) {
+                if (msg[1 + 2 * t] < 0.0) continue;
+                const double mg = std::fabs(msg[2 + 2 * t]);
+                smallest = std::min(smallest, mg);
+                if (mg >= a) glob.emplace_back((int64_t)msg[1 + 2 * t], msg[2 + 2 * t]);
+            }
+            if (msg[0] > (double)K && smallest >= a) {               // (decided from the gathered messages: the same on every rank)
+                set_error("column-sharded multivariate fit: shard %d holds more than %lld entries tied at the projection's threshold", (int)rk, (long long)K);
+                return MIH_BAD_ARG;
+            }
+        }
+        std::sort(glob.begin(), glob.end());
+        for (auto &e : glob) { Bg.idx.push_back(e.first); Bg.val.push_back(e.second); }
+        return MIH_OK;
+    }
+    // the shard's part of the whole model: entries of columns [col0, col0 + p), local linear index
+    void local_from_global()
+    {
+        B.clear();
+        const int64_t lo = col0 * r, hi = (col0 + p) * r;
+        for (size_t t = 0; t < Bg.idx.size(); ++t)
+            if (Bg.idx[t] >= lo && Bg.idx[t] < hi) { B.idx.push_back(Bg.idx[t] - lo); B.val.push_back(Bg.val[t]); }
     }
     // _iht_gradstep! + project_k!(v) (multivariate.jl:99-127) from base (Bb, Cb)
     int gradstep(const Sparse &Bb, const std::vector<double> &Cb, double eta)
@@ -716,7 +900,7 @@ struct MvVar {
     int init_pre(const uint8_t *train)
     {
         if (k < 1) { set_error("Multivariate IHT requires k >= 1!"); return MIH_BAD_ARG; }
-        B.clear(); B0.clear(); best_B.clear(); cols.clear(); dfcols.clear(); spec_ok = false;
+        B.clear(); B0.clear(); best_B.clear(); Bg.clear(); B0g.clear(); cols.clear(); dfcols.clear(); spec_ok = false;
         std::fill(C.begin(), C.end(), 0.0); C0 = C; best_C = C; std::fill(df2.begin(), df2.end(), 0.0);
         for (int l = 0; l < q; ++l) idc[l] = zkeep[l];
         std::fill(G.begin(), G.end(), 0.0);
@@ -747,7 +931,16 @@ struct MvVar {
         hipLaunchKernelGGL(k_mv_full, dim3(nblk(p)), dim3(256), sizeof(double) * 257 * (size_t)r, s, DF.p, p, r, 1.0, full.p, cmat(tail), r * q);
         Sparse snp; std::vector<double> ct; std::vector<uint8_t> cnz;
         MIH_TRY(project_full(snp, ct, cnz));
-        hipLaunchKernelGGL(k_mv_unvec, dim3(nblk(p * r)), dim3(256), 0, s, full.p, p, r, DF.p);
+        if (!comm) hipLaunchKernelGGL(k_mv_unvec, dim3(nblk(p * r)), dim3(256), 0, s, full.p, p, r, DF.p);
+        else {               // `full` was not cut at the GLOBAL threshold: df = the survivors, zero elsewhere
+            MIH_HIP(hipMemsetAsync(DF.p, 0, sizeof(double) * (size_t)r * p, s));
+            MIH_TRY(ensure_stage((int64_t)snp.idx.size()));
+            if (!snp.idx.empty()) {
+                MIH_TRY(upload_pair(snp.idx.data(), sizeof(int64_t) * snp.idx.size(), sidx.p, snp.val.data(), sizeof(double) * snp.val.size(), sval.p));
+                hipLaunchKernelGGL(k_mv_put_df, dim3(nblk((int64_t)snp.idx.size())), dim3(256), 0, s, sidx.p, sval.p, (int64_t)snp.idx.size(), p, r, DF.p);
+            }
+            Bg.clear();      // (what was projected is the gradient: the model itself is still zero)
+        }
         for (int l = 0; l < q; ++l) if (!zkeep[l]) for (int i = 0; i < r; ++i) df2[i + r * l] = cnz[i + r * l] ? ct[i + r * l] : 0.0;
         cols.clear();
         for (size_t t = 0; t < snp.idx.size(); ++t) { int64_t j = snp.idx[t] / r; if (cols.empty() || cols.back() != j) cols.push_back(j); }
@@ -756,7 +949,7 @@ struct MvVar {
     }
     double save_prev(double cur, double best)
     {
-        B0 = B; C0 = C; G0 = G;
+        B0 = B; C0 = C; G0 = G; B0g = Bg;
         if (cur > best) { best_B = B; best_C = C; }
         return cur > best ? cur : best;
     }
@@ -769,6 +962,7 @@ struct MvVar {
     }
     double check_convergence() const
     {
+        const Sparse &B = comm ? this->Bg : this->B, &B0 = comm ? this->B0g : this->B0;      // (a column shard: over the whole model)
         double d = 0.0, nbm = 0.0;
         size_t i = 0, j = 0;
         while (i < B.idx.size() || j < B0.idx.size()) {
@@ -853,7 +1047,6 @@ static int mv_check(const mih_mat *h, const mih_fit_params *prm)
 {
     if (!h || !prm) { set_error("null handle/params"); return MIH_BAD_ARG; }
     if (prm->max_iter < 0 || prm->max_step < 0) { set_error("max_iter / max_step must be nonnegative"); return MIH_BAD_ARG; }
-    if (prm->comm) { set_error("column-sharded fits are univariate only"); return MIH_BAD_ARG; }
     if (!(prm->tol > 2.220446049250313e-16)) { set_error("Value of global tol must exceed machine precision!"); return MIH_BAD_ARG; }
     if (h->kind == 0 && !h->center) { set_error("x is not centered! Please construct SnpLinAlg{Float64}(::SnpArray, center=true, scale=true)"); return MIH_NOT_CENTERED; }
     return MIH_OK;
@@ -915,6 +1108,7 @@ int mih_cv_mv(const mih_mat *h, const mih_fit_params *prm, const double *Y, int6
 {
     PoolScope from_reserve(h ? h->pool : nullptr);      // device buffers out of the matrix's reserve (DevPool, common.h)
     MIH_TRY(mv_check(h, prm));
+    if (prm->comm) { set_error("cross-validation shards over (fold,k) combinations (rank/world), not over columns"); return MIH_BAD_ARG; }
     if (!Y || !Z || !folds || !path || !mses_raw || nfolds < 1 || npath < 1 || world < 1 || rank < 0 || rank >= world) { set_error("null/invalid argument"); return MIH_BAD_ARG; }
     if (r < 1 || r > kMaxR) { set_error("number of traits r=%lld must be in 1..%d", (long long)r, kMaxR); return MIH_BAD_DIM; }
     int64_t n = h->n;

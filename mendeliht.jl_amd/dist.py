@@ -306,7 +306,8 @@ def fit_iht_sharded(y, x_shard, z=None, *, col_offset, p_global, weight=None, na
     """fit_iht on a design matrix whose SNP columns are sharded over the ranks of the process group.
 
     x_shard holds columns [col_offset, col_offset + x_shard.p); y, z are replicated.  Returns the same
-    IHTResult on every rank with the full-length beta assembled from the shards.  native=True: the exchanges run
+    IHTResult on every rank with the full-length beta assembled from the shards (a multivariate y -- r x n -- gives the
+    mIHTResult with the r x p_global B).  native=True: the exchanges run
     inside the library over its own RCCL communicator (one GPU per rank) instead of through torch.distributed callbacks.
     """
     import torch
@@ -329,14 +330,26 @@ def fit_iht_sharded(y, x_shard, z=None, *, col_offset, p_global, weight=None, na
         # garbage collector at interpreter exit (ncclCommDestroy after the other ranks have gone can hang)
         if native:
             comm.close()
-    beta = np.zeros(p_global)
-    nz = np.flatnonzero(res.beta)
-    mine = (nz + col_offset, res.beta[nz])
+    mv = np.ndim(res.beta) == 2
+    if mv:                          # multivariate (mIHTResult): beta is B, r x p, this shard's columns
+        r = res.beta.shape[0]
+        tr, col = np.nonzero(res.beta)
+        mine = (tr, col + col_offset, res.beta[tr, col])
+    else:
+        nz = np.flatnonzero(res.beta)
+        mine = (nz + col_offset, res.beta[nz])
     if comm.world > 1:
         parts = [None] * comm.world
         dist.all_gather_object(parts, mine)
     else:
         parts = [mine]
+    if mv:
+        B = np.zeros((r, p_global), order="F")
+        for ti, gi, gv in parts:
+            B[ti, gi] = gv
+        res.beta = B
+        return res
+    beta = np.zeros(p_global)
     for gi, gv in parts:
         beta[gi] = gv
     res.beta = beta

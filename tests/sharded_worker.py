@@ -23,6 +23,29 @@ def summary(res):
                 tol=res.trace["tol"].tolist(), choose_fired=bool(res.choose_fired), sigma_g=res.σg)
 
 
+def summary_mv(res):
+    """a multivariate fit (mIHTResult): beta is B, r x p"""
+    B = np.asarray(res.beta)
+    tr, col = np.nonzero(B)
+    order = np.lexsort((tr, col))
+    return dict(support=[[int(tr[t]), int(col[t])] for t in order], beta=[float(B[tr[t], col[t]]) for t in order],
+                c=np.asarray(res.c).ravel(order="F").tolist(), logl=res.logl, iter=int(res.iter), logl_trace=res.trace["logl"].tolist(),
+                bt=res.trace["backtracks"].tolist(), tol=res.trace["tol"].tolist(), choose_fired=bool(res.choose_fired),
+                Sigma=np.asarray(res.Sigma).ravel().tolist(), sigma_g=np.asarray(res.sigma_g).tolist())
+
+
+def mv_traits(x, rng, r, k, q):
+    """r correlated traits with k planted effects and q covariates on the matrix x (GPU product: the worker has no CPU checker)"""
+    p, n = x.p, x.n
+    XB = np.zeros((r, n))
+    for _ in range(k):
+        XB[rng.integers(r)] += x.xv_sparse(np.array([rng.integers(p)]), np.array([rng.standard_normal() * 0.6]))
+    A = rng.standard_normal((r, r))
+    L = np.linalg.cholesky(A @ A.T / r + np.eye(r) * 0.5)
+    Z = np.vstack([np.ones(n)] + [rng.standard_normal(n) for _ in range(q - 1)])
+    return XB + rng.standard_normal((r, q)) @ Z + L @ rng.standard_normal((r, n)), Z
+
+
 def native_main(out_path):
     """MIH_NATIVE=1: the library's own exchange (mih_comm_create_rccl: ncclAllReduce / ncclAllGather on a private stream) against
     the torch.distributed callbacks, rank by rank, bit for bit.  With one GPU per rank that is the real librccl over
@@ -66,6 +89,16 @@ def native_main(out_path):
         if rank == 0:                                        # ... and the unsharded fit on the whole matrix
             xf = m.SnpLinAlg(cc, n=nn, center=True, scale=True, impute=True, device=local)
             out[name]["single"] = summary(m.fit_iht(yy, xf, zz, verbose=False, **kw))
+    # the column-sharded MULTIVARIATE fit (round 5): three traits, two covariates (one of them competing in the projection)
+    Ym, Zm = mv_traits(x2, np.random.default_rng(77), 3, 10, 2)
+    lo, cnt = D.column_block(p2, rank, world)
+    xs = m.SnpLinAlg(cols2[lo:lo + cnt], n=n2, center=True, scale=True, impute=True, device=local)
+    mkw = dict(k=12, zkeep=[True, False], verbose=False)
+    out["mv_r3"] = dict(native=summary_mv(D.fit_iht_sharded(Ym, xs, Zm, col_offset=lo, p_global=p2, native=True, **mkw)),
+                        callbacks=summary_mv(D.fit_iht_sharded(Ym, xs, Zm, col_offset=lo, p_global=p2, native=False, ordered_sum=True, **mkw)))
+    if rank == 0:
+        out["mv_r3"]["single"] = summary_mv(m.fit_iht(Ym, x2, Zm, **mkw))
+    del xs
     # a large model first and small ones after it: the communicator's staging buffer grows (ensure_stage) and is re-used
     lo, cnt = D.column_block(p2, rank, world)
     xs = m.SnpLinAlg(cols2[lo:lo + cnt], n=n2, center=True, scale=True, impute=True, device=local)
@@ -103,6 +136,8 @@ def main():
     cases = {}
 
     def run(name, cols, n, y, z, **kw):
+        if os.environ.get("MIH_WORKER_TRACE"):
+            print("case", name, "rank", rank, file=sys.stderr, flush=True)
         p = cols.shape[0]
         lo, cnt = D.column_block(p, rank, world)
         xs = m.SnpLinAlg(cols[lo:lo + cnt], n=n, center=True, scale=True, impute=True)
@@ -178,6 +213,31 @@ def main():
             rkw["train"] = (srng.random(rn) < 0.8).astype(np.uint8)
         del xr_
         run(f"random{t}", rcols, rn, ry, rz, **rkw)
+
+    # 5c. multivariate traits (round 5: mih_fit_mv takes a column shard): the reference's shipped example, three traits with a
+    #     competing covariate on the ragged matrix with missing genotypes, and tied columns across the shard boundary
+    def run_mv(name, cols_, n_, Y, Z, **kw):
+        if os.environ.get("MIH_WORKER_TRACE"):
+            print("case", name, "rank", rank, file=sys.stderr, flush=True)
+        p_ = cols_.shape[0]
+        lo_, cnt_ = D.column_block(p_, rank, world)
+        xs_ = m.SnpLinAlg(cols_[lo_:lo_ + cnt_], n=n_, center=True, scale=True, impute=True)
+        sh_ = D.fit_iht_sharded(Y, xs_, Z, col_offset=lo_, p_global=p_, verbose=False, **kw)
+        entry_ = dict(sharded=summary_mv(sh_), block=[lo_, cnt_])
+        if rank == 0:
+            xf_ = m.SnpLinAlg(cols_, n=n_, center=True, scale=True, impute=True)
+            entry_["single"] = summary_mv(m.fit_iht(Y, xf_, Z, verbose=False, **kw))
+        cases[name] = entry_
+
+    nm = 1000
+    bedm = m.read_bed(os.path.join(FIX, "multivariate.bed"), nm)
+    Ymv = np.loadtxt(os.path.join(FIX, "multivariate.phen"), delimiter=",").T
+    run_mv("mv_shipped", bedm, nm, Ymv, None, k=10)
+    Y3, Z3 = mv_traits(xo, np.random.default_rng(78), 3, 10, 2)
+    run_mv("mv_r3_cov", cols, n, Y3, Z3, k=12, zkeep=[True, False])
+    e1 = xo.xv_sparse(np.array([lo1 + cnt1 - 1]), np.array([1.0]))
+    Yt = np.vstack([e1 + 0.01 * rng.standard_normal(n), -0.5 * e1 + 0.01 * rng.standard_normal(n)])
+    run_mv("mv_ties_choose", dup, n, Yt, None, k=1, max_iter=8)      # (a degenerate problem: the first steps, before rounding decides the trajectory)
 
     # 6. cross-validation with the (fold, k) grid sharded over the same ranks (one all-gather of the losses)
     from conftest import hash_folds

@@ -40,6 +40,23 @@ def test_sharded_fit_matches_single_process(tmp_path, world):
     assert cv["distributed"] == cv["single"]                               # (fold,k) grid over the ranks == one process
     for oc in others:
         assert oc.pop("cv_grid")["distributed"] == cv["single"]
+    # multivariate traits over the column shards (round 5): same support, iterations and backtracks as the single-process fit,
+    # B / C / Sigma to rounding, the same model on every rank; the tied columns fire _choose! over the WHOLE model
+    for name in ("mv_shipped", "mv_r3_cov", "mv_ties_choose"):
+        case = res["cases"].pop(name)
+        sh, one = case["sharded"], case["single"]
+        assert sh["support"] == one["support"] and len(sh["support"]) > 0, name
+        assert sh["iter"] == one["iter"] and sh["bt"] == one["bt"], name
+        np.testing.assert_allclose(sh["beta"], one["beta"], rtol=0, atol=1e-9, err_msg=name)
+        np.testing.assert_allclose(sh["c"], one["c"], rtol=0, atol=1e-9, err_msg=name)
+        np.testing.assert_allclose(sh["Sigma"], one["Sigma"], rtol=1e-9, err_msg=name)
+        np.testing.assert_allclose(sh["sigma_g"], one["sigma_g"], rtol=1e-9, err_msg=name)
+        np.testing.assert_allclose(sh["logl_trace"], one["logl_trace"], rtol=1e-11, err_msg=name)
+        assert sh["choose_fired"] == one["choose_fired"], name
+        for oc in others:
+            o2 = oc.pop(name)["sharded"]
+            assert o2["support"] == sh["support"] and o2["beta"] == sh["beta"] and o2["logl"] == sh["logl"] and o2["Sigma"] == sh["Sigma"], name
+    assert one["choose_fired"]                                             # (mv_ties_choose, the last of the three)
     tally = SweepTally(f"column-sharded fits, world {world}", ceiling=1, floor=8)
     for name, case in res["cases"].items():
         sh, one = case["sharded"], case["single"]
@@ -144,6 +161,15 @@ def test_native_exchange_with_more_than_one_rank_on_one_gpu(tmp_path, world):
         assert sh["support"] == one["support"] and sh["iter"] == one["iter"] and sh["bt"] == one["bt"], name
         np.testing.assert_allclose(sh["beta"], one["beta"], rtol=0, atol=1e-9, err_msg=name)
         np.testing.assert_allclose(sh["logl_trace"], one["logl_trace"], rtol=1e-11, err_msg=name)
+    # the multivariate fit through the native exchange: the callbacks' result on every rank, the single-process fit to rounding
+    for k in range(world):
+        a, b = res[k]["cases"]["mv_r3"]["native"], res[k]["cases"]["mv_r3"]["callbacks"]
+        _same_summary(a, b, ("mv_r3", k))
+        assert a == res[0]["cases"]["mv_r3"]["native"], k
+    one, sh = res[0]["cases"]["mv_r3"]["single"], res[0]["cases"]["mv_r3"]["native"]
+    assert sh["support"] == one["support"] and sh["iter"] == one["iter"] and sh["bt"] == one["bt"] and sh["iter"] >= 5
+    np.testing.assert_allclose(sh["beta"], one["beta"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(sh["Sigma"], one["Sigma"], rtol=1e-9)
     g = json.load(open(os.path.join(GOLD, "golden_normal_k7.json")))     # the reference's recorded run through the native exchange
     sh = res[0]["cases"]["normal_k7"]["native"]
     assert sh["iter"] == g["iterations"] and [j + 1 for j in sh["support"]] == g["positions_1based"]
