@@ -305,21 +305,28 @@ def cv_roofline(cst):
 FP64_VECTOR_PEAK_TFLOPS = 78.6     # MI355X dense FP64 vector peak (MI355X_MICROARCH.md): the ruler for "f64-equivalent" multiply-adds
 
 
-def mv_object(m, x, n, p, torch, r=10, k=500):
+def mv_object(m, x, n, p, torch, r=10, k=500, comm=None, lo=0, sum_over_ranks=None):
     """BASELINE configs[4]: multivariate IHT (MvNormal, r = 10 traits, k = 500) on the resident matrix -- the 10-residual fused
-    X'(Y - mu) pass and a whole iteration, timed inside a short fit (the library's HIP events around every pass)."""
+    X'(Y - mu) pass and a whole iteration, timed inside a short fit (the library's HIP events around every pass).
+    comm: x is this rank's block of the p columns (first column lo) and the fit is column-sharded (round 5: mih_fit_mv takes a
+    shard); the planted X B is summed over the ranks once, at set-up."""
     rng = np.random.default_rng(3)
     lin = rng.choice(r * p, k, replace=False)
     Y = rng.standard_normal((r, n))
     for t in range(r):
         cols = np.unique(lin[lin % r == t] // r)
-        Y[t] += x.xv_sparse(cols, rng.choice([-1.0, 1.0], cols.size) * rng.uniform(0.15, 0.45, cols.size)) + 1.0
-    m.fit_iht(Y, x, None, k=k, verbose=False, max_iter=3)                  # warm-up
+        eff = rng.choice([-1.0, 1.0], cols.size) * rng.uniform(0.15, 0.45, cols.size)
+        mine = (cols >= lo) & (cols < lo + x.p)
+        xb = x.xv_sparse(cols[mine] - lo, eff[mine])
+        Y[t] += (sum_over_ranks(xb) if comm is not None else xb) + 1.0
+    fit = (lambda **kw: m.fit_iht(Y, x, None, k=k, verbose=False, comm=comm, **kw)) if comm is not None else \
+          (lambda **kw: m.fit_iht(Y, x, None, k=k, verbose=False, **kw))
+    fit(max_iter=3)                                                        # warm-up
     m.profile_read(x, reset=True)
     m.profile_enable(x, True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    res = m.fit_iht(Y, x, None, k=k, verbose=False, max_iter=12)
+    res = fit(max_iter=12)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     m.profile_enable(x, False)
@@ -328,14 +335,15 @@ def mv_object(m, x, n, p, torch, r=10, k=500):
     pass_ms = sum(q["ms"] for q in steady) / max(len(steady), 1)
     gaps = [ps[i + 1]["start_ms"] - ps[i]["start_ms"] - ps[i]["ms"] for i in range(1, len(ps) - 1)]
     alg = x.algorithmic_bytes(r)
-    return {"workload": f"fit_iht MvNormal r={r} traits k={k} on the same SnpArray n={n} p={p} (BASELINE configs[4]), max_iter=12",
+    return {"workload": f"fit_iht MvNormal r={r} traits k={k} on the same SnpArray n={n} p={p} (BASELINE configs[4]), max_iter=12"
+                        + (f"; SNP columns sharded over {comm.world} ranks (this rank: {x.p} columns; per-rank pass and bytes)" if comm is not None else ""),
             "iterations": int(res.iter), "ms_per_iteration": 1e3 * res.time / max(res.iter, 1), "fit_wall_s": wall,
             "pass_ms": pass_ms, "outside_the_pass_ms": sum(gaps) / max(len(gaps), 1), "pass_kernel": steady[0]["kernel"] if steady else None,
             "nonzero": int(np.count_nonzero(res.beta)),
             "roofline": {"bound": "mfma (matrix pipe under the package power cap; DESIGN.md 3.1b)", "hbm_GBps": alg / pass_ms / 1e6,
                          "frac_of_hbm_peak": alg / pass_ms / 1e6 / HBM_PEAK_GBPS,
-                         "f64_equivalent_TFLOPs": 2.0 * n * p * r / (pass_ms * 1e-3) / 1e12,
-                         "frac_of_fp64_vector_peak": 2.0 * n * p * r / (pass_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                         "f64_equivalent_TFLOPs": 2.0 * n * x.p * r / (pass_ms * 1e-3) / 1e12,
+                         "frac_of_fp64_vector_peak": 2.0 * n * x.p * r / (pass_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
                          "note": "2 n p r multiply-adds per pass, each exact (fixed-point residual digits on the matrix cores): what a "
                                  "dense f64 X'R would need 78.6 TFLOP/s of vector FMAs for"}}
 
@@ -513,6 +521,13 @@ def main():
     recovered = int(sum_over_ranks([found])[0]) if sharded else int(found)
     sess.close()
     del sess                                                # (it holds a reference to the matrix: the shard must be gone before the full replica comes)
+    # ---- secondary at N > 1: BASELINE configs[4] column-sharded over the same ranks, through the same communicator ----------
+    mv_sharded = None
+    if sharded and comm is not None and not a.no_mv:
+        try:
+            mv_sharded = mv_object(m, x, n, p, torch, comm=comm, lo=lo, sum_over_ranks=sum_over_ranks)
+        except Exception as e:      # noqa: BLE001 -- reported in the line, the headline stands
+            mv_sharded = {"error": repr(e)}
     if comm is not None and hasattr(comm, "close"):
         comm.close()                                        # collectively, while every rank is alive
     rows = gather_rows([st["launches"], st["ms_sum"], st["bytes"], float(cnt)]) if sharded else [[st["launches"], st["ms_sum"], st["bytes"], float(cnt)]]
@@ -710,6 +725,8 @@ def main():
     # ---- secondary: BASELINE configs[4] (N = 1): MvNormal, r = 10 traits, k = 500 on the same matrix ------------------------
     if world == 1 and mode == "fit" and not a.no_mv and (n, p) == (500_000, 1_000_000):
         out["mv"] = mv_object(m, x, n, p, torch)
+    elif rank == 0 and mv_sharded is not None:
+        out["mv"] = mv_sharded
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"], cores = cpu_baseline(m, n, p, k, seed, a.cpu_seconds)
