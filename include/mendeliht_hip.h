@@ -255,9 +255,10 @@ typedef struct mih_fit_params {
      * evaluated by rank c mod world (mih_cv_assignment does not apply).  Ignored without est_r: those fits are independent. */
     int32_t  cv_threads;
     /* How iht_one_step! (fit.jl:213-263) is driven.  0 = the step is resident on the device wherever the fit allows it (a plain 2-bit
-     * univariate fit: no column shard, group projection, est_r or debias): the k-sparse iterate, the exact finish of project_k!,
+     * univariate fit: no group projection, est_r or debias; a column shard only over the library's own communicator,
+     * mih_comm_create_rccl, whose collectives are then queued inside the chain): the k-sparse iterate, the exact finish of project_k!,
      * the backtracking decision and the stopping rule live in device memory, the host queues the kernels of a step without
-     * waiting and reads one record per step, one step behind.  Exact ties that need _choose! hand the step back to the host-driven
+     * waiting and reads one record per series of attempts, one step behind.  Exact ties that need _choose! hand the step back to the host-driven
      * path.  1 = every step host-driven (rounds 1-4: 26 launches, three waits).  Same results either way, bit for bit. */
     int32_t  step_mode;
 } mih_fit_params;
@@ -384,7 +385,7 @@ enum { MIH_CNT_LANES = 0,          /* lock-step lanes started (summed over calls
        MIH_CNT_MAX_LANE_SLOTS = 7, /* most fits in flight on ONE lane */
        MIH_CNT_INIT_SCORES = 8,    /* initial scores (init_iht_indices!, one per fit): rode a pass or were served by a copy */
        MIH_CNT_RESIDENT_STEPS = 9, /* iht_one_step! calls that ran resident on the device (step_mode 0; single fits and sessions) */
-       MIH_CNT_RESIDENT_ATTEMPTS = 10, /* backtracking attempts the host re-queued for them */
+       MIH_CNT_RESIDENT_ATTEMPTS = 10, /* series of attempt slots that ended with their step still backtracking (it went on in the next series) */
        MIH_CNT_RESIDENT_HANDBACKS = 11, /* steps the device handed back to the host-driven path (_choose! ties, lists beyond its buffers) */
        MIH_CNT_RESIDENT_DIRECT = 12, /* attempts whose projection was queued as a direct gather (threshold forecast, verified) */
        MIH_CNT_RESIDENT_REDOS = 13,  /* ... of which the forecast failed: re-queued with the two histogram sweeps */
