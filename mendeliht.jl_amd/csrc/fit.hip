@@ -1425,7 +1425,7 @@ struct IhtVar {
     bool res_ok = false, res_active = false, res_zero_list = false;
     int res_epoch = 0; uint64_t res_seq = 0; int64_t res_kcap = 0;
     std::vector<uint64_t> res_out;                       // sequence numbers of the steps in flight, oldest first
-    DevBuf<ResCtl> rctl; DevBuf<int64_t> ridx; DevBuf<double> rval; DevBuf<int32_t> rslot; DevBuf<uint32_t> rhist; DevBuf<uint64_t> rsel;
+    DevBuf<ResCtl> rctl; DevBuf<int64_t> ridx; DevBuf<double> rval; DevBuf<int32_t> rslot; DevBuf<uint32_t> rhist; DevBuf<uint64_t> rsel; DevBuf<double> rwalk; DevBuf<uint32_t> rtick;
     bool res_sharded = false; DevBuf<int64_t> rgidx; DevBuf<double> rgval, rmsg; PinBuf<double> rg_h;        // column shard: whole models, messages
     PinBuf<ResCtl> rctl_h; PinBuf<ResRecord> rrec; PinBuf<int64_t> ridx_h; PinBuf<double> rval_h; PinBuf<int32_t> rslot_h;
     struct ResRun { int64_t limit = 0, issued = 0, done = 0; int max_step = 3; };
@@ -1447,6 +1447,8 @@ struct IhtVar {
         MIH_TRY(rctl.alloc(1)); MIH_TRY(ridx.alloc((size_t)res_kcap * 3)); MIH_TRY(rval.alloc((size_t)res_kcap * 3));
         MIH_TRY(rslot.alloc((size_t)res_kcap * 4)); MIH_TRY(rhist.alloc(4096));
         MIH_TRY(rsel.alloc((size_t)kResCollectBlocks * (1 + 2 * kResCollectSlots)));
+        MIH_TRY(rwalk.alloc((size_t)(q + 1) * kZtrBlocks * 256)); MIH_TRY(rtick.alloc((size_t)(q + 1) * kZtrBlocks));      // k_res_stats: the walkers' sums, a ticket per walk-block
+        MIH_HIP(hipMemsetAsync(rtick.p, 0, sizeof(uint32_t) * (size_t)(q + 1) * kZtrBlocks, s));
         if (res_sharded) {
             const size_t mlen = 2 + 2 * (size_t)K;
             MIH_TRY(rgidx.alloc((size_t)res_kcap * 3)); MIH_TRY(rgval.alloc((size_t)res_kcap * 3));          // the two whole models + the shard's own survivors
@@ -1486,6 +1488,8 @@ struct IhtVar {
         M.miss_ptr = h->miss_ptr; M.miss_row = h->miss_row;
         return M;
     }
+    // k_res_xgk / k_res_xb: workgroups of 1024 rows (64 dwords of every cached column), 68 KB of dynamic LDS
+    unsigned res_wide_blocks() const { return (unsigned)((h->n_pad / 16 + 63) / 64); }
     uint64_t res_zkeep_mask() const { uint64_t m = 0; for (int l = 0; l < q; ++l) if (zkeep[l]) m |= 1ull << l; return m; }
     bool res_fix() const { return h->impute && h->total_missing > 0; }
     void xv_cache_forget()           // the host's map of the column cache no longer describes it (the device kept the books), or vice versa
@@ -1642,9 +1646,9 @@ struct IhtVar {
     {
         const ResPtrs P = res_ptrs(); const ResMat M = res_mat();
         if (!res_fix() && !res_sharded)
-            hipLaunchKernelGGL(k_res_xgk<false>, dim3(nb), dim3(256), 0, s, P, res_epoch, M, z.p, xb.p, zc.p, mu.p, w.p, q, dist, link, nb_r, xgk.p, red.p);
+            hipLaunchKernelGGL(k_res_xgk<false>, dim3(res_wide_blocks()), dim3(kResWideRows), kResWideLds, s, P, res_epoch, M, z.p, xb.p, zc.p, mu.p, w.p, q, dist, link, nb_r, xgk.p, red.p);
         else {
-            hipLaunchKernelGGL(k_res_xgk<true>, dim3(nb), dim3(256), 0, s, P, res_epoch, M, z.p, xb.p, zc.p, mu.p, w.p, q, dist, link, nb_r, xgk.p, red.p);
+            hipLaunchKernelGGL(k_res_xgk<true>, dim3(res_wide_blocks()), dim3(kResWideRows), kResWideLds, s, P, res_epoch, M, z.p, xb.p, zc.p, mu.p, w.p, q, dist, link, nb_r, xgk.p, red.p);
             if (res_fix()) hipLaunchKernelGGL(k_res_missing, dim3(1), dim3(1024), 0, s, P, res_epoch, -1, 0, M, xgk.p);
             if (res_sharded) {
                 hipLaunchKernelGGL(k_res_sumsq, dim3(1), dim3(1), 0, s, P, res_epoch, xgk.p + n);
@@ -1683,12 +1687,12 @@ struct IhtVar {
             hipLaunchKernelGGL(k_res_select_global, dim3(1), dim3(1024), 0, s, P, res_epoch, a, K, seq, M, full.p, p, q, zk, (int)zkeepn, groups * (k + zkeepn));
         }
         if (!res_fix() && !res_sharded)
-            hipLaunchKernelGGL(k_res_xb<false>, dim3(nb), dim3(256), 0, s, P, res_epoch, a, M, z.p, y.p, w.p, q, dist, link, nb_r, xb.p, zc.p, mu.p, red.p);
+            hipLaunchKernelGGL(k_res_xb<false>, dim3(res_wide_blocks()), dim3(kResWideRows), kResWideLds, s, P, res_epoch, a, M, z.p, y.p, w.p, q, dist, link, nb_r, xb.p, zc.p, mu.p, red.p);
         else {
             // (the partial product goes to a scratch vector -- xgk is free here -- so that a chain whose gate is closed, whose
             // collectives run all the same, leaves xb alone)
             double *part = res_sharded ? xgk.p : xb.p;
-            hipLaunchKernelGGL(k_res_xb<true>, dim3(nb), dim3(256), 0, s, P, res_epoch, a, M, z.p, y.p, w.p, q, dist, link, nb_r, part, zc.p, mu.p, red.p);
+            hipLaunchKernelGGL(k_res_xb<true>, dim3(res_wide_blocks()), dim3(kResWideRows), kResWideLds, s, P, res_epoch, a, M, z.p, y.p, w.p, q, dist, link, nb_r, part, zc.p, mu.p, red.p);
             if (res_fix()) hipLaunchKernelGGL(k_res_missing, dim3(1), dim3(1024), 0, s, P, res_epoch, a, 1, M, part);
             if (res_sharded) MIH_TRY(allreduce_dev(part, n, 0));
             hipLaunchKernelGGL(k_res_mu, dim3(nb), dim3(256), 0, s, P, res_epoch, a, (const double *)part, z.p, y.p, w.p, n, q, dist, link, nb_r, xb.p, zc.p, mu.p, red.p);
@@ -1731,8 +1735,8 @@ struct IhtVar {
     int res_enqueue_back()
     {
         const ResPtrs P = res_ptrs();
-        hipLaunchKernelGGL(k_res_stats, dim3(kZtrBlocks, q + 1), dim3(256), 0, s, P, res_epoch, z.p, xb.p, zc.p, y.p, mu.p, w.p, n, q, dist, link, nb_r,
-                           r.p, ztr.p, xtv.scal.p + xtv.rhs_cap * 4);
+        hipLaunchKernelGGL(k_res_stats, dim3(4 * kZtrBlocks, q + 1), dim3(64), 0, s, P, res_epoch, z.p, xb.p, zc.p, y.p, mu.p, w.p, n, q, dist, link, nb_r,
+                           r.p, ztr.p, xtv.scal.p + xtv.rhs_cap * 4, rwalk.p, rtick.p);
         xtv.gate = &rctl.p->live_epoch; xtv.gate_val = res_gate_step(res_epoch); xtv.stats_done = true;
         xtv.shook.spart = xtv.scal.p + xtv.rhs_cap * 4; xtv.shook.zpart = ztr.p; xtv.shook.df2 = rctl.p->df2; xtv.shook.q = q;
         xtv.shook.zblocks = kZtrBlocks; xtv.shook.ebits = xtv.dm.ebits;

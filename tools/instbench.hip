@@ -92,6 +92,47 @@ __global__ void __launch_bounds__(256) k_mix_sdwa_fma(unsigned long long *t, uin
     if ((threadIdx.x & 63) == 0) t[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
+// u32 -> f64 conversion (the X_S v decode of round 5 asks: is it a full-rate instruction?)
+__global__ void __launch_bounds__(256) k_cvt_f64_u32(unsigned long long *t, uint32_t *sink, uint32_t seed)
+{
+    double a[16]; uint32_t b = seed ^ threadIdx.x;
+    for (int i = 0; i < 16; ++i) a[i] = 0.0;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < ITER; ++it) {
+        #pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(a[i]) : "v"(b));
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    double s = 0; for (int i = 0; i < 16; ++i) s += a[i];
+    if (s == 0.1234567) sink[0] = 1;
+    if ((threadIdx.x & 63) == 0) t[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+// the two decodes of a 2-bit dosage for an f64 multiply-add, 16 dosages of one dword per iteration:
+//   A: v_bfe_u32, v_cvt_f64_u32, v_fma_f64        B: v_bfe_u32 into the low half of (2^52 | g), v_add_f64 (- 2^52), v_fma_f64
+template <int VARIANT>
+__global__ void __launch_bounds__(256) k_decode_fma(unsigned long long *t, uint32_t *sink, uint32_t seed)
+{
+    double acc[16]; for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+    const double r = 1.0 + 1e-9 * threadIdx.x;
+    uint32_t w = seed ^ (threadIdx.x * 2654435761u);
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < ITER; ++it) {
+        #pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t g = (w >> (2 * i)) & 3u;
+            double d;
+            if (VARIANT == 0) d = (double)g;
+            else d = __hiloint2double(0x43300000, (int)g) - 4503599627370496.0;
+            acc[i] = fma(d, r, acc[i]);
+        }
+        asm volatile("" : "+v"(w));
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    double s = 0; for (int i = 0; i < 16; ++i) s += acc[i];
+    if (s == 0.1234567) sink[0] = 1;
+    if ((threadIdx.x & 63) == 0) t[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x16 __attribute__((ext_vector_type(16)));
@@ -184,6 +225,7 @@ int main()
     R(k_add_u32, 16) R(k_mad_u24, 16) R(k_mul_lo, 16) R(k_fma_f32, 16) R(k_pk_fma_f16, 16) R(k_dot4_i8, 16) R(k_dot8_i4, 16) R(k_cndmask, 16) R(k_cvt_f32_u32, 16)
     R(k_fma_f64, 16) R(k_add_f64, 16) R(k_mul_f64, 16) R(k_pk_fma_f32, 16) R(k_pk_add_f32, 16) R(k_lshl_add_u64, 16) R(k_mov_b64, 16)
     R(k_mix_sdwa_fma, 32)
+    R(k_cvt_f64_u32, 16) R(k_decode_fma<0>, 16) R(k_decode_fma<1>, 16)
     R(k_mfma_i8_32, 16) R(k_mfma_i8_16, 16) R(k_mfma_f64_16, 16) R(k_mfma_f64_4, 16)
     R(k_mfma_sc_fp4_fp8, 16) R(k_mfma_sc_fp4_fp4, 16) R(k_mfma_sc_fp8_fp8, 16) R(k_mfma_sc16_fp4_fp8, 16)
     return 0;
