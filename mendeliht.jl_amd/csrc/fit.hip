@@ -1447,8 +1447,9 @@ struct IhtVar {
         MIH_TRY(rctl.alloc(1)); MIH_TRY(ridx.alloc((size_t)res_kcap * 3)); MIH_TRY(rval.alloc((size_t)res_kcap * 3));
         MIH_TRY(rslot.alloc((size_t)res_kcap * 4)); MIH_TRY(rhist.alloc(4096));
         MIH_TRY(rsel.alloc((size_t)kResCollectBlocks * (1 + 2 * kResCollectSlots)));
-        MIH_TRY(rwalk.alloc((size_t)(q + 1) * kZtrBlocks * 256)); MIH_TRY(rtick.alloc((size_t)(q + 1) * kZtrBlocks));      // k_res_stats: the walkers' sums, a ticket per walk-block
-        MIH_HIP(hipMemsetAsync(rtick.p, 0, sizeof(uint32_t) * (size_t)(q + 1) * kZtrBlocks, s));
+        const size_t slices = (size_t)(q + kResStatCov - 1) / kResStatCov;
+        MIH_TRY(rwalk.alloc(slices * kStatBlocksRes * 10 * 256)); MIH_TRY(rtick.alloc(slices * kStatBlocksRes));      // k_res_stats: the walkers' sums, a ticket per walk-block
+        MIH_HIP(hipMemsetAsync(rtick.p, 0, sizeof(uint32_t) * slices * kStatBlocksRes, s));
         if (res_sharded) {
             const size_t mlen = 2 + 2 * (size_t)K;
             MIH_TRY(rgidx.alloc((size_t)res_kcap * 3)); MIH_TRY(rgval.alloc((size_t)res_kcap * 3));          // the two whole models + the shard's own survivors
@@ -1687,15 +1688,15 @@ struct IhtVar {
             hipLaunchKernelGGL(k_res_select_global, dim3(1), dim3(1024), 0, s, P, res_epoch, a, K, seq, M, full.p, p, q, zk, (int)zkeepn, groups * (k + zkeepn));
         }
         if (!res_fix() && !res_sharded)
-            hipLaunchKernelGGL(k_res_xb<false>, dim3(res_wide_blocks()), dim3(kResWideRows), kResWideLds, s, P, res_epoch, a, M, z.p, y.p, w.p, q, dist, link, nb_r, xb.p, zc.p, mu.p, red.p);
+            hipLaunchKernelGGL(k_res_xb<false>, dim3(res_wide_blocks()), dim3(kResWideRows), kResWideLds, s, P, res_epoch, a, M, z.p, y.p, w.p, q, dist, link, nb_r, xb.p, zc.p, mu.p, red.p, r.p);
         else {
             // (the partial product goes to a scratch vector -- xgk is free here -- so that a chain whose gate is closed, whose
             // collectives run all the same, leaves xb alone)
             double *part = res_sharded ? xgk.p : xb.p;
-            hipLaunchKernelGGL(k_res_xb<true>, dim3(res_wide_blocks()), dim3(kResWideRows), kResWideLds, s, P, res_epoch, a, M, z.p, y.p, w.p, q, dist, link, nb_r, part, zc.p, mu.p, red.p);
+            hipLaunchKernelGGL(k_res_xb<true>, dim3(res_wide_blocks()), dim3(kResWideRows), kResWideLds, s, P, res_epoch, a, M, z.p, y.p, w.p, q, dist, link, nb_r, part, zc.p, mu.p, red.p, r.p);
             if (res_fix()) hipLaunchKernelGGL(k_res_missing, dim3(1), dim3(1024), 0, s, P, res_epoch, a, 1, M, part);
             if (res_sharded) MIH_TRY(allreduce_dev(part, n, 0));
-            hipLaunchKernelGGL(k_res_mu, dim3(nb), dim3(256), 0, s, P, res_epoch, a, (const double *)part, z.p, y.p, w.p, n, q, dist, link, nb_r, xb.p, zc.p, mu.p, red.p);
+            hipLaunchKernelGGL(k_res_mu, dim3(nb), dim3(256), 0, s, P, res_epoch, a, (const double *)part, z.p, y.p, w.p, n, q, dist, link, nb_r, xb.p, zc.p, mu.p, red.p, r.p);
         }
         hipLaunchKernelGGL(k_res_decide, dim3(1), dim3(256), 0, s, P, res_epoch, a, more ? 1 : 0, seq, red.p, nb, n, dist);
         MIH_HIP(hipGetLastError());
@@ -1735,8 +1736,9 @@ struct IhtVar {
     int res_enqueue_back()
     {
         const ResPtrs P = res_ptrs();
-        hipLaunchKernelGGL(k_res_stats, dim3(4 * kZtrBlocks, q + 1), dim3(64), 0, s, P, res_epoch, z.p, xb.p, zc.p, y.p, mu.p, w.p, n, q, dist, link, nb_r,
-                           r.p, ztr.p, xtv.scal.p + xtv.rhs_cap * 4, rwalk.p, rtick.p);
+        static_assert(kZtrBlocks == 2 * kStatBlocksRes, "k_res_stats pairs the walks of k_zt_r and k_r_stats");
+        hipLaunchKernelGGL(k_res_stats, dim3(4 * kStatBlocksRes, (q + kResStatCov - 1) / kResStatCov), dim3(64), 0, s, P, res_epoch, z.p, r.p, n, q,
+                           ztr.p, xtv.scal.p + xtv.rhs_cap * 4, rwalk.p, rtick.p);
         xtv.gate = &rctl.p->live_epoch; xtv.gate_val = res_gate_step(res_epoch); xtv.stats_done = true;
         xtv.shook.spart = xtv.scal.p + xtv.rhs_cap * 4; xtv.shook.zpart = ztr.p; xtv.shook.df2 = rctl.p->df2; xtv.shook.q = q;
         xtv.shook.zblocks = kZtrBlocks; xtv.shook.ebits = xtv.dm.ebits;
