@@ -516,6 +516,22 @@ def main():
               "backtracks": int(nbt2), "what": "mih_fit_params::step_mode = 1: the host-driven step of rounds 1-4 (26 launches, three host "
               "waits per step without backtracking), same box, same fit, a fresh session"}
 
+    # ... and of what the measurement itself costs (N = 1): the same session goes on for a few steps with the hook OFF.  The hook
+    # brackets every X'r pass with two HIP event records, queue operations of their own inside the step chain; the timed region
+    # above carries them (the roofline is measured there), this figure says what a step takes without them
+    unhooked = None
+    if world == 1:
+        nun = min(a.steps, 20)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        sess.run(nun)
+        torch.cuda.synchronize()
+        el3 = time.perf_counter() - t2
+        kern_ms_timed = st["ms_sum"] / max(st["launches"], 1)
+        unhooked = {"steps": nun, "ms_per_step": 1e3 * el3 / nun, "outside_the_pass_ms_per_step": 1e3 * el3 / nun - kern_ms_timed,
+                    "what": "the same fit continued with the measurement hook off (no HIP event records around the passes); the pass kernel's "
+                            "duration is taken from the timed region"}
+
     bhat, _ = sess.model()
     found = float(np.intersect1d(np.flatnonzero(bhat) + lo, supp).size)
     recovered = int(sum_over_ranks([found])[0]) if sharded else int(found)
@@ -586,6 +602,8 @@ def main():
         }
         if ab is not None:
             out["config"]["host_driven_steps_same_box"] = ab
+        if unhooked is not None:
+            out["config"]["without_the_measurement_hook"] = unhooked
         # what is outside the pass, split: the exchanges (per kind, timed on the fit's stream / the host clock by the library's hook)
         # and the chain of small kernels
         ex_ms = sum(v["ms"] for v in exch.values()) / a.steps

@@ -25,10 +25,9 @@ for a, b in steps[-back:]:
         gap = (st - prev_end) / 1e3 if prev_end else 0.0
         big = en - st > 1_000_000
         if big and first is not None:
-            print(f"   -> between the passes: {(st - first) / 1e3:8.1f} us ({b - a - 1} launches, {empty} of them gated off: under 3.2 us)\n")
+            print(f"   -> between the passes: {(st - first) / 1e3:8.1f} us ({b - a - 1} launches)\n")
         print(f"{name:46s} {(en - st) / 1e3:10.1f} us   gap {gap:6.1f} us")
         if big: first = en
-        elif en - st < 3200: empty += 1
         prev_end = en
 # mean over all steps of the kind
 if steps:
