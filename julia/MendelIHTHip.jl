@@ -285,7 +285,8 @@ function fit_iht(Y::AbstractMatrix{Float64}, xt::Transpose{Float64, HipSnpLinAlg
         group::AbstractVector{Int}=Int[], weight::AbstractVector{Float64}=Float64[],
         zkeep::BitVector=trues(size(Z, 1)), est_r::Symbol=:None, use_maf::Bool=false, debias::Bool=false,
         verbose::Bool=true, tol::Float64=1e-4, max_iter::Int=200, min_iter::Int=5, max_step::Int=3,
-        io::IO=stdout, init_beta::Bool=false, memory_efficient::Bool=true, xtv_digits::Int=0)
+        io::IO=stdout, init_beta::Bool=false, memory_efficient::Bool=true, xtv_digits::Int=0,
+        comm::Ptr{Cvoid}=C_NULL)                 # a MihComm / `rccl_comm(...)`: x holds this process's block of SNP columns, B comes back for them
     x = xt.parent
     d isa MvNormal || throw(ArgumentError("multivariate responses need d = MvNormal"))
     (isempty(group) && isempty(weight) && !use_maf && est_r === :None && J == 1) ||
@@ -296,7 +297,7 @@ function fit_iht(Y::AbstractMatrix{Float64}, xt::Transpose{Float64, HipSnpLinAlg
     r, n = size(YY); q = size(ZZ, 1)
     n == x.n || throw(DimensionMismatch("Y has $n samples, x has $(x.n)"))
     prm, keep = make_params(x, k, 1, Normal(), IdentityLink(), Int[], Float64[], zkeep, :None, false, false, tol,
-                            max_iter, min_iter, max_step, init_beta, C_NULL, xtv_digits)
+                            max_iter, min_iter, max_step, init_beta, comm, xtv_digits)
     B = zeros(r, x.p); C = zeros(r, q); S = zeros(r, r); pve = zeros(r)
     lt = zeros(max_iter + 1); tt = zeros(max_iter + 1); bt = zeros(Int32, max_iter + 1)
     res = MihMvResult(0, 0, 0, 0, 0, pointer(B), pointer(C), pointer(S), pointer(pve), pointer(lt), pointer(tt), pointer(bt))

@@ -1846,12 +1846,16 @@ def test_randomized_multivariate_cv_vs_oracle(mih, oracle):
             stable = np.ones_like(ok)
             for g in _NUDGES:
                 stable &= np.isclose(oracle.cv_mv(ox, Y, Z * g, path=path, q=q, folds=folds, **extra)[1], oraw, rtol=1e-5, atol=0)
+            mono = np.zeros(q, dtype=bool)
             if extra.get("init_beta"):          # a SNP monomorphic in a fold's training rows (ib_cond, iht_oracle.h; seed 10137): the univariate
                 for f in range(q):              # regressions of initialize_beta! (multivariate.jl:519-560) see the same constant predictor
                     one = oracle.fit_iht(ox, Y[0], None, k=1, max_iter=1, train=(folds != f + 1).astype(np.uint8), init_beta=True)
-                    if one["ib_cond"] < 1e-10:
-                        stable[f, :] = False
-            assert (ok | ~stable).all() and (~stable).sum() <= max(2, stable.size // 5), (tag, np.argwhere(~ok & stable), raw, oraw)
+                    mono[f] = one["ib_cond"] < 1e-10
+            # (seed 12023, round 5: n = 291 in two folds -- a fold of that class is set aside WHOLE, every model size of it; the ceiling
+            # on entries that are merely unstable under nudges applies to the other folds, and one fold at most may be of that class)
+            nudged = int((~stable[~mono]).sum())
+            stable[mono, :] = False
+            assert (ok | ~stable).all() and nudged <= max(2, stable.size // 5) and mono.sum() <= 1, (tag, np.argwhere(~ok & stable), mono, raw, oraw)
             tally.set_aside("entry unstable in the oracle itself", tag, count=int((~ok).sum()))
             tally.ok(int(ok.sum()))
             whole = stable.all(axis=0)
