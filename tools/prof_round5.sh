@@ -11,7 +11,7 @@ rm -rf $R/gpurun_out/prof_r05_stats $R/gpurun_out/prof_r05_fetch $R/gpurun_out/p
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_r05_stats -o bench -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/r05_bench_under_rocprof.json 2> $R/gpurun_out/prof_r05_stats.err
 echo "stats rc=$?"
 cp $(find $R/gpurun_out/prof_r05_stats -name "*kernel_stats.csv" | head -1) $R/gpurun_out/r05_bench_kernel_stats.csv
-python3 $R/tools/trace_chain.py $R/gpurun_out/prof_r05_stats 3 > $R/gpurun_out/r05_step_chain.txt 2>&1; tail -25 $R/gpurun_out/r05_step_chain.txt
+python3 $R/tools/trace_chain.py $R/gpurun_out/prof_r05_stats 2 any > $R/gpurun_out/r05_step_chain_with_legs.txt 2>&1; tail -5 $R/gpurun_out/r05_step_chain_with_legs.txt
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/prof_r05_fetch -o pmc -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-cv --no-mv > $R/gpurun_out/prof_r05_fetch.json 2> $R/gpurun_out/prof_r05_fetch.err
 echo "fetch rc=$?"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/prof_r05_write -o pmc -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-cv --no-mv > $R/gpurun_out/prof_r05_write.json 2> $R/gpurun_out/prof_r05_write.err
