@@ -2469,7 +2469,7 @@ def test_resident_steps_equal_host_driven_steps(mih, oracle, normal_pair, normal
     """(VERDICT r4 item 1) iht_one_step! resident on the device (mih_fit_params::step_mode = 0: the iterate, the finish of
     project_k!, the backtracking decision and the stopping rule in device memory, one record per step for the host) against
     the host-driven step of rounds 1-4 (step_mode = 1): the same iteration log, support, estimates and fitted means -- bit for
-    bit, since every sum is formed in the same order -- over families, covariates with and without zkeep, prior weights,
+    bit, since every sum is formed in the same order -- over families, covariates with and without zkeep (up to six), prior weights,
     init_beta, imputed missing entries, steps that backtrack, a step budget that runs out, and exact ties (the device hands
     those steps back: _choose!)."""
     x, ox = normal_pair
@@ -2504,6 +2504,16 @@ def test_resident_steps_equal_host_driven_steps(mih, oracle, normal_pair, normal
     cases.append(("missing entries, normal", dict(y=em + 0.5 + rng.standard_normal(6001), x=xm, z=zm, k=8)))
     cases.append(("missing entries, bernoulli", dict(y=(rng.random(6001) < 1 / (1 + np.exp(-em))).astype(float), x=xm, z=zm, k=6,
                                                      d=mih.Bernoulli(), l=mih.LogitLink())))
+    # six covariates, three of them competing in the projection: k_res_stats takes Z'r four covariates at a time (two slices of its
+    # grid), the covariate tail rides in the select; a 1537-row matrix: two of the 1024-row workgroups of the X_S v kernels, the second ragged
+    z6 = np.column_stack([np.ones(6001)] + [rng.standard_normal(6001) for _ in range(5)])
+    cases.append(("six covariates, poisson", dict(y=rng.poisson(np.exp(0.25 * em + 0.2 * z6[:, 3])).astype(float), x=xm, z=z6, k=7,
+                                                  zkeep=[1, 1, 0, 0, 1, 0], d=mih.Poisson(), l=mih.LogLink())))
+    xs = mih.SnpLinAlg.synthetic(1537, 700, seed=11)
+    es = xs.xv_sparse(np.array([5, 77, 300, 699]), np.array([0.8, -0.6, 0.5, 0.7]))
+    z6s = z6[:1537]
+    cases.append(("six covariates, normal, 1537 rows", dict(y=es + z6s @ np.array([0.3, 0.2, 0.0, -0.4, 0.1, 0.0]) + rng.standard_normal(1537), x=xs, z=z6s,
+                                                            k=6, zkeep=[1, 0, 0, 0, 0, 0])))
     cols, yt, tied = tied_case()
     xt = mih.SnpLinAlg(cols, n=1000, center=True, scale=True, impute=True)
     cases.append(("exact ties: _choose!", dict(y=yt, x=xt, z=None, k=2)))
