@@ -147,7 +147,12 @@ def test_stand_in_rccl_matches_the_real_prototypes_and_codes(tmp_path):
     src = os.path.join(ROOT, "tests", "fake_rccl.c")
     lib = tmp_path / "libfake_rccl.so"
     subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", src,
-                           "-o", str(lib), "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-lpthread"])
+                           "-o", str(lib), "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-lpthread", "-ldl"])
+    # ... and the code object of its one kernel (the device-side all-reduce) cross-compiles for gfx950; its argument block is the C file's
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--genco", "--offload-arch=gfx950", "-O2", os.path.join(ROOT, "tests", "fake_rccl_kernels.hip"),
+                           "-o", str(tmp_path / "fake_rccl_kernels.hsaco")])
+    ksrc = open(os.path.join(ROOT, "tests", "fake_rccl_kernels.hip")).read()
+    assert "struct FakePeers { const double *p[16]; int n; };" in ksrc and "typedef struct { const double *p[16]; int n; } fake_peers;" in open(src).read()
     out = subprocess.check_output(["nm", "-D", "--defined-only", str(lib)], text=True)
     have = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
     assert {"ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclAllReduce", "ncclAllGather", "ncclGetErrorString"} <= have

@@ -124,11 +124,14 @@ def _same_summary(a, b, what):
 
 def _build_fake_rccl():
     """tests/libfake_rccl.so from tests/fake_rccl.c (gcc against the real <rccl/rccl.h>: the stand-in's definitions must match
-    the real prototypes to compile)."""
+    the real prototypes to compile) and, beside it, the code object of its one kernel (the device-side all-reduce of round 5)."""
     src, lib = os.path.join(ROOT, "tests", "fake_rccl.c"), os.path.join(ROOT, "tests", "libfake_rccl.so")
     if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
         subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", src, "-o", lib,
-                               "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-lpthread"])
+                               "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-lpthread", "-ldl"])
+    ksrc, kobj = os.path.join(ROOT, "tests", "fake_rccl_kernels.hip"), os.path.join(ROOT, "tests", "fake_rccl_kernels.hsaco")
+    if not os.path.exists(kobj) or os.path.getmtime(kobj) < os.path.getmtime(ksrc):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--genco", "--offload-arch=gfx950", "-O2", ksrc, "-o", kobj])
     return lib
 
 

@@ -6,7 +6,8 @@ tag=$1
 cd $GRAFT_REPO_ROOT
 timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -14 | tee gpurun_out/${tag}_gpu_suite_tail.txt
 timeout 900 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; tail -c 300 gpurun_out/${tag}_bench.err
-gcc -O2 -shared -fPIC -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include tests/fake_rccl.c -o tests/libfake_rccl.so -L/opt/rocm/lib -lamdhip64 -lrt -lpthread
+gcc -O2 -shared -fPIC -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include tests/fake_rccl.c -o tests/libfake_rccl.so -L/opt/rocm/lib -lamdhip64 -lrt -lpthread -ldl
+/opt/rocm/bin/hipcc --genco --offload-arch=gfx950 -O2 tests/fake_rccl_kernels.hip -o tests/fake_rccl_kernels.hsaco
 MIH_FAKE_RCCL_SLOT_MB=64 MIH_BENCH_BACKEND=gloo MIH_BENCH_ONE_DEVICE=1 MENDELIHT_RCCL_LIB=$PWD/tests/libfake_rccl.so timeout 600 python bench.py --gpus 2 --steps 10 --warmup 3 --no-cv > gpurun_out/${tag}_bench_n2_standin.json 2> gpurun_out/${tag}_bench_n2_standin.err
 tail -c 300 gpurun_out/${tag}_bench_n2_standin.err
 python - <<PY
