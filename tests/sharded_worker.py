@@ -235,6 +235,13 @@ def main():
     run_mv("mv_shipped", bedm, nm, Ymv, None, k=10)
     Y3, Z3 = mv_traits(xo, np.random.default_rng(78), 3, 10, 2)
     run_mv("mv_r3_cov", cols, n, Y3, Z3, k=12, zkeep=[True, False])
+    # a matrix of 40 columns: with three ranks a shard's r * p entries are fewer than the K the projection asks for (it sends all it has)
+    trng = np.random.default_rng(79)
+    tcols = make_bed(trng, 300, 40)
+    xt_ = m.SnpLinAlg(tcols, n=300, center=True, scale=True, impute=True)
+    Yt_, _ = mv_traits(xt_, trng, 2, 6, 1)
+    del xt_
+    run_mv("mv_tiny", tcols, 300, Yt_, None, k=30, max_iter=40)
     e1 = xo.xv_sparse(np.array([lo1 + cnt1 - 1]), np.array([1.0]))
     Yt = np.vstack([e1 + 0.01 * rng.standard_normal(n), -0.5 * e1 + 0.01 * rng.standard_normal(n)])
     run_mv("mv_ties_choose", dup, n, Yt, None, k=1, max_iter=8)      # (a degenerate problem: the first steps, before rounding decides the trajectory)

@@ -42,7 +42,7 @@ def test_sharded_fit_matches_single_process(tmp_path, world):
         assert oc.pop("cv_grid")["distributed"] == cv["single"]
     # multivariate traits over the column shards (round 5): same support, iterations and backtracks as the single-process fit,
     # B / C / Sigma to rounding, the same model on every rank; the tied columns fire _choose! over the WHOLE model
-    for name in ("mv_shipped", "mv_r3_cov", "mv_ties_choose"):
+    for name in ("mv_shipped", "mv_r3_cov", "mv_tiny", "mv_ties_choose"):
         case = res["cases"].pop(name)
         sh, one = case["sharded"], case["single"]
         assert sh["support"] == one["support"] and len(sh["support"]) > 0, name
@@ -56,7 +56,7 @@ def test_sharded_fit_matches_single_process(tmp_path, world):
         for oc in others:
             o2 = oc.pop(name)["sharded"]
             assert o2["support"] == sh["support"] and o2["beta"] == sh["beta"] and o2["logl"] == sh["logl"] and o2["Sigma"] == sh["Sigma"], name
-    assert one["choose_fired"]                                             # (mv_ties_choose, the last of the three)
+    assert one["choose_fired"]                                             # (mv_ties_choose, the last of the four)
     tally = SweepTally(f"column-sharded fits, world {world}", ceiling=1, floor=8)
     for name, case in res["cases"].items():
         sh, one = case["sharded"], case["single"]
