@@ -926,11 +926,12 @@ def fit_iht(y, x, z=None, *, k=10, J=1, d=None, l=None, group=None, weight=None,
     def progress(_user, it, logl, bt, tl):
         line = f"Iteration {it}: loglikelihood = {logl!r}, backtracks = {bt}, tol = {tl!r}"
         lines.append(line)
-        if verbose:
-            print(line, file=io)
+        print(line, file=io)
 
+    # the per-iteration callback only when its lines are printed as they come (verbose): a fit whose steps the HOST drives waits
+    # for it between two steps (tens of microseconds of interpreter per iteration); a quiet fit gets the same lines from the trace
     keep = []
-    prm = _params(k, J, d, l, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, q, x.p, keep, progress,
+    prm = _params(k, J, d, l, tol, max_iter, min_iter, max_step, est_r, zkeep, weight, group, q, x.p, keep, progress if verbose else None,
                   init_beta=init_beta, comm=comm, debias=debias, xtv_digits=xtv_digits, choose=choose, step_mode=step_mode)
     if verbose:
         _print_parameters(io, k, d, l, use_maf, group, debias, tol, max_iter, min_iter)
@@ -943,6 +944,8 @@ def fit_iht(y, x, z=None, *, k=10, J=1, d=None, l=None, group=None, weight=None,
     res.logl_trace, res.tol_trace, res.bt_trace = _p(lt), _p(tt), _p(bt)
     _check(lib().mih_fit_iht(x._h, C.byref(prm), _p(y), _p(z), q, _p(tr), C.byref(res)))
     m = res.n_trace
+    if not verbose:
+        lines = _trace_lines(lt, bt, tt, m)
     if verbose and res.iter >= max_iter:
         print(f"Did not converge after {max_iter} iterations! IHT run time was {res.time} seconds", file=io)
     dd = NegativeBinomial(res.nb_r) if isinstance(d, NegativeBinomial) else d
@@ -951,6 +954,11 @@ def fit_iht(y, x, z=None, *, k=10, J=1, d=None, l=None, group=None, weight=None,
     return IHTResult(res.time, res.logl, res.iter, beta, c, J, k, np.array([] if group is None else group), dd, res.pve,
                      trace=dict(logl=lt[:m].copy(), tol=tt[:m].copy(), backtracks=bt[:m].copy(), lines=lines),
                      choose_fired=bool(res.choose_fired), mu=mu)
+
+
+def _trace_lines(lt, bt, tt, m):
+    """the lines the progress callback prints, from the trace arrays of a quiet fit"""
+    return [f"Iteration {i + 1}: loglikelihood = {float(lt[i])!r}, backtracks = {int(bt[i])}, tol = {float(tt[i])!r}" for i in range(m)]
 
 
 def _checky(y, d):
@@ -978,11 +986,10 @@ def _fit_mv(Y, x, Z, k, d, l, zkeep, verbose, tol, max_iter, min_iter, max_step,
     def progress(_user, it, logl, bt, tl):
         line = f"Iteration {it}: loglikelihood = {logl!r}, backtracks = {bt}, tol = {tl!r}"
         lines.append(line)
-        if verbose:
-            print(line, file=io)
+        print(line, file=io)
 
     keep = []
-    prm = _params(k, 1, Normal(), l, tol, max_iter, min_iter, max_step, "None", zkeep, None, None, q, x.p, keep, progress,
+    prm = _params(k, 1, Normal(), l, tol, max_iter, min_iter, max_step, "None", zkeep, None, None, q, x.p, keep, progress if verbose else None,
                   init_beta=init_beta, xtv_digits=xtv_digits, choose=choose, comm=comm)
     if verbose:
         _print_parameters(io, k, MvNormal(), l, False, None, False, tol, max_iter, min_iter)
@@ -996,6 +1003,8 @@ def _fit_mv(Y, x, Z, k, d, l, zkeep, verbose, tol, max_iter, min_iter, max_step,
     res.logl_trace, res.tol_trace, res.bt_trace = _p(lt), _p(tt), _p(bt)
     _check(lib().mih_fit_mv(x._h, C.byref(prm), _p(Y), r, _p(Z), q, _p(tr), C.byref(res)))
     m = res.n_trace
+    if not verbose:
+        lines = _trace_lines(lt, bt, tt, m)
     return mIHTResult(res.time, res.logl, res.iter, B, Cm, k, r, S, pve,
                       trace=dict(logl=lt[:m].copy(), tol=tt[:m].copy(), backtracks=bt[:m].copy(), lines=lines),
                       choose_fired=bool(res.choose_fired))

@@ -88,7 +88,13 @@ k_zt_r(const double *__restrict__ z, const double *__restrict__ r, int64_t n, do
 {
     const double *zl = z + (int64_t)blockIdx.y * n;
     double v[1] = {0.0};
-    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += 256ll * kZtrBlocks) v[0] += zl[i] * r[i];
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += 8 * 256ll * kZtrBlocks) {       // eight rows in flight, the sum in the walk's order
+        double a8[8], b8[8];
+        #pragma unroll
+        for (int u = 0; u < 8; ++u) { const int64_t iu = i + u * 256ll * kZtrBlocks; a8[u] = iu < n ? zl[iu] : 0.0; b8[u] = iu < n ? r[iu] : 0.0; }
+        #pragma unroll
+        for (int u = 0; u < 8; ++u) if (i + u * 256ll * kZtrBlocks < n) v[0] += a8[u] * b8[u];
+    }
     block_sum<1>(v, part + (int64_t)blockIdx.y * kZtrBlocks + blockIdx.x);
     if (threadIdx.x == 0) {           // the block that delivers last adds the partials in block order (k_zt_r_final's sum)
         __threadfence();

@@ -105,9 +105,15 @@ k_r_stats(const double *__restrict__ r, int64_t n, int m, double *__restrict__ p
     __shared__ bool last;
     const int v = blockIdx.y;                    // one grid row per residual
     double mx = 0.0, sm = 0.0;
-    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        double x = r[(int64_t)v * n + i];
-        mx = fmax(mx, fabs(x)); sm += x;
+    // eight rows of the thread's walk in flight (the residual is cold after the pass: one load at a time was a round trip per row,
+    // 30 of them at n = 500 000); the additions stay in the order of the walk
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += 8 * stride) {
+        double x8[8];
+        #pragma unroll
+        for (int u = 0; u < 8; ++u) x8[u] = (i + u * stride < n) ? r[(int64_t)v * n + i + u * stride] : 0.0;
+        #pragma unroll
+        for (int u = 0; u < 8; ++u) if (i + u * stride < n) { mx = fmax(mx, fabs(x8[u])); sm += x8[u]; }
     }
     smax[threadIdx.x] = mx; ssum[threadIdx.x] = sm;
     __syncthreads();

@@ -116,6 +116,27 @@ def normal_data():
                 y2=np.loadtxt(os.path.join(FIX, "phenotypes.txt")))
 
 
+def free_device_bytes():
+    """Free HBM on the device, asked of the HIP runtime(s) this process already holds (the library's own first).  torch.cuda would do,
+    but only if torch initialised ITS runtime before the library did: a test selected alone (-k) met 'No HIP GPUs are available'."""
+    import ctypes
+    seen = []
+    for ln in open("/proc/self/maps"):
+        path = ln.split()[-1]
+        if "libamdhip64" in path and path not in seen:
+            seen.append(path)
+    for path in seen:
+        try:
+            hip = ctypes.CDLL(path)
+            f, t = ctypes.c_size_t(0), ctypes.c_size_t(0)
+            if hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)) == 0 and t.value:
+                return f.value
+        except OSError:
+            pass
+    import torch
+    return torch.cuda.mem_get_info()[0]
+
+
 def make_bed(rng, n, p, missing_rate=0.0, maf_lo=0.02, maf_hi=0.5):
     """Random PLINK columns with the reference simulator's distributions
     (simulate_utilities.jl:33-47: maf ~ U, g ~ Binomial(2, maf); codes :88-99)."""

@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import FIX, GOLD, ROOT, SweepTally, check_recorded_cv_curve, hash_folds, make_bed, perm_folds, tied_case
+from conftest import FIX, GOLD, ROOT, SweepTally, check_recorded_cv_curve, free_device_bytes, hash_folds, make_bed, perm_folds, tied_case
 
 pytestmark = pytest.mark.gpu
 
@@ -2642,7 +2642,7 @@ def test_config3_full_size(mih, oracle):
     keyed by (seed, column)) a 3 x 3 grid of held-out losses equals the oracle's (tools/validate_large.py promoted to a test;
     the oracle needs ~0.4 s per X'r pass there, so the grid is what the CPU finishes in about a minute)."""
     n, p = 500_000, 1_000_000
-    free_b = __import__("torch").cuda.mem_get_info()[0]
+    free_b = free_device_bytes()
     if free_b < 170e9:
         pytest.skip("needs 170 GB of free HBM")
     x, yb, folds = _config3_problem(mih, n, p)
@@ -2712,7 +2712,7 @@ def test_config4_full_size(mih, oracle):
     (2) on the first 50 000 columns of the SAME matrix (the generator is keyed by (seed, column)) a k = 40 fit equals the oracle's
     iteration for iteration (multivariate.jl:66-92, 220-254; test/multivariate_test.jl:58,72)."""
     n, p, r, k = 500_000, 1_000_000, 10, 500
-    free_b = __import__("torch").cuda.mem_get_info()[0]
+    free_b = free_device_bytes()
     if free_b < 170e9:
         pytest.skip("needs 170 GB of free HBM")
     x = mih.SnpLinAlg.synthetic(n, p, seed=2024)
