@@ -91,6 +91,27 @@ int main()
     printf("walk 1 in,   64 blocks, 1 in flight : %6.2f us\n", chain([&] { hipLaunchKernelGGL((k_walk<1, 1>), dim3(64), dim3(256), 0, 0, in, out, part, n); }, 200));
     printf("walk 1 in,   64 blocks, 16 in flight: %6.2f us\n", chain([&] { hipLaunchKernelGGL((k_walk<1, 16>), dim3(64), dim3(256), 0, 0, in, out, part, n); }, 200));
     printf("walk 1 in,   64 blocks, 32 in flight: %6.2f us\n", chain([&] { hipLaunchKernelGGL((k_walk<1, 32>), dim3(64), dim3(256), 0, 0, in, out, part, n); }, 200));
+    {   // the same chain of small kernels as a hipGraph: does a captured chain have cheaper boundaries than stream launches the host queues ahead?
+        hipStream_t st; CK(hipStreamCreate(&st));
+        hipGraph_t g; hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+        for (int i = 0; i < 13; ++i) hipLaunchKernelGGL(k_rowwise<1>, dim3(nb), dim3(256), 0, st, in, out, n);
+        CK(hipStreamEndCapture(st, &g));
+        CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (int i = 0; i < 5; ++i) CK(hipGraphLaunch(ge, st));
+        CK(hipStreamSynchronize(st));
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < 50; ++i) CK(hipGraphLaunch(ge, st));
+        CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("13 row-wise kernels as a hipGraph   : %6.2f us per kernel (graph launches back to back)\n", ms * 1e3f / (50 * 13));
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < 50 * 13; ++i) hipLaunchKernelGGL(k_rowwise<1>, dim3(nb), dim3(256), 0, st, in, out, n);
+        CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("the same 650 kernels, stream launches: %6.2f us per kernel\n", ms * 1e3f / (50 * 13));
+    }
     CK(hipMalloc((void **)&g_evict, g_evict_bytes));
     printf("-- cold (1 GB rewritten before each launch; the event pair's own cost is in every line) --\n");
     printf("empty kernel                        : %6.2f us\n", cold([&] { hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, 0, (int *)nullptr); }, 30));
