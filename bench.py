@@ -335,7 +335,28 @@ def mv_object(m, x, n, p, torch, r=10, k=500, comm=None, lo=0, sum_over_ranks=No
     pass_ms = sum(q["ms"] for q in steady) / max(len(steady), 1)
     gaps = [ps[i + 1]["start_ms"] - ps[i]["start_ms"] - ps[i]["ms"] for i in range(1, len(ps) - 1)]
     alg = x.algorithmic_bytes(r)
-    return {"workload": f"fit_iht MvNormal r={r} traits k={k} on the same SnpArray n={n} p={p} (BASELINE configs[4]), max_iter=12"
+    auto = None
+    if comm is None:            # the same fit with xtv_digits = -1: per pass, the 43-bit format when every trait's T1 row passes the guard
+        fit(max_iter=3, xtv_digits=-1)
+        m.profile_read(x, reset=True)
+        m.profile_counters(x, reset=True)
+        m.profile_enable(x, True)
+        torch.cuda.synchronize()
+        res2 = fit(max_iter=12, xtv_digits=-1)
+        torch.cuda.synchronize()
+        m.profile_enable(x, False)
+        ps2 = m.profile_passes(x, reset=True)
+        c2 = m.profile_counters(x, reset=True)
+        st2 = ps2[1:]
+        nz = res.beta != 0
+        auto = {"what": "mih_fit_params::xtv_digits = -1: per pass, the 43-bit fixed-point format (four residuals per operand) when every "
+                        "trait's row of T1 = Gamma * resid has max|t| <= 128 rms(t), the 54-bit format otherwise",
+                "iterations": int(res2.iter), "ms_per_iteration": 1e3 * res2.time / max(res2.iter, 1),
+                "pass_ms": sum(q["ms"] for q in st2) / max(len(st2), 1), "pass_kernel": st2[0]["kernel"] if st2 else None,
+                "residuals_in_the_43_bit_format": int(c2["residuals_43bit"]), "passes": len(ps2),
+                "same_support": bool(np.array_equal(res2.beta != 0, nz)),
+                "largest_relative_difference_of_an_effect": float(np.max(np.abs(res2.beta[nz] - res.beta[nz]) / np.abs(res.beta[nz]))) if nz.any() else 0.0}
+    return {"auto_digits": auto, "workload": f"fit_iht MvNormal r={r} traits k={k} on the same SnpArray n={n} p={p} (BASELINE configs[4]), max_iter=12"
                         + (f"; SNP columns sharded over {comm.world} ranks (this rank: {x.p} columns; per-rank pass and bytes)" if comm is not None else ""),
             "iterations": int(res.iter), "ms_per_iteration": 1e3 * res.time / max(res.iter, 1), "fit_wall_s": wall,
             "pass_ms": pass_ms, "outside_the_pass_ms": sum(gaps) / max(len(gaps), 1), "pass_kernel": steady[0]["kernel"] if steady else None,

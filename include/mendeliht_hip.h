@@ -224,7 +224,9 @@ typedef struct mih_fit_params {
                                  43-bit format (4908: four residuals per operand, ~19 % less pass time at configs[3]; its
                                  rounding then stays ~1e-11 of a column's X'r), otherwise in the 54-bit format.  The choice
                                  depends on that residual alone, so a fit still gives the same bits whatever its company.
-                                 Normal fits, single fits and multivariate fits: as 0. */
+                                 mih_fit_mv: per X'R pass, the 43-bit format when EVERY trait's row of T1 = Gamma * resid passes
+                                 that test (three operands instead of four at r = 10), else the 54-bit one; one more small
+                                 readback per iteration.  Univariate Normal fits, single fits and mih_cv_mv: as 0. */
     /* The reference's RANDOM tie-break, _choose! (src/utilities.jl:444-458, src/multivariate.jl:310-351): when a projection
      * leaves more than k non-zero effects (exact ties in |b|) the reference removes the excess at random with the caller's
      * RNG.  NULL: the library removes the smallest |b| (ties: highest index) and raises choose_fired in the result.

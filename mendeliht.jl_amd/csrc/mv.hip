@@ -546,8 +546,32 @@ struct MvVar {
     int score()
     {
         MIH_TRY(score_pre());
-        MIH_TRY(xtv_device(h, xtv, T1.p, r, DF.p, s));
+        MIH_TRY(pass());
         return score_post();
+    }
+    // The r-trait X'R pass.  xtv_digits = -1 (round 5, opt-in as in the lock-step drivers): when EVERY trait's row of T1 passes the
+    // guard max |t| <= 128 rms(t) the pass takes the 43-bit fixed-point format (four residuals per operand: three operands instead
+    // of four at r = 10), else the 54-bit default -- decided per pass from this fit's own T1, at the price of one more readback.
+    DevBuf<double> guard;
+    int pass()
+    {
+        if (own_stream && tune.digits == -1 && xtv.has_alt) {
+            if (guard.n < (size_t)(2 * nb + 1) * r) { MIH_HIP(hipStreamSynchronize(s)); MIH_TRY(guard.alloc((size_t)(2 * nb + 1) * r)); }
+            double *flags = guard.p + (size_t)2 * nb * r;
+            for (int i = 0; i < r; ++i) {
+                hipLaunchKernelGGL(k_r_guard, dim3(nb), dim3(256), 0, s, T1.p + (size_t)i * n, n, guard.p + (size_t)2 * nb * i);
+                hipLaunchKernelGGL(k_r_guard_final, dim3(1), dim3(256), 0, s, guard.p + (size_t)2 * nb * i, nb, n, flags + i);
+            }
+            std::vector<double> f((size_t)r);
+            MIH_TRY(readback(flags, (size_t)r, f.data()));
+            bool all = true;
+            for (int i = 0; i < r; ++i) all = all && f[(size_t)i] == 1.0;
+            xtv.use_alt = all;
+            if (all) h->prof->count(MIH_CNT_RESIDUALS_43BIT, r);
+        }
+        const int rc = xtv_device(h, xtv, T1.p, r, DF.p, s);
+        xtv.use_alt = false;
+        return rc;
     }
     int score_pre()
     {
@@ -894,7 +918,7 @@ struct MvVar {
     int init(const uint8_t *train)
     {
         MIH_TRY(init_pre(train));
-        MIH_TRY(xtv_device(h, xtv, T1.p, r, DF.p, s));
+        MIH_TRY(pass());
         return init_post();
     }
     int init_pre(const uint8_t *train)
@@ -978,7 +1002,7 @@ struct MvVar {
     int one_step(double old_logl, int nstep, int *bt, double *new_logl)
     {
         MIH_TRY(step_pre(old_logl, nstep, bt, new_logl));
-        MIH_TRY(xtv_device(h, xtv, T1.p, r, DF.p, s));
+        MIH_TRY(pass());
         return step_post(*new_logl);
     }
     // everything of iht_one_step! before the X'R pass (ends with T1 = Gamma * resid)
@@ -1027,7 +1051,7 @@ struct MvVar {
                 if (std::isnan(next_logl)) { set_error("Loglikelihood function is NaN, aborting..."); return MIH_NAN_LOGL; }
                 if (std::isinf(next_logl)) { set_error("Loglikelihood function is Inf, aborting..."); return MIH_INF_LOGL; }
             } else {
-                MIH_TRY(xtv_device(h, xtv, T1.p, r, DF.p, s));
+                MIH_TRY(pass());
                 MIH_TRY(step_post(next_logl));
             }
             if (lt) lt[nt] = next_logl;

@@ -2196,6 +2196,27 @@ def test_auto_digit_mode_in_the_lockstep_drivers(mih, oracle):
     a = mih.fit_iht(yb, x, None, k=6, d=mih.Bernoulli(), l=mih.LogitLink(), verbose=False, xtv_digits=-1)
     b = mih.fit_iht(yb, x, None, k=6, d=mih.Bernoulli(), l=mih.LogitLink(), verbose=False)
     assert np.array_equal(a.beta, b.beta) and a.iter == b.iter
+    # the multivariate fit (round 5): per pass, all r rows of T1 = Gamma * resid must pass the guard -- Gaussian traits do: every
+    # pass in the 43-bit format, the oracle's support / iterations / backtracks, B to 1e-9; one trait with a planted outlier of 10^6
+    # standard deviations: its passes keep 54 bits and the fit is the default fit bit for bit
+    Ym, Zm = _mv_problem(oracle, ox, rng, 4, 9, 2)
+    mih.profile_enable(x, True)
+    mih.profile_counters(x, reset=True)
+    ma = mih.fit_iht(Ym, x, Zm, k=9, verbose=False, xtv_digits=-1)
+    cm = mih.profile_counters(x, reset=True)
+    md = mih.fit_iht(Ym, x, Zm, k=9, verbose=False)
+    om = oracle.fit_mv(ox, Ym, Zm, k=9)
+    assert cm["residuals_43bit"] >= 4 * (ma.iter - 1) > 0 and mih.profile_counters(x, reset=True)["residuals_43bit"] == 0
+    assert ma.iter == md.iter == om["iter"] and list(ma.trace["backtracks"]) == list(om["bt_trace"])
+    assert np.array_equal(ma.beta != 0, om["B"] != 0) and not np.array_equal(ma.beta, md.beta)
+    np.testing.assert_allclose(ma.beta, md.beta, rtol=1e-9, atol=1e-13)
+    np.testing.assert_allclose(ma.beta, om["B"], rtol=1e-5, atol=1e-12)
+    Yo = Ym.copy(); Yo[2, 17] += 1e6 * Ym[2].std()
+    oa = mih.fit_iht(Yo, x, Zm, k=9, verbose=False, xtv_digits=-1, max_iter=8)
+    co = mih.profile_counters(x, reset=True)
+    od = mih.fit_iht(Yo, x, Zm, k=9, verbose=False, max_iter=8)
+    mih.profile_enable(x, False)
+    assert co["residuals_43bit"] == 0 and np.array_equal(oa.beta, od.beta) and oa.iter == od.iter
 
 
 def test_fits_and_cv_at_full_row_count(mih, oracle):
