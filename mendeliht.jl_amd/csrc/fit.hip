@@ -1692,6 +1692,7 @@ struct IhtVar {
     // res_begin): their projections take the direct gather, unless the forecast has failed three times in this run of steps.
     // first_slow: the attempt being re-queued because its forecast failed.
     int res_spec = 0, res_fast_fails = 0, res_known = 0, res_last[3] = {0, 0, 0};
+    static int res_spec_cap() { static const int c = probe_env("MENDELIHT_SPEC_CAP") ? atoi(probe_env("MENDELIHT_SPEC_CAP")) : 2; return c; }       // (measurement build: slots per series beyond the first)
     int res_enqueue_attempts(uint64_t seq, int a0, int max_step, bool first_slow = false)
     {
         const int slots = 1 + std::max(0, std::min(max_step - std::min(a0, max_step), res_spec));      // (attempt max_step always stands: utilities.jl:484)
@@ -1770,7 +1771,7 @@ struct IhtVar {
             case RES_ACCEPT:
                 ++rr.done; res_known = std::max(res_known, rec->nbt + 1);
                 res_last[2] = res_last[1]; res_last[1] = res_last[0]; res_last[0] = rec->nbt;
-                res_spec = std::min(2, std::max(res_last[0], std::max(res_last[1], res_last[2])));       // (three slots at most: a longer series is rare and goes on in the next)
+                res_spec = std::min(res_spec_cap(), std::max(res_last[0], std::max(res_last[1], res_last[2])));
                 h->prof->count(MIH_CNT_RESIDENT_STEPS, 1);
                 return MIH_OK;
             case RES_PENDING:                // the series ended with the step still backtracking: the series queued behind goes on with it
