@@ -517,8 +517,8 @@ struct IhtVar {
                 comm->col_offset < 0 || comm->col_offset + p > comm->p_global) {
                 set_error("invalid mih_comm (callbacks, rank/world or column range)"); return MIH_BAD_ARG;
             }
-            if (prm->group || prm->ks || prm->init_beta || prm->debias) {
-                set_error("group projection, init_beta and debias are not available in a column-sharded fit"); return MIH_BAD_ARG;
+            if (prm->group || prm->ks || prm->debias) {
+                set_error("group projection and debias are not available in a column-sharded fit"); return MIH_BAD_ARG;
             }
             col0 = comm->col_offset; pg = comm->p_global;
         }
@@ -1082,6 +1082,7 @@ struct IhtVar {
             double c0sum = 0.0;
             MIH_TRY(init_beta_regress_device(h, w.p, y.p, 1, N, &Sy, betad.p, &c0sum, red, scal, s, tune));
             ibc.assign(q, 0.0);
+            double cov_c0 = 0.0;
             // non-genetic covariates 2..q on the host (utilities.jl:799-806)
             for (int l = 1; l < q; ++l) {
                 double sx = 0, sxx = 0, sxy = 0;
@@ -1090,9 +1091,13 @@ struct IhtVar {
                 double u11 = std::sqrt(N), u12 = sx / u11, d = sxx - u12 * u12, b0v, b1v;
                 if (!(N > 0.0) || !(d > 0.0)) { b0v = Sy; b1v = sxy; }
                 else { double u22 = std::sqrt(d), w1 = Sy / u11, w2 = (sxy - u12 * w1) / u22; b1v = w2 / u22; b0v = (w1 - u12 * b1v) / u11; }
-                c0sum += b0v; ibc[l] = b1v;
+                if (comm) cov_c0 += b0v; else c0sum += b0v;
+                ibc[l] = b1v;
             }
-            ibc[0] = c0sum / (double)(p + q - 1);
+            // column shard: the intercepts of the SNP regressions of ALL shards (one scalar exchange), the replicated covariates'
+            // once, and the divisor counts every SNP column (utilities.jl:808)
+            if (comm) { MIH_TRY(allreduce_host(&c0sum, 1, 0)); c0sum += cov_c0; }
+            ibc[0] = c0sum / (double)(pg + q - 1);
             for (int l = 0; l < q; ++l) ibc[l] = ibc[l] < -2.0 ? -2.0 : (ibc[l] > 2.0 ? 2.0 : ibc[l]);
             if (!from_shared) { if (train) ib_train.assign(train, train + n); else ib_train.clear(); ib_valid = true; }
             else MIH_TRY(stream_sync_coop(s));         // the shared regressions are complete before any other stream reads them
@@ -1119,6 +1124,7 @@ struct IhtVar {
             for (size_t t = 0; t < hw.size(); ++t) snp.val[t] /= hw[t];
         }
         b = snp; b0 = b;
+        if (comm) { b0g = bg; b0g_ok = bg_ok; }          // (project_full_sharded left the whole projected model in bg)
         for (int l = 0; l < q; ++l) { if (!zkeep[l]) c[l] = cnz[l] ? ct[l] : 0.0; idc[l] = (c[l] != 0.0); }
         idx.idx = b.idx;
         MIH_TRY(gather_df_support());

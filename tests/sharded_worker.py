@@ -71,7 +71,8 @@ def native_main(out_path):
     yb = (rng.random(n2) < 1 / (1 + np.exp(-eta))).astype(float)
     out = {}
     for name, (cc, nn, yy, zz, kw) in {"normal_k7": (cols, n, y, z, dict(k=7)),
-                                       "logistic": (cols2, n2, yb, None, dict(k=9, d=m.Bernoulli(), l=m.LogitLink()))}.items():
+                                       "logistic": (cols2, n2, yb, None, dict(k=9, d=m.Bernoulli(), l=m.LogitLink())),
+                                       "init_beta": (cols2, n2, eta + 0.3 + np.random.default_rng(5).standard_normal(n2), None, dict(k=8, init_beta=True))}.items():
         p = cc.shape[0]
         lo, cnt = D.column_block(p, rank, world)
         xs = m.SnpLinAlg(cc[lo:lo + cnt], n=nn, center=True, scale=True, impute=True, device=local)
@@ -189,6 +190,11 @@ def main():
         dup[7] = dup[lo1 + cnt1 - 1]                         # 4 tied columns, k = 2: nonzero = 4 > k + zkeepn = 3
     run("ties_choose", dup, n, xo.xv_sparse(np.array([lo1 + cnt1 - 1]), np.array([1.0])) + 0.01 * rng.standard_normal(n),
         None, k=2)
+
+    # 5a. init_beta (round 5: the column-sharded fit takes it): the univariate regressions are column-local, the mean of their
+    #     intercepts is one scalar exchange; with a covariate that competes in the projection, and with a train mask
+    run("init_beta", cols, n, eta + 0.4 + rng.standard_normal(n), zz, k=8, init_beta=True, zkeep=[True, False, True])
+    run("init_beta_train", cols, n, eta + rng.standard_normal(n), None, k=6, init_beta=True, train=train)
 
     # 5b. seeded random cases (MIH_SWEEP_SEED for other draws): shapes down to fewer columns than one 32-column tile per rank,
     #     families, covariates in and out of zkeep, prior weights, train masks -- sharded == single, as above

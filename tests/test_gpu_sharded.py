@@ -50,14 +50,14 @@ def test_sharded_fit_matches_single_process(tmp_path, world):
         np.testing.assert_allclose(sh["beta"], one["beta"], rtol=0, atol=1e-9, err_msg=name)
         np.testing.assert_allclose(sh["c"], one["c"], rtol=0, atol=1e-9, err_msg=name)
         np.testing.assert_allclose(sh["Sigma"], one["Sigma"], rtol=1e-9, err_msg=name)
-        np.testing.assert_allclose(sh["sigma_g"], one["sigma_g"], rtol=1e-9, err_msg=name)
+        np.testing.assert_allclose(sh["sigma_g"], one["sigma_g"], rtol=1e-9, atol=1e-12, err_msg=name)      # (a pve of 1e-36 in the tied case is zero)
         np.testing.assert_allclose(sh["logl_trace"], one["logl_trace"], rtol=1e-11, err_msg=name)
         assert sh["choose_fired"] == one["choose_fired"], name
         for oc in others:
             o2 = oc.pop(name)["sharded"]
             assert o2["support"] == sh["support"] and o2["beta"] == sh["beta"] and o2["logl"] == sh["logl"] and o2["Sigma"] == sh["Sigma"], name
     assert one["choose_fired"]                                             # (mv_ties_choose, the last of the four)
-    tally = SweepTally(f"column-sharded fits, world {world}", ceiling=1, floor=8)
+    tally = SweepTally(f"column-sharded fits, world {world}", ceiling=1, floor=10)
     for name, case in res["cases"].items():
         sh, one = case["sharded"], case["single"]
         # the Newton update of the NegBin r stops at |dr| <= 1e-6 (utilities.jl:242): rounding-level
@@ -152,7 +152,7 @@ def test_native_exchange_with_more_than_one_rank_on_one_gpu(tmp_path, world):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     res = [json.load(open(str(out) + f".native.r{k}")) for k in range(world)]
-    for name in ("normal_k7", "logistic"):
+    for name in ("normal_k7", "logistic", "init_beta"):
         for k in range(world):
             a, b = res[k]["cases"][name]["native"], res[k]["cases"][name]["callbacks"]
             _same_summary(a, b, (name, k))                               # every field, bit for bit (json round-trips doubles)
