@@ -1709,8 +1709,8 @@ struct IhtVar {
         }
         return MIH_OK;
     }
-    // the score that ends the step: the residual with Z'r and its statistics, the gated X'r pass (its digit kernel finishes those
-    // sums, its finalize kernel also leaves df on the new support and the coefficients of X_S df_S)
+    // the score that ends the step: Z'r and the statistics of the residual the accepted attempt left, the gated X'r pass (its digit
+    // kernel finishes those sums, its finalize kernel also leaves df on the new support and the coefficients of X_S df_S)
     int res_enqueue_back()
     {
         const ResPtrs P = res_ptrs();
