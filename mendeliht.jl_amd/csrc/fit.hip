@@ -1470,6 +1470,9 @@ struct IhtVar {
     unsigned res_wide_blocks() const { return (unsigned)((h->n_pad / 16 + 63) / 64); }
     uint64_t res_zkeep_mask() const { uint64_t m = 0; for (int l = 0; l < q; ++l) if (zkeep[l]) m |= 1ull << l; return m; }
     bool res_fix() const { return h->impute && h->total_missing > 0; }
+    // Normal / identity on the plain (unsharded, no imputed entries) path: the attempts do not store xb, zc, mu (k_res_xb's `lean`);
+    // res_end forms them again from the model that comes home
+    bool res_lean() const { return !res_sharded && !res_fix() && dist == MIH_NORMAL && link == MIH_IDENTITY; }
     void xv_cache_forget()           // the host's map of the column cache no longer describes it (the device kept the books), or vice versa
     {
         xv.slot_of.clear(); std::fill(xv.col_of.begin(), xv.col_of.end(), (int64_t)-1); std::fill(xv.stamp.begin(), xv.stamp.end(), (uint64_t)0); xv.tick = 0;
@@ -1583,6 +1586,10 @@ struct IhtVar {
         if (next_logl) *next_logl = C.logl_cur;
         if (best) *best = C.best_logl;
         xv_cache_forget(); stage_forget(); spec_ok = false; df2_pending = false;
+        if (res_lean()) {            // xb, zc, mu of the iterate, which the lean attempts did not store: k_xv_snp_cached + k_zmul + k_mu_loglik, the same sums
+            MIH_TRY(update_xb());
+            MIH_TRY(mu_loglik(1, nullptr, nullptr));
+        }
         return MIH_OK;
     }
     int64_t res_iter0 = 0;
@@ -1665,12 +1672,12 @@ struct IhtVar {
             hipLaunchKernelGGL(k_res_select_global, dim3(1), dim3(1024), 0, s, P, res_epoch, a, K, seq, M, full.p, p, q, zk, (int)zkeepn, groups * (k + zkeepn));
         }
         if (!res_fix() && !res_sharded)
-            hipLaunchKernelGGL(k_res_xb<false>, dim3(res_wide_blocks()), dim3(kResWideRows), kResWideLds, s, P, res_epoch, a, M, z.p, y.p, w.p, q, dist, link, nb_r, xb.p, zc.p, mu.p, red.p, r.p);
+            hipLaunchKernelGGL(k_res_xb<false>, dim3(res_wide_blocks()), dim3(kResWideRows), kResWideLds, s, P, res_epoch, a, M, z.p, y.p, w.p, q, dist, link, nb_r, xb.p, zc.p, mu.p, red.p, r.p, res_lean() ? 1 : 0);
         else {
             // (the partial product goes to a scratch vector -- xgk is free here -- so that a chain whose gate is closed, whose
             // collectives run all the same, leaves xb alone)
             double *part = res_sharded ? xgk.p : xb.p;
-            hipLaunchKernelGGL(k_res_xb<true>, dim3(res_wide_blocks()), dim3(kResWideRows), kResWideLds, s, P, res_epoch, a, M, z.p, y.p, w.p, q, dist, link, nb_r, part, zc.p, mu.p, red.p, r.p);
+            hipLaunchKernelGGL(k_res_xb<true>, dim3(res_wide_blocks()), dim3(kResWideRows), kResWideLds, s, P, res_epoch, a, M, z.p, y.p, w.p, q, dist, link, nb_r, part, zc.p, mu.p, red.p, r.p, 0);
             if (res_fix()) hipLaunchKernelGGL(k_res_missing, dim3(1), dim3(1024), 0, s, P, res_epoch, a, 1, M, part);
             if (res_sharded) MIH_TRY(allreduce_dev(part, n, 0));
             hipLaunchKernelGGL(k_res_mu, dim3(nb), dim3(256), 0, s, P, res_epoch, a, (const double *)part, z.p, y.p, w.p, n, q, dist, link, nb_r, xb.p, zc.p, mu.p, red.p, r.p);
