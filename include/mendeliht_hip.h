@@ -394,7 +394,10 @@ enum { MIH_CNT_LANES = 0,          /* lock-step lanes started (summed over calls
        MIH_CNT_RESIDENT_REDOS = 13,  /* ... of which the forecast failed: re-queued with the two histogram sweeps */
        MIH_CNT_SKIPPED_LAST_SCORES = 14, /* lock-step fits that converged: their last step's score (which the reference computes and never reads) was not computed */
        MIH_CNT_RESIDUALS_43BIT = 15, /* xtv_digits = -1: residuals the lock-step drivers scored in the 43-bit format (the rest: 54-bit) */
-       MIH_PROFILE_NCOUNTERS = 16 };
+       MIH_CNT_PEELED_RESIDUALS = 16, /* residuals whose outlier guard fired: up to 64 rows towering over the rest left the fixed point and
+                                       * rode the f64 side channel of k_xtv_finalize (csrc/peel.h); counted by mih_xtv_batched_fmt, mih_fit_iht, mih_fit_mv
+                                       * and the lock-step drivers when they end */
+       MIH_PROFILE_NCOUNTERS = 17 };
 int mih_profile_enable(const mih_mat *h, int on);
 /* synchronises the recorded launches; totals since the last reset */
 int mih_profile_read(const mih_mat *h, double *xtv_kernel_ms, int64_t *xtv_launches, int reset);

@@ -115,7 +115,8 @@ class _PassRecord(C.Structure):
 
 
 PROFILE_COUNTERS = ("lanes", "max_in_flight", "handovers", "shared_init", "rounds", "fits", "scores", "max_lane_slots", "init_scores",
-                    "resident_steps", "resident_attempts", "resident_handbacks", "resident_direct", "resident_redos", "skipped_last_scores", "residuals_43bit")
+                    "resident_steps", "resident_attempts", "resident_handbacks", "resident_direct", "resident_redos", "skipped_last_scores", "residuals_43bit",
+                    "peeled_residuals")
 
 _PROGRESS = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double)
 

@@ -409,6 +409,8 @@ struct XtvWork {            // scratch for one in-flight X'r
     DevBuf<double>   partial;  // splits * rhs * ncg*32 raw dots
     DevBuf<double>   scal;     // rhs * 4 : {max|r|, 2^-e, sum r, 2^e}
     DevBuf<unsigned> stat_done; // rhs : blocks of k_r_stats that have delivered their partial (zero between launches)
+    double peels_counted = 0.0; // ... of whose guards' running counts the measurement hook has taken this much (xtv_count_peels)
+    DevBuf<double>   peel;     // rhs * kPeelStride : the rows of each residual that ride the f64 side channel instead of the fixed point (peel.h)
     int m_cap = 0, splits_cap = 0;
     DigitMode dm = {13, 16, 2, 16, 56, 20};   // fixed at init (tune.digits and the matrix height)
     int ops_cap = 0;           // B operands the buffers hold
@@ -427,6 +429,7 @@ struct XtvWork {            // scratch for one in-flight X'r
 int  xtv_work_init(const mih_mat *h, XtvWork &w, int m, const XtvTune &tune, bool batched = true);
 // r_dev: m vectors of length n (column-major n x m) on device; out_dev p x m.
 int  xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double *out_dev, hipStream_t s);
+void xtv_count_peels(const mih_mat *h, XtvWork &w, hipStream_t s);
 // residuals of two full fused passes (six operands each by default) in the batched format: how many fits the lock-step drivers keep in flight
 int  xtv_lockstep_width(const mih_mat *h, const XtvTune &tune);
 

@@ -9,6 +9,7 @@
 // scalars; per iteration the host reads back only: the step-size reduction, the
 // projection survivors (k entries), the loglikelihood scalars, Z'r and df[S].
 #include "common.h"
+#include "peel.h"
 #include "fit_common.h"
 #include <map>
 #include <functional>
@@ -1542,7 +1543,9 @@ struct IhtVar {
         return MIH_OK;
     }
     // ... and back: b, c, idc, the list, df on it, df2, the best model; *next_logl / *best as fit_iht! carries them
-    int res_end(double *next_logl, double *best)
+    // handback: the device handed the step back (RES_ABORT) -- possibly after attempts it had rejected, whose sweeps overwrote xb, zc
+    // and mu with those candidates' values; the host-driven replay starts with iht_stepsize!, which reads them
+    int res_end(double *next_logl, double *best, bool handback = false)
     {
         if (!res_active) return MIH_OK;
         res_active = false;
@@ -1586,7 +1589,7 @@ struct IhtVar {
         if (next_logl) *next_logl = C.logl_cur;
         if (best) *best = C.best_logl;
         xv_cache_forget(); stage_forget(); spec_ok = false; df2_pending = false;
-        if (res_lean()) {            // xb, zc, mu of the iterate, which the lean attempts did not store: k_xv_snp_cached + k_zmul + k_mu_loglik, the same sums
+        if (res_lean() || handback) {  // xb, zc, mu of the iterate, which the lean attempts did not store (and the others overwrote with a rejected candidate's): k_xv_snp_cached + k_zmul + k_mu_loglik, the same sums
             MIH_TRY(update_xb());
             MIH_TRY(mu_loglik(1, nullptr, nullptr));
         }
@@ -1664,8 +1667,11 @@ struct IhtVar {
             hipLaunchKernelGGL(k_res_hist2, dim3(kResHistBlocks), dim3(256), 0, s, P, res_epoch, a, full.p, sel_len, Ksel);
             hipLaunchKernelGGL(k_res_collect, dim3(kResCollectBlocks), dim3(256), 0, s, P, res_epoch, a, full.p, sel_len);
         }
+        // (measurement build) MENDELIHT_RES_FORCE_ABORT_ES=N: the device hands a step back once it has backtracked N times -- the replay
+        // of a step whose rejected attempts have been through xb, zc, mu (test_handback_after_rejected_attempts)
+        static const int force_abort_es = probe_env("MENDELIHT_RES_FORCE_ABORT_ES") ? atoi(probe_env("MENDELIHT_RES_FORCE_ABORT_ES")) : -1;
         if (!res_sharded)
-            hipLaunchKernelGGL(k_res_select, dim3(1), dim3(1024), 0, s, P, res_epoch, a, fast ? 1 : 0, K, seq, M, wp, p, q, zk, (int)zkeepn, groups * (k + zkeepn));
+            hipLaunchKernelGGL(k_res_select, dim3(1), dim3(1024), 0, s, P, res_epoch, a, fast ? 1 : 0, K, seq, M, wp, p, q, zk, (int)zkeepn, groups * (k + zkeepn), force_abort_es);
         else {
             hipLaunchKernelGGL(k_res_select_local, dim3(1), dim3(1024), 0, s, P, res_epoch, a, fast ? 1 : 0, Ksel, K, (int32_t)xv.slots);
             MIH_TRY(res_allgather_messages(2 + 2 * (int64_t)K));
@@ -1724,6 +1730,7 @@ struct IhtVar {
         static_assert(kZtrBlocks == 2 * kStatBlocksRes, "k_res_stats pairs the walks of k_zt_r and k_r_stats");
         hipLaunchKernelGGL(k_res_stats, dim3(4 * kStatBlocksRes, (q + kResStatCov - 1) / kResStatCov), dim3(64), 0, s, P, res_epoch, z.p, r.p, n, q,
                            ztr.p, xtv.scal.p + xtv.rhs_cap * 4, rwalk.p, rtick.p);
+        hipLaunchKernelGGL(k_res_peel, dim3(1), dim3(1024), 0, s, P, res_epoch, r.p, n, xtv.scal.p + xtv.rhs_cap * 4, xtv.peel.p);
         xtv.gate = &rctl.p->live_epoch; xtv.gate_val = res_gate_step(res_epoch); xtv.stats_done = true;
         xtv.shook.spart = xtv.scal.p + xtv.rhs_cap * 4; xtv.shook.zpart = ztr.p; xtv.shook.df2 = rctl.p->df2; xtv.shook.q = q;
         xtv.shook.zblocks = kZtrBlocks; xtv.shook.ebits = xtv.dm.ebits;
@@ -1840,7 +1847,7 @@ struct IhtVar {
             if (res_active) {
                 ResRecord rec; bool aborted = false;
                 MIH_TRY(res_next(rr, &rec, &aborted));
-                if (aborted) MIH_TRY(res_end(&next_logl, &best));
+                if (aborted) MIH_TRY(res_end(&next_logl, &best, true));
                 else {
                     if (rec.status == RES_STOP_NAN || rec.status == RES_STOP_INF) {
                         MIH_TRY(res_end(nullptr, nullptr));
@@ -1928,6 +1935,7 @@ int mih_fit_iht(const mih_mat *h, const mih_fit_params *prm, const double *y, co
     std::vector<double> mu(h->n);
     MIH_HIP(hipMemcpyAsync(mu.data(), v.mu.p, sizeof(double) * h->n, hipMemcpyDeviceToHost, v.s));
     MIH_HIP(hipStreamSynchronize(v.s));
+    xtv_count_peels(h, v.xtv, v.s);
     res->pve = sample_var(mu.data(), h->n) / sample_var(y, h->n);   // pve.jl:22,32
     res->nb_r = v.nb_r;
     res->choose_fired = v.choose_fired ? 1 : 0;
@@ -2382,7 +2390,9 @@ static int cv_run_lanes(const mih_mat *h, const mih_fit_params &pr, size_t total
                 hipStream_t ws = worker_stream(h, (lane_id % 2) * kWorkerStreamsPerLane + i);
                 if (ws) shared.streams.push_back(ws);
             }
-        return cv_run_rolling(h, pr, total, queue, cap, make, xw, R, DF, s, mses_raw, merge_tail ? &handover : nullptr, lane_id, init_slots, shared, lanes == 2 ? inflight : nullptr, chains);
+        const int rc = cv_run_rolling(h, pr, total, queue, cap, make, xw, R, DF, s, mses_raw, merge_tail ? &handover : nullptr, lane_id, init_slots, shared, lanes == 2 ? inflight : nullptr, chains);
+        if (rc == MIH_OK) xtv_count_peels(h, xw, s);
+        return rc;
     };
     if (lanes == 1) return lane(0);
     std::vector<int> rcs((size_t)lanes, MIH_OK);
@@ -2637,7 +2647,7 @@ static int session_steps(mih_session_impl *s, int64_t nsteps, double *logl, int6
         if (v.res_active) {
             ResRecord rec; bool aborted = false;
             MIH_TRY(v.res_next(rr, &rec, &aborted));
-            if (aborted) MIH_TRY(v.res_end(&s->next_logl, &s->best));
+            if (aborted) MIH_TRY(v.res_end(&s->next_logl, &s->best, true));
             else {
                 if (rec.status == RES_STOP_NAN || rec.status == RES_STOP_INF) {
                     MIH_TRY(v.res_end(nullptr, nullptr));

@@ -43,6 +43,7 @@
 // An operand carries one 28-digit base-4 residual, two 16-digit base-13 residuals, three 10-digit base-49 residuals,
 // or four 8-digit residuals (opt-in fast modes): DigitMode.
 #include "common.h"
+#include "peel.h"
 #include <algorithm>
 #include <mutex>
 #include <utility>
@@ -98,7 +99,7 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 __global__ void __launch_bounds__(256)
 k_r_stats(const double *__restrict__ r, int64_t n, int m, double *__restrict__ part /* [m][gridDim.x][2] */,
           unsigned *__restrict__ done /* [m], zero */, int ebits, double *__restrict__ scal,
-          const int32_t *__restrict__ gate, int32_t gate_val)
+          const int32_t *__restrict__ gate, int32_t gate_val, double *__restrict__ peel /* [m][kPeelStride], or null */)
 {
     if (gate && *gate != gate_val) return;
     __shared__ double smax[256], ssum[256];
@@ -121,28 +122,38 @@ k_r_stats(const double *__restrict__ r, int64_t n, int m, double *__restrict__ p
         if ((int)threadIdx.x < k) { smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + k]); ssum[threadIdx.x] += ssum[threadIdx.x + k]; }
         __syncthreads();
     }
+    const int nblocks = (int)gridDim.x;
     if (threadIdx.x == 0) {
-        const int nblocks = (int)gridDim.x;
         part[((int64_t)v * nblocks + blockIdx.x) * 2] = smax[0]; part[((int64_t)v * nblocks + blockIdx.x) * 2 + 1] = ssum[0];
         __threadfence();
         last = atomicAdd(&done[v], 1u) == (unsigned)nblocks - 1;
-        if (last) {
-            __threadfence();
-            double fmx = 0.0, fsm = 0.0;
-            for (int b = 0; b < nblocks; ++b) {
-                fmx = fmax(fmx, __hip_atomic_load(&part[((int64_t)v * nblocks + b) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                fsm += __hip_atomic_load(&part[((int64_t)v * nblocks + b) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            // exponent e with max|r| * 2^e < 2^(ebits+1) (DigitMode::ebits); an all-zero (or non-finite) residual keeps e = 0
-            int e = 0;
-            if (fmx > 0.0 && fmx < 1.0e300) e = ebits - ilogb(fmx);
-            if (e > 1000) e = 1000;          // a (numerically zero) residual below 2^-947: keep 2^e finite
-            scal[4 * v + 0] = fmx;
-            scal[4 * v + 1] = ldexp(1.0, -e);
-            scal[4 * v + 2] = fsm;
-            scal[4 * v + 3] = ldexp(1.0, e);
-            done[v] = 0;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    // (round 6) the outlier side channel (peel.h): the whole block looks at the block maxima; rows that tower over the rest leave the
+    // fixed-point residual and the scale is taken from what is left.  No outlier (every residual so far): `top` is max|r|, as before.
+    double top = -1.0;
+    if (peel) {
+        const int64_t nb64 = (n + 255) / 256;
+        top = peel_decide(r + (int64_t)v * n, n, part + (int64_t)v * nblocks * 2, (int)(nb64 < nblocks ? nb64 : nblocks), peel + (int64_t)v * kPeelStride);
+    }
+    if (threadIdx.x == 0) {
+        double fmx = 0.0, fsm = 0.0;
+        for (int b = 0; b < nblocks; ++b) {
+            fmx = fmax(fmx, __hip_atomic_load(&part[((int64_t)v * nblocks + b) * 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            fsm += __hip_atomic_load(&part[((int64_t)v * nblocks + b) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (top < 0.0) top = fmx;
+        // exponent e with top * 2^e < 2^(ebits+1) (DigitMode::ebits); an all-zero (or non-finite) residual keeps e = 0
+        int e = 0;
+        if (top > 0.0 && top < 1.0e300) e = ebits - ilogb(top);
+        if (e > 1000) e = 1000;          // a (numerically zero) residual below 2^-947: keep 2^e finite
+        scal[4 * v + 0] = fmx;
+        scal[4 * v + 1] = ldexp(1.0, -e);
+        scal[4 * v + 2] = fsm;
+        scal[4 * v + 3] = ldexp(1.0, e);
+        done[v] = 0;
     }
 }
 
@@ -166,7 +177,8 @@ __device__ __forceinline__ int digit49(int m)
 // mfma_fp4; an FP6 element j sits in bits 6j..6j+5 of the lane's 192 bits, the last 64 of them in `dig2`).
 __global__ void __launch_bounds__(256)
 k_digits(const double *__restrict__ r, int64_t n, int64_t nblk, int m, DigitMode dm,
-         double *scal, uint4 *__restrict__ dig /* [nops][nblk][64] */, uint2 *__restrict__ dig2, FlatPasses fp, XtvStatsHook sh)
+         double *scal, uint4 *__restrict__ dig /* [nops][nblk][64] */, uint2 *__restrict__ dig2, FlatPasses fp, XtvStatsHook sh,
+         const double *__restrict__ peel /* [m][kPeelStride]: rows that left the fixed-point residual (peel.h), or null */)
 {
     // The wave's 64 rows go into the B-operand image of their block directly: img[wave][half][digit] is the 128 (FP4) or 192 (FP6)
     // bits lane (half, digit) of the fragment carries, and every row ORs its code into its element's place (LDS atomics; round 4 --
@@ -179,8 +191,9 @@ k_digits(const double *__restrict__ r, int64_t n, int64_t nblk, int m, DigitMode
         if (threadIdx.x == 0) {
             double fmx = 0.0, fsm = 0.0;
             for (int b = 0; b < 64; ++b) { fmx = fmax(fmx, sh.spart[2 * b]); fsm += sh.spart[2 * b + 1]; }
+            const double top = (peel && peel[0] > 0.0) ? peel[2] : fmx;       // (k_res_peel took rows out: the scale of the rest)
             int e = 0;
-            if (fmx > 0.0 && fmx < 1.0e300) e = sh.ebits - ilogb(fmx);
+            if (top > 0.0 && top < 1.0e300) e = sh.ebits - ilogb(top);
             if (e > 1000) e = 1000;
             s_scale = ldexp(1.0, e);
             if (blockIdx.x == 0) { scal[0] = fmx; scal[1] = ldexp(1.0, -e); scal[2] = fsm; scal[3] = ldexp(1.0, e); }
@@ -206,7 +219,11 @@ k_digits(const double *__restrict__ r, int64_t n, int64_t nblk, int m, DigitMode
     __syncthreads();
     if (vs < m && blk < nblk) {
         const int64_t i = blk * 64 + lane;
-        const double x = (i < n) ? r[(int64_t)vs * n + i] : 0.0;
+        double x = (i < n) ? r[(int64_t)vs * n + i] : 0.0;
+        if (peel) {                                     // a peeled row's digits are zero: k_xtv_finalize adds its term in f64
+            const double *pl = peel + (int64_t)vs * kPeelStride;
+            if (pl[0] > 0.0 && fabs(x) > pl[1]) x = 0.0;
+        }
         long long R = __double2ll_rn(x * (sh.spart ? s_scale : scal[4 * vs + 3]));
         // element of this row in its half's fragment (the A fragment's order, mfma_fp4): 8 (2u + (s & 1)) + (s >> 1) for row 16u + s
         const int hh = lane >> 5, uu = (lane >> 4) & 1, ss = lane & 15;
@@ -1143,12 +1160,23 @@ k_xtv_dma16(const uint4 *__restrict__ X, int64_t nbp, int64_t ncg, const uint4 *
 // scal, r and out advance by one residual's stride each.  A thread keeps its column and walks the residuals (round 4; before,
 // one grid row per residual read mu, sinv and the two missing-list bounds once per residual: 64 MB per residual at p = 1M and
 // four slices, 40 MB now); the arithmetic of every (residual, column) is unchanged.
+// (round 6) pl: the rows k_r_stats / k_res_peel took out of the fixed-point residual (peel.h) -- their terms g_ij r_i are added here in
+// f64, ascending rows, behind the slices' sum; a missing genotype is stored as dosage 0 and gets its imputed value below, like the rest
 __device__ __forceinline__ double xtv_finalize_col(int64_t j, const double *__restrict__ pu, int splits, int64_t pstride, double sum_r,
                                                    const double *__restrict__ ru, double m, double si, int64_t a, int64_t b,
-                                                   const int32_t *__restrict__ miss_row, int center, int scale)
+                                                   const int32_t *__restrict__ miss_row, int center, int scale,
+                                                   const double *__restrict__ pl, const uint32_t *__restrict__ X, int64_t nbp)
 {
     double dot = 0.0;
     for (int s = 0; s < splits; ++s) dot += pu[(int64_t)s * pstride + j];
+    if (pl) {
+        const int np = (int)pl[0];
+        for (int t = 0; t < np; ++t) {
+            const int64_t i = (int64_t)pl[4 + t];
+            const uint32_t g = (X[xword(nbp, j, i >> 4)] >> (2 * (int)(i & 15))) & 3u;
+            dot += (double)g * pl[4 + kPeelMax + t];
+        }
+    }
     if (b > a) {
         double ms = 0.0;
         for (int64_t t = a; t < b; ++t) ms += ru[miss_row[t]];
@@ -1164,7 +1192,8 @@ k_xtv_finalize(const double *__restrict__ partial, int splits, int64_t pstride, 
                const double *__restrict__ mu, const double *__restrict__ sinv,
                const int64_t *__restrict__ miss_ptr, const int32_t *__restrict__ miss_row,
                int center, int scale, int impute, double *__restrict__ out,
-               const int32_t *__restrict__ gate, int32_t gate_val, XtvSupportHook hook)
+               const int32_t *__restrict__ gate, int32_t gate_val, XtvSupportHook hook,
+               const double *__restrict__ peel, const uint32_t *__restrict__ X, int64_t nbp)
 {
     if (gate && *gate != gate_val) return;
     const int64_t pblocks = (p + 255) / 256;
@@ -1176,7 +1205,7 @@ k_xtv_finalize(const double *__restrict__ partial, int splits, int64_t pstride, 
         const double m = mu[j], si = scale ? sinv[j] : 1.0;
         int64_t a = 0, b = 0;
         if (impute) { a = miss_ptr[j]; b = miss_ptr[j + 1]; }
-        const double dot = xtv_finalize_col(j, partial, splits, pstride, scal[2], r, m, si, a, b, miss_row, center, scale);
+        const double dot = xtv_finalize_col(j, partial, splits, pstride, scal[2], r, m, si, a, b, miss_row, center, scale, peel, X, nbp);
         const double av = si * dot;
         hook.gval[t] = dot; hook.A[t] = av; hook.B[t] = center ? -m * av : 0.0;
         return;
@@ -1188,7 +1217,8 @@ k_xtv_finalize(const double *__restrict__ partial, int splits, int64_t pstride, 
     if (impute) { a = miss_ptr[j]; b = miss_ptr[j + 1]; }
     for (int u = 0; u < nres; ++u)
         out[(int64_t)u * p + j] = xtv_finalize_col(j, partial + (int64_t)u * splits * pstride, splits, pstride, scal[4 * u + 2],
-                                                   r + (int64_t)u * n, m, si, a, b, miss_row, center, scale);
+                                                   r + (int64_t)u * n, m, si, a, b, miss_row, center, scale,
+                                                   peel ? peel + (int64_t)u * kPeelStride : nullptr, X, nbp);
 }
 
 // ---- dense design matrix: out_j = sum_i D[i,j] r_i (one wave per column) ---------------
@@ -1542,12 +1572,28 @@ int xtv_work_init(const mih_mat *h, XtvWork &w, int m, const XtvTune &tune, bool
     MIH_TRY(w.partial.alloc((size_t)kMaxSplits * rhs_cap * (size_t)h->ncg * 32));
     MIH_TRY(w.scal.alloc(rhs_cap * 4 + (size_t)m * kStatBlocks * 2));
     MIH_TRY(w.stat_done.alloc(rhs_cap));
+    MIH_TRY(w.peel.alloc(rhs_cap * kPeelStride));
+    MIH_HIP(hipMemsetAsync(w.peel.p, 0, sizeof(double) * rhs_cap * kPeelStride, h->stream));       // (no rows peeled; the guards' running counts at zero)
     MIH_HIP(hipMemset(w.stat_done.p, 0, sizeof(unsigned) * rhs_cap));       // k_r_stats leaves its counters at zero
     MIH_HIP(hipMemsetAsync(w.digits.p, 0, sizeof(*w.digits.p) * dwords, h->stream));
     MIH_HIP(hipMemsetAsync(w.scal.p, 0, sizeof(double) * rhs_cap * 4, h->stream));
     MIH_HIP(hipStreamSynchronize(h->stream));
     w.m_cap = m; w.splits_cap = kMaxSplits;
     return MIH_OK;
+}
+
+// measurement hook: how often the outlier guard (peel.h) of this workspace's residual slots has fired since the last call
+// (MIH_CNT_PEELED_RESIDUALS); synchronises the stream
+void xtv_count_peels(const mih_mat *h, XtvWork &w, hipStream_t s)
+{
+    if (!h->prof->on || !w.peel.p || w.rhs_cap == 0) return;
+    std::vector<double> c(w.rhs_cap, 0.0);
+    if (hipMemcpy2DAsync(c.data(), sizeof(double), w.peel.p + 3, sizeof(double) * kPeelStride, sizeof(double), w.rhs_cap, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return; }
+    double total = 0.0;
+    for (double v : c) total += v;
+    h->prof->count(MIH_CNT_PEELED_RESIDUALS, (int64_t)(total - w.peels_counted));
+    w.peels_counted = total;
 }
 
 int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double *out_dev, hipStream_t s)
@@ -1595,7 +1641,7 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
     double *part = w.scal.p + w.rhs_cap * 4;
     dm.gate = w.gate; dm.gate_val = w.gate_val;
     if (!w.stats_done)
-        hipLaunchKernelGGL(k_r_stats, dim3(kStatBlocks, (unsigned)m), dim3(256), 0, s, r_dev, h->n, m, part, w.stat_done.p, dm.ebits, w.scal.p, w.gate, w.gate_val);
+        hipLaunchKernelGGL(k_r_stats, dim3(kStatBlocks, (unsigned)m), dim3(256), 0, s, r_dev, h->n, m, part, w.stat_done.p, dm.ebits, w.scal.p, w.gate, w.gate_val, w.peel.p);
     uint4 *dig_all = reinterpret_cast<uint4 *>(w.digits.p);
     uint2 *dig2_all = reinterpret_cast<uint2 *>(w.digits.p + (size_t)w.ops_cap * (size_t)nblk * 64 * 4);   // FP6 only
     FlatPasses fp{};
@@ -1622,7 +1668,7 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
     // a falling residual count from round to round, every loss checked by the tests of the full configs[3] grid),
     // and test_flat_packing_ignores_what_an_earlier_pass_left_in_the_tail_columns runs 19 residuals and then 1 .. 18 on ONE workspace.
     hipLaunchKernelGGL(k_digits, dim3((unsigned)((nblk + 3) / 4), (unsigned)(dm.flat ? m : nops * per_op)), dim3(256), 0, s, r_dev, h->n, nblk, m, dm,
-                       w.scal.p, dig_all, dig2_all, fp, (w.stats_done && m == 1) ? w.shook : XtvStatsHook());
+                       w.scal.p, dig_all, dig2_all, fp, (w.stats_done && m == 1) ? w.shook : XtvStatsHook(), w.peel.p);
     for (int q = 0; dm.flat && q < fp.npass; ++q) {
         const int u0 = fp.u0[q], u1 = fp.u0[q + 1], t = fp.t0[q], nr = fp.t0[q + 1] - t;
         DigitMode dq = dm;
@@ -1642,7 +1688,8 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
         if (rc) return rc;
         hipLaunchKernelGGL(k_xtv_finalize, dim3((unsigned)((h->p + 255) / 256)), dim3(256), 0, s,
                            partial, splits, pstride, h->p, u1 - u0, w.scal.p + 4 * u0, r_dev + (int64_t)u0 * h->n, h->n, h->mu, h->sinv,
-                           h->miss_ptr, h->miss_row, h->center, h->scale, h->impute && h->total_missing > 0, out_dev + (int64_t)u0 * h->p, w.gate, w.gate_val, XtvSupportHook());
+                           h->miss_ptr, h->miss_row, h->center, h->scale, h->impute && h->total_missing > 0, out_dev + (int64_t)u0 * h->p, w.gate, w.gate_val, XtvSupportHook(),
+                           w.peel.p + (int64_t)u0 * kPeelStride, h->X, h->nbp);
     }
     if (dm.flat) { MIH_HIP(hipGetLastError()); return MIH_OK; }
     for (int t = 0; t < nops;) {          // t counts B operands
@@ -1675,7 +1722,7 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
                                w.partial.p + (int64_t)u0 * splits * pstride, splits, pstride, h->p, u1 - u0,
                                w.scal.p + 4 * u0, r_dev + (int64_t)u0 * h->n, h->n, h->mu, h->sinv, h->miss_ptr, h->miss_row,
                                h->center, h->scale, h->impute && h->total_missing > 0, out_dev + (int64_t)u0 * h->p, w.gate, w.gate_val,
-                               hooked ? w.hook : XtvSupportHook());
+                               hooked ? w.hook : XtvSupportHook(), w.peel.p + (int64_t)u0 * kPeelStride, h->X, h->nbp);
         }
         t += nr;
     }
@@ -1778,6 +1825,7 @@ int mih_xtv_batched_fmt(const mih_mat *h, const double *R, int m, int digits, do
     MIH_TRY(xtv_device(h, w, r.p, m, out.p, h->stream));
     MIH_HIP(hipMemcpyAsync(OUT, out.p, sizeof(double) * (size_t)m * h->p, hipMemcpyDeviceToHost, h->stream));
     MIH_HIP(hipStreamSynchronize(h->stream));
+    xtv_count_peels(h, w, h->stream);
     return MIH_OK;
 }
 
