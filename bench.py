@@ -40,9 +40,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-METRIC = "IHT iterations/sec + X'r GB/s vs HBM roofline, n=500k p=1M k=200"
+METRIC = "IHT iterations/sec + X\u1d40r GB/s vs HBM roofline, n=500k p=1M k=200"       # BASELINE.json's string, verbatim
+FP6_PEAK_PFLOPS = 10.0   # dense FP6 / FP4 MFMA peak (MI355X_MICROARCH.md: "~10 PF dense"): the ruler of the fused multi-residual passes
 DTYPE = "f64 (residual as a 54-bit fixed-point number, exact accumulation on the matrix cores, f64 recombination)"
-TRAFFIC_FILE = os.path.join("profiles", "r05_traffic.json")    # separate rocprofv3 --pmc passes of this command (tools/prof_bench.sh)
+TRAFFIC_FILE = os.path.join("profiles", "r06_traffic.json")    # separate rocprofv3 --pmc passes of this command (tools/prof_bench.sh)
 
 
 def parse():
@@ -61,6 +62,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of each baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cv", action="store_true", help="skip the secondary cv_iht measurement (configs[3])")
+    ap.add_argument("--no-dense", action="store_true", help="skip the secondary dense-matrix measurement (configs[1], N = 1 only)")
     ap.add_argument("--no-mv", action="store_true", help="skip the secondary multivariate measurement (configs[4], N = 1 only)")
     ap.add_argument("--step-mode", type=int, default=0, choices=[0, 1],
                     help="0: iht_one_step! resident on the device (default), 1: host-driven steps (the path of rounds 1-4)")
@@ -278,14 +280,19 @@ def pass_stats(m, x, passes):
     """Per-launch records of the dominant kernel -> what the roofline object needs: launches, summed and union busy time,
     ALGORITHMIC bytes of exactly those launches (algorithmic_bytes(residuals) each), residual scores, the kernel's name."""
     if not passes:
-        return {"launches": 0, "ms_sum": 0.0, "ms_union": 0.0, "bytes": 0.0, "residuals": 0, "kernel": None, "kernels": {}}
+        return {"launches": 0, "ms_sum": 0.0, "ms_union": 0.0, "bytes": 0.0, "residuals": 0, "kernel": None, "kernels": {}, "digit_columns": 0, "mfma_flop": 0.0}
     by_m = {}
     names = {}
     for q in passes:
         by_m[q["residuals"]] = by_m.get(q["residuals"], 0) + 1
         names[q["kernel"]] = names.get(q["kernel"], 0) + 1
     alg = {mm: x.algorithmic_bytes(mm) for mm in by_m}
+    # what the matrix pipe multiplies in a launch: every row of every column against the 32 digit columns of each operand (16 of the
+    # last one when the kernel leaves its empty second fragment out: ",half" in the name), 2 flop per multiply-add
+    n_pad = (x.n + 127) // 128 * 128
+    cols = sum(32 * q["operands"] - (16 if ",half" in q["kernel"] else 0) for q in passes)
     return {"launches": len(passes), "ms_sum": sum(q["ms"] for q in passes), "ms_union": m.busy_union_ms(passes),
+            "digit_columns": cols, "mfma_flop": 2.0 * n_pad * x.p * cols,
             "bytes": float(sum(alg[q["residuals"]] for q in passes)), "residuals": int(sum(q["residuals"] for q in passes)),
             "kernel": max(names, key=names.get), "kernels": names}
 
@@ -296,10 +303,14 @@ def cv_roofline(cst):
             "frac": cst["bytes"] / (cst["ms_sum"] * 1e-3) / 1e9 / HBM_PEAK_GBPS if cst["launches"] else None,
             "kernel": cst["kernel"], "kernel_ms": cst["ms_sum"] / max(cst["launches"], 1),
             "algorithmic_bytes_per_launch": cst["bytes"] / max(cst["launches"], 1),
+            "digit_columns_per_launch": cst["digit_columns"] / max(cst["launches"], 1),
+            "fp6_PFLOPs": cst["mfma_flop"] / (cst["ms_sum"] * 1e-3) / 1e15 if cst["launches"] else None,
+            "frac_of_fp6_peak": cst["mfma_flop"] / (cst["ms_sum"] * 1e-3) / 1e15 / FP6_PEAK_PFLOPS if cst["launches"] else None,
             "note": "sum of algorithmic_bytes(residuals of the launch) / sum of HIP-event durations; the two lock-step lanes' passes "
                     "overlap, so the sum exceeds the union (and may exceed the wall time). A fused pass streams X once for up to 19 "
                     "residuals and is bound by the matrix pipe under the power cap, not by HBM: wider passes LOWER this fraction while "
-                    "the cost per residual falls (xtv_kernel_ms_per_residual_scored; DESIGN.md 3.1b)"}
+                    "the cost per residual falls (xtv_kernel_ms_per_residual_scored; DESIGN.md 3.1b).  frac_of_fp6_peak: 2 x n_pad x p x "
+                    "(digit columns the launches multiplied) / their summed duration / 10 PF"}
 
 
 FP64_VECTOR_PEAK_TFLOPS = 78.6     # MI355X dense FP64 vector peak (MI355X_MICROARCH.md): the ruler for "f64-equivalent" multiply-adds
@@ -335,6 +346,9 @@ def mv_object(m, x, n, p, torch, r=10, k=500, comm=None, lo=0, sum_over_ranks=No
     pass_ms = sum(q["ms"] for q in steady) / max(len(steady), 1)
     gaps = [ps[i + 1]["start_ms"] - ps[i]["start_ms"] - ps[i]["ms"] for i in range(1, len(ps) - 1)]
     alg = x.algorithmic_bytes(r)
+    n_pad = (n + 127) // 128 * 128
+    cols = sum(32 * q["operands"] - (16 if ",half" in q["kernel"] else 0) for q in steady) / max(len(steady), 1)
+    outside = sum(gaps) / max(len(gaps), 1)
     auto = None
     if comm is None:            # the same fit with xtv_digits = -1: per pass, the 43-bit format when every trait's T1 row passes the guard
         fit(max_iter=3, xtv_digits=-1)
@@ -359,14 +373,35 @@ def mv_object(m, x, n, p, torch, r=10, k=500, comm=None, lo=0, sum_over_ranks=No
     return {"auto_digits": auto, "workload": f"fit_iht MvNormal r={r} traits k={k} on the same SnpArray n={n} p={p} (BASELINE configs[4]), max_iter=12"
                         + (f"; SNP columns sharded over {comm.world} ranks (this rank: {x.p} columns; per-rank pass and bytes)" if comm is not None else ""),
             "iterations": int(res.iter), "ms_per_iteration": 1e3 * res.time / max(res.iter, 1), "fit_wall_s": wall,
-            "pass_ms": pass_ms, "outside_the_pass_ms": sum(gaps) / max(len(gaps), 1), "pass_kernel": steady[0]["kernel"] if steady else None,
+            "pass_ms": pass_ms, "outside_the_pass_ms": outside, "ms_per_step_with_pass": pass_ms + outside,
+            "ms_per_iteration_note": "ms_per_iteration is the reference's .time / .iter: a fit of N iterations runs N - 1 step passes (the converging "
+                                     "step's score is skipped), so it is SMALLER than a step; ms_per_step_with_pass = pass + what lies between two passes",
+            "pass_kernel": steady[0]["kernel"] if steady else None,
             "nonzero": int(np.count_nonzero(res.beta)),
             "roofline": {"bound": "mfma (matrix pipe under the package power cap; DESIGN.md 3.1b)", "hbm_GBps": alg / pass_ms / 1e6,
                          "frac_of_hbm_peak": alg / pass_ms / 1e6 / HBM_PEAK_GBPS,
                          "f64_equivalent_TFLOPs": 2.0 * n * x.p * r / (pass_ms * 1e-3) / 1e12,
                          "frac_of_fp64_vector_peak": 2.0 * n * x.p * r / (pass_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                         "digit_columns_per_launch": cols, "fp6_PFLOPs": 2.0 * n_pad * x.p * cols / (pass_ms * 1e-3) / 1e15,
+                         "frac_of_fp6_peak": 2.0 * n_pad * x.p * cols / (pass_ms * 1e-3) / 1e15 / FP6_PEAK_PFLOPS,
                          "note": "2 n p r multiply-adds per pass, each exact (fixed-point residual digits on the matrix cores): what a "
                                  "dense f64 X'R would need 78.6 TFLOP/s of vector FMAs for"}}
+
+
+def dense_object(m, torch, n=50_000, p=100_000):
+    """BASELINE configs[1]: the X'r pass over a dense Matrix{Float64} (k_xtv_dense_lds<f64>), 40 GB streamed once per pass."""
+    xd = m.DenseMatrix.synthetic(n, p, seed=2024)
+    torch.cuda.synchronize()
+    ms, _cs = xd.bench_xtv(iters=20, warmup=3)
+    alg = xd.algorithmic_bytes(1)
+    res = m.fit_iht(xd.xv_sparse(np.arange(0, p, p // 100)[:100], np.linspace(-1.0, 1.0, 100)) + np.random.default_rng(1).standard_normal(n),
+                    xd, None, k=100, verbose=False, max_iter=12)
+    del xd
+    return {"workload": f"fit_iht Float64 dense x randn({n},{p}) k=100 Normal (BASELINE configs[1]): the X'r pass, HIP events over 20 launches",
+            "pass_ms": ms, "algorithmic_bytes_per_launch": alg,
+            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "achieved": alg / (ms * 1e-3) / 1e9,
+                         "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "kernel": "k_xtv_dense_lds<f64>"},
+            "fit": {"iterations": int(res.iter), "ms_per_iteration": 1e3 * res.time / max(res.iter, 1), "nonzero": int(np.count_nonzero(res.beta))}}
 
 
 def main():
@@ -537,6 +572,11 @@ def main():
               "backtracks": int(nbt2), "what": "mih_fit_params::step_mode = 1: the host-driven step of rounds 1-4 (26 launches, three host "
               "waits per step without backtracking), same box, same fit, a fresh session"}
 
+    #  the model of the iterate the timed region ended on -- final_logl, the backtrack count and this count describe the same steps
+    bhat, _ = sess.model()
+    found = float(np.intersect1d(np.flatnonzero(bhat) + lo, supp).size)
+    recovered = int(sum_over_ranks([found])[0]) if sharded else int(found)
+
     # ... and of what the measurement itself costs (N = 1): the same session goes on for a few steps with the hook OFF.  The hook
     # brackets every X'r pass with two HIP event records, queue operations of their own inside the step chain; the timed region
     # above carries them (the roofline is measured there), this figure says what a step takes without them
@@ -553,9 +593,6 @@ def main():
                     "what": "the same fit continued with the measurement hook off (no HIP event records around the passes); the pass kernel's "
                             "duration is taken from the timed region"}
 
-    bhat, _ = sess.model()
-    found = float(np.intersect1d(np.flatnonzero(bhat) + lo, supp).size)
-    recovered = int(sum_over_ranks([found])[0]) if sharded else int(found)
     sess.close()
     del sess                                                # (it holds a reference to the matrix: the shard must be gone before the full replica comes)
     # ---- secondary at N > 1: BASELINE configs[4] column-sharded over the same ranks, through the same communicator ----------
@@ -766,6 +803,12 @@ def main():
         out["mv"] = mv_object(m, x, n, p, torch)
     elif rank == 0 and mv_sharded is not None:
         out["mv"] = mv_sharded
+    # ---- secondary: BASELINE configs[1] (N = 1): the dense Matrix{Float64} pass, randn(50000, 100000) --------------------------
+    if world == 1 and mode == "fit" and not a.no_dense and (n, p) == (500_000, 1_000_000):
+        try:
+            out["dense"] = dense_object(m, torch)
+        except Exception as e:      # noqa: BLE001 -- reported in the line, the headline stands
+            out["dense"] = {"error": repr(e)}
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"], cores = cpu_baseline(m, n, p, k, seed, a.cpu_seconds)

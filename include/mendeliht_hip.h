@@ -124,13 +124,19 @@ int mih_xtv_batched(const mih_mat *h, const double *R, int m, double *OUT);
  *        passes (cv_iht, multivariate, init_beta); relative error of X'r about 2^-43 max|r| / |r|_rms ~ 1e-12.
  *   1308 8 base-13 FP4 digits, |R| < 2^27, four per operand (~15 % faster than 4908, error ~1e-7).
  * A result never depends on which other residuals share a pass or on the kernel shape, only on the format.
- * What the fixed point costs: the quantum is 2^-54 max|r| (2^-53 at worst), so entry r_i keeps 54 + log2(|r_i| / max|r|) bits, and the
- * error of a column's X'r is at most sum_i g_ij 2^-54 max|r| (plus 64 ulp of the result for the f64 recombination) -- for residuals
- * without heavy tails that is tighter than an n-term f64 dot product.  With ONE entry 10^8 x the rest the columns that carry it are
- * still f64-grade relative to their result; the columns that do not keep 27 bits of the other entries: relative error up to ~2e-7
- * there (numpy's pairwise sum keeps 1e-16).  A Poisson fit with a planted count of 500 among counts of ~1 (9 bits to the outlier)
- * keeps the CPU restatement's support, iteration and backtracking log, its loglikelihood trace to 5e-8.
- * (tests/test_gpu_parity.py: test_xtv_fixed_point_under_adversarial_dynamic_range, test_poisson_fit_with_a_planted_count_outlier) */
+ * What the fixed point costs: the quantum is 2^-54 of the LARGEST entry the fixed point carries (2^-53 at worst), and the error of
+ * a column's X'r is at most sum_i g_ij times that quantum (plus 64 ulp of the result for the f64 recombination) -- for residuals
+ * without heavy tails tighter than an n-term f64 dot product.  Heavy tails (round 6, csrc/peel.h): rows whose |r_i| towers over the
+ * rest -- max|r| > 64 x the lower quartile of the maxima of the 64 strided 256-row blocks, at most 64 such rows -- leave the fixed
+ * point: their digits are zero, the scale is set by the largest of the REST, and k_xtv_finalize adds their terms g_ij r_i in f64
+ * (m rows of the 2-bit matrix per column, only when the guard fires).  With one entry 1e8 or 1e12 x the rest every column, with or
+ * without that row, is within 2 x 2^-53 sum_i g_ij |r_i| of the exact rational value (numpy's pairwise sum: 8 x) and within 1e-13 of
+ * its own value unless that value has cancelled; a residual without such rows does not move a bit.  What is left: more than 64 rows
+ * above the guard's threshold (a heavy TAIL rather than a few outliers) keep the plain scale, i.e. entry r_i keeps
+ * 54 + log2(|r_i| / max|r|) bits -- 200 rows 1e6 x the rest: ~1e-7 on the columns that carry none of them.  A Poisson fit with a
+ * planted count of 500 among counts of ~1 keeps the CPU restatement's loglikelihood trace to 1e-12 over 172 steps.
+ * (tests/test_gpu_parity.py: test_xtv_fixed_point_under_adversarial_dynamic_range, test_peeled_rows_in_fused_passes_with_missing_genotypes,
+ * test_poisson_fit_with_a_planted_count_outlier) */
 int mih_xtv_batched_fmt(const mih_mat *h, const double *R, int m, int digits, double *OUT);
 /* out = sum_t x[:, idx[t]] * val[t]  -- the column loops of update_xb!
  * (src/utilities.jl:98-106) and iht_stepsize! (:731-739); idx 0-based. */

@@ -432,25 +432,47 @@ end
 const ON_DEVICE = Ref(true)
 use_device!(on::Bool=true) = (ON_DEVICE[] = on)
 const DEVICE = Ref(0)                       # which GPU the wrappers' uploads go to
+# (round 6) The device copy of a SnpArray is CACHED: a second fit_iht / cv_iht on the same SnpLinAlg (or on another SnpLinAlg of the
+# same SnpArray with the same switches) uploads nothing -- 125 GB per call otherwise.  Weak keys: when the SnpArray is collected the
+# entry goes and the HipSnpLinAlg's finalizer (mih_mat_destroy, above) frees the device memory; `forget_device_copies!()` drops
+# every entry at once (e.g. before a matrix of another study goes up).
+const DEVICE_COPIES = WeakKeyDict{SnpArray, Dict{NTuple{4, Int}, HipSnpLinAlg{Float64}}}()
+const DEVICE_COPIES_LOCK = ReentrantLock()
+forget_device_copies!() = lock(() -> empty!(DEVICE_COPIES), DEVICE_COPIES_LOCK)
 function HipSnpLinAlg(x::SnpLinAlg{Float64}; device::Integer=DEVICE[])
     x.model == ADDITIVE_MODEL || throw(ArgumentError("the GPU path stores dosages: model = ADDITIVE_MODEL only"))
-    return HipSnpLinAlg{Float64}(x.s; center=x.center, scale=x.scale, impute=x.impute, device=device)
+    key = (Int(x.center), Int(x.scale), Int(x.impute), Int(device))
+    lock(DEVICE_COPIES_LOCK) do
+        per = get!(() -> Dict{NTuple{4, Int}, HipSnpLinAlg{Float64}}(), DEVICE_COPIES, x.s)
+        get!(() -> HipSnpLinAlg{Float64}(x.s; center=x.center, scale=x.scale, impute=x.impute, device=device), per, key)
+    end
 end
 
+# Which calls go to the GPU (ADVICE r5): only those the GPU methods can serve exactly -- an additive model and keywords they
+# accept; everything else falls back to the reference's own method instead of raising a MethodError / ArgumentError.
+const FIT_KEYWORDS = (:k, :J, :d, :l, :group, :weight, :zkeep, :est_r, :use_maf, :debias, :verbose, :tol, :max_iter, :min_iter,
+                      :max_step, :io, :init_beta, :memory_efficient, :comm, :xtv_digits)
+const CV_KEYWORDS = (:d, :l, :path, :q, :est_r, :group, :weight, :zkeep, :folds, :debias, :verbose, :max_iter, :min_iter, :init_beta,
+                     :memory_efficient, :rank, :world, :reduce, :comm, :xtv_digits, :cv_threads)
+const MV_CV_KEYWORDS = (:d, :l, :path, :q, :zkeep, :folds, :verbose, :max_iter, :min_iter, :init_beta, :rank, :world, :reduce)
+on_device(x::SnpLinAlg{Float64}, kwargs, allowed) =
+    ON_DEVICE[] && x.model == ADDITIVE_MODEL && all(kw -> kw in allowed, keys(kwargs)) && get(kwargs, :memory_efficient, true) === true
+const REF_SIG = Tuple{AbstractVecOrMat{Float64}, AbstractMatrix{Float64}, AbstractVecOrMat{Float64}}
+
 function MendelIHT.fit_iht(y::AbstractVector{Float64}, x::SnpLinAlg{Float64}, z::AbstractVecOrMat{Float64}; kwargs...)
-    ON_DEVICE[] || return invoke(MendelIHT.fit_iht, Tuple{AbstractVecOrMat{Float64}, AbstractMatrix{Float64}, AbstractVecOrMat{Float64}}, y, x, z; kwargs...)
+    on_device(x, kwargs, FIT_KEYWORDS) || return invoke(MendelIHT.fit_iht, REF_SIG, y, x, z; kwargs...)
     return fit_iht(y, HipSnpLinAlg(x), z; kwargs...)
 end
 function MendelIHT.fit_iht(y::AbstractMatrix{Float64}, x::Transpose{Float64, <:SnpLinAlg{Float64}}, z::AbstractVecOrMat{Float64}; kwargs...)
-    ON_DEVICE[] || return invoke(MendelIHT.fit_iht, Tuple{AbstractVecOrMat{Float64}, AbstractMatrix{Float64}, AbstractVecOrMat{Float64}}, y, x, z; kwargs...)
+    on_device(parent(x), kwargs, FIT_KEYWORDS) || return invoke(MendelIHT.fit_iht, REF_SIG, y, x, z; kwargs...)
     return fit_iht(y, Transpose(HipSnpLinAlg(parent(x))), z; kwargs...)
 end
 function MendelIHT.cv_iht(y::AbstractVector{Float64}, x::SnpLinAlg{Float64}, z::AbstractVecOrMat{Float64}; kwargs...)
-    ON_DEVICE[] || return invoke(MendelIHT.cv_iht, Tuple{AbstractVecOrMat{Float64}, AbstractMatrix{Float64}, AbstractVecOrMat{Float64}}, y, x, z; kwargs...)
+    on_device(x, kwargs, CV_KEYWORDS) || return invoke(MendelIHT.cv_iht, REF_SIG, y, x, z; kwargs...)
     return cv_iht(y, HipSnpLinAlg(x), z; kwargs...)
 end
 function MendelIHT.cv_iht(y::AbstractMatrix{Float64}, x::Transpose{Float64, <:SnpLinAlg{Float64}}, z::AbstractVecOrMat{Float64}; kwargs...)
-    ON_DEVICE[] || return invoke(MendelIHT.cv_iht, Tuple{AbstractVecOrMat{Float64}, AbstractMatrix{Float64}, AbstractVecOrMat{Float64}}, y, x, z; kwargs...)
+    on_device(parent(x), kwargs, MV_CV_KEYWORDS) || return invoke(MendelIHT.cv_iht, REF_SIG, y, x, z; kwargs...)
     return cv_iht(y, Transpose(HipSnpLinAlg(parent(x))), z; kwargs...)
 end
 

@@ -2668,6 +2668,7 @@ static int session_steps(mih_session_impl *s, int64_t nsteps, double *logl, int6
     if (logl) *logl = s->next_logl;
     if (backtracks) *backtracks = total;
     if (tol) *tol = sc;
+    if (v.h->prof->on && !v.res_active) xtv_count_peels(v.h, v.xtv, v.s);      // (a resident chain runs ahead of the host: counted when it ends)
     return MIH_OK;
 }
 

@@ -2162,7 +2162,7 @@ def test_peeled_rows_in_fused_passes_with_missing_genotypes(mih, oracle):
     for v in range(m):
         want = ox.xtv(R[v])
         scale = np.abs(want) + 1e-3 * np.abs(want).max()
-        tol = 1e-6 if v == heavy else 1e-12
+        tol = 1e-6 if v == heavy else 1e-11          # (the oracle is a plain f64 loop over 6001 terms: ~1e-12 of its own)
         assert np.all(np.abs(got[v] - want) <= tol * scale), (v, float((np.abs(got[v] - want) / scale).max()))
     plain = [v for v in range(m) if v not in planted and v != heavy]
     alone = x.xtv(R[plain[:3]].T).T
@@ -2177,7 +2177,12 @@ def test_poisson_fit_with_a_planted_count_outlier(mih, oracle, normal_pair):
     """ A heavy tail in the RESIDUAL of a real fit: Poisson counts y ~ 1 with ONE planted y = 500.
     The first iterates are wild (the outlier's mean sits at the +-20 clamp: a working residual of -4.8e8 among entries of ~1) and
     later y - mu has one entry ~500 x the rest.  Round 5 kept the oracle's support and logs but its loglikelihood trace to 5e-8 only
-    (27 bits lost on the bulk at the first steps); with the outlier row on the f64 side channel the trace is the oracle's to 1e-11.
+    (27 bits lost on the bulk in the first ~65 steps).  With the outlier row on the f64 side channel (csrc/peel.h; the guard fires in
+    the first ~66 scores of either fit):
+      * k = 6: the whole 172-step trace is the oracle's to 1e-12 (measured 1.1e-13), beta to 1e-10 (3e-12);
+      * k = 10: the first 85 steps to 1e-12 (1.5e-13); step 89 is a large step (tol 0.19) that multiplies ANY difference by ~400 and
+        the fit creeps on to max_iter amplifying it further -- the ORACLE's own trace moves by 7e-12 there and by 4.5e-9 at the end
+        when every y_i is nudged by one ulp (measured here, per step, four nudged runs); the HIP path is held to 100 x that spread.
     Both step modes, bit for bit."""
     x, ox = normal_pair
     rng = np.random.default_rng(77)
@@ -2188,13 +2193,31 @@ def test_poisson_fit_with_a_planted_count_outlier(mih, oracle, normal_pair):
     for k in (6, 10):
         mih.profile_counters(x, reset=True)
         res = mih.fit_iht(y, x, None, k=k, d=mih.Poisson(), l=mih.LogLink(), verbose=False)
-        assert mih.profile_counters(x, reset=True)["peeled_residuals"] >= 1
+        assert mih.profile_counters(x, reset=True)["peeled_residuals"] >= 40
         o = oracle.fit_iht(ox, y, None, k=k, dist="poisson", link="log")
         assert res.iter == o["iter"], (k, res.iter, o["iter"])
         assert list(res.trace["backtracks"]) == list(o["bt_trace"])
         assert np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"]))
-        np.testing.assert_allclose(res.beta, o["beta"], rtol=1e-9, atol=1e-12)
-        np.testing.assert_allclose(res.trace["logl"], o["logl_trace"], rtol=1e-11)
+        ol = np.asarray(o["logl_trace"])
+        got = np.abs(np.asarray(res.trace["logl"]) - ol) / np.abs(ol)
+        if k == 6:
+            assert got.max() <= 1e-12, got.max()
+            np.testing.assert_allclose(res.beta, o["beta"], rtol=1e-10, atol=1e-14)
+        else:
+            assert got[:85].max() <= 1e-12, got[:85].max()
+            spread, bspread = np.zeros(ol.size), 0.0
+            nz = np.flatnonzero(o["beta"])
+            for t in range(4):                               # what one ulp in every y_i does to the oracle itself
+                r2 = np.random.default_rng(100 + t)
+                y2 = np.where(r2.random(y.size) < 0.5, np.nextafter(y, np.inf), np.nextafter(y, -np.inf))
+                y2[y == 0] = 0.0
+                o2 = oracle.fit_iht(ox, y2, None, k=k, dist="poisson", link="log")
+                assert o2["iter"] == o["iter"] and np.array_equal(np.flatnonzero(o2["beta"]), nz)
+                spread = np.maximum(spread, np.abs(np.asarray(o2["logl_trace"]) - ol) / np.abs(ol))
+                bspread = max(bspread, float(np.max(np.abs(o2["beta"][nz] - o["beta"][nz]) / np.abs(o["beta"][nz]))))
+            assert np.all(got <= 1e-12 + 100 * spread), float((got / (1e-12 + 100 * spread)).max())
+            assert np.max(np.abs(res.beta[nz] - o["beta"][nz]) / np.abs(o["beta"][nz])) <= 100 * bspread
+            np.testing.assert_allclose(res.beta, o["beta"], rtol=1e-4, atol=1e-12)          # (north_star's GLM tolerance, whatever the spread)
         host = mih.fit_iht(y, x, None, k=k, d=mih.Poisson(), l=mih.LogLink(), verbose=False, step_mode=1)
         _same_fit(res, host, f"poisson outlier k={k}")
     mih.profile_enable(x, False)
