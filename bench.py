@@ -572,11 +572,6 @@ def main():
               "backtracks": int(nbt2), "what": "mih_fit_params::step_mode = 1: the host-driven step of rounds 1-4 (26 launches, three host "
               "waits per step without backtracking), same box, same fit, a fresh session"}
 
-    #  the model of the iterate the timed region ended on -- final_logl, the backtrack count and this count describe the same steps
-    bhat, _ = sess.model()
-    found = float(np.intersect1d(np.flatnonzero(bhat) + lo, supp).size)
-    recovered = int(sum_over_ranks([found])[0]) if sharded else int(found)
-
     # ... and of what the measurement itself costs (N = 1): the same session goes on for a few steps with the hook OFF.  The hook
     # brackets every X'r pass with two HIP event records, queue operations of their own inside the step chain; the timed region
     # above carries them (the roofline is measured there), this figure says what a step takes without them
@@ -585,13 +580,19 @@ def main():
         nun = min(a.steps, 20)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        sess.run(nun)
+        logl_after, _nbt3, _tol3 = sess.run(nun)
         torch.cuda.synchronize()
         el3 = time.perf_counter() - t2
         kern_ms_timed = st["ms_sum"] / max(st["launches"], 1)
-        unhooked = {"steps": nun, "ms_per_step": 1e3 * el3 / nun, "outside_the_pass_ms_per_step": 1e3 * el3 / nun - kern_ms_timed,
+        unhooked = {"steps": nun, "logl_after_these_steps": logl_after, "ms_per_step": 1e3 * el3 / nun, "outside_the_pass_ms_per_step": 1e3 * el3 / nun - kern_ms_timed,
                     "what": "the same fit continued with the measurement hook off (no HIP event records around the passes); the pass kernel's "
                             "duration is taken from the timed region"}
+
+    #  the model is read AFTER the continuation (reading it brings the iterate home and the chain would have to warm up again):
+    # true_effects_recovered describes the iterate whose loglikelihood is without_the_measurement_hook.logl_after_these_steps
+    bhat, _ = sess.model()
+    found = float(np.intersect1d(np.flatnonzero(bhat) + lo, supp).size)
+    recovered = int(sum_over_ranks([found])[0]) if sharded else int(found)
 
     sess.close()
     del sess                                                # (it holds a reference to the matrix: the shard must be gone before the full replica comes)

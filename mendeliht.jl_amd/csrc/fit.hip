@@ -1023,6 +1023,7 @@ struct IhtVar {
     int init_pre(const uint8_t *train)
     {
         train_cur = train; spec_ok = false;
+        res_ok = res_eligible; lane_queued = false;
         b.clear(); b0.clear(); best_b.clear(); idx.clear();
         bg.clear(); b0g.clear(); bg_ok = b0g_ok = true;        // (b = 0 on every shard)
         std::fill(c.begin(), c.end(), 0.0); c0 = c; best_c = c; std::fill(df2.begin(), df2.end(), 0.0);
@@ -1401,6 +1402,7 @@ struct IhtVar {
     // column shards, groups, est_r, debias, dense matrices, lock-step lanes); a fit that qualifies runs its steps through
     // res_next().  Between res_begin() and res_end() the iterate lives on the device only.
     bool res_ok = false, res_active = false, res_zero_list = false;
+    bool res_eligible = false;           // what res_setup found; res_ok falls to false when a res_begin declines (lists beyond the buffers) and comes back with the next fit on this variable (init_pre)
     int res_epoch = 0; uint64_t res_seq = 0; int64_t res_kcap = 0;
     std::vector<uint64_t> res_out;                       // sequence numbers of the steps in flight, oldest first
     DevBuf<ResCtl> rctl; DevBuf<int64_t> ridx; DevBuf<double> rval; DevBuf<int32_t> rslot; DevBuf<uint32_t> rhist; DevBuf<uint64_t> rsel; DevBuf<double> rwalk; DevBuf<uint32_t> rtick;
@@ -1410,9 +1412,11 @@ struct IhtVar {
 
     int res_setup(const mih_fit_params *prm, int64_t kcap)
     {
-        res_ok = false;
+        res_ok = res_eligible = false;
         const int64_t K = k + zkeepn;
-        if (h->kind != 0 || has_group || !ks.empty() || est_r != MIH_ESTR_NONE || debias || batched || prm->step_mode != 0) return MIH_OK;
+        // (round 6) a lock-step lane's fit runs resident too: its chain is queued behind the lane's fused pass (lane_queue_step) and
+        // stops at the working residual; the score itself stays the lane's
+        if (h->kind != 0 || has_group || !ks.empty() || est_r != MIH_ESTR_NONE || debias || prm->step_mode != 0) return MIH_OK;
         if (probe_env("MENDELIHT_NO_RESIDENT")) return MIH_OK;              // measurement build: A/B against the host-driven step
         // a column shard: only with the library's own communicator (its collectives are queued INSIDE the gated chain; callbacks of
         // the host language need the host), no prior weights (the shards do not hold each other's), and a pool of candidates
@@ -1425,9 +1429,11 @@ struct IhtVar {
         MIH_TRY(rctl.alloc(1)); MIH_TRY(ridx.alloc((size_t)res_kcap * 3)); MIH_TRY(rval.alloc((size_t)res_kcap * 3));
         MIH_TRY(rslot.alloc((size_t)res_kcap * 4)); MIH_TRY(rhist.alloc(4096));
         MIH_TRY(rsel.alloc((size_t)kResCollectBlocks * (1 + 2 * kResCollectSlots)));
-        const size_t slices = (size_t)(q + kResStatCov - 1) / kResStatCov;
-        MIH_TRY(rwalk.alloc(slices * kStatBlocksRes * 10 * 256)); MIH_TRY(rtick.alloc(slices * kStatBlocksRes));      // k_res_stats: the walkers' sums, a ticket per walk-block
-        MIH_HIP(hipMemsetAsync(rtick.p, 0, sizeof(uint32_t) * slices * kStatBlocksRes, s));
+        if (!batched) {             // (a lane's fit has no score of its own: no k_res_stats)
+            const size_t slices = (size_t)(q + kResStatCov - 1) / kResStatCov;
+            MIH_TRY(rwalk.alloc(slices * kStatBlocksRes * 10 * 256)); MIH_TRY(rtick.alloc(slices * kStatBlocksRes));      // k_res_stats: the walkers' sums, a ticket per walk-block
+            MIH_HIP(hipMemsetAsync(rtick.p, 0, sizeof(uint32_t) * slices * kStatBlocksRes, s));
+        }
         if (res_sharded) {
             const size_t mlen = 2 + 2 * (size_t)K;
             MIH_TRY(rgidx.alloc((size_t)res_kcap * 3)); MIH_TRY(rgval.alloc((size_t)res_kcap * 3));          // the two whole models + the shard's own survivors
@@ -1438,7 +1444,7 @@ struct IhtVar {
         MIH_TRY(ridx_h.alloc((size_t)res_kcap * 3, true)); MIH_TRY(rval_h.alloc((size_t)res_kcap * 3, true)); MIH_TRY(rslot_h.alloc((size_t)res_kcap * 4, true));
         MIH_HIP(hipMemsetAsync(rhist.p, 0, sizeof(uint32_t) * 4096, s));
         std::memset(rrec.p, 0, sizeof(ResRecord) * kResRing);
-        res_ok = true;
+        res_ok = res_eligible = true;
         return MIH_OK;
     }
     ResPtrs res_ptrs() const
@@ -1497,7 +1503,7 @@ struct IhtVar {
             fits = decline == 0.0;
         }
         if (!fits) return MIH_BAD_ARG;
-        MIH_HIP(hipStreamSynchronize(s));                    // the pinned staging below may still be read by an earlier upload
+        MIH_TRY(stream_sync_coop(s));                        // the pinned staging below may still be read by an earlier upload (a lane's other fits go on meanwhile)
         ResCtl &C = *rctl_h.p;
         std::memset(&C, 0, sizeof(C));
         C.live_epoch = res_gate_step(res_epoch); C.cur = 0; C.es = 0; C.iter = (int32_t)iter_done;
@@ -1822,6 +1828,73 @@ struct IhtVar {
         }
     }
 
+    // ---- a lock-step lane's fit, resident (round 6; cross_validation.jl:100-121, fit.jl:213-263) --------------------------------------
+    // The lane scores the residuals of all its fits with ONE fused pass per round, so a fit's chain has no step-end of its own: behind
+    // the pass the fit queues Z'r (into the control block), df on its support, the step's start and its attempt slots -- WITHOUT
+    // waiting (lane_queue_step) -- and reads the step's record when the lane collects the residuals of its next pass
+    // (lane_collect_step): one host wait per step and fit instead of three plus two per backtrack, and the chains of a lane's fits
+    // run on the device while its host thread is still queuing the others'.
+    uint64_t lane_seq = 0; bool lane_queued = false;
+    int lane_queue_step(double next_logl, double best, int64_t iter_done, const mih_fit_params *prm)
+    {
+        lane_queued = false;
+        if (!res_ok) return MIH_OK;
+        if (!res_active) {               // (the fit's first step, or the step after one the device handed back)
+            if (res_begin(next_logl, best, iter_done, 1, prm) != MIH_OK) { res_ok = false; return MIH_OK; }
+        } else {
+            hipLaunchKernelGGL(k_zt_r, dim3(kZtrBlocks, q), dim3(256), 0, s, z.p, r.p, n, ztr.p, ztr_done.p, rctl.p->df2);
+            MIH_TRY(res_enqueue_support());
+        }
+        lane_seq = ++res_seq;
+        MIH_TRY(res_enqueue_front());
+        MIH_TRY(res_enqueue_attempts(lane_seq, 0, prm->max_step));
+        lane_queued = true;
+        return MIH_OK;
+    }
+    // *stepped = false: no chain was queued, or the device handed the step back (the iterate is home again): the host-driven step_pre
+    // follows.  *stop: the device applied the stopping rule (fit.jl:197) and it held.
+    int lane_collect_step(const mih_fit_params *prm, double *next_logl, double *best, int *nbt, double *tol, bool *stepped, bool *stop)
+    {
+        *stepped = false; *stop = false;
+        if (!lane_queued) return MIH_OK;
+        lane_queued = false;
+        uint64_t seq = lane_seq;
+        for (;;) {
+            ResRecord rec;
+            MIH_TRY(res_wait(seq, &rec));
+            switch (rec.status) {
+            case RES_ACCEPT: case RES_STOP_CONVERGED:
+                res_known = std::max(res_known, rec.nbt + 1);
+                res_last[2] = res_last[1]; res_last[1] = res_last[0]; res_last[0] = rec.nbt;
+                res_spec = std::min(res_spec_cap(), std::max(res_last[0], std::max(res_last[1], res_last[2])));
+                h->prof->count(MIH_CNT_RESIDENT_STEPS, 1);
+                if (rec.status == RES_STOP_CONVERGED) { ++res_epoch; *stop = true; }
+                *next_logl = rec.logl; *nbt = rec.nbt; *tol = rec.tol; *stepped = true;
+                return MIH_OK;
+            case RES_PENDING:                // the series ended with the step still backtracking: another series of slots goes on with it
+                h->prof->count(MIH_CNT_RESIDENT_ATTEMPTS, 1);
+                seq = ++res_seq;
+                MIH_TRY(res_enqueue_attempts(seq, rec.nbt, prm->max_step));
+                break;
+            case RES_REDO_SLOW:              // the direct gather's forecast failed: the same attempt again, with the histograms
+                ++res_epoch; ++res_fast_fails;
+                h->prof->count(MIH_CNT_RESIDENT_REDOS, 1);
+                seq = ++res_seq;
+                MIH_TRY(res_enqueue_attempts(seq, rec.nbt, prm->max_step, true));
+                break;
+            case RES_STOP_NAN: case RES_STOP_INF:
+                ++res_epoch;
+                MIH_TRY(res_end(nullptr, nullptr));
+                if (rec.status == RES_STOP_NAN) { set_error("Loglikelihood function is NaN, aborting..."); return MIH_NAN_LOGL; }
+                set_error("Loglikelihood function is Inf, aborting..."); return MIH_INF_LOGL;
+            case RES_ABORT:
+                h->prof->count(MIH_CNT_RESIDENT_HANDBACKS, 1);
+                return res_end(next_logl, best, true);
+            default: set_error("device-resident step: unknown record status %d", rec.status); return MIH_HIP_ERROR;
+            }
+        }
+    }
+
     // fit_iht! (fit.jl:145-207)
     int fit_loop(const mih_fit_params *prm, double *best_out, int64_t *iter_out, double *lt, double *tt,
                  int32_t *btt, int32_t *ntrace)
@@ -2010,6 +2083,7 @@ static int cv_finish(CvFit &f, double *mses_raw)
 {
     if (probe_env("MENDELIHT_CV_TRACE"))             // measurement build: which fit took how many iterations (the queue's order is built on it)
         fprintf(stderr, "fit out_index %lld k %lld: %d iterations\n", (long long)f.out_index, (long long)f.v->k, f.iter);
+    if (f.v->res_active) MIH_TRY(f.v->res_end(&f.next_logl, &f.best));          // (a resident fit's iterate and its two loglikelihoods come home)
     f.best = f.v->save_prev(f.next_logl, f.best);
     MIH_TRY(f.v->save_best_model());
     if (f.chain_r) *f.chain_r = f.v->nb_r;             // v.d stays as the last mle_for_r left it (cross_validation.jl:91,110)
@@ -2201,6 +2275,7 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
                     if (it != df0.end()) {       // its initial X'r is known from an earlier round: no pass, straight on to its first step
                         MIH_HIP(hipMemcpyAsync(f.v->df.p, it->second, sizeof(double) * h->p, hipMemcpyDeviceToDevice, f.v->s));    // (written on the lane's stream rounds ago)
                         MIH_TRY(f.v->init_post());
+                        if (f.iter < pr.max_iter) MIH_TRY(f.v->lane_queue_step(f.next_logl, f.best, f.iter - 1, &pr));    // (its first step, resident)
                         h->prof->count(MIH_CNT_SHARED_INIT, 1);
                         h->prof->count(MIH_CNT_INIT_SCORES, 1);     // its initial score, served by a copy
                         continue;
@@ -2219,8 +2294,13 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
                 }
                 slot[t].reset(); continue;
             }
-            f.best = f.v->save_prev(f.next_logl, f.best);
-            MIH_TRY(f.v->step_pre(f.next_logl, pr.max_step, &f.nbt, &f.next_logl));
+            // (round 6) a resident fit: the step's chain was queued behind the last pass (slot_post); its record is read here
+            bool stepped = false, dev_stop = false; double dev_tol = 0.0;
+            MIH_TRY(f.v->lane_collect_step(&pr, &f.next_logl, &f.best, &f.nbt, &dev_tol, &stepped, &dev_stop));
+            if (!stepped) {
+                f.best = f.v->save_prev(f.next_logl, f.best);
+                MIH_TRY(f.v->step_pre(f.next_logl, pr.max_step, &f.nbt, &f.next_logl));
+            }
             h->prof->count(MIH_CNT_SCORES, 1);                                            // an IHT iteration (fit.jl's counter)
             // (round 5) debias! (fit.jl:188) and the convergence test (fit.jl:197) need nothing of the score that ends this step:
             // they look at b, b0, c, c0 only.  A fit that converges HERE is finished (save_best_model, predict!) without riding
@@ -2229,7 +2309,7 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
             IhtVar &v = *f.v;
             if (v.debias && f.iter >= 5 && v.b.idx == v.b0.idx && !v.b.idx.empty())          // fit.jl:188: v.idx == v.idx0 && debias!(v)
                 MIH_TRY(debias_glm_device(h, v.b.idx.data(), (int64_t)v.b.idx.size(), v.y.p, v.dist, v.link, v.nb_r, v.b.val.data(), v.s));
-            const double sc = v.check_convergence();
+            const double sc = stepped ? dev_tol : v.check_convergence();                   // (k_res_select's tol: the same maxima)
             if (f.iter >= pr.min_iter && sc < pr.tol) {
                 if (std::isnan(f.next_logl)) { set_error("Loglikelihood function is NaN, aborting..."); return MIH_NAN_LOGL; }
                 if (std::isinf(f.next_logl)) { set_error("Loglikelihood function is Inf, aborting..."); return MIH_INF_LOGL; }
@@ -2245,9 +2325,13 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
     };
     // ... and AFTER it: the fit takes its X'r, ends the step (or its initialisation) and decides whether it is done
     auto slot_post = [&](CvFit *f, char is_fresh) -> int {
-        if (is_fresh) return f->v->init_post();
-        MIH_TRY(f->v->step_post(f->next_logl));           // (debias! and the convergence test of this step ran before the pass: slot_pre)
-        f->iter++;
+        if (is_fresh) MIH_TRY(f->v->init_post());
+        else {
+            if (!f->v->res_active) MIH_TRY(f->v->step_post(f->next_logl));      // (debias! and the convergence test of this step ran before the pass: slot_pre)
+            f->iter++;
+        }
+        // the next step's chain goes out now, behind the pass, without a wait (a fit that does not qualify steps host-driven in slot_pre)
+        if (f->iter < pr.max_iter) MIH_TRY(f->v->lane_queue_step(f->next_logl, f->best, f->iter - 1, &pr));
         return MIH_OK;
     };
     for (;;) {

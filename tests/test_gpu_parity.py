@@ -2649,6 +2649,68 @@ def test_resident_steps_equal_host_driven_steps(mih, oracle, normal_pair, normal
     assert mih.fit_iht(yt, xt, None, k=2, verbose=False, step_mode=0).choose_fired
 
 
+def test_resident_lockstep_equals_host_driven(mih, oracle, normal_pair, normal_data):
+    """ The lock-step lanes' fits run their steps resident on the device too (round 6): behind the lane's fused
+    pass a fit queues Z'r, df on its support, the step's start and its attempt slots without waiting and reads ONE record when
+    the lane collects the residuals of its next pass.  step_mode 0 (resident) against step_mode 1 (host-driven, rounds 1-5):
+    the same held-out losses BIT FOR BIT -- Normal with covariates on a matrix with imputed entries (two lanes, a tail hand-over),
+    logistic, Poisson with backtracking, init_beta, a model path -- and the counters say which way the steps ran.  Fits the
+    resident chain does not take (debias, est_r) step host-driven in either mode."""
+    xm = mih.SnpLinAlg.synthetic(6001, 900, seed=3, missing_rate=0.01)
+    rng = np.random.default_rng(606)
+    supp = np.sort(rng.choice(900, 8, replace=False))
+    em = xm.xv_sparse(supp, rng.standard_normal(8) * 0.6)
+    zm = np.column_stack([np.ones(6001), rng.standard_normal(6001)])
+    yn = em + 0.5 + 0.3 * zm[:, 1] + rng.standard_normal(6001)
+    yb = (rng.random(6001) < 1 / (1 + np.exp(-em))).astype(float)
+    yp = rng.poisson(np.exp(0.3 * em)).astype(float)
+    folds = hash_folds(6001, 5)
+    x, _ = normal_pair
+    y, z = normal_data["y"], normal_data["z"]
+    runs = {
+        "normal, 5 x 12 (two lanes)": lambda: mih.cv_iht(yn, xm, zm, path=range(1, 13), q=5, folds=folds, verbose=False, return_raw=True)[1],
+        "logistic": lambda: mih.cv_iht(yb, xm, None, path=range(2, 9), q=5, folds=folds, verbose=False, return_raw=True, d=mih.Bernoulli(), l=mih.LogitLink())[1],
+        "poisson": lambda: mih.cv_iht(yp, xm, zm, path=[3, 6, 9], q=5, folds=folds, verbose=False, return_raw=True, d=mih.Poisson(), l=mih.LogLink())[1],
+        "init_beta": lambda: mih.cv_iht(yn, xm, zm, path=range(1, 9), q=3, folds=hash_folds(6001, 3), verbose=False, return_raw=True, init_beta=True)[1],
+        "zkeep = [1, 0]": lambda: mih.cv_iht(y, x, z, path=range(4, 10), q=3, folds=hash_folds(1000, 3), verbose=False, return_raw=True, zkeep=[1, 0])[1],
+        "model path": lambda: np.asarray(mih.iht_run_many_models(y, x, z, path=range(1, 11), verbose=False)),
+    }
+    got = {}
+    for mode in (0, 1):
+        mih.set_step_mode(mode)
+        try:
+            for name, fn in runs.items():
+                mat = x if ("zkeep" in name or "path" in name) else xm
+                mih.profile_enable(mat, True)
+                mih.profile_counters(mat, reset=True)
+                out = fn()
+                cnt = mih.profile_counters(mat, reset=True)
+                mih.profile_enable(mat, False)
+                got[(mode, name)] = (out, cnt)
+        finally:
+            mih.set_step_mode(0)
+    backtracked = 0
+    for name in runs:
+        (a, ca), (b, cb) = got[(0, name)], got[(1, name)]
+        assert np.array_equal(np.asarray(a).view(np.uint64), np.asarray(b).view(np.uint64)), name
+        assert ca["scores"] == cb["scores"] and ca["fits"] == cb["fits"], (name, ca, cb)
+        assert cb["resident_steps"] == 0 and cb["resident_handbacks"] == 0, (name, cb)
+        assert ca["resident_steps"] + ca["resident_handbacks"] == ca["scores"] > 0, (name, ca)
+        assert ca["resident_handbacks"] == 0, (name, ca)
+        backtracked += ca["resident_attempts"] + ca["resident_redos"]
+    assert got[(0, "normal, 5 x 12 (two lanes)")][1]["lanes"] == 2
+    # fits the chain does not take: the same results, no resident step
+    mih.profile_enable(xm, True)
+    mih.profile_counters(xm, reset=True)
+    d0 = mih.cv_iht(yb, xm, None, path=[3, 5], q=3, folds=hash_folds(6001, 3), verbose=False, return_raw=True, d=mih.Bernoulli(), l=mih.LogitLink(), debias=True, max_iter=30)[1]
+    assert mih.profile_counters(xm, reset=True)["resident_steps"] == 0 and np.count_nonzero(d0) == 6
+    mih.profile_enable(xm, False)
+    # ... and the resident lanes against the oracle, directly
+    ox = oracle.Mat.from_bed_columns(xm.export_bed(), 6001)
+    _, want = oracle.cv_iht(ox, yb, None, path=list(range(2, 9)), q=5, folds=folds, dist="bernoulli", link="logit")
+    np.testing.assert_allclose(np.asarray(got[(0, "logistic")][0]).reshape(want.shape), want, rtol=1e-8)
+
+
 def test_resident_session_keeps_the_iterate_on_the_device(mih, normal_pair, normal_data):
     """mih_session_step / _run / _model with the iterate resident on the device: single steps, a run of steps, the model read in
     between (the iterate comes home and goes back) -- all equal to the host-driven session, step for step."""
