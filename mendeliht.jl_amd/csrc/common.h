@@ -404,6 +404,11 @@ struct XtvStatsHook {
     const double *zpart = nullptr; double *df2 = nullptr; int q = 0, zblocks = 0;
     int ebits = 0;
 };
+// The fused passes of a matrix's lock-step lanes run ONE AFTER THE OTHER (round 6): every pass waits for the pass queued before it,
+// whichever lane queued it.  Two passes dispatched side by side share the CUs and end together, the lanes fall into step, and each
+// round then ends with a phase of small per-fit kernels that no pass overlaps; in single file lane A's chains run under lane B's
+// pass and the matrix pipe never waits (tools/trace_cv_rounds.sh: 85 -> 76 ms per pair of passes).
+struct PassOrder { std::mutex mu; hipEvent_t last = nullptr; };
 struct XtvWork {            // scratch for one in-flight X'r
     DevBuf<uint32_t> digits;   // ops * nblk * 64 lanes * 4 dwords (+ 2 dwords, stored behind, for FP6) : digit planes of r (B operands)
     DevBuf<double>   partial;  // splits * rhs * ncg*32 raw dots
@@ -422,6 +427,7 @@ struct XtvWork {            // scratch for one in-flight X'r
     // xtv_digits = -1 (auto): the lock-step drivers score a residual whose max |r| / rms(r) is small in the 43-bit format, the others
     // in the 54-bit one -- per RESIDUAL (a fit's bits never depend on its company); use_alt selects the format of ONE xtv_device call
     DigitMode dm_alt = {49, 8, 4, 8, 42, 18}; bool has_alt = false, use_alt = false;
+    PassOrder *order = nullptr; hipEvent_t pass_done = nullptr;   // a lane's workspace: its passes take their turn (PassOrder); pass_done is this lane's event
     XtvSupportHook hook;       // ... and whose finalize kernel also serves the support of the iterate
     XtvStatsHook shook;        // ... and whose digit kernel finishes those statistics
 };

@@ -83,31 +83,37 @@ k_resid(const double *__restrict__ xb, const double *__restrict__ zc, const doub
 
 // df2 = Z' r (utilities.jl:134): kZtrBlocks workgroups per covariate (grid.y), fixed-order trees
 constexpr int kZtrBlocks = 128;
-__global__ void __launch_bounds__(256)
-k_zt_r(const double *__restrict__ z, const double *__restrict__ r, int64_t n, double *__restrict__ part,
-       unsigned *__restrict__ done /* [q], zero */, double *__restrict__ out)
+// (the body: covariate l of one fit; block bx of kZtrBlocks)
+__device__ __forceinline__ void b_zt_r(int l, int bx, const double *__restrict__ z, const double *__restrict__ r, int64_t n, double *__restrict__ part,
+                                       unsigned *__restrict__ done /* [q], zero */, double *__restrict__ out)
 {
-    const double *zl = z + (int64_t)blockIdx.y * n;
+    const double *zl = z + (int64_t)l * n;
     double v[1] = {0.0};
-    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += 8 * 256ll * kZtrBlocks) {       // eight rows in flight, the sum in the walk's order
+    for (int64_t i = bx * 256ll + threadIdx.x; i < n; i += 8 * 256ll * kZtrBlocks) {       // eight rows in flight, the sum in the walk's order
         double a8[8], b8[8];
         #pragma unroll
         for (int u = 0; u < 8; ++u) { const int64_t iu = i + u * 256ll * kZtrBlocks; a8[u] = iu < n ? zl[iu] : 0.0; b8[u] = iu < n ? r[iu] : 0.0; }
         #pragma unroll
         for (int u = 0; u < 8; ++u) if (i + u * 256ll * kZtrBlocks < n) v[0] += a8[u] * b8[u];
     }
-    block_sum<1>(v, part + (int64_t)blockIdx.y * kZtrBlocks + blockIdx.x);
+    block_sum<1>(v, part + (int64_t)l * kZtrBlocks + bx);
     if (threadIdx.x == 0) {           // the block that delivers last adds the partials in block order (k_zt_r_final's sum)
         __threadfence();
-        if (atomicAdd(&done[blockIdx.y], 1u) == (unsigned)kZtrBlocks - 1) {
+        if (atomicAdd(&done[l], 1u) == (unsigned)kZtrBlocks - 1) {
             __threadfence();
             double a = 0.0;
             for (int b = 0; b < kZtrBlocks; ++b)
-                a += __hip_atomic_load(&part[(int64_t)blockIdx.y * kZtrBlocks + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            out[blockIdx.y] = a;
-            done[blockIdx.y] = 0;
+                a += __hip_atomic_load(&part[(int64_t)l * kZtrBlocks + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out[l] = a;
+            done[l] = 0;
         }
     }
+}
+__global__ void __launch_bounds__(256)
+k_zt_r(const double *__restrict__ z, const double *__restrict__ r, int64_t n, double *__restrict__ part,
+       unsigned *__restrict__ done /* [q], zero */, double *__restrict__ out)
+{
+    b_zt_r((int)blockIdx.y, (int)blockIdx.x, z, r, n, part, done, out);
 }
 
 // NegBin nuisance-parameter sums over all samples (utilities.jl:158-173 MM, :186-194 Newton).
@@ -1720,9 +1726,15 @@ struct IhtVar {
     static int res_spec_cap() { static const int c = probe_env("MENDELIHT_SPEC_CAP") ? atoi(probe_env("MENDELIHT_SPEC_CAP")) : 2; return c; }       // (measurement build: slots per series beyond the first)
     int res_enqueue_attempts(uint64_t seq, int a0, int max_step, bool first_slow = false)
     {
-        const int slots = 1 + std::max(0, std::min(max_step - std::min(a0, max_step), res_spec));      // (attempt max_step always stands: utilities.jl:484)
+        // A lane's fit (batched): ONE slot per series and no direct gather.  Its chain runs while the other lane's fused pass holds every
+        // CU, where even a slot that turns out empty costs what its ~1500 workgroups cost to schedule (each needs a CU the pass has to
+        // give up), and the fits of a cross-validation are short (5-17 steps): the threshold forecast failed in 13 % of their steps
+        // (configs[3]: 150 redos in 1147 steps), as many as backtracked at all.  A step that backtracks costs its fit one more round trip.
+        static const bool lane_spec = probe_env("MENDELIHT_LANE_SPEC") != nullptr;          // (measurement build: the single fit's policy in the lanes)
+        const bool plain = batched && !lane_spec;
+        const int slots = plain ? 1 : 1 + std::max(0, std::min(max_step - std::min(a0, max_step), res_spec));      // (attempt max_step always stands: utilities.jl:484)
         for (int j = 0; j < slots; ++j) {
-            const bool fast = res_known > 0 && res_fast_fails < 3 && !(first_slow && j == 0);
+            const bool fast = !plain && res_known > 0 && res_fast_fails < 3 && !(first_slow && j == 0);
             if (fast) h->prof->count(MIH_CNT_RESIDENT_DIRECT, 1);
             MIH_TRY(res_enqueue_attempt(seq, 0, j + 1 < slots, fast));
         }
@@ -1751,8 +1763,10 @@ struct IhtVar {
     // between two kernels of the chain): the host polls the pinned ring -- briefly, then with short sleeps (it runs a step ahead of
     // the records it reads, and an X'r pass of tens of ms is in front of most of them), looking at the stream now and then so that a
     // failed launch does not leave it waiting.
-    int res_wait(uint64_t seq, ResRecord *out)
+    // `on`: the stream the chain was queued on (a lane's batched series run on the LANE's stream, not on this fit's)
+    int res_wait(uint64_t seq, ResRecord *out, hipStream_t on = nullptr)
     {
+        const hipStream_t sq = on ? on : s;
         volatile ResRecord *slot_ = rrec.p + (seq % kResRing);
         const auto t0 = std::chrono::steady_clock::now();
         auto next_query = t0 + std::chrono::milliseconds(50);
@@ -1765,7 +1779,7 @@ struct IhtVar {
             if (now - t0 > std::chrono::microseconds(200)) std::this_thread::sleep_for(std::chrono::microseconds(100));
             if (now > next_query) {
                 next_query = now + std::chrono::milliseconds(50);
-                const hipError_t e = hipStreamQuery(s);
+                const hipError_t e = hipStreamQuery(sq);
                 if (e == hipSuccess) {                     // everything queued has run: the record is there, or never will be
                     if (__atomic_load_n(&slot_->seq, __ATOMIC_ACQUIRE) == seq) break;
                     set_error("device-resident step %llu left no record", (unsigned long long)seq);
@@ -1892,6 +1906,44 @@ struct IhtVar {
                 return res_end(next_logl, best, true);
             default: set_error("device-resident step: unknown record status %d", rec.status); return MIH_HIP_ERROR;
             }
+        }
+    }
+
+    // ... and BATCHED over the lane's fits (k_lane_*, resident.inc): this fit's record of the array the lane's kernels read.
+    // step_start: the step begins here (X_S df_S, the step size); new_score: Z'r and df on the support are taken from the score that
+    // has just arrived (not for a fit res_begin has just set up: it brought them along)
+    void lane_fill(LaneFit &a, uint64_t seq, bool step_start, bool new_score) const
+    {
+        static const int force_abort_es = probe_env("MENDELIHT_RES_FORCE_ABORT_ES") ? atoi(probe_env("MENDELIHT_RES_FORCE_ABORT_ES")) : -1;
+        a.P = res_ptrs(); a.M = res_mat(); a.epoch = res_epoch; a.front = step_start ? 1 : 0; a.score = new_score ? 1 : 0;
+        a.q = q; a.dist = dist; a.link = link; a.zkeepn = (int)zkeepn; a.lean = res_lean() ? 1 : 0; a.force_abort_es = force_abort_es;
+        a.nb_r = nb_r; a.zkeep = res_zkeep_mask(); a.K = (uint64_t)(k + zkeepn); a.seq = seq;
+        a.max_nonzero = ((J == 0) ? 1 : J) * (k + zkeepn); a.p = p;
+        a.z = z.p; a.y = y.p; a.w = w.p; a.weight = has_weight ? weight.p : nullptr;
+        a.xb = xb.p; a.zc = zc.p; a.mu = mu.p; a.r = r.p; a.xgk = xgk.p; a.red = red.p; a.df = df.p; a.full = full.p;
+        a.ztr = ztr.p; a.df2 = rctl.p->df2; a.ztr_done = ztr_done.p; a.nb = nb; a.pad = 0;
+    }
+    // what a record of the batched chain means for this fit (the cases of lane_collect_step).  *again: the step is still backtracking,
+    // the lane queues another series for it
+    int lane_take_record(const ResRecord &rec, double *next_logl, double *best, int *nbt, double *tol, bool *stepped, bool *again)
+    {
+        *stepped = false; *again = false;
+        switch (rec.status) {
+        case RES_ACCEPT: case RES_STOP_CONVERGED:
+            h->prof->count(MIH_CNT_RESIDENT_STEPS, 1);
+            if (rec.status == RES_STOP_CONVERGED) ++res_epoch;
+            *next_logl = rec.logl; *nbt = rec.nbt; *tol = rec.tol; *stepped = true;
+            return MIH_OK;
+        case RES_PENDING: h->prof->count(MIH_CNT_RESIDENT_ATTEMPTS, 1); *again = true; return MIH_OK;
+        case RES_STOP_NAN: case RES_STOP_INF:
+            ++res_epoch;
+            MIH_TRY(res_end(nullptr, nullptr));
+            if (rec.status == RES_STOP_NAN) { set_error("Loglikelihood function is NaN, aborting..."); return MIH_NAN_LOGL; }
+            set_error("Loglikelihood function is Inf, aborting..."); return MIH_INF_LOGL;
+        case RES_ABORT:
+            h->prof->count(MIH_CNT_RESIDENT_HANDBACKS, 1);
+            return res_end(next_logl, best, true);
+        default: set_error("device-resident step: unknown record status %d", rec.status); return MIH_HIP_ERROR;
         }
     }
 
@@ -2039,6 +2091,9 @@ struct CvFit {
     int iter = 1, nbt = 0;
     double next_logl = -std::numeric_limits<double>::infinity(), best = -std::numeric_limits<double>::infinity();
     bool done = false;
+    // the lane's batched chain (k_lane_*): this fit wants its next step in the series the lane queues behind the pass / a series is in
+    // flight for it / its record has been read
+    bool wants_step = false, fresh_begin = false, in_batch = false, have_rec = false; ResRecord rec;
     // est_r in cv_iht: this fit is number chain_pos of chain `chain` (CvChains); when it ends it leaves its NegBin r in *chain_r
     int64_t chain = -1; size_t chain_pos = 0; double *chain_r = nullptr;
     // iht_run_many_models mode (no hold-out): where to put the finished model instead of a held-out deviance
@@ -2049,6 +2104,30 @@ struct CvFit {
 // the lane's stream waits for everything fit f has queued on its own stream (f.v->s != lane stream only with private streams)
 static int fit_to_lane(CvFit &f, hipStream_t lane_s);
 static int lane_to_fit(CvFit &f, hipStream_t lane_s, hipEvent_t lane_ev);
+
+// The residuals of a lane's fits into the pass's R, the scores out of its DF, ONE launch each way instead of a copy per fit (round 6:
+// 38 copies of 4 - 8 MB around every pass were 1.5 ms of the window between two passes: tools/cv_window_trace.sh)
+constexpr int kLaneCopyMax = 64;
+struct LaneCopy { const double *src[kLaneCopyMax]; double *dst[kLaneCopyMax]; };
+__global__ void __launch_bounds__(256)
+k_lane_copy(LaneCopy c, int64_t len)
+{
+    const double *__restrict__ a = c.src[blockIdx.y]; double *__restrict__ b = c.dst[blockIdx.y];
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const int64_t n2 = len >> 1;
+    if ((((uintptr_t)a | (uintptr_t)b) & 15) == 0) {
+        for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n2; i += 256ll * gridDim.x)
+            reinterpret_cast<d2 *>(b)[i] = reinterpret_cast<const d2 *>(a)[i];
+        if ((len & 1) && blockIdx.x == 0 && threadIdx.x == 0) b[len - 1] = a[len - 1];
+    } else
+        for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < len; i += 256ll * gridDim.x) b[i] = a[i];
+}
+static void lane_copy(hipStream_t s, LaneCopy &c, int cnt, int64_t len)
+{
+    if (cnt <= 0) return;
+    const unsigned gx = (unsigned)std::min<int64_t>((len / 2 + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_lane_copy, dim3(std::max(gx, 1u), (unsigned)cnt), dim3(256), 0, s, c, len);
+}
 
 static int cv_batched_xtv(const mih_mat *h, XtvWork &xw, std::vector<CvFit *> &fits, DevBuf<double> &R, DevBuf<double> &DF,
                           hipStream_t s)
@@ -2062,9 +2141,11 @@ static int cv_batched_xtv(const mih_mat *h, XtvWork &xw, std::vector<CvFit *> &f
     for (CvFit *f : fits) if (!(xw.has_alt && f->fast43)) order.push_back(f);
     const int m54 = (int)order.size();
     for (CvFit *f : fits) if (xw.has_alt && f->fast43) order.push_back(f);
-    for (int t = 0; t < m; ++t) {
-        MIH_TRY(fit_to_lane(*order[(size_t)t], s));                 // its residual is ready
-        MIH_HIP(hipMemcpyAsync(R.p + (size_t)t * h->n, order[(size_t)t]->v->r.p, sizeof(double) * h->n, hipMemcpyDeviceToDevice, s));
+    for (int t = 0; t < m; ++t) MIH_TRY(fit_to_lane(*order[(size_t)t], s));                 // its residual is ready
+    for (int t0 = 0; t0 < m; t0 += kLaneCopyMax) {
+        LaneCopy c; const int cnt = std::min(m - t0, kLaneCopyMax);
+        for (int t = 0; t < cnt; ++t) { c.src[t] = order[(size_t)(t0 + t)]->v->r.p; c.dst[t] = R.p + (size_t)(t0 + t) * h->n; }
+        lane_copy(s, c, cnt, h->n);
     }
     if (m54) MIH_TRY(xtv_device(h, xw, R.p, m54, DF.p, s));
     if (m > m54) {
@@ -2074,8 +2155,12 @@ static int cv_batched_xtv(const mih_mat *h, XtvWork &xw, std::vector<CvFit *> &f
         MIH_TRY(rc);
         h->prof->count(MIH_CNT_RESIDUALS_43BIT, m - m54);
     }
-    for (int t = 0; t < m; ++t)
-        MIH_HIP(hipMemcpyAsync(order[(size_t)t]->v->df.p, DF.p + (size_t)t * h->p, sizeof(double) * h->p, hipMemcpyDeviceToDevice, s));
+    for (int t0 = 0; t0 < m; t0 += kLaneCopyMax) {
+        LaneCopy c; const int cnt = std::min(m - t0, kLaneCopyMax);
+        for (int t = 0; t < cnt; ++t) { c.src[t] = DF.p + (size_t)(t0 + t) * h->p; c.dst[t] = order[(size_t)(t0 + t)]->v->df.p; }
+        lane_copy(s, c, cnt, h->p);
+    }
+    MIH_HIP(hipGetLastError());
     return MIH_OK;
 }
 
@@ -2230,6 +2315,92 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
     hipEvent_t lane_ev = nullptr;         // "the lane's stream has got this far": the fits' streams wait for it behind the pass
     MIH_HIP(hipEventCreateWithFlags(&lane_ev, hipEventDisableTiming));
     struct EvGuard { hipEvent_t e; ~EvGuard() { (void)hipEventDestroy(e); } } ev_guard{lane_ev};
+    // ---- the lane's batched chain (round 6): the records its kernels read, and the two halves of a round's step --------------------
+    // Which way a lane's resident fits step (tools/ab_cv_lanes.sh, tools/ab_cv_share.sh; configs[3], same box):
+    //   one chain per fit on the fit's own stream (lane_queue_step)   2.43-2.46 s for the 100 fits, 0.42-0.44 s for a rank's 13   <- the library
+    //   ONE batched chain per lane round (launch_series, k_lane_*)    2.58-2.63 s, 0.43-0.45 s     (measurement build: MENDELIHT_LANE_BATCHED=1)
+    //   host-driven steps (step_mode 1, rounds 1-5)                   2.42-2.49 s, 0.42-0.46 s
+    // The small kernels of a round can only run in the window between two fused passes (a pass's workgroups hold every CU), so what
+    // counts is their GPU time, not the host's waits: the batched chain needs 30 launches per round instead of ~250, but its two
+    // wide products (k_lane_xb, k_lane_xgk: 0.75 and 0.83 ms for 19 fits, 0.7 TB/s) and the attempt slots it queues for every fit
+    // whether it backtracks or not cost more than the launches saved.  Kept, bit for bit with the others, as the base for that work.
+    static const bool per_fit_chains = probe_env("MENDELIHT_LANE_BATCHED") == nullptr;
+    PinBuf<LaneFit> largs_h; DevBuf<LaneFit> largs_d;
+    { ArenaScope own_buffers(nullptr); MIH_TRY(largs_h.alloc((size_t)cap * 2, true)); MIH_TRY(largs_d.alloc((size_t)cap * 2)); }
+    struct DrainFirst { hipStream_t s; ~DrainFirst() { (void)hipStreamSynchronize(s); } } drain_first{s};      // (an error return: no kernel may still read the records above)
+    int largs_slot = 0;
+    std::vector<CvFit *> in_flight;                          // fits with a series of the batched chain queued and its record not read yet
+    // one series for `fits` on the lane's stream: (step_start) Z'r, df on the support, X_S df_S, the step size; then ONE attempt
+    auto launch_series = [&](std::vector<CvFit *> &fits, bool step_start) -> int {
+        const int F = (int)fits.size();
+        if (F == 0) return MIH_OK;
+        LaneFit *hp = largs_h.p + (size_t)largs_slot * cap; LaneFit *dp = largs_d.p + (size_t)largs_slot * cap;
+        largs_slot ^= 1;
+        const IhtVar &v0 = *fits[0]->v;
+        int64_t kc = 0; bool any_score = false;
+        for (int t = 0; t < F; ++t) {
+            IhtVar &v = *fits[(size_t)t]->v;
+            v.lane_seq = ++v.res_seq;
+            const bool new_score = step_start && !fits[(size_t)t]->fresh_begin;
+            v.lane_fill(hp[t], v.lane_seq, step_start, new_score);
+            any_score = any_score || new_score;
+            kc = std::max(kc, v.res_kcap);
+            fits[(size_t)t]->in_batch = true; fits[(size_t)t]->have_rec = false;
+        }
+        MIH_HIP(hipMemcpyAsync(dp, hp, sizeof(LaneFit) * (size_t)F, hipMemcpyHostToDevice, s));
+        const bool fix = v0.res_fix();
+        const unsigned wide = v0.res_wide_blocks(), nbk = (unsigned)v0.nb;
+        if (step_start) {
+            if (any_score) {
+                hipLaunchKernelGGL(k_lane_zt_r, dim3(kZtrBlocks, (unsigned)v0.q, (unsigned)F), dim3(256), 0, s, dp);
+                hipLaunchKernelGGL(k_lane_support, dim3((unsigned)nblk(kc), (unsigned)F), dim3(256), 0, s, dp);
+            }
+            if (!fix) hipLaunchKernelGGL(k_lane_xgk<false>, dim3(wide, (unsigned)F), dim3(kResWideRows), kResWideLds, s, dp);
+            else {
+                hipLaunchKernelGGL(k_lane_xgk<true>, dim3(wide, (unsigned)F), dim3(kResWideRows), kResWideLds, s, dp);
+                hipLaunchKernelGGL(k_lane_missing, dim3(1, (unsigned)F), dim3(1024), 0, s, dp, -1, 0);
+                hipLaunchKernelGGL(k_lane_stepsize, dim3(nbk, (unsigned)F), dim3(256), 0, s, dp);
+            }
+            hipLaunchKernelGGL(k_lane_eta, dim3(1, (unsigned)F), dim3(256), 0, s, dp);
+        }
+        // attempt slots: each serves whichever attempt a fit is due (its control block counts); a fit whose step has stood finds its
+        // gate closed in the slots behind.  The logistic fits of configs[3] backtrack about once per step, and a slot that turns out
+        // empty for every fit costs six launches that exit at once -- less than the round trip a series cut short would cost all
+        // of its fits: 1 + max_step slots, so a series always ends every step it began (attempt max_step stands: utilities.jl:484)
+        const int slots = 1 + std::max(0, pr.max_step);
+        for (int j = 0; j < slots; ++j) {
+            hipLaunchKernelGGL(k_lane_grad, dim3(kResGradBlocks, (unsigned)F), dim3(256), 0, s, dp);
+            hipLaunchKernelGGL(k_lane_hist2, dim3(kResHistBlocks, (unsigned)F), dim3(256), 0, s, dp);
+            hipLaunchKernelGGL(k_lane_collect, dim3(kResCollectBlocks, (unsigned)F), dim3(256), 0, s, dp);
+            hipLaunchKernelGGL(k_lane_select, dim3(1, (unsigned)F), dim3(1024), 0, s, dp);
+            if (!fix) hipLaunchKernelGGL(k_lane_xb<false>, dim3(wide, (unsigned)F), dim3(kResWideRows), kResWideLds, s, dp);
+            else {
+                hipLaunchKernelGGL(k_lane_xb<true>, dim3(wide, (unsigned)F), dim3(kResWideRows), kResWideLds, s, dp);
+                hipLaunchKernelGGL(k_lane_missing, dim3(1, (unsigned)F), dim3(1024), 0, s, dp, 0, 1);
+                hipLaunchKernelGGL(k_lane_mu, dim3(nbk, (unsigned)F), dim3(256), 0, s, dp);
+            }
+            hipLaunchKernelGGL(k_lane_decide, dim3(1, (unsigned)F), dim3(256), 0, s, dp, j + 1 < slots ? 1 : 0);
+        }
+        MIH_HIP(hipGetLastError());
+        return MIH_OK;
+    };
+    // the records of the series in flight; a fit whose step is still backtracking rides another series (its attempt counter says which
+    // attempt is due), until every fit's step has stood, stopped or been handed back
+    auto collect_series = [&]() -> int {
+        std::vector<CvFit *> again;
+        while (!in_flight.empty()) {
+            again.clear();
+            for (CvFit *f : in_flight) {
+                MIH_TRY(f->v->res_wait(f->v->lane_seq, &f->rec, s));
+                if (f->rec.status == RES_PENDING) { f->v->h->prof->count(MIH_CNT_RESIDENT_ATTEMPTS, 1); again.push_back(f); }
+                else { f->have_rec = true; f->in_batch = false; }
+            }
+            for (CvFit *f : again) f->fresh_begin = false;
+            MIH_TRY(launch_series(again, false));
+            in_flight = again;
+        }
+        return MIH_OK;
+    };
     struct SlotOut { CvFit *f = nullptr; char fresh = 0; };
     std::vector<SlotOut> outs((size_t)cap);
     std::vector<std::function<int()>> tasks;
@@ -2296,6 +2467,11 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
             }
             // (round 6) a resident fit: the step's chain was queued behind the last pass (slot_post); its record is read here
             bool stepped = false, dev_stop = false; double dev_tol = 0.0;
+            if (f.have_rec) {                                   // (the lane's batched chain: collect_series has read this fit's record)
+                bool again = false;
+                f.have_rec = false;
+                MIH_TRY(f.v->lane_take_record(f.rec, &f.next_logl, &f.best, &f.nbt, &dev_tol, &stepped, &again));
+            } else
             MIH_TRY(f.v->lane_collect_step(&pr, &f.next_logl, &f.best, &f.nbt, &dev_tol, &stepped, &dev_stop));
             if (!stepped) {
                 f.best = f.v->save_prev(f.next_logl, f.best);
@@ -2330,12 +2506,21 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
             if (!f->v->res_active) MIH_TRY(f->v->step_post(f->next_logl));      // (debias! and the convergence test of this step ran before the pass: slot_pre)
             f->iter++;
         }
-        // the next step's chain goes out now, behind the pass, without a wait (a fit that does not qualify steps host-driven in slot_pre)
-        if (f->iter < pr.max_iter) MIH_TRY(f->v->lane_queue_step(f->next_logl, f->best, f->iter - 1, &pr));
+        // the next step goes out now, behind the pass, without a wait (a fit that does not qualify steps host-driven in slot_pre):
+        // as one of the lane's batched series (launch_series, behind these tasks), or as a chain of its own on its stream
+        f->wants_step = false; f->fresh_begin = false;
+        if (f->iter >= pr.max_iter || !f->v->res_ok) return MIH_OK;
+        if (per_fit_chains) return f->v->lane_queue_step(f->next_logl, f->best, f->iter - 1, &pr);
+        if (!f->v->res_active) {
+            if (f->v->res_begin(f->next_logl, f->best, f->iter - 1, 1, &pr) != MIH_OK) { f->v->res_ok = false; return MIH_OK; }
+            f->fresh_begin = true;
+        }
+        f->wants_step = true;
         return MIH_OK;
     };
     for (;;) {
         h->prof->count(MIH_CNT_ROUNDS, 1);
+        MIH_TRY(collect_series());                       // (every fit of this lane is quiescent again: what the hand-over below relies on)
         if (trace_rounds) {
             const double t = tnow();
             fprintf(stderr, "lane %d round %d: %.2f ms (before the pass %.2f ms, behind it %.2f ms of host time), %zu scores\n", lane_id, round_no++,
@@ -2420,6 +2605,16 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
         tasks.clear();
         for (size_t t = 0; t < need.size(); ++t) { CvFit *f = need[t]; const char fr = fresh[t]; tasks.emplace_back([&slot_post, f, fr]() { return slot_post(f, fr); }); }
         MIH_TRY(sched.run(tasks));
+        {
+            std::vector<CvFit *> wants;
+            for (CvFit *f : need) if (f->wants_step) {
+                f->wants_step = false;
+                if (f->fresh_begin) MIH_TRY(fit_to_lane(*f, s));          // (res_begin's uploads went through the fit's own stream)
+                wants.push_back(f);
+            }
+            MIH_TRY(launch_series(wants, true));
+            for (CvFit *f : wants) { f->fresh_begin = false; in_flight.push_back(f); }
+        }
         t_post = tnow() - t_b;
     }
     return MIH_OK;
@@ -2446,6 +2641,10 @@ static int cv_run_lanes(const mih_mat *h, const mih_fit_params &pr, size_t total
     inflight[0].store(0); inflight[1].store(0);
     const bool merge_tail = lanes == 2 && !chains && !probe_env("MENDELIHT_CV_NO_MERGE");     // (a chain stays with its lane)
     std::vector<DevBuf<double>> yds((size_t)lanes), zds((size_t)lanes);
+    PassOrder pass_order;                                      // the lanes' fused passes in single file (common.h)
+    // (measured: neutral at configs[3] -- 2.74 s either way with per-fit chains, tools/ab_cv_lanes.sh -- so off unless asked for:
+    // MENDELIHT_CV_PASS_ORDER=1, measurement build)
+    const bool ordered = lanes > 1 && probe_env("MENDELIHT_CV_PASS_ORDER") != nullptr;
     auto lane = [&](int lane_id) -> int {
         PoolScope from_reserve(h->pool);                        // workspaces and IHTVariables out of the matrix's reserve (no hipMalloc)
         MIH_HIP(hipSetDevice(h->device));
@@ -2458,6 +2657,11 @@ static int cv_run_lanes(const mih_mat *h, const mih_fit_params &pr, size_t total
         struct DrainOnExit { hipStream_t s; ~DrainOnExit() { (void)hipStreamSynchronize(s); } } drain{s};
         MIH_TRY(xtv_work_init(h, xw, cap, tune));
         xw.stream_tag = lane_id + 1;
+        hipEvent_t pass_done = nullptr;
+        if (ordered) MIH_HIP(hipEventCreateWithFlags(&pass_done, hipEventDisableTiming));
+        // (declared behind `drain`: destroyed first -- after this lane's last pass was queued, and an event another stream still waits on may be destroyed)
+        struct PassEv { hipEvent_t e; PassOrder *o; ~PassEv() { if (e) { std::lock_guard<std::mutex> g(o->mu); if (o->last == e) o->last = nullptr; (void)hipEventSynchronize(e); (void)hipEventDestroy(e); } } } pass_ev{pass_done, &pass_order};
+        if (ordered) { xw.order = &pass_order; xw.pass_done = pass_done; }
         h->prof->count(MIH_CNT_LANES, 1);
         MIH_TRY(R.alloc((size_t)cap * h->n));
         const int init_slots = std::min(init_keys, 8);          // shared initial scores (cv_run_rolling): 8 MB each at p = 1M

@@ -344,8 +344,19 @@ hipStream_t worker_stream(const mih_mat *h, int i)
     if (i < 0 || i >= 2 * kWorkerStreamsPerLane) return nullptr;
     if ((int)h->worker_streams.size() <= i) h->worker_streams.resize((size_t)i + 1, nullptr);
     if (!h->worker_streams[(size_t)i]) {
+        // (round 6, measured and NOT adopted) the greatest stream priority for the per-fit chains of the lock-step lanes: no gain -- a
+        // fused pass's workgroups hold every CU until the kernel's last wave of workgroups, whatever the priority of another queue, so
+        // the chains run in the windows between two passes either way -- and 0.1 s of 2.4 LOST at configs[3]: with priority the chains
+        // of lane A finish before lane B's pass has drained, both lanes queue their passes together, the passes share the CUs and
+        // end together, and every round then ends with BOTH lanes' chains in one window (tools/ab_cv_lanes.sh).  Measurement build:
+        // MENDELIHT_WORKER_PRIORITY=1 switches it on.
         hipStream_t st = nullptr;
-        if (hipStreamCreate(&st) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        int least = 0, greatest = 0;
+        const bool prio = probe_env("MENDELIHT_WORKER_PRIORITY") != nullptr && atoi(probe_env("MENDELIHT_WORKER_PRIORITY")) != 0;
+        if (prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least) {
+            if (hipStreamCreateWithPriority(&st, hipStreamDefault, greatest) != hipSuccess) { (void)hipGetLastError(); st = nullptr; }
+        } else (void)hipGetLastError();
+        if (!st && hipStreamCreate(&st) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         h->worker_streams[(size_t)i] = st;
     }
     return h->worker_streams[(size_t)i];

@@ -1582,6 +1582,24 @@ int xtv_work_init(const mih_mat *h, XtvWork &w, int m, const XtvTune &tune, bool
     return MIH_OK;
 }
 
+// a lane's pass takes its turn behind the pass queued last on this matrix's lanes (PassOrder, common.h)
+struct PassTurn {
+    XtvWork &w; hipStream_t s; bool held = false;
+    PassTurn(XtvWork &ww, hipStream_t ss) : w(ww), s(ss)
+    {
+        if (!w.order || !w.pass_done) return;
+        w.order->mu.lock(); held = true;
+        if (w.order->last && w.order->last != w.pass_done) (void)hipStreamWaitEvent(s, w.order->last, 0);
+    }
+    ~PassTurn()
+    {
+        if (!held) return;
+        (void)hipEventRecord(w.pass_done, s);
+        w.order->last = w.pass_done;
+        w.order->mu.unlock();
+    }
+};
+
 // measurement hook: how often the outlier guard (peel.h) of this workspace's residual slots has fired since the last call
 // (MIH_CNT_PEELED_RESIDUALS); synchronises the stream
 void xtv_count_peels(const mih_mat *h, XtvWork &w, hipStream_t s)
@@ -1678,8 +1696,12 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
         const bool prof = prof_begin(h, s, rec);
         const bool half = tn.half && (u1 - u0) * dm.slots - 32 * (nr - 1) <= 16;      // the last operand's second fragment holds no column
         char name[48] = {0};
-        int rc = dispatch_xtv(tn, nr, half, h, dig_all + (int64_t)t * nblk * 64, dig2_all + (int64_t)t * nblk * 64, nblk * 64, splits, dq,
+        int rc;
+        {
+            PassTurn turn(w, s);
+            rc = dispatch_xtv(tn, nr, half, h, dig_all + (int64_t)t * nblk * 64, dig2_all + (int64_t)t * nblk * 64, nblk * 64, splits, dq,
                               w.scal.p + 4 * u0, partial, s, name);
+        }
         if (prof) {
             rec.residuals = u1 - u0; rec.operands = nr; rec.stream_tag = w.stream_tag;
             memcpy(rec.kernel, name, sizeof(rec.kernel));
@@ -1709,7 +1731,11 @@ int xtv_device(const mih_mat *h, XtvWork &w, const double *r_dev, int m, double 
         // residuals in the pass's last operand; if they end within its first 16 columns the second fragment is left out
         const bool half = dm.lay16 && tn.half && (u1 - (t + nr - 1) * per_op) * dm.slots <= 16;
         char name[48] = {0};
-        int rc = dispatch_xtv(tn, nr, half, h, dig, dig2, nblk * 64, splits, dm, w.scal.p + 4 * u0, partial, s, name);
+        int rc;
+        {
+            PassTurn turn(w, s);
+            rc = dispatch_xtv(tn, nr, half, h, dig, dig2, nblk * 64, splits, dm, w.scal.p + 4 * u0, partial, s, name);
+        }
         if (prof) {
             rec.residuals = u1 - u0; rec.operands = nr; rec.stream_tag = w.stream_tag;
             memcpy(rec.kernel, name, sizeof(rec.kernel));

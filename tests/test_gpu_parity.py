@@ -2823,13 +2823,17 @@ def test_polled_readbacks_and_shared_initial_scores_change_nothing(mih, tmp_path
     cross-validation / model-path drivers with every fit riding its own initial score and without the tail hand-over
     (MENDELIHT_CV_NO_INIT_SHARE=1, MENDELIHT_CV_NO_MERGE=1), with one lock-step lane instead of two, and with every buffer
     of an IHTVariable as its own allocation instead of a carve-out of one block (MENDELIHT_NO_ARENA=1), and with the fits of a
-    lane walked one after the other on the lane's stream instead of as coroutines on streams of their own (MENDELIHT_CV_NO_COOP=1).
+    lane walked one after the other on the lane's stream instead of as coroutines on streams of their own (MENDELIHT_CV_NO_COOP=1);
+    (round 6) the lanes' resident fits stepping through ONE batched chain per lane round instead of a chain per fit
+    (MENDELIHT_LANE_BATCHED=1: the k_lane_* kernels), the lanes' passes in single file on priority streams.
     Univariate Normal and logistic fits, a cross-validation, a model path and a multivariate fit."""
     res = []
     # the first run is the PRODUCT library (which reads none of the switches), the others the measurement build of the same
     # sources: the product's bits are also those of the measurement build's defaults
     for i, extra in enumerate((None, {}, {"MENDELIHT_NO_SPIN": "1"}, {"MENDELIHT_CV_NO_INIT_SHARE": "1", "MENDELIHT_CV_NO_MERGE": "1"},
-                               {"MENDELIHT_CV_LANES": "1"}, {"MENDELIHT_NO_ARENA": "1"}, {"MENDELIHT_CV_NO_COOP": "1"})):
+                               {"MENDELIHT_CV_LANES": "1"}, {"MENDELIHT_NO_ARENA": "1"}, {"MENDELIHT_CV_NO_COOP": "1"},
+                               {"MENDELIHT_LANE_BATCHED": "1"}, {"MENDELIHT_CV_PASS_ORDER": "1", "MENDELIHT_WORKER_PRIORITY": "1"},
+                               {"MENDELIHT_LANE_BATCHED": "1", "MENDELIHT_CV_NO_COOP": "1"})):
         res.append(_run_probe_snippet(_NOSPIN_SNIPPET, tmp_path / f"variant_{i}.npz", extra_env=extra or {}, probes=extra is not None))
     assert len(res[0].files) == 12
     for other in res[1:]:
