@@ -479,6 +479,7 @@ struct TopkWork {
     DevBuf<uint64_t> state;    // [0]=prefix, [1]=remaining k, [2]=threshold bits, [3]=count_ge
     PinBuf<uint64_t> hsel;     // pinned landing buffer for the count + the first `expect` pairs
     DevBuf<uint64_t> sel;      // compacted survivors as (index, value bits) pairs; pair 0 holds the count
+    DevBuf<uint64_t> fin;      // k_topk_finish: count, threshold key, the survivors ordered by index
     int64_t cap = 0;           // pairs the buffer can hold after the header
     int64_t expect = 0;        // survivors expected by the caller (k + slack): fetched with the count in ONE copy
     bool radix8 = false;       // MENDELIHT_TOPK_RADIX8=1: always the 8 x 8-bit select (the two-pass select's fallback)

@@ -547,7 +547,7 @@ struct IhtVar {
             size_t dev = sizeof(double) * ((size_t)n * (7 + q) + 2 * (size_t)p + q + 8) + (size_t)n
                          + sizeof(double) * ((size_t)nb * 4 + kMaxQ + 8 + (size_t)kMaxQ * kZtrBlocks) + sizeof(unsigned) * kMaxQ
                          + 3 * sizeof(double) * (size_t)kcap + xv_work_bytes(h, kcap, kcap - 1024)
-                         + sizeof(uint32_t) * 2048 + 64 + 16 * ((size_t)kcap + 1025)
+                         + sizeof(uint32_t) * 2048 + 64 + 16 * ((size_t)kcap + 1025) + 16 * (4096 + 1) + 256
                          + (prm->weight ? sizeof(double) * (size_t)p : 0) + (prm->group ? sizeof(int64_t) * ((size_t)p + ks.size() + 1) : 0)
                          + 48 * 256
                          + sizeof(ResCtl) + (size_t)kcap * (3 * 16 + 4 * 4) + 4096 * sizeof(uint32_t) + 8 * 256       // resident steps

@@ -432,7 +432,7 @@ struct MvVar {
             const size_t redn = std::max<size_t>((size_t)nb, (size_t)kMaxR * kMaxR * kRedBlocks);
             size_t dev = sizeof(double) * (5 * rn + 8 + (size_t)q * n + 2 * (size_t)n + (size_t)r * p + (size_t)r * (p + q) + redn + (size_t)kMaxR * kMaxR + 64
                                            + 2 * (size_t)kcap + (size_t)kcap * r) + (size_t)n + sizeof(int32_t) * 2 * (size_t)kMaxR * kMaxR
-                         + xv_work_bytes(h, kcap, kcap - 1024) + sizeof(uint32_t) * 2048 + 64 + 16 * ((size_t)kcap + 1025) + 40 * 256;
+                         + xv_work_bytes(h, kcap, kcap - 1024) + sizeof(uint32_t) * 2048 + 64 + 16 * ((size_t)kcap + 1025) + 16 * (4096 + 1) + 256 + 40 * 256;
             size_t pin = sizeof(uint64_t) * (2 + 2 * ((size_t)kcap + 64) + 16 + HostStage::kSlots * ((size_t)kcap * (r + 1) + 8)) + 6 * 256;
             MIH_TRY(arena.reserve(dev, pin));
         }

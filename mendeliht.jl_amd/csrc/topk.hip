@@ -208,6 +208,55 @@ k_zero_below(double *__restrict__ x, int64_t len, uint64_t thr)
     for (; i < len; i += stride) { const double v = x[i]; if (abs_key(v) < thr && v != 0.0) x[i] = 0.0; }
 }
 
+// (round 6) project_k!'s exact finish ON THE DEVICE (utilities.jl:553-559: |x_i| >= the K-th largest magnitude survives, ties kept):
+// one workgroup ranks the gathered candidates -- every entry at or above the threshold's 22-bit prefix, so the K largest of the
+// vector are among them -- by counting (an entry survives iff fewer than K candidates are strictly larger: any order of counting
+// gives the same set), orders the survivors by index and leaves `count, threshold key, (index, value bits) ...` for the way home.
+// Rounds 1-5 brought the candidates home and ran std::nth_element + std::sort on the host.  out[0] = ~0: more candidates than this
+// kernel ranks (massive ties): the host finishes as before.
+constexpr int kFinishCap = 4096;
+__global__ void __launch_bounds__(1024)
+k_topk_finish(const uint64_t *__restrict__ sel, uint32_t cap, uint64_t k, uint64_t *__restrict__ out)
+{
+    __shared__ uint64_t bits[kFinishCap]; __shared__ int64_t idx[kFinishCap]; __shared__ int32_t keep[kFinishCap];
+    __shared__ int ns; __shared__ unsigned long long kmin;
+    const int tid = threadIdx.x;
+    const uint64_t cnt64 = sel[0];
+    if (cnt64 > (uint64_t)kFinishCap || cnt64 > (uint64_t)cap) { if (tid == 0) { out[0] = ~0ull; out[1] = 0; } return; }
+    const int cnt = (int)cnt64;
+    if (tid == 0) { ns = 0; kmin = ~0ull; }
+    for (int e = tid; e < cnt; e += 1024) { idx[e] = (int64_t)sel[2 + 2 * e]; bits[e] = sel[3 + 2 * e]; }
+    __syncthreads();
+    const uint64_t M = 0x7FFFFFFFFFFFFFFFull;
+    for (int e = tid; e < cnt; e += 1024) {
+        const uint64_t ke = bits[e] & M;
+        uint64_t larger = 0;
+        for (int f = 0; f < cnt; ++f) larger += (bits[f] & M) > ke;
+        const bool sv = (uint64_t)cnt < k || larger < k;             // fewer than K non-zeros in all: everything gathered survives
+        keep[e] = sv ? 1 : 0;
+        if (sv) { atomicAdd(&ns, 1); if ((uint64_t)cnt >= k) atomicMin(&kmin, (unsigned long long)ke); }
+    }
+    __syncthreads();
+    for (int e = tid; e < cnt; e += 1024) {
+        if (!keep[e]) continue;
+        const int64_t je = idx[e];
+        int pos = 0;
+        for (int f = 0; f < cnt; ++f) pos += (keep[f] && idx[f] < je) ? 1 : 0;
+        out[2 + 2 * pos] = (uint64_t)je; out[3 + 2 * pos] = bits[e];
+    }
+    if (tid == 0) { out[0] = (uint64_t)ns; out[1] = (uint64_t)cnt >= k ? (uint64_t)kmin : 0ull; }
+}
+// x_i with |x_i| below the threshold k_topk_finish left -> 0
+__global__ void __launch_bounds__(256)
+k_zero_below_dev(double *__restrict__ x, int64_t len, const uint64_t *__restrict__ fin)
+{
+    if (fin[0] == ~0ull) return;
+    const uint64_t thr = fin[1];
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < len; i += stride) { const double v = x[i]; if (abs_key(v) < thr && v != 0.0) x[i] = 0.0; }
+}
+
 __global__ void __launch_bounds__(256)
 k_publish(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst_host, uint64_t words, long long pairs_first,
           uint64_t *__restrict__ flag_host, uint64_t seq)
@@ -321,6 +370,7 @@ int topk_work_init(TopkWork &w, int64_t max_keep)
     w.expect = max_keep + 64;
     w.cap = max_keep + 1024;
     MIH_TRY(w.sel.alloc(2 + 2 * (size_t)w.cap));
+    MIH_TRY(w.fin.alloc(2 + 2 * (size_t)kFinishCap));
     MIH_TRY(w.hsel.alloc(2 + 2 * (size_t)w.expect, true));
     MIH_TRY(w.flag.word.alloc(8, true)); w.flag.word.p[0] = 0; w.flag.seq = 0;
     return MIH_OK;
@@ -377,6 +427,33 @@ static int topk_two_pass(double *x_dev, int64_t len, int64_t k, TopkWork &w, hip
     hipLaunchKernelGGL(k_pick11, dim3(1), dim3(256), 0, s, w.hist.p, w.state.p, 1, (uint64_t)k, w.sel.p);
     hipLaunchKernelGGL(k_collect, dim3(grid), dim3(256), 0, s, x_dev, len, w.state.p, w.sel.p, (uint32_t)w.cap);
     const int64_t first = std::min<int64_t>(w.expect, w.cap);
+    // (round 6) the exact finish on the device: the survivors come home ranked and ordered (k_topk_finish); the host's own finish
+    // below stays for more candidates than that kernel ranks
+    static const bool host_finish = probe_env("MENDELIHT_TOPK_HOST_FINISH") != nullptr;        // (measurement build: rounds 1-5's finish)
+    if (!host_finish && w.fin.p) {
+        hipLaunchKernelGGL(k_topk_finish, dim3(1), dim3(1024), 0, s, w.sel.p, (uint32_t)w.cap, (uint64_t)k, w.fin.p);
+        if (zero_in_place) hipLaunchKernelGGL(k_zero_below_dev, dim3(grid), dim3(256), 0, s, x_dev, len, w.fin.p);
+        const int64_t fcap = std::min<int64_t>(first, kFinishCap);
+        MIH_TRY(readback_words(s, w.flag, w.fin.p, w.hsel.p, 2 + 2 * (size_t)fcap, fcap));
+        if (w.hsel.p[0] != ~0ull) {
+            const int64_t nsv = (int64_t)w.hsel.p[0];
+            std::vector<uint64_t> host(w.hsel.p, w.hsel.p + 2 + 2 * (size_t)std::min<int64_t>(nsv, fcap));
+            if (nsv > fcap) {          // more survivors than the landing buffer expected (ties): fetch the rest
+                host.resize(2 + 2 * (size_t)nsv);
+                MIH_HIP(hipMemcpy(host.data() + 2 + 2 * fcap, w.fin.p + 2 + 2 * fcap, sizeof(uint64_t) * 2 * (size_t)(nsv - fcap), hipMemcpyDeviceToHost));
+            }
+            idx_out.resize((size_t)nsv); val_out.resize((size_t)nsv);
+            for (int64_t t = 0; t < nsv; ++t) {
+                idx_out[(size_t)t] = (int64_t)host[2 + 2 * (size_t)t];
+                const uint64_t bits = host[3 + 2 * (size_t)t];
+                double v; std::memcpy(&v, &bits, sizeof(v));
+                val_out[(size_t)t] = v;
+            }
+            done = true;
+            return MIH_OK;
+        }
+        // (massive ties: the candidates themselves come home, as in rounds 1-5)
+    }
     MIH_TRY(readback_words(s, w.flag, w.sel.p, w.hsel.p, 2 + 2 * (size_t)first, first));
     const int64_t cnt = (int64_t)w.hsel.p[0];
     if (cnt > w.cap) return MIH_OK;                        // massive ties: the exact 8-bit select handles any count
