@@ -215,35 +215,58 @@ k_zero_below(double *__restrict__ x, int64_t len, uint64_t thr)
 // Rounds 1-5 brought the candidates home and ran std::nth_element + std::sort on the host.  out[0] = ~0: more candidates than this
 // kernel ranks (massive ties): the host finishes as before.
 constexpr int kFinishCap = 4096;
+constexpr int kFinishBin = 1024;            // candidates sharing the threshold's 22-bit prefix that it ranks among themselves
 __global__ void __launch_bounds__(1024)
-k_topk_finish(const uint64_t *__restrict__ sel, uint32_t cap, uint64_t k, uint64_t *__restrict__ out)
+k_topk_finish(const uint64_t *__restrict__ sel, uint32_t cap, uint64_t k, const uint64_t *__restrict__ state, uint64_t *__restrict__ out)
 {
     __shared__ uint64_t bits[kFinishCap]; __shared__ int64_t idx[kFinishCap]; __shared__ int32_t keep[kFinishCap];
-    __shared__ int ns; __shared__ unsigned long long kmin;
+    __shared__ uint64_t bkey[kFinishBin]; __shared__ int32_t bpos[kFinishBin];
+    __shared__ int ns, nbin; __shared__ unsigned long long kmin;
     const int tid = threadIdx.x;
     const uint64_t cnt64 = sel[0];
     if (cnt64 > (uint64_t)kFinishCap || cnt64 > (uint64_t)cap) { if (tid == 0) { out[0] = ~0ull; out[1] = 0; } return; }
     const int cnt = (int)cnt64;
-    if (tid == 0) { ns = 0; kmin = ~0ull; }
-    for (int e = tid; e < cnt; e += 1024) { idx[e] = (int64_t)sel[2 + 2 * e]; bits[e] = sel[3 + 2 * e]; }
+    // what the two histogram passes left (k_pick11): the threshold's 22-bit prefix and its rank among the entries that share it
+    const uint64_t pre = state[0], rem = state[1], M = 0x7FFFFFFFFFFFFFFFull;
+    if (tid == 0) { ns = 0; nbin = 0; kmin = ~0ull; }
     __syncthreads();
-    const uint64_t M = 0x7FFFFFFFFFFFFFFFull;
     for (int e = tid; e < cnt; e += 1024) {
-        const uint64_t ke = bits[e] & M;
+        const int64_t je = (int64_t)sel[2 + 2 * e]; const uint64_t be = sel[3 + 2 * e];
+        idx[e] = je; bits[e] = be;
+        const uint64_t top = (be & M) >> 41;
+        keep[e] = top > pre ? 1 : 0;                         // above the prefix: among the K largest for certain
+        if (top == pre) { const int q = atomicAdd(&nbin, 1); if (q < kFinishBin) { bkey[q] = be & M; bpos[q] = e; } }
+    }
+    __syncthreads();
+    const int nb = nbin;
+    if (nb > kFinishBin) { if (tid == 0) { out[0] = ~0ull; out[1] = 0; } return; }      // (uniform: massive ties, the host finishes)
+    // the sharers among themselves: an entry survives iff fewer than `rem` of them are strictly larger (ties at the threshold are
+    // kept); fewer than K non-zeros in all: everything gathered survives
+    for (int q = tid; q < nb; q += 1024) {
+        const uint64_t kq = bkey[q];
         uint64_t larger = 0;
-        for (int f = 0; f < cnt; ++f) larger += (bits[f] & M) > ke;
-        const bool sv = (uint64_t)cnt < k || larger < k;             // fewer than K non-zeros in all: everything gathered survives
-        keep[e] = sv ? 1 : 0;
-        if (sv) { atomicAdd(&ns, 1); if ((uint64_t)cnt >= k) atomicMin(&kmin, (unsigned long long)ke); }
+        for (int f = 0; f < nb; ++f) larger += bkey[f] > kq;
+        if ((uint64_t)cnt < k || larger < rem) keep[bpos[q]] = 1;
     }
     __syncthreads();
-    for (int e = tid; e < cnt; e += 1024) {
-        if (!keep[e]) continue;
-        const int64_t je = idx[e];
+    // order by index: T threads per candidate, each counting over its share of the list (a count: any order)
+    int T = 1;
+    while (T < 64 && 2 * T * cnt <= 1024) T *= 2;
+    const int share = (cnt + T - 1) / T;
+    for (int base = 0; base < cnt; base += 1024 / T) {
+        const int e = base + tid / T, part = tid % T;
+        const bool on = e < cnt && keep[e];
+        const int64_t je = on ? idx[e] : 0;
         int pos = 0;
-        for (int f = 0; f < cnt; ++f) pos += (keep[f] && idx[f] < je) ? 1 : 0;
-        out[2 + 2 * pos] = (uint64_t)je; out[3 + 2 * pos] = bits[e];
+        if (on) { const int f1 = (part + 1) * share < cnt ? (part + 1) * share : cnt; for (int f = part * share; f < f1; ++f) pos += (keep[f] && idx[f] < je) ? 1 : 0; }
+        for (int off = 1; off < T; off <<= 1) pos += __shfl_xor(pos, off, 64);
+        if (on && part == 0) {
+            out[2 + 2 * pos] = (uint64_t)je; out[3 + 2 * pos] = bits[e];
+            atomicAdd(&ns, 1);
+            if ((uint64_t)cnt >= k) atomicMin(&kmin, (unsigned long long)(bits[e] & M));
+        }
     }
+    __syncthreads();
     if (tid == 0) { out[0] = (uint64_t)ns; out[1] = (uint64_t)cnt >= k ? (uint64_t)kmin : 0ull; }
 }
 // x_i with |x_i| below the threshold k_topk_finish left -> 0
@@ -431,7 +454,7 @@ static int topk_two_pass(double *x_dev, int64_t len, int64_t k, TopkWork &w, hip
     // below stays for more candidates than that kernel ranks
     static const bool host_finish = probe_env("MENDELIHT_TOPK_HOST_FINISH") != nullptr;        // (measurement build: rounds 1-5's finish)
     if (!host_finish && w.fin.p) {
-        hipLaunchKernelGGL(k_topk_finish, dim3(1), dim3(1024), 0, s, w.sel.p, (uint32_t)w.cap, (uint64_t)k, w.fin.p);
+        hipLaunchKernelGGL(k_topk_finish, dim3(1), dim3(1024), 0, s, w.sel.p, (uint32_t)w.cap, (uint64_t)k, w.state.p, w.fin.p);
         if (zero_in_place) hipLaunchKernelGGL(k_zero_below_dev, dim3(grid), dim3(256), 0, s, x_dev, len, w.fin.p);
         const int64_t fcap = std::min<int64_t>(first, kFinishCap);
         MIH_TRY(readback_words(s, w.flag, w.fin.p, w.hsel.p, 2 + 2 * (size_t)fcap, fcap));

@@ -68,12 +68,17 @@ static uint32_t rnd() { rng_state = rng_state * 1664525u + 1013904223u; return r
 int main(int argc, char **argv)
 {
     const int iters = argc > 1 ? atoi(argv[1]) : 20000;
+    // (round 6) mfma_rate ITERS DATA SHAPE SECONDS: only that operand data and instruction shape, launched back to back for SECONDS
+    // (tools/energy_table.py samples the package power beside it)
+    const int only_data = argc > 2 ? atoi(argv[2]) : -1, only_shape = argc > 3 ? atoi(argv[3]) : -1;
+    const double seconds = argc > 4 ? atof(argv[4]) : 0.0;
     hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0));
     const int cus = pr.multiProcessorCount;
     uint32_t *opnd; float *sink; unsigned long long *stamps;
     CK(hipMalloc(&opnd, 6 * 8 * 64 * 4)); CK(hipMalloc(&sink, (size_t)cus * 512 * 4 * 4)); CK(hipMalloc(&stamps, (size_t)cus * 8 * 16 * 4));
     static const int E2M3U[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 26, 28, 30, 32};
     for (int data = 0; data < 3; ++data) {          // 0 zeros, 1 dosage-like A x random digits B, 2 dense random A x random digits
+        if (only_data >= 0 && data != only_data) continue;
         std::vector<uint32_t> h(6 * 8 * 64, 0u);
         if (data) {
             for (int q = 0; q < 4; ++q) for (int i = 0; i < 4; ++i) for (int l = 0; l < 64; ++l) {
@@ -99,11 +104,14 @@ int main(int argc, char **argv)
         (void)E2M3U;
         CK(hipMemcpy(opnd, h.data(), h.size() * 4, hipMemcpyHostToDevice));
         for (int shape = 0; shape < 6; ++shape) {   // (waves per SIMD, FP6?, 16x16x128?)
+            if (only_shape >= 0 && shape != only_shape) continue;
             const int wps = shape & 1 ? 2 : 1; const bool fp6 = shape < 2 || shape >= 4; const bool s16 = shape >= 4;
             const int threads = 256 * wps, blocks = cus;
             hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
             float best = 1e30f; double clk = 0;
-            for (int rep = 0; rep < 6; ++rep) {      // ~1 s of back-to-back launches: the clock settles under load
+            hipEvent_t w0, w1; CK(hipEventCreate(&w0)); CK(hipEventCreate(&w1)); CK(hipEventRecord(w0));
+            for (int rep = 0; rep < 6 || seconds > 0.0; ++rep) {      // ~1 s of back-to-back launches: the clock settles under load
+                if (seconds > 0.0 && rep >= 6) { CK(hipEventRecord(w1)); CK(hipEventSynchronize(w1)); float el; CK(hipEventElapsedTime(&el, w0, w1)); if (el > 1e3 * seconds) break; }
                 CK(hipEventRecord(e0));
                 if (s16) hipLaunchKernelGGL((k_rate16<16>), dim3(blocks), dim3(threads), 0, 0, opnd, 2 * iters, sink, stamps);   // same MACs per launch
                 else if (fp6) hipLaunchKernelGGL((k_rate<8, true>), dim3(blocks), dim3(threads), 0, 0, opnd, iters, sink, stamps);
