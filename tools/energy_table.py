@@ -36,6 +36,14 @@ def watch(cmd, ready=None, env=None, settle=2.0):
     return pw, ck, open("/tmp/energy_child.log").read()
 
 
+def active_mean(pw):
+    """package power while the kernel runs: the samples within 10 % of the largest (a sample that falls between two batches of
+    launches of the looping child reads several hundred watts less)"""
+    top = max(pw)
+    act = [v for v in pw if v >= 0.9 * top]
+    return sum(act) / len(act)
+
+
 idle = [sample()[0] for _ in range(5)]
 rows = []
 env = dict(os.environ, MENDELIHT_HIP_PROBES="1")
@@ -52,10 +60,10 @@ for m, dg in specs:
     cols = m * (8 if dg == 4908 else 10)
     ops = 1 if m == 1 and not dg else (cols + 31) // 32
     mfma = ops * (n_pad / 64) * (p / 32)
-    W = sum(pw) / len(pw)
+    W = active_mean(pw)
     rows.append({"workload": f"{'single-fit pass (428)' if m == 1 and not dg else 'fused pass'}, {m} residual(s), format {dg or ('428' if m == 1 else 4910)}",
-                 "residuals": m, "operands": ops, "ms_per_pass": ms_pass, "mean_W": round(W, 1), "min_W": min(pw), "max_W": max(pw), "samples": len(pw),
-                 "sclk_MHz": round(sum(ck) / max(len(ck), 1)), "J_per_pass": round(W * ms_pass * 1e-3, 2),
+                 "residuals": m, "operands": ops, "ms_per_pass": ms_pass, "active_W": round(W, 1), "all_samples_mean_W": round(sum(pw) / len(pw), 1), "min_W": min(pw), "max_W": max(pw), "samples": len(pw),
+                 "samples_W": pw, "sclk_MHz": round(sum(ck) / max(len(ck), 1)), "J_per_pass": round(W * ms_pass * 1e-3, 2),
                  "J_per_residual": round(W * ms_pass * 1e-3 / m, 3), "mfma_32x32x64_equivalents": mfma, "nJ_per_mfma": round(W * ms_pass * 1e-3 / mfma * 1e9, 2)})
     print(json.dumps(rows[-1]), flush=True)
 # the same instruction with its operands in registers
@@ -67,9 +75,9 @@ for shape, name in ((5, "FP4xFP6 16x16x128, 2 waves/SIMD"), (1, "FP4xFP6 32x32x6
     mt = re.search(r"([0-9.]+) ms\s+([0-9.e+]+) MFMA/s\s+in-kernel clock (\d+) MHz", txt)
     if not pw or not mt:
         rows.append({"workload": "mfma_rate " + name, "error": txt[-300:]}); continue
-    W = sum(pw) / len(pw)
+    W = active_mean(pw)
     rate = float(mt.group(2))
-    rows.append({"workload": "tools/mfma_rate (operands in registers, dosage-like x digits): " + name, "mean_W": round(W, 1), "samples": len(pw),
+    rows.append({"workload": "tools/mfma_rate (operands in registers, dosage-like x digits): " + name, "active_W": round(W, 1), "samples": len(pw), "samples_W": pw,
                  "mfma_per_s": rate, "in_kernel_clock_MHz": int(mt.group(3)), "sclk_MHz": round(sum(ck) / max(len(ck), 1)), "nJ_per_mfma": round(W / rate * 1e9, 2)})
     print(json.dumps(rows[-1]), flush=True)
 json.dump({"idle_W": idle, "rows": rows, "how": "rocm-smi --showpower / --showclocks sampled beside a looping child (first 2 s dropped)"}, open(out_file, "w"), indent=1)

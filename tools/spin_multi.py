@@ -11,5 +11,5 @@ m.probe_set(multi_variant=mv)
 print("ready", flush=True)
 t0 = time.time()
 while time.time() - t0 < secs:
-    ms, _ = x.bench_xtv_batched(nrhs, max_fused=4, iters=20, warmup=0, xtv_digits=digits) if nrhs > 1 or digits else x.bench_xtv(iters=20, warmup=0)
+    ms, _ = x.bench_xtv_batched(nrhs, max_fused=4, iters=100, warmup=0, xtv_digits=digits) if nrhs > 1 or digits else x.bench_xtv(iters=100, warmup=0)
     print(f"nrhs={nrhs} {ms:.2f} ms/pass", flush=True)
