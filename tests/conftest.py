@@ -116,6 +116,13 @@ def normal_data():
                 y2=np.loadtxt(os.path.join(FIX, "phenotypes.txt")))
 
 
+@pytest.fixture(scope="module")
+def normal_pair(mih, oracle, normal_data):
+    bed = mih.read_bed(normal_data["bed"], normal_data["n"])
+    x = mih.SnpLinAlg(bed, normal_data["n"], center=True, scale=True, impute=True)
+    return x, oracle.Mat.from_bed_columns(bed, normal_data["n"])
+
+
 def free_device_bytes():
     """Free HBM on the device, asked of the HIP runtime(s) this process already holds (the library's own first).  torch.cuda would do,
     but only if torch initialised ITS runtime before the library did: a test selected alone (-k) met 'No HIP GPUs are available'."""

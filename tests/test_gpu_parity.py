@@ -1,4 +1,7 @@
-"""Parity of the HIP path (through the C ABI) against the CPU oracle and the golden vectors.
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the golden vectors: fits, cross-validation, model paths,
+wrappers, error paths and the randomized sweeps (b, f1, f3).  The other rows: test_gpu_linalg.py (a1, a7, a8, f2),
+test_gpu_mv.py (a14), test_gpu_resident.py (a12: the device-resident step), test_gpu_fullsize.py (every BASELINE config at its own size),
+test_gpu_stress.py.
 
 Tolerances (BASELINE.json north_star): support indices bit-exact at fixed k; beta within 1e-5
 relative for Gaussian, 1e-4 for GLM links.  Kernel-level results are held to 1e-11.
@@ -9,242 +12,15 @@ import os
 import numpy as np
 import pytest
 
-from conftest import FIX, GOLD, ROOT, SweepTally, check_recorded_cv_curve, free_device_bytes, hash_folds, make_bed, perm_folds, tied_case
+from conftest import FIX, GOLD, ROOT, SweepTally, check_recorded_cv_curve, free_device_bytes, hash_folds, make_bed, perm_folds, seeded_draw, tied_case
+from gpu_helpers import _BT_TIE, _NUDGES, _config3_problem, _config4_problem, _dosages, _exact_xtv, _mv_problem, _run_probe_snippet, _same_fit, _sim, _unstable, rel
 
 pytestmark = pytest.mark.gpu
-
-
-def rel(a, b):
-    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / (np.max(np.abs(b)) + 1e-300))
-
-
-@pytest.fixture(scope="module")
-def normal_pair(mih, oracle, normal_data):
-    bed = mih.read_bed(normal_data["bed"], normal_data["n"])
-    x = mih.SnpLinAlg(bed, normal_data["n"], center=True, scale=True, impute=True)
-    return x, oracle.Mat.from_bed_columns(bed, normal_data["n"])
 
 
 def test_device_present_and_native_library_loaded(mih):
     assert mih.device_count() >= 1
     assert os.path.exists(mih.library_path())
-
-
-_ROUND1_SNIPPET = r"""
-import os, sys
-import numpy as np
-sys.path.insert(0, sys.argv[1])
-import mendeliht_amd as m
-assert m.using_probes()
-n = 1000
-x = m.SnpLinAlg(m.read_bed(os.path.join(sys.argv[1], "tests", "fixtures", "normal.bed"), n), n, center=True, scale=True, impute=True)
-r = np.random.default_rng(0).standard_normal(n)
-out = {"default": x.xtv(r), "base1316": x.xtv(r, xtv_digits=1316)}
-nv = 0
-while True:                                                  # round 1's per-wave-load shapes
-    try:
-        m.probe_set(variant=nv)
-    except m.MendelIHTError:
-        break
-    out[f"variant{nv}"] = x.xtv(r, xtv_digits=1316)
-    nv += 1
-m.probe_set(variant=-1)
-for mv in (9, 10, 11, 12, 13, 14):                           # the register-staged single-operand shapes
-    m.probe_set(multi_variant=mv)
-    out[f"multi{mv}"] = x.xtv(r, xtv_digits=1316)
-m.probe_set(multi_variant=0)
-R = np.asfortranarray(np.random.default_rng(1).standard_normal((n, 7)))
-out["R7_default"] = x.xtv(R)
-m.probe_set(multi_variant=6)                                 # round 1's register-staged FP6 kernels (32x32x64)
-out["R7_regstaged"] = x.xtv(R)
-m.probe_set(multi_variant=20)                                # the 32x32x64 LDS-DMA ring
-out["R7_ring32"] = x.xtv(R)
-m.probe_set(multi_variant=0)
-xs = m.SnpLinAlg.synthetic(500_000, 64, seed=2024)           # full row count (eight row slices)
-r1 = np.random.default_rng(5).standard_normal(500_000)
-out["big_default"] = xs.xtv(r1)
-nb = 0
-while True:
-    try:
-        m.probe_set(variant=nb)
-    except m.MendelIHTError:
-        break
-    out[f"big_variant{nb}"] = xs.xtv(r1)
-    nb += 1
-m.probe_set(variant=-1)
-np.savez(sys.argv[2], **out)
-"""
-
-
-def _run_probe_snippet(snippet, out_file, extra_env=None, probes=True, timeout=900):
-    """A python snippet in its own process, on the measurement build of the library (MENDELIHT_HIP_PROBES=1) or on the product."""
-    import subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items() if k != "MENDELIHT_HIP_PROBES"}
-    if probes:
-        env["MENDELIHT_HIP_PROBES"] = "1"
-    env.update(extra_env or {})
-    r = subprocess.run([sys.executable, "-c", snippet, root, str(out_file)], capture_output=True, text=True, timeout=timeout, env=env)
-    assert r.returncode == 0, r.stdout + r.stderr
-    return np.load(out_file)
-
-
-_TAIL_COLUMNS_SNIPPET = r"""
-import ctypes as C, os, sys
-import numpy as np
-sys.path.insert(0, sys.argv[1])
-import mendeliht_amd as m
-from mendeliht_amd import api
-assert m.using_probes()
-n, mcap = 1000, 19
-x = m.SnpLinAlg(m.read_bed(os.path.join(sys.argv[1], "tests", "fixtures", "normal.bed"), n), n, center=True, scale=True, impute=True)
-rng = np.random.default_rng(7)
-R = np.asfortranarray(rng.standard_normal((n, mcap)) * np.exp(rng.uniform(-3, 3, mcap)))      # a different scale per residual
-ms = np.array([19] + list(range(1, 19)) + [19], dtype=np.int32)       # a full pass first, then every shorter count, then full again
-out = np.zeros(int(ms.sum()) * x.p)
-api._check(api.lib().mih_probe_xtv_sequence(x._h, api._p(R), mcap, api._p(ms), ms.size, 0, api._p(out)))
-np.savez(sys.argv[2], R=R, ms=ms, out=out)
-"""
-
-
-def test_flat_packing_ignores_what_an_earlier_pass_left_in_the_tail_columns(mih, normal_pair, tmp_path):
-    """ With the flat digit packing k_digits writes only the columns of the call's m residuals; the unused tail columns
-    of the last operand keep the digits of an earlier call.  A lock-step lane does exactly that from round to round.  Here: 19
-    residuals, then 1 .. 18, then 19 again on ONE workspace (measurement build: mih_probe_xtv_sequence) -- every result must be
-    bit for bit what a FRESH workspace gives for the same residuals (mih_xtv_batched_fmt, product library, this process)."""
-    x, _ = normal_pair
-    got = _run_probe_snippet(_TAIL_COLUMNS_SNIPPET, tmp_path / "tail.npz")
-    R, ms, out = got["R"], got["ms"], got["out"]
-    fresh = {int(mm): x.xtv(np.asfortranarray(R[:, :mm])).reshape(x.p, -1, order="F") for mm in sorted(set(ms.tolist()))}
-    off = 0
-    for mm in ms.tolist():
-        blk = out[off:off + mm * x.p].reshape(x.p, mm, order="F")
-        assert np.array_equal(blk, fresh[mm]), mm
-        off += mm * x.p
-    assert np.array_equal(fresh[19][:, :7], fresh[7])              # and a residual's X'r does not depend on the company it rides with
-
-
-def test_mu_sinv_and_xtv_against_oracle(mih, normal_pair):
-    x, ox = normal_pair
-    assert not mih.using_probes()                                   # the tests run on the product library
-    mu, s = x.mu_sigma()
-    omu, os_ = ox.mu_sinv()
-    assert np.array_equal(mu, omu) and np.array_equal(s, os_)
-    r = np.random.default_rng(0).standard_normal(x.n)
-    ref = ox.xtv(r)
-    default = x.xtv(r)                                              # library default: FP6 digit planes through the LDS-DMA ring
-    assert rel(default, ref) < 1e-11
-    base = x.xtv(r, xtv_digits=1316)
-    assert rel(base, default) < 1e-13
-    assert np.array_equal(x.xtv(r), default)
-
-
-def test_product_kernels_equal_the_round1_kernel_families(mih, normal_pair, oracle, tmp_path):
-    """The product library has one kernel per (format family, operand count).  The measurement build (same sources,
-    -DMIH_PROBES) still carries round 1's kernel families -- per-wave digit loads, digit planes staged through registers -- and
-    the 32x32x64 ring: with the same row slicing they must give the product's bits, on the reference's shipped data and at the
-    full row count of the benchmark (against the oracle there)."""
-    x, ox = normal_pair
-    got = _run_probe_snippet(_ROUND1_SNIPPET, tmp_path / "round1.npz")
-    r = np.random.default_rng(0).standard_normal(x.n)
-    default, base = x.xtv(r), x.xtv(r, xtv_digits=1316)            # this process: the product library
-    assert np.array_equal(got["default"], default) and np.array_equal(got["base1316"], base)
-    nv = sum(1 for k in got.files if k.startswith("variant"))
-    assert nv >= 3
-    same_slices = (5, 6, 7)                                         # shapes with one row slice, like the default at n = 1000
-    for v in range(nv):
-        assert rel(got[f"variant{v}"], base) < 1e-13, v             # the slice partials are rounded f64 sums of exact digit sums
-        if v in same_slices:
-            assert np.array_equal(got[f"variant{v}"], base), v      # same slicing: every kernel shape agrees bit for bit
-    for mv in (9, 10, 11, 12, 13, 14):
-        assert np.array_equal(got[f"multi{mv}"], base), mv
-    R = np.asfortranarray(np.random.default_rng(1).standard_normal((x.n, 7)))
-    mine = x.xtv(R)
-    for k in ("R7_default", "R7_regstaged", "R7_ring32"):
-        assert np.array_equal(got[k], mine), k
-    xs = mih.SnpLinAlg.synthetic(500_000, 64, seed=2024)
-    r1 = np.random.default_rng(5).standard_normal(500_000)
-    oxs = oracle.Mat.from_bed_columns(xs.export_bed(), 500_000)
-    want = oxs.xtv(r1)
-    assert np.array_equal(got["big_default"], xs.xtv(r1))
-    nb = sum(1 for k in got.files if k.startswith("big_variant"))
-    assert nb >= 3
-    for v in range(nb):
-        assert rel(got[f"big_variant{v}"], want) < 1e-10, v
-
-
-@pytest.mark.parametrize("n,p,miss", [(1003, 257, 0.02), (77, 33, 0.1), (5000, 100, 0.0), (2049, 64, 0.05),
-                                      (16, 5, 0.0), (1, 3, 0.0), (4097, 9, 0.3)])
-@pytest.mark.parametrize("flags", [(1, 1, 1), (1, 1, 0), (0, 0, 1), (1, 0, 1)])
-def test_ragged_missing_flags(mih, oracle, n, p, miss, flags):
-    """n not divisible by 4/16/64/1024, missing genotypes, monomorphic columns, every flag combination."""
-    rng = np.random.default_rng(n * 31 + p)
-    cols = make_bed(rng, n, p, miss)
-    cols[0, :] = 0                                     # all-zero column: sinv = 1
-    c, s, i = flags
-    x = mih.SnpLinAlg(cols, n, center=c, scale=s, impute=i)
-    ox = oracle.Mat.from_bed_columns(cols, n, center=c, scale=s, impute=i)
-    mu, sv = x.mu_sigma()
-    omu, osv = ox.mu_sinv()
-    np.testing.assert_allclose(mu, omu, rtol=1e-15)
-    np.testing.assert_allclose(sv, osv, rtol=1e-15)
-    r = rng.standard_normal(n)
-    ref = ox.xtv(r)
-    # absolute error against the scale of the terms being summed (a column can sum to exactly 0)
-    assert np.max(np.abs(x.xtv(r) - ref)) < 1e-11 * max(np.max(np.abs(ref)), np.sum(np.abs(r)))
-    idx = np.sort(rng.choice(p, size=min(4, p), replace=False))
-    val = rng.standard_normal(idx.size)
-    mask = np.zeros(p, np.uint8)
-    mask[idx] = 1
-    coef = np.zeros(p)
-    coef[idx] = val
-    assert rel(x.xv_sparse(idx, val), ox.xv_masked(mask, coef)) < 1e-11
-    assert np.array_equal(x.export_bed(), cols)        # encode -> device layout -> decode round trip
-
-
-def test_xtv_batched_and_empty_support(mih, oracle, normal_pair):
-    x, ox = normal_pair
-    R = np.random.default_rng(1).standard_normal((x.n, 9))
-    assert rel(x.xtv(R[:, :3]), ox.xtv_multi(R[:, :3])) < 1e-11
-    singles = np.column_stack([x.xtv(R[:, v]) for v in range(9)])
-    for m_rhs in range(1, 10):          # every split into 4-/2-/1-RHS passes (3 left over ride a padded 4-pass)
-        assert np.array_equal(x.xtv(R[:, :m_rhs]), singles[:, :m_rhs]), m_rhs
-    assert np.all(x.xv_sparse(np.zeros(0, np.int64), np.zeros(0)) == 0.0)
-    with pytest.raises(mih.MendelIHTError):
-        x.xv_sparse(np.array([x.p]), np.array([1.0]))
-
-
-def test_synthetic_matrix_matches_oracle_after_export(mih, oracle):
-    for miss in (0.0, 0.03):
-        x = mih.SnpLinAlg.synthetic(3001, 130, seed=11, missing_rate=miss)
-        cols = x.export_bed()
-        ox = oracle.Mat.from_bed_columns(cols, 3001)
-        mu, _ = x.mu_sigma()
-        assert np.all((mu > 0) & (mu < 1.2))
-        r = np.random.default_rng(2).standard_normal(3001)
-        assert rel(x.xtv(r), ox.xtv(r)) < 1e-11
-        x2 = mih.SnpLinAlg.synthetic(3001, 40, seed=11, missing_rate=miss)   # same seed: same leading columns
-        assert np.array_equal(x2.export_bed(), cols[:40])
-
-
-def test_project_k_device(mih, oracle):
-    """project_k! (utilities.jl:553-559) incl. the reference's top-k property test (utilities_test.jl:166-176)."""
-    rng = np.random.default_rng(3)
-    x = rng.random(100000)
-    out = mih.project_k(x, 100)
-    assert np.array_equal(out, oracle.project_k(x, 100))
-    assert np.count_nonzero(out) == 100
-    v = rng.standard_normal(1000003)
-    for k in (1, 7, 200, 5000, v.size):
-        assert np.array_equal(mih.project_k(v, k), oracle.project_k(v, k)), k
-    t = np.array([1.0, -2.0, 2.0, 0.5, np.inf, -0.0])
-    assert np.array_equal(mih.project_k(t, 2), oracle.project_k(t, 2))     # tie at the threshold kept; Inf survives
-    assert list(mih.project_k(np.array([1.0, -2.0, 2.0, 0.5]), 1)) == [0.0, -2.0, 2.0, 0.0]
-    with pytest.raises(mih.MendelIHTError):
-        mih.project_k(t, -1)
-    with pytest.raises(mih.MendelIHTError):
-        mih.project_k(t, 0)
-
 
 def test_g1_golden_log_on_gpu(mih, normal_pair, normal_data):
     """The reference's recorded run (docs/src/man/examples.md:230-267) reproduced by the HIP path."""
@@ -262,7 +38,6 @@ def test_g1_golden_log_on_gpu(mih, normal_pair, normal_data):
     assert res.σg == pytest.approx(g["pve"], rel=1e-9)
     assert res.trace["lines"][0].startswith("Iteration 1: loglikelihood = -1403.60851544")
 
-
 @pytest.mark.parametrize("curve", ["docs_curve", "shipped_summary_curve"])
 def test_cv_curves_the_reference_recorded_on_gpu(mih, oracle, normal_pair, normal_data, curve):
     """cv_iht of the HIP path against the reference's OWN recorded curves (docs/src/man/examples.md:169-192 and
@@ -278,17 +53,6 @@ def test_cv_curves_the_reference_recorded_on_gpu(mih, oracle, normal_pair, norma
         check_recorded_cv_curve(mse, g)
         omse, _ = oracle.cv_iht(ox, y, normal_data["z"], path=g["path"], q=g["q"], folds=folds, zkeep=g["zkeep"])
         np.testing.assert_allclose(mse, omse, rtol=1e-8)
-
-
-def _sim(oracle, ox, rng, k, scale=0.5):
-    p = ox.p
-    b = np.zeros(p)
-    supp = rng.choice(p, k, replace=False)
-    b[supp] = rng.standard_normal(k) * scale
-    mask = np.zeros(p, np.uint8)
-    mask[supp] = 1
-    return ox.xv_masked(mask, b)
-
 
 @pytest.mark.parametrize("family", ["normal", "bernoulli", "poisson", "negbin"])
 def test_fit_iht_families_vs_oracle(mih, oracle, normal_pair, family):
@@ -318,7 +82,6 @@ def test_fit_iht_families_vs_oracle(mih, oracle, normal_pair, family):
     assert res.σg == pytest.approx(o["pve"], rel=1e-6)
     assert np.count_nonzero(res.beta) == 8 and res.c[0] != 0                        # L0_reg_test.jl:21-24
 
-
 def test_fit_iht_zkeep_weights_train_mask(mih, oracle):
     rng = np.random.default_rng(12)
     n, p = 700, 500
@@ -340,7 +103,6 @@ def test_fit_iht_zkeep_weights_train_mask(mih, oracle):
         np.testing.assert_allclose(res.beta, o["beta"], rtol=1e-5, atol=1e-12)
         np.testing.assert_allclose(res.c, o["c"], rtol=1e-5, atol=1e-12)
         assert res.logl == pytest.approx(o["logl"], rel=1e-9)
-
 
 def test_fit_iht_dense_matrix(mih, oracle):
     """The reference's Matrix{Float64} design matrix (test/L0_reg_test.jl dense cases)."""
@@ -365,7 +127,6 @@ def test_fit_iht_dense_matrix(mih, oracle):
     assert np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"]))
     np.testing.assert_allclose(res.beta, o["beta"], rtol=1e-4, atol=1e-12)
 
-
 def test_max_iter_semantics_and_errors(mih, normal_pair, normal_data):
     x, _ = normal_pair
     res = mih.fit_iht(normal_data["y"], x, normal_data["z"], k=7, max_iter=3, verbose=False)
@@ -378,7 +139,6 @@ def test_max_iter_semantics_and_errors(mih, normal_pair, normal_data):
     with pytest.raises(mih.MendelIHTError):
         mih.cv_iht(normal_data["y"], x, None, path=[x.p + 1], q=3, folds=hash_folds(x.n, 3), verbose=False)
 
-
 def test_session_steps_equal_fit_trace(mih, normal_pair, normal_data):
     x, _ = normal_pair
     res = mih.fit_iht(normal_data["y"], x, normal_data["z"], k=7, verbose=False)
@@ -387,7 +147,6 @@ def test_session_steps_equal_fit_trace(mih, normal_pair, normal_data):
         logl, bt, tol = s.step()
         assert logl == res.trace["logl"][i] and bt == res.trace["backtracks"][i] and tol == res.trace["tol"][i]
     s.close()
-
 
 @pytest.mark.parametrize("family", ["normal", "bernoulli"])
 def test_cv_iht_vs_oracle_and_sharding(mih, oracle, normal_pair, normal_data, family):
@@ -424,7 +183,6 @@ def test_cv_iht_vs_oracle_and_sharding(mih, oracle, normal_pair, normal_data, fa
              for r in range(2)]
     assert np.array_equal(parts[0] + parts[1], raw)
     assert np.count_nonzero(parts[0]) + np.count_nonzero(parts[1]) == raw.size
-
 
 def test_file_level_wrappers(mih, tmp_path, normal_data):
     """iht(...) / cross_validate(...) on a PLINK trio (src/wrapper.jl:52-120, 301-349): the reference's recorded run through the
@@ -494,58 +252,6 @@ def test_file_level_wrappers(mih, tmp_path, normal_data):
     np.testing.assert_allclose(np.loadtxt(tmp_path / "cov.txt"), rm.Σ)
     assert "Trait 2's SNP PVE:" in open(tmp_path / "ms.txt").read()
 
-
-def test_full_size_properties_n500k(mih, oracle):
-    """BASELINE configs[2] geometry (n = 500 000): properties that need no full-size oracle.
-    Column count is cut to 16 384 (2 GB of 2-bit data) so the test stays in seconds; the leading columns are
-    bit-identical to the p = 1M benchmark matrix (per-column RNG keys)."""
-    n, p = 500_000, 16_384
-    x = mih.SnpLinAlg.synthetic(n, p, seed=2024)
-    rng = np.random.default_rng(5)
-    r1, r2 = rng.standard_normal(n), rng.standard_normal(n)
-    a, b = 0.75, -1.5
-    o1, o2, o12 = x.xtv(r1), x.xtv(r2), x.xtv(a * r1 + b * r2)
-    assert rel(o12, a * o1 + b * o2) < 1e-10                       # linearity
-    assert np.array_equal(x.xtv(r1), o1)                           # run-to-run bit reproducibility
-    assert np.max(np.abs(x.xtv(np.ones(n)))) < 1e-6                # centred columns: X'1 = 0
-    xs = mih.SnpLinAlg.synthetic(n, 64, seed=2024)                 # oracle on a column sample
-    ox = oracle.Mat.from_bed_columns(xs.export_bed(), n)
-    assert rel(o1[:64], ox.xtv(r1)) < 1e-10
-    idx = np.sort(rng.choice(64, 9, replace=False))
-    val = rng.standard_normal(9)
-    mask = np.zeros(64, np.uint8)
-    mask[idx] = 1
-    coef = np.zeros(64)
-    coef[idx] = val
-    assert rel(x.xv_sparse(idx, val), ox.xv_masked(mask, coef)) < 1e-11
-
-
-def test_project_group_sparse_device(mih, oracle):
-    """project_group_sparse! (utilities.jl:613-679) incl. the reference's property tests (utilities_test.jl:180-213)."""
-    rng = np.random.default_rng(30)
-    m, n, k, J = 5, 50, 3, 2
-    y = rng.standard_normal(n)
-    group = np.repeat(np.arange(1, m + 1), n // m)
-    out = mih.project_group_sparse(y, group, J, k)
-    assert np.array_equal(out, oracle.project_group_sparse(y, group, J, k))
-    nzg = [np.count_nonzero(out[group == g]) for g in range(1, m + 1)]
-    assert sum(c > 0 for c in nzg) == J and all(c in (0, k) for c in nzg)
-    one = np.ones(n, dtype=np.int64)
-    assert np.array_equal(mih.project_group_sparse(y, one, 1, 7), mih.project_k(y, 7))   # J=1 group == project_k!
-    ks = np.array([1, 2, 3, 4, 5])
-    assert np.array_equal(mih.project_group_sparse(y, group, 5, ks), oracle.project_group_sparse(y, group, 5, ks))
-    # large, unordered labels, empty groups, ties
-    p = 200003
-    v = rng.standard_normal(p)
-    v[::7] = np.round(v[::7], 1)                     # many exact ties
-    g = rng.integers(1, 5000, size=p)
-    g[g == 17] = 18                                  # an empty group
-    for (JJ, kk) in [(10, 3), (4999, 1), (1, 50)]:
-        assert np.array_equal(mih.project_group_sparse(v, g, JJ, kk), oracle.project_group_sparse(v, g, JJ, kk)), (JJ, kk)
-    kv = rng.integers(0, 4, size=4999)
-    assert np.array_equal(mih.project_group_sparse(v, g, 300, kv), oracle.project_group_sparse(v, g, 300, kv))
-
-
 def test_fit_iht_group_projection(mih, oracle):
     """Group IHT (test/L0_reg_test.jl:176-242): scalar k per group and per-group k vector."""
     rng = np.random.default_rng(31)
@@ -574,7 +280,6 @@ def test_fit_iht_group_projection(mih, oracle):
     assert np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"]))
     np.testing.assert_allclose(res.beta, o["beta"], rtol=1e-5, atol=1e-12)
 
-
 @pytest.mark.parametrize("branch", ["rolling", "debias", "init_beta"])
 def test_cv_iht_with_groups_on_both_drivers(mih, oracle, branch):
     """cv_iht(group=...) sets v.k = sparsity per (fold, k) fit (cross_validation.jl:110) and project_group_sparse! reads that k
@@ -598,104 +303,6 @@ def test_cv_iht_with_groups_on_both_drivers(mih, oracle, branch):
     np.testing.assert_allclose(mse, omse, rtol=1e-6)
     assert len(set(np.round(mse, 9))) == len(path)          # the model size really changed from entry to entry
 
-
-def _mv_problem(oracle, ox, rng, r, k, q=1):
-    p, n = ox.p, ox.n
-    B = np.zeros((r, p))
-    for _ in range(k):
-        B[rng.integers(r), rng.integers(p)] = rng.standard_normal() * 0.6
-    XB = np.zeros((r, n))
-    for i in range(r):
-        mask = (B[i] != 0).astype(np.uint8)
-        XB[i] = ox.xv_masked(mask, B[i])
-    A = rng.standard_normal((r, r))
-    L = np.linalg.cholesky(A @ A.T / r + np.eye(r) * 0.5)
-    Z = np.vstack([np.ones(n)] + [rng.standard_normal(n) for _ in range(q - 1)])
-    Cm = rng.standard_normal((r, q))
-    Y = XB + Cm @ Z + L @ rng.standard_normal((r, n))
-    return Y, Z
-
-
-@pytest.mark.parametrize("r,k,q", [(2, 10, 1), (3, 12, 2), (5, 20, 1)])
-def test_multivariate_fit_vs_oracle(mih, oracle, normal_pair, r, k, q):
-    """fit_iht with MvNormal traits (src/multivariate.jl; test/multivariate_test.jl:84-118)."""
-    x, ox = normal_pair
-    rng = np.random.default_rng(40 + r)
-    Y, Z = _mv_problem(oracle, ox, rng, r, k, q)
-    zk = None if q == 1 else [1] + [0] * (q - 1)
-    res = mih.fit_iht(Y, x, Z, k=k, zkeep=zk, verbose=False)
-    o = oracle.fit_mv(ox, Y, Z, k=k, zkeep=zk)
-    assert res.iter == o["iter"] and res.iter >= 5
-    assert np.array_equal(res.beta != 0, o["B"] != 0)                         # bit-exact support
-    np.testing.assert_allclose(res.beta, o["B"], rtol=1e-5, atol=1e-12)
-    np.testing.assert_allclose(res.c, o["C"], rtol=1e-5, atol=1e-12)
-    np.testing.assert_allclose(res.Σ, o["Sigma"], rtol=1e-6)
-    np.testing.assert_allclose(res.σg, o["pve"], rtol=1e-6)
-    assert res.logl == pytest.approx(o["logl"], rel=1e-9)
-    assert list(res.trace["backtracks"]) == list(o["bt_trace"])
-    assert res.beta.shape == (r, x.p) and np.count_nonzero(res.beta) <= k and np.all(res.σg > 0)
-
-
-def test_multivariate_shipped_data_and_cv(mih, oracle):
-    """data/multivariate.* (true Sigma shipped) + cv_iht on multivariate traits (cv_iht_test.jl:259-284)."""
-    n = 1000
-    bed = mih.read_bed(os.path.join(FIX, "multivariate.bed"), n)
-    x = mih.SnpLinAlg(bed, n, center=True, scale=True, impute=True)
-    ox = oracle.Mat.from_bed_columns(bed, n)
-    Y = np.loadtxt(os.path.join(FIX, "multivariate.phen"), delimiter=",").T
-    S = np.loadtxt(os.path.join(FIX, "multivariate.trait.cov"), delimiter=",")
-    res = mih.fit_iht(Y, x, None, k=10, verbose=False)
-    o = oracle.fit_mv(ox, Y, None, k=10)
-    assert res.iter == o["iter"]
-    assert np.array_equal(res.beta != 0, o["B"] != 0)
-    np.testing.assert_allclose(res.beta, o["B"], rtol=1e-5, atol=1e-12)
-    np.testing.assert_allclose(res.Σ, S, atol=0.12)
-    with pytest.raises(mih.MendelIHTError):
-        mih.fit_iht(Y.T, x, None, k=10, verbose=False)                         # un-transposed input: DimensionMismatch
-    folds = hash_folds(n, 3)
-    mse, raw = mih.cv_iht(Y, x, None, path=[2, 6, 10, 14], q=3, folds=folds, verbose=False, return_raw=True)
-    omse, oraw = oracle.cv_mv(ox, Y, None, path=[2, 6, 10, 14], q=3, folds=folds)
-    np.testing.assert_allclose(raw, oraw, rtol=1e-4)
-    np.testing.assert_allclose(mse, omse, rtol=1e-4)
-    assert np.all(mse > 0)
-
-
-def test_multivariate_init_beta(mih, oracle, normal_pair):
-    """init_beta=true for MvNormal traits (initialize_beta!(::mIHTVariable), multivariate.jl:519-558; used by
-    test/multivariate.ipynb and test/NFBC-chr21.ipynb): shipped data, a covariate problem with a train mask, CV."""
-    n = 1000
-    bed = mih.read_bed(os.path.join(FIX, "multivariate.bed"), n)
-    x = mih.SnpLinAlg(bed, n, center=True, scale=True, impute=True)
-    ox = oracle.Mat.from_bed_columns(bed, n)
-    Y = np.loadtxt(os.path.join(FIX, "multivariate.phen"), delimiter=",").T
-    res = mih.fit_iht(Y, x, None, k=10, init_beta=True, verbose=False)
-    o = oracle.fit_mv(ox, Y, None, k=10, init_beta=True)
-    plain = oracle.fit_mv(ox, Y, None, k=10)
-    assert res.iter == o["iter"] and list(res.trace["backtracks"]) == list(o["bt_trace"])
-    assert np.array_equal(res.beta != 0, o["B"] != 0)
-    np.testing.assert_allclose(res.beta, o["B"], rtol=1e-5, atol=1e-12)
-    np.testing.assert_allclose(res.c, o["C"], rtol=1e-5)
-    np.testing.assert_allclose(res.trace["logl"], o["logl_trace"], rtol=1e-9)
-    assert o["logl"] != plain["logl"]                                          # the start really differs
-    # covariates (one of them not kept), missing genotypes in X, a train mask
-    x2, ox2 = normal_pair
-    rng = np.random.default_rng(77)
-    Y2, Z2 = _mv_problem(oracle, ox2, rng, 3, 9, 3)
-    train = (np.arange(x2.n) % 4 != 1).astype(np.uint8)
-    zk = [1, 1, 0]
-    r2 = mih.fit_iht(Y2, x2, Z2, k=9, zkeep=zk, init_beta=True, train=train, verbose=False)
-    o2 = oracle.fit_mv(ox2, Y2, Z2, k=9, zkeep=zk, init_beta=True, train=train)
-    assert r2.iter == o2["iter"]
-    assert np.array_equal(r2.beta != 0, o2["B"] != 0)
-    np.testing.assert_allclose(r2.beta, o2["B"], rtol=1e-5, atol=1e-12)
-    np.testing.assert_allclose(r2.c, o2["C"], rtol=1e-5, atol=1e-12)
-    assert r2.logl == pytest.approx(o2["logl"], rel=1e-9)
-    folds = hash_folds(n, 3)
-    mse = mih.cv_iht(Y, x, None, path=[3, 8], q=3, folds=folds, init_beta=True, verbose=False)
-    omse, _ = oracle.cv_mv(ox, Y, None, path=[3, 8], q=3, folds=folds, init_beta=True)
-    np.testing.assert_allclose(mse, omse, rtol=1e-4)
-
-
 @pytest.mark.parametrize("method", ["MM", "Newton"])
 def test_negbin_nuisance_estimation(mih, oracle, normal_pair, method):
     """est_r=:MM / :Newton (utilities.jl:141-247; test/L0_reg_test.jl:245-296)."""
@@ -714,7 +321,6 @@ def test_negbin_nuisance_estimation(mih, oracle, normal_pair, method):
     assert 1.0 < res.d.r < 50.0
     with pytest.raises(mih.MendelIHTError):
         mih.fit_iht(y, x, None, k=6, d=mih.Poisson(), l=mih.LogLink(), est_r="MM", verbose=False)   # fit.jl:93-94
-
 
 @pytest.mark.parametrize("method", ["MM", "Newton"])
 def test_cv_negbin_est_r_chains_in_lockstep(mih, oracle, method):
@@ -766,7 +372,6 @@ def test_cv_negbin_est_r_chains_in_lockstep(mih, oracle, method):
         o = oracle.fit_iht(ox, y, None, k=kk, dist="negbin", link="log", nb_r=1.0, est_r=method.lower(), max_iter=100)
         assert got == pytest.approx(o["logl"], rel=1e-7), kk
 
-
 def test_init_beta(mih, oracle, normal_pair, normal_data):
     """init_beta=true (fit.jl:80; utilities.jl:776-842; test/L0_reg_test.jl:299-320)."""
     x, ox = normal_pair
@@ -802,50 +407,6 @@ def test_init_beta(mih, oracle, normal_pair, normal_data):
     omse, _ = oracle.cv_iht(oxs, y, z, path=[3, 5, 7], q=3, folds=folds, init_beta=True)
     np.testing.assert_allclose(mse, omse, rtol=1e-5)
 
-
-def test_full_size_baseline_config_p1M(mih, oracle):
-    """BASELINE configs[2] at its FULL size (n = 500 000, p = 1 000 000; 125 GB of 2-bit data in HBM): size-independent
-    properties + the oracle on BOTH ends of the matrix -- its first 96 and its last 96 columns (the generator is keyed by
-    (seed, global column), so `synthetic(n, 96, col_offset=p - 96)` is the big matrix's tail): X'r, the column statistics and
-    X beta through columns of either end."""
-    n, p = 500_000, 1_000_000
-    x = mih.SnpLinAlg.synthetic(n, p, seed=2024)
-    rng = np.random.default_rng(6)
-    r1, r2 = rng.standard_normal(n), rng.standard_normal(n)
-    o1, o2 = x.xtv(r1), x.xtv(r2)
-    o12 = x.xtv(0.5 * r1 - 2.0 * r2)
-    assert rel(o12, 0.5 * o1 - 2.0 * o2) < 1e-10                   # linearity
-    assert np.array_equal(x.xtv(r1), o1)                           # bit-reproducible
-    assert np.max(np.abs(x.xtv(np.ones(n)))) < 1e-6                # centred columns
-    R = np.column_stack([r1, r2, r1 + r2, r1 - r2, 2 * r1])        # fused multi-RHS pass == single passes
-    O5 = x.xtv(R)
-    assert np.array_equal(O5[:, 0], o1) and np.array_equal(O5[:, 1], o2)
-    mu, sinv = x.mu_sigma()
-    val = rng.standard_normal(4)
-    for lo in (0, p - 96):                                         # the first and the last 96 columns against the oracle
-        xs = mih.SnpLinAlg.synthetic(n, 96, seed=2024, col_offset=lo)
-        ox = oracle.Mat.from_bed_columns(xs.export_bed(), n)
-        assert rel(o1[lo:lo + 96], ox.xtv(r1)) < 1e-10
-        assert rel(O5[lo:lo + 96, 3], ox.xtv(r1 - r2)) < 1e-10
-        omu, osinv = ox.mu_sinv()
-        assert np.array_equal(mu[lo:lo + 96], omu) and np.array_equal(sinv[lo:lo + 96], osinv)
-        idx = np.array([3, 40, 77, 95])                            # X*beta through columns of this end (95: the very last column of the matrix)
-        mask = np.zeros(96, np.uint8); mask[idx] = 1
-        coef = np.zeros(96); coef[idx] = val
-        assert rel(x.xv_sparse(lo + idx, val), ox.xv_masked(mask, coef)) < 1e-10
-        del xs, ox
-    last = x.xv_sparse(np.array([p - 1]), val[3:])
-    assert abs(last.mean()) < 1e-9 * (1 + np.abs(last).max())      # a standardized column has mean 0
-    mih.set_xtv_digits(4908)                                        # the opt-in fast mode at full size
-    try:
-        f1 = x.xtv(r1)
-        F5 = x.xtv(R)
-    finally:
-        mih.set_xtv_digits(0)
-    assert np.max(np.abs(f1 - o1)) < 1e-8 * np.sqrt(n) * np.abs(r1).max()
-    assert np.array_equal(F5[:, 0], f1) and np.max(np.abs(F5 - O5)) < 1e-8 * np.sqrt(n) * np.abs(R).max()
-
-
 def test_iht_run_many_models(mih, oracle, normal_pair, normal_data, capsys):
     """iht_run_many_models (cross_validation.jl:232-273): one full-data fit per model size, max_iter = 100."""
     x, ox = normal_pair
@@ -865,7 +426,6 @@ def test_iht_run_many_models(mih, oracle, normal_pair, normal_data, capsys):
     yb = (rng.random(x.n) < 0.5).astype(float)
     llb = mih.iht_run_many_models(yb, x, None, path=[2, 5], d=mih.Bernoulli, verbose=False)     # canonical link
     np.testing.assert_allclose(llb, [oracle.fit_iht(ox, yb, None, k=k, max_iter=100, dist="bernoulli", link="logit")["logl"] for k in (2, 5)], rtol=1e-8)
-
 
 def test_concurrent_fits_share_one_matrix(mih, normal_pair, normal_data):
     """SURVEY 8b threading row: cv_iht calls the path from several host threads on a SHARED x
@@ -891,79 +451,6 @@ def test_concurrent_fits_share_one_matrix(mih, normal_pair, normal_data):
     assert not errs
     for a, b in zip(want, got):
         assert np.array_equal(a.beta, b.beta) and np.array_equal(a.c, b.c) and a.logl == b.logl and a.iter == b.iter
-
-
-@pytest.mark.parametrize("mode,quantum", [(4908, 1e-12), (1308, 2e-7)])
-def test_fast_digit_mode(mih, oracle, normal_pair, normal_data, mode, quantum):
-    """xtv_digits = 4908: 43-bit fixed-point residuals as 8 base-49 FP6 digits, four per MFMA B operand (the
-    opt-in mode for fused multi-RHS passes), and (1308): 27-bit residuals as 8 base-13 FP4 digits.  X'r stays within the format's
-    quantum of the exact mode, is independent of how the residuals are grouped into passes, and fits /
-    cross-validation stay inside the north_star tolerance."""
-    x, ox = normal_pair
-    n = x.n
-    R = np.random.default_rng(5).standard_normal((n, 9))
-    exact = x.xtv(R)
-    mih.set_xtv_digits(mode)
-    try:
-        fast = x.xtv(R)
-        scale = np.sqrt(n) * np.abs(R).max()                      # size of a null-SNP score
-        assert np.max(np.abs(fast - exact)) < quantum * scale
-        assert not np.array_equal(fast, exact)                    # it really is the other arithmetic
-        singles = np.column_stack([x.xtv(R[:, v]) for v in range(9)])
-        for m_rhs in range(1, 10):                                # pairs, padded 4-operand passes, odd tails
-            assert np.array_equal(x.xtv(R[:, :m_rhs]), singles[:, :m_rhs]), m_rhs
-        assert np.array_equal(x.xtv(R), fast)                     # reproducible
-        y, z = normal_data["y"], normal_data["z"]
-        res = mih.fit_iht(y, x, z, k=7, verbose=False)
-        o = oracle.fit_iht(ox, y, z, k=7)
-        assert res.iter == o["iter"] and np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"]))
-        np.testing.assert_allclose(res.beta[res.beta != 0], o["beta"][o["beta"] != 0], rtol=1e-5)
-        assert res.logl == pytest.approx(o["logl"], rel=1e-8)
-        folds = hash_folds(n, 3)
-        path = list(range(1, 8))
-        mse = mih.cv_iht(y, x, z, path=path, q=3, folds=folds, verbose=False)
-        omse, _ = oracle.cv_iht(ox, y, z, path=path, q=3, folds=folds)
-        np.testing.assert_allclose(mse, omse, rtol=1e-5)
-        rng = np.random.default_rng(41)
-        Y, Z = _mv_problem(oracle, ox, rng, 3, 8, 2)
-        rm = mih.fit_iht(Y, x, Z, k=8, verbose=False)
-        om = oracle.fit_mv(ox, Y, Z, k=8)
-        assert np.array_equal(rm.beta != 0, om["B"] != 0)
-        np.testing.assert_allclose(rm.beta, om["B"], rtol=1e-5, atol=1e-12)
-    finally:
-        mih.set_xtv_digits(0)
-    assert np.array_equal(x.xtv(R), exact)                        # back to the exact mode
-    with pytest.raises(mih.MendelIHTError):
-        mih.set_xtv_digits(20)
-
-
-def test_digit_modes_agree(mih, oracle, normal_pair):
-    """Every fixed-point format of the residual (xtv_digits) against the oracle's f64 X'r: the default
-    (10 base-49 FP6 digits, three residuals per operand), 16 base-13 FP4 digits (two per operand) and 28 base-4
-    digits (one per operand) agree to f64 rounding; the 43-bit and 27-bit formats to their quantum; each is
-    independent of how residuals share operands."""
-    x, ox = normal_pair
-    n = x.n
-    rng = np.random.default_rng(77)
-    R = rng.standard_normal((n, 18)) * np.logspace(-3, 4, 18)      # very different scales side by side
-    O = np.column_stack([ox.xtv(R[:, v]) for v in range(18)])
-    scale = np.sqrt(n) * np.abs(R).max(axis=0)
-    out = {}
-    try:
-        for mode, tol in ((0, 2e-15), (4910, 2e-15), (1316, 2e-15), (428, 2e-15), (4908, 1e-12), (1308, 2e-7)):
-            mih.set_xtv_digits(mode)
-            got = x.xtv(R)
-            assert np.all(np.max(np.abs(got - O), axis=0) < tol * scale + 1e-13 * np.abs(O).max(axis=0)), mode
-            for m_rhs in (1, 2, 3, 4, 5, 7, 8, 10, 13, 15, 16, 17):   # 1 .. 9 operands: every pass split, 6-operand passes with and without a half-empty last operand
-                assert np.array_equal(x.xtv(R[:, :m_rhs]), got[:, :m_rhs]), (mode, m_rhs)
-            out[mode] = got
-    finally:
-        mih.set_xtv_digits(0)
-    assert np.array_equal(out[0], out[4910])
-    for mode in (1316, 428):
-        assert np.all(np.max(np.abs(out[0] - out[mode]), axis=0) <= 2e-15 * scale), mode
-    assert not np.array_equal(out[0], out[4908]) and not np.array_equal(out[0], out[1308])
-
 
 @pytest.mark.parametrize("case", ["gamma_log", "invgauss_log", "bernoulli_probit", "bernoulli_cloglog", "bernoulli_cauchit",
                                   "poisson_sqrt", "gamma_inverse"])
@@ -1008,7 +495,6 @@ def test_more_families_and_links(mih, oracle, normal_pair, case):
     assert list(res.trace["backtracks"]) == list(o["bt_trace"])
     assert type(mih.canonicallink(d)).__name__ in ("InverseLink", "InverseSquareLink", "LogitLink", "LogLink")
 
-
 @pytest.mark.parametrize("family", ["normal", "bernoulli", "poisson"])
 def test_debias(mih, oracle, normal_pair, normal_data, family):
     """debias=true (fit.jl:188 + debias!, utilities.jl:1014-1020): GLM refit of the support after a step that
@@ -1044,7 +530,6 @@ def test_debias(mih, oracle, normal_pair, normal_data, family):
     with pytest.raises(mih.MendelIHTError):
         mih.fit_iht(np.vstack([y, y]), x, None, k=4, debias=True, verbose=False)   # multivariate: disabled in the reference
 
-
 def test_snplinalg_fit_equals_dense_copy(mih, oracle):
     """test/L0_reg_test.jl:340-348, 361-363: the memory-efficient SnpLinAlg path and a dense Float64 copy of
     the same standardized matrix give the same model (here both on the GPU: 2-bit MFMA path vs f64 path)."""
@@ -1070,38 +555,6 @@ def test_snplinalg_fit_equals_dense_copy(mih, oracle):
         assert a.iter == b.iter and np.array_equal(np.flatnonzero(a.beta), np.flatnonzero(b.beta))
         np.testing.assert_allclose(a.beta, b.beta, rtol=tol, atol=1e-12)
         assert a.logl == pytest.approx(b.logl, rel=1e-10)
-
-
-def test_maf_weights(mih, normal_pair):
-    """test/utilities_test.jl:215-232."""
-    x, ox = normal_pair
-    bed = mih.read_bed(os.path.join(FIX, "normal.bed"), x.n)
-    code = np.unpackbits(bed[:2], axis=1, bitorder="little").reshape(2, -1, 2)[:, :x.n, :]
-    code = code[:, :, 0] + 2 * code[:, :, 1]
-    w = mih.maf_weights(x)
-    assert np.all(w >= 1.0)
-    for j in range(2):
-        ok = code[j] != 1
-        f = np.select([code[j] == 2, code[j] == 3], [1.0, 2.0], 0.0)[ok].sum() / (2 * ok.sum())
-        m = min(f, 1 - f)
-        assert w[j] == pytest.approx(1 / (2 * np.sqrt(m * (1 - m))), rel=1e-12)
-    w2 = mih.maf_weights(x, max_weight=2.0)
-    assert np.all((w2 >= 1.0) & (w2 <= 2.0))
-    res = mih.fit_iht(np.loadtxt(os.path.join(FIX, "normal_y_fam6.txt")), x, None, k=5, weight=w2, verbose=False)
-    assert np.count_nonzero(res.beta) == 5
-
-
-def test_xtv_extreme_residual_scales(mih, oracle, normal_pair):
-    """The fixed-point scale 2^e follows max|r|: huge, tiny, denormal and all-zero residuals stay finite and accurate."""
-    x, ox = normal_pair
-    r = np.random.default_rng(8).standard_normal(x.n)
-    base = ox.xtv(r)
-    for scale in (1e150, 1e-150, 1e-290, 5e-310):
-        out = x.xtv(r * scale)
-        assert np.all(np.isfinite(out))
-        assert rel(out, base * scale) < (1e-10 if scale > 1e-300 else 1e-3), scale
-    assert np.all(x.xtv(np.zeros(x.n)) == 0.0)
-
 
 def test_large_k_and_many_covariates(mih, oracle, normal_pair, normal_data):
     """Buffers that grow with the model: k = 1500 of p = 10 000 SNPs, and q = 24 covariates of which 19 compete
@@ -1134,7 +587,6 @@ def test_large_k_and_many_covariates(mih, oracle, normal_pair, normal_data):
     with pytest.raises(mih.MendelIHTError):
         mih.fit_iht(y, x, np.ones((n, 65)), k=3, verbose=False)
 
-
 def test_cv_iht_over_replicas_in_one_process(mih, normal_data):
     """mih_cv_iht_multi: one host thread per matrix replica (one per GPU; here both on the single test GPU),
     the (fold,k) grid split between them -- same losses as the single-replica call."""
@@ -1152,25 +604,6 @@ def test_cv_iht_over_replicas_in_one_process(mih, normal_data):
     assert np.array_equal(three, one)
     with pytest.raises(mih.MendelIHTError):
         mih.cv_iht(y, [xa, mih.SnpLinAlg(bed[:100], n, center=True, scale=True)], z, path=path, q=3, folds=folds, verbose=False)
-
-
-_BT_TIE = 1e-13      # orc_result.bt_cond below this: `old_logl > new_logl` compared two sums of n terms that agree to their rounding error
-_NUDGES = [1.0 + e * 2.0 ** -51 for e in (2, 1, 3, 4, 6, 8)]      # a few ulps: one nudge can land on the same branch by luck (seed 2449)
-
-
-def _unstable(a, b, rtol, atol=1e-10):
-    """The oracle against ITSELF on covariates scaled by 1 + a few 2^-51 (a: the run on the original input, b: a nudged one, dicts
-    of arrays / scalars): True when an ulp-sized change of the input moves the oracle's own answer by more than the tolerance.
-    Such a trajectory amplifies rounding from step to step (seed 2121 of tools/fuzz_parity.py: the intercepts of a multivariate
-    fit drift apart by x1.87 per iteration, 1e-15 -> 4e-7 over 40 steps; seed 2275: a Bernoulli fit that backtracks three
-    times in most steps) -- no two floating-point implementations agree on it, the reference under another BLAS included,
-    so the sweeps do not hold the GPU to it."""
-    for key in a:
-        va, vb = np.asarray(a[key], dtype=float), np.asarray(b[key], dtype=float)
-        if va.shape != vb.shape or not np.allclose(va, vb, rtol=rtol, atol=atol):
-            return True
-    return False
-
 
 def _fits_case(mih, oracle, rng, trial, fams):
     """One random fit of test_randomized_fits_vs_oracle (replayed by tools/repro_fuzz.py)."""
@@ -1202,7 +635,6 @@ def _fits_case(mih, oracle, rng, trial, fams):
     if rng.random() < 0.4:
         kw["train"] = (rng.random(n) < 0.8).astype(np.uint8)
     return n, p, k, miss, q, od, ol, D, L, tol, x, ox, y, z, kw
-
 
 def test_randomized_fits_vs_oracle(mih, oracle):
     """A seeded sweep over shapes, missing rates, families, covariates, zkeep masks, prior weights, train masks
@@ -1259,7 +691,6 @@ def test_randomized_fits_vs_oracle(mih, oracle):
             raise
         tally.ok()
     tally.finish()
-
 
 def _options_case(mih, oracle, rng, trial):
     """One random case of test_randomized_options_vs_oracle (also replayed by hand when a seed of tools/fuzz_parity.py fails)."""
@@ -1323,7 +754,6 @@ def _options_case(mih, oracle, rng, trial):
     tag = (trial, n, p, q, miss, fam, mode, np.ravel(k).tolist(), sorted(both))
     return x, ox, y, z, k, kw, okw, both, tol, fam, tag
 
-
 def test_randomized_options_vs_oracle(mih, oracle):
     """Seeded sweep over the keyword surface the first sweep leaves out: group / J / vector k (doubly sparse projection), debias,
     init_beta, NegativeBinomial with est_r, Gamma / InverseGaussian, non-canonical links -- combined at random, on random
@@ -1384,7 +814,6 @@ def test_randomized_options_vs_oracle(mih, oracle):
         tally.ok()
     tally.finish()
 
-
 def test_randomized_genotype_linear_algebra(mih, oracle):
     """Seeded sweep of the genotype linear algebra itself: row counts around every tile boundary of the kernels (the 4-per-byte
     packing, the 128-row MFMA step, the 2^18-row slices), a single SNP up to a few thousand, missing rates up to 30 %, the
@@ -1430,7 +859,6 @@ def test_randomized_genotype_linear_algebra(mih, oracle):
         coef = np.zeros(p); coef[idx] = val
         np.testing.assert_allclose(x.xv_sparse(idx, val), ox.xv_masked(mask, coef), rtol=1e-12, atol=1e-12 * (1 + np.abs(val).sum()), err_msg=str(tag))
 
-
 def test_randomized_projections(mih, oracle):
     """Seeded sweep of the two projections (utilities.jl:553-559, :613-679) on their own: lengths from 1 to a few hundred thousand
     (around the 2 x 11-bit histogram passes of the device top-k and its 64 Ki-candidate host finish), k from 1 to the length,
@@ -1470,32 +898,6 @@ def test_randomized_projections(mih, oracle):
         got, want = mih.project_group_sparse(w, group, J, kg), oracle.project_group_sparse(w, group, J, kg)
         assert np.array_equal(got, want), tag + (G, J, np.ravel(kg)[:8].tolist(), np.flatnonzero(got != want)[:5])
 
-
-def test_group_norms_round_the_square_then_the_sum(mih, oracle):
-    """project_group_sparse! ranks the groups by `group_norm[n] + y[j]^2` (utilities.jl:626): the square is rounded, then the sum.
-    Fused into an fma -- what the HIP compiler did to the device kernel until round 4 (seed 9079 of tools/fuzz_parity.py found it)
-    -- 2.2^2 + 1.8^2 + 1.3^2 comes out as 9.77 instead of 9.770000000000001 and ties with 2.0^2 + 1.7^2 + 1.2^2 + 1.2^2 = 9.77, and the
-    tie goes to the group with the lower label.  Known answer: the group with the larger (unfused) norm survives J = 1."""
-    y = np.array([-2.0, 1.7, -1.2, 1.2, 2.2, -1.8, 1.3, 0.05])
-    group = np.array([1, 1, 1, 1, 2, 2, 2, 3])
-    assert (2.2 * 2.2 + 1.8 * 1.8) + 1.3 * 1.3 > ((2.0 * 2.0 + 1.7 * 1.7) + 1.2 * 1.2) + 1.2 * 1.2       # 9.770000000000001 > 9.77
-    want = np.array([0, 0, 0, 0, 2.2, -1.8, 1.3, 0])
-    for k in (4, np.array([4, 3, 1])):
-        assert np.array_equal(oracle.project_group_sparse(y, group, 1, k), want)
-        assert np.array_equal(mih.project_group_sparse(y, group, 1, k), want)
-    # embedded in a long vector (several blocks of the device sorts), the two groups scattered
-    rng = np.random.default_rng(3)
-    n = 5000
-    big = np.round(rng.standard_normal(n) * 0.1, 2)
-    grp = rng.integers(3, 40, n)
-    pos = rng.choice(n, 7, replace=False)
-    big[pos] = y[:7]; grp[pos] = group[:7]
-    kk = np.full(39, 2); kk[0], kk[1] = 4, 3
-    got, ref = mih.project_group_sparse(big, grp, 2, kk), oracle.project_group_sparse(big, grp, 2, kk)
-    assert np.array_equal(got, ref)
-    assert np.array_equal(got[pos[4:7]], y[4:7]) and np.count_nonzero(got[pos[:4]]) == 4      # both survive J = 2: ranks 1 and 2, in that order
-
-
 def test_error_paths_nan_loglikelihood_and_bad_arguments(mih, normal_pair, normal_data):
     """fit.jl:259-260 (NaN/Inf loglikelihood aborts), fit.jl:87-94 argument errors, k > p."""
     x, _ = normal_pair
@@ -1515,7 +917,6 @@ def test_error_paths_nan_loglikelihood_and_bad_arguments(mih, normal_pair, norma
         mih.fit_iht(np.abs(normal_data["y"]), x, None, k=3, d=mih.Bernoulli(), l=mih.LogitLink(), verbose=False)   # checky
     ok = mih.fit_iht(normal_data["y"], x, None, k=5, verbose=False)                     # the handle survives the failures
     assert np.count_nonzero(ok.beta) == 5
-
 
 def test_float32_dense_matrix(mih, oracle):
     """`x::Matrix{Float32}` (test/L0_reg_test.jl:245-297 NegBin nuisance parameter on a Float32 matrix;
@@ -1553,7 +954,6 @@ def test_float32_dense_matrix(mih, oracle):
     xr = mih.DenseMatrix(X32[:801])
     assert rel(xr.xtv(r[:801]), X64[:801].T @ r[:801]) < 1e-12
 
-
 @pytest.mark.parametrize("fam", ["normal", "bernoulli", "poisson", "negbin"])
 def test_simulate_and_recover(mih, fam):
     """The pattern of test/L0_reg_test.jl:1-102: simulate_random_snparray + simulate_random_response, then fit_iht with
@@ -1571,7 +971,6 @@ def test_simulate_and_recover(mih, fam):
     with pytest.raises(mih.MendelIHTError):
         mih.simulate_random_response(x, k, mih.NegativeBinomial, mih.IdentityLink())
 
-
 def _mvfit_case(mih, oracle, rng, trial):
     """One random fit of test_randomized_multivariate_fits_vs_oracle (replayed by tools/repro_fuzz.py)."""
     n = int(rng.integers(150, 1500)); p = int(rng.integers(60, 400)); r = int(rng.integers(2, 6))
@@ -1588,7 +987,6 @@ def _mvfit_case(mih, oracle, rng, trial):
     if rng.random() < 0.3:
         kw["init_beta"] = True
     return n, p, r, q, k, miss, x, ox, Y, Z, kw
-
 
 def test_randomized_multivariate_fits_vs_oracle(mih, oracle):
     """Seeded sweep of multivariate fits: traits r, covariates q (some not kept), k, missingness, train masks,
@@ -1622,7 +1020,6 @@ def test_randomized_multivariate_fits_vs_oracle(mih, oracle):
             raise
         tally.ok()
     tally.finish()
-
 
 def test_gpu_against_committed_oracle_goldens(mih, normal_pair):
     """The GPU path against tests/golden/oracle_goldens.json (oracle results committed as data: the families that no
@@ -1662,37 +1059,6 @@ def test_gpu_against_committed_oracle_goldens(mih, normal_pair):
     np.testing.assert_allclose([rm.beta[i, j] for i, j in gm["support"]], gm["B"], rtol=1e-5)
     np.testing.assert_allclose(rm.Σ, gm["Sigma"], rtol=1e-6)
 
-
-@pytest.mark.parametrize("n", [40_000_000, 6_000_000])
-def test_forty_million_rows(mih, oracle, n):
-    """n = 40 000 000 samples (x 64 SNPs): more rows than 16 exact row slices of the FP6 (2^18 rows) and base-13
-    (2^20) residual formats hold, so the default steps down to base-4 digits and raises the number of slices to
-    keep the f32 accumulators exact; 32-bit row indices and 64-bit offsets at scale.  n = 6 000 000: the
-    intermediate step (base-13 digits)."""
-    p = 64
-    x = mih.SnpLinAlg.synthetic(n, p, seed=99, missing_rate=0.001)
-    rng = np.random.default_rng(9)
-    r = rng.standard_normal(n)
-    out = x.xtv(r)
-    if n < 2 ** 24:
-        mih.set_xtv_digits(1316)                                     # what the default stepped down to
-        try:
-            assert np.array_equal(x.xtv(r), out)
-        finally:
-            mih.set_xtv_digits(0)
-        R3 = np.column_stack([r, -2.0 * r, r[::-1]])
-        O3 = x.xtv(R3)
-        assert np.array_equal(O3[:, 0], out) and np.array_equal(O3[:, 1], -2.0 * out)
-    ox = oracle.Mat.from_bed_columns(x.export_bed()[:8], n)          # the first 8 columns on the CPU
-    ref = ox.xtv(r)
-    assert rel(out[:8], ref) < 1e-10
-    assert np.array_equal(x.xtv(r), out)
-    idx = np.array([1, 5]); val = np.array([0.7, -1.1])
-    mask = np.zeros(8, np.uint8); mask[idx] = 1
-    coef = np.zeros(8); coef[idx] = val
-    assert rel(x.xv_sparse(idx, val), ox.xv_masked(mask, coef)) < 1e-11
-
-
 def test_tiny_problems(mih, oracle):
     """Degenerate sizes: a handful of samples, a single SNP, fewer rows than one 128-row tile."""
     rng = np.random.default_rng(0)
@@ -1710,27 +1076,6 @@ def test_tiny_problems(mih, oracle):
     x1 = mih.SnpLinAlg(make_bed(rng, 1, 4, maf_lo=0.3), n=1, center=True, scale=True, impute=True)
     with pytest.raises(mih.MendelIHTError, match="NaN|Inf"):             # one sample: zero deviance, NaN loglikelihood
         mih.fit_iht(np.array([0.3]), x1, None, k=1, verbose=False)
-
-
-@pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_dense_xtv_shapes(mih, dtype):
-    """Dense X'r over row counts around the 256-load step of the LDS-staged kernel (one step, exact multiples, ragged
-    tails, many steps), odd / non-multiple-of-4 row counts (the fallback kernels) and column counts that leave idle
-    waves in the last block; both storage types, several right-hand sides, run-to-run reproducible."""
-    rng = np.random.default_rng(31)
-    for n in (2, 4, 510, 512, 516, 1024, 1028, 3000, 4100, 501, 1026):
-        for p in (1, 3, 4, 9):
-            X = rng.standard_normal((n, p)).astype(dtype)
-            xd = mih.DenseMatrix(X)
-            R = rng.standard_normal((n, 15))
-            want = X.astype(np.float64).T @ R
-            got = xd.xtv(R)                                             # fused passes of 8 (f64) / 4 + 4 + 2 + 1 residuals
-            assert rel(got, want) < 1e-12, (n, p)
-            assert np.array_equal(xd.xtv(R), got)
-            assert np.array_equal(xd.xtv(R[:, 1]), got[:, 1])           # fused == single, bit for bit
-            assert np.array_equal(xd.xtv(R[:, 2:5]), got[:, 2:5])
-            assert np.array_equal(xd.xtv(R[:, 3:11]), got[:, 3:11])
-
 
 def _cv_case(mih, oracle, rng, trial, fams):
     """One random grid of test_randomized_cv_vs_oracle (also replayed by tools/repro_fuzz.py when a seed of tools/fuzz_parity.py fails)."""
@@ -1757,7 +1102,6 @@ def _cv_case(mih, oracle, rng, trial, fams):
         group[:G] = np.arange(1, G + 1)                            # every label occurs; cv_iht fixes J = 1 (cross_validation.jl:91)
         extra["group"] = np.sort(group)
     return n, p, q, od, ol, D, L, tol, x, ox, y, path, folds, extra
-
 
 def test_randomized_cv_vs_oracle(mih, oracle):
     """Seeded sweep of cross-validations through the rolling lock-step driver (fused FP6 passes, slots refilled as fits
@@ -1815,7 +1159,6 @@ def test_randomized_cv_vs_oracle(mih, oracle):
         assert np.array_equal(halves[0] + halves[1], raw), tag
     tally.finish()
 
-
 def _mvcv_case(mih, oracle, rng, trial):
     """One random grid of test_randomized_multivariate_cv_vs_oracle (replayed by tools/repro_fuzz.py)."""
     n = int(rng.integers(200, 1200)); p = int(rng.integers(60, 300)); r = int(rng.integers(2, 5))
@@ -1832,7 +1175,6 @@ def _mvcv_case(mih, oracle, rng, trial):
     if rng.random() < 0.25:
         extra["init_beta"] = True
     return n, p, r, qz, q, x, ox, Y, Z, path, folds, extra
-
 
 def test_randomized_multivariate_cv_vs_oracle(mih, oracle):
     """Seeded sweep of multivariate cross-validations (mih_cv_mv: the lock-step batches of r-trait fits, one fused X'R pass per
@@ -1869,7 +1211,6 @@ def test_randomized_multivariate_cv_vs_oracle(mih, oracle):
             np.testing.assert_allclose(mse, omse, rtol=1e-5, err_msg=str(tag))
     tally.finish()
 
-
 def _path_case(mih, oracle, rng, trial, fams):
     """One random model path of test_randomized_model_paths_vs_oracle (replayed by tools/repro_fuzz.py)."""
     n = int(rng.integers(150, 1500)); p = int(rng.integers(60, 400)); q = int(rng.integers(1, 4))
@@ -1901,7 +1242,6 @@ def _path_case(mih, oracle, rng, trial, fams):
         if est != "None":
             kw["est_r"], okw["est_r"] = str(est), str(est).lower()
     return n, p, q, od, ol, D, L, x, ox, y, z, path, kw, okw, d
-
 
 def test_randomized_model_paths_vs_oracle(mih, oracle):
     """Seeded sweep of iht_run_many_models (cross_validation.jl:232-273; the lock-step path driver, the sequential branch for
@@ -1950,7 +1290,6 @@ def test_randomized_model_paths_vs_oracle(mih, oracle):
         assert np.array_equal(halves[0] + halves[1], ll), tag
     tally.finish()
 
-
 def test_more_ranks_than_work_items(mih):
     """Sharding with more ranks than (fold, k) combinations / path entries (8 GPUs, a 2 x 2 grid): the ranks without work return
     zeros and the parts still add up to the single-process result bit for bit -- univariate and multivariate cross-validation,
@@ -1970,7 +1309,6 @@ def test_more_ranks_than_work_items(mih):
     with pytest.raises(mih.MendelIHTError, match="no training samples"):
         mih.cv_iht(y, x, None, path=[1], q=2, folds=np.ones(n, dtype=np.int32), verbose=False)      # every sample in fold 1: nothing to train fold 1's model on
 
-
 def test_c_abi_refuses_bad_arguments_without_crashing(mih):
     """85 calls with bad arguments straight at the C ABI (tools/abi_edge_probe.py, in a child process so that a crash would be
     seen as one): NULL pointers, zero / negative / oversized dimensions, out-of-range indices, labels, folds, ranks, unknown
@@ -1981,247 +1319,6 @@ def test_c_abi_refuses_bad_arguments_without_crashing(mih):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "abi_edge_probe.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "probe finished" in r.stdout and "ACCEPTED: []" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
     assert r.stdout.count(": rc=") >= 80
-
-
-def test_mirror_accepts_any_array_layout(mih):
-    """The host mirror hands the library contiguous Float64 / Int64 / UInt8 buffers whatever it is given: C- or Fortran-ordered
-    and strided covariates, strided / list / column-vector responses, genotype columns out of a strided view, paths as ranges
-    or Int32 arrays, folds as lists or floats, weights, groups and train masks in other dtypes -- always the same model, bit
-    for bit (a C-ordered z read as column-major would be a silently different design)."""
-    rng = np.random.default_rng(0)
-    n, p = 500, 150
-    cols = make_bed(rng, n, p)
-    x = mih.SnpLinAlg(cols, n=n, center=True, scale=True, impute=True)
-    z = np.column_stack([np.ones(n), rng.standard_normal(n), rng.standard_normal(n)])
-    y = rng.standard_normal(n) + 0.5 * z[:, 1]
-    base = mih.fit_iht(y, x, np.asfortranarray(z), k=4, verbose=False)
-    assert base.c[1] == pytest.approx(0.5, abs=0.15)                       # the covariate was read as the covariate
-    same = lambda res, ref=base: np.array_equal(res.beta, ref.beta) and np.array_equal(res.c, ref.c)
-    big = np.zeros((n, 6)); big[:, ::2] = z
-    yy = np.zeros(2 * n); yy[::2] = y
-    cols_big = np.zeros((p, cols.shape[1] * 2), dtype=np.uint8); cols_big[:, ::2] = cols
-    x2 = mih.SnpLinAlg(cols_big[:, ::2], n=n, center=True, scale=True, impute=True)
-    for name, res in (("z C-order", mih.fit_iht(y, x, np.ascontiguousarray(z), k=4, verbose=False)),
-                      ("z strided", mih.fit_iht(y, x, big[:, ::2], k=4, verbose=False)),
-                      ("z nested lists", mih.fit_iht(y, x, z.tolist(), k=4, verbose=False)),
-                      ("y strided", mih.fit_iht(yy[::2], x, z, k=4, verbose=False)),
-                      ("y list", mih.fit_iht(y.tolist(), x, z, k=4, verbose=False)),
-                      ("y column vector", mih.fit_iht(y.reshape(-1, 1), x, z, k=4, verbose=False)),
-                      ("strided genotype columns", mih.fit_iht(y, x2, z, k=4, verbose=False))):
-        assert same(res), name
-    folds = hash_folds(n, 3)
-    a = mih.cv_iht(y, x, z, path=[1, 2, 3], q=3, folds=folds, verbose=False)
-    assert np.array_equal(a, mih.cv_iht(y, x, z, path=range(1, 4), q=3, folds=folds.astype(np.int64).tolist(), verbose=False))
-    assert np.array_equal(a, mih.cv_iht(y, x, z, path=np.array([1, 2, 3], dtype=np.int32), q=3, folds=folds.astype(np.float64), verbose=False))
-    Y = np.vstack([y, rng.standard_normal(n)])
-    m1 = mih.fit_iht(Y, x, z.T.copy(), k=4, verbose=False)
-    assert np.array_equal(m1.beta, mih.fit_iht(np.asfortranarray(Y), x, np.asfortranarray(z.T), k=4, verbose=False).beta)
-    assert np.array_equal(m1.beta, mih.fit_iht(np.ascontiguousarray(Y), x, np.ascontiguousarray(z.T), k=4, verbose=False).beta)
-    w = rng.uniform(0.5, 2, p); wbig = np.zeros(2 * p); wbig[::2] = w
-    w1 = mih.fit_iht(y, x, z, k=4, weight=w, verbose=False)
-    assert same(mih.fit_iht(y, x, z, k=4, weight=wbig[::2], verbose=False), w1) and same(mih.fit_iht(y, x, z, k=4, weight=w.tolist(), verbose=False), w1)
-    g = (np.arange(p) % 5 + 1)
-    g1 = mih.fit_iht(y, x, z, k=2, J=2, group=g, verbose=False)
-    assert same(mih.fit_iht(y, x, z, k=2, J=2, group=g.astype(np.int32), verbose=False), g1) and same(mih.fit_iht(y, x, z, k=2, J=2, group=g.tolist(), verbose=False), g1)
-    t = rng.random(n) < 0.8
-    t1 = mih.fit_iht(y, x, z, k=4, train=t, verbose=False)
-    assert same(mih.fit_iht(y, x, z, k=4, train=t.astype(np.uint8), verbose=False), t1) and same(mih.fit_iht(y, x, z, k=4, train=t.astype(np.int64), verbose=False), t1)
-
-
-def test_xtv_accuracy_against_exact_rational_arithmetic(mih):
-    """The fixed-point X'r against EXACT dot products (Python rationals) of the raw dosages: the only rounding is that
-    of the residual to 2^-55 max|r| (2^-58 in the base-13 format) plus the recombination in f64, so the error stays
-    at a few 1e-16 of sqrt(n) max|r| -- well inside what an n-term f64 dot product guarantees (n 2^-53 sum|g r|)."""
-    from fractions import Fraction
-
-    rng = np.random.default_rng(2718)
-    n, p = 3000, 40
-    cols = make_bed(rng, n, p, maf_lo=0.05)
-    x = mih.SnpLinAlg(cols, n=n, center=False, scale=False, impute=False)
-    bits = np.unpackbits(cols, axis=1, bitorder="little").reshape(p, -1, 2)[:, :n, :]
-    code = bits[:, :, 0] + 2 * bits[:, :, 1]
-    g = np.select([code == 0, code == 2, code == 3], [0, 1, 2], default=0)            # missing (code 1) counts as 0
-    r = rng.standard_normal(n) * np.exp(rng.uniform(-6, 6, n))                       # 5 decades of dynamic range
-    rf = [Fraction(float(v)) for v in r]
-    exact = [sum((int(gi) * ri for gi, ri in zip(g[j], rf) if gi), Fraction(0)) for j in range(p)]
-    scale = np.sqrt(n) * np.abs(r).max()
-    f64_bound = n * 2.0 ** -53 * (g * np.abs(r)).sum(axis=1)
-    try:
-        for mode, tol in ((0, 6e-16), (1316, 2e-16), (428, 6e-16)):
-            mih.set_xtv_digits(mode)
-            got = x.xtv(r)
-            err = np.array([abs(float(Fraction(float(got[j])) - exact[j])) for j in range(p)])
-            assert err.max() <= tol * scale, (mode, err.max() / scale)
-            assert np.all(err <= f64_bound), mode
-    finally:
-        mih.set_xtv_digits(0)
-
-
-def _exact_xtv(g, r):
-    from fractions import Fraction
-    rf = [Fraction(float(v)) for v in r]
-    return [sum((int(gi) * ri for gi, ri in zip(g[j], rf) if gi), Fraction(0)) for j in range(g.shape[0])]
-
-
-def _dosages(cols, n):
-    p = cols.shape[0]
-    bits = np.unpackbits(cols, axis=1, bitorder="little").reshape(p, -1, 2)[:, :n, :]
-    code = bits[:, :, 0] + 2 * bits[:, :, 1]
-    return np.select([code == 0, code == 2, code == 3], [0, 1, 2], default=0)
-
-
-@pytest.mark.parametrize("shape", ["one_outlier_1e8", "one_outlier_1e12", "two_outliers", "twelve_decades", "cauchy"])
-def test_xtv_fixed_point_under_adversarial_dynamic_range(mih, shape):
-    """ X'r stays f64-grade whatever the residual looks like.  The fixed point keeps 54 bits of the LARGEST
-    entry it carries; rows that tower over the rest (max|r| > 64 x the lower quartile of the 256-row block maxima, at most 64 of
-    them: csrc/peel.h) leave it and ride an f64 side channel in k_xtv_finalize, so the scale is set by the rest.  Against EXACT
-    rational dot products, for the three residual formats:
-      * one entry 1e8 / 1e12 x the rest, two outliers of different size: ONE residual peeled (counter), every column -- with
-        or without the outlier -- within 2 ulp-sums (2 x 2^-53 sum_i g_ij |r_i|; numpy's pairwise sum is held to 8) and within
-        1e-13 of its own value where that value has not cancelled (round 5: 2e-7 on the columns without the outlier);
-      * twelve decades, log-uniform: no outlier by the guard's rule, nothing peeled, 8 ulp-sums like numpy's (as in round 5);
-      * a Cauchy residual (a heavy tail rather than a few outliers): whether or not the guard peels the extreme row, the result
-        is within 32 ulp-sums."""
-    rng = np.random.default_rng(31415)
-    n, p = 3000, 48
-    cols = make_bed(rng, n, p, maf_lo=0.05)
-    x = mih.SnpLinAlg(cols, n=n, center=False, scale=False, impute=False)
-    g = _dosages(cols, n)
-    r = rng.standard_normal(n)
-    i0 = int(np.argmax(np.abs(r)))
-    if shape == "one_outlier_1e8":
-        r[i0] *= 1e8
-    elif shape == "one_outlier_1e12":
-        r[i0] *= 1e12
-    elif shape == "two_outliers":
-        r[5] *= 1e9
-        r[2000] *= -3e6
-    elif shape == "twelve_decades":
-        r = rng.standard_normal(n) * 10.0 ** rng.uniform(-12, 0, n)
-    else:
-        r = rng.standard_cauchy(n)
-    exact = _exact_xtv(g, r)
-    from fractions import Fraction
-    ex = np.array([float(e) for e in exact])
-    pairwise = np.array([np.sum(g[j].astype(np.float64) * r) for j in range(p)])
-    err_np = np.array([abs(float(Fraction(float(pairwise[j])) - exact[j])) for j in range(p)])
-    ulp_sums = 2.0 ** -53 * (g * np.abs(r)).sum(axis=1)
-    assert np.all(err_np <= 8 * ulp_sums)
-    outliers = shape in ("one_outlier_1e8", "one_outlier_1e12", "two_outliers")
-    mih.profile_enable(x, True)
-    try:
-        for mode in (0, 428, 1316):
-            mih.set_xtv_digits(mode)
-            mih.profile_counters(x, reset=True)
-            got = x.xtv(r)
-            peeled = mih.profile_counters(x, reset=True)["peeled_residuals"]
-            err = np.array([abs(float(Fraction(float(got[j])) - exact[j])) for j in range(p)])
-            if outliers:
-                assert peeled == 1, (mode, peeled)
-                assert np.all(err <= 2 * ulp_sums), (mode, float((err / ulp_sums).max()))
-                rel = err / np.abs(ex)
-                assert rel.max() <= 1e-12 and rel[np.abs(ex) >= 1.0].max() <= 1e-13, (mode, rel.max())
-            elif shape == "twelve_decades":
-                assert peeled == 0, (mode, peeled)
-                assert np.all(err <= 8 * ulp_sums), (mode, float((err / ulp_sums).max()))
-            else:
-                assert peeled in (0, 1), (mode, peeled)          # (this draw's extreme row may or may not clear 64 x the quartile)
-                assert np.all(err <= 32 * ulp_sums), (mode, float((err / ulp_sums).max()))
-    finally:
-        mih.set_xtv_digits(0)
-        mih.profile_enable(x, False)
-
-
-def test_peeled_rows_in_fused_passes_with_missing_genotypes(mih, oracle):
-    """The side channel inside fused multi-residual passes and on a matrix with imputed entries: 23 residuals in one call (two
-    passes of the flat packing), some with planted outliers -- one of them on a row where genotypes are missing --, some without.
-    (1) every residual against the oracle's f64 dot products; (2) a residual WITHOUT an outlier gives the bits it gives alone and
-    in any company (the guard looks at its own block maxima only); (3) the counter says which residuals were peeled; (4) more
-    than 64 rows above the guard's threshold: no peel, the plain scale (the result of round 5, to its documented accuracy)."""
-    n, p = 6001, 700
-    x = mih.SnpLinAlg.synthetic(n, p, seed=5, missing_rate=0.02)
-    cols = x.export_bed()
-    ox = oracle.Mat.from_bed_columns(cols, n)
-    codes = np.unpackbits(cols, axis=1, bitorder="little").reshape(p, -1, 2)[:, :n, :]
-    miss_rows = np.flatnonzero(((codes[:, :, 0] == 1) & (codes[:, :, 1] == 0)).any(axis=0))
-    assert miss_rows.size > 100
-    rng = np.random.default_rng(99)
-    m = 23
-    R = rng.standard_normal((m, n))
-    planted = {2: [(int(miss_rows[7]), 3e9)], 5: [(17, -1e7), (4000, 2e11)], 11: [(int(i), 1e6 * (1 + t)) for t, i in enumerate(rng.choice(n, 40, replace=False))],
-               20: [(n - 1, 5e8)]}
-    for v, lst in planted.items():
-        for i, f in lst:
-            R[v, i] *= f
-    heavy = 14                                    # 200 rows 1e6 x the rest: beyond the side channel's 64
-    R[heavy, rng.choice(n, 200, replace=False)] *= 1e6
-    mih.profile_enable(x, True)
-    mih.profile_counters(x, reset=True)
-    got = x.xtv(R.T).T
-    assert mih.profile_counters(x, reset=True)["peeled_residuals"] == len(planted)
-    for v in range(m):
-        want = ox.xtv(R[v])
-        scale = np.abs(want) + 1e-3 * np.abs(want).max()
-        tol = 1e-6 if v == heavy else 1e-11          # (the oracle is a plain f64 loop over 6001 terms: ~1e-12 of its own)
-        assert np.all(np.abs(got[v] - want) <= tol * scale), (v, float((np.abs(got[v] - want) / scale).max()))
-    plain = [v for v in range(m) if v not in planted and v != heavy]
-    alone = x.xtv(R[plain[:3]].T).T
-    for t, v in enumerate(plain[:3]):
-        assert np.array_equal(alone[t].view(np.uint64), got[v].view(np.uint64)), v
-    one = x.xtv(R[[5]].T).T
-    assert np.array_equal(one[0].view(np.uint64), got[5].view(np.uint64))          # ... and a peeled one too
-    mih.profile_enable(x, False)
-
-
-def test_poisson_fit_with_a_planted_count_outlier(mih, oracle, normal_pair):
-    """ A heavy tail in the RESIDUAL of a real fit: Poisson counts y ~ 1 with ONE planted y = 500.
-    The first iterates are wild (the outlier's mean sits at the +-20 clamp: a working residual of -4.8e8 among entries of ~1) and
-    later y - mu has one entry ~500 x the rest.  Round 5 kept the oracle's support and logs but its loglikelihood trace to 5e-8 only
-    (27 bits lost on the bulk in the first ~65 steps).  With the outlier row on the f64 side channel (csrc/peel.h; the guard fires in
-    the first ~66 scores of either fit):
-      * k = 6: the whole 172-step trace is the oracle's to 1e-12 (measured 1.1e-13), beta to 1e-10 (3e-12);
-      * k = 10: the first 85 steps to 1e-12 (1.5e-13); step 89 is a large step (tol 0.19) that multiplies ANY difference by ~400 and
-        the fit creeps on to max_iter amplifying it further -- the ORACLE's own trace moves by 7e-12 there and by 4.5e-9 at the end
-        when every y_i is nudged by one ulp (measured here, per step, four nudged runs); the HIP path is held to 100 x that spread.
-    Both step modes, bit for bit."""
-    x, ox = normal_pair
-    rng = np.random.default_rng(77)
-    eta = _sim(oracle, ox, rng, 6, scale=0.25)
-    y = rng.poisson(np.exp(eta)).astype(float)
-    y[int(np.argmin(np.abs(eta)))] = 500.0
-    mih.profile_enable(x, True)
-    for k in (6, 10):
-        mih.profile_counters(x, reset=True)
-        res = mih.fit_iht(y, x, None, k=k, d=mih.Poisson(), l=mih.LogLink(), verbose=False)
-        assert mih.profile_counters(x, reset=True)["peeled_residuals"] >= 40
-        o = oracle.fit_iht(ox, y, None, k=k, dist="poisson", link="log")
-        assert res.iter == o["iter"], (k, res.iter, o["iter"])
-        assert list(res.trace["backtracks"]) == list(o["bt_trace"])
-        assert np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"]))
-        ol = np.asarray(o["logl_trace"])
-        got = np.abs(np.asarray(res.trace["logl"]) - ol) / np.abs(ol)
-        if k == 6:
-            assert got.max() <= 1e-12, got.max()
-            np.testing.assert_allclose(res.beta, o["beta"], rtol=1e-10, atol=1e-14)
-        else:
-            assert got[:85].max() <= 1e-12, got[:85].max()
-            spread, bspread = np.zeros(ol.size), 0.0
-            nz = np.flatnonzero(o["beta"])
-            for t in range(4):                               # what one ulp in every y_i does to the oracle itself
-                r2 = np.random.default_rng(100 + t)
-                y2 = np.where(r2.random(y.size) < 0.5, np.nextafter(y, np.inf), np.nextafter(y, -np.inf))
-                y2[y == 0] = 0.0
-                o2 = oracle.fit_iht(ox, y2, None, k=k, dist="poisson", link="log")
-                assert o2["iter"] == o["iter"] and np.array_equal(np.flatnonzero(o2["beta"]), nz)
-                spread = np.maximum(spread, np.abs(np.asarray(o2["logl_trace"]) - ol) / np.abs(ol))
-                bspread = max(bspread, float(np.max(np.abs(o2["beta"][nz] - o["beta"][nz]) / np.abs(o["beta"][nz]))))
-            assert np.all(got <= 1e-12 + 100 * spread), float((got / (1e-12 + 100 * spread)).max())
-            assert np.max(np.abs(res.beta[nz] - o["beta"][nz]) / np.abs(o["beta"][nz])) <= 100 * bspread
-            np.testing.assert_allclose(res.beta, o["beta"], rtol=1e-4, atol=1e-12)          # (north_star's GLM tolerance, whatever the spread)
-        host = mih.fit_iht(y, x, None, k=k, d=mih.Poisson(), l=mih.LogLink(), verbose=False, step_mode=1)
-        _same_fit(res, host, f"poisson outlier k={k}")
-    mih.profile_enable(x, False)
-
 
 def test_auto_digit_mode_in_the_lockstep_drivers(mih, oracle):
     """ xtv_digits = -1: the lock-step drivers score a residual of a GLM fit in the 43-bit format when ITS
@@ -2297,49 +1394,6 @@ def test_auto_digit_mode_in_the_lockstep_drivers(mih, oracle):
     mih.profile_enable(x, False)
     assert co["residuals_43bit"] == 0 and np.array_equal(oa.beta, od.beta) and oa.iter == od.iter
 
-
-def test_fits_and_cv_at_full_row_count(mih, oracle):
-    """n = 500 000 samples (BASELINE configs[2]/[3] row count) with a column count the oracle still finishes in
-    seconds: fit_iht (Normal, Bernoulli) and a small cv_iht grid against the oracle -- n-vector reductions, the
-    fixed-point residual and the lock-step driver at the full row count."""
-    n, p = 500_000, 384
-    x = mih.SnpLinAlg.synthetic(n, p, seed=2024)
-    ox = oracle.Mat.from_bed_columns(x.export_bed(), n)
-    rng = np.random.default_rng(12)
-    eta = _sim(oracle, ox, rng, 6, scale=0.3)
-    y = eta + 1 + rng.standard_normal(n)
-    res = mih.fit_iht(y, x, None, k=8, verbose=False)
-    o = oracle.fit_iht(ox, y, None, k=8)
-    assert res.iter == o["iter"] and np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"]))
-    np.testing.assert_allclose(res.beta, o["beta"], rtol=1e-5, atol=1e-12)
-    assert res.logl == pytest.approx(o["logl"], rel=1e-10)
-    yb = (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float)
-    res = mih.fit_iht(yb, x, None, k=6, d=mih.Bernoulli(), l=mih.LogitLink(), verbose=False)
-    o = oracle.fit_iht(ox, yb, None, k=6, dist="bernoulli", link="logit")
-    assert res.iter == o["iter"] and np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"]))
-    np.testing.assert_allclose(res.beta, o["beta"], rtol=1e-4, atol=1e-12)
-    folds = hash_folds(n, 3)
-    path = [2, 5, 8, 11]
-    mse = mih.cv_iht(yb, x, None, d=mih.Bernoulli(), l=mih.LogitLink(), path=path, q=3, folds=folds, verbose=False)
-    omse, _ = oracle.cv_iht(ox, yb, None, path=path, q=3, folds=folds, dist="bernoulli", link="logit")
-    np.testing.assert_allclose(mse, omse, rtol=1e-5)
-
-
-def test_multivariate_fit_at_full_row_count(mih, oracle):
-    """Multivariate Gaussian IHT (4 traits, 2 covariates) at n = 500 000 rows against the oracle."""
-    n, p = 500_000, 256
-    x = mih.SnpLinAlg.synthetic(n, p, seed=2024)
-    ox = oracle.Mat.from_bed_columns(x.export_bed(), n)
-    rng = np.random.default_rng(14)
-    Y, Z = _mv_problem(oracle, ox, rng, 4, 9, 2)
-    res = mih.fit_iht(Y, x, Z, k=9, verbose=False)
-    o = oracle.fit_mv(ox, Y, Z, k=9)
-    assert res.iter == o["iter"] and np.array_equal(res.beta != 0, o["B"] != 0)
-    np.testing.assert_allclose(res.beta, o["B"], rtol=1e-5, atol=1e-12)
-    np.testing.assert_allclose(res.c, o["C"], rtol=1e-5, atol=1e-12)
-    np.testing.assert_allclose(res.Σ, o["Sigma"], rtol=1e-8)
-
-
 # ---- BASELINE.json configs at their own sizes / trait counts (VERDICT r1, "configs_untested") -------------------------
 def test_config0_normal_bed_k9_against_g1b(mih, normal_pair, normal_data):
     """configs[0]: fit_iht on data/normal.bed, k = 9, Normal, intercept only (README.md:104) on the GPU against the
@@ -2351,98 +1405,6 @@ def test_config0_normal_bed_k9_against_g1b(mih, normal_pair, normal_data):
     assert res.logl == pytest.approx(-1612.734968, abs=1e-5)
     assert list(np.flatnonzero(res.beta) + 1) == [1266, 3137, 4246, 4717, 6290, 7629, 7755, 8375, 9415]
     assert res.c[0] == pytest.approx(1.65222721, abs=1e-7)
-
-
-def test_config4_multivariate_r10(mih, oracle, normal_pair):
-    """configs[4]'s trait count: MvNormal with r = 10 traits (10 x 10 pivoted Cholesky step size, ten residuals in one
-    fused four-operand pass with two idle residual slots) against oracle.fit_mv, plus cv_iht with r = 10 (two fits in
-    flight per lock-step round)."""
-    x, ox = normal_pair
-    rng = np.random.default_rng(410)
-    Y, Z = _mv_problem(oracle, ox, rng, 10, 40, 2)
-    res = mih.fit_iht(Y, x, Z, k=40, verbose=False)
-    o = oracle.fit_mv(ox, Y, Z, k=40)
-    assert res.iter == o["iter"] and res.iter >= 5
-    assert np.array_equal(res.beta != 0, o["B"] != 0)
-    np.testing.assert_allclose(res.beta, o["B"], rtol=1e-5, atol=1e-12)
-    np.testing.assert_allclose(res.c, o["C"], rtol=1e-5, atol=1e-12)
-    np.testing.assert_allclose(res.Σ, o["Sigma"], rtol=1e-6)
-    assert res.logl == pytest.approx(o["logl"], rel=1e-9)
-    assert list(res.trace["backtracks"]) == list(o["bt_trace"])
-    assert res.beta.shape == (10, x.p) and np.count_nonzero(res.beta) <= 40
-    folds = hash_folds(ox.n, 3)
-    path = [10, 25, 40, 60]
-    mse, raw = mih.cv_iht(Y, x, Z, path=path, q=3, folds=folds, verbose=False, return_raw=True)
-    omse, oraw = oracle.cv_mv(ox, Y, Z, path=path, q=3, folds=folds)
-    np.testing.assert_allclose(raw, oraw, rtol=1e-6)
-    np.testing.assert_allclose(mse, omse, rtol=1e-6)
-
-
-@pytest.mark.parametrize("r", [6, 7, 8, 9, 11, 12])
-def test_multivariate_trait_counts_of_every_product_kernel_shape(mih, oracle, normal_pair, r):
-    """The multi-trait X*B kernel is instantiated for 4, 6, 8, 10 and 12 traits per thread (csrc/xv.hip, k_xv_snp_cached_mt:
-    padded coefficient records and column offsets, batches of eight columns): trait counts the sweeps (2 .. 5) and configs[4]
-    (10) do not reach, with support sizes that are not multiples of eight, against oracle.fit_mv."""
-    x, ox = normal_pair
-    rng = np.random.default_rng(600 + r)
-    k = 13 + r                                        # 19 .. 25 entries: supports of 8 m + 1 .. 8 m + 7 columns among them
-    Y, Z = _mv_problem(oracle, ox, rng, r, 9, 2)
-    res = mih.fit_iht(Y, x, Z, k=k, verbose=False, max_iter=30)
-    o = oracle.fit_mv(ox, Y, Z, k=k, max_iter=30)
-    assert res.iter == o["iter"] and res.iter >= 4
-    assert np.array_equal(res.beta != 0, o["B"] != 0)
-    np.testing.assert_allclose(res.beta, o["B"], rtol=1e-5, atol=1e-12)
-    np.testing.assert_allclose(res.c, o["C"], rtol=1e-5, atol=1e-12)
-    np.testing.assert_allclose(res.Σ, o["Sigma"], rtol=1e-6)
-    assert res.logl == pytest.approx(o["logl"], rel=1e-9)
-    assert list(res.trace["backtracks"]) == list(o["bt_trace"])
-
-
-def test_config4_multivariate_r10_at_full_row_count(mih, oracle):
-    """r = 10 traits, k = 500 / 20 scaled to the column count, at n = 500 000 rows against the oracle."""
-    n, p = 500_000, 256
-    x = mih.SnpLinAlg.synthetic(n, p, seed=2024)
-    ox = oracle.Mat.from_bed_columns(x.export_bed(), n)
-    rng = np.random.default_rng(15)
-    Y, Z = _mv_problem(oracle, ox, rng, 10, 25, 1)
-    res = mih.fit_iht(Y, x, Z, k=25, verbose=False)
-    o = oracle.fit_mv(ox, Y, Z, k=25)
-    assert res.iter == o["iter"] and np.array_equal(res.beta != 0, o["B"] != 0)
-    np.testing.assert_allclose(res.beta, o["B"], rtol=1e-5, atol=1e-12)
-    np.testing.assert_allclose(res.c, o["C"], rtol=1e-5, atol=1e-12)
-    np.testing.assert_allclose(res.Σ, o["Sigma"], rtol=1e-8)
-    assert res.logl == pytest.approx(o["logl"], rel=1e-10)
-
-
-def test_config1_dense_f64_full_size(mih):
-    """configs[1] at its own size: Matrix{Float64} 50 000 x 100 000 (40 GB synthetic, on the device).  The oracle cannot
-    hold it, so: X'r against numpy on 64 sampled columns (fetched as X e_j), linearity, bit-reproducibility, fused
-    multi-RHS bits, and one k = 100 fit whose returned model reproduces its own loglikelihood on the host."""
-    n, p, k = 50_000, 100_000, 100
-    x = mih.DenseMatrix.synthetic(n, p, seed=7)
-    rng = np.random.default_rng(71)
-    r1, r2 = rng.standard_normal(n), rng.standard_normal(n)
-    g1, g2 = x.xtv(r1), x.xtv(r2)
-    assert np.array_equal(g1, x.xtv(r1))                                   # bit-reproducible
-    both = x.xtv(np.column_stack([r1, r2]))
-    assert np.array_equal(both[:, 0], g1) and np.array_equal(both[:, 1], g2)      # fused passes: same bits
-    np.testing.assert_allclose(x.xtv(2.0 * r1 - 0.5 * r2), 2.0 * g1 - 0.5 * g2, rtol=0, atol=1e-9 * np.abs(g1).max())
-    sample = np.sort(rng.choice(p, 64, replace=False))
-    cols = np.stack([x.xv_sparse(np.array([j]), np.array([1.0])) for j in sample], axis=1)        # n x 64
-    np.testing.assert_allclose(g1[sample], cols.T @ r1, rtol=0, atol=1e-11 * np.sqrt(n))
-    supp = np.sort(rng.choice(p, k, replace=False))
-    beta = rng.choice([-1.0, 1.0], k) * rng.uniform(0.3, 1.0, k)
-    y = x.xv_sparse(supp, beta) + 1.0 + rng.standard_normal(n)
-    res = mih.fit_iht(y, x, None, k=k, verbose=False)
-    nz = np.flatnonzero(res.beta)
-    assert nz.size == k and np.array_equal(nz, supp)                        # every effect is >= 0.3 sd: full recovery
-    np.testing.assert_allclose(res.beta[nz], beta, atol=0.03)
-    assert np.all(np.diff(res.trace["logl"]) >= -1e-9 * np.abs(res.trace["logl"][:-1]))     # monotone ascent
-    resid = y - (x.xv_sparse(nz, res.beta[nz]) + res.c[0])
-    phi = resid @ resid / n
-    logl_host = -0.5 * n * (np.log(2 * np.pi * phi) + 1.0)
-    assert res.logl == pytest.approx(logl_host, rel=1e-10)
-
 
 def test_bench_workload_fewer_columns_against_oracle(mih, oracle):
     """The bench.py workload (configs[2]: n = 500 000, k = 200, Normal) with 60 000 of its 1 000 000 columns, GPU against
@@ -2460,46 +1422,6 @@ def test_bench_workload_fewer_columns_against_oracle(mih, oracle):
     np.testing.assert_allclose(res.beta, o["beta"], rtol=0, atol=1e-12)
     assert res.logl == pytest.approx(o["logl"], rel=1e-12)
 
-
-def test_naive_impute(mih, tmp_path):
-    """naive_impute (src/utilities.jl:862-899): missing entries -> the SNP's most frequent genotype, ties resolved in the
-    order of the reference's if / elseif chain (0x02, then 0x03, then 0x00); every other entry and the file header are
-    unchanged.  Bit-exact against a direct numpy statement of that loop."""
-    rng = np.random.default_rng(862)
-    n, p = 1003, 257
-    cols = make_bed(rng, n, p, missing_rate=0.07)
-    code = np.stack([(cols[:, i // 4] >> (2 * (i % 4))) & 3 for i in range(n)], axis=1)          # p x n PLINK codes
-    # force ties: column 5 gets equal 0x00 and 0x02 counts, column 6 equal 0x02 and 0x03, column 7 equal 0x00 and 0x03
-    for j, (a, b) in ((5, (0, 2)), (6, (2, 3)), (7, (0, 3))):
-        code[j, :] = 1
-        code[j, 0:300] = a
-        code[j, 300:600] = b
-        code[j, 600:650] = ({0, 2, 3} - {a, b}).pop()
-    padded = np.zeros((p, ((n + 3) // 4) * 4), dtype=np.uint8)
-    padded[:, :n] = code
-    cols = (padded[:, 0::4] | (padded[:, 1::4] << 2) | (padded[:, 2::4] << 4) | (padded[:, 3::4] << 6)).astype(np.uint8)
-    want = code.copy()
-    for j in range(p):
-        e0, e1, e2 = (code[j] == 0).sum(), (code[j] == 2).sum(), (code[j] == 3).sum()
-        most = max(e0, e1, e2)
-        fill = 2 if most == e1 else 3 if most == e2 else 0
-        want[j, code[j] == 1] = fill
-    assert want[5, 700] == 2 and want[6, 700] == 2 and want[7, 700] == 3                       # the tie rules fired
-    dest = tmp_path / "imputed.bed"
-    mih.naive_impute(cols, str(dest), n=n)
-    raw = np.fromfile(dest, dtype=np.uint8)
-    assert bytes(raw[:3]) == b"\x6c\x1b\x01" and raw.size == 3 + p * ((n + 3) // 4)
-    got = raw[3:].reshape(p, -1)
-    gcode = np.stack([(got[:, i // 4] >> (2 * (i % 4))) & 3 for i in range(n)], axis=1)
-    assert np.array_equal(gcode, want)
-    assert not np.any(gcode == 1)
-    if n % 4:                                                                                   # padding bits of the last byte stay 0
-        assert np.all(got[:, -1] >> (2 * (n % 4)) == 0)
-    # a SnpLinAlg built from the imputed file has no missing entries and the same non-missing genotypes
-    x2 = mih.SnpLinAlg(mih.read_bed(str(dest), n), n)
-    assert np.array_equal(x2.export_bed(), got)
-
-
 def test_c_abi_harness_reproduces_the_recorded_run(mih, tmp_path):
     """tests/abi_harness.c (plain C, dlopen, no ctypes mirrors) runs the reference's recorded fit (G1) and a small
     cross-validation through mih_snp_create / mih_fit_iht / mih_cv_iht -- the calls a Julia ccall binding makes."""
@@ -2509,7 +1431,6 @@ def test_c_abi_harness_reproduces_the_recorded_run(mih, tmp_path):
     r = subprocess.run([str(exe), mih.library_path(), FIX], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "PASS" in r.stdout and "5 iterations" in r.stdout
-
 
 def test_native_rccl_communicator_world1(mih, normal_pair, normal_data):
     """mih_comm_create_rccl: the library's own RCCL communicator behind the `mih_comm` of a column-sharded fit.  The test
@@ -2533,451 +1454,6 @@ def test_native_rccl_communicator_world1(mih, normal_pair, normal_data):
     one = mih.fit_iht(yb, x, z, **kw)
     sh = D.fit_iht_sharded(yb, x, z, col_offset=0, p_global=x.p, native=True, **kw)
     assert sh.iter == one.iter and np.array_equal(sh.beta, one.beta) and sh.logl == one.logl
-
-
-def test_session_run_is_k_session_steps(mih, normal_pair, normal_data):
-    """mih_session_run(K) (what bench.py times) = K calls of mih_session_step: same loglikelihood, backtracks and model."""
-    x, _ = normal_pair
-    y, z = normal_data["y"], normal_data["z"]
-    a = mih.IHTSession(y, x, z, k=9)
-    b = mih.IHTSession(y, x, z, k=9)
-    nbt = 0
-    for _ in range(4):
-        la, bt, ta = a.step()
-        nbt += bt
-    lb, btb, tb = b.run(4)
-    assert la == lb and ta == tb and nbt == btb
-    (ba, ca), (bb, cb) = a.model(), b.model()
-    assert np.array_equal(ba, bb) and np.array_equal(ca, cb)
-    a.close(); b.close()
-
-
-def _same_fit(a, b, what):
-    assert a.iter == b.iter, (what, a.iter, b.iter)
-    assert list(a.trace["backtracks"]) == list(b.trace["backtracks"]), what
-    assert np.array_equal(np.flatnonzero(a.beta), np.flatnonzero(b.beta)), what
-    # every sum of the resident chain is formed in the host-driven kernels' order; only the scalar log / lgamma of the
-    # loglikelihood's closed form comes from another libm (device against host): the last bit of the trace may differ
-    np.testing.assert_allclose(a.trace["logl"], b.trace["logl"], rtol=4e-16, atol=0, err_msg=what)
-    assert np.array_equal(a.trace["tol"], b.trace["tol"]), what
-    assert np.array_equal(a.beta, b.beta) and np.array_equal(a.c, b.c), what
-    assert np.array_equal(a.mu, b.mu), what
-    assert a.choose_fired == b.choose_fired, what
-
-
-def test_resident_steps_equal_host_driven_steps(mih, oracle, normal_pair, normal_data):
-    """(VERDICT r4 item 1) iht_one_step! resident on the device (mih_fit_params::step_mode = 0: the iterate, the finish of
-    project_k!, the backtracking decision and the stopping rule in device memory, one record per step for the host) against
-    the host-driven step of rounds 1-4 (step_mode = 1): the same iteration log, support, estimates and fitted means -- bit for
-    bit, since every sum is formed in the same order -- over families, covariates with and without zkeep (up to six), prior weights,
-    init_beta, imputed missing entries, steps that backtrack, a step budget that runs out, and exact ties (the device hands
-    those steps back: _choose!)."""
-    x, ox = normal_pair
-    y, z, n = normal_data["y"], normal_data["z"], normal_data["n"]
-    rng = np.random.default_rng(4242)
-    cases = []
-    cases.append(("G1 normal + covariates", dict(y=y, x=x, z=z, k=7)))
-    cases.append(("normal k=12 intercept only", dict(y=y, x=x, z=None, k=12)))
-    cases.append(("zkeep = [1, 0]", dict(y=y, x=x, z=z, k=9, zkeep=[1, 0])))
-    cases.append(("zkeep = [0, 0]", dict(y=normal_data["y2"], x=x, z=z, k=9, zkeep=[0, 0])))
-    wts = 0.5 + rng.random(x.p)
-    cases.append(("prior weights", dict(y=y, x=x, z=z, k=8, weight=wts)))
-    cases.append(("init_beta", dict(y=y, x=x, z=z, k=7, init_beta=True)))
-    cases.append(("max_iter = 3", dict(y=y, x=x, z=z, k=7, max_iter=3)))
-    cases.append(("max_iter = 1", dict(y=y, x=x, z=z, k=7, max_iter=1)))
-    cases.append(("min_iter = 9, tight tol", dict(y=y, x=x, z=z, k=7, min_iter=9, tol=1e-9)))
-    eta = _sim(oracle, ox, rng, 8)
-    yb = (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float)
-    cases.append(("bernoulli/logit", dict(y=yb, x=x, z=None, k=8, d=mih.Bernoulli(), l=mih.LogitLink())))
-    cases.append(("bernoulli/probit", dict(y=yb, x=x, z=z, k=6, d=mih.Bernoulli(), l=mih.ProbitLink())))
-    yp = rng.poisson(np.exp(0.3 * eta)).astype(float)
-    cases.append(("poisson/log", dict(y=yp, x=x, z=None, k=8, d=mih.Poisson(), l=mih.LogLink())))
-    cases.append(("poisson/log max_step=1", dict(y=yp, x=x, z=z, k=10, d=mih.Poisson(), l=mih.LogLink(), max_step=1)))
-    ynb = rng.negative_binomial(10, 10 / (np.exp(0.3 * eta) + 10)).astype(float)
-    cases.append(("negbin/log fixed r", dict(y=ynb, x=x, z=None, k=8, d=mih.NegativeBinomial(10.0), l=mih.LogLink())))
-    yg = rng.gamma(2.0, np.exp(0.2 * eta) / 2.0)
-    cases.append(("gamma/log", dict(y=yg, x=x, z=None, k=6, d=mih.Gamma(), l=mih.LogLink())))
-    xm = mih.SnpLinAlg.synthetic(6001, 900, seed=3, missing_rate=0.01)           # imputed entries: the split kernels
-    supp = np.sort(rng.choice(900, 8, replace=False))
-    em = xm.xv_sparse(supp, rng.standard_normal(8) * 0.6)
-    zm = np.column_stack([np.ones(6001), rng.standard_normal(6001)])
-    cases.append(("missing entries, normal", dict(y=em + 0.5 + rng.standard_normal(6001), x=xm, z=zm, k=8)))
-    cases.append(("missing entries, bernoulli", dict(y=(rng.random(6001) < 1 / (1 + np.exp(-em))).astype(float), x=xm, z=zm, k=6,
-                                                     d=mih.Bernoulli(), l=mih.LogitLink())))
-    # six covariates, three of them competing in the projection: k_res_stats takes Z'r four covariates at a time (two slices of its
-    # grid), the covariate tail rides in the select; a 1537-row matrix: two of the 1024-row workgroups of the X_S v kernels, the second ragged
-    z6 = np.column_stack([np.ones(6001)] + [rng.standard_normal(6001) for _ in range(5)])
-    cases.append(("six covariates, poisson", dict(y=rng.poisson(np.exp(0.25 * em + 0.2 * z6[:, 3])).astype(float), x=xm, z=z6, k=7,
-                                                  zkeep=[1, 1, 0, 0, 1, 0], d=mih.Poisson(), l=mih.LogLink())))
-    xs = mih.SnpLinAlg.synthetic(1537, 700, seed=11)
-    es = xs.xv_sparse(np.array([5, 77, 300, 699]), np.array([0.8, -0.6, 0.5, 0.7]))
-    z6s = z6[:1537]
-    cases.append(("six covariates, normal, 1537 rows", dict(y=es + z6s @ np.array([0.3, 0.2, 0.0, -0.4, 0.1, 0.0]) + rng.standard_normal(1537), x=xs, z=z6s,
-                                                            k=6, zkeep=[1, 0, 0, 0, 0, 0])))
-    cols, yt, tied = tied_case()
-    xt = mih.SnpLinAlg(cols, n=1000, center=True, scale=True, impute=True)
-    cases.append(("exact ties: _choose!", dict(y=yt, x=xt, z=None, k=2)))
-    nbt_seen, tally = 0, dict(resident_steps=0, resident_attempts=0, resident_handbacks=0, resident_direct=0, resident_redos=0)
-    for what, kw in cases:
-        kw = dict(kw)
-        yy, xx, zz = kw.pop("y"), kw.pop("x"), kw.pop("z")
-        mih.profile_enable(xx, True)
-        mih.profile_counters(xx, reset=True)
-        a = mih.fit_iht(yy, xx, zz, verbose=False, step_mode=0, **kw)
-        cnt = mih.profile_counters(xx, reset=True)
-        b = mih.fit_iht(yy, xx, zz, verbose=False, step_mode=1, **kw)
-        host = mih.profile_counters(xx, reset=True)
-        mih.profile_enable(xx, False)
-        _same_fit(a, b, what)
-        nbt_seen += int(np.sum(a.trace["backtracks"]))
-        # the steps of the step_mode = 0 fit really ran on the device (all but those it handed back), none of the other fit's did
-        steps = len(a.trace["logl"])
-        assert cnt["resident_steps"] + cnt["resident_handbacks"] == steps, (what, cnt, steps)
-        assert cnt["resident_attempts"] <= int(np.sum(a.trace["backtracks"])), (what, cnt)
-        assert host["resident_steps"] == 0 and host["resident_handbacks"] == 0, (what, host)
-        if "ties" in what:
-            assert cnt["resident_handbacks"] >= 1, (what, cnt)
-        else:
-            assert cnt["resident_handbacks"] == 0, (what, cnt)       # (attempts the forecast had queued in advance are not counted)
-        for key in tally:
-            tally[key] += cnt[key]
-    assert nbt_seen > 0 and tally["resident_attempts"] > 0        # some of those steps backtracked: the re-queued attempts were exercised
-    assert tally["resident_steps"] > 60, tally
-    # most projections after a fit's first steps take the direct gather (a verified forecast of the threshold); some forecasts fail
-    # and are redone with the histogram sweeps -- same results either way (the comparisons above)
-    assert tally["resident_direct"] > 40 and tally["resident_redos"] < tally["resident_direct"] // 4, tally
-    assert mih.fit_iht(yt, xt, None, k=2, verbose=False, step_mode=0).choose_fired
-
-
-def test_resident_lockstep_equals_host_driven(mih, oracle, normal_pair, normal_data):
-    """ The lock-step lanes' fits run their steps resident on the device too (round 6): behind the lane's fused
-    pass a fit queues Z'r, df on its support, the step's start and its attempt slots without waiting and reads ONE record when
-    the lane collects the residuals of its next pass.  step_mode 0 (resident) against step_mode 1 (host-driven, rounds 1-5):
-    the same held-out losses BIT FOR BIT -- Normal with covariates on a matrix with imputed entries (two lanes, a tail hand-over),
-    logistic, Poisson with backtracking, init_beta, a model path -- and the counters say which way the steps ran.  Fits the
-    resident chain does not take (debias, est_r) step host-driven in either mode."""
-    xm = mih.SnpLinAlg.synthetic(6001, 900, seed=3, missing_rate=0.01)
-    rng = np.random.default_rng(606)
-    supp = np.sort(rng.choice(900, 8, replace=False))
-    em = xm.xv_sparse(supp, rng.standard_normal(8) * 0.6)
-    zm = np.column_stack([np.ones(6001), rng.standard_normal(6001)])
-    yn = em + 0.5 + 0.3 * zm[:, 1] + rng.standard_normal(6001)
-    yb = (rng.random(6001) < 1 / (1 + np.exp(-em))).astype(float)
-    yp = rng.poisson(np.exp(0.3 * em)).astype(float)
-    folds = hash_folds(6001, 5)
-    x, _ = normal_pair
-    y, z = normal_data["y"], normal_data["z"]
-    runs = {
-        "normal, 5 x 12 (two lanes)": lambda: mih.cv_iht(yn, xm, zm, path=range(1, 13), q=5, folds=folds, verbose=False, return_raw=True)[1],
-        "logistic": lambda: mih.cv_iht(yb, xm, None, path=range(2, 9), q=5, folds=folds, verbose=False, return_raw=True, d=mih.Bernoulli(), l=mih.LogitLink())[1],
-        "poisson": lambda: mih.cv_iht(yp, xm, zm, path=[3, 6, 9], q=5, folds=folds, verbose=False, return_raw=True, d=mih.Poisson(), l=mih.LogLink())[1],
-        "init_beta": lambda: mih.cv_iht(yn, xm, zm, path=range(1, 9), q=3, folds=hash_folds(6001, 3), verbose=False, return_raw=True, init_beta=True)[1],
-        "zkeep = [1, 0]": lambda: mih.cv_iht(y, x, z, path=range(4, 10), q=3, folds=hash_folds(1000, 3), verbose=False, return_raw=True, zkeep=[1, 0])[1],
-        "model path": lambda: np.asarray(mih.iht_run_many_models(y, x, z, path=range(1, 11), verbose=False)),
-    }
-    got = {}
-    for mode in (0, 1):
-        mih.set_step_mode(mode)
-        try:
-            for name, fn in runs.items():
-                mat = x if ("zkeep" in name or "path" in name) else xm
-                mih.profile_enable(mat, True)
-                mih.profile_counters(mat, reset=True)
-                out = fn()
-                cnt = mih.profile_counters(mat, reset=True)
-                mih.profile_enable(mat, False)
-                got[(mode, name)] = (out, cnt)
-        finally:
-            mih.set_step_mode(0)
-    backtracked = 0
-    for name in runs:
-        (a, ca), (b, cb) = got[(0, name)], got[(1, name)]
-        assert np.array_equal(np.asarray(a).view(np.uint64), np.asarray(b).view(np.uint64)), name
-        assert ca["scores"] == cb["scores"] and ca["fits"] == cb["fits"], (name, ca, cb)
-        assert cb["resident_steps"] == 0 and cb["resident_handbacks"] == 0, (name, cb)
-        assert ca["resident_steps"] + ca["resident_handbacks"] == ca["scores"] > 0, (name, ca)
-        assert ca["resident_handbacks"] == 0, (name, ca)
-        backtracked += ca["resident_attempts"] + ca["resident_redos"]
-    assert got[(0, "normal, 5 x 12 (two lanes)")][1]["lanes"] == 2
-    # fits the chain does not take: the same results, no resident step
-    mih.profile_enable(xm, True)
-    mih.profile_counters(xm, reset=True)
-    d0 = mih.cv_iht(yb, xm, None, path=[3, 5], q=3, folds=hash_folds(6001, 3), verbose=False, return_raw=True, d=mih.Bernoulli(), l=mih.LogitLink(), debias=True, max_iter=30)[1]
-    assert mih.profile_counters(xm, reset=True)["resident_steps"] == 0 and np.count_nonzero(d0) == 6
-    mih.profile_enable(xm, False)
-    # ... and the resident lanes against the oracle, directly
-    ox = oracle.Mat.from_bed_columns(xm.export_bed(), 6001)
-    _, want = oracle.cv_iht(ox, yb, None, path=list(range(2, 9)), q=5, folds=folds, dist="bernoulli", link="logit")
-    np.testing.assert_allclose(np.asarray(got[(0, "logistic")][0]).reshape(want.shape), want, rtol=1e-8)
-
-
-def test_resident_session_keeps_the_iterate_on_the_device(mih, normal_pair, normal_data):
-    """mih_session_step / _run / _model with the iterate resident on the device: single steps, a run of steps, the model read in
-    between (the iterate comes home and goes back) -- all equal to the host-driven session, step for step."""
-    x, _ = normal_pair
-    y, z = normal_data["y"], normal_data["z"]
-    a = mih.IHTSession(y, x, z, k=9, step_mode=0)
-    b = mih.IHTSession(y, x, z, k=9, step_mode=1)
-    for _ in range(2):
-        assert a.step() == b.step()
-    (ba, ca), (bb, cb) = a.model(), b.model()
-    assert np.array_equal(ba, bb) and np.array_equal(ca, cb)
-    la, bta, ta = a.run(5)
-    lb, btb, tb = b.run(5)
-    assert abs(la - lb) <= 4e-16 * abs(lb) and bta == btb and ta == tb
-    assert a.step()[1:] == b.step()[1:]
-    (ba, ca), (bb, cb) = a.model(), b.model()
-    assert np.array_equal(ba, bb) and np.array_equal(ca, cb)
-    a.close(); b.close()
-
-
-_HANDBACK_SNIPPET = r"""
-import os, sys, numpy as np
-sys.path.insert(0, sys.argv[1])
-import mendeliht_amd as m
-n = 1000
-x = m.SnpLinAlg(m.read_bed(os.path.join(sys.argv[1], "tests", "fixtures", "normal.bed"), n), n, center=True, scale=True, impute=True)
-rng = np.random.default_rng(4242)
-supp = np.sort(rng.choice(x.p, 8, replace=False))
-eta = x.xv_sparse(supp, rng.standard_normal(8) * 0.5)
-z = np.column_stack([np.ones(n), rng.standard_normal(n)])
-yp = rng.poisson(np.exp(0.3 * eta)).astype(float)
-yb = (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float)
-xm = m.SnpLinAlg.synthetic(6001, 900, seed=3, missing_rate=0.01)
-em = xm.xv_sparse(np.sort(rng.choice(900, 8, replace=False)), rng.standard_normal(8) * 0.6)
-ym = rng.poisson(np.exp(0.25 * em)).astype(float)
-out = {}
-mode = int(os.environ.get("STEP_MODE", "0"))
-for tag, (yy, xx, zz, kw) in {"poisson": (yp, x, z, dict(k=10, d=m.Poisson(), l=m.LogLink())),
-                              "bernoulli": (yb, x, None, dict(k=8, d=m.Bernoulli(), l=m.LogitLink())),
-                              "missing": (ym, xm, None, dict(k=7, d=m.Poisson(), l=m.LogLink()))}.items():
-    m.profile_enable(xx, True)
-    m.profile_counters(xx, reset=True)
-    r = m.fit_iht(yy, xx, zz, verbose=False, step_mode=mode, **kw)
-    c = m.profile_counters(xx, reset=True)
-    out[tag + "_beta"], out[tag + "_c"], out[tag + "_mu"] = r.beta, r.c, r.mu
-    out[tag + "_logl"], out[tag + "_tol"], out[tag + "_bt"] = r.trace["logl"], r.trace["tol"], np.asarray(r.trace["backtracks"], dtype=np.float64)
-    out[tag + "_counts"] = np.array([c["resident_steps"], c["resident_handbacks"]], dtype=np.float64)
-np.savez(sys.argv[2], **out)
-"""
-
-
-def test_handback_after_rejected_attempts(mih, tmp_path):
-    """ A step the device hands back AFTER it has rejected attempts: those attempts' sweeps have overwritten xb,
-    zc and mu with the rejected candidates' values, and the host-driven replay begins with iht_stepsize!, which reads them.
-    res_end now forms them again from the iterate that comes home.  The measurement build hands back every step that has
-    backtracked once (MENDELIHT_RES_FORCE_ABORT_ES=1) -- Poisson with a covariate, logistic, and Poisson on a matrix with imputed
-    entries -- and every fit equals the host-driven one bit for bit (before the fix: a different step size after the first replay)."""
-    forced = _run_probe_snippet(_HANDBACK_SNIPPET, tmp_path / "forced.npz", extra_env={"MENDELIHT_RES_FORCE_ABORT_ES": "1", "STEP_MODE": "0"})
-    host = _run_probe_snippet(_HANDBACK_SNIPPET, tmp_path / "host.npz", extra_env={"STEP_MODE": "1"})
-    handbacks = 0
-    for tag in ("poisson", "bernoulli", "missing"):
-        for key in ("beta", "c", "mu", "tol", "bt"):
-            assert np.array_equal(forced[f"{tag}_{key}"].view(np.uint64), host[f"{tag}_{key}"].view(np.uint64)), (tag, key)
-        np.testing.assert_allclose(forced[f"{tag}_logl"], host[f"{tag}_logl"], rtol=4e-16, atol=0)
-        assert host[f"{tag}_counts"][0] == 0
-        # every step that backtracked was handed back, the others ran on the device
-        nbt_steps = int(np.count_nonzero(forced[f"{tag}_bt"]))
-        assert forced[f"{tag}_counts"][1] == nbt_steps, (tag, forced[f"{tag}_counts"], nbt_steps)
-        assert forced[f"{tag}_counts"][0] + forced[f"{tag}_counts"][1] == forced[f"{tag}_bt"].size
-        handbacks += nbt_steps
-    assert handbacks >= 3
-
-
-_NOSPIN_SNIPPET = r"""
-import sys, json, numpy as np
-sys.path.insert(0, sys.argv[1])
-import mendeliht_amd as m
-hash_folds = m.hash_folds
-x = m.SnpLinAlg.synthetic(6001, 900, seed=3, missing_rate=0.01)
-rng = np.random.default_rng(1)
-supp = np.sort(rng.choice(900, 8, replace=False))
-eta = x.xv_sparse(supp, rng.standard_normal(8) * 0.6)
-y = eta + 0.5 + rng.standard_normal(6001)
-yb = (rng.random(6001) < 1 / (1 + np.exp(-eta))).astype(float)
-z = np.column_stack([np.ones(6001), rng.standard_normal(6001)])
-out = {}
-r = m.fit_iht(y, x, z, k=8, verbose=False)
-out["beta"], out["c"], out["logl"] = r.beta, r.c, np.array([r.logl, r.iter])
-r = m.fit_iht(yb, x, z, k=5, d=m.Bernoulli(), l=m.LogitLink(), verbose=False)
-out["bbeta"], out["blogl"] = r.beta, np.array([r.logl, r.iter])
-_, raw = m.cv_iht(yb, x, z, path=range(1, 9), q=3, folds=hash_folds(6001, 3), verbose=False, return_raw=True, d=m.Bernoulli(), l=m.LogitLink())
-out["cv"] = raw
-out["path"] = np.asarray(m.iht_run_many_models(yb, x, z, path=range(1, 7), verbose=False, d=m.Bernoulli(), l=m.LogitLink()))
-Y = np.vstack([y, 0.5 * y + rng.standard_normal(6001), rng.standard_normal(6001)])
-r = m.fit_iht(Y, x, None, k=12, verbose=False, max_iter=10)
-out["mvbeta"], out["mvlogl"] = r.beta, np.array([r.logl, r.iter])
-_, raw = m.cv_iht(Y, x, None, path=[2, 5, 9, 14], q=3, folds=hash_folds(6001, 3), verbose=False, return_raw=True)
-out["mvcv"] = raw
-_, raw = m.cv_iht(y, x, z, path=range(1, 9), q=3, folds=hash_folds(6001, 3), verbose=False, return_raw=True, init_beta=True)
-out["cv_init_beta"] = raw
-_, raw = m.cv_iht(yb, x, z, path=range(2, 8), q=3, folds=hash_folds(6001, 3), verbose=False, return_raw=True, d=m.Bernoulli(), l=m.LogitLink(), debias=True, max_iter=30)
-out["cv_debias"] = raw
-np.savez(sys.argv[2], **out)
-"""
-
-
-def test_polled_readbacks_and_shared_initial_scores_change_nothing(mih, tmp_path):
-    """Switches that must not move a bit (each is read once per process, hence one process per variant): the polled readbacks
-    (k_publish / k_final_sum_pub + SpinFlag) against device-to-host copies + hipStreamSynchronize (MENDELIHT_NO_SPIN=1); the
-    cross-validation / model-path drivers with every fit riding its own initial score and without the tail hand-over
-    (MENDELIHT_CV_NO_INIT_SHARE=1, MENDELIHT_CV_NO_MERGE=1), with one lock-step lane instead of two, and with every buffer
-    of an IHTVariable as its own allocation instead of a carve-out of one block (MENDELIHT_NO_ARENA=1), and with the fits of a
-    lane walked one after the other on the lane's stream instead of as coroutines on streams of their own (MENDELIHT_CV_NO_COOP=1);
-    (round 6) the lanes' resident fits stepping through ONE batched chain per lane round instead of a chain per fit
-    (MENDELIHT_LANE_BATCHED=1: the k_lane_* kernels), the lanes' passes in single file on priority streams.
-    Univariate Normal and logistic fits, a cross-validation, a model path and a multivariate fit."""
-    res = []
-    # the first run is the PRODUCT library (which reads none of the switches), the others the measurement build of the same
-    # sources: the product's bits are also those of the measurement build's defaults
-    for i, extra in enumerate((None, {}, {"MENDELIHT_NO_SPIN": "1"}, {"MENDELIHT_CV_NO_INIT_SHARE": "1", "MENDELIHT_CV_NO_MERGE": "1"},
-                               {"MENDELIHT_CV_LANES": "1"}, {"MENDELIHT_NO_ARENA": "1"}, {"MENDELIHT_CV_NO_COOP": "1"},
-                               {"MENDELIHT_LANE_BATCHED": "1"}, {"MENDELIHT_CV_PASS_ORDER": "1", "MENDELIHT_WORKER_PRIORITY": "1"},
-                               {"MENDELIHT_LANE_BATCHED": "1", "MENDELIHT_CV_NO_COOP": "1"})):
-        res.append(_run_probe_snippet(_NOSPIN_SNIPPET, tmp_path / f"variant_{i}.npz", extra_env=extra or {}, probes=extra is not None))
-    assert len(res[0].files) == 12
-    for other in res[1:]:
-        assert sorted(res[0].files) == sorted(other.files)
-        for k in res[0].files:
-            assert np.array_equal(res[0][k].view(np.uint64), other[k].view(np.uint64)), k
-    assert res[0]["logl"][1] > 2 and np.count_nonzero(res[0]["cv"]) == 24 and res[0]["path"].size == 6 and np.count_nonzero(res[0]["mvcv"]) == 12
-
-
-def _config3_problem(mih, n, p, seed=2024):
-    """BASELINE configs[3] in small: Bernoulli/Logit response with 10 true effects on a synthetic SnpArray, explicit hash folds."""
-    x = mih.SnpLinAlg.synthetic(n, p, seed=seed)
-    rng = np.random.default_rng(2025)
-    supp = np.sort(rng.choice(p, 10, replace=False))
-    eta = x.xv_sparse(supp, rng.standard_normal(10) * 0.5)
-    yb = (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float)
-    return x, yb, hash_folds(n, 5)
-
-
-def test_config3_full_size(mih, oracle):
-    """BASELINE configs[3] at its OWN size (VERDICT r3 "weak" 4): cv_iht Bernoulli/Logit, path = 1:20, 5 folds, all 100 fits on
-    the n = 500 000 x p = 1 000 000 synthetic SnpArray -- the run bench.py times, asserted here.  (1) the cross-validation
-    selects the planted model size; (2) the eight `rank = r, world = 8` shards -- what each GPU of a node runs -- add up to the
-    single-rank loss matrix bit for bit; (3) on the sub-problem of the first 100 000 columns of the SAME matrix (the generator is
-    keyed by (seed, column)) a 3 x 3 grid of held-out losses equals the oracle's (tools/validate_large.py promoted to a test;
-    the oracle needs ~0.4 s per X'r pass there, so the grid is what the CPU finishes in about a minute)."""
-    n, p = 500_000, 1_000_000
-    free_b = free_device_bytes()
-    if free_b < 170e9:
-        pytest.skip("needs 170 GB of free HBM")
-    x, yb, folds = _config3_problem(mih, n, p)
-    path = range(1, 21)
-    mse, raw = mih.cv_iht(yb, x, None, path=path, q=5, folds=folds, verbose=False, return_raw=True, d=mih.Bernoulli(), l=mih.LogitLink())
-    assert np.count_nonzero(raw) == 100 and np.all(raw > 0)
-    assert int(np.argmin(mse)) + 1 == 10                                    # ten planted effects (bench.py asserts the same)
-    total = np.zeros_like(raw)
-    for r in range(8):
-        part = mih.cv_iht(yb, x, None, path=path, q=5, folds=folds, verbose=False, return_raw=True, d=mih.Bernoulli(), l=mih.LogitLink(),
-                          rank=r, world=8)[1]
-        assert 12 <= np.count_nonzero(part) <= 13
-        assert np.array_equal(part[part != 0], raw[part != 0])
-        total += part
-    assert np.array_equal(total, raw)
-    del x
-    # the first 100 000 columns against the oracle (fewer if the host is short of memory: 12.5 GB of PLINK columns + the oracle's copy)
-    avail = 0
-    for ln in open("/proc/meminfo"):
-        if ln.startswith("MemAvailable"):
-            avail = int(ln.split()[1]) * 1024
-    ps = 100_000 if avail > 60e9 else 40_000
-    xs = mih.SnpLinAlg.synthetic(n, ps, seed=2024)
-    rng = np.random.default_rng(77)
-    supp = np.sort(rng.choice(ps, 10, replace=False))
-    eta = xs.xv_sparse(supp, rng.standard_normal(10) * 0.5)
-    ys = (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float)
-    f3 = hash_folds(n, 3)
-    sub = [5, 10, 15]
-    gm, graw = mih.cv_iht(ys, xs, None, path=sub, q=3, folds=f3, verbose=False, return_raw=True, d=mih.Bernoulli(), l=mih.LogitLink())
-    cols = xs.export_bed()
-    del xs
-    ox = oracle.Mat.from_bed_columns(cols, n)
-    del cols
-    nthreads = oracle.lib().orc_get_threads()
-    oracle.set_threads(16)                                                  # (more OpenMP threads than the container's CPU quota only slow it down)
-    try:
-        om, oraw = oracle.cv_iht(ox, ys, None, path=sub, q=3, folds=f3, dist="bernoulli", link="logit")
-    finally:
-        oracle.set_threads(nthreads)
-    np.testing.assert_allclose(graw, oraw, rtol=1e-4)                       # north_star: 1e-4 for GLM links
-    np.testing.assert_allclose(graw, oraw, rtol=1e-8)                       # what it is
-    np.testing.assert_allclose(gm, om, rtol=1e-8)
-
-
-def _config4_problem(x, rng, r, k, lo=0.15, hi=0.45):
-    """r traits on matrix x with k planted effects spread over the traits (each trait its own columns), an intercept per trait and
-    errors with an AR(1) covariance: returns Y (r x n), the planted B (r x p) as {trait: (columns, effects)} and Sigma."""
-    n, p = x.n, x.p
-    lin = rng.choice(r * p, k, replace=False)
-    Sigma = 0.5 ** np.abs(np.subtract.outer(np.arange(r), np.arange(r)))        # AR(1), rho = 0.5
-    L = np.linalg.cholesky(Sigma)
-    Y = L @ rng.standard_normal((r, n))
-    planted = {}
-    for t in range(r):
-        cols = np.unique(lin[lin % r == t] // r)
-        eff = rng.choice([-1.0, 1.0], cols.size) * rng.uniform(lo, hi, cols.size)
-        planted[t] = (cols, eff)
-        Y[t] += x.xv_sparse(cols, eff) + 1.0 + 0.1 * t
-    return Y, planted, Sigma
-
-
-def test_config4_full_size(mih, oracle):
-    """BASELINE configs[4] at its OWN size: MvNormal, r = 10 traits, k = 500, on the n = 500 000 x p = 1 000 000
-    synthetic SnpArray.  (1) the loglikelihood never falls, the planted support comes back, the estimates and the error
-    covariance are the planted ones to sampling error, and an iteration takes <= 30 ms (the 10-residual fused pass is ~26 ms);
-    (2) on the first 50 000 columns of the SAME matrix (the generator is keyed by (seed, column)) a k = 40 fit equals the oracle's
-    iteration for iteration (multivariate.jl:66-92, 220-254; test/multivariate_test.jl:58,72)."""
-    n, p, r, k = 500_000, 1_000_000, 10, 500
-    free_b = free_device_bytes()
-    if free_b < 170e9:
-        pytest.skip("needs 170 GB of free HBM")
-    x = mih.SnpLinAlg.synthetic(n, p, seed=2024)
-    rng = np.random.default_rng(404)
-    Y, planted, Sigma = _config4_problem(x, rng, r, k)
-    nplanted = sum(c.size for c, _ in planted.values())
-    mih.fit_iht(Y, x, None, k=k, verbose=False, max_iter=3)                  # warm-up: first-call work (workspaces out of the reserve)
-    res = mih.fit_iht(Y, x, None, k=k, verbose=False, max_iter=100)
-    assert 5 <= res.iter < 100
-    ll = np.asarray(res.trace["logl"])
-    assert np.all(np.diff(ll) >= -1e-9 * np.abs(ll[:-1]))                    # monotone ascent (multivariate.jl:226-254 backtracks otherwise)
-    assert res.beta.shape == (r, p) and np.count_nonzero(res.beta) <= k
-    hit = 0
-    for t, (cols, eff) in planted.items():
-        got = np.flatnonzero(res.beta[t])
-        hit += np.intersect1d(got, cols).size
-        both = np.intersect1d(got, cols)
-        np.testing.assert_allclose(res.beta[t][both], eff[np.searchsorted(cols, both)], atol=0.02)       # se ~ 1 / sqrt(n maf) << 0.02
-    assert hit >= 0.99 * nplanted, (hit, nplanted)
-    np.testing.assert_allclose(res.Σ, Sigma, atol=0.02)
-    np.testing.assert_allclose(res.c[:, 0], 1.0 + 0.1 * np.arange(r), atol=0.02)
-    per_iter_ms = 1e3 * res.time / res.iter
-    assert per_iter_ms <= 30.0, per_iter_ms
-    del x
-    # the first 50 000 columns against the oracle, iteration for iteration
-    ps, ks = 50_000, 40
-    xs = mih.SnpLinAlg.synthetic(n, ps, seed=2024)
-    Ys, _, _ = _config4_problem(xs, np.random.default_rng(405), r, ks)
-    gs = mih.fit_iht(Ys, xs, None, k=ks, verbose=False, max_iter=12)
-    cols = xs.export_bed()
-    del xs
-    ox = oracle.Mat.from_bed_columns(cols, n)
-    del cols
-    nthreads = oracle.lib().orc_get_threads()
-    oracle.set_threads(16)
-    try:
-        o = oracle.fit_mv(ox, Ys, None, k=ks, max_iter=12)
-    finally:
-        oracle.set_threads(nthreads)
-    assert gs.iter == o["iter"] and list(gs.trace["backtracks"]) == list(o["bt_trace"])
-    assert np.array_equal(gs.beta != 0, o["B"] != 0)
-    np.testing.assert_allclose(gs.beta, o["B"], rtol=1e-5, atol=1e-12)
-    np.testing.assert_allclose(gs.c, o["C"], rtol=1e-5, atol=1e-12)
-    np.testing.assert_allclose(gs.Σ, o["Sigma"], rtol=1e-8)
-    np.testing.assert_allclose(gs.trace["logl"], o["logl_trace"], rtol=1e-10)
-
 
 def test_config3_full_grid_against_oracle(mih, oracle):
     """The EXACT driver shape of BASELINE configs[3]: cv_iht Bernoulli/Logit, path = 1:20, q = 5 = 100
@@ -3034,69 +1510,6 @@ def test_config3_full_grid_against_oracle(mih, oracle):
         tot += part
     assert np.array_equal(tot.view(np.uint64), raw.view(np.uint64))             # bit-exact: a fit does not depend on its rank
 
-
-def test_config4_multivariate_r10_k500_against_oracle(mih, oracle):
-    """BASELINE configs[4]'s model size: MvNormal with r = 10 traits and k = 500 non-zero entries at
-    p = 20 000 SNPs against oracle.fit_mv (multivariate.jl:99-127: top-k over all r * p entries): same iterations, backtracks
-    and support, B and C to 1e-5, Sigma and the loglikelihood."""
-    n, p, r, k = 3_000, 20_000, 10, 500
-    x = mih.SnpLinAlg.synthetic(n, p, seed=41)
-    ox = oracle.Mat.from_bed_columns(x.export_bed(), n)
-    rng = np.random.default_rng(4100)
-    Y, Z = _mv_problem(oracle, ox, rng, r, k, 2)
-    res = mih.fit_iht(Y, x, Z, k=k, verbose=False, max_iter=60)
-    o = oracle.fit_mv(ox, Y, Z, k=k, max_iter=60)
-    assert res.iter == o["iter"] and res.iter >= 5
-    assert list(res.trace["backtracks"]) == list(o["bt_trace"])
-    assert np.count_nonzero(res.beta) == np.count_nonzero(o["B"]) and 400 <= np.count_nonzero(res.beta) <= k
-    assert np.array_equal(res.beta != 0, o["B"] != 0)
-    np.testing.assert_allclose(res.beta, o["B"], rtol=1e-5, atol=1e-12)
-    np.testing.assert_allclose(res.c, o["C"], rtol=1e-5, atol=1e-12)
-    np.testing.assert_allclose(res.Σ, o["Sigma"], rtol=1e-6)
-    assert res.logl == pytest.approx(o["logl"], rel=1e-9)
-
-
-def test_concurrent_fits_with_different_digit_formats(mih):
-    """The library has no process-wide kernel or format selector: the residual format travels with the call.
-    Two host threads fitting CONCURRENTLY on one shared matrix, one in the default 54-bit format and one in the 43-bit fast
-    format (plus a cross-validation in a third), must give the bits of the same calls run one after the other."""
-    import threading
-    n, p = 12_000, 3_000
-    x = mih.SnpLinAlg.synthetic(n, p, seed=77, missing_rate=0.01)
-    rng = np.random.default_rng(78)
-    supp = np.sort(rng.choice(p, 12, replace=False))
-    eta = x.xv_sparse(supp, rng.standard_normal(12) * 0.5)
-    Y = np.vstack([eta + rng.standard_normal(n), 0.5 * eta + rng.standard_normal(n), rng.standard_normal(n)])
-    yb = (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float)
-    folds = hash_folds(n, 3)
-    jobs = {
-        "mv_default": lambda: mih.fit_iht(Y, x, None, k=20, verbose=False, max_iter=30, xtv_digits=0).beta,
-        "mv_fast": lambda: mih.fit_iht(Y, x, None, k=20, verbose=False, max_iter=30, xtv_digits=4908).beta,
-        "cv_1316": lambda: mih.cv_iht(yb, x, None, path=range(1, 9), q=3, folds=folds, verbose=False, return_raw=True,
-                                      d=mih.Bernoulli(), l=mih.LogitLink(), xtv_digits=1316)[1],
-        "xtv_fast": lambda: x.xtv(Y.T.copy(), xtv_digits=4908),
-        "xtv_default": lambda: x.xtv(Y.T.copy()),
-    }
-    serial = {k: f() for k, f in jobs.items()}
-    assert not np.array_equal(serial["xtv_fast"], serial["xtv_default"])        # the formats really differ
-    for _ in range(3):
-        out, errs = {}, []
-
-        def run(name):
-            try:
-                out[name] = jobs[name]()
-            except Exception as e:                                              # noqa: BLE001
-                errs.append((name, e))
-        th = [threading.Thread(target=run, args=(k,)) for k in jobs]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        assert not errs, errs
-        for k in jobs:
-            assert np.array_equal(np.asarray(out[k]).view(np.uint64), np.asarray(serial[k]).view(np.uint64)), k
-
-
 def test_snplinalg_float32_callers(mih, normal_data):
     """T = Float32 (src/MendelIHT.jl:39: Float = Union{Float64, Float32}): SnpLinAlg{Float32} on the 2-bit path.  The device
     arithmetic does not depend on T, so the Float32 caller gets the Float64 fit, cast: same support, same iterations, beta equal
@@ -3113,7 +1526,6 @@ def test_snplinalg_float32_callers(mih, normal_data):
     np.testing.assert_allclose(r32.beta, r64.beta, rtol=2e-5, atol=1e-7)        # y, z themselves were rounded to Float32
     with pytest.raises(mih.MendelIHTError):
         mih.SnpLinAlg(bed, n, dtype=np.float16)
-
 
 @pytest.mark.parametrize("fam", ["normal", "bernoulli", "poisson"])
 def test_wrapper_three_input_routes_agree(mih, tmp_path, fam):
@@ -3153,7 +1565,6 @@ def test_wrapper_three_input_routes_agree(mih, tmp_path, fam):
     m3 = mih.cross_validate(prefix, d, covariates=str(tmp_path / "cov.txt"), phenotypes=str(tmp_path / "phen.txt"), **ckw)
     assert np.array_equal(m1, m2) and np.array_equal(m1, m3) and np.all(m1 > 0)           # test/cv_iht_test.jl: all(mses .> 0), path = 0:..
 
-
 def test_cv_init_beta_full_grid_against_oracle(mih, oracle):
     """cv_iht(init_beta = true) -- the setting of the reference's large real runs (manuscript/UKBB_hyptertension/ukbb.jl:16-18) --
     on the LOCK-STEP driver (round 3): path = 1:20, q = 5, Normal, two lanes; the p univariate regressions of initialize_beta!
@@ -3182,7 +1593,6 @@ def test_cv_init_beta_full_grid_against_oracle(mih, oracle):
     logl = mih.iht_run_many_models(y, x, z, path=range(1, 9), verbose=False)            # model path on the same driver
     assert np.all(np.diff(logl) > 0)
 
-
 def test_lockstep_error_paths_leave_the_library_usable(mih):
     """A fit that fails inside a lock-step round (NaN loglikelihood, fit.jl:259) fails the whole cross-validation with the
     reference's error -- from a coroutine of a lane, with the other fits of both lanes in flight -- and leaves nothing behind: the
@@ -3204,59 +1614,6 @@ def test_lockstep_error_paths_leave_the_library_usable(mih):
             mih.iht_run_many_models(bad, x, None, path=range(1, 9), verbose=False)
     after = mih.cv_iht(y, x, None, **kw)[1]
     assert np.array_equal(before.view(np.uint64), after.view(np.uint64))
-
-
-def test_ingest_pipeline_at_full_row_count(mih):
-    """mih_snp_create's upload pipeline (round 3: eight workers with their own streams pulling 16 MB chunks of whole column groups
-    from one queue) at the row count of the benchmark: 3000 columns of n = 500 000 (375 MB, 24 chunks, a ragged last one) with
-    missing genotypes must give the matrix the on-device generator built -- same bytes back out, same column statistics, same
-    X'r bits."""
-    n, p = 500_000, 3000
-    xs = mih.SnpLinAlg.synthetic(n, p, seed=31, missing_rate=0.01)
-    cols = xs.export_bed()
-    x = mih.SnpLinAlg(cols, n=n, center=True, scale=True, impute=True)
-    assert np.array_equal(x.export_bed(), cols)
-    mu_s, sv_s = xs.mu_sigma()
-    mu, sv = x.mu_sigma()
-    assert np.array_equal(mu, mu_s) and np.array_equal(sv, sv_s)
-    r = np.random.default_rng(3).standard_normal(n)
-    assert np.array_equal(x.xtv(r), xs.xtv(r))
-    # a strided source (col_stride_bytes > ceil(n/4)) through the same pipeline
-    wide = np.zeros((p, cols.shape[1] + 37), dtype=np.uint8)
-    wide[:, :cols.shape[1]] = cols
-    x2 = mih.SnpLinAlg(wide, n=n, center=True, scale=True, impute=True)
-    assert np.array_equal(x2.export_bed(), cols)
-
-
-def test_ingest_of_a_tall_matrix_stays_within_the_staging_budget(mih):
-    """ A chunk of the upload pipeline is at least one group of 32 columns, so above a 512 KB column stride it outgrows
-    the 16 MB target: at n = 4.4M rows (1.1 MB per column) a chunk is 35 MB and eight workers with two buffers each would pin 560 MB
-    of host memory and take as much VRAM; mih_snp_create caps the staging of all workers at 512 MB (fewer workers) and degrades
-    to one worker if the allocation fails.  The matrix must be the one the on-device generator builds: same bytes back out, same
-    column statistics, same X'r bits (n > 2^22 rows: the fused formats step down, §3.1), incl. a strided source and a ragged
-    last chunk (70 columns = 32 + 32 + 6)."""
-    n, p = 4_400_000, 70
-    xs = mih.SnpLinAlg.synthetic(n, p, seed=77, missing_rate=0.002)
-    cols = xs.export_bed()
-    assert cols.shape == (p, (n + 3) // 4)
-    x = mih.SnpLinAlg(cols, n=n, center=True, scale=True, impute=True)
-    assert np.array_equal(x.export_bed(), cols)
-    mu_s, sv_s = xs.mu_sigma()
-    mu, sv = x.mu_sigma()
-    assert np.array_equal(mu, mu_s) and np.array_equal(sv, sv_s)
-    r = np.random.default_rng(4).standard_normal(n)
-    got = x.xtv(r)
-    assert np.array_equal(got, xs.xtv(r))
-    # column 3 against numpy (dosage codes 00 -> 0, 10 -> 1, 11 -> 2, 01 -> missing = the column mean)
-    j = 3
-    code = np.stack([(cols[j] >> (2 * t)) & 3 for t in range(4)], axis=1).ravel()[:n]
-    g = np.array([0.0, np.nan, 1.0, 2.0])[code]
-    g[np.isnan(g)] = mu[j]
-    assert got[j] == pytest.approx(float(np.dot((g - mu[j]) * sv[j], r)), rel=1e-10)
-    wide = np.zeros((p, cols.shape[1] + 5), dtype=np.uint8)
-    wide[:, :cols.shape[1]] = cols
-    assert np.array_equal(mih.SnpLinAlg(wide, n=n, center=True, scale=True, impute=True).export_bed(), cols)
-
 
 def test_choose_callback_makes_the_references_random_draw(mih, oracle):
     """_choose! (src/utilities.jl:444-458, src/multivariate.jl:310-351): the one place on the path where the reference draws

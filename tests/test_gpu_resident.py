@@ -1,0 +1,349 @@
+"""iht_one_step! resident on the device -- single fits, sessions, the lock-step lanes -- against the host-driven step,
+bit for bit; the switches that must change nothing (split out of test_gpu_parity.py in round 6)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import FIX, GOLD, ROOT, SweepTally, check_recorded_cv_curve, free_device_bytes, hash_folds, make_bed, perm_folds, seeded_draw, tied_case
+from gpu_helpers import _BT_TIE, _NUDGES, _config3_problem, _config4_problem, _dosages, _exact_xtv, _mv_problem, _run_probe_snippet, _same_fit, _sim, _unstable, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def test_poisson_fit_with_a_planted_count_outlier(mih, oracle, normal_pair):
+    """ A heavy tail in the RESIDUAL of a real fit: Poisson counts y ~ 1 with ONE planted y = 500.
+    The first iterates are wild (the outlier's mean sits at the +-20 clamp: a working residual of -4.8e8 among entries of ~1) and
+    later y - mu has one entry ~500 x the rest.  Round 5 kept the oracle's support and logs but its loglikelihood trace to 5e-8 only
+    (27 bits lost on the bulk in the first ~65 steps).  With the outlier row on the f64 side channel (csrc/peel.h; the guard fires in
+    the first ~66 scores of either fit):
+      * k = 6: the whole 172-step trace is the oracle's to 1e-12 (measured 1.1e-13), beta to 1e-10 (3e-12);
+      * k = 10: the first 85 steps to 1e-12 (1.5e-13); step 89 is a large step (tol 0.19) that multiplies ANY difference by ~400 and
+        the fit creeps on to max_iter amplifying it further -- the ORACLE's own trace moves by 7e-12 there and by 4.5e-9 at the end
+        when every y_i is nudged by one ulp (measured here, per step, four nudged runs); the HIP path is held to 100 x that spread.
+    Both step modes, bit for bit."""
+    x, ox = normal_pair
+    rng = np.random.default_rng(77)
+    eta = _sim(oracle, ox, rng, 6, scale=0.25)
+    y = rng.poisson(np.exp(eta)).astype(float)
+    y[int(np.argmin(np.abs(eta)))] = 500.0
+    mih.profile_enable(x, True)
+    for k in (6, 10):
+        mih.profile_counters(x, reset=True)
+        res = mih.fit_iht(y, x, None, k=k, d=mih.Poisson(), l=mih.LogLink(), verbose=False)
+        assert mih.profile_counters(x, reset=True)["peeled_residuals"] >= 40
+        o = oracle.fit_iht(ox, y, None, k=k, dist="poisson", link="log")
+        assert res.iter == o["iter"], (k, res.iter, o["iter"])
+        assert list(res.trace["backtracks"]) == list(o["bt_trace"])
+        assert np.array_equal(np.flatnonzero(res.beta), np.flatnonzero(o["beta"]))
+        ol = np.asarray(o["logl_trace"])
+        got = np.abs(np.asarray(res.trace["logl"]) - ol) / np.abs(ol)
+        if k == 6:
+            assert got.max() <= 1e-12, got.max()
+            np.testing.assert_allclose(res.beta, o["beta"], rtol=1e-10, atol=1e-14)
+        else:
+            assert got[:85].max() <= 1e-12, got[:85].max()
+            spread, bspread = np.zeros(ol.size), 0.0
+            nz = np.flatnonzero(o["beta"])
+            for t in range(4):                               # what one ulp in every y_i does to the oracle itself
+                r2 = np.random.default_rng(100 + t)
+                y2 = np.where(r2.random(y.size) < 0.5, np.nextafter(y, np.inf), np.nextafter(y, -np.inf))
+                y2[y == 0] = 0.0
+                o2 = oracle.fit_iht(ox, y2, None, k=k, dist="poisson", link="log")
+                assert o2["iter"] == o["iter"] and np.array_equal(np.flatnonzero(o2["beta"]), nz)
+                spread = np.maximum(spread, np.abs(np.asarray(o2["logl_trace"]) - ol) / np.abs(ol))
+                bspread = max(bspread, float(np.max(np.abs(o2["beta"][nz] - o["beta"][nz]) / np.abs(o["beta"][nz]))))
+            assert np.all(got <= 1e-12 + 100 * spread), float((got / (1e-12 + 100 * spread)).max())
+            assert np.max(np.abs(res.beta[nz] - o["beta"][nz]) / np.abs(o["beta"][nz])) <= 100 * bspread
+            np.testing.assert_allclose(res.beta, o["beta"], rtol=1e-4, atol=1e-12)          # (north_star's GLM tolerance, whatever the spread)
+        host = mih.fit_iht(y, x, None, k=k, d=mih.Poisson(), l=mih.LogLink(), verbose=False, step_mode=1)
+        _same_fit(res, host, f"poisson outlier k={k}")
+    mih.profile_enable(x, False)
+
+def test_session_run_is_k_session_steps(mih, normal_pair, normal_data):
+    """mih_session_run(K) (what bench.py times) = K calls of mih_session_step: same loglikelihood, backtracks and model."""
+    x, _ = normal_pair
+    y, z = normal_data["y"], normal_data["z"]
+    a = mih.IHTSession(y, x, z, k=9)
+    b = mih.IHTSession(y, x, z, k=9)
+    nbt = 0
+    for _ in range(4):
+        la, bt, ta = a.step()
+        nbt += bt
+    lb, btb, tb = b.run(4)
+    assert la == lb and ta == tb and nbt == btb
+    (ba, ca), (bb, cb) = a.model(), b.model()
+    assert np.array_equal(ba, bb) and np.array_equal(ca, cb)
+    a.close(); b.close()
+
+def test_resident_steps_equal_host_driven_steps(mih, oracle, normal_pair, normal_data):
+    """ iht_one_step! resident on the device (mih_fit_params::step_mode = 0: the iterate, the finish of
+    project_k!, the backtracking decision and the stopping rule in device memory, one record per step for the host) against
+    the host-driven step of rounds 1-4 (step_mode = 1): the same iteration log, support, estimates and fitted means -- bit for
+    bit, since every sum is formed in the same order -- over families, covariates with and without zkeep (up to six), prior weights,
+    init_beta, imputed missing entries, steps that backtrack, a step budget that runs out, and exact ties (the device hands
+    those steps back: _choose!)."""
+    x, ox = normal_pair
+    y, z, n = normal_data["y"], normal_data["z"], normal_data["n"]
+    rng = np.random.default_rng(4242)
+    cases = []
+    cases.append(("G1 normal + covariates", dict(y=y, x=x, z=z, k=7)))
+    cases.append(("normal k=12 intercept only", dict(y=y, x=x, z=None, k=12)))
+    cases.append(("zkeep = [1, 0]", dict(y=y, x=x, z=z, k=9, zkeep=[1, 0])))
+    cases.append(("zkeep = [0, 0]", dict(y=normal_data["y2"], x=x, z=z, k=9, zkeep=[0, 0])))
+    wts = 0.5 + rng.random(x.p)
+    cases.append(("prior weights", dict(y=y, x=x, z=z, k=8, weight=wts)))
+    cases.append(("init_beta", dict(y=y, x=x, z=z, k=7, init_beta=True)))
+    cases.append(("max_iter = 3", dict(y=y, x=x, z=z, k=7, max_iter=3)))
+    cases.append(("max_iter = 1", dict(y=y, x=x, z=z, k=7, max_iter=1)))
+    cases.append(("min_iter = 9, tight tol", dict(y=y, x=x, z=z, k=7, min_iter=9, tol=1e-9)))
+    eta = _sim(oracle, ox, rng, 8)
+    yb = (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float)
+    cases.append(("bernoulli/logit", dict(y=yb, x=x, z=None, k=8, d=mih.Bernoulli(), l=mih.LogitLink())))
+    cases.append(("bernoulli/probit", dict(y=yb, x=x, z=z, k=6, d=mih.Bernoulli(), l=mih.ProbitLink())))
+    yp = rng.poisson(np.exp(0.3 * eta)).astype(float)
+    cases.append(("poisson/log", dict(y=yp, x=x, z=None, k=8, d=mih.Poisson(), l=mih.LogLink())))
+    cases.append(("poisson/log max_step=1", dict(y=yp, x=x, z=z, k=10, d=mih.Poisson(), l=mih.LogLink(), max_step=1)))
+    ynb = rng.negative_binomial(10, 10 / (np.exp(0.3 * eta) + 10)).astype(float)
+    cases.append(("negbin/log fixed r", dict(y=ynb, x=x, z=None, k=8, d=mih.NegativeBinomial(10.0), l=mih.LogLink())))
+    yg = rng.gamma(2.0, np.exp(0.2 * eta) / 2.0)
+    cases.append(("gamma/log", dict(y=yg, x=x, z=None, k=6, d=mih.Gamma(), l=mih.LogLink())))
+    xm = mih.SnpLinAlg.synthetic(6001, 900, seed=3, missing_rate=0.01)           # imputed entries: the split kernels
+    supp = np.sort(rng.choice(900, 8, replace=False))
+    em = xm.xv_sparse(supp, rng.standard_normal(8) * 0.6)
+    zm = np.column_stack([np.ones(6001), rng.standard_normal(6001)])
+    cases.append(("missing entries, normal", dict(y=em + 0.5 + rng.standard_normal(6001), x=xm, z=zm, k=8)))
+    cases.append(("missing entries, bernoulli", dict(y=(rng.random(6001) < 1 / (1 + np.exp(-em))).astype(float), x=xm, z=zm, k=6,
+                                                     d=mih.Bernoulli(), l=mih.LogitLink())))
+    # six covariates, three of them competing in the projection: k_res_stats takes Z'r four covariates at a time (two slices of its
+    # grid), the covariate tail rides in the select; a 1537-row matrix: two of the 1024-row workgroups of the X_S v kernels, the second ragged
+    z6 = np.column_stack([np.ones(6001)] + [rng.standard_normal(6001) for _ in range(5)])
+    cases.append(("six covariates, poisson", dict(y=rng.poisson(np.exp(0.25 * em + 0.2 * z6[:, 3])).astype(float), x=xm, z=z6, k=7,
+                                                  zkeep=[1, 1, 0, 0, 1, 0], d=mih.Poisson(), l=mih.LogLink())))
+    xs = mih.SnpLinAlg.synthetic(1537, 700, seed=11)
+    es = xs.xv_sparse(np.array([5, 77, 300, 699]), np.array([0.8, -0.6, 0.5, 0.7]))
+    z6s = z6[:1537]
+    cases.append(("six covariates, normal, 1537 rows", dict(y=es + z6s @ np.array([0.3, 0.2, 0.0, -0.4, 0.1, 0.0]) + rng.standard_normal(1537), x=xs, z=z6s,
+                                                            k=6, zkeep=[1, 0, 0, 0, 0, 0])))
+    cols, yt, tied = tied_case()
+    xt = mih.SnpLinAlg(cols, n=1000, center=True, scale=True, impute=True)
+    cases.append(("exact ties: _choose!", dict(y=yt, x=xt, z=None, k=2)))
+    nbt_seen, tally = 0, dict(resident_steps=0, resident_attempts=0, resident_handbacks=0, resident_direct=0, resident_redos=0)
+    for what, kw in cases:
+        kw = dict(kw)
+        yy, xx, zz = kw.pop("y"), kw.pop("x"), kw.pop("z")
+        mih.profile_enable(xx, True)
+        mih.profile_counters(xx, reset=True)
+        a = mih.fit_iht(yy, xx, zz, verbose=False, step_mode=0, **kw)
+        cnt = mih.profile_counters(xx, reset=True)
+        b = mih.fit_iht(yy, xx, zz, verbose=False, step_mode=1, **kw)
+        host = mih.profile_counters(xx, reset=True)
+        mih.profile_enable(xx, False)
+        _same_fit(a, b, what)
+        nbt_seen += int(np.sum(a.trace["backtracks"]))
+        # the steps of the step_mode = 0 fit really ran on the device (all but those it handed back), none of the other fit's did
+        steps = len(a.trace["logl"])
+        assert cnt["resident_steps"] + cnt["resident_handbacks"] == steps, (what, cnt, steps)
+        assert cnt["resident_attempts"] <= int(np.sum(a.trace["backtracks"])), (what, cnt)
+        assert host["resident_steps"] == 0 and host["resident_handbacks"] == 0, (what, host)
+        if "ties" in what:
+            assert cnt["resident_handbacks"] >= 1, (what, cnt)
+        else:
+            assert cnt["resident_handbacks"] == 0, (what, cnt)       # (attempts the forecast had queued in advance are not counted)
+        for key in tally:
+            tally[key] += cnt[key]
+    assert nbt_seen > 0 and tally["resident_attempts"] > 0        # some of those steps backtracked: the re-queued attempts were exercised
+    assert tally["resident_steps"] > 60, tally
+    # most projections after a fit's first steps take the direct gather (a verified forecast of the threshold); some forecasts fail
+    # and are redone with the histogram sweeps -- same results either way (the comparisons above)
+    assert tally["resident_direct"] > 40 and tally["resident_redos"] < tally["resident_direct"] // 4, tally
+    assert mih.fit_iht(yt, xt, None, k=2, verbose=False, step_mode=0).choose_fired
+
+def test_resident_lockstep_equals_host_driven(mih, oracle, normal_pair, normal_data):
+    """ The lock-step lanes' fits run their steps resident on the device too (round 6): behind the lane's fused
+    pass a fit queues Z'r, df on its support, the step's start and its attempt slots without waiting and reads ONE record when
+    the lane collects the residuals of its next pass.  step_mode 0 (resident) against step_mode 1 (host-driven, rounds 1-5):
+    the same held-out losses BIT FOR BIT -- Normal with covariates on a matrix with imputed entries (two lanes, a tail hand-over),
+    logistic, Poisson with backtracking, init_beta, a model path -- and the counters say which way the steps ran.  Fits the
+    resident chain does not take (debias, est_r) step host-driven in either mode."""
+    xm = mih.SnpLinAlg.synthetic(6001, 900, seed=3, missing_rate=0.01)
+    rng = np.random.default_rng(606)
+    supp = np.sort(rng.choice(900, 8, replace=False))
+    em = xm.xv_sparse(supp, rng.standard_normal(8) * 0.6)
+    zm = np.column_stack([np.ones(6001), rng.standard_normal(6001)])
+    yn = em + 0.5 + 0.3 * zm[:, 1] + rng.standard_normal(6001)
+    yb = (rng.random(6001) < 1 / (1 + np.exp(-em))).astype(float)
+    yp = rng.poisson(np.exp(0.3 * em)).astype(float)
+    folds = hash_folds(6001, 5)
+    x, _ = normal_pair
+    y, z = normal_data["y"], normal_data["z"]
+    runs = {
+        "normal, 5 x 12 (two lanes)": lambda: mih.cv_iht(yn, xm, zm, path=range(1, 13), q=5, folds=folds, verbose=False, return_raw=True)[1],
+        "logistic": lambda: mih.cv_iht(yb, xm, None, path=range(2, 9), q=5, folds=folds, verbose=False, return_raw=True, d=mih.Bernoulli(), l=mih.LogitLink())[1],
+        "poisson": lambda: mih.cv_iht(yp, xm, zm, path=[3, 6, 9], q=5, folds=folds, verbose=False, return_raw=True, d=mih.Poisson(), l=mih.LogLink())[1],
+        "init_beta": lambda: mih.cv_iht(yn, xm, zm, path=range(1, 9), q=3, folds=hash_folds(6001, 3), verbose=False, return_raw=True, init_beta=True)[1],
+        "zkeep = [1, 0]": lambda: mih.cv_iht(y, x, z, path=range(4, 10), q=3, folds=hash_folds(1000, 3), verbose=False, return_raw=True, zkeep=[1, 0])[1],
+        "model path": lambda: np.asarray(mih.iht_run_many_models(y, x, z, path=range(1, 11), verbose=False)),
+    }
+    got = {}
+    for mode in (0, 1):
+        mih.set_step_mode(mode)
+        try:
+            for name, fn in runs.items():
+                mat = x if ("zkeep" in name or "path" in name) else xm
+                mih.profile_enable(mat, True)
+                mih.profile_counters(mat, reset=True)
+                out = fn()
+                cnt = mih.profile_counters(mat, reset=True)
+                mih.profile_enable(mat, False)
+                got[(mode, name)] = (out, cnt)
+        finally:
+            mih.set_step_mode(0)
+    backtracked = 0
+    for name in runs:
+        (a, ca), (b, cb) = got[(0, name)], got[(1, name)]
+        assert np.array_equal(np.asarray(a).view(np.uint64), np.asarray(b).view(np.uint64)), name
+        assert ca["scores"] == cb["scores"] and ca["fits"] == cb["fits"], (name, ca, cb)
+        assert cb["resident_steps"] == 0 and cb["resident_handbacks"] == 0, (name, cb)
+        assert ca["resident_steps"] + ca["resident_handbacks"] == ca["scores"] > 0, (name, ca)
+        assert ca["resident_handbacks"] == 0, (name, ca)
+        backtracked += ca["resident_attempts"] + ca["resident_redos"]
+    assert got[(0, "normal, 5 x 12 (two lanes)")][1]["lanes"] == 2
+    # fits the chain does not take: the same results, no resident step
+    mih.profile_enable(xm, True)
+    mih.profile_counters(xm, reset=True)
+    d0 = mih.cv_iht(yb, xm, None, path=[3, 5], q=3, folds=hash_folds(6001, 3), verbose=False, return_raw=True, d=mih.Bernoulli(), l=mih.LogitLink(), debias=True, max_iter=30)[1]
+    assert mih.profile_counters(xm, reset=True)["resident_steps"] == 0 and np.count_nonzero(d0) == 6
+    mih.profile_enable(xm, False)
+    # ... and the resident lanes against the oracle, directly
+    ox = oracle.Mat.from_bed_columns(xm.export_bed(), 6001)
+    _, want = oracle.cv_iht(ox, yb, None, path=list(range(2, 9)), q=5, folds=folds, dist="bernoulli", link="logit")
+    np.testing.assert_allclose(np.asarray(got[(0, "logistic")][0]).reshape(want.shape), want, rtol=1e-8)
+
+def test_resident_session_keeps_the_iterate_on_the_device(mih, normal_pair, normal_data):
+    """mih_session_step / _run / _model with the iterate resident on the device: single steps, a run of steps, the model read in
+    between (the iterate comes home and goes back) -- all equal to the host-driven session, step for step."""
+    x, _ = normal_pair
+    y, z = normal_data["y"], normal_data["z"]
+    a = mih.IHTSession(y, x, z, k=9, step_mode=0)
+    b = mih.IHTSession(y, x, z, k=9, step_mode=1)
+    for _ in range(2):
+        assert a.step() == b.step()
+    (ba, ca), (bb, cb) = a.model(), b.model()
+    assert np.array_equal(ba, bb) and np.array_equal(ca, cb)
+    la, bta, ta = a.run(5)
+    lb, btb, tb = b.run(5)
+    assert abs(la - lb) <= 4e-16 * abs(lb) and bta == btb and ta == tb
+    assert a.step()[1:] == b.step()[1:]
+    (ba, ca), (bb, cb) = a.model(), b.model()
+    assert np.array_equal(ba, bb) and np.array_equal(ca, cb)
+    a.close(); b.close()
+
+_HANDBACK_SNIPPET = r"""
+import os, sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import mendeliht_amd as m
+n = 1000
+x = m.SnpLinAlg(m.read_bed(os.path.join(sys.argv[1], "tests", "fixtures", "normal.bed"), n), n, center=True, scale=True, impute=True)
+rng = np.random.default_rng(4242)
+supp = np.sort(rng.choice(x.p, 8, replace=False))
+eta = x.xv_sparse(supp, rng.standard_normal(8) * 0.5)
+z = np.column_stack([np.ones(n), rng.standard_normal(n)])
+yp = rng.poisson(np.exp(0.3 * eta)).astype(float)
+yb = (rng.random(n) < 1 / (1 + np.exp(-eta))).astype(float)
+xm = m.SnpLinAlg.synthetic(6001, 900, seed=3, missing_rate=0.01)
+em = xm.xv_sparse(np.sort(rng.choice(900, 8, replace=False)), rng.standard_normal(8) * 0.6)
+ym = rng.poisson(np.exp(0.25 * em)).astype(float)
+out = {}
+mode = int(os.environ.get("STEP_MODE", "0"))
+for tag, (yy, xx, zz, kw) in {"poisson": (yp, x, z, dict(k=10, d=m.Poisson(), l=m.LogLink())),
+                              "bernoulli": (yb, x, None, dict(k=8, d=m.Bernoulli(), l=m.LogitLink())),
+                              "missing": (ym, xm, None, dict(k=7, d=m.Poisson(), l=m.LogLink()))}.items():
+    m.profile_enable(xx, True)
+    m.profile_counters(xx, reset=True)
+    r = m.fit_iht(yy, xx, zz, verbose=False, step_mode=mode, **kw)
+    c = m.profile_counters(xx, reset=True)
+    out[tag + "_beta"], out[tag + "_c"], out[tag + "_mu"] = r.beta, r.c, r.mu
+    out[tag + "_logl"], out[tag + "_tol"], out[tag + "_bt"] = r.trace["logl"], r.trace["tol"], np.asarray(r.trace["backtracks"], dtype=np.float64)
+    out[tag + "_counts"] = np.array([c["resident_steps"], c["resident_handbacks"]], dtype=np.float64)
+np.savez(sys.argv[2], **out)
+"""
+
+def test_handback_after_rejected_attempts(mih, tmp_path):
+    """ A step the device hands back AFTER it has rejected attempts: those attempts' sweeps have overwritten xb,
+    zc and mu with the rejected candidates' values, and the host-driven replay begins with iht_stepsize!, which reads them.
+    res_end now forms them again from the iterate that comes home.  The measurement build hands back every step that has
+    backtracked once (MENDELIHT_RES_FORCE_ABORT_ES=1) -- Poisson with a covariate, logistic, and Poisson on a matrix with imputed
+    entries -- and every fit equals the host-driven one bit for bit (before the fix: a different step size after the first replay)."""
+    forced = _run_probe_snippet(_HANDBACK_SNIPPET, tmp_path / "forced.npz", extra_env={"MENDELIHT_RES_FORCE_ABORT_ES": "1", "STEP_MODE": "0"})
+    host = _run_probe_snippet(_HANDBACK_SNIPPET, tmp_path / "host.npz", extra_env={"STEP_MODE": "1"})
+    handbacks = 0
+    for tag in ("poisson", "bernoulli", "missing"):
+        for key in ("beta", "c", "mu", "tol", "bt"):
+            assert np.array_equal(forced[f"{tag}_{key}"].view(np.uint64), host[f"{tag}_{key}"].view(np.uint64)), (tag, key)
+        np.testing.assert_allclose(forced[f"{tag}_logl"], host[f"{tag}_logl"], rtol=4e-16, atol=0)
+        assert host[f"{tag}_counts"][0] == 0
+        # every step that backtracked was handed back, the others ran on the device
+        nbt_steps = int(np.count_nonzero(forced[f"{tag}_bt"]))
+        assert forced[f"{tag}_counts"][1] == nbt_steps, (tag, forced[f"{tag}_counts"], nbt_steps)
+        assert forced[f"{tag}_counts"][0] + forced[f"{tag}_counts"][1] == forced[f"{tag}_bt"].size
+        handbacks += nbt_steps
+    assert handbacks >= 3
+
+_NOSPIN_SNIPPET = r"""
+import sys, json, numpy as np
+sys.path.insert(0, sys.argv[1])
+import mendeliht_amd as m
+hash_folds = m.hash_folds
+x = m.SnpLinAlg.synthetic(6001, 900, seed=3, missing_rate=0.01)
+rng = np.random.default_rng(1)
+supp = np.sort(rng.choice(900, 8, replace=False))
+eta = x.xv_sparse(supp, rng.standard_normal(8) * 0.6)
+y = eta + 0.5 + rng.standard_normal(6001)
+yb = (rng.random(6001) < 1 / (1 + np.exp(-eta))).astype(float)
+z = np.column_stack([np.ones(6001), rng.standard_normal(6001)])
+out = {}
+r = m.fit_iht(y, x, z, k=8, verbose=False)
+out["beta"], out["c"], out["logl"] = r.beta, r.c, np.array([r.logl, r.iter])
+r = m.fit_iht(yb, x, z, k=5, d=m.Bernoulli(), l=m.LogitLink(), verbose=False)
+out["bbeta"], out["blogl"] = r.beta, np.array([r.logl, r.iter])
+_, raw = m.cv_iht(yb, x, z, path=range(1, 9), q=3, folds=hash_folds(6001, 3), verbose=False, return_raw=True, d=m.Bernoulli(), l=m.LogitLink())
+out["cv"] = raw
+out["path"] = np.asarray(m.iht_run_many_models(yb, x, z, path=range(1, 7), verbose=False, d=m.Bernoulli(), l=m.LogitLink()))
+Y = np.vstack([y, 0.5 * y + rng.standard_normal(6001), rng.standard_normal(6001)])
+r = m.fit_iht(Y, x, None, k=12, verbose=False, max_iter=10)
+out["mvbeta"], out["mvlogl"] = r.beta, np.array([r.logl, r.iter])
+_, raw = m.cv_iht(Y, x, None, path=[2, 5, 9, 14], q=3, folds=hash_folds(6001, 3), verbose=False, return_raw=True)
+out["mvcv"] = raw
+_, raw = m.cv_iht(y, x, z, path=range(1, 9), q=3, folds=hash_folds(6001, 3), verbose=False, return_raw=True, init_beta=True)
+out["cv_init_beta"] = raw
+_, raw = m.cv_iht(yb, x, z, path=range(2, 8), q=3, folds=hash_folds(6001, 3), verbose=False, return_raw=True, d=m.Bernoulli(), l=m.LogitLink(), debias=True, max_iter=30)
+out["cv_debias"] = raw
+np.savez(sys.argv[2], **out)
+"""
+
+def test_polled_readbacks_and_shared_initial_scores_change_nothing(mih, tmp_path):
+    """Switches that must not move a bit (each is read once per process, hence one process per variant): the polled readbacks
+    (k_publish / k_final_sum_pub + SpinFlag) against device-to-host copies + hipStreamSynchronize (MENDELIHT_NO_SPIN=1); the
+    cross-validation / model-path drivers with every fit riding its own initial score and without the tail hand-over
+    (MENDELIHT_CV_NO_INIT_SHARE=1, MENDELIHT_CV_NO_MERGE=1), with one lock-step lane instead of two, and with every buffer
+    of an IHTVariable as its own allocation instead of a carve-out of one block (MENDELIHT_NO_ARENA=1), and with the fits of a
+    lane walked one after the other on the lane's stream instead of as coroutines on streams of their own (MENDELIHT_CV_NO_COOP=1);
+    (round 6) the lanes' resident fits stepping through ONE batched chain per lane round instead of a chain per fit
+    (MENDELIHT_LANE_BATCHED=1: the k_lane_* kernels), the lanes' passes in single file on priority streams.
+    Univariate Normal and logistic fits, a cross-validation, a model path and a multivariate fit."""
+    res = []
+    # the first run is the PRODUCT library (which reads none of the switches), the others the measurement build of the same
+    # sources: the product's bits are also those of the measurement build's defaults
+    for i, extra in enumerate((None, {}, {"MENDELIHT_NO_SPIN": "1"}, {"MENDELIHT_CV_NO_INIT_SHARE": "1", "MENDELIHT_CV_NO_MERGE": "1"},
+                               {"MENDELIHT_CV_LANES": "1"}, {"MENDELIHT_NO_ARENA": "1"}, {"MENDELIHT_CV_NO_COOP": "1"},
+                               {"MENDELIHT_LANE_BATCHED": "1"}, {"MENDELIHT_CV_PASS_ORDER": "1", "MENDELIHT_WORKER_PRIORITY": "1"},
+                               {"MENDELIHT_LANE_BATCHED": "1", "MENDELIHT_CV_NO_COOP": "1"})):
+        res.append(_run_probe_snippet(_NOSPIN_SNIPPET, tmp_path / f"variant_{i}.npz", extra_env=extra or {}, probes=extra is not None))
+    assert len(res[0].files) == 12
+    for other in res[1:]:
+        assert sorted(res[0].files) == sorted(other.files)
+        for k in res[0].files:
+            assert np.array_equal(res[0][k].view(np.uint64), other[k].view(np.uint64)), k
+    assert res[0]["logl"][1] > 2 and np.count_nonzero(res[0]["cv"]) == 24 and res[0]["path"].size == 6 and np.count_nonzero(res[0]["mvcv"]) == 12

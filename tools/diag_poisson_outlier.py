@@ -14,7 +14,7 @@ x = mih.SnpLinAlg(bed, n, center=True, scale=True, impute=True)
 ox = O.Mat.from_bed_columns(bed, n)
 rng = np.random.default_rng(77)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-import test_gpu_parity as T
+import gpu_helpers as T
 eta = T._sim(O, ox, rng, 6, scale=0.25)
 y = rng.poisson(np.exp(eta)).astype(float)
 i0 = int(np.argmin(np.abs(eta)))

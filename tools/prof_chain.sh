@@ -3,7 +3,7 @@
 # usage: tools/prof_chain.sh TAG [pytest -k expression]
 tag=$1; sel=${2:-"resident or g1_golden or session_run"}
 R=$GRAFT_REPO_ROOT
-cd $R && timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "$sel" 2>&1 | tail -8
+cd $R && timeout 900 python -m pytest tests -x -q -m gpu -k "$sel" 2>&1 | tail -8
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_${tag}_stats
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag}_stats -o bench -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-cv --no-mv > $R/gpurun_out/prof_${tag}_stats.json 2> $R/gpurun_out/prof_${tag}_stats.err
