@@ -1605,11 +1605,13 @@ struct PassTurn {
 void xtv_count_peels(const mih_mat *h, XtvWork &w, hipStream_t s)
 {
     if (!h->prof->on || !w.peel.p || w.rhs_cap == 0) return;
-    std::vector<double> c(w.rhs_cap, 0.0);
-    if (hipMemcpy2DAsync(c.data(), sizeof(double), w.peel.p + 3, sizeof(double) * kPeelStride, sizeof(double), w.rhs_cap, hipMemcpyDeviceToHost, s) != hipSuccess ||
+    // (the whole buffer in ONE plain copy, <= 20 KB: a strided hipMemcpy2DAsync of the counts alone took ~6 ms per call in a process
+    // that also holds PyTorch's HIP runtime -- bench.py's host-driven A/B read 0.64 ms outside the pass instead of 0.31)
+    std::vector<double> c(w.rhs_cap * kPeelStride, 0.0);
+    if (hipMemcpyAsync(c.data(), w.peel.p, sizeof(double) * c.size(), hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return; }
     double total = 0.0;
-    for (double v : c) total += v;
+    for (size_t v = 0; v < w.rhs_cap; ++v) total += c[v * kPeelStride + 3];
     h->prof->count(MIH_CNT_PEELED_RESIDUALS, (int64_t)(total - w.peels_counted));
     w.peels_counted = total;
 }
