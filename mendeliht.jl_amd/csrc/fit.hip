@@ -29,6 +29,7 @@
 namespace mih {
 
 constexpr int kMaxQ = 64;
+constexpr int kLaneCuReserve = 0;          // CUs a lock-step lane's fused passes leave to the per-fit kernels (lane_stream_create)
 struct QVec { double v[kMaxQ]; };
 
 // zc = Z c  (utilities.jl:113), optional clamp (utilities.jl:114-117)
@@ -2620,6 +2621,35 @@ static int cv_run_rolling(const mih_mat *h, const mih_fit_params &pr, size_t tot
     return MIH_OK;
 }
 
+// A lane's stream, on which its fused passes run.  (round 6) The passes leave a few CUs of the chip alone (a CU mask on the stream):
+// a fused pass's workgroups hold every CU they can get until the kernel's last wave of workgroups, so the small per-fit kernels of
+// BOTH lanes could only run in the window between two passes (228 ms of configs[3]'s 2.43 s); with `reserve` CUs kept
+// out of the passes' reach they run WHILE the other lane's pass is in flight.  The pass is bound by the matrix pipe under the
+// package power cap, not by the number of CUs: what it loses in CUs it gets back in clock (measured: tools/ab_cv_lanes.sh).
+static int lane_cu_reserve()
+{
+    static const int v = [] { const char *e = probe_env("MENDELIHT_LANE_CU_RESERVE"); return e ? atoi(e) : kLaneCuReserve; }();
+    return v;
+}
+static int lane_stream_create(const mih_mat *h, hipStream_t *out)
+{
+    const int reserve = lane_cu_reserve();
+    if (reserve > 0) {
+        hipDeviceProp_t pr;
+        if (hipGetDeviceProperties(&pr, h->device) == hipSuccess && pr.multiProcessorCount > 2 * reserve) {
+            const int cus = pr.multiProcessorCount, words = (cus + 31) / 32;
+            std::vector<uint32_t> mask((size_t)words, 0u);
+            // the reserved CUs spread evenly over the mask's bits (whatever the order of XCDs and shader engines behind them)
+            const int every = cus / reserve;
+            for (int c = 0; c < cus; ++c) if (!(c % every == every - 1 && c / every < reserve)) mask[(size_t)(c >> 5)] |= 1u << (c & 31);
+            if (hipExtStreamCreateWithCUMask(out, (uint32_t)words, mask.data()) == hipSuccess) return MIH_OK;
+            (void)hipGetLastError();
+        } else (void)hipGetLastError();
+    }
+    MIH_HIP(hipStreamCreate(out));
+    return MIH_OK;
+}
+
 // Two rolling drivers ("lanes"), each with its own host thread, stream and fused-pass workspace, pull fits from one
 // queue: while one lane's host thread walks the small per-fit kernel chains between two passes (about 0.5 ms per
 // fit and round), the other lane's fused pass keeps the GPU busy.  Every fit is independent of the lane it runs in.
@@ -2649,7 +2679,7 @@ static int cv_run_lanes(const mih_mat *h, const mih_fit_params &pr, size_t total
         PoolScope from_reserve(h->pool);                        // workspaces and IHTVariables out of the matrix's reserve (no hipMalloc)
         MIH_HIP(hipSetDevice(h->device));
         hipStream_t s = nullptr;
-        MIH_HIP(hipStreamCreate(&s));
+        MIH_TRY(lane_stream_create(h, &s));
         struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{s};
         XtvWork xw; DevBuf<double> R, DF;
         //  the workspace goes back to the matrix's reserve when this scope ends, on error returns too: nothing of this

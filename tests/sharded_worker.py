@@ -72,7 +72,10 @@ def native_main(out_path):
     out = {}
     for name, (cc, nn, yy, zz, kw) in {"normal_k7": (cols, n, y, z, dict(k=7)),
                                        "logistic": (cols2, n2, yb, None, dict(k=9, d=m.Bernoulli(), l=m.LogitLink())),
-                                       "init_beta": (cols2, n2, eta + 0.3 + np.random.default_rng(5).standard_normal(n2), None, dict(k=8, init_beta=True))}.items():
+                                       "init_beta": (cols2, n2, eta + 0.3 + np.random.default_rng(5).standard_normal(n2), None, dict(k=8, init_beta=True)),
+                                       # (round 6) a count outlier: k_res_peel in the resident sharded chain, k_r_stats's guard in the callbacks' steps
+                                       "poisson_outlier": (cols2, n2, np.where(np.arange(n2) == 77, 400.0, np.random.default_rng(6).poisson(np.exp(0.3 * eta))).astype(float), None,
+                                                           dict(k=7, d=m.Poisson(), l=m.LogLink()))}.items():
         p = cc.shape[0]
         lo, cnt = D.column_block(p, rank, world)
         xs = m.SnpLinAlg(cc[lo:lo + cnt], n=nn, center=True, scale=True, impute=True, device=local)
@@ -176,6 +179,11 @@ def main():
     yp = rng.poisson(lam).astype(float)
     train = (np.arange(n) % 5 != 0).astype(np.uint8)
     run("poisson_train", cols, n, yp, None, k=6, d=m.Poisson(), l=m.LogLink(), train=train)
+
+    # 3b. (round 6) Poisson with a planted count outlier: the working residual has one row towering over the rest, which leaves the
+    #     fixed point and rides the f64 side channel of every shard's finalize (csrc/peel.h): every rank makes the same decision
+    yo = yp.copy(); yo[int(np.argmin(np.abs(lam - 1.0)))] = 500.0
+    run("poisson_outlier", cols, n, yo, None, k=6, d=m.Poisson(), l=m.LogLink())
 
     # 4. NegBin with the nuisance parameter estimated (replicated n-vector work)
     ynb = rng.negative_binomial(2, 2.0 / (2.0 + lam)).astype(float)        # overdispersed counts: r is identifiable

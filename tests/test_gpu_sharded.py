@@ -152,7 +152,7 @@ def test_native_exchange_with_more_than_one_rank_on_one_gpu(tmp_path, world):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     res = [json.load(open(str(out) + f".native.r{k}")) for k in range(world)]
-    for name in ("normal_k7", "logistic", "init_beta"):
+    for name in ("normal_k7", "logistic", "init_beta", "poisson_outlier"):
         for k in range(world):
             a, b = res[k]["cases"][name]["native"], res[k]["cases"][name]["callbacks"]
             _same_summary(a, b, (name, k))                               # every field, bit for bit (json round-trips doubles)

@@ -26,9 +26,11 @@ print(json.dumps({"variant": sys.argv[1], "seconds": ts[1:], "hash": hashlib.sha
 PY
 }
 for rep in 1 2; do
-run "host-driven (round 5)" MIH_MODE=1
-run "resident, batched over the lane (round 6)" MIH_MODE=0
-run "resident, batched, passes in single file" MIH_MODE=0 MENDELIHT_CV_PASS_ORDER=1
-run "resident, one chain per fit on its own stream" MIH_MODE=0 MENDELIHT_LANE_PER_FIT=1
-run "host-driven, priority streams + single file" MIH_MODE=1 MENDELIHT_WORKER_PRIORITY=1 MENDELIHT_CV_PASS_ORDER=1
+run "host-driven, no CUs reserved" MIH_MODE=1 MENDELIHT_LANE_CU_RESERVE=0
+run "host-driven, 8 CUs reserved" MIH_MODE=1 MENDELIHT_LANE_CU_RESERVE=8
+run "resident per fit, no CUs reserved" MIH_MODE=0 MENDELIHT_LANE_CU_RESERVE=0
+run "resident per fit, 8 CUs reserved" MIH_MODE=0 MENDELIHT_LANE_CU_RESERVE=8
+run "resident per fit, 16 CUs reserved" MIH_MODE=0 MENDELIHT_LANE_CU_RESERVE=16
+run "resident per fit, 32 CUs reserved" MIH_MODE=0 MENDELIHT_LANE_CU_RESERVE=32
+run "resident batched, 16 CUs reserved" MIH_MODE=0 MENDELIHT_LANE_CU_RESERVE=16 MENDELIHT_LANE_BATCHED=1
 done
