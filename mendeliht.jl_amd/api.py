@@ -303,7 +303,7 @@ def _link(name, code):
     return type(name, (), {"code": code, "__repr__": lambda self: f"{name}()"})
 
 
-# the remaining GLM.jl Link types a caller may pass as `l` (linkinv / mueta closed forms in csrc/fit.hip)
+# the remaining GLM.jl Link types a caller may pass as `l` (linkinv / mueta closed forms in csrc/fit_common.h)
 ProbitLink = _link("ProbitLink", 3)
 CloglogLink = _link("CloglogLink", 4)
 CauchitLink = _link("CauchitLink", 5)

@@ -154,7 +154,7 @@ struct Arena {
     }
 };
 inline Arena *&current_arena() { static thread_local Arena *a = nullptr; return a; }
-// Cooperative waits.  In a lock-step round the fits of a lane are coroutines of ONE host thread (CoopSched, fit.hip): a fit that
+// Cooperative waits.  In a lock-step round the fits of a lane are coroutines of ONE host thread (CoopSched; LaneSched of fit_common.h, driven by fit_lockstep.hip): a fit that
 // reaches a readback does not spin -- it yields, and the thread queues the next fit's kernels meanwhile.  Allocation scopes are
 // thread-local state living on a coroutine's stack, so nothing may yield while one is open (coop_blocked).
 struct CoopSched { virtual void yield() = 0; virtual ~CoopSched() {} };
@@ -362,7 +362,7 @@ struct DigitMode {
     int flat = 0;    // (round 4) the residuals of a pass occupy digit columns 10 j .. 10 j + 9 of the pass's operands back to back,
                      // across operand boundaries: 19 ten-digit residuals in the 192 columns of six operands instead of 18
     int nres = 0;    // flat: residuals in this pass
-    // device-resident steps (fit.hip): the digit kernel and the single-fit pass run only while *gate == gate_val -- a chain queued
+    // device-resident steps (fit_state.h): the digit kernel and the single-fit pass run only while *gate == gate_val -- a chain queued
     // ahead of the host's knowledge (a step that turned out to need backtracking, a fit that converged) then does nothing
     const int32_t *gate = nullptr; int32_t gate_val = 0;
 };
@@ -388,7 +388,7 @@ XtvTune xtv_tune(int digits);
 inline XtvTune xtv_tune(const mih_fit_params *prm) { return xtv_tune(prm ? prm->xtv_digits : 0); }
 bool xtv_digits_valid(int digits);
 
-// Device-resident steps (fit.hip): the finalize kernel of a single-residual pass also leaves df on the support of the current iterate
+// Device-resident steps (fit_state.h): the finalize kernel of a single-residual pass also leaves df on the support of the current iterate
 // and k_xv_coef's coefficients of X_S df_S (iht_stepsize!) -- extra workgroups that redo the finalize arithmetic of those columns.
 struct XtvSupportHook {
     const int32_t *cur = nullptr;                 // which of the two lists is the current iterate's (nullptr: no hook)
@@ -423,7 +423,7 @@ struct XtvWork {            // scratch for one in-flight X'r
     XtvTune tune;              // fixed at init
     int stream_tag = 0;        // which lock-step lane launches on this workspace (profile records)
     const int32_t *gate = nullptr; int32_t gate_val = 0;   // see DigitMode::gate; set by the caller around one xtv_device call
-    bool stats_done = false;   // ... whose residual statistics (scal) the caller has computed already (k_res_stats, fit.hip)
+    bool stats_done = false;   // ... whose residual statistics (scal) the caller has computed already (k_res_stats, fit_state.h)
     // xtv_digits = -1 (auto): the lock-step drivers score a residual whose max |r| / rms(r) is small in the 43-bit format, the others
     // in the 54-bit one -- per RESIDUAL (a fit's bits never depend on its company); use_alt selects the format of ONE xtv_device call
     DigitMode dm_alt = {49, 8, 4, 8, 42, 18}; bool has_alt = false, use_alt = false;
@@ -503,7 +503,7 @@ int  debias_glm_device(const mih_mat *h, const int64_t *idx_host, int64_t k, con
 int  comm_native_allreduce_on_stream(const mih_comm *c, double *buf_dev, int64_t count, int32_t op, hipStream_t s, int device);
 int  comm_native_allgather_on_stream(const mih_comm *c, const double *send_dev, double *recv_dev, int64_t count, hipStream_t s, int device);
 bool comm_is_native(const mih_comm *c, int device);       // the library's own RCCL communicator, on that device
-// rank_of[fold * npath + ik]: which rank of `world` evaluates that (fold, k) combination (mih_cv_assignment; fit.hip)
+// rank_of[fold * npath + ik]: which rank of `world` evaluates that (fold, k) combination (mih_cv_assignment; fit_lockstep.hip)
 void cv_assign(const int64_t *path, int64_t npath, int32_t nfolds, int32_t world, std::vector<int32_t> &rank_of);
 // initialize_beta! regressions for m response planes (fit.hip); shared by the univariate and multivariate fits
 int  init_beta_regress_device(const mih_mat *h, const double *w_dev, const double *Y_dev, int m, double N,

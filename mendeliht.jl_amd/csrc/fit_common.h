@@ -1,4 +1,4 @@
-// fit_common.h -- small device helpers shared by the univariate (fit.hip) and multivariate
+// fit_common.h -- small device helpers shared by the univariate (fit_state.h, fit.hip, fit_lockstep.hip) and multivariate
 // (mv.hip) IHT drivers.  Kernels are `static` so each translation unit gets its own copy.
 #pragma once
 #include "common.h"

@@ -358,7 +358,7 @@ struct MvVar {
     bool own_stream = true;
     ~MvVar() { if (s) (void)hipStreamSynchronize(s); if (s && own_stream) (void)hipStreamDestroy(s); }       // see ~IhtVar
 
-    // Column-sharded fit (mih_comm, as the univariate IhtVar of fit.hip): this process owns columns [col0, col0 + p) of pg; Y, Z
+    // Column-sharded fit (mih_comm, as the univariate IhtVar of fit_state.h): this process owns columns [col0, col0 + p) of pg; Y, Z
     // and every n x r matrix are replicated, so the residuals, the Gram matrix, Gamma, the loglikelihood and T1 = Gamma * resid are
     // computed redundantly and identically on every rank and the X'R pass needs no exchange.  Per iteration: one all-reduce of
     // n r + 1 doubles (X_S df_S of iht_stepsize!, the shards' |df_S|^2 riding as the last element), one of n r doubles per
@@ -372,7 +372,7 @@ struct MvVar {
     static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     int comm_fail(int rc) { set_error("communicator callback failed (%d)", rc); return MIH_BAD_ARG; }
     // sum over the shards of a device vector: queued on this stream when the communicator is the library's own, else through
-    // the caller's callback (which is handed the device pointer) after a stream synchronisation.  Timed by kind as in fit.hip
+    // the caller's callback (which is handed the device pointer) after a stream synchronisation.  Timed by kind as in fit_state.h
     // (0: with the step size's numerator riding along, 1: plain products)
     int allreduce_dev(double *buf, int64_t cnt, int kind)
     {
@@ -594,7 +594,7 @@ struct MvVar {
         return readback(scal.p, np_, df2.data());   // [i + r*l]
     }
     // The end of a step (or of the initialisation) and the beginning of the next step in ONE host synchronisation (the univariate
-    // step_post_fused, fit.hip): [with_df2: df2 = T1 Z' (score!, multivariate.jl:88-91)], df on the support (gathered on the
+    // step_post_fused, fit_state.h): [with_df2: df2 = T1 Z' (score!, multivariate.jl:88-91)], df on the support (gathered on the
     // device, [trait][column]) and the whole iht_stepsize! of the next step -- X_S df_S straight from the device copy of df_S,
     // the pivoted Cholesky factor of Gamma, the weighted sum of squares -- are queued back to back and come home in one copy:
     // [df_S | df2 | sum].  Two synchronisations and three small copies less per iteration than three separate round trips; the
@@ -781,7 +781,7 @@ struct MvVar {
         }
         return MIH_OK;
     }
-    // project_k!(v) over the shards (IhtVar::project_full_sharded of fit.hip for vec(B)): the K-th largest |entry| of the whole
+    // project_k!(v) over the shards (IhtVar::project_full_sharded of fit_state.h for vec(B)): the K-th largest |entry| of the whole
     // r(pg + q) vector is the K-th largest of the union of every shard's own top-K and the covariate tail (which every rank
     // holds); ties at that value are kept.  A shard sends its candidates as (global linear index, value) pairs, so every rank ends
     // up with the whole model of the step (Bg).  A shard with more than K entries at or above its own threshold (exact ties
@@ -1145,7 +1145,7 @@ int mih_cv_mv(const mih_mat *h, const mih_fit_params *prm, const double *Y, int6
     // round issues ONE fused X'R pass for the r traits of every fit that needs a score (as mih_cv_iht does)
     std::vector<std::pair<int32_t, int64_t>> mine;
     std::vector<int32_t> rank_of;
-    cv_assign(path, npath, nfolds, world, rank_of);          // the same sharding rule as mih_cv_iht (fit.hip)
+    cv_assign(path, npath, nfolds, world, rank_of);          // the same sharding rule as mih_cv_iht (fit_lockstep.hip)
     int64_t combo = 0;
     for (int32_t fold = 1; fold <= nfolds; ++fold)
         for (int64_t ik = 0; ik < npath; ++ik, ++combo)
@@ -1162,7 +1162,7 @@ int mih_cv_mv(const mih_mat *h, const mih_fit_params *prm, const double *Y, int6
     MIH_TRY(xtv_work_init(h, xw, mb * rr, tune));
     xw.stream_tag = 1;
     MIH_TRY(R.alloc((size_t)mb * rr * n));
-    // as in cv_run_rolling (fit.hip): the fits of a fold start from the same residuals (initial score before k plays a role,
+    // as in cv_run_rolling (fit_lockstep.hip): the fits of a fold start from the same residuals (initial score before k plays a role,
     // multivariate.jl:376-452) -- one fit per fold rides the pass, its r x p block of X'R is kept behind the pass's outputs;
     // finished fits hand their mIHTVariable (sized for max(path)) to the fits started next
     const bool share_init = !prm->init_beta && probe_env("MENDELIHT_CV_NO_INIT_SHARE") == nullptr;
@@ -1207,7 +1207,7 @@ int mih_cv_mv(const mih_mat *h, const mih_fit_params *prm, const double *Y, int6
         pool.push_back(std::move(f.v));
         return MIH_OK;
     };
-    // rolling lock-step (as cv_run_rolling in fit.hip): a new fit needs its initial score, a running fit the score that
+    // rolling lock-step (as cv_run_rolling in fit_lockstep.hip): a new fit needs its initial score, a running fit the score that
     // ends its step -- one fused pass serves both kinds, and a finished fit's slot is refilled in the next round
     std::vector<std::unique_ptr<MvFit>> slot((size_t)mb);
     std::vector<MvFit *> need;
@@ -1251,7 +1251,7 @@ int mih_cv_mv(const mih_mat *h, const mih_fit_params *prm, const double *Y, int6
                 f.best = f.v->save_prev(f.next_logl, f.best);
                 MIH_TRY(f.v->step_pre(f.next_logl, pr.max_step, &f.nbt, &f.next_logl));
                 {   // (round 5) the convergence test needs nothing of the score that ends this step: a fit that converges is finished
-                    // without riding the pass, its slot is refilled in this same round (as in the univariate driver, fit.hip)
+                    // without riding the pass, its slot is refilled in this same round (as in the univariate driver, fit_lockstep.hip)
                     const double sc = f.v->check_convergence();
                     if (f.iter >= pr.min_iter && sc < pr.tol) {
                         if (std::isnan(f.next_logl)) { set_error("Loglikelihood function is NaN, aborting..."); return MIH_NAN_LOGL; }

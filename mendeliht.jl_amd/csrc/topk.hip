@@ -7,7 +7,7 @@
 //     that prefix, and the host finishes among the few entries that share it (std::nth_element on the keys, ties kept).  Eight
 //     sweeps of 8 bits (k_hist / k_pick / k_threshold) remain as the fallback for massive ties (more prefix-sharers than the
 //     gather buffer holds).
-//   * a device-resident fit (fit.hip, resident.inc) does NOT come here: its select -- the same two sweeps or a verified direct
+//   * a device-resident fit (fit_state.h, resident.inc) does NOT come here: its select -- the same two sweeps or a verified direct
 //     gather, and the exact finish by rank counting in one workgroup -- never leaves the device (k_res_grad .. k_res_select).
 // Also here: the polled readback (SpinFlag / k_publish) and the pinned upload ring (HostStage / k_stage) of the host-driven step.
 #include "common.h"
