@@ -1375,6 +1375,7 @@ struct IhtVar {
     int res_epoch = 0; uint64_t res_seq = 0; int64_t res_kcap = 0;
     std::vector<uint64_t> res_out;                       // sequence numbers of the steps in flight, oldest first
     DevBuf<ResCtl> rctl; DevBuf<int64_t> ridx; DevBuf<double> rval; DevBuf<int32_t> rslot; DevBuf<uint32_t> rhist; DevBuf<uint64_t> rsel; DevBuf<double> rwalk; DevBuf<uint32_t> rtick;
+    bool res_big = false; DevBuf<uint64_t> rbig;            // a model beyond kResMaxList entries: k_res_select_big and its scratch
     bool res_sharded = false; DevBuf<int64_t> rgidx; DevBuf<double> rgval, rmsg; PinBuf<double> rg_h;        // column shard: whole models, messages
     PinBuf<ResCtl> rctl_h; PinBuf<ResRecord> rrec; PinBuf<int64_t> ridx_h; PinBuf<double> rval_h; PinBuf<int32_t> rslot_h;
     struct ResRun { int64_t limit = 0, issued = 0, done = 0; int max_step = 3; };
@@ -1392,12 +1393,16 @@ struct IhtVar {
         // (world x K and the covariate tail) the second stage of the select can rank
         res_sharded = comm != nullptr;
         if (comm && (!comm_is_native(comm, h->device) || has_weight || (int64_t)comm->world * K + q > kResMaxInBin || K + 64 > kResShardList)) return MIH_OK;
-        if (xv.slots <= 0 || xv.slots > 160 * 32 || K < 1 || K > pg + q || h->p >= (1ll << 40)) return MIH_OK;
-        if (K + 64 > kResMaxList) return MIH_OK;               // (k_res_select orders the survivors in LDS: models beyond ~2000 effects take the host-driven step)
+        // (round 6) a model beyond ~2000 effects ranks and orders its survivors in a scratch block of device memory (k_res_select_big)
+        // instead of LDS; beyond ~8000, in a column shard or in a lane's batched chain it takes the host-driven step
+        res_big = K + 64 > kResMaxList;
+        if (res_big && (K + 64 > kResBigList || comm || (batched && probe_env("MENDELIHT_LANE_BATCHED")))) return MIH_OK;
+        if (xv.slots <= 0 || xv.slots > (res_big ? 2 * kResBigList + 1024 : 160 * 32) || K < 1 || K > pg + q || h->p >= (1ll << 40)) return MIH_OK;
         res_kcap = std::min<int64_t>(kcap, (int64_t)xv.coefA.n);
         MIH_TRY(rctl.alloc(1)); MIH_TRY(ridx.alloc((size_t)res_kcap * 3)); MIH_TRY(rval.alloc((size_t)res_kcap * 3));
         MIH_TRY(rslot.alloc((size_t)res_kcap * 4)); MIH_TRY(rhist.alloc(4096));
         MIH_TRY(rsel.alloc((size_t)kResCollectBlocks * (1 + 2 * kResCollectSlots)));
+        if (res_big) { ArenaScope own_buffer(nullptr); MIH_TRY(rbig.alloc((size_t)kResBigScratchWords)); }
         if (!batched) {             // (a lane's fit has no score of its own: no k_res_stats)
             const size_t slices = (size_t)(q + kResStatCov - 1) / kResStatCov;
             MIH_TRY(rwalk.alloc(slices * kStatBlocksRes * 10 * 256)); MIH_TRY(rtick.alloc(slices * kStatBlocksRes));      // k_res_stats: the walkers' sums, a ticket per walk-block
@@ -1423,7 +1428,7 @@ struct IhtVar {
         for (int i = 0; i < 3; ++i) { P.idx[i] = ridx.p + (size_t)i * res_kcap; P.val[i] = rval.p + (size_t)i * res_kcap; }
         for (int i = 0; i < 2; ++i) { P.slot[i] = rslot.p + (size_t)i * res_kcap; P.fresh[i] = rslot.p + (size_t)(2 + i) * res_kcap; }
         P.gval = gval.p; P.coefA = xv.coefA.p; P.coefB = xv.coefB.p;
-        P.hist = rhist.p; P.sel = rsel.p; P.sel_cap = 0; P.kcap = res_kcap; P.rec = rrec.p;
+        P.hist = rhist.p; P.sel = rsel.p; P.sel_cap = 0; P.kcap = res_kcap; P.rec = rrec.p; P.big = res_big ? rbig.p : nullptr;
         P.gidx[0] = P.gidx[1] = P.lc_idx = nullptr; P.gvals[0] = P.gvals[1] = P.lc_val = P.msg = P.msgs = nullptr; P.world = 1; P.rank = 0; P.col0 = 0;
         if (res_sharded) {
             for (int i = 0; i < 2; ++i) { P.gidx[i] = rgidx.p + (size_t)i * res_kcap; P.gvals[i] = rgval.p + (size_t)i * res_kcap; }
@@ -1645,7 +1650,9 @@ struct IhtVar {
         // (measurement build) MENDELIHT_RES_FORCE_ABORT_ES=N: the device hands a step back once it has backtracked N times -- the replay
         // of a step whose rejected attempts have been through xb, zc, mu (test_handback_after_rejected_attempts)
         static const int force_abort_es = probe_env("MENDELIHT_RES_FORCE_ABORT_ES") ? atoi(probe_env("MENDELIHT_RES_FORCE_ABORT_ES")) : -1;
-        if (!res_sharded)
+        if (!res_sharded && res_big)
+            hipLaunchKernelGGL(k_res_select_big, dim3(1), dim3(1024), 0, s, P, res_epoch, a, fast ? 1 : 0, K, seq, M, wp, p, q, zk, (int)zkeepn, groups * (k + zkeepn), force_abort_es);
+        else if (!res_sharded)
             hipLaunchKernelGGL(k_res_select, dim3(1), dim3(1024), 0, s, P, res_epoch, a, fast ? 1 : 0, K, seq, M, wp, p, q, zk, (int)zkeepn, groups * (k + zkeepn), force_abort_es);
         else {
             hipLaunchKernelGGL(k_res_select_local, dim3(1), dim3(1024), 0, s, P, res_epoch, a, fast ? 1 : 0, Ksel, K, (int32_t)xv.slots);
@@ -1697,7 +1704,7 @@ struct IhtVar {
         const bool plain = batched && !lane_spec;
         const int slots = plain ? 1 : 1 + std::max(0, std::min(max_step - std::min(a0, max_step), res_spec));      // (attempt max_step always stands: utilities.jl:484)
         for (int j = 0; j < slots; ++j) {
-            const bool fast = !plain && res_known > 0 && res_fast_fails < 3 && !(first_slow && j == 0);
+            const bool fast = !plain && !res_big && res_known > 0 && res_fast_fails < 3 && !(first_slow && j == 0);
             if (fast) h->prof->count(MIH_CNT_RESIDENT_DIRECT, 1);
             MIH_TRY(res_enqueue_attempt(seq, 0, j + 1 < slots, fast));
         }
