@@ -268,7 +268,9 @@ typedef struct mih_fit_params {
      * mih_comm_create_rccl, whose collectives are then queued inside the chain): the k-sparse iterate, the exact finish of project_k!,
      * the backtracking decision and the stopping rule live in device memory, the host queues the kernels of a step without
      * waiting and reads one record per series of attempts, one step behind.  Exact ties that need _choose! hand the step back to the host-driven
-     * path.  1 = every step host-driven (rounds 1-4: 26 launches, three waits).  Same results either way, bit for bit. */
+     * path.  Since round 6 also the fits of the lock-step drivers (mih_cv_iht, mih_fit_iht_path: a fit queues its step behind its lane's
+     * fused pass and reads one record per step) and models of up to ~8000 effects (k_res_select_big; ~2000 before).
+     * 1 = every step host-driven (rounds 1-4: 26 launches, three waits).  Same results either way, bit for bit. */
     int32_t  step_mode;
 } mih_fit_params;
 enum { MIH_CHOOSE_SAMPLE = 0, MIH_CHOOSE_SHUFFLE_B = 1, MIH_CHOOSE_SHUFFLE_C = 2 };
@@ -393,7 +395,7 @@ enum { MIH_CNT_LANES = 0,          /* lock-step lanes started (summed over calls
        MIH_CNT_SCORES = 6,         /* IHT iterations of those fits as fit.jl counts them (one score ends each -- except a fit's last, see [14]) */
        MIH_CNT_MAX_LANE_SLOTS = 7, /* most fits in flight on ONE lane */
        MIH_CNT_INIT_SCORES = 8,    /* initial scores (init_iht_indices!, one per fit): rode a pass or were served by a copy */
-       MIH_CNT_RESIDENT_STEPS = 9, /* iht_one_step! calls that ran resident on the device (step_mode 0; single fits and sessions) */
+       MIH_CNT_RESIDENT_STEPS = 9, /* iht_one_step! calls that ran resident on the device (step_mode 0; single fits, sessions and -- round 6 -- the lock-step drivers' fits) */
        MIH_CNT_RESIDENT_ATTEMPTS = 10, /* series of attempt slots that ended with their step still backtracking (it went on in the next series) */
        MIH_CNT_RESIDENT_HANDBACKS = 11, /* steps the device handed back to the host-driven path (_choose! ties, lists beyond its buffers) */
        MIH_CNT_RESIDENT_DIRECT = 12, /* attempts whose projection was queued as a direct gather (threshold forecast, verified) */

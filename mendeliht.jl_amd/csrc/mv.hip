@@ -1102,6 +1102,7 @@ int mih_fit_mv(const mih_mat *h, const mih_fit_params *prm, const double *Y, int
     auto t0 = std::chrono::steady_clock::now();
     MIH_TRY(v.fit_loop(prm, &res->logl, &res->iter, res->logl_trace, res->tol_trace, res->bt_trace, &res->n_trace));
     res->time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    xtv_count_peels(h, v.xtv, v.s);                  // (measurement hook: how often a trait's row of T1 had rows peeled, csrc/peel.h)
     res->choose_fired = v.choose_fired ? 1 : 0;
     int rr = (int)r;
     if (res->B) {
