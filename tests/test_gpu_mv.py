@@ -150,3 +150,28 @@ def test_config4_multivariate_r10_k500_against_oracle(mih, oracle):
     np.testing.assert_allclose(res.c, o["C"], rtol=1e-5, atol=1e-12)
     np.testing.assert_allclose(res.Σ, o["Sigma"], rtol=1e-6)
     assert res.logl == pytest.approx(o["logl"], rel=1e-9)
+
+
+def test_multivariate_fit_with_a_gross_outlier_in_one_trait(mih, oracle, normal_pair):
+    """(round 6) The rows of T1 = Gamma * resid are the residuals of the multivariate score (multivariate.jl:84-86).  ONE sample with
+    a trait value 4e7 x the rest: the fit keeps the oracle's iteration log and support, B / C / Sigma to the Gaussian tolerance and
+    its loglikelihood trace to 1e-10.  (The outlier guard of csrc/peel.h fires once, for the initial score: from then on
+    Gamma = inv(R R' / n) scales the outlying trait down by its own variance -- Gamma_11 ~ n / 1.6e15 -- and no row of T1 towers.)"""
+    x, ox = normal_pair
+    rng = np.random.default_rng(515)
+    r, k = 3, 9
+    Y, Z = _mv_problem(oracle, ox, rng, r, k, 1)
+    Y[1, 123] = 4.0e7
+    mih.profile_enable(x, True)
+    mih.profile_counters(x, reset=True)
+    res = mih.fit_iht(Y, x, Z, k=k, verbose=False)
+    cnt = mih.profile_counters(x, reset=True)
+    mih.profile_enable(x, False)
+    o = oracle.fit_mv(ox, Y, Z, k=k)
+    assert res.iter == o["iter"] and list(res.trace["backtracks"]) == list(o["bt_trace"])
+    assert np.array_equal(res.beta != 0, o["B"] != 0)
+    np.testing.assert_allclose(res.beta, o["B"], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(res.c, o["C"], rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(res.Σ, o["Sigma"], rtol=1e-6)
+    np.testing.assert_allclose(res.trace["logl"], o["logl_trace"], rtol=1e-10)
+    assert 1 <= cnt["peeled_residuals"] <= r * res.iter, cnt
