@@ -110,3 +110,24 @@ def _config4_problem(x, rng, r, k, lo=0.15, hi=0.45):
         planted[t] = (cols, eff)
         Y[t] += x.xv_sparse(cols, eff) + 1.0 + 0.1 * t
     return Y, planted, Sigma
+
+
+def peel_rule(r, ratio=64.0, max_rows=64):
+    """The outlier guard of the fixed-point residual restated (csrc/peel.h): max|r| per strided 256-row block (block b: rows
+    256 b + t + 16384 j), bq = the ceil(B/4)-th smallest of the B non-empty blocks' maxima; the guard fires iff max|r| > ratio * bq;
+    then the rows with |r_i| > ratio * bq are peeled if there are at most max_rows of them.  Returns the peeled row indices."""
+    r = np.asarray(r, dtype=np.float64)
+    n = r.size
+    nb = min(64, (n + 255) // 256)
+    a = np.abs(r)
+    bmax = np.zeros(nb)
+    for b in range(nb):
+        rows = np.concatenate([np.arange(lo, min(lo + 256, n)) for lo in range(256 * b, n, 16384)])
+        bmax[b] = a[rows].max()
+    bq = np.sort(bmax)[(nb + 3) // 4 - 1]
+    tau = ratio * bq
+    if not (bmax.max() > tau) or not np.isfinite(bmax.max()):
+        return np.zeros(0, dtype=np.int64)
+    rows = np.flatnonzero(a > tau)
+    return rows if rows.size <= max_rows else np.zeros(0, dtype=np.int64)
+
