@@ -1254,12 +1254,20 @@ def test_randomized_model_paths_vs_oracle(mih, oracle):
     for trial in range(5):
         n, p, q, od, ol, D, L, x, ox, y, z, path, kw, okw, d = _path_case(mih, oracle, rng, trial, fams)
         tag = (trial, n, p, q, od, path, sorted(kw))
-        ll = np.asarray(mih.iht_run_many_models(y, x, z, path=path, d=d, l=L(), verbose=False, **kw))
         def orc(kk, g=1.0):                            # None: the reference algorithm itself ends in an error (GLM.jl's refit failing inside debias!)
             try:
                 return oracle.fit_iht(ox, y, z * g, k=kk, dist=od, link=ol, max_iter=100, **okw)
             except RuntimeError:
                 return None
+        try:
+            ll = np.asarray(mih.iht_run_many_models(y, x, z, path=path, d=d, l=L(), verbose=False, **kw))
+        except mih.MendelIHTError as e:
+            # (round 6, seed 16136) the LIBRARY ended in the reference's debias! error: a finding unless the oracle does the same on the
+            # original input or under a nudge for some size of the path (tests/test_oracle_illconditioned_cpu.py replays the seed)
+            assert "debias" in str(e) and kw.get("debias"), (tag, str(e))
+            assert any(orc(k, g) is None for k in path for g in [1.0] + _NUDGES), (tag, "only the library ended in the debias! error")
+            tally.set_aside("the debias! refit's error comes and goes under ulp nudges", tag, count=len(path))
+            continue
         runs = [orc(k) for k in path]
         want = np.array([o["logl"] if o is not None else np.nan for o in runs])
         tol = 1e-5 if "est_r" in kw else 1e-7

@@ -107,3 +107,25 @@ def test_zero_over_zero_step_size(oracle):
         x, ox, y, z, k, kw, okw, both, tol, fam, tag = T._options_case(FAKE, oracle, rng, t)   # an ordinary trial of the same seed (NegBin, :MM): neither fires
     o = oracle.fit_iht(ox, y, z, k=k, max_iter=40, **okw, **both)
     assert o["eta_cond"] > 1e-12 and o["bt_cond"] > 1000 * T._BT_TIE
+
+
+def test_debias_error_that_comes_and_goes_under_nudges_in_a_model_path(oracle):
+    """Seed 16136 (round 6's campaign: model paths, trial 2, NegBin / log with est_r = :Newton and debias, n = 151, k = 11): the HIP
+    path ended in the reference's "debias: step-halving failed" error where the oracle's fit of the original input finishes -- and
+    the oracle itself ends in that error under the first ulp-sized nudge of z, its loglikelihood moving in the fifth digit from nudge
+    to nudge (class (d) of DESIGN 4, here in the model-path sweep, whose harness compares loglikelihoods and does not catch the
+    library's error).  The smaller model sizes of the same path are stable and are what the sweep checks."""
+    n, p, q, od, ol, D, L, x, ox, y, z, path, kw, okw, d = _replay(T._path_case, 16136, 2, FAMS4)
+    assert (n, p, od) == (151, 268, "negbin") and path == [5, 6, 7, 8, 10, 11] and okw.get("debias") and okw.get("est_r") == "newton"
+    plain = oracle.fit_iht(ox, y, z, k=11, dist=od, link=ol, max_iter=100, **okw)
+    outcomes = []
+    for g in T._NUDGES:
+        try:
+            outcomes.append(oracle.fit_iht(ox, y, z * g, k=11, dist=od, link=ol, max_iter=100, **okw)["logl"])
+        except RuntimeError:
+            outcomes.append(None)
+    assert any(v is None for v in outcomes)                                   # the reference's error, under a nudge
+    done = [v for v in outcomes if v is not None] + [plain["logl"]]
+    assert max(done) - min(done) > 1e-6 * abs(plain["logl"])                   # ... and where it finishes, a different optimum each time
+    stable = [oracle.fit_iht(ox, y, z * g, k=5, dist=od, link=ol, max_iter=100, **okw)["logl"] for g in [1.0] + T._NUDGES[:3]]
+    assert max(stable) - min(stable) < 1e-9 * abs(stable[0])
