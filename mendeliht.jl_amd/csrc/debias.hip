@@ -14,6 +14,7 @@
 #include "common.h"
 #include "fit_common.h"
 #include <cmath>
+#include <cstdio>
 #include <limits>
 #include <vector>
 
@@ -210,6 +211,7 @@ int debias_glm_device(const mih_mat *h, const int64_t *idx_host, int64_t k64, co
         return MIH_OK;
     };
 
+    static const bool trace = probe_env("MENDELIHT_DEBIAS_TRACE") != nullptr;      // (measurement build: the IRLS iterates, tools/repro_fuzz.py)
     double dev, devold;
     hipLaunchKernelGGL(k_db_start, dim3(nb), dim3(256), 0, s, y_dev, n, dist, link, eta.p);
     MIH_TRY(update(1, &dev));                                 // wrkresp = eta + wrkresid at mustart
@@ -217,6 +219,7 @@ int debias_glm_device(const mih_mat *h, const int64_t *idx_host, int64_t k64, co
     MIH_TRY(linpred(1.0));
     beta0 = trial;                                            // installbeta! from beta0 = 0
     MIH_TRY(update(0, &devold));
+    if (trace) fprintf(stderr, "debias: k %d start dev %.15g\n", k, devold);
     bool cvg = false;
     for (int it = 1; it <= 30; ++it) {
         MIH_TRY(delbeta());
@@ -230,6 +233,7 @@ int debias_glm_device(const mih_mat *h, const int64_t *idx_host, int64_t k64, co
             MIH_TRY(update(0, &dev));
         }
         beta0 = trial;
+        if (trace) fprintf(stderr, "debias: it %d f %g dev %.15g devold-dev %.3e\n", it, f, dev, devold - dev);
         if (devold - dev < std::fmax(1e-6 * devold, 1e-6)) { cvg = true; break; }
         if (!std::isfinite(dev)) { set_error("debias: non-finite deviance"); return MIH_BAD_ARG; }
         devold = dev;

@@ -478,6 +478,7 @@ typedef struct {
     double eta_cond;      /* orc_result.eta_cond */
     double ib_cond;       /* orc_result.ib_cond */
     double bt_cond;       /* orc_result.bt_cond */
+    double db_minstep;    /* orc_result.db_minstep */
     int (*choose_cb)(void *, int32_t, const int64_t *, int64_t, int64_t, int64_t *);
     void *choose_user;
     int init_beta;
@@ -497,7 +498,7 @@ static ihtvar *iv_create(const orc_mat *x, const orc_params *prm, const double *
     v->dist = prm->dist; v->link = prm->link; v->nb_r = prm->nb_r; v->est_r = prm->est_r;
     v->group = prm->group; v->weight = prm->weight; v->init_beta = prm->init_beta;
     v->choose_cb = prm->choose; v->choose_user = prm->choose_user;
-    v->eta_cond = 1.0; v->ib_cond = 1.0; v->bt_cond = 1.0;
+    v->eta_cond = 1.0; v->ib_cond = 1.0; v->bt_cond = 1.0; v->db_minstep = 1.0;
     v->b = dalloc(p); v->b0 = dalloc(p); v->best_b = dalloc(p); v->df = dalloc(p);
     v->xb = dalloc(n); v->xgk = dalloc(n); v->r = dalloc(n); v->zc = dalloc(n);
     v->zdf2 = dalloc(n); v->mu = dalloc(n); v->cv_wts = dalloc(n);
@@ -1068,6 +1069,7 @@ static int debias(ihtvar *v)
         dev = glm_update_mu(v, lp, mu, wres, wwt);
         while (dev > devold + 1e-6 * dev) {              /* step halving */
             f /= 2.0;
+            if (f < v->db_minstep) v->db_minstep = f;      /* diagnostic only (orc_result.db_minstep) */
             if (!(f > 0.001)) { rc = ORC_BAD_ARG; goto done; }
             for (int64_t i = 0; i < n; ++i) { double s = 0.0; for (int64_t a = 0; a < k; ++a) s += X[i + n * a] * (beta0[a] + f * del[a]); lp[i] = s; }
             dev = glm_update_mu(v, lp, mu, wres, wwt);
@@ -1091,6 +1093,7 @@ int orc_debias_glm(const orc_mat *x, const uint8_t *idx, const double *y, int di
 {
     ihtvar v;
     memset(&v, 0, sizeof(v));
+    v.db_minstep = 1.0;
     v.x = x; v.y = y; v.n = x->n; v.p = x->p; v.dist = dist; v.link = link; v.nb_r = nb_r;
     v.idx = (uint8_t *)idx; v.b = b;
     return debias(&v);
@@ -1159,6 +1162,7 @@ int orc_fit_iht(const orc_mat *x, const orc_params *prm, const double *y,
     rc = init_iht_indices(v, train);
     if (!rc) rc = fit_loop(v, prm, &res->logl, &res->iter, res->logl_trace, res->tol_trace,
                            res->bt_trace, &res->n_trace);
+    res->db_minstep = v->db_minstep;                 /* (also when the fit ends in an error: debias!'s refit may be that error) */
     if (!rc) {
         res->pve = sample_var(v->mu, v->n) / sample_var(v->y, v->n);  /* pve.jl:22,32 */
         res->nb_r = v->nb_r; res->choose_fired = v->choose_fired; res->eta_cond = v->eta_cond; res->ib_cond = v->ib_cond; res->bt_cond = v->bt_cond;

@@ -111,6 +111,18 @@ typedef struct orc_result {
                                  -2492.3159915021474 against ...480): whether that counts as "lower" -- two halvings of the
                                  step here, none on the device, estimates 7e-7 apart -- is decided by the order of the n terms
                                  of the loglikelihood sum.  The sweeps set a fit that DIFFERS and has bt_cond below 1e-13 aside. */
+    double   db_minstep;      /* diagnostic, not in the reference: the smallest step factor any IRLS iteration of any debias! refit of
+                                 this fit was halved to (GLM.jl's step halving: f = 1/2, 1/4, ... while the deviance rises; 1 = no
+                                 refit ever halved).  Written even when the fit ends in an error (the refit's own "step-halving
+                                 failed" / "did not converge" is such an error).  A well-posed refit takes full Newton steps; one
+                                 that halves crawls along a non-convex deviance -- debias! fits WITHOUT intercept or covariates
+                                 (utilities.jl:1014-1020), so with the sqrt link eta = X_S b changes sign over the samples, mu =
+                                 eta^2 folds, the working residual (y - eta^2) / 2 eta blows up where eta passes zero -- and no
+                                 two implementations follow the same crawl: seed 16330 of tools/fuzz_parity.py, where this file
+                                 (under every order of the rows) and a numpy restatement run out of their 30 iterations at
+                                 deviances 10 688 .. 11 291, and the device's 28th step, halved twice, happens to lower the
+                                 deviance by less than the tolerance and counts as converged.  The sweeps set a fit with debias
+                                 that DIFFERS and has db_minstep below 1 aside. */
 } orc_result;
 
 /* ---- SnpLinAlg restatement (SnpArrays.jl linalg_direct.jl) ------------- */

@@ -62,7 +62,7 @@ class _Result(C.Structure):
     _fields_ = [("logl", C.c_double), ("iter", C.c_int64), ("pve", C.c_double),
                 ("nb_r", C.c_double), ("choose_fired", C.c_int32), ("n_trace", C.c_int32),
                 ("beta", C.c_void_p), ("c", C.c_void_p), ("logl_trace", C.c_void_p),
-                ("tol_trace", C.c_void_p), ("bt_trace", C.c_void_p), ("mu", C.c_void_p), ("eta_cond", C.c_double), ("ib_cond", C.c_double), ("bt_cond", C.c_double)]
+                ("tol_trace", C.c_void_p), ("bt_trace", C.c_void_p), ("mu", C.c_void_p), ("eta_cond", C.c_double), ("ib_cond", C.c_double), ("bt_cond", C.c_double), ("db_minstep", C.c_double)]
 
 
 class _MvResult(C.Structure):
@@ -278,11 +278,13 @@ def fit_iht(x, y, z=None, k=10, J=1, dist="normal", link="identity", nb_r=1.0, t
     res.logl_trace, res.tol_trace, res.bt_trace = _p(lt), _p(tt), _p(bt)
     rc = lib().orc_fit_iht(x.h, C.byref(prm), _p(y), _p(z), q, _p(tr), C.byref(res))
     if rc:
-        raise RuntimeError(f"orc_fit_iht rc={rc}")
+        e = RuntimeError(f"orc_fit_iht rc={rc}")
+        e.db_minstep = res.db_minstep                # (diagnostic: was it debias!'s refit, crawling by halved steps?  iht_oracle.h)
+        raise e
     nt = res.n_trace
     return dict(logl=res.logl, iter=res.iter, pve=res.pve, beta=beta, c=c, mu=mu, nb_r=res.nb_r,
                 choose_fired=bool(res.choose_fired), logl_trace=lt[:nt].copy(), tol_trace=tt[:nt].copy(),
-                bt_trace=bt[:nt].copy(), eta_cond=res.eta_cond, ib_cond=res.ib_cond, bt_cond=res.bt_cond)
+                bt_trace=bt[:nt].copy(), eta_cond=res.eta_cond, ib_cond=res.ib_cond, bt_cond=res.bt_cond, db_minstep=res.db_minstep)
 
 
 def cv_iht(x, y, z=None, path=range(1, 21), q=5, folds=None, dist="normal", link="identity", nb_r=1.0,

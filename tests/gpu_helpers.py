@@ -63,6 +63,38 @@ def _unstable(a, b, rtol, atol=1e-10):
             return True
     return False
 
+def _rows_permuted(oracle, ox, perm):
+    """The oracle's matrix with its rows in another order.  With y, z and every per-sample option permuted alike the PROBLEM is the same
+    one -- same columns, same means and scales (integer counts), same optimum -- but every sum over the samples (X'r, the loglikelihood,
+    the step size, debias!'s normal equations) adds its terms in another order: exactly the freedom another correct implementation
+    of the reference has (a threaded BLAS, this library's tiles).  A trajectory the oracle does not reproduce under that is one
+    nobody can be held to (the set-aside classes that were accepted by argument)."""
+    keep, n = ox._keep, ox.n
+    if keep.dtype != np.uint8:
+        return oracle.Mat.from_dense(np.asarray(keep)[perm])
+    code = np.stack([(keep >> s) & 3 for s in (0, 2, 4, 6)], axis=2).reshape(keep.shape[0], -1)[:, :n][:, perm]
+    pad = np.zeros((keep.shape[0], keep.shape[1] * 4), np.uint8)
+    pad[:, :n] = code
+    return oracle.Mat.from_bed_columns(pad[:, 0::4] | (pad[:, 1::4] << 2) | (pad[:, 2::4] << 4) | (pad[:, 3::4] << 6), n)
+
+def _row_orders(n, count=4):
+    return [np.random.default_rng(7700 + t).permutation(n) for t in range(count)]
+
+def _within_own_spread(o, own, got, tols, factor=4.0):
+    """o: the oracle's answer, own: its answers to the same problem re-associated (ulp nudges of z, other row orders), got: the
+    device's; dicts of arrays / scalars over the keys of tols = {key: (rtol, atol)}.  True when the device is within the tolerance
+    PLUS factor x the oracle's own spread, entry by entry, and that spread is not nil: a trajectory the oracle reproduces to within
+    the tolerance but not by much (seed 16276 of tools/fuzz_parity.py: an effect of 0.008 moves by 8e-7 from one row order to the
+    next, the device's is 1.5e-6 away, the tolerance is 8e-7)."""
+    any_spread = False
+    for key, (rtol, atol) in tols.items():
+        ref = np.asarray(o[key], dtype=float)
+        spread = np.max([np.abs(np.asarray(v[key], dtype=float) - ref) for v in own], axis=0)
+        any_spread |= bool(np.max(spread) > 0.0)
+        if np.shape(got[key]) != ref.shape or not np.all(np.abs(np.asarray(got[key], dtype=float) - ref) <= rtol * np.abs(ref) + atol + factor * spread):
+            return False
+    return any_spread
+
 def _exact_xtv(g, r):
     from fractions import Fraction
     rf = [Fraction(float(v)) for v in r]

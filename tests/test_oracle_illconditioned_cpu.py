@@ -129,3 +129,80 @@ def test_debias_error_that_comes_and_goes_under_nudges_in_a_model_path(oracle):
     assert max(done) - min(done) > 1e-6 * abs(plain["logl"])                   # ... and where it finishes, a different optimum each time
     stable = [oracle.fit_iht(ox, y, z * g, k=5, dist=od, link=ol, max_iter=100, **okw)["logl"] for g in [1.0] + T._NUDGES[:3]]
     assert max(stable) - min(stable) < 1e-9 * abs(stable[0])
+
+
+def _options_oracle(oracle, seed, trial):
+    x, ox, y, z, k, kw, okw, both, tol, fam, tag = _replay(T._options_case, seed, trial)
+
+    def run(m, yy, zz):
+        try:
+            return oracle.fit_iht(m, yy, zz, k=k, max_iter=40, **okw, **both), None
+        except RuntimeError as e:
+            return None, e
+    return ox, y, z, tol, fam, both, run
+
+
+def test_row_orders_reach_what_the_nudges_of_z_cannot(oracle):
+    """Round 6 ("differs after a step that used up max_step backtracks" was accepted by argument).  Seed
+    16133, trial 11: Poisson with the sqrt link and debias.  Scaling z by an ulp leaves the oracle's answer where it is -- debias!
+    fits the SNP columns alone -- but the same problem with its samples in another order (every sum over the samples re-associated)
+    moves it beyond the tolerance: the probe the sweeps now apply before they hold the device to such a trajectory."""
+    ox, y, z, tol, fam, both, run = _options_oracle(oracle, 16133, 11)
+    assert fam == "poisson_sqrt" and both.get("debias")
+    o, _ = run(ox, y, z)
+    strip = lambda d: {key: d[key] for key in ("iter", "beta", "c", "logl")}
+    for g in T._NUDGES:
+        v, _ = run(ox, y, z * g)
+        assert not T._unstable(strip(o), dict(strip(v), c=v["c"] * g), tol, atol=1e-9)
+    moved = []
+    for pm in T._row_orders(len(y)):
+        v, _ = run(T._rows_permuted(oracle, ox, pm), y[pm], z[pm])
+        moved.append(v is None or T._unstable(strip(o), strip(v), tol, atol=1e-9))
+    assert any(moved), moved
+
+
+def test_row_order_leaves_a_well_conditioned_fit_alone(oracle):
+    """... and the probe is not a blanket excuse: the reference's recorded-size Normal fit of the first sweep (seed 20260, trial 0) is
+    the same fit under every row order, to 1e-9 of its estimates."""
+    n, p, k, miss, q, od, ol, D, L, tol, x, ox, y, z, kw = _replay(T._fits_case, 20260, 0, FAMS3)
+    o = oracle.fit_iht(ox, y, z, k=k, dist=od, link=ol, max_iter=60, **kw)
+    for pm in T._row_orders(len(y)):
+        kr = dict(kw, train=kw["train"][pm]) if "train" in kw else kw
+        v = oracle.fit_iht(T._rows_permuted(oracle, ox, pm), y[pm], z[pm], k=k, dist=od, link=ol, max_iter=60, **kr)
+        assert v["iter"] == o["iter"] and np.array_equal(np.flatnonzero(v["beta"]), np.flatnonzero(o["beta"]))
+        np.testing.assert_allclose(v["beta"], o["beta"], rtol=1e-9, atol=1e-12)
+        assert v["logl"] == pytest.approx(o["logl"], rel=1e-12)
+
+
+def test_debias_refit_that_crawls_by_halved_steps(oracle):
+    """Seed 16330, trial 0 (Poisson / sqrt, debias, k = 8): at iteration 5 the oracle's debias! refit runs out of its 30 IRLS iterations
+    -- under EVERY row order -- after halving its steps down to 1/256; the device's 28th step, halved twice, lowers the deviance
+    by less than the tolerance and counts as converged (profiles/README.md, round 6).  The oracle reports the crawl
+    (orc_result.db_minstep, also on the error path); a refit that never halves reports 1."""
+    ox, y, z, tol, fam, both, run = _options_oracle(oracle, 16330, 0)
+    o, e = run(ox, y, z)
+    assert o is None and e.db_minstep < 0.05
+    for pm in T._row_orders(len(y), 2):
+        v, e2 = run(T._rows_permuted(oracle, ox, pm), y[pm], z[pm])
+        assert v is None and e2.db_minstep < 0.05
+    n, p, k, miss, q, od, ol, D, L, tol, x, ox, y, z, kw = _replay(T._fits_case, 20260, 0, FAMS3)
+    assert oracle.fit_iht(ox, y, z, k=k, dist=od, link=ol, max_iter=60, debias=True, **kw)["db_minstep"] == 1.0
+
+
+def test_oracle_spread_that_takes_up_most_of_the_tolerance(oracle):
+    """Seed 16276, trial 2 (Poisson / sqrt, debias): the oracle reproduces itself under re-association to within the tolerance -- but
+    an effect of 0.008 moves by up to 8e-7 (1e-4 of it is 8e-7): the sweeps hold the device to the tolerance plus four times that
+    spread (_within_own_spread), and to nothing looser."""
+    ox, y, z, tol, fam, both, run = _options_oracle(oracle, 16276, 2)
+    o, _ = run(ox, y, z)
+    strip = lambda d: {key: d[key] for key in ("iter", "beta", "c", "logl")}
+    rows = [run(T._rows_permuted(oracle, ox, pm), y[pm], z[pm])[0] for pm in T._row_orders(len(y))]
+    assert all(v is not None and not T._unstable(strip(o), strip(v), tol, atol=1e-9) for v in rows)
+    supp = np.flatnonzero(o["beta"])
+    spread = np.max([np.abs(v["beta"][supp] - o["beta"][supp]) for v in rows], axis=0)
+    assert 0.2 * tol < np.max(spread / np.abs(o["beta"][supp])) < tol
+    tols = dict(beta=(tol, 1e-9), c=(tol, 1e-9), logl=(1e-7, 0.0))
+    near = dict(beta=o["beta"] * (1 + 1.9 * tol * (np.abs(o["beta"]) == np.abs(o["beta"][supp]).min())), c=o["c"], logl=o["logl"])       # the device's answer was 1.84e-4 off on the smallest effect
+    far = dict(near, beta=o["beta"] * (1 + 20 * tol))
+    assert T._within_own_spread(o, rows, near, tols) and not T._within_own_spread(o, rows, far, tols)
+    assert not T._within_own_spread(o, [o], near, tols)            # (no spread, no allowance)

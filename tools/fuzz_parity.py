@@ -4,6 +4,7 @@ the genotype linear algebra itself, the two projections, multivariate cross-vali
 per seed.
 
   python tools/fuzz_parity.py [first_seed] [count]        # writes one line per seed, a summary at the end
+  MIH_FUZZ_K=randomized_options python tools/fuzz_parity.py ...    # one sweep only (pytest -k)
 """
 import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,7 +18,7 @@ open(tally, "w").close()
 for seed in range(first, first + count):
     env = dict(os.environ, MIH_SWEEP_SEED=str(seed), MIH_SWEEP_LOG=tally)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-m", "gpu", "-x",
-                        "-k", "randomized", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True)
+                        "-k", os.environ.get("MIH_FUZZ_K", "randomized"), "-p", "no:cacheprovider"], env=env, capture_output=True, text=True)
     tail = [l for l in r.stdout.strip().splitlines() if l.strip()][-1] if r.stdout.strip() else "(no output)"
     print(f"seed {seed}: rc={r.returncode} {tail}", flush=True)
     if r.returncode:

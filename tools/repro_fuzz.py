@@ -15,15 +15,37 @@ if what == "options":
     for trial in range(want + 1):
         x, ox, y, z, k, kw, okw, both, tol, fam, tag = T._options_case(mih, oracle, rng, trial)
     print("tag", tag)
-    o = oracle.fit_iht(ox, y, z, k=k, max_iter=40, **okw, **both)
-    res = mih.fit_iht(y, x, z, k=k, max_iter=40, verbose=False, **kw, **both)
-    print("oracle: iter", o["iter"], "logl", o["logl"], "r", o["nb_r"], "bt", o["bt_trace"].tolist(), "eta_cond", o["eta_cond"])
-    print("gpu   : iter", res.iter, "logl", res.logl, "r", getattr(res.d, "r", None), "bt", res.trace["backtracks"].tolist())
-    print("oracle logl trace", o["logl_trace"].tolist())
-    print("gpu    logl trace", res.trace["logl"].tolist())
+    def side(f):                                   # (either side may end in the reference's error: that is a result too)
+        try:
+            return f(), None
+        except (RuntimeError, mih.MendelIHTError) as e:
+            return None, str(e)
+    o, oe = side(lambda: oracle.fit_iht(ox, y, z, k=k, max_iter=40, **okw, **both))
+    res, re_ = side(lambda: mih.fit_iht(y, x, z, k=k, max_iter=40, verbose=False, **kw, **both))
+    if o is None: print("oracle: ERROR", oe)
+    else:
+        print("oracle: iter", o["iter"], "logl", o["logl"], "r", o["nb_r"], "bt", o["bt_trace"].tolist(), "eta_cond", o["eta_cond"], "bt_cond", o["bt_cond"])
+        print("oracle logl trace", o["logl_trace"].tolist())
+        print("oracle support", np.flatnonzero(o["beta"]).tolist(), "c", o["c"].tolist())
+    if res is None: print("gpu   : ERROR", re_)
+    else:
+        print("gpu   : iter", res.iter, "logl", res.logl, "r", getattr(res.d, "r", None), "bt", res.trace["backtracks"].tolist())
+        print("gpu    logl trace", res.trace["logl"].tolist())
+        print("gpu    support", np.flatnonzero(res.beta).tolist(), "c", res.c.tolist())
+    if o is not None and res is not None:
+        sb = np.flatnonzero((o["beta"] != 0) | (res.beta != 0))
+        print("oracle beta", o["beta"][sb].tolist())
+        print("gpu    beta", res.beta[sb].tolist())
+        print("relative differences: beta", (np.abs(res.beta[sb] - o["beta"][sb]) / np.maximum(np.abs(o["beta"][sb]), 1e-300)).tolist(),
+              "c", (np.abs(res.c - o["c"]) / np.abs(o["c"])).tolist())
+        print("tol trace oracle", o["tol_trace"].tolist() if "tol_trace" in o else None)
+        print("tol trace gpu   ", res.trace["tol"].tolist())
     for g in T._NUDGES:
-        o2 = oracle.fit_iht(ox, y, z * g, k=k, max_iter=40, **okw, **both)
-        print("nudge", g, "iter", o2["iter"], "logl", o2["logl"], "r", o2["nb_r"])
+        o2, e2 = side(lambda: oracle.fit_iht(ox, y, z * g, k=k, max_iter=40, **okw, **both))
+        print("nudge", g, ("ERROR " + e2) if o2 is None else ("iter %d logl %r r %r" % (o2["iter"], o2["logl"], o2["nb_r"])))
+    for t, pm in enumerate(T._row_orders(len(y), int(os.environ.get("MIH_ROW_ORDERS", 4)))):
+        o2, e2 = side(lambda: oracle.fit_iht(T._rows_permuted(oracle, ox, pm), y[pm], z[pm], k=k, max_iter=40, **okw, **both))
+        print("row order", t, ("ERROR " + e2) if o2 is None else ("iter %d logl %r bt %s" % (o2["iter"], o2["logl"], o2["bt_trace"].tolist())))
 if what == "projections":
     n = int(rng.choice([1, 2, 3, 31, 64, 1000, 2047, 2049, 65535, 65537])) if rng.random() < 0.4 else int(rng.integers(1, 300000))
     v = rng.standard_normal(n) * 10.0 ** float(rng.integers(-3, 4))
