@@ -569,10 +569,18 @@ static int lane_stream_create(const mih_mat *h, hipStream_t *out)
         hipDeviceProp_t pr;
         if (hipGetDeviceProperties(&pr, h->device) == hipSuccess && pr.multiProcessorCount > 2 * reserve) {
             const int cus = pr.multiProcessorCount, words = (cus + 31) / 32;
-            std::vector<uint32_t> mask((size_t)words, 0u);
-            // the reserved CUs spread evenly over the mask's bits (whatever the order of XCDs and shader engines behind them)
-            const int every = cus / reserve;
-            for (int c = 0; c < cus; ++c) if (!(c % every == every - 1 && c / every < reserve)) mask[(size_t)(c >> 5)] |= 1u << (c & 31);
+            std::vector<uint32_t> mask((size_t)words, 0xffffffffu);
+            if (cus & 31) mask[(size_t)words - 1] = (1u << (cus & 31)) - 1u;
+            // Bit b of the mask is CU b / 8 of XCD b % 8 (tools/cu_mask_map.hip, profiles/r06_cu_mask_map.json), and a kernel's
+            // workgroups are dealt to the XCDs round-robin whatever CUs each has: the reserved CUs must come EVENLY from the XCDs, or
+            // the XCD that lost most is the straggler of every pass (the round's first attempt took every 32nd bit -- all of
+            // them CUs of XCD 7: 8 reserved CUs cost 25 %, 16 cost 66 %, and 32, a whole XCD, were not honoured at all).
+            const int xcds = (cus % 8 == 0 && cus >= 64) ? 8 : 1, per_xcd = cus / xcds, take = std::max(1, reserve / xcds);
+            for (int x = 0; x < xcds; ++x)
+                for (int t = 0; t < take; ++t) {
+                    const int b = (per_xcd - 1 - t * (per_xcd / take)) * xcds + x;
+                    mask[(size_t)(b >> 5)] &= ~(1u << (b & 31));
+                }
             if (hipExtStreamCreateWithCUMask(out, (uint32_t)words, mask.data()) == hipSuccess) return MIH_OK;
             (void)hipGetLastError();
         } else (void)hipGetLastError();
