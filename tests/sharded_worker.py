@@ -150,6 +150,10 @@ def main():
         if rank == 0:
             xf = m.SnpLinAlg(cols, n=n, center=True, scale=True, impute=True)
             entry["single"] = summary(m.fit_iht(y, xf, z, verbose=False, **kw))
+            if name.startswith("random") and z is not None:
+                # (round 6) the single-process fit on covariates scaled by a few ulps: if the sharded fit differs, the test asks whether
+                # the single-process fit reproduces ITSELF (nothing is set aside by argument)
+                entry["single_nudged"] = [dict(summary(m.fit_iht(y, xf, z * g, verbose=False, **kw)), g=g) for g in (1.0 + 2.0 ** -51, 1.0 + 3 * 2.0 ** -51, 1.0 + 2.0 ** -49)]
         cases[name] = entry
 
     # 1. the reference's shipped example (G1): Normal, k = 7, two covariates

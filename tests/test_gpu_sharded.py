@@ -73,10 +73,15 @@ def test_sharded_fit_matches_single_process(tmp_path, world):
             assert abs(sh["sigma_g"] - one["sigma_g"]) < tb, name
             assert sh["choose_fired"] == one["choose_fired"], name
         except AssertionError:
-            #  a random trajectory that used up max_step backtracks is chaotic -- the order of the shards' partial sums
-            # decides it -- but it is compared first and set aside (counted, with a ceiling) only when it differs
-            if name.startswith("random") and max(one["bt"], default=0) >= 3:
-                tally.set_aside("max_step backtracks: rounding decides the trajectory", (name,))
+            #  a random trajectory is compared first and set aside (counted, with a ceiling) only when it differs -- and (round 6)
+            # only when the single-process fit does not reproduce ITSELF on covariates scaled by a few ulps (the worker's single_nudged:
+            # iterations, backtracks, support, estimates to the same tolerance); "it used up max_step backtracks" is no longer a reason
+            def moved(v):
+                return v["iter"] != one["iter"] or v["bt"] != one["bt"] or v["support"] != one["support"] or \
+                       np.max(np.abs(np.asarray(v["beta"]) - np.asarray(one["beta"])), initial=0.0) > tb or \
+                       np.max(np.abs(np.asarray(v["c"]) / v["g"] - np.asarray(one["c"])), initial=0.0) > tb
+            if name.startswith("random") and any(moved(v) for v in case.get("single_nudged", [])):
+                tally.set_aside("the single-process fit does not reproduce itself under ulp nudges", (name,))
                 continue
             raise
         tally.ok()
