@@ -135,6 +135,8 @@ int mih_xtv_batched(const mih_mat *h, const double *R, int m, double *OUT);
  * above the guard's threshold (a heavy TAIL rather than a few outliers) keep the plain scale, i.e. entry r_i keeps
  * 54 + log2(|r_i| / max|r|) bits -- 200 rows 1e6 x the rest: ~1e-7 on the columns that carry none of them.  A Poisson fit with a
  * planted count of 500 among counts of ~1 keeps the CPU restatement's loglikelihood trace to 1e-12 over 172 steps.
+ * A residual with a NaN or +-Inf entry gives NaN in EVERY column of its row of OUT (the reference's floating-point mul! gives NaN or
+ * +-Inf in every column that touches the entry -- all of them for a centered matrix); the other residuals of the call are untouched.
  * (tests/test_gpu_parity.py: test_xtv_fixed_point_under_adversarial_dynamic_range, test_peeled_rows_in_fused_passes_with_missing_genotypes,
  * test_poisson_fit_with_a_planted_count_outlier) */
 int mih_xtv_batched_fmt(const mih_mat *h, const double *R, int m, int digits, double *OUT);

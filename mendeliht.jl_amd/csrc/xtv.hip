@@ -1167,6 +1167,9 @@ __device__ __forceinline__ double xtv_finalize_col(int64_t j, const double *__re
                                                    const int32_t *__restrict__ miss_row, int center, int scale,
                                                    const double *__restrict__ pl, const uint32_t *__restrict__ X, int64_t nbp)
 {
+    // a NaN or +-Inf anywhere in the residual (its sum says so): the reference's floating-point mul! gives NaN or +-Inf in every column it
+    // touches -- in every column of a centered matrix; the fixed point has no such value, so the answer is NaN in every column
+    if (!(fabs(sum_r) <= 1.7976931348623157e308)) return __longlong_as_double(0x7ff8000000000000ll);
     double dot = 0.0;
     for (int s = 0; s < splits; ++s) dot += pu[(int64_t)s * pstride + j];
     if (pl) {

@@ -706,3 +706,35 @@ def test_ingest_of_a_tall_matrix_stays_within_the_staging_budget(mih):
     wide = np.zeros((p, cols.shape[1] + 5), dtype=np.uint8)
     wide[:, :cols.shape[1]] = cols
     assert np.array_equal(mih.SnpLinAlg(wide, n=n, center=True, scale=True, impute=True).export_bed(), cols)
+
+
+@pytest.mark.parametrize("center", [True, False])
+def test_xtv_with_a_non_finite_residual(mih, oracle, center):
+    """A NaN or an Inf in the residual: the reference's `mul!` is a floating-point sum (utilities.jl:133) and hands the value on -- NaN or
+    +-Inf in every column that touches the entry.  The fixed point has no such value: the affected residual's row of the result is NaN
+    in every column (include/mendeliht_hip.h), centered matrix or not, whatever the format; the other residuals of the same fused
+    pass are what they are without it."""
+    rng = np.random.default_rng(99)
+    n, p = 1300, 70
+    cols = make_bed(rng, n, p, missing_rate=0.01)
+    x = mih.SnpLinAlg(cols, n=n, center=center, scale=center, impute=True)
+    ox = oracle.Mat.from_bed_columns(cols, n, center=center, scale=center, impute=True)
+    R = rng.standard_normal((5, n))
+    clean = x.xtv(R.T).T
+    bad = R.copy()
+    bad[1, 17] = np.nan
+    bad[3, 1200] = np.inf
+    try:
+        for mode in (0, 428, 1316):
+            mih.set_xtv_digits(mode)
+            got = x.xtv(bad.T).T
+            assert np.all(np.isnan(got[1])) and np.all(np.isnan(got[3])), mode
+            for v in (0, 2, 4):
+                assert np.array_equal(got[v], x.xtv(R[v])), (mode, v)
+            assert np.all(np.isnan(x.xtv(bad[1]))) and np.all(np.isnan(x.xtv(-bad[3]))), mode      # the single-residual kernel
+    finally:
+        mih.set_xtv_digits(0)
+    for v in (0, 2, 4):
+        assert rel(clean[v], ox.xtv(R[v])) < 1e-12
+    with np.errstate(invalid="ignore"):
+        assert not np.any(np.isfinite(ox.xtv(bad[1])[np.abs(ox.xtv(np.eye(n)[17])) > 0]))      # the oracle's floating-point sums hand the NaN on
