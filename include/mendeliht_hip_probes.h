@@ -5,7 +5,7 @@
  * kernels bit for bit against the round-1 kernel families, and to run timing probes.  The measurement build also reads
  * the MENDELIHT_* A/B environment switches (XTV_MAX_OPS, XTV_SLICES, XTV_NO_HALF, CV_LANES, CV_NO_MERGE,
  * CV_NO_INIT_SHARE, CV_NO_COOP, COOP_SPIN_US, CV_ASSIGN, CV_TRACE, INGEST_TRACE, TRACE_ETA, NO_SPIN, NO_ARENA, TOPK_RADIX8, XV_MULTI,
- * and the round-6 ones: RES_FORCE_ABORT_ES, LANE_BATCHED, CV_PASS_ORDER, WORKER_PRIORITY, TOPK_HOST_FINISH, DEBIAS_TRACE = the IRLS
+ * and the round-6 ones: RES_FORCE_ABORT_ES, LANE_BATCHED, CV_PASS_ORDER, WORKER_PRIORITY, TOPK_HOST_FINISH, CV_ORDER, LANE_CU_RESERVE, DEBIAS_TRACE = the IRLS
  * iterates of debias!'s GLM refit on stderr); the product reads none
  * of them.
  * These knobs are process-wide on purpose (one measurement at a time).

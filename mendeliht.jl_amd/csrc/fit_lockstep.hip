@@ -184,8 +184,10 @@ struct CvQueue {
     std::vector<int> key;            // key[i]: what fit i shares its length with (the index of its k in the path); empty: plain order
     std::vector<int> seen;           // seen[key]: most iterations a finished fit of that key took (0: none finished)
     bool stop = false;               // an error somewhere: hand out nothing more
+    long unknown_bias = 0;
     void init(size_t n, std::vector<int> keys)
     {
+        if (const char *e = probe_env("MENDELIHT_CV_ORDER")) unknown_bias = !strcmp(e, "kdesc") ? 1 : !strcmp(e, "kasc") ? -1 : 0;
         total = n; ntaken = 0; taken.assign(n, 0); key = std::move(keys);
         int kmax = -1; for (int v : key) kmax = std::max(kmax, v);
         seen.assign((size_t)(kmax + 1), 0);
@@ -197,7 +199,8 @@ struct CvQueue {
         size_t best = total; long bestp = -1;
         for (size_t i = 0; i < total; ++i) {
             if (taken[i]) continue;
-            const long pr = key.empty() ? 0 : (seen[(size_t)key[i]] == 0 ? (1l << 30) : (long)seen[(size_t)key[i]]);
+            // (unknown lengths: in the caller's order, or -- measurement build, MENDELIHT_CV_ORDER=kdesc / kasc -- the larger / smaller model sizes first)
+            const long pr = key.empty() ? 0 : (seen[(size_t)key[i]] == 0 ? (1l << 30) + unknown_bias * (long)key[i] : (long)seen[(size_t)key[i]]);
             if (pr > bestp) { bestp = pr; best = i; }
             if (key.empty()) break;
         }
