@@ -206,3 +206,19 @@ def test_oracle_spread_that_takes_up_most_of_the_tolerance(oracle):
     far = dict(near, beta=o["beta"] * (1 + 20 * tol))
     assert T._within_own_spread(o, rows, near, tols) and not T._within_own_spread(o, rows, far, tols)
     assert not T._within_own_spread(o, [o], near, tols)            # (no spread, no allowance)
+
+
+def test_recorded_run_under_every_row_order(oracle, normal_data):
+    """The probe against the reference's own record (docs/src/man/examples.md:230-267, tests/golden/golden_normal_k7.json): the recorded
+    fit with its 1000 samples in four other orders is the recorded fit -- iterations, backtracks, support, the loglikelihood of
+    every iteration to 1e-11.  What a row order moves on a well-conditioned problem is rounding, nothing else."""
+    import json, os
+    g = json.load(open(os.path.join(T.GOLD, "golden_normal_k7.json")))
+    x = oracle.Mat.from_bed_file(normal_data["bed"], normal_data["n"])
+    y, z = normal_data["y"], normal_data["z"]
+    for pm in T._row_orders(normal_data["n"]):
+        r = oracle.fit_iht(T._rows_permuted(oracle, x, pm), y[pm], z[pm], k=7)
+        assert r["iter"] == g["iterations"] and list(r["bt_trace"]) == g["backtracks"]
+        assert list(np.flatnonzero(r["beta"]) + 1) == g["positions_1based"]
+        np.testing.assert_allclose(r["logl_trace"], g["logl"], rtol=1e-11)
+        np.testing.assert_allclose(r["c"], g["c_printed"], rtol=5e-6)
