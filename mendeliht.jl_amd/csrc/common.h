@@ -13,6 +13,7 @@
 #include <cstring>
 #include <string>
 #include <unordered_map>
+#include <functional>
 #include <vector>
 #include "../../include/mendeliht_hip.h"
 
@@ -497,8 +498,13 @@ int  collect_nonzero_device(double *x_dev, int64_t len, TopkWork &w, hipStream_t
 int  group_project_device(double *y_dev, const int64_t *group_dev, int64_t len, int64_t G, int64_t J,
                           const int64_t *k_dev, int k_is_vector, hipStream_t s);
 // debias! (utilities.jl:1014-1020): GLM refit of y on the k support columns (debias.hip); beta_out[k] on the host
+// A column shard (round 6): `k` is the shard's own part of the support, k_total the whole support's size and k_off the place of the
+// shard's first column in it (the shards' column blocks follow each other in rank order, so the whole support is the shards' lists
+// one after the other); the shard decodes its own columns into an n x k_total panel of zeros and `reduce` sums the panels of all
+// shards (an exact sum: one non-zero contribution per entry); every shard then runs the SAME refit and gets all k_total coefficients.
+struct DebiasShard { int64_t k_total = 0, k_off = 0; std::function<int(double *, int64_t)> reduce; };
 int  debias_glm_device(const mih_mat *h, const int64_t *idx_host, int64_t k, const double *y_dev, int dist, int link,
-                       double nb_r, double *beta_out, hipStream_t s);
+                       double nb_r, double *beta_out, hipStream_t s, const DebiasShard *shard = nullptr);
 // ncclAllReduce on the fit's own stream when `c` is the library's communicator (comm.hip); -1 otherwise
 int  comm_native_allreduce_on_stream(const mih_comm *c, double *buf_dev, int64_t count, int32_t op, hipStream_t s, int device);
 int  comm_native_allgather_on_stream(const mih_comm *c, const double *send_dev, double *recv_dev, int64_t count, hipStream_t s, int device);

@@ -157,10 +157,12 @@ static bool chol_solve_upper(std::vector<double> &G, int m, int k, std::vector<d
 }
 
 int debias_glm_device(const mih_mat *h, const int64_t *idx_host, int64_t k64, const double *y_dev, int dist, int link,
-                      double nb_r, double *beta_out, hipStream_t s)
+                      double nb_r, double *beta_out, hipStream_t s, const DebiasShard *shard)
 {
     const int64_t n = h->n;
-    const int k = (int)k64, m = k + 1;
+    const int kloc = (int)k64;                                  // the columns this process decodes (all of them without a shard)
+    const int k = shard ? (int)shard->k_total : kloc, m = k + 1;
+    const int koff = shard ? (int)shard->k_off : 0;
     if (k == 0) return MIH_OK;
     if (link == MIH_PROBIT) { set_error("debias is not available with ProbitLink (no closed-form link function)"); return MIH_BAD_ARG; }
     const int T = (m + kGramTile - 1) / kGramTile;
@@ -170,20 +172,23 @@ int debias_glm_device(const mih_mat *h, const int64_t *idx_host, int64_t k64, co
     DevBuf<double> panel, eta, wwt, coef, part, G, red, scal; DevBuf<int64_t> idx; DevBuf<int32_t> tl;
     MIH_TRY(panel.alloc((size_t)n * m)); MIH_TRY(eta.alloc(n)); MIH_TRY(wwt.alloc(n)); MIH_TRY(coef.alloc(k));
     MIH_TRY(part.alloc((size_t)npairs * kGramSlices * kGramTile * kGramTile)); MIH_TRY(G.alloc((size_t)m * m));
-    MIH_TRY(red.alloc(nb)); MIH_TRY(scal.alloc(4)); MIH_TRY(idx.alloc(k)); MIH_TRY(tl.alloc(tiles.size()));
-    MIH_HIP(hipMemcpyAsync(idx.p, idx_host, sizeof(int64_t) * k, hipMemcpyHostToDevice, s));
+    MIH_TRY(red.alloc(nb)); MIH_TRY(scal.alloc(4)); MIH_TRY(idx.alloc(kloc > 0 ? kloc : 1)); MIH_TRY(tl.alloc(tiles.size()));
+    if (kloc > 0) MIH_HIP(hipMemcpyAsync(idx.p, idx_host, sizeof(int64_t) * kloc, hipMemcpyHostToDevice, s));
     MIH_HIP(hipMemcpyAsync(tl.p, tiles.data(), sizeof(int32_t) * tiles.size(), hipMemcpyHostToDevice, s));
-    if (h->kind == 0) {
+    if (shard) MIH_HIP(hipMemsetAsync(panel.p, 0, sizeof(double) * (size_t)n * k, s));       // (the other shards' columns: zeros, until the sum)
+    double *mine = panel.p + (size_t)n * koff;                  // this process's columns of the panel
+    if (kloc > 0 && h->kind == 0) {
         int64_t ndw = h->n_pad / 16;
-        hipLaunchKernelGGL(k_db_cols_snp, dim3(nblk(ndw), (unsigned)k), dim3(256), 0, s, h->X, h->nbp, ndw, n, idx.p, h->mu, h->sinv,
-                           h->center, h->scale, panel.p);
+        hipLaunchKernelGGL(k_db_cols_snp, dim3(nblk(ndw), (unsigned)kloc), dim3(256), 0, s, h->X, h->nbp, ndw, n, idx.p, h->mu, h->sinv,
+                           h->center, h->scale, mine);
         if (h->total_missing > 0)
-            hipLaunchKernelGGL(k_db_cols_missing, dim3((unsigned)k), dim3(256), 0, s, idx.p, h->mu, h->sinv, h->center, h->scale,
-                               h->impute, h->miss_ptr, h->miss_row, n, panel.p);
-    } else {
-        if (h->Df) hipLaunchKernelGGL(k_db_cols_dense<float>, dim3(nblk(n), (unsigned)k), dim3(256), 0, s, h->Df, n, idx.p, panel.p);
-        else hipLaunchKernelGGL(k_db_cols_dense<double>, dim3(nblk(n), (unsigned)k), dim3(256), 0, s, h->D, n, idx.p, panel.p);
+            hipLaunchKernelGGL(k_db_cols_missing, dim3((unsigned)kloc), dim3(256), 0, s, idx.p, h->mu, h->sinv, h->center, h->scale,
+                               h->impute, h->miss_ptr, h->miss_row, n, mine);
+    } else if (kloc > 0) {
+        if (h->Df) hipLaunchKernelGGL(k_db_cols_dense<float>, dim3(nblk(n), (unsigned)kloc), dim3(256), 0, s, h->Df, n, idx.p, mine);
+        else hipLaunchKernelGGL(k_db_cols_dense<double>, dim3(nblk(n), (unsigned)kloc), dim3(256), 0, s, h->D, n, idx.p, mine);
     }
+    if (shard) MIH_TRY(shard->reduce(panel.p, n * (int64_t)k));
     double *target = panel.p + (size_t)n * k;        // last panel column: the right-hand side of the WLS
 
     auto update = [&](int add_eta, double *dev) -> int {      // updateMu! + deviance

@@ -459,6 +459,33 @@ struct IhtVar {
         h->prof->exch_host(3, now_ms() - t0);
         return rc ? comm_fail(rc) : MIH_OK;
     }
+    // debias! over the column shards (round 6): `v.idx == v.idx0` holds when it holds on every shard; the whole support is the shards'
+    // lists one after the other (column blocks in rank order), so one all-gather of [same?, count] tells every shard whether to
+    // refit, how large the panel is and where its own columns sit in it.  The panel is summed over the shards (debias.hip) and every
+    // shard runs the same refit on the same numbers: the coefficients of its own columns go into b, all of them into the whole model.
+    int debias_sharded()
+    {
+        const double mine[2] = {b.idx == b0.idx ? 1.0 : 0.0, (double)b.idx.size()};
+        std::vector<double> all;
+        MIH_TRY(allgather_host(mine, 2, all));
+        int64_t total = 0, off = 0;
+        bool same = true;
+        for (int32_t r = 0; r < comm->world; ++r) {
+            same = same && all[(size_t)2 * r] != 0.0;
+            if (r < comm->rank) off += (int64_t)all[(size_t)2 * r + 1];
+            total += (int64_t)all[(size_t)2 * r + 1];
+        }
+        if (!same || total == 0) return MIH_OK;
+        std::vector<double> beta((size_t)total);
+        DebiasShard sh;
+        sh.k_total = total; sh.k_off = off;
+        sh.reduce = [this](double *buf, int64_t cnt) { return allreduce_dev(buf, cnt, 0); };
+        MIH_TRY(debias_glm_device(h, b.idx.data(), (int64_t)b.idx.size(), y.p, dist, link, nb_r, beta.data(), s, &sh));
+        for (size_t t = 0; t < b.idx.size(); ++t) b.val[t] = beta[(size_t)off + t];
+        if (bg_ok && (int64_t)bg.idx.size() == total) bg.val = beta;       // (bg is sorted by global column: the shards' lists in rank order)
+        else bg_ok = false;
+        return MIH_OK;
+    }
     int allgather_host(const double *send, int64_t cnt, std::vector<double> &recv)
     {
         recv.assign((size_t)cnt * comm->world, 0.0);
@@ -487,8 +514,8 @@ struct IhtVar {
                 comm->col_offset < 0 || comm->col_offset + p > comm->p_global) {
                 set_error("invalid mih_comm (callbacks, rank/world or column range)"); return MIH_BAD_ARG;
             }
-            if (prm->group || prm->ks || prm->debias) {
-                set_error("group projection and debias are not available in a column-sharded fit"); return MIH_BAD_ARG;
+            if (prm->group || prm->ks) {
+                set_error("group projection is not available in a column-sharded fit"); return MIH_BAD_ARG;
             }
             col0 = comm->col_offset; pg = comm->p_global;
         }
@@ -1958,7 +1985,8 @@ struct IhtVar {
                 // score inside iht_one_step! and never reads it) -- as the device-resident chain and the lock-step drivers do
                 best = save_prev(next_logl, best);
                 MIH_TRY(step_pre(next_logl, prm->max_step, &nbt, &next_logl));
-                if (debias && iter >= 5 && b.idx == b0.idx && !b.idx.empty())      // fit.jl:188: v.idx == v.idx0 && debias!(v)
+                if (debias && iter >= 5 && comm) MIH_TRY(debias_sharded());
+                else if (debias && iter >= 5 && b.idx == b0.idx && !b.idx.empty())      // fit.jl:188: v.idx == v.idx0 && debias!(v)
                     MIH_TRY(debias_glm_device(h, b.idx.data(), (int64_t)b.idx.size(), y.p, dist, link, nb_r, b.val.data(), s));
                 sc = check_convergence();
                 if (iter >= prm->min_iter && sc < prm->tol) {

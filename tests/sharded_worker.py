@@ -75,7 +75,9 @@ def native_main(out_path):
                                        "init_beta": (cols2, n2, eta + 0.3 + np.random.default_rng(5).standard_normal(n2), None, dict(k=8, init_beta=True)),
                                        # (round 6) a count outlier: k_res_peel in the resident sharded chain, k_r_stats's guard in the callbacks' steps
                                        "poisson_outlier": (cols2, n2, np.where(np.arange(n2) == 77, 400.0, np.random.default_rng(6).poisson(np.exp(0.3 * eta))).astype(float), None,
-                                                           dict(k=7, d=m.Poisson(), l=m.LogLink()))}.items():
+                                                           dict(k=7, d=m.Poisson(), l=m.LogLink())),
+                                       # (round 6) debias over the shards: the panel's all-reduce on the library's communicator (host-driven steps either way)
+                                       "debias": (cols2, n2, yb, None, dict(k=6, d=m.Bernoulli(), l=m.LogitLink(), debias=True))}.items():
         p = cc.shape[0]
         lo, cnt = D.column_block(p, rank, world)
         xs = m.SnpLinAlg(cc[lo:lo + cnt], n=nn, center=True, scale=True, impute=True, device=local)
@@ -93,6 +95,8 @@ def native_main(out_path):
         if rank == 0:                                        # ... and the unsharded fit on the whole matrix
             xf = m.SnpLinAlg(cc, n=nn, center=True, scale=True, impute=True, device=local)
             out[name]["single"] = summary(m.fit_iht(yy, xf, zz, verbose=False, **kw))
+            if kw.get("debias"):                             # (what the refit changes: the test asserts that it ran)
+                out[name]["single_plain"] = summary(m.fit_iht(yy, xf, zz, verbose=False, **dict(kw, debias=False)))
     # the column-sharded MULTIVARIATE fit (round 5): three traits, two covariates (one of them competing in the projection)
     Ym, Zm = mv_traits(x2, np.random.default_rng(77), 3, 10, 2)
     lo, cnt = D.column_block(p2, rank, world)
@@ -207,6 +211,13 @@ def main():
     #     intercepts is one scalar exchange; with a covariate that competes in the projection, and with a train mask
     run("init_beta", cols, n, eta + 0.4 + rng.standard_normal(n), zz, k=8, init_beta=True, zkeep=[True, False, True])
     run("init_beta_train", cols, n, eta + rng.standard_normal(n), None, k=6, init_beta=True, train=train)
+
+    # 5a'. (round 6) debias: the GLM refit of the support runs on a panel summed over the shards; every shard runs the same refit.
+    #      Normal with two covariates (the support settles, the refit runs from iteration 5 on), Poisson / log on the ragged matrix
+    #      with missing genotypes (imputed entries in the panel), and a model small enough that a shard holds none of its columns
+    run("debias_normal", cols, n, eta + 0.4 + rng.standard_normal(n), zz, k=8, debias=True)
+    run("debias_poisson", cols, n, yp, None, k=6, d=m.Poisson(), l=m.LogLink(), debias=True)
+    run("debias_k1", cols, n, eta + rng.standard_normal(n), None, k=1, debias=True, max_iter=20)
 
     # 5b. seeded random cases (MIH_SWEEP_SEED for other draws): shapes down to fewer columns than one 32-column tile per rank,
     #     families, covariates in and out of zkeep, prior weights, train masks -- sharded == single, as above

@@ -169,6 +169,16 @@ def test_native_exchange_with_more_than_one_rank_on_one_gpu(tmp_path, world):
         assert sh["support"] == one["support"] and sh["iter"] == one["iter"] and sh["bt"] == one["bt"], name
         np.testing.assert_allclose(sh["beta"], one["beta"], rtol=0, atol=1e-9, err_msg=name)
         np.testing.assert_allclose(sh["logl_trace"], one["logl_trace"], rtol=1e-11, err_msg=name)
+    # (round 6) debias over the shards: host-driven steps either way, the panel's sum on the library's communicator or through the callbacks
+    for k in range(world):
+        a, b = res[k]["cases"]["debias"]["native"], res[k]["cases"]["debias"]["callbacks"]
+        _same_summary(a, b, ("debias", k))
+        assert a == res[0]["cases"]["debias"]["native"], ("debias", k)
+    one, sh = res[0]["cases"]["debias"]["single"], res[0]["cases"]["debias"]["native"]
+    assert sh["support"] == one["support"] and sh["iter"] == one["iter"] >= 6 and sh["bt"] == one["bt"], "debias"
+    np.testing.assert_allclose(sh["beta"], one["beta"], rtol=0, atol=1e-9, err_msg="debias")
+    plain = res[0]["cases"]["debias"]["single_plain"]               # the refit ran and moved the estimates (or the trajectory)
+    assert plain["support"] != one["support"] or plain["iter"] != one["iter"] or np.max(np.abs(np.asarray(plain["beta"]) - np.asarray(one["beta"]))) > 1e-6
     # the multivariate fit through the native exchange: the callbacks' result on every rank, the single-process fit to rounding
     for k in range(world):
         a, b = res[k]["cases"]["mv_r3"]["native"], res[k]["cases"]["mv_r3"]["callbacks"]
