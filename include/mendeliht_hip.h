@@ -219,10 +219,12 @@ typedef struct mih_fit_params {
                                  (initialize_beta!, src/utilities.jl:776-812; Normal only) */
     const mih_comm *comm;     /* NULL = single process; else this process's shard of a column-sharded
                                  fit: h, weight, res->beta (mih_mv_result::B) cover the LOCAL columns only (mih_fit_iht,
-                                 mih_session_* and mih_fit_mv; no group projection / cross-validation; init_beta for the
-                                 univariate fit only; debias (round 6) for the univariate fit: the support's n x k panel is
-                                 summed over the shards -- one all-reduce of n * k doubles per refit -- and every shard runs
-                                 the same refit) */
+                                 mih_session_* and mih_fit_mv; no cross-validation; init_beta for the univariate fit only.
+                                 Round 6, univariate fit: debias -- the support's n x k panel is summed over the shards, one
+                                 all-reduce of n * k doubles per refit, and every shard runs the same refit -- and the group
+                                 projection: `group` holds the labels 1..G of the LOCAL columns (G, J, k and a vector k are
+                                 the whole matrix's), every shard sends its own k_g largest of each group -- two all-gathers
+                                 per projection -- and walks the union by the reference's rule) */
     int32_t  debias;          /* fit.jl:73,188 debias: after a step (iter >= 5) that kept the support, refit the
                                  support columns by GLM (debias!, src/utilities.jl:1014-1020; the reference needs
                                  memory_efficient=false for it, the device builds the n x k panel on the fly) */

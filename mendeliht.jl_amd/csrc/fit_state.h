@@ -514,9 +514,6 @@ struct IhtVar {
                 comm->col_offset < 0 || comm->col_offset + p > comm->p_global) {
                 set_error("invalid mih_comm (callbacks, rank/world or column range)"); return MIH_BAD_ARG;
             }
-            if (prm->group || prm->ks) {
-                set_error("group projection is not available in a column-sharded fit"); return MIH_BAD_ARG;
-            }
             col0 = comm->col_offset; pg = comm->p_global;
         }
         k = prm->k; J = prm->J; dist = prm->dist; link = prm->link; est_r = prm->est_r; nb_r = prm->nb_r;
@@ -576,6 +573,12 @@ struct IhtVar {
             for (int64_t j = 0; j < p; ++j) {
                 if (prm->group[j] < 1) { set_error("group labels must be 1..G"); return MIH_BAD_ARG; }
                 G = std::max(G, prm->group[j]);
+            }
+            if (comm) {           // a column shard (round 6): the labels of the LOCAL columns; G is the largest label anywhere
+                double gmax = (double)G;
+                MIH_TRY(allreduce_host(&gmax, 1, 1));
+                G = (int64_t)gmax;
+                group_host.assign(prm->group, prm->group + p);
             }
             if (!ks.empty() && (int64_t)ks.size() < G) { set_error("k (vector) must have one entry per group"); return MIH_BAD_DIM; }
             MIH_TRY(group_dev.alloc(p));
@@ -953,6 +956,69 @@ struct IhtVar {
         return MIH_OK;
     }
 
+    // project_group_sparse! (utilities.jl:613-679) over the column shards (round 6).  The reference walks sortperm(|y|, rev = true) -- stable:
+    // ties in ascending index -- gives group g its first k_g entries, adds their squares (square rounded, then the sum) to the group's
+    // norm in that order, and keeps the J groups of largest norm (ties: the lower label).  A shard's own k_g largest of a group (the
+    // device projection with J = G: every group kept) contain whatever of the group's global k_g largest lies in its columns -- a
+    // shard's index order is the global one -- so the union of the shards' candidates, walked by the same rule on the host of
+    // every rank, gives the reference's survivors.  Two all-gathers (counts, then [global column, value, label] per candidate);
+    // y_dev is left projected, `mine` gets the shard's survivors, bg the whole vector's.
+    int group_project_sharded(double *y_dev, Sparse &mine)
+    {
+#pragma clang fp contract(off)
+        MIH_TRY(group_project_device(y_dev, group_dev.p, p, G, G, kgrp_dev.p, ks.empty() ? 0 : 1, s));
+        std::vector<int64_t> ci; std::vector<double> cv;
+        MIH_TRY(collect_nonzero_device(y_dev, p, topk, s, ci, cv));
+        const double cnt = (double)ci.size();
+        std::vector<double> counts, all;
+        MIH_TRY(allgather_host(&cnt, 1, counts));
+        int64_t slot = 0;
+        for (double c : counts) slot = std::max(slot, (int64_t)c);
+        mine.clear(); bg.clear(); bg_ok = true;
+        if (slot == 0) return MIH_OK;                              // (nothing but zeros anywhere: y_dev is what it should be)
+        std::vector<double> msg((size_t)3 * slot, -1.0);
+        for (size_t t = 0; t < ci.size(); ++t) {
+            msg[3 * t] = (double)(col0 + ci[t]); msg[3 * t + 1] = cv[t]; msg[3 * t + 2] = (double)group_host[(size_t)ci[t]];
+        }
+        MIH_TRY(allgather_host(msg.data(), 3 * slot, all));
+        struct Cand { int64_t j; double v; int64_t g; };
+        std::vector<Cand> u;
+        for (int32_t r = 0; r < comm->world; ++r)                  // (rank order = ascending global column)
+            for (int64_t t = 0; t < (int64_t)counts[(size_t)r]; ++t) {
+                const double *e = &all[((size_t)r * slot + (size_t)t) * 3];
+                u.push_back(Cand{(int64_t)e[0], e[1], (int64_t)e[2]});
+            }
+        std::stable_sort(u.begin(), u.end(), [](const Cand &a, const Cand &c) { return a.j < c.j; });
+        std::stable_sort(u.begin(), u.end(), [](const Cand &a, const Cand &c) { return std::fabs(a.v) > std::fabs(c.v); });
+        std::vector<double> norm((size_t)G + 1, 0.0);
+        std::vector<int64_t> taken((size_t)G + 1, 0);
+        std::vector<char> kept(u.size(), 0);
+        for (size_t t = 0; t < u.size(); ++t) {
+            const int64_t g = u[t].g, kg = ks.empty() ? k : ks[(size_t)g - 1];
+            if (taken[(size_t)g] >= kg) continue;
+            const double sq = u[t].v * u[t].v;
+            norm[(size_t)g] = norm[(size_t)g] + sq;
+            ++taken[(size_t)g]; kept[t] = 1;
+        }
+        std::vector<int64_t> order((size_t)G);
+        for (int64_t g = 0; g < G; ++g) order[(size_t)g] = g + 1;
+        std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t c) { return norm[(size_t)a] > norm[(size_t)c]; });
+        std::vector<char> in((size_t)G + 1, 0);
+        for (int64_t t = 0; t < J && t < G; ++t) in[(size_t)order[(size_t)t]] = 1;
+        std::vector<std::pair<int64_t, double>> sv;
+        for (size_t t = 0; t < u.size(); ++t) if (kept[t] && in[(size_t)u[t].g]) sv.emplace_back(u[t].j, u[t].v);
+        std::sort(sv.begin(), sv.end());
+        for (auto &e : sv) {
+            bg.idx.push_back(e.first); bg.val.push_back(e.second);
+            if (e.first >= col0 && e.first < col0 + p) { mine.idx.push_back(e.first - col0); mine.val.push_back(e.second); }
+        }
+        MIH_HIP(hipMemsetAsync(y_dev, 0, sizeof(double) * p, s));
+        MIH_TRY(upload(mine.idx, mine.val));
+        if (!mine.idx.empty())
+            hipLaunchKernelGGL(k_scatter_set, dim3(nblk((int64_t)mine.idx.size())), dim3(256), 0, s, sidx.p, sval.p, (int64_t)mine.idx.size(), y_dev);
+        return MIH_OK;
+    }
+
     // _iht_gradstep! (utilities.jl:252-280) from base model (bb, cc) with step eta
     int gradstep(const Sparse &bb, const std::vector<double> &cc, double eta)
     {
@@ -963,9 +1029,12 @@ struct IhtVar {
             MIH_TRY(upload(bb.idx, bb.val));
             if (!bb.idx.empty())
                 hipLaunchKernelGGL(k_scatter_b, dim3(nblk((int64_t)bb.idx.size())), dim3(256), 0, s, sidx.p, sval.p, (int64_t)bb.idx.size(), df.p, (const double *)nullptr, eta, full.p);
-            MIH_TRY(group_project_device(full.p, group_dev.p, p, G, J, kgrp_dev.p, ks.empty() ? 0 : 1, s));
             Sparse snp;
-            MIH_TRY(collect_nonzero_device(full.p, p, topk, s, snp.idx, snp.val));
+            if (comm) MIH_TRY(group_project_sharded(full.p, snp));
+            else {
+                MIH_TRY(group_project_device(full.p, group_dev.p, p, G, J, kgrp_dev.p, ks.empty() ? 0 : 1, s));
+                MIH_TRY(collect_nonzero_device(full.p, p, topk, s, snp.idx, snp.val));
+            }
             b = snp;
             for (int l = 0; l < q; ++l) { c[l] = std::fma(eta, df2[l], cc[l]); idc[l] = (c[l] != 0.0); }
             if (ks.empty()) MIH_TRY(choose());         // typeof(k) == Int && _choose!(v)
@@ -1008,6 +1077,7 @@ struct IhtVar {
     bool has_group = false;
     int64_t G = 0;
     DevBuf<int64_t> group_dev, kgrp_dev;
+    std::vector<int64_t> group_host;             // (column shard) the local columns' labels, for the candidates' messages
 
     // init_iht_indices! (utilities.jl:366-438), init_beta=false
     int init(const uint8_t *train)
@@ -1143,7 +1213,8 @@ struct IhtVar {
         if (!ks.empty()) {
             // utilities.jl:427-429: project_group_sparse!(v.df, group, J, ks); idx is then taken from
             // v.b (all zero) -> empty initial support; idc = trues
-            MIH_TRY(group_project_device(df.p, group_dev.p, p, G, J, kgrp_dev.p, 1, s));
+            if (comm) { Sparse kept; MIH_TRY(group_project_sharded(df.p, kept)); bg.clear(); bg_ok = true; }     // (the gradient was projected: the model is still 0 everywhere)
+            else MIH_TRY(group_project_device(df.p, group_dev.p, p, G, J, kgrp_dev.p, 1, s));
             idx.clear();
             for (int l = 0; l < q; ++l) idc[l] = 1;
             return MIH_OK;

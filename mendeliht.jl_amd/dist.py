@@ -319,6 +319,8 @@ def fit_iht_sharded(y, x_shard, z=None, *, col_offset, p_global, weight=None, na
             ColumnComm(col_offset, p_global, device=x_shard.device, ordered_sum=ordered_sum))
     if weight is not None:
         weight = np.asarray(weight, dtype=np.float64)[col_offset:col_offset + x_shard.p]
+    if kw.get("group") is not None:          # (round 6) group labels 1..G of ALL p_global columns: the shard takes its own; J and k stay global
+        kw = dict(kw, group=np.asarray(kw["group"])[col_offset:col_offset + x_shard.p])
     try:
         res = fit_iht(y, x_shard, z, weight=weight, comm=comm, **kw)
     except Exception:

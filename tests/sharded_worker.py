@@ -219,6 +219,16 @@ def main():
     run("debias_poisson", cols, n, yp, None, k=6, d=m.Poisson(), l=m.LogLink(), debias=True)
     run("debias_k1", cols, n, eta + rng.standard_normal(n), None, k=1, debias=True, max_iter=20)
 
+    # 5a". (round 6) the doubly sparse projection over the shards: groups that straddle the shard boundaries (random labels) and sorted
+    #      labels, a scalar k per group (J groups of k: _choose! may fire) and a vector k (the initial projection of the gradient too)
+    Gn = 12
+    glab = rng.integers(1, Gn + 1, p); glab[:Gn] = np.arange(1, Gn + 1)
+    run("group_random_labels", cols, n, eta + 0.3 + rng.standard_normal(n), None, group=glab, J=3, k=2)
+    gs = np.sort(glab)
+    run("group_sorted_labels", cols, n, yb, zz, group=gs, J=4, k=3, d=m.Bernoulli(), l=m.LogitLink())
+    run("group_vector_k", cols, n, eta + rng.standard_normal(n), None, group=glab, J=3, k=rng.integers(1, 4, Gn))
+    run("group_debias", cols, n, eta + 0.1 + rng.standard_normal(n), None, group=gs, J=2, k=3, debias=True)
+
     # 5b. seeded random cases (MIH_SWEEP_SEED for other draws): shapes down to fewer columns than one 32-column tile per rank,
     #     families, covariates in and out of zkeep, prior weights, train masks -- sharded == single, as above
     srng = np.random.default_rng(int(os.environ.get("MIH_SWEEP_SEED", 1234)))

@@ -85,6 +85,8 @@ def test_sharded_fit_matches_single_process(tmp_path, world):
                 continue
             raise
         tally.ok()
+        if name.startswith("group_"):        # (round 6) the doubly sparse projection over the shards did something: a model of at most J groups' worth of effects
+            assert 0 < len(sh["support"]) <= {"group_random_labels": 6, "group_sorted_labels": 12, "group_vector_k": 9, "group_debias": 6}[name], (name, sh["support"])
         for oc in others:                                                   # every rank returns the same model
             assert oc[name]["sharded"]["support"] == sh["support"], name
             assert oc[name]["sharded"]["beta"] == sh["beta"], name
