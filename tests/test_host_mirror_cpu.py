@@ -524,3 +524,31 @@ def test_julia_glue_blocks_and_brackets_balance():
     cut = src.rindex("\nend", 0, src.index("function make_params"))          # drop the `end` of the function before make_params
     o2, e2, _, left = _julia_block_balance(src[:cut] + src[cut + 4:])
     assert o2 == e2 + 1 and left
+
+
+def test_sharded_fit_hands_every_shard_its_own_weights_and_group_labels(mih, monkeypatch):
+    """dist.fit_iht_sharded (host logic, no device): `weight` and `group` are given for ALL p_global columns -- the reference's
+    keywords -- and a shard's fit must get the entries of its own columns only (mih_fit_params: h, weight, group cover the LOCAL
+    columns; J, k and a vector k stay the whole matrix's); the full-length beta is assembled from the shard's block."""
+    import types
+    import mendeliht_amd                        # noqa: F401  (the alias module registers the package)
+    from mendeliht_amd import api as api_mod, dist as D
+    seen = {}
+
+    def fake_fit(y, x, z, weight=None, comm=None, **kw):
+        seen.update(weight=weight, comm=comm, kw=kw)
+        beta = np.zeros(x.p)
+        beta[[0, x.p - 1]] = [1.5, -2.5]
+        return types.SimpleNamespace(beta=beta)
+    monkeypatch.setattr(api_mod, "fit_iht", fake_fit)
+    p_global, lo, cnt = 50, 20, 17
+    shard = types.SimpleNamespace(p=cnt, device=0)
+    w = np.arange(p_global, dtype=float) + 1.0
+    g = np.repeat(np.arange(1, 11), 5)
+    kvec = np.arange(1, 11)
+    res = D.fit_iht_sharded(np.zeros(4), shard, None, col_offset=lo, p_global=p_global, weight=w, group=g, J=3, k=kvec, debias=True)
+    assert np.array_equal(seen["weight"], w[lo:lo + cnt])
+    assert np.array_equal(seen["kw"]["group"], g[lo:lo + cnt]) and seen["kw"]["J"] == 3 and np.array_equal(seen["kw"]["k"], kvec) and seen["kw"]["debias"] is True
+    assert seen["comm"].world == 1 and seen["comm"]._c.col_offset == lo and seen["comm"]._c.p_global == p_global
+    want = np.zeros(p_global); want[lo] = 1.5; want[lo + cnt - 1] = -2.5
+    assert np.array_equal(res.beta, want)
